@@ -1,0 +1,250 @@
+/*
+ * pbbss.h -- C ABI of libpbbss_hip.so: the MI355X (gfx950) engine for the
+ * pb_bss cACGMM EM loop and mask-based beamformer extraction.
+ *
+ * Drop-in boundary.  The reference (fgnt/pb_bss) has no
+ * FFI registry: its only native seam is the optional Cython module imported at
+ * pb_bss/extraction/beamformer.py:38-56.  Every entry point below replaces the
+ * NumPy/LAPACK body of one reference function; the citation names it
+ * (paths relative to /root/reference/pb_bss/).
+ *
+ * Conventions
+ *  - All data pointers are DEVICE pointers owned by the caller (PyTorch-ROCm
+ *    tensors in the Python host layer).  The library allocates only private
+ *    scratch inside the handle and never frees caller memory.
+ *  - Row-major, last index fastest.  "c64" = interleaved (re,im) float32,
+ *    "c128" = interleaved float64.  B is the flattened "independent" axis
+ *    (frequency bins x batch), D sensors, T frames, K classes.
+ *  - Arithmetic is IEEE float64 on the device regardless of the storage type
+ *    (float32 cannot hold 1e-5 over an EM trajectory).
+ *  - Calls are asynchronous on `stream` (a hipStream_t passed as void*).
+ *  - Return value: PBBSS_OK or a negative error code; numerical trouble is
+ *    reported per problem in caller-provided `status` arrays, never thrown.
+ *  - Thread safety: one handle per (device, host thread); no global state.
+ */
+#ifndef PBBSS_H_
+#define PBBSS_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PBBSS_VERSION 100 /* 0.1.0 */
+
+/* ---- error codes --------------------------------------------------------- */
+#define PBBSS_OK 0
+#define PBBSS_ERR_INVALID_ARG (-1)   /* NULL pointer / bad enum / size <= 0   */
+#define PBBSS_ERR_UNSUPPORTED (-2)   /* shape outside the compiled kernels    */
+#define PBBSS_ERR_HIP (-3)           /* a HIP runtime call failed             */
+#define PBBSS_ERR_LDS_CAPACITY (-4)  /* T too large for the LDS-resident path */
+
+/* ---- per-problem status bits (int32 status arrays) ------------------------ */
+#define PBBSS_ST_NONFINITE 1u      /* non-finite covariance / eigenvalues
+                                      (reference: assert np.isfinite, cacg.py:127,326,333) */
+#define PBBSS_ST_EIG_NOCONV 2u     /* Jacobi did not converge (reference: LinAlgError) */
+#define PBBSS_ST_FLOORED 4u        /* >=1 eigenvalue hit the floor (informational) */
+#define PBBSS_ST_SLOWPATH 8u       /* in-loop eigen path was taken (informational) */
+#define PBBSS_ST_NOT_POSDEF 16u    /* Cholesky of B failed (GEV: LAPACK INFO > N)  */
+#define PBBSS_ST_SINGULAR 32u      /* LU met a zero pivot (np.linalg.LinAlgError)  */
+
+typedef struct pbbss_handle_s* pbbss_handle_t;
+
+int pbbss_version(void);
+const char* pbbss_error_string(int code);
+
+/* Bind a handle to HIP device `device_id`; queries CU count / LDS size. */
+int pbbss_create(pbbss_handle_t* out, int device_id);
+int pbbss_destroy(pbbss_handle_t h);
+
+/* ------------------------------------------------------------------------- */
+/* a1  normalize_observation                                                  */
+/*     distribution/complex_angular_central_gaussian.py:34-55                 */
+/*     (+ _unit_norm eps_style='where', distribution/utils.py:223-256)        */
+/* y (B,T,D) -> out (B,D,T), unit L2 norm over D; all-zero frames stay zero.  */
+/* is_c128: 0 = complex64 in/out, 1 = complex128 in/out.                      */
+/* ------------------------------------------------------------------------- */
+int pbbss_normalize_observation(pbbss_handle_t h, const void* y, int is_c128,
+                                int64_t B, int T, int D, void* out,
+                                void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* EM options: the keyword arguments of CACGMMTrainer.fit                     */
+/*     distribution/cacgmm.py:142-157                                         */
+/* ------------------------------------------------------------------------- */
+#define PBBSS_COVNORM_NONE 0       /* covariance_norm=False      */
+#define PBBSS_COVNORM_EIGENVALUE 1 /* covariance_norm='eigenvalue' */
+#define PBBSS_COVNORM_TRACE 2      /* covariance_norm='trace'    */
+
+#define PBBSS_WEIGHT_PER_CLASS_MEAN 0 /* weight_constant_axis=(-1,): mean over frames   */
+#define PBBSS_WEIGHT_UNIFORM 1        /* weight_constant_axis=-2: constant 1/K          */
+
+#define PBBSS_LAYOUT_TD 0 /* observation (B,T,D): raw, the kernel unit-normalises */
+#define PBBSS_LAYOUT_DT 1 /* observation (B,D,T): already normalised (as _predict/_fit get it) */
+
+typedef struct pbbss_em_opts {
+  int32_t iterations;       /* >= 0 EM iterations (M-steps)                     */
+  int32_t covariance_norm;  /* PBBSS_COVNORM_*                                   */
+  int32_t weight_mode;      /* PBBSS_WEIGHT_*                                    */
+  int32_t hermitize;        /* accepted for API parity; the accumulation is     */
+                            /* Hermitian by construction (cacg.py:335-336)      */
+  int32_t layout;           /* PBBSS_LAYOUT_*                                    */
+  int32_t y_is_c128;        /* 0 complex64 observation, 1 complex128             */
+  int32_t final_predict;    /* 1: after the last M-step run one E-step with      */
+                            /* affiliation_eps = 0 (== model.predict(y))         */
+  int32_t force_eig;        /* 1: eigendecompose every iteration (no Cholesky    */
+                            /* fast path); for tests                             */
+  double affiliation_eps;   /* clip of the posteriors inside the loop (1e-10)    */
+  double eigenvalue_floor;  /* relative eigenvalue floor (1e-10)                 */
+} pbbss_em_opts;
+
+/* ------------------------------------------------------------------------- */
+/* a8  CACGMMTrainer.fit / fit_predict   distribution/cacgmm.py:142-313        */
+/*     (loop body: a2 _log_pdf cacg.py:167-203, a3 log_pdf_to_affiliation      */
+/*      mixture_model_utils.py:7-55, a5 estimate_mixture_weight :133-203,     */
+/*      a6 _fit cacg.py:253-342, a7 from_covariance cacg.py:82-132)            */
+/*                                                                             */
+/* Initialisation: exactly one of                                              */
+/*   gamma0 (B,K,T) f64 affiliations  (cacgmm.py:211-228), or                  */
+/*   the model triple in_eigvec c128 (B,K,D,D), in_eigval f64 (B,K,D),         */
+/*   in_weight f64 (B,K)  (cacgmm.py:229-234).                                 */
+/* Optional: saliency f64 (B,T) or NULL; activity uint8 (B,K,T) or NULL        */
+/* (source_activity_mask).                                                     */
+/* Outputs (caller-allocated): eigvec c128 (B,K,D,D) columns = eigenvectors,   */
+/* eigenvalues ascending as numpy.linalg.eigh; eigval f64 (B,K,D); weight f64  */
+/* (B,K); status int32 (B,K) PBBSS_ST_* bits; optional affiliation f64 (B,K,T) */
+/* and quadratic_form f64 (B,K,T) written by the final predict (may be NULL).  */
+/* The whole EM loop runs on the device in one launch; nothing returns to the  */
+/* host between iterations.                                                    */
+/* ------------------------------------------------------------------------- */
+int pbbss_cacgmm_fit(pbbss_handle_t h, const void* y, int64_t B, int T, int D,
+                     int K, const double* gamma0, const void* in_eigvec,
+                     const double* in_eigval, const double* in_weight,
+                     const double* saliency, const uint8_t* activity,
+                     const pbbss_em_opts* opts, void* out_eigvec,
+                     double* out_eigval, double* out_weight,
+                     int32_t* out_status, double* out_affiliation,
+                     double* out_quadratic_form, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* a4  CACGMM.predict / _predict   distribution/cacgmm.py:64-95                */
+/* One E-step from a model.  weight is addressed with element strides          */
+/* (wb, wk, wt) so any reference broadcast shape works: (B,K,1) -> (K,1,0),    */
+/* (K,1) -> (0,1,0), (1,K,T) -> (0,T,1).  Outputs f64 (B,K,T); quadratic_form  */
+/* and log_pdf may be NULL.                                                    */
+/* ------------------------------------------------------------------------- */
+int pbbss_cacgmm_predict(pbbss_handle_t h, const void* y, int64_t B, int T,
+                         int D, int K, const void* eigvec, const double* eigval,
+                         const double* weight, int64_t wb, int64_t wk,
+                         int64_t wt, const uint8_t* activity, int layout,
+                         int y_is_c128, double affiliation_eps,
+                         double* out_affiliation, double* out_quadratic_form,
+                         double* out_log_pdf, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* a6+a7  ComplexAngularCentralGaussianTrainer._fit  cacg.py:253-342           */
+/* One stand-alone M-step on NORMALISED observations y (B,D,T) (layout DT) or   */
+/* raw (B,T,D): covariance = D * sum_t (saliency/q) y y^H / max(sum_t          */
+/* saliency, tiny), Hermitian eigendecomposition, eigenvalue normalisation and */
+/* floor.  saliency (B,K,T) f64 (the "masked affiliation"), quadratic_form     */
+/* (B,K,T) f64.  Also returns the covariance itself if out_cov != NULL.        */
+/* ------------------------------------------------------------------------- */
+int pbbss_cacg_m_step(pbbss_handle_t h, const void* y, int64_t B, int T, int D,
+                      int K, const double* saliency,
+                      const double* quadratic_form, int layout, int y_is_c128,
+                      int covariance_norm, double eigenvalue_floor,
+                      void* out_eigvec, double* out_eigval, void* out_cov,
+                      int32_t* out_status, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* Batched Hermitian eigendecomposition (numpy.linalg.eigh as used at          */
+/* cacg.py:95 and extraction/beamformer.py:180).  a c128 (N,D,D) -> eigenvalues */
+/* ascending f64 (N,D), eigenvectors c128 (N,D,D) in columns.  D <= 8.         */
+/* ------------------------------------------------------------------------- */
+int pbbss_heev_batched(pbbss_handle_t h, const void* a, int64_t N, int D,
+                       double* out_eigval, void* out_eigvec,
+                       int32_t* out_status, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* a10  get_power_spectral_density_matrix   extraction/beamformer.py:59-160     */
+/* x (B,D,T) c64/c128; mask f64 (B,K,T) (mask_b_stride = K*T) or shared over   */
+/* sources; normalize: divide the mask by max(sum_t mask, 1e-10) first.        */
+/* mask == NULL: plain sample covariance / T (K must be 1).                    */
+/* out c128 (B,K,D,D).                                                         */
+/* ------------------------------------------------------------------------- */
+int pbbss_psd(pbbss_handle_t h, const void* x, int x_is_c128, int64_t B, int T,
+              int D, int K, const double* mask, int normalize, void* out,
+              void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* a11  get_gev_vector -> _c_get_gev_vector                                    */
+/*      extraction/beamformer.py:292-364, cythonized/get_gev_vector.pyx:42-150 */
+/* Principal generalised eigenvector of (target, noise), c128 (N,D,D) each,    */
+/* normalised so that w^H noise w = 1 (LAPACK zhegvd ITYPE=1).  status[n] != 0  */
+/* mirrors INFO != 0: PBBSS_ST_NOT_POSDEF | (minor_order << 8), or              */
+/* PBBSS_ST_EIG_NOCONV; the host raises ValueError exactly like the .pyx.      */
+/* ------------------------------------------------------------------------- */
+int pbbss_gev(pbbss_handle_t h, const void* target, const void* noise,
+              int64_t N, int D, void* out_w, int32_t* out_status, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* Batched complex solve  A X = Bm  (numpy.linalg.solve inside stable_solve,   */
+/* math/solve.py:20-114; extraction/beamformer.py:250,277,682).  A (N,D,D),    */
+/* Bm (N,D,M) c128, M <= D.  LU with partial pivoting.  status PBBSS_ST_SINGULAR */
+/* where a pivot is exactly zero (host then takes the lstsq fallback).         */
+/* ------------------------------------------------------------------------- */
+int pbbss_solve(pbbss_handle_t h, const void* A, const void* Bm, int64_t N,
+                int D, int M, void* out_x, int32_t* out_status, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* a12  get_mvdr_vector_souden  extraction/beamformer.py:627-698               */
+/*      (+ get_optimal_reference_channel :601-624)                             */
+/* phase 1 (this call): G = noise^-1 target; mat = G / max(Re tr G, eps);      */
+/* per-matrix SNR numerators/denominators for every candidate reference        */
+/* channel: snr_num/snr_den c128 (N,D) = diag(mat^H target mat), diag(mat^H     */
+/* noise mat).  The host sums them over frequency (all-reduce when F is        */
+/* sharded), takes the argmax and selects column r of out_mat (N,D,D).         */
+/* ------------------------------------------------------------------------- */
+int pbbss_mvdr_souden(pbbss_handle_t h, const void* target, const void* noise,
+                      int64_t N, int D, double eps, void* out_mat,
+                      void* out_snr_num, void* out_snr_den,
+                      int32_t* out_status, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* a13  get_mvdr_vector  extraction/beamformer.py:230-260                      */
+/* w = noise^-1 h / (h^H noise^-1 h), noise hermitised first.                  */
+/* atf c128 (N,D), noise c128 (N,D,D) -> out c128 (N,D).                        */
+/* ------------------------------------------------------------------------- */
+int pbbss_mvdr(pbbss_handle_t h, const void* atf, const void* noise, int64_t N,
+               int D, void* out_w, int32_t* out_status, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* a14  blind_analytic_normalization  extraction/beamformer.py:459-488         */
+/* w c128 (N,D), noise c128 (N,D,D) -> out c128 (N,D).                          */
+/* ------------------------------------------------------------------------- */
+int pbbss_ban(pbbss_handle_t h, const void* w, const void* noise, int64_t N,
+              int D, void* out_w, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* a15  apply_beamforming_vector  extraction/beamformer.py:572-583             */
+/* out[b,t] = sum_d conj(w[b,d]) x[b,d,t];  w c128 (B,D), x (B,D,T) c64/c128,  */
+/* out c128 (B,T).                                                             */
+/* ------------------------------------------------------------------------- */
+int pbbss_apply_beamforming_vector(pbbss_handle_t h, const void* w,
+                                   const void* x, int x_is_c128, int64_t B,
+                                   int T, int D, void* out, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* Timing hook for bench.py: runs `fit` with HIP events recorded on `stream`   */
+/* around the EM kernel launch(es) only and returns the elapsed milliseconds   */
+/* of the most recent call (the roofline figure needs the kernel duration on   */
+/* the launch stream; torch.cuda.Event only sees torch's current stream).      */
+/* ------------------------------------------------------------------------- */
+int pbbss_set_timing(pbbss_handle_t h, int enable);
+int pbbss_last_kernel_ms(pbbss_handle_t h, float* out_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PBBSS_H_ */

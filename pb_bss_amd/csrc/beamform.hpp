@@ -1,0 +1,24 @@
+// Host-callable launchers of the extraction kernels (beamform.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "em_launch.hpp"
+
+namespace pbbss {
+int launch_heev(const double* a, int64_t N, int D, double* val, double* vec, int32_t* st,
+                hipStream_t s);
+int launch_gev(const double* t, const double* nn, int64_t N, int D, double* w, int32_t* st,
+               hipStream_t s);
+int launch_solve(const double* A, const double* Bm, int64_t N, int D, int M, double* x,
+                 int32_t* st, hipStream_t s);
+int launch_mvdr_souden(const double* t, const double* nn, int64_t N, int D, double eps,
+                       double* mat, double* num, double* den, int32_t* st, hipStream_t s);
+int launch_mvdr(const double* atf, const double* nn, int64_t N, int D, double* w, int32_t* st,
+                hipStream_t s);
+int launch_ban(const double* w, const double* nn, int64_t N, int D, double* out, hipStream_t s);
+int launch_apply(const double* w, const void* x, int x128, int64_t B, int T, int D, double* out,
+                 hipStream_t s);
+int launch_normalize(const void* y, int is128, int64_t B, int T, int D, void* out, hipStream_t s);
+int launch_psd(const void* x, int x128, int64_t B, int T, int D, int K, const double* mask,
+               int normalize, double* out, const EmLaunchCfg& cfg, hipStream_t s);
+}  // namespace pbbss

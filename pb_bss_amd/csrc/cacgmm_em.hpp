@@ -1,0 +1,695 @@
+// Persistent cACGMM EM kernel for gfx950 (MI355X).
+//
+// One 256-thread workgroup (4 waves, one per SIMD) owns one independent problem
+// b (a frequency bin of one utterance) for the WHOLE EM loop: the observation
+// y[b] is read from HBM once, kept in LDS, and every iteration (E-step,
+// M-step, factorisation) runs on-chip.  Reference loop being replaced:
+// distribution/cacgmm.py:252-278 (fit), :73-95 (_predict), :315-345 (_m_step).
+//
+// Math (float64 throughout; see DESIGN.md "kernel math"):
+//   P_t   = y_t y_t^H / |y_t|^2          Hermitian outer product, D^2 reals
+//   q_kt  = <A_k, P_t>  with A_k = B_k^-1   (cacg.py:185-199; the reference's
+//                                            einsum also forms B^-1 first)
+//   gamma = softmax_k(-D ln q_kt - ln det B_k) * pi_k, clipped (mixture_model_utils.py:7-55)
+//   C_k   = D * sum_t gamma_kt/q_kt P_t / sum_t gamma_kt   (cacg.py:316-327)
+//   B_k   = eigen-floored C_k               (cacg.py:82-132)
+// Inside the loop B_k^-1 and det B_k come from a Cholesky factorisation of C_k
+// whenever a cheap bound proves no eigenvalue can reach the relative floor
+// (posteriors are invariant to the scale of B_k, cacg.py:113 "The scale of
+// the eigenvals does not matter"); otherwise, and always for the returned
+// model, a Jacobi eigendecomposition applies the reference's normalisation
+// and floor exactly.
+//
+// Phases per iteration (barrier separated):
+//   E  frames split over the 4 waves, lane = frame: q, posteriors, and the
+//      M-step weights w_kt = gamma_kt/q_kt/|y_t|^2 -> LDS
+//   M  Hermitian entries split over the 4 waves, every wave sweeps all frames,
+//      lane = frame: acc_k[e] += w_kt P_t[e]; wave butterfly; -> LDS
+//   F  wave k factors C_k (lane = matrix entry): Cholesky / inverse or Jacobi
+#pragma once
+#include "pbbss.h"
+#include "wave_la.hpp"
+
+namespace pbbss {
+
+struct EmArgs {
+  const void* y;
+  int64_t B;
+  int T;
+  // initialisation
+  const double* gamma0;  // (B,K,T) or null
+  const double* q0;      // (B,K,T) or null (=ones)
+  const double* in_eigvec;  // c128 (B,K,D,D) interleaved, or null
+  const double* in_eigval;  // (B,K,D)
+  const double* in_weight;  // strided, see wb/wk/wt
+  int64_t wb, wk, wt;
+  const double* saliency;   // (B,T) or null
+  const uint8_t* activity;  // (B,K,T) or null
+  // outputs (any may be null)
+  double* out_eigvec;
+  double* out_eigval;
+  double* out_weight;
+  int32_t* out_status;
+  double* out_aff;
+  double* out_q;
+  double* out_logpdf;
+  double* out_cov;  // c128 (B,K,D,D): covariance of the last M-step (after /denominator)
+  // options
+  int iterations;
+  int covariance_norm;
+  int weight_mode;
+  int layout;
+  int final_predict;
+  int force_eig;
+  double aff_eps;
+  double final_eps;
+  double eig_floor;
+};
+
+template <int D, int K, typename YS>
+struct EmKernel {
+  static constexpr int DP = (D + 1) / 2;
+  static constexpr int NOFF = D * (D - 1) / 2;
+  static constexpr int NA = D * D;  // packed reals of one Hermitian matrix
+  static constexpr int NDW = (D + kEmWaves - 1) / kEmWaves;     // diag entries per wave (max)
+  static constexpr int NOW = (NOFF + kEmWaves - 1) / kEmWaves;  // off-diag pairs per wave (max)
+  static constexpr int kOperandChunk = 4;  // pairs of A_k operands in flight in the E phase
+  using YS4 = typename std::conditional<std::is_same<YS, float>::value, float4, double4>::type;
+  using YS2 = typename std::conditional<std::is_same<YS, float>::value, float2, double2>::type;
+
+  struct Lds {
+    YS* ybuf;        // [DP][Tp][4]   channel pairs, frame contiguous
+    double* inv_n2;  // [Tp]
+    double* wbuf;    // [K][Tp]       M-step weights
+    double* cmat;    // [K][D][D][2]  covariance sums
+    double* apack;   // [K][NA]       A_k packed for the dot with P: diag, then (2Re, 2Im) per pair
+    double* wgt;     // [K]           mixture weights
+    double* detm;    // [K]           det B_k mantissa
+    double* red;     // [kEmWaves][K] cross-wave partial sums
+    double* ssum;    // [K]           sum_t gamma_kt (saliency applied)
+    int* dete;       // [K]           det B_k exponent
+    int* status;     // [K]
+    int Tp;
+  };
+
+  static __host__ __device__ size_t lds_bytes(int T) {
+    size_t Tp = (size_t)((T + 1) & ~1);
+    size_t n = 0;
+    n += (size_t)DP * Tp * 4 * sizeof(YS);
+    n += Tp * 8;
+    n += (size_t)K * Tp * 8;
+    n += (size_t)K * D * D * 16;
+    n += (size_t)K * NA * 8;
+    n += (size_t)K * 8 * 3;         // wgt, detm, ssum
+    n += (size_t)kEmWaves * K * 8;  // red
+    n += (size_t)K * 4 * 2;         // dete, status
+    return (n + 15) & ~(size_t)15;
+  }
+
+  static __device__ Lds carve(char* base, int T) {
+    Lds L;
+    L.Tp = (T + 1) & ~1;
+    char* p = base;
+    L.ybuf = reinterpret_cast<YS*>(p);
+    p += (size_t)DP * L.Tp * 4 * sizeof(YS);
+    L.inv_n2 = reinterpret_cast<double*>(p);
+    p += (size_t)L.Tp * 8;
+    L.wbuf = reinterpret_cast<double*>(p);
+    p += (size_t)K * L.Tp * 8;
+    L.cmat = reinterpret_cast<double*>(p);
+    p += (size_t)K * D * D * 16;
+    L.apack = reinterpret_cast<double*>(p);
+    p += (size_t)K * NA * 8;
+    L.wgt = reinterpret_cast<double*>(p);
+    p += K * 8;
+    L.detm = reinterpret_cast<double*>(p);
+    p += K * 8;
+    L.ssum = reinterpret_cast<double*>(p);
+    p += K * 8;
+    L.red = reinterpret_cast<double*>(p);
+    p += kEmWaves * K * 8;
+    L.dete = reinterpret_cast<int*>(p);
+    p += K * 4;
+    L.status = reinterpret_cast<int*>(p);
+    return L;
+  }
+
+  // ---- observation frame t from LDS, widened to float64 -------------------
+  static __device__ __forceinline__ void load_frame(const Lds& L, int t, double (&re)[D],
+                                                    double (&im)[D]) {
+    static_for<0, DP>([&](auto dpc) {
+      constexpr int dp = dpc;
+      YS4 v = *reinterpret_cast<const YS4*>(L.ybuf + ((size_t)dp * L.Tp + t) * 4);
+      re[2 * dp] = (double)v.x;
+      im[2 * dp] = (double)v.y;
+      if constexpr (2 * dp + 1 < D) {
+        re[2 * dp + 1] = (double)v.z;
+        im[2 * dp + 1] = (double)v.w;
+      }
+    });
+  }
+
+  // ---- phase L: HBM -> LDS, squared norms ---------------------------------
+  static __device__ void phase_load(const EmArgs& a, const Lds& L, int64_t b, int tid) {
+    const int T = a.T;
+    const YS2* yg = reinterpret_cast<const YS2*>(a.y);
+    for (int t = tid; t < L.Tp; t += kEmThreads) {
+      double n2 = 0.0;
+      YS vr[2 * DP], vi[2 * DP];
+#pragma unroll
+      for (int d = 0; d < 2 * DP; ++d) {
+        vr[d] = (YS)0;
+        vi[d] = (YS)0;
+      }
+      if (t < T) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+          size_t idx = (a.layout == PBBSS_LAYOUT_TD) ? ((size_t)b * T + t) * D + d
+                                                     : ((size_t)b * D + d) * T + t;
+          YS2 v = yg[idx];
+          vr[d] = v.x;
+          vi[d] = v.y;
+          n2 += (double)v.x * (double)v.x + (double)v.y * (double)v.y;
+        }
+      }
+#pragma unroll
+      for (int dp = 0; dp < DP; ++dp) {
+        YS4 o;
+        o.x = vr[2 * dp];
+        o.y = vi[2 * dp];
+        o.z = vr[2 * dp + 1];
+        o.w = vi[2 * dp + 1];
+        *reinterpret_cast<YS4*>(L.ybuf + ((size_t)dp * L.Tp + t) * 4) = o;
+      }
+      double inv;
+      if (a.layout == PBBSS_LAYOUT_TD) {
+        inv = (n2 > 0.0) ? 1.0 / n2 : 0.0;  // unit-norm, zero frames stay zero (utils.py:251)
+      } else {
+        inv = 1.0;  // caller already normalised (as _predict / _fit receive it)
+      }
+      L.inv_n2[t] = (t < T) ? inv : 0.0;
+    }
+  }
+
+  // ---- M-step weight of one frame/class  (cacg.py:310, :322) ---------------
+  static __device__ __forceinline__ double mweight(double g_sal, double q, double inv_n2) {
+    return g_sal / fmax(q, 10.0 * kTiny) * inv_n2;
+  }
+
+  // ---- phase I: weights from an affiliation initialisation -----------------
+  static __device__ void phase_init_gamma(const EmArgs& a, const Lds& L, int64_t b, int tid,
+                                          int wave, int lane) {
+    double s[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) s[k] = 0.0;
+    for (int t = tid; t < a.T; t += kEmThreads) {
+      double sal = a.saliency ? a.saliency[(size_t)b * a.T + t] : 1.0;
+      double inv = L.inv_n2[t];
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        size_t idx = ((size_t)b * K + k) * a.T + t;
+        double g = a.gamma0[idx] * sal;
+        double q = a.q0 ? a.q0[idx] : 1.0;
+        L.wbuf[(size_t)k * L.Tp + t] = mweight(g, q, inv);
+        s[k] += g;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      double tot = wave_sum(s[k]);
+      if (lane == 0) L.red[wave * K + k] = tot;
+    }
+  }
+
+  // ---- phase E -------------------------------------------------------------
+  // FINAL=false: in-loop E-step -> wbuf + class sums.
+  // FINAL=true : posteriors / quadratic form / log-pdf to HBM.
+  // TW: mixture weights vary over frames (weight_constant_axis=-3 models,
+  //     cacgmm.py:59) and are read with strides from HBM; otherwise the
+  //     per-class weights in LDS are used.  (A runtime flag here makes hipcc
+  //     unswitch the frame loop and spill ~300 VGPRs, hence a template.)
+  template <bool FINAL, bool TW>
+  static __device__ void phase_e(const EmArgs& a, const Lds& L, int64_t b, int tid, int wave,
+                                 int lane, double eps) {
+    constexpr int NF = 1;  // frames per lane per pass (NF=2 shares A_k operand loads but makes hipcc 7.2 spill)
+    double s[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) s[k] = 0.0;
+    double detm[K], wgt[K];
+    int dete[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      detm[k] = L.detm[k];
+      dete[k] = L.dete[k];
+      wgt[k] = L.wgt[k];
+    }
+    for (int t0 = 0; t0 < a.T; t0 += NF * kEmThreads) {
+      int tt[NF];
+      bool ok[NF];
+      double re[NF][D], im[NF][D], q[NF][K];
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        int t = t0 + f * kEmThreads + tid;
+        ok[f] = t < a.T;
+        tt[f] = ok[f] ? t : (a.T - 1);
+        load_frame(L, tt[f], re[f], im[f]);
+#pragma unroll
+        for (int k = 0; k < K; ++k) q[f][k] = 0.0;
+      }
+      // q_k = <A_k, P>: diagonal then strict upper triangle
+      static_for<0, D>([&](auto ic) {
+        constexpr int i = ic;
+        double ak[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) ak[k] = L.apack[k * NA + i];
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+          double dg = re[f][i] * re[f][i] + im[f][i] * im[f][i];
+#pragma unroll
+          for (int k = 0; k < K; ++k) q[f][k] = fma(ak[k], dg, q[f][k]);
+        }
+      });
+      static_for<0, NOFF>([&](auto pc) {
+        constexpr int p = pc;
+        constexpr int i = tri_i<D>(p), j = tri_j<D>(p);
+        // keep the compiler from hoisting all K*D*D operand loads ahead of the
+        // FMAs (that costs >450 VGPRs): a compiler-only fence every few pairs
+        if constexpr (p % kOperandChunk == 0) asm volatile("" ::: "memory");
+        double ar[K], ai[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          ar[k] = L.apack[k * NA + D + 2 * p];
+          ai[k] = L.apack[k * NA + D + 2 * p + 1];
+        }
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+          double pr = re[f][i] * re[f][j] + im[f][i] * im[f][j];   // Re y_i conj(y_j)
+          double pim = im[f][i] * re[f][j] - re[f][i] * im[f][j];  // Im y_i conj(y_j)
+#pragma unroll
+          for (int k = 0; k < K; ++k) q[f][k] = fma(ar[k], pr, fma(ai[k], pim, q[f][k]));
+        }
+      });
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        const int t = tt[f];
+        const double inv = L.inv_n2[t];
+        // softmax over classes in mantissa/exponent form:
+        //   exp(log_pdf_k) = 1 / (det_k q_k^D)   (cacg.py:200-201)
+        double val[K];
+        int ex[K];
+        int emax = INT32_MIN;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          double qq = fmax(fabs(q[f][k] * inv), kTiny);  // cacg.py:185-199
+          q[f][k] = qq;
+          int e;
+          double m = frexp(qq, &e);
+          val[k] = 1.0 / (detm[k] * ipow<D>(m));
+          ex[k] = -(e * D + dete[k]);
+          emax = max(emax, ex[k]);
+        }
+        double g[K], den = 0.0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          double w;
+          if constexpr (TW) {
+            w = a.in_weight[b * a.wb + k * a.wk + (int64_t)t * a.wt];
+          } else {
+            w = wgt[k];
+          }
+          double v = ldexp(val[k], ex[k] - emax) * w;  // mixture_model_utils.py:32-37
+          if (a.activity) v *= (double)a.activity[((size_t)b * K + k) * a.T + t];
+          g[k] = v;
+          den += v;
+        }
+        den = fmax(den, kTiny);  // mixture_model_utils.py:43-47
+        const double sal = (!FINAL && a.saliency) ? a.saliency[(size_t)b * a.T + t] : 1.0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          double gam = g[k] / den;
+          if (eps != 0.0) gam = fmin(fmax(gam, eps), 1.0 - eps);  // :50-53, no renormalisation
+          if constexpr (FINAL) {
+            if (ok[f]) {
+              size_t idx = ((size_t)b * K + k) * a.T + t;
+              if (a.out_aff) a.out_aff[idx] = gam;
+              if (a.out_q) a.out_q[idx] = q[f][k];
+              if (a.out_logpdf) {
+                // -D ln q - ln det B   (cacg.py:200-201); det = detm * 2^dete
+                a.out_logpdf[idx] = -(double)D * log(q[f][k]) -
+                                    (log(detm[k]) + (double)dete[k] * 0.6931471805599453);
+              }
+            }
+          } else {
+            double gs = ok[f] ? gam * sal : 0.0;
+            if (ok[f]) L.wbuf[(size_t)k * L.Tp + t] = mweight(gs, q[f][k], inv);
+            s[k] += gs;
+          }
+        }
+      }
+    }
+    if constexpr (!FINAL) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        double tot = wave_sum(s[k]);
+        if (lane == 0) L.red[wave * K + k] = tot;
+      }
+    }
+  }
+
+  // ---- phase M: wave W accumulates its share of the Hermitian entries ------
+  template <int W>
+  static __device__ void phase_m(const EmArgs& a, const Lds& L, int lane) {
+    double ad[K][NDW], ar[K][NOW], ai[K][NOW];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+#pragma unroll
+      for (int x = 0; x < NDW; ++x) ad[k][x] = 0.0;
+#pragma unroll
+      for (int x = 0; x < NOW; ++x) {
+        ar[k][x] = 0.0;
+        ai[k][x] = 0.0;
+      }
+    }
+    for (int t0 = 0; t0 < a.T; t0 += kWave) {
+      const int t = t0 + lane;
+      const bool ok = t < a.T;
+      const int tc = ok ? t : a.T - 1;
+      double re[D], im[D], w[K];
+      load_frame(L, tc, re, im);
+#pragma unroll
+      for (int k = 0; k < K; ++k) w[k] = ok ? L.wbuf[(size_t)k * L.Tp + tc] : 0.0;
+      static_for<0, D>([&](auto ic) {
+        constexpr int i = ic;
+        if constexpr (i % kEmWaves == W) {
+          double dg = re[i] * re[i] + im[i] * im[i];
+#pragma unroll
+          for (int k = 0; k < K; ++k) ad[k][i / kEmWaves] = fma(w[k], dg, ad[k][i / kEmWaves]);
+        }
+      });
+      static_for<0, NOFF>([&](auto pc) {
+        constexpr int p = pc;
+        if constexpr (p % kEmWaves == W) {
+          constexpr int i = tri_i<D>(p), j = tri_j<D>(p);
+          double pr = re[i] * re[j] + im[i] * im[j];
+          double pim = im[i] * re[j] - re[i] * im[j];
+#pragma unroll
+          for (int k = 0; k < K; ++k) {
+            ar[k][p / kEmWaves] = fma(w[k], pr, ar[k][p / kEmWaves]);
+            ai[k][p / kEmWaves] = fma(w[k], pim, ai[k][p / kEmWaves]);
+          }
+        }
+      });
+    }
+    // butterfly over the 64 frames-lanes, then lane 0 stores C_ij and C_ji = conj
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      static_for<0, D>([&](auto ic) {
+        constexpr int i = ic;
+        if constexpr (i % kEmWaves == W) {
+          double v = wave_sum(ad[k][i / kEmWaves]);
+          if (lane == 0) {
+            double* c = L.cmat + (((size_t)k * D + i) * D + i) * 2;
+            c[0] = v;
+            c[1] = 0.0;
+          }
+        }
+      });
+      static_for<0, NOFF>([&](auto pc) {
+        constexpr int p = pc;
+        if constexpr (p % kEmWaves == W) {
+          constexpr int i = tri_i<D>(p), j = tri_j<D>(p);
+          double vr = wave_sum(ar[k][p / kEmWaves]);
+          double vi = wave_sum(ai[k][p / kEmWaves]);
+          if (lane == 0) {
+            double* c = L.cmat + (((size_t)k * D + i) * D + j) * 2;
+            c[0] = vr;
+            c[1] = vi;
+            double* ct = L.cmat + (((size_t)k * D + j) * D + i) * 2;
+            ct[0] = vr;
+            ct[1] = -vi;
+          }
+        }
+      });
+    }
+  }
+
+  // packed index of pair (i < j)
+  static __device__ __forceinline__ int pair_index(int i, int j) {
+    return i * D - (i * (i + 1)) / 2 + (j - i - 1);
+  }
+
+  // store Hermitian G (lane = entry) as the dot-ready A_k
+  static __device__ __forceinline__ void store_apack(const Lds& L, int k, LaneIJ c, double gre,
+                                                     double gim) {
+    if (c.i < D && c.j < D) {
+      if (c.i == c.j) {
+        L.apack[k * NA + c.i] = gre;
+      } else if (c.i < c.j) {
+        int p = pair_index(c.i, c.j);
+        L.apack[k * NA + D + 2 * p] = 2.0 * gre;
+        L.apack[k * NA + D + 2 * p + 1] = 2.0 * gim;
+      }
+    }
+  }
+
+  // A = V diag(1/lam) V^H, V_ij on lanes, lam_col = eigenvalue of this lane's column
+  static __device__ __forceinline__ void inverse_from_eig(double vre, double vim, double lam_col,
+                                                          LaneIJ c, double& gre, double& gim) {
+    gre = 0.0;
+    gim = 0.0;
+#pragma unroll
+    for (int e = 0; e < D; ++e) {
+      double il = 1.0 / lane_get(lam_col, ij_lane(0, e));
+      double ar = lane_get(vre, ij_lane(c.i, e)), ai = lane_get(vim, ij_lane(c.i, e));
+      double br = lane_get(vre, ij_lane(c.j, e)), bi = lane_get(vim, ij_lane(c.j, e));
+      // V_ie conj(V_je) / lam_e
+      gre += (ar * br + ai * bi) * il;
+      gim += (ai * br - ar * bi) * il;
+    }
+  }
+
+  // ---- phase F for one class (one wave) ------------------------------------
+  static __device__ void factor_class(const EmArgs& a, const Lds& L, int64_t b, int k, int lane,
+                                      bool last) {
+    const LaneIJ c = lane_ij(lane);
+    const bool valid = c.i < D && c.j < D;
+    const double S = L.ssum[k];
+    const double scale = (double)D / fmax(S, kTiny);  // cacg.py:316, :327
+    double are = 0.0, aim = 0.0;
+    if (valid) {
+      const double* cm = L.cmat + (((size_t)k * D + c.i) * D + c.j) * 2;
+      are = cm[0] * scale;
+      aim = cm[1] * scale;
+    }
+    int st = 0;
+    const bool finite_in = isfinite(are) && isfinite(aim);
+    if (wave_or(finite_in ? 0 : 1)) st |= PBBSS_ST_NONFINITE;  // cacg.py:333
+    if (last && a.out_cov && valid) {
+      double* oc = a.out_cov + ((((size_t)b * K + k) * D + c.i) * D + c.j) * 2;
+      oc[0] = are;
+      oc[1] = aim;
+    }
+    bool need_eig = last || a.force_eig || (st & PBBSS_ST_NONFINITE);
+    if (!need_eig) {
+      double lre = are, lim = aim;
+      ScaledReal det;
+      int info = wave_cholesky<D>(lre, lim, c, det);
+      bool ok = (info == 0);
+      if (ok) {
+        double xre, xim, gre, gim;
+        wave_tri_inverse<D>(lre, lim, c, xre, xim);
+        wave_gram<D>(xre, xim, c, gre, gim);
+        // lambda_min >= 1/||A^-1||_F and lambda_max <= tr C: if even this pessimistic
+        // ratio stays clear of the floor, no eigenvalue is floored (cacg.py:112-126)
+        double trc = wave_sum((valid && c.i == c.j) ? are : 0.0);
+        double fro2 = wave_sum(valid ? gre * gre + gim * gim : 0.0);
+        double bound = trc * sqrt(fro2);
+        ok = isfinite(bound) && (bound * a.eig_floor < 1e-2) && (bound < 1e13);
+        if (ok) {
+          store_apack(L, k, c, gre, gim);
+          if (lane == 0) {
+            L.detm[k] = det.m;
+            L.dete[k] = det.e;
+          }
+        }
+      }
+      if (!ok) {
+        need_eig = true;
+        st |= PBBSS_ST_SLOWPATH;
+      }
+    }
+    if (need_eig) {
+      if (a.covariance_norm == PBBSS_COVNORM_TRACE) {  // cacg.py:88-90
+        double tr = wave_sum((valid && c.i == c.j) ? are : 0.0);
+        double it = 1.0 / fmax(tr, kTiny);
+        are *= it;
+        aim *= it;
+      }
+      double vre, vim;
+      int sweeps = wave_jacobi_heev<D>(are, aim, c, vre, vim);
+      if (sweeps < 0) st |= PBBSS_ST_EIG_NOCONV;
+      // eigenvalue of this lane's column, broadcast from the diagonal
+      double lam = lane_get(are, ij_lane(c.j, c.j));
+      double lmax = wave_max((c.i == 0 && c.j < D) ? lam : -1.79e308);
+      double lout;
+      if (a.covariance_norm == PBBSS_COVNORM_EIGENVALUE) {  // cacg.py:112-121
+        lout = lam / fmax(lmax, kTiny);
+        if (lout < a.eig_floor) {
+          lout = a.eig_floor;
+          if (c.i == 0 && c.j < D) st |= PBBSS_ST_FLOORED;
+        }
+      } else {  // cacg.py:122-126
+        double fl = lmax * a.eig_floor;
+        lout = lam;
+        if (lout < fl) {
+          lout = fl;
+          if (c.i == 0 && c.j < D) st |= PBBSS_ST_FLOORED;
+        }
+      }
+      if (c.i == 0 && c.j < D && !isfinite(lout)) st |= PBBSS_ST_NONFINITE;  // cacg.py:127
+      st = wave_or(st);
+      if (c.j >= D) lout = 1.0;  // padding columns: harmless in the products below
+      if (last) {
+        // numpy.linalg.eigh order: ascending eigenvalues, eigenvectors in columns
+        int rank = wave_sort_rank<D>(lam, c);
+        if (valid) {
+          if (a.out_eigvec) {
+            double* ov = a.out_eigvec + ((((size_t)b * K + k) * D + c.i) * D + rank) * 2;
+            ov[0] = vre;
+            ov[1] = vim;
+          }
+          if (a.out_eigval && c.i == 0) a.out_eigval[((size_t)b * K + k) * D + rank] = lout;
+        }
+      }
+      double gre, gim;
+      inverse_from_eig(vre, vim, lout, c, gre, gim);
+      store_apack(L, k, c, gre, gim);
+      ScaledReal det{1.0, 0};
+#pragma unroll
+      for (int e = 0; e < D; ++e) scaled_mul(det, fmax(lane_get(lout, ij_lane(0, e)), kTiny));
+      if (lane == 0) {
+        L.detm[k] = det.m;
+        L.dete[k] = det.e;
+      }
+    }
+    if (lane == 0) L.status[k] |= st;
+  }
+
+  // model (V, lambda) given by the caller -> A_k, det  (cacgmm.py:229-234)
+  static __device__ void prep_from_model(const EmArgs& a, const Lds& L, int64_t b, int k,
+                                         int lane) {
+    const LaneIJ c = lane_ij(lane);
+    const bool valid = c.i < D && c.j < D;
+    double vre = 0.0, vim = 0.0, lam = 1.0;
+    if (valid) {
+      const double* v = a.in_eigvec + ((((size_t)b * K + k) * D + c.i) * D + c.j) * 2;
+      vre = v[0];
+      vim = v[1];
+      lam = a.in_eigval[((size_t)b * K + k) * D + c.j];
+    }
+    double gre, gim;
+    inverse_from_eig(vre, vim, lam, c, gre, gim);
+    store_apack(L, k, c, gre, gim);
+    ScaledReal det{1.0, 0};
+#pragma unroll
+    for (int e = 0; e < D; ++e) scaled_mul(det, fmax(lane_get(lam, ij_lane(0, e)), kTiny));
+    if (lane == 0) {
+      L.detm[k] = det.m;
+      L.dete[k] = det.e;
+      // loop E-steps read wgt from LDS; a (b,k)-strided weight is enough there
+      L.wgt[k] = a.in_weight ? a.in_weight[b * a.wb + k * a.wk] : 1.0 / K;
+    }
+  }
+
+  // class sums -> mixture weights  (mixture_model_utils.py:133-203)
+  static __device__ void finish_sums(const EmArgs& a, const Lds& L, int tid) {
+    if (tid == 0) {
+      double s[K], tot = 0.0;
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        s[k] = 0.0;
+#pragma unroll
+        for (int w = 0; w < kEmWaves; ++w) s[k] += L.red[w * K + k];
+        L.ssum[k] = s[k];
+        tot += fabs(s[k]);
+      }
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        double w;
+        if (a.weight_mode == PBBSS_WEIGHT_UNIFORM) {
+          w = 1.0 / K;  // :180-183
+        } else if (a.saliency) {
+          w = s[k] / ((tot == 0.0) ? 1e-10 : tot);  // :192-201
+        } else {
+          w = s[k] / (double)a.T;  // :188
+        }
+        L.wgt[k] = w;
+      }
+    }
+  }
+
+  static __device__ void run(const EmArgs& a, char* smem) {
+    const int tid = threadIdx.x;
+    // wave index is uniform across the wavefront: tell the compiler so the phase
+    // dispatch below is a scalar branch, not four exec-masked code paths
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const Lds L = carve(smem, a.T);
+    for (int64_t b = blockIdx.x; b < a.B; b += gridDim.x) {
+      __syncthreads();  // previous problem fully retired before LDS is reused
+      phase_load(a, L, b, tid);
+      if (tid < K) L.status[tid] = 0;
+      __syncthreads();
+      const bool model_in = (a.gamma0 == nullptr);
+      if (model_in) {
+        for (int k = wave; k < K; k += kEmWaves) prep_from_model(a, L, b, k, lane);
+      } else {
+        phase_init_gamma(a, L, b, tid, wave, lane);
+      }
+      __syncthreads();
+      if (!model_in) {
+        finish_sums(a, L, tid);
+        __syncthreads();
+      }
+      for (int it = 0; it < a.iterations; ++it) {
+        if (it > 0 || model_in) {
+          phase_e<false, false>(a, L, b, tid, wave, lane, a.aff_eps);
+          __syncthreads();
+          finish_sums(a, L, tid);
+          __syncthreads();
+        }
+        switch (wave) {
+          case 0: phase_m<0>(a, L, lane); break;
+          case 1: phase_m<1>(a, L, lane); break;
+          case 2: phase_m<2>(a, L, lane); break;
+          default: phase_m<3>(a, L, lane); break;
+        }
+        __syncthreads();
+        const bool last = (it == a.iterations - 1);
+        for (int k = wave; k < K; k += kEmWaves) factor_class(a, L, b, k, lane, last);
+        __syncthreads();
+      }
+      if (tid < K) {
+        if (a.out_weight && a.iterations > 0) a.out_weight[(size_t)b * K + tid] = L.wgt[tid];
+        if (a.out_status) a.out_status[(size_t)b * K + tid] = L.status[tid];
+      }
+      if (a.final_predict) {
+        // after a fit: model.predict(y) with the new per-class weights; a bare
+        // predict (iterations == 0) may carry frame-varying weights (wt != 0)
+        if (a.iterations == 0 && a.wt != 0) {
+          phase_e<true, true>(a, L, b, tid, wave, lane, a.final_eps);
+        } else {
+          phase_e<true, false>(a, L, b, tid, wave, lane, a.final_eps);
+        }
+      }
+    }
+  }
+};
+
+template <int D, int K, typename YS>
+__global__ void __launch_bounds__(kEmThreads, 3) cacgmm_em_kernel(EmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  EmKernel<D, K, YS>::run(a, smem);
+}
+
+}  // namespace pbbss

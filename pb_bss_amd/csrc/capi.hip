@@ -1,0 +1,289 @@
+// extern "C" boundary of libpbbss_hip.so (see include/pbbss.h).  Argument
+// validation, handle state, kernel dispatch; no numerical code lives here.
+#include "pbbss.h"
+#include "beamform.hpp"
+#include "em_launch.hpp"
+
+#define PBBSS_API extern "C" __attribute__((visibility("default")))
+
+struct pbbss_handle_s {
+  int device;
+  pbbss::EmLaunchCfg cfg;
+  int timing;
+  float last_ms;
+  hipEvent_t ev0, ev1;
+};
+
+namespace {
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+struct TimedRegion {
+  pbbss_handle_t h;
+  hipStream_t s;
+  TimedRegion(pbbss_handle_t h_, hipStream_t s_) : h(h_), s(s_) {
+    if (h->timing) (void)hipEventRecord(h->ev0, s);
+  }
+  ~TimedRegion() {
+    if (h->timing) (void)hipEventRecord(h->ev1, s);
+  }
+};
+}  // namespace
+
+PBBSS_API int pbbss_version(void) { return PBBSS_VERSION; }
+
+PBBSS_API const char* pbbss_error_string(int code) {
+  switch (code) {
+    case PBBSS_OK: return "ok";
+    case PBBSS_ERR_INVALID_ARG: return "invalid argument";
+    case PBBSS_ERR_UNSUPPORTED:
+      return "shape not covered by the compiled kernels (need 2 <= D <= 8, 1 <= K <= 4)";
+    case PBBSS_ERR_HIP: return "HIP runtime error";
+    case PBBSS_ERR_LDS_CAPACITY:
+      return "observation does not fit the LDS-resident EM kernel (too many frames)";
+    default: return "unknown error";
+  }
+}
+
+PBBSS_API int pbbss_create(pbbss_handle_t* out, int device_id) {
+  if (!out) return PBBSS_ERR_INVALID_ARG;
+  if (hipSetDevice(device_id) != hipSuccess) return PBBSS_ERR_HIP;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return PBBSS_ERR_HIP;
+  pbbss_handle_t h = new pbbss_handle_s();
+  h->device = device_id;
+  h->cfg.num_cu = prop.multiProcessorCount;
+  // gfx950: 160 KiB per CU, one workgroup may take all of it
+  size_t lds = prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor
+                                                     : prop.sharedMemPerBlock;
+  if (lds < prop.sharedMemPerBlock) lds = prop.sharedMemPerBlock;
+  h->cfg.lds_limit = lds;
+  h->timing = 0;
+  h->last_ms = 0.f;
+  if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
+    delete h;
+    return PBBSS_ERR_HIP;
+  }
+  *out = h;
+  return PBBSS_OK;
+}
+
+PBBSS_API int pbbss_destroy(pbbss_handle_t h) {
+  if (!h) return PBBSS_ERR_INVALID_ARG;
+  (void)hipEventDestroy(h->ev0);
+  (void)hipEventDestroy(h->ev1);
+  delete h;
+  return PBBSS_OK;
+}
+
+PBBSS_API int pbbss_set_timing(pbbss_handle_t h, int enable) {
+  if (!h) return PBBSS_ERR_INVALID_ARG;
+  h->timing = enable ? 1 : 0;
+  return PBBSS_OK;
+}
+
+PBBSS_API int pbbss_last_kernel_ms(pbbss_handle_t h, float* out_ms) {
+  if (!h || !out_ms) return PBBSS_ERR_INVALID_ARG;
+  if (!h->timing) return PBBSS_ERR_INVALID_ARG;
+  if (hipEventSynchronize(h->ev1) != hipSuccess) return PBBSS_ERR_HIP;
+  if (hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1) != hipSuccess) return PBBSS_ERR_HIP;
+  *out_ms = h->last_ms;
+  return PBBSS_OK;
+}
+
+PBBSS_API int pbbss_normalize_observation(pbbss_handle_t h, const void* y, int is_c128,
+                                          int64_t B, int T, int D, void* out, void* stream) {
+  if (!h || !y || !out || B <= 0 || T <= 0 || D <= 0) return PBBSS_ERR_INVALID_ARG;
+  if (B > 65535) {  // grid.y limit: split the batch
+    for (int64_t b0 = 0; b0 < B; b0 += 65535) {
+      int64_t nb = (B - b0 < 65535) ? (B - b0) : 65535;
+      size_t esz = is_c128 ? 16 : 8;
+      int rc = pbbss::launch_normalize((const char*)y + (size_t)b0 * T * D * esz, is_c128, nb, T,
+                                       D, (char*)out + (size_t)b0 * T * D * esz,
+                                       as_stream(stream));
+      if (rc != PBBSS_OK) return rc;
+    }
+    return PBBSS_OK;
+  }
+  return pbbss::launch_normalize(y, is_c128, B, T, D, out, as_stream(stream));
+}
+
+PBBSS_API int pbbss_cacgmm_fit(pbbss_handle_t h, const void* y, int64_t B, int T, int D, int K,
+                               const double* gamma0, const void* in_eigvec,
+                               const double* in_eigval, const double* in_weight,
+                               const double* saliency, const uint8_t* activity,
+                               const pbbss_em_opts* o, void* out_eigvec, double* out_eigval,
+                               double* out_weight, int32_t* out_status, double* out_affiliation,
+                               double* out_quadratic_form, void* stream) {
+  if (!h || !y || !o || B <= 0 || T <= 0) return PBBSS_ERR_INVALID_ARG;
+  if (o->iterations <= 0) return PBBSS_ERR_INVALID_ARG;  // cacgmm.py:200
+  const bool has_gamma = gamma0 != nullptr;
+  const bool has_model = in_eigvec && in_eigval && in_weight;
+  if (has_gamma == has_model) return PBBSS_ERR_INVALID_ARG;  // xor, cacgmm.py:190
+  if (!out_eigvec || !out_eigval || !out_weight || !out_status) return PBBSS_ERR_INVALID_ARG;
+  if (o->covariance_norm < 0 || o->covariance_norm > 2) return PBBSS_ERR_INVALID_ARG;
+  if (o->weight_mode < 0 || o->weight_mode > 1) return PBBSS_ERR_INVALID_ARG;
+  if (D < 2 || D > 8 || K < 1 || K > 4) return PBBSS_ERR_UNSUPPORTED;
+  pbbss::EmArgs a{};
+  a.y = y;
+  a.B = B;
+  a.T = T;
+  a.gamma0 = gamma0;
+  a.in_eigvec = static_cast<const double*>(in_eigvec);
+  a.in_eigval = in_eigval;
+  a.in_weight = in_weight;
+  a.wb = K;
+  a.wk = 1;
+  a.wt = 0;
+  a.saliency = saliency;
+  a.activity = activity;
+  a.out_eigvec = static_cast<double*>(out_eigvec);
+  a.out_eigval = out_eigval;
+  a.out_weight = out_weight;
+  a.out_status = out_status;
+  a.out_aff = out_affiliation;
+  a.out_q = out_quadratic_form;
+  a.iterations = o->iterations;
+  a.covariance_norm = o->covariance_norm;
+  a.weight_mode = o->weight_mode;
+  a.layout = o->layout;
+  a.final_predict = o->final_predict && (out_affiliation || out_quadratic_form);
+  a.force_eig = o->force_eig;
+  a.aff_eps = o->affiliation_eps;
+  a.final_eps = 0.0;  // model.predict: affiliation_eps = 0 (cacgmm.py:73)
+  a.eig_floor = o->eigenvalue_floor;
+  TimedRegion tr(h, as_stream(stream));
+  return pbbss::em_launch(D, K, o->y_is_c128, a, h->cfg, as_stream(stream));
+}
+
+PBBSS_API int pbbss_cacgmm_predict(pbbss_handle_t h, const void* y, int64_t B, int T, int D,
+                                   int K, const void* eigvec, const double* eigval,
+                                   const double* weight, int64_t wb, int64_t wk, int64_t wt,
+                                   const uint8_t* activity, int layout, int y_is_c128,
+                                   double affiliation_eps, double* out_affiliation,
+                                   double* out_quadratic_form, double* out_log_pdf,
+                                   void* stream) {
+  if (!h || !y || !eigvec || !eigval || !weight || B <= 0 || T <= 0) return PBBSS_ERR_INVALID_ARG;
+  if (!out_affiliation && !out_quadratic_form && !out_log_pdf) return PBBSS_ERR_INVALID_ARG;
+  if (D < 2 || D > 8 || K < 1 || K > 4) return PBBSS_ERR_UNSUPPORTED;
+  pbbss::EmArgs a{};
+  a.y = y;
+  a.B = B;
+  a.T = T;
+  a.in_eigvec = static_cast<const double*>(eigvec);
+  a.in_eigval = eigval;
+  a.in_weight = weight;
+  a.wb = wb;
+  a.wk = wk;
+  a.wt = wt;
+  a.activity = activity;
+  a.out_aff = out_affiliation;
+  a.out_q = out_quadratic_form;
+  a.out_logpdf = out_log_pdf;
+  a.iterations = 0;
+  a.layout = layout;
+  a.final_predict = 1;
+  a.final_eps = affiliation_eps;
+  a.covariance_norm = PBBSS_COVNORM_EIGENVALUE;
+  TimedRegion tr(h, as_stream(stream));
+  return pbbss::em_launch(D, K, y_is_c128, a, h->cfg, as_stream(stream));
+}
+
+PBBSS_API int pbbss_cacg_m_step(pbbss_handle_t h, const void* y, int64_t B, int T, int D, int K,
+                                const double* saliency, const double* quadratic_form, int layout,
+                                int y_is_c128, int covariance_norm, double eigenvalue_floor,
+                                void* out_eigvec, double* out_eigval, void* out_cov,
+                                int32_t* out_status, void* stream) {
+  if (!h || !y || !saliency || B <= 0 || T <= 0) return PBBSS_ERR_INVALID_ARG;
+  if (!out_eigvec || !out_eigval || !out_status) return PBBSS_ERR_INVALID_ARG;
+  if (covariance_norm < 0 || covariance_norm > 2) return PBBSS_ERR_INVALID_ARG;
+  if (D < 2 || D > 8 || K < 1 || K > 4) return PBBSS_ERR_UNSUPPORTED;
+  pbbss::EmArgs a{};
+  a.y = y;
+  a.B = B;
+  a.T = T;
+  a.gamma0 = saliency;         // the "masked affiliation" (cacgmm.py:332-338)
+  a.q0 = quadratic_form;       // null = ones
+  a.out_eigvec = static_cast<double*>(out_eigvec);
+  a.out_eigval = out_eigval;
+  a.out_status = out_status;
+  a.out_cov = static_cast<double*>(out_cov);
+  a.iterations = 1;
+  a.covariance_norm = covariance_norm;
+  a.weight_mode = PBBSS_WEIGHT_PER_CLASS_MEAN;
+  a.layout = layout;
+  a.eig_floor = eigenvalue_floor;
+  return pbbss::em_launch(D, K, y_is_c128, a, h->cfg, as_stream(stream));
+}
+
+PBBSS_API int pbbss_heev_batched(pbbss_handle_t h, const void* a, int64_t N, int D,
+                                 double* out_eigval, void* out_eigvec, int32_t* out_status,
+                                 void* stream) {
+  if (!h || !a || !out_eigval || !out_eigvec || N <= 0) return PBBSS_ERR_INVALID_ARG;
+  return pbbss::launch_heev(static_cast<const double*>(a), N, D, out_eigval,
+                            static_cast<double*>(out_eigvec), out_status, as_stream(stream));
+}
+
+PBBSS_API int pbbss_psd(pbbss_handle_t h, const void* x, int x_is_c128, int64_t B, int T, int D,
+                        int K, const double* mask, int normalize, void* out, void* stream) {
+  if (!h || !x || !out || B <= 0 || T <= 0 || K <= 0) return PBBSS_ERR_INVALID_ARG;
+  if (!mask && K != 1) return PBBSS_ERR_INVALID_ARG;
+  return pbbss::launch_psd(x, x_is_c128, B, T, D, K, mask, normalize, static_cast<double*>(out),
+                           h->cfg, as_stream(stream));
+}
+
+PBBSS_API int pbbss_gev(pbbss_handle_t h, const void* target, const void* noise, int64_t N,
+                        int D, void* out_w, int32_t* out_status, void* stream) {
+  if (!h || !target || !noise || !out_w || N <= 0) return PBBSS_ERR_INVALID_ARG;
+  return pbbss::launch_gev(static_cast<const double*>(target), static_cast<const double*>(noise),
+                           N, D, static_cast<double*>(out_w), out_status, as_stream(stream));
+}
+
+PBBSS_API int pbbss_solve(pbbss_handle_t h, const void* A, const void* Bm, int64_t N, int D,
+                          int M, void* out_x, int32_t* out_status, void* stream) {
+  if (!h || !A || !Bm || !out_x || N <= 0 || M <= 0) return PBBSS_ERR_INVALID_ARG;
+  if (M > 8) return PBBSS_ERR_UNSUPPORTED;
+  return pbbss::launch_solve(static_cast<const double*>(A), static_cast<const double*>(Bm), N, D,
+                             M, static_cast<double*>(out_x), out_status, as_stream(stream));
+}
+
+PBBSS_API int pbbss_mvdr_souden(pbbss_handle_t h, const void* target, const void* noise,
+                                int64_t N, int D, double eps, void* out_mat, void* out_snr_num,
+                                void* out_snr_den, int32_t* out_status, void* stream) {
+  if (!h || !target || !noise || !out_mat || N <= 0) return PBBSS_ERR_INVALID_ARG;
+  return pbbss::launch_mvdr_souden(static_cast<const double*>(target),
+                                   static_cast<const double*>(noise), N, D, eps,
+                                   static_cast<double*>(out_mat),
+                                   static_cast<double*>(out_snr_num),
+                                   static_cast<double*>(out_snr_den), out_status,
+                                   as_stream(stream));
+}
+
+PBBSS_API int pbbss_mvdr(pbbss_handle_t h, const void* atf, const void* noise, int64_t N, int D,
+                         void* out_w, int32_t* out_status, void* stream) {
+  if (!h || !atf || !noise || !out_w || N <= 0) return PBBSS_ERR_INVALID_ARG;
+  return pbbss::launch_mvdr(static_cast<const double*>(atf), static_cast<const double*>(noise), N,
+                            D, static_cast<double*>(out_w), out_status, as_stream(stream));
+}
+
+PBBSS_API int pbbss_ban(pbbss_handle_t h, const void* w, const void* noise, int64_t N, int D,
+                        void* out_w, void* stream) {
+  if (!h || !w || !noise || !out_w || N <= 0) return PBBSS_ERR_INVALID_ARG;
+  return pbbss::launch_ban(static_cast<const double*>(w), static_cast<const double*>(noise), N, D,
+                           static_cast<double*>(out_w), as_stream(stream));
+}
+
+PBBSS_API int pbbss_apply_beamforming_vector(pbbss_handle_t h, const void* w, const void* x,
+                                             int x_is_c128, int64_t B, int T, int D, void* out,
+                                             void* stream) {
+  if (!h || !w || !x || !out || B <= 0 || T <= 0 || D <= 0) return PBBSS_ERR_INVALID_ARG;
+  if (D >= 30) return PBBSS_ERR_INVALID_ARG;  // beamformer.py:582
+  for (int64_t b0 = 0; b0 < B; b0 += 65535) {
+    int64_t nb = (B - b0 < 65535) ? (B - b0) : 65535;
+    size_t esz = x_is_c128 ? 16 : 8;
+    int rc = pbbss::launch_apply(static_cast<const double*>(w) + b0 * D * 2,
+                                 (const char*)x + (size_t)b0 * D * T * esz, x_is_c128, nb, T, D,
+                                 static_cast<double*>(out) + b0 * T * 2, as_stream(stream));
+    if (rc != PBBSS_OK) return rc;
+  }
+  return PBBSS_OK;
+}

@@ -1,0 +1,327 @@
+// Wave-cooperative dense linear algebra on ONE small complex matrix per
+// wavefront (D <= 8): lane l owns entry (i, j) = (l >> 3, l & 7) of each matrix
+// it works on, held in two float64 registers (re, im).  All exchange is
+// cross-lane (ds_bpermute), no LDS memory and no barriers, so four waves of a
+// workgroup can factor four matrices independently.
+//
+// Replaces the LAPACK calls on the reference hot path:
+//   numpy.linalg.eigh      distribution/complex_angular_central_gaussian.py:95
+//                          extraction/beamformer.py:180
+//   zhegvd                 extraction/cythonized/get_gev_vector.pyx:124-129
+//   numpy.linalg.solve     math/solve.py:96, extraction/beamformer.py:250
+// Every routine must be called by all 64 lanes of the wave (convergent).
+#pragma once
+#include "pbbss_dev.hpp"
+
+namespace pbbss {
+
+struct LaneIJ {
+  int i, j;
+};
+__device__ __forceinline__ LaneIJ lane_ij(int lane) { return {lane >> 3, lane & 7}; }
+__device__ __forceinline__ int ij_lane(int i, int j) { return (i << 3) | j; }
+
+// ---------------------------------------------------------------------------
+// Cholesky  A = L L^H  (right-looking).  In: Hermitian A_ij.  Out: L_ij valid
+// for i >= j (strict upper part is scratch).  det(A) = prod pivots is returned
+// as mantissa/exponent.  Returns 0 on success, else 1 + index of the first
+// non-positive (or non-finite) pivot -- LAPACK zpotrf INFO semantics.
+// ---------------------------------------------------------------------------
+template <int D>
+__device__ __forceinline__ int wave_cholesky(double& are, double& aim, LaneIJ c,
+                                             ScaledReal& det) {
+  int info = 0;
+  det.m = 1.0;
+  det.e = 0;
+#pragma unroll
+  for (int p = 0; p < D; ++p) {
+    double d = lane_get(are, ij_lane(p, p));
+    bool good = (d > 0.0) && (d < 1.79e308);
+    if (!good && info == 0) info = p + 1;
+    double ds = good ? d : 1.0;
+    scaled_mul(det, ds);
+    double rs = 1.0 / sqrt(ds);
+    if (c.j == p && c.i >= p) {
+      are *= rs;
+      aim = (c.i == p) ? 0.0 : aim * rs;
+    }
+    double lir = lane_get(are, ij_lane(c.i, p)), lii = lane_get(aim, ij_lane(c.i, p));
+    double ljr = lane_get(are, ij_lane(c.j, p)), lji = lane_get(aim, ij_lane(c.j, p));
+    if (c.i > p && c.j > p) {  // a_ij -= L_ip * conj(L_jp)
+      are -= lir * ljr + lii * lji;
+      aim -= lii * ljr - lir * lji;
+    }
+  }
+  return info;
+}
+
+// X = L^-1 for lower-triangular L (row-oriented forward substitution on I).
+template <int D>
+__device__ __forceinline__ void wave_tri_inverse(double lre, double lim, LaneIJ c,
+                                                 double& xre, double& xim) {
+  xre = (c.i == c.j) ? 1.0 : 0.0;
+  xim = 0.0;
+#pragma unroll
+  for (int m = 0; m < D; ++m) {
+    double rd = 1.0 / lane_get(lre, ij_lane(m, m));
+    if (c.i == m) {
+      xre *= rd;
+      xim *= rd;
+    }
+    double xmr = lane_get(xre, ij_lane(m, c.j)), xmi = lane_get(xim, ij_lane(m, c.j));
+    double lr = lane_get(lre, ij_lane(c.i, m)), li = lane_get(lim, ij_lane(c.i, m));
+    if (c.i > m) {
+      xre -= lr * xmr - li * xmi;
+      xim -= lr * xmi + li * xmr;
+    }
+  }
+}
+
+// G = X^H X  (G_ij = sum_m conj(X_mi) X_mj)
+template <int D>
+__device__ __forceinline__ void wave_gram(double xre, double xim, LaneIJ c,
+                                          double& gre, double& gim) {
+  gre = 0.0;
+  gim = 0.0;
+#pragma unroll
+  for (int m = 0; m < D; ++m) {
+    double ar = lane_get(xre, ij_lane(m, c.i)), ai = lane_get(xim, ij_lane(m, c.i));
+    double br = lane_get(xre, ij_lane(m, c.j)), bi = lane_get(xim, ij_lane(m, c.j));
+    gre += ar * br + ai * bi;
+    gim += ar * bi - ai * br;
+  }
+}
+
+// C = A * B (all D x D), C_ij = sum_m A_im B_mj
+template <int D>
+__device__ __forceinline__ void wave_matmul(double are, double aim, double bre,
+                                            double bim, LaneIJ c, double& cre,
+                                            double& cim) {
+  cre = 0.0;
+  cim = 0.0;
+#pragma unroll
+  for (int m = 0; m < D; ++m) {
+    double ar = lane_get(are, ij_lane(c.i, m)), ai = lane_get(aim, ij_lane(c.i, m));
+    double br = lane_get(bre, ij_lane(m, c.j)), bi = lane_get(bim, ij_lane(m, c.j));
+    cre += ar * br - ai * bi;
+    cim += ar * bi + ai * br;
+  }
+}
+
+// conjugate transpose: out_ij = conj(a_ji)
+__device__ __forceinline__ void wave_adjoint(double are, double aim, LaneIJ c,
+                                             double& ore, double& oim) {
+  ore = lane_get(are, ij_lane(c.j, c.i));
+  oim = -lane_get(aim, ij_lane(c.j, c.i));
+}
+
+// ---------------------------------------------------------------------------
+// Hermitian eigendecomposition by parallel cyclic Jacobi: a round-robin
+// tournament schedule zeroes D/2 disjoint off-diagonal pairs per round with
+// unitary plane rotations  A <- J^H A J,  V <- V J.
+// In: Hermitian A_ij.  Out: A diagonal (eigenvalues on lanes (j,j), unsorted),
+// V_ij = i-th component of the eigenvector belonging to a_jj.
+// Returns the number of sweeps used, or -1 if not converged in kMaxSweeps.
+// ---------------------------------------------------------------------------
+constexpr int kJacobiMaxSweeps = 24;
+constexpr double kJacobiTol = 1e-29;      // off-diagonal Frobenius^2 / total Frobenius^2
+constexpr double kJacobiTolLoose = 1e-24; // accepted if the sweep budget runs out
+
+template <int D>
+__device__ __forceinline__ int wave_jacobi_heev(double& are, double& aim, LaneIJ c,
+                                                double& vre, double& vim) {
+  constexpr int N = D + (D & 1);  // tournament size (even)
+  const bool valid = (c.i < D) && (c.j < D);
+  if (!valid) {
+    are = 0.0;
+    aim = 0.0;
+  }
+  if (c.i == c.j) aim = 0.0;
+  vre = (c.i == c.j) ? 1.0 : 0.0;
+  vim = 0.0;
+  // Frobenius norm for the convergence threshold
+  const double fro2 = wave_sum(are * are + aim * aim);
+  if (!(fro2 > 0.0)) return 0;  // zero (or NaN) matrix: nothing to rotate
+  int sweeps = -1;
+  for (int sweep = 0; sweep < kJacobiMaxSweeps; ++sweep) {
+    double off2 = wave_sum((c.i != c.j) ? (are * are + aim * aim) : 0.0);
+    if (off2 <= kJacobiTol * fro2) {
+      sweeps = sweep;
+      break;
+    }
+#pragma unroll 1
+    for (int r = 0; r < N - 1; ++r) {
+      // partner of index x in round r of the circle method
+      auto partner = [&](int x) -> int {
+        if (x >= N) return x;  // padding lanes of the 8x8 lane grid
+        if (x == N - 1) return r;
+        if (x == r) return N - 1;
+        int y = 2 * r - x;
+        y %= (N - 1);
+        if (y < 0) y += N - 1;
+        return y;
+      };
+      // --- rotation for the pair that contains this lane's ROW index
+      const int pi_ = partner(c.i);
+      const int p = min(c.i, pi_), q = max(c.i, pi_);
+      const bool live = (q < D) && (p != q);
+      const int ps = live ? p : 0, qs = live ? q : 0;
+      double app = lane_get(are, ij_lane(ps, ps));
+      double aqq = lane_get(are, ij_lane(qs, qs));
+      double xr = lane_get(are, ij_lane(ps, qs));
+      double xi = lane_get(aim, ij_lane(ps, qs));
+      double g2 = xr * xr + xi * xi;
+      double cs = 1.0, sur = 0.0, sui = 0.0;  // c, s*u (u = a_pq/|a_pq|)
+      if (live && g2 > 0.0) {
+        double g = sqrt(g2);
+        double tau = (aqq - app) / (2.0 * g);
+        double t = 1.0 / (fabs(tau) + sqrt(1.0 + tau * tau));
+        t = (tau < 0.0) ? -t : t;
+        cs = 1.0 / sqrt(1.0 + t * t);
+        double s = t * cs;
+        double ig = s / g;
+        sur = xr * ig;
+        sui = xi * ig;
+      }
+      // parameters of the pair containing this lane's COLUMN index live on lane (j, j)
+      double cc = lane_get(cs, ij_lane(c.j, c.j));
+      double cur = lane_get(sur, ij_lane(c.j, c.j));
+      double cui = lane_get(sui, ij_lane(c.j, c.j));
+      const int pj = partner(c.j);
+      const bool col_is_p = c.j < pj;
+      // --- row transform  B = J^H A : row p' = c A_p - s u A_q ; row q' = s conj(u) A_p + c A_q
+      {
+        double orr = lane_get(are, ij_lane(pi_ < 8 ? pi_ : c.i, c.j));
+        double oii = lane_get(aim, ij_lane(pi_ < 8 ? pi_ : c.i, c.j));
+        double nr, ni;
+        if (c.i < pi_) {  // this lane is in row p: a = c a - (s u) o
+          nr = cs * are - (sur * orr - sui * oii);
+          ni = cs * aim - (sur * oii + sui * orr);
+        } else {          // row q: a = (s conj u) o + c a
+          nr = cs * are + (sur * orr + sui * oii);
+          ni = cs * aim + (sur * oii - sui * orr);
+        }
+        are = nr;
+        aim = ni;
+      }
+      // --- column transform  A' = B J : col p' = c B_p - s conj(u) B_q ; col q' = s u B_p + c B_q
+      {
+        double orr = lane_get(are, ij_lane(c.i, pj < 8 ? pj : c.j));
+        double oii = lane_get(aim, ij_lane(c.i, pj < 8 ? pj : c.j));
+        double vor = lane_get(vre, ij_lane(c.i, pj < 8 ? pj : c.j));
+        double voi = lane_get(vim, ij_lane(c.i, pj < 8 ? pj : c.j));
+        double nr, ni, wr, wi;
+        if (col_is_p) {  // col p: a = c a - (s conj u) o
+          nr = cc * are - (cur * orr + cui * oii);
+          ni = cc * aim - (cur * oii - cui * orr);
+          wr = cc * vre - (cur * vor + cui * voi);
+          wi = cc * vim - (cur * voi - cui * vor);
+        } else {         // col q: a = (s u) o + c a
+          nr = cc * are + (cur * orr - cui * oii);
+          ni = cc * aim + (cur * oii + cui * orr);
+          wr = cc * vre + (cur * vor - cui * voi);
+          wi = cc * vim + (cur * voi + cui * vor);
+        }
+        are = nr;
+        aim = ni;
+        vre = wr;
+        vim = wi;
+      }
+      if (c.i == c.j) aim = 0.0;
+    }
+  }
+  if (sweeps < 0) {  // budget exhausted: accept if at the rounding-noise floor
+    double off2 = wave_sum((c.i != c.j) ? (are * are + aim * aim) : 0.0);
+    if (off2 <= kJacobiTolLoose * fro2) sweeps = kJacobiMaxSweeps;
+  }
+  return sweeps;
+}
+
+// rank of eigenvalue j among the D eigenvalues (ascending, ties by index):
+// column j of V belongs at sorted position rank.  lam = value on lane (j,j)
+// already broadcast down the column (every lane holds lambda of ITS column j).
+template <int D>
+__device__ __forceinline__ int wave_sort_rank(double lam_col, LaneIJ c) {
+  int rank = 0;
+#pragma unroll
+  for (int m = 0; m < D; ++m) {
+    double lm = lane_get(lam_col, ij_lane(0, m));  // row 0 holds every column's value
+    rank += (lm < lam_col || (lm == lam_col && m < c.j)) ? 1 : 0;
+  }
+  return rank;
+}
+
+// ---------------------------------------------------------------------------
+// LU with partial pivoting applied to [A | B] (B has M <= D columns, stored in
+// lanes j < M of the second matrix).  Returns X = A^-1 B in (xre, xim) and
+// sets `singular` when an exactly-zero pivot is met (LAPACK zgesv INFO > 0,
+// which numpy turns into LinAlgError("Singular matrix")).
+// ---------------------------------------------------------------------------
+template <int D>
+__device__ __forceinline__ bool wave_lu_solve(double are, double aim, double bre,
+                                              double bim, LaneIJ c, double& xre,
+                                              double& xim) {
+  bool singular = false;
+#pragma unroll
+  for (int p = 0; p < D; ++p) {
+    // pivot search in column p, rows >= p (cabs1-like: |re| + |im| as LAPACK izamax)
+    int piv = p;
+    double best = -1.0;
+#pragma unroll
+    for (int r = p; r < D; ++r) {
+      double mr = fabs(lane_get(are, ij_lane(r, p))) + fabs(lane_get(aim, ij_lane(r, p)));
+      if (mr > best) {
+        best = mr;
+        piv = r;
+      }
+    }
+    if (!(best > 0.0)) singular = true;
+    // swap rows p and piv of A and B
+    if (piv != p) {
+      int src = (c.i == p) ? piv : ((c.i == piv) ? p : c.i);
+      double t0 = lane_get(are, ij_lane(src, c.j)), t1 = lane_get(aim, ij_lane(src, c.j));
+      double t2 = lane_get(bre, ij_lane(src, c.j)), t3 = lane_get(bim, ij_lane(src, c.j));
+      are = t0;
+      aim = t1;
+      bre = t2;
+      bim = t3;
+    }
+    double pr = lane_get(are, ij_lane(p, p)), pim = lane_get(aim, ij_lane(p, p));
+    double den = pr * pr + pim * pim;
+    double ir = singular ? 0.0 : pr / den, ii = singular ? 0.0 : -pim / den;  // 1/pivot
+    // multiplier l_ip = a_ip / pivot for rows i > p
+    double ar = lane_get(are, ij_lane(c.i, p)), ai = lane_get(aim, ij_lane(c.i, p));
+    double lr = ar * ir - ai * ii, li = ar * ii + ai * ir;
+    double ur = lane_get(are, ij_lane(p, c.j)), ui = lane_get(aim, ij_lane(p, c.j));
+    double vr = lane_get(bre, ij_lane(p, c.j)), vi = lane_get(bim, ij_lane(p, c.j));
+    if (c.i > p) {
+      are -= lr * ur - li * ui;
+      aim -= lr * ui + li * ur;
+      bre -= lr * vr - li * vi;
+      bim -= lr * vi + li * vr;
+    }
+  }
+  // back substitution on the upper triangle: rows from D-1 down to 0
+#pragma unroll
+  for (int p = D - 1; p >= 0; --p) {
+    double pr = lane_get(are, ij_lane(p, p)), pim = lane_get(aim, ij_lane(p, p));
+    double den = pr * pr + pim * pim;
+    double ir = (den > 0.0) ? pr / den : 0.0, ii = (den > 0.0) ? -pim / den : 0.0;
+    if (c.i == p) {  // x_p = b_p / u_pp
+      double nr = bre * ir - bim * ii, ni = bre * ii + bim * ir;
+      bre = nr;
+      bim = ni;
+    }
+    double ur = lane_get(are, ij_lane(c.i, p)), ui = lane_get(aim, ij_lane(c.i, p));
+    double xr = lane_get(bre, ij_lane(p, c.j)), xi = lane_get(bim, ij_lane(p, c.j));
+    if (c.i < p) {
+      bre -= ur * xr - ui * xi;
+      bim -= ur * xi + ui * xr;
+    }
+  }
+  xre = bre;
+  xim = bim;
+  return singular;
+}
+
+}  // namespace pbbss
