@@ -1,0 +1,171 @@
+"""NumPy/SciPy restatement of the reference beamformer path (TEST INFRASTRUCTURE).
+
+Oracle for pb_bss.extraction.beamformer / beamformer_wrapper / math.solve.
+Never imported by the product package.  Citations are ``file:line`` under
+/root/reference/pb_bss/.  Pinned against the real reference by
+oracle/make_golden.py -> tests/golden/.
+"""
+import numpy as np
+import scipy.linalg
+
+__all__ = [
+    'psd', 'gev_vector', 'stable_solve', 'optimal_reference_channel',
+    'mvdr_souden', 'mvdr', 'ban', 'apply_bf', 'pca_vector', 'bf_vector',
+]
+
+
+def psd(observation, mask=None, normalize=True):
+    """extraction/beamformer.py:59-160 for the default axis arguments.
+    observation (..., D, T); mask (..., K, T) or (..., T) -> (..., [K,] D, D)."""
+    if mask is None:
+        p = np.einsum('...dt,...et->...de', observation, observation.conj())
+        return p / observation.shape[-1]
+    mask = np.array(mask, dtype=np.float64 if np.asarray(mask).dtype == bool
+                    else np.asarray(mask).dtype, copy=True)
+    if normalize:
+        mask = mask / np.maximum(np.sum(mask, axis=-1, keepdims=True), 1e-10)
+    if mask.ndim + 1 == observation.ndim:
+        return np.einsum('...dt,...et->...de', mask[..., None, :] * observation,
+                         observation.conj())
+    return np.einsum('...kt,...dt,...et->...kde', mask, observation,
+                     observation.conj())
+
+
+def gev_vector(target_psd, noise_psd):
+    """extraction/beamformer.py:367-411 (_get_gev_vector, eigh branch) ==
+    cythonized/get_gev_vector.pyx:42-150 up to the eigenvector phase:
+    principal generalised eigenvector, normalised w^H Phi_nn w = 1."""
+    D = target_psd.shape[-1]
+    shape = target_psd.shape
+    t = target_psd.reshape(-1, D, D)
+    n = noise_psd.reshape(-1, D, D)
+    out = np.empty((t.shape[0], D), dtype=np.complex128)
+    for f in range(t.shape[0]):
+        vals, vecs = scipy.linalg.eigh(t[f], n[f])
+        out[f] = vecs[:, np.argmax(vals)]
+    return out.reshape(shape[:-1])
+
+
+def stable_solve(A, B):
+    """math/solve.py:20-114: batched solve, per-matrix lstsq on singular ones."""
+    A = np.asarray(A)
+    B = np.asarray(B)
+    try:
+        return np.linalg.solve(A, B)
+    except np.linalg.LinAlgError:
+        a = A.reshape(-1, *A.shape[-2:])
+        b = B.reshape(-1, *B.shape[-2:])
+        c = np.zeros_like(b)
+        for i in range(a.shape[0]):
+            try:
+                c[i] = np.linalg.solve(a[i], b[i])
+            except np.linalg.LinAlgError:
+                c[i] = np.linalg.lstsq(a[i], b[i], rcond=None)[0]
+        return c.reshape(B.shape)
+
+
+def optimal_reference_channel(w_mat, target_psd, noise_psd, eps=None):
+    """extraction/beamformer.py:601-624."""
+    if w_mat.ndim != 3:
+        raise ValueError('expects (frequency, sensors, sensors)')
+    if eps is None:
+        eps = np.finfo(w_mat.dtype).tiny
+    num = np.einsum('...FdR,...FdD,...FDR->...R', w_mat.conj(), target_psd, w_mat)
+    den = np.einsum('...FdR,...FdD,...FDR->...R', w_mat.conj(), noise_psd, w_mat)
+    snr = num / np.maximum(den, eps)
+    assert np.all(np.isfinite(snr)), snr
+    return np.argmax(snr.real)
+
+
+def mvdr_souden(target_psd, noise_psd, ref_channel=None, eps=None,
+                return_ref_channel=False):
+    """extraction/beamformer.py:627-698."""
+    phi = stable_solve(noise_psd, target_psd)
+    lam = np.trace(phi, axis1=-1, axis2=-2)[..., None, None]
+    if eps is None:
+        eps = np.finfo(lam.dtype).tiny
+    mat = phi / np.maximum(lam.real, eps)
+    if ref_channel is None:
+        ref_channel = optimal_reference_channel(mat, target_psd, noise_psd, eps=eps)
+    w = mat[..., ref_channel]
+    return (w, ref_channel) if return_ref_channel else w
+
+
+def mvdr(atf_vector, noise_psd):
+    """extraction/beamformer.py:230-260."""
+    while atf_vector.ndim > noise_psd.ndim - 1:
+        noise_psd = noise_psd[None]
+    noise_psd = 0.5 * (noise_psd + np.conj(noise_psd.swapaxes(-1, -2)))
+    num = np.linalg.solve(noise_psd, atf_vector[..., None])[..., 0]
+    den = np.einsum('...d,...d->...', atf_vector.conj(), num)
+    return num / den[..., None]
+
+
+def ban(vector, noise_psd):
+    """extraction/beamformer.py:459-488."""
+    nom = np.sqrt(np.einsum('...a,...ab,...bc,...c->...', vector.conj(),
+                            noise_psd, noise_psd, vector))
+    den = np.einsum('...a,...ab,...b->...', vector.conj(), noise_psd, vector)
+    den = np.sqrt(den * den.conj())
+    norm = np.divide(nom, den, out=np.zeros_like(nom), where=den != 0)
+    return vector * np.abs(norm[..., None])
+
+
+def apply_bf(vector, mix):
+    """extraction/beamformer.py:572-583."""
+    assert vector.shape[-1] < 30
+    return np.einsum('...a,...at->...t', vector.conj(), mix)
+
+
+def pca_vector(target_psd):
+    """extraction/beamformer.py:163-224 (scaling=None)."""
+    shape = target_psd.shape
+    vals, vecs = np.linalg.eigh(target_psd.reshape(-1, *shape[-2:]))
+    return vecs[..., -1].reshape(shape[:-1])
+
+
+def bf_vector(beamformer, target_psd, noise_psd=None, **kw):
+    """extraction/beamformer_wrapper.py:117-236 for the cores on the hot path:
+    'gev', 'mvdr_souden', 'pca', 'pca+mvdr', 'scaled_gev_atf+mvdr',
+    'rank1_gev+...' / 'rank1_pca+...', 'ch<N>', each optionally with '+ban'."""
+    do_ban = beamformer.endswith('+ban')
+    core = beamformer[:-4] if do_ban else beamformer
+
+    def rank1(kind, cov):
+        if kind == 'rank1_pca':
+            a = pca_vector(cov)
+        elif kind == 'rank1_gev':
+            a = np.einsum('...dD,...D->...d', noise_psd, gev_vector(cov, noise_psd))
+        else:
+            raise ValueError(kind)
+        r1 = np.einsum('...d,...D->...dD', a, a.conj())
+        scale = np.trace(cov, axis1=-1, axis2=-2) / np.trace(r1, axis1=-1, axis2=-2)
+        return scale[..., None, None] * r1
+
+    if core == 'pca':
+        w = pca_vector(target_psd)
+    elif core in ('pca+mvdr', 'scaled_gev_atf+mvdr'):
+        if core.startswith('pca'):
+            atf = pca_vector(target_psd)
+        else:
+            atf = np.einsum('...dD,...D->...d', noise_psd,
+                            gev_vector(target_psd, noise_psd))
+        w = mvdr(atf, noise_psd)
+    elif core in ('mvdr_souden', 'rank1_pca+mvdr_souden', 'rank1_gev+mvdr_souden'):
+        if core != 'mvdr_souden':
+            target_psd = rank1(core.split('+')[0], target_psd)
+        w = mvdr_souden(target_psd, noise_psd, **kw)
+    elif core in ('gev', 'rank1_pca+gev', 'rank1_gev+gev'):
+        if core != 'gev':
+            target_psd = rank1(core.split('+')[0], target_psd)
+        w = gev_vector(target_psd, noise_psd)
+    elif core.startswith('ch') and core[2:].isdigit():
+        D = target_psd.shape[-1]
+        w = np.zeros(D)
+        w[int(core[2:])] = 1
+        w = np.broadcast_to(w, target_psd.shape[:-1])
+    else:
+        raise ValueError(f'Could not find implementation for {core}.')
+    if do_ban:
+        w = ban(w, noise_psd)
+    return w

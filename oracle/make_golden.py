@@ -1,0 +1,182 @@
+"""Generate tests/golden/*.npz from the REAL reference (fgnt/pb_bss).
+
+Run in the build container (where /root/reference exists):
+
+    python -m oracle.make_golden
+
+Each fixture stores seeded inputs and the outputs of the unmodified reference
+functions (imported through oracle/refshim.py).  The committed fixtures pin
+both the NumPy oracle (tests/test_oracle_golden.py, CPU) and the HIP path
+(tests/test_gpu_golden.py) on boxes where the reference itself is absent.
+"""
+import os
+import warnings
+
+import numpy as np
+
+from oracle import refshim, synth
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                   'tests', 'golden')
+
+
+def _save(name, **arrays):
+    path = os.path.join(OUT, name + '.npz')
+    np.savez_compressed(path, **arrays)
+    print(f'{name}: {os.path.getsize(path) / 1024:.1f} KiB')
+
+
+def cacgmm_cases():
+    from pb_bss.distribution import CACGMMTrainer
+    cases = [
+        # name, F, T, D, K, iterations, fit kwargs
+        ('cacgmm_f5_t60_d3_k2', 5, 60, 3, 2, 5, {}),
+        ('cacgmm_f9_t120_d8_k3', 9, 120, 8, 3, 10, {}),
+        ('cacgmm_f6_t80_d6_k3_trace', 6, 80, 6, 3, 4, dict(covariance_norm='trace')),
+        ('cacgmm_f6_t80_d4_k2_nonorm', 6, 80, 4, 2, 4, dict(covariance_norm=False)),
+        ('cacgmm_f4_t70_d5_k3_uniform', 4, 70, 5, 3, 4, dict(weight_constant_axis=-2)),
+        ('cacgmm_f7_t64_d4_k2_shared', 7, 64, 4, 2, 4, dict(weight_constant_axis=(-3,))),
+        ('cacgmm_f7_t64_d4_k3_shared_ft', 7, 64, 4, 3, 3, dict(weight_constant_axis=(-3, -1))),
+    ]
+    for name, F, T, D, K, iters, kw in cases:
+        Y, init = synth.make_stft(F, T, D, K, seed=len(name))
+        Y128 = Y.astype(np.complex128)  # the float64 path of the reference
+        model = CACGMMTrainer().fit(Y128, initialization=init, iterations=iters, **kw)
+        aff, q = model.predict(Y128, return_quadratic_form=True)
+        _save(name, Y=Y, init=init, iterations=iters,
+              weight=model.weight,
+              eigvec=model.cacg.covariance_eigenvectors,
+              eigval=model.cacg.covariance_eigenvalues,
+              covariance=model.cacg.covariance,
+              affiliation=aff, quadratic_form=q,
+              log_likelihood=model.log_likelihood(Y128),
+              kwargs=np.array(repr(kw)))
+    # saliency + zero frames + rank-deficient (floor) + batch axis
+    Y, init = synth.make_stft(5, 90, 4, 2, seed=3)
+    Y[:, 7] = 0
+    rng = np.random.default_rng(0)
+    sal = rng.uniform(0.2, 1.0, size=(5, 90))
+    Y128 = Y.astype(np.complex128)
+    model = CACGMMTrainer().fit(Y128, initialization=init, iterations=4, saliency=sal)
+    _save('cacgmm_saliency_zero_frame', Y=Y, init=init, iterations=4, saliency=sal,
+          weight=model.weight, eigvec=model.cacg.covariance_eigenvectors,
+          eigval=model.cacg.covariance_eigenvalues,
+          covariance=model.cacg.covariance, affiliation=model.predict(Y128))
+    Y, init = synth.make_rank_deficient(4, 80, 5, 2, rank=2, seed=1)
+    Y128 = Y.astype(np.complex128)
+    model = CACGMMTrainer().fit(Y128, initialization=init, iterations=2)
+    _save('cacgmm_rank_deficient', Y=Y, init=init, iterations=2,
+          weight=model.weight, eigvec=model.cacg.covariance_eigenvectors,
+          eigval=model.cacg.covariance_eigenvalues,
+          covariance=model.cacg.covariance, affiliation=model.predict(Y128))
+    Yb = np.stack([synth.make_stft(3, 50, 4, 2, seed=s)[0] for s in (1, 2)])
+    ib = np.stack([synth.make_stft(3, 50, 4, 2, seed=s)[1] for s in (1, 2)])
+    model = CACGMMTrainer().fit(Yb.astype(np.complex128), initialization=ib, iterations=3)
+    _save('cacgmm_batch_axis', Y=Yb, init=ib, iterations=3,
+          weight=model.weight, eigvec=model.cacg.covariance_eigenvectors,
+          eigval=model.cacg.covariance_eigenvalues,
+          covariance=model.cacg.covariance,
+          affiliation=model.predict(Yb.astype(np.complex128)))
+
+
+def cacg_cases():
+    from pb_bss.distribution.complex_angular_central_gaussian import (
+        ComplexAngularCentralGaussianTrainer, normalize_observation)
+    from pb_bss.distribution.mixture_model_utils import estimate_mixture_weight
+    # doctest KAT of _fit (complex_angular_central_gaussian.py:278-289)
+    y = np.array([[1, 0, 0], [1, 0, 0], [0, 1, 0], [0, 1, 0]], dtype=np.complex128).T
+    q = np.array([[1, 0], [1, 0], [1, 0], [1, 0]], dtype=np.float64).T
+    m = ComplexAngularCentralGaussianTrainer()._fit(y=y, saliency=None, quadratic_form=q)
+    _save('cacg_fit_doctest', y=y, quadratic_form=q,
+          eigvec=m.covariance_eigenvectors, eigval=m.covariance_eigenvalues,
+          covariance=m.covariance)
+    # one M-step + log pdf on random data with a class axis
+    rng = np.random.default_rng(5)
+    Y = (rng.standard_normal((4, 70, 5)) + 1j * rng.standard_normal((4, 70, 5)))
+    yn = normalize_observation(Y)
+    sal = rng.uniform(size=(4, 3, 70))
+    qf = rng.uniform(0.5, 2.0, size=(4, 3, 70))
+    m = ComplexAngularCentralGaussianTrainer()._fit(y=yn[:, None], saliency=sal, quadratic_form=qf)
+    lp, q2 = m._log_pdf(yn[:, None])
+    _save('cacg_m_step_log_pdf', Y=Y, yn=yn, saliency=sal, quadratic_form=qf,
+          eigvec=m.covariance_eigenvectors, eigval=m.covariance_eigenvalues,
+          covariance=m.covariance, log_pdf=lp, q_out=q2)
+    # plain cACG fit (no mixture), test_complex_angular_central_gaussian.py style
+    # (the reference's fit only works without independent axes:
+    #  `np.ones(*independent, N)`, complex_angular_central_gaussian.py:235)
+    m = ComplexAngularCentralGaussianTrainer().fit(Y[0], iterations=5)
+    _save('cacg_trainer_fit', Y=Y[0], covariance=m.covariance,
+          eigval=m.covariance_eigenvalues, log_pdf=m.log_pdf(Y[0]))
+    aff = np.array([[0.4, 1, 0.4], [0.6, 0, 0.6]])
+    _save('mixture_weight_doctest', affiliation=aff,
+          w_default=estimate_mixture_weight(aff),
+          w_axis_m2=estimate_mixture_weight(aff, weight_constant_axis=-2),
+          w_stack_m3=estimate_mixture_weight([aff, aff], weight_constant_axis=-3))
+
+
+def beamformer_cases():
+    from pb_bss.extraction import beamformer as bf
+    from pb_bss.extraction.beamformer_wrapper import get_bf_vector
+    rng = np.random.default_rng(11)
+    F, T, D, K = 17, 90, 6, 3
+
+    def cn(*s):
+        return rng.standard_normal(s) + 1j * rng.standard_normal(s)
+
+    X = cn(F, D, T)
+    mask = rng.uniform(size=(F, K, T))
+    psd = bf.get_power_spectral_density_matrix(X, mask)
+    psd_nonorm = bf.get_power_spectral_density_matrix(X, mask, normalize=False)
+    psd_plain = bf.get_power_spectral_density_matrix(X)
+    psd_2d = bf.get_power_spectral_density_matrix(X, mask[:, 0])
+    psd_src0 = bf.get_power_spectral_density_matrix(
+        X, mask.transpose(1, 0, 2), source_dim=0)
+    target = psd[:, 0]
+    noise = psd[:, 1] + psd[:, 2]
+    out = dict(X=X, mask=mask, psd=psd, psd_nonorm=psd_nonorm, psd_plain=psd_plain,
+               psd_2d=psd_2d, psd_src0=psd_src0, target=target, noise=noise)
+    out['gev'] = bf._get_gev_vector(target, noise)  # SciPy loop (Cython not built here)
+    out['pca'] = bf.get_pca_vector(target)
+    w_s, ref = bf.get_mvdr_vector_souden(target, noise, return_ref_channel=True)
+    out['mvdr_souden'] = w_s
+    out['mvdr_souden_ref'] = ref
+    out['mvdr_souden_ch1'] = bf.get_mvdr_vector_souden(target, noise, ref_channel=1)
+    atf = bf.get_pca_vector(target)
+    out['mvdr'] = bf.get_mvdr_vector(atf, noise)
+    out['ban'] = bf.blind_analytic_normalization(out['gev'], noise)
+    out['applied'] = bf.apply_beamforming_vector(w_s, X)
+    out['ref_channel_fn'] = bf.get_optimal_reference_channel(
+        np.linalg.solve(noise, target), target, noise)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        for name in ['pca', 'gev', 'gev+ban', 'mvdr_souden', 'mvdr_souden+ban',
+                     'pca+mvdr', 'scaled_gev_atf+mvdr', 'rank1_pca+mvdr_souden',
+                     'rank1_gev+mvdr_souden+ban', 'rank1_gev+gev', 'rank1_pca+gev',
+                     'ch2']:
+            out['bf__' + name.replace('+', '__')] = get_bf_vector(name, target, noise)
+    _save('beamformer_f17_d6', **out)
+    # MVDR-Souden known answer (tests/test_extraction/test_beamformer.py:185-209)
+    obs = np.array([[0, 0, 1], [0, 0.1, 1], [0.1, 0, 1]])
+    pxx = obs.T.conj() @ obs
+    pnn = np.eye(3)
+    w, = bf.get_mvdr_vector_souden(pxx[None], pnn[None])
+    from pb_bss.math.solve import stable_solve
+    A = cn(5, 4, 4)
+    Bm = cn(5, 4, 4)
+    A[2, 1, :] = 0
+    A[3] = 0
+    _save('mvdr_souden_kat', pxx=pxx, pnn=pnn, w=w, w_repr=np.array(repr(w)),
+          solve_A=A, solve_B=Bm, solve_X=stable_solve(A, Bm))
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    refshim.load()
+    warnings.filterwarnings('ignore', category=DeprecationWarning)
+    cacgmm_cases()
+    cacg_cases()
+    beamformer_cases()
+
+
+if __name__ == '__main__':
+    main()

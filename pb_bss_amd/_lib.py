@@ -1,0 +1,194 @@
+"""ctypes binding of libpbbss_hip.so (the C ABI declared in include/pbbss.h).
+
+The product path has NO CPU fallback: if the shared library is missing or a
+call fails this module raises.  PyTorch-ROCm is used only as the owner of
+device memory and streams; all arithmetic happens inside the HIP library.
+"""
+import ctypes
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libpbbss_hip.so')
+
+# ---- constants mirrored from include/pbbss.h ---------------------------------
+OK = 0
+ERR_INVALID_ARG = -1
+ERR_UNSUPPORTED = -2
+ERR_HIP = -3
+ERR_LDS_CAPACITY = -4
+
+ST_NONFINITE = 1
+ST_EIG_NOCONV = 2
+ST_FLOORED = 4
+ST_SLOWPATH = 8
+ST_NOT_POSDEF = 16
+ST_SINGULAR = 32
+
+COVNORM = {False: 0, None: 0, 'eigenvalue': 1, 'trace': 2}
+WEIGHT_PER_CLASS_MEAN = 0
+WEIGHT_UNIFORM = 1
+LAYOUT_TD = 0
+LAYOUT_DT = 1
+
+EXPORTS = (
+    'pbbss_version', 'pbbss_error_string', 'pbbss_create', 'pbbss_destroy',
+    'pbbss_normalize_observation', 'pbbss_cacgmm_fit', 'pbbss_cacgmm_predict',
+    'pbbss_cacg_m_step', 'pbbss_heev_batched', 'pbbss_psd', 'pbbss_gev',
+    'pbbss_solve', 'pbbss_mvdr_souden', 'pbbss_mvdr', 'pbbss_ban',
+    'pbbss_apply_beamforming_vector', 'pbbss_set_timing',
+    'pbbss_last_kernel_ms',
+)
+
+
+class EmOpts(ctypes.Structure):
+    """struct pbbss_em_opts"""
+    _fields_ = [
+        ('iterations', ctypes.c_int32),
+        ('covariance_norm', ctypes.c_int32),
+        ('weight_mode', ctypes.c_int32),
+        ('hermitize', ctypes.c_int32),
+        ('layout', ctypes.c_int32),
+        ('y_is_c128', ctypes.c_int32),
+        ('final_predict', ctypes.c_int32),
+        ('force_eig', ctypes.c_int32),
+        ('affiliation_eps', ctypes.c_double),
+        ('eigenvalue_floor', ctypes.c_double),
+    ]
+
+
+class PbbssError(RuntimeError):
+    pass
+
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+def load():
+    """dlopen the HIP library; raises if it has not been built."""
+    global _lib
+    with _lib_lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise PbbssError(
+                f'{LIB_PATH} not found: build it with '
+                '`make -C pb_bss_amd/csrc -j8` (or __graft_entry__.build()). '
+                'There is no CPU fallback.')
+        lib = ctypes.CDLL(LIB_PATH)
+        vp, i32, i64, dbl = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double
+        lib.pbbss_version.restype = ctypes.c_int
+        lib.pbbss_error_string.restype = ctypes.c_char_p
+        lib.pbbss_error_string.argtypes = [i32]
+        lib.pbbss_create.argtypes = [ctypes.POINTER(vp), i32]
+        lib.pbbss_destroy.argtypes = [vp]
+        lib.pbbss_set_timing.argtypes = [vp, i32]
+        lib.pbbss_last_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
+        lib.pbbss_normalize_observation.argtypes = [vp, vp, i32, i64, i32, i32, vp, vp]
+        lib.pbbss_cacgmm_fit.argtypes = [
+            vp, vp, i64, i32, i32, i32, vp, vp, vp, vp, vp, vp,
+            ctypes.POINTER(EmOpts), vp, vp, vp, vp, vp, vp, vp]
+        lib.pbbss_cacgmm_predict.argtypes = [
+            vp, vp, i64, i32, i32, i32, vp, vp, vp, i64, i64, i64, vp, i32, i32,
+            dbl, vp, vp, vp, vp]
+        lib.pbbss_cacg_m_step.argtypes = [
+            vp, vp, i64, i32, i32, i32, vp, vp, i32, i32, i32, dbl, vp, vp, vp,
+            vp, vp]
+        lib.pbbss_heev_batched.argtypes = [vp, vp, i64, i32, vp, vp, vp, vp]
+        lib.pbbss_psd.argtypes = [vp, vp, i32, i64, i32, i32, i32, vp, i32, vp, vp]
+        lib.pbbss_gev.argtypes = [vp, vp, vp, i64, i32, vp, vp, vp]
+        lib.pbbss_solve.argtypes = [vp, vp, vp, i64, i32, i32, vp, vp, vp]
+        lib.pbbss_mvdr_souden.argtypes = [vp, vp, vp, i64, i32, dbl, vp, vp, vp, vp, vp]
+        lib.pbbss_mvdr.argtypes = [vp, vp, vp, i64, i32, vp, vp, vp]
+        lib.pbbss_ban.argtypes = [vp, vp, vp, i64, i32, vp, vp]
+        lib.pbbss_apply_beamforming_vector.argtypes = [vp, vp, vp, i32, i64, i32, i32, vp, vp]
+        for name in EXPORTS:
+            fn = getattr(lib, name)
+            if name not in ('pbbss_error_string',):
+                fn.restype = ctypes.c_int
+        _lib = lib
+        return lib
+
+
+def check(rc, what=''):
+    if rc != OK:
+        msg = load().pbbss_error_string(rc).decode()
+        if rc == ERR_UNSUPPORTED:
+            raise NotImplementedError(f'{what}: {msg}')
+        raise PbbssError(f'{what}: {msg} (code {rc})')
+
+
+# ---- device handles -----------------------------------------------------------
+_handles = {}
+_handles_lock = threading.Lock()
+
+
+def torch():
+    import torch as _torch
+    return _torch
+
+
+def require_gpu():
+    t = torch()
+    if not t.cuda.is_available():
+        raise PbbssError(
+            'pb_bss_amd needs a ROCm GPU (torch.cuda.is_available() is False); '
+            'there is no CPU fallback in the product path.')
+    return t
+
+
+def handle(device_index=None):
+    """One C handle per (device, host thread)."""
+    t = require_gpu()
+    if device_index is None:
+        device_index = t.cuda.current_device()
+    key = (device_index, threading.get_ident())
+    with _handles_lock:
+        h = _handles.get(key)
+        if h is None:
+            lib = load()
+            hp = ctypes.c_void_p()
+            check(lib.pbbss_create(ctypes.byref(hp), device_index), 'pbbss_create')
+            h = hp
+            _handles[key] = h
+        return h
+
+
+def stream_ptr(device_index=None):
+    t = torch()
+    return ctypes.c_void_p(t.cuda.current_stream(device_index).cuda_stream)
+
+
+def ptr(tensor):
+    """Device pointer of a contiguous torch tensor (None -> NULL)."""
+    if tensor is None:
+        return None
+    assert tensor.is_cuda and tensor.is_contiguous(), (tensor.device, tensor.stride())
+    return ctypes.c_void_p(tensor.data_ptr())
+
+
+# ---- host <-> device plumbing ---------------------------------------------------
+def is_torch(x):
+    return type(x).__module__.startswith('torch')
+
+
+def to_device(x, dtype=None, device=None):
+    """numpy array or torch tensor -> contiguous cuda tensor of `dtype`."""
+    t = require_gpu()
+    if device is None:
+        device = t.device('cuda', t.cuda.current_device())
+    if is_torch(x):
+        out = x.to(device=device, dtype=dtype) if dtype is not None else x.to(device)
+    else:
+        arr = np.ascontiguousarray(x)
+        out = t.from_numpy(arr).to(device)
+        if dtype is not None and out.dtype != dtype:
+            out = out.to(dtype)
+    return out.contiguous()
+
+
+def to_host(x):
+    return x.detach().cpu().numpy()

@@ -173,6 +173,7 @@ __global__ void __launch_bounds__(kLaThreads) solve_kernel(const double* A, cons
     bim = p[1];
   }
   bool sing = wave_lu_solve<D>(are, aim, bre, bim, c, xre, xim);
+  if (sing) wave_pinv_solve<D>(are, aim, bre, bim, c, xre, xim);  // math/solve.py:111-113
   if (c.i < D && c.j < M) {
     double* p = out + ((n * D + c.i) * M + c.j) * 2;
     p[0] = xre;
@@ -195,6 +196,7 @@ __global__ void __launch_bounds__(kLaThreads)
   load_mat<D>(target, n, c, tre, tim);
   load_mat<D>(noise, n, c, nre, nim);
   bool sing = wave_lu_solve<D>(nre, nim, tre, tim, c, gre, gim);  // G = noise^-1 target  (:682)
+  if (sing) wave_pinv_solve<D>(nre, nim, tre, tim, c, gre, gim);  // stable_solve's lstsq branch
   // lambda = trace(G); mat = G / max(lambda.real, eps)            (:683-686)
   double tr = wave_sum((valid && c.i == c.j) ? gre : 0.0);
   double sc = 1.0 / fmax(tr, eps);
@@ -256,6 +258,7 @@ __global__ void __launch_bounds__(kLaThreads) mvdr_kernel(const double* atf, con
   }
   double xre, xim;
   bool sing = wave_lu_solve<D>(nre, nim, hre, him, c, xre, xim);  // numerator (:250)
+  if (sing) wave_pinv_solve<D>(nre, nim, hre, him, c, xre, xim);  // lstsq fallback (:251-256)
   // denominator = h^H x (:257)
   double dr = (c.j == 0 && c.i < D) ? (hre * xre + him * xim) : 0.0;
   double di = (c.j == 0 && c.i < D) ? (hre * xim - him * xre) : 0.0;

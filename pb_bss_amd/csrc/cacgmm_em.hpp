@@ -44,7 +44,8 @@ struct EmArgs {
   const double* in_weight;  // strided, see wb/wk/wt
   int64_t wb, wk, wt;
   const double* saliency;   // (B,T) or null
-  const uint8_t* activity;  // (B,K,T) or null
+  const uint8_t* activity;        // (B,K,T) or null: source_activity_mask of the EM loop
+  const uint8_t* final_activity;  // mask of the final predict (CACGMM.predict argument)
   // outputs (any may be null)
   double* out_eigvec;
   double* out_eigval;
@@ -89,6 +90,7 @@ struct EmKernel {
     double* ssum;    // [K]           sum_t gamma_kt (saliency applied)
     int* dete;       // [K]           det B_k exponent
     int* status;     // [K]
+    int* flags;      // [1]  bit0: the problem contains an all-zero frame
     int Tp;
   };
 
@@ -102,7 +104,7 @@ struct EmKernel {
     n += (size_t)K * NA * 8;
     n += (size_t)K * 8 * 3;         // wgt, detm, ssum
     n += (size_t)kEmWaves * K * 8;  // red
-    n += (size_t)K * 4 * 2;         // dete, status
+    n += (size_t)K * 4 * 2 + 16;    // dete, status, flags
     return (n + 15) & ~(size_t)15;
   }
 
@@ -131,6 +133,8 @@ struct EmKernel {
     L.dete = reinterpret_cast<int*>(p);
     p += K * 4;
     L.status = reinterpret_cast<int*>(p);
+    p += K * 4;
+    L.flags = reinterpret_cast<int*>(p);
     return L;
   }
 
@@ -153,6 +157,7 @@ struct EmKernel {
   static __device__ void phase_load(const EmArgs& a, const Lds& L, int64_t b, int tid) {
     const int T = a.T;
     const YS2* yg = reinterpret_cast<const YS2*>(a.y);
+    bool zero_seen = false;
     for (int t = tid; t < L.Tp; t += kEmThreads) {
       double n2 = 0.0;
       YS vr[2 * DP], vi[2 * DP];
@@ -188,7 +193,12 @@ struct EmKernel {
         inv = 1.0;  // caller already normalised (as _predict / _fit receive it)
       }
       L.inv_n2[t] = (t < T) ? inv : 0.0;
+      if (t < T && !(n2 > 0.0)) zero_seen = true;
     }
+    // An all-zero frame has q floored at `tiny` whatever the scale of B_k
+    // (cacg.py:185-199), so its posterior depends on the eigenvalue
+    // normalisation: such problems must take the exact eigen path.
+    if (zero_seen) atomicOr(L.flags, 1);
   }
 
   // ---- M-step weight of one frame/class  (cacg.py:310, :322) ---------------
@@ -318,7 +328,8 @@ struct EmKernel {
             w = wgt[k];
           }
           double v = ldexp(val[k], ex[k] - emax) * w;  // mixture_model_utils.py:32-37
-          if (a.activity) v *= (double)a.activity[((size_t)b * K + k) * a.T + t];
+          const uint8_t* act = FINAL ? a.final_activity : a.activity;
+          if (act) v *= (double)act[((size_t)b * K + k) * a.T + t];
           g[k] = v;
           den += v;
         }
@@ -489,7 +500,7 @@ struct EmKernel {
       oc[0] = are;
       oc[1] = aim;
     }
-    bool need_eig = last || a.force_eig || (st & PBBSS_ST_NONFINITE);
+    bool need_eig = last || a.force_eig || (st & PBBSS_ST_NONFINITE) || (*L.flags & 1);
     if (!need_eig) {
       double lre = are, lim = aim;
       ScaledReal det;
@@ -637,8 +648,10 @@ struct EmKernel {
     const Lds L = carve(smem, a.T);
     for (int64_t b = blockIdx.x; b < a.B; b += gridDim.x) {
       __syncthreads();  // previous problem fully retired before LDS is reused
-      phase_load(a, L, b, tid);
       if (tid < K) L.status[tid] = 0;
+      if (tid == 0) *L.flags = 0;
+      __syncthreads();
+      phase_load(a, L, b, tid);
       __syncthreads();
       const bool model_in = (a.gamma0 == nullptr);
       if (model_in) {

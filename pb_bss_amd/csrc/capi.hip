@@ -175,7 +175,7 @@ PBBSS_API int pbbss_cacgmm_predict(pbbss_handle_t h, const void* y, int64_t B, i
   a.wb = wb;
   a.wk = wk;
   a.wt = wt;
-  a.activity = activity;
+  a.final_activity = activity;  // CACGMM.predict(source_activity_mask=...)
   a.out_aff = out_affiliation;
   a.out_q = out_quadratic_form;
   a.out_logpdf = out_log_pdf;

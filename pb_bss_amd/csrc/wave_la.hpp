@@ -324,4 +324,64 @@ __device__ __forceinline__ bool wave_lu_solve(double are, double aim, double bre
   return singular;
 }
 
+
+// ---------------------------------------------------------------------------
+// Minimum-norm least squares X = A^+ B for an (exactly) singular A, the
+// on-device counterpart of the numpy.linalg.lstsq fallback in
+// math/solve.py:95-114 and extraction/beamformer.py:251-256.
+// Hermitian A (every PSD matrix): A^+ = V diag(1/lambda_i if |lambda_i| >
+// D*eps*max|lambda| else 0) V^H -- the same cut-off numpy's lstsq applies to
+// the singular values.  General A: X = (A^H A)^+ A^H B.
+// ---------------------------------------------------------------------------
+template <int D>
+__device__ __forceinline__ void wave_pinv_solve(double are, double aim, double bre,
+                                                double bim, LaneIJ c, double& xre,
+                                                double& xim) {
+  const bool valid = c.i < D && c.j < D;
+  if (!valid) {
+    are = 0.0;
+    aim = 0.0;
+  }
+  if (c.i >= D) {
+    bre = 0.0;
+    bim = 0.0;
+  }
+  double tre, tim;
+  wave_adjoint(are, aim, c, tre, tim);
+  const double dif = wave_sum((are - tre) * (are - tre) + (aim - tim) * (aim - tim));
+  const double nrm = wave_sum(are * are + aim * aim);
+  const bool herm = dif <= 1e-28 * nrm;
+  double gre, gim, rre, rim;
+  if (herm) {
+    gre = 0.5 * (are + tre);
+    gim = 0.5 * (aim + tim);
+    rre = bre;
+    rim = bim;
+  } else {
+    wave_matmul<D>(tre, tim, are, aim, c, gre, gim);  // A^H A
+    wave_matmul<D>(tre, tim, bre, bim, c, rre, rim);  // A^H B
+    double gtr, gti;
+    wave_adjoint(gre, gim, c, gtr, gti);
+    gre = 0.5 * (gre + gtr);
+    gim = 0.5 * (gim + gti);
+  }
+  double vre, vim;
+  wave_jacobi_heev<D>(gre, gim, c, vre, vim);
+  double lam = lane_get(gre, ij_lane(c.j, c.j));
+  double lmax = wave_max((c.i == 0 && c.j < D) ? fabs(lam) : 0.0);
+  double thr = (double)D * 2.220446049250313e-16 * lmax;
+  double inv = (fabs(lam) > thr && c.j < D) ? 1.0 / lam : 0.0;  // per column index
+  double vhr, vhi, yre, yim;
+  wave_adjoint(vre, vim, c, vhr, vhi);
+  wave_matmul<D>(vhr, vhi, rre, rim, c, yre, yim);  // V^H R
+  double sc = lane_get(inv, ij_lane(0, c.i));       // scale row e by 1/lambda_e
+  yre *= sc;
+  yim *= sc;
+  if (!valid) {
+    vre = 0.0;
+    vim = 0.0;
+  }
+  wave_matmul<D>(vre, vim, yre, yim, c, xre, xim);  // V (...)
+}
+
 }  // namespace pbbss

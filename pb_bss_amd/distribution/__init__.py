@@ -1,0 +1,14 @@
+"""Drop-in for the hot-path part of pb_bss.distribution
+(reference: pb_bss/distribution/__init__.py)."""
+from .complex_angular_central_gaussian import (
+    ComplexAngularCentralGaussian,
+    ComplexAngularCentralGaussianTrainer,
+    normalize_observation,
+)
+from .cacgmm import CACGMM, CACGMMTrainer
+
+__all__ = [
+    'CACGMM', 'CACGMMTrainer',
+    'ComplexAngularCentralGaussian', 'ComplexAngularCentralGaussianTrainer',
+    'normalize_observation',
+]

@@ -1,0 +1,361 @@
+"""cACGMM model and EM trainer backed by the persistent HIP EM kernel.
+
+Mirrors pb_bss/distribution/cacgmm.py: `CACGMM` (predict / log_likelihood)
+and `CACGMMTrainer` (fit / fit_predict) with the reference's argument names,
+shapes (y is (..., N, D); affiliations (..., K, N)) and assertions.
+
+Two execution paths:
+  * fused   -- the whole EM loop in ONE kernel launch (pbbss_cacgmm_fit).  Used
+               whenever every independent problem is self-contained:
+               weight_constant_axis in {(-1,), -1, -2}, no inline aligner.
+  * stepwise -- E-step / host hook / M-step per iteration (pbbss_cacgmm_predict
+               + pbbss_cacg_m_step) for options that couple frequencies:
+               weight_constant_axis containing -3, inline_permutation_aligner
+               (cacgmm.py:260-267).
+Arithmetic is float64 on the device for complex64 and complex128 input alike
+(SURVEY.md section 7); outputs are float64 / complex128.
+"""
+from dataclasses import dataclass, field
+from operator import xor
+
+import numpy as np
+
+from .. import _lib, engine
+from .complex_angular_central_gaussian import (
+    ComplexAngularCentralGaussian,
+    ComplexAngularCentralGaussianTrainer,
+    _complex_device,
+    normalize_observation,
+)
+from .mixture_model_utils import (
+    apply_inline_permutation_alignment,
+    estimate_mixture_weight,
+)
+from .utils import _ProbabilisticModel, as_result
+
+__all__ = ['CACGMM', 'CACGMMTrainer', 'normalize_observation']
+
+
+def _weight_for_predict(weight, indep, K, N, device):
+    """Expand a reference-shaped weight ((..., K, 1), (K, 1), (..., 1, K, N), ...)
+    to (B, K) or (B, K, N) float64 on the device."""
+    t = _lib.torch()
+    w = _lib.to_device(weight, t.float64).to(device)
+    if w.shape[-1] == 1:
+        return w.expand(*indep, K, 1).reshape(-1, K).contiguous()
+    return w.expand(*indep, K, N).reshape(-1, K, N).contiguous()
+
+
+def _activity(mask, indep, K, N, device):
+    if mask is None:
+        return None
+    t = _lib.torch()
+    is_bool = (mask.dtype == t.bool) if _lib.is_torch(mask) else (mask.dtype == bool)
+    assert is_bool, mask.dtype  # reference: mixture_model_utils.py:40
+    m = _lib.to_device(mask).to(device).to(t.uint8)
+    assert tuple(m.shape[-2:]) == (K, N), (m.shape, K, N)
+    return m.expand(*indep, K, N).reshape(-1, K, N).contiguous()
+
+
+@dataclass
+class CACGMM(_ProbabilisticModel):
+    """weight (..., K, 1) [or (K, 1) / (..., 1, K, N)], cacg parameters with a
+    class axis (..., K, D, D) / (..., K, D).  Reference: cacgmm.py:58-62."""
+    weight: np.ndarray = None
+    cacg: ComplexAngularCentralGaussian = field(
+        default_factory=ComplexAngularCentralGaussian)
+
+    def predict(self, y, return_quadratic_form=False, source_activity_mask=None):
+        """y (..., N, D) -> affiliation (..., K, N); affiliation_eps = 0.
+        Reference: cacgmm.py:64-71."""
+        like_torch = _lib.is_torch(y)
+        y = _complex_device(y)
+        *indep, N, D = y.shape
+        aff, q, _ = self._device_e_step(y.reshape(-1, N, D), tuple(indep), N,
+                                        _lib.LAYOUT_TD, source_activity_mask,
+                                        0.0, want_q=return_quadratic_form)
+        if return_quadratic_form:
+            return as_result(aff, like_torch), as_result(q, like_torch)
+        return as_result(aff, like_torch)
+
+    def _predict(self, y, source_activity_mask=None, affiliation_eps=0.):
+        """y normalised (..., D, N).  Returns (affiliation, quadratic_form,
+        log_pdf), each (..., K, N).  Reference: cacgmm.py:73-95."""
+        like_torch = _lib.is_torch(y)
+        y = _complex_device(y)
+        *indep, D, N = y.shape
+        aff, q, lp = self._device_e_step(y.reshape(-1, D, N), tuple(indep), N,
+                                         _lib.LAYOUT_DT, source_activity_mask,
+                                         affiliation_eps, want_q=True,
+                                         want_log_pdf=True)
+        return (as_result(aff, like_torch), as_result(q, like_torch),
+                as_result(lp, like_torch))
+
+    def _device_e_step(self, y_flat, indep, N, layout, source_activity_mask,
+                       affiliation_eps, want_q=False, want_log_pdf=False):
+        t = _lib.torch()
+        vec = _lib.to_device(self.cacg.covariance_eigenvectors, t.complex128)
+        val = _lib.to_device(self.cacg.covariance_eigenvalues, t.float64)
+        K, D = vec.shape[-3], vec.shape[-1]
+        vb = vec.expand(*indep, K, D, D).reshape(-1, K, D, D).contiguous()
+        lb = val.expand(*indep, K, D).reshape(-1, K, D).contiguous()
+        w = _weight_for_predict(self.weight, indep, K, N, y_flat.device)
+        act = _activity(source_activity_mask, indep, K, N, y_flat.device)
+        aff, q, lp = engine.em_predict(
+            y_flat, vb, lb, w, activity=act, layout=layout,
+            affiliation_eps=affiliation_eps, want_q=want_q,
+            want_log_pdf=want_log_pdf)
+        shape = (*indep, K, N)
+        return (aff.reshape(shape), None if q is None else q.reshape(shape),
+                None if lp is None else lp.reshape(shape))
+
+    def log_likelihood(self, y):
+        """sum over time-frequency of logsumexp_k(log_pdf) -- the reference
+        (cacgmm.py:97-138) does not apply the mixture weights here."""
+        t = _lib.torch()
+        y = _complex_device(y)
+        *indep, N, D = y.shape
+        _, _, lp = self._device_e_step(y.reshape(-1, N, D), tuple(indep), N,
+                                       _lib.LAYOUT_TD, None, 0.0,
+                                       want_log_pdf=True)
+        return np.float64(t.logsumexp(lp, dim=-2).sum().item())
+
+
+class CACGMMTrainer:
+    def fit(
+            self,
+            y,
+            initialization=None,
+            num_classes=None,
+            iterations=100,
+            *,
+            saliency=None,
+            source_activity_mask=None,
+            weight_constant_axis=(-1,),
+            hermitize=True,
+            covariance_norm='eigenvalue',
+            affiliation_eps=1e-10,
+            eigenvalue_floor=1e-10,
+            inline_permutation_aligner=None,
+    ):
+        """Same contract as the reference (cacgmm.py:142-280).
+
+        y: (..., N, D) complex.  initialization: affiliations (..., K, N) in
+        [0, 1] or a CACGMM; otherwise num_classes (random initialisation from
+        the global NumPy RNG exactly as the reference, cacgmm.py:208-209).
+        Returns a CACGMM (NumPy fields for NumPy input, torch for torch input).
+        """
+        assert xor(initialization is None, num_classes is None), (
+            "Incompatible input combination. "
+            "Exactly one of the two inputs has to be None: "
+            f"{initialization is None} xor {num_classes is None}"
+        )
+        like_torch = _lib.is_torch(y)
+        t = _lib.torch()
+        y = _complex_device(y)
+        assert y.shape[-1] > 1, y.shape
+        assert iterations > 0, iterations
+        *indep, N, D = y.shape
+        indep = tuple(indep)
+        dev = y.device
+
+        model = None
+        gamma0 = None
+        if initialization is None:
+            assert num_classes is not None, num_classes
+            shape = (*indep, num_classes, N)
+            aff = np.random.uniform(size=shape)  # global RNG, as the reference
+            aff /= np.einsum('...kn->...n', aff)[..., None, :]
+            gamma0 = _lib.to_device(aff, t.float64).to(dev)
+        elif isinstance(initialization, CACGMM):
+            num_classes = initialization.cacg.covariance_eigenvectors.shape[-3]
+            model = initialization
+        elif isinstance(initialization, np.ndarray) or _lib.is_torch(initialization):
+            num_classes = initialization.shape[-2]
+            assert num_classes > 1, num_classes
+            shape = (*indep, num_classes, N)
+            assert initialization.ndim == len(shape), (initialization.shape, shape)
+            assert tuple(initialization.shape[-2:]) == shape[-2:], (
+                initialization.shape, shape)
+            gamma0 = _lib.to_device(initialization, t.float64).to(dev).expand(shape)
+        else:
+            raise TypeError('No sufficient initialization.')
+        K = num_classes
+
+        if isinstance(weight_constant_axis, list):
+            weight_constant_axis = tuple(weight_constant_axis)
+        if source_activity_mask is not None:
+            assert tuple(source_activity_mask.shape[-2:]) == (K, N), (
+                source_activity_mask.shape, indep, K, N)
+            if gamma0 is not None and not isinstance(initialization, CACGMM) \
+                    and initialization is not None:
+                assert tuple(source_activity_mask.shape) == tuple(initialization.shape), (
+                    source_activity_mask.shape, initialization.shape)
+        assert K < 20, f'num_classes: {K}, sure?'
+        assert D < 35, f'Channels: {D}, sure?'
+
+        ndim = len(indep) + 2
+        mode = self._weight_mode(weight_constant_axis, ndim)
+        fused = (mode is not None and inline_permutation_aligner is None)
+        if fused and model is not None:
+            # a resumed model must carry per-class weights the kernel can hold
+            w = model.weight
+            fused = (w is not None and w.shape[-1] == 1)
+
+        act = _activity(source_activity_mask, indep, K, N, dev)
+        sal = None
+        if saliency is not None:
+            sal = _lib.to_device(saliency, t.float64).to(dev).expand(*indep, N)
+            sal = sal.reshape(-1, N).contiguous()
+
+        if fused:
+            return self._fit_fused(
+                y.reshape(-1, N, D), indep, K, gamma0, model, iterations, sal,
+                act, mode, covariance_norm, affiliation_eps, eigenvalue_floor,
+                hermitize, like_torch)
+        return self._fit_stepwise(
+            y.reshape(-1, N, D), indep, K, gamma0, model, iterations, saliency,
+            sal, act, weight_constant_axis, covariance_norm, affiliation_eps,
+            eigenvalue_floor, hermitize, inline_permutation_aligner, like_torch)
+
+    @staticmethod
+    def _weight_mode(axis, ndim):
+        """Map weight_constant_axis to the kernel's built-in modes, or None."""
+        if isinstance(axis, int):
+            if axis % ndim - ndim == -2:
+                return _lib.WEIGHT_UNIFORM  # mixture_model_utils.py:180-183
+            axis = (axis,)
+        axes = {a % ndim - ndim for a in axis}
+        if axes == {-1}:
+            return _lib.WEIGHT_PER_CLASS_MEAN
+        return None
+
+    # ------------------------------------------------------------------ fused
+    def _fit_fused(self, yb, indep, K, gamma0, model, iterations, sal, act, mode,
+                   covariance_norm, affiliation_eps, eigenvalue_floor, hermitize,
+                   like_torch, final_predict=False):
+        t = _lib.torch()
+        B, N, D = yb.shape
+        dev_model = None
+        g0 = None
+        if model is not None:
+            vec = _lib.to_device(model.cacg.covariance_eigenvectors, t.complex128)
+            val = _lib.to_device(model.cacg.covariance_eigenvalues, t.float64)
+            w = _lib.to_device(model.weight, t.float64)
+            dev_model = (
+                vec.expand(*indep, K, D, D).reshape(B, K, D, D).contiguous(),
+                val.expand(*indep, K, D).reshape(B, K, D).contiguous(),
+                w.expand(*indep, K, 1).reshape(B, K).contiguous())
+        else:
+            g0 = gamma0.reshape(B, K, N).contiguous()
+        r = engine.em_fit(
+            yb, K, gamma0=g0, model=dev_model, iterations=iterations,
+            saliency=sal, activity=act, covariance_norm=covariance_norm,
+            weight_mode=mode, affiliation_eps=affiliation_eps,
+            eigenvalue_floor=eigenvalue_floor, hermitize=hermitize,
+            layout=_lib.LAYOUT_TD, final_predict=final_predict)
+        if mode == _lib.WEIGHT_UNIFORM:
+            weight = t.full((K, 1), 1.0 / K, dtype=t.float64, device=yb.device)
+        else:
+            weight = r['weight'].reshape(*indep, K, 1)
+        out = CACGMM(
+            weight=as_result(weight, like_torch),
+            cacg=ComplexAngularCentralGaussian(
+                covariance_eigenvectors=as_result(
+                    r['eigvec'].reshape(*indep, K, D, D), like_torch),
+                covariance_eigenvalues=as_result(
+                    r['eigval'].reshape(*indep, K, D), like_torch)))
+        if final_predict:
+            return out, as_result(r['affiliation'].reshape(*indep, K, N), like_torch)
+        return out
+
+    # --------------------------------------------------------------- stepwise
+    def _fit_stepwise(self, yb, indep, K, gamma0, model, iterations, saliency,
+                      sal, act, weight_constant_axis, covariance_norm,
+                      affiliation_eps, eigenvalue_floor, hermitize, aligner,
+                      like_torch):
+        """The reference loop (cacgmm.py:252-278) with device E/M steps."""
+        t = _lib.torch()
+        B, N, D = yb.shape
+        yn = engine.normalize_observation(yb)  # (B, D, N)
+        shape = (*indep, K, N)
+        if model is None:
+            aff = _lib.to_host(gamma0.reshape(shape))
+            q = np.ones(shape, dtype=np.float64)
+        else:
+            model = CACGMM(
+                weight=_lib.to_host(_lib.to_device(model.weight, t.float64)),
+                cacg=ComplexAngularCentralGaussian(
+                    covariance_eigenvectors=_lib.to_host(_lib.to_device(
+                        model.cacg.covariance_eigenvectors, t.complex128)),
+                    covariance_eigenvalues=_lib.to_host(_lib.to_device(
+                        model.cacg.covariance_eigenvalues, t.float64))))
+        sal_host = None if saliency is None else np.broadcast_to(
+            _lib.to_host(_lib.to_device(saliency, t.float64)), (*indep, N))
+        for _ in range(iterations):
+            if model is not None:
+                vec = _lib.to_device(model.cacg.covariance_eigenvectors, t.complex128)
+                val = _lib.to_device(model.cacg.covariance_eigenvalues, t.float64)
+                w = _weight_for_predict(model.weight, indep, K, N, yn.device)
+                d_aff, d_q, _ = engine.em_predict(
+                    yn, vec.expand(*indep, K, D, D).reshape(B, K, D, D).contiguous(),
+                    val.expand(*indep, K, D).reshape(B, K, D).contiguous(), w,
+                    activity=act, layout=_lib.LAYOUT_DT,
+                    affiliation_eps=affiliation_eps, want_q=True)
+                aff = _lib.to_host(d_aff).reshape(shape)
+                q = _lib.to_host(d_q).reshape(shape)
+                if aligner is not None:
+                    aff, q = apply_inline_permutation_alignment(
+                        affiliation=aff, quadratic_form=q,
+                        weight_constant_axis=weight_constant_axis, aligner=aligner)
+            weight = estimate_mixture_weight(
+                affiliation=aff, saliency=sal_host,
+                weight_constant_axis=weight_constant_axis)
+            masked = aff if sal_host is None else aff * sal_host[..., None, :]
+            vec, val, _, _ = engine.cacg_m_step(
+                yn, _lib.to_device(np.ascontiguousarray(masked).reshape(B, K, N)),
+                _lib.to_device(np.ascontiguousarray(q).reshape(B, K, N)),
+                layout=_lib.LAYOUT_DT, covariance_norm=covariance_norm,
+                eigenvalue_floor=eigenvalue_floor)
+            model = CACGMM(
+                weight=weight,
+                cacg=ComplexAngularCentralGaussian(
+                    covariance_eigenvectors=_lib.to_host(vec).reshape(*indep, K, D, D),
+                    covariance_eigenvalues=_lib.to_host(val).reshape(*indep, K, D)))
+        if like_torch:
+            model = CACGMM(
+                weight=_lib.to_device(model.weight),
+                cacg=ComplexAngularCentralGaussian(
+                    covariance_eigenvectors=_lib.to_device(
+                        model.cacg.covariance_eigenvectors),
+                    covariance_eigenvalues=_lib.to_device(
+                        model.cacg.covariance_eigenvalues)))
+        return model
+
+    def fit_predict(
+            self,
+            y,
+            initialization=None,
+            num_classes=None,
+            iterations=100,
+            *,
+            saliency=None,
+            source_activity_mask=None,
+            weight_constant_axis=(-1,),
+            hermitize=True,
+            covariance_norm='eigenvalue',
+            affiliation_eps=1e-10,
+            eigenvalue_floor=1e-10,
+            inline_permutation_aligner=None,
+    ):
+        """Fit a model, then return the posterior affiliations
+        (reference: cacgmm.py:282-313)."""
+        model = self.fit(
+            y=y, initialization=initialization, num_classes=num_classes,
+            iterations=iterations, saliency=saliency,
+            source_activity_mask=source_activity_mask,
+            weight_constant_axis=weight_constant_axis, hermitize=hermitize,
+            covariance_norm=covariance_norm, affiliation_eps=affiliation_eps,
+            eigenvalue_floor=eigenvalue_floor,
+            inline_permutation_aligner=inline_permutation_aligner)
+        return model.predict(y)

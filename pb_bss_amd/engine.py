@@ -1,0 +1,284 @@
+"""Thin device-tensor layer over the C ABI: every function takes/returns
+contiguous torch CUDA tensors with the independent axes flattened to one batch
+axis B, launches exactly the library call named in its docstring on the current
+torch stream, and raises the reference's exception types from status words.
+
+No arithmetic is done here beyond shape bookkeeping.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+
+def _t():
+    return _lib.torch()
+
+
+def _view_real(x):
+    """complex tensor -> same memory seen as interleaved real (for pointers)."""
+    return x
+
+
+def _status_raise_em(status, what):
+    """Mirror the reference's failure modes of the M-step."""
+    st = int(status.max().item()) if status.numel() else 0
+    if st == 0:
+        return
+    bits = int(np.bitwise_or.reduce(_lib.to_host(status).ravel()))
+    if bits & _lib.ST_NONFINITE:
+        # distribution/complex_angular_central_gaussian.py:127, :326, :333
+        raise AssertionError(
+            f'{what}: non-finite covariance / eigenvalues '
+            '(reference: assert np.isfinite(...))')
+    if bits & _lib.ST_EIG_NOCONV:
+        # complex_angular_central_gaussian.py:94-110 (LinAlgError from eigh/eig)
+        raise np.linalg.LinAlgError(f'{what}: Hermitian eigensolver did not converge')
+
+
+def normalize_observation(y):
+    """pbbss_normalize_observation: (B,T,D) complex -> (B,D,T), unit norm."""
+    t = _t()
+    B, T, D = y.shape
+    is128 = y.dtype == t.complex128
+    out = t.empty((B, D, T), dtype=y.dtype, device=y.device)
+    rc = _lib.load().pbbss_normalize_observation(
+        _lib.handle(y.device.index), _lib.ptr(y), int(is128), B, T, D,
+        _lib.ptr(out), _lib.stream_ptr(y.device.index))
+    _lib.check(rc, 'normalize_observation')
+    return out
+
+
+def em_fit(y, K, *, gamma0=None, model=None, iterations=100, saliency=None,
+           activity=None, covariance_norm='eigenvalue', weight_mode=0,
+           affiliation_eps=1e-10, eigenvalue_floor=1e-10, hermitize=True,
+           layout=_lib.LAYOUT_TD, final_predict=False, return_q=False,
+           force_eig=False, check_status=True):
+    """pbbss_cacgmm_fit.  y (B,T,D) [layout TD] or (B,D,T) [layout DT] complex.
+
+    gamma0 (B,K,T) f64, or model=(eigvec (B,K,D,D) c128, eigval (B,K,D), weight (B,K)).
+    Returns dict(eigvec, eigval, weight (B,K), status, affiliation?, quadratic_form?).
+    """
+    t = _t()
+    dev = y.device
+    if layout == _lib.LAYOUT_TD:
+        B, T, D = y.shape
+    else:
+        B, D, T = y.shape
+    is128 = y.dtype == t.complex128
+    assert y.dtype in (t.complex64, t.complex128), y.dtype
+    opts = _lib.EmOpts(
+        iterations=int(iterations),
+        covariance_norm=_lib.COVNORM[covariance_norm],
+        weight_mode=int(weight_mode), hermitize=int(bool(hermitize)),
+        layout=int(layout), y_is_c128=int(is128),
+        final_predict=int(bool(final_predict)), force_eig=int(bool(force_eig)),
+        affiliation_eps=float(affiliation_eps),
+        eigenvalue_floor=float(eigenvalue_floor))
+    f64 = t.float64
+    out_vec = t.empty((B, K, D, D), dtype=t.complex128, device=dev)
+    out_val = t.empty((B, K, D), dtype=f64, device=dev)
+    out_w = t.empty((B, K), dtype=f64, device=dev)
+    out_st = t.zeros((B, K), dtype=t.int32, device=dev)
+    out_aff = t.empty((B, K, T), dtype=f64, device=dev) if final_predict else None
+    out_q = t.empty((B, K, T), dtype=f64, device=dev) if (final_predict and return_q) else None
+    if model is not None:
+        in_vec, in_val, in_w = model
+        assert in_vec.shape == (B, K, D, D) and in_val.shape == (B, K, D) and in_w.shape == (B, K)
+    else:
+        in_vec = in_val = in_w = None
+        assert gamma0.shape == (B, K, T) and gamma0.dtype == f64, (gamma0.shape, gamma0.dtype)
+    if saliency is not None:
+        assert saliency.shape == (B, T) and saliency.dtype == f64
+    if activity is not None:
+        assert activity.shape == (B, K, T) and activity.dtype == t.uint8
+    rc = _lib.load().pbbss_cacgmm_fit(
+        _lib.handle(dev.index), _lib.ptr(y), B, T, D, K, _lib.ptr(gamma0),
+        _lib.ptr(in_vec), _lib.ptr(in_val), _lib.ptr(in_w), _lib.ptr(saliency),
+        _lib.ptr(activity), ctypes.byref(opts), _lib.ptr(out_vec),
+        _lib.ptr(out_val), _lib.ptr(out_w), _lib.ptr(out_st), _lib.ptr(out_aff),
+        _lib.ptr(out_q), _lib.stream_ptr(dev.index))
+    _lib.check(rc, f'cacgmm_fit(B={B},T={T},D={D},K={K})')
+    if check_status:
+        _status_raise_em(out_st, 'CACGMMTrainer.fit')
+    return dict(eigvec=out_vec, eigval=out_val, weight=out_w, status=out_st,
+                affiliation=out_aff, quadratic_form=out_q)
+
+
+def em_predict(y, eigvec, eigval, weight, *, activity=None,
+               layout=_lib.LAYOUT_TD, affiliation_eps=0.0,
+               want_q=False, want_log_pdf=False, want_affiliation=True):
+    """pbbss_cacgmm_predict.  weight is (B,K) or (B,K,T) f64."""
+    t = _t()
+    dev = y.device
+    if layout == _lib.LAYOUT_TD:
+        B, T, D = y.shape
+    else:
+        B, D, T = y.shape
+    K = eigvec.shape[1]
+    is128 = y.dtype == t.complex128
+    f64 = t.float64
+    if weight.dim() == 2:
+        wb, wk, wt = K, 1, 0
+    else:
+        assert weight.shape == (B, K, T), weight.shape
+        wb, wk, wt = K * T, T, 1
+    aff = t.empty((B, K, T), dtype=f64, device=dev) if want_affiliation else None
+    q = t.empty((B, K, T), dtype=f64, device=dev) if want_q else None
+    lp = t.empty((B, K, T), dtype=f64, device=dev) if want_log_pdf else None
+    rc = _lib.load().pbbss_cacgmm_predict(
+        _lib.handle(dev.index), _lib.ptr(y), B, T, D, K, _lib.ptr(eigvec),
+        _lib.ptr(eigval), _lib.ptr(weight), wb, wk, wt, _lib.ptr(activity),
+        int(layout), int(is128), float(affiliation_eps), _lib.ptr(aff),
+        _lib.ptr(q), _lib.ptr(lp), _lib.stream_ptr(dev.index))
+    _lib.check(rc, f'cacgmm_predict(B={B},T={T},D={D},K={K})')
+    return aff, q, lp
+
+
+def cacg_m_step(y, saliency, quadratic_form, *, layout=_lib.LAYOUT_DT,
+                covariance_norm='eigenvalue', eigenvalue_floor=1e-10,
+                want_cov=False, check_status=True):
+    """pbbss_cacg_m_step: saliency/quadratic_form (B,K,T) f64."""
+    t = _t()
+    dev = y.device
+    if layout == _lib.LAYOUT_TD:
+        B, T, D = y.shape
+    else:
+        B, D, T = y.shape
+    K = saliency.shape[1]
+    is128 = y.dtype == t.complex128
+    out_vec = t.empty((B, K, D, D), dtype=t.complex128, device=dev)
+    out_val = t.empty((B, K, D), dtype=t.float64, device=dev)
+    out_st = t.zeros((B, K), dtype=t.int32, device=dev)
+    out_cov = t.empty((B, K, D, D), dtype=t.complex128, device=dev) if want_cov else None
+    rc = _lib.load().pbbss_cacg_m_step(
+        _lib.handle(dev.index), _lib.ptr(y), B, T, D, K, _lib.ptr(saliency),
+        _lib.ptr(quadratic_form), int(layout), int(is128),
+        _lib.COVNORM[covariance_norm], float(eigenvalue_floor),
+        _lib.ptr(out_vec), _lib.ptr(out_val), _lib.ptr(out_cov),
+        _lib.ptr(out_st), _lib.stream_ptr(dev.index))
+    _lib.check(rc, f'cacg_m_step(B={B},T={T},D={D},K={K})')
+    if check_status:
+        _status_raise_em(out_st, 'ComplexAngularCentralGaussianTrainer._fit')
+    return out_vec, out_val, out_cov, out_st
+
+
+def heev(a):
+    """pbbss_heev_batched: a (N,D,D) c128 -> (eigval (N,D), eigvec (N,D,D), status)."""
+    t = _t()
+    N, D, _ = a.shape
+    val = t.empty((N, D), dtype=t.float64, device=a.device)
+    vec = t.empty((N, D, D), dtype=t.complex128, device=a.device)
+    st = t.zeros((N,), dtype=t.int32, device=a.device)
+    rc = _lib.load().pbbss_heev_batched(
+        _lib.handle(a.device.index), _lib.ptr(a), N, D, _lib.ptr(val),
+        _lib.ptr(vec), _lib.ptr(st), _lib.stream_ptr(a.device.index))
+    _lib.check(rc, f'heev(N={N},D={D})')
+    return val, vec, st
+
+
+def psd(x, mask, normalize=True):
+    """pbbss_psd: x (B,D,T) complex, mask (B,K,T) f64 or None -> (B,K,D,D) c128."""
+    t = _t()
+    B, D, T = x.shape
+    K = 1 if mask is None else mask.shape[1]
+    out = t.empty((B, K, D, D), dtype=t.complex128, device=x.device)
+    rc = _lib.load().pbbss_psd(
+        _lib.handle(x.device.index), _lib.ptr(x), int(x.dtype == t.complex128),
+        B, T, D, K, _lib.ptr(mask), int(bool(normalize)), _lib.ptr(out),
+        _lib.stream_ptr(x.device.index))
+    _lib.check(rc, f'psd(B={B},T={T},D={D},K={K})')
+    return out
+
+
+def gev(target, noise):
+    """pbbss_gev: (N,D,D) c128 x2 -> (w (N,D) c128, status (N,))."""
+    t = _t()
+    N, D, _ = target.shape
+    w = t.empty((N, D), dtype=t.complex128, device=target.device)
+    st = t.zeros((N,), dtype=t.int32, device=target.device)
+    rc = _lib.load().pbbss_gev(
+        _lib.handle(target.device.index), _lib.ptr(target), _lib.ptr(noise), N,
+        D, _lib.ptr(w), _lib.ptr(st), _lib.stream_ptr(target.device.index))
+    _lib.check(rc, f'gev(N={N},D={D})')
+    return w, st
+
+
+def solve(A, Bm):
+    """pbbss_solve: A (N,D,D), Bm (N,D,M) c128 -> (X, status)."""
+    t = _t()
+    N, D, _ = A.shape
+    M = Bm.shape[-1]
+    x = t.empty((N, D, M), dtype=t.complex128, device=A.device)
+    st = t.zeros((N,), dtype=t.int32, device=A.device)
+    rc = _lib.load().pbbss_solve(
+        _lib.handle(A.device.index), _lib.ptr(A), _lib.ptr(Bm), N, D, M,
+        _lib.ptr(x), _lib.ptr(st), _lib.stream_ptr(A.device.index))
+    _lib.check(rc, f'solve(N={N},D={D},M={M})')
+    return x, st
+
+
+def mvdr_souden(target, noise, eps):
+    """pbbss_mvdr_souden -> (mat (N,D,D), snr_num (N,D), snr_den (N,D), status)."""
+    t = _t()
+    N, D, _ = target.shape
+    mat = t.empty((N, D, D), dtype=t.complex128, device=target.device)
+    num = t.empty((N, D), dtype=t.complex128, device=target.device)
+    den = t.empty((N, D), dtype=t.complex128, device=target.device)
+    st = t.zeros((N,), dtype=t.int32, device=target.device)
+    rc = _lib.load().pbbss_mvdr_souden(
+        _lib.handle(target.device.index), _lib.ptr(target), _lib.ptr(noise), N,
+        D, float(eps), _lib.ptr(mat), _lib.ptr(num), _lib.ptr(den), _lib.ptr(st),
+        _lib.stream_ptr(target.device.index))
+    _lib.check(rc, f'mvdr_souden(N={N},D={D})')
+    return mat, num, den, st
+
+
+def mvdr(atf, noise):
+    """pbbss_mvdr: atf (N,D), noise (N,D,D) c128 -> (w (N,D), status)."""
+    t = _t()
+    N, D = atf.shape
+    w = t.empty((N, D), dtype=t.complex128, device=atf.device)
+    st = t.zeros((N,), dtype=t.int32, device=atf.device)
+    rc = _lib.load().pbbss_mvdr(
+        _lib.handle(atf.device.index), _lib.ptr(atf), _lib.ptr(noise), N, D,
+        _lib.ptr(w), _lib.ptr(st), _lib.stream_ptr(atf.device.index))
+    _lib.check(rc, f'mvdr(N={N},D={D})')
+    return w, st
+
+
+def ban(w, noise):
+    """pbbss_ban: w (N,D), noise (N,D,D) c128 -> (N,D) c128."""
+    t = _t()
+    N, D = w.shape
+    out = t.empty((N, D), dtype=t.complex128, device=w.device)
+    rc = _lib.load().pbbss_ban(
+        _lib.handle(w.device.index), _lib.ptr(w), _lib.ptr(noise), N, D,
+        _lib.ptr(out), _lib.stream_ptr(w.device.index))
+    _lib.check(rc, f'ban(N={N},D={D})')
+    return out
+
+
+def apply_bf(w, x):
+    """pbbss_apply_beamforming_vector: w (B,D) c128, x (B,D,T) -> (B,T) c128."""
+    t = _t()
+    B, D, T = x.shape
+    out = t.empty((B, T), dtype=t.complex128, device=x.device)
+    rc = _lib.load().pbbss_apply_beamforming_vector(
+        _lib.handle(x.device.index), _lib.ptr(w), _lib.ptr(x),
+        int(x.dtype == t.complex128), B, T, D, _lib.ptr(out),
+        _lib.stream_ptr(x.device.index))
+    _lib.check(rc, f'apply_beamforming_vector(B={B},T={T},D={D})')
+    return out
+
+
+def set_timing(enable, device_index=None):
+    _lib.check(_lib.load().pbbss_set_timing(_lib.handle(device_index), int(enable)), 'set_timing')
+
+
+def last_kernel_ms(device_index=None):
+    ms = ctypes.c_float()
+    _lib.check(_lib.load().pbbss_last_kernel_ms(_lib.handle(device_index), ctypes.byref(ms)),
+               'last_kernel_ms')
+    return float(ms.value)

@@ -1,0 +1,21 @@
+"""Drop-in for the hot-path part of pb_bss.extraction
+(reference: pb_bss/extraction/__init__.py)."""
+from .beamformer import (
+    apply_beamforming_vector,
+    blind_analytic_normalization,
+    get_gev_vector,
+    get_mvdr_vector,
+    get_mvdr_vector_souden,
+    get_optimal_reference_channel,
+    get_pca_vector,
+    get_power_spectral_density_matrix,
+    stable_solve,
+)
+from .beamformer_wrapper import get_bf_vector
+
+__all__ = [
+    'get_power_spectral_density_matrix', 'get_mvdr_vector_souden',
+    'get_mvdr_vector', 'get_pca_vector', 'get_gev_vector',
+    'blind_analytic_normalization', 'apply_beamforming_vector',
+    'get_optimal_reference_channel', 'stable_solve', 'get_bf_vector',
+]

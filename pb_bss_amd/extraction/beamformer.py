@@ -1,0 +1,247 @@
+"""Mask-based beamformer extraction on the device.
+
+Mirrors pb_bss/extraction/beamformer.py (and pb_bss/math/solve.py for
+`stable_solve`): same function names, argument meaning, shape conventions
+(time last: X (..., D, T), mask (..., K, T), PSD (..., K, D, D)) and error
+behaviour.  Bodies call the HIP library; NumPy in -> NumPy out, torch CUDA in
+-> torch CUDA out.  Results are complex128 (float64 arithmetic on the device).
+"""
+import numpy as np
+
+from .. import _lib, engine
+
+__all__ = [
+    'get_power_spectral_density_matrix', 'get_mvdr_vector_souden',
+    'get_mvdr_vector', 'get_pca_vector', 'get_gev_vector',
+    'blind_analytic_normalization', 'apply_beamforming_vector',
+    'get_optimal_reference_channel', 'stable_solve',
+]
+
+
+def _res(x, like_torch):
+    return x if like_torch else _lib.to_host(x)
+
+
+def _c128(x):
+    t = _lib.torch()
+    return _lib.to_device(np.asarray(x) if not _lib.is_torch(x) else x, t.complex128)
+
+
+def _obs(x):
+    t = _lib.torch()
+    x = _lib.to_device(x)
+    if x.dtype not in (t.complex64, t.complex128):
+        x = x.to(t.complex128)
+    return x
+
+
+def get_power_spectral_density_matrix(observation, mask=None, sensor_dim=-2,
+                                      source_dim=-2, time_dim=-1, normalize=True):
+    """Weighted PSD (covariance) matrices.  Reference: beamformer.py:59-160.
+
+    observation (..., sensors, frames) complex; mask (bins, frames) /
+    (..., frames) or (..., sources, frames); the *_dim arguments permute axes as
+    in the reference.  Returns (..., sensors, sensors), (..., sources, sensors,
+    sensors) or (sources, ..., sensors, sensors) for source_dim < -2.
+    """
+    like_torch = _lib.is_torch(observation)
+    t = _lib.torch()
+    x = _obs(observation)
+    nd = x.ndim
+    sensor_dim, source_dim, time_dim = (d % nd - nd for d in (sensor_dim, source_dim, time_dim))
+    perm = [i for i in range(-nd, 0) if i not in (sensor_dim, time_dim)] + [sensor_dim, time_dim]
+    x = x.permute(*[p % nd for p in perm])
+    *lead, D, T = x.shape
+    xb = x.reshape(-1, D, T).contiguous()
+    if mask is None:
+        out = engine.psd(xb, None)
+        return _res(out.reshape(*lead, D, D), like_torch)
+    m = _lib.to_device(mask)
+    m = m.to(t.float64)  # bool / float32 masks are widened (reference :124-125)
+    if m.ndim + 1 == nd:
+        mb = m.expand(*lead, T).reshape(-1, 1, T).contiguous()
+        out = engine.psd(xb, mb, normalize=normalize)
+        return _res(out.reshape(*lead, D, D), like_torch)
+    mperm = [i for i in range(-nd, 0) if i not in (source_dim, time_dim)] + [source_dim, time_dim]
+    m = m.permute(*[p % nd for p in mperm])
+    K = m.shape[-2]
+    mb = m.expand(*lead, K, T).reshape(-1, K, T).contiguous()
+    out = engine.psd(xb, mb, normalize=normalize).reshape(*lead, K, D, D)
+    if source_dim < -2:
+        # PSD shape (sources, ..., sensors, sensors) as the reference (:155-158)
+        out = out.movedim(-3, source_dim % nd)
+    return _res(out, like_torch)
+
+
+def get_pca_vector(target_psd_matrix, scaling=None):
+    """Principal eigenvector of the target PSD.  Reference: beamformer.py:163-224."""
+    like_torch = _lib.is_torch(target_psd_matrix)
+    t = _lib.torch()
+    a = _c128(target_psd_matrix)
+    *lead, D, _ = a.shape
+    val, vec, st = engine.heev(a.reshape(-1, D, D).contiguous())
+    if int(st.max().item()) != 0:
+        raise np.linalg.LinAlgError('Eigenvalues did not converge')
+    w = vec[:, :, -1].reshape(*lead, D)
+    lam = val[:, -1].reshape(*lead)
+    if scaling is None:
+        pass
+    elif scaling == 'trace':
+        tr = t.einsum('...dd', a)
+        w = w * (t.sqrt(tr) / t.linalg.vector_norm(w, dim=-1))[..., None]
+    elif scaling == 'eigenvalue':
+        w = w * (lam / t.linalg.vector_norm(w, dim=-1))[..., None]
+    else:
+        raise ValueError
+    return _res(w, like_torch)
+
+
+def stable_solve(A, B):
+    """Batched A X = B with a minimum-norm least-squares answer for exactly
+    singular matrices.  Reference: math/solve.py:20-114 (np.linalg.solve with
+    per-matrix lstsq fallback); both branches run on the device."""
+    like_torch = _lib.is_torch(A)
+    a = _c128(A)
+    b = _c128(B)
+    assert a.shape[:-2] == b.shape[:-2], (a.shape, b.shape)
+    assert a.shape[-1] == b.shape[-2], (a.shape, b.shape)
+    D, M = b.shape[-2:]
+    x, _ = engine.solve(a.reshape(-1, D, D).contiguous(), b.reshape(-1, D, M).contiguous())
+    return _res(x.reshape(b.shape), like_torch)
+
+
+def get_mvdr_vector(atf_vector, noise_psd_matrix):
+    """w = Phi_nn^-1 h / (h^H Phi_nn^-1 h).  Reference: beamformer.py:230-260.
+    atf_vector (..., bins, sensors); noise_psd_matrix (bins, sensors, sensors)."""
+    assert noise_psd_matrix is not None
+    like_torch = _lib.is_torch(atf_vector)
+    h = _c128(atf_vector)
+    n = _c128(noise_psd_matrix)
+    while h.ndim > n.ndim - 1:
+        n = n[None]
+    n = n.expand(*h.shape[:-1], *n.shape[-2:])
+    D = h.shape[-1]
+    w, _ = engine.mvdr(h.reshape(-1, D).contiguous(), n.reshape(-1, D, D).contiguous())
+    return _res(w.reshape(h.shape), like_torch)
+
+
+def get_gev_vector(target_psd_matrix, noise_psd_matrix, force_cython=False,
+                   use_eig=False):
+    """Principal generalised eigenvector of (target, noise), normalised like
+    LAPACK zhegvd (w^H Phi_nn w = 1).  Reference: beamformer.py:292-364 and
+    cythonized/get_gev_vector.pyx:42-150.
+
+    `force_cython` / `use_eig` are accepted for signature compatibility: there
+    is one native solver here (Cholesky reduction + Jacobi, Hermitian-definite).
+    A noise PSD that is not positive definite raises ValueError under
+    force_cython (the .pyx message) and numpy.linalg.LinAlgError otherwise
+    (what the reference's SciPy fallback, :395-410, ends with).
+    """
+    assert noise_psd_matrix is not None
+    like_torch = _lib.is_torch(target_psd_matrix)
+    a = _c128(target_psd_matrix)
+    b = _c128(noise_psd_matrix)
+    D = a.shape[-1]
+    assert D == a.shape[-2], a.shape
+    assert a.shape == b.shape, (a.shape, b.shape)
+    w, st = engine.gev(a.reshape(-1, D, D).contiguous(), b.reshape(-1, D, D).contiguous())
+    bad = (st != 0).nonzero()
+    if bad.numel():
+        f = int(bad[0].item())
+        code = int(st[f].item())
+        if code & _lib.ST_NOT_POSDEF:
+            msg = (f'the leading minor of order {code >> 8} of B is not positive '
+                   'definite. The factorization of B could not be completed and '
+                   f'no eigenvalues or eigenvectors were computed for frequency {f}')
+        else:
+            msg = f'Algorithm failed to compute an eigenvalue for frequency {f}'
+        if force_cython:
+            raise ValueError(msg)
+        raise np.linalg.LinAlgError(f'Error for frequency {f}\n{msg}')
+    return _res(w.reshape(a.shape[:-1]), like_torch)
+
+
+def blind_analytic_normalization(vector, noise_psd_matrix):
+    """BAN post-filter.  Reference: beamformer.py:459-488."""
+    like_torch = _lib.is_torch(vector)
+    w = _c128(vector)
+    n = _c128(noise_psd_matrix)
+    D = w.shape[-1]
+    lead = np.broadcast_shapes(tuple(w.shape[:-1]), tuple(n.shape[:-2]))
+    wb = w.expand(*lead, D).reshape(-1, D).contiguous()
+    nb = n.expand(*lead, D, D).reshape(-1, D, D).contiguous()
+    out = engine.ban(wb, nb)
+    return _res(out.reshape(*lead, D), like_torch)
+
+
+def apply_beamforming_vector(vector, mix):
+    """s[..., t] = sum_d conj(w[..., d]) x[..., d, t].  Reference: beamformer.py:572-583."""
+    like_torch = _lib.is_torch(mix)
+    w = _c128(vector)
+    x = _obs(mix)
+    assert w.shape[-1] < 30, (w.shape, x.shape)
+    D, T = x.shape[-2:]
+    lead = np.broadcast_shapes(tuple(w.shape[:-1]), tuple(x.shape[:-2]))
+    wb = w.expand(*lead, D).reshape(-1, D).contiguous()
+    xb = x.expand(*lead, D, T).reshape(-1, D, T).contiguous()
+    out = engine.apply_bf(wb, xb)
+    return _res(out.reshape(*lead, T), like_torch)
+
+
+def _select_reference_channel(num, den, eps):
+    """argmax_r sum_f num[f, r] / max(sum_f den[f, r], eps) with NumPy's complex
+    ordering in the maximum (reference :616-624).  num/den: host (F, D)."""
+    snr = num.sum(axis=0) / np.maximum(den.sum(axis=0), eps)
+    assert np.all(np.isfinite(snr)), snr
+    return int(np.argmax(snr.real))
+
+
+def get_optimal_reference_channel(w_mat, target_psd_matrix, noise_psd_matrix, eps=None):
+    """Reference channel maximising the post-filter SNR summed over ALL
+    frequencies.  Reference: beamformer.py:601-624."""
+    t = _lib.torch()
+    w = _c128(w_mat)
+    if w.ndim != 3:
+        raise ValueError(
+            'Estimating the ref_channel expects currently that the input '
+            'has 3 ndims (frequency x sensors x sensors). '
+            'Considering an independent dim in the SNR estimate is not '
+            'unique.')
+    if eps is None:
+        eps = np.finfo(np.float64).tiny
+    tp = _c128(target_psd_matrix)
+    nn = _c128(noise_psd_matrix)
+    num = t.einsum('fdr,fde,fer->fr', w.conj(), tp, w)
+    den = t.einsum('fdr,fde,fer->fr', w.conj(), nn, w)
+    return _select_reference_channel(_lib.to_host(num), _lib.to_host(den), eps)
+
+
+def get_mvdr_vector_souden(target_psd_matrix, noise_psd_matrix, ref_channel=None,
+                           eps=None, return_ref_channel=False):
+    """MVDR beamformer in the Souden formulation.  Reference:
+    beamformer.py:627-698.  (..., bins, sensors, sensors) -> (..., bins, sensors).
+    The automatic reference channel needs exactly 3 dims (bins first) because
+    its SNR estimate sums over all frequencies."""
+    assert noise_psd_matrix is not None
+    like_torch = _lib.is_torch(target_psd_matrix)
+    tp = _c128(target_psd_matrix)
+    nn = _c128(noise_psd_matrix)
+    D = tp.shape[-1]
+    if eps is None:
+        eps = np.finfo(np.float64).tiny
+    mat, num, den, _ = engine.mvdr_souden(
+        tp.reshape(-1, D, D).contiguous(),
+        nn.expand(tp.shape).reshape(-1, D, D).contiguous(), eps)
+    if ref_channel is None:
+        if tp.ndim != 3:
+            raise ValueError(
+                'Estimating the ref_channel expects currently that the input '
+                'has 3 ndims (frequency x sensors x sensors). '
+                'Considering an independent dim in the SNR estimate is not '
+                'unique.')
+        ref_channel = _select_reference_channel(_lib.to_host(num), _lib.to_host(den), eps)
+    assert np.isscalar(ref_channel), ref_channel
+    w = mat.reshape(*tp.shape)[..., ref_channel]
+    if return_ref_channel:
+        return _res(w, like_torch), ref_channel
+    return _res(w, like_torch)

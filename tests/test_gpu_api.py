@@ -1,0 +1,257 @@
+"""GPU: behaviour tests of the drop-in API, modelled on the reference's own
+test-suite (tests/test_distribution/test_cacgmm.py, tests/test_extraction/*)."""
+import itertools
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _sample_cacg(rng, size, covariance):
+    """Unit-norm samples of a complex Gaussian (what sample_cacgmm draws,
+    distribution/cacgmm.py:27-55)."""
+    D = covariance.shape[-1]
+    L = np.linalg.cholesky(covariance)
+    z = (rng.standard_normal((size, D)) + 1j * rng.standard_normal((size, D))) / np.sqrt(2)
+    x = z @ L.T
+    return x / np.linalg.norm(x, axis=-1, keepdims=True)
+
+
+def _sample_cacgmm(rng, size, weight, covariance):
+    labels = rng.choice(len(weight), size=size, p=weight)
+    x = np.zeros((size, covariance.shape[-1]), np.complex128)
+    for k in range(len(weight)):
+        x[labels == k] = _sample_cacg(rng, int((labels == k).sum()), covariance[k])
+    return x
+
+
+def _best_perm(a, b):
+    return min(itertools.permutations(range(len(a))),
+               key=lambda p: np.abs(a[list(p)] - b).sum())
+
+
+def test_cacgmm_recovers_parameters():
+    """tests/test_distribution/test_cacgmm.py:25-53: 10000 samples, D=3, K=2,
+    covariance atol 0.1, weights atol 0.15."""
+    from pb_bss_amd.distribution import CACGMMTrainer
+    rng = np.random.default_rng(0)
+    np.random.seed(0)
+    D = 3
+    cov1 = np.array([[10, 1 + 1j, 1 + 1j], [1 - 1j, 5, 1], [1 - 1j, 1, 2]], np.complex128)
+    cov2 = np.array([[2, 0, 0], [0, 3, 0], [0, 0, 2]], np.complex128)
+    cov1 /= np.trace(cov1)
+    cov2 /= np.trace(cov2)
+    cov = np.stack([cov1, cov2])
+    weight = np.array([0.3, 0.7])
+    x = _sample_cacgmm(rng, 10000, weight, cov)
+    model = CACGMMTrainer().fit(x, num_classes=2, covariance_norm='trace')
+    perm = list(_best_perm(model.cacg.covariance, cov))
+    assert np.allclose(model.cacg.covariance[perm], cov, atol=0.1)
+    assert np.allclose(model.weight[perm, 0], weight, atol=0.15)
+    assert model.weight.shape == (2, 1)
+    assert model.cacg.covariance_eigenvectors.shape == (2, 3, 3)
+    assert model.predict(x).shape == (2, 10000)
+
+
+def test_independent_dims_and_init_shapes():
+    """tests/test_distribution/test_cacgmm.py:71-163: independent axes and
+    broadcastable initialisations."""
+    from pb_bss_amd.distribution import CACGMMTrainer
+    from oracle import cacgmm as oc
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((3, 200, 4)) + 1j * rng.standard_normal((3, 200, 4))
+    init = rng.uniform(size=(1, 2, 200))
+    init /= init.sum(-2, keepdims=True)
+    m = CACGMMTrainer().fit(x, initialization=init, iterations=3)
+    assert m.weight.shape == (3, 2, 1)
+    ref = oc.em_fit(x, np.broadcast_to(init, (3, 2, 200)), iterations=3)
+    assert np.abs(m.weight - ref['weight']).max() < 1e-10
+    with pytest.raises(AssertionError):
+        CACGMMTrainer().fit(x, initialization=init[0], iterations=1)  # wrong ndim
+    with pytest.raises(AssertionError):
+        CACGMMTrainer().fit(x, iterations=1)  # neither init nor num_classes
+    with pytest.raises(AssertionError):
+        CACGMMTrainer().fit(x.real, num_classes=2, iterations=1)  # not complex
+    np.random.seed(3)
+    m1 = CACGMMTrainer().fit(x, num_classes=3, iterations=2)
+    np.random.seed(3)
+    m2 = CACGMMTrainer().fit(x, num_classes=3, iterations=2)
+    assert (m1.weight == m2.weight).all(), 'same global-RNG initialisation as the reference'
+    assert m1.weight.shape == (3, 3, 1)
+
+
+def test_resume_and_fit_predict_and_torch_io():
+    import torch
+    from pb_bss_amd.distribution import CACGMM, CACGMMTrainer
+    from oracle import synth
+    Y, init = synth.make_stft(6, 100, 4, 2, seed=4)
+    a = CACGMMTrainer().fit(Y, initialization=init, iterations=5)
+    b = CACGMMTrainer().fit(Y, initialization=init, iterations=3)
+    b = CACGMMTrainer().fit(Y, initialization=b, iterations=2)
+    assert isinstance(b, CACGMM)
+    assert np.abs(a.predict(Y) - b.predict(Y)).max() < 1e-9
+    fp = CACGMMTrainer().fit_predict(Y, initialization=init, iterations=5)
+    assert np.abs(fp - a.predict(Y)).max() < 1e-12
+    yt = torch.from_numpy(Y).cuda()
+    mt = CACGMMTrainer().fit(yt, initialization=torch.from_numpy(init).cuda(), iterations=5)
+    assert mt.weight.is_cuda and mt.cacg.covariance_eigenvectors.is_cuda
+    pt = mt.predict(yt)
+    assert pt.is_cuda and np.abs(pt.cpu().numpy() - a.predict(Y)).max() < 1e-12
+
+
+def test_stepwise_path_equals_fused_path():
+    """weight_constant_axis=(-1,) through the per-iteration E/M entry points
+    (forced with a no-op aligner-free stepwise call) equals the fused kernel."""
+    from pb_bss_amd.distribution import CACGMMTrainer
+    from pb_bss_amd.distribution.cacgmm import CACGMMTrainer as T
+    from pb_bss_amd import _lib
+    from oracle import synth
+    Y, init = synth.make_stft(5, 80, 4, 3, seed=8)
+    a = CACGMMTrainer().fit(Y, initialization=init, iterations=4)
+    t = _lib.torch()
+    yb = _lib.to_device(Y)
+    b = T()._fit_stepwise(yb, (5,), 3, _lib.to_device(init), None, 4, None, None, None,
+                          (-1,), 'eigenvalue', 1e-10, 1e-10, True, None, False)
+    assert np.abs(a.weight - b.weight).max() < 1e-10
+    assert np.abs(a.cacg.covariance - b.cacg.covariance).max() < 1e-9
+
+
+def test_inline_permutation_aligner_hook():
+    from pb_bss_amd.distribution import CACGMMTrainer
+    from oracle import synth
+
+    class Swap:  # swaps classes 0/1 in every second frequency
+        def calculate_mapping(self, mask):
+            K, F, T = mask.shape
+            m = np.tile(np.arange(K)[:, None], (1, F))
+            m[:2, 1::2] = m[:2, 1::2][::-1]
+            return m
+
+        @staticmethod
+        def apply_mapping(mask, mapping):
+            return mask[mapping, range(mapping.shape[1])]
+
+    Y, init = synth.make_stft(4, 60, 3, 2, seed=2)
+    m = CACGMMTrainer().fit(Y, initialization=init, iterations=3,
+                            weight_constant_axis=(-3,), inline_permutation_aligner=Swap())
+    assert m.weight.shape == (1, 2, 60)
+    assert np.isfinite(m.cacg.covariance).all()
+
+
+def test_unsupported_shapes_fail_loudly():
+    from pb_bss_amd.distribution import CACGMMTrainer
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((2, 50, 9)) + 1j * rng.standard_normal((2, 50, 9))
+    with pytest.raises(NotImplementedError):
+        CACGMMTrainer().fit(x, num_classes=2, iterations=1)  # D = 9 > 8
+    x = rng.standard_normal((2, 50, 4)) + 1j * rng.standard_normal((2, 50, 4))
+    with pytest.raises(NotImplementedError):
+        CACGMMTrainer().fit(x, num_classes=5, iterations=1)  # K = 5 > 4
+
+
+# ------------------------------------------------------------------ extraction
+def _psd(rng, shape):
+    D = shape[-1]
+    x = rng.standard_normal((*shape[:-2], D, D + 3)) + 1j * rng.standard_normal((*shape[:-2], D, D + 3))
+    return x @ x.conj().swapaxes(-1, -2) + 2 * D * np.eye(D)
+
+
+@pytest.mark.parametrize('shape', [(51, 6, 6), (1, 6, 6), (2, 51, 6, 6)])
+def test_beamformer_dimensions(shape):
+    """tests/test_extraction/test_beamformer.py:25-118: three shape regimes."""
+    from pb_bss_amd import extraction as ex
+    rng = np.random.default_rng(0)
+    t, n = _psd(rng, shape), _psd(rng, shape)
+    assert ex.get_gev_vector(t, n).shape == shape[:-1]
+    assert ex.get_pca_vector(t).shape == shape[:-1]
+    assert ex.get_mvdr_vector_souden(t, n, ref_channel=0).shape == shape[:-1]
+    if len(shape) == 3:
+        assert ex.get_mvdr_vector_souden(t, n).shape == shape[:-1]
+    else:
+        with pytest.raises(ValueError):
+            ex.get_mvdr_vector_souden(t, n)
+    w = ex.get_gev_vector(t, n)
+    assert ex.blind_analytic_normalization(w, n).shape == shape[:-1]
+    x = rng.standard_normal((*shape[:-2], 6, 40)) + 0j
+    assert ex.apply_beamforming_vector(w, x).shape == (*shape[:-2], 40)
+    assert ex.get_mvdr_vector(w, n).shape == shape[:-1]
+
+
+def test_gev_equals_pca_for_identity_noise_and_wrapper_equivalences():
+    """test_beamformer.py:98-104 and test_beamformer_wrapper.py:39-91."""
+    from pb_bss_amd import extraction as ex
+    rng = np.random.default_rng(1)
+    t = _psd(rng, (33, 6, 6))
+    n = _psd(rng, (33, 6, 6))
+    eye = np.broadcast_to(np.eye(6), t.shape)
+
+    def cos(a, b):
+        return np.abs(np.einsum('...d,...d', a.conj(), b)) / np.linalg.norm(a, axis=-1) / np.linalg.norm(b, axis=-1)
+
+    assert np.abs(cos(ex.get_gev_vector(t, eye), ex.get_pca_vector(t)) - 1).max() < 1e-6
+    for name in ['pca', 'pca+mvdr', 'scaled_gev_atf+mvdr', 'mvdr_souden', 'gev',
+                 'rank1_pca+mvdr_souden', 'rank1_gev+mvdr_souden', 'rank1_pca+gev',
+                 'rank1_gev+gev', 'gev+ban', 'mvdr_souden+ban', 'ch0']:
+        assert ex.get_bf_vector(name, t, n).shape == (33, 6), name
+    assert np.abs(cos(ex.get_bf_vector('rank1_gev+gev', t, n), ex.get_bf_vector('gev', t, n)) - 1).max() < 1e-6
+    with pytest.raises(ValueError):
+        ex.get_bf_vector('nonsense', t, n)
+    with pytest.raises(AssertionError):
+        ex.get_bf_vector('lcmv', t, n)
+
+
+def test_gev_not_positive_definite_raises():
+    from pb_bss_amd import extraction as ex
+    rng = np.random.default_rng(2)
+    t = _psd(rng, (5, 4, 4))
+    n = _psd(rng, (5, 4, 4))
+    n[3] = -n[3]
+    with pytest.raises(np.linalg.LinAlgError):
+        ex.get_gev_vector(t, n)
+    with pytest.raises(ValueError, match='not positive'):
+        ex.get_gev_vector(t, n, force_cython=True)
+
+
+def test_mvdr_souden_difficulties():
+    """tests/test_extraction/test_beamformer.py:211-376: zero / inf inputs."""
+    from pb_bss_amd.extraction import get_mvdr_vector_souden
+    obs = np.array([[0, 0, 1], [0, 0.1, 1], [0.1, 0, 1]])
+    pxx = obs.T.conj() @ obs
+    pnn = np.eye(3)
+    well, = get_mvdr_vector_souden(pxx[None], pnn[None])
+    w3 = get_mvdr_vector_souden([pxx] * 3, [pnn] * 3)
+    assert np.allclose([well] * 3, w3)
+    for a, b in [(pxx[None] * 0, pnn[None]), (pxx[None], pnn[None] * 0),
+                 (pxx[None] * 0, pnn[None] * 0)]:
+        w = get_mvdr_vector_souden(a, b)
+        assert (w == 0).all(), w
+        with pytest.raises(AssertionError):
+            get_mvdr_vector_souden(a, b, eps=0)
+    with np.errstate(all='ignore'):
+        for a, b in [(pxx[None] * np.inf, pnn[None]), (pxx[None], pnn[None] * np.inf)]:
+            with pytest.raises(AssertionError):
+                get_mvdr_vector_souden(a, b)
+    for a, b in [([pxx * 0, pxx], [pnn, pnn]), ([pxx, pxx], [pnn * 0, pnn]),
+                 ([pxx * 0, pxx], [pnn * 0, pnn])]:
+        w, ref = get_mvdr_vector_souden(a, b, return_ref_channel=True)
+        assert ref == 2
+        assert np.allclose(w, np.array([[0., 0., 0.], well]))
+
+
+def test_psd_properties():
+    """tests/test_extraction/test_covariance_matrix.py:31-155."""
+    from pb_bss_amd.extraction import get_power_spectral_density_matrix as psd
+    rng = np.random.default_rng(3)
+    F, T, D, K = 21, 57, 5, 2
+    X = rng.standard_normal((F, D, T)) + 1j * rng.standard_normal((F, D, T))
+    mask = rng.uniform(size=(F, K, T))
+    p = psd(X, mask)
+    assert p.shape == (F, K, D, D)
+    assert np.abs(p - p.conj().swapaxes(-1, -2)).max() < 1e-14  # Hermitian
+    assert (np.linalg.eigvalsh(p) > -1e-12).all()                # PSD
+    assert np.abs(psd(X, 7.5 * mask) - p).max() < 1e-13          # mask scale invariance
+    assert np.abs(psd(X, mask > 0.5) - psd(X, (mask > 0.5).astype(float))).max() == 0  # bool mask
+    assert psd(X.transpose(0, 2, 1), mask, sensor_dim=-1, time_dim=-2).shape == (F, K, D, D)
+    assert np.abs(psd(X.transpose(0, 2, 1), mask.transpose(0, 2, 1), sensor_dim=-1,
+                      source_dim=-1, time_dim=-2) - p).max() < 1e-14

@@ -1,0 +1,207 @@
+"""GPU parity of the persistent cACGMM EM kernel against the NumPy oracle
+(oracle/cacgmm.py, itself pinned to the reference by tests/golden).
+
+Protocol: the device gets the complex64 observation and a
+float64 initialisation; the oracle gets the exact complex128 upcast of the same
+values, so both sides compute in float64 on identical inputs.
+Tolerances: single step 1e-9, trajectories 1e-5 (BASELINE.json north_star)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(x, dtype=None):
+    from pb_bss_amd import _lib
+    return _lib.to_device(x, dtype)
+
+
+def _host(x):
+    from pb_bss_amd import _lib
+    return _lib.to_host(x)
+
+
+def _oracle_fit(Y, init, iterations, **kw):
+    from oracle import cacgmm as oc
+    Y128 = Y.astype(np.complex128)
+    m = oc.em_fit(Y128, init, iterations=iterations, **kw)
+    return m, oc.em_predict(m, Y128)
+
+
+def _device_fit(Y, init, iterations, **kw):
+    from pb_bss_amd import engine
+    K = init.shape[-2]
+    return engine.em_fit(_dev(Y), K, gamma0=_dev(init), iterations=iterations,
+                         final_predict=True, return_q=True, **kw)
+
+
+def _cov(vec, val):
+    return np.einsum('...wx,...x,...zx->...wz', vec, val, vec.conj())
+
+
+@pytest.mark.parametrize('F,T,D,K', [(5, 64, 2, 2), (9, 200, 3, 2), (17, 130, 6, 3),
+                                     (33, 500, 8, 3), (4, 257, 8, 4), (3, 100, 7, 1)])
+def test_single_m_step_and_predict(F, T, D, K):
+    """iterations=1: weighted covariance + eigh + floor, then one E-step."""
+    from oracle import synth
+    Y, init = synth.make_stft(F, T, D, max(K, 2), seed=F)
+    init = init[:, :K] / init[:, :K].sum(axis=1, keepdims=True)
+    m, mask = _oracle_fit(Y, init, 1)
+    r = _device_fit(Y, init, 1)
+    assert np.abs(_host(r['weight'])[..., None] - m['weight']).max() < 1e-14
+    cov = _cov(_host(r['eigvec']), _host(r['eigval']))
+    ref = _cov(m['eigvec'], m['eigval'])
+    assert np.abs(cov - ref).max() < 1e-12
+    assert np.abs(_host(r['eigval']) - m['eigval']).max() < 1e-12
+    assert np.abs(_host(r['affiliation']) - mask).max() < 1e-9
+
+
+@pytest.mark.parametrize('iters', [2, 5, 20])
+def test_trajectory_small(iters):
+    from oracle import synth
+    Y, init = synth.make_stft(65, 300, 8, 3, seed=0)
+    m, mask = _oracle_fit(Y, init, iters)
+    r = _device_fit(Y, init, iters)
+    assert (_host(r['status']) & 3 == 0).all()
+    err = np.abs(_host(r['affiliation']) - mask).max()
+    assert err < 1e-7, err
+    assert np.abs(_host(r['weight'])[..., None] - m['weight']).max() < 1e-8
+
+
+def test_config1_plumbing_shape():
+    """BASELINE config 1: F=129, T=200, D=2, K=2, 20 iterations."""
+    from oracle import synth
+    Y, init = synth.make_stft(129, 200, 2, 2, seed=0)
+    m, mask = _oracle_fit(Y, init, 20)
+    r = _device_fit(Y, init, 20)
+    assert np.abs(_host(r['affiliation']) - mask).max() < 1e-8
+
+
+def test_config2_full_100_iterations():
+    """BASELINE config 2 (the headline): F=513, T=500, D=8, K=3, 100 iterations,
+    masks within 1e-5 max-abs of the float64 reference path."""
+    from oracle import synth
+    Y, init = synth.make_stft(513, 500, 8, 3, seed=0)
+    m, mask = _oracle_fit(Y, init, 100)
+    r = _device_fit(Y, init, 100)
+    err = np.abs(_host(r['affiliation']) - mask).max()
+    assert err < 1e-5, err
+    cov = _cov(_host(r['eigvec']), _host(r['eigval']))
+    assert np.abs(cov - _cov(m['eigvec'], m['eigval'])).max() < 1e-5
+
+
+def test_force_eig_equals_fast_path():
+    """The Cholesky fast path and the per-iteration Jacobi path are the same
+    algorithm up to rounding."""
+    from oracle import synth
+    Y, init = synth.make_stft(33, 250, 8, 3, seed=3)
+    a = _device_fit(Y, init, 10)
+    b = _device_fit(Y, init, 10, force_eig=True)
+    assert np.abs(_host(a['affiliation']) - _host(b['affiliation'])).max() < 1e-9
+
+
+def test_rank_deficient_hits_floor():
+    """D > rank: eigenvalues are floored at 1e-10 (cacg.py:112-121); the
+    in-loop slow path must reproduce the reference."""
+    from oracle import synth
+    from pb_bss_amd import _lib
+    Y, init = synth.make_rank_deficient(9, 200, 6, 2, rank=3, seed=2)
+    m, mask = _oracle_fit(Y, init, 3)
+    r = _device_fit(Y, init, 3)
+    st = _host(r['status'])
+    assert (st & _lib.ST_FLOORED).all()
+    # B^-1 carries 1e10 in the null space and the complex64 rounding of Y leaks
+    # ~6e-8 of every frame into it: q is accurate to cond*eps ~ 1e-6 relative on
+    # BOTH sides (the reference's einsum also forms B^-1 first), so two correct
+    # float64 implementations agree only to ~1e-6 per step here.
+    assert np.abs(_host(r['eigval']) - m['eigval']).max() < 1e-4
+    assert np.abs(_host(r['affiliation']) - mask).max() < 1e-3
+
+
+def test_white_noise_worst_conditioning():
+    from oracle import synth
+    Y, init = synth.make_white(33, 400, 8, 3, seed=1)
+    m, mask = _oracle_fit(Y, init, 10)
+    r = _device_fit(Y, init, 10)
+    assert np.abs(_host(r['affiliation']) - mask).max() < 1e-8
+
+
+def test_zero_frames_and_complex128_input():
+    from oracle import synth, cacgmm as oc
+    from pb_bss_amd import engine
+    Y, init = synth.make_stft(7, 150, 4, 2, seed=5, dtype=np.complex128)
+    Y[:, 10] = 0
+    m = oc.em_fit(Y, init, iterations=4)
+    mask = oc.em_predict(m, Y)
+    r = engine.em_fit(_dev(Y), 2, gamma0=_dev(init), iterations=4, final_predict=True)
+    assert np.isfinite(_host(r['affiliation'])).all()
+    assert np.abs(_host(r['affiliation']) - mask).max() < 1e-10
+
+
+@pytest.mark.parametrize('covariance_norm', ['eigenvalue', 'trace', False])
+def test_covariance_norm_and_options(covariance_norm):
+    from oracle import synth
+    Y, init = synth.make_stft(9, 120, 5, 3, seed=7)
+    rng = np.random.default_rng(0)
+    sal = rng.uniform(0.1, 1.0, size=(9, 120))
+    m, mask = _oracle_fit(Y, init, 4, covariance_norm=covariance_norm, saliency=sal)
+    r = _device_fit(Y, init, 4, covariance_norm=covariance_norm, saliency=_dev(sal))
+    assert np.abs(_host(r['eigval']) - m['eigval']).max() < 1e-10 * max(1, m['eigval'].max())
+    assert np.abs(_host(r['weight'])[..., None] - m['weight']).max() < 1e-10
+    assert np.abs(_host(r['affiliation']) - mask).max() < 1e-9
+
+
+def test_source_activity_mask_and_uniform_weight():
+    from oracle import synth
+    Y, init = synth.make_stft(6, 90, 4, 3, seed=9)
+    rng = np.random.default_rng(1)
+    act = rng.uniform(size=init.shape) > 0.2
+    act[:, 0] = True
+    m, mask = _oracle_fit(Y, init, 3, source_activity_mask=act, weight_constant_axis=-2)
+    r = _device_fit(Y, init, 3, activity=_dev(act.astype(np.uint8)), weight_mode=1)
+    from oracle import cacgmm as oc
+    mask = oc.em_predict(m, Y.astype(np.complex128))
+    assert np.abs(_host(r['weight']) - 1 / 3).max() < 1e-15
+    assert np.abs(_host(r['affiliation']) - mask).max() < 1e-9
+
+
+def test_model_initialisation_resume():
+    """fit(initialization=model) resumes (cacgmm.py:229-234): 3 + 2 == 5."""
+    from oracle import synth
+    from pb_bss_amd import engine
+    Y, init = synth.make_stft(12, 160, 6, 3, seed=11)
+    a = _device_fit(Y, init, 5)
+    b3 = _device_fit(Y, init, 3)
+    b = engine.em_fit(_dev(Y), 3, model=(b3['eigvec'], b3['eigval'], b3['weight']),
+                      iterations=2, final_predict=True)
+    assert np.abs(_host(a['affiliation']) - _host(b['affiliation'])).max() < 1e-9
+
+
+def test_predict_entry_point_q_and_log_pdf():
+    from oracle import synth, cacgmm as oc
+    from pb_bss_amd import engine, _lib
+    Y, init = synth.make_stft(10, 140, 8, 3, seed=13)
+    Y128 = Y.astype(np.complex128)
+    m = oc.em_fit(Y128, init, iterations=3)
+    yn = oc.normalize_observation(Y128)
+    aff, q, lp = oc.e_step(yn, m['weight'], m['eigvec'], m['eigval'], affiliation_eps=1e-10)
+    d_aff, d_q, d_lp = engine.em_predict(
+        _dev(yn), _dev(m['eigvec']), _dev(m['eigval']), _dev(m['weight'][..., 0]),
+        layout=_lib.LAYOUT_DT, affiliation_eps=1e-10, want_q=True, want_log_pdf=True)
+    assert np.abs(_host(d_q) - q).max() / q.max() < 1e-11
+    assert np.abs(_host(d_lp) - lp).max() < 1e-9
+    assert np.abs(_host(d_aff) - aff).max() < 1e-10
+
+
+def test_standalone_m_step_entry_point():
+    from oracle import synth, cacgmm as oc
+    from pb_bss_amd import engine, _lib
+    Y, init = synth.make_stft(8, 110, 6, 2, seed=17)
+    yn = oc.normalize_observation(Y.astype(np.complex128))
+    rng = np.random.default_rng(3)
+    q = rng.uniform(0.5, 2.0, size=init.shape)
+    vec, val = oc.cacg_m_step(yn[..., None, :, :], init, q)
+    d_vec, d_val, d_cov, st = engine.cacg_m_step(_dev(yn), _dev(init), _dev(q),
+                                                 layout=_lib.LAYOUT_DT, want_cov=True)
+    assert np.abs(_cov(_host(d_vec), _host(d_val)) - _cov(vec, val)).max() < 1e-12
+    assert np.abs(_host(d_val) - val).max() < 1e-12

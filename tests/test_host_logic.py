@@ -1,0 +1,69 @@
+"""CPU: host-side logic of the drop-in layer that needs no GPU."""
+import numpy as np
+
+from oracle import cacgmm as oc
+
+
+def test_host_mixture_weight_matches_oracle_and_doctest():
+    from pb_bss_amd.distribution.mixture_model_utils import (
+        estimate_mixture_weight, log_pdf_to_affiliation)
+    a = np.array([[0.4, 1, 0.4], [0.6, 0, 0.6]])
+    assert np.allclose(estimate_mixture_weight(a), [[0.6], [0.4]])
+    assert np.allclose(estimate_mixture_weight(a, weight_constant_axis=-2), [[0.5], [0.5]])
+    assert np.allclose(estimate_mixture_weight(np.stack([a, a]), weight_constant_axis=-3),
+                       [[[0.4, 1, 0.4], [0.6, 0, 0.6]]])
+    rng = np.random.default_rng(0)
+    aff = rng.uniform(size=(4, 3, 10))
+    sal = rng.uniform(size=(4, 10))
+    for ax in [-1, (-1,), (-3,), (-3, -1), -2]:
+        assert np.allclose(estimate_mixture_weight(aff, sal, ax),
+                           oc.estimate_mixture_weight(aff, sal, ax))
+        assert np.allclose(estimate_mixture_weight(aff, None, ax),
+                           oc.estimate_mixture_weight(aff, None, ax))
+    lp = rng.standard_normal((4, 3, 10)) * 50
+    w = rng.uniform(size=(4, 3, 1))
+    act = rng.uniform(size=(4, 3, 10)) > 0.3
+    assert np.allclose(log_pdf_to_affiliation(w, lp, act, 1e-10),
+                       oc.log_pdf_to_affiliation(w, lp, act, 1e-10))
+
+
+def test_weight_mode_mapping():
+    from pb_bss_amd import _lib
+    from pb_bss_amd.distribution.cacgmm import CACGMMTrainer
+    wm = CACGMMTrainer._weight_mode
+    assert wm((-1,), 3) == _lib.WEIGHT_PER_CLASS_MEAN
+    assert wm(-1, 3) == _lib.WEIGHT_PER_CLASS_MEAN
+    assert wm(2, 3) == _lib.WEIGHT_PER_CLASS_MEAN
+    assert wm(-2, 3) == _lib.WEIGHT_UNIFORM
+    assert wm(1, 3) == _lib.WEIGHT_UNIFORM
+    assert wm((-3,), 3) is None
+    assert wm((-3, -1), 3) is None
+    assert wm(-3, 3) is None
+
+
+def test_model_containers_roundtrip():
+    from pb_bss_amd.distribution import CACGMM, ComplexAngularCentralGaussian
+    m = CACGMM(weight=np.ones((2, 1)),
+               cacg=ComplexAngularCentralGaussian(np.eye(2)[None].repeat(2, 0), np.ones((2, 2))))
+    d = m.to_dict()
+    assert set(d) == {'weight', 'cacg'} and set(d['cacg']) == {
+        'covariance_eigenvectors', 'covariance_eigenvalues'}
+    m2 = CACGMM.from_dict({'weight': d['weight'],
+                           'cacg': ComplexAngularCentralGaussian.from_dict(d['cacg'])})
+    assert np.allclose(m2.cacg.covariance, m.cacg.covariance)
+    assert np.allclose(m.cacg.log_determinant, 0)
+    try:
+        m.cacg.covariances
+    except AttributeError as e:
+        assert 'Close matches' in str(e) and 'covariance_eigenvalues' in str(e)
+    else:
+        raise AssertionError('expected AttributeError')
+
+
+def test_synth_is_deterministic():
+    from oracle import synth
+    a = synth.make_stft(3, 10, 4, 2, seed=1)
+    b = synth.make_stft(3, 10, 4, 2, seed=1)
+    assert (a[0] == b[0]).all() and (a[1] == b[1]).all()
+    assert a[0].dtype == np.complex64 and a[1].dtype == np.float64
+    assert np.allclose(a[1].sum(axis=1), 1)
