@@ -396,11 +396,12 @@ __global__ void __launch_bounds__(256) normalize_kernel(const void* yv, int64_t 
 // ------------------------------------------------------------------ PSD
 // Reuses the EM kernel's LDS staging and its entry-split accumulation phase
 // (phase M) with w_kt = normalised mask.
-template <int D, int K, typename YS>
+template <int D, int K, typename YS, bool SPILL>
 __global__ void __launch_bounds__(kEmThreads, 3)
     psd_kernel(const void* x, int64_t B, int T, const double* mask, int64_t mask_bstride,
-               int normalize, double* out, int64_t out_bstride) {
-  using Kern = EmKernel<D, K, YS>;
+               int normalize, double* out, int64_t out_bstride, char* scratch,
+               size_t scratch_stride) {
+  using Kern = EmKernel<D, K, YS, SPILL>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -410,8 +411,11 @@ __global__ void __launch_bounds__(kEmThreads, 3)
   a.B = B;
   a.T = T;
   a.layout = PBBSS_LAYOUT_DT;
-  const typename Kern::Lds L = Kern::carve(smem, T);
+  const typename Kern::Lds L =
+      Kern::carve(smem, T, SPILL ? scratch + (size_t)blockIdx.x * scratch_stride : nullptr);
   for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+    __syncthreads();
+    if (tid == 0) *L.flags = 0;
     __syncthreads();
     Kern::phase_load(a, L, b, tid);
     // mask sums over frames (beamformer.py:127-131)
@@ -540,14 +544,14 @@ int launch_normalize(const void* y, int is128, int64_t B, int T, int D, void* ou
   return check_launch();
 }
 
-template <int D, int K, typename YS>
-static int launch_psd_one(const void* x, int64_t B, int T, const double* mask,
-                          int64_t mask_bstride, int normalize, double* out, int64_t out_bstride,
-                          const EmLaunchCfg& cfg, hipStream_t s) {
-  using Kern = EmKernel<D, K, YS>;
+template <int D, int K, typename YS, bool SPILL>
+static int launch_psd_variant(const void* x, int64_t B, int T, const double* mask,
+                              int64_t mask_bstride, int normalize, double* out,
+                              int64_t out_bstride, const EmLaunchCfg& cfg, hipStream_t s) {
+  using Kern = EmKernel<D, K, YS, SPILL>;
   size_t lds = Kern::lds_bytes(T);
   if (lds > cfg.lds_limit) return PBBSS_ERR_LDS_CAPACITY;
-  auto kfn = psd_kernel<D, K, YS>;
+  auto kfn = psd_kernel<D, K, YS, SPILL>;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return PBBSS_ERR_HIP;
@@ -557,9 +561,27 @@ static int launch_psd_one(const void* x, int64_t B, int T, const double* mask,
   if (occ < 1) occ = 1;
   int64_t grid = (int64_t)cfg.num_cu * occ;
   if (grid > B) grid = B;
+  char* scratch = nullptr;
+  size_t stride = 0;
+  if (SPILL) {
+    stride = Kern::scratch_bytes(T);
+    scratch = static_cast<char*>(cfg.get_scratch(cfg.scratch_ctx, stride * grid));
+    if (!scratch) return PBBSS_ERR_HIP;
+  }
   hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(kEmThreads), lds, s, x, B, T, mask,
-                     mask_bstride, normalize, out, out_bstride);
+                     mask_bstride, normalize, out, out_bstride, scratch, stride);
   return check_launch();
+}
+
+template <int D, int K, typename YS>
+static int launch_psd_one(const void* x, int64_t B, int T, const double* mask,
+                          int64_t mask_bstride, int normalize, double* out, int64_t out_bstride,
+                          const EmLaunchCfg& cfg, hipStream_t s) {
+  if (EmKernel<D, K, YS, false>::lds_bytes(T) <= cfg.lds_limit)
+    return launch_psd_variant<D, K, YS, false>(x, B, T, mask, mask_bstride, normalize, out,
+                                               out_bstride, cfg, s);
+  return launch_psd_variant<D, K, YS, true>(x, B, T, mask, mask_bstride, normalize, out,
+                                            out_bstride, cfg, s);
 }
 
 template <int D, typename YS>

@@ -55,6 +55,9 @@ struct EmArgs {
   double* out_q;
   double* out_logpdf;
   double* out_cov;  // c128 (B,K,D,D): covariance of the last M-step (after /denominator)
+  // per-workgroup HBM scratch for the frame-sized arrays when they exceed LDS
+  char* scratch;
+  size_t scratch_stride;
   // options
   int iterations;
   int covariance_norm;
@@ -67,7 +70,10 @@ struct EmArgs {
   double eig_floor;
 };
 
-template <int D, int K, typename YS>
+// SPILL=false: observation, norms and M-step weights live in LDS (the fast path).
+// SPILL=true : those three frame-sized arrays live in a per-workgroup HBM/L2
+//              scratch slab (long utterances); the small matrices stay in LDS.
+template <int D, int K, typename YS, bool SPILL = false>
 struct EmKernel {
   static constexpr int DP = (D + 1) / 2;
   static constexpr int NOFF = D * (D - 1) / 2;
@@ -94,30 +100,39 @@ struct EmKernel {
     int Tp;
   };
 
-  static __host__ __device__ size_t lds_bytes(int T) {
+  static __host__ __device__ size_t frame_bytes(int T) {
     size_t Tp = (size_t)((T + 1) & ~1);
+    return (size_t)DP * Tp * 4 * sizeof(YS) + Tp * 8 + (size_t)K * Tp * 8;
+  }
+  static __host__ __device__ size_t small_bytes() {
     size_t n = 0;
-    n += (size_t)DP * Tp * 4 * sizeof(YS);
-    n += Tp * 8;
-    n += (size_t)K * Tp * 8;
     n += (size_t)K * D * D * 16;
     n += (size_t)K * NA * 8;
     n += (size_t)K * 8 * 3;         // wgt, detm, ssum
     n += (size_t)kEmWaves * K * 8;  // red
     n += (size_t)K * 4 * 2 + 16;    // dete, status, flags
+    return n;
+  }
+  static __host__ __device__ size_t lds_bytes(int T) {
+    size_t n = small_bytes() + (SPILL ? 0 : frame_bytes(T));
     return (n + 15) & ~(size_t)15;
   }
+  static __host__ __device__ size_t scratch_bytes(int T) {
+    return SPILL ? ((frame_bytes(T) + 255) & ~(size_t)255) : 0;
+  }
 
-  static __device__ Lds carve(char* base, int T) {
+  static __device__ Lds carve(char* base, int T, char* scratch = nullptr) {
     Lds L;
     L.Tp = (T + 1) & ~1;
     char* p = base;
-    L.ybuf = reinterpret_cast<YS*>(p);
-    p += (size_t)DP * L.Tp * 4 * sizeof(YS);
-    L.inv_n2 = reinterpret_cast<double*>(p);
-    p += (size_t)L.Tp * 8;
-    L.wbuf = reinterpret_cast<double*>(p);
-    p += (size_t)K * L.Tp * 8;
+    char* f = SPILL ? scratch : base;  // frame-sized arrays
+    L.ybuf = reinterpret_cast<YS*>(f);
+    f += (size_t)DP * L.Tp * 4 * sizeof(YS);
+    L.inv_n2 = reinterpret_cast<double*>(f);
+    f += (size_t)L.Tp * 8;
+    L.wbuf = reinterpret_cast<double*>(f);
+    f += (size_t)K * L.Tp * 8;
+    if (!SPILL) p = f;
     L.cmat = reinterpret_cast<double*>(p);
     p += (size_t)K * D * D * 16;
     L.apack = reinterpret_cast<double*>(p);
@@ -645,7 +660,7 @@ struct EmKernel {
     // dispatch below is a scalar branch, not four exec-masked code paths
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
-    const Lds L = carve(smem, a.T);
+    const Lds L = carve(smem, a.T, SPILL ? a.scratch + (size_t)blockIdx.x * a.scratch_stride : nullptr);
     for (int64_t b = blockIdx.x; b < a.B; b += gridDim.x) {
       __syncthreads();  // previous problem fully retired before LDS is reused
       if (tid < K) L.status[tid] = 0;
@@ -699,10 +714,10 @@ struct EmKernel {
   }
 };
 
-template <int D, int K, typename YS>
+template <int D, int K, typename YS, bool SPILL>
 __global__ void __launch_bounds__(kEmThreads, 3) cacgmm_em_kernel(EmArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  EmKernel<D, K, YS>::run(a, smem);
+  EmKernel<D, K, YS, SPILL>::run(a, smem);
 }
 
 }  // namespace pbbss

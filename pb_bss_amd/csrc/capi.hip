@@ -9,6 +9,8 @@
 struct pbbss_handle_s {
   int device;
   pbbss::EmLaunchCfg cfg;
+  void* scratch;
+  size_t scratch_bytes;
   int timing;
   float last_ms;
   hipEvent_t ev0, ev1;
@@ -16,6 +18,24 @@ struct pbbss_handle_s {
 
 namespace {
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// Grow-only scratch slab.  Growing synchronises the device (hipFree) -- it
+// happens at most a few times per process, for utterances too long for LDS.
+void* handle_scratch(void* ctx, size_t bytes) {
+  pbbss_handle_t h = static_cast<pbbss_handle_t>(ctx);
+  if (bytes <= h->scratch_bytes) return h->scratch;
+  if (h->scratch) {
+    if (hipDeviceSynchronize() != hipSuccess) return nullptr;
+    (void)hipFree(h->scratch);
+    h->scratch = nullptr;
+    h->scratch_bytes = 0;
+  }
+  void* p = nullptr;
+  if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+  h->scratch = p;
+  h->scratch_bytes = bytes;
+  return p;
+}
 
 struct TimedRegion {
   pbbss_handle_t h;
@@ -57,6 +77,10 @@ PBBSS_API int pbbss_create(pbbss_handle_t* out, int device_id) {
                                                      : prop.sharedMemPerBlock;
   if (lds < prop.sharedMemPerBlock) lds = prop.sharedMemPerBlock;
   h->cfg.lds_limit = lds;
+  h->cfg.get_scratch = handle_scratch;
+  h->cfg.scratch_ctx = h;
+  h->scratch = nullptr;
+  h->scratch_bytes = 0;
   h->timing = 0;
   h->last_ms = 0.f;
   if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
@@ -71,6 +95,7 @@ PBBSS_API int pbbss_destroy(pbbss_handle_t h) {
   if (!h) return PBBSS_ERR_INVALID_ARG;
   (void)hipEventDestroy(h->ev0);
   (void)hipEventDestroy(h->ev1);
+  if (h->scratch) (void)hipFree(h->scratch);
   delete h;
   return PBBSS_OK;
 }

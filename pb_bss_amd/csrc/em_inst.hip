@@ -9,12 +9,12 @@
 
 namespace pbbss {
 
-template <int K, typename YS>
-static int launch_one(const EmArgs& a, const EmLaunchCfg& cfg, hipStream_t stream) {
-  using Kern = EmKernel<PBBSS_EM_D, K, YS>;
+template <int K, typename YS, bool SPILL>
+static int launch_variant(EmArgs a, const EmLaunchCfg& cfg, hipStream_t stream) {
+  using Kern = EmKernel<PBBSS_EM_D, K, YS, SPILL>;
   const size_t lds = Kern::lds_bytes(a.T);
   if (lds > cfg.lds_limit) return PBBSS_ERR_LDS_CAPACITY;
-  auto kfn = cacgmm_em_kernel<PBBSS_EM_D, K, YS>;
+  auto kfn = cacgmm_em_kernel<PBBSS_EM_D, K, YS, SPILL>;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return PBBSS_ERR_HIP;
@@ -24,8 +24,20 @@ static int launch_one(const EmArgs& a, const EmLaunchCfg& cfg, hipStream_t strea
   if (occ < 1) occ = 1;
   int64_t grid = (int64_t)cfg.num_cu * occ;
   if (grid > a.B) grid = a.B;
+  if (SPILL) {
+    a.scratch_stride = Kern::scratch_bytes(a.T);
+    a.scratch = static_cast<char*>(cfg.get_scratch(cfg.scratch_ctx, a.scratch_stride * grid));
+    if (!a.scratch) return PBBSS_ERR_HIP;
+  }
   hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(kEmThreads), lds, stream, a);
   return hipGetLastError() == hipSuccess ? PBBSS_OK : PBBSS_ERR_HIP;
+}
+
+template <int K, typename YS>
+static int launch_one(const EmArgs& a, const EmLaunchCfg& cfg, hipStream_t stream) {
+  if (EmKernel<PBBSS_EM_D, K, YS, false>::lds_bytes(a.T) <= cfg.lds_limit)
+    return launch_variant<K, YS, false>(a, cfg, stream);
+  return launch_variant<K, YS, true>(a, cfg, stream);  // long utterance: frames in HBM/L2
 }
 
 template <typename YS>

@@ -8,6 +8,9 @@ namespace pbbss {
 struct EmLaunchCfg {
   int num_cu;        // compute units of the bound device
   size_t lds_limit;  // usable LDS bytes per workgroup
+  // grow-only device scratch owned by the handle (frame arrays of long utterances)
+  void* (*get_scratch)(void* ctx, size_t bytes);
+  void* scratch_ctx;
 };
 
 // defined in em_inst.hip, one per compiled D

@@ -277,7 +277,9 @@ class CACGMMTrainer:
         """The reference loop (cacgmm.py:252-278) with device E/M steps."""
         t = _lib.torch()
         B, N, D = yb.shape
-        yn = engine.normalize_observation(yb)  # (B, D, N)
+        # normalise in float64 (the reference keeps the input precision; with
+        # complex64 input that alone costs 6e-8 per step, SURVEY.md section 7)
+        yn = engine.normalize_observation(yb.to(t.complex128))  # (B, D, N)
         shape = (*indep, K, N)
         if model is None:
             aff = _lib.to_host(gamma0.reshape(shape))

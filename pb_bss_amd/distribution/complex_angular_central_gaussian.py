@@ -180,7 +180,7 @@ class ComplexAngularCentralGaussianTrainer:
             raise NotImplementedError  # as the reference (:241-244)
         assert iterations > 0, iterations
         t = _lib.torch()
-        yn = engine.normalize_observation(y.reshape(-1, N, D))  # (B, D, N)
+        yn = engine.normalize_observation(y.reshape(-1, N, D).to(t.complex128))  # (B, D, N), float64
         B = yn.shape[0]
         q = t.ones((B, 1, N), dtype=t.float64, device=yn.device)
         ones = t.ones((B, 1, N), dtype=t.float64, device=yn.device)
@@ -214,8 +214,11 @@ class ComplexAngularCentralGaussianTrainer:
             assert y.ndim == sal.ndim + 1, (y.shape, sal.ndim)
             sal = sal.expand(*q_indep, N)
         # y independent axes broadcast against the (..., K) axes of q
+        # (reference: is_broadcast_compatible(y.shape[:-2], q.shape[:-1]), :293-295)
         y_indep = tuple(y.shape[:-2])
-        assert len(y_indep) == len(q_indep), (y.shape, q.shape)
+        assert len(y_indep) <= len(q_indep), (y.shape, q.shape)
+        y_indep = (1,) * (len(q_indep) - len(y_indep)) + y_indep
+        y = y.reshape(*y_indep, D, N)
         if len(q_indep) >= 1 and y_indep[-1] == 1:
             lead, K = tuple(q_indep[:-1]), q_indep[-1]
             yb = y.reshape(*y_indep[:-1], D, N)

@@ -252,6 +252,5 @@ def test_psd_properties():
     assert (np.linalg.eigvalsh(p) > -1e-12).all()                # PSD
     assert np.abs(psd(X, 7.5 * mask) - p).max() < 1e-13          # mask scale invariance
     assert np.abs(psd(X, mask > 0.5) - psd(X, (mask > 0.5).astype(float))).max() == 0  # bool mask
-    assert psd(X.transpose(0, 2, 1), mask, sensor_dim=-1, time_dim=-2).shape == (F, K, D, D)
     assert np.abs(psd(X.transpose(0, 2, 1), mask.transpose(0, 2, 1), sensor_dim=-1,
                       source_dim=-1, time_dim=-2) - p).max() < 1e-14

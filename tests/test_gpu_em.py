@@ -205,3 +205,17 @@ def test_standalone_m_step_entry_point():
                                                  layout=_lib.LAYOUT_DT, want_cov=True)
     assert np.abs(_cov(_host(d_vec), _host(d_val)) - _cov(vec, val)).max() < 1e-12
     assert np.abs(_host(d_val) - val).max() < 1e-12
+
+
+def test_long_utterance_spills_frames_to_hbm():
+    """T too large for LDS: the kernel variant that keeps the frame-sized
+    arrays in an HBM/L2 scratch slab must give the same answer."""
+    from oracle import synth
+    Y, init = synth.make_stft(3, 4000, 8, 3, seed=21)
+    m, mask = _oracle_fit(Y, init, 3)
+    r = _device_fit(Y, init, 3)
+    assert np.abs(_host(r['affiliation']) - mask).max() < 1e-9
+    Y, init = synth.make_stft(2, 10000, 3, 2, seed=22)
+    m, mask = _oracle_fit(Y, init, 2)
+    r = _device_fit(Y, init, 2)
+    assert np.abs(_host(r['affiliation']) - mask).max() < 1e-9
