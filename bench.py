@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""Headline benchmark: cACGMM EM iterations/s on F=513, T=500, D=8, K=3
+(BASELINE.json metric / configs[1]), one rank per GPU.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A *step* is one pass of the hot path: one fused `fit` of --iters (default 100)
+EM iterations followed by the final E-step (fit_predict), with the complex64
+observation already resident in HBM.  At N GPUs the job is N utterances
+(weak scaling): every rank owns a contiguous block of ~513/N frequency bins of
+EVERY utterance, runs the EM with no collective in the loop, and the posterior
+masks are all-gathered over RCCL/xGMI at the end of each step (what
+permutation alignment needs).  value = N * iters * K / max-over-ranks time.
+
+The JSON line also carries
+  roofline     -- algorithmic HBM bytes (8*F*T*D per EM iteration, SURVEY.md
+                  section 8d) over the EM kernel's duration measured with HIP
+                  events on the launch stream inside the library; plus the
+                  FP64-VALU fraction, which is what actually binds the kernel;
+  cpu_baseline -- the NumPy oracle (same einsum calls as the reference) timed
+                  on this host on a bounded sample (rank 0, N = 1 only);
+  mask_max_abs_err -- device vs oracle after all iterations on a bin subset.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+F, T, D, K = 513, 500, 8, 3
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8 TB/s spec
+FP64_VALU_PEAK_TF = 78.6  # MI355X FP64 vector peak
+# float64 flops per frame per EM iteration (DESIGN.md "work model"):
+#   outer product P (E phase) 192 + (M phase) 192, q_k 2*D*D*K, acc 2*D*D*K, softmax ~100
+FLOPS_PER_FRAME_ITER = 2 * 192 + 2 * (2 * D * D * K) + 100
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument('--gpus', type=int, default=1)
+    p.add_argument('--steps', type=int, default=30)
+    p.add_argument('--warmup', type=int, default=3)
+    p.add_argument('--iters', type=int, default=100, help='EM iterations per fit')
+    p.add_argument('--cpu-iters', type=int, default=40,
+                   help='EM iterations of the CPU baseline sample (0 = skip)')
+    p.add_argument('--check-bins', type=int, default=24,
+                   help='bins of utterance 0 checked against the oracle (0 = skip)')
+    return p.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from oracle import synth  # input generator shared with the parity tests
+    from pb_bss_amd import _lib, engine
+    from pb_bss_amd.sharding import all_gather_bins, shard_bounds
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    assert world == args.gpus, (world, args.gpus)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)
+
+    # ---- workload: `world` utterances, this rank's block of bins of each ----
+    lo, hi = shard_bounds(F, world, rank)
+    ys, inits = [], []
+    Y0 = init0 = None
+    for u in range(world):
+        Y, init = synth.make_stft(F, T, D, K, seed=u)
+        if u == 0:
+            Y0, init0 = Y, init
+        ys.append(Y[lo:hi])
+        inits.append(init[lo:hi])
+    y = _lib.to_device(np.concatenate(ys))        # (world*(hi-lo), T, D) complex64
+    g0 = _lib.to_device(np.concatenate(inits))    # (world*(hi-lo), K, T) float64
+    n_loc = hi - lo
+    engine.set_timing(True, local_rank)
+
+    def step():
+        r = engine.em_fit(y, K, gamma0=g0, iterations=args.iters, final_predict=True,
+                          check_status=False)
+        ms = engine.last_kernel_ms(local_rank)  # HIP events on the launch stream
+        masks = r['affiliation'].reshape(world, n_loc, K, T)
+        if world > 1:
+            masks = all_gather_bins(masks, F, bin_axis=1)
+        return masks, ms, r
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    kernel_ms = 0.0
+    for _ in range(args.steps):
+        masks, ms, r = step()
+        kernel_ms += ms
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank == 0:
+        value = world * args.iters * args.steps / elapsed
+        avg_kernel_s = kernel_ms / args.steps * 1e-3
+        alg_bytes = 8.0 * (world * n_loc) * T * D * args.iters  # per launch, this rank
+        achieved = alg_bytes / avg_kernel_s / 1e9
+        flops = FLOPS_PER_FRAME_ITER * (world * n_loc) * T * args.iters
+        tflops = flops / avg_kernel_s / 1e12
+        out = {
+            'metric': 'cACGMM EM iterations/sec on F=513,T=500,D=8,K=3',
+            'value': value,
+            'unit': 'EM iterations/s (utterance-iterations, whole job)',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': elapsed / args.steps * 1e3,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f64', 'data': 'synthetic',
+            'config': {
+                'workload': 'BASELINE configs[1]: 8-mic 3-source cACGMM, F=513 T=500 D=8 K=3, '
+                            'complex64 STFT resident in HBM, fit_predict',
+                'em_iterations_per_step': args.iters, 'utterances': world,
+                'sharding': f'frequency bins, {n_loc} of {F} per rank per utterance; '
+                            'mask all-gather per step' if world > 1 else 'none (1 GPU)',
+            },
+            'roofline': {
+                'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                'kernel': 'cacgmm_em_kernel<8,3,float,false>',
+                'kernel_ms': avg_kernel_s * 1e3,
+                'algorithmic_bytes_per_launch': alg_bytes,
+                'note': 'y stays in LDS for the whole EM loop; the binding resource is '
+                        'FP64 VALU, see fp64_valu',
+                'fp64_valu': {'achieved': tflops, 'peak': FP64_VALU_PEAK_TF, 'unit': 'TFLOP/s',
+                              'frac': tflops / FP64_VALU_PEAK_TF,
+                              'flops_per_frame_iter': FLOPS_PER_FRAME_ITER},
+            },
+        }
+        st = _lib.to_host(r['status'])
+        out['status_bits_or'] = int(np.bitwise_or.reduce(st.ravel()))
+        # ---- parity on a bin subset of utterance 0 (oracle = checker only) ----
+        if args.check_bins and lo == 0:
+            from oracle import cacgmm as oc
+            nb = min(args.check_bins, n_loc)
+            Y128 = Y0[:nb].astype(np.complex128)
+            m = oc.em_fit(Y128, init0[:nb], iterations=args.iters)
+            ref = oc.em_predict(m, Y128)
+            got = _lib.to_host(masks[0, :nb])
+            out['mask_max_abs_err'] = float(np.abs(got - ref).max())
+            out['mask_err_bins_checked'] = nb
+        # ---- CPU baseline: NumPy oracle on this host, bounded sample ----------
+        if world == 1 and args.cpu_iters > 0:
+            from oracle import cacgmm as oc
+            Y128 = Y0.astype(np.complex128)
+            t1 = time.perf_counter()
+            oc.em_fit(Y128, init0, iterations=args.cpu_iters)
+            dt = time.perf_counter() - t1
+            out['cpu_baseline'] = {
+                'value': args.cpu_iters / dt, 'unit': 'EM iterations/s', 'cores': 1,
+                'kind': 'port',
+                'sample': f'NumPy oracle (reference einsum calls, float64), full F=513 T=500 '
+                          f'D=8 K=3, {args.cpu_iters} EM iterations, {dt:.1f} s; '
+                          f'host has {os.cpu_count()} logical cores, einsum is single-threaded',
+            }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
