@@ -242,6 +242,10 @@ int pbbss_apply_beamforming_vector(pbbss_handle_t h, const void* w,
 /* the launch stream; torch.cuda.Event only sees torch's current stream).      */
 /* ------------------------------------------------------------------------- */
 int pbbss_set_timing(pbbss_handle_t h, int enable);
+/* Development aid: device buffer of 32 uint64 receiving per-phase shader-cycle sums
+ * of the EM kernel ([wave 0..3][phase 0..7]); only written by library builds made
+ * with -DPBBSS_PHASE_PROFILE (`make prof`), ignored otherwise.  NULL disables. */
+int pbbss_set_phase_profile(pbbss_handle_t h, void* dev_counters);
 int pbbss_last_kernel_ms(pbbss_handle_t h, float* out_ms);
 
 #ifdef __cplusplus

@@ -11,7 +11,7 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libpbbss_hip.so')
+LIB_PATH = os.path.join(_HERE, os.environ.get('PBBSS_LIB', 'libpbbss_hip.so'))
 
 # ---- constants mirrored from include/pbbss.h ---------------------------------
 OK = 0
@@ -39,7 +39,7 @@ EXPORTS = (
     'pbbss_cacg_m_step', 'pbbss_heev_batched', 'pbbss_psd', 'pbbss_gev',
     'pbbss_solve', 'pbbss_mvdr_souden', 'pbbss_mvdr', 'pbbss_ban',
     'pbbss_apply_beamforming_vector', 'pbbss_set_timing',
-    'pbbss_last_kernel_ms',
+    'pbbss_last_kernel_ms', 'pbbss_set_phase_profile',
 )
 
 
@@ -87,6 +87,7 @@ def load():
         lib.pbbss_destroy.argtypes = [vp]
         lib.pbbss_set_timing.argtypes = [vp, i32]
         lib.pbbss_last_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
+        lib.pbbss_set_phase_profile.argtypes = [vp, vp]
         lib.pbbss_normalize_observation.argtypes = [vp, vp, i32, i64, i32, i32, vp, vp]
         lib.pbbss_cacgmm_fit.argtypes = [
             vp, vp, i64, i32, i32, i32, vp, vp, vp, vp, vp, vp,

@@ -58,6 +58,8 @@ struct EmArgs {
   // per-workgroup HBM scratch for the frame-sized arrays when they exceed LDS
   char* scratch;
   size_t scratch_stride;
+  // optional phase cycle counters (only honoured by builds with -DPBBSS_PHASE_PROFILE)
+  unsigned long long* prof;
   // options
   int iterations;
   int covariance_norm;
@@ -80,7 +82,7 @@ struct EmKernel {
   static constexpr int NA = D * D;  // packed reals of one Hermitian matrix
   static constexpr int NDW = (D + kEmWaves - 1) / kEmWaves;     // diag entries per wave (max)
   static constexpr int NOW = (NOFF + kEmWaves - 1) / kEmWaves;  // off-diag pairs per wave (max)
-  static constexpr int kOperandChunk = 4;  // pairs of A_k operands in flight in the E phase
+  static constexpr int kOperandChunk = 2;  // pairs of A_k operands per prefetch stage of the E phase
   using YS4 = typename std::conditional<std::is_same<YS, float>::value, float4, double4>::type;
   using YS2 = typename std::conditional<std::is_same<YS, float>::value, float2, double2>::type;
 
@@ -260,14 +262,6 @@ struct EmKernel {
     double s[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) s[k] = 0.0;
-    double detm[K], wgt[K];
-    int dete[K];
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-      detm[k] = L.detm[k];
-      dete[k] = L.dete[k];
-      wgt[k] = L.wgt[k];
-    }
     for (int t0 = 0; t0 < a.T; t0 += NF * kEmThreads) {
       int tt[NF];
       bool ok[NF];
@@ -281,39 +275,78 @@ struct EmKernel {
 #pragma unroll
         for (int k = 0; k < K; ++k) q[f][k] = 0.0;
       }
-      // q_k = <A_k, P>: diagonal then strict upper triangle
-      static_for<0, D>([&](auto ic) {
-        constexpr int i = ic;
-        double ak[K];
+      // q_k = <A_k, P>: diagonal, then the strict upper triangle in chunks of
+      // kOperandChunk pairs.  The A_k operands of chunk c+1 are fetched from LDS
+      // (uniform address = broadcast read) BEFORE the FMAs of chunk c issue, so
+      // the LDS latency hides behind float64 work; compiler fences pin that
+      // order (left alone hipcc loads just-in-time and stalls on every read).
+      {
+        constexpr int NCH = (NOFF + kOperandChunk - 1) / kOperandChunk;
+        double op[2][kOperandChunk][K][2];
+        auto fetch = [&](auto cc, auto bb) {
+          constexpr int c = cc, bsel = bb;
 #pragma unroll
-        for (int k = 0; k < K; ++k) ak[k] = L.apack[k * NA + i];
+          for (int x = 0; x < kOperandChunk; ++x) {
+            if (c * kOperandChunk + x < NOFF) {
 #pragma unroll
-        for (int f = 0; f < NF; ++f) {
-          double dg = re[f][i] * re[f][i] + im[f][i] * im[f][i];
+              for (int k = 0; k < K; ++k) {
+                op[bsel][x][k][0] = L.apack[k * NA + D + 2 * (c * kOperandChunk + x)];
+                op[bsel][x][k][1] = L.apack[k * NA + D + 2 * (c * kOperandChunk + x) + 1];
+              }
+            }
+          }
+        };
+        if constexpr (NCH > 0) fetch(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        asm volatile("" ::: "memory");
+        static_for<0, D>([&](auto ic) {
+          constexpr int i = ic;
+          double ad[K];
 #pragma unroll
-          for (int k = 0; k < K; ++k) q[f][k] = fma(ak[k], dg, q[f][k]);
-        }
-      });
-      static_for<0, NOFF>([&](auto pc) {
-        constexpr int p = pc;
-        constexpr int i = tri_i<D>(p), j = tri_j<D>(p);
-        // keep the compiler from hoisting all K*D*D operand loads ahead of the
-        // FMAs (that costs >450 VGPRs): a compiler-only fence every few pairs
-        if constexpr (p % kOperandChunk == 0) asm volatile("" ::: "memory");
-        double ar[K], ai[K];
+          for (int k = 0; k < K; ++k) ad[k] = L.apack[k * NA + i];
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-          ar[k] = L.apack[k * NA + D + 2 * p];
-          ai[k] = L.apack[k * NA + D + 2 * p + 1];
-        }
+          for (int f = 0; f < NF; ++f) {
+            double dg = re[f][i] * re[f][i] + im[f][i] * im[f][i];
 #pragma unroll
-        for (int f = 0; f < NF; ++f) {
-          double pr = re[f][i] * re[f][j] + im[f][i] * im[f][j];   // Re y_i conj(y_j)
-          double pim = im[f][i] * re[f][j] - re[f][i] * im[f][j];  // Im y_i conj(y_j)
+            for (int k = 0; k < K; ++k) q[f][k] = fma(ad[k], dg, q[f][k]);
+          }
+        });
+        static_for<0, NCH>([&](auto cc) {
+          constexpr int c = cc;
+          constexpr int cur = c & 1;
+          if constexpr (c + 1 < NCH) {
+            fetch(std::integral_constant<int, c + 1>{}, std::integral_constant<int, 1 - cur>{});
+          }
+          asm volatile("" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+          static_for<0, kOperandChunk>([&](auto xc) {
+            constexpr int x = xc;
+            constexpr int p = c * kOperandChunk + x;
+            if constexpr (p < NOFF) {
+              constexpr int i = tri_i<D>(p), j = tri_j<D>(p);
 #pragma unroll
-          for (int k = 0; k < K; ++k) q[f][k] = fma(ar[k], pr, fma(ai[k], pim, q[f][k]));
-        }
-      });
+              for (int f = 0; f < NF; ++f) {
+                double pr = re[f][i] * re[f][j] + im[f][i] * im[f][j];   // Re y_i conj(y_j)
+                double pim = im[f][i] * re[f][j] - re[f][i] * im[f][j];  // Im y_i conj(y_j)
+#pragma unroll
+                for (int k = 0; k < K; ++k)
+                  q[f][k] = fma(op[cur][x][k][0], pr, fma(op[cur][x][k][1], pim, q[f][k]));
+              }
+            }
+          });
+          asm volatile("" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      }
+      // per-class constants (fetched here, not at phase entry: keeping them live
+      // across the operand loop costs spills)
+      double detm[K], wgt[K];
+      int dete[K];
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        detm[k] = L.detm[k];
+        dete[k] = L.dete[k];
+        wgt[k] = L.wgt[k];
+      }
 #pragma unroll
       for (int f = 0; f < NF; ++f) {
         const int t = tt[f];
@@ -383,19 +416,18 @@ struct EmKernel {
   }
 
   // ---- phase M: wave W accumulates its share of the Hermitian entries ------
+  // Entry slots of wave W within one class: diagonal i = 4s + W (s < NDW), then
+  // (re, im) of the strict-upper pairs p = 4s + W (s < NOW).  All classes are
+  // accumulated in one flat array acc[k * NSLOT + slot], padded to a multiple
+  // of 16 for the halving butterfly.
+  static constexpr int NSLOT = NDW + 2 * NOW;
+  static constexpr int NACC = ((K * NSLOT + 15) / 16) * 16;
+
   template <int W>
   static __device__ void phase_m(const EmArgs& a, const Lds& L, int lane) {
-    double ad[K][NDW], ar[K][NOW], ai[K][NOW];
+    double acc[NACC];
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-#pragma unroll
-      for (int x = 0; x < NDW; ++x) ad[k][x] = 0.0;
-#pragma unroll
-      for (int x = 0; x < NOW; ++x) {
-        ar[k][x] = 0.0;
-        ai[k][x] = 0.0;
-      }
-    }
+    for (int x = 0; x < NACC; ++x) acc[x] = 0.0;
     for (int t0 = 0; t0 < a.T; t0 += kWave) {
       const int t = t0 + lane;
       const bool ok = t < a.T;
@@ -409,53 +441,54 @@ struct EmKernel {
         if constexpr (i % kEmWaves == W) {
           double dg = re[i] * re[i] + im[i] * im[i];
 #pragma unroll
-          for (int k = 0; k < K; ++k) ad[k][i / kEmWaves] = fma(w[k], dg, ad[k][i / kEmWaves]);
+          for (int k = 0; k < K; ++k)
+            acc[k * NSLOT + i / kEmWaves] = fma(w[k], dg, acc[k * NSLOT + i / kEmWaves]);
         }
       });
       static_for<0, NOFF>([&](auto pc) {
         constexpr int p = pc;
         if constexpr (p % kEmWaves == W) {
           constexpr int i = tri_i<D>(p), j = tri_j<D>(p);
+          constexpr int s = NDW + 2 * (p / kEmWaves);
           double pr = re[i] * re[j] + im[i] * im[j];
           double pim = im[i] * re[j] - re[i] * im[j];
 #pragma unroll
           for (int k = 0; k < K; ++k) {
-            ar[k][p / kEmWaves] = fma(w[k], pr, ar[k][p / kEmWaves]);
-            ai[k][p / kEmWaves] = fma(w[k], pim, ai[k][p / kEmWaves]);
+            acc[k * NSLOT + s] = fma(w[k], pr, acc[k * NSLOT + s]);
+            acc[k * NSLOT + s + 1] = fma(w[k], pim, acc[k * NSLOT + s + 1]);
           }
         }
       });
     }
-    // butterfly over the 64 frames-lanes, then lane 0 stores C_ij and C_ji = conj
+    // halving butterfly over the 64 frame-lanes; 16 lanes each store NACC/16 totals
+    wave_reduce_scatter<NACC>(acc, lane);
+    if ((lane & 3) == 0) {
+      const int base = reduce_scatter_base<NACC>(lane);
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-      static_for<0, D>([&](auto ic) {
-        constexpr int i = ic;
-        if constexpr (i % kEmWaves == W) {
-          double v = wave_sum(ad[k][i / kEmWaves]);
-          if (lane == 0) {
-            double* c = L.cmat + (((size_t)k * D + i) * D + i) * 2;
-            c[0] = v;
-            c[1] = 0.0;
+      for (int m = 0; m < NACC / 16; ++m) {
+        const int idx = base + m;
+        if (idx < K * NSLOT) {
+          const int k = idx / NSLOT, s = idx % NSLOT;
+          if (s < NDW) {
+            const int i = s * kEmWaves + W;
+            if (i < D) {
+              double* cc = L.cmat + (((size_t)k * D + i) * D + i) * 2;
+              cc[0] = acc[m];
+              cc[1] = 0.0;
+            }
+          } else {
+            const int p = ((s - NDW) >> 1) * kEmWaves + W;
+            if (p < NOFF) {
+              const int i = tri_i<D>(p), j = tri_j<D>(p);
+              const bool is_im = ((s - NDW) & 1) != 0;
+              // C_ij gets +v (re) / +v (im); C_ji = conj(C_ij)
+              L.cmat[(((size_t)k * D + i) * D + j) * 2 + (is_im ? 1 : 0)] = acc[m];
+              L.cmat[(((size_t)k * D + j) * D + i) * 2 + (is_im ? 1 : 0)] =
+                  is_im ? -acc[m] : acc[m];
+            }
           }
         }
-      });
-      static_for<0, NOFF>([&](auto pc) {
-        constexpr int p = pc;
-        if constexpr (p % kEmWaves == W) {
-          constexpr int i = tri_i<D>(p), j = tri_j<D>(p);
-          double vr = wave_sum(ar[k][p / kEmWaves]);
-          double vi = wave_sum(ai[k][p / kEmWaves]);
-          if (lane == 0) {
-            double* c = L.cmat + (((size_t)k * D + i) * D + j) * 2;
-            c[0] = vr;
-            c[1] = vi;
-            double* ct = L.cmat + (((size_t)k * D + j) * D + i) * 2;
-            ct[0] = vr;
-            ct[1] = -vi;
-          }
-        }
-      });
+      }
     }
   }
 
@@ -517,18 +550,16 @@ struct EmKernel {
     }
     bool need_eig = last || a.force_eig || (st & PBBSS_ST_NONFINITE) || (*L.flags & 1);
     if (!need_eig) {
-      double lre = are, lim = aim;
+      double gre = are, gim = aim;
       ScaledReal det;
-      int info = wave_cholesky<D>(lre, lim, c, det);
+      int info = wave_hpd_inverse<D>(gre, gim, c, det);
       bool ok = (info == 0);
       if (ok) {
-        double xre, xim, gre, gim;
-        wave_tri_inverse<D>(lre, lim, c, xre, xim);
-        wave_gram<D>(xre, xim, c, gre, gim);
         // lambda_min >= 1/||A^-1||_F and lambda_max <= tr C: if even this pessimistic
         // ratio stays clear of the floor, no eigenvalue is floored (cacg.py:112-126)
-        double trc = wave_sum((valid && c.i == c.j) ? are : 0.0);
-        double fro2 = wave_sum(valid ? gre * gre + gim * gim : 0.0);
+        double trc = (valid && c.i == c.j) ? are : 0.0;
+        double fro2 = valid ? gre * gre + gim * gim : 0.0;
+        wave_sum2(trc, fro2);
         double bound = trc * sqrt(fro2);
         ok = isfinite(bound) && (bound * a.eig_floor < 1e-2) && (bound < 1e13);
         if (ok) {
@@ -661,6 +692,18 @@ struct EmKernel {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     const Lds L = carve(smem, a.T, SPILL ? a.scratch + (size_t)blockIdx.x * a.scratch_stride : nullptr);
+#ifdef PBBSS_PHASE_PROFILE
+    unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = __builtin_readcyclecounter();
+#define PBBSS_TICK(i)                                        \
+  {                                                          \
+    unsigned long long tn = __builtin_readcyclecounter();    \
+    pc[i] += tn - tprev;                                     \
+    tprev = tn;                                              \
+  }
+#else
+#define PBBSS_TICK(i)
+#endif
     for (int64_t b = blockIdx.x; b < a.B; b += gridDim.x) {
       __syncthreads();  // previous problem fully retired before LDS is reused
       if (tid < K) L.status[tid] = 0;
@@ -679,12 +722,15 @@ struct EmKernel {
         finish_sums(a, L, tid);
         __syncthreads();
       }
+      PBBSS_TICK(0)
       for (int it = 0; it < a.iterations; ++it) {
         if (it > 0 || model_in) {
           phase_e<false, false>(a, L, b, tid, wave, lane, a.aff_eps);
+          PBBSS_TICK(1)
           __syncthreads();
           finish_sums(a, L, tid);
           __syncthreads();
+          PBBSS_TICK(2)
         }
         switch (wave) {
           case 0: phase_m<0>(a, L, lane); break;
@@ -692,10 +738,14 @@ struct EmKernel {
           case 2: phase_m<2>(a, L, lane); break;
           default: phase_m<3>(a, L, lane); break;
         }
+        PBBSS_TICK(3)
         __syncthreads();
+        PBBSS_TICK(4)
         const bool last = (it == a.iterations - 1);
         for (int k = wave; k < K; k += kEmWaves) factor_class(a, L, b, k, lane, last);
+        PBBSS_TICK(5)
         __syncthreads();
+        PBBSS_TICK(6)
       }
       if (tid < K) {
         if (a.out_weight && a.iterations > 0) a.out_weight[(size_t)b * K + tid] = L.wgt[tid];
@@ -710,7 +760,15 @@ struct EmKernel {
           phase_e<true, false>(a, L, b, tid, wave, lane, a.final_eps);
         }
       }
+      PBBSS_TICK(7)
     }
+#ifdef PBBSS_PHASE_PROFILE
+    // [wave][8] cycle sums over all workgroups: 0 load/init, 1 E, 2 E-barrier+sums,
+    // 3 M, 4 M-barrier, 5 factor, 6 factor-barrier, 7 final predict
+    if (a.prof && lane == 0) {
+      for (int i = 0; i < 8; ++i) atomicAdd(a.prof + wave * 8 + i, pc[i]);
+    }
+#endif
   }
 };
 

@@ -11,6 +11,7 @@ struct pbbss_handle_s {
   pbbss::EmLaunchCfg cfg;
   void* scratch;
   size_t scratch_bytes;
+  unsigned long long* prof;
   int timing;
   float last_ms;
   hipEvent_t ev0, ev1;
@@ -81,6 +82,7 @@ PBBSS_API int pbbss_create(pbbss_handle_t* out, int device_id) {
   h->cfg.scratch_ctx = h;
   h->scratch = nullptr;
   h->scratch_bytes = 0;
+  h->prof = nullptr;
   h->timing = 0;
   h->last_ms = 0.f;
   if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
@@ -103,6 +105,12 @@ PBBSS_API int pbbss_destroy(pbbss_handle_t h) {
 PBBSS_API int pbbss_set_timing(pbbss_handle_t h, int enable) {
   if (!h) return PBBSS_ERR_INVALID_ARG;
   h->timing = enable ? 1 : 0;
+  return PBBSS_OK;
+}
+
+PBBSS_API int pbbss_set_phase_profile(pbbss_handle_t h, void* dev_counters) {
+  if (!h) return PBBSS_ERR_INVALID_ARG;
+  h->prof = static_cast<unsigned long long*>(dev_counters);
   return PBBSS_OK;
 }
 
@@ -176,6 +184,7 @@ PBBSS_API int pbbss_cacgmm_fit(pbbss_handle_t h, const void* y, int64_t B, int T
   a.aff_eps = o->affiliation_eps;
   a.final_eps = 0.0;  // model.predict: affiliation_eps = 0 (cacgmm.py:73)
   a.eig_floor = o->eigenvalue_floor;
+  a.prof = h->prof;
   TimedRegion tr(h, as_stream(stream));
   return pbbss::em_launch(D, K, o->y_is_c128, a, h->cfg, as_stream(stream));
 }

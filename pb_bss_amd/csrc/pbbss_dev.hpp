@@ -96,6 +96,76 @@ __device__ __forceinline__ void scaled_mul(ScaledReal& s, double x) {
   s.e += e2;
 }
 
+
+// broadcast the value held by a COMPILE-TIME-known lane to the whole wave
+// through SGPRs (v_readlane_b32): no LDS-crossbar round trip.
+__device__ __forceinline__ double lane_bcast_const(double v, int src_lane_uniform) {
+  union {
+    double d;
+    int i[2];
+  } u;
+  u.d = v;
+  u.i[0] = __builtin_amdgcn_readlane(u.i[0], src_lane_uniform);
+  u.i[1] = __builtin_amdgcn_readlane(u.i[1], src_lane_uniform);
+  return u.d;
+}
+
+// Sum N per-lane values over the 64 lanes with a halving ("reduce-scatter")
+// butterfly: the four steps over lane bits 5..2 each exchange only HALF of the
+// remaining values (lanes with the bit clear keep the lower half, the others
+// the upper half), two full steps over bits 1..0 finish.  N must be a multiple
+// of 16.  On return v[0 .. N/16) hold the totals of the original indices
+//     base + m,  base = (N/16) * (b2 + 2*b3 + 4*b4 + 8*b5)   (b_i = lane bit i)
+// on every lane (lanes differing only in bits 1..0 hold identical values).
+// All exchanges of a step are independent, so their ds_bpermute latencies overlap
+// (the naive "one all-reduce per value" chain is ~10x slower: 6 dependent hops each).
+template <int N>
+__device__ __forceinline__ void wave_reduce_scatter(double (&v)[N], int lane) {
+  static_assert(N % 16 == 0, "pad to a multiple of 16");
+  static_for<0, 4>([&](auto sc) {
+    constexpr int s = sc;
+    constexpr int H = N >> (s + 1);
+    constexpr int bit = 32 >> s;
+    const bool up = (lane & bit) != 0;
+    double send[H];
+#pragma unroll
+    for (int n = 0; n < H; ++n) {
+      double lo = v[n], hi = v[n + H];
+      send[n] = up ? lo : hi;
+      v[n] = up ? hi : lo;
+    }
+#pragma unroll
+    for (int n = 0; n < H; ++n) send[n] = __shfl_xor(send[n], bit, kWave);
+#pragma unroll
+    for (int n = 0; n < H; ++n) v[n] += send[n];
+  });
+  constexpr int R = N / 16;
+#pragma unroll
+  for (int o = 2; o > 0; o >>= 1) {
+    double t[R];
+#pragma unroll
+    for (int n = 0; n < R; ++n) t[n] = __shfl_xor(v[n], o, kWave);
+#pragma unroll
+    for (int n = 0; n < R; ++n) v[n] += t[n];
+  }
+}
+// first original index owned by `lane` after wave_reduce_scatter<N>
+template <int N>
+__device__ __forceinline__ int reduce_scatter_base(int lane) {
+  return (N / 16) * ((lane >> 2) & 15);
+}
+
+// two interleaved all-reduce sums (halves the dependent-hop latency of two
+// back-to-back wave_sum calls)
+__device__ __forceinline__ void wave_sum2(double& a, double& b) {
+#pragma unroll
+  for (int o = kWave / 2; o > 0; o >>= 1) {
+    double ta = __shfl_xor(a, o, kWave), tb = __shfl_xor(b, o, kWave);
+    a += ta;
+    b += tb;
+  }
+}
+
 constexpr double kTiny = 2.2250738585072014e-308;  // np.finfo(np.float64).tiny
 
 }  // namespace pbbss

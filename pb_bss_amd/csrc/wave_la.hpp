@@ -55,6 +55,51 @@ __device__ __forceinline__ int wave_cholesky(double& are, double& aim, LaneIJ c,
   return info;
 }
 
+// ---------------------------------------------------------------------------
+// In-place Gauss-Jordan inverse of a Hermitian positive definite matrix (no
+// pivoting needed: the pivots are the Cholesky pivots d_p > 0).  One sweep per
+// column p:  a_pp <- 1/d, row p <- row/d, col p <- -col/d,
+//            a_ij <- a_ij - a_ip a_pj / d.
+// Per sweep: one SGPR broadcast of the pivot and ONE parallel cross-lane hop
+// (row element a_pj and column element a_ip) -- about a third of the dependent
+// hops of Cholesky + triangular inverse + Gram product.  det(A) = prod d_p is
+// returned as mantissa/exponent; info = 0 or 1 + index of the first bad pivot.
+// ---------------------------------------------------------------------------
+template <int D>
+__device__ __forceinline__ int wave_hpd_inverse(double& are, double& aim, LaneIJ c,
+                                                ScaledReal& det) {
+  int info = 0;
+  det.m = 1.0;
+  det.e = 0;
+#pragma unroll
+  for (int p = 0; p < D; ++p) {
+    double d = lane_bcast_const(are, ij_lane(p, p));
+    bool good = (d > 0.0) && (d < 1.79e308);
+    if (!good && info == 0) info = p + 1;
+    double ds = good ? d : 1.0;
+    scaled_mul(det, ds);
+    double inv = 1.0 / ds;
+    double rr = lane_get(are, ij_lane(p, c.j)), ri = lane_get(aim, ij_lane(p, c.j));  // a_pj
+    double cr = lane_get(are, ij_lane(c.i, p)), ci = lane_get(aim, ij_lane(c.i, p));  // a_ip
+    const bool ip = (c.i == p), jp = (c.j == p);
+    if (ip && jp) {
+      are = inv;
+      aim = 0.0;
+    } else if (ip) {
+      are = rr * inv;
+      aim = ri * inv;
+    } else if (jp) {
+      are = -cr * inv;
+      aim = -ci * inv;
+    } else {
+      double tr = (cr * rr - ci * ri) * inv, ti = (cr * ri + ci * rr) * inv;
+      are -= tr;
+      aim -= ti;
+    }
+  }
+  return info;
+}
+
 // X = L^-1 for lower-triangular L (row-oriented forward substitution on I).
 template <int D>
 __device__ __forceinline__ void wave_tri_inverse(double lre, double lim, LaneIJ c,

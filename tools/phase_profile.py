@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Per-phase shader-cycle breakdown of the EM kernel (needs the profiling build:
+`make -C pb_bss_amd/csrc prof`, run with PBBSS_LIB=libpbbss_hip_prof.so)."""
+import os
+import sys
+import ctypes
+os.environ.setdefault('PBBSS_LIB', 'libpbbss_hip_prof.so')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from oracle import synth
+from pb_bss_amd import _lib, engine
+
+NAMES = ['load/init', 'E', 'E-barrier+sums', 'M', 'M-barrier', 'factor', 'factor-barrier', 'final predict']
+
+
+def main():
+    nutt = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+    iters = 100
+    Y = np.concatenate([synth.make_stft(513, 500, 8, 3, seed=s)[0] for s in range(nutt)])
+    g = np.concatenate([synth.make_stft(513, 500, 8, 3, seed=s)[1] for s in range(nutt)])
+    y, g0 = _lib.to_device(Y), _lib.to_device(g)
+    cnt = torch.zeros(32, dtype=torch.int64, device='cuda')
+    h = _lib.handle()
+    _lib.load().pbbss_set_phase_profile(h, ctypes.c_void_p(cnt.data_ptr()))
+    engine.set_timing(True)
+    engine.em_fit(y, 3, gamma0=g0, iterations=iters, final_predict=True)  # warm-up
+    cnt.zero_()
+    engine.em_fit(y, 3, gamma0=g0, iterations=iters, final_predict=True)
+    ms = engine.last_kernel_ms()
+    c = cnt.cpu().numpy().reshape(4, 8).astype(np.float64)
+    nwg = min(513 * nutt, 256 * 3)
+    print(f'utterances {nutt}: kernel {ms:.3f} ms, {nutt*iters/ms*1e3:.0f} utt-iter/s; cycles per workgroup-iteration '
+          f'(avg over {nwg} workgroups, s_memtime ticks):')
+    per = c / (513 * nutt) / iters  # per problem-iteration
+    for w in range(4):
+        print(f'  wave {w}: ' + ', '.join(f'{n} {per[w, i]:.0f}' for i, n in enumerate(NAMES)))
+    tot = per[0].sum()
+    print(f'  wave0 total {tot:.0f} ticks per problem-iteration')
+
+
+if __name__ == '__main__':
+    main()
