@@ -236,6 +236,29 @@ int pbbss_apply_beamforming_vector(pbbss_handle_t h, const void* w,
                                    int T, int D, void* out, void* stream);
 
 /* ------------------------------------------------------------------------- */
+/* N1  DHTVPermutationAlignment.calculate_mapping  permutation_alignment.py:295-355 */
+/*     (similarity_metric='cos'; algorithm 'greedy' (optimal=0) or 'optimal'),  */
+/*     score matrix :380-407, assignment :469-589.                              */
+/* mask f64 (U,K,F,T) (U utterances); plan int32 (P,3) rows (iterations, start, */
+/* end) = DHTVPermutationAlignment.alignment_plan (:204-293), a DEVICE array;    */
+/* scratch f64 (U,K,F,T) receives the aligned unit-norm features; out_mapping    */
+/* int32 (U,K,F) is the reverse mapping; status int32 (U) gets                    */
+/* PBBSS_ST_NONFINITE where the reference raises 'score matrix is infeasible'.   */
+/* K <= 8.  One launch runs the whole plan.                                       */
+/* ------------------------------------------------------------------------- */
+int pbbss_dhtv_calculate_mapping(pbbss_handle_t h, const double* mask, int64_t U,
+                                 int K, int F, int T, const int32_t* plan, int P,
+                                 int optimal, double* scratch,
+                                 int32_t* out_mapping, int32_t* out_status,
+                                 void* stream);
+
+/* apply_mapping  permutation_alignment.py:54-104:                              */
+/* out[u,k,f,:] = mask[u, mapping[u,k,f], f, :];  mask/out f64 (U,K,F,T).        */
+int pbbss_apply_mapping(pbbss_handle_t h, const double* mask,
+                        const int32_t* mapping, int64_t U, int K, int F, int T,
+                        double* out, void* stream);
+
+/* ------------------------------------------------------------------------- */
 /* Timing hook for bench.py: runs `fit` with HIP events recorded on `stream`   */
 /* around the EM kernel launch(es) only and returns the elapsed milliseconds   */
 /* of the most recent call (the roofline figure needs the kernel duration on   */

@@ -169,6 +169,29 @@ def beamformer_cases():
           solve_A=A, solve_B=Bm, solve_X=stable_solve(A, Bm))
 
 
+def dhtv_cases():
+    from pb_bss.permutation_alignment import DHTVPermutationAlignment
+    rng = np.random.default_rng(7)
+    out = {}
+    for tag, size, K, T in [('s512_k2', 512, 2, 60), ('s1024_k3', 1024, 3, 48)]:
+        F = size // 2 + 1
+        act = rng.uniform(size=(K, T)) ** 4
+        mask = act[:, None, :] * rng.uniform(0.5, 1.0, size=(K, F, T)) \
+            + 0.05 * rng.uniform(size=(K, F, T))
+        mask /= mask.sum(0, keepdims=True)
+        perm = np.stack([rng.permutation(K) for _ in range(F)], 1)
+        pm = mask[perm, range(F)].astype(np.float32)  # stored compactly; exact upcast in tests
+        solver = DHTVPermutationAlignment.from_stft_size(size)
+        m64 = pm.astype(np.float64)
+        out[tag + '_mask'] = pm
+        out[tag + '_mapping'] = solver.calculate_mapping(m64)
+        out[tag + '_plan'] = np.asarray(solver.alignment_plan)
+        out[tag + '_aligned_sum'] = solver.apply_mapping(m64, out[tag + '_mapping']).sum(-1)
+        solver.algorithm = 'optimal'
+        out[tag + '_mapping_optimal'] = solver.calculate_mapping(m64)
+    _save('dhtv_alignment', **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     refshim.load()
@@ -176,6 +199,7 @@ def main():
     cacgmm_cases()
     cacg_cases()
     beamformer_cases()
+    dhtv_cases()
 
 
 if __name__ == '__main__':

@@ -1,0 +1,116 @@
+"""NumPy restatement of the reference DHTV permutation alignment
+(TEST INFRASTRUCTURE).  Citations: /root/reference/pb_bss/permutation_alignment.py.
+Pinned by oracle/make_golden.py -> tests/golden/dhtv_*.npz.
+"""
+import itertools
+
+import numpy as np
+
+__all__ = ['alignment_plan', 'mapping_from_score_matrix', 'dhtv_calculate_mapping',
+           'apply_mapping', 'PRESETS']
+
+# from_stft_size presets, permutation_alignment.py:164-184
+PRESETS = {
+    512: dict(segment_start=70, segment_width=100, segment_shift=20,
+              main_iterations=20, sub_iterations=2),
+    1024: dict(segment_start=100, segment_width=100, segment_shift=20,
+               main_iterations=20, sub_iterations=2),
+}
+
+
+def _interleave(a, b):
+    out = []
+    for i in range(max(len(a), len(b))):
+        if i < len(a):
+            out.append(a[i])
+        if i < len(b):
+            out.append(b[i])
+    return out
+
+
+def alignment_plan(stft_size, segment_start, segment_width, segment_shift,
+                   main_iterations, sub_iterations):
+    """[(iterations, start, end), ...]: the seed segment first, then segments
+    growing alternately upwards and downwards (permutation_alignment.py:204-293)."""
+    F = stft_size // 2 + 1
+    if segment_start + segment_width > F:
+        raise ValueError(
+            f'segment_start ({segment_start}) + segment_width ({segment_width})\n'
+            f'must be smaller than stft_size // 2 + 1 ({F}),\n'
+            f'but it is {segment_start + segment_width}')
+    up = [[sub_iterations, s, s + segment_width]
+          for s in range(segment_start + segment_shift, F - segment_width, segment_shift)]
+    down = [[sub_iterations, s, s + segment_width]
+            for s in range(segment_start - segment_shift, 0, -segment_shift)]
+    first = [main_iterations, segment_start, segment_start + segment_width]
+    if up:
+        up[-1][-1] = F
+    else:
+        first[-1] = F
+    if down:
+        down[-1][1] = 0
+    else:
+        first[1] = 0
+    return [first] + _interleave(up, down)
+
+
+def _unit(a):
+    """permutation_alignment.py:358-377: a / max(||a||, tiny) along the last axis."""
+    n = np.linalg.norm(a, axis=-1, keepdims=True)
+    return a / np.maximum(n, np.finfo(n.dtype).tiny)
+
+
+def mapping_from_score_matrix(score, algorithm='greedy'):
+    """permutation_alignment.py:469-589 for one (K, K) score matrix
+    (rows = reference/centroid class, columns = mask class)."""
+    score = np.asarray(score, dtype=np.float64)
+    if not np.all(np.isfinite(score)):
+        raise ValueError('score matrix is infeasible')
+    K = score.shape[0]
+    if algorithm == 'greedy':
+        s = score.copy()
+        out = np.zeros(K, dtype=int)
+        for _ in range(K):
+            i, j = np.unravel_index(np.argmax(s), s.shape)
+            s[i, :] = -np.inf
+            s[:, j] = -np.inf
+            out[i] = j
+        return out
+    if algorithm == 'optimal':
+        best, best_p = -np.inf, None
+        for p in itertools.permutations(range(K)):
+            v = sum(score[range(K), p])
+            if v > best:
+                best, best_p = v, p
+        return np.array(best_p)
+    raise ValueError(algorithm)
+
+
+def dhtv_calculate_mapping(mask, plan, algorithm='greedy'):
+    """permutation_alignment.py:295-355 with similarity_metric='cos'.
+    mask (K, F, T) -> reverse mapping (K, F)."""
+    K, F, _ = mask.shape
+    assert F % 2 == 1, (F, 'Sure? Usually F is odd.')
+    feat = _unit(np.array(mask, dtype=np.float64))
+    mapping = np.repeat(np.arange(K)[:, None], F, axis=1)
+    ident = np.arange(K)
+    for iterations, start, end in plan:
+        for _ in range(iterations):
+            cent = _unit(np.mean(feat[:, start:end, :], axis=1))
+            changed = False
+            for f in range(start, end):
+                score = np.einsum('KT,kT->kK', feat[:, f, :], cent)
+                perm = mapping_from_score_matrix(score, algorithm)
+                if not (perm == ident).all():
+                    changed = True
+                    feat[:, f, :] = feat[perm, f, :]
+                    mapping[:, f] = mapping[perm, f]
+            if not changed:
+                break
+    return mapping
+
+
+def apply_mapping(mask, mapping):
+    """permutation_alignment.py:54-104: mask (K, F, ...), mapping (K, F)."""
+    K, F = mapping.shape
+    return mask[mapping, range(F)]

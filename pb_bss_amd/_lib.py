@@ -40,6 +40,7 @@ EXPORTS = (
     'pbbss_solve', 'pbbss_mvdr_souden', 'pbbss_mvdr', 'pbbss_ban',
     'pbbss_apply_beamforming_vector', 'pbbss_set_timing',
     'pbbss_last_kernel_ms', 'pbbss_set_phase_profile',
+    'pbbss_dhtv_calculate_mapping', 'pbbss_apply_mapping',
 )
 
 
@@ -88,6 +89,8 @@ def load():
         lib.pbbss_set_timing.argtypes = [vp, i32]
         lib.pbbss_last_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
         lib.pbbss_set_phase_profile.argtypes = [vp, vp]
+        lib.pbbss_dhtv_calculate_mapping.argtypes = [vp, vp, i64, i32, i32, i32, vp, i32, i32, vp, vp, vp, vp]
+        lib.pbbss_apply_mapping.argtypes = [vp, vp, vp, i64, i32, i32, i32, vp, vp]
         lib.pbbss_normalize_observation.argtypes = [vp, vp, i32, i64, i32, i32, vp, vp]
         lib.pbbss_cacgmm_fit.argtypes = [
             vp, vp, i64, i32, i32, i32, vp, vp, vp, vp, vp, vp,

@@ -2,6 +2,7 @@
 // validation, handle state, kernel dispatch; no numerical code lives here.
 #include "pbbss.h"
 #include "beamform.hpp"
+#include "dhtv.hpp"
 #include "em_launch.hpp"
 
 #define PBBSS_API extern "C" __attribute__((visibility("default")))
@@ -320,4 +321,21 @@ PBBSS_API int pbbss_apply_beamforming_vector(pbbss_handle_t h, const void* w, co
     if (rc != PBBSS_OK) return rc;
   }
   return PBBSS_OK;
+}
+
+PBBSS_API int pbbss_dhtv_calculate_mapping(pbbss_handle_t h, const double* mask, int64_t U, int K,
+                                           int F, int T, const int32_t* plan, int P, int optimal,
+                                           double* scratch, int32_t* out_mapping,
+                                           int32_t* out_status, void* stream) {
+  if (!h || !mask || !plan || !scratch || !out_mapping || !out_status) return PBBSS_ERR_INVALID_ARG;
+  if (U <= 0 || F <= 0 || T <= 0 || P <= 0) return PBBSS_ERR_INVALID_ARG;
+  return pbbss::launch_dhtv(mask, U, K, F, T, plan, P, optimal, scratch, out_mapping, out_status,
+                            h->cfg.lds_limit, as_stream(stream));
+}
+
+PBBSS_API int pbbss_apply_mapping(pbbss_handle_t h, const double* mask, const int32_t* mapping,
+                                  int64_t U, int K, int F, int T, double* out, void* stream) {
+  if (!h || !mask || !mapping || !out || U <= 0 || K <= 0 || F <= 0 || T <= 0)
+    return PBBSS_ERR_INVALID_ARG;
+  return pbbss::launch_apply_mapping(mask, mapping, U, K, F, T, out, as_stream(stream));
 }

@@ -1,0 +1,299 @@
+// DHTV frequency-permutation alignment on the device.
+//
+// Reference: permutation_alignment.py:295-355 (DHTVPermutationAlignment.
+// calculate_mapping, similarity_metric='cos'), :380-407 (score matrix),
+// :469-589 (_mapping_from_score_matrix), :54-104 (apply_mapping).
+//
+// One 1024-thread workgroup per utterance runs the WHOLE alignment plan in one
+// launch (the reference's python loops are plan x iteration x frequency).
+// Inside one iteration every frequency of the segment is independent given the
+// time centroid, so the 16 waves each take frequencies round-robin:
+//   centroid  thread = (class, frame) column, sum over the segment's bins
+//   scores    wave = frequency, lanes = frames: K x K dot products, butterfly
+//   assign    greedy / brute-force optimal on the K x K scores (uniform code)
+//   permute   the K feature rows of that frequency and its mapping column
+// Features (unit-norm masks, float64) live in a caller-provided scratch copy in
+// HBM/L2 (K*F*T*8 bytes per utterance); the normalised centroid in LDS.
+#include "dhtv.hpp"
+#include "pbbss_dev.hpp"
+
+namespace pbbss {
+
+constexpr int kDhtvThreads = 1024;
+constexpr int kDhtvWaves = kDhtvThreads / kWave;
+constexpr int kDhtvMaxK = 8;
+
+__device__ __forceinline__ double block_sum(double v, double* red, int tid) {
+  // sum over the whole workgroup (red: kDhtvWaves doubles in LDS)
+  v = wave_sum(v);
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = v;
+  __syncthreads();
+  double s = 0.0;
+#pragma unroll
+  for (int w = 0; w < kDhtvWaves; ++w) s += red[w];
+  return s;
+}
+
+// permutation index -> permutation in itertools.permutations (lexicographic) order
+__device__ __forceinline__ void nth_permutation(int n, int K, int* out) {
+  int avail[kDhtvMaxK];
+  for (int i = 0; i < K; ++i) avail[i] = i;
+  int fact = 1;
+  for (int i = 2; i < K; ++i) fact *= i;  // (K-1)!
+  for (int i = 0; i < K; ++i) {
+    int idx = n / fact;
+    n %= fact;
+    out[i] = avail[idx];
+    for (int j = idx; j < K - 1 - i; ++j) avail[j] = avail[j + 1];
+    if (K - 1 - i > 0) fact /= (K - 1 - i);
+  }
+}
+
+template <int K>
+__global__ void __launch_bounds__(kDhtvThreads)
+    dhtv_kernel(const double* __restrict__ mask, double* __restrict__ feat_all,
+                int32_t* __restrict__ mapping_all, const int32_t* __restrict__ plan, int P, int F,
+                int T, int optimal, int32_t* __restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* cent = reinterpret_cast<double*>(smem);  // [K][T]
+  double* red = cent + (size_t)K * T;              // [kDhtvWaves]
+  int* flag = reinterpret_cast<int*>(red + kDhtvWaves);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t u = blockIdx.x;
+  const double* m = mask + u * (int64_t)K * F * T;
+  double* feat = feat_all + u * (int64_t)K * F * T;
+  int32_t* mapping = mapping_all + u * (int64_t)K * F;
+
+  // features = mask / max(||mask||, tiny) per (class, bin) row  (:310, :358-377)
+  int nonfinite = 0;
+  for (int row = wave; row < K * F; row += kDhtvWaves) {
+    const double* src = m + (int64_t)row * T;
+    double ss = 0.0;
+    for (int t = lane; t < T; t += kWave) {
+      double v = src[t];
+      ss += v * v;
+    }
+    ss = wave_sum(ss);
+    if (!isfinite(ss)) nonfinite = 1;
+    double inv = 1.0 / fmax(sqrt(ss), kTiny);
+    double* dst = feat + (int64_t)row * T;
+    for (int t = lane; t < T; t += kWave) dst[t] = src[t] * inv;
+  }
+  for (int i = tid; i < K * F; i += kDhtvThreads) mapping[i] = i / F;
+  if (tid == 0) *flag = 0;
+  __syncthreads();
+
+  for (int seg = 0; seg < P; ++seg) {
+    const int iterations = plan[3 * seg], start = plan[3 * seg + 1], end = plan[3 * seg + 2];
+    const double inv_n = 1.0 / (double)(end - start);
+    for (int it = 0; it < iterations; ++it) {
+      // time centroid = mean over the segment's bins, then unit norm per class (:334-340)
+      for (int col = tid; col < K * T; col += kDhtvThreads) {
+        const int k = col / T, t = col - k * T;
+        const double* p = feat + ((int64_t)k * F + start) * T + t;
+        double s = 0.0;
+        for (int f = start; f < end; ++f, p += T) s += *p;
+        cent[col] = s * inv_n;
+      }
+      __syncthreads();
+      for (int k = 0; k < K; ++k) {
+        double ss = 0.0;
+        for (int t = tid; t < T; t += kDhtvThreads) {
+          double v = cent[k * T + t];
+          ss += v * v;
+        }
+        ss = block_sum(ss, red, tid);
+        double inv = 1.0 / fmax(sqrt(ss), kTiny);
+        for (int t = tid; t < T; t += kDhtvThreads) cent[k * T + t] *= inv;
+      }
+      __syncthreads();
+      // every frequency of the segment against the centroid
+      int changed = 0;
+      for (int f = start + wave; f < end; f += kDhtvWaves) {
+        double sc[K][K];  // [reference class][mask class]  ('K...T,k...T->...kK')
+#pragma unroll
+        for (int a = 0; a < K; ++a)
+#pragma unroll
+          for (int b = 0; b < K; ++b) sc[a][b] = 0.0;
+        for (int t = lane; t < T; t += kWave) {
+          double fv[K], cv[K];
+#pragma unroll
+          for (int k = 0; k < K; ++k) {
+            fv[k] = feat[((int64_t)k * F + f) * T + t];
+            cv[k] = cent[k * T + t];
+          }
+#pragma unroll
+          for (int a = 0; a < K; ++a)
+#pragma unroll
+            for (int b = 0; b < K; ++b) sc[a][b] = fma(cv[a], fv[b], sc[a][b]);
+        }
+        bool finite = true;
+#pragma unroll
+        for (int a = 0; a < K; ++a)
+#pragma unroll
+          for (int b = 0; b < K; ++b) {
+            sc[a][b] = wave_sum(sc[a][b]);
+            finite = finite && isfinite(sc[a][b]);
+          }
+        if (!finite) nonfinite = 1;  // reference: ValueError('score matrix is infeasible')
+        int perm[K];
+        if (!optimal) {
+          // greedy: repeatedly take the flat (row-major) argmax, first maximum wins (:537-553)
+          bool row_used[K], col_used[K];
+#pragma unroll
+          for (int a = 0; a < K; ++a) {
+            row_used[a] = false;
+            col_used[a] = false;
+            perm[a] = a;
+          }
+#pragma unroll
+          for (int r = 0; r < K; ++r) {
+            double best = 0.0;
+            int bi = -1, bj = -1;
+#pragma unroll
+            for (int a = 0; a < K; ++a)
+#pragma unroll
+              for (int b = 0; b < K; ++b) {
+                // masked entries are -inf in the reference: an unmasked one always
+                // wins the first comparison; among all-masked (cannot happen) none
+                bool ok = !row_used[a] && !col_used[b];
+                if (ok && (bi < 0 || sc[a][b] > best)) {
+                  best = sc[a][b];
+                  bi = a;
+                  bj = b;
+                }
+              }
+#pragma unroll
+            for (int a = 0; a < K; ++a) {
+              if (a == bi) {
+                row_used[a] = true;
+                perm[a] = bj;
+              }
+              if (a == bj) col_used[a] = true;
+            }
+          }
+        } else {
+          // brute force over itertools.permutations order, strict improvement (:566-586)
+          int nperm = 1;
+          for (int i = 2; i <= K; ++i) nperm *= i;
+          double best = -1.79e308;
+#pragma unroll
+          for (int a = 0; a < K; ++a) perm[a] = a;
+          for (int n = 0; n < nperm; ++n) {
+            int p[kDhtvMaxK];
+            nth_permutation(n, K, p);
+            double v = 0.0;
+            for (int a = 0; a < K; ++a) {
+              double x = 0.0;
+#pragma unroll
+              for (int aa = 0; aa < K; ++aa)
+#pragma unroll
+                for (int bb = 0; bb < K; ++bb)
+                  if (aa == a && bb == p[a]) x = sc[aa][bb];
+              v += x;
+            }
+            if (v > best) {
+              best = v;
+#pragma unroll
+              for (int a = 0; a < K; ++a) perm[a] = p[a];
+            }
+          }
+        }
+        bool ident = true;
+#pragma unroll
+        for (int a = 0; a < K; ++a) ident = ident && (perm[a] == a);
+        if (!ident) {
+          changed = 1;
+          // features[:, f, :] = features[perm, f, :]; mapping[:, f] = mapping[perm, f] (:348-350)
+          for (int t = lane; t < T; t += kWave) {
+            double v[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) v[k] = feat[((int64_t)k * F + f) * T + t];
+#pragma unroll
+            for (int a = 0; a < K; ++a) {
+              double x = v[0];
+#pragma unroll
+              for (int k = 1; k < K; ++k) x = (perm[a] == k) ? v[k] : x;
+              feat[((int64_t)a * F + f) * T + t] = x;
+            }
+          }
+          if (lane == 0) {
+            int mv[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) mv[k] = mapping[k * F + f];
+#pragma unroll
+            for (int a = 0; a < K; ++a) {
+              int x = mv[0];
+#pragma unroll
+              for (int k = 1; k < K; ++k) x = (perm[a] == k) ? mv[k] : x;
+              mapping[a * F + f] = x;
+            }
+          }
+        }
+      }
+      if (changed && lane == 0) atomicOr(flag, 1);
+      __syncthreads();
+      const int any = *flag;
+      __syncthreads();
+      if (tid == 0) *flag = 0;
+      __syncthreads();
+      if (!any) break;  // nothing_changed (:352-353)
+    }
+  }
+  if (nonfinite && lane == 0) atomicOr(status + u, (int32_t)PBBSS_ST_NONFINITE);
+}
+
+// mask (U,K,F,T) gathered along the class axis: out[u,k,f,:] = mask[u,mapping[u,k,f],f,:]
+__global__ void __launch_bounds__(256)
+    apply_mapping_kernel(const double* __restrict__ mask, const int32_t* __restrict__ mapping,
+                         int K, int F, int T, double* __restrict__ out) {
+  const int64_t row = blockIdx.x;  // (u, k, f)
+  const int64_t u = row / ((int64_t)K * F);
+  const int f = (int)(row % F);
+  const int src_k = mapping[row];
+  const double* src = mask + ((u * K + src_k) * F + f) * (int64_t)T;
+  double* dst = out + row * (int64_t)T;
+  for (int t = threadIdx.x; t < T; t += blockDim.x) dst[t] = src[t];
+}
+
+int launch_dhtv(const double* mask, int64_t U, int K, int F, int T, const int32_t* plan, int P,
+                int optimal, double* feat, int32_t* mapping, int32_t* status, size_t lds_limit,
+                hipStream_t s) {
+  if (K < 1 || K > kDhtvMaxK) return PBBSS_ERR_UNSUPPORTED;
+  size_t lds = ((size_t)K * T + kDhtvWaves) * sizeof(double) + 16;
+  if (lds > lds_limit) return PBBSS_ERR_LDS_CAPACITY;
+#define PBBSS_DHTV_CASE(KK)                                                                     \
+  case KK: {                                                                                    \
+    auto kfn = dhtv_kernel<KK>;                                                                 \
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                                 \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+      return PBBSS_ERR_HIP;                                                                     \
+    hipLaunchKernelGGL(kfn, dim3((unsigned)U), dim3(kDhtvThreads), lds, s, mask, feat, mapping, \
+                       plan, P, F, T, optimal, status);                                         \
+  } break;
+  switch (K) {
+    PBBSS_DHTV_CASE(1)
+    PBBSS_DHTV_CASE(2)
+    PBBSS_DHTV_CASE(3)
+    PBBSS_DHTV_CASE(4)
+    PBBSS_DHTV_CASE(5)
+    PBBSS_DHTV_CASE(6)
+    PBBSS_DHTV_CASE(7)
+    PBBSS_DHTV_CASE(8)
+    default: return PBBSS_ERR_UNSUPPORTED;
+  }
+#undef PBBSS_DHTV_CASE
+  return hipGetLastError() == hipSuccess ? PBBSS_OK : PBBSS_ERR_HIP;
+}
+
+int launch_apply_mapping(const double* mask, const int32_t* mapping, int64_t U, int K, int F,
+                         int T, double* out, hipStream_t s) {
+  int64_t rows = U * K * F;
+  if (rows > 2147483647LL) return PBBSS_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(apply_mapping_kernel, dim3((unsigned)rows), dim3(256), 0, s, mask, mapping, K,
+                     F, T, out);
+  return hipGetLastError() == hipSuccess ? PBBSS_OK : PBBSS_ERR_HIP;
+}
+
+}  // namespace pbbss

@@ -282,3 +282,31 @@ def last_kernel_ms(device_index=None):
     _lib.check(_lib.load().pbbss_last_kernel_ms(_lib.handle(device_index), ctypes.byref(ms)),
                'last_kernel_ms')
     return float(ms.value)
+
+
+def dhtv_calculate_mapping(mask, plan, optimal=False):
+    """pbbss_dhtv_calculate_mapping: mask (U,K,F,T) f64, plan int32 (P,3) on the
+    device -> (mapping int32 (U,K,F), aligned unit-norm features (U,K,F,T), status (U,))."""
+    t = _t()
+    U, K, F, T = mask.shape
+    feat = t.empty_like(mask)
+    mapping = t.empty((U, K, F), dtype=t.int32, device=mask.device)
+    st = t.zeros((U,), dtype=t.int32, device=mask.device)
+    rc = _lib.load().pbbss_dhtv_calculate_mapping(
+        _lib.handle(mask.device.index), _lib.ptr(mask), U, K, F, T, _lib.ptr(plan),
+        int(plan.shape[0]), int(bool(optimal)), _lib.ptr(feat), _lib.ptr(mapping),
+        _lib.ptr(st), _lib.stream_ptr(mask.device.index))
+    _lib.check(rc, f'dhtv_calculate_mapping(U={U},K={K},F={F},T={T})')
+    return mapping, feat, st
+
+
+def apply_mapping(mask, mapping):
+    """pbbss_apply_mapping: mask (U,K,F,T) f64, mapping int32 (U,K,F) -> (U,K,F,T)."""
+    t = _t()
+    U, K, F, T = mask.shape
+    out = t.empty_like(mask)
+    rc = _lib.load().pbbss_apply_mapping(
+        _lib.handle(mask.device.index), _lib.ptr(mask), _lib.ptr(mapping), U, K, F, T,
+        _lib.ptr(out), _lib.stream_ptr(mask.device.index))
+    _lib.check(rc, f'apply_mapping(U={U},K={K},F={F},T={T})')
+    return out

@@ -1,0 +1,142 @@
+"""Frequency-permutation alignment on the device (DHTV).
+
+Mirrors pb_bss/permutation_alignment.py for the solver that follows the EM in
+the canonical pipeline (`DHTVPermutationAlignment.from_stft_size(...)(mask)`,
+examples/mixture_model_example.ipynb): same constructor arguments, presets,
+`alignment_plan`, `calculate_mapping`, `apply_mapping`, `__call__`.
+The whole plan runs in one kernel launch (csrc/dhtv.hip); masks are
+(K, F, T) like the reference, or (..., K, F, T) for batches of utterances.
+
+Device coverage: similarity_metric 'cos' (the default of `from_stft_size`)
+with algorithm 'greedy' (default) or 'optimal'.  Other metrics raise
+NotImplementedError.
+"""
+import numpy as np
+
+from . import _lib, engine
+
+__all__ = ['DHTVPermutationAlignment', 'apply_mapping']
+
+
+def _interleave(a, b):
+    out = []
+    for i in range(max(len(a), len(b))):
+        out.extend(x[i] for x in (a, b) if i < len(x))
+    return out
+
+
+def apply_mapping(mask, mapping):
+    """mask (K, F, ...) [or (..., K, F, T)], reverse mapping (K, F): frequency-aligned
+    mask, `mask[mapping, range(F)]` in the reference (permutation_alignment.py:54-104)."""
+    like_torch = _lib.is_torch(mask)
+    t = _lib.torch()
+    m = _lib.to_device(mask, t.float64)
+    mp = _lib.to_device(mapping).to(m.device).to(t.int32)
+    if m.ndim == 2:  # (K, F): trailing axis of length 1
+        m = m[..., None]
+    *lead, K, F, T = m.shape
+    assert K < 20, (K, mapping.shape)
+    assert tuple(mp.shape[-2:]) == (K, F), (mask.shape, mapping.shape)
+    out = engine.apply_mapping(m.reshape(-1, K, F, T).contiguous(),
+                               mp.expand(*lead, K, F).reshape(-1, K, F).contiguous())
+    out = out.reshape(*lead, K, F, T)
+    if np.ndim(mask) == 2:
+        out = out[..., 0]
+    return out if like_torch else _lib.to_host(out)
+
+
+class _PermutationAlignment:
+    def calculate_mapping(self, mask, *args, **kwargs):
+        raise NotImplementedError()
+
+    def __call__(self, mask, *args, **kwargs):
+        mapping = self.calculate_mapping(mask, *args, **kwargs)
+        return self.apply_mapping(mask, mapping)
+
+    @staticmethod
+    def apply_mapping(mask, mapping):
+        return apply_mapping(mask, mapping)
+
+
+class DHTVPermutationAlignment(_PermutationAlignment):
+    """Segment-wise centroid alignment (reference :133-355; does not solve the
+    global permutation problem)."""
+
+    def __init__(self, *, stft_size, segment_start, segment_width, segment_shift,
+                 main_iterations, sub_iterations, similarity_metric='cos',
+                 algorithm='greedy'):
+        self.stft_size = stft_size
+        self.segment_start = segment_start
+        self.segment_width = segment_width
+        self.segment_shift = segment_shift
+        self.main_iterations = main_iterations
+        self.sub_iterations = sub_iterations
+        self.similarity_metric = similarity_metric
+        self.algorithm = algorithm
+
+    @classmethod
+    def from_stft_size(cls, stft_size, similarity_metric='cos'):
+        """Presets of the reference (:164-184)."""
+        if stft_size == 512:
+            start = 70
+        elif stft_size == 1024:
+            start = 100
+        else:
+            raise ValueError('There is no default for stft_size={}.', stft_size)
+        return cls(stft_size=stft_size, segment_start=start, segment_width=100,
+                   segment_shift=20, main_iterations=20, sub_iterations=2,
+                   similarity_metric=similarity_metric)
+
+    @property
+    def alignment_plan(self):
+        """[[iterations, start, end], ...] (reference :204-293): the seed segment
+        with `main_iterations`, then segments grown alternately towards high
+        and low frequencies with `sub_iterations` each."""
+        F = self.stft_size // 2 + 1
+        if self.segment_start + self.segment_width > F:
+            raise ValueError(
+                f'segment_start ({self.segment_start}) '
+                f'+ segment_width ({self.segment_width})\n'
+                f'must be smaller than stft_size // 2 + 1 ({F}),\n'
+                f'but it is {self.segment_start + self.segment_width}')
+        w, sh = self.segment_width, self.segment_shift
+        up = [[self.sub_iterations, s, s + w]
+              for s in range(self.segment_start + sh, F - w, sh)]
+        down = [[self.sub_iterations, s, s + w]
+                for s in range(self.segment_start - sh, 0, -sh)]
+        first = [self.main_iterations, self.segment_start, self.segment_start + w]
+        if up:
+            up[-1][-1] = F
+        else:
+            first[-1] = F
+        if down:
+            down[-1][1] = 0
+        else:
+            first[1] = 0
+        return [first] + _interleave(up, down)
+
+    def calculate_mapping(self, mask, plot=False):
+        """mask (K, F, T) [or (..., K, F, T)] -> reverse mapping (K, F) int64."""
+        if plot:
+            raise NotImplementedError('plot=True needs paderbox; use the reference for plots')
+        if self.similarity_metric != 'cos':
+            raise NotImplementedError(
+                f'similarity_metric={self.similarity_metric!r}: only the default '
+                "'cos' runs on the device")
+        if self.algorithm not in ('greedy', 'optimal'):
+            raise ValueError(self.algorithm)
+        like_torch = _lib.is_torch(mask)
+        t = _lib.torch()
+        m = _lib.to_device(mask, t.float64)
+        *lead, K, F, T = m.shape
+        assert F % 2 == 1, (F, 'Sure? Usually F is odd.')
+        assert K < 10, (K, 'Sure?')
+        plan = np.asarray(self.alignment_plan, dtype=np.int32)
+        assert plan[:, 2].max() <= F and plan[:, 1].min() >= 0, (plan, F)
+        mapping, _, st = engine.dhtv_calculate_mapping(
+            m.reshape(-1, K, F, T).contiguous(), _lib.to_device(plan).to(m.device),
+            optimal=(self.algorithm == 'optimal'))
+        if int(st.max().item()) != 0:
+            raise ValueError('score matrix is infeasible')  # reference :512-514
+        mapping = mapping.reshape(*lead, K, F).to(t.int64)
+        return mapping if like_torch else _lib.to_host(mapping)

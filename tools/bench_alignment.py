@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Timing of the device DHTV permutation alignment vs the NumPy oracle
+(K=3, F=513, T=500: the masks of BASELINE config 2)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from oracle import permutation_alignment as op
+from pb_bss_amd import _lib, engine
+from pb_bss_amd.permutation_alignment import DHTVPermutationAlignment
+
+rng = np.random.default_rng(0)
+K, F, T = 3, 513, 500
+act = rng.uniform(size=(K, T)) ** 4
+mask = act[:, None, :] * rng.uniform(0.5, 1.0, size=(K, F, T)) + 0.05 * rng.uniform(size=(K, F, T))
+mask /= mask.sum(0, keepdims=True)
+perm = np.stack([rng.permutation(K) for _ in range(F)], 1)
+pm = mask[perm, range(F)]
+solver = DHTVPermutationAlignment.from_stft_size(1024)
+plan = _lib.to_device(np.asarray(solver.alignment_plan, np.int32))
+for U in (1, 16, 64):
+    m = _lib.to_device(np.broadcast_to(pm, (U, K, F, T)).copy())
+    engine.dhtv_calculate_mapping(m, plan)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(5):
+        mapping, feat, st = engine.dhtv_calculate_mapping(m, plan)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
+    print(f'device DHTV U={U}: {dt*1e3:.3f} ms per call, {dt/U*1e3:.3f} ms/utterance')
+t0 = time.perf_counter(); ref = op.dhtv_calculate_mapping(pm, solver.alignment_plan); dt = time.perf_counter() - t0
+print(f'NumPy oracle: {dt*1e3:.1f} ms/utterance; identical mapping: {(ref == _lib.to_host(mapping[0])).all()}')
