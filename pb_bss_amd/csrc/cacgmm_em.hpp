@@ -94,6 +94,7 @@ struct EmKernel {
     double* apack;   // [K][NA]       A_k packed for the dot with P: diag, then (2Re, 2Im) per pair
     double* wgt;     // [K]           mixture weights
     double* detm;    // [K]           det B_k mantissa
+    double* rdet;    // [K]           1 / detm
     double* red;     // [kEmWaves][K] cross-wave partial sums
     double* ssum;    // [K]           sum_t gamma_kt (saliency applied)
     int* dete;       // [K]           det B_k exponent
@@ -110,7 +111,7 @@ struct EmKernel {
     size_t n = 0;
     n += (size_t)K * D * D * 16;
     n += (size_t)K * NA * 8;
-    n += (size_t)K * 8 * 3;         // wgt, detm, ssum
+    n += (size_t)K * 8 * 4;         // wgt, detm, rdet, ssum
     n += (size_t)kEmWaves * K * 8;  // red
     n += (size_t)K * 4 * 2 + 16;    // dete, status, flags
     return n;
@@ -142,6 +143,8 @@ struct EmKernel {
     L.wgt = reinterpret_cast<double*>(p);
     p += K * 8;
     L.detm = reinterpret_cast<double*>(p);
+    p += K * 8;
+    L.rdet = reinterpret_cast<double*>(p);
     p += K * 8;
     L.ssum = reinterpret_cast<double*>(p);
     p += K * 8;
@@ -339,11 +342,12 @@ struct EmKernel {
       }
       // per-class constants (fetched here, not at phase entry: keeping them live
       // across the operand loop costs spills)
-      double detm[K], wgt[K];
+      double detm[K], rdet[K], wgt[K];
       int dete[K];
 #pragma unroll
       for (int k = 0; k < K; ++k) {
         detm[k] = L.detm[k];
+        rdet[k] = L.rdet[k];
         dete[k] = L.dete[k];
         wgt[k] = L.wgt[k];
       }
@@ -353,7 +357,9 @@ struct EmKernel {
         const double inv = L.inv_n2[t];
         // softmax over classes in mantissa/exponent form:
         //   exp(log_pdf_k) = 1 / (det_k q_k^D)   (cacg.py:200-201)
-        double val[K];
+        // with q = m 2^e: one reciprocal of the mantissa serves both 1/q (M-step
+        // weight) and q^-D = (1/m)^D 2^(-eD); 1/det_k is precomputed per class.
+        double val[K], rq[K];
         int ex[K];
         int emax = INT32_MIN;
 #pragma unroll
@@ -362,7 +368,9 @@ struct EmKernel {
           q[f][k] = qq;
           int e;
           double m = frexp(qq, &e);
-          val[k] = 1.0 / (detm[k] * ipow<D>(m));
+          double rm = fast_rcp(m);            // m in [0.5, 1)
+          rq[k] = ldexp(rm, -e);              // 1/q (finite: q >= tiny)
+          val[k] = rdet[k] * ipow<D>(rm);
           ex[k] = -(e * D + dete[k]);
           emax = max(emax, ex[k]);
         }
@@ -382,10 +390,11 @@ struct EmKernel {
           den += v;
         }
         den = fmax(den, kTiny);  // mixture_model_utils.py:43-47
+        const double rden = fast_rcp(den);
         const double sal = (!FINAL && a.saliency) ? a.saliency[(size_t)b * a.T + t] : 1.0;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-          double gam = g[k] / den;
+          double gam = g[k] * rden;
           if (eps != 0.0) gam = fmin(fmax(gam, eps), 1.0 - eps);  // :50-53, no renormalisation
           if constexpr (FINAL) {
             if (ok[f]) {
@@ -400,7 +409,10 @@ struct EmKernel {
             }
           } else {
             double gs = ok[f] ? gam * sal : 0.0;
-            if (ok[f]) L.wbuf[(size_t)k * L.Tp + t] = mweight(gs, q[f][k], inv);
+            // M-step weight gamma/max(q, 10 tiny)/|y|^2 (cacg.py:310, :322); q >= 10 tiny
+            // except for all-zero frames, where inv = 0 makes the weight 0 anyway
+            double rqk = (q[f][k] >= 10.0 * kTiny) ? rq[k] : (1.0 / (10.0 * kTiny));
+            if (ok[f]) L.wbuf[(size_t)k * L.Tp + t] = gs * rqk * inv;
             s[k] += gs;
           }
         }
@@ -566,6 +578,7 @@ struct EmKernel {
           store_apack(L, k, c, gre, gim);
           if (lane == 0) {
             L.detm[k] = det.m;
+            L.rdet[k] = 1.0 / det.m;
             L.dete[k] = det.e;
           }
         }
@@ -626,6 +639,7 @@ struct EmKernel {
       for (int e = 0; e < D; ++e) scaled_mul(det, fmax(lane_get(lout, ij_lane(0, e)), kTiny));
       if (lane == 0) {
         L.detm[k] = det.m;
+        L.rdet[k] = 1.0 / det.m;
         L.dete[k] = det.e;
       }
     }
@@ -652,6 +666,7 @@ struct EmKernel {
     for (int e = 0; e < D; ++e) scaled_mul(det, fmax(lane_get(lam, ij_lane(0, e)), kTiny));
     if (lane == 0) {
       L.detm[k] = det.m;
+      L.rdet[k] = 1.0 / det.m;
       L.dete[k] = det.e;
       // loop E-steps read wgt from LDS; a (b,k)-strided weight is enough there
       L.wgt[k] = a.in_weight ? a.in_weight[b * a.wb + k * a.wk] : 1.0 / K;

@@ -166,6 +166,18 @@ __device__ __forceinline__ void wave_sum2(double& a, double& b) {
   }
 }
 
+
+// 1/x to ~1 ulp for finite normal x: hardware estimate + two Newton steps
+// (5 VALU instructions instead of the ~11 of an IEEE-correct division).
+__device__ __forceinline__ double fast_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  double e = fma(-x, r, 1.0);
+  r = fma(e, r, r);
+  e = fma(-x, r, 1.0);
+  r = fma(e, r, r);
+  return r;
+}
+
 constexpr double kTiny = 2.2250738585072014e-308;  // np.finfo(np.float64).tiny
 
 }  // namespace pbbss
