@@ -48,20 +48,98 @@ __device__ __forceinline__ double lane_get(double v, int src_lane) {
 __device__ __forceinline__ int lane_get(int v, int src_lane) {
   return __shfl(v, src_lane, kWave);
 }
-// all-reduce sum over the 64 lanes (every lane receives the total)
+// ---- DPP / permlane-swap building blocks (VALU only, no LDS crossbar) -------
+// DPP controls (gfx9 encoding)
+constexpr int kDppQuadXor1 = 0xB1;       // quad_perm [1,0,3,2]
+constexpr int kDppQuadXor2 = 0x4E;       // quad_perm [2,3,0,1]
+constexpr int kDppQuadIdent = 0xE4;      // quad_perm [0,1,2,3]
+constexpr int kDppRowHalfMirror = 0x141; // lane l <-> 7-l inside each 8 lanes
+constexpr int kDppRowMirror = 0x140;     // lane l <-> 15-l inside each 16-lane row
+constexpr int kDppRowRor4 = 0x124, kDppRowRor8 = 0x128, kDppRowRor12 = 0x12C;
+
+union F64Bits {
+  double d;
+  int i[2];
+  unsigned u[2];
+};
+
+// result lane l = enabled(bank) ? src[perm(l)] : old[l]
+template <int CTRL, int BANK>
+__device__ __forceinline__ double dpp_f64(double old, double src) {
+  F64Bits o, s, r;
+  o.d = old;
+  s.d = src;
+  r.i[0] = __builtin_amdgcn_update_dpp(o.i[0], s.i[0], CTRL, 0xF, BANK, false);
+  r.i[1] = __builtin_amdgcn_update_dpp(o.i[1], s.i[1], CTRL, 0xF, BANK, false);
+  return r.d;
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int src) {
+  return __builtin_amdgcn_update_dpp(src, src, CTRL, 0xF, 0xF, false);
+}
+// v_permlane32_swap: a[32..63] <-> b[0..31];  v_permlane16_swap: odd rows of a <-> even rows of b
+__device__ __forceinline__ void swap32_f64(double& a, double& b) {
+  F64Bits A, B;
+  A.d = a;
+  B.d = b;
+  auto r0 = __builtin_amdgcn_permlane32_swap(A.u[0], B.u[0], false, false);
+  auto r1 = __builtin_amdgcn_permlane32_swap(A.u[1], B.u[1], false, false);
+  A.u[0] = r0[0];
+  B.u[0] = r0[1];
+  A.u[1] = r1[0];
+  B.u[1] = r1[1];
+  a = A.d;
+  b = B.d;
+}
+__device__ __forceinline__ void swap16_f64(double& a, double& b) {
+  F64Bits A, B;
+  A.d = a;
+  B.d = b;
+  auto r0 = __builtin_amdgcn_permlane16_swap(A.u[0], B.u[0], false, false);
+  auto r1 = __builtin_amdgcn_permlane16_swap(A.u[1], B.u[1], false, false);
+  A.u[0] = r0[0];
+  B.u[0] = r0[1];
+  A.u[1] = r1[0];
+  B.u[1] = r1[1];
+  a = A.d;
+  b = B.d;
+}
+
+// all-reduce over the 64 lanes with a binary op (every lane receives the result):
+// quad permutes, 8- and 16-lane mirrors, then the two cross-row swaps.
+template <typename Op>
+__device__ __forceinline__ double wave_allreduce(double v, Op op) {
+  v = op(v, dpp_f64<kDppQuadXor1, 0xF>(v, v));
+  v = op(v, dpp_f64<kDppQuadXor2, 0xF>(v, v));
+  v = op(v, dpp_f64<kDppRowHalfMirror, 0xF>(v, v));
+  v = op(v, dpp_f64<kDppRowMirror, 0xF>(v, v));
+  double a = v, b = v;
+  swap16_f64(a, b);
+  v = op(a, b);
+  a = v;
+  b = v;
+  swap32_f64(a, b);
+  return op(a, b);
+}
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = kWave / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
-  return v;
+  return wave_allreduce(v, [](double x, double y) { return x + y; });
 }
 __device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-  for (int o = kWave / 2; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, kWave));
-  return v;
+  return wave_allreduce(v, [](double x, double y) { return fmax(x, y); });
 }
 __device__ __forceinline__ int wave_or(int v) {
-#pragma unroll
-  for (int o = kWave / 2; o > 0; o >>= 1) v |= __shfl_xor(v, o, kWave);
+  v |= dpp_i32<kDppQuadXor1>(v);
+  v |= dpp_i32<kDppQuadXor2>(v);
+  v |= dpp_i32<kDppRowHalfMirror>(v);
+  v |= dpp_i32<kDppRowMirror>(v);
+  {
+    auto r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+    v = (int)(r[0] | r[1]);
+  }
+  {
+    auto r = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+    v = (int)(r[0] | r[1]);
+  }
   return v;
 }
 
@@ -117,37 +195,61 @@ __device__ __forceinline__ double lane_bcast_const(double v, int src_lane_unifor
 // of 16.  On return v[0 .. N/16) hold the totals of the original indices
 //     base + m,  base = (N/16) * (b2 + 2*b3 + 4*b4 + 8*b5)   (b_i = lane bit i)
 // on every lane (lanes differing only in bits 1..0 hold identical values).
-// All exchanges of a step are independent, so their ds_bpermute latencies overlap
-// (the naive "one all-reduce per value" chain is ~10x slower: 6 dependent hops each).
+// Bits 5 and 4 use v_permlane32_swap / v_permlane16_swap (gfx950): swapping the
+// (lower, upper) value pair between partner lanes and adding leaves the lower
+// value's pair-sum on the bit-clear lanes and the upper value's on the bit-set
+// lanes -- two swaps and one add per output, no selects.  Bits 3 and 2 use DPP
+// row rotations with bank masks, bits 1 and 0 DPP quad permutes.  Everything is
+// VALU: no ds_bpermute, nothing on the LDS pipe.
 template <int N>
 __device__ __forceinline__ void wave_reduce_scatter(double (&v)[N], int lane) {
   static_assert(N % 16 == 0, "pad to a multiple of 16");
-  static_for<0, 4>([&](auto sc) {
-    constexpr int s = sc;
-    constexpr int H = N >> (s + 1);
-    constexpr int bit = 32 >> s;
-    const bool up = (lane & bit) != 0;
-    double send[H];
+  (void)lane;
+  {  // bit 5
+    constexpr int H = N / 2;
 #pragma unroll
     for (int n = 0; n < H; ++n) {
       double lo = v[n], hi = v[n + H];
-      send[n] = up ? lo : hi;
-      v[n] = up ? hi : lo;
+      swap32_f64(lo, hi);
+      v[n] = lo + hi;
     }
+  }
+  {  // bit 4
+    constexpr int H = N / 4;
 #pragma unroll
-    for (int n = 0; n < H; ++n) send[n] = __shfl_xor(send[n], bit, kWave);
+    for (int n = 0; n < H; ++n) {
+      double lo = v[n], hi = v[n + H];
+      swap16_f64(lo, hi);
+      v[n] = lo + hi;
+    }
+  }
+  {  // bit 3: partner = lane ^ 8 inside the 16-lane row (rotation by 8); banks 0,1 are bit-clear
+    constexpr int H = N / 8;
 #pragma unroll
-    for (int n = 0; n < H; ++n) v[n] += send[n];
-  });
+    for (int n = 0; n < H; ++n) {
+      double lo = v[n], hi = v[n + H];
+      double recv = dpp_f64<kDppRowRor8, 0x3>(lo, lo);   // bit-clear lanes <- partner's lower value
+      recv = dpp_f64<kDppRowRor8, 0xC>(recv, hi);        // bit-set lanes   <- partner's upper value
+      double keep = dpp_f64<kDppQuadIdent, 0xC>(lo, hi);  // own lower / own upper
+      v[n] = keep + recv;
+    }
+  }
+  {  // bit 2: partner = lane ^ 4; banks 0,2 are bit-clear (take from lane+4 = ror 12), 1,3 bit-set
+    constexpr int H = N / 16;
+#pragma unroll
+    for (int n = 0; n < H; ++n) {
+      double lo = v[n], hi = v[n + H];
+      double recv = dpp_f64<kDppRowRor12, 0x5>(lo, lo);
+      recv = dpp_f64<kDppRowRor4, 0xA>(recv, hi);
+      double keep = dpp_f64<kDppQuadIdent, 0xA>(lo, hi);
+      v[n] = keep + recv;
+    }
+  }
   constexpr int R = N / 16;
 #pragma unroll
-  for (int o = 2; o > 0; o >>= 1) {
-    double t[R];
+  for (int n = 0; n < R; ++n) v[n] += dpp_f64<kDppQuadXor2, 0xF>(v[n], v[n]);
 #pragma unroll
-    for (int n = 0; n < R; ++n) t[n] = __shfl_xor(v[n], o, kWave);
-#pragma unroll
-    for (int n = 0; n < R; ++n) v[n] += t[n];
-  }
+  for (int n = 0; n < R; ++n) v[n] += dpp_f64<kDppQuadXor1, 0xF>(v[n], v[n]);
 }
 // first original index owned by `lane` after wave_reduce_scatter<N>
 template <int N>
@@ -155,17 +257,11 @@ __device__ __forceinline__ int reduce_scatter_base(int lane) {
   return (N / 16) * ((lane >> 2) & 15);
 }
 
-// two interleaved all-reduce sums (halves the dependent-hop latency of two
-// back-to-back wave_sum calls)
+// two all-reduce sums (independent instruction streams interleave)
 __device__ __forceinline__ void wave_sum2(double& a, double& b) {
-#pragma unroll
-  for (int o = kWave / 2; o > 0; o >>= 1) {
-    double ta = __shfl_xor(a, o, kWave), tb = __shfl_xor(b, o, kWave);
-    a += ta;
-    b += tb;
-  }
+  a = wave_sum(a);
+  b = wave_sum(b);
 }
-
 
 // 1/x to ~1 ulp for finite normal x: hardware estimate + two Newton steps
 // (5 VALU instructions instead of the ~11 of an IEEE-correct division).
