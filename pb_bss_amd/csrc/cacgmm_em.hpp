@@ -544,7 +544,29 @@ struct EmKernel {
                                       bool last) {
     const LaneIJ c = lane_ij(lane);
     const bool valid = c.i < D && c.j < D;
-    const double S = L.ssum[k];
+    // class sums of the E phase (per-wave partials in L.red) -> sum_t gamma_kt and the
+    // new mixture weight (mixture_model_utils.py:133-203); done here by the wave that
+    // owns class k instead of a separate single-thread step between two barriers
+    double S = 0.0, tot = 0.0;
+#pragma unroll
+    for (int kk = 0; kk < K; ++kk) {
+      double sk = 0.0;
+#pragma unroll
+      for (int w = 0; w < kEmWaves; ++w) sk += L.red[w * K + kk];
+      tot += fabs(sk);
+      S = (kk == k) ? sk : S;
+    }
+    if (lane == 0) {
+      double wnew;
+      if (a.weight_mode == PBBSS_WEIGHT_UNIFORM) {
+        wnew = 1.0 / K;  // :180-183
+      } else if (a.saliency) {
+        wnew = S / ((tot == 0.0) ? 1e-10 : tot);  // :192-201
+      } else {
+        wnew = S / (double)a.T;  // :188
+      }
+      L.wgt[k] = wnew;
+    }
     const double scale = (double)D / fmax(S, kTiny);  // cacg.py:316, :327
     double are = 0.0, aim = 0.0;
     if (valid) {
@@ -673,33 +695,6 @@ struct EmKernel {
     }
   }
 
-  // class sums -> mixture weights  (mixture_model_utils.py:133-203)
-  static __device__ void finish_sums(const EmArgs& a, const Lds& L, int tid) {
-    if (tid == 0) {
-      double s[K], tot = 0.0;
-#pragma unroll
-      for (int k = 0; k < K; ++k) {
-        s[k] = 0.0;
-#pragma unroll
-        for (int w = 0; w < kEmWaves; ++w) s[k] += L.red[w * K + k];
-        L.ssum[k] = s[k];
-        tot += fabs(s[k]);
-      }
-#pragma unroll
-      for (int k = 0; k < K; ++k) {
-        double w;
-        if (a.weight_mode == PBBSS_WEIGHT_UNIFORM) {
-          w = 1.0 / K;  // :180-183
-        } else if (a.saliency) {
-          w = s[k] / ((tot == 0.0) ? 1e-10 : tot);  // :192-201
-        } else {
-          w = s[k] / (double)a.T;  // :188
-        }
-        L.wgt[k] = w;
-      }
-    }
-  }
-
   static __device__ void run(const EmArgs& a, char* smem) {
     const int tid = threadIdx.x;
     // wave index is uniform across the wavefront: tell the compiler so the phase
@@ -733,17 +728,11 @@ struct EmKernel {
         phase_init_gamma(a, L, b, tid, wave, lane);
       }
       __syncthreads();
-      if (!model_in) {
-        finish_sums(a, L, tid);
-        __syncthreads();
-      }
       PBBSS_TICK(0)
       for (int it = 0; it < a.iterations; ++it) {
         if (it > 0 || model_in) {
           phase_e<false, false>(a, L, b, tid, wave, lane, a.aff_eps);
           PBBSS_TICK(1)
-          __syncthreads();
-          finish_sums(a, L, tid);
           __syncthreads();
           PBBSS_TICK(2)
         }

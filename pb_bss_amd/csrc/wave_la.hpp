@@ -77,26 +77,26 @@ __device__ __forceinline__ int wave_hpd_inverse(double& are, double& aim, LaneIJ
     bool good = (d > 0.0) && (d < 1.79e308);
     if (!good && info == 0) info = p + 1;
     double ds = good ? d : 1.0;
-    scaled_mul(det, ds);
-    double inv = 1.0 / ds;
+    int ex;
+    det.m *= frexp(ds, &ex);  // mantissas in [0.5, 1): D <= 8 factors cannot underflow
+    det.e += ex;
+    double inv = fast_rcp(ds);
     double rr = lane_get(are, ij_lane(p, c.j)), ri = lane_get(aim, ij_lane(p, c.j));  // a_pj
     double cr = lane_get(are, ij_lane(c.i, p)), ci = lane_get(aim, ij_lane(c.i, p));  // a_ip
     const bool ip = (c.i == p), jp = (c.j == p);
-    if (ip && jp) {
-      are = inv;
-      aim = 0.0;
-    } else if (ip) {
-      are = rr * inv;
-      aim = ri * inv;
-    } else if (jp) {
-      are = -cr * inv;
-      aim = -ci * inv;
-    } else {
-      double tr = (cr * rr - ci * ri) * inv, ti = (cr * ri + ci * rr) * inv;
-      are -= tr;
-      aim -= ti;
-    }
+    // branch-free form of the four update rules
+    double tr = (cr * rr - ci * ri) * inv, ti = (cr * ri + ci * rr) * inv;
+    double row_r = rr * inv, row_i = ri * inv;      // i == p, j != p
+    double col_r = -cr * inv, col_i = -ci * inv;    // j == p, i != p
+    double gen_r = are - tr, gen_i = aim - ti;      // i != p, j != p
+    double nr = ip ? (jp ? inv : row_r) : (jp ? col_r : gen_r);
+    double ni = ip ? (jp ? 0.0 : row_i) : (jp ? col_i : gen_i);
+    are = nr;
+    aim = ni;
   }
+  int e2;
+  det.m = frexp(det.m, &e2);
+  det.e += e2;
   return info;
 }
 
