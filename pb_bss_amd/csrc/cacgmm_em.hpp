@@ -776,8 +776,12 @@ struct EmKernel {
   }
 };
 
+// Register budget: K <= 4 fits 168 VGPRs (3 workgroups per CU, the LDS limit at T=500);
+// more classes need more M-phase accumulators (16 float64 per class) -> 2 per CU.
+constexpr int em_waves_per_simd(int K) { return K <= 4 ? 3 : 2; }
+
 template <int D, int K, typename YS, bool SPILL>
-__global__ void __launch_bounds__(kEmThreads, 3) cacgmm_em_kernel(EmArgs a) {
+__global__ void __launch_bounds__(kEmThreads, em_waves_per_simd(K)) cacgmm_em_kernel(EmArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   EmKernel<D, K, YS, SPILL>::run(a, smem);
 }

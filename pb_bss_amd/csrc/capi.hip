@@ -58,7 +58,7 @@ PBBSS_API const char* pbbss_error_string(int code) {
     case PBBSS_OK: return "ok";
     case PBBSS_ERR_INVALID_ARG: return "invalid argument";
     case PBBSS_ERR_UNSUPPORTED:
-      return "shape not covered by the compiled kernels (need 2 <= D <= 8, 1 <= K <= 4)";
+      return "shape not covered by the compiled kernels (need 2 <= D <= 8, 1 <= K <= 6)";
     case PBBSS_ERR_HIP: return "HIP runtime error";
     case PBBSS_ERR_LDS_CAPACITY:
       return "observation does not fit the LDS-resident EM kernel (too many frames)";
@@ -156,7 +156,7 @@ PBBSS_API int pbbss_cacgmm_fit(pbbss_handle_t h, const void* y, int64_t B, int T
   if (!out_eigvec || !out_eigval || !out_weight || !out_status) return PBBSS_ERR_INVALID_ARG;
   if (o->covariance_norm < 0 || o->covariance_norm > 2) return PBBSS_ERR_INVALID_ARG;
   if (o->weight_mode < 0 || o->weight_mode > 1) return PBBSS_ERR_INVALID_ARG;
-  if (D < 2 || D > 8 || K < 1 || K > 4) return PBBSS_ERR_UNSUPPORTED;
+  if (D < 2 || D > 8 || K < 1 || K > 6) return PBBSS_ERR_UNSUPPORTED;
   pbbss::EmArgs a{};
   a.y = y;
   a.B = B;
@@ -199,7 +199,7 @@ PBBSS_API int pbbss_cacgmm_predict(pbbss_handle_t h, const void* y, int64_t B, i
                                    void* stream) {
   if (!h || !y || !eigvec || !eigval || !weight || B <= 0 || T <= 0) return PBBSS_ERR_INVALID_ARG;
   if (!out_affiliation && !out_quadratic_form && !out_log_pdf) return PBBSS_ERR_INVALID_ARG;
-  if (D < 2 || D > 8 || K < 1 || K > 4) return PBBSS_ERR_UNSUPPORTED;
+  if (D < 2 || D > 8 || K < 1 || K > 6) return PBBSS_ERR_UNSUPPORTED;
   pbbss::EmArgs a{};
   a.y = y;
   a.B = B;
@@ -231,7 +231,7 @@ PBBSS_API int pbbss_cacg_m_step(pbbss_handle_t h, const void* y, int64_t B, int 
   if (!h || !y || !saliency || B <= 0 || T <= 0) return PBBSS_ERR_INVALID_ARG;
   if (!out_eigvec || !out_eigval || !out_status) return PBBSS_ERR_INVALID_ARG;
   if (covariance_norm < 0 || covariance_norm > 2) return PBBSS_ERR_INVALID_ARG;
-  if (D < 2 || D > 8 || K < 1 || K > 4) return PBBSS_ERR_UNSUPPORTED;
+  if (D < 2 || D > 8 || K < 1 || K > 6) return PBBSS_ERR_UNSUPPORTED;
   pbbss::EmArgs a{};
   a.y = y;
   a.B = B;

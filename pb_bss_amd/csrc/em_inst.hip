@@ -47,6 +47,8 @@ static int launch_k(int K, const EmArgs& a, const EmLaunchCfg& cfg, hipStream_t 
     case 2: return launch_one<2, YS>(a, cfg, stream);
     case 3: return launch_one<3, YS>(a, cfg, stream);
     case 4: return launch_one<4, YS>(a, cfg, stream);
+    case 5: return launch_one<5, YS>(a, cfg, stream);
+    case 6: return launch_one<6, YS>(a, cfg, stream);
     default: return PBBSS_ERR_UNSUPPORTED;
   }
 }

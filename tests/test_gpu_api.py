@@ -147,7 +147,7 @@ def test_unsupported_shapes_fail_loudly():
         CACGMMTrainer().fit(x, num_classes=2, iterations=1)  # D = 9 > 8
     x = rng.standard_normal((2, 50, 4)) + 1j * rng.standard_normal((2, 50, 4))
     with pytest.raises(NotImplementedError):
-        CACGMMTrainer().fit(x, num_classes=5, iterations=1)  # K = 5 > 4
+        CACGMMTrainer().fit(x, num_classes=7, iterations=1)  # K = 7 > 6
 
 
 # ------------------------------------------------------------------ extraction
@@ -254,3 +254,16 @@ def test_psd_properties():
     assert np.abs(psd(X, mask > 0.5) - psd(X, (mask > 0.5).astype(float))).max() == 0  # bool mask
     assert np.abs(psd(X.transpose(0, 2, 1), mask.transpose(0, 2, 1), sensor_dim=-1,
                       source_dim=-1, time_dim=-2) - p).max() < 1e-14
+
+
+@pytest.mark.parametrize('K,D', [(5, 6), (6, 8), (5, 3)])
+def test_more_classes(K, D):
+    """K = 5, 6 run on the 2-workgroups-per-CU instantiation."""
+    from pb_bss_amd.distribution import CACGMMTrainer
+    from oracle import cacgmm as oc, synth
+    Y, init = synth.make_stft(6, 150, D, K, seed=K * 10 + D)
+    m = CACGMMTrainer().fit(Y, initialization=init, iterations=5)
+    Y128 = Y.astype(np.complex128)
+    ref = oc.em_fit(Y128, init, iterations=5)
+    assert np.abs(m.weight - ref['weight']).max() < 1e-10
+    assert np.abs(m.predict(Y) - oc.em_predict(ref, Y128)).max() < 1e-8
