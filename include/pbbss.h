@@ -259,6 +259,41 @@ int pbbss_apply_mapping(pbbss_handle_t h, const double* mask,
                         double* out, void* stream);
 
 /* ------------------------------------------------------------------------- */
+/* N2  CWMMTrainer.fit / fit_predict, CWMM.predict   distribution/cwmm.py:76-240, */
+/*     :25-52; ComplexWatson.log_pdf / log_norm_1f1  complex_watson.py:73-87,     */
+/*     :157-168; ComplexWatsonTrainer._fit + spline  :238-271, :300-315.          */
+/* y (B,T,D) complex, raw (the kernel unit-normalises, complex_watson.py:16-29). */
+/* Initialisation: gamma0 (B,K,T) f64 affiliations, or a model (in_mode c128     */
+/* (B,K,D), in_concentration f64 (B,K), in_weight f64 (B,K)).  iterations may be */
+/* 0 with a model (pure predict).  The concentration look-up is the quadratic    */
+/* B-spline the reference builds with SciPy (interp1d(kind='quadratic')):        */
+/* spline_t (n_coef + 3 knots) and spline_c (n_coef coefficients) are DEVICE     */
+/* arrays, valid for eigenvalues in [ev_min, ev_max]; below -> 0, above ->        */
+/* max_concentration (the reference's fill_value).  saliency f64 (B,T) or NULL.   */
+/* Outputs: mode c128 (B,K,D), concentration f64 (B,K), weight f64 (B,K),        */
+/* status int32 (B,K); optional affiliation / log_pdf f64 (B,K,T) from the final  */
+/* E-step (final_predict).  2 <= D <= 8, K <= 4.                                  */
+/* ------------------------------------------------------------------------- */
+typedef struct pbbss_cwmm_opts {
+  int32_t iterations;
+  int32_t weight_mode;   /* PBBSS_WEIGHT_* */
+  int32_t y_is_c128;
+  int32_t final_predict;
+  int32_t n_coef;        /* number of B-spline coefficients */
+  int32_t reserved;
+  double ev_min, ev_max, max_concentration;
+} pbbss_cwmm_opts;
+
+int pbbss_cwmm_fit(pbbss_handle_t h, const void* y, int64_t B, int T, int D, int K,
+                   const double* gamma0, const void* in_mode,
+                   const double* in_concentration, const double* in_weight,
+                   const double* saliency, const pbbss_cwmm_opts* opts,
+                   const double* spline_t, const double* spline_c, void* out_mode,
+                   double* out_concentration, double* out_weight,
+                   int32_t* out_status, double* out_affiliation,
+                   double* out_log_pdf, void* stream);
+
+/* ------------------------------------------------------------------------- */
 /* Timing hook for bench.py: runs `fit` with HIP events recorded on `stream`   */
 /* around the EM kernel launch(es) only and returns the elapsed milliseconds   */
 /* of the most recent call (the roofline figure needs the kernel duration on   */

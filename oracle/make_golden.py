@@ -192,6 +192,33 @@ def dhtv_cases():
     _save('dhtv_alignment', **out)
 
 
+def cwmm_cases():
+    from pb_bss.distribution.cwmm import CWMMTrainer
+    from pb_bss.distribution.complex_watson import ComplexWatson, ComplexWatsonTrainer
+    for name, F, T, D, K, iters, kw in [
+            ('cwmm_f6_t120_d6_k3', 6, 120, 6, 3, 8, {}),
+            ('cwmm_f5_t90_d3_k2', 5, 90, 3, 2, 6, {}),
+            ('cwmm_f4_t80_d8_k2_uniform', 4, 80, 8, 2, 5, dict(weight_constant_axis=-2))]:
+        Y, init = synth.make_stft(F, T, D, K, seed=len(name) + 3)
+        Y128 = Y.astype(np.complex128)
+        model = CWMMTrainer().fit(Y128, initialization=init, iterations=iters, **kw)
+        yn = Y128 / np.maximum(np.linalg.norm(Y128, axis=-1, keepdims=True), np.finfo(float).tiny)
+        _save(name, Y=Y, init=init, iterations=iters, kwargs=np.array(repr(kw)),
+              weight=model.weight, mode=model.complex_watson.mode,
+              concentration=model.complex_watson.concentration,
+              affiliation=model.predict(Y128),
+              log_pdf=model.complex_watson.log_pdf(yn[..., None, :, :]))
+    t = ComplexWatsonTrainer(5)
+    ev = np.array([0, 1 / 5, 1 / 5 + 1e-4, 0.3, 0.7, 0.9599999, 1])
+    ks = np.array([0.0, 1e-3, 0.5, 5.0, 50.0, 300.0, 500.0])
+    _save('watson_scalar_functions', eigenvalues=ev,
+          ratio_inverse_d5=t.hypergeometric_ratio_inverse(ev),  # doctest complex_watson.py:268-271
+          concentrations=ks,
+          log_norm_d5=ComplexWatson.log_norm_1f1(ks, 5),
+          log_norm_d8=ComplexWatson.log_norm_1f1(ks, 8),
+          ratio_d5=t.hypergeometric_ratio(ks))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     refshim.load()
@@ -200,6 +227,7 @@ def main():
     cacg_cases()
     beamformer_cases()
     dhtv_cases()
+    cwmm_cases()
 
 
 if __name__ == '__main__':

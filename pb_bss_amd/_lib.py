@@ -40,7 +40,7 @@ EXPORTS = (
     'pbbss_solve', 'pbbss_mvdr_souden', 'pbbss_mvdr', 'pbbss_ban',
     'pbbss_apply_beamforming_vector', 'pbbss_set_timing',
     'pbbss_last_kernel_ms', 'pbbss_set_phase_profile',
-    'pbbss_dhtv_calculate_mapping', 'pbbss_apply_mapping',
+    'pbbss_dhtv_calculate_mapping', 'pbbss_apply_mapping', 'pbbss_cwmm_fit',
 )
 
 
@@ -57,6 +57,21 @@ class EmOpts(ctypes.Structure):
         ('force_eig', ctypes.c_int32),
         ('affiliation_eps', ctypes.c_double),
         ('eigenvalue_floor', ctypes.c_double),
+    ]
+
+
+class CwmmOpts(ctypes.Structure):
+    """struct pbbss_cwmm_opts"""
+    _fields_ = [
+        ('iterations', ctypes.c_int32),
+        ('weight_mode', ctypes.c_int32),
+        ('y_is_c128', ctypes.c_int32),
+        ('final_predict', ctypes.c_int32),
+        ('n_coef', ctypes.c_int32),
+        ('reserved', ctypes.c_int32),
+        ('ev_min', ctypes.c_double),
+        ('ev_max', ctypes.c_double),
+        ('max_concentration', ctypes.c_double),
     ]
 
 
@@ -91,6 +106,9 @@ def load():
         lib.pbbss_set_phase_profile.argtypes = [vp, vp]
         lib.pbbss_dhtv_calculate_mapping.argtypes = [vp, vp, i64, i32, i32, i32, vp, i32, i32, vp, vp, vp, vp]
         lib.pbbss_apply_mapping.argtypes = [vp, vp, vp, i64, i32, i32, i32, vp, vp]
+        lib.pbbss_cwmm_fit.argtypes = [
+            vp, vp, i64, i32, i32, i32, vp, vp, vp, vp, vp, ctypes.POINTER(CwmmOpts), vp, vp,
+            vp, vp, vp, vp, vp, vp, vp]
         lib.pbbss_normalize_observation.argtypes = [vp, vp, i32, i64, i32, i32, vp, vp]
         lib.pbbss_cacgmm_fit.argtypes = [
             vp, vp, i64, i32, i32, i32, vp, vp, vp, vp, vp, vp,

@@ -339,3 +339,53 @@ PBBSS_API int pbbss_apply_mapping(pbbss_handle_t h, const double* mask, const in
     return PBBSS_ERR_INVALID_ARG;
   return pbbss::launch_apply_mapping(mask, mapping, U, K, F, T, out, as_stream(stream));
 }
+
+PBBSS_API int pbbss_cwmm_fit(pbbss_handle_t h, const void* y, int64_t B, int T, int D, int K,
+                             const double* gamma0, const void* in_mode,
+                             const double* in_concentration, const double* in_weight,
+                             const double* saliency, const pbbss_cwmm_opts* o,
+                             const double* spline_t, const double* spline_c, void* out_mode,
+                             double* out_concentration, double* out_weight, int32_t* out_status,
+                             double* out_affiliation, double* out_log_pdf, void* stream) {
+  if (!h || !y || !o || B <= 0 || T <= 0) return PBBSS_ERR_INVALID_ARG;
+  if (o->iterations < 0) return PBBSS_ERR_INVALID_ARG;
+  const bool has_gamma = gamma0 != nullptr;
+  const bool has_model = in_mode && in_concentration && in_weight;
+  if (has_gamma == has_model) return PBBSS_ERR_INVALID_ARG;
+  if (o->iterations == 0 && !has_model) return PBBSS_ERR_INVALID_ARG;
+  if (o->iterations > 0 && (!spline_t || !spline_c || o->n_coef < 3)) return PBBSS_ERR_INVALID_ARG;
+  if (o->iterations > 0 && (!out_mode || !out_concentration || !out_weight))
+    return PBBSS_ERR_INVALID_ARG;
+  if (o->weight_mode < 0 || o->weight_mode > 1) return PBBSS_ERR_INVALID_ARG;
+  if (D < 2 || D > 8 || K < 1 || K > 4) return PBBSS_ERR_UNSUPPORTED;
+  pbbss::WatsonArgs wa{};
+  wa.em.y = y;
+  wa.em.B = B;
+  wa.em.T = T;
+  wa.em.gamma0 = gamma0;
+  wa.em.in_weight = in_weight;
+  wa.em.wb = K;
+  wa.em.wk = 1;
+  wa.em.wt = 0;
+  wa.em.saliency = saliency;
+  wa.em.out_weight = out_weight;
+  wa.em.out_status = out_status;
+  wa.em.out_aff = out_affiliation;
+  wa.em.out_logpdf = out_log_pdf;
+  wa.em.iterations = o->iterations;
+  wa.em.weight_mode = o->weight_mode;
+  wa.em.layout = PBBSS_LAYOUT_TD;
+  wa.em.final_predict = o->final_predict && (out_affiliation || out_log_pdf);
+  wa.in_mode = static_cast<const double*>(in_mode);
+  wa.in_conc = in_concentration;
+  wa.spline_t = spline_t;
+  wa.spline_c = spline_c;
+  wa.n_coef = o->n_coef;
+  wa.ev_min = o->ev_min;
+  wa.ev_max = o->ev_max;
+  wa.max_concentration = o->max_concentration;
+  wa.out_mode = static_cast<double*>(out_mode);
+  wa.out_conc = out_concentration;
+  TimedRegion tr(h, as_stream(stream));
+  return pbbss::cw_launch(D, K, o->y_is_c128, wa, h->cfg, as_stream(stream));
+}

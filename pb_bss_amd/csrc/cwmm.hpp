@@ -1,0 +1,352 @@
+// Persistent complex-Watson mixture-model (cWMM) EM kernel for gfx950
+// (BASELINE config 4).
+//
+// Reference: distribution/cwmm.py:151-240 (CWMMTrainer._fit / _m_step),
+// :25-52 (CWMM.predict), distribution/complex_watson.py:73-87 (log_pdf),
+// :157-168 (log_norm_1f1), :238-271 (concentration from the largest eigenvalue
+// through a quadratic spline of the inverse hypergeometric ratio), :300-315
+// (_fit: weighted covariance -> dominant eigenvector).
+//
+// Same skeleton as the cACGMM kernel (cacgmm_em.hpp), whose staging, outer
+// product / quadratic form and entry-split M phase are reused verbatim:
+//   E  q_kt = |m_k^H y_t|^2 = <m_k m_k^H, P_t>;  log p = kappa_k q_kt - ln c(kappa_k);
+//      softmax with a max-shift (float64 exp), weights in the linear domain
+//   M  C_k = sum_t gamma_kt P_t / sum_t gamma_kt      (no 1/q weighting)
+//   F  wave k: Jacobi eigendecomposition -> (lambda_max, m_k); kappa_k by de Boor
+//      evaluation of the host-built quadratic B-spline (the host builds it with
+//      SciPy exactly as the reference does and passes knots + coefficients);
+//      ln c(kappa) = ln(2 pi^D / (D-1)!) + ln 1F1(1; D; kappa) in closed form.
+#pragma once
+#include "cacgmm_em.hpp"
+
+namespace pbbss {
+
+struct WatsonArgs {
+  EmArgs em;                 // y, B, T, gamma0, saliency, iterations, weight_mode, layout, outputs
+  const double* in_mode;     // c128 (B,K,D) or null
+  const double* in_conc;     // (B,K)
+  const double* spline_t;    // knots (n_coef + 3)
+  const double* spline_c;    // coefficients (n_coef)
+  int n_coef;
+  double ev_min, ev_max;     // interpolation range of the eigenvalue (outside: fill values)
+  double max_concentration;
+  double* out_mode;          // c128 (B,K,D)
+  double* out_conc;          // (B,K)
+};
+
+// ln 1F1(1; D; kappa): series for small kappa, closed form
+//   1F1(1; D; k) = (D-1)! k^-(D-1) (e^k - sum_{r<=D-2} k^r / r!)   otherwise.
+template <int D>
+__device__ __forceinline__ double log_hyp1f1_1_D(double kappa) {
+  if (kappa < 25.0) {
+    double s = 1.0, term = 1.0;
+    for (int m = 1; m < 400; ++m) {
+      term *= kappa / (double)(D + m - 1);
+      s += term;
+      if (term < 1e-18 * s) break;
+    }
+    return log(s);
+  }
+  double ssum = 0.0, term = 1.0, lfact = 0.0;
+#pragma unroll
+  for (int r = 0; r < D - 1; ++r) {
+    if (r > 0) {
+      term *= kappa / (double)r;
+      lfact += log((double)r);  // ln (D-2)! after the loop, need ln (D-1)! below
+    }
+    ssum += term;
+  }
+  lfact += (D >= 2) ? log((double)(D - 1)) : 0.0;  // ln (D-1)!
+  return lfact - (double)(D - 1) * log(kappa) + kappa + log1p(-exp(-kappa) * ssum);
+}
+
+// ln c(kappa) as complex_watson.py:157-168
+template <int D>
+__device__ __forceinline__ double watson_log_norm(double kappa) {
+  double lfact = 0.0;
+#pragma unroll
+  for (int r = 2; r <= D - 1; ++r) lfact += log((double)r);
+  return log(2.0) + (double)D * 1.1447298858494002 /* ln pi */ - lfact + log_hyp1f1_1_D<D>(kappa);
+}
+
+// scipy.interpolate.interp1d(kind='quadratic', bounds_error=False, fill_value=(0, max))
+// == BSpline(t, c, k=2) evaluated with de Boor inside [ev_min, ev_max]
+__device__ __forceinline__ double watson_concentration(const WatsonArgs& a, double ev) {
+  if (!(ev >= a.ev_min)) return 0.0;  // also NaN -> 0 like fill_value below the range
+  if (ev > a.ev_max) return a.max_concentration;
+  constexpr int k = 2;
+  const int n = a.n_coef;
+  // largest i in [k, n-1] with t[i] <= ev
+  int lo = k, hi = n - 1;
+  while (lo < hi) {
+    int mid = (lo + hi + 1) >> 1;
+    if (a.spline_t[mid] <= ev) lo = mid; else hi = mid - 1;
+  }
+  const int i = lo;
+  double d[k + 1];
+#pragma unroll
+  for (int j = 0; j <= k; ++j) d[j] = a.spline_c[j + i - k];
+#pragma unroll
+  for (int r = 1; r <= k; ++r) {
+#pragma unroll
+    for (int j = k; j >= r; --j) {
+      double tl = a.spline_t[j + i - k], tr = a.spline_t[j + 1 + i - r];
+      double alpha = (ev - tl) / (tr - tl);
+      d[j] = (1.0 - alpha) * d[j - 1] + alpha * d[j];
+    }
+  }
+  return d[k];
+}
+
+template <int D, int K, typename YS, bool SPILL>
+struct WatsonKernel {
+  using Base = EmKernel<D, K, YS, SPILL>;
+  using Lds = typename Base::Lds;
+  static constexpr int NA = Base::NA;
+  // L.detm[k] holds kappa_k, L.rdet[k] holds ln c(kappa_k)
+
+  template <bool FINAL>
+  static __device__ void phase_e(const WatsonArgs& wa, const Lds& L, int64_t b, int tid, int wave,
+                                 int lane) {
+    const EmArgs& a = wa.em;
+    double s[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) s[k] = 0.0;
+    for (int t0 = 0; t0 < a.T; t0 += kEmThreads) {
+      const int tt = t0 + tid;
+      const bool ok = tt < a.T;
+      const int t = ok ? tt : a.T - 1;
+      double re[D], im[D], q[K];
+      Base::load_frame(L, t, re, im);
+#pragma unroll
+      for (int k = 0; k < K; ++k) q[k] = 0.0;
+      static_for<0, D>([&](auto ic) {
+        constexpr int i = ic;
+        double dg = re[i] * re[i] + im[i] * im[i];
+#pragma unroll
+        for (int k = 0; k < K; ++k) q[k] = fma(L.apack[k * NA + i], dg, q[k]);
+      });
+      static_for<0, Base::NOFF>([&](auto pc) {
+        constexpr int p = pc;
+        constexpr int i = tri_i<D>(p), j = tri_j<D>(p);
+        double pr = re[i] * re[j] + im[i] * im[j];
+        double pim = im[i] * re[j] - re[i] * im[j];
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+          q[k] = fma(L.apack[k * NA + D + 2 * p], pr,
+                     fma(L.apack[k * NA + D + 2 * p + 1], pim, q[k]));
+      });
+      const double inv = L.inv_n2[t];
+      double lp[K], mx = -1.79e308;
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        lp[k] = L.detm[k] * (q[k] * inv) - L.rdet[k];  // complex_watson.py:83-86
+        mx = fmax(mx, lp[k]);
+      }
+      double g[K], den = 0.0;
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        double w = L.wgt[k];
+        g[k] = exp(lp[k] - mx) * w;  // mixture_model_utils.py:32-37
+        den += g[k];
+      }
+      den = fmax(den, kTiny);
+      const double sal = (!FINAL && a.saliency) ? a.saliency[(size_t)b * a.T + t] : 1.0;
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        double gam = g[k] / den;
+        if constexpr (FINAL) {
+          if (ok) {
+            size_t idx = ((size_t)b * K + k) * a.T + t;
+            if (a.out_aff) a.out_aff[idx] = gam;
+            if (a.out_logpdf) a.out_logpdf[idx] = lp[k];
+          }
+        } else {
+          double gs = ok ? gam * sal : 0.0;
+          if (ok) L.wbuf[(size_t)k * L.Tp + t] = gs * inv;  // complex_watson.py:306-309
+          s[k] += gs;
+        }
+      }
+    }
+    if constexpr (!FINAL) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        double tot = wave_sum(s[k]);
+        if (lane == 0) L.red[wave * K + k] = tot;
+      }
+    }
+  }
+
+  // affiliation initialisation -> M-step weights (cwmm.py:162-163 with saliency)
+  static __device__ void phase_init_gamma(const EmArgs& a, const Lds& L, int64_t b, int tid,
+                                          int wave, int lane) {
+    double s[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) s[k] = 0.0;
+    for (int t = tid; t < a.T; t += kEmThreads) {
+      double sal = a.saliency ? a.saliency[(size_t)b * a.T + t] : 1.0;
+      double inv = L.inv_n2[t];
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        double g = a.gamma0[((size_t)b * K + k) * a.T + t] * sal;
+        L.wbuf[(size_t)k * L.Tp + t] = g * inv;
+        s[k] += g;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      double tot = wave_sum(s[k]);
+      if (lane == 0) L.red[wave * K + k] = tot;
+    }
+  }
+
+  // mode vector on lanes (i, 0..) -> A_k = m m^H packed; kappa, ln c
+  static __device__ __forceinline__ void set_class(const Lds& L, int k, int lane, LaneIJ c,
+                                                   double mre_i, double mim_i, double mre_j,
+                                                   double mim_j, double kappa) {
+    // A_ij = m_i conj(m_j)
+    double gre = mre_i * mre_j + mim_i * mim_j;
+    double gim = mim_i * mre_j - mre_i * mim_j;
+    Base::store_apack(L, k, c, gre, gim);
+    if (lane == 0) {
+      L.detm[k] = kappa;
+      L.rdet[k] = watson_log_norm<D>(kappa);
+    }
+  }
+
+  static __device__ void factor_class(const WatsonArgs& wa, const Lds& L, int64_t b, int k,
+                                      int lane, bool last) {
+    const EmArgs& a = wa.em;
+    const LaneIJ c = lane_ij(lane);
+    const bool valid = c.i < D && c.j < D;
+    double S = 0.0, tot = 0.0;
+#pragma unroll
+    for (int kk = 0; kk < K; ++kk) {
+      double sk = 0.0;
+#pragma unroll
+      for (int w = 0; w < kEmWaves; ++w) sk += L.red[w * K + kk];
+      tot += fabs(sk);
+      S = (kk == k) ? sk : S;
+    }
+    if (lane == 0) {
+      double wnew;
+      if (a.weight_mode == PBBSS_WEIGHT_UNIFORM) {
+        wnew = 1.0 / K;
+      } else {
+        // the reference always passes a saliency (ones by default, cwmm.py:134-135):
+        // L1-normalised weighted sums (mixture_model_utils.py:192-201)
+        wnew = S / ((tot == 0.0) ? 1e-10 : tot);
+      }
+      L.wgt[k] = wnew;
+    }
+    double are = 0.0, aim = 0.0;
+    if (valid) {
+      const double* cm = L.cmat + (((size_t)k * D + c.i) * D + c.j) * 2;
+      const double scale = 1.0 / S;  // complex_watson.py:311 (no floor in the reference)
+      are = cm[0] * scale;
+      aim = cm[1] * scale;
+    }
+    int st = 0;
+    if (wave_or((isfinite(are) && isfinite(aim)) ? 0 : 1)) st |= PBBSS_ST_NONFINITE;
+    double vre, vim;
+    int sweeps = wave_jacobi_heev<D>(are, aim, c, vre, vim);
+    if (sweeps < 0) st |= PBBSS_ST_EIG_NOCONV;
+    double lam = lane_get(are, ij_lane(c.j, c.j));
+    int rank = wave_sort_rank<D>(lam, c);
+    int col = 0;
+    double lmax = 0.0;
+#pragma unroll
+    for (int m = 0; m < D; ++m) {
+      int rm = lane_get(rank, ij_lane(0, m));
+      double lm = lane_get(lam, ij_lane(0, m));
+      if (rm == D - 1) {
+        col = m;
+        lmax = lm;
+      }
+    }
+    const double kappa = watson_concentration(wa, lmax);
+    // mode components for this lane's row and column index
+    double mre_i = lane_get(vre, ij_lane(c.i, col)), mim_i = lane_get(vim, ij_lane(c.i, col));
+    double mre_j = lane_get(vre, ij_lane(c.j, col)), mim_j = lane_get(vim, ij_lane(c.j, col));
+    set_class(L, k, lane, c, mre_i, mim_i, mre_j, mim_j, kappa);
+    if (last) {
+      if (c.j == 0 && c.i < D && wa.out_mode) {
+        double* o = wa.out_mode + (((size_t)b * K + k) * D + c.i) * 2;
+        o[0] = mre_i;
+        o[1] = mim_i;
+      }
+      if (lane == 0 && wa.out_conc) wa.out_conc[(size_t)b * K + k] = kappa;
+    }
+    if (lane == 0) L.status[k] |= st;
+  }
+
+  static __device__ void prep_from_model(const WatsonArgs& wa, const Lds& L, int64_t b, int k,
+                                         int lane) {
+    const EmArgs& a = wa.em;
+    const LaneIJ c = lane_ij(lane);
+    double mre_i = 0, mim_i = 0, mre_j = 0, mim_j = 0;
+    if (c.i < D) {
+      mre_i = wa.in_mode[(((size_t)b * K + k) * D + c.i) * 2];
+      mim_i = wa.in_mode[(((size_t)b * K + k) * D + c.i) * 2 + 1];
+    }
+    if (c.j < D) {
+      mre_j = wa.in_mode[(((size_t)b * K + k) * D + c.j) * 2];
+      mim_j = wa.in_mode[(((size_t)b * K + k) * D + c.j) * 2 + 1];
+    }
+    set_class(L, k, lane, c, mre_i, mim_i, mre_j, mim_j, wa.in_conc[(size_t)b * K + k]);
+    if (lane == 0) L.wgt[k] = a.in_weight ? a.in_weight[b * a.wb + k * a.wk] : 1.0 / K;
+  }
+
+  static __device__ void run(const WatsonArgs& wa, char* smem) {
+    const EmArgs& a = wa.em;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const Lds L = Base::carve(
+        smem, a.T, SPILL ? a.scratch + (size_t)blockIdx.x * a.scratch_stride : nullptr);
+    for (int64_t b = blockIdx.x; b < a.B; b += gridDim.x) {
+      __syncthreads();
+      if (tid < K) L.status[tid] = 0;
+      if (tid == 0) *L.flags = 0;
+      __syncthreads();
+      Base::phase_load(a, L, b, tid);
+      __syncthreads();
+      const bool model_in = (a.gamma0 == nullptr);
+      if (model_in) {
+        for (int k = wave; k < K; k += kEmWaves) prep_from_model(wa, L, b, k, lane);
+      } else {
+        phase_init_gamma(a, L, b, tid, wave, lane);
+      }
+      __syncthreads();
+      for (int it = 0; it < a.iterations; ++it) {
+        if (it > 0 || model_in) {
+          phase_e<false>(wa, L, b, tid, wave, lane);
+          __syncthreads();
+        }
+        switch (wave) {
+          case 0: Base::template phase_m<0>(a, L, lane); break;
+          case 1: Base::template phase_m<1>(a, L, lane); break;
+          case 2: Base::template phase_m<2>(a, L, lane); break;
+          default: Base::template phase_m<3>(a, L, lane); break;
+        }
+        __syncthreads();
+        const bool last = (it == a.iterations - 1);
+        for (int k = wave; k < K; k += kEmWaves) factor_class(wa, L, b, k, lane, last);
+        __syncthreads();
+      }
+      if (tid < K) {
+        if (a.out_weight && a.iterations > 0) a.out_weight[(size_t)b * K + tid] = L.wgt[tid];
+        if (a.out_status) a.out_status[(size_t)b * K + tid] = L.status[tid];
+      }
+      if (a.final_predict) phase_e<true>(wa, L, b, tid, wave, lane);
+    }
+  }
+};
+
+template <int D, int K, typename YS, bool SPILL>
+__global__ void __launch_bounds__(kEmThreads, em_waves_per_simd(K)) cwmm_em_kernel(WatsonArgs wa) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  WatsonKernel<D, K, YS, SPILL>::run(wa, smem);
+}
+
+}  // namespace pbbss

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "cacgmm_em.hpp"
+#include "cwmm.hpp"
 
 namespace pbbss {
 
@@ -32,6 +33,30 @@ inline int em_launch(int D, int K, int y_is_c128, const EmArgs& a, const EmLaunc
     case 6: return em_launch_d6(K, y_is_c128, a, cfg, s);
     case 7: return em_launch_d7(K, y_is_c128, a, cfg, s);
     case 8: return em_launch_d8(K, y_is_c128, a, cfg, s);
+    default: return PBBSS_ERR_UNSUPPORTED;
+  }
+}
+
+
+// complex-Watson mixture kernels (cw_inst.hip), one per compiled D
+int cw_launch_d2(int K, int y_is_c128, const WatsonArgs&, const EmLaunchCfg&, hipStream_t);
+int cw_launch_d3(int K, int y_is_c128, const WatsonArgs&, const EmLaunchCfg&, hipStream_t);
+int cw_launch_d4(int K, int y_is_c128, const WatsonArgs&, const EmLaunchCfg&, hipStream_t);
+int cw_launch_d5(int K, int y_is_c128, const WatsonArgs&, const EmLaunchCfg&, hipStream_t);
+int cw_launch_d6(int K, int y_is_c128, const WatsonArgs&, const EmLaunchCfg&, hipStream_t);
+int cw_launch_d7(int K, int y_is_c128, const WatsonArgs&, const EmLaunchCfg&, hipStream_t);
+int cw_launch_d8(int K, int y_is_c128, const WatsonArgs&, const EmLaunchCfg&, hipStream_t);
+
+inline int cw_launch(int D, int K, int y_is_c128, const WatsonArgs& a, const EmLaunchCfg& cfg,
+                     hipStream_t s) {
+  switch (D) {
+    case 2: return cw_launch_d2(K, y_is_c128, a, cfg, s);
+    case 3: return cw_launch_d3(K, y_is_c128, a, cfg, s);
+    case 4: return cw_launch_d4(K, y_is_c128, a, cfg, s);
+    case 5: return cw_launch_d5(K, y_is_c128, a, cfg, s);
+    case 6: return cw_launch_d6(K, y_is_c128, a, cfg, s);
+    case 7: return cw_launch_d7(K, y_is_c128, a, cfg, s);
+    case 8: return cw_launch_d8(K, y_is_c128, a, cfg, s);
     default: return PBBSS_ERR_UNSUPPORTED;
   }
 }

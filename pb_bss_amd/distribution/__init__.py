@@ -6,9 +6,12 @@ from .complex_angular_central_gaussian import (
     normalize_observation,
 )
 from .cacgmm import CACGMM, CACGMMTrainer
+from .complex_watson import ComplexWatson, ComplexWatsonTrainer
+from .cwmm import CWMM, CWMMTrainer
 
 __all__ = [
-    'CACGMM', 'CACGMMTrainer',
+    'CACGMM', 'CACGMMTrainer', 'CWMM', 'CWMMTrainer',
+    'ComplexWatson', 'ComplexWatsonTrainer',
     'ComplexAngularCentralGaussian', 'ComplexAngularCentralGaussianTrainer',
     'normalize_observation',
 ]

@@ -310,3 +310,47 @@ def apply_mapping(mask, mapping):
         _lib.ptr(out), _lib.stream_ptr(mask.device.index))
     _lib.check(rc, f'apply_mapping(U={U},K={K},F={F},T={T})')
     return out
+
+
+def cwmm_fit(y, K, spline, *, gamma0=None, model=None, iterations=100, saliency=None,
+             weight_mode=0, final_predict=False, want_log_pdf=False, check_status=True):
+    """pbbss_cwmm_fit.  y (B,T,D) complex; gamma0 (B,K,T) f64 or
+    model=(mode (B,K,D) c128, concentration (B,K), weight (B,K)).
+    `spline` = dict(t, c device f64 arrays, ev_min, ev_max, max_concentration);
+    may be None for a pure predict (iterations=0)."""
+    t = _t()
+    dev = y.device
+    B, T, D = y.shape
+    is128 = y.dtype == t.complex128
+    opts = _lib.CwmmOpts(
+        iterations=int(iterations), weight_mode=int(weight_mode), y_is_c128=int(is128),
+        final_predict=int(bool(final_predict or want_log_pdf)),
+        n_coef=0 if spline is None else int(spline['c'].numel()), reserved=0,
+        ev_min=0.0 if spline is None else float(spline['ev_min']),
+        ev_max=0.0 if spline is None else float(spline['ev_max']),
+        max_concentration=0.0 if spline is None else float(spline['max_concentration']))
+    f64 = t.float64
+    out_mode = t.empty((B, K, D), dtype=t.complex128, device=dev)
+    out_conc = t.empty((B, K), dtype=f64, device=dev)
+    out_w = t.empty((B, K), dtype=f64, device=dev)
+    out_st = t.zeros((B, K), dtype=t.int32, device=dev)
+    out_aff = t.empty((B, K, T), dtype=f64, device=dev) if final_predict else None
+    out_lp = t.empty((B, K, T), dtype=f64, device=dev) if want_log_pdf else None
+    in_mode = in_conc = in_w = None
+    if model is not None:
+        in_mode, in_conc, in_w = model
+        assert in_mode.shape == (B, K, D) and in_conc.shape == (B, K) and in_w.shape == (B, K)
+    else:
+        assert gamma0.shape == (B, K, T) and gamma0.dtype == f64
+    rc = _lib.load().pbbss_cwmm_fit(
+        _lib.handle(dev.index), _lib.ptr(y), B, T, D, K, _lib.ptr(gamma0), _lib.ptr(in_mode),
+        _lib.ptr(in_conc), _lib.ptr(in_w), _lib.ptr(saliency), ctypes.byref(opts),
+        None if spline is None else _lib.ptr(spline['t']),
+        None if spline is None else _lib.ptr(spline['c']),
+        _lib.ptr(out_mode), _lib.ptr(out_conc), _lib.ptr(out_w), _lib.ptr(out_st),
+        _lib.ptr(out_aff), _lib.ptr(out_lp), _lib.stream_ptr(dev.index))
+    _lib.check(rc, f'cwmm_fit(B={B},T={T},D={D},K={K})')
+    if check_status and iterations > 0:
+        _status_raise_em(out_st, 'CWMMTrainer.fit')
+    return dict(mode=out_mode, concentration=out_conc, weight=out_w, status=out_st,
+                affiliation=out_aff, log_pdf=out_lp)

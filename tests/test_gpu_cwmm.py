@@ -1,0 +1,102 @@
+"""GPU: complex-Watson mixture model (SURVEY 8f row N2 / BASELINE config 4)
+against vectors of the real reference and the NumPy oracle."""
+import ast
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name + '.npz'))
+
+
+def cos_sim(a, b):
+    return np.abs(np.einsum('...d,...d->...', a.conj(), b)) / (
+        np.linalg.norm(a, axis=-1) * np.linalg.norm(b, axis=-1))
+
+
+@pytest.mark.parametrize('name', ['cwmm_f6_t120_d6_k3', 'cwmm_f5_t90_d3_k2',
+                                  'cwmm_f4_t80_d8_k2_uniform'])
+def test_cwmm_trainer_matches_reference(name):
+    from pb_bss_amd.distribution import CWMMTrainer
+    g = load(name)
+    kw = ast.literal_eval(str(g['kwargs']))
+    model = CWMMTrainer().fit(g['Y'], initialization=g['init'],
+                              iterations=int(g['iterations']), **kw)
+    assert model.weight.shape == g['weight'].shape
+    assert model.complex_watson.mode.shape == g['mode'].shape
+    assert model.complex_watson.concentration.shape == g['concentration'].shape
+    assert np.abs(model.weight - g['weight']).max() < 1e-9
+    assert np.abs(model.complex_watson.concentration - g['concentration']).max() \
+        < 1e-8 * g['concentration'].max()
+    assert np.abs(cos_sim(model.complex_watson.mode, g['mode']) - 1).max() < 1e-10
+    aff = model.predict(g['Y'])
+    assert np.abs(aff - g['affiliation']).max() < 1e-8
+    yn = g['Y'].astype(np.complex128)
+    yn = yn / np.linalg.norm(yn, axis=-1, keepdims=True)
+    lp = model.complex_watson.log_pdf(yn[..., None, :, :])
+    assert lp.shape == g['log_pdf'].shape
+    assert np.abs(lp - g['log_pdf']).max() < 1e-7 * np.abs(g['log_pdf']).max()
+
+
+def test_cwmm_config4_shape_and_mvdr():
+    """BASELINE config 4 (reduced F): 6-mic array, T=800, K=3 through the Watson
+    trainer, then MVDR-Souden extraction, against the oracle chain."""
+    from pb_bss_amd.distribution import CWMMTrainer
+    from pb_bss_amd import extraction as ex
+    from oracle import beamformer as ob, cwmm as ow, synth
+    F, T, D, K = 33, 800, 6, 3
+    Y, init = synth.make_stft(F, T, D, K, seed=4)
+    Y128 = Y.astype(np.complex128)
+    masks = CWMMTrainer().fit_predict(Y, initialization=init, iterations=15)
+    ref = ow.cwmm_predict(ow.cwmm_fit(Y128, init, iterations=15), Y128)
+    assert masks.shape == (F, K, T)
+    assert np.abs(masks - ref).max() < 1e-7
+    X = Y128.transpose(0, 2, 1)
+    psd = ex.get_power_spectral_density_matrix(Y.transpose(0, 2, 1), masks)
+    psd_ref = ob.psd(X, ref)
+    w = ex.get_mvdr_vector_souden(psd[:, 0], psd[:, 1] + psd[:, 2])
+    w_ref = ob.mvdr_souden(psd_ref[:, 0], psd_ref[:, 1] + psd_ref[:, 2])
+    assert np.abs(w - w_ref).max() < 1e-6 * np.abs(w_ref).max()
+
+
+def test_watson_trainer_and_scalar_functions():
+    from pb_bss_amd.distribution import ComplexWatsonTrainer, CWMMTrainer
+    from oracle import cwmm as ow
+    g = load('watson_scalar_functions')
+    t = ComplexWatsonTrainer(5)
+    assert np.allclose(t.hypergeometric_ratio_inverse(g['eigenvalues']), g['ratio_inverse_d5'],
+                       rtol=1e-13, atol=0)
+    rng = np.random.default_rng(0)
+    y = rng.standard_normal((3, 400, 5)) + 1j * rng.standard_normal((3, 400, 5))
+    y[..., 0] *= 3
+    m = t.fit(y)
+    yn = ow.normalize_observation(y)
+    mode, conc = ow.watson_m_step(yn, np.ones((3, 400)), ow.make_spline(5))
+    assert np.abs(m.concentration - conc).max() < 1e-9 * conc.max()
+    assert np.abs(cos_sim(m.mode, mode) - 1).max() < 1e-12
+    # reference test (tests/test_distribution/test_cwmm.py:33-37): shapes
+    np.random.seed(0)
+    x = rng.standard_normal((2000, 3)) + 1j * rng.standard_normal((2000, 3))
+    model = CWMMTrainer().fit(x, num_classes=2, iterations=10)
+    assert model.weight.shape == (2, 1)
+    assert model.complex_watson.mode.shape == (2, 3)
+    assert model.complex_watson.concentration.shape == (2,)
+    with pytest.raises(AssertionError):
+        CWMMTrainer().fit(x, num_classes=2, affiliation_eps=1e-10)
+
+
+def test_cwmm_stepwise_shared_weights():
+    from pb_bss_amd.distribution import CWMMTrainer
+    from oracle import cwmm as ow, synth
+    Y, init = synth.make_stft(5, 70, 4, 2, seed=12)
+    Y128 = Y.astype(np.complex128)
+    m = CWMMTrainer().fit(Y, initialization=init, iterations=3, weight_constant_axis=(-3, -1))
+    ref = ow.cwmm_fit(Y128, init, iterations=3, weight_constant_axis=(-3, -1))
+    assert m.weight.shape == ref['weight'].shape == (1, 2, 1)
+    assert np.abs(m.weight - ref['weight']).max() < 1e-10
+    assert np.abs(m.complex_watson.concentration - ref['concentration']).max() < 1e-8
