@@ -40,10 +40,3 @@ def as_result(x, like_torch):
     if x is None:
         return None
     return x if like_torch else _lib.to_host(x)
-
-
-def flatten_independent(shape_tail_dims, x):
-    """Split x.shape into (*independent, *tail) and flatten the independent axes."""
-    indep = tuple(x.shape[:x.ndim - shape_tail_dims])
-    B = int(np.prod(indep)) if indep else 1
-    return indep, B

@@ -16,11 +16,6 @@ def _t():
     return _lib.torch()
 
 
-def _view_real(x):
-    """complex tensor -> same memory seen as interleaved real (for pointers)."""
-    return x
-
-
 def _status_raise_em(status, what):
     """Mirror the reference's failure modes of the M-step."""
     st = int(status.max().item()) if status.numel() else 0
