@@ -212,6 +212,19 @@ int pbbss_mvdr_souden(pbbss_handle_t h, const void* target, const void* noise,
                       int32_t* out_status, void* stream);
 
 /* ------------------------------------------------------------------------- */
+/* N4  get_wmwf_vector  extraction/beamformer.py:701-753                       */
+/* Speech-distortion-weighted multichannel Wiener filter, same structure as    */
+/* pbbss_mvdr_souden: filter = (noise^-1 target) / (mu + trace) or, with       */
+/* frequency_dependent != 0, / sqrt(target[0,0] * trace).  out_mat c128        */
+/* (N,D,D); the reference channel is a column of it (per-matrix SNR terms in   */
+/* out_snr_num / out_snr_den c128 (N,D), may be NULL).                         */
+/* ------------------------------------------------------------------------- */
+int pbbss_wmwf(pbbss_handle_t h, const void* target, const void* noise, int64_t N,
+               int D, double distortion_weight, int frequency_dependent,
+               void* out_mat, void* out_snr_num, void* out_snr_den,
+               int32_t* out_status, void* stream);
+
+/* ------------------------------------------------------------------------- */
 /* a13  get_mvdr_vector  extraction/beamformer.py:230-260                      */
 /* w = noise^-1 h / (h^H noise^-1 h), noise hermitised first.                  */
 /* atf c128 (N,D), noise c128 (N,D,D) -> out c128 (N,D).                        */

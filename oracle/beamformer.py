@@ -10,7 +10,7 @@ import scipy.linalg
 
 __all__ = [
     'psd', 'gev_vector', 'stable_solve', 'optimal_reference_channel',
-    'mvdr_souden', 'mvdr', 'ban', 'apply_bf', 'pca_vector', 'bf_vector',
+    'mvdr_souden', 'mvdr', 'ban', 'apply_bf', 'pca_vector', 'bf_vector', 'wmwf',
 ]
 
 
@@ -111,6 +111,22 @@ def ban(vector, noise_psd):
     return vector * np.abs(norm[..., None])
 
 
+def wmwf(target_psd, noise_psd, reference_channel=None, channel_selection_vector=None,
+         distortion_weight=1.):
+    """extraction/beamformer.py:701-753."""
+    phi = stable_solve(noise_psd, target_psd)
+    lam = np.trace(phi, axis1=-1, axis2=-2)[..., None, None]
+    if isinstance(distortion_weight, str):
+        filt = phi / np.sqrt(target_psd[..., 0:1, 0:1] * lam)
+    else:
+        filt = phi / (distortion_weight + lam)
+    if channel_selection_vector is not None:
+        return np.sum(filt * channel_selection_vector[..., None, :], axis=-1)
+    if reference_channel is None:
+        reference_channel = optimal_reference_channel(filt, target_psd, noise_psd)
+    return filt[..., reference_channel]
+
+
 def apply_bf(vector, mix):
     """extraction/beamformer.py:572-583."""
     assert vector.shape[-1] < 30
@@ -155,6 +171,10 @@ def bf_vector(beamformer, target_psd, noise_psd=None, **kw):
         if core != 'mvdr_souden':
             target_psd = rank1(core.split('+')[0], target_psd)
         w = mvdr_souden(target_psd, noise_psd, **kw)
+    elif core in ('wmwf', 'rank1_pca+wmwf', 'rank1_gev+wmwf'):
+        if core != 'wmwf':
+            target_psd = rank1(core.split('+')[0], target_psd)
+        w = wmwf(target_psd, noise_psd, **kw)
     elif core in ('gev', 'rank1_pca+gev', 'rank1_gev+gev'):
         if core != 'gev':
             target_psd = rank1(core.split('+')[0], target_psd)

@@ -145,6 +145,10 @@ def beamformer_cases():
     out['mvdr'] = bf.get_mvdr_vector(atf, noise)
     out['ban'] = bf.blind_analytic_normalization(out['gev'], noise)
     out['applied'] = bf.apply_beamforming_vector(w_s, X)
+    out['wmwf'] = bf.get_wmwf_vector(target, noise)
+    out['wmwf_mu3_ch2'] = bf.get_wmwf_vector(target, noise, reference_channel=2, distortion_weight=3.)
+    out['wmwf_freqdep'] = bf.get_wmwf_vector(target, noise, reference_channel=0,
+                                             distortion_weight='frequency_dependent')
     out['ref_channel_fn'] = bf.get_optimal_reference_channel(
         np.linalg.solve(noise, target), target, noise)
     with warnings.catch_warnings():
@@ -152,7 +156,7 @@ def beamformer_cases():
         for name in ['pca', 'gev', 'gev+ban', 'mvdr_souden', 'mvdr_souden+ban',
                      'pca+mvdr', 'scaled_gev_atf+mvdr', 'rank1_pca+mvdr_souden',
                      'rank1_gev+mvdr_souden+ban', 'rank1_gev+gev', 'rank1_pca+gev',
-                     'ch2']:
+                     'wmwf', 'rank1_gev+wmwf+ban', 'ch2']:
             out['bf__' + name.replace('+', '__')] = get_bf_vector(name, target, noise)
     _save('beamformer_f17_d6', **out)
     # MVDR-Souden known answer (tests/test_extraction/test_beamformer.py:185-209)

@@ -41,6 +41,7 @@ EXPORTS = (
     'pbbss_apply_beamforming_vector', 'pbbss_set_timing',
     'pbbss_last_kernel_ms', 'pbbss_set_phase_profile',
     'pbbss_dhtv_calculate_mapping', 'pbbss_apply_mapping', 'pbbss_cwmm_fit',
+    'pbbss_wmwf',
 )
 
 
@@ -125,6 +126,7 @@ def load():
         lib.pbbss_solve.argtypes = [vp, vp, vp, i64, i32, i32, vp, vp, vp]
         lib.pbbss_mvdr_souden.argtypes = [vp, vp, vp, i64, i32, dbl, vp, vp, vp, vp, vp]
         lib.pbbss_mvdr.argtypes = [vp, vp, vp, i64, i32, vp, vp, vp]
+        lib.pbbss_wmwf.argtypes = [vp, vp, vp, i64, i32, dbl, i32, vp, vp, vp, vp, vp]
         lib.pbbss_ban.argtypes = [vp, vp, vp, i64, i32, vp, vp]
         lib.pbbss_apply_beamforming_vector.argtypes = [vp, vp, vp, i32, i64, i32, i32, vp, vp]
         for name in EXPORTS:

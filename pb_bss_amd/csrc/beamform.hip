@@ -183,10 +183,14 @@ __global__ void __launch_bounds__(kLaThreads) solve_kernel(const double* A, cons
 }
 
 // ------------------------------------------------------------------ MVDR (Souden)
+// mode 0: MVDR-Souden   mat = G / max(Re tr G, eps)                 (beamformer.py:683-686)
+// mode 1: wMWF          mat = G / (mu + tr G)                       (beamformer.py:736-742)
+// mode 2: wMWF 'frequency_dependent'  mat = G / sqrt(target_00 * tr G)   (:737-740)
 template <int D>
 __global__ void __launch_bounds__(kLaThreads)
     mvdr_souden_kernel(const double* target, const double* noise, int64_t N, double eps,
-                       double* out_mat, double* snr_num, double* snr_den, int32_t* status) {
+                       int mode, double* out_mat, double* snr_num, double* snr_den,
+                       int32_t* status) {
   const int lane = threadIdx.x & 63;
   const int64_t n = (int64_t)blockIdx.x * kLaWaves + (threadIdx.x >> 6);
   if (n >= N) return;
@@ -199,9 +203,31 @@ __global__ void __launch_bounds__(kLaThreads)
   if (sing) wave_pinv_solve<D>(nre, nim, tre, tim, c, gre, gim);  // stable_solve's lstsq branch
   // lambda = trace(G); mat = G / max(lambda.real, eps)            (:683-686)
   double tr = wave_sum((valid && c.i == c.j) ? gre : 0.0);
-  double sc = 1.0 / fmax(tr, eps);
-  gre *= sc;
-  gim *= sc;
+  if (mode == 0) {
+    double sc = 1.0 / fmax(tr, eps);
+    gre *= sc;
+    gim *= sc;
+  } else {
+    // complex denominator: lambda = tr G is complex in the reference's wMWF
+    double ti = wave_sum((valid && c.i == c.j) ? gim : 0.0);
+    double dr, di;
+    if (mode == 1) {
+      dr = eps + tr;  // eps carries the distortion weight mu
+      di = ti;
+    } else {
+      // sqrt(phi_x1x1 * lambda), principal branch
+      double pr = lane_bcast_const(tre, 0), pi = lane_bcast_const(tim, 0);
+      double zr = pr * tr - pi * ti, zi = pr * ti + pi * tr;
+      double mag = sqrt(sqrt(zr * zr + zi * zi));
+      double ang = 0.5 * atan2(zi, zr);
+      dr = mag * cos(ang);
+      di = mag * sin(ang);
+    }
+    double den = dr * dr + di * di;
+    double nr = (gre * dr + gim * di) / den, ni = (gim * dr - gre * di) / den;
+    gre = nr;
+    gim = ni;
+  }
   if (!valid) {
     gre = 0.0;
     gim = 0.0;
@@ -505,10 +531,11 @@ int launch_solve(const double* A, const double* Bm, int64_t N, int D, int M, dou
                                          s, A, Bm, N, M, x, st));
   return check_launch();
 }
-int launch_mvdr_souden(const double* t, const double* nn, int64_t N, int D, double eps,
+int launch_mvdr_souden(const double* t, const double* nn, int64_t N, int D, double eps, int mode,
                        double* mat, double* num, double* den, int32_t* st, hipStream_t s) {
   PBBSS_DISPATCH_D(D, hipLaunchKernelGGL(mvdr_souden_kernel<DD>, dim3(la_grid(N)),
-                                         dim3(kLaThreads), 0, s, t, nn, N, eps, mat, num, den, st));
+                                         dim3(kLaThreads), 0, s, t, nn, N, eps, mode, mat, num,
+                                         den, st));
   return check_launch();
 }
 int launch_mvdr(const double* atf, const double* nn, int64_t N, int D, double* w, int32_t* st,

@@ -11,7 +11,7 @@ int launch_gev(const double* t, const double* nn, int64_t N, int D, double* w, i
                hipStream_t s);
 int launch_solve(const double* A, const double* Bm, int64_t N, int D, int M, double* x,
                  int32_t* st, hipStream_t s);
-int launch_mvdr_souden(const double* t, const double* nn, int64_t N, int D, double eps,
+int launch_mvdr_souden(const double* t, const double* nn, int64_t N, int D, double eps, int mode,
                        double* mat, double* num, double* den, int32_t* st, hipStream_t s);
 int launch_mvdr(const double* atf, const double* nn, int64_t N, int D, double* w, int32_t* st,
                 hipStream_t s);

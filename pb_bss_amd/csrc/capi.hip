@@ -286,7 +286,7 @@ PBBSS_API int pbbss_mvdr_souden(pbbss_handle_t h, const void* target, const void
                                 void* out_snr_den, int32_t* out_status, void* stream) {
   if (!h || !target || !noise || !out_mat || N <= 0) return PBBSS_ERR_INVALID_ARG;
   return pbbss::launch_mvdr_souden(static_cast<const double*>(target),
-                                   static_cast<const double*>(noise), N, D, eps,
+                                   static_cast<const double*>(noise), N, D, eps, 0,
                                    static_cast<double*>(out_mat),
                                    static_cast<double*>(out_snr_num),
                                    static_cast<double*>(out_snr_den), out_status,
@@ -388,4 +388,17 @@ PBBSS_API int pbbss_cwmm_fit(pbbss_handle_t h, const void* y, int64_t B, int T, 
   wa.out_conc = out_concentration;
   TimedRegion tr(h, as_stream(stream));
   return pbbss::cw_launch(D, K, o->y_is_c128, wa, h->cfg, as_stream(stream));
+}
+
+PBBSS_API int pbbss_wmwf(pbbss_handle_t h, const void* target, const void* noise, int64_t N, int D,
+                         double distortion_weight, int frequency_dependent, void* out_mat,
+                         void* out_snr_num, void* out_snr_den, int32_t* out_status,
+                         void* stream) {
+  if (!h || !target || !noise || !out_mat || N <= 0) return PBBSS_ERR_INVALID_ARG;
+  return pbbss::launch_mvdr_souden(static_cast<const double*>(target),
+                                   static_cast<const double*>(noise), N, D, distortion_weight,
+                                   frequency_dependent ? 2 : 1, static_cast<double*>(out_mat),
+                                   static_cast<double*>(out_snr_num),
+                                   static_cast<double*>(out_snr_den), out_status,
+                                   as_stream(stream));
 }

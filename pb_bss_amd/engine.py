@@ -349,3 +349,19 @@ def cwmm_fit(y, K, spline, *, gamma0=None, model=None, iterations=100, saliency=
         _status_raise_em(out_st, 'CWMMTrainer.fit')
     return dict(mode=out_mode, concentration=out_conc, weight=out_w, status=out_st,
                 affiliation=out_aff, log_pdf=out_lp)
+
+
+def wmwf(target, noise, distortion_weight=1.0, frequency_dependent=False):
+    """pbbss_wmwf -> (filter matrix (N,D,D), snr_num (N,D), snr_den (N,D), status)."""
+    t = _t()
+    N, D, _ = target.shape
+    mat = t.empty((N, D, D), dtype=t.complex128, device=target.device)
+    num = t.empty((N, D), dtype=t.complex128, device=target.device)
+    den = t.empty((N, D), dtype=t.complex128, device=target.device)
+    st = t.zeros((N,), dtype=t.int32, device=target.device)
+    rc = _lib.load().pbbss_wmwf(
+        _lib.handle(target.device.index), _lib.ptr(target), _lib.ptr(noise), N, D,
+        float(distortion_weight), int(bool(frequency_dependent)), _lib.ptr(mat),
+        _lib.ptr(num), _lib.ptr(den), _lib.ptr(st), _lib.stream_ptr(target.device.index))
+    _lib.check(rc, f'wmwf(N={N},D={D})')
+    return mat, num, den, st

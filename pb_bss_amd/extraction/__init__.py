@@ -9,6 +9,7 @@ from .beamformer import (
     get_optimal_reference_channel,
     get_pca_vector,
     get_power_spectral_density_matrix,
+    get_wmwf_vector,
     stable_solve,
 )
 from .beamformer_wrapper import get_bf_vector
@@ -18,4 +19,5 @@ __all__ = [
     'get_mvdr_vector', 'get_pca_vector', 'get_gev_vector',
     'blind_analytic_normalization', 'apply_beamforming_vector',
     'get_optimal_reference_channel', 'stable_solve', 'get_bf_vector',
+    'get_wmwf_vector',
 ]

@@ -14,7 +14,7 @@ __all__ = [
     'get_power_spectral_density_matrix', 'get_mvdr_vector_souden',
     'get_mvdr_vector', 'get_pca_vector', 'get_gev_vector',
     'blind_analytic_normalization', 'apply_beamforming_vector',
-    'get_optimal_reference_channel', 'stable_solve',
+    'get_optimal_reference_channel', 'stable_solve', 'get_wmwf_vector',
 ]
 
 
@@ -245,3 +245,38 @@ def get_mvdr_vector_souden(target_psd_matrix, noise_psd_matrix, ref_channel=None
     if return_ref_channel:
         return _res(w, like_torch), ref_channel
     return _res(w, like_torch)
+
+
+def get_wmwf_vector(target_psd_matrix, noise_psd_matrix, reference_channel=None,
+                    channel_selection_vector=None, distortion_weight=1.):
+    """Speech-distortion-weighted multichannel Wiener filter.  Reference:
+    beamformer.py:701-753.  filter = (Phi_nn^-1 Phi_xx) / (mu + trace) (or
+    / sqrt(Phi_xx[0,0] * trace) for distortion_weight='frequency_dependent');
+    the result is the reference-channel column, a `channel_selection_vector`
+    weighted sum of columns, or the SNR-optimal column when neither is given."""
+    assert noise_psd_matrix is not None
+    like_torch = _lib.is_torch(target_psd_matrix)
+    tp = _c128(target_psd_matrix)
+    nn = _c128(noise_psd_matrix)
+    D = tp.shape[-1]
+    freq_dep = isinstance(distortion_weight, str)
+    if freq_dep:
+        assert distortion_weight == 'frequency_dependent', distortion_weight
+    mat, num, den, _ = engine.wmwf(
+        tp.reshape(-1, D, D).contiguous(), nn.expand(tp.shape).reshape(-1, D, D).contiguous(),
+        0.0 if freq_dep else float(distortion_weight), freq_dep)
+    filt = mat.reshape(*tp.shape)
+    if channel_selection_vector is not None:
+        sel = _lib.to_device(channel_selection_vector).to(filt.device).to(filt.dtype)
+        return _res((filt * sel[..., None, :]).sum(dim=-1), like_torch)
+    if reference_channel is None:
+        if tp.ndim != 3:
+            raise ValueError(
+                'Estimating the ref_channel expects currently that the input '
+                'has 3 ndims (frequency x sensors x sensors). '
+                'Considering an independent dim in the SNR estimate is not '
+                'unique.')
+        reference_channel = _select_reference_channel(
+            _lib.to_host(num), _lib.to_host(den), np.finfo(np.float64).tiny)
+    assert np.isscalar(reference_channel), reference_channel
+    return _res(filt[..., reference_channel], like_torch)

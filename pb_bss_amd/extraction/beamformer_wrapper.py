@@ -3,9 +3,8 @@
 Mirrors pb_bss/extraction/beamformer_wrapper.py:117-236 (`get_bf_vector`) and
 its rank-1 / ATF helpers (:11-104) on top of the device functions in
 `beamformer.py`.  Cores on the hot path: 'pca', 'gev', 'mvdr_souden',
-'pca+mvdr', 'scaled_gev_atf+mvdr', the 'rank1_pca+...' / 'rank1_gev+...'
-variants and 'ch<N>', each optionally followed by '+ban'.  'wmwf' variants
-are outside this round's scope and raise NotImplementedError.
+'pca+mvdr', 'scaled_gev_atf+mvdr', 'wmwf', the 'rank1_pca+...' / 'rank1_gev+...'
+variants and 'ch<N>', each optionally followed by '+ban'.
 """
 import numpy as np
 
@@ -16,6 +15,7 @@ from .beamformer import (
     get_mvdr_vector,
     get_mvdr_vector_souden,
     get_pca_vector,
+    get_wmwf_vector,
 )
 
 __all__ = ['get_bf_vector']
@@ -109,9 +109,12 @@ def get_bf_vector(beamformer, target_psd_matrix, noise_psd_matrix=None, **bf_kwa
                 **bf_kwargs.pop('atf_kwargs', {}))
         w = get_gev_vector(target_psd_matrix, noise_psd_matrix, **bf_kwargs)
     elif core in ['wmwf', 'rank1_pca+wmwf', 'rank1_gev+wmwf']:
-        raise NotImplementedError(
-            f'{core}: the wMWF family is outside the accelerated hot path '
-            '(SURVEY.md section 8f, row N4)')
+        if core != 'wmwf':
+            rank1_type, _ = core.split('+')
+            target_psd_matrix = _rank_1_approximation(
+                rank1_type, target_psd_matrix, noise_psd_matrix,
+                **bf_kwargs.pop('atf_kwargs', {}))
+        w = get_wmwf_vector(target_psd_matrix, noise_psd_matrix, **bf_kwargs)
     elif 'ch' in core and core[2:].isdigit():
         D = target_psd_matrix.shape[-1]
         w = np.zeros(D)

@@ -117,6 +117,14 @@ def test_beamformer_api_matches_reference():
     assert np.abs(ex.get_mvdr_vector(g['pca'], n) - g['mvdr']).max() < 1e-9
     assert np.abs(ex.blind_analytic_normalization(g['gev'], n) - g['ban']).max() < 1e-11
     assert np.abs(ex.apply_beamforming_vector(g['mvdr_souden'], X) - g['applied']).max() < 1e-11
+    assert np.abs(ex.get_wmwf_vector(t, n) - g['wmwf']).max() < 1e-10
+    assert np.abs(ex.get_wmwf_vector(t, n, reference_channel=2, distortion_weight=3.)
+                  - g['wmwf_mu3_ch2']).max() < 1e-10
+    assert np.abs(ex.get_wmwf_vector(t, n, reference_channel=0, distortion_weight='frequency_dependent')
+                  - g['wmwf_freqdep']).max() < 1e-10
+    sel = np.zeros(6); sel[1] = 1
+    assert np.abs(ex.get_wmwf_vector(t, n, channel_selection_vector=sel)
+                  - ex.get_wmwf_vector(t, n, reference_channel=1)).max() < 1e-15
     for key in g.files:
         if not key.startswith('bf__'):
             continue
