@@ -313,7 +313,15 @@ int pbbss_cwmm_fit(pbbss_handle_t h, const void* y, int64_t B, int T, int D, int
 /* the launch stream; torch.cuda.Event only sees torch's current stream).      */
 /* ------------------------------------------------------------------------- */
 int pbbss_set_timing(pbbss_handle_t h, int enable);
-/* Development aid: device buffer of 32 uint64 receiving per-phase shader-cycle sums
+/* Tail handling of pbbss_cacgmm_fit (on by default): when B = m * CUs + r with 1 <= r <= 8
+ * (e.g. 513 = 2 * 256 + 1 frequency bins) the r remainder problems are run as "split"
+ * groups -- several workgroups share one problem's frames and exchange partial sums
+ * through L2 -- concurrently on an internal side stream, so that no CU hosts an extra
+ * full workgroup.  pbbss_split_error reads (synchronously) whether a bounded
+ * inter-workgroup wait ever timed out (0 = never). */
+int pbbss_set_split_tail(pbbss_handle_t h, int enable);
+int pbbss_split_error(pbbss_handle_t h, int* out_flag);
+/* Development aid: device buffer of 64 uint64 receiving per-phase shader-cycle sums
  * of the EM kernel ([wave 0..3][phase 0..7]); only written by library builds made
  * with -DPBBSS_PHASE_PROFILE (`make prof`), ignored otherwise.  NULL disables. */
 int pbbss_set_phase_profile(pbbss_handle_t h, void* dev_counters);

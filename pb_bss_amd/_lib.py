@@ -41,7 +41,7 @@ EXPORTS = (
     'pbbss_apply_beamforming_vector', 'pbbss_set_timing',
     'pbbss_last_kernel_ms', 'pbbss_set_phase_profile',
     'pbbss_dhtv_calculate_mapping', 'pbbss_apply_mapping', 'pbbss_cwmm_fit',
-    'pbbss_wmwf',
+    'pbbss_wmwf', 'pbbss_set_split_tail', 'pbbss_split_error',
 )
 
 
@@ -105,6 +105,8 @@ def load():
         lib.pbbss_set_timing.argtypes = [vp, i32]
         lib.pbbss_last_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
         lib.pbbss_set_phase_profile.argtypes = [vp, vp]
+        lib.pbbss_set_split_tail.argtypes = [vp, i32]
+        lib.pbbss_split_error.argtypes = [vp, ctypes.POINTER(ctypes.c_int)]
         lib.pbbss_dhtv_calculate_mapping.argtypes = [vp, vp, i64, i32, i32, i32, vp, i32, i32, vp, vp, vp, vp]
         lib.pbbss_apply_mapping.argtypes = [vp, vp, vp, i64, i32, i32, i32, vp, vp]
         lib.pbbss_cwmm_fit.argtypes = [

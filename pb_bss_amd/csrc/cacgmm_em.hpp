@@ -60,6 +60,15 @@ struct EmArgs {
   size_t scratch_stride;
   // optional phase cycle counters (only honoured by builds with -DPBBSS_PHASE_PROFILE)
   unsigned long long* prof;
+  // ---- split-bin variant (SPLIT=true): G workgroups share the frames of one problem ----
+  // a.T is then the frame count of ONE workgroup's window; global frame = t_first + t
+  int T_total;        // frames of the whole problem (row stride of (B,K,T) arrays); 0 => a.T
+  int split_groups;   // G
+  int split_window;   // frames per workgroup window (multiple of 64)
+  int64_t b_first;    // first problem handled by this launch
+  double* xslab;      // [2][n_problems][G][slab_len] partial sums exchanged through L2
+  unsigned* xcount;   // [n_problems] arrival counters (zeroed before the launch)
+  int* xerror;        // set to 1 if a bounded spin ran out
   // options
   int iterations;
   int covariance_norm;
@@ -158,6 +167,11 @@ struct EmKernel {
     return L;
   }
 
+  // row stride of the (B,K,T)/(B,T) arrays and first global frame of this workgroup
+  static __device__ __forceinline__ int t_stride(const EmArgs& a) {
+    return a.T_total ? a.T_total : a.T;
+  }
+
   // ---- observation frame t from LDS, widened to float64 -------------------
   static __device__ __forceinline__ void load_frame(const Lds& L, int t, double (&re)[D],
                                                     double (&im)[D]) {
@@ -174,8 +188,10 @@ struct EmKernel {
   }
 
   // ---- phase L: HBM -> LDS, squared norms ---------------------------------
-  static __device__ void phase_load(const EmArgs& a, const Lds& L, int64_t b, int tid) {
+  static __device__ void phase_load(const EmArgs& a, const Lds& L, int64_t b, int tid,
+                                    int tf = 0) {
     const int T = a.T;
+    const int TS = t_stride(a);
     const YS2* yg = reinterpret_cast<const YS2*>(a.y);
     bool zero_seen = false;
     for (int t = tid; t < L.Tp; t += kEmThreads) {
@@ -189,8 +205,8 @@ struct EmKernel {
       if (t < T) {
 #pragma unroll
         for (int d = 0; d < D; ++d) {
-          size_t idx = (a.layout == PBBSS_LAYOUT_TD) ? ((size_t)b * T + t) * D + d
-                                                     : ((size_t)b * D + d) * T + t;
+          size_t idx = (a.layout == PBBSS_LAYOUT_TD) ? ((size_t)b * TS + tf + t) * D + d
+                                                     : ((size_t)b * D + d) * TS + tf + t;
           YS2 v = yg[idx];
           vr[d] = v.x;
           vi[d] = v.y;
@@ -228,16 +244,17 @@ struct EmKernel {
 
   // ---- phase I: weights from an affiliation initialisation -----------------
   static __device__ void phase_init_gamma(const EmArgs& a, const Lds& L, int64_t b, int tid,
-                                          int wave, int lane) {
+                                          int wave, int lane, int tf = 0) {
+    const int TS = t_stride(a);
     double s[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) s[k] = 0.0;
     for (int t = tid; t < a.T; t += kEmThreads) {
-      double sal = a.saliency ? a.saliency[(size_t)b * a.T + t] : 1.0;
+      double sal = a.saliency ? a.saliency[(size_t)b * TS + tf + t] : 1.0;
       double inv = L.inv_n2[t];
 #pragma unroll
       for (int k = 0; k < K; ++k) {
-        size_t idx = ((size_t)b * K + k) * a.T + t;
+        size_t idx = ((size_t)b * K + k) * TS + tf + t;
         double g = a.gamma0[idx] * sal;
         double q = a.q0 ? a.q0[idx] : 1.0;
         L.wbuf[(size_t)k * L.Tp + t] = mweight(g, q, inv);
@@ -260,7 +277,8 @@ struct EmKernel {
   //     unswitch the frame loop and spill ~300 VGPRs, hence a template.)
   template <bool FINAL, bool TW>
   static __device__ void phase_e(const EmArgs& a, const Lds& L, int64_t b, int tid, int wave,
-                                 int lane, double eps) {
+                                 int lane, double eps, int tf = 0) {
+    const int TS = t_stride(a);
     constexpr int NF = 1;  // frames per lane per pass (NF=2 shares A_k operand loads but makes hipcc 7.2 spill)
     double s[K];
 #pragma unroll
@@ -379,26 +397,26 @@ struct EmKernel {
         for (int k = 0; k < K; ++k) {
           double w;
           if constexpr (TW) {
-            w = a.in_weight[b * a.wb + k * a.wk + (int64_t)t * a.wt];
+            w = a.in_weight[b * a.wb + k * a.wk + (int64_t)(tf + t) * a.wt];
           } else {
             w = wgt[k];
           }
           double v = ldexp(val[k], ex[k] - emax) * w;  // mixture_model_utils.py:32-37
           const uint8_t* act = FINAL ? a.final_activity : a.activity;
-          if (act) v *= (double)act[((size_t)b * K + k) * a.T + t];
+          if (act) v *= (double)act[((size_t)b * K + k) * TS + tf + t];
           g[k] = v;
           den += v;
         }
         den = fmax(den, kTiny);  // mixture_model_utils.py:43-47
         const double rden = fast_rcp(den);
-        const double sal = (!FINAL && a.saliency) ? a.saliency[(size_t)b * a.T + t] : 1.0;
+        const double sal = (!FINAL && a.saliency) ? a.saliency[(size_t)b * TS + tf + t] : 1.0;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
           double gam = g[k] * rden;
           if (eps != 0.0) gam = fmin(fmax(gam, eps), 1.0 - eps);  // :50-53, no renormalisation
           if constexpr (FINAL) {
             if (ok[f]) {
-              size_t idx = ((size_t)b * K + k) * a.T + t;
+              size_t idx = ((size_t)b * K + k) * TS + tf + t;
               if (a.out_aff) a.out_aff[idx] = gam;
               if (a.out_q) a.out_q[idx] = q[f][k];
               if (a.out_logpdf) {
@@ -472,8 +490,14 @@ struct EmKernel {
         }
       });
     }
+#ifdef PBBSS_PHASE_PROFILE
+    unsigned long long tm0 = __builtin_readcyclecounter();
+#endif
     // halving butterfly over the 64 frame-lanes; 16 lanes each store NACC/16 totals
     wave_reduce_scatter<NACC>(acc, lane);
+#ifdef PBBSS_PHASE_PROFILE
+    unsigned long long tm1 = __builtin_readcyclecounter();
+#endif
     if ((lane & 3) == 0) {
       const int base = reduce_scatter_base<NACC>(lane);
 #pragma unroll
@@ -502,6 +526,14 @@ struct EmKernel {
         }
       }
     }
+#ifdef PBBSS_PHASE_PROFILE
+    if (a.prof && lane == 0 && W == 0) {
+      unsigned long long tm2 = __builtin_readcyclecounter();
+      atomicAdd(a.prof + 64, tm1 - tm0);  // butterfly
+      atomicAdd(a.prof + 65, tm2 - tm1);  // write-back
+      atomicAdd(a.prof + 66, 1ull);
+    }
+#endif
   }
 
   // packed index of pair (i < j)
@@ -563,7 +595,7 @@ struct EmKernel {
       } else if (a.saliency) {
         wnew = S / ((tot == 0.0) ? 1e-10 : tot);  // :192-201
       } else {
-        wnew = S / (double)a.T;  // :188
+        wnew = S / (double)t_stride(a);  // :188
       }
       L.wgt[k] = wnew;
     }
@@ -695,6 +727,198 @@ struct EmKernel {
     }
   }
 
+  // ===================== split-bin variant ====================================
+  // G workgroups share ONE problem: each owns a window of `split_window` frames,
+  // runs the E and M phases on it, and the partial covariance / class sums are
+  // exchanged through an L2-resident slab once per iteration; every workgroup
+  // then factors the (identical) totals redundantly.  Used for the few remainder
+  // problems of a launch (B = 2^n + 1 frequency bins on a 256-CU device would
+  // otherwise put a third full workgroup on one CU and set the kernel time).
+  //
+  // Hand-off protocol (cdna_hip_programming.md guideline 16, form R1): write-through
+  // (sc1, relaxed agent-scope) slab stores -> every storing wave drains vmcnt(0) ->
+  // __syncthreads -> one lane arrives on a monotonic agent-scope counter and polls it
+  // (relaxed, bounded, s_sleep) -> __syncthreads -> sc1 loads of all slabs.  No cache
+  // flushing fences (each costs ~1.7 us).  Slabs are double-buffered by iteration
+  // parity; a timed-out spin sets *xerror and never hangs.
+  static constexpr int kSlabLen = K * NA + K + 1;
+  static constexpr unsigned kSpinLimit = 20000000u;  // ~2 s of polling before giving up
+
+  static __device__ void split_exchange(const EmArgs& a, const Lds& L, int prob, int nprob, int g,
+                                        int it, int tid) {
+    const int G = a.split_groups;
+    double* slabs = a.xslab + ((size_t)(it & 1) * nprob + prob) * (size_t)G * kSlabLen;
+    double* mine = slabs + (size_t)g * kSlabLen;
+    for (int idx = tid; idx < kSlabLen; idx += kEmThreads) {
+      double v;
+      if (idx < K * NA) {
+        const int k = idx / NA, e = idx % NA;
+        if (e < D) {
+          v = L.cmat[(((size_t)k * D + e) * D + e) * 2];
+        } else {
+          const int p = (e - D) >> 1;
+          const int i = tri_i<D>(p), j = tri_j<D>(p);
+          v = L.cmat[(((size_t)k * D + i) * D + j) * 2 + ((e - D) & 1)];
+        }
+      } else if (idx < K * NA + K) {
+        const int k = idx - K * NA;
+        v = 0.0;
+#pragma unroll
+        for (int w = 0; w < kEmWaves; ++w) v += L.red[w * K + k];
+      } else {
+        v = (double)(*L.flags & 1);
+      }
+      // write-through (sc1) store: visible in L2 without a release fence
+      __hip_atomic_store(mine + idx, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its stores
+    __syncthreads();
+    if (tid == 0) {
+      unsigned* cnt = a.xcount + prob;
+      __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned target = (unsigned)G * (unsigned)(it + 1);
+      unsigned spins = 0;
+      while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > kSpinLimit) {
+          atomicExch(a.xerror, 1);
+          break;
+        }
+      }
+    }
+    __syncthreads();
+    // class sums first into registers (L.red is both source above and target below)
+    for (int idx = tid; idx < kSlabLen; idx += kEmThreads) {
+      // sc1 loads (L2, bypassing this CU's L1) pair with the sc1 stores: no acquire fence.
+      // All peers' values are requested back-to-back (one L2 round trip, not G of them).
+      double tot = 0.0;
+      for (int g0 = 0; g0 < G; g0 += 8) {
+        double part[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int gg = (g0 + u < G) ? g0 + u : g;  // clamp to a valid slab, masked below
+          part[u] = __hip_atomic_load(slabs + (size_t)gg * kSlabLen + idx, __ATOMIC_RELAXED,
+                                      __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) tot += (g0 + u < G) ? part[u] : 0.0;
+      }
+      if (idx < K * NA) {
+        const int k = idx / NA, e = idx % NA;
+        if (e < D) {
+          double* c = L.cmat + (((size_t)k * D + e) * D + e) * 2;
+          c[0] = tot;
+          c[1] = 0.0;
+        } else {
+          const int p = (e - D) >> 1;
+          const int i = tri_i<D>(p), j = tri_j<D>(p);
+          const int im = (e - D) & 1;
+          L.cmat[(((size_t)k * D + i) * D + j) * 2 + im] = tot;
+          L.cmat[(((size_t)k * D + j) * D + i) * 2 + im] = im ? -tot : tot;
+        }
+      } else if (idx < K * NA + K) {
+        const int k = idx - K * NA;
+        L.red[k] = tot;  // wave 0's slot carries the total, the others are cleared
+#pragma unroll
+        for (int w = 1; w < kEmWaves; ++w) L.red[w * K + k] = 0.0;
+      } else {
+        if (tot > 0.0) *L.flags |= 1;
+      }
+    }
+    __syncthreads();
+  }
+
+  static __device__ void run_split(const EmArgs& ga, char* smem) {
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int G = ga.split_groups;
+    const int prob = blockIdx.x / G, g = blockIdx.x % G;
+    const int nprob = gridDim.x / G;
+    const int64_t b = ga.b_first + prob;
+    const int tf = g * ga.split_window;
+    // The split waves sit on CUs that also host two full workgroups; their work is a
+    // sliver of the CU's but their dependency chain sets the launch time: let them win
+    // the issue arbitration.
+    __builtin_amdgcn_s_setprio(3);
+    EmArgs a = ga;  // this workgroup's window
+    a.T = min(ga.split_window, ga.T_total - tf);
+    const Lds L = carve(smem, ga.split_window, nullptr);
+#ifdef PBBSS_PHASE_PROFILE
+    unsigned long long spc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long stprev = __builtin_readcyclecounter();
+#define PBBSS_STICK(i)                                       \
+  {                                                          \
+    unsigned long long tn = __builtin_readcyclecounter();    \
+    spc[i] += tn - stprev;                                   \
+    stprev = tn;                                             \
+  }
+#else
+#define PBBSS_STICK(i)
+#endif
+    if (tid < K) L.status[tid] = 0;
+    if (tid == 0) *L.flags = 0;
+    __syncthreads();
+    phase_load(a, L, b, tid, tf);
+    __syncthreads();
+    const bool model_in = (a.gamma0 == nullptr);
+    if (model_in) {
+      for (int k = wave; k < K; k += kEmWaves) prep_from_model(a, L, b, k, lane);
+    } else {
+      phase_init_gamma(a, L, b, tid, wave, lane, tf);
+    }
+    __syncthreads();
+    for (int it = 0; it < a.iterations; ++it) {
+      if (it > 0 || model_in) {
+        // windows are <= 256 frames (one E pass): waves that own no frame skip the phase
+        if ((wave << 6) < a.T) {
+          phase_e<false, false>(a, L, b, tid, wave, lane, a.aff_eps, tf);
+        } else if (lane < K) {
+          L.red[wave * K + lane] = 0.0;
+        }
+        PBBSS_STICK(1)
+        __syncthreads();
+        PBBSS_STICK(2)
+      }
+      switch (wave) {
+        case 0: phase_m<0>(a, L, lane); break;
+        case 1: phase_m<1>(a, L, lane); break;
+        case 2: phase_m<2>(a, L, lane); break;
+        default: phase_m<3>(a, L, lane); break;
+      }
+      PBBSS_STICK(3)
+      __syncthreads();
+      split_exchange(a, L, prob, nprob, g, it, tid);
+      PBBSS_STICK(4)
+      const bool last = (it == a.iterations - 1);
+      // every workgroup factors the same totals; only group 0 writes the model
+      EmArgs fa = a;
+      if (g != 0) {
+        fa.out_eigvec = nullptr;
+        fa.out_eigval = nullptr;
+        fa.out_cov = nullptr;
+      }
+      for (int k = wave; k < K; k += kEmWaves) factor_class(fa, L, b, k, lane, last);
+      PBBSS_STICK(5)
+      __syncthreads();
+      PBBSS_STICK(6)
+    }
+#ifdef PBBSS_PHASE_PROFILE
+    // split launches report into the second half of the counter buffer: [32 + wave*8 + i]
+    if (ga.prof && lane == 0) {
+      for (int i = 0; i < 8; ++i) atomicAdd(ga.prof + 32 + wave * 8 + i, spc[i]);
+    }
+#endif
+    if (tid < K && g == 0) {
+      if (a.out_weight && a.iterations > 0) a.out_weight[(size_t)b * K + tid] = L.wgt[tid];
+      // a timed-out inter-workgroup wait invalidates the result: report it as a failed solve
+      const int xerr = __hip_atomic_load(a.xerror, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (a.out_status)
+        a.out_status[(size_t)b * K + tid] = L.status[tid] | (xerr ? PBBSS_ST_EIG_NOCONV : 0);
+    }
+    if (a.final_predict) phase_e<true, false>(a, L, b, tid, wave, lane, a.final_eps, tf);
+  }
+
   static __device__ void run(const EmArgs& a, char* smem) {
     const int tid = threadIdx.x;
     // wave index is uniform across the wavefront: tell the compiler so the phase
@@ -784,6 +1008,12 @@ template <int D, int K, typename YS, bool SPILL>
 __global__ void __launch_bounds__(kEmThreads, em_waves_per_simd(K)) cacgmm_em_kernel(EmArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   EmKernel<D, K, YS, SPILL>::run(a, smem);
+}
+
+template <int D, int K, typename YS>
+__global__ void __launch_bounds__(kEmThreads, em_waves_per_simd(K)) cacgmm_em_split_kernel(EmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  EmKernel<D, K, YS, false>::run_split(a, smem);
 }
 
 }  // namespace pbbss

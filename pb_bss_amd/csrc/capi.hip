@@ -1,6 +1,7 @@
 // extern "C" boundary of libpbbss_hip.so (see include/pbbss.h).  Argument
 // validation, handle state, kernel dispatch; no numerical code lives here.
 #include "pbbss.h"
+#include <cstdlib>
 #include "beamform.hpp"
 #include "dhtv.hpp"
 #include "em_launch.hpp"
@@ -81,6 +82,26 @@ PBBSS_API int pbbss_create(pbbss_handle_t* out, int device_id) {
   h->cfg.lds_limit = lds;
   h->cfg.get_scratch = handle_scratch;
   h->cfg.scratch_ctx = h;
+  h->cfg.allow_split = 1;
+  h->cfg.split_window = pbbss::kSplitWindow;
+  if (const char* w = getenv("PBBSS_SPLIT_WINDOW")) {
+    int v = atoi(w);
+    if (v >= 64 && v % 64 == 0) h->cfg.split_window = v;
+  }
+  h->cfg.xbuf_bytes = (size_t)1 << 20;
+  h->cfg.xbuf = nullptr;
+  h->cfg.side_stream = nullptr;
+  {
+    void* xb = nullptr;
+    if (hipMalloc(&xb, h->cfg.xbuf_bytes) != hipSuccess ||
+        hipStreamCreateWithFlags(&h->cfg.side_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&h->cfg.ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->cfg.ev_join, hipEventDisableTiming) != hipSuccess) {
+      delete h;
+      return PBBSS_ERR_HIP;
+    }
+    h->cfg.xbuf = static_cast<char*>(xb);
+  }
   h->scratch = nullptr;
   h->scratch_bytes = 0;
   h->prof = nullptr;
@@ -99,6 +120,10 @@ PBBSS_API int pbbss_destroy(pbbss_handle_t h) {
   (void)hipEventDestroy(h->ev0);
   (void)hipEventDestroy(h->ev1);
   if (h->scratch) (void)hipFree(h->scratch);
+  if (h->cfg.xbuf) (void)hipFree(h->cfg.xbuf);
+  if (h->cfg.side_stream) (void)hipStreamDestroy(h->cfg.side_stream);
+  (void)hipEventDestroy(h->cfg.ev_fork);
+  (void)hipEventDestroy(h->cfg.ev_join);
   delete h;
   return PBBSS_OK;
 }
@@ -112,6 +137,21 @@ PBBSS_API int pbbss_set_timing(pbbss_handle_t h, int enable) {
 PBBSS_API int pbbss_set_phase_profile(pbbss_handle_t h, void* dev_counters) {
   if (!h) return PBBSS_ERR_INVALID_ARG;
   h->prof = static_cast<unsigned long long*>(dev_counters);
+  return PBBSS_OK;
+}
+
+PBBSS_API int pbbss_set_split_tail(pbbss_handle_t h, int enable) {
+  if (!h) return PBBSS_ERR_INVALID_ARG;
+  h->cfg.allow_split = enable ? 1 : 0;
+  return PBBSS_OK;
+}
+
+PBBSS_API int pbbss_split_error(pbbss_handle_t h, int* out_flag) {
+  if (!h || !out_flag) return PBBSS_ERR_INVALID_ARG;
+  int v = 0;
+  if (hipMemcpy(&v, h->cfg.xbuf + 128, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)
+    return PBBSS_ERR_HIP;
+  *out_flag = v;
   return PBBSS_OK;
 }
 

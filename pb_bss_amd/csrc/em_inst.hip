@@ -33,11 +33,57 @@ static int launch_variant(EmArgs a, const EmLaunchCfg& cfg, hipStream_t stream) 
   return hipGetLastError() == hipSuccess ? PBBSS_OK : PBBSS_ERR_HIP;
 }
 
+// Remainder problems [b_first, b_first + r) as split groups on the side stream,
+// concurrent with the main launch (fork/join through events).
+template <int K, typename YS>
+static int launch_split(EmArgs a, int64_t b_first, int r, const EmLaunchCfg& cfg,
+                        hipStream_t stream) {
+  using Kern = EmKernel<PBBSS_EM_D, K, YS, false>;
+  const int window = cfg.split_window > 256 ? 256 : cfg.split_window;  // one E pass per window
+  const int G = (a.T + window - 1) / window;
+  const size_t lds = Kern::lds_bytes(window);
+  const size_t slab_bytes = (size_t)2 * r * G * Kern::kSlabLen * sizeof(double);
+  const size_t head = 256;  // counters (r uint) + error word
+  if (head + slab_bytes > cfg.xbuf_bytes) return PBBSS_ERR_UNSUPPORTED;
+  auto kfn = cacgmm_em_split_kernel<PBBSS_EM_D, K, YS>;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return PBBSS_ERR_HIP;
+  a.T_total = a.T;
+  a.split_groups = G;
+  a.split_window = window;
+  a.b_first = b_first;
+  a.xcount = reinterpret_cast<unsigned*>(cfg.xbuf);
+  a.xerror = reinterpret_cast<int*>(cfg.xbuf + 128);
+  a.xslab = reinterpret_cast<double*>(cfg.xbuf + head);
+  if (hipEventRecord(cfg.ev_fork, stream) != hipSuccess) return PBBSS_ERR_HIP;
+  if (hipStreamWaitEvent(cfg.side_stream, cfg.ev_fork, 0) != hipSuccess) return PBBSS_ERR_HIP;
+  if (hipMemsetAsync(cfg.xbuf, 0, head, cfg.side_stream) != hipSuccess) return PBBSS_ERR_HIP;
+  hipLaunchKernelGGL(kfn, dim3((unsigned)(r * G)), dim3(kEmThreads), lds, cfg.side_stream, a);
+  if (hipGetLastError() != hipSuccess) return PBBSS_ERR_HIP;
+  if (hipEventRecord(cfg.ev_join, cfg.side_stream) != hipSuccess) return PBBSS_ERR_HIP;
+  return PBBSS_OK;
+}
+
 template <int K, typename YS>
 static int launch_one(const EmArgs& a, const EmLaunchCfg& cfg, hipStream_t stream) {
-  if (EmKernel<PBBSS_EM_D, K, YS, false>::lds_bytes(a.T) <= cfg.lds_limit)
-    return launch_variant<K, YS, false>(a, cfg, stream);
-  return launch_variant<K, YS, true>(a, cfg, stream);  // long utterance: frames in HBM/L2
+  if (EmKernel<PBBSS_EM_D, K, YS, false>::lds_bytes(a.T) > cfg.lds_limit)
+    return launch_variant<K, YS, true>(a, cfg, stream);  // long utterance: frames in HBM/L2
+  // Tail handling: with B = m * num_cu + r (small r) the r extra problems would add a
+  // full workgroup to r CUs and set the kernel time; split them over many CUs instead.
+  const int64_t r = a.B % cfg.num_cu;
+  const bool split = cfg.allow_split && a.iterations > 0 && a.B > cfg.num_cu &&
+                     a.B <= 3 * (int64_t)cfg.num_cu && r >= 1 && r <= kSplitMaxProblems &&
+                     a.T >= 2 * cfg.split_window && a.wt == 0;
+  if (!split) return launch_variant<K, YS, false>(a, cfg, stream);
+  EmArgs main_a = a;
+  main_a.B = a.B - r;
+  int rc = launch_split<K, YS>(a, a.B - r, (int)r, cfg, stream);
+  if (rc != PBBSS_OK) return rc;
+  rc = launch_variant<K, YS, false>(main_a, cfg, stream);
+  if (rc != PBBSS_OK) return rc;
+  if (hipStreamWaitEvent(stream, cfg.ev_join, 0) != hipSuccess) return PBBSS_ERR_HIP;
+  return PBBSS_OK;
 }
 
 template <typename YS>

@@ -12,7 +12,17 @@ struct EmLaunchCfg {
   // grow-only device scratch owned by the handle (frame arrays of long utterances)
   void* (*get_scratch)(void* ctx, size_t bytes);
   void* scratch_ctx;
+  // split-bin remainder launches: side stream + fork/join events + exchange buffer
+  hipStream_t side_stream;
+  hipEvent_t ev_fork, ev_join;
+  char* xbuf;        // [xbuf_bytes] device memory: counters, error word, slabs
+  size_t xbuf_bytes;
+  int allow_split;   // 0 disables the split variant (tests / debugging)
+  int split_window;  // frames per workgroup of a split problem (multiple of 64)
 };
+
+constexpr int kSplitWindow = 64;      // default frames per workgroup of a split problem
+constexpr int kSplitMaxProblems = 8;  // at most this many remainder problems are split
 
 // defined in em_inst.hip, one per compiled D
 int em_launch_d2(int K, int y_is_c128, const EmArgs&, const EmLaunchCfg&, hipStream_t);

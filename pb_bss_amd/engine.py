@@ -365,3 +365,17 @@ def wmwf(target, noise, distortion_weight=1.0, frequency_dependent=False):
         _lib.ptr(num), _lib.ptr(den), _lib.ptr(st), _lib.stream_ptr(target.device.index))
     _lib.check(rc, f'wmwf(N={N},D={D})')
     return mat, num, den, st
+
+
+def set_split_tail(enable, device_index=None):
+    """pbbss_set_split_tail: toggle the split-bin handling of remainder problems."""
+    _lib.check(_lib.load().pbbss_set_split_tail(_lib.handle(device_index), int(bool(enable))),
+               'set_split_tail')
+
+
+def split_error(device_index=None):
+    """pbbss_split_error: 1 if an inter-workgroup wait of a split launch ever timed out."""
+    flag = ctypes.c_int()
+    _lib.check(_lib.load().pbbss_split_error(_lib.handle(device_index), ctypes.byref(flag)),
+               'split_error')
+    return int(flag.value)

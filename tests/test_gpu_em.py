@@ -219,3 +219,26 @@ def test_long_utterance_spills_frames_to_hbm():
     m, mask = _oracle_fit(Y, init, 2)
     r = _device_fit(Y, init, 2)
     assert np.abs(_host(r['affiliation']) - mask).max() < 1e-9
+
+
+@pytest.mark.parametrize('F,T,D,K', [(257, 200, 4, 2), (258, 130, 8, 3), (513, 300, 6, 4)])
+def test_split_tail_equals_plain_launch(F, T, D, K):
+    """B = m*256 + r: the r remainder problems run as split groups (several
+    workgroups share one bin's frames and exchange partial sums through L2).
+    Same answer as the plain launch and as the oracle; no inter-workgroup
+    wait may time out."""
+    from oracle import synth
+    from pb_bss_amd import engine
+    Y, init = synth.make_stft(F, T, D, K, seed=F + T)
+    engine.set_split_tail(False)
+    try:
+        plain = _device_fit(Y, init, 6)
+    finally:
+        engine.set_split_tail(True)
+    split = _device_fit(Y, init, 6)
+    assert engine.split_error() == 0
+    for key in ('affiliation', 'eigval', 'weight', 'quadratic_form'):
+        ref = _host(plain[key])
+        assert np.abs(_host(split[key]) - ref).max() < 1e-10 * max(1.0, np.abs(ref).max()), key
+    m, mask = _oracle_fit(Y[-3:], init[-3:], 6)   # the tail bins against the oracle
+    assert np.abs(_host(split['affiliation'])[-3:] - mask).max() < 1e-9

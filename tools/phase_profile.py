@@ -20,7 +20,7 @@ def main():
     Y = np.concatenate([synth.make_stft(513, 500, 8, 3, seed=s)[0] for s in range(nutt)])
     g = np.concatenate([synth.make_stft(513, 500, 8, 3, seed=s)[1] for s in range(nutt)])
     y, g0 = _lib.to_device(Y), _lib.to_device(g)
-    cnt = torch.zeros(32, dtype=torch.int64, device='cuda')
+    cnt = torch.zeros(72, dtype=torch.int64, device='cuda')
     h = _lib.handle()
     _lib.load().pbbss_set_phase_profile(h, ctypes.c_void_p(cnt.data_ptr()))
     engine.set_timing(True)
@@ -28,7 +28,11 @@ def main():
     cnt.zero_()
     engine.em_fit(y, 3, gamma0=g0, iterations=iters, final_predict=True)
     ms = engine.last_kernel_ms()
-    c = cnt.cpu().numpy().reshape(4, 8).astype(np.float64)
+    call = cnt.cpu().numpy().astype(np.float64)
+    c = call[:32].reshape(4, 8)
+    cs = call[32:64].reshape(4, 8)
+    if call[66] > 0:
+        print(f'  phase M (wave 0): butterfly {call[64]/call[66]:.0f} ticks, write-back {call[65]/call[66]:.0f} ticks per call')
     nwg = min(513 * nutt, 256 * 3)
     print(f'utterances {nutt}: kernel {ms:.3f} ms, {nutt*iters/ms*1e3:.0f} utt-iter/s; cycles per workgroup-iteration '
           f'(avg over {nwg} workgroups, s_memtime ticks):')
@@ -36,6 +40,11 @@ def main():
     for w in range(4):
         print(f'  wave {w}: ' + ', '.join(f'{n} {per[w, i]:.0f}' for i, n in enumerate(NAMES)))
     tot = per[0].sum()
+    if cs.sum() > 0:
+        G = (500 + 63) // 64
+        print('  split group (per workgroup-iteration, 8 workgroups): 1 E, 2 E-barrier, 3 M, 4 M-barrier+exchange, 5 factor, 6 barrier')
+        for w in range(4):
+            print(f'    wave {w}: ' + ', '.join(f'{i}:{cs[w, i] / G / iters:.0f}' for i in range(8)))
     print(f'  wave0 total {tot:.0f} ticks per problem-iteration')
 
 
