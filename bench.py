@@ -157,7 +157,8 @@ def main():
             'roofline': {
                 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
-                'kernel': 'cacgmm_em_kernel<8,3,float,false>',
+                'kernel': 'cacgmm_em_kernel<8,3,float,false> (+ concurrent cacgmm_em_split_kernel for '
+                          'the remainder bins; kernel_ms brackets both)',
                 'kernel_ms': avg_kernel_s * 1e3,
                 'algorithmic_bytes_per_launch': alg_bytes,
                 'note': 'y stays in LDS for the whole EM loop; the binding resource is '

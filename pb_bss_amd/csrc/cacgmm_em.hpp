@@ -69,6 +69,7 @@ struct EmArgs {
   double* xslab;      // [2][n_problems][G][slab_len] partial sums exchanged through L2
   unsigned* xcount;   // [n_problems] arrival counters (zeroed before the launch)
   int* xerror;        // set to 1 if a bounded spin ran out
+  int split_prio;     // s_setprio level of the split waves (0..3)
   // options
   int iterations;
   int covariance_norm;
@@ -840,7 +841,12 @@ struct EmKernel {
     // The split waves sit on CUs that also host two full workgroups; their work is a
     // sliver of the CU's but their dependency chain sets the launch time: let them win
     // the issue arbitration.
-    __builtin_amdgcn_s_setprio(3);
+    switch (ga.split_prio) {
+      case 1: __builtin_amdgcn_s_setprio(1); break;
+      case 2: __builtin_amdgcn_s_setprio(2); break;
+      case 3: __builtin_amdgcn_s_setprio(3); break;
+      default: break;
+    }
     EmArgs a = ga;  // this workgroup's window
     a.T = min(ga.split_window, ga.T_total - tf);
     const Lds L = carve(smem, ga.split_window, nullptr);

@@ -84,6 +84,8 @@ PBBSS_API int pbbss_create(pbbss_handle_t* out, int device_id) {
   h->cfg.scratch_ctx = h;
   h->cfg.allow_split = 1;
   h->cfg.split_window = pbbss::kSplitWindow;
+  h->cfg.split_prio = 1;
+  if (const char* p = getenv("PBBSS_SPLIT_PRIO")) h->cfg.split_prio = atoi(p);
   if (const char* w = getenv("PBBSS_SPLIT_WINDOW")) {
     int v = atoi(w);
     if (v >= 64 && v % 64 == 0) h->cfg.split_window = v;

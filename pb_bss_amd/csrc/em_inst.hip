@@ -52,6 +52,7 @@ static int launch_split(EmArgs a, int64_t b_first, int r, const EmLaunchCfg& cfg
   a.T_total = a.T;
   a.split_groups = G;
   a.split_window = window;
+  a.split_prio = cfg.split_prio;
   a.b_first = b_first;
   a.xcount = reinterpret_cast<unsigned*>(cfg.xbuf);
   a.xerror = reinterpret_cast<int*>(cfg.xbuf + 128);

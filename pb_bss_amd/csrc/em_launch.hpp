@@ -19,6 +19,7 @@ struct EmLaunchCfg {
   size_t xbuf_bytes;
   int allow_split;   // 0 disables the split variant (tests / debugging)
   int split_window;  // frames per workgroup of a split problem (multiple of 64)
+  int split_prio;    // s_setprio level of the split waves
 };
 
 constexpr int kSplitWindow = 64;      // default frames per workgroup of a split problem
