@@ -516,7 +516,7 @@ struct EmKernel {
           } else {
             const int p = ((s - NDW) >> 1) * kEmWaves + W;
             if (p < NOFF) {
-              const int i = tri_i<D>(p), j = tri_j<D>(p);
+              const int i = kTriTable<D>.i[p], j = kTriTable<D>.j[p];
               const bool is_im = ((s - NDW) & 1) != 0;
               // C_ij gets +v (re) / +v (im); C_ji = conj(C_ij)
               L.cmat[(((size_t)k * D + i) * D + j) * 2 + (is_im ? 1 : 0)] = acc[m];
@@ -758,7 +758,7 @@ struct EmKernel {
           v = L.cmat[(((size_t)k * D + e) * D + e) * 2];
         } else {
           const int p = (e - D) >> 1;
-          const int i = tri_i<D>(p), j = tri_j<D>(p);
+          const int i = kTriTable<D>.i[p], j = kTriTable<D>.j[p];
           v = L.cmat[(((size_t)k * D + i) * D + j) * 2 + ((e - D) & 1)];
         }
       } else if (idx < K * NA + K) {
@@ -812,7 +812,7 @@ struct EmKernel {
           c[1] = 0.0;
         } else {
           const int p = (e - D) >> 1;
-          const int i = tri_i<D>(p), j = tri_j<D>(p);
+          const int i = kTriTable<D>.i[p], j = kTriTable<D>.j[p];
           const int im = (e - D) & 1;
           L.cmat[(((size_t)k * D + i) * D + j) * 2 + im] = tot;
           L.cmat[(((size_t)k * D + j) * D + i) * 2 + im] = im ? -tot : tot;

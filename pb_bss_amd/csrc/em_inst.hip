@@ -73,9 +73,13 @@ static int launch_one(const EmArgs& a, const EmLaunchCfg& cfg, hipStream_t strea
   // Tail handling: with B = m * num_cu + r (small r) the r extra problems would add a
   // full workgroup to r CUs and set the kernel time; split them over many CUs instead.
   const int64_t r = a.B % cfg.num_cu;
+  const int window = cfg.split_window > 256 ? 256 : cfg.split_window;
+  const size_t slab_need =
+      256 + (size_t)2 * r * ((a.T + window - 1) / window) *
+                EmKernel<PBBSS_EM_D, K, YS, false>::kSlabLen * sizeof(double);
   const bool split = cfg.allow_split && a.iterations > 0 && a.B > cfg.num_cu &&
                      a.B <= 3 * (int64_t)cfg.num_cu && r >= 1 && r <= kSplitMaxProblems &&
-                     a.T >= 2 * cfg.split_window && a.wt == 0;
+                     a.T >= 2 * cfg.split_window && a.wt == 0 && slab_need <= cfg.xbuf_bytes;
   if (!split) return launch_variant<K, YS, false>(a, cfg, stream);
   EmArgs main_a = a;
   main_a.B = a.B - r;

@@ -41,6 +41,23 @@ __host__ __device__ constexpr int tri_j(int p) {
   return i + 1 + p;
 }
 
+
+// (i, j) of every strict-upper pair p as a constant table (run-time lookups; the
+// constexpr functions above are for compile-time indices only)
+template <int D>
+struct TriTable {
+  unsigned char i[D * (D - 1) / 2 + 1];
+  unsigned char j[D * (D - 1) / 2 + 1];
+  constexpr TriTable() : i{}, j{} {
+    for (int p = 0; p < D * (D - 1) / 2; ++p) {
+      i[p] = (unsigned char)tri_i<D>(p);
+      j[p] = (unsigned char)tri_j<D>(p);
+    }
+  }
+};
+template <int D>
+__device__ constexpr TriTable<D> kTriTable{};
+
 // ---- wave64 cross-lane --------------------------------------------------
 __device__ __forceinline__ double lane_get(double v, int src_lane) {
   return __shfl(v, src_lane, kWave);
