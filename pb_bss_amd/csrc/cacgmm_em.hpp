@@ -279,6 +279,8 @@ struct EmKernel {
   template <bool FINAL, bool TW>
   static __device__ void phase_e(const EmArgs& a, const Lds& L, int64_t b, int tid, int wave,
                                  int lane, double eps, int tf = 0) {
+    tid = opaque(tid);
+    lane = opaque(lane);
     const int TS = t_stride(a);
     constexpr int NF = 1;  // frames per lane per pass (NF=2 shares A_k operand loads but makes hipcc 7.2 spill)
     double s[K];
@@ -456,6 +458,7 @@ struct EmKernel {
 
   template <int W>
   static __device__ void phase_m(const EmArgs& a, const Lds& L, int lane) {
+    lane = opaque(lane);
     double acc[NACC];
 #pragma unroll
     for (int x = 0; x < NACC; ++x) acc[x] = 0.0;
@@ -575,6 +578,7 @@ struct EmKernel {
   // ---- phase F for one class (one wave) ------------------------------------
   static __device__ void factor_class(const EmArgs& a, const Lds& L, int64_t b, int k, int lane,
                                       bool last) {
+    lane = opaque(lane);
     const LaneIJ c = lane_ij(lane);
     const bool valid = c.i < D && c.j < D;
     // class sums of the E phase (per-wave partials in L.red) -> sum_t gamma_kt and the

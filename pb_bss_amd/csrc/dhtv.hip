@@ -89,12 +89,19 @@ __global__ void __launch_bounds__(kDhtvThreads)
     const double inv_n = 1.0 / (double)(end - start);
     for (int it = 0; it < iterations; ++it) {
       // time centroid = mean over the segment's bins, then unit norm per class (:334-340)
+      // (eight independent partial sums: the loads of a column are L2 round trips, a
+      // single running sum would serialise ~100 of them per thread)
       for (int col = tid; col < K * T; col += kDhtvThreads) {
         const int k = col / T, t = col - k * T;
         const double* p = feat + ((int64_t)k * F + start) * T + t;
-        double s = 0.0;
-        for (int f = start; f < end; ++f, p += T) s += *p;
-        cent[col] = s * inv_n;
+        double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int f = start;
+        for (; f + 8 <= end; f += 8, p += 8 * (int64_t)T) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) s[u] += p[u * (int64_t)T];
+        }
+        for (; f < end; ++f, p += T) s[0] += *p;
+        cent[col] = (((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]))) * inv_n;
       }
       __syncthreads();
       for (int k = 0; k < K; ++k) {
@@ -116,17 +123,28 @@ __global__ void __launch_bounds__(kDhtvThreads)
         for (int a = 0; a < K; ++a)
 #pragma unroll
           for (int b = 0; b < K; ++b) sc[a][b] = 0.0;
-        for (int t = lane; t < T; t += kWave) {
-          double fv[K], cv[K];
+        // four frame-steps per trip: all their global loads are issued before the first
+        // FMA so the L2 round trips overlap (a 1-step loop serialises 8 of them per bin)
+        for (int t0 = lane; t0 < T; t0 += 4 * kWave) {
+          double fv[4][K], cv[4][K];
 #pragma unroll
-          for (int k = 0; k < K; ++k) {
-            fv[k] = feat[((int64_t)k * F + f) * T + t];
-            cv[k] = cent[k * T + t];
+          for (int u = 0; u < 4; ++u) {
+            const int t = t0 + u * kWave;
+            const bool ok = t < T;
+            const int tc = ok ? t : lane;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+              double v = feat[((int64_t)k * F + f) * T + tc];
+              fv[u][k] = ok ? v : 0.0;
+              cv[u][k] = cent[k * T + tc];
+            }
           }
 #pragma unroll
-          for (int a = 0; a < K; ++a)
+          for (int u = 0; u < 4; ++u)
 #pragma unroll
-            for (int b = 0; b < K; ++b) sc[a][b] = fma(cv[a], fv[b], sc[a][b]);
+            for (int a = 0; a < K; ++a)
+#pragma unroll
+              for (int b = 0; b < K; ++b) sc[a][b] = fma(cv[u][a], fv[u][b], sc[a][b]);
         }
         bool finite = true;
 #pragma unroll

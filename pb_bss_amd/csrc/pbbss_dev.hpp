@@ -58,6 +58,17 @@ struct TriTable {
 template <int D>
 __device__ constexpr TriTable<D> kTriTable{};
 
+
+// Hide a value's provenance from the optimiser.  Used on lane / thread ids at the top
+// of each phase of the persistent EM loop: otherwise LICM hoists every lane-derived
+// address computation out of the iteration loop, runs out of registers and spills
+// them to scratch (~60 scratch loads per iteration); recomputing a few integer ops
+// in place is cheaper.
+__device__ __forceinline__ int opaque(int x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
+
 // ---- wave64 cross-lane --------------------------------------------------
 __device__ __forceinline__ double lane_get(double v, int src_lane) {
   return __shfl(v, src_lane, kWave);
