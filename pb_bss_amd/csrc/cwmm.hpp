@@ -108,6 +108,8 @@ struct WatsonKernel {
   template <bool FINAL>
   static __device__ void phase_e(const WatsonArgs& wa, const Lds& L, int64_t b, int tid, int wave,
                                  int lane) {
+    tid = opaque(tid);
+    lane = opaque(lane);
     const EmArgs& a = wa.em;
     double s[K];
 #pragma unroll
@@ -216,6 +218,7 @@ struct WatsonKernel {
 
   static __device__ void factor_class(const WatsonArgs& wa, const Lds& L, int64_t b, int k,
                                       int lane, bool last) {
+    lane = opaque(lane);
     const EmArgs& a = wa.em;
     const LaneIJ c = lane_ij(lane);
     const bool valid = c.i < D && c.j < D;
