@@ -223,6 +223,58 @@ def cwmm_cases():
           ratio_d5=t.hypergeometric_ratio(ks))
 
 
+def embed_cases():
+    """N2 (vMF mixture) and N3 (joint spatial+spectral mixtures) fixtures."""
+    from pb_bss.distribution import (VMFMMTrainer, GCACGMMTrainer, VMFCACGMMTrainer,
+                                     GaussianTrainer, VonMisesFisherTrainer)
+    from pb_bss.distribution.von_mises_fisher import VonMisesFisher
+    Y, e, init = synth.make_joint(6, 80, 4, 3, 10, seed=3)
+    e64 = e.astype(np.float64)
+    Y128 = Y.astype(np.complex128)
+    flat = e64.reshape(-1, 10)
+    i0 = init.transpose(1, 0, 2).reshape(3, -1)
+    m = VMFMMTrainer().fit(flat, initialization=i0, iterations=7)
+    _save('embed_vmfmm_n480_e10_k3', y=e.reshape(-1, 10), init=i0, iterations=7,
+          mean=m.vmf.mean, concentration=m.vmf.concentration, weight=m.weight,
+          affiliation=m.predict(flat), log_pdf=m.vmf.log_pdf(flat[None]))
+    sal = np.abs(Y128[..., 0])
+    m = VMFMMTrainer().fit(e64, initialization=init, iterations=5, saliency=sal,
+                           max_concentration=40.)
+    _save('embed_vmfmm_indep_f6_t80_e10_k3', y=e, init=init, saliency=sal, iterations=5,
+          max_concentration=40., mean=m.vmf.mean, concentration=m.vmf.concentration,
+          weight=m.weight, affiliation=m.predict(e64))
+    ks = np.array([1e-10, 1e-3, 0.7, 5.0, 37.5, 120.0, 500.0])
+    _save('embed_vmf_log_norm', concentrations=ks,
+          **{f'log_norm_d{d}': VonMisesFisher(np.ones(d) / np.sqrt(d), ks).log_norm()
+             for d in (2, 3, 10, 40)})
+    rng = np.random.default_rng(21)
+    w = rng.uniform(size=(3, 480))
+    g = {ct: GaussianTrainer()._fit(flat[None], saliency=w, covariance_type=ct)
+         for ct in ('spherical', 'diagonal', 'full')}
+    v = VonMisesFisherTrainer()._fit(flat[None], saliency=w, min_concentration=1e-10,
+                                     max_concentration=500)
+    _save('embed_single_fits', y=e.reshape(-1, 10), saliency=w,
+          vmf_mean=v.mean, vmf_concentration=v.concentration,
+          **{f'{ct}_{k}': getattr(g[ct], k) for ct in g for k in ('mean', 'covariance')},
+          **{f'{ct}_log_pdf': g[ct].log_pdf(flat[None]) for ct in g})
+    for name, trainer, kind, emb, kw in [
+            ('embed_gcacgmm_spherical', GCACGMMTrainer, 'gaussian', e, {}),
+            ('embed_gcacgmm_weights', GCACGMMTrainer, 'gaussian', e,
+             dict(spatial_weight=0.7, spectral_weight=1.3, weight_constant_axis=(-3,))),
+            ('embed_gcacgmm_inline_pa', GCACGMMTrainer, 'gaussian', e,
+             dict(inline_permutation_alignment=True, weight_constant_axis=(-3, -1))),
+            ('embed_vmfcacgmm', VMFCACGMMTrainer, 'vmf', (2 * e).astype(np.float32), {})]:
+        emb64 = emb.astype(np.float64)
+        m = trainer().fit(Y128, emb64, initialization=init, iterations=5, **kw)
+        spec = m.gaussian if kind == 'gaussian' else m.vmf
+        extra = (dict(covariance=spec.covariance) if kind == 'gaussian'
+                 else dict(concentration=spec.concentration))
+        _save(name, Y=Y, embedding=emb, init=init, iterations=5, kwargs=np.array(repr(kw)),
+              weight=np.asarray(m.weight), mean=spec.mean,
+              eigvec=m.cacg.covariance_eigenvectors, eigval=m.cacg.covariance_eigenvalues,
+              affiliation=m.predict(Y128, emb64), **extra)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     refshim.load()
@@ -232,6 +284,7 @@ def main():
     beamformer_cases()
     dhtv_cases()
     cwmm_cases()
+    embed_cases()
 
 
 if __name__ == '__main__':

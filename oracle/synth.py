@@ -52,3 +52,27 @@ def make_rank_deficient(F, T, D, K, rank, seed=2, dtype=np.complex64):
     init = rng.uniform(size=(F, K, T))
     init /= init.sum(axis=1, keepdims=True)
     return Y, init
+
+
+def make_joint(F, T, D, K, E, seed=0, snr_db=20.0, spread=0.35, dtype=np.complex64,
+               embedding_dtype=np.float32):
+    """STFT plus a Deep-Clustering-style embedding per time-frequency point
+    (BASELINE config 5): e[f,t,:] = unit(mu_k* + spread * N(0, I_E)) where k* is the
+    dominant source of the point and mu_k are random unit vectors.
+    Returns (Y (F,T,D), embedding (F,T,E), init (F,K,T))."""
+    rng = np.random.default_rng(seed)
+    a = _cn(rng, (F, K, D))
+    a /= np.linalg.norm(a, axis=-1, keepdims=True)
+    s = _cn(rng, (K, F, T)) * rng.standard_normal((K, F, T)) ** 2
+    x = np.einsum('fkd,kft->ftd', a, s)
+    n = _cn(rng, (F, T, D))
+    n *= np.sqrt(np.mean(np.abs(x) ** 2) / np.mean(np.abs(n) ** 2) / (10.0 ** (snr_db / 10.0)))
+    Y = (x + n).astype(dtype)
+    init = rng.uniform(size=(F, K, T))
+    init /= init.sum(axis=1, keepdims=True)
+    mu = rng.standard_normal((K, E))
+    mu /= np.linalg.norm(mu, axis=-1, keepdims=True)
+    dominant = np.argmax(np.abs(s), axis=0)                       # (F, T)
+    e = mu[dominant] + spread * rng.standard_normal((F, T, E))
+    e /= np.linalg.norm(e, axis=-1, keepdims=True)
+    return Y, e.astype(embedding_dtype), init
