@@ -307,6 +307,84 @@ int pbbss_cwmm_fit(pbbss_handle_t h, const void* y, int64_t B, int T, int D, int
                    double* out_log_pdf, void* stream);
 
 /* ------------------------------------------------------------------------- */
+/* N2/N3  Real-embedding mixture components: von Mises-Fisher and spherical      */
+/* Gaussian (distribution/von_mises_fisher.py:33-144, gaussian.py:100-193).      */
+/* y (B,N,E) real, row-major, float32 or float64 (y_is_f64); 1 <= E <= 256,      */
+/* K <= 6.  `scale` (B,K) is the vMF concentration or the spherical covariance.   */
+/* ------------------------------------------------------------------------- */
+#define PBBSS_EMBED_VMF 0             /* VonMisesFisher                       */
+#define PBBSS_EMBED_GAUSS_SPHERICAL 1 /* SphericalGaussian                    */
+
+/* VonMisesFisher.log_pdf (von_mises_fisher.py:62-78; rows are unit-normalised   */
+/* first) / SphericalGaussian.log_pdf (gaussian.py:116-137): out (B,K,N) f64.    */
+int pbbss_embed_log_pdf(pbbss_handle_t h, const void* y, int y_is_f64, int64_t B,
+                        int64_t N, int E, int K, int kind, const double* mean,
+                        const double* scale, double* out_log_pdf, void* stream);
+
+/* VonMisesFisherTrainer._fit (von_mises_fisher.py:119-144; normalize != 0 adds   */
+/* the row normalisation of .fit, :105-107) / GaussianTrainer._fit with           */
+/* covariance_type='spherical' (gaussian.py:152-193).  weights (B,K,N) f64 are    */
+/* the per-class saliencies.  out_mean (B,K,E), out_scale (B,K).                  */
+int pbbss_embed_fit(pbbss_handle_t h, const void* y, int y_is_f64, int64_t B,
+                    int64_t N, int E, int K, int kind, int normalize,
+                    const double* weights, double min_concentration,
+                    double max_concentration, double* out_mean,
+                    double* out_scale, void* stream);
+
+typedef struct pbbss_mix_opts {
+  int32_t iterations;       /* EM iterations; 0 = E-step only with the given model */
+  int32_t kind;             /* PBBSS_EMBED_* of the spectral half (joint models)   */
+  int32_t weight_mode;      /* vmfmm: PBBSS_WEIGHT_*; joint: PBBSS_JOINT_WEIGHT_*   */
+  int32_t embedding_is_f64;
+  int32_t obs_is_c128;
+  int32_t final_predict;    /* write model.predict(...) to out_affiliation         */
+  int32_t inline_pa;        /* inline permutation alignment (mixture_model_utils.py:58) */
+  int32_t covariance_norm;  /* PBBSS_COVNORM_* of the cACG half                    */
+  double min_concentration, max_concentration;
+  double affiliation_eps, eigenvalue_floor;
+  double spatial_weight, spectral_weight;
+} pbbss_mix_opts;
+
+/* N2  VMFMMTrainer.fit / fit_predict, VMFMM.predict  distribution/vmfmm.py:19-172. */
+/* y (B,N,E) real, raw (rows are unit-normalised here, vmfmm.py:76-78).           */
+/* gamma0 (B,K,N) affiliations, or (iterations == 0) a model in_mean (B,K,E),      */
+/* in_concentration (B,K), in_weight (B,K).  saliency (B,N) or NULL.  Outputs:    */
+/* mean (B,K,E), concentration (B,K), weight (B,K); optional affiliation /        */
+/* log_pdf (B,K,N) from the final E-step.  All float64.                           */
+int pbbss_vmfmm_fit(pbbss_handle_t h, const void* y, int64_t B, int64_t N, int E,
+                    int K, const double* gamma0, const double* in_mean,
+                    const double* in_concentration, const double* in_weight,
+                    const double* saliency, const pbbss_mix_opts* opts,
+                    double* out_mean, double* out_concentration,
+                    double* out_weight, double* out_affiliation,
+                    double* out_log_pdf, void* stream);
+
+/* N3  GCACGMMTrainer.fit / GCACGMM.predict  distribution/gcacgmm.py:47-333 and    */
+/*     VMFCACGMMTrainer.fit / VMFCACGMM.predict  distribution/vmfcacgmm.py:43-301. */
+/* observation (F,T,D) complex raw, embedding (F,T,E) real raw; one mixture over   */
+/* all F*T points for the spectral half, one cACG per (f,k).  Class weights by     */
+/* weight_constant_axis:                                                          */
+#define PBBSS_JOINT_WEIGHT_FK 0       /* (-1,)        -> weight (F,K)          */
+#define PBBSS_JOINT_WEIGHT_UNIFORM 1  /* -2 in axis   -> weight (1) = 1/K      */
+#define PBBSS_JOINT_WEIGHT_K 2        /* (-3,-1)      -> weight (K)            */
+#define PBBSS_JOINT_WEIGHT_KT 3       /* (-3,)        -> weight (K,T)          */
+#define PBBSS_JOINT_WEIGHT_CONST 4    /* (-3,-2,-1)   -> weight (1) = 1        */
+/* Initialisation: gamma0 (F,K,T), or (iterations == 0) a model (in_eigvec c128    */
+/* (F,K,D,D), in_eigval (F,K,D), in_weight (shape above), in_mean (K,E), in_scale  */
+/* (K)).  With gamma0, a non-NULL in_scale is the `fixed_covariance` of            */
+/* gcacgmm.py:305-312.  saliency (F,T) or NULL.  Outputs as the inputs' shapes;    */
+/* out_status int32 (F,K); out_affiliation (F,K,T) = model.predict (final_predict). */
+int pbbss_joint_fit(pbbss_handle_t h, const void* observation,
+                    const void* embedding, int64_t F, int T, int D, int E, int K,
+                    const double* gamma0, const void* in_eigvec,
+                    const double* in_eigval, const double* in_weight,
+                    const double* in_mean, const double* in_scale,
+                    const double* saliency, const pbbss_mix_opts* opts,
+                    void* out_eigvec, double* out_eigval, double* out_weight,
+                    double* out_mean, double* out_scale, int32_t* out_status,
+                    double* out_affiliation, void* stream);
+
+/* ------------------------------------------------------------------------- */
 /* Timing hook for bench.py: runs `fit` with HIP events recorded on `stream`   */
 /* around the EM kernel launch(es) only and returns the elapsed milliseconds   */
 /* of the most recent call (the roofline figure needs the kernel duration on   */

@@ -42,7 +42,13 @@ EXPORTS = (
     'pbbss_last_kernel_ms', 'pbbss_set_phase_profile',
     'pbbss_dhtv_calculate_mapping', 'pbbss_apply_mapping', 'pbbss_cwmm_fit',
     'pbbss_wmwf', 'pbbss_set_split_tail', 'pbbss_split_error',
+    'pbbss_embed_log_pdf', 'pbbss_embed_fit', 'pbbss_vmfmm_fit', 'pbbss_joint_fit',
 )
+
+EMBED_VMF = 0
+EMBED_GAUSS_SPHERICAL = 1
+# weight_constant_axis of the joint models -> PBBSS_JOINT_WEIGHT_*
+JOINT_WEIGHT_FK, JOINT_WEIGHT_UNIFORM, JOINT_WEIGHT_K, JOINT_WEIGHT_KT, JOINT_WEIGHT_CONST = range(5)
 
 
 class EmOpts(ctypes.Structure):
@@ -73,6 +79,26 @@ class CwmmOpts(ctypes.Structure):
         ('ev_min', ctypes.c_double),
         ('ev_max', ctypes.c_double),
         ('max_concentration', ctypes.c_double),
+    ]
+
+
+class MixOpts(ctypes.Structure):
+    """struct pbbss_mix_opts"""
+    _fields_ = [
+        ('iterations', ctypes.c_int32),
+        ('kind', ctypes.c_int32),
+        ('weight_mode', ctypes.c_int32),
+        ('embedding_is_f64', ctypes.c_int32),
+        ('obs_is_c128', ctypes.c_int32),
+        ('final_predict', ctypes.c_int32),
+        ('inline_pa', ctypes.c_int32),
+        ('covariance_norm', ctypes.c_int32),
+        ('min_concentration', ctypes.c_double),
+        ('max_concentration', ctypes.c_double),
+        ('affiliation_eps', ctypes.c_double),
+        ('eigenvalue_floor', ctypes.c_double),
+        ('spatial_weight', ctypes.c_double),
+        ('spectral_weight', ctypes.c_double),
     ]
 
 
@@ -131,6 +157,14 @@ def load():
         lib.pbbss_wmwf.argtypes = [vp, vp, vp, i64, i32, dbl, i32, vp, vp, vp, vp, vp]
         lib.pbbss_ban.argtypes = [vp, vp, vp, i64, i32, vp, vp]
         lib.pbbss_apply_beamforming_vector.argtypes = [vp, vp, vp, i32, i64, i32, i32, vp, vp]
+        lib.pbbss_embed_log_pdf.argtypes = [vp, vp, i32, i64, i64, i32, i32, i32, vp, vp, vp, vp]
+        lib.pbbss_embed_fit.argtypes = [vp, vp, i32, i64, i64, i32, i32, i32, i32, vp, dbl, dbl,
+                                        vp, vp, vp]
+        lib.pbbss_vmfmm_fit.argtypes = [vp, vp, i64, i64, i32, i32, vp, vp, vp, vp, vp,
+                                        ctypes.POINTER(MixOpts), vp, vp, vp, vp, vp, vp]
+        lib.pbbss_joint_fit.argtypes = [vp, vp, vp, i64, i32, i32, i32, i32, vp, vp, vp, vp, vp,
+                                        vp, vp, ctypes.POINTER(MixOpts), vp, vp, vp, vp, vp, vp,
+                                        vp, vp]
         for name in EXPORTS:
             fn = getattr(lib, name)
             if name not in ('pbbss_error_string',):

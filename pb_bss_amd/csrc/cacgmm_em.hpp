@@ -82,6 +82,15 @@ struct EmArgs {
   double eig_floor;
 };
 
+// Extra inputs of the joint spatial+spectral E-step (gcacgmm.py:66-117, vmfcacgmm.py:57-97):
+//   log p_k(t) = spatial_weight * cACG_log_pdf_{perm[k]}(t) + extra_logpdf[b,k,t]
+// (extra_logpdf already carries the spectral weight).  perm == null: identity.
+struct JointExtras {
+  const double* extra_logpdf;  // (B,K,T)
+  double spatial_weight;
+  const int* perm;             // [K] in LDS: spatial class used by class slot k (inline PA)
+};
+
 // SPILL=false: observation, norms and M-step weights live in LDS (the fast path).
 // SPILL=true : those three frame-sized arrays live in a per-workgroup HBM/L2
 //              scratch slab (long utterances); the small matrices stay in LDS.
@@ -276,9 +285,10 @@ struct EmKernel {
   //     cacgmm.py:59) and are read with strides from HBM; otherwise the
   //     per-class weights in LDS are used.  (A runtime flag here makes hipcc
   //     unswitch the frame loop and spill ~300 VGPRs, hence a template.)
-  template <bool FINAL, bool TW>
+  template <bool FINAL, bool TW, bool JOINT = false>
   static __device__ void phase_e(const EmArgs& a, const Lds& L, int64_t b, int tid, int wave,
-                                 int lane, double eps, int tf = 0) {
+                                 int lane, double eps, int tf = 0,
+                                 const JointExtras* jx = nullptr) {
     tid = opaque(tid);
     lane = opaque(lane);
     const int TS = t_stride(a);
@@ -372,6 +382,55 @@ struct EmKernel {
         dete[k] = L.dete[k];
         wgt[k] = L.wgt[k];
       }
+      if constexpr (JOINT) {
+        // log-domain softmax of the weighted sum of spatial and spectral log-pdfs
+        // (gcacgmm.py:108-115 -> mixture_model_utils.py:30-53)
+        static_assert(NF == 1, "joint E-step is written for one frame per lane");
+        const int t = tt[0];
+        const double inv = L.inv_n2[t];
+        double lps[K], lp[K], mx = -1.79e308;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          double qq = fmax(fabs(q[0][k] * inv), kTiny);  // cacg.py:185-199
+          q[0][k] = qq;
+          lps[k] = -(double)D * log(qq) - (log(detm[k]) + (double)dete[k] * 0.6931471805599453);
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          double sp = lps[k];
+          if (jx->perm) {
+            const int pk = jx->perm[k];
+#pragma unroll
+            for (int j = 0; j < K; ++j) sp = (pk == j) ? lps[j] : sp;
+          }
+          lp[k] = jx->spatial_weight * sp + jx->extra_logpdf[((size_t)b * K + k) * TS + tf + t];
+          mx = fmax(mx, lp[k]);
+        }
+        double g[K], den = 0.0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          double w = TW ? a.in_weight[b * a.wb + k * a.wk + (int64_t)(tf + t) * a.wt] : wgt[k];
+          g[k] = exp(lp[k] - mx) * w;
+          den += g[k];
+        }
+        den = fmax(den, kTiny);
+        const double sal = (!FINAL && a.saliency) ? a.saliency[(size_t)b * TS + tf + t] : 1.0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          double gam = g[k] / den;
+          if (eps != 0.0) gam = fmin(fmax(gam, eps), 1.0 - eps);
+          size_t idx = ((size_t)b * K + k) * TS + tf + t;
+          if (ok[0]) {
+            if (a.out_aff) a.out_aff[idx] = gam;  // unmasked affiliation of this E-step
+            if (a.out_q) a.out_q[idx] = q[0][k];
+          }
+          if constexpr (!FINAL) {
+            double gs = ok[0] ? gam * sal : 0.0;
+            if (ok[0]) L.wbuf[(size_t)k * L.Tp + t] = mweight(gs, q[0][k], inv);
+            s[k] += gs;
+          }
+        }
+      } else {
 #pragma unroll
       for (int f = 0; f < NF; ++f) {
         const int t = tt[f];
@@ -438,6 +497,7 @@ struct EmKernel {
           }
         }
       }
+      }  // !JOINT
     }
     if constexpr (!FINAL) {
 #pragma unroll
@@ -732,6 +792,168 @@ struct EmKernel {
     }
   }
 
+  // ===================== joint spatial + spectral models ======================
+  // q_k(t) = <A_k, P_t> / |y_t|^2 without the operand pipelining of phase_e (used
+  // once per launch by the inline permutation search below)
+  static __device__ __forceinline__ void quad_forms(const Lds& L, int t, double (&q)[K]) {
+    double re[D], im[D];
+    load_frame(L, t, re, im);
+#pragma unroll
+    for (int k = 0; k < K; ++k) q[k] = 0.0;
+    static_for<0, D>([&](auto ic) {
+      constexpr int i = ic;
+      double dg = re[i] * re[i] + im[i] * im[i];
+#pragma unroll
+      for (int k = 0; k < K; ++k) q[k] = fma(L.apack[k * NA + i], dg, q[k]);
+    });
+    static_for<0, NOFF>([&](auto pc) {
+      constexpr int p = pc;
+      constexpr int i = tri_i<D>(p), j = tri_j<D>(p);
+      double pr = re[i] * re[j] + im[i] * im[j];
+      double pim = im[i] * re[j] - re[i] * im[j];
+#pragma unroll
+      for (int k = 0; k < K; ++k)
+        q[k] = fma(L.apack[k * NA + D + 2 * p], pr, fma(L.apack[k * NA + D + 2 * p + 1], pim, q[k]));
+    });
+    const double inv = L.inv_n2[t];
+#pragma unroll
+    for (int k = 0; k < K; ++k) q[k] = fmax(fabs(q[k] * inv), kTiny);
+  }
+
+  // p-th permutation of (0..K-1) in lexicographic order (itertools.permutations order)
+  static __device__ __forceinline__ void nth_permutation(int p, int (&perm)[K]) {
+    int fact = 1;
+#pragma unroll
+    for (int i = 2; i < K; ++i) fact *= i;  // (K-1)!
+    unsigned used = 0;
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+      int d = p / fact;
+      p -= d * fact;
+      if (i < K - 1) fact /= (K - 1 - i);
+      int pick = 0;
+#pragma unroll
+      for (int c = 0, seen = 0; c < K; ++c) {
+        if (!(used >> c & 1)) {
+          if (seen == d) pick = c;
+          ++seen;
+        }
+      }
+      used |= 1u << pick;
+      perm[i] = pick;
+    }
+  }
+
+  // Inline permutation alignment of integration models (mixture_model_utils.py:58-130):
+  // per frequency bin, the class permutation of the spatial log-pdf that maximises
+  // sum_{k,t} softmax_k(lp)(t) * lp_k(t), lp = spatial[perm] + spectral (no weights).
+  // The weighted spatial log-pdf is parked in wbuf (free until the E-step).
+  static __device__ void phase_joint_pa(const EmArgs& a, const Lds& L, int64_t b, int tid,
+                                        int wave, int lane, const JointExtras& jx, int* perm_out) {
+    for (int t = tid; t < a.T; t += kEmThreads) {
+      double q[K];
+      quad_forms(L, t, q);
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        double ld = log(L.detm[k]) + (double)L.dete[k] * 0.6931471805599453;
+        L.wbuf[(size_t)k * L.Tp + t] = jx.spatial_weight * (-(double)D * log(q[k]) - ld);
+      }
+    }
+    __syncthreads();
+    int nperm = 1;
+#pragma unroll
+    for (int i = 2; i <= K; ++i) nperm *= i;
+    double best = -INFINITY;
+    int best_p = 0;
+    for (int p = 0; p < nperm; ++p) {
+      int perm[K];
+      nth_permutation(p, perm);
+      double part = 0.0;
+      for (int t = tid; t < a.T; t += kEmThreads) {
+        double lp[K], mx = -1.79e308;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          lp[k] = L.wbuf[(size_t)perm[k] * L.Tp + t] +
+                  jx.extra_logpdf[((size_t)b * K + k) * a.T + t];
+          mx = fmax(mx, lp[k]);
+        }
+        double e[K], den = 0.0, num = 0.0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          e[k] = exp(lp[k] - mx);
+          den += e[k];
+          num = fma(e[k], lp[k], num);
+        }
+        part += num / fmax(den, kTiny);
+      }
+      part = wave_sum(part);
+      __syncthreads();  // previous round's reads of red are done
+      if (lane == 0) L.red[wave] = part;
+      __syncthreads();
+      double tot = 0.0;
+#pragma unroll
+      for (int w = 0; w < kEmWaves; ++w) tot += L.red[w];
+      if (tot > best) {  // strict: the first maximiser wins, as in the reference loop
+        best = tot;
+        best_p = p;
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int perm[K];
+      nth_permutation(best_p, perm);
+#pragma unroll
+      for (int k = 0; k < K; ++k) perm_out[k] = perm[k];
+    }
+    __syncthreads();
+  }
+
+  // One joint EM iteration for the cACG half (a.iterations == 1): E-step with the old
+  // model + spectral log-pdf -> affiliation (and q) to HBM, covariance update, eigen
+  // decomposition.  a.iterations == 0: the E-step only (model.predict).
+  // Mixture weights are always read through (wb, wk, wt) from a.in_weight.
+  static __device__ void run_joint(const EmArgs& a, const JointExtras& jx0, int inline_pa,
+                                   char* smem) {
+    static_assert(!SPILL, "joint kernels keep the observation in LDS");
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const Lds L = carve(smem, a.T);
+    int* perm = reinterpret_cast<int*>(smem + lds_bytes(a.T));
+    for (int64_t b = blockIdx.x; b < a.B; b += gridDim.x) {
+      __syncthreads();
+      if (tid < K) L.status[tid] = 0;
+      if (tid == 0) *L.flags = 0;
+      __syncthreads();
+      phase_load(a, L, b, tid);
+      __syncthreads();
+      for (int k = wave; k < K; k += kEmWaves) prep_from_model(a, L, b, k, lane);
+      __syncthreads();
+      JointExtras jx = jx0;
+      jx.perm = nullptr;
+      if (inline_pa) {
+        phase_joint_pa(a, L, b, tid, wave, lane, jx, perm);
+        jx.perm = perm;
+      }
+      if (a.iterations == 0) {
+        phase_e<true, true, true>(a, L, b, tid, wave, lane, a.final_eps, 0, &jx);
+        continue;
+      }
+      phase_e<false, true, true>(a, L, b, tid, wave, lane, a.aff_eps, 0, &jx);
+      __syncthreads();
+      switch (wave) {
+        case 0: phase_m<0>(a, L, lane); break;
+        case 1: phase_m<1>(a, L, lane); break;
+        case 2: phase_m<2>(a, L, lane); break;
+        default: phase_m<3>(a, L, lane); break;
+      }
+      __syncthreads();
+      for (int k = wave; k < K; k += kEmWaves) factor_class(a, L, b, k, lane, true);
+      __syncthreads();
+      if (tid < K && a.out_status) a.out_status[(size_t)b * K + tid] = L.status[tid];
+    }
+  }
+
   // ===================== split-bin variant ====================================
   // G workgroups share ONE problem: each owns a window of `split_window` frames,
   // runs the E and M phases on it, and the partial covariance / class sums are
@@ -1018,6 +1240,13 @@ template <int D, int K, typename YS, bool SPILL>
 __global__ void __launch_bounds__(kEmThreads, em_waves_per_simd(K)) cacgmm_em_kernel(EmArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   EmKernel<D, K, YS, SPILL>::run(a, smem);
+}
+
+template <int D, int K, typename YS>
+__global__ void __launch_bounds__(kEmThreads, em_waves_per_simd(K))
+    cacgmm_joint_kernel(EmArgs a, JointExtras jx, int inline_pa) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  EmKernel<D, K, YS, false>::run_joint(a, jx, inline_pa, smem);
 }
 
 template <int D, int K, typename YS>

@@ -4,6 +4,7 @@
 #include <cstdlib>
 #include "beamform.hpp"
 #include "dhtv.hpp"
+#include "embed.hpp"
 #include "em_launch.hpp"
 
 #define PBBSS_API extern "C" __attribute__((visibility("default")))
@@ -13,6 +14,8 @@ struct pbbss_handle_s {
   pbbss::EmLaunchCfg cfg;
   void* scratch;
   size_t scratch_bytes;
+  void* work;         // second grow-only slab: workspaces of the multi-kernel mixture loops
+  size_t work_bytes;
   unsigned long long* prof;
   int timing;
   float last_ms;
@@ -39,6 +42,35 @@ void* handle_scratch(void* ctx, size_t bytes) {
   h->scratch_bytes = bytes;
   return p;
 }
+
+void* handle_work(pbbss_handle_t h, size_t bytes) {
+  if (bytes <= h->work_bytes) return h->work;
+  if (h->work) {
+    if (hipDeviceSynchronize() != hipSuccess) return nullptr;
+    (void)hipFree(h->work);
+    h->work = nullptr;
+    h->work_bytes = 0;
+  }
+  void* p = nullptr;
+  if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+  h->work = p;
+  h->work_bytes = bytes;
+  return p;
+}
+
+// bump allocator over the work slab (256-byte aligned pieces)
+struct WorkCarver {
+  char* base;
+  size_t off = 0;
+  explicit WorkCarver(void* b) : base(static_cast<char*>(b)) {}
+  static size_t pad(size_t n) { return (n + 255) & ~(size_t)255; }
+  template <typename T>
+  T* take(size_t count) {
+    T* p = reinterpret_cast<T*>(base + off);
+    off += pad(count * sizeof(T));
+    return p;
+  }
+};
 
 struct TimedRegion {
   pbbss_handle_t h;
@@ -106,6 +138,8 @@ PBBSS_API int pbbss_create(pbbss_handle_t* out, int device_id) {
   }
   h->scratch = nullptr;
   h->scratch_bytes = 0;
+  h->work = nullptr;
+  h->work_bytes = 0;
   h->prof = nullptr;
   h->timing = 0;
   h->last_ms = 0.f;
@@ -122,6 +156,7 @@ PBBSS_API int pbbss_destroy(pbbss_handle_t h) {
   (void)hipEventDestroy(h->ev0);
   (void)hipEventDestroy(h->ev1);
   if (h->scratch) (void)hipFree(h->scratch);
+  if (h->work) (void)hipFree(h->work);
   if (h->cfg.xbuf) (void)hipFree(h->cfg.xbuf);
   if (h->cfg.side_stream) (void)hipStreamDestroy(h->cfg.side_stream);
   (void)hipEventDestroy(h->cfg.ev_fork);
@@ -443,4 +478,263 @@ PBBSS_API int pbbss_wmwf(pbbss_handle_t h, const void* target, const void* noise
                                    static_cast<double*>(out_snr_num),
                                    static_cast<double*>(out_snr_den), out_status,
                                    as_stream(stream));
+}
+
+// ---------------------------------------------------------------------------
+// N2/N3: real-embedding mixtures and the joint spatial+spectral models.  These
+// are multi-kernel loops enqueued asynchronously on `stream` (no host sync).
+// ---------------------------------------------------------------------------
+namespace {
+inline bool embed_shape_ok(int64_t B, int64_t N, int E, int K) {
+  return B >= 1 && B <= 65535 && N >= 1 && E >= 1 && E <= pbbss::kEmbedMaxE && K >= 1 &&
+         K <= pbbss::kEmbedMaxK;
+}
+inline int copy_d2d(void* dst, const void* src, size_t bytes, hipStream_t s) {
+  if (dst == src || bytes == 0) return PBBSS_OK;
+  return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s) == hipSuccess ? PBBSS_OK
+                                                                                   : PBBSS_ERR_HIP;
+}
+}  // namespace
+
+PBBSS_API int pbbss_embed_log_pdf(pbbss_handle_t h, const void* y, int y_is_f64, int64_t B,
+                                  int64_t N, int E, int K, int kind, const double* mean,
+                                  const double* scale, double* out_log_pdf, void* stream) {
+  if (!h || !y || !mean || !scale || !out_log_pdf) return PBBSS_ERR_INVALID_ARG;
+  if (!embed_shape_ok(B, N, E, K)) return PBBSS_ERR_UNSUPPORTED;
+  hipStream_t s = as_stream(stream);
+  const size_t esz = y_is_f64 ? 8 : 4;
+  const size_t need = WorkCarver::pad((size_t)B * E * N * esz) + 2 * WorkCarver::pad((size_t)B * K * 8);
+  void* w = handle_work(h, need);
+  if (!w) return PBBSS_ERR_HIP;
+  WorkCarver wc(w);
+  char* yd = wc.take<char>((size_t)B * E * N * esz);
+  double* offset = wc.take<double>((size_t)B * K);
+  double* prec = wc.take<double>((size_t)B * K);
+  int rc = pbbss::launch_embed_prepare(y, y_is_f64, B, N, E, 0, yd, nullptr, s);
+  if (rc != PBBSS_OK) return rc;
+  rc = pbbss::launch_embed_offsets(kind, B * K, E, scale, offset, prec, s);
+  if (rc != PBBSS_OK) return rc;
+  return pbbss::launch_embed_estep(kind, yd, y_is_f64, B, N, E, K, mean, prec, offset, nullptr,
+                                   1.0, N, out_log_pdf, nullptr, s);
+}
+
+PBBSS_API int pbbss_embed_fit(pbbss_handle_t h, const void* y, int y_is_f64, int64_t B, int64_t N,
+                              int E, int K, int kind, int normalize, const double* weights,
+                              double min_concentration, double max_concentration,
+                              double* out_mean, double* out_scale, void* stream) {
+  if (!h || !y || !weights || !out_mean || !out_scale) return PBBSS_ERR_INVALID_ARG;
+  if (!embed_shape_ok(B, N, E, K)) return PBBSS_ERR_UNSUPPORTED;
+  hipStream_t s = as_stream(stream);
+  const size_t np = pbbss::embed_partial_doubles(B, N, E, K, nullptr);
+  size_t need = WorkCarver::pad(np * 8);
+  if (normalize) need += 2 * WorkCarver::pad((size_t)B * N * E * 8);
+  void* w = handle_work(h, need);
+  if (!w) return PBBSS_ERR_HIP;
+  WorkCarver wc(w);
+  double* part = wc.take<double>(np);
+  const void* yr = y;
+  int yr_f64 = y_is_f64;
+  if (normalize) {
+    double* yd = wc.take<double>((size_t)B * N * E);
+    double* yn = wc.take<double>((size_t)B * N * E);
+    int rc = pbbss::launch_embed_prepare(y, y_is_f64, B, N, E, 1, yd, yn, s);
+    if (rc != PBBSS_OK) return rc;
+    yr = yn;
+    yr_f64 = 1;
+  }
+  return pbbss::launch_embed_fit(kind, yr, yr_f64, B, N, E, K, weights, N, nullptr,
+                                 min_concentration, max_concentration, -1, part, out_mean,
+                                 out_scale, nullptr, s);
+}
+
+PBBSS_API int pbbss_vmfmm_fit(pbbss_handle_t h, const void* y, int64_t B, int64_t N, int E, int K,
+                              const double* gamma0, const double* in_mean,
+                              const double* in_concentration, const double* in_weight,
+                              const double* saliency, const pbbss_mix_opts* o, double* out_mean,
+                              double* out_concentration, double* out_weight,
+                              double* out_affiliation, double* out_log_pdf, void* stream) {
+  if (!h || !y || !o) return PBBSS_ERR_INVALID_ARG;
+  if (!embed_shape_ok(B, N, E, K)) return PBBSS_ERR_UNSUPPORTED;
+  if (o->iterations < 0 || o->weight_mode < 0 || o->weight_mode > 1) return PBBSS_ERR_INVALID_ARG;
+  const bool has_gamma = gamma0 != nullptr;
+  const bool has_model = in_mean && in_concentration && in_weight;
+  if (has_gamma == has_model) return PBBSS_ERR_INVALID_ARG;
+  if ((o->iterations == 0) != has_model) return PBBSS_ERR_INVALID_ARG;  // vmfmm.py:70-74
+  if (!out_mean || !out_concentration || !out_weight) return PBBSS_ERR_INVALID_ARG;
+  hipStream_t s = as_stream(stream);
+  const size_t nyz = (size_t)B * N * E;
+  const size_t np = pbbss::embed_partial_doubles(B, N, E, K, nullptr);
+  const size_t need = 2 * WorkCarver::pad(nyz * 8) + WorkCarver::pad((size_t)B * K * N * 8) +
+                      WorkCarver::pad(np * 8) + 2 * WorkCarver::pad((size_t)B * K * 8);
+  void* w = handle_work(h, need);
+  if (!w) return PBBSS_ERR_HIP;
+  WorkCarver wc(w);
+  double* yd = wc.take<double>(nyz);
+  double* yr = wc.take<double>(nyz);
+  double* aff = wc.take<double>((size_t)B * K * N);
+  double* part = wc.take<double>(np);
+  double* offset = wc.take<double>((size_t)B * K);
+  double* prec = wc.take<double>((size_t)B * K);
+  TimedRegion tr(h, s);
+  int rc = pbbss::launch_embed_prepare(y, o->embedding_is_f64, B, N, E, 1, yd, yr, s);
+  if (rc != PBBSS_OK) return rc;
+  if (has_model) {
+    if ((rc = copy_d2d(out_mean, in_mean, (size_t)B * K * E * 8, s)) != PBBSS_OK) return rc;
+    if ((rc = copy_d2d(out_concentration, in_concentration, (size_t)B * K * 8, s)) != PBBSS_OK) return rc;
+    if ((rc = copy_d2d(out_weight, in_weight, (size_t)B * K * 8, s)) != PBBSS_OK) return rc;
+  }
+  for (int it = 0; it < o->iterations; ++it) {
+    const double* src = gamma0;
+    if (it > 0) {  // vmfmm.py:137-138
+      rc = pbbss::launch_embed_offsets(PBBSS_EMBED_VMF, B * K, E, out_concentration, offset, prec, s);
+      if (rc != PBBSS_OK) return rc;
+      rc = pbbss::launch_embed_estep(PBBSS_EMBED_VMF, yd, 1, B, N, E, K, out_mean, prec, offset,
+                                     out_weight, 1.0, N, nullptr, aff, s);
+      if (rc != PBBSS_OK) return rc;
+      src = aff;
+    }
+    rc = pbbss::launch_embed_fit(PBBSS_EMBED_VMF, yr, 1, B, N, E, K, src, N, saliency,
+                                 o->min_concentration, o->max_concentration, o->weight_mode, part,
+                                 out_mean, out_concentration, out_weight, s);
+    if (rc != PBBSS_OK) return rc;
+  }
+  if (o->final_predict && (out_affiliation || out_log_pdf)) {
+    rc = pbbss::launch_embed_offsets(PBBSS_EMBED_VMF, B * K, E, out_concentration, offset, prec, s);
+    if (rc != PBBSS_OK) return rc;
+    rc = pbbss::launch_embed_estep(PBBSS_EMBED_VMF, yd, 1, B, N, E, K, out_mean, prec, offset,
+                                   out_weight, 1.0, N, out_log_pdf, out_affiliation, s);
+    if (rc != PBBSS_OK) return rc;
+  }
+  return PBBSS_OK;
+}
+
+PBBSS_API int pbbss_joint_fit(pbbss_handle_t h, const void* observation, const void* embedding,
+                              int64_t F, int T, int D, int E, int K, const double* gamma0,
+                              const void* in_eigvec, const double* in_eigval,
+                              const double* in_weight, const double* in_mean,
+                              const double* in_scale, const double* saliency,
+                              const pbbss_mix_opts* o, void* out_eigvec, double* out_eigval,
+                              double* out_weight, double* out_mean, double* out_scale,
+                              int32_t* out_status, double* out_affiliation, void* stream) {
+  if (!h || !observation || !embedding || !o || F <= 0 || T <= 0) return PBBSS_ERR_INVALID_ARG;
+  if (D < 2 || D > 8 || K < 1 || K > 6) return PBBSS_ERR_UNSUPPORTED;
+  const int64_t N = F * (int64_t)T;
+  if (!embed_shape_ok(1, N, E, K)) return PBBSS_ERR_UNSUPPORTED;
+  if (o->iterations < 0 || o->weight_mode < 0 || o->weight_mode > 4) return PBBSS_ERR_INVALID_ARG;
+  if (o->kind != PBBSS_EMBED_VMF && o->kind != PBBSS_EMBED_GAUSS_SPHERICAL) return PBBSS_ERR_UNSUPPORTED;
+  if (o->covariance_norm < 0 || o->covariance_norm > 2) return PBBSS_ERR_INVALID_ARG;
+  const bool has_gamma = gamma0 != nullptr;
+  const bool has_model = in_eigvec && in_eigval && in_weight && in_mean && in_scale;
+  if (has_gamma == has_model) return PBBSS_ERR_INVALID_ARG;
+  if ((o->iterations == 0) != has_model) return PBBSS_ERR_INVALID_ARG;
+  if (!out_eigvec || !out_eigval || !out_weight || !out_mean || !out_scale || !out_status)
+    return PBBSS_ERR_INVALID_ARG;
+  hipStream_t s = as_stream(stream);
+  int64_t wb = 0, wk = 0, wt = 0;
+  size_t wcount = 1;
+  switch (o->weight_mode) {
+    case PBBSS_JOINT_WEIGHT_FK: wb = K; wk = 1; wcount = (size_t)F * K; break;
+    case PBBSS_JOINT_WEIGHT_K: wk = 1; wcount = K; break;
+    case PBBSS_JOINT_WEIGHT_KT: wk = T; wt = 1; wcount = (size_t)K * T; break;
+    default: break;
+  }
+  const size_t esz = o->embedding_is_f64 ? 8 : 4;
+  const size_t np = pbbss::embed_partial_doubles(1, N, E, K, nullptr);
+  const size_t nfkt = (size_t)F * K * T;
+  const size_t need = WorkCarver::pad((size_t)E * N * esz) + 2 * WorkCarver::pad(nfkt * 8) +
+                      WorkCarver::pad(np * 8) + 2 * WorkCarver::pad((size_t)K * 8) +
+                      WorkCarver::pad((size_t)F * K * 8);
+  void* w = handle_work(h, need);
+  if (!w) return PBBSS_ERR_HIP;
+  WorkCarver wc(w);
+  char* yd = wc.take<char>((size_t)E * N * esz);
+  double* aff = wc.take<double>(nfkt);
+  double* slp = wc.take<double>(nfkt);
+  double* part = wc.take<double>(np);
+  double* offset = wc.take<double>(K);
+  double* prec = wc.take<double>(K);
+  double* tmp = wc.take<double>((size_t)F * K);
+  TimedRegion tr(h, s);
+  int rc = pbbss::launch_embed_prepare(embedding, o->embedding_is_f64, 1, N, E, 0, yd, nullptr, s);
+  if (rc != PBBSS_OK) return rc;
+  if (has_model) {
+    if ((rc = copy_d2d(out_eigvec, in_eigvec, (size_t)F * K * D * D * 16, s)) != PBBSS_OK) return rc;
+    if ((rc = copy_d2d(out_eigval, in_eigval, (size_t)F * K * D * 8, s)) != PBBSS_OK) return rc;
+    if ((rc = copy_d2d(out_weight, in_weight, wcount * 8, s)) != PBBSS_OK) return rc;
+    if ((rc = copy_d2d(out_mean, in_mean, (size_t)K * E * 8, s)) != PBBSS_OK) return rc;
+    if ((rc = copy_d2d(out_scale, in_scale, (size_t)K * 8, s)) != PBBSS_OK) return rc;
+  }
+  // spectral log-pdf (times spectral_weight) of every point, laid out (F,K,T)
+  auto spectral = [&]() -> int {
+    int r = pbbss::launch_embed_offsets(o->kind, K, E, out_scale, offset, prec, s);
+    if (r != PBBSS_OK) return r;
+    return pbbss::launch_embed_estep(o->kind, yd, o->embedding_is_f64, 1, N, E, K, out_mean, prec,
+                                     offset, nullptr, o->spectral_weight, T, slp, nullptr, s);
+  };
+  auto joint = [&](int iterations, double* aff_out, int inline_pa) -> int {
+    pbbss::EmArgs a{};
+    a.y = observation;
+    a.B = F;
+    a.T = T;
+    a.in_eigvec = static_cast<const double*>(out_eigvec);  // in place: one workgroup per bin
+    a.in_eigval = out_eigval;
+    a.in_weight = out_weight;
+    a.wb = wb;
+    a.wk = wk;
+    a.wt = wt;
+    a.saliency = saliency;
+    a.out_eigvec = static_cast<double*>(out_eigvec);
+    a.out_eigval = out_eigval;
+    a.out_status = out_status;
+    a.out_aff = aff_out;
+    a.iterations = iterations;
+    a.covariance_norm = o->covariance_norm;
+    a.weight_mode = PBBSS_WEIGHT_PER_CLASS_MEAN;
+    a.layout = PBBSS_LAYOUT_TD;
+    a.aff_eps = o->affiliation_eps;
+    a.final_eps = 0.0;
+    a.eig_floor = o->eigenvalue_floor;
+    pbbss::JointExtras jx{slp, o->spatial_weight, nullptr};
+    return pbbss::joint_launch(D, K, o->obs_is_c128, a, jx, inline_pa, h->cfg, s);
+  };
+  for (int it = 0; it < o->iterations; ++it) {
+    const double* src = gamma0;
+    if (it == 0) {
+      // first M-step from the initial affiliations, quadratic form = 1 (gcacgmm.py:194-196)
+      pbbss::EmArgs a{};
+      a.y = observation;
+      a.B = F;
+      a.T = T;
+      a.gamma0 = gamma0;
+      a.saliency = saliency;
+      a.out_eigvec = static_cast<double*>(out_eigvec);
+      a.out_eigval = out_eigval;
+      a.out_status = out_status;
+      a.iterations = 1;
+      a.covariance_norm = o->covariance_norm;
+      a.weight_mode = PBBSS_WEIGHT_PER_CLASS_MEAN;
+      a.layout = PBBSS_LAYOUT_TD;
+      a.eig_floor = o->eigenvalue_floor;
+      rc = pbbss::em_launch(D, K, o->obs_is_c128, a, h->cfg, s);
+      if (rc != PBBSS_OK) return rc;
+    } else {
+      if ((rc = spectral()) != PBBSS_OK) return rc;
+      if ((rc = joint(1, aff, o->inline_pa)) != PBBSS_OK) return rc;
+      src = aff;
+    }
+    rc = pbbss::launch_joint_weight(o->weight_mode, src, saliency, F, K, T, tmp, out_weight, s);
+    if (rc != PBBSS_OK) return rc;
+    rc = pbbss::launch_embed_fit(o->kind, embedding, o->embedding_is_f64, 1, N, E, K, src, T,
+                                 saliency, o->min_concentration, o->max_concentration, -1, part,
+                                 out_mean, out_scale, nullptr, s);
+    if (rc != PBBSS_OK) return rc;
+    if (in_scale && has_gamma) {  // fixed_covariance (gcacgmm.py:305-312)
+      if ((rc = copy_d2d(out_scale, in_scale, (size_t)K * 8, s)) != PBBSS_OK) return rc;
+    }
+  }
+  if (o->final_predict && out_affiliation) {
+    if ((rc = spectral()) != PBBSS_OK) return rc;
+    if ((rc = joint(0, out_affiliation, 0)) != PBBSS_OK) return rc;
+  }
+  return PBBSS_OK;
 }

@@ -1,0 +1,618 @@
+// Real-embedding mixture kernels for gfx950.
+//
+// Reference: distribution/von_mises_fisher.py:33-44 (log_norm), :62-78 (log_pdf),
+// :119-144 (fit); distribution/gaussian.py:108-137 (SphericalGaussian.log_pdf),
+// :152-193 (GaussianTrainer._fit); distribution/mixture_model_utils.py:7-55, 133-203;
+// distribution/gcacgmm.py:286-295 (class weights of the joint models).
+//
+// These paths stream N x E real embeddings (N = F*T ~ 2.6e5, E ~ 40) twice per EM
+// iteration and do ~K flops per element: HBM/Infinity-Cache bound.  Layouts:
+//   E-step  thread = sample, reads the (E, N) transposed copy: every load of a wave is
+//           one contiguous 256/512-byte row segment; class means are LDS broadcasts.
+//   M-step  thread = (sample slot s, dimension d) over the row-major (N, E) array: the
+//           256 threads of a workgroup read one contiguous block of 256/E samples per
+//           trip; per-thread accumulators for all classes, one LDS reduction over the
+//           slots per workgroup, ordered (deterministic) reduction over workgroups in
+//           a finalize kernel.
+#include "embed.hpp"
+#include <cmath>
+#include "pbbss_dev.hpp"
+
+namespace pbbss {
+namespace {
+
+constexpr int kThreads = 256;
+constexpr double kLn2Pi = 1.8378770664093454;  // ln(2 pi)
+
+__device__ __forceinline__ size_t aff_index(int64_t b, int k, int64_t n, int K, int64_t N,
+                                            int64_t Tin) {
+  const int64_t f = n / Tin;
+  return (size_t)b * K * N + (size_t)f * K * Tin + (size_t)k * Tin + (size_t)(n - f * Tin);
+}
+
+// ---------------------------------------------------------------- prepare
+// One workgroup: R rows of one mixture staged in LDS (row stride E+1), optional
+// unit-norm scaling, written out transposed (and row-major when normalising).
+template <typename TS, bool NORMALIZE>
+__global__ void __launch_bounds__(kThreads) embed_prepare_kernel(const TS* y, int64_t N, int E,
+                                                                 int R, void* yd_, double* yr) {
+  using OUT = typename std::conditional<NORMALIZE, double, TS>::type;
+  extern __shared__ double sm[];
+  double* tile = sm;                // [R][E+1]
+  double* scale = sm + R * (E + 1);  // [R]
+  const int64_t b = blockIdx.y;
+  const int64_t n0 = (int64_t)blockIdx.x * R;
+  const int rows = (int)((N - n0 < R) ? (N - n0) : R);
+  const int tid = threadIdx.x;
+  const TS* src = y + ((size_t)b * N + n0) * E;
+  for (int i = tid; i < rows * E; i += kThreads) {
+    int r = i / E, d = i - r * E;
+    tile[r * (E + 1) + d] = (double)src[i];
+  }
+  __syncthreads();
+  if (NORMALIZE) {
+    if (tid < rows) {
+      double n2 = 0.0;
+      for (int d = 0; d < E; ++d) n2 = fma(tile[tid * (E + 1) + d], tile[tid * (E + 1) + d], n2);
+      scale[tid] = 1.0 / fmax(sqrt(n2), kTiny);  // vmfmm.py:76-78
+    }
+    __syncthreads();
+    double* dst = yr + ((size_t)b * N + n0) * E;
+    for (int i = tid; i < rows * E; i += kThreads) {
+      int r = i / E, d = i - r * E;
+      dst[i] = tile[r * (E + 1) + d] * scale[r];
+    }
+  }
+  OUT* yd = static_cast<OUT*>(yd_) + (size_t)b * E * N + n0;
+  for (int i = tid; i < rows * E; i += kThreads) {
+    int d = i / rows, r = i - d * rows;
+    double v = tile[r * (E + 1) + d];
+    if (NORMALIZE) v *= scale[r];
+    yd[(size_t)d * N + r] = (OUT)v;
+  }
+}
+
+// ---------------------------------------------------------------- offsets
+// ln( I_nu(x) / x^nu ) by the ascending series (all terms positive), summed in the
+// log domain by one wavefront:  sum_m (x^2/4)^m / (m! Gamma(m+nu+1)) * 2^-nu.
+__device__ double wave_log_bessel_over_power(double nu, double x, int lane) {
+  const double lx = 2.0 * log(x) - 1.3862943611198906;  // ln(x^2 / 4)
+  const int M = (int)ceil(fmin(x, 1.0e6)) + 48;        // terms fall by > 4x per step past m = x
+  double mx = -INFINITY;
+  for (int m = lane; m < M; m += kWave) {
+    double lt = (m ? (double)m * lx : 0.0) - lgamma((double)m + 1.0) - lgamma((double)m + nu + 1.0);
+    mx = fmax(mx, lt);
+  }
+  mx = wave_max(mx);
+  double sum = 0.0;
+  for (int m = lane; m < M; m += kWave) {
+    double lt = (m ? (double)m * lx : 0.0) - lgamma((double)m + 1.0) - lgamma((double)m + nu + 1.0);
+    sum += exp(lt - mx);
+  }
+  sum = wave_sum(sum);
+  return -nu * 0.6931471805599453 + mx + log(sum);
+}
+
+// one wavefront per (mixture, class)
+__global__ void __launch_bounds__(kThreads) embed_offsets_kernel(int kind, int64_t BK, int E,
+                                                                 const double* scale,
+                                                                 double* offset, double* prec) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t i = (int64_t)blockIdx.x * (kThreads / kWave) + (threadIdx.x >> 6);
+  if (i >= BK) return;
+  const double sc = scale[i];
+  if (kind == PBBSS_EMBED_VMF) {
+    // log_norm = E/2 ln 2pi + ln ive(nu, k) + (|k| - nu ln k) = E/2 ln 2pi + ln(I_nu(k) / k^nu)
+    const double nu = 0.5 * E - 1.0;
+    const double ln_c = 0.5 * E * kLn2Pi + wave_log_bessel_over_power(nu, sc, lane);
+    if (lane == 0) {
+      offset[i] = -ln_c;
+      prec[i] = sc;
+    }
+  } else if (lane == 0) {
+    const double pc = 1.0 / sqrt(sc);  // sklearn _compute_precision_cholesky, 'diag' branch
+    offset[i] = -0.5 * E * kLn2Pi + (double)E * log(pc);
+    prec[i] = pc;
+  }
+}
+
+// ---------------------------------------------------------------- E-step
+template <int KIND, int K, typename TS>
+__global__ void __launch_bounds__(kThreads)
+    embed_estep_kernel(const TS* yd, int64_t N, int E, const double* mean, const double* prec,
+                       const double* offset, const double* weight, double out_scale, int64_t Tin,
+                       double* out_lp, double* out_aff) {
+  extern __shared__ double sm[];
+  double* mu = sm;            // [K][E]
+  double* pr = sm + K * E;    // [K]
+  double* of = pr + K;        // [K]
+  double* wg = of + K;        // [K]
+  const int64_t b = blockIdx.y;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < K * E; i += kThreads) mu[i] = mean[(size_t)b * K * E + i];
+  if (tid < K) {
+    pr[tid] = prec[b * K + tid];
+    of[tid] = offset[b * K + tid];
+    wg[tid] = weight ? weight[b * K + tid] : 1.0;
+  }
+  __syncthreads();
+  const int64_t n = (int64_t)blockIdx.x * kThreads + tid;
+  if (n >= N) return;
+  const TS* col = yd + (size_t)b * E * N + n;
+  double acc[K], n2 = 0.0, pk[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    acc[k] = 0.0;
+    pk[k] = pr[k];
+  }
+  constexpr int U = 8;  // loads in flight per lane
+  for (int d0 = 0; d0 < E; d0 += U) {
+    double v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = (d0 + u < E) ? (double)col[(size_t)(d0 + u) * N] : 0.0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (d0 + u < E) {
+        if (KIND == PBBSS_EMBED_VMF) {
+          n2 = fma(v[u], v[u], n2);
+#pragma unroll
+          for (int k = 0; k < K; ++k) acc[k] = fma(v[u], mu[k * E + d0 + u], acc[k]);
+        } else {
+#pragma unroll
+          for (int k = 0; k < K; ++k) {
+            double w = pk[k] * (v[u] - mu[k * E + d0 + u]);  // gaussian.py:127-131
+            acc[k] = fma(w, w, acc[k]);
+          }
+        }
+      }
+    }
+  }
+  double lp[K], mx = -1.79e308;
+  const double inv = (KIND == PBBSS_EMBED_VMF) ? 1.0 / fmax(sqrt(n2), kTiny) : 0.0;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    lp[k] = (KIND == PBBSS_EMBED_VMF) ? fma(pk[k], acc[k] * inv, of[k])   // von_mises_fisher.py:71-77
+                                      : of[k] - 0.5 * acc[k];            // gaussian.py:132-136
+    mx = fmax(mx, lp[k]);
+  }
+  if (out_lp) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) out_lp[aff_index(b, k, n, K, N, Tin)] = out_scale * lp[k];
+  }
+  if (out_aff) {  // mixture_model_utils.py:30-47, affiliation_eps = 0
+    double g[K], den = 0.0;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      g[k] = exp(lp[k] - mx) * wg[k];
+      den += g[k];
+    }
+    den = fmax(den, kTiny);
+#pragma unroll
+    for (int k = 0; k < K; ++k) out_aff[aff_index(b, k, n, K, N, Tin)] = g[k] / den;
+  }
+}
+
+// ---------------------------------------------------------------- M-step partial sums
+// PASS 0: S1[k][d] = sum_n w_k(n) y[n][d], S0[k] = sum_n w_k(n)
+// PASS 1: S2[k][d] = sum_n w_k(n) (y[n][d] - mean[k][d])^2
+// part layout: [b][chunk][k][E+1]  (slot E = S0)
+template <int K, typename TS, int PASS>
+__global__ void __launch_bounds__(kThreads)
+    embed_fit_kernel(const TS* yr, int64_t N, int E, int C, int64_t L, const double* aff,
+                     int64_t Tin, const double* sal, const double* mean, double* part) {
+  extern __shared__ double sm[];
+  const int S = kThreads / E;
+  double* red = sm;               // [S][K][E]
+  double* red0 = sm + S * K * E;  // [S][K]
+  const int64_t b = blockIdx.y;
+  const int c = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int s = tid / E;
+  const int d = tid - s * E;
+  const bool active = s < S;
+  const int64_t n0 = (int64_t)c * L;
+  const int64_t n1 = (n0 + L < N) ? (n0 + L) : N;
+  double acc[K], acc0[K], mu[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    acc[k] = 0.0;
+    acc0[k] = 0.0;
+    mu[k] = (PASS == 1 && active) ? mean[((size_t)b * K + k) * E + d] : 0.0;
+  }
+  if (active) {
+    constexpr int U = 4;
+    const TS* base = yr + (size_t)b * N * E;
+    for (int64_t n = n0 + s; n < n1; n += (int64_t)U * S) {
+      double yv[U], sv[U], w[U][K];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t nn = n + (int64_t)u * S;
+        const bool ok = nn < n1;
+        const int64_t nc = ok ? nn : n;
+        yv[u] = (double)base[(size_t)nc * E + d];
+        sv[u] = ok ? (sal ? sal[(size_t)b * N + nc] : 1.0) : 0.0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) w[u][k] = aff[aff_index(b, k, nc, K, N, Tin)];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          const double wk = w[u][k] * sv[u];  // affiliation * saliency (vmfmm.py:167)
+          if (PASS == 0) {
+            acc[k] = fma(wk, yv[u], acc[k]);
+            acc0[k] += wk;
+          } else {
+            const double df = yv[u] - mu[k];
+            acc[k] = fma(wk * df, df, acc[k]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      red[(s * K + k) * E + d] = acc[k];
+      if (PASS == 0 && d == 0) red0[s * K + k] = acc0[k];
+    }
+  }
+  __syncthreads();
+  double* dst = part + ((size_t)b * C + c) * K * (E + 1);
+  for (int i = tid; i < K * E; i += kThreads) {
+    const int k = i / E, dd = i - k * E;
+    double t = 0.0;
+    for (int ss = 0; ss < S; ++ss) t += red[(ss * K + k) * E + dd];
+    dst[k * (E + 1) + dd] = t;
+  }
+  if (PASS == 0 && tid < K) {
+    double t = 0.0;
+    for (int ss = 0; ss < S; ++ss) t += red0[ss * K + tid];
+    dst[tid * (E + 1) + E] = t;
+  }
+}
+
+// ---------------------------------------------------------------- M-step finalize
+// One workgroup per mixture: ordered sum over the chunk partials, then the model.
+template <int KIND, int PASS>
+__global__ void __launch_bounds__(kThreads)
+    embed_finalize_kernel(const double* part, int C, int E, int K, double cmin, double cmax,
+                          int weight_mode, double* den_buf, double* out_mean, double* out_scale,
+                          double* out_weight) {
+  extern __shared__ double sm[];  // [K][E+1]
+  const int64_t b = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int lane = tid & (kWave - 1);
+  const int wave = tid >> 6;
+  const int W = K * (E + 1);
+  for (int i = tid; i < W; i += kThreads) {
+    const double* p = part + (size_t)b * C * W + i;
+    double t = 0.0;
+    for (int c = 0; c < C; ++c) t += p[(size_t)c * W];
+    sm[i] = t;
+  }
+  __syncthreads();
+  for (int k = wave; k < K; k += kThreads / kWave) {
+    const double* row = sm + k * (E + 1);
+    if (PASS == 0) {
+      const double s0 = row[E];
+      if (KIND == PBBSS_EMBED_VMF) {
+        double n2 = 0.0;
+        for (int d = lane; d < E; d += kWave) n2 = fma(row[d], row[d], n2);
+        n2 = wave_sum(n2);
+        const double norm = sqrt(n2);
+        const double rn = 1.0 / fmax(norm, kTiny);  // Banerjee 2005 eq. 2.4
+        for (int d = lane; d < E; d += kWave) out_mean[((size_t)b * K + k) * E + d] = row[d] * rn;
+        if (lane == 0) {
+          const double rbar = norm / s0;                                         // eq. 2.5
+          double conc = (rbar * E - rbar * rbar * rbar) / (1.0 - rbar * rbar);  // eq. 4.4
+          conc = conc < cmin ? cmin : (conc > cmax ? cmax : conc);              // NaN stays NaN
+          out_scale[b * K + k] = conc;
+        }
+      } else {
+        const double den = fmax(s0, kTiny);  // gaussian.py:160-163
+        for (int d = lane; d < E; d += kWave) out_mean[((size_t)b * K + k) * E + d] = row[d] / den;
+        if (lane == 0) den_buf[b * K + k] = den;
+      }
+    } else {
+      double t = 0.0;
+      for (int d = lane; d < E; d += kWave) t += row[d];
+      t = wave_sum(t);
+      if (lane == 0) out_scale[b * K + k] = t / (den_buf[b * K + k] * (double)E);  // 'spherical'
+    }
+  }
+  if (PASS == 0 && out_weight && weight_mode >= 0 && tid == 0) {
+    if (weight_mode == 1) {
+      for (int k = 0; k < K; ++k) out_weight[b * K + k] = 1.0 / K;
+    } else {
+      // estimate_mixture_weight with saliency: L1 unit norm over classes, eps 'where' 1e-10
+      double tot = 0.0;
+      for (int k = 0; k < K; ++k) tot += fabs(sm[k * (E + 1) + E]);
+      if (tot == 0.0) tot = 1e-10;
+      for (int k = 0; k < K; ++k) out_weight[b * K + k] = sm[k * (E + 1) + E] / tot;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- joint-model class weights
+// mode 0 / 2: workgroup f: sum_t aff[f,k,t] sal[f,t]  -> tmp[f,k]; mode 0 normalises in place
+__global__ void __launch_bounds__(kThreads)
+    joint_rowsum_kernel(const double* aff, const double* sal, int K, int T, int normalize,
+                        double* tmp, double* out) {
+  __shared__ double red[kThreads / kWave][kEmbedMaxK];
+  const int64_t f = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
+  double s[kEmbedMaxK];
+#pragma unroll
+  for (int k = 0; k < kEmbedMaxK; ++k) s[k] = 0.0;
+  for (int t = tid; t < T; t += kThreads) {
+    const double sv = sal ? sal[(size_t)f * T + t] : 1.0;
+#pragma unroll
+    for (int k = 0; k < kEmbedMaxK; ++k)
+      if (k < K) s[k] += aff[((size_t)f * K + k) * T + t] * sv;
+  }
+#pragma unroll
+  for (int k = 0; k < kEmbedMaxK; ++k) {
+    double t = wave_sum(s[k]);
+    if (lane == 0) red[wave][k] = t;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double v[kEmbedMaxK], tot = 0.0;
+    for (int k = 0; k < K; ++k) {
+      v[k] = 0.0;
+      for (int w = 0; w < kThreads / kWave; ++w) v[k] += red[w][k];
+      tot += v[k];
+    }
+    for (int k = 0; k < K; ++k) {
+      if (normalize) out[f * K + k] = v[k] / tot;  // gcacgmm.py:292-294
+      else tmp[f * K + k] = v[k];
+    }
+  }
+}
+
+__global__ void joint_rows_to_class_kernel(const double* tmp, int64_t F, int K, double* out) {
+  // single workgroup: (-3,-1): sum over f of the row sums, normalised over k
+  __shared__ double red[kThreads / kWave][kEmbedMaxK];
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
+  double s[kEmbedMaxK];
+#pragma unroll
+  for (int k = 0; k < kEmbedMaxK; ++k) s[k] = 0.0;
+  for (int64_t f = tid; f < F; f += kThreads) {
+#pragma unroll
+    for (int k = 0; k < kEmbedMaxK; ++k)
+      if (k < K) s[k] += tmp[f * K + k];
+  }
+#pragma unroll
+  for (int k = 0; k < kEmbedMaxK; ++k) {
+    double t = wave_sum(s[k]);
+    if (lane == 0) red[wave][k] = t;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double v[kEmbedMaxK], tot = 0.0;
+    for (int k = 0; k < K; ++k) {
+      v[k] = 0.0;
+      for (int w = 0; w < kThreads / kWave; ++w) v[k] += red[w][k];
+      tot += v[k];
+    }
+    for (int k = 0; k < K; ++k) out[k] = v[k] / tot;
+  }
+}
+
+// mode 3 (-3,): thread t: sum over f, normalised over k  -> (K,T)
+__global__ void __launch_bounds__(kThreads)
+    joint_colsum_kernel(const double* aff, const double* sal, int64_t F, int K, int T,
+                        double* out) {
+  const int t = blockIdx.x * kThreads + threadIdx.x;
+  if (t >= T) return;
+  double s[kEmbedMaxK];
+#pragma unroll
+  for (int k = 0; k < kEmbedMaxK; ++k) s[k] = 0.0;
+  for (int64_t f = 0; f < F; ++f) {
+    const double sv = sal ? sal[(size_t)f * T + t] : 1.0;
+#pragma unroll
+    for (int k = 0; k < kEmbedMaxK; ++k)
+      if (k < K) s[k] += aff[((size_t)f * K + k) * T + t] * sv;
+  }
+  double tot = 0.0;
+#pragma unroll
+  for (int k = 0; k < kEmbedMaxK; ++k)
+    if (k < K) tot += s[k];
+#pragma unroll
+  for (int k = 0; k < kEmbedMaxK; ++k)
+    if (k < K) out[(size_t)k * T + t] = s[k] / tot;
+}
+
+__global__ void joint_fill_kernel(double* out, double v) { out[0] = v; }
+
+inline int ok_or_hip() { return hipGetLastError() == hipSuccess ? PBBSS_OK : PBBSS_ERR_HIP; }
+
+int fit_chunks(int64_t B, int64_t N, int E) {
+  const int S = kThreads / E;
+  int64_t want = 1024 / (B < 1024 ? B : 1024);
+  if (want < 1) want = 1;
+  int64_t maxc = (N + (int64_t)S * 4 - 1) / ((int64_t)S * 4);  // >= 4 trips of one slot per chunk
+  if (maxc < 1) maxc = 1;
+  return (int)(want < maxc ? want : maxc);
+}
+
+}  // namespace
+
+size_t embed_partial_doubles(int64_t B, int64_t N, int E, int K, int* chunks_out) {
+  const int C = fit_chunks(B, N, E);
+  if (chunks_out) *chunks_out = C;
+  return (size_t)B * C * K * (E + 1) + (size_t)B * K;
+}
+
+int launch_embed_prepare(const void* y, int y_is_f64, int64_t B, int64_t N, int E, int normalize,
+                         void* yd, double* yr, hipStream_t s) {
+  if (E < 1 || E > kEmbedMaxE || B > 65535) return PBBSS_ERR_UNSUPPORTED;
+  int R = 4096 / (E + 1);
+  if (R > 64) R = 64;
+  if (R < 1) R = 1;
+  const size_t lds = ((size_t)R * (E + 1) + R) * sizeof(double);
+  dim3 grid((unsigned)((N + R - 1) / R), (unsigned)B);
+  if (normalize) {
+    if (y_is_f64)
+      hipLaunchKernelGGL((embed_prepare_kernel<double, true>), grid, dim3(kThreads), lds, s,
+                         static_cast<const double*>(y), N, E, R, yd, yr);
+    else
+      hipLaunchKernelGGL((embed_prepare_kernel<float, true>), grid, dim3(kThreads), lds, s,
+                         static_cast<const float*>(y), N, E, R, yd, yr);
+  } else {
+    if (y_is_f64)
+      hipLaunchKernelGGL((embed_prepare_kernel<double, false>), grid, dim3(kThreads), lds, s,
+                         static_cast<const double*>(y), N, E, R, yd, yr);
+    else
+      hipLaunchKernelGGL((embed_prepare_kernel<float, false>), grid, dim3(kThreads), lds, s,
+                         static_cast<const float*>(y), N, E, R, yd, yr);
+  }
+  return ok_or_hip();
+}
+
+int launch_embed_offsets(int kind, int64_t BK, int E, const double* scale, double* offset,
+                         double* prec, hipStream_t s) {
+  const int per = kThreads / kWave;
+  hipLaunchKernelGGL(embed_offsets_kernel, dim3((unsigned)((BK + per - 1) / per)), dim3(kThreads),
+                     0, s, kind, BK, E, scale, offset, prec);
+  return ok_or_hip();
+}
+
+namespace {
+template <int KIND, int K, typename TS>
+int estep_go(const void* yd, int64_t B, int64_t N, int E, const double* mean, const double* prec,
+             const double* offset, const double* weight, double out_scale, int64_t Tin,
+             double* out_lp, double* out_aff, hipStream_t s) {
+  const size_t lds = ((size_t)K * E + 3 * K) * sizeof(double);
+  dim3 grid((unsigned)((N + kThreads - 1) / kThreads), (unsigned)B);
+  hipLaunchKernelGGL((embed_estep_kernel<KIND, K, TS>), grid, dim3(kThreads), lds, s,
+                     static_cast<const TS*>(yd), N, E, mean, prec, offset, weight, out_scale, Tin,
+                     out_lp, out_aff);
+  return ok_or_hip();
+}
+
+template <int KIND, typename TS>
+int estep_k(int K, const void* yd, int64_t B, int64_t N, int E, const double* mean,
+            const double* prec, const double* offset, const double* weight, double out_scale,
+            int64_t Tin, double* out_lp, double* out_aff, hipStream_t s) {
+#define PBBSS_ESTEP_CASE(KK) \
+  case KK: return estep_go<KIND, KK, TS>(yd, B, N, E, mean, prec, offset, weight, out_scale, Tin, out_lp, out_aff, s);
+  switch (K) {
+    PBBSS_ESTEP_CASE(1) PBBSS_ESTEP_CASE(2) PBBSS_ESTEP_CASE(3)
+    PBBSS_ESTEP_CASE(4) PBBSS_ESTEP_CASE(5) PBBSS_ESTEP_CASE(6)
+    default: return PBBSS_ERR_UNSUPPORTED;
+  }
+#undef PBBSS_ESTEP_CASE
+}
+
+template <int K, typename TS>
+int fit_go(int kind, const void* yr, int64_t B, int64_t N, int E, const double* aff, int64_t Tin,
+           const double* sal, double cmin, double cmax, int weight_mode, double* part,
+           double* out_mean, double* out_scale, double* out_weight, hipStream_t s) {
+  int C = 0;
+  const size_t np = embed_partial_doubles(B, N, E, K, &C);
+  double* den_buf = part + np - (size_t)B * K;
+  const int S = kThreads / E;
+  int64_t L = (N + C - 1) / C;
+  L = (L + S - 1) / S * S;
+  const size_t lds_fit = ((size_t)S * K * E + (size_t)S * K) * sizeof(double);
+  const size_t lds_fin = (size_t)K * (E + 1) * sizeof(double);
+  dim3 grid((unsigned)C, (unsigned)B);
+  hipLaunchKernelGGL((embed_fit_kernel<K, TS, 0>), grid, dim3(kThreads), lds_fit, s,
+                     static_cast<const TS*>(yr), N, E, C, L, aff, Tin, sal,
+                     (const double*)nullptr, part);
+  if (kind == PBBSS_EMBED_VMF) {
+    hipLaunchKernelGGL((embed_finalize_kernel<PBBSS_EMBED_VMF, 0>), dim3((unsigned)B),
+                       dim3(kThreads), lds_fin, s, part, C, E, K, cmin, cmax, weight_mode, den_buf,
+                       out_mean, out_scale, out_weight);
+    return ok_or_hip();
+  }
+  hipLaunchKernelGGL((embed_finalize_kernel<PBBSS_EMBED_GAUSS_SPHERICAL, 0>), dim3((unsigned)B),
+                     dim3(kThreads), lds_fin, s, part, C, E, K, cmin, cmax, weight_mode, den_buf,
+                     out_mean, out_scale, out_weight);
+  hipLaunchKernelGGL((embed_fit_kernel<K, TS, 1>), grid, dim3(kThreads), lds_fit, s,
+                     static_cast<const TS*>(yr), N, E, C, L, aff, Tin, sal, out_mean, part);
+  hipLaunchKernelGGL((embed_finalize_kernel<PBBSS_EMBED_GAUSS_SPHERICAL, 1>), dim3((unsigned)B),
+                     dim3(kThreads), lds_fin, s, part, C, E, K, cmin, cmax, -1, den_buf, out_mean,
+                     out_scale, (double*)nullptr);
+  return ok_or_hip();
+}
+
+template <typename TS>
+int fit_k(int K, int kind, const void* yr, int64_t B, int64_t N, int E, const double* aff,
+          int64_t Tin, const double* sal, double cmin, double cmax, int weight_mode, double* part,
+          double* out_mean, double* out_scale, double* out_weight, hipStream_t s) {
+#define PBBSS_FIT_CASE(KK) \
+  case KK: return fit_go<KK, TS>(kind, yr, B, N, E, aff, Tin, sal, cmin, cmax, weight_mode, part, out_mean, out_scale, out_weight, s);
+  switch (K) {
+    PBBSS_FIT_CASE(1) PBBSS_FIT_CASE(2) PBBSS_FIT_CASE(3)
+    PBBSS_FIT_CASE(4) PBBSS_FIT_CASE(5) PBBSS_FIT_CASE(6)
+    default: return PBBSS_ERR_UNSUPPORTED;
+  }
+#undef PBBSS_FIT_CASE
+}
+}  // namespace
+
+int launch_embed_estep(int kind, const void* yd, int y_is_f64, int64_t B, int64_t N, int E, int K,
+                       const double* mean, const double* prec, const double* offset,
+                       const double* weight, double out_scale, int64_t Tin, double* out_lp,
+                       double* out_aff, hipStream_t s) {
+  if (E < 1 || E > kEmbedMaxE || B > 65535) return PBBSS_ERR_UNSUPPORTED;
+  if (kind == PBBSS_EMBED_VMF) {
+    return y_is_f64 ? estep_k<PBBSS_EMBED_VMF, double>(K, yd, B, N, E, mean, prec, offset, weight,
+                                                       out_scale, Tin, out_lp, out_aff, s)
+                    : estep_k<PBBSS_EMBED_VMF, float>(K, yd, B, N, E, mean, prec, offset, weight,
+                                                      out_scale, Tin, out_lp, out_aff, s);
+  }
+  if (kind == PBBSS_EMBED_GAUSS_SPHERICAL) {
+    return y_is_f64 ? estep_k<PBBSS_EMBED_GAUSS_SPHERICAL, double>(
+                          K, yd, B, N, E, mean, prec, offset, weight, out_scale, Tin, out_lp,
+                          out_aff, s)
+                    : estep_k<PBBSS_EMBED_GAUSS_SPHERICAL, float>(
+                          K, yd, B, N, E, mean, prec, offset, weight, out_scale, Tin, out_lp,
+                          out_aff, s);
+  }
+  return PBBSS_ERR_UNSUPPORTED;
+}
+
+int launch_embed_fit(int kind, const void* yr, int y_is_f64, int64_t B, int64_t N, int E, int K,
+                     const double* aff, int64_t Tin, const double* sal, double cmin, double cmax,
+                     int weight_mode, double* part, double* out_mean, double* out_scale,
+                     double* out_weight, hipStream_t s) {
+  if (E < 1 || E > kEmbedMaxE || B > 65535) return PBBSS_ERR_UNSUPPORTED;
+  if (kind != PBBSS_EMBED_VMF && kind != PBBSS_EMBED_GAUSS_SPHERICAL) return PBBSS_ERR_UNSUPPORTED;
+  return y_is_f64 ? fit_k<double>(K, kind, yr, B, N, E, aff, Tin, sal, cmin, cmax, weight_mode,
+                                  part, out_mean, out_scale, out_weight, s)
+                  : fit_k<float>(K, kind, yr, B, N, E, aff, Tin, sal, cmin, cmax, weight_mode,
+                                 part, out_mean, out_scale, out_weight, s);
+}
+
+int launch_joint_weight(int mode, const double* aff, const double* sal, int64_t F, int K, int T,
+                        double* tmp, double* out_weight, hipStream_t s) {
+  if (K < 1 || K > kEmbedMaxK) return PBBSS_ERR_UNSUPPORTED;
+  switch (mode) {
+    case 0:
+      hipLaunchKernelGGL(joint_rowsum_kernel, dim3((unsigned)F), dim3(kThreads), 0, s, aff, sal, K,
+                         T, 1, tmp, out_weight);
+      break;
+    case 1:
+      hipLaunchKernelGGL(joint_fill_kernel, dim3(1), dim3(1), 0, s, out_weight, 1.0 / K);
+      break;
+    case 2:
+      hipLaunchKernelGGL(joint_rowsum_kernel, dim3((unsigned)F), dim3(kThreads), 0, s, aff, sal, K,
+                         T, 0, tmp, out_weight);
+      hipLaunchKernelGGL(joint_rows_to_class_kernel, dim3(1), dim3(kThreads), 0, s, tmp, F, K,
+                         out_weight);
+      break;
+    case 3:
+      hipLaunchKernelGGL(joint_colsum_kernel, dim3((unsigned)((T + kThreads - 1) / kThreads)),
+                         dim3(kThreads), 0, s, aff, sal, F, K, T, out_weight);
+      break;
+    case 4:
+      hipLaunchKernelGGL(joint_fill_kernel, dim3(1), dim3(1), 0, s, out_weight, 1.0);
+      break;
+    default: return PBBSS_ERR_INVALID_ARG;
+  }
+  return ok_or_hip();
+}
+
+}  // namespace pbbss

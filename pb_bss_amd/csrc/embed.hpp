@@ -1,0 +1,58 @@
+// Real-embedding mixture components: the von
+// Mises-Fisher and spherical-Gaussian halves of pb_bss.distribution.{vmfmm,
+// gcacgmm, vmfcacgmm}.  Host-side launchers; kernels live in embed.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include "pbbss.h"
+
+namespace pbbss {
+
+constexpr int kEmbedMaxK = 6;     // classes (same bound as the spatial kernels)
+constexpr int kEmbedMaxE = 256;   // embedding dimension (one workgroup row of the fit kernel)
+
+// bytes of the (B, E, N) transposed copy / of the fit partial sums
+size_t embed_partial_doubles(int64_t B, int64_t N, int E, int K, int* chunks_out);
+
+// y (B,N,E) row-major -> yd (B,E,N); NORMALIZE: rows scaled to unit norm
+// (von_mises_fisher.py:105-107) and ALSO written row-major to yr (float64).
+int launch_embed_prepare(const void* y, int y_is_f64, int64_t B, int64_t N, int E, int normalize,
+                         void* yd, double* yr, hipStream_t s);
+
+// offset_k of the class log-pdfs: vMF  -log_norm(kappa)        (von_mises_fisher.py:33-44)
+//                                 Gauss -E/2 ln 2pi + E ln(1/sqrt(cov)) (gaussian.py:108-137)
+// and prec_k: vMF kappa; Gauss 1/cov.
+int launch_embed_offsets(int kind, int64_t BK, int E, const double* scale, double* offset,
+                         double* prec, hipStream_t s);
+
+// class log-pdfs (times out_scale) and/or posteriors of every sample.
+//   yd (B,E,N) of type y_is_f64; mean (B,K,E); prec/offset (B,K) from launch_embed_offsets;
+//   weight (B,K) or null (needed for out_aff); out index of (b,k,n):
+//   b*K*N + (n / Tin)*K*Tin + k*Tin + n % Tin   (Tin = N: plain (B,K,N); Tin = T: 'k,ft->fkt')
+int launch_embed_estep(int kind, const void* yd, int y_is_f64, int64_t B, int64_t N, int E, int K,
+                       const double* mean, const double* prec, const double* offset,
+                       const double* weight, double out_scale, int64_t Tin, double* out_lp,
+                       double* out_aff, hipStream_t s);
+
+// weighted fit:  w_k(n) = aff[index(b,k,n)] * (sal ? sal[b*N+n] : 1)
+//   vMF   (von_mises_fisher.py:119-144): mean direction, concentration clipped to [cmin,cmax]
+//   Gauss (gaussian.py:152-193, 'spherical'): mean, then variance about that mean (2nd pass)
+//   weight_mode >= 0 also writes the mixture weights (B,K) (mixture_model_utils.py:133-203):
+//   0 L1-normalised masked sums, 1 uniform 1/K.
+// part: scratch of embed_partial_doubles() doubles.
+int launch_embed_fit(int kind, const void* yr, int y_is_f64, int64_t B, int64_t N, int E, int K,
+                     const double* aff, int64_t Tin, const double* sal, double cmin, double cmax,
+                     int weight_mode, double* part, double* out_mean, double* out_scale,
+                     double* out_weight, hipStream_t s);
+
+// masked affiliation sums of the joint models (gcacgmm.py:286-295): aff (F,K,T), sal (F,T)
+//   mode 0 'fk' (-1,): w[f,k] = sum_t / sum_k sum_t          -> (F,K)
+//   mode 1 uniform    : 1/K                                   -> (1)
+//   mode 2 'k' (-3,-1): sum_ft / sum_k sum_ft                 -> (K)
+//   mode 3 'kt' (-3,) : sum_f / sum_k sum_f                   -> (K,T)
+//   mode 4 ''         : 1                                     -> (1)
+// tmp: F*K doubles of scratch.
+int launch_joint_weight(int mode, const double* aff, const double* sal, int64_t F, int K, int T,
+                        double* tmp, double* out_weight, hipStream_t s);
+
+}  // namespace pbbss

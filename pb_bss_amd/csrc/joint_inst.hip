@@ -1,0 +1,56 @@
+// Joint spatial+spectral E/M step of the cACG half (gcacgmm.py / vmfcacgmm.py), one
+// translation unit per sensor count D (-DPBBSS_EM_D=<D>) like em_inst.hip.
+#include "cacgmm_em.hpp"
+#include "em_launch.hpp"
+
+#ifndef PBBSS_EM_D
+#error "compile with -DPBBSS_EM_D=<sensors>"
+#endif
+
+namespace pbbss {
+
+template <int K, typename YS>
+static int launch_joint(const EmArgs& a, const JointExtras& jx, int inline_pa,
+                        const EmLaunchCfg& cfg, hipStream_t stream) {
+  using Kern = EmKernel<PBBSS_EM_D, K, YS, false>;
+  const size_t lds = Kern::lds_bytes(a.T) + 64;  // + class permutation of the inline PA
+  if (lds > cfg.lds_limit) return PBBSS_ERR_LDS_CAPACITY;
+  auto kfn = cacgmm_joint_kernel<PBBSS_EM_D, K, YS>;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return PBBSS_ERR_HIP;
+  int occ = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn, kEmThreads, lds) != hipSuccess)
+    return PBBSS_ERR_HIP;
+  if (occ < 1) occ = 1;
+  int64_t grid = (int64_t)cfg.num_cu * occ;
+  if (grid > a.B) grid = a.B;
+  hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(kEmThreads), lds, stream, a, jx, inline_pa);
+  return hipGetLastError() == hipSuccess ? PBBSS_OK : PBBSS_ERR_HIP;
+}
+
+template <typename YS>
+static int launch_joint_k(int K, const EmArgs& a, const JointExtras& jx, int inline_pa,
+                          const EmLaunchCfg& cfg, hipStream_t stream) {
+  switch (K) {
+    case 1: return launch_joint<1, YS>(a, jx, inline_pa, cfg, stream);
+    case 2: return launch_joint<2, YS>(a, jx, inline_pa, cfg, stream);
+    case 3: return launch_joint<3, YS>(a, jx, inline_pa, cfg, stream);
+    case 4: return launch_joint<4, YS>(a, jx, inline_pa, cfg, stream);
+    case 5: return launch_joint<5, YS>(a, jx, inline_pa, cfg, stream);
+    case 6: return launch_joint<6, YS>(a, jx, inline_pa, cfg, stream);
+    default: return PBBSS_ERR_UNSUPPORTED;
+  }
+}
+
+#define PBBSS_CAT2(a, b) a##b
+#define PBBSS_CAT(a, b) PBBSS_CAT2(a, b)
+
+int PBBSS_CAT(joint_launch_d, PBBSS_EM_D)(int K, int y_is_c128, const EmArgs& a,
+                                          const JointExtras& jx, int inline_pa,
+                                          const EmLaunchCfg& cfg, hipStream_t stream) {
+  return y_is_c128 ? launch_joint_k<double>(K, a, jx, inline_pa, cfg, stream)
+                   : launch_joint_k<float>(K, a, jx, inline_pa, cfg, stream);
+}
+
+}  // namespace pbbss

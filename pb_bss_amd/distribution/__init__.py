@@ -8,9 +8,17 @@ from .complex_angular_central_gaussian import (
 from .cacgmm import CACGMM, CACGMMTrainer
 from .complex_watson import ComplexWatson, ComplexWatsonTrainer
 from .cwmm import CWMM, CWMMTrainer
+from .von_mises_fisher import VonMisesFisher, VonMisesFisherTrainer
+from .vmfmm import VMFMM, VMFMMTrainer
+from .gaussian import SphericalGaussian, GaussianTrainer
+from .gcacgmm import GCACGMM, GCACGMMTrainer
+from .vmfcacgmm import VMFCACGMM, VMFCACGMMTrainer
 
 __all__ = [
     'CACGMM', 'CACGMMTrainer', 'CWMM', 'CWMMTrainer',
+    'VonMisesFisher', 'VonMisesFisherTrainer', 'VMFMM', 'VMFMMTrainer',
+    'SphericalGaussian', 'GaussianTrainer', 'GCACGMM', 'GCACGMMTrainer',
+    'VMFCACGMM', 'VMFCACGMMTrainer',
     'ComplexWatson', 'ComplexWatsonTrainer',
     'ComplexAngularCentralGaussian', 'ComplexAngularCentralGaussianTrainer',
     'normalize_observation',

@@ -379,3 +379,138 @@ def split_error(device_index=None):
     _lib.check(_lib.load().pbbss_split_error(_lib.handle(device_index), ctypes.byref(flag)),
                'split_error')
     return int(flag.value)
+
+
+# ---- N2/N3: real-embedding mixtures and joint spatial+spectral models ---------
+def _real_embedding(y):
+    """float32 stays float32 on the device (the kernels widen to float64 on load)."""
+    t = _t()
+    if y.dtype not in (t.float32, t.float64):
+        y = y.to(t.float64)
+    return y.contiguous()
+
+
+def embed_log_pdf(y, kind, mean, scale):
+    """pbbss_embed_log_pdf.  y (B,N,E) real; mean (B,K,E); scale (B,K) -> (B,K,N) f64."""
+    t = _t()
+    y = _real_embedding(y)
+    B, N, E = y.shape
+    K = mean.shape[1]
+    out = t.empty((B, K, N), dtype=t.float64, device=y.device)
+    rc = _lib.load().pbbss_embed_log_pdf(
+        _lib.handle(y.device.index), _lib.ptr(y), int(y.dtype == t.float64), B, N, E, K, int(kind),
+        _lib.ptr(mean), _lib.ptr(scale), _lib.ptr(out), _lib.stream_ptr(y.device.index))
+    _lib.check(rc, f'embed_log_pdf(B={B},N={N},E={E},K={K})')
+    return out
+
+
+def embed_fit(y, kind, weights, *, normalize=False, min_concentration=1e-10,
+              max_concentration=500.):
+    """pbbss_embed_fit.  y (B,N,E) real; weights (B,K,N) f64 -> mean (B,K,E), scale (B,K)."""
+    t = _t()
+    y = _real_embedding(y)
+    B, N, E = y.shape
+    K = weights.shape[1]
+    assert weights.shape == (B, K, N) and weights.dtype == t.float64
+    mean = t.empty((B, K, E), dtype=t.float64, device=y.device)
+    scale = t.empty((B, K), dtype=t.float64, device=y.device)
+    rc = _lib.load().pbbss_embed_fit(
+        _lib.handle(y.device.index), _lib.ptr(y), int(y.dtype == t.float64), B, N, E, K, int(kind),
+        int(bool(normalize)), _lib.ptr(weights), float(min_concentration),
+        float(max_concentration), _lib.ptr(mean), _lib.ptr(scale), _lib.stream_ptr(y.device.index))
+    _lib.check(rc, f'embed_fit(B={B},N={N},E={E},K={K})')
+    return mean, scale
+
+
+def vmfmm_fit(y, K, *, gamma0=None, model=None, iterations=100, saliency=None, weight_mode=0,
+              min_concentration=1e-10, max_concentration=500., final_predict=False,
+              want_log_pdf=False):
+    """pbbss_vmfmm_fit.  y (B,N,E) real; gamma0 (B,K,N) f64 or (iterations=0)
+    model=(mean (B,K,E), concentration (B,K), weight (B,K))."""
+    t = _t()
+    y = _real_embedding(y)
+    dev = y.device
+    B, N, E = y.shape
+    f64 = t.float64
+    opts = _lib.MixOpts(iterations=int(iterations), kind=_lib.EMBED_VMF,
+                        weight_mode=int(weight_mode), embedding_is_f64=int(y.dtype == f64),
+                        final_predict=int(bool(final_predict or want_log_pdf)),
+                        min_concentration=float(min_concentration),
+                        max_concentration=float(max_concentration))
+    mean = t.empty((B, K, E), dtype=f64, device=dev)
+    conc = t.empty((B, K), dtype=f64, device=dev)
+    weight = t.empty((B, K), dtype=f64, device=dev)
+    aff = t.empty((B, K, N), dtype=f64, device=dev) if final_predict else None
+    lp = t.empty((B, K, N), dtype=f64, device=dev) if want_log_pdf else None
+    in_mean = in_conc = in_w = None
+    if model is not None:
+        in_mean, in_conc, in_w = model
+        assert in_mean.shape == (B, K, E) and in_conc.shape == (B, K) and in_w.shape == (B, K)
+    else:
+        assert gamma0.shape == (B, K, N) and gamma0.dtype == f64
+    rc = _lib.load().pbbss_vmfmm_fit(
+        _lib.handle(dev.index), _lib.ptr(y), B, N, E, K, _lib.ptr(gamma0), _lib.ptr(in_mean),
+        _lib.ptr(in_conc), _lib.ptr(in_w), _lib.ptr(saliency), ctypes.byref(opts),
+        _lib.ptr(mean), _lib.ptr(conc), _lib.ptr(weight), _lib.ptr(aff), _lib.ptr(lp),
+        _lib.stream_ptr(dev.index))
+    _lib.check(rc, f'vmfmm_fit(B={B},N={N},E={E},K={K})')
+    return dict(mean=mean, concentration=conc, weight=weight, affiliation=aff, log_pdf=lp)
+
+
+def joint_weight_shape(weight_mode, F, K, T):
+    return {_lib.JOINT_WEIGHT_FK: (F, K), _lib.JOINT_WEIGHT_UNIFORM: (), _lib.JOINT_WEIGHT_K: (K,),
+            _lib.JOINT_WEIGHT_KT: (K, T), _lib.JOINT_WEIGHT_CONST: ()}[weight_mode]
+
+
+def joint_fit(observation, embedding, K, kind, *, gamma0=None, model=None, iterations=100,
+              saliency=None, weight_mode=0, covariance_norm=1, eigenvalue_floor=1e-10,
+              affiliation_eps=1e-10, spatial_weight=1., spectral_weight=1., inline_pa=False,
+              min_concentration=1e-10, max_concentration=500., fixed_scale=None,
+              final_predict=False, check_status=True):
+    """pbbss_joint_fit.  observation (F,T,D) complex, embedding (F,T,E) real;
+    gamma0 (F,K,T) f64 or (iterations=0) model=(eigvec, eigval, weight, mean (K,E), scale (K))."""
+    t = _t()
+    embedding = _real_embedding(embedding)
+    dev = observation.device
+    F, T, D = observation.shape
+    E = embedding.shape[-1]
+    assert embedding.shape == (F, T, E)
+    f64 = t.float64
+    opts = _lib.MixOpts(iterations=int(iterations), kind=int(kind), weight_mode=int(weight_mode),
+                        embedding_is_f64=int(embedding.dtype == f64),
+                        obs_is_c128=int(observation.dtype == t.complex128),
+                        final_predict=int(bool(final_predict)), inline_pa=int(bool(inline_pa)),
+                        covariance_norm=int(covariance_norm),
+                        min_concentration=float(min_concentration),
+                        max_concentration=float(max_concentration),
+                        affiliation_eps=float(affiliation_eps),
+                        eigenvalue_floor=float(eigenvalue_floor),
+                        spatial_weight=float(spatial_weight),
+                        spectral_weight=float(spectral_weight))
+    wshape = joint_weight_shape(weight_mode, F, K, T)
+    eigvec = t.empty((F, K, D, D), dtype=t.complex128, device=dev)
+    eigval = t.empty((F, K, D), dtype=f64, device=dev)
+    weight = t.empty(wshape, dtype=f64, device=dev)
+    mean = t.empty((K, E), dtype=f64, device=dev)
+    scale = t.empty((K,), dtype=f64, device=dev)
+    status = t.zeros((F, K), dtype=t.int32, device=dev)
+    aff = t.empty((F, K, T), dtype=f64, device=dev) if final_predict else None
+    in_vec = in_val = in_w = in_mean = None
+    in_scale = fixed_scale
+    if model is not None:
+        in_vec, in_val, in_w, in_mean, in_scale = model
+        assert in_vec.shape == (F, K, D, D) and in_val.shape == (F, K, D)
+        assert tuple(in_w.shape) == tuple(wshape) and in_mean.shape == (K, E) and in_scale.shape == (K,)
+    else:
+        assert gamma0.shape == (F, K, T) and gamma0.dtype == f64
+    rc = _lib.load().pbbss_joint_fit(
+        _lib.handle(dev.index), _lib.ptr(observation), _lib.ptr(embedding), F, T, D, E, K,
+        _lib.ptr(gamma0), _lib.ptr(in_vec), _lib.ptr(in_val), _lib.ptr(in_w), _lib.ptr(in_mean),
+        _lib.ptr(in_scale), _lib.ptr(saliency), ctypes.byref(opts), _lib.ptr(eigvec),
+        _lib.ptr(eigval), _lib.ptr(weight), _lib.ptr(mean), _lib.ptr(scale), _lib.ptr(status),
+        _lib.ptr(aff), _lib.stream_ptr(dev.index))
+    _lib.check(rc, f'joint_fit(F={F},T={T},D={D},E={E},K={K})')
+    if check_status and iterations > 0:
+        _status_raise_em(status, 'joint model fit')
+    return dict(eigvec=eigvec, eigval=eigval, weight=weight, mean=mean, scale=scale,
+                status=status, affiliation=aff)

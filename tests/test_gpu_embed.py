@@ -1,0 +1,177 @@
+"""GPU: real-embedding mixtures: von Mises-Fisher and
+spherical-Gaussian kernels, VMFMM, and the joint spatial+spectral models GCACGMM /
+VMFCACGMM, against vectors of the real reference (tests/golden/embed_*.npz) and
+the NumPy oracle on larger seeded problems.  Everything goes through the C ABI."""
+import ast
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name + '.npz'))
+
+
+def cov(vec, val):
+    return np.einsum('...wx,...x,...zx->...wz', vec, val, vec.conj())
+
+
+def test_vmf_log_norm_series_matches_scipy_ive():
+    from pb_bss_amd.distribution import VonMisesFisher
+    g = load('embed_vmf_log_norm')
+    ks = g['concentrations']
+    for d in (2, 3, 10, 40):
+        mean = np.tile(np.ones(d) / np.sqrt(d), (len(ks), 1))
+        got = VonMisesFisher(mean=mean, concentration=ks).log_norm()
+        np.testing.assert_allclose(got, g[f'log_norm_d{d}'], rtol=1e-12, atol=2e-12)
+
+
+@pytest.mark.parametrize('dtype', [np.float32, np.float64])
+def test_single_fits_and_log_pdf_match_reference(dtype):
+    from pb_bss_amd.distribution import GaussianTrainer, VonMisesFisherTrainer
+    g = load('embed_single_fits')
+    y = g['y'].astype(dtype)[None]          # (1, N, E); the fixture data are float32 values
+    sal = g['saliency']                     # (K, N)
+    v = VonMisesFisherTrainer()._fit(y, saliency=sal, min_concentration=1e-10,
+                                     max_concentration=500)
+    assert v.mean.shape == g['vmf_mean'].shape and v.concentration.shape == (3,)
+    np.testing.assert_allclose(v.mean, g['vmf_mean'], atol=1e-13)
+    np.testing.assert_allclose(v.concentration, g['vmf_concentration'], rtol=1e-11)
+    m = GaussianTrainer()._fit(y, saliency=sal, covariance_type='spherical')
+    np.testing.assert_allclose(m.mean, g['spherical_mean'], atol=1e-13)
+    np.testing.assert_allclose(m.covariance, g['spherical_covariance'], rtol=1e-11)
+    np.testing.assert_allclose(m.log_pdf(y), g['spherical_log_pdf'], rtol=1e-10, atol=1e-9)
+    with pytest.raises(NotImplementedError):
+        GaussianTrainer()._fit(y, saliency=sal, covariance_type='full')
+
+
+def test_vmfmm_matches_reference_flat_and_independent_axes():
+    from pb_bss_amd.distribution import VMFMMTrainer
+    g = load('embed_vmfmm_n480_e10_k3')
+    model = VMFMMTrainer().fit(g['y'], initialization=g['init'], iterations=int(g['iterations']))
+    assert model.vmf.mean.shape == g['mean'].shape
+    assert model.vmf.concentration.shape == g['concentration'].shape
+    assert model.weight.shape == g['weight'].shape
+    np.testing.assert_allclose(model.vmf.mean, g['mean'], atol=1e-10)
+    np.testing.assert_allclose(model.vmf.concentration, g['concentration'], rtol=1e-9)
+    np.testing.assert_allclose(model.weight, g['weight'], atol=1e-11)
+    np.testing.assert_allclose(model.predict(g['y']), g['affiliation'], atol=1e-9)
+    np.testing.assert_allclose(model.vmf.log_pdf(g['y'][None]), g['log_pdf'], atol=1e-8)
+    g = load('embed_vmfmm_indep_f6_t80_e10_k3')
+    model = VMFMMTrainer().fit(g['y'], initialization=g['init'], iterations=int(g['iterations']),
+                               saliency=g['saliency'],
+                               max_concentration=float(g['max_concentration']))
+    assert model.vmf.mean.shape == g['mean'].shape == (6, 3, 10)
+    np.testing.assert_allclose(model.vmf.mean, g['mean'], atol=1e-10)
+    np.testing.assert_allclose(model.vmf.concentration, g['concentration'], rtol=1e-9)
+    np.testing.assert_allclose(model.weight, g['weight'], atol=1e-11)
+    np.testing.assert_allclose(model.predict(g['y']), g['affiliation'], atol=1e-9)
+
+
+@pytest.mark.parametrize('N,E,K', [(1000, 2, 2), (4099, 3, 4), (30000, 40, 3), (2500, 64, 6),
+                                   (700, 100, 2), (5, 7, 1)])
+def test_vmfmm_shapes_against_oracle(N, E, K):
+    """odd sample counts, one sample per workgroup slot, E not dividing 256, K = 1..6"""
+    from pb_bss_amd.distribution import VMFMMTrainer
+    from oracle import embed as oe
+    rng = np.random.default_rng(N + E)
+    mu = rng.standard_normal((K, E))
+    y = (mu[rng.integers(K, size=N)] + 0.7 * rng.standard_normal((N, E))).astype(np.float32)
+    init = rng.uniform(size=(K, N))
+    init /= init.sum(0)
+    sal = rng.uniform(0.1, 1.0, size=N)
+    ref = oe.vmfmm_fit(y.astype(np.float64), init, 6, saliency=sal)
+    model = VMFMMTrainer().fit(y, initialization=init, iterations=6, saliency=sal)
+    np.testing.assert_allclose(model.vmf.mean, ref['mean'], atol=1e-9)
+    np.testing.assert_allclose(model.vmf.concentration, ref['concentration'], rtol=1e-8)
+    np.testing.assert_allclose(model.weight, ref['weight'], atol=1e-10)
+    np.testing.assert_allclose(model.predict(y), oe.vmfmm_predict(ref, y.astype(np.float64)),
+                               atol=1e-8)
+
+
+def test_vmfmm_torch_in_torch_out_and_uniform_weight():
+    import torch
+    from pb_bss_amd.distribution import VMFMMTrainer
+    from oracle import embed as oe
+    rng = np.random.default_rng(5)
+    y = rng.standard_normal((3, 400, 8))
+    init = rng.uniform(size=(3, 2, 400))
+    init /= init.sum(1, keepdims=True)
+    yt = torch.as_tensor(y, device='cuda')
+    model = VMFMMTrainer().fit(yt, initialization=torch.as_tensor(init, device='cuda'),
+                               iterations=4, weight_constant_axis=-2)
+    assert model.vmf.mean.is_cuda and model.weight.shape == (2, 1)
+    ref = oe.vmfmm_fit(y, init, 4, weight_constant_axis=-2)
+    np.testing.assert_allclose(model.vmf.mean.cpu().numpy(), ref['mean'], atol=1e-10)
+    aff = model.predict(yt)
+    assert aff.is_cuda and aff.shape == (3, 2, 400)
+    np.testing.assert_allclose(aff.cpu().numpy(), oe.vmfmm_predict(ref, y), atol=1e-9)
+
+
+JOINT = [('embed_gcacgmm_spherical', 'gaussian'), ('embed_gcacgmm_weights', 'gaussian'),
+         ('embed_gcacgmm_inline_pa', 'gaussian'), ('embed_vmfcacgmm', 'vmf')]
+
+
+@pytest.mark.parametrize('name,kind', JOINT)
+def test_joint_models_match_reference(name, kind):
+    from pb_bss_amd.distribution import GCACGMMTrainer, VMFCACGMMTrainer
+    g = load(name)
+    kw = ast.literal_eval(str(g['kwargs']))
+    trainer = GCACGMMTrainer() if kind == 'gaussian' else VMFCACGMMTrainer()
+    model = trainer.fit(g['Y'], g['embedding'], initialization=g['init'],
+                        iterations=int(g['iterations']), **kw)
+    spec = model.gaussian if kind == 'gaussian' else model.vmf
+    assert np.shape(model.weight) == g['weight'].shape
+    np.testing.assert_allclose(np.asarray(model.weight), g['weight'], atol=1e-9)
+    np.testing.assert_allclose(spec.mean, g['mean'], atol=1e-9)
+    if kind == 'gaussian':
+        np.testing.assert_allclose(spec.covariance, g['covariance'], rtol=1e-8)
+    else:
+        np.testing.assert_allclose(spec.concentration, g['concentration'], rtol=1e-8)
+    np.testing.assert_allclose(cov(model.cacg.covariance_eigenvectors, model.cacg.covariance_eigenvalues),
+                               cov(g['eigvec'], g['eigval']), atol=1e-7)
+    aff = model.predict(g['Y'], g['embedding'])
+    assert aff.shape == g['affiliation'].shape
+    assert np.abs(aff - g['affiliation']).max() < 1e-7
+
+
+@pytest.mark.parametrize('kind,kw', [
+    ('gaussian', {}),
+    ('gaussian', dict(weight_constant_axis=(-3, -2, -1), spectral_weight=0.5)),
+    ('gaussian', dict(weight_constant_axis=(-2,))),
+    ('vmf', dict(weight_constant_axis=(-3, -1), max_concentration=80.)),
+])
+def test_joint_models_config5_shape_against_oracle(kind, kw):
+    """BASELINE config 5 at reduced F: 8 mics, K=3, 40-dim embeddings, with saliency."""
+    from pb_bss_amd.distribution import GCACGMMTrainer, VMFCACGMMTrainer
+    from oracle import embed as oe, synth
+    F, T, D, K, E = 24, 300, 8, 3, 40
+    Y, e, init = synth.make_joint(F, T, D, K, E, seed=9)
+    sal = np.random.default_rng(1).uniform(0.2, 1.0, size=(F, T))
+    trainer = GCACGMMTrainer() if kind == 'gaussian' else VMFCACGMMTrainer()
+    masks = trainer.fit_predict(Y, e, initialization=init, iterations=8, saliency=sal, **kw)
+    ref = oe.joint_fit(kind, Y.astype(np.complex128), e.astype(np.float64), init, 8,
+                       saliency=sal, **kw)
+    want = oe.joint_model_predict(ref, Y.astype(np.complex128), e.astype(np.float64))
+    assert masks.shape == (F, K, T)
+    assert np.abs(masks - want).max() < 1e-6
+
+
+def test_joint_fixed_covariance_and_errors():
+    from pb_bss_amd.distribution import GCACGMMTrainer
+    from oracle import embed as oe, synth
+    Y, e, init = synth.make_joint(5, 90, 3, 2, 12, seed=2)
+    fixed = np.array([0.02, 0.05])
+    model = GCACGMMTrainer().fit(Y, e, initialization=init, iterations=4, fixed_covariance=fixed)
+    ref = oe.joint_fit('gaussian', Y.astype(np.complex128), e.astype(np.float64), init, 4,
+                       fixed_covariance=fixed)
+    np.testing.assert_allclose(model.gaussian.covariance, fixed)
+    np.testing.assert_allclose(model.gaussian.mean, ref['mean'], atol=1e-9)
+    with pytest.raises(NotImplementedError):
+        GCACGMMTrainer().fit(Y, e, initialization=init, iterations=2, covariance_type='full')
+    with pytest.raises(AssertionError):
+        GCACGMMTrainer().fit(Y, e, initialization=init, num_classes=2)
