@@ -89,6 +89,13 @@ struct JointExtras {
   const double* extra_logpdf;  // (B,K,T)
   double spatial_weight;
   const int* perm;             // [K] in LDS: spatial class used by class slot k (inline PA)
+  // Between the iterations of one fit the cACG model travels as the packed inverse
+  // covariance A_k and det B_k ((B,K,D*D+2) float64) instead of (V, lambda): the M-step can
+  // then take the Gauss-Jordan fast path, and only the last iteration pays for the
+  // eigendecomposition the caller sees.
+  const double* state_in;      // null: build A_k from a.in_eigvec / a.in_eigval
+  double* state_out;           // null: do not export
+  int emit_model;              // 1: exact eigen path, write a.out_eigvec / a.out_eigval
 };
 
 // SPILL=false: observation, norms and M-step weights live in LDS (the fast path).
@@ -927,7 +934,20 @@ struct EmKernel {
       __syncthreads();
       phase_load(a, L, b, tid);
       __syncthreads();
-      for (int k = wave; k < K; k += kEmWaves) prep_from_model(a, L, b, k, lane);
+      for (int k = wave; k < K; k += kEmWaves) {
+        if (jx0.state_in) {
+          const double* st = jx0.state_in + ((size_t)b * K + k) * (NA + 2);
+          for (int i = lane; i < NA; i += kWave) L.apack[k * NA + i] = st[i];
+          if (lane == 0) {
+            const double dm = st[NA];
+            L.detm[k] = dm;
+            L.rdet[k] = 1.0 / dm;
+            L.dete[k] = (int)st[NA + 1];
+          }
+        } else {
+          prep_from_model(a, L, b, k, lane);
+        }
+      }
       __syncthreads();
       JointExtras jx = jx0;
       jx.perm = nullptr;
@@ -948,7 +968,17 @@ struct EmKernel {
         default: phase_m<3>(a, L, lane); break;
       }
       __syncthreads();
-      for (int k = wave; k < K; k += kEmWaves) factor_class(a, L, b, k, lane, true);
+      for (int k = wave; k < K; k += kEmWaves) {
+        factor_class(a, L, b, k, lane, jx0.emit_model != 0);
+        if (jx0.state_out) {  // same wave wrote apack / det of class k: wave-ordered LDS
+          double* st = jx0.state_out + ((size_t)b * K + k) * (NA + 2);
+          for (int i = lane; i < NA; i += kWave) st[i] = L.apack[k * NA + i];
+          if (lane == 0) {
+            st[NA] = L.detm[k];
+            st[NA + 1] = (double)L.dete[k];
+          }
+        }
+      }
       __syncthreads();
       if (tid < K && a.out_status) a.out_status[(size_t)b * K + tid] = L.status[tid];
     }

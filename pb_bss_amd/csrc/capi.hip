@@ -544,7 +544,7 @@ PBBSS_API int pbbss_embed_fit(pbbss_handle_t h, const void* y, int y_is_f64, int
   }
   return pbbss::launch_embed_fit(kind, yr, yr_f64, B, N, E, K, weights, N, nullptr,
                                  min_concentration, max_concentration, -1, part, out_mean,
-                                 out_scale, nullptr, s);
+                                 out_scale, nullptr, nullptr, nullptr, s);
 }
 
 PBBSS_API int pbbss_vmfmm_fit(pbbss_handle_t h, const void* y, int64_t B, int64_t N, int E, int K,
@@ -585,9 +585,7 @@ PBBSS_API int pbbss_vmfmm_fit(pbbss_handle_t h, const void* y, int64_t B, int64_
   }
   for (int it = 0; it < o->iterations; ++it) {
     const double* src = gamma0;
-    if (it > 0) {  // vmfmm.py:137-138
-      rc = pbbss::launch_embed_offsets(PBBSS_EMBED_VMF, B * K, E, out_concentration, offset, prec, s);
-      if (rc != PBBSS_OK) return rc;
+    if (it > 0) {  // vmfmm.py:137-138 (offsets come from the previous M-step's finalize)
       rc = pbbss::launch_embed_estep(PBBSS_EMBED_VMF, yd, 1, B, N, E, K, out_mean, prec, offset,
                                      out_weight, 1.0, N, nullptr, aff, s);
       if (rc != PBBSS_OK) return rc;
@@ -595,12 +593,14 @@ PBBSS_API int pbbss_vmfmm_fit(pbbss_handle_t h, const void* y, int64_t B, int64_
     }
     rc = pbbss::launch_embed_fit(PBBSS_EMBED_VMF, yr, 1, B, N, E, K, src, N, saliency,
                                  o->min_concentration, o->max_concentration, o->weight_mode, part,
-                                 out_mean, out_concentration, out_weight, s);
+                                 out_mean, out_concentration, out_weight, offset, prec, s);
     if (rc != PBBSS_OK) return rc;
   }
   if (o->final_predict && (out_affiliation || out_log_pdf)) {
-    rc = pbbss::launch_embed_offsets(PBBSS_EMBED_VMF, B * K, E, out_concentration, offset, prec, s);
-    if (rc != PBBSS_OK) return rc;
+    if (o->iterations == 0) {
+      rc = pbbss::launch_embed_offsets(PBBSS_EMBED_VMF, B * K, E, out_concentration, offset, prec, s);
+      if (rc != PBBSS_OK) return rc;
+    }
     rc = pbbss::launch_embed_estep(PBBSS_EMBED_VMF, yd, 1, B, N, E, K, out_mean, prec, offset,
                                    out_weight, 1.0, N, out_log_pdf, out_affiliation, s);
     if (rc != PBBSS_OK) return rc;
@@ -641,9 +641,10 @@ PBBSS_API int pbbss_joint_fit(pbbss_handle_t h, const void* observation, const v
   const size_t esz = o->embedding_is_f64 ? 8 : 4;
   const size_t np = pbbss::embed_partial_doubles(1, N, E, K, nullptr);
   const size_t nfkt = (size_t)F * K * T;
+  const size_t nstate = (size_t)F * K * (D * D + 2);
   const size_t need = WorkCarver::pad((size_t)E * N * esz) + 2 * WorkCarver::pad(nfkt * 8) +
                       WorkCarver::pad(np * 8) + 2 * WorkCarver::pad((size_t)K * 8) +
-                      WorkCarver::pad((size_t)F * K * 8);
+                      WorkCarver::pad((size_t)F * K * 8) + WorkCarver::pad(nstate * 8);
   void* w = handle_work(h, need);
   if (!w) return PBBSS_ERR_HIP;
   WorkCarver wc(w);
@@ -654,6 +655,7 @@ PBBSS_API int pbbss_joint_fit(pbbss_handle_t h, const void* observation, const v
   double* offset = wc.take<double>(K);
   double* prec = wc.take<double>(K);
   double* tmp = wc.take<double>((size_t)F * K);
+  double* jstate = wc.take<double>(nstate);
   TimedRegion tr(h, s);
   int rc = pbbss::launch_embed_prepare(embedding, o->embedding_is_f64, 1, N, E, 0, yd, nullptr, s);
   if (rc != PBBSS_OK) return rc;
@@ -665,13 +667,17 @@ PBBSS_API int pbbss_joint_fit(pbbss_handle_t h, const void* observation, const v
     if ((rc = copy_d2d(out_scale, in_scale, (size_t)K * 8, s)) != PBBSS_OK) return rc;
   }
   // spectral log-pdf (times spectral_weight) of every point, laid out (F,K,T)
+  const bool fixed_scale = in_scale && has_gamma;
   auto spectral = [&]() -> int {
-    int r = pbbss::launch_embed_offsets(o->kind, K, E, out_scale, offset, prec, s);
-    if (r != PBBSS_OK) return r;
+    if (fixed_scale || o->iterations == 0) {  // otherwise the M-step finalize wrote them
+      int r = pbbss::launch_embed_offsets(o->kind, K, E, out_scale, offset, prec, s);
+      if (r != PBBSS_OK) return r;
+    }
     return pbbss::launch_embed_estep(o->kind, yd, o->embedding_is_f64, 1, N, E, K, out_mean, prec,
                                      offset, nullptr, o->spectral_weight, T, slp, nullptr, s);
   };
-  auto joint = [&](int iterations, double* aff_out, int inline_pa) -> int {
+  auto joint = [&](int iterations, double* aff_out, int inline_pa, const double* state_in,
+                   double* state_out, int emit_model) -> int {
     pbbss::EmArgs a{};
     a.y = observation;
     a.B = F;
@@ -694,7 +700,7 @@ PBBSS_API int pbbss_joint_fit(pbbss_handle_t h, const void* observation, const v
     a.aff_eps = o->affiliation_eps;
     a.final_eps = 0.0;
     a.eig_floor = o->eigenvalue_floor;
-    pbbss::JointExtras jx{slp, o->spatial_weight, nullptr};
+    pbbss::JointExtras jx{slp, o->spatial_weight, nullptr, state_in, state_out, emit_model};
     return pbbss::joint_launch(D, K, o->obs_is_c128, a, jx, inline_pa, h->cfg, s);
   };
   for (int it = 0; it < o->iterations; ++it) {
@@ -719,22 +725,27 @@ PBBSS_API int pbbss_joint_fit(pbbss_handle_t h, const void* observation, const v
       if (rc != PBBSS_OK) return rc;
     } else {
       if ((rc = spectral()) != PBBSS_OK) return rc;
-      if ((rc = joint(1, aff, o->inline_pa)) != PBBSS_OK) return rc;
+      // the model travels as packed inverse covariances between iterations; the first joint
+      // step reads the eigen model of the initial M-step, the last one emits (V, lambda)
+      const bool last = (it == o->iterations - 1);
+      rc = joint(1, aff, o->inline_pa, it == 1 ? nullptr : jstate, last ? nullptr : jstate,
+                 last ? 1 : 0);
+      if (rc != PBBSS_OK) return rc;
       src = aff;
     }
     rc = pbbss::launch_joint_weight(o->weight_mode, src, saliency, F, K, T, tmp, out_weight, s);
     if (rc != PBBSS_OK) return rc;
     rc = pbbss::launch_embed_fit(o->kind, embedding, o->embedding_is_f64, 1, N, E, K, src, T,
                                  saliency, o->min_concentration, o->max_concentration, -1, part,
-                                 out_mean, out_scale, nullptr, s);
+                                 out_mean, out_scale, nullptr, offset, prec, s);
     if (rc != PBBSS_OK) return rc;
-    if (in_scale && has_gamma) {  // fixed_covariance (gcacgmm.py:305-312)
+    if (fixed_scale) {  // fixed_covariance (gcacgmm.py:305-312)
       if ((rc = copy_d2d(out_scale, in_scale, (size_t)K * 8, s)) != PBBSS_OK) return rc;
     }
   }
   if (o->final_predict && out_affiliation) {
     if ((rc = spectral()) != PBBSS_OK) return rc;
-    if ((rc = joint(0, out_affiliation, 0)) != PBBSS_OK) return rc;
+    if ((rc = joint(0, out_affiliation, 0, nullptr, nullptr, 0)) != PBBSS_OK) return rc;
   }
   return PBBSS_OK;
 }

@@ -271,27 +271,66 @@ __global__ void __launch_bounds__(kThreads)
 }
 
 // ---------------------------------------------------------------- M-step finalize
-// One workgroup per mixture: ordered sum over the chunk partials, then the model.
+// One 1024-thread workgroup per mixture: ordered two-level sum over the chunk partials
+// (slot = chunk index mod nslot, then over slots), then the model and -- so that the
+// next E-step needs no separate launch -- the log-pdf offsets / precisions.
+constexpr int kFinThreads = 1024;
+
+__device__ __forceinline__ double vmf_offset(int E, double conc, int lane) {
+  // -log_norm = -(E/2 ln 2pi + ln ive(nu, k) + (|k| - nu ln k)) = -(E/2 ln 2pi + ln(I_nu(k)/k^nu))
+  return -(0.5 * E * kLn2Pi + wave_log_bessel_over_power(0.5 * E - 1.0, conc, lane));
+}
+
 template <int KIND, int PASS>
-__global__ void __launch_bounds__(kThreads)
+__global__ void __launch_bounds__(kFinThreads)
     embed_finalize_kernel(const double* part, int C, int E, int K, double cmin, double cmax,
                           int weight_mode, double* den_buf, double* out_mean, double* out_scale,
-                          double* out_weight) {
-  extern __shared__ double sm[];  // [K][E+1]
+                          double* out_weight, double* out_offset, double* out_prec) {
+  extern __shared__ double sm[];  // tot [K][E+1], then red [nslot][W] (W < 1024) 
   const int64_t b = blockIdx.x;
   const int tid = threadIdx.x;
   const int lane = tid & (kWave - 1);
   const int wave = tid >> 6;
   const int W = K * (E + 1);
-  for (int i = tid; i < W; i += kThreads) {
-    const double* p = part + (size_t)b * C * W + i;
-    double t = 0.0;
-    for (int c = 0; c < C; ++c) t += p[(size_t)c * W];
-    sm[i] = t;
+  double* tot = sm;
+  double* red = sm + W;
+  const double* pb = part + (size_t)b * C * W;
+  if (W >= kFinThreads) {
+    for (int i = tid; i < W; i += kFinThreads) {
+      double t = 0.0;
+      for (int c = 0; c < C; ++c) t += pb[(size_t)c * W + i];
+      tot[i] = t;
+    }
+  } else {
+    const int nslot = kFinThreads / W;
+    const int slot = tid / W;
+    const int i = tid - slot * W;
+    if (slot < nslot) {
+      double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+      int c = slot;
+      for (; c + 3 * nslot < C; c += 4 * nslot) {
+        double a0 = pb[(size_t)c * W + i];
+        double a1 = pb[(size_t)(c + nslot) * W + i];
+        double a2 = pb[(size_t)(c + 2 * nslot) * W + i];
+        double a3 = pb[(size_t)(c + 3 * nslot) * W + i];
+        t0 += a0;
+        t1 += a1;
+        t2 += a2;
+        t3 += a3;
+      }
+      for (; c < C; c += nslot) t0 += pb[(size_t)c * W + i];
+      red[slot * W + i] = (t0 + t1) + (t2 + t3);
+    }
+    __syncthreads();
+    for (int j = tid; j < W; j += kFinThreads) {
+      double t = 0.0;
+      for (int sl = 0; sl < nslot; ++sl) t += red[sl * W + j];
+      tot[j] = t;
+    }
   }
   __syncthreads();
-  for (int k = wave; k < K; k += kThreads / kWave) {
-    const double* row = sm + k * (E + 1);
+  for (int k = wave; k < K; k += kFinThreads / kWave) {
+    const double* row = tot + k * (E + 1);
     if (PASS == 0) {
       const double s0 = row[E];
       if (KIND == PBBSS_EMBED_VMF) {
@@ -301,11 +340,17 @@ __global__ void __launch_bounds__(kThreads)
         const double norm = sqrt(n2);
         const double rn = 1.0 / fmax(norm, kTiny);  // Banerjee 2005 eq. 2.4
         for (int d = lane; d < E; d += kWave) out_mean[((size_t)b * K + k) * E + d] = row[d] * rn;
+        const double rbar = norm / s0;                                         // eq. 2.5
+        double conc = (rbar * E - rbar * rbar * rbar) / (1.0 - rbar * rbar);  // eq. 4.4
+        conc = conc < cmin ? cmin : (conc > cmax ? cmax : conc);              // NaN stays NaN
+        double off = 0.0;
+        if (out_offset) off = vmf_offset(E, conc, lane);
         if (lane == 0) {
-          const double rbar = norm / s0;                                         // eq. 2.5
-          double conc = (rbar * E - rbar * rbar * rbar) / (1.0 - rbar * rbar);  // eq. 4.4
-          conc = conc < cmin ? cmin : (conc > cmax ? cmax : conc);              // NaN stays NaN
           out_scale[b * K + k] = conc;
+          if (out_offset) {
+            out_offset[b * K + k] = off;
+            out_prec[b * K + k] = conc;
+          }
         }
       } else {
         const double den = fmax(s0, kTiny);  // gaussian.py:160-163
@@ -316,7 +361,15 @@ __global__ void __launch_bounds__(kThreads)
       double t = 0.0;
       for (int d = lane; d < E; d += kWave) t += row[d];
       t = wave_sum(t);
-      if (lane == 0) out_scale[b * K + k] = t / (den_buf[b * K + k] * (double)E);  // 'spherical'
+      if (lane == 0) {
+        const double cv = t / (den_buf[b * K + k] * (double)E);  // 'spherical'
+        out_scale[b * K + k] = cv;
+        if (out_offset) {
+          const double pc = 1.0 / sqrt(cv);
+          out_offset[b * K + k] = -0.5 * E * kLn2Pi + (double)E * log(pc);
+          out_prec[b * K + k] = pc;
+        }
+      }
     }
   }
   if (PASS == 0 && out_weight && weight_mode >= 0 && tid == 0) {
@@ -324,10 +377,10 @@ __global__ void __launch_bounds__(kThreads)
       for (int k = 0; k < K; ++k) out_weight[b * K + k] = 1.0 / K;
     } else {
       // estimate_mixture_weight with saliency: L1 unit norm over classes, eps 'where' 1e-10
-      double tot = 0.0;
-      for (int k = 0; k < K; ++k) tot += fabs(sm[k * (E + 1) + E]);
-      if (tot == 0.0) tot = 1e-10;
-      for (int k = 0; k < K; ++k) out_weight[b * K + k] = sm[k * (E + 1) + E] / tot;
+      double t = 0.0;
+      for (int k = 0; k < K; ++k) t += fabs(tot[k * (E + 1) + E]);
+      if (t == 0.0) t = 1e-10;
+      for (int k = 0; k < K; ++k) out_weight[b * K + k] = tot[k * (E + 1) + E] / t;
     }
   }
 }
@@ -507,7 +560,8 @@ int estep_k(int K, const void* yd, int64_t B, int64_t N, int E, const double* me
 template <int K, typename TS>
 int fit_go(int kind, const void* yr, int64_t B, int64_t N, int E, const double* aff, int64_t Tin,
            const double* sal, double cmin, double cmax, int weight_mode, double* part,
-           double* out_mean, double* out_scale, double* out_weight, hipStream_t s) {
+           double* out_mean, double* out_scale, double* out_weight, double* out_offset,
+           double* out_prec, hipStream_t s) {
   int C = 0;
   const size_t np = embed_partial_doubles(B, N, E, K, &C);
   double* den_buf = part + np - (size_t)B * K;
@@ -515,34 +569,36 @@ int fit_go(int kind, const void* yr, int64_t B, int64_t N, int E, const double* 
   int64_t L = (N + C - 1) / C;
   L = (L + S - 1) / S * S;
   const size_t lds_fit = ((size_t)S * K * E + (size_t)S * K) * sizeof(double);
-  const size_t lds_fin = (size_t)K * (E + 1) * sizeof(double);
+  const size_t Wv = (size_t)K * (E + 1);
+  const size_t lds_fin = (Wv + (Wv < (size_t)kFinThreads ? (kFinThreads / Wv) * Wv : 0)) * sizeof(double);
   dim3 grid((unsigned)C, (unsigned)B);
   hipLaunchKernelGGL((embed_fit_kernel<K, TS, 0>), grid, dim3(kThreads), lds_fit, s,
                      static_cast<const TS*>(yr), N, E, C, L, aff, Tin, sal,
                      (const double*)nullptr, part);
   if (kind == PBBSS_EMBED_VMF) {
     hipLaunchKernelGGL((embed_finalize_kernel<PBBSS_EMBED_VMF, 0>), dim3((unsigned)B),
-                       dim3(kThreads), lds_fin, s, part, C, E, K, cmin, cmax, weight_mode, den_buf,
-                       out_mean, out_scale, out_weight);
+                       dim3(kFinThreads), lds_fin, s, part, C, E, K, cmin, cmax, weight_mode,
+                       den_buf, out_mean, out_scale, out_weight, out_offset, out_prec);
     return ok_or_hip();
   }
   hipLaunchKernelGGL((embed_finalize_kernel<PBBSS_EMBED_GAUSS_SPHERICAL, 0>), dim3((unsigned)B),
-                     dim3(kThreads), lds_fin, s, part, C, E, K, cmin, cmax, weight_mode, den_buf,
-                     out_mean, out_scale, out_weight);
+                     dim3(kFinThreads), lds_fin, s, part, C, E, K, cmin, cmax, weight_mode, den_buf,
+                     out_mean, out_scale, out_weight, (double*)nullptr, (double*)nullptr);
   hipLaunchKernelGGL((embed_fit_kernel<K, TS, 1>), grid, dim3(kThreads), lds_fit, s,
                      static_cast<const TS*>(yr), N, E, C, L, aff, Tin, sal, out_mean, part);
   hipLaunchKernelGGL((embed_finalize_kernel<PBBSS_EMBED_GAUSS_SPHERICAL, 1>), dim3((unsigned)B),
-                     dim3(kThreads), lds_fin, s, part, C, E, K, cmin, cmax, -1, den_buf, out_mean,
-                     out_scale, (double*)nullptr);
+                     dim3(kFinThreads), lds_fin, s, part, C, E, K, cmin, cmax, -1, den_buf, out_mean,
+                     out_scale, (double*)nullptr, out_offset, out_prec);
   return ok_or_hip();
 }
 
 template <typename TS>
 int fit_k(int K, int kind, const void* yr, int64_t B, int64_t N, int E, const double* aff,
           int64_t Tin, const double* sal, double cmin, double cmax, int weight_mode, double* part,
-          double* out_mean, double* out_scale, double* out_weight, hipStream_t s) {
+          double* out_mean, double* out_scale, double* out_weight, double* out_offset,
+          double* out_prec, hipStream_t s) {
 #define PBBSS_FIT_CASE(KK) \
-  case KK: return fit_go<KK, TS>(kind, yr, B, N, E, aff, Tin, sal, cmin, cmax, weight_mode, part, out_mean, out_scale, out_weight, s);
+  case KK: return fit_go<KK, TS>(kind, yr, B, N, E, aff, Tin, sal, cmin, cmax, weight_mode, part, out_mean, out_scale, out_weight, out_offset, out_prec, s);
   switch (K) {
     PBBSS_FIT_CASE(1) PBBSS_FIT_CASE(2) PBBSS_FIT_CASE(3)
     PBBSS_FIT_CASE(4) PBBSS_FIT_CASE(5) PBBSS_FIT_CASE(6)
@@ -577,13 +633,13 @@ int launch_embed_estep(int kind, const void* yd, int y_is_f64, int64_t B, int64_
 int launch_embed_fit(int kind, const void* yr, int y_is_f64, int64_t B, int64_t N, int E, int K,
                      const double* aff, int64_t Tin, const double* sal, double cmin, double cmax,
                      int weight_mode, double* part, double* out_mean, double* out_scale,
-                     double* out_weight, hipStream_t s) {
+                     double* out_weight, double* out_offset, double* out_prec, hipStream_t s) {
   if (E < 1 || E > kEmbedMaxE || B > 65535) return PBBSS_ERR_UNSUPPORTED;
   if (kind != PBBSS_EMBED_VMF && kind != PBBSS_EMBED_GAUSS_SPHERICAL) return PBBSS_ERR_UNSUPPORTED;
   return y_is_f64 ? fit_k<double>(K, kind, yr, B, N, E, aff, Tin, sal, cmin, cmax, weight_mode,
-                                  part, out_mean, out_scale, out_weight, s)
+                                  part, out_mean, out_scale, out_weight, out_offset, out_prec, s)
                   : fit_k<float>(K, kind, yr, B, N, E, aff, Tin, sal, cmin, cmax, weight_mode,
-                                 part, out_mean, out_scale, out_weight, s);
+                                 part, out_mean, out_scale, out_weight, out_offset, out_prec, s);
 }
 
 int launch_joint_weight(int mode, const double* aff, const double* sal, int64_t F, int K, int T,
