@@ -96,6 +96,9 @@ struct JointExtras {
   const double* state_in;      // null: build A_k from a.in_eigvec / a.in_eigval
   double* state_out;           // null: do not export
   int emit_model;              // 1: exact eigen path, write a.out_eigvec / a.out_eigval
+  // class weights of weight_constant_axis=(-1,) (gcacgmm.py:291-295): w[b,k] = sum_t masked
+  // affiliation / sum over k, written by the workgroup that owns bin b (may alias a.in_weight)
+  double* weight_fk_out;
 };
 
 // SPILL=false: observation, norms and M-step weights live in LDS (the fast path).
@@ -961,6 +964,18 @@ struct EmKernel {
       }
       phase_e<false, true, true>(a, L, b, tid, wave, lane, a.aff_eps, 0, &jx);
       __syncthreads();
+      if (jx0.weight_fk_out && tid == 0) {
+        double v[K], tot = 0.0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          v[k] = 0.0;
+#pragma unroll
+          for (int w = 0; w < kEmWaves; ++w) v[k] += L.red[w * K + k];
+          tot += v[k];
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) jx0.weight_fk_out[(size_t)b * K + k] = v[k] / tot;
+      }
       switch (wave) {
         case 0: phase_m<0>(a, L, lane); break;
         case 1: phase_m<1>(a, L, lane); break;

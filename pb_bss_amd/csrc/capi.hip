@@ -700,7 +700,9 @@ PBBSS_API int pbbss_joint_fit(pbbss_handle_t h, const void* observation, const v
     a.aff_eps = o->affiliation_eps;
     a.final_eps = 0.0;
     a.eig_floor = o->eigenvalue_floor;
-    pbbss::JointExtras jx{slp, o->spatial_weight, nullptr, state_in, state_out, emit_model};
+    pbbss::JointExtras jx{slp, o->spatial_weight, nullptr, state_in, state_out, emit_model,
+                          (iterations > 0 && o->weight_mode == PBBSS_JOINT_WEIGHT_FK) ? out_weight
+                                                                                     : nullptr};
     return pbbss::joint_launch(D, K, o->obs_is_c128, a, jx, inline_pa, h->cfg, s);
   };
   for (int it = 0; it < o->iterations; ++it) {
@@ -733,8 +735,10 @@ PBBSS_API int pbbss_joint_fit(pbbss_handle_t h, const void* observation, const v
       if (rc != PBBSS_OK) return rc;
       src = aff;
     }
-    rc = pbbss::launch_joint_weight(o->weight_mode, src, saliency, F, K, T, tmp, out_weight, s);
-    if (rc != PBBSS_OK) return rc;
+    if (it == 0 || o->weight_mode != PBBSS_JOINT_WEIGHT_FK) {  // 'fk' weights: joint kernel
+      rc = pbbss::launch_joint_weight(o->weight_mode, src, saliency, F, K, T, tmp, out_weight, s);
+      if (rc != PBBSS_OK) return rc;
+    }
     rc = pbbss::launch_embed_fit(o->kind, embedding, o->embedding_is_f64, 1, N, E, K, src, T,
                                  saliency, o->min_concentration, o->max_concentration, -1, part,
                                  out_mean, out_scale, nullptr, offset, prec, s);

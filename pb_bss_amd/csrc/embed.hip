@@ -78,19 +78,25 @@ __global__ void __launch_bounds__(kThreads) embed_prepare_kernel(const TS* y, in
 __device__ double wave_log_bessel_over_power(double nu, double x, int lane) {
   const double lx = 2.0 * log(x) - 1.3862943611198906;  // ln(x^2 / 4)
   const int M = (int)ceil(fmin(x, 1.0e6)) + 48;        // terms fall by > 4x per step past m = x
-  double mx = -INFINITY;
-  for (int m = lane; m < M; m += kWave) {
-    double lt = (m ? (double)m * lx : 0.0) - lgamma((double)m + 1.0) - lgamma((double)m + nu + 1.0);
-    mx = fmax(mx, lt);
+  // lane owns the terms [m0, m0 + R): ln t_m0 from lgamma, then
+  // ln t_(m+1) = ln t_m + ln(x^2/4) - ln(m+1) - ln(m+1+nu); running log-sum-exp per lane
+  const int R = (M + kWave - 1) / kWave;
+  const int m0 = lane * R;
+  double lt = (m0 ? (double)m0 * lx : 0.0) - lgamma((double)m0 + 1.0) - lgamma((double)m0 + nu + 1.0);
+  double mx = lt, sum = 1.0;
+  for (int r = 1; r < R; ++r) {
+    const double m1 = (double)(m0 + r);
+    lt += lx - log(m1) - log(m1 + nu);
+    if (lt > mx) {
+      sum = sum * exp(mx - lt) + 1.0;
+      mx = lt;
+    } else {
+      sum += exp(lt - mx);
+    }
   }
-  mx = wave_max(mx);
-  double sum = 0.0;
-  for (int m = lane; m < M; m += kWave) {
-    double lt = (m ? (double)m * lx : 0.0) - lgamma((double)m + 1.0) - lgamma((double)m + nu + 1.0);
-    sum += exp(lt - mx);
-  }
-  sum = wave_sum(sum);
-  return -nu * 0.6931471805599453 + mx + log(sum);
+  const double gmx = wave_max(mx);
+  sum = wave_sum(sum * exp(mx - gmx));
+  return -nu * 0.6931471805599453 + gmx + log(sum);
 }
 
 // one wavefront per (mixture, class)
@@ -196,12 +202,13 @@ __global__ void __launch_bounds__(kThreads)
 // PASS 0: S1[k][d] = sum_n w_k(n) y[n][d], S0[k] = sum_n w_k(n)
 // PASS 1: S2[k][d] = sum_n w_k(n) (y[n][d] - mean[k][d])^2
 // part layout: [b][chunk][k][E+1]  (slot E = S0)
+constexpr int kFitThreads = 1024;  // 16 waves: one workgroup per CU keeps 1024 loads in flight
+
 template <int K, typename TS, int PASS>
-__global__ void __launch_bounds__(kThreads)
-    embed_fit_kernel(const TS* yr, int64_t N, int E, int C, int64_t L, const double* aff,
+__global__ void __launch_bounds__(kFitThreads)
+    embed_fit_kernel(const TS* yr, int64_t N, int E, int S, int C, int64_t L, const double* aff,
                      int64_t Tin, const double* sal, const double* mean, double* part) {
   extern __shared__ double sm[];
-  const int S = kThreads / E;
   double* red = sm;               // [S][K][E]
   double* red0 = sm + S * K * E;  // [S][K]
   const int64_t b = blockIdx.y;
@@ -257,7 +264,7 @@ __global__ void __launch_bounds__(kThreads)
   }
   __syncthreads();
   double* dst = part + ((size_t)b * C + c) * K * (E + 1);
-  for (int i = tid; i < K * E; i += kThreads) {
+  for (int i = tid; i < K * E; i += kFitThreads) {
     const int k = i / E, dd = i - k * E;
     double t = 0.0;
     for (int ss = 0; ss < S; ++ss) t += red[(ss * K + k) * E + dd];
@@ -479,9 +486,18 @@ __global__ void joint_fill_kernel(double* out, double v) { out[0] = v; }
 
 inline int ok_or_hip() { return hipGetLastError() == hipSuccess ? PBBSS_OK : PBBSS_ERR_HIP; }
 
-int fit_chunks(int64_t B, int64_t N, int E) {
-  const int S = kThreads / E;
-  int64_t want = 1024 / (B < 1024 ? B : 1024);
+// sample slots of one fit workgroup: as many as 1024 threads hold, capped so that the
+// slot-reduction buffer stays within 48 KiB of LDS
+int fit_slots(int E, int K) {
+  int S = kFitThreads / E;
+  const int cap = 6144 / (K * (E + 1));
+  if (S > cap) S = cap;
+  return S < 1 ? 1 : S;
+}
+
+int fit_chunks(int64_t B, int64_t N, int E, int K) {
+  const int S = fit_slots(E, K);
+  int64_t want = 256 / (B < 256 ? B : 256);  // ~one 1024-thread workgroup per CU in total
   if (want < 1) want = 1;
   int64_t maxc = (N + (int64_t)S * 4 - 1) / ((int64_t)S * 4);  // >= 4 trips of one slot per chunk
   if (maxc < 1) maxc = 1;
@@ -491,7 +507,7 @@ int fit_chunks(int64_t B, int64_t N, int E) {
 }  // namespace
 
 size_t embed_partial_doubles(int64_t B, int64_t N, int E, int K, int* chunks_out) {
-  const int C = fit_chunks(B, N, E);
+  const int C = fit_chunks(B, N, E, K);
   if (chunks_out) *chunks_out = C;
   return (size_t)B * C * K * (E + 1) + (size_t)B * K;
 }
@@ -565,15 +581,15 @@ int fit_go(int kind, const void* yr, int64_t B, int64_t N, int E, const double* 
   int C = 0;
   const size_t np = embed_partial_doubles(B, N, E, K, &C);
   double* den_buf = part + np - (size_t)B * K;
-  const int S = kThreads / E;
+  const int S = fit_slots(E, K);
   int64_t L = (N + C - 1) / C;
   L = (L + S - 1) / S * S;
   const size_t lds_fit = ((size_t)S * K * E + (size_t)S * K) * sizeof(double);
   const size_t Wv = (size_t)K * (E + 1);
   const size_t lds_fin = (Wv + (Wv < (size_t)kFinThreads ? (kFinThreads / Wv) * Wv : 0)) * sizeof(double);
   dim3 grid((unsigned)C, (unsigned)B);
-  hipLaunchKernelGGL((embed_fit_kernel<K, TS, 0>), grid, dim3(kThreads), lds_fit, s,
-                     static_cast<const TS*>(yr), N, E, C, L, aff, Tin, sal,
+  hipLaunchKernelGGL((embed_fit_kernel<K, TS, 0>), grid, dim3(kFitThreads), lds_fit, s,
+                     static_cast<const TS*>(yr), N, E, S, C, L, aff, Tin, sal,
                      (const double*)nullptr, part);
   if (kind == PBBSS_EMBED_VMF) {
     hipLaunchKernelGGL((embed_finalize_kernel<PBBSS_EMBED_VMF, 0>), dim3((unsigned)B),
@@ -584,8 +600,8 @@ int fit_go(int kind, const void* yr, int64_t B, int64_t N, int E, const double* 
   hipLaunchKernelGGL((embed_finalize_kernel<PBBSS_EMBED_GAUSS_SPHERICAL, 0>), dim3((unsigned)B),
                      dim3(kFinThreads), lds_fin, s, part, C, E, K, cmin, cmax, weight_mode, den_buf,
                      out_mean, out_scale, out_weight, (double*)nullptr, (double*)nullptr);
-  hipLaunchKernelGGL((embed_fit_kernel<K, TS, 1>), grid, dim3(kThreads), lds_fit, s,
-                     static_cast<const TS*>(yr), N, E, C, L, aff, Tin, sal, out_mean, part);
+  hipLaunchKernelGGL((embed_fit_kernel<K, TS, 1>), grid, dim3(kFitThreads), lds_fit, s,
+                     static_cast<const TS*>(yr), N, E, S, C, L, aff, Tin, sal, out_mean, part);
   hipLaunchKernelGGL((embed_finalize_kernel<PBBSS_EMBED_GAUSS_SPHERICAL, 1>), dim3((unsigned)B),
                      dim3(kFinThreads), lds_fin, s, part, C, E, K, cmin, cmax, -1, den_buf, out_mean,
                      out_scale, (double*)nullptr, out_offset, out_prec);
