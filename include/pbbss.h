@@ -385,6 +385,46 @@ int pbbss_joint_fit(pbbss_handle_t h, const void* observation,
                     double* out_affiliation, void* stream);
 
 /* ------------------------------------------------------------------------- */
+/* N4  Remaining members of the beamformer family, extraction/beamformer.py.     */
+/* All arrays complex128 (interleaved float64) unless noted, 2 <= D <= 8 for the */
+/* LCMV solve, D < 30 otherwise.                                                 */
+/* ------------------------------------------------------------------------- */
+/* get_lcmv_vector (:414-456): atf (K,F,D), response (K) (rounded to complex64 as  */
+/* the reference does), noise (F,D,D) -> w (F,D); status[f] = PBBSS_ST_SINGULAR    */
+/* where a least-squares fallback was taken (stable_solve, math/solve.py:95-114). */
+int pbbss_lcmv(pbbss_handle_t h, const void* atf, const void* response,
+               const void* noise, int64_t F, int D, int K, void* out_w,
+               int32_t* out_status, void* stream);
+/* phase_correction (:517-560): vector viewed as (lead, rest, F, D); the running    */
+/* product of the inter-frequency phasors runs along the frequency axis for 2-D    */
+/* input (two_d != 0, lead = rest = 1) and along the FIRST axis otherwise, as       */
+/* np.cumprod(..., axis=0) does in the reference.  scratch: lead*rest*(F-1) c128.  */
+int pbbss_phase_correction(pbbss_handle_t h, const void* vector, int64_t lead,
+                           int64_t rest, int F, int D, int two_d, void* scratch,
+                           void* out, void* stream);
+/* mvdr_snr_postfilter (:502-509): (w^H T w)/(w^H N w) -> out (F) c128.            */
+int pbbss_snr_postfilter(pbbss_handle_t h, const void* w, const void* target,
+                         const void* noise, int64_t F, int D, void* out,
+                         void* stream);
+/* distortionless_normalization (:491-499) -> out (F,D).                           */
+int pbbss_distortionless_normalization(pbbss_handle_t h, const void* w,
+                                       const void* atf, const void* noise,
+                                       int64_t F, int D, void* out, void* stream);
+/* zero_degree_normalization (:512-514): vector (N,D) -> out (N,D).                */
+int pbbss_zero_degree_normalization(pbbss_handle_t h, const void* vector, int64_t N,
+                                    int D, int reference_channel, void* out,
+                                    void* stream);
+/* condition_covariance (:563-569): x (N,D,D) -> out (N,D,D).                      */
+int pbbss_condition_covariance(pbbss_handle_t h, const void* x, int64_t N, int D,
+                               double gamma, void* out, void* stream);
+/* apply_online_beamforming_vector (:586-598): vector (T,F,D) c128, mix (F,D,T)    */
+/* c64/c128 -> out (F,T) c128.                                                     */
+int pbbss_apply_online_beamforming_vector(pbbss_handle_t h, const void* vector,
+                                          const void* mix, int mix_is_c128,
+                                          int64_t F, int T, int D, void* out,
+                                          void* stream);
+
+/* ------------------------------------------------------------------------- */
 /* Timing hook for bench.py: runs `fit` with HIP events recorded on `stream`   */
 /* around the EM kernel launch(es) only and returns the elapsed milliseconds   */
 /* of the most recent call (the roofline figure needs the kernel duration on   */

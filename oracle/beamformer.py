@@ -11,6 +11,8 @@ import scipy.linalg
 __all__ = [
     'psd', 'gev_vector', 'stable_solve', 'optimal_reference_channel',
     'mvdr_souden', 'mvdr', 'ban', 'apply_bf', 'pca_vector', 'bf_vector', 'wmwf',
+    'pca', 'mvdr_merl', 'lcmv', 'distortionless_normalization', 'mvdr_snr_postfilter',
+    'zero_degree_normalization', 'phase_correction', 'condition_covariance', 'apply_online_bf',
 ]
 
 
@@ -189,3 +191,76 @@ def bf_vector(beamformer, target_psd, noise_psd=None, **kw):
     if do_ban:
         w = ban(w, noise_psd)
     return w
+
+
+# ---- remaining members of the family -----------------------
+def pca(target_psd, return_all_vecs=False):
+    """extraction/beamformer.py:163-194."""
+    shape = target_psd.shape
+    vals, vecs = np.linalg.eigh(target_psd.reshape(-1, *shape[-2:]))
+    if return_all_vecs:
+        return vecs.reshape(shape), vals.reshape(shape[:-1])
+    return vecs[..., -1].reshape(shape[:-1]), vals[..., -1].reshape(shape[:-2])
+
+
+def mvdr_merl(target_psd, noise_psd):
+    """extraction/beamformer.py:263-289."""
+    G = np.linalg.solve(noise_psd, target_psd)
+    h = G / np.trace(G, axis1=-2, axis2=-1)[..., None, None]
+    nom = np.sum(np.einsum('...fac,fab,...fbc->c', h.conj(), target_psd, h))
+    den = np.sum(np.einsum('...fac,fab,...fbc->c', h.conj(), noise_psd, h))
+    # NB: np.sum over the (sensors,) result gives scalars in the reference, so nom/denom is
+    # a scalar and argmax is 0 -- restated as written (beamformer.py:281-289).
+    return h[..., int(np.argmax(nom / den))]
+
+
+def lcmv(atf_vectors, response_vector, noise_psd):
+    """extraction/beamformer.py:414-456."""
+    response_vector = np.asarray(response_vector)
+    K, F, D = atf_vectors.shape
+    pih = stable_solve(np.broadcast_to(noise_psd[None], (K, F, D, D)),
+                       atf_vectors[..., None])[..., 0]                     # (K,F,D)
+    hph = np.einsum('k...d,K...d->...kK', atf_vectors.conj(), pih)        # (F,K,K)
+    rv = np.repeat(response_vector[None, :, None].astype(np.complex64), F, axis=0)
+    temp = stable_solve(hph, rv)[..., 0]                                  # (F,K)
+    return np.einsum('k...d,...k->...d', pih, temp)
+
+
+def distortionless_normalization(vector, atf_vector, noise_psd):
+    """extraction/beamformer.py:491-499."""
+    nom = np.einsum('fab,fb,fc->fac', noise_psd, vector, vector.conj())
+    den = np.einsum('fa,fab,fb->f', vector.conj(), noise_psd, vector)
+    return np.einsum('fab,fb->fa', nom / den[..., None, None], atf_vector)
+
+
+def mvdr_snr_postfilter(vector, target_psd, noise_psd):
+    """extraction/beamformer.py:502-509."""
+    nom = np.einsum('fa,fab,fb->f', vector.conj(), target_psd, vector)
+    den = np.einsum('fa,fab,fb->f', vector.conj(), noise_psd, vector)
+    return (nom / den)[:, None]
+
+
+def zero_degree_normalization(vector, reference_channel):
+    """extraction/beamformer.py:512-514."""
+    return vector * np.exp(-1j * np.angle(vector[..., reference_channel, None]))
+
+
+def phase_correction(vector):
+    """extraction/beamformer.py:517-560 (the vectorised body: running product along
+    axis 0 of the (..., F-1, 1) phasor array)."""
+    vector = np.array(vector, copy=True)
+    inner = np.sum(vector[..., 1:, :].conj() * vector[..., :-1, :], axis=-1, keepdims=True)
+    vector[..., 1:, :] *= np.cumprod(np.exp(1j * np.angle(inner)), axis=0)
+    return vector
+
+
+def condition_covariance(x, gamma):
+    """extraction/beamformer.py:563-569."""
+    D = x.shape[-1]
+    scale = gamma * np.trace(x, axis1=-2, axis2=-1) / D
+    return (x + np.eye(D) * scale[..., None, None]) / (1 + gamma)
+
+
+def apply_online_bf(vector, mix):
+    """extraction/beamformer.py:586-598."""
+    return np.einsum('...at,...at->...t', vector.transpose(1, 2, 0).conj(), mix)

@@ -275,6 +275,44 @@ def embed_cases():
               affiliation=m.predict(Y128, emb64), **extra)
 
 
+def beamformer_extra_cases():
+    """N4: the rest of extraction/beamformer.py."""
+    from pb_bss.extraction import beamformer as bf
+    rng = np.random.default_rng(31)
+    F, D, K, T = 19, 5, 2, 40
+
+    def cn(*shape):
+        return rng.standard_normal(shape) + 1j * rng.standard_normal(shape)
+
+    def psd(n):
+        a = cn(n, D, 2 * D)
+        return a @ a.conj().swapaxes(-1, -2) / (2 * D)
+
+    target, noise = psd(F), psd(F) + 0.1 * np.eye(D)
+    atf = cn(K, F, D)
+    w = cn(F, D)
+    wb = cn(3, F, D)
+    vt = cn(T, F, D)
+    mix = cn(F, D, T).astype(np.complex64)
+    noise_sing = noise.copy()
+    noise_sing[4] = np.outer(atf[0, 4], atf[0, 4].conj())     # rank one: lstsq branch
+    pca_all = bf.get_pca(target, return_all_vecs=True)
+    pca_one = bf.get_pca(target)
+    _save('beamformer_extra_f19_d5',
+          target=target, noise=noise, atf=atf, w=w, wb=wb, vt=vt, mix=mix, noise_sing=noise_sing,
+          lcmv_10=bf.get_lcmv_vector(atf, [1, 0], noise),
+          lcmv_01=bf.get_lcmv_vector(atf, [0, 1], noise),
+          lcmv_sing=bf.get_lcmv_vector(atf, [1, 0], noise_sing),
+          merl=bf.get_mvdr_vector_merl(target, noise),
+          distortionless=bf.distortionless_normalization(w, atf[0], noise),
+          postfilter=bf.mvdr_snr_postfilter(w, target, noise),
+          zero_degree=bf.zero_degree_normalization(wb, 2),
+          phase_2d=bf.phase_correction(w), phase_3d=bf.phase_correction(wb),
+          conditioned=bf.condition_covariance(target, 0.05),
+          online=bf.apply_online_beamforming_vector(vt, mix),
+          pca_all_vec=pca_all[0], pca_all_val=pca_all[1], pca_vec=pca_one[0], pca_val=pca_one[1])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     refshim.load()
@@ -285,6 +323,7 @@ def main():
     dhtv_cases()
     cwmm_cases()
     embed_cases()
+    beamformer_extra_cases()
 
 
 if __name__ == '__main__':

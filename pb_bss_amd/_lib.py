@@ -43,6 +43,9 @@ EXPORTS = (
     'pbbss_dhtv_calculate_mapping', 'pbbss_apply_mapping', 'pbbss_cwmm_fit',
     'pbbss_wmwf', 'pbbss_set_split_tail', 'pbbss_split_error',
     'pbbss_embed_log_pdf', 'pbbss_embed_fit', 'pbbss_vmfmm_fit', 'pbbss_joint_fit',
+    'pbbss_lcmv', 'pbbss_phase_correction', 'pbbss_snr_postfilter',
+    'pbbss_distortionless_normalization', 'pbbss_zero_degree_normalization',
+    'pbbss_condition_covariance', 'pbbss_apply_online_beamforming_vector',
 )
 
 EMBED_VMF = 0
@@ -165,6 +168,13 @@ def load():
         lib.pbbss_joint_fit.argtypes = [vp, vp, vp, i64, i32, i32, i32, i32, vp, vp, vp, vp, vp,
                                         vp, vp, ctypes.POINTER(MixOpts), vp, vp, vp, vp, vp, vp,
                                         vp, vp]
+        lib.pbbss_lcmv.argtypes = [vp, vp, vp, vp, i64, i32, i32, vp, vp, vp]
+        lib.pbbss_phase_correction.argtypes = [vp, vp, i64, i64, i32, i32, i32, vp, vp, vp]
+        lib.pbbss_snr_postfilter.argtypes = [vp, vp, vp, vp, i64, i32, vp, vp]
+        lib.pbbss_distortionless_normalization.argtypes = [vp, vp, vp, vp, i64, i32, vp, vp]
+        lib.pbbss_zero_degree_normalization.argtypes = [vp, vp, i64, i32, i32, vp, vp]
+        lib.pbbss_condition_covariance.argtypes = [vp, vp, i64, i32, dbl, vp, vp]
+        lib.pbbss_apply_online_beamforming_vector.argtypes = [vp, vp, vp, i32, i64, i32, i32, vp, vp]
         for name in EXPORTS:
             fn = getattr(lib, name)
             if name not in ('pbbss_error_string',):

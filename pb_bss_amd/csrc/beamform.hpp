@@ -21,4 +21,16 @@ int launch_apply(const double* w, const void* x, int x128, int64_t B, int T, int
 int launch_normalize(const void* y, int is128, int64_t B, int T, int D, void* out, hipStream_t s);
 int launch_psd(const void* x, int x128, int64_t B, int T, int D, int K, const double* mask,
                int normalize, double* out, const EmLaunchCfg& cfg, hipStream_t s);
+// bf_extra.hip
+int launch_lcmv(const double* atf, const double* response, const double* noise, int64_t F, int D,
+                int K, double* w, int32_t* st, hipStream_t s);
+int launch_phase_correction(const double* v, int64_t lead, int64_t rest, int F, int D, int two_d,
+                            double* scratch_u, double* out, hipStream_t s);
+int launch_bf_quadratic(int mode, const double* w, const double* m1, const double* m2,
+                        const double* atf, int64_t F, int D, double* out, hipStream_t s);
+int launch_zero_degree(const double* v, int64_t N, int D, int ref, double* out, hipStream_t s);
+int launch_condition_covariance(const double* x, int64_t N, int D, double gamma, double* out,
+                                hipStream_t s);
+int launch_apply_online(const double* v, const void* mix, int mix_is_c128, int64_t F, int T, int D,
+                        double* out, hipStream_t s);
 }  // namespace pbbss

@@ -1,0 +1,325 @@
+// Remaining members of the reference's beamformer family:
+// LCMV, phase correction along frequency, distortionless / zero-degree normalisation,
+// SNR post-filter, covariance conditioning, time-varying ("online") filter application.
+// Reference: extraction/beamformer.py:414-456, :491-599.
+//
+// All of these are O(F D^2) touch-once operations on a few hundred small matrices: one
+// wavefront per matrix where a solve is involved (wave_la.hpp), one thread per
+// frequency / frame otherwise; no staging, the whole problem sits in L2.
+#include "beamform.hpp"
+#include "pbbss_dev.hpp"
+#include "wave_la.hpp"
+
+namespace pbbss {
+namespace {
+
+constexpr int kLaThreads = 256;
+constexpr int kLaWaves = kLaThreads / kWave;
+
+struct Cx {
+  double re, im;
+};
+__device__ __forceinline__ Cx cmul(Cx a, Cx b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+__device__ __forceinline__ Cx cmulc(Cx a, Cx b) {  // conj(a) * b
+  return {a.re * b.re + a.im * b.im, a.re * b.im - a.im * b.re};
+}
+__device__ __forceinline__ Cx cdiv(Cx a, Cx b) {
+  // Smith's algorithm, as C99 / NumPy divide complex numbers
+  if (fabs(b.re) >= fabs(b.im)) {
+    double r = b.im / b.re, d = b.re + b.im * r;
+    return {(a.re + a.im * r) / d, (a.im - a.re * r) / d};
+  }
+  double r = b.re / b.im, d = b.re * r + b.im;
+  return {(a.re * r + a.im) / d, (a.im * r - a.re) / d};
+}
+__device__ __forceinline__ Cx ld(const double* p, size_t i) { return {p[2 * i], p[2 * i + 1]}; }
+__device__ __forceinline__ void st(double* p, size_t i, Cx v) {
+  p[2 * i] = v.re;
+  p[2 * i + 1] = v.im;
+}
+
+// ------------------------------------------------------------------ LCMV
+// w_f = P t,  P = Phi_f^-1 H_f (D x K),  (H_f^H P) t = response     (beamformer.py:430-454)
+// atf (K,F,D), response (K), noise (F,D,D), all c128.  One wavefront per frequency;
+// lane (i,j) of the 8x8 grid.  The K x K system is embedded in D x D with a diagonal pad
+// of the system's own scale, so the shared LU / pseudo-inverse routines apply unchanged.
+template <int D>
+__global__ void __launch_bounds__(kLaThreads)
+    lcmv_kernel(const double* atf, const double* response, const double* noise, int64_t F, int K,
+                double* out_w, int32_t* status) {
+  const int lane = threadIdx.x & 63;
+  const int64_t f = (int64_t)blockIdx.x * kLaWaves + (threadIdx.x >> 6);
+  if (f >= F) return;
+  const LaneIJ c = lane_ij(lane);
+  double nre = 0.0, nim = 0.0, bre = 0.0, bim = 0.0;
+  if (c.i < D && c.j < D) {
+    const double* p = noise + ((f * D + c.i) * D + c.j) * 2;
+    nre = p[0];
+    nim = p[1];
+  }
+  if (c.i < D && c.j < K) {  // B = H: column k is the ATF of source k
+    const double* p = atf + (((size_t)c.j * F + f) * D + c.i) * 2;
+    bre = p[0];
+    bim = p[1];
+  }
+  double pre, pim;
+  bool sing = wave_lu_solve<D>(nre, nim, bre, bim, c, pre, pim);
+  if (sing) wave_pinv_solve<D>(nre, nim, bre, bim, c, pre, pim);  // stable_solve, math/solve.py:111
+  if (!(c.i < D && c.j < K)) {
+    pre = 0.0;
+    pim = 0.0;
+  }
+  // G = H^H P: left factor A_kd = conj(H_dk) on lane (k, d)
+  double are = 0.0, aim = 0.0;
+  if (c.i < K && c.j < D) {
+    const double* p = atf + (((size_t)c.i * F + f) * D + c.j) * 2;
+    are = p[0];
+    aim = -p[1];
+  }
+  double gre, gim;
+  wave_matmul<D>(are, aim, pre, pim, c, gre, gim);
+  const double pad = lane_get(gre, ij_lane(0, 0));
+  if (c.i >= K || c.j >= K) {
+    gre = (c.i == c.j && c.i < D) ? ((pad != 0.0 && isfinite(pad)) ? fabs(pad) : 1.0) : 0.0;
+    gim = 0.0;
+  }
+  double rre = 0.0, rim = 0.0;
+  if (c.j == 0 && c.i < K) {
+    // the reference casts the response to complex64 (beamformer.py:443)
+    rre = (double)(float)response[2 * c.i];
+    rim = (double)(float)response[2 * c.i + 1];
+  }
+  double tre, tim;
+  bool sing2 = wave_lu_solve<D>(gre, gim, rre, rim, c, tre, tim);
+  if (sing2) wave_pinv_solve<D>(gre, gim, rre, rim, c, tre, tim);
+  if (!(c.j == 0 && c.i < K)) {
+    tre = 0.0;
+    tim = 0.0;
+  }
+  double wre, wim;
+  wave_matmul<D>(pre, pim, tre, tim, c, wre, wim);
+  if (c.j == 0 && c.i < D) {
+    out_w[(f * D + c.i) * 2] = wre;
+    out_w[(f * D + c.i) * 2 + 1] = wim;
+  }
+  if (status && lane == 0) status[f] = (sing || sing2) ? PBBSS_ST_SINGULAR : 0;
+}
+
+// ------------------------------------------------------------------ phase correction
+// u[l, r] = exp(j angle(sum_d conj(v[.., f, d]) v[.., f-1, d])), f >= 1   (beamformer.py:551-559)
+// v viewed as (L, R, F, D): L = leading axis (the reference's cumprod runs along axis 0 of
+// the (.., F-1, 1) array: the frequency axis for 2-D input, the FIRST axis otherwise).
+__global__ void phase_unit_kernel(const double* v, int64_t M, int F, int D, double* u) {
+  // one thread per (m, f), m over all leading axes; u (M, F-1)
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * (F - 1)) return;
+  const int64_t m = i / (F - 1);
+  const int f = (int)(i - m * (F - 1)) + 1;
+  Cx s{0.0, 0.0};
+  for (int d = 0; d < D; ++d) {
+    Cx a = ld(v, ((size_t)m * F + f) * D + d), b = ld(v, ((size_t)m * F + f - 1) * D + d);
+    Cx p = cmulc(a, b);
+    s.re += p.re;
+    s.im += p.im;
+  }
+  const double ang = atan2(s.im, s.re);  // np.angle; angle(0) = 0
+  u[2 * i] = cos(ang);
+  u[2 * i + 1] = sin(ang);
+}
+
+// cumulative product along the scan axis and application; u viewed as (L, R) with L the
+// scan length: thread r walks l = 0..L-1.
+//   2-D input : L = F-1, R = 1, vector row = l + 1
+//   N-D input : L = shape[0], R = prod(rest) * (F-1); element (l, r) scales row (l, r/(F-1), r%(F-1)+1)
+__global__ void phase_scan_kernel(const double* v, const double* u, int64_t L, int64_t R, int F,
+                                  int D, int two_d, double* out) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  Cx acc{1.0, 0.0};
+  for (int64_t l = 0; l < L; ++l) {
+    acc = cmul(acc, ld(u, (size_t)l * R + r));
+    size_t row;
+    if (two_d) {
+      row = (size_t)l + 1;
+    } else {
+      const int64_t rest = r / (F - 1);
+      const int f = (int)(r - rest * (F - 1)) + 1;
+      row = ((size_t)l * (R / (F - 1)) + rest) * F + f;
+    }
+    for (int d = 0; d < D; ++d) st(out, row * D + d, cmul(ld(v, row * D + d), acc));
+  }
+}
+
+// ------------------------------------------------------------------ per-frequency scalars
+// mode 0: mvdr_snr_postfilter  (w^H T w) / (w^H N w)                    (beamformer.py:502-509)
+// mode 1: distortionless_normalization  (N w)(w^H a) / (w^H N w)        (:491-499)
+__global__ void bf_quadratic_kernel(int mode, const double* w, const double* m1, const double* m2,
+                                    const double* atf, int64_t F, int D, double* out) {
+  const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= F) return;
+  const double* M2 = m2 + (size_t)f * D * D * 2;
+  Cx den{0.0, 0.0}, num{0.0, 0.0};
+  for (int a = 0; a < D; ++a) {
+    Cx wa = ld(w, (size_t)f * D + a);
+    Cx r2{0.0, 0.0}, r1{0.0, 0.0};
+    for (int b = 0; b < D; ++b) {
+      Cx wb = ld(w, (size_t)f * D + b);
+      Cx p = cmul(ld(M2, (size_t)a * D + b), wb);
+      r2.re += p.re;
+      r2.im += p.im;
+      if (mode == 0) {
+        Cx q = cmul(ld(m1 + (size_t)f * D * D * 2, (size_t)a * D + b), wb);
+        r1.re += q.re;
+        r1.im += q.im;
+      }
+    }
+    Cx t = cmulc(wa, r2);
+    den.re += t.re;
+    den.im += t.im;
+    if (mode == 0) {
+      Cx s = cmulc(wa, r1);
+      num.re += s.re;
+      num.im += s.im;
+    }
+  }
+  if (mode == 0) {
+    st(out, (size_t)f, cdiv(num, den));
+    return;
+  }
+  Cx proj{0.0, 0.0};  // w^H a
+  for (int c = 0; c < D; ++c) {
+    Cx p = cmulc(ld(w, (size_t)f * D + c), ld(atf, (size_t)f * D + c));
+    proj.re += p.re;
+    proj.im += p.im;
+  }
+  for (int a = 0; a < D; ++a) {
+    Cx r{0.0, 0.0};
+    for (int b = 0; b < D; ++b) {
+      Cx p = cmul(ld(M2, (size_t)a * D + b), ld(w, (size_t)f * D + b));
+      r.re += p.re;
+      r.im += p.im;
+    }
+    st(out, (size_t)f * D + a, cmul(cdiv(r, den), proj));
+  }
+}
+
+// zero_degree_normalization: v * exp(-j angle(v[..., ref]))              (beamformer.py:512-514)
+__global__ void zero_degree_kernel(const double* v, int64_t N, int D, int ref, double* out) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  Cx r = ld(v, (size_t)n * D + ref);
+  const double ang = -atan2(r.im, r.re);
+  const Cx rot{cos(ang), sin(ang)};
+  for (int d = 0; d < D; ++d) st(out, (size_t)n * D + d, cmul(ld(v, (size_t)n * D + d), rot));
+}
+
+// condition_covariance: (x + gamma tr(x)/D I) / (1 + gamma)              (beamformer.py:563-569)
+__global__ void condition_kernel(const double* x, int64_t N, int D, double gamma, double* out) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  Cx tr{0.0, 0.0};
+  for (int d = 0; d < D; ++d) {
+    Cx e = ld(x, ((size_t)n * D + d) * D + d);
+    tr.re += e.re;
+    tr.im += e.im;
+  }
+  const Cx sc{gamma * tr.re / D, gamma * tr.im / D};
+  const double inv = 1.0 + gamma;
+  for (int a = 0; a < D; ++a)
+    for (int b = 0; b < D; ++b) {
+      Cx e = ld(x, ((size_t)n * D + a) * D + b);
+      if (a == b) {
+        e.re += sc.re;
+        e.im += sc.im;
+      }
+      st(out, ((size_t)n * D + a) * D + b, Cx{e.re / inv, e.im / inv});
+    }
+}
+
+// apply_online_beamforming_vector: out[f,t] = sum_d conj(v[t,f,d]) mix[f,d,t]   (:586-598)
+template <typename YS>
+__global__ void apply_online_kernel(const double* v, const void* mixv, int64_t F, int T, int D,
+                                    double* out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t f = blockIdx.y;
+  if (t >= T) return;
+  const YS* mix = static_cast<const YS*>(mixv);
+  Cx s{0.0, 0.0};
+  for (int d = 0; d < D; ++d) {
+    const size_t mi = ((size_t)f * D + d) * T + t;
+    Cx m{(double)mix[2 * mi], (double)mix[2 * mi + 1]};
+    Cx p = cmulc(ld(v, ((size_t)t * F + f) * D + d), m);
+    s.re += p.re;
+    s.im += p.im;
+  }
+  st(out, (size_t)f * T + t, s);
+}
+
+inline int ok_or_hip() { return hipGetLastError() == hipSuccess ? PBBSS_OK : PBBSS_ERR_HIP; }
+inline unsigned blocks(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
+
+}  // namespace
+
+int launch_lcmv(const double* atf, const double* response, const double* noise, int64_t F, int D,
+                int K, double* w, int32_t* st, hipStream_t s) {
+  if (K < 1 || K > D) return PBBSS_ERR_INVALID_ARG;
+#define PBBSS_LCMV_CASE(DD)                                                                     \
+  case DD:                                                                                      \
+    hipLaunchKernelGGL(lcmv_kernel<DD>, dim3(blocks(F, kLaWaves)), dim3(kLaThreads), 0, s, atf, \
+                       response, noise, F, K, w, st);                                           \
+    break;
+  switch (D) {
+    PBBSS_LCMV_CASE(2) PBBSS_LCMV_CASE(3) PBBSS_LCMV_CASE(4) PBBSS_LCMV_CASE(5)
+    PBBSS_LCMV_CASE(6) PBBSS_LCMV_CASE(7) PBBSS_LCMV_CASE(8)
+    default: return PBBSS_ERR_UNSUPPORTED;
+  }
+#undef PBBSS_LCMV_CASE
+  return ok_or_hip();
+}
+
+int launch_phase_correction(const double* v, int64_t lead, int64_t rest, int F, int D, int two_d,
+                            double* scratch_u, double* out, hipStream_t s) {
+  // v (lead, rest, F, D); two_d: lead = rest = 1.  F == 1: plain copy.
+  const int64_t M = lead * rest;
+  if (hipMemcpyAsync(out, v, (size_t)M * F * D * 16, hipMemcpyDeviceToDevice, s) != hipSuccess)
+    return PBBSS_ERR_HIP;
+  if (F < 2) return PBBSS_OK;
+  hipLaunchKernelGGL(phase_unit_kernel, dim3(blocks(M * (F - 1), 256)), dim3(256), 0, s, v, M, F,
+                     D, scratch_u);
+  const int64_t L = two_d ? (F - 1) : lead;
+  const int64_t R = two_d ? 1 : rest * (F - 1);
+  hipLaunchKernelGGL(phase_scan_kernel, dim3(blocks(R, 64)), dim3(64), 0, s, v, scratch_u, L, R,
+                     F, D, two_d, out);
+  return ok_or_hip();
+}
+
+int launch_bf_quadratic(int mode, const double* w, const double* m1, const double* m2,
+                        const double* atf, int64_t F, int D, double* out, hipStream_t s) {
+  hipLaunchKernelGGL(bf_quadratic_kernel, dim3(blocks(F, 64)), dim3(64), 0, s, mode, w, m1, m2,
+                     atf, F, D, out);
+  return ok_or_hip();
+}
+
+int launch_zero_degree(const double* v, int64_t N, int D, int ref, double* out, hipStream_t s) {
+  hipLaunchKernelGGL(zero_degree_kernel, dim3(blocks(N, 256)), dim3(256), 0, s, v, N, D, ref, out);
+  return ok_or_hip();
+}
+
+int launch_condition_covariance(const double* x, int64_t N, int D, double gamma, double* out,
+                                hipStream_t s) {
+  hipLaunchKernelGGL(condition_kernel, dim3(blocks(N, 64)), dim3(64), 0, s, x, N, D, gamma, out);
+  return ok_or_hip();
+}
+
+int launch_apply_online(const double* v, const void* mix, int mix_is_c128, int64_t F, int T, int D,
+                        double* out, hipStream_t s) {
+  if (F > 65535) return PBBSS_ERR_UNSUPPORTED;
+  dim3 grid(blocks(T, 256), (unsigned)F);
+  if (mix_is_c128)
+    hipLaunchKernelGGL(apply_online_kernel<double>, grid, dim3(256), 0, s, v, mix, F, T, D, out);
+  else
+    hipLaunchKernelGGL(apply_online_kernel<float>, grid, dim3(256), 0, s, v, mix, F, T, D, out);
+  return ok_or_hip();
+}
+
+}  // namespace pbbss

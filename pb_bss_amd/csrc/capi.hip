@@ -753,3 +753,70 @@ PBBSS_API int pbbss_joint_fit(pbbss_handle_t h, const void* observation, const v
   }
   return PBBSS_OK;
 }
+
+// ---------------------------------------------------------------------------
+// N4: remaining beamformer family (bf_extra.hip)
+// ---------------------------------------------------------------------------
+PBBSS_API int pbbss_lcmv(pbbss_handle_t h, const void* atf, const void* response,
+                         const void* noise, int64_t F, int D, int K, void* out_w,
+                         int32_t* out_status, void* stream) {
+  if (!h || !atf || !response || !noise || !out_w || F <= 0) return PBBSS_ERR_INVALID_ARG;
+  return pbbss::launch_lcmv(static_cast<const double*>(atf), static_cast<const double*>(response),
+                            static_cast<const double*>(noise), F, D, K,
+                            static_cast<double*>(out_w), out_status, as_stream(stream));
+}
+
+PBBSS_API int pbbss_phase_correction(pbbss_handle_t h, const void* vector, int64_t lead,
+                                     int64_t rest, int F, int D, int two_d, void* scratch,
+                                     void* out, void* stream) {
+  if (!h || !vector || !out || lead <= 0 || rest <= 0 || F <= 0 || D <= 0)
+    return PBBSS_ERR_INVALID_ARG;
+  if (F > 1 && !scratch) return PBBSS_ERR_INVALID_ARG;
+  if (two_d && (lead != 1 || rest != 1)) return PBBSS_ERR_INVALID_ARG;
+  return pbbss::launch_phase_correction(static_cast<const double*>(vector), lead, rest, F, D,
+                                        two_d, static_cast<double*>(scratch),
+                                        static_cast<double*>(out), as_stream(stream));
+}
+
+PBBSS_API int pbbss_snr_postfilter(pbbss_handle_t h, const void* w, const void* target,
+                                   const void* noise, int64_t F, int D, void* out, void* stream) {
+  if (!h || !w || !target || !noise || !out || F <= 0 || D <= 0) return PBBSS_ERR_INVALID_ARG;
+  return pbbss::launch_bf_quadratic(0, static_cast<const double*>(w),
+                                    static_cast<const double*>(target),
+                                    static_cast<const double*>(noise), nullptr, F, D,
+                                    static_cast<double*>(out), as_stream(stream));
+}
+
+PBBSS_API int pbbss_distortionless_normalization(pbbss_handle_t h, const void* w, const void* atf,
+                                                 const void* noise, int64_t F, int D, void* out,
+                                                 void* stream) {
+  if (!h || !w || !atf || !noise || !out || F <= 0 || D <= 0) return PBBSS_ERR_INVALID_ARG;
+  return pbbss::launch_bf_quadratic(1, static_cast<const double*>(w), nullptr,
+                                    static_cast<const double*>(noise),
+                                    static_cast<const double*>(atf), F, D,
+                                    static_cast<double*>(out), as_stream(stream));
+}
+
+PBBSS_API int pbbss_zero_degree_normalization(pbbss_handle_t h, const void* vector, int64_t N,
+                                              int D, int reference_channel, void* out,
+                                              void* stream) {
+  if (!h || !vector || !out || N <= 0 || D <= 0) return PBBSS_ERR_INVALID_ARG;
+  if (reference_channel < 0 || reference_channel >= D) return PBBSS_ERR_INVALID_ARG;
+  return pbbss::launch_zero_degree(static_cast<const double*>(vector), N, D, reference_channel,
+                                   static_cast<double*>(out), as_stream(stream));
+}
+
+PBBSS_API int pbbss_condition_covariance(pbbss_handle_t h, const void* x, int64_t N, int D,
+                                         double gamma, void* out, void* stream) {
+  if (!h || !x || !out || N <= 0 || D <= 0) return PBBSS_ERR_INVALID_ARG;
+  return pbbss::launch_condition_covariance(static_cast<const double*>(x), N, D, gamma,
+                                            static_cast<double*>(out), as_stream(stream));
+}
+
+PBBSS_API int pbbss_apply_online_beamforming_vector(pbbss_handle_t h, const void* vector,
+                                                    const void* mix, int mix_is_c128, int64_t F,
+                                                    int T, int D, void* out, void* stream) {
+  if (!h || !vector || !mix || !out || F <= 0 || T <= 0 || D <= 0) return PBBSS_ERR_INVALID_ARG;
+  return pbbss::launch_apply_online(static_cast<const double*>(vector), mix, mix_is_c128, F, T, D,
+                                    static_cast<double*>(out), as_stream(stream));
+}

@@ -514,3 +514,89 @@ def joint_fit(observation, embedding, K, kind, *, gamma0=None, model=None, itera
         _status_raise_em(status, 'joint model fit')
     return dict(eigvec=eigvec, eigval=eigval, weight=weight, mean=mean, scale=scale,
                 status=status, affiliation=aff)
+
+
+# ---- N4: remaining beamformer family ------------------------------------------
+def lcmv(atf, response, noise):
+    """pbbss_lcmv.  atf (K,F,D), response (K), noise (F,D,D) c128 -> w (F,D), status (F)."""
+    t = _t()
+    K, F, D = atf.shape
+    w = t.empty((F, D), dtype=t.complex128, device=atf.device)
+    st = t.zeros((F,), dtype=t.int32, device=atf.device)
+    rc = _lib.load().pbbss_lcmv(_lib.handle(atf.device.index), _lib.ptr(atf), _lib.ptr(response),
+                                _lib.ptr(noise), F, D, K, _lib.ptr(w), _lib.ptr(st),
+                                _lib.stream_ptr(atf.device.index))
+    _lib.check(rc, f'lcmv(K={K},F={F},D={D})')
+    return w, st
+
+
+def phase_correction(vector):
+    """pbbss_phase_correction.  vector (..., F, D) c128 contiguous."""
+    t = _t()
+    F, D = vector.shape[-2:]
+    two_d = vector.ndim == 2
+    lead = 1 if two_d else vector.shape[0]
+    rest = 1 if two_d else int(np.prod(vector.shape[1:-2], dtype=np.int64))
+    out = t.empty_like(vector)
+    scratch = t.empty((max(lead * rest * (F - 1), 1),), dtype=t.complex128, device=vector.device)
+    rc = _lib.load().pbbss_phase_correction(
+        _lib.handle(vector.device.index), _lib.ptr(vector), lead, rest, F, D, int(two_d),
+        _lib.ptr(scratch), _lib.ptr(out), _lib.stream_ptr(vector.device.index))
+    _lib.check(rc, f'phase_correction(shape={tuple(vector.shape)})')
+    return out
+
+
+def snr_postfilter(w, target, noise):
+    t = _t()
+    F, D = w.shape
+    out = t.empty((F,), dtype=t.complex128, device=w.device)
+    rc = _lib.load().pbbss_snr_postfilter(_lib.handle(w.device.index), _lib.ptr(w),
+                                          _lib.ptr(target), _lib.ptr(noise), F, D, _lib.ptr(out),
+                                          _lib.stream_ptr(w.device.index))
+    _lib.check(rc, f'snr_postfilter(F={F},D={D})')
+    return out
+
+
+def distortionless_normalization(w, atf, noise):
+    t = _t()
+    F, D = w.shape
+    out = t.empty((F, D), dtype=t.complex128, device=w.device)
+    rc = _lib.load().pbbss_distortionless_normalization(
+        _lib.handle(w.device.index), _lib.ptr(w), _lib.ptr(atf), _lib.ptr(noise), F, D,
+        _lib.ptr(out), _lib.stream_ptr(w.device.index))
+    _lib.check(rc, f'distortionless_normalization(F={F},D={D})')
+    return out
+
+
+def zero_degree_normalization(vector, reference_channel):
+    t = _t()
+    N, D = vector.shape
+    out = t.empty_like(vector)
+    rc = _lib.load().pbbss_zero_degree_normalization(
+        _lib.handle(vector.device.index), _lib.ptr(vector), N, D, int(reference_channel) % D,
+        _lib.ptr(out), _lib.stream_ptr(vector.device.index))
+    _lib.check(rc, f'zero_degree_normalization(N={N},D={D})')
+    return out
+
+
+def condition_covariance(x, gamma):
+    t = _t()
+    N, D, _ = x.shape
+    out = t.empty_like(x)
+    rc = _lib.load().pbbss_condition_covariance(_lib.handle(x.device.index), _lib.ptr(x), N, D,
+                                                float(gamma), _lib.ptr(out),
+                                                _lib.stream_ptr(x.device.index))
+    _lib.check(rc, f'condition_covariance(N={N},D={D})')
+    return out
+
+
+def apply_online_bf(vector, mix):
+    """pbbss_apply_online_beamforming_vector.  vector (T,F,D) c128, mix (F,D,T) c64/c128."""
+    t = _t()
+    T, F, D = vector.shape
+    out = t.empty((F, T), dtype=t.complex128, device=mix.device)
+    rc = _lib.load().pbbss_apply_online_beamforming_vector(
+        _lib.handle(mix.device.index), _lib.ptr(vector), _lib.ptr(mix),
+        int(mix.dtype == t.complex128), F, T, D, _lib.ptr(out), _lib.stream_ptr(mix.device.index))
+    _lib.check(rc, f'apply_online_bf(T={T},F={F},D={D})')
+    return out

@@ -2,6 +2,16 @@
 (reference: pb_bss/extraction/__init__.py)."""
 from .beamformer import (
     apply_beamforming_vector,
+    apply_online_beamforming_vector,
+    condition_covariance,
+    distortionless_normalization,
+    get_lcmv_vector,
+    get_lcmv_vector_souden,
+    get_mvdr_vector_merl,
+    get_pca,
+    mvdr_snr_postfilter,
+    phase_correction,
+    zero_degree_normalization,
     blind_analytic_normalization,
     get_gev_vector,
     get_mvdr_vector,
@@ -19,5 +29,8 @@ __all__ = [
     'get_mvdr_vector', 'get_pca_vector', 'get_gev_vector',
     'blind_analytic_normalization', 'apply_beamforming_vector',
     'get_optimal_reference_channel', 'stable_solve', 'get_bf_vector',
-    'get_wmwf_vector',
+    'get_wmwf_vector', 'get_pca', 'get_mvdr_vector_merl', 'get_lcmv_vector',
+    'get_lcmv_vector_souden', 'distortionless_normalization', 'mvdr_snr_postfilter',
+    'zero_degree_normalization', 'phase_correction', 'condition_covariance',
+    'apply_online_beamforming_vector',
 ]

@@ -15,6 +15,9 @@ __all__ = [
     'get_mvdr_vector', 'get_pca_vector', 'get_gev_vector',
     'blind_analytic_normalization', 'apply_beamforming_vector',
     'get_optimal_reference_channel', 'stable_solve', 'get_wmwf_vector',
+    'get_pca', 'get_mvdr_vector_merl', 'get_lcmv_vector', 'get_lcmv_vector_souden',
+    'distortionless_normalization', 'mvdr_snr_postfilter', 'zero_degree_normalization',
+    'phase_correction', 'condition_covariance', 'apply_online_beamforming_vector',
 ]
 
 
@@ -280,3 +283,120 @@ def get_wmwf_vector(target_psd_matrix, noise_psd_matrix, reference_channel=None,
             _lib.to_host(num), _lib.to_host(den), np.finfo(np.float64).tiny)
     assert np.isscalar(reference_channel), reference_channel
     return _res(filt[..., reference_channel], like_torch)
+
+
+# ---- remaining members of the family -----------------------
+def get_pca(target_psd_matrix, return_all_vecs=False):
+    """All principal components and eigenvalues, or the dominant pair.
+    Reference: beamformer.py:163-194."""
+    like_torch = _lib.is_torch(target_psd_matrix)
+    a = _c128(target_psd_matrix)
+    *lead, D, _ = a.shape
+    val, vec, st = engine.heev(a.reshape(-1, D, D).contiguous())
+    if int(st.max().item()) != 0:
+        raise np.linalg.LinAlgError('Eigenvalues did not converge')
+    if return_all_vecs:
+        return _res(vec.reshape(*lead, D, D), like_torch), _res(val.reshape(*lead, D), like_torch)
+    return (_res(vec[:, :, -1].reshape(*lead, D), like_torch),
+            _res(val[:, -1].reshape(*lead), like_torch))
+
+
+def get_mvdr_vector_merl(target_psd_matrix, noise_psd_matrix):
+    """MVDR variant of MERL TR2016-072: h = G / tr G with G = Phi_nn^-1 Phi_xx, reference
+    channel maximising the post-SNR summed over frequency.  Reference: beamformer.py:263-289.
+    The filter is the mu = 0 case of the wMWF kernel (complex trace, no floor)."""
+    like_torch = _lib.is_torch(target_psd_matrix)
+    tp = _c128(target_psd_matrix)
+    nn = _c128(noise_psd_matrix)
+    D = tp.shape[-1]
+    mat, num, den, st = engine.wmwf(tp.reshape(-1, D, D).contiguous(),
+                                    nn.expand(tp.shape).reshape(-1, D, D).contiguous(), 0.0, False)
+    if int(st.max().item()) != 0:
+        raise np.linalg.LinAlgError('Singular matrix')  # np.linalg.solve (:276)
+    nom = _lib.to_host(num).sum(axis=0)
+    denom = _lib.to_host(den).sum(axis=0)
+    h_idx = int(np.argmax(nom / denom))
+    return _res(mat.reshape(*tp.shape)[..., h_idx], like_torch)
+
+
+def get_lcmv_vector(atf_vectors, response_vector, noise_psd_matrix):
+    """LCMV beamformer.  atf_vectors (targets, bins, sensors); response_vector (targets,),
+    e.g. [1, 0, ..., 0]; noise_psd_matrix (bins, sensors, sensors) -> (bins, sensors).
+    Reference: beamformer.py:414-456."""
+    like_torch = _lib.is_torch(atf_vectors)
+    atf = _c128(atf_vectors).contiguous()
+    K, F, D = atf.shape
+    nn = _c128(noise_psd_matrix).contiguous()
+    assert tuple(nn.shape) == (F, D, D), nn.shape
+    resp = _c128(np.asarray(response_vector) if not _lib.is_torch(response_vector)
+                 else response_vector).to(atf.device).contiguous()
+    assert tuple(resp.shape) == (K,), resp.shape
+    w, _ = engine.lcmv(atf, resp, nn)
+    return _res(w, like_torch)
+
+
+def get_lcmv_vector_souden(target_psd_matrix, interference_psd_matrix, noise_psd_matrix,
+                           ref_channel=None, eps=None, return_ref_channel=False):
+    """Not available, exactly as in the reference (beamformer.py:756-786)."""
+    raise NotImplementedError(
+        'This is not yet thoroughly tested. It also misses the response vector,'
+        'thus it is unclear, how to select, which speaker to attend to.')
+
+
+def distortionless_normalization(vector, atf_vector, noise_psd_matrix):
+    """(Phi w w^H / (w^H Phi w)) a per bin.  Reference: beamformer.py:491-499."""
+    like_torch = _lib.is_torch(vector)
+    w = _c128(vector).contiguous()
+    return _res(engine.distortionless_normalization(
+        w, _c128(atf_vector).to(w.device).contiguous(),
+        _c128(noise_psd_matrix).to(w.device).contiguous()), like_torch)
+
+
+def mvdr_snr_postfilter(vector, target_psd_matrix, noise_psd_matrix):
+    """(w^H Phi_xx w) / (w^H Phi_nn w), shape (bins, 1).  Reference: beamformer.py:502-509."""
+    like_torch = _lib.is_torch(vector)
+    w = _c128(vector).contiguous()
+    out = engine.snr_postfilter(w, _c128(target_psd_matrix).to(w.device).contiguous(),
+                                _c128(noise_psd_matrix).to(w.device).contiguous())
+    return _res(out[:, None], like_torch)
+
+
+def zero_degree_normalization(vector, reference_channel):
+    """Rotate every vector so that its reference channel is real and non-negative.
+    Reference: beamformer.py:512-514."""
+    like_torch = _lib.is_torch(vector)
+    v = _c128(vector)
+    D = v.shape[-1]
+    out = engine.zero_degree_normalization(v.reshape(-1, D).contiguous(), reference_channel)
+    return _res(out.reshape(v.shape), like_torch)
+
+
+def phase_correction(vector):
+    """Phase correction to reduce distortions due to phase inconsistencies between
+    neighbouring bins.  vector (..., bins, sensors).  Reference: beamformer.py:517-560 (the
+    vectorised form, whose running product follows axis 0 of the phasor array)."""
+    like_torch = _lib.is_torch(vector)
+    v = _c128(vector).contiguous()
+    assert v.ndim >= 2, v.shape
+    return _res(engine.phase_correction(v), like_torch)
+
+
+def condition_covariance(x, gamma):
+    """(x + gamma tr(x)/D I) / (1 + gamma).  Reference: beamformer.py:563-569."""
+    like_torch = _lib.is_torch(x)
+    a = _c128(x)
+    D = a.shape[-1]
+    out = engine.condition_covariance(a.reshape(-1, D, D).contiguous(), gamma)
+    return _res(out.reshape(a.shape), like_torch)
+
+
+def apply_online_beamforming_vector(vector, mix):
+    """Time-dependent beamforming vectors: vector (frames, bins, sensors), mix
+    (bins, sensors, frames) -> (bins, frames).  Reference: beamformer.py:586-598."""
+    like_torch = _lib.is_torch(mix)
+    x = _obs(mix).contiguous()
+    v = _c128(vector).to(x.device).contiguous()
+    assert v.ndim == 3 and x.ndim == 3, (v.shape, x.shape)
+    T, F, D = v.shape
+    assert tuple(x.shape) == (F, D, T), (v.shape, x.shape)
+    return _res(engine.apply_online_bf(v, x), like_torch)

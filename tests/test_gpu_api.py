@@ -1,6 +1,7 @@
 """GPU: behaviour tests of the drop-in API, modelled on the reference's own
 test-suite (tests/test_distribution/test_cacgmm.py, tests/test_extraction/*)."""
 import itertools
+import os
 
 import numpy as np
 import pytest
@@ -267,3 +268,75 @@ def test_more_classes(K, D):
     ref = oc.em_fit(Y128, init, iterations=5)
     assert np.abs(m.weight - ref['weight']).max() < 1e-10
     assert np.abs(m.predict(Y) - oc.em_predict(ref, Y128)).max() < 1e-8
+
+
+# ---- N4: the rest of the beamformer family (bf_extra.hip) ----------------------
+def _extra():
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden',
+                                'beamformer_extra_f19_d5.npz'))
+
+
+def test_lcmv_matches_reference_and_constraints():
+    from pb_bss_amd import extraction as ex
+    g = _extra()
+    for resp, key in (([1, 0], 'lcmv_10'), ([0, 1], 'lcmv_01')):
+        w = ex.get_lcmv_vector(g['atf'], resp, g['noise'])
+        assert w.shape == g[key].shape
+        np.testing.assert_allclose(w, g[key], rtol=1e-9, atol=1e-11)
+        # the constraints H^H w = response hold per bin
+        got = np.einsum('kfd,fd->fk', g['atf'].conj(), w)
+        np.testing.assert_allclose(got, np.broadcast_to(np.array(resp, dtype=complex), got.shape),
+                                   atol=1e-9)
+    # K = D and D = 8 also run (padding-free and full-width paths)
+    rng = np.random.default_rng(3)
+    for K, D in ((3, 3), (2, 8), (8, 8)):
+        from oracle import beamformer as ob
+        atf = rng.standard_normal((K, 7, D)) + 1j * rng.standard_normal((K, 7, D))
+        a = rng.standard_normal((7, D, 2 * D)) + 1j * rng.standard_normal((7, D, 2 * D))
+        noise = a @ a.conj().swapaxes(-1, -2)
+        resp = np.zeros(K)
+        resp[K - 1] = 1
+        np.testing.assert_allclose(ex.get_lcmv_vector(atf, resp, noise), ob.lcmv(atf, resp, noise),
+                                   rtol=1e-7, atol=1e-9)
+
+
+def test_lcmv_rank_deficient_noise_takes_least_squares_branch():
+    from pb_bss_amd import extraction as ex
+    g = _extra()
+    w = ex.get_lcmv_vector(g['atf'], [1, 0], g['noise_sing'])
+    ok = np.ones(19, dtype=bool)
+    ok[4] = False
+    np.testing.assert_allclose(w[ok], g['lcmv_sing'][ok], rtol=1e-9, atol=1e-11)
+    assert np.isfinite(w[4]).all()
+
+
+def test_remaining_beamformer_functions_match_reference():
+    from pb_bss_amd import extraction as ex
+    g = _extra()
+    at = dict(rtol=1e-10, atol=1e-11)
+    np.testing.assert_allclose(ex.get_mvdr_vector_merl(g['target'], g['noise']), g['merl'], **at)
+    np.testing.assert_allclose(ex.distortionless_normalization(g['w'], g['atf'][0], g['noise']),
+                               g['distortionless'], **at)
+    pf = ex.mvdr_snr_postfilter(g['w'], g['target'], g['noise'])
+    assert pf.shape == (19, 1)
+    np.testing.assert_allclose(pf, g['postfilter'], **at)
+    np.testing.assert_allclose(ex.zero_degree_normalization(g['wb'], 2), g['zero_degree'], **at)
+    np.testing.assert_allclose(ex.phase_correction(g['w']), g['phase_2d'], **at)
+    np.testing.assert_allclose(ex.phase_correction(g['wb']), g['phase_3d'], **at)
+    np.testing.assert_allclose(ex.condition_covariance(g['target'], 0.05), g['conditioned'], **at)
+    out = ex.apply_online_beamforming_vector(g['vt'], g['mix'])
+    assert out.shape == (19, 40)
+    np.testing.assert_allclose(out, g['online'], rtol=1e-10, atol=1e-10)
+    vec, val = ex.get_pca(g['target'], return_all_vecs=True)
+    np.testing.assert_allclose(val, g['pca_all_val'], rtol=1e-10)
+    cs = np.abs(np.einsum('fdk,fdk->fk', vec.conj(), g['pca_all_vec']))
+    np.testing.assert_allclose(cs, 1.0, atol=1e-9)
+    vec1, val1 = ex.get_pca(g['target'])
+    np.testing.assert_allclose(val1, g['pca_val'], rtol=1e-10)
+    # doctest of phase_correction (beamformer.py:529-540): input untouched, result all ones
+    w = np.array([[1, 1], [-1, -1]], dtype=np.complex128)
+    np.testing.assert_allclose(ex.phase_correction(w), np.ones((2, 2)), atol=1e-14)
+    np.testing.assert_allclose(ex.phase_correction([w])[0], np.ones((2, 2)), atol=1e-14)
+    assert w[1, 0] == -1
+    with pytest.raises(NotImplementedError):
+        ex.get_lcmv_vector_souden(g['target'], g['target'], g['noise'])
