@@ -53,6 +53,28 @@ def parse():
     return p.parse_args()
 
 
+def pmc_traffic():
+    """HBM bytes per launch (main + concurrent split kernel) from the committed rocprofv3 PMC
+    passes of this same command (tools/profile_round.sh -> profiles/rNN_x_profile.txt):
+    (FETCH_SIZE + WRITE_SIZE) KiB.  PMC passes cannot run inside the timed bench, so the
+    figure is read back from the newest committed summary; None if there is none."""
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)),
+                                          'profiles', 'r*_profile.txt')))
+    if not files:
+        return None, None
+    kib = 0.0
+    for line in open(files[-1]):
+        parts = [x.strip() for x in line.split('|')]
+        if len(parts) == 4 and parts[1] in ('FETCH_SIZE', 'WRITE_SIZE'):
+            kib += float(parts[3])
+    if kib == 0.0:
+        return None, None
+    return kib * 1024.0, ('profiles/' + os.path.basename(files[-1]) +
+                          ': FETCH_SIZE + WRITE_SIZE of both kernels, separate --pmc passes; '
+                          '8-byte-per-lane loads, FETCH_SIZE not rescaled')
+
+
 def main():
     args = parse()
     import torch
@@ -139,6 +161,8 @@ def main():
         achieved = alg_bytes / avg_kernel_s / 1e9
         flops = FLOPS_PER_FRAME_ITER * (world * n_loc) * T * args.iters
         tflops = flops / avg_kernel_s / 1e12
+        traffic, traffic_src = (pmc_traffic() if (world == 1 and args.iters == 100)
+                                else (None, None))
         out = {
             'metric': 'cACGMM EM iterations/sec on F=513,T=500,D=8,K=3',
             'value': value,
@@ -156,7 +180,8 @@ def main():
             },
             'roofline': {
                 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                'traffic_source': traffic_src,
                 'kernel': 'cacgmm_em_kernel<8,3,float,false> (+ concurrent cacgmm_em_split_kernel for '
                           'the remainder bins; kernel_ms brackets both)',
                 'kernel_ms': avg_kernel_s * 1e3,

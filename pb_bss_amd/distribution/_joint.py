@@ -14,9 +14,9 @@ def weight_mode(weight_constant_axis):
     """gcacgmm.py:158-162: axes refer to the (F, K, T) affiliation."""
     if isinstance(weight_constant_axis, int):
         weight_constant_axis = (weight_constant_axis,)
-    axes = tuple(sorted(a % 3 - 3 for a in weight_constant_axis))
-    if -2 in axes:
+    if -2 in weight_constant_axis:  # the literal test of gcacgmm.py:288: (-3, -2, -1) -> 1/K
         return _lib.JOINT_WEIGHT_UNIFORM
+    axes = tuple(sorted(a % 3 - 3 for a in weight_constant_axis))
     try:
         return {(-1,): _lib.JOINT_WEIGHT_FK, (-3, -1): _lib.JOINT_WEIGHT_K,
                 (-3,): _lib.JOINT_WEIGHT_KT, (-3, -2, -1): _lib.JOINT_WEIGHT_CONST}[axes]

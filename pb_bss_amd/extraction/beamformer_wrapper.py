@@ -74,10 +74,36 @@ def _rank_1_approximation(atf_type, target_psd_matrix, noise_psd_matrix, **atf_k
     return _rank_one(_match(target_psd_matrix, a), a)
 
 
+# filter stage -> (device function, needs the noise PSD, may be preceded by a rank-1 stage)
+_FILTER_STAGE = {
+    'mvdr_souden': (get_mvdr_vector_souden, True),
+    'gev': (get_gev_vector, True),
+    'wmwf': (get_wmwf_vector, True),
+}
+_ATF_STAGE = ('pca', 'scaled_gev_atf')       # '<atf>+mvdr'
+_RANK1_STAGE = ('rank1_pca', 'rank1_gev')    # '<rank1>+<filter>'
+
+
+def _parse(core):
+    """'pca' | 'ch<N>' | '<atf>+mvdr' | ['<rank1>+']<filter>  ->  (kind, pre-stage, filter)."""
+    parts = core.split('+')
+    if parts == ['pca']:
+        return 'pca', None, None
+    if len(parts) == 1 and 'ch' in core and core[2:].isdigit():
+        return 'channel', int(core[2:]), None
+    if len(parts) == 2 and parts[1] == 'mvdr' and parts[0] in _ATF_STAGE:
+        return 'atf_mvdr', parts[0], None
+    if parts[-1] in _FILTER_STAGE and (
+            len(parts) == 1 or (len(parts) == 2 and parts[0] in _RANK1_STAGE)):
+        return 'filter', parts[0] if len(parts) == 2 else None, parts[-1]
+    return None, None, None
+
+
 def get_bf_vector(beamformer, target_psd_matrix, noise_psd_matrix=None, **bf_kwargs):
-    """Light wrapper to obtain a beamforming vector, e.g. 'mvdr_souden',
-    'gev+ban', 'rank1_gev+mvdr_souden+ban'.  Steps are separated by '+';
-    options for the ATF / rank-1 step go in bf_kwargs['atf_kwargs']."""
+    """Light wrapper to obtain a beamforming vector from a '+'-separated recipe, e.g.
+    'mvdr_souden', 'gev+ban', 'rank1_gev+mvdr_souden+ban', 'scaled_gev_atf+mvdr', 'ch0'
+    (reference: beamformer_wrapper.py:117-236).  Options of the ATF / rank-1 stage go in
+    bf_kwargs['atf_kwargs'], everything else to the filter stage."""
     assert 'lcmv' not in beamformer, (
         'Since the LCMV beamformer and its variants sufficiently differ from '
         'all other beamforming approaches, we provide a separate wrapper '
@@ -86,46 +112,29 @@ def get_bf_vector(beamformer, target_psd_matrix, noise_psd_matrix=None, **bf_kwa
     assert isinstance(beamformer, str), beamformer
     ban = beamformer.endswith('+ban')
     core = beamformer[:-len('+ban')] if ban else beamformer
-
-    if core == 'pca':
-        w = get_pca_vector(target_psd_matrix, **bf_kwargs)
-    elif core in ['pca+mvdr', 'scaled_gev_atf+mvdr']:
-        atf, _ = core.split('+')
-        atf_vector = _atf_vector(atf, target_psd_matrix, noise_psd_matrix,
-                                 **bf_kwargs.pop('atf_kwargs', {}))
-        w = get_mvdr_vector(atf_vector, noise_psd_matrix)
-    elif core in ['mvdr_souden', 'rank1_pca+mvdr_souden', 'rank1_gev+mvdr_souden']:
-        if core != 'mvdr_souden':
-            rank1_type, _ = core.split('+')
-            target_psd_matrix = _rank_1_approximation(
-                rank1_type, target_psd_matrix, noise_psd_matrix,
-                **bf_kwargs.pop('atf_kwargs', {}))
-        w = get_mvdr_vector_souden(target_psd_matrix, noise_psd_matrix, **bf_kwargs)
-    elif core in ['gev', 'rank1_pca+gev', 'rank1_gev+gev']:
-        if core != 'gev':
-            rank1_type, _ = core.split('+')
-            target_psd_matrix = _rank_1_approximation(
-                rank1_type, target_psd_matrix, noise_psd_matrix,
-                **bf_kwargs.pop('atf_kwargs', {}))
-        w = get_gev_vector(target_psd_matrix, noise_psd_matrix, **bf_kwargs)
-    elif core in ['wmwf', 'rank1_pca+wmwf', 'rank1_gev+wmwf']:
-        if core != 'wmwf':
-            rank1_type, _ = core.split('+')
-            target_psd_matrix = _rank_1_approximation(
-                rank1_type, target_psd_matrix, noise_psd_matrix,
-                **bf_kwargs.pop('atf_kwargs', {}))
-        w = get_wmwf_vector(target_psd_matrix, noise_psd_matrix, **bf_kwargs)
-    elif 'ch' in core and core[2:].isdigit():
-        D = target_psd_matrix.shape[-1]
-        w = np.zeros(D)
-        w[int(core[2:])] = 1
-        w = np.broadcast_to(w, tuple(target_psd_matrix.shape[:-1]))
-        if _lib.is_torch(target_psd_matrix):
-            w = _lib.to_device(np.ascontiguousarray(w))
-    else:
+    kind, pre, filt = _parse(core)
+    if kind is None:
         raise ValueError(
             f'Could not find implementation for {core}.\n'
             f'Original call contained {beamformer}.')
+    if kind == 'pca':
+        w = get_pca_vector(target_psd_matrix, **bf_kwargs)
+    elif kind == 'channel':
+        D = target_psd_matrix.shape[-1]
+        w = np.zeros(D)
+        w[pre] = 1
+        w = np.broadcast_to(w, tuple(target_psd_matrix.shape[:-1]))
+        if _lib.is_torch(target_psd_matrix):
+            w = _lib.to_device(np.ascontiguousarray(w))
+    elif kind == 'atf_mvdr':
+        atf = _atf_vector(pre, target_psd_matrix, noise_psd_matrix,
+                          **bf_kwargs.pop('atf_kwargs', {}))
+        w = get_mvdr_vector(atf, noise_psd_matrix)
+    else:
+        if pre is not None:
+            target_psd_matrix = _rank_1_approximation(
+                pre, target_psd_matrix, noise_psd_matrix, **bf_kwargs.pop('atf_kwargs', {}))
+        w = _FILTER_STAGE[filt][0](target_psd_matrix, noise_psd_matrix, **bf_kwargs)
     if ban:
         w = blind_analytic_normalization(w, noise_psd_matrix)
     return w

@@ -143,6 +143,8 @@ def test_joint_models_match_reference(name, kind):
     ('gaussian', {}),
     ('gaussian', dict(weight_constant_axis=(-3, -2, -1), spectral_weight=0.5)),
     ('gaussian', dict(weight_constant_axis=(-2,))),
+    ('gaussian', dict(weight_constant_axis=(0, 1, 2))),
+    ('gaussian', dict(weight_constant_axis=(-3,), inline_permutation_alignment=True)),
     ('vmf', dict(weight_constant_axis=(-3, -1), max_concentration=80.)),
 ])
 def test_joint_models_config5_shape_against_oracle(kind, kw):

@@ -67,3 +67,33 @@ def test_synth_is_deterministic():
     assert (a[0] == b[0]).all() and (a[1] == b[1]).all()
     assert a[0].dtype == np.complex64 and a[1].dtype == np.float64
     assert np.allclose(a[1].sum(axis=1), 1)
+
+
+def test_beamformer_recipe_parser():
+    """get_bf_vector's recipe grammar (reference dispatch: beamformer_wrapper.py:160-226)."""
+    from pb_bss_amd.extraction.beamformer_wrapper import _parse
+    assert _parse('pca') == ('pca', None, None)
+    assert _parse('ch3') == ('channel', 3, None)
+    assert _parse('pca+mvdr') == ('atf_mvdr', 'pca', None)
+    assert _parse('scaled_gev_atf+mvdr') == ('atf_mvdr', 'scaled_gev_atf', None)
+    for f in ('mvdr_souden', 'gev', 'wmwf'):
+        assert _parse(f) == ('filter', None, f)
+        for r in ('rank1_pca', 'rank1_gev'):
+            assert _parse(f'{r}+{f}') == ('filter', r, f)
+    for bad in ('nonsense', 'rank1_pca+mvdr', 'gev+mvdr', 'pca+gev', 'chx', 'mvdr', 'rank1_foo+gev'):
+        assert _parse(bad)[0] is None, bad
+
+
+def test_joint_weight_mode_mapping():
+    """weight_constant_axis of the joint models (gcacgmm.py:158-162) -> PBBSS_JOINT_WEIGHT_*."""
+    from pb_bss_amd import _lib
+    from pb_bss_amd.distribution import _joint
+    assert _joint.weight_mode((-1,)) == _lib.JOINT_WEIGHT_FK
+    assert _joint.weight_mode((2,)) == _lib.JOINT_WEIGHT_FK
+    assert _joint.weight_mode((-3, -1)) == _lib.JOINT_WEIGHT_K
+    assert _joint.weight_mode((-3,)) == _lib.JOINT_WEIGHT_KT
+    # the reference tests `-2 in weight_constant_axis` literally (gcacgmm.py:288)
+    assert _joint.weight_mode((-3, -2, -1)) == _lib.JOINT_WEIGHT_UNIFORM
+    assert _joint.weight_mode((0, 1, 2)) == _lib.JOINT_WEIGHT_CONST
+    assert _joint.weight_mode((-2,)) == _lib.JOINT_WEIGHT_UNIFORM
+    assert _joint.weight_mode((-2, -1)) == _lib.JOINT_WEIGHT_UNIFORM
