@@ -313,6 +313,23 @@ def beamformer_extra_cases():
           pca_all_vec=pca_all[0], pca_all_val=pca_all[1], pca_vec=pca_one[0], pca_val=pca_one[1])
 
 
+def sampler_cases():
+    """Seeded draws of the reference's host-side samplers (global NumPy RNG)."""
+    from pb_bss.distribution.cacgmm import sample_cacgmm
+    from pb_bss.distribution import ComplexAngularCentralGaussian
+    rng = np.random.default_rng(4)
+    a = rng.standard_normal((2, 3, 6)) + 1j * rng.standard_normal((2, 3, 6))
+    cov = a @ a.conj().swapaxes(-1, -2)
+    weight = np.array([0.3, 0.7])
+    np.random.seed(11)
+    x, labels = sample_cacgmm(50, weight, cov, return_label=True)
+    np.random.seed(12)
+    m = ComplexAngularCentralGaussian.from_covariance(cov[0].copy())
+    y = m.sample(size=(20,))
+    _save('sampler_draws', covariance=cov, weight=weight, x=x, labels=labels,
+          eigvec=m.covariance_eigenvectors, eigval=m.covariance_eigenvalues, y=y)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     refshim.load()
@@ -324,6 +341,7 @@ def main():
     cwmm_cases()
     embed_cases()
     beamformer_extra_cases()
+    sampler_cases()
 
 
 if __name__ == '__main__':

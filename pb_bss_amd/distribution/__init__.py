@@ -4,8 +4,9 @@ from .complex_angular_central_gaussian import (
     ComplexAngularCentralGaussian,
     ComplexAngularCentralGaussianTrainer,
     normalize_observation,
+    sample_complex_angular_central_gaussian,
 )
-from .cacgmm import CACGMM, CACGMMTrainer
+from .cacgmm import CACGMM, CACGMMTrainer, sample_cacgmm
 from .complex_watson import ComplexWatson, ComplexWatsonTrainer
 from .cwmm import CWMM, CWMMTrainer
 from .von_mises_fisher import VonMisesFisher, VonMisesFisherTrainer
@@ -21,5 +22,5 @@ __all__ = [
     'VMFCACGMM', 'VMFCACGMMTrainer',
     'ComplexWatson', 'ComplexWatsonTrainer',
     'ComplexAngularCentralGaussian', 'ComplexAngularCentralGaussianTrainer',
-    'normalize_observation',
+    'normalize_observation', 'sample_cacgmm', 'sample_complex_angular_central_gaussian',
 ]

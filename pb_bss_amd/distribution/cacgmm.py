@@ -33,7 +33,34 @@ from .mixture_model_utils import (
 )
 from .utils import _ProbabilisticModel, as_result
 
-__all__ = ['CACGMM', 'CACGMMTrainer', 'normalize_observation']
+__all__ = ['CACGMM', 'CACGMMTrainer', 'normalize_observation', 'sample_cacgmm']
+
+
+def sample_cacgmm(size, weight, covariance, return_label=False):
+    """`size` draws from a cACG mixture with class probabilities `weight` (K,) and class
+    covariances (K, D, D); host-side test-data utility on the global NumPy RNG (labels
+    first, then the classes in order).  Reference: cacgmm.py:27-55."""
+    from .complex_angular_central_gaussian import sample_complex_angular_central_gaussian
+    weight = np.asarray(weight)
+    covariance = np.asarray(covariance)
+    assert weight.ndim == 1, weight
+    assert isinstance(size, int), size
+    assert covariance.ndim == 3, covariance.shape
+    num_classes, = weight.shape
+    D = covariance.shape[-1]
+    assert covariance.shape == (num_classes, D, D), (covariance.shape, num_classes, D)
+    labels = np.random.choice(range(num_classes), size=size, p=weight)
+    x = np.zeros((size, D), dtype=np.complex128)
+    for k in range(num_classes):
+        # the reference samples from the eigen-normalised model (from_covariance, :49-52):
+        # the direction distribution only depends on the covariance up to scale, but the
+        # Cholesky factor (and with it the exact draws) does not -- restate that scaling.
+        lam, vec = np.linalg.eigh(covariance[k])
+        lam = lam / np.maximum(np.amax(lam, axis=-1, keepdims=True), np.finfo(lam.dtype).tiny)
+        cov_k = (vec * lam[..., None, :]) @ vec.conj().T
+        x[labels == k, :] = sample_complex_angular_central_gaussian(
+            size=(int(np.sum(labels == k)),), covariance=cov_k)
+    return (x, labels) if return_label else x
 
 
 def _weight_for_predict(weight, indep, K, N, device):

@@ -15,6 +15,7 @@ __all__ = [
     'ComplexAngularCentralGaussian',
     'ComplexAngularCentralGaussianTrainer',
     'normalize_observation',
+    'sample_complex_angular_central_gaussian',
 ]
 
 
@@ -37,6 +38,24 @@ def normalize_observation(observation):
     *indep, N, D = y.shape
     out = engine.normalize_observation(y.reshape(-1, N, D))
     return as_result(out.reshape(*indep, D, N), like_torch)
+
+
+def sample_complex_angular_central_gaussian(size, covariance):
+    """Draw `size` unit vectors from a cACG: a circularly-symmetric complex Gaussian
+    sample with the given (D, D) covariance, projected to the unit sphere.  Host-side
+    test-data utility (global NumPy RNG, real parts drawn before imaginary parts, so a
+    seeded run reproduces the reference's draws).  Reference:
+    complex_angular_central_gaussian.py:58-65, complex_circular_symmetric_gaussian.py:47-69."""
+    covariance = np.asarray(_lib.to_host(covariance) if _lib.is_torch(covariance) else covariance)
+    if covariance.ndim > 2:
+        raise NotImplementedError(
+            "Not quite clear how the correct broadcasting would look like.")
+    D = covariance.shape[-1]
+    re = np.random.normal(size=(*size, D))
+    im = np.random.normal(size=(*size, D))
+    x = (re + 1j * im) / np.sqrt(2)
+    x = x @ np.linalg.cholesky(covariance).T
+    return x / np.linalg.norm(x, axis=-1, keepdims=True)
 
 
 def _broadcast_params(eigvec, eigval, indep, K):
@@ -102,6 +121,11 @@ class ComplexAngularCentralGaussian(_ProbabilisticModel):
             t = _lib.torch()
             return t.einsum('...wx,...x,...zx->...wz', v, lam.to(v.dtype), v.conj())
         return np.einsum('...wx,...x,...zx->...wz', v, lam, v.conj())
+
+    def sample(self, size):
+        """Reference :134-138."""
+        cov = self.covariance
+        return sample_complex_angular_central_gaussian(size=size, covariance=cov)
 
     @property
     def log_determinant(self):

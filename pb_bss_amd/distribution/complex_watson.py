@@ -51,6 +51,11 @@ class ComplexWatson(_ProbabilisticModel):
             conc = _lib.to_host(conc)
         return self.log_norm_1f1(conc, self.mode.shape[-1])
 
+    def pdf(self, y):
+        """exp(log_pdf(y)) (reference :61-71)."""
+        lp = self.log_pdf(y)
+        return lp.exp() if _lib.is_torch(lp) else np.exp(lp)
+
     def log_pdf(self, y):
         """y (..., N, D) unit norm -> (..., N) after broadcasting with the
         parameter axes; mixture models pass y[..., None, :, :] against

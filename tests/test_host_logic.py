@@ -97,3 +97,23 @@ def test_joint_weight_mode_mapping():
     assert _joint.weight_mode((0, 1, 2)) == _lib.JOINT_WEIGHT_CONST
     assert _joint.weight_mode((-2,)) == _lib.JOINT_WEIGHT_UNIFORM
     assert _joint.weight_mode((-2, -1)) == _lib.JOINT_WEIGHT_UNIFORM
+
+
+def test_host_samplers_reproduce_reference_draws():
+    """sample_cacgmm / ComplexAngularCentralGaussian.sample consume the global NumPy RNG in
+    the reference's order (cacgmm.py:27-55, complex_circular_symmetric_gaussian.py:47-69)."""
+    import os
+    from pb_bss_amd.distribution import ComplexAngularCentralGaussian, sample_cacgmm
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden',
+                             'sampler_draws.npz'))
+    np.random.seed(11)
+    x, labels = sample_cacgmm(50, g['weight'], g['covariance'], return_label=True)
+    np.testing.assert_array_equal(labels, g['labels'])
+    np.testing.assert_allclose(x, g['x'], atol=1e-12)
+    np.testing.assert_allclose(np.linalg.norm(x, axis=-1), 1.0, atol=1e-14)
+    np.random.seed(12)
+    m = ComplexAngularCentralGaussian(covariance_eigenvectors=g['eigvec'],
+                                      covariance_eigenvalues=g['eigval'])
+    y = m.sample(size=(20,))
+    assert y.shape == (20, 3)
+    np.testing.assert_allclose(y, g['y'], atol=1e-12)
