@@ -1,0 +1,97 @@
+"""GPU: error behaviour of the C ABI itself (include/pbbss.h): integer return codes, no
+exceptions or aborts across the boundary, handles can be created / destroyed repeatedly,
+and calls on separate handles from separate host threads do not interfere."""
+import ctypes
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _env():
+    import torch
+    from pb_bss_amd import _lib
+    lib = _lib.load()
+    return torch, _lib, lib, _lib.handle(0), _lib.stream_ptr(0)
+
+
+def test_invalid_arguments_return_codes_not_crashes():
+    torch, _lib, lib, h, stream = _env()
+    B, T, D, K = 3, 40, 4, 2
+    y = torch.zeros((B, T, D), dtype=torch.complex64, device='cuda')
+    g = torch.full((B, K, T), 0.5, dtype=torch.float64, device='cuda')
+    vec = torch.zeros((B, K, D, D), dtype=torch.complex128, device='cuda')
+    val = torch.zeros((B, K, D), dtype=torch.float64, device='cuda')
+    w = torch.zeros((B, K), dtype=torch.float64, device='cuda')
+    st = torch.zeros((B, K), dtype=torch.int32, device='cuda')
+    opts = _lib.EmOpts(iterations=2, covariance_norm=1, weight_mode=0, layout=0,
+                       affiliation_eps=1e-10, eigenvalue_floor=1e-10)
+
+    def fit(handle=h, yy=y, gg=g, KK=K, DD=D, o=opts, vv=vec):
+        return lib.pbbss_cacgmm_fit(handle, _lib.ptr(yy), B, T, DD, KK, _lib.ptr(gg), None, None,
+                                    None, None, None, ctypes.byref(o) if o else None, _lib.ptr(vv),
+                                    _lib.ptr(val), _lib.ptr(w), _lib.ptr(st), None, None, stream)
+    assert fit(handle=None) == _lib.ERR_INVALID_ARG
+    assert fit(yy=None) == _lib.ERR_INVALID_ARG
+    assert fit(o=None) == _lib.ERR_INVALID_ARG
+    assert fit(vv=None) == _lib.ERR_INVALID_ARG
+    assert fit(gg=None) == _lib.ERR_INVALID_ARG              # neither affiliations nor a model
+    assert fit(DD=9) == _lib.ERR_UNSUPPORTED
+    assert fit(KK=7) == _lib.ERR_UNSUPPORTED
+    bad = _lib.EmOpts(iterations=0, covariance_norm=1)
+    assert fit(o=bad) == _lib.ERR_INVALID_ARG                # cacgmm.py:200 asserts iterations > 0
+    bad = _lib.EmOpts(iterations=1, covariance_norm=7)
+    assert fit(o=bad) == _lib.ERR_INVALID_ARG
+    for code in (0, -1, -2, -3, -4, -99):
+        assert isinstance(lib.pbbss_error_string(code), bytes)
+    # embedding entry points: E > 256 and K > 6 are refused, not mis-executed
+    e = torch.zeros((1, 10, 300), dtype=torch.float32, device='cuda')
+    m = torch.zeros((1, 2, 300), dtype=torch.float64, device='cuda')
+    s = torch.ones((1, 2), dtype=torch.float64, device='cuda')
+    o = torch.zeros((1, 2, 10), dtype=torch.float64, device='cuda')
+    assert lib.pbbss_embed_log_pdf(h, _lib.ptr(e), 0, 1, 10, 300, 2, 0, _lib.ptr(m), _lib.ptr(s),
+                                   _lib.ptr(o), stream) == _lib.ERR_UNSUPPORTED
+    # LCMV needs K <= D
+    a = torch.zeros((3, 5, 2), dtype=torch.complex128, device='cuda')
+    assert lib.pbbss_lcmv(h, _lib.ptr(a), _lib.ptr(a), _lib.ptr(a), 5, 2, 3, _lib.ptr(a), None,
+                          stream) == _lib.ERR_INVALID_ARG
+    torch.cuda.synchronize()
+    assert fit() == _lib.OK                                   # the handle is still usable
+
+
+def test_joint_kernel_reports_lds_capacity_instead_of_spilling():
+    """the joint spatial+spectral step keeps the observation in LDS only"""
+    from oracle import synth
+    from pb_bss_amd import _lib
+    from pb_bss_amd.distribution import GCACGMMTrainer
+    Y, e, init = synth.make_joint(2, 4000, 8, 3, 4, seed=0)
+    with pytest.raises(_lib.PbbssError, match='LDS'):
+        GCACGMMTrainer().fit(Y, e, initialization=init, iterations=2)
+
+
+def test_handles_create_destroy_and_threads():
+    torch, _lib, lib, _, _ = _env()
+    for _ in range(20):
+        hh = ctypes.c_void_p()
+        assert lib.pbbss_create(ctypes.byref(hh), 0) == _lib.OK
+        assert lib.pbbss_destroy(hh) == _lib.OK
+    assert lib.pbbss_destroy(None) == _lib.ERR_INVALID_ARG
+    from oracle import synth
+    from pb_bss_amd.distribution import CACGMMTrainer
+    Y, init = synth.make_stft(40, 120, 4, 2, seed=1)
+    want = CACGMMTrainer().fit_predict(Y, initialization=init, iterations=10)
+    got, errs = {}, []
+
+    def work(i):
+        try:
+            got[i] = CACGMMTrainer().fit_predict(Y, initialization=init, iterations=10)
+        except Exception as exc:  # noqa: BLE001 - reported below
+            errs.append(exc)
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
+    for i in range(4):
+        assert np.array_equal(got[i], want)
