@@ -438,6 +438,10 @@ int pbbss_set_timing(pbbss_handle_t h, int enable);
  * full workgroup.  pbbss_split_error reads (synchronously) whether a bounded
  * inter-workgroup wait ever timed out (0 = never). */
 int pbbss_set_split_tail(pbbss_handle_t h, int enable);
+/* pbbss_dhtv_calculate_mapping: workgroups that share ONE utterance (team kernel, used for
+ * few utterances where a single workgroup is bound by one CU's L2 latency): 0 = automatic
+ * (default), 1 = always one workgroup per utterance, 2..32 = fixed team size. */
+int pbbss_set_dhtv_team(pbbss_handle_t h, int workgroups_per_utterance);
 int pbbss_split_error(pbbss_handle_t h, int* out_flag);
 /* Development aid: device buffer of 64 uint64 receiving per-phase shader-cycle sums
  * of the EM kernel ([wave 0..3][phase 0..7]); only written by library builds made

@@ -46,6 +46,7 @@ EXPORTS = (
     'pbbss_lcmv', 'pbbss_phase_correction', 'pbbss_snr_postfilter',
     'pbbss_distortionless_normalization', 'pbbss_zero_degree_normalization',
     'pbbss_condition_covariance', 'pbbss_apply_online_beamforming_vector',
+    'pbbss_set_dhtv_team',
 )
 
 EMBED_VMF = 0
@@ -135,6 +136,7 @@ def load():
         lib.pbbss_last_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
         lib.pbbss_set_phase_profile.argtypes = [vp, vp]
         lib.pbbss_set_split_tail.argtypes = [vp, i32]
+        lib.pbbss_set_dhtv_team.argtypes = [vp, i32]
         lib.pbbss_split_error.argtypes = [vp, ctypes.POINTER(ctypes.c_int)]
         lib.pbbss_dhtv_calculate_mapping.argtypes = [vp, vp, i64, i32, i32, i32, vp, i32, i32, vp, vp, vp, vp]
         lib.pbbss_apply_mapping.argtypes = [vp, vp, vp, i64, i32, i32, i32, vp, vp]

@@ -16,6 +16,9 @@ struct pbbss_handle_s {
   size_t scratch_bytes;
   void* work;         // second grow-only slab: workspaces of the multi-kernel mixture loops
   size_t work_bytes;
+  void* team_buf;     // control words + centroid partials of the DHTV team kernel
+  size_t team_bytes;
+  int dhtv_team;      // workgroups per utterance (0 = default, 1 = one-workgroup kernel)
   unsigned long long* prof;
   int timing;
   float last_ms;
@@ -140,6 +143,14 @@ PBBSS_API int pbbss_create(pbbss_handle_t* out, int device_id) {
   h->scratch_bytes = 0;
   h->work = nullptr;
   h->work_bytes = 0;
+  h->team_bytes = (size_t)4 << 20;
+  h->team_buf = nullptr;
+  if (hipMalloc(&h->team_buf, h->team_bytes) != hipSuccess) {
+    h->team_buf = nullptr;  // the one-workgroup kernel needs none
+    h->team_bytes = 0;
+  }
+  h->dhtv_team = 0;
+  if (const char* tv = getenv("PBBSS_DHTV_TEAM")) h->dhtv_team = atoi(tv);
   h->prof = nullptr;
   h->timing = 0;
   h->last_ms = 0.f;
@@ -157,6 +168,7 @@ PBBSS_API int pbbss_destroy(pbbss_handle_t h) {
   (void)hipEventDestroy(h->ev1);
   if (h->scratch) (void)hipFree(h->scratch);
   if (h->work) (void)hipFree(h->work);
+  if (h->team_buf) (void)hipFree(h->team_buf);
   if (h->cfg.xbuf) (void)hipFree(h->cfg.xbuf);
   if (h->cfg.side_stream) (void)hipStreamDestroy(h->cfg.side_stream);
   (void)hipEventDestroy(h->cfg.ev_fork);
@@ -180,6 +192,13 @@ PBBSS_API int pbbss_set_phase_profile(pbbss_handle_t h, void* dev_counters) {
 PBBSS_API int pbbss_set_split_tail(pbbss_handle_t h, int enable) {
   if (!h) return PBBSS_ERR_INVALID_ARG;
   h->cfg.allow_split = enable ? 1 : 0;
+  return PBBSS_OK;
+}
+
+PBBSS_API int pbbss_set_dhtv_team(pbbss_handle_t h, int workgroups_per_utterance) {
+  if (!h || workgroups_per_utterance < 0 || workgroups_per_utterance > pbbss::kDhtvTeamMax)
+    return PBBSS_ERR_INVALID_ARG;
+  h->dhtv_team = workgroups_per_utterance;
   return PBBSS_OK;
 }
 
@@ -407,7 +426,8 @@ PBBSS_API int pbbss_dhtv_calculate_mapping(pbbss_handle_t h, const double* mask,
   if (!h || !mask || !plan || !scratch || !out_mapping || !out_status) return PBBSS_ERR_INVALID_ARG;
   if (U <= 0 || F <= 0 || T <= 0 || P <= 0) return PBBSS_ERR_INVALID_ARG;
   return pbbss::launch_dhtv(mask, U, K, F, T, plan, P, optimal, scratch, out_mapping, out_status,
-                            h->cfg.lds_limit, as_stream(stream));
+                            h->cfg.lds_limit, h->cfg.num_cu, h->dhtv_team, h->team_buf,
+                            h->team_bytes, as_stream(stream));
 }
 
 PBBSS_API int pbbss_apply_mapping(pbbss_handle_t h, const double* mask, const int32_t* mapping,

@@ -50,6 +50,73 @@ __device__ __forceinline__ void nth_permutation(int n, int K, int* out) {
   }
 }
 
+// greedy / brute-force optimal assignment on the K x K score matrix (uniform across the wave)
+template <int K>
+__device__ __forceinline__ void assign_classes(double (&sc)[K][K], int optimal, int (&perm)[K]) {
+    if (!optimal) {
+      // greedy: repeatedly take the flat (row-major) argmax, first maximum wins (:537-553)
+      bool row_used[K], col_used[K];
+#pragma unroll
+      for (int a = 0; a < K; ++a) {
+        row_used[a] = false;
+        col_used[a] = false;
+        perm[a] = a;
+      }
+#pragma unroll
+      for (int r = 0; r < K; ++r) {
+        double best = 0.0;
+        int bi = -1, bj = -1;
+#pragma unroll
+        for (int a = 0; a < K; ++a)
+#pragma unroll
+          for (int b = 0; b < K; ++b) {
+            // masked entries are -inf in the reference: an unmasked one always
+            // wins the first comparison; among all-masked (cannot happen) none
+            bool ok = !row_used[a] && !col_used[b];
+            if (ok && (bi < 0 || sc[a][b] > best)) {
+              best = sc[a][b];
+              bi = a;
+              bj = b;
+            }
+          }
+#pragma unroll
+        for (int a = 0; a < K; ++a) {
+          if (a == bi) {
+            row_used[a] = true;
+            perm[a] = bj;
+          }
+          if (a == bj) col_used[a] = true;
+        }
+      }
+    } else {
+      // brute force over itertools.permutations order, strict improvement (:566-586)
+      int nperm = 1;
+      for (int i = 2; i <= K; ++i) nperm *= i;
+      double best = -1.79e308;
+#pragma unroll
+      for (int a = 0; a < K; ++a) perm[a] = a;
+      for (int n = 0; n < nperm; ++n) {
+        int p[kDhtvMaxK];
+        nth_permutation(n, K, p);
+        double v = 0.0;
+        for (int a = 0; a < K; ++a) {
+          double x = 0.0;
+#pragma unroll
+          for (int aa = 0; aa < K; ++aa)
+#pragma unroll
+            for (int bb = 0; bb < K; ++bb)
+              if (aa == a && bb == p[a]) x = sc[aa][bb];
+          v += x;
+        }
+        if (v > best) {
+          best = v;
+#pragma unroll
+          for (int a = 0; a < K; ++a) perm[a] = p[a];
+        }
+      }
+    }
+}
+
 template <int K>
 __global__ void __launch_bounds__(kDhtvThreads)
     dhtv_kernel(const double* __restrict__ mask, double* __restrict__ feat_all,
@@ -156,68 +223,7 @@ __global__ void __launch_bounds__(kDhtvThreads)
           }
         if (!finite) nonfinite = 1;  // reference: ValueError('score matrix is infeasible')
         int perm[K];
-        if (!optimal) {
-          // greedy: repeatedly take the flat (row-major) argmax, first maximum wins (:537-553)
-          bool row_used[K], col_used[K];
-#pragma unroll
-          for (int a = 0; a < K; ++a) {
-            row_used[a] = false;
-            col_used[a] = false;
-            perm[a] = a;
-          }
-#pragma unroll
-          for (int r = 0; r < K; ++r) {
-            double best = 0.0;
-            int bi = -1, bj = -1;
-#pragma unroll
-            for (int a = 0; a < K; ++a)
-#pragma unroll
-              for (int b = 0; b < K; ++b) {
-                // masked entries are -inf in the reference: an unmasked one always
-                // wins the first comparison; among all-masked (cannot happen) none
-                bool ok = !row_used[a] && !col_used[b];
-                if (ok && (bi < 0 || sc[a][b] > best)) {
-                  best = sc[a][b];
-                  bi = a;
-                  bj = b;
-                }
-              }
-#pragma unroll
-            for (int a = 0; a < K; ++a) {
-              if (a == bi) {
-                row_used[a] = true;
-                perm[a] = bj;
-              }
-              if (a == bj) col_used[a] = true;
-            }
-          }
-        } else {
-          // brute force over itertools.permutations order, strict improvement (:566-586)
-          int nperm = 1;
-          for (int i = 2; i <= K; ++i) nperm *= i;
-          double best = -1.79e308;
-#pragma unroll
-          for (int a = 0; a < K; ++a) perm[a] = a;
-          for (int n = 0; n < nperm; ++n) {
-            int p[kDhtvMaxK];
-            nth_permutation(n, K, p);
-            double v = 0.0;
-            for (int a = 0; a < K; ++a) {
-              double x = 0.0;
-#pragma unroll
-              for (int aa = 0; aa < K; ++aa)
-#pragma unroll
-                for (int bb = 0; bb < K; ++bb)
-                  if (aa == a && bb == p[a]) x = sc[aa][bb];
-              v += x;
-            }
-            if (v > best) {
-              best = v;
-#pragma unroll
-              for (int a = 0; a < K; ++a) perm[a] = p[a];
-            }
-          }
-        }
+        assign_classes<K>(sc, optimal, perm);
         bool ident = true;
 #pragma unroll
         for (int a = 0; a < K; ++a) ident = ident && (perm[a] == a);
@@ -262,6 +268,233 @@ __global__ void __launch_bounds__(kDhtvThreads)
   if (nonfinite && lane == 0) atomicOr(status + u, (int32_t)PBBSS_ST_NONFINITE);
 }
 
+// ---------------------------------------------------------------------------------------
+// Team variant for FEW utterances: the single-workgroup kernel above is bound by ONE compute
+// unit's L2 bandwidth and latency (2.8 ms for F=513, T=500, K=3 -- longer than the 100 EM
+// iterations that produced the masks).  Here G workgroups share one utterance:
+//   A  partial time centroids: workgroup (column block, bin chunk) sums its bins of the
+//      segment for 1024 (class, frame) columns -> partial buffer in L2
+//   -- team barrier --
+//      every workgroup adds the chunk partials in a fixed order into its LDS centroid and
+//      normalises it (redundantly: 12 KB, cheaper than another exchange)
+//   B  one wavefront per frequency bin of the segment: scores, assignment, row permutation
+//   -- team barrier (also carries the "something changed" flag) --
+// Cross-workgroup data (features, mapping, partials, flags) move with write-through (sc1)
+// stores and L1-bypassing (sc1) loads; the barrier is a monotonic agent-scope counter with a
+// bounded spin (cdna_hip_programming.md guideline 16, form R1) -- same protocol as the
+// split-bin EM groups.  Needs all G workgroups of an utterance co-resident: G <= 32.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ double ld_sc1(const double* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_sc1(double* p, double v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int ld_sc1(const int32_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_sc1(int32_t* p, int v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+constexpr unsigned kTeamSpinLimit = 20000000u;
+
+// ctrl: [0] barrier counter, [1] error word, [2], [3] "changed" flags by iteration parity
+__device__ __forceinline__ void team_barrier(unsigned* ctrl, unsigned& target, int G, int tid) {
+  target += (unsigned)G;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's sc1 stores have reached L2
+  __syncthreads();
+  if (tid == 0) {
+    __hip_atomic_fetch_add(ctrl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned spins = 0;
+    while (__hip_atomic_load(ctrl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(1);
+      // a timed-out wait is sticky: every later barrier of the team falls through at once
+      // (the result is reported as failed), so a lost workgroup can never hang the device
+      if ((spins & 1023u) == 1023u &&
+          __hip_atomic_load(ctrl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)
+        break;
+      if (++spins > kTeamSpinLimit) {
+        __hip_atomic_store(ctrl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+    }
+  }
+  __syncthreads();
+}
+
+template <int K>
+__global__ void __launch_bounds__(kDhtvThreads)
+    dhtv_team_kernel(const double* __restrict__ mask, double* feat_all, int32_t* mapping_all,
+                     const int32_t* __restrict__ plan, int P, int F, int T, int optimal,
+                     int32_t* status, int G, double* part_all, unsigned* ctrl_all) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* cent = reinterpret_cast<double*>(smem);  // [K][T]
+  double* red = cent + (size_t)K * T;              // [kDhtvWaves]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t u = blockIdx.x / G;
+  const int g = blockIdx.x % G;
+  const double* m = mask + u * (int64_t)K * F * T;
+  double* feat = feat_all + u * (int64_t)K * F * T;
+  int32_t* mapping = mapping_all + u * (int64_t)K * F;
+  const int KT = K * T;
+  const int ncb = (KT + kDhtvThreads - 1) / kDhtvThreads;  // column blocks
+  const int NCH = G / ncb > 0 ? G / ncb : 1;               // bin chunks (G >= ncb by launch)
+  double* part = part_all + u * (int64_t)NCH * KT;
+  unsigned* ctrl = ctrl_all + u * 4;
+  unsigned target = 0;
+
+  int nonfinite = 0;
+  for (int row = g * kDhtvWaves + wave; row < K * F; row += G * kDhtvWaves) {
+    const double* src = m + (int64_t)row * T;
+    double ss = 0.0;
+    for (int t = lane; t < T; t += kWave) {
+      double v = src[t];
+      ss += v * v;
+    }
+    ss = wave_sum(ss);
+    if (!isfinite(ss)) nonfinite = 1;
+    double inv = 1.0 / fmax(sqrt(ss), kTiny);
+    double* dst = feat + (int64_t)row * T;
+    for (int t = lane; t < T; t += kWave) st_sc1(dst + t, src[t] * inv);
+  }
+  if (g == 0)
+    for (int i = tid; i < K * F; i += kDhtvThreads) st_sc1(mapping + i, i / F);
+  team_barrier(ctrl, target, G, tid);
+
+  int itn = 0;  // global iteration counter (parity of the changed flag)
+  for (int seg = 0; seg < P; ++seg) {
+    const int iterations = plan[3 * seg], start = plan[3 * seg + 1], end = plan[3 * seg + 2];
+    const double inv_n = 1.0 / (double)(end - start);
+    const int L = (end - start + NCH - 1) / NCH;
+    for (int it = 0; it < iterations; ++it, ++itn) {
+      // ---- A: partial centroid of (column block cb, bin chunk c)
+      {
+        const int cb = g % ncb, c = g / ncb;
+        const int col = cb * kDhtvThreads + tid;
+        if (c < NCH && col < KT) {
+          const int k = col / T, t = col - k * T;
+          const int f0 = start + c * L, f1 = (f0 + L < end) ? f0 + L : end;
+          const double* p = feat + ((int64_t)k * F + f0) * T + t;
+          double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+          int f = f0;
+          for (; f + 8 <= f1; f += 8, p += 8 * (int64_t)T) {
+#pragma unroll
+            for (int x = 0; x < 8; ++x) s[x] += ld_sc1(p + x * (int64_t)T);
+          }
+          for (; f < f1; ++f, p += T) s[0] += ld_sc1(p);
+          st_sc1(part + (int64_t)c * KT + col,
+                 ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7])));
+        }
+      }
+      team_barrier(ctrl, target, G, tid);
+      if (g == 0 && tid == 0) st_sc1(reinterpret_cast<int32_t*>(ctrl + 2 + ((itn + 1) & 1)), 0);
+      // ---- centroid = ordered sum of the chunk partials, mean, unit norm per class
+      for (int col = tid; col < KT; col += kDhtvThreads) {
+        double sacc = 0.0;
+        for (int c = 0; c < NCH; ++c) sacc += ld_sc1(part + (int64_t)c * KT + col);
+        cent[col] = sacc * inv_n;
+      }
+      __syncthreads();
+      for (int k = 0; k < K; ++k) {
+        double ss = 0.0;
+        for (int t = tid; t < T; t += kDhtvThreads) {
+          double v = cent[k * T + t];
+          ss += v * v;
+        }
+        ss = block_sum(ss, red, tid);
+        double inv = 1.0 / fmax(sqrt(ss), kTiny);
+        for (int t = tid; t < T; t += kDhtvThreads) cent[k * T + t] *= inv;
+      }
+      __syncthreads();
+      // ---- B: one wavefront per bin
+      int changed = 0;
+      for (int f = start + g * kDhtvWaves + wave; f < end; f += G * kDhtvWaves) {
+        double sc[K][K];
+#pragma unroll
+        for (int a = 0; a < K; ++a)
+#pragma unroll
+          for (int b = 0; b < K; ++b) sc[a][b] = 0.0;
+        for (int t0 = lane; t0 < T; t0 += 4 * kWave) {
+          double fv[4][K], cv[4][K];
+#pragma unroll
+          for (int x = 0; x < 4; ++x) {
+            const int t = t0 + x * kWave;
+            const bool ok = t < T;
+            const int tc = ok ? t : lane;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+              double v = ld_sc1(feat + ((int64_t)k * F + f) * T + tc);
+              fv[x][k] = ok ? v : 0.0;
+              cv[x][k] = cent[k * T + tc];
+            }
+          }
+#pragma unroll
+          for (int x = 0; x < 4; ++x)
+#pragma unroll
+            for (int a = 0; a < K; ++a)
+#pragma unroll
+              for (int b = 0; b < K; ++b) sc[a][b] = fma(cv[x][a], fv[x][b], sc[a][b]);
+        }
+        bool finite = true;
+#pragma unroll
+        for (int a = 0; a < K; ++a)
+#pragma unroll
+          for (int b = 0; b < K; ++b) {
+            sc[a][b] = wave_sum(sc[a][b]);
+            finite = finite && isfinite(sc[a][b]);
+          }
+        if (!finite) nonfinite = 1;
+        int perm[K];
+        assign_classes<K>(sc, optimal, perm);
+        bool ident = true;
+#pragma unroll
+        for (int a = 0; a < K; ++a) ident = ident && (perm[a] == a);
+        if (!ident) {
+          changed = 1;
+          for (int t = lane; t < T; t += kWave) {
+            double v[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) v[k] = ld_sc1(feat + ((int64_t)k * F + f) * T + t);
+#pragma unroll
+            for (int a = 0; a < K; ++a) {
+              double x = v[0];
+#pragma unroll
+              for (int k = 1; k < K; ++k) x = (perm[a] == k) ? v[k] : x;
+              st_sc1(feat + ((int64_t)a * F + f) * T + t, x);
+            }
+          }
+          if (lane == 0) {
+            int mv[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) mv[k] = ld_sc1(mapping + k * F + f);
+#pragma unroll
+            for (int a = 0; a < K; ++a) {
+              int x = mv[0];
+#pragma unroll
+              for (int k = 1; k < K; ++k) x = (perm[a] == k) ? mv[k] : x;
+              st_sc1(mapping + a * F + f, x);
+            }
+          }
+        }
+      }
+      if (changed && lane == 0)
+        __hip_atomic_fetch_or(ctrl + 2 + (itn & 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      team_barrier(ctrl, target, G, tid);
+      const unsigned any =
+          __hip_atomic_load(ctrl + 2 + (itn & 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (!any) {
+        ++itn;
+        break;  // nothing_changed (:352-353)
+      }
+    }
+  }
+  const unsigned xerr = __hip_atomic_load(ctrl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if ((nonfinite || xerr) && lane == 0)
+    atomicOr(status + u, (int32_t)(nonfinite ? PBBSS_ST_NONFINITE : 0) |
+                             (int32_t)(xerr ? PBBSS_ST_EIG_NOCONV : 0));
+}
+
 // mask (U,K,F,T) gathered along the class axis: out[u,k,f,:] = mask[u,mapping[u,k,f],f,:]
 __global__ void __launch_bounds__(256)
     apply_mapping_kernel(const double* __restrict__ mask, const int32_t* __restrict__ mapping,
@@ -277,18 +510,44 @@ __global__ void __launch_bounds__(256)
 
 int launch_dhtv(const double* mask, int64_t U, int K, int F, int T, const int32_t* plan, int P,
                 int optimal, double* feat, int32_t* mapping, int32_t* status, size_t lds_limit,
-                hipStream_t s) {
+                int num_cu, int team_size, void* team_buf, size_t team_bytes, hipStream_t s) {
   if (K < 1 || K > kDhtvMaxK) return PBBSS_ERR_UNSUPPORTED;
   size_t lds = ((size_t)K * T + kDhtvWaves) * sizeof(double) + 16;
   if (lds > lds_limit) return PBBSS_ERR_LDS_CAPACITY;
+  // team size: all U * G workgroups must be co-resident (one 1024-thread workgroup per CU)
+  const int ncb = (K * T + kDhtvThreads - 1) / kDhtvThreads;
+  int G = team_size;
+  if (G <= 0) {  // default ~ 32 / sqrt(U): measured optimum 16 for 1..4 utterances, 8 for 16, 4 for 64
+    G = 16;
+    while (G > 2 && (int64_t)G * G * U > 1024) --G;
+  }
+  if (G > kDhtvTeamMax) G = kDhtvTeamMax;
+  if ((int64_t)G * U > num_cu) G = (int)(num_cu / U);
+  G = (G / ncb) * ncb;                                    // whole bin chunks per column block
+  const size_t ctrl_bytes = (size_t)U * 4 * sizeof(unsigned);
+  const size_t ctrl_pad = (ctrl_bytes + 255) & ~(size_t)255;
+  const size_t part_bytes = (size_t)U * (G > 0 ? G / ncb : 0) * K * T * sizeof(double);
+  const bool team = team_buf && G >= 2 * ncb && ctrl_pad + part_bytes <= team_bytes;
+  unsigned* ctrl = static_cast<unsigned*>(team_buf);
+  double* part = reinterpret_cast<double*>(static_cast<char*>(team_buf) + ctrl_pad);
+  if (team && hipMemsetAsync(ctrl, 0, ctrl_bytes, s) != hipSuccess) return PBBSS_ERR_HIP;
 #define PBBSS_DHTV_CASE(KK)                                                                     \
   case KK: {                                                                                    \
-    auto kfn = dhtv_kernel<KK>;                                                                 \
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                                 \
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
-      return PBBSS_ERR_HIP;                                                                     \
-    hipLaunchKernelGGL(kfn, dim3((unsigned)U), dim3(kDhtvThreads), lds, s, mask, feat, mapping, \
-                       plan, P, F, T, optimal, status);                                         \
+    if (team) {                                                                                 \
+      auto kfn = dhtv_team_kernel<KK>;                                                          \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                               \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+        return PBBSS_ERR_HIP;                                                                   \
+      hipLaunchKernelGGL(kfn, dim3((unsigned)(U * G)), dim3(kDhtvThreads), lds, s, mask, feat,  \
+                         mapping, plan, P, F, T, optimal, status, G, part, ctrl);               \
+    } else {                                                                                    \
+      auto kfn = dhtv_kernel<KK>;                                                               \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                               \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+        return PBBSS_ERR_HIP;                                                                   \
+      hipLaunchKernelGGL(kfn, dim3((unsigned)U), dim3(kDhtvThreads), lds, s, mask, feat,        \
+                         mapping, plan, P, F, T, optimal, status);                              \
+    }                                                                                           \
   } break;
   switch (K) {
     PBBSS_DHTV_CASE(1)

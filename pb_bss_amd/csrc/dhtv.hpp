@@ -5,9 +5,13 @@
 #include "pbbss.h"
 
 namespace pbbss {
+// team: for few utterances several workgroups share one utterance (dhtv_team_kernel);
+// team_buf = handle-owned device memory of team_bytes (control words + centroid partials),
+// null / too small / team_size <= 1 selects the one-workgroup-per-utterance kernel.
+constexpr int kDhtvTeamMax = 32;
 int launch_dhtv(const double* mask, int64_t U, int K, int F, int T, const int32_t* plan, int P,
                 int optimal, double* feat, int32_t* mapping, int32_t* status, size_t lds_limit,
-                hipStream_t s);
+                int num_cu, int team_size, void* team_buf, size_t team_bytes, hipStream_t s);
 int launch_apply_mapping(const double* mask, const int32_t* mapping, int64_t U, int K, int F,
                          int T, double* out, hipStream_t s);
 }  // namespace pbbss

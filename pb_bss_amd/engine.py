@@ -373,6 +373,12 @@ def set_split_tail(enable, device_index=None):
                'set_split_tail')
 
 
+def set_dhtv_team(workgroups_per_utterance, device_index=None):
+    """pbbss_set_dhtv_team: 0 automatic, 1 one workgroup per utterance, 2..32 fixed team."""
+    _lib.check(_lib.load().pbbss_set_dhtv_team(_lib.handle(device_index),
+                                               int(workgroups_per_utterance)), 'set_dhtv_team')
+
+
 def split_error(device_index=None):
     """pbbss_split_error: 1 if an inter-workgroup wait of a split launch ever timed out."""
     flag = ctypes.c_int()

@@ -65,3 +65,29 @@ def test_em_masks_align_end_to_end():
     solver = DHTVPermutationAlignment.from_stft_size(512)
     mapping = solver.calculate_mapping(kft)
     assert (mapping == op.dhtv_calculate_mapping(kft, solver.alignment_plan)).all()
+
+
+@pytest.mark.parametrize('K,F,T,stft', [(2, 257, 130, 512), (3, 513, 500, 1024), (4, 257, 300, 512)])
+def test_team_kernel_equals_single_workgroup_kernel_and_oracle(K, F, T, stft):
+    """few utterances: several workgroups share one utterance (pbbss_set_dhtv_team);
+    every team size must reproduce the one-workgroup kernel's mapping and the oracle's"""
+    from pb_bss_amd import engine
+    from pb_bss_amd.permutation_alignment import DHTVPermutationAlignment
+    from oracle import permutation_alignment as op
+    rng = np.random.default_rng(K * 100 + F)
+    act = rng.uniform(size=(2, K, 1, T)) ** 4
+    mask = act * rng.uniform(0.5, 1.0, size=(2, K, F, T)) + 0.05 * rng.uniform(size=(2, K, F, T))
+    mask /= mask.sum(1, keepdims=True)
+    for u in range(2):
+        for f in range(F):
+            mask[u, :, f] = mask[u, rng.permutation(K), f]
+    solver = DHTVPermutationAlignment.from_stft_size(stft)
+    want = np.stack([op.dhtv_calculate_mapping(mask[u], solver.alignment_plan) for u in range(2)])
+    try:
+        for team in (1, 2, 5, 16, 32, 0):
+            engine.set_dhtv_team(team)
+            got = solver.calculate_mapping(mask)
+            assert np.array_equal(got, want), team
+            assert np.array_equal(solver.calculate_mapping(mask[0]), want[0]), team
+    finally:
+        engine.set_dhtv_team(0)

@@ -17,7 +17,7 @@ perm = np.stack([rng.permutation(K) for _ in range(F)], 1)
 pm = mask[perm, range(F)]
 solver = DHTVPermutationAlignment.from_stft_size(1024)
 plan = _lib.to_device(np.asarray(solver.alignment_plan, np.int32))
-for U in (1, 16, 64):
+for U in (1, 2, 4, 8, 16, 64):
     m = _lib.to_device(np.broadcast_to(pm, (U, K, F, T)).copy())
     engine.dhtv_calculate_mapping(m, plan)
     torch.cuda.synchronize(); t0 = time.perf_counter()
