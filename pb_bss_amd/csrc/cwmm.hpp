@@ -216,8 +216,14 @@ struct WatsonKernel {
     }
   }
 
+  // (pvre, pvim): eigenvector matrix of this class from the previous EM iteration, kept in
+  // the registers of the wave that owns the class.  The covariance is rotated into that basis
+  // first (B = V'^H C V'), which is nearly diagonal once EM settles, so the cyclic Jacobi
+  // converges in fewer sweeps; V = V' W.  Same eigenpairs to rounding; the eigenvector phase
+  // is free and cancels in m m^H.  `warm` is false on the first iteration.
   static __device__ void factor_class(const WatsonArgs& wa, const Lds& L, int64_t b, int k,
-                                      int lane, bool last) {
+                                      int lane, bool last, bool warm, double& pvre,
+                                      double& pvim) {
     lane = opaque(lane);
     const EmArgs& a = wa.em;
     const LaneIJ c = lane_ij(lane);
@@ -252,8 +258,30 @@ struct WatsonKernel {
     int st = 0;
     if (wave_or((isfinite(are) && isfinite(aim)) ? 0 : 1)) st |= PBBSS_ST_NONFINITE;
     double vre, vim;
-    int sweeps = wave_jacobi_heev<D>(are, aim, c, vre, vim);
+    int sweeps;
+    if (warm && !(st & PBBSS_ST_NONFINITE)) {
+      double hre, him, tre, tim, bre, bim;
+      wave_adjoint(pvre, pvim, c, hre, him);               // V'^H
+      wave_matmul<D>(are, aim, pvre, pvim, c, tre, tim);   // C V'
+      wave_matmul<D>(hre, him, tre, tim, c, bre, bim);     // V'^H C V'
+      wave_adjoint(bre, bim, c, tre, tim);                 // re-symmetrise the rounding
+      bre = 0.5 * (bre + tre);
+      bim = 0.5 * (bim + tim);
+      if (!valid) {
+        bre = 0.0;
+        bim = 0.0;
+      }
+      double wre, wim;
+      sweeps = wave_jacobi_heev<D>(bre, bim, c, wre, wim);
+      wave_matmul<D>(pvre, pvim, wre, wim, c, vre, vim);   // V = V' W
+      are = bre;
+      aim = bim;
+    } else {
+      sweeps = wave_jacobi_heev<D>(are, aim, c, vre, vim);
+    }
     if (sweeps < 0) st |= PBBSS_ST_EIG_NOCONV;
+    pvre = valid ? vre : 0.0;
+    pvim = valid ? vim : 0.0;
     double lam = lane_get(are, ij_lane(c.j, c.j));
     int rank = wave_sort_rank<D>(lam, c);
     int col = 0;
@@ -321,6 +349,7 @@ struct WatsonKernel {
         phase_init_gamma(a, L, b, tid, wave, lane);
       }
       __syncthreads();
+      double pvre = 0.0, pvim = 0.0;  // previous eigenvectors of class `wave` (K <= 4 <= waves)
       for (int it = 0; it < a.iterations; ++it) {
         if (it > 0 || model_in) {
           phase_e<false>(wa, L, b, tid, wave, lane);
@@ -334,7 +363,8 @@ struct WatsonKernel {
         }
         __syncthreads();
         const bool last = (it == a.iterations - 1);
-        for (int k = wave; k < K; k += kEmWaves) factor_class(wa, L, b, k, lane, last);
+        static_assert(K <= kEmWaves, "one class per wave: the warm start lives in its registers");
+        if (wave < K) factor_class(wa, L, b, wave, lane, last, it > 0, pvre, pvim);
         __syncthreads();
       }
       if (tid < K) {

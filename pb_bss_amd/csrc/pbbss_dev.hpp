@@ -302,6 +302,18 @@ __device__ __forceinline__ double fast_rcp(double x) {
   return r;
 }
 
+// 1/sqrt(x) to ~1 ulp for finite normal x > 0: hardware estimate + two Newton steps
+// (y <- y + y * (0.5 - 0.5 x y^2)), no division, no IEEE sqrt sequence.
+__device__ __forceinline__ double fast_rsqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  const double hx = 0.5 * x;
+  double e = fma(-hx * y, y, 0.5);
+  y = fma(y, e, y);
+  e = fma(-hx * y, y, 0.5);
+  y = fma(y, e, y);
+  return y;
+}
+
 constexpr double kTiny = 2.2250738585072014e-308;  // np.finfo(np.float64).tiny
 
 }  // namespace pbbss

@@ -218,15 +218,21 @@ __device__ __forceinline__ int wave_jacobi_heev(double& are, double& aim, LaneIJ
       double g2 = xr * xr + xi * xi;
       double cs = 1.0, sur = 0.0, sui = 0.0;  // c, s*u (u = a_pq/|a_pq|)
       if (live && g2 > 0.0) {
-        double g = sqrt(g2);
-        double tau = (aqq - app) / (2.0 * g);
-        double t = 1.0 / (fabs(tau) + sqrt(1.0 + tau * tau));
-        t = (tau < 0.0) ? -t : t;
-        cs = 1.0 / sqrt(1.0 + t * t);
-        double s = t * cs;
-        double ig = s / g;
-        sur = xr * ig;
-        sui = xi * ig;
+        // Jacobi angle without sqrt/divide sequences: with d = a_qq - a_pp, g = |a_pq| and
+        // h = sqrt(d^2 + 4 g^2) the classical tau / t / c / s formulas reduce to
+        //   c^2 = (h + |d|) / (2 h),   s u = sign(d) a_pq / (h c)      (sign(0) = +1)
+        // i.e. two Newton-refined reciprocal square roots on the dependent path of a round.
+        const double d = aqq - app;
+        const double h2 = fma(d, d, 4.0 * g2);
+        if (h2 > 0.0 && h2 < 1.79e308) {
+          const double rh = fast_rsqrt(h2);
+          const double c2 = fma(0.5 * fabs(d), rh, 0.5);
+          const double rc = fast_rsqrt(c2);  // c2 in [0.5, 1]
+          cs = c2 * rc;
+          const double ig = ((d < 0.0) ? -rh : rh) * rc;
+          sur = xr * ig;
+          sui = xi * ig;
+        }
       }
       // parameters of the pair containing this lane's COLUMN index live on lane (j, j)
       double cc = lane_get(cs, ij_lane(c.j, c.j));
