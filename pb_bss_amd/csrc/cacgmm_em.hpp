@@ -830,6 +830,69 @@ struct EmKernel {
     for (int k = 0; k < K; ++k) q[k] = fmax(fabs(q[k] * inv), kTiny);
   }
 
+  // <A_k, P_t> for one frame with the operand pipelining of phase_e (A_k of chunk c+1 fetched
+  // from LDS before the FMAs of chunk c issue; compiler fences pin that order -- left alone
+  // hipcc front-loads all K*D*D broadcast reads of a pass and spills them).  Unscaled.
+  static __device__ __forceinline__ void quad_forms_pipelined(const Lds& L, const double (&re)[D],
+                                                              const double (&im)[D],
+                                                              double (&q)[K]) {
+    constexpr int NCH = (NOFF + kOperandChunk - 1) / kOperandChunk;
+    double op[2][kOperandChunk][K][2];
+    auto fetch = [&](auto cc, auto bb) {
+      constexpr int c = cc, bsel = bb;
+#pragma unroll
+      for (int x = 0; x < kOperandChunk; ++x) {
+        if (c * kOperandChunk + x < NOFF) {
+#pragma unroll
+          for (int k = 0; k < K; ++k) {
+            op[bsel][x][k][0] = L.apack[k * NA + D + 2 * (c * kOperandChunk + x)];
+            op[bsel][x][k][1] = L.apack[k * NA + D + 2 * (c * kOperandChunk + x) + 1];
+          }
+        }
+      }
+    };
+#pragma unroll
+    for (int k = 0; k < K; ++k) q[k] = 0.0;
+    if constexpr (NCH > 0) fetch(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+    asm volatile("" ::: "memory");
+    static_for<0, D>([&](auto ic) {
+      constexpr int i = ic;
+      double ad[K];
+#pragma unroll
+      for (int k = 0; k < K; ++k) ad[k] = L.apack[k * NA + i];
+      double dg = re[i] * re[i] + im[i] * im[i];
+#pragma unroll
+      for (int k = 0; k < K; ++k) q[k] = fma(ad[k], dg, q[k]);
+    });
+    static_for<0, NCH>([&](auto cc) {
+      constexpr int c = cc;
+      constexpr int cur = c & 1;
+      if constexpr (c + 1 < NCH) {
+        fetch(std::integral_constant<int, c + 1>{}, std::integral_constant<int, 1 - cur>{});
+      }
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<0, kOperandChunk>([&](auto xc) {
+        constexpr int x = xc;
+        constexpr int p = c * kOperandChunk + x;
+        if constexpr (p < NOFF) {
+          constexpr int i = tri_i<D>(p), j = tri_j<D>(p);
+          double pr = re[i] * re[j] + im[i] * im[j];
+          double pim = im[i] * re[j] - re[i] * im[j];
+#pragma unroll
+          for (int k = 0; k < K; ++k)
+            q[k] = fma(op[cur][x][k][0], pr, fma(op[cur][x][k][1], pim, q[k]));
+        }
+      });
+      // tie the partial sums to the fence: the FMAs are pure arithmetic, which instruction
+      // selection may otherwise sink below all later fences (then every prefetched operand
+      // is spilled until the arithmetic finally runs)
+#pragma unroll
+      for (int k = 0; k < K; ++k) asm volatile("" : "+v"(q[k])::"memory");
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  }
+
   // p-th permutation of (0..K-1) in lexicographic order (itertools.permutations order)
   static __device__ __forceinline__ void nth_permutation(int p, int (&perm)[K]) {
     int fact = 1;

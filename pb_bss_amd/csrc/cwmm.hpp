@@ -120,24 +120,7 @@ struct WatsonKernel {
       const int t = ok ? tt : a.T - 1;
       double re[D], im[D], q[K];
       Base::load_frame(L, t, re, im);
-#pragma unroll
-      for (int k = 0; k < K; ++k) q[k] = 0.0;
-      static_for<0, D>([&](auto ic) {
-        constexpr int i = ic;
-        double dg = re[i] * re[i] + im[i] * im[i];
-#pragma unroll
-        for (int k = 0; k < K; ++k) q[k] = fma(L.apack[k * NA + i], dg, q[k]);
-      });
-      static_for<0, Base::NOFF>([&](auto pc) {
-        constexpr int p = pc;
-        constexpr int i = tri_i<D>(p), j = tri_j<D>(p);
-        double pr = re[i] * re[j] + im[i] * im[j];
-        double pim = im[i] * re[j] - re[i] * im[j];
-#pragma unroll
-        for (int k = 0; k < K; ++k)
-          q[k] = fma(L.apack[k * NA + D + 2 * p], pr,
-                     fma(L.apack[k * NA + D + 2 * p + 1], pim, q[k]));
-      });
+      Base::quad_forms_pipelined(L, re, im, q);  // |m_k^H y|^2 = <m_k m_k^H, P_t>
       const double inv = L.inv_n2[t];
       double lp[K], mx = -1.79e308;
 #pragma unroll
