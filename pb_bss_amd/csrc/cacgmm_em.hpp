@@ -306,6 +306,10 @@ struct EmKernel {
     double s[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) s[k] = 0.0;
+    double jlogdet[K];  // ln det B_k of the joint (log-domain) E-step, once per phase
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+      jlogdet[k] = JOINT ? log(L.detm[k]) + (double)L.dete[k] * 0.6931471805599453 : 0.0;
     for (int t0 = 0; t0 < a.T; t0 += NF * kEmThreads) {
       int tt[NF];
       bool ok[NF];
@@ -403,7 +407,7 @@ struct EmKernel {
         for (int k = 0; k < K; ++k) {
           double qq = fmax(fabs(q[0][k] * inv), kTiny);  // cacg.py:185-199
           q[0][k] = qq;
-          lps[k] = -(double)D * log(qq) - (log(detm[k]) + (double)dete[k] * 0.6931471805599453);
+          lps[k] = -(double)D * log(qq) - jlogdet[k];
         }
 #pragma unroll
         for (int k = 0; k < K; ++k) {
