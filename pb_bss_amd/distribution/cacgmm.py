@@ -164,6 +164,7 @@ class CACGMMTrainer:
             affiliation_eps=1e-10,
             eigenvalue_floor=1e-10,
             inline_permutation_aligner=None,
+            _with_affiliation=False,
     ):
         """Same contract as the reference (cacgmm.py:142-280).
 
@@ -239,7 +240,7 @@ class CACGMMTrainer:
             return self._fit_fused(
                 y.reshape(-1, N, D), indep, K, gamma0, model, iterations, sal,
                 act, mode, covariance_norm, affiliation_eps, eigenvalue_floor,
-                hermitize, like_torch)
+                hermitize, like_torch, final_predict=_with_affiliation)
         return self._fit_stepwise(
             y.reshape(-1, N, D), indep, K, gamma0, model, iterations, saliency,
             sal, act, weight_constant_axis, covariance_norm, affiliation_eps,
@@ -386,5 +387,10 @@ class CACGMMTrainer:
             weight_constant_axis=weight_constant_axis, hermitize=hermitize,
             covariance_norm=covariance_norm, affiliation_eps=affiliation_eps,
             eigenvalue_floor=eigenvalue_floor,
-            inline_permutation_aligner=inline_permutation_aligner)
+            inline_permutation_aligner=inline_permutation_aligner,
+            _with_affiliation=True)
+        if isinstance(model, tuple):
+            # fused path: the kernel's final E-step IS model.predict(y) (new weights,
+            # affiliation_eps = 0, no activity mask) -- no second launch, no re-upload
+            return model[1]
         return model.predict(y)

@@ -18,7 +18,11 @@ def full():
     from pb_bss_amd.distribution import CACGMMTrainer
     Y, init = synth.make_stft(F, T, D, K, seed=0)
     model = CACGMMTrainer().fit(Y, initialization=init, iterations=100)
-    return Y, init, model, model.predict(Y)
+    masks = CACGMMTrainer().fit_predict(Y, initialization=init, iterations=100)
+    # fit_predict returns the kernel's own final E-step; model.predict rebuilds B^-1 from the
+    # returned (V, lambda) in a second launch: same numbers up to rounding
+    np.testing.assert_allclose(model.predict(Y), masks, atol=1e-12)
+    return Y, init, model, masks
 
 
 def test_posteriors_are_a_partition_of_unity(full):
