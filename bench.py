@@ -75,6 +75,29 @@ def pmc_traffic():
                           '8-byte-per-lane loads, FETCH_SIZE not rescaled')
 
 
+def pmc_sustained_clock_ghz():
+    """Shader clock the EM kernel actually ran at in the committed profile: the persistent
+    kernel keeps its waves resident for the whole launch, so SQ_WAVE_CYCLES (4-cycle units)
+    per wave over the kernel duration is the clock.  None without a profile."""
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)),
+                                          'profiles', 'r*_profile.txt')))
+    if not files:
+        return None
+    cyc = waves = us = None
+    for line in open(files[-1]):
+        parts = [x.strip() for x in line.split('|')]
+        if len(parts) == 4 and parts[0] == 'main' and parts[1] == 'SQ_WAVE_CYCLES':
+            cyc = float(parts[3])
+        if len(parts) == 4 and parts[0] == 'main' and parts[1] == 'SQ_WAVES':
+            waves = float(parts[3])
+        if len(parts) == 6 and 'cacgmm_em_kernel' in parts[0]:
+            us = float(parts[2])
+    if not (cyc and waves and us):
+        return None
+    return cyc * 4.0 / waves / (us * 1e3)
+
+
 def main():
     args = parse()
     import torch
@@ -163,6 +186,7 @@ def main():
         tflops = flops / avg_kernel_s / 1e12
         traffic, traffic_src = (pmc_traffic() if (world == 1 and args.iters == 100)
                                 else (None, None))
+        clock_ghz = pmc_sustained_clock_ghz()
         out = {
             'metric': 'cACGMM EM iterations/sec on F=513,T=500,D=8,K=3',
             'value': value,
@@ -190,7 +214,13 @@ def main():
                         'FP64 VALU, see fp64_valu',
                 'fp64_valu': {'achieved': tflops, 'peak': FP64_VALU_PEAK_TF, 'unit': 'TFLOP/s',
                               'frac': tflops / FP64_VALU_PEAK_TF,
-                              'flops_per_frame_iter': FLOPS_PER_FRAME_ITER},
+                              'flops_per_frame_iter': FLOPS_PER_FRAME_ITER,
+                              'sustained_clock_ghz': clock_ghz,
+                              'frac_at_sustained_clock': (
+                                  None if not clock_ghz else
+                                  tflops / (FP64_VALU_PEAK_TF * clock_ghz / 2.4)),
+                              'note': 'peak assumes 2.4 GHz; sustained_clock_ghz = SQ_WAVE_CYCLES '
+                                      'per resident wave / kernel time in the committed profile'},
             },
         }
         st = _lib.to_host(r['status'])
