@@ -9,7 +9,7 @@ EM iterations followed by the final E-step (fit_predict), with the complex64
 observation already resident in HBM.  At N GPUs the job is N utterances
 (weak scaling): every rank owns a contiguous block of ~513/N frequency bins of
 EVERY utterance, runs the EM with no collective in the loop, and the posterior
-masks are all-gathered over RCCL/xGMI at the end of each step (what
+masks are all-gathered over RCCL/xGMI at the end of each step (inside the timed region) (what
 permutation alignment needs).  value = N * iters * K / max-over-ranks time.
 
 The JSON line also carries
@@ -118,8 +118,6 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         dist.init_process_group('nccl', device_id=dev)
-    comm_stream = torch.cuda.Stream(device=dev) if use_dist else None
-    pending = []  # (event, gathered masks) of steps whose all-gather is still in flight
 
     # ---- workload: `world` utterances, this rank's block of bins of each ----
     lo, hi = shard_bounds(F, world, rank)
@@ -142,22 +140,16 @@ def main():
         ms = engine.last_kernel_ms(local_rank)  # HIP events on the launch stream
         masks = r['affiliation'].reshape(world, n_loc, K, T)
         if use_dist:
-            # the one exchange step of the path: all-gather the masks over RCCL/xGMI on
-            # a side stream, so the next step's EM kernel overlaps the collective
-            ready = torch.cuda.Event()
-            ready.record()
-            with torch.cuda.stream(comm_stream):
-                comm_stream.wait_event(ready)
-                masks = all_gather_bins(masks, F, bin_axis=1)
-                done = torch.cuda.Event()
-                done.record()
-            pending.append((done, masks, r['affiliation']))
-            while len(pending) > 2:  # keep at most two gathers in flight
-                pending.pop(0)[0].synchronize()
+            # the one exchange step of the path: all-gather the masks over RCCL/xGMI, in stream
+            # order after the EM kernel.  (Overlapping it with the NEXT step's EM on a side
+            # stream was measured to be slower: whatever occupies a CU while the persistent
+            # kernel's workgroups are being placed skews their distribution for the whole
+            # launch -- 1.71 -> 2.45 ms per EM kernel with one rank.)
+            masks = all_gather_bins(masks, F, bin_axis=1)
         return masks, ms, r
 
     def fence():
-        torch.cuda.synchronize()  # all streams of this device, incl. the gathers in flight
+        torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
@@ -200,7 +192,7 @@ def main():
                             'complex64 STFT resident in HBM, fit_predict',
                 'em_iterations_per_step': args.iters, 'utterances': world,
                 'sharding': (f'frequency bins, {n_loc} of {F} per rank per utterance; RCCL mask '
-                             'all-gather per step on a side stream') if use_dist else 'none (1 GPU)',
+                             'all-gather per step, in stream order after the EM kernel') if use_dist else 'none (1 GPU)',
             },
             'roofline': {
                 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
@@ -249,9 +241,22 @@ def main():
                           f'D=8 K=3, {args.cpu_iters} EM iterations, {dt:.1f} s; '
                           f'host has {os.cpu_count()} logical cores, einsum is single-threaded',
             }
-        print(json.dumps(out))
+        line = json.dumps(out)
+    else:
+        line = None
     if use_dist:
         dist.destroy_process_group()
+    if line is not None:
+        # RCCL writes a version banner through C stdio; when stdout is a pipe it sits in libc's
+        # buffer until exit and would land AFTER the JSON line: flush it out first, so that the
+        # result is the last line on stdout
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        sys.stdout.flush()
+        print(line, flush=True)
 
 
 if __name__ == '__main__':

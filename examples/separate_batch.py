@@ -21,7 +21,21 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def separate(Y, init, iterations, stft_size, group=None):
+def separate_by_utterance(Y, init, iterations, stft_size, group=None):
+    """Utterance-level data parallelism (preferable when U >= ranks): every rank
+    runs the whole chain on its own block of utterances with NO collective in between and the
+    results are all-gathered once at the end."""
+    import torch.distributed as dist
+    from pb_bss_amd.sharding import all_gather_bins, shard_bounds
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    U = Y.shape[0]
+    assert U >= world, (U, world)
+    lo, hi = shard_bounds(U, world, rank)
+    out = separate(Y[lo:hi], init[lo:hi], iterations, stft_size, group=None, sharded=False)
+    return {k: all_gather_bins(v.contiguous(), U, bin_axis=0, group=group) for k, v in out.items()}
+
+
+def separate(Y, init, iterations, stft_size, group=None, sharded=True):
     """Y (U, F, T, D) complex torch-CUDA or NumPy; init (U, F, K, T).
     Returns dict(masks (U, K, F, T) aligned, enhanced (U, K, F, T), mapping)."""
     import torch
@@ -35,7 +49,7 @@ def separate(Y, init, iterations, stft_size, group=None):
 
     Y = _lib.to_device(Y)
     init = _lib.to_device(init, torch.float64)
-    if dist.is_available() and dist.is_initialized():
+    if sharded and dist.is_available() and dist.is_initialized():
         masks = fit_predict_sharded(Y, init, iterations=iterations, bin_axis=-3, group=group)
     else:
         masks = CACGMMTrainer().fit_predict(Y, initialization=init, iterations=iterations)
@@ -52,7 +66,8 @@ def separate(Y, init, iterations, stft_size, group=None):
         noise = psd.sum(dim=-3) - target
         w = get_bf_vector('gev+ban', target, noise)                 # (U, F, D)
         enhanced.append(apply_beamforming_vector(w, X))             # (U, F, T)
-    return dict(masks=aligned, enhanced=torch.stack(enhanced, dim=1), mapping=mapping)
+    return dict(masks=aligned, enhanced=torch.stack(enhanced, dim=1),
+                mapping=_lib.to_device(mapping) if not _lib.is_torch(mapping) else mapping)
 
 
 def main():
@@ -63,6 +78,9 @@ def main():
     ap.add_argument('--T', type=int, default=500)
     ap.add_argument('--D', type=int, default=8)
     ap.add_argument('--K', type=int, default=3)
+    ap.add_argument('--shard', choices=['bins', 'utterances'], default='bins',
+                    help='multi-GPU: frequency bins of every utterance over the ranks (one mask '
+                         'all-gather), or whole utterances per rank (no collective until the end)')
     args = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -82,7 +100,10 @@ def main():
     separate(Yd[:1], initd[:1], 2, stft_size)  # warm-up
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    out = separate(Yd, initd, args.iterations, stft_size)
+    if use_dist and args.shard == 'utterances':
+        out = separate_by_utterance(Yd, initd, args.iterations, stft_size)
+    else:
+        out = separate(Yd, initd, args.iterations, stft_size)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if rank == 0:

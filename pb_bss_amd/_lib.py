@@ -125,6 +125,11 @@ def load():
                 f'{LIB_PATH} not found: build it with '
                 '`make -C pb_bss_amd/csrc -j8` (or __graft_entry__.build()). '
                 'There is no CPU fallback.')
+        # PyTorch ships its own copy of the HIP runtime (torch/lib/libamdhip64.so).  It must be
+        # mapped BEFORE this library is: the loader then resolves our libamdhip64.so.7 dependency
+        # to that same copy.  Loaded the other way round, the process ends up with two HIP/HSA
+        # runtimes and whichever initialises second reports "no ROCm-capable device".
+        import torch  # noqa: F401
         lib = ctypes.CDLL(LIB_PATH)
         vp, i32, i64, dbl = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double
         lib.pbbss_version.restype = ctypes.c_int

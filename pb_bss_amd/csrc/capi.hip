@@ -1,6 +1,7 @@
 // extern "C" boundary of libpbbss_hip.so (see include/pbbss.h).  Argument
 // validation, handle state, kernel dispatch; no numerical code lives here.
 #include "pbbss.h"
+#include <cstdio>
 #include <cstdlib>
 #include "beamform.hpp"
 #include "dhtv.hpp"
@@ -75,6 +76,29 @@ struct WorkCarver {
   }
 };
 
+// The split-bin groups must run CONCURRENTLY with the main EM launch.  HIP maps streams onto
+// a handful of hardware queues round-robin; a plain extra stream can land on the queue of the
+// caller's stream (observed after RCCL had created its own streams: the two launches then
+// serialise, 1.7 -> 2.4 ms).  A stream of a different (highest) priority lives on a separate
+// set of queues.
+bool make_side_stream(hipStream_t* out) {
+  const bool dbg = getenv("PBBSS_DEBUG") != nullptr;
+  int least = 0, greatest = 0;
+  hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+  if (dbg) fprintf(stderr, "pbbss: priority range rc=%d least=%d greatest=%d\n", (int)e, least, greatest);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    greatest = 0;
+  }
+  e = hipStreamCreateWithPriority(out, hipStreamNonBlocking, greatest);
+  if (dbg) fprintf(stderr, "pbbss: hipStreamCreateWithPriority rc=%d (%s)\n", (int)e, hipGetErrorString(e));
+  if (e == hipSuccess) return true;
+  (void)hipGetLastError();
+  e = hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+  if (dbg) fprintf(stderr, "pbbss: hipStreamCreateWithFlags rc=%d (%s)\n", (int)e, hipGetErrorString(e));
+  return e == hipSuccess;
+}
+
 struct TimedRegion {
   pbbss_handle_t h;
   hipStream_t s;
@@ -104,9 +128,14 @@ PBBSS_API const char* pbbss_error_string(int code) {
 
 PBBSS_API int pbbss_create(pbbss_handle_t* out, int device_id) {
   if (!out) return PBBSS_ERR_INVALID_ARG;
-  if (hipSetDevice(device_id) != hipSuccess) return PBBSS_ERR_HIP;
+  const bool dbg = getenv("PBBSS_DEBUG") != nullptr;
+  hipError_t e0 = hipSetDevice(device_id);
+  if (dbg) fprintf(stderr, "pbbss: hipSetDevice(%d) rc=%d (%s)\n", device_id, (int)e0, hipGetErrorString(e0));
+  if (e0 != hipSuccess) return PBBSS_ERR_HIP;
   hipDeviceProp_t prop;
-  if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return PBBSS_ERR_HIP;
+  e0 = hipGetDeviceProperties(&prop, device_id);
+  if (dbg) fprintf(stderr, "pbbss: hipGetDeviceProperties rc=%d (%s)\n", (int)e0, hipGetErrorString(e0));
+  if (e0 != hipSuccess) return PBBSS_ERR_HIP;
   pbbss_handle_t h = new pbbss_handle_s();
   h->device = device_id;
   h->cfg.num_cu = prop.multiProcessorCount;
@@ -131,7 +160,7 @@ PBBSS_API int pbbss_create(pbbss_handle_t* out, int device_id) {
   {
     void* xb = nullptr;
     if (hipMalloc(&xb, h->cfg.xbuf_bytes) != hipSuccess ||
-        hipStreamCreateWithFlags(&h->cfg.side_stream, hipStreamNonBlocking) != hipSuccess ||
+        !make_side_stream(&h->cfg.side_stream) ||
         hipEventCreateWithFlags(&h->cfg.ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->cfg.ev_join, hipEventDisableTiming) != hipSuccess) {
       delete h;

@@ -12,6 +12,11 @@ tests of the gather logic.
 F is generally not divisible by the world size (513 = 8*64 + 1): shards are
 contiguous blocks whose sizes differ by at most one; the gather pads every
 shard to the largest block and trims after the collective.
+
+The same helpers shard ANY independent axis: with whole utterances per rank
+(`bin_axis` = the utterance axis) nothing is exchanged until the final gather
+(examples/separate_batch.py --shard utterances), which is preferable once
+there are at least as many utterances as GPUs.
 """
 import numpy as np
 
