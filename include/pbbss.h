@@ -54,7 +54,14 @@ typedef struct pbbss_handle_s* pbbss_handle_t;
 int pbbss_version(void);
 const char* pbbss_error_string(int code);
 
-/* Bind a handle to HIP device `device_id`; queries CU count / LDS size. */
+/* Bind a handle to HIP device `device_id`; queries CU count / LDS size, allocates the small
+ * device-side control buffers and a highest-priority side stream (split-bin groups).
+ * Calling convention of every entry point below: `stream` is a hipStream_t of THAT device
+ * (NULL = the default stream) and that device is the calling thread's current device; all
+ * pointers are device pointers unless stated otherwise; calls only enqueue work (no host
+ * synchronisation) unless stated otherwise; one handle must not be used from two host
+ * threads at the same time (create one per thread, as pb_bss_amd/_lib.py does).  PBBSS_DEBUG
+ * in the environment makes pbbss_create report failing HIP calls on stderr. */
 int pbbss_create(pbbss_handle_t* out, int device_id);
 int pbbss_destroy(pbbss_handle_t h);
 
