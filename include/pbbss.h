@@ -57,7 +57,8 @@ const char* pbbss_error_string(int code);
 /* Bind a handle to HIP device `device_id`; queries CU count / LDS size, allocates the small
  * device-side control buffers and a highest-priority side stream (split-bin groups).
  * Calling convention of every entry point below: `stream` is a hipStream_t of THAT device
- * (NULL = the default stream) and that device is the calling thread's current device; all
+ * (NULL = the default stream); the library selects the handle's device for the duration of
+ * each call and restores the caller's selection; all
  * pointers are device pointers unless stated otherwise; calls only enqueue work (no host
  * synchronisation) unless stated otherwise; one handle must not be used from two host
  * threads at the same time (create one per thread, as pb_bss_amd/_lib.py does).  PBBSS_DEBUG

@@ -99,6 +99,24 @@ bool make_side_stream(hipStream_t* out) {
   return e == hipSuccess;
 }
 
+// Every entry point runs with the handle's device current (a caller holding tensors on several
+// GPUs in one process may have another one selected) and restores the caller's selection.
+struct DeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  explicit DeviceGuard(pbbss_handle_t h) {
+    if (!h) return;
+    if (hipGetDevice(&prev) != hipSuccess) {
+      (void)hipGetLastError();
+      return;
+    }
+    if (prev != h->device) switched = (hipSetDevice(h->device) == hipSuccess);
+  }
+  ~DeviceGuard() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+};
+
 struct TimedRegion {
   pbbss_handle_t h;
   hipStream_t s;
@@ -232,6 +250,7 @@ PBBSS_API int pbbss_set_dhtv_team(pbbss_handle_t h, int workgroups_per_utterance
 }
 
 PBBSS_API int pbbss_split_error(pbbss_handle_t h, int* out_flag) {
+  DeviceGuard device_guard(h);
   if (!h || !out_flag) return PBBSS_ERR_INVALID_ARG;
   int v = 0;
   if (hipMemcpy(&v, h->cfg.xbuf + 128, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)
@@ -241,6 +260,7 @@ PBBSS_API int pbbss_split_error(pbbss_handle_t h, int* out_flag) {
 }
 
 PBBSS_API int pbbss_last_kernel_ms(pbbss_handle_t h, float* out_ms) {
+  DeviceGuard device_guard(h);
   if (!h || !out_ms) return PBBSS_ERR_INVALID_ARG;
   if (!h->timing) return PBBSS_ERR_INVALID_ARG;
   if (hipEventSynchronize(h->ev1) != hipSuccess) return PBBSS_ERR_HIP;
@@ -251,6 +271,7 @@ PBBSS_API int pbbss_last_kernel_ms(pbbss_handle_t h, float* out_ms) {
 
 PBBSS_API int pbbss_normalize_observation(pbbss_handle_t h, const void* y, int is_c128,
                                           int64_t B, int T, int D, void* out, void* stream) {
+  DeviceGuard device_guard(h);
   if (!h || !y || !out || B <= 0 || T <= 0 || D <= 0) return PBBSS_ERR_INVALID_ARG;
   if (B > 65535) {  // grid.y limit: split the batch
     for (int64_t b0 = 0; b0 < B; b0 += 65535) {
@@ -273,6 +294,7 @@ PBBSS_API int pbbss_cacgmm_fit(pbbss_handle_t h, const void* y, int64_t B, int T
                                const pbbss_em_opts* o, void* out_eigvec, double* out_eigval,
                                double* out_weight, int32_t* out_status, double* out_affiliation,
                                double* out_quadratic_form, void* stream) {
+  DeviceGuard device_guard(h);
   if (!h || !y || !o || B <= 0 || T <= 0) return PBBSS_ERR_INVALID_ARG;
   if (o->iterations <= 0) return PBBSS_ERR_INVALID_ARG;  // cacgmm.py:200
   const bool has_gamma = gamma0 != nullptr;
@@ -322,6 +344,7 @@ PBBSS_API int pbbss_cacgmm_predict(pbbss_handle_t h, const void* y, int64_t B, i
                                    double affiliation_eps, double* out_affiliation,
                                    double* out_quadratic_form, double* out_log_pdf,
                                    void* stream) {
+  DeviceGuard device_guard(h);
   if (!h || !y || !eigvec || !eigval || !weight || B <= 0 || T <= 0) return PBBSS_ERR_INVALID_ARG;
   if (!out_affiliation && !out_quadratic_form && !out_log_pdf) return PBBSS_ERR_INVALID_ARG;
   if (D < 2 || D > 8 || K < 1 || K > 6) return PBBSS_ERR_UNSUPPORTED;
@@ -353,6 +376,7 @@ PBBSS_API int pbbss_cacg_m_step(pbbss_handle_t h, const void* y, int64_t B, int 
                                 int y_is_c128, int covariance_norm, double eigenvalue_floor,
                                 void* out_eigvec, double* out_eigval, void* out_cov,
                                 int32_t* out_status, void* stream) {
+  DeviceGuard device_guard(h);
   if (!h || !y || !saliency || B <= 0 || T <= 0) return PBBSS_ERR_INVALID_ARG;
   if (!out_eigvec || !out_eigval || !out_status) return PBBSS_ERR_INVALID_ARG;
   if (covariance_norm < 0 || covariance_norm > 2) return PBBSS_ERR_INVALID_ARG;
@@ -378,6 +402,7 @@ PBBSS_API int pbbss_cacg_m_step(pbbss_handle_t h, const void* y, int64_t B, int 
 PBBSS_API int pbbss_heev_batched(pbbss_handle_t h, const void* a, int64_t N, int D,
                                  double* out_eigval, void* out_eigvec, int32_t* out_status,
                                  void* stream) {
+  DeviceGuard device_guard(h);
   if (!h || !a || !out_eigval || !out_eigvec || N <= 0) return PBBSS_ERR_INVALID_ARG;
   return pbbss::launch_heev(static_cast<const double*>(a), N, D, out_eigval,
                             static_cast<double*>(out_eigvec), out_status, as_stream(stream));
@@ -385,6 +410,7 @@ PBBSS_API int pbbss_heev_batched(pbbss_handle_t h, const void* a, int64_t N, int
 
 PBBSS_API int pbbss_psd(pbbss_handle_t h, const void* x, int x_is_c128, int64_t B, int T, int D,
                         int K, const double* mask, int normalize, void* out, void* stream) {
+  DeviceGuard device_guard(h);
   if (!h || !x || !out || B <= 0 || T <= 0 || K <= 0) return PBBSS_ERR_INVALID_ARG;
   if (!mask && K != 1) return PBBSS_ERR_INVALID_ARG;
   return pbbss::launch_psd(x, x_is_c128, B, T, D, K, mask, normalize, static_cast<double*>(out),
@@ -393,6 +419,7 @@ PBBSS_API int pbbss_psd(pbbss_handle_t h, const void* x, int x_is_c128, int64_t 
 
 PBBSS_API int pbbss_gev(pbbss_handle_t h, const void* target, const void* noise, int64_t N,
                         int D, void* out_w, int32_t* out_status, void* stream) {
+  DeviceGuard device_guard(h);
   if (!h || !target || !noise || !out_w || N <= 0) return PBBSS_ERR_INVALID_ARG;
   return pbbss::launch_gev(static_cast<const double*>(target), static_cast<const double*>(noise),
                            N, D, static_cast<double*>(out_w), out_status, as_stream(stream));
@@ -400,6 +427,7 @@ PBBSS_API int pbbss_gev(pbbss_handle_t h, const void* target, const void* noise,
 
 PBBSS_API int pbbss_solve(pbbss_handle_t h, const void* A, const void* Bm, int64_t N, int D,
                           int M, void* out_x, int32_t* out_status, void* stream) {
+  DeviceGuard device_guard(h);
   if (!h || !A || !Bm || !out_x || N <= 0 || M <= 0) return PBBSS_ERR_INVALID_ARG;
   if (M > 8) return PBBSS_ERR_UNSUPPORTED;
   return pbbss::launch_solve(static_cast<const double*>(A), static_cast<const double*>(Bm), N, D,
@@ -409,6 +437,7 @@ PBBSS_API int pbbss_solve(pbbss_handle_t h, const void* A, const void* Bm, int64
 PBBSS_API int pbbss_mvdr_souden(pbbss_handle_t h, const void* target, const void* noise,
                                 int64_t N, int D, double eps, void* out_mat, void* out_snr_num,
                                 void* out_snr_den, int32_t* out_status, void* stream) {
+  DeviceGuard device_guard(h);
   if (!h || !target || !noise || !out_mat || N <= 0) return PBBSS_ERR_INVALID_ARG;
   return pbbss::launch_mvdr_souden(static_cast<const double*>(target),
                                    static_cast<const double*>(noise), N, D, eps, 0,
@@ -420,6 +449,7 @@ PBBSS_API int pbbss_mvdr_souden(pbbss_handle_t h, const void* target, const void
 
 PBBSS_API int pbbss_mvdr(pbbss_handle_t h, const void* atf, const void* noise, int64_t N, int D,
                          void* out_w, int32_t* out_status, void* stream) {
+  DeviceGuard device_guard(h);
   if (!h || !atf || !noise || !out_w || N <= 0) return PBBSS_ERR_INVALID_ARG;
   return pbbss::launch_mvdr(static_cast<const double*>(atf), static_cast<const double*>(noise), N,
                             D, static_cast<double*>(out_w), out_status, as_stream(stream));
@@ -427,6 +457,7 @@ PBBSS_API int pbbss_mvdr(pbbss_handle_t h, const void* atf, const void* noise, i
 
 PBBSS_API int pbbss_ban(pbbss_handle_t h, const void* w, const void* noise, int64_t N, int D,
                         void* out_w, void* stream) {
+  DeviceGuard device_guard(h);
   if (!h || !w || !noise || !out_w || N <= 0) return PBBSS_ERR_INVALID_ARG;
   return pbbss::launch_ban(static_cast<const double*>(w), static_cast<const double*>(noise), N, D,
                            static_cast<double*>(out_w), as_stream(stream));
@@ -435,6 +466,7 @@ PBBSS_API int pbbss_ban(pbbss_handle_t h, const void* w, const void* noise, int6
 PBBSS_API int pbbss_apply_beamforming_vector(pbbss_handle_t h, const void* w, const void* x,
                                              int x_is_c128, int64_t B, int T, int D, void* out,
                                              void* stream) {
+  DeviceGuard device_guard(h);
   if (!h || !w || !x || !out || B <= 0 || T <= 0 || D <= 0) return PBBSS_ERR_INVALID_ARG;
   if (D >= 30) return PBBSS_ERR_INVALID_ARG;  // beamformer.py:582
   for (int64_t b0 = 0; b0 < B; b0 += 65535) {
@@ -452,6 +484,7 @@ PBBSS_API int pbbss_dhtv_calculate_mapping(pbbss_handle_t h, const double* mask,
                                            int F, int T, const int32_t* plan, int P, int optimal,
                                            double* scratch, int32_t* out_mapping,
                                            int32_t* out_status, void* stream) {
+  DeviceGuard device_guard(h);
   if (!h || !mask || !plan || !scratch || !out_mapping || !out_status) return PBBSS_ERR_INVALID_ARG;
   if (U <= 0 || F <= 0 || T <= 0 || P <= 0) return PBBSS_ERR_INVALID_ARG;
   return pbbss::launch_dhtv(mask, U, K, F, T, plan, P, optimal, scratch, out_mapping, out_status,
@@ -461,6 +494,7 @@ PBBSS_API int pbbss_dhtv_calculate_mapping(pbbss_handle_t h, const double* mask,
 
 PBBSS_API int pbbss_apply_mapping(pbbss_handle_t h, const double* mask, const int32_t* mapping,
                                   int64_t U, int K, int F, int T, double* out, void* stream) {
+  DeviceGuard device_guard(h);
   if (!h || !mask || !mapping || !out || U <= 0 || K <= 0 || F <= 0 || T <= 0)
     return PBBSS_ERR_INVALID_ARG;
   return pbbss::launch_apply_mapping(mask, mapping, U, K, F, T, out, as_stream(stream));
@@ -473,6 +507,7 @@ PBBSS_API int pbbss_cwmm_fit(pbbss_handle_t h, const void* y, int64_t B, int T, 
                              const double* spline_t, const double* spline_c, void* out_mode,
                              double* out_concentration, double* out_weight, int32_t* out_status,
                              double* out_affiliation, double* out_log_pdf, void* stream) {
+  DeviceGuard device_guard(h);
   if (!h || !y || !o || B <= 0 || T <= 0) return PBBSS_ERR_INVALID_ARG;
   if (o->iterations < 0) return PBBSS_ERR_INVALID_ARG;
   const bool has_gamma = gamma0 != nullptr;
@@ -520,6 +555,7 @@ PBBSS_API int pbbss_wmwf(pbbss_handle_t h, const void* target, const void* noise
                          double distortion_weight, int frequency_dependent, void* out_mat,
                          void* out_snr_num, void* out_snr_den, int32_t* out_status,
                          void* stream) {
+  DeviceGuard device_guard(h);
   if (!h || !target || !noise || !out_mat || N <= 0) return PBBSS_ERR_INVALID_ARG;
   return pbbss::launch_mvdr_souden(static_cast<const double*>(target),
                                    static_cast<const double*>(noise), N, D, distortion_weight,
@@ -548,6 +584,7 @@ inline int copy_d2d(void* dst, const void* src, size_t bytes, hipStream_t s) {
 PBBSS_API int pbbss_embed_log_pdf(pbbss_handle_t h, const void* y, int y_is_f64, int64_t B,
                                   int64_t N, int E, int K, int kind, const double* mean,
                                   const double* scale, double* out_log_pdf, void* stream) {
+  DeviceGuard device_guard(h);
   if (!h || !y || !mean || !scale || !out_log_pdf) return PBBSS_ERR_INVALID_ARG;
   if (!embed_shape_ok(B, N, E, K)) return PBBSS_ERR_UNSUPPORTED;
   hipStream_t s = as_stream(stream);
@@ -571,6 +608,7 @@ PBBSS_API int pbbss_embed_fit(pbbss_handle_t h, const void* y, int y_is_f64, int
                               int E, int K, int kind, int normalize, const double* weights,
                               double min_concentration, double max_concentration,
                               double* out_mean, double* out_scale, void* stream) {
+  DeviceGuard device_guard(h);
   if (!h || !y || !weights || !out_mean || !out_scale) return PBBSS_ERR_INVALID_ARG;
   if (!embed_shape_ok(B, N, E, K)) return PBBSS_ERR_UNSUPPORTED;
   hipStream_t s = as_stream(stream);
@@ -602,6 +640,7 @@ PBBSS_API int pbbss_vmfmm_fit(pbbss_handle_t h, const void* y, int64_t B, int64_
                               const double* saliency, const pbbss_mix_opts* o, double* out_mean,
                               double* out_concentration, double* out_weight,
                               double* out_affiliation, double* out_log_pdf, void* stream) {
+  DeviceGuard device_guard(h);
   if (!h || !y || !o) return PBBSS_ERR_INVALID_ARG;
   if (!embed_shape_ok(B, N, E, K)) return PBBSS_ERR_UNSUPPORTED;
   if (o->iterations < 0 || o->weight_mode < 0 || o->weight_mode > 1) return PBBSS_ERR_INVALID_ARG;
@@ -665,6 +704,7 @@ PBBSS_API int pbbss_joint_fit(pbbss_handle_t h, const void* observation, const v
                               const pbbss_mix_opts* o, void* out_eigvec, double* out_eigval,
                               double* out_weight, double* out_mean, double* out_scale,
                               int32_t* out_status, double* out_affiliation, void* stream) {
+  DeviceGuard device_guard(h);
   if (!h || !observation || !embedding || !o || F <= 0 || T <= 0) return PBBSS_ERR_INVALID_ARG;
   if (D < 2 || D > 8 || K < 1 || K > 6) return PBBSS_ERR_UNSUPPORTED;
   const int64_t N = F * (int64_t)T;
@@ -809,6 +849,7 @@ PBBSS_API int pbbss_joint_fit(pbbss_handle_t h, const void* observation, const v
 PBBSS_API int pbbss_lcmv(pbbss_handle_t h, const void* atf, const void* response,
                          const void* noise, int64_t F, int D, int K, void* out_w,
                          int32_t* out_status, void* stream) {
+  DeviceGuard device_guard(h);
   if (!h || !atf || !response || !noise || !out_w || F <= 0) return PBBSS_ERR_INVALID_ARG;
   return pbbss::launch_lcmv(static_cast<const double*>(atf), static_cast<const double*>(response),
                             static_cast<const double*>(noise), F, D, K,
@@ -818,6 +859,7 @@ PBBSS_API int pbbss_lcmv(pbbss_handle_t h, const void* atf, const void* response
 PBBSS_API int pbbss_phase_correction(pbbss_handle_t h, const void* vector, int64_t lead,
                                      int64_t rest, int F, int D, int two_d, void* scratch,
                                      void* out, void* stream) {
+  DeviceGuard device_guard(h);
   if (!h || !vector || !out || lead <= 0 || rest <= 0 || F <= 0 || D <= 0)
     return PBBSS_ERR_INVALID_ARG;
   if (F > 1 && !scratch) return PBBSS_ERR_INVALID_ARG;
@@ -829,6 +871,7 @@ PBBSS_API int pbbss_phase_correction(pbbss_handle_t h, const void* vector, int64
 
 PBBSS_API int pbbss_snr_postfilter(pbbss_handle_t h, const void* w, const void* target,
                                    const void* noise, int64_t F, int D, void* out, void* stream) {
+  DeviceGuard device_guard(h);
   if (!h || !w || !target || !noise || !out || F <= 0 || D <= 0) return PBBSS_ERR_INVALID_ARG;
   return pbbss::launch_bf_quadratic(0, static_cast<const double*>(w),
                                     static_cast<const double*>(target),
@@ -839,6 +882,7 @@ PBBSS_API int pbbss_snr_postfilter(pbbss_handle_t h, const void* w, const void* 
 PBBSS_API int pbbss_distortionless_normalization(pbbss_handle_t h, const void* w, const void* atf,
                                                  const void* noise, int64_t F, int D, void* out,
                                                  void* stream) {
+  DeviceGuard device_guard(h);
   if (!h || !w || !atf || !noise || !out || F <= 0 || D <= 0) return PBBSS_ERR_INVALID_ARG;
   return pbbss::launch_bf_quadratic(1, static_cast<const double*>(w), nullptr,
                                     static_cast<const double*>(noise),
@@ -849,6 +893,7 @@ PBBSS_API int pbbss_distortionless_normalization(pbbss_handle_t h, const void* w
 PBBSS_API int pbbss_zero_degree_normalization(pbbss_handle_t h, const void* vector, int64_t N,
                                               int D, int reference_channel, void* out,
                                               void* stream) {
+  DeviceGuard device_guard(h);
   if (!h || !vector || !out || N <= 0 || D <= 0) return PBBSS_ERR_INVALID_ARG;
   if (reference_channel < 0 || reference_channel >= D) return PBBSS_ERR_INVALID_ARG;
   return pbbss::launch_zero_degree(static_cast<const double*>(vector), N, D, reference_channel,
@@ -857,6 +902,7 @@ PBBSS_API int pbbss_zero_degree_normalization(pbbss_handle_t h, const void* vect
 
 PBBSS_API int pbbss_condition_covariance(pbbss_handle_t h, const void* x, int64_t N, int D,
                                          double gamma, void* out, void* stream) {
+  DeviceGuard device_guard(h);
   if (!h || !x || !out || N <= 0 || D <= 0) return PBBSS_ERR_INVALID_ARG;
   return pbbss::launch_condition_covariance(static_cast<const double*>(x), N, D, gamma,
                                             static_cast<double*>(out), as_stream(stream));
@@ -865,6 +911,7 @@ PBBSS_API int pbbss_condition_covariance(pbbss_handle_t h, const void* x, int64_
 PBBSS_API int pbbss_apply_online_beamforming_vector(pbbss_handle_t h, const void* vector,
                                                     const void* mix, int mix_is_c128, int64_t F,
                                                     int T, int D, void* out, void* stream) {
+  DeviceGuard device_guard(h);
   if (!h || !vector || !mix || !out || F <= 0 || T <= 0 || D <= 0) return PBBSS_ERR_INVALID_ARG;
   return pbbss::launch_apply_online(static_cast<const double*>(vector), mix, mix_is_c128, F, T, D,
                                     static_cast<double*>(out), as_stream(stream));
