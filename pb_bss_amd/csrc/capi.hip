@@ -631,7 +631,7 @@ PBBSS_API int pbbss_embed_fit(pbbss_handle_t h, const void* y, int y_is_f64, int
   }
   return pbbss::launch_embed_fit(kind, yr, yr_f64, B, N, E, K, weights, N, nullptr,
                                  min_concentration, max_concentration, -1, part, out_mean,
-                                 out_scale, nullptr, nullptr, nullptr, s);
+                                 out_scale, nullptr, nullptr, nullptr, 0, s);
 }
 
 PBBSS_API int pbbss_vmfmm_fit(pbbss_handle_t h, const void* y, int64_t B, int64_t N, int E, int K,
@@ -681,7 +681,7 @@ PBBSS_API int pbbss_vmfmm_fit(pbbss_handle_t h, const void* y, int64_t B, int64_
     }
     rc = pbbss::launch_embed_fit(PBBSS_EMBED_VMF, yr, 1, B, N, E, K, src, N, saliency,
                                  o->min_concentration, o->max_concentration, o->weight_mode, part,
-                                 out_mean, out_concentration, out_weight, offset, prec, s);
+                                 out_mean, out_concentration, out_weight, offset, prec, 0, s);
     if (rc != PBBSS_OK) return rc;
   }
   if (o->final_predict && (out_affiliation || out_log_pdf)) {
@@ -830,7 +830,7 @@ PBBSS_API int pbbss_joint_fit(pbbss_handle_t h, const void* observation, const v
     }
     rc = pbbss::launch_embed_fit(o->kind, embedding, o->embedding_is_f64, 1, N, E, K, src, T,
                                  saliency, o->min_concentration, o->max_concentration, -1, part,
-                                 out_mean, out_scale, nullptr, offset, prec, s);
+                                 out_mean, out_scale, nullptr, offset, prec, it == 0 ? 2 : 1, s);
     if (rc != PBBSS_OK) return rc;
     if (fixed_scale) {  // fixed_covariance (gcacgmm.py:305-312)
       if ((rc = copy_d2d(out_scale, in_scale, (size_t)K * 8, s)) != PBBSS_OK) return rc;

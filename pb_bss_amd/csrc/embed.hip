@@ -201,16 +201,22 @@ __global__ void __launch_bounds__(kThreads)
 // ---------------------------------------------------------------- M-step partial sums
 // PASS 0: S1[k][d] = sum_n w_k(n) y[n][d], S0[k] = sum_n w_k(n)
 // PASS 1: S2[k][d] = sum_n w_k(n) (y[n][d] - mean[k][d])^2
-// part layout: [b][chunk][k][E+1]  (slot E = S0)
+// PASS 2: PASS 0 plus, in the same sweep, S2'[k][d] = sum_n w_k(n) (y[n][d] - c[k][d])^2 about a
+//         SHIFT c (the previous iteration's mean, or the first row of y when there is none):
+//         the finalize turns it into the variance about the new mean without a second pass over
+//         the embedding; with c within the data's spread there is no cancellation to speak of.
+// part layout: [b][chunk][k][E+1]  (slot E = S0); PASS 2 writes S2' to part2 (same layout)
 constexpr int kFitThreads = 1024;  // 16 waves: one workgroup per CU keeps 1024 loads in flight
 
 template <int K, typename TS, int PASS>
 __global__ void __launch_bounds__(kFitThreads)
     embed_fit_kernel(const TS* yr, int64_t N, int E, int S, int C, int64_t L, const double* aff,
-                     int64_t Tin, const double* sal, const double* mean, double* part) {
+                     int64_t Tin, const double* sal, const double* mean, double* part,
+                     double* part2, int shift_first_row) {
   extern __shared__ double sm[];
   double* red = sm;               // [S][K][E]
   double* red0 = sm + S * K * E;  // [S][K]
+  double* red2 = red0 + S * K;    // [S][K][E]  (PASS 2)
   const int64_t b = blockIdx.y;
   const int c = blockIdx.x;
   const int tid = threadIdx.x;
@@ -219,12 +225,16 @@ __global__ void __launch_bounds__(kFitThreads)
   const bool active = s < S;
   const int64_t n0 = (int64_t)c * L;
   const int64_t n1 = (n0 + L < N) ? (n0 + L) : N;
-  double acc[K], acc0[K], mu[K];
+  double acc[K], acc0[K], acc2[K], mu[K];
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     acc[k] = 0.0;
     acc0[k] = 0.0;
-    mu[k] = (PASS == 1 && active) ? mean[((size_t)b * K + k) * E + d] : 0.0;
+    acc2[k] = 0.0;
+    mu[k] = 0.0;
+    if (PASS == 1 && active) mu[k] = mean[((size_t)b * K + k) * E + d];
+    if (PASS == 2 && active)
+      mu[k] = shift_first_row ? (double)yr[(size_t)b * N * E + d] : mean[((size_t)b * K + k) * E + d];
   }
   if (active) {
     constexpr int U = 4;
@@ -246,12 +256,17 @@ __global__ void __launch_bounds__(kFitThreads)
 #pragma unroll
         for (int k = 0; k < K; ++k) {
           const double wk = w[u][k] * sv[u];  // affiliation * saliency (vmfmm.py:167)
-          if (PASS == 0) {
+          if (PASS == 0 || PASS == 2) {
             acc[k] = fma(wk, yv[u], acc[k]);
             acc0[k] += wk;
-          } else {
+          }
+          if (PASS == 1) {
             const double df = yv[u] - mu[k];
             acc[k] = fma(wk * df, df, acc[k]);
+          }
+          if (PASS == 2) {
+            const double df = yv[u] - mu[k];
+            acc2[k] = fma(wk * df, df, acc2[k]);
           }
         }
       }
@@ -259,7 +274,8 @@ __global__ void __launch_bounds__(kFitThreads)
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       red[(s * K + k) * E + d] = acc[k];
-      if (PASS == 0 && d == 0) red0[s * K + k] = acc0[k];
+      if (PASS != 1 && d == 0) red0[s * K + k] = acc0[k];
+      if (PASS == 2) red2[(s * K + k) * E + d] = acc2[k];
     }
   }
   __syncthreads();
@@ -269,8 +285,13 @@ __global__ void __launch_bounds__(kFitThreads)
     double t = 0.0;
     for (int ss = 0; ss < S; ++ss) t += red[(ss * K + k) * E + dd];
     dst[k * (E + 1) + dd] = t;
+    if (PASS == 2) {
+      double t2 = 0.0;
+      for (int ss = 0; ss < S; ++ss) t2 += red2[(ss * K + k) * E + dd];
+      part2[((size_t)b * C + c) * K * (E + 1) + k * (E + 1) + dd] = t2;
+    }
   }
-  if (PASS == 0 && tid < K) {
+  if (PASS != 1 && tid < K) {
     double t = 0.0;
     for (int ss = 0; ss < S; ++ss) t += red0[ss * K + tid];
     dst[tid * (E + 1) + E] = t;
@@ -392,6 +413,67 @@ __global__ void __launch_bounds__(kFinThreads)
   }
 }
 
+// Spherical Gaussian from ONE sweep (PASS 2 partials): mean = S1 / den, and with the shift c
+//   sum_n w (y - mean)^2 = S2' - 2 (mean - c)(S1 - c S0) + (mean - c)^2 S0      per dimension.
+__global__ void __launch_bounds__(kFinThreads)
+    embed_finalize_single_kernel(const double* part, const double* part2, int C, int E, int K,
+                                 const void* yr, int y_is_f64, int64_t N, int shift_first_row,
+                                 double* out_mean, double* out_scale, double* out_offset,
+                                 double* out_prec) {
+  extern __shared__ double sm[];  // tot1 [K][E+1], tot2 [K][E+1]
+  const int64_t b = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int lane = tid & (kWave - 1);
+  const int wave = tid >> 6;
+  const int W = K * (E + 1);
+  double* tot1 = sm;
+  double* tot2 = sm + W;
+  for (int i = tid; i < 2 * W; i += kFinThreads) {
+    const double* p = (i < W ? part : part2) + (size_t)b * C * W + (i < W ? i : i - W);
+    double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+    int c = 0;
+    for (; c + 3 < C; c += 4) {
+      t0 += p[(size_t)c * W];
+      t1 += p[(size_t)(c + 1) * W];
+      t2 += p[(size_t)(c + 2) * W];
+      t3 += p[(size_t)(c + 3) * W];
+    }
+    for (; c < C; ++c) t0 += p[(size_t)c * W];
+    sm[i] = (t0 + t1) + (t2 + t3);
+  }
+  __syncthreads();
+  for (int k = wave; k < K; k += kFinThreads / kWave) {
+    const double* r1 = tot1 + k * (E + 1);
+    const double* r2 = tot2 + k * (E + 1);
+    const double s0 = r1[E];
+    const double den = fmax(s0, kTiny);  // gaussian.py:160-163
+    double acc = 0.0;
+    for (int d = lane; d < E; d += kWave) {
+      double cshift;
+      if (shift_first_row) {
+        cshift = y_is_f64 ? static_cast<const double*>(yr)[(size_t)b * N * E + d]
+                          : (double)static_cast<const float*>(yr)[(size_t)b * N * E + d];
+      } else {
+        cshift = out_mean[((size_t)b * K + k) * E + d];  // previous mean (read before the write)
+      }
+      const double m = r1[d] / den;
+      const double dm = m - cshift;
+      acc += r2[d] - 2.0 * dm * (r1[d] - cshift * s0) + dm * dm * s0;
+      out_mean[((size_t)b * K + k) * E + d] = m;
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) {
+      const double cv = acc / (den * (double)E);  // 'spherical', gaussian.py:179-182
+      out_scale[b * K + k] = cv;
+      if (out_offset) {
+        const double pc = 1.0 / sqrt(cv);
+        out_offset[b * K + k] = -0.5 * E * kLn2Pi + (double)E * log(pc);
+        out_prec[b * K + k] = pc;
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------- joint-model class weights
 // mode 0 / 2: workgroup f: sum_t aff[f,k,t] sal[f,t]  -> tmp[f,k]; mode 0 normalises in place
 __global__ void __launch_bounds__(kThreads)
@@ -490,7 +572,7 @@ inline int ok_or_hip() { return hipGetLastError() == hipSuccess ? PBBSS_OK : PBB
 // slot-reduction buffer stays within 48 KiB of LDS
 int fit_slots(int E, int K) {
   int S = kFitThreads / E;
-  const int cap = 6144 / (K * (E + 1));
+  const int cap = 3072 / (K * (E + 1));  // two slot-reduction buffers (single-pass Gaussian) in 48 KiB
   if (S > cap) S = cap;
   return S < 1 ? 1 : S;
 }
@@ -509,7 +591,7 @@ int fit_chunks(int64_t B, int64_t N, int E, int K) {
 size_t embed_partial_doubles(int64_t B, int64_t N, int E, int K, int* chunks_out) {
   const int C = fit_chunks(B, N, E, K);
   if (chunks_out) *chunks_out = C;
-  return (size_t)B * C * K * (E + 1) + (size_t)B * K;
+  return 2 * (size_t)B * C * K * (E + 1) + (size_t)B * K;  // S1/S0, S2' (single pass), den
 }
 
 int launch_embed_prepare(const void* y, int y_is_f64, int64_t B, int64_t N, int E, int normalize,
@@ -577,20 +659,33 @@ template <int K, typename TS>
 int fit_go(int kind, const void* yr, int64_t B, int64_t N, int E, const double* aff, int64_t Tin,
            const double* sal, double cmin, double cmax, int weight_mode, double* part,
            double* out_mean, double* out_scale, double* out_weight, double* out_offset,
-           double* out_prec, hipStream_t s) {
+           double* out_prec, int single_pass, hipStream_t s) {
   int C = 0;
   const size_t np = embed_partial_doubles(B, N, E, K, &C);
   double* den_buf = part + np - (size_t)B * K;
   const int S = fit_slots(E, K);
   int64_t L = (N + C - 1) / C;
   L = (L + S - 1) / S * S;
-  const size_t lds_fit = ((size_t)S * K * E + (size_t)S * K) * sizeof(double);
   const size_t Wv = (size_t)K * (E + 1);
+  const size_t lds_fit = (2 * (size_t)S * K * E + (size_t)S * K) * sizeof(double);
   const size_t lds_fin = (Wv + (Wv < (size_t)kFinThreads ? (kFinThreads / Wv) * Wv : 0)) * sizeof(double);
   dim3 grid((unsigned)C, (unsigned)B);
+  if (kind == PBBSS_EMBED_GAUSS_SPHERICAL && single_pass != 0) {
+    // single sweep: shift = previous mean (single_pass == 1) or the first row (== 2)
+    double* part2 = part + (size_t)B * C * K * (E + 1);
+    const int first = single_pass == 2;
+    hipLaunchKernelGGL((embed_fit_kernel<K, TS, 2>), grid, dim3(kFitThreads), lds_fit, s,
+                       static_cast<const TS*>(yr), N, E, S, C, L, aff, Tin, sal, out_mean, part,
+                       part2, first);
+    hipLaunchKernelGGL(embed_finalize_single_kernel, dim3((unsigned)B), dim3(kFinThreads),
+                       2 * Wv * sizeof(double), s, part, part2, C, E, K, yr,
+                       (int)std::is_same<TS, double>::value, N, first, out_mean, out_scale,
+                       out_offset, out_prec);
+    return ok_or_hip();
+  }
   hipLaunchKernelGGL((embed_fit_kernel<K, TS, 0>), grid, dim3(kFitThreads), lds_fit, s,
                      static_cast<const TS*>(yr), N, E, S, C, L, aff, Tin, sal,
-                     (const double*)nullptr, part);
+                     (const double*)nullptr, part, (double*)nullptr, 0);
   if (kind == PBBSS_EMBED_VMF) {
     hipLaunchKernelGGL((embed_finalize_kernel<PBBSS_EMBED_VMF, 0>), dim3((unsigned)B),
                        dim3(kFinThreads), lds_fin, s, part, C, E, K, cmin, cmax, weight_mode,
@@ -601,7 +696,8 @@ int fit_go(int kind, const void* yr, int64_t B, int64_t N, int E, const double* 
                      dim3(kFinThreads), lds_fin, s, part, C, E, K, cmin, cmax, weight_mode, den_buf,
                      out_mean, out_scale, out_weight, (double*)nullptr, (double*)nullptr);
   hipLaunchKernelGGL((embed_fit_kernel<K, TS, 1>), grid, dim3(kFitThreads), lds_fit, s,
-                     static_cast<const TS*>(yr), N, E, S, C, L, aff, Tin, sal, out_mean, part);
+                     static_cast<const TS*>(yr), N, E, S, C, L, aff, Tin, sal, out_mean, part,
+                     (double*)nullptr, 0);
   hipLaunchKernelGGL((embed_finalize_kernel<PBBSS_EMBED_GAUSS_SPHERICAL, 1>), dim3((unsigned)B),
                      dim3(kFinThreads), lds_fin, s, part, C, E, K, cmin, cmax, -1, den_buf, out_mean,
                      out_scale, (double*)nullptr, out_offset, out_prec);
@@ -612,9 +708,9 @@ template <typename TS>
 int fit_k(int K, int kind, const void* yr, int64_t B, int64_t N, int E, const double* aff,
           int64_t Tin, const double* sal, double cmin, double cmax, int weight_mode, double* part,
           double* out_mean, double* out_scale, double* out_weight, double* out_offset,
-          double* out_prec, hipStream_t s) {
+          double* out_prec, int single_pass, hipStream_t s) {
 #define PBBSS_FIT_CASE(KK) \
-  case KK: return fit_go<KK, TS>(kind, yr, B, N, E, aff, Tin, sal, cmin, cmax, weight_mode, part, out_mean, out_scale, out_weight, out_offset, out_prec, s);
+  case KK: return fit_go<KK, TS>(kind, yr, B, N, E, aff, Tin, sal, cmin, cmax, weight_mode, part, out_mean, out_scale, out_weight, out_offset, out_prec, single_pass, s);
   switch (K) {
     PBBSS_FIT_CASE(1) PBBSS_FIT_CASE(2) PBBSS_FIT_CASE(3)
     PBBSS_FIT_CASE(4) PBBSS_FIT_CASE(5) PBBSS_FIT_CASE(6)
@@ -649,13 +745,16 @@ int launch_embed_estep(int kind, const void* yd, int y_is_f64, int64_t B, int64_
 int launch_embed_fit(int kind, const void* yr, int y_is_f64, int64_t B, int64_t N, int E, int K,
                      const double* aff, int64_t Tin, const double* sal, double cmin, double cmax,
                      int weight_mode, double* part, double* out_mean, double* out_scale,
-                     double* out_weight, double* out_offset, double* out_prec, hipStream_t s) {
+                     double* out_weight, double* out_offset, double* out_prec, int single_pass,
+                     hipStream_t s) {
   if (E < 1 || E > kEmbedMaxE || B > 65535) return PBBSS_ERR_UNSUPPORTED;
   if (kind != PBBSS_EMBED_VMF && kind != PBBSS_EMBED_GAUSS_SPHERICAL) return PBBSS_ERR_UNSUPPORTED;
   return y_is_f64 ? fit_k<double>(K, kind, yr, B, N, E, aff, Tin, sal, cmin, cmax, weight_mode,
-                                  part, out_mean, out_scale, out_weight, out_offset, out_prec, s)
+                                  part, out_mean, out_scale, out_weight, out_offset, out_prec,
+                                  single_pass, s)
                   : fit_k<float>(K, kind, yr, B, N, E, aff, Tin, sal, cmin, cmax, weight_mode,
-                                 part, out_mean, out_scale, out_weight, out_offset, out_prec, s);
+                                 part, out_mean, out_scale, out_weight, out_offset, out_prec,
+                                 single_pass, s);
 }
 
 int launch_joint_weight(int mode, const double* aff, const double* sal, int64_t F, int K, int T,

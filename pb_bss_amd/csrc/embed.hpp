@@ -41,10 +41,15 @@ int launch_embed_estep(int kind, const void* yd, int y_is_f64, int64_t B, int64_
 //   0 L1-normalised masked sums, 1 uniform 1/K.
 // part: scratch of embed_partial_doubles() doubles.  out_offset / out_prec (B,K), optional:
 // what launch_embed_offsets would compute from out_scale, produced in the same launch.
+// single_pass (spherical Gaussian only): 0 = two sweeps as the reference (mean, then variance
+// about it); 1 = one sweep with the variance accumulated about out_mean's CURRENT content (the
+// previous iteration's mean) and corrected in the finalize; 2 = same with the first row of y
+// as the shift (no previous mean yet).
 int launch_embed_fit(int kind, const void* yr, int y_is_f64, int64_t B, int64_t N, int E, int K,
                      const double* aff, int64_t Tin, const double* sal, double cmin, double cmax,
                      int weight_mode, double* part, double* out_mean, double* out_scale,
-                     double* out_weight, double* out_offset, double* out_prec, hipStream_t s);
+                     double* out_weight, double* out_offset, double* out_prec, int single_pass,
+                     hipStream_t s);
 
 // masked affiliation sums of the joint models (gcacgmm.py:286-295): aff (F,K,T), sal (F,T)
 //   mode 0 'fk' (-1,): w[f,k] = sum_t / sum_k sum_t          -> (F,K)
