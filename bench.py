@@ -46,7 +46,7 @@ def parse():
     p.add_argument('--steps', type=int, default=30)
     p.add_argument('--warmup', type=int, default=3)
     p.add_argument('--iters', type=int, default=100, help='EM iterations per fit')
-    p.add_argument('--cpu-iters', type=int, default=40,
+    p.add_argument('--cpu-iters', type=int, default=100,
                    help='EM iterations of the CPU baseline sample (0 = skip)')
     p.add_argument('--check-bins', type=int, default=24,
                    help='bins of utterance 0 checked against the oracle (0 = skip)')
