@@ -6,6 +6,7 @@
 #include "beamform.hpp"
 #include "dhtv.hpp"
 #include "embed.hpp"
+#include "generic.hpp"
 #include "em_launch.hpp"
 
 #define PBBSS_API extern "C" __attribute__((visibility("default")))
@@ -75,6 +76,12 @@ struct WorkCarver {
     return p;
   }
 };
+
+inline int copy_d2d(void* dst, const void* src, size_t bytes, hipStream_t s) {
+  if (dst == src || bytes == 0) return PBBSS_OK;
+  return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s) == hipSuccess ? PBBSS_OK
+                                                                                   : PBBSS_ERR_HIP;
+}
 
 // The split-bin groups must run CONCURRENTLY with the main EM launch.  HIP maps streams onto
 // a handful of hardware queues round-robin; a plain extra stream can land on the queue of the
@@ -303,6 +310,59 @@ PBBSS_API int pbbss_cacgmm_fit(pbbss_handle_t h, const void* y, int64_t B, int T
   if (!out_eigvec || !out_eigval || !out_weight || !out_status) return PBBSS_ERR_INVALID_ARG;
   if (o->covariance_norm < 0 || o->covariance_norm > 2) return PBBSS_ERR_INVALID_ARG;
   if (o->weight_mode < 0 || o->weight_mode > 1) return PBBSS_ERR_INVALID_ARG;
+  if (D > 8) {
+    // generic-size path (generic.hip): E-step, covariance + weights, eigendecomposition per
+    // iteration, enqueued back to back; the model lives in the caller's output buffers
+    if (!pbbss::gen_supported(D, K)) return PBBSS_ERR_UNSUPPORTED;
+    if (o->layout != PBBSS_LAYOUT_TD) return PBBSS_ERR_UNSUPPORTED;
+    hipStream_t s = as_stream(stream);
+    const size_t nkt = (size_t)B * K * T;
+    const size_t need = 2 * WorkCarver::pad(nkt * 8) + WorkCarver::pad((size_t)B * K * D * D * 16);
+    void* wmem = handle_work(h, need);
+    if (!wmem) return PBBSS_ERR_HIP;
+    WorkCarver wc(wmem);
+    double* aff = wc.take<double>(nkt);
+    double* qf = wc.take<double>(nkt);
+    double* cov = wc.take<double>((size_t)B * K * D * D * 2);
+    TimedRegion tr(h, s);
+    int rc;
+    if (has_model) {
+      if ((rc = copy_d2d(out_eigvec, in_eigvec, (size_t)B * K * D * D * 16, s)) != PBBSS_OK) return rc;
+      if ((rc = copy_d2d(out_eigval, in_eigval, (size_t)B * K * D * 8, s)) != PBBSS_OK) return rc;
+      if ((rc = copy_d2d(out_weight, in_weight, (size_t)B * K * 8, s)) != PBBSS_OK) return rc;
+    }
+    if (hipMemsetAsync(out_status, 0, (size_t)B * K * sizeof(int32_t), s) != hipSuccess) return PBBSS_ERR_HIP;
+    for (int it = 0; it < o->iterations; ++it) {
+      const double* g_src = gamma0;
+      const double* q_src = nullptr;
+      if (it > 0 || has_model) {
+        rc = pbbss::launch_gen_estep(y, o->y_is_c128, PBBSS_LAYOUT_TD, B, T, D, K,
+                                     static_cast<const double*>(out_eigvec), out_eigval,
+                                     out_weight, K, 1, 0, activity, o->affiliation_eps, aff, qf,
+                                     nullptr, h->cfg.lds_limit, s);
+        if (rc != PBBSS_OK) return rc;
+        g_src = aff;
+        q_src = qf;
+      }
+      rc = pbbss::launch_gen_cov(y, o->y_is_c128, PBBSS_LAYOUT_TD, B, T, D, K, g_src,
+                                 (int64_t)K * T, q_src, saliency, 0, o->weight_mode, cov,
+                                 out_weight, nullptr, h->cfg.lds_limit, s);
+      if (rc != PBBSS_OK) return rc;
+      // per-(b,k) status of the LAST iteration (earlier ones are overwritten)
+      rc = pbbss::launch_gen_heev(cov, B * K, D, o->covariance_norm, o->eigenvalue_floor,
+                                  out_eigval, static_cast<double*>(out_eigvec), out_status,
+                                  h->cfg.lds_limit, s);
+      if (rc != PBBSS_OK) return rc;
+    }
+    if (o->final_predict && (out_affiliation || out_quadratic_form)) {
+      rc = pbbss::launch_gen_estep(y, o->y_is_c128, PBBSS_LAYOUT_TD, B, T, D, K,
+                                   static_cast<const double*>(out_eigvec), out_eigval, out_weight,
+                                   K, 1, 0, nullptr, 0.0, out_affiliation, out_quadratic_form,
+                                   nullptr, h->cfg.lds_limit, s);
+      if (rc != PBBSS_OK) return rc;
+    }
+    return PBBSS_OK;
+  }
   if (D < 2 || D > 8 || K < 1 || K > 6) return PBBSS_ERR_UNSUPPORTED;
   pbbss::EmArgs a{};
   a.y = y;
@@ -347,6 +407,13 @@ PBBSS_API int pbbss_cacgmm_predict(pbbss_handle_t h, const void* y, int64_t B, i
   DeviceGuard device_guard(h);
   if (!h || !y || !eigvec || !eigval || !weight || B <= 0 || T <= 0) return PBBSS_ERR_INVALID_ARG;
   if (!out_affiliation && !out_quadratic_form && !out_log_pdf) return PBBSS_ERR_INVALID_ARG;
+  if (D > 8) {
+    TimedRegion tr(h, as_stream(stream));
+    return pbbss::launch_gen_estep(y, y_is_c128, layout, B, T, D, K,
+                                   static_cast<const double*>(eigvec), eigval, weight, wb, wk, wt,
+                                   activity, affiliation_eps, out_affiliation, out_quadratic_form,
+                                   out_log_pdf, h->cfg.lds_limit, as_stream(stream));
+  }
   if (D < 2 || D > 8 || K < 1 || K > 6) return PBBSS_ERR_UNSUPPORTED;
   pbbss::EmArgs a{};
   a.y = y;
@@ -380,6 +447,22 @@ PBBSS_API int pbbss_cacg_m_step(pbbss_handle_t h, const void* y, int64_t B, int 
   if (!h || !y || !saliency || B <= 0 || T <= 0) return PBBSS_ERR_INVALID_ARG;
   if (!out_eigvec || !out_eigval || !out_status) return PBBSS_ERR_INVALID_ARG;
   if (covariance_norm < 0 || covariance_norm > 2) return PBBSS_ERR_INVALID_ARG;
+  if (D > 8) {
+    hipStream_t s = as_stream(stream);
+    double* cov = static_cast<double*>(out_cov);
+    if (!cov) {
+      void* wmem = handle_work(h, (size_t)B * K * D * D * 16);
+      if (!wmem) return PBBSS_ERR_HIP;
+      cov = static_cast<double*>(wmem);
+    }
+    int rc = pbbss::launch_gen_cov(y, y_is_c128, layout, B, T, D, K, saliency, (int64_t)K * T,
+                                   quadratic_form, nullptr, 0, PBBSS_WEIGHT_PER_CLASS_MEAN, cov,
+                                   nullptr, nullptr, h->cfg.lds_limit, s);
+    if (rc != PBBSS_OK) return rc;
+    return pbbss::launch_gen_heev(cov, B * K, D, covariance_norm, eigenvalue_floor, out_eigval,
+                                  static_cast<double*>(out_eigvec), out_status, h->cfg.lds_limit,
+                                  s);
+  }
   if (D < 2 || D > 8 || K < 1 || K > 6) return PBBSS_ERR_UNSUPPORTED;
   pbbss::EmArgs a{};
   a.y = y;
@@ -404,6 +487,10 @@ PBBSS_API int pbbss_heev_batched(pbbss_handle_t h, const void* a, int64_t N, int
                                  void* stream) {
   DeviceGuard device_guard(h);
   if (!h || !a || !out_eigval || !out_eigvec || N <= 0) return PBBSS_ERR_INVALID_ARG;
+  if (D > 8)
+    return pbbss::launch_gen_heev(static_cast<const double*>(a), N, D, -1, 0.0, out_eigval,
+                                  static_cast<double*>(out_eigvec), out_status, h->cfg.lds_limit,
+                                  as_stream(stream));
   return pbbss::launch_heev(static_cast<const double*>(a), N, D, out_eigval,
                             static_cast<double*>(out_eigvec), out_status, as_stream(stream));
 }
@@ -413,6 +500,21 @@ PBBSS_API int pbbss_psd(pbbss_handle_t h, const void* x, int x_is_c128, int64_t 
   DeviceGuard device_guard(h);
   if (!h || !x || !out || B <= 0 || T <= 0 || K <= 0) return PBBSS_ERR_INVALID_ARG;
   if (!mask && K != 1) return PBBSS_ERR_INVALID_ARG;
+  if (D > 8) {
+    double* o = static_cast<double*>(out);
+    for (int k0 = 0; k0 < K; k0 += 6) {  // chunks of <= 6 sources per launch
+      const int kc = (K - k0 < 6) ? (K - k0) : 6;
+      int rc = pbbss::launch_gen_cov(x, x_is_c128, PBBSS_LAYOUT_DT, B, T, D, kc,
+                                     mask ? mask + (int64_t)k0 * T : nullptr, (int64_t)K * T,
+                                     nullptr, nullptr, (mask && normalize) ? 1 : 2,
+                                     PBBSS_WEIGHT_PER_CLASS_MEAN, o, nullptr, nullptr,
+                                     h->cfg.lds_limit, as_stream(stream));
+      if (rc != PBBSS_OK) return rc;
+      if (K > 6) return PBBSS_ERR_UNSUPPORTED;  // strided output of chunked sources: not yet
+      o += (int64_t)kc * D * D * 2;
+    }
+    return PBBSS_OK;
+  }
   return pbbss::launch_psd(x, x_is_c128, B, T, D, K, mask, normalize, static_cast<double*>(out),
                            h->cfg, as_stream(stream));
 }
@@ -573,11 +675,6 @@ namespace {
 inline bool embed_shape_ok(int64_t B, int64_t N, int E, int K) {
   return B >= 1 && B <= 65535 && N >= 1 && E >= 1 && E <= pbbss::kEmbedMaxE && K >= 1 &&
          K <= pbbss::kEmbedMaxK;
-}
-inline int copy_d2d(void* dst, const void* src, size_t bytes, hipStream_t s) {
-  if (dst == src || bytes == 0) return PBBSS_OK;
-  return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s) == hipSuccess ? PBBSS_OK
-                                                                                   : PBBSS_ERR_HIP;
 }
 }  // namespace
 

@@ -1,0 +1,633 @@
+// Generic-size path of the cACGMM trainer for 9 <= D <= 32 sensors (the persistent kernel of
+// cacgmm_em.hpp is specialised for D <= 8, where a D x D matrix maps onto one wavefront).
+// Same functions as SURVEY.md section 8a rows a2-a8 / a10, decomposed into three kernels per
+// EM iteration that the C ABI enqueues back to back (no host synchronisation):
+//   gen_estep  one workgroup per frequency bin: B_k^-1 = V diag(1/lambda) V^H built in LDS,
+//              thread = frame: q = y^H B^-1 y (D^2 complex MACs per class against LDS
+//              broadcasts), log-domain softmax            (cacg.py:167-203, mm_utils.py:7-55)
+//   gen_cov    one workgroup per bin: thread = covariance entries (i,j), frames staged
+//              through a 32-frame LDS tile: C_k = sum_t w_kt y_t y_t^H with the M-step or the
+//              PSD normalisation, class weights             (cacg.py:253-342, beamformer.py:59)
+//   gen_heev   one workgroup per matrix: parallel cyclic Jacobi in LDS (D/2 disjoint
+//              rotations per round, ping-pong buffers), ascending eigenvalues, the
+//              reference's normalisation and floor           (cacg.py:82-132)
+// Matrices are padded to DP = 16 or 32 (template) so that register arrays index statically.
+// Float64 arithmetic throughout, as the D <= 8 path.
+#include "generic.hpp"
+#include <cmath>
+#include "pbbss_dev.hpp"
+
+namespace pbbss {
+namespace {
+
+constexpr int kGenThreads = 256;
+constexpr int kGenWaves = kGenThreads / kWave;
+constexpr int kGenMaxK = 6;
+constexpr int kTile = 32;  // frames per LDS tile of gen_cov
+
+__device__ __forceinline__ double block_sum(double v, double* red, int tid) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = v;
+  __syncthreads();
+  double s = 0.0;
+#pragma unroll
+  for (int w = 0; w < kGenWaves; ++w) s += red[w];
+  return s;
+}
+
+template <typename YS>
+__device__ __forceinline__ void load_y(const void* y, int layout, int64_t b, int t, int d, int T,
+                                       int D, double& re, double& im) {
+  const size_t idx = (layout == PBBSS_LAYOUT_TD) ? ((size_t)b * T + t) * D + d
+                                                 : ((size_t)b * D + d) * T + t;
+  const YS* p = static_cast<const YS*>(y) + 2 * idx;
+  re = (double)p[0];
+  im = (double)p[1];
+}
+
+// ------------------------------------------------------------------ E-step
+struct GenEstep {
+  const void* y;
+  int layout;
+  int64_t B;
+  int T, D, K;
+  const double* eigvec;  // c128 (B,K,D,D)
+  const double* eigval;  // (B,K,D)
+  const double* weight;
+  int64_t wb, wk, wt;
+  const uint8_t* activity;
+  double eps;
+  double* out_aff;
+  double* out_q;
+  double* out_logpdf;
+};
+
+template <int DP, typename YS>
+__global__ void __launch_bounds__(kGenThreads) gen_estep_kernel(GenEstep a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* ainv = reinterpret_cast<double*>(smem);           // [K][DP][DP][2]
+  double* logdet = ainv + (size_t)a.K * DP * DP * 2;        // [K]
+  const int tid = threadIdx.x;
+  const int64_t b = blockIdx.x;
+  const int D = a.D, K = a.K, T = a.T;
+  // B_k^-1 = V diag(1/lambda) V^H  (the reference's einsum forms the same product first)
+  for (int idx = tid; idx < K * DP * DP; idx += kGenThreads) {
+    const int k = idx / (DP * DP), r = idx - k * DP * DP, i = r / DP, j = r - i * DP;
+    double sr = 0.0, si = 0.0;
+    if (i < D && j < D) {
+      const double* v = a.eigvec + ((size_t)b * K + k) * D * D * 2;
+      const double* lam = a.eigval + ((size_t)b * K + k) * D;
+      for (int e = 0; e < D; ++e) {
+        const double il = 1.0 / lam[e];
+        const double ar = v[(i * D + e) * 2], ai = v[(i * D + e) * 2 + 1];
+        const double br = v[(j * D + e) * 2], bi = v[(j * D + e) * 2 + 1];
+        sr += (ar * br + ai * bi) * il;   // V_ie conj(V_je)
+        si += (ai * br - ar * bi) * il;
+      }
+    }
+    ainv[idx * 2] = sr;
+    ainv[idx * 2 + 1] = si;
+  }
+  if (tid < K) {
+    double s = 0.0;
+    for (int e = 0; e < D; ++e) s += log(a.eigval[((size_t)b * K + tid) * D + e]);
+    logdet[tid] = s;  // cacg.py:151
+  }
+  __syncthreads();
+  for (int t = tid; t < T; t += kGenThreads) {
+    double yr[DP], yi[DP], n2 = 0.0;
+#pragma unroll
+    for (int d = 0; d < DP; ++d) {
+      yr[d] = 0.0;
+      yi[d] = 0.0;
+      if (d < D) {
+        load_y<YS>(a.y, a.layout, b, t, d, T, D, yr[d], yi[d]);
+        n2 += yr[d] * yr[d] + yi[d] * yi[d];
+      }
+    }
+    // raw observations are unit-normalised (zero frames stay zero, utils.py:223-256)
+    const double inv = (a.layout == PBBSS_LAYOUT_TD) ? ((n2 > 0.0) ? 1.0 / n2 : 0.0) : 1.0;
+    double lp[kGenMaxK], qv[kGenMaxK], mx = -1.79e308;
+#pragma unroll
+    for (int k = 0; k < kGenMaxK; ++k) {
+      lp[k] = -1.79e308;
+      qv[k] = 0.0;
+      if (k < K) {
+        const double* A = ainv + (size_t)k * DP * DP * 2;
+        double q = 0.0;
+#pragma unroll
+        for (int i = 0; i < DP; ++i) {
+          if (i < D) {
+            double ur = 0.0, ui = 0.0;  // (B^-1 y)_i
+#pragma unroll
+            for (int j = 0; j < DP; ++j) {
+              if (j < D) {
+                const double ar = A[(i * DP + j) * 2], ai = A[(i * DP + j) * 2 + 1];
+                ur += ar * yr[j] - ai * yi[j];
+                ui += ar * yi[j] + ai * yr[j];
+              }
+            }
+            q += yr[i] * ur + yi[i] * ui;  // Re conj(y_i) u_i
+          }
+        }
+        q = fmax(fabs(q * inv), kTiny);  // cacg.py:185-199
+        qv[k] = q;
+        lp[k] = -(double)D * log(q) - logdet[k];
+        mx = fmax(mx, lp[k]);
+      }
+    }
+    double g[kGenMaxK], den = 0.0;
+#pragma unroll
+    for (int k = 0; k < kGenMaxK; ++k) {
+      g[k] = 0.0;
+      if (k < K) {
+        double v = exp(lp[k] - mx) * a.weight[b * a.wb + k * a.wk + (int64_t)t * a.wt];
+        if (a.activity) v *= (double)a.activity[((size_t)b * K + k) * T + t];
+        g[k] = v;
+        den += v;
+      }
+    }
+    den = fmax(den, kTiny);
+#pragma unroll
+    for (int k = 0; k < kGenMaxK; ++k) {
+      if (k < K) {
+        double gam = g[k] / den;
+        if (a.eps != 0.0) gam = fmin(fmax(gam, a.eps), 1.0 - a.eps);
+        const size_t idx = ((size_t)b * K + k) * T + t;
+        if (a.out_aff) a.out_aff[idx] = gam;
+        if (a.out_q) a.out_q[idx] = qv[k];
+        if (a.out_logpdf) a.out_logpdf[idx] = lp[k];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ weighted covariance
+struct GenCov {
+  const void* y;
+  int layout;
+  int64_t B;
+  int T, D, K;
+  const double* gamma;     // (B,K,T) (mask_b_stride elements between problems) or null (ones, K = 1)
+  int64_t gamma_bstride;
+  const double* q;         // (B,K,T) or null (ones)
+  const double* saliency;  // (B,T) or null
+  int mode;                // 0 M-step (cacg.py:310-327), 1 PSD normalised mask, 2 PSD plain sums
+  int weight_mode;
+  double* out_cov;         // c128 (B,K,D,D)
+  double* out_weight;      // (B,K) or null
+  double* out_sum;         // (B,K) class sums or null
+};
+
+template <int DP, typename YS>
+__global__ void __launch_bounds__(kGenThreads) gen_cov_kernel(GenCov a) {
+  constexpr int R = (DP * DP + kGenThreads - 1) / kGenThreads;  // entries per thread
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* ytile = reinterpret_cast<double*>(smem);            // [kTile][DP][2]
+  double* wtile = ytile + (size_t)kTile * DP * 2;             // [K][kTile]
+  double* red = wtile + (size_t)kGenMaxK * kTile;             // [kGenWaves]
+  double* csum = red + kGenWaves;                             // [K]
+  const int tid = threadIdx.x;
+  const int64_t b = blockIdx.x;
+  const int D = a.D, K = a.K, T = a.T;
+  double accr[R][kGenMaxK], acci[R][kGenMaxK], ssum[kGenMaxK];
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int k = 0; k < kGenMaxK; ++k) {
+      accr[r][k] = 0.0;
+      acci[r][k] = 0.0;
+    }
+#pragma unroll
+  for (int k = 0; k < kGenMaxK; ++k) ssum[k] = 0.0;
+  for (int t0 = 0; t0 < T; t0 += kTile) {
+    __syncthreads();
+    // stage: thread (frame, channel pairs) -> normalised y; weights
+    for (int idx = tid; idx < kTile * DP; idx += kGenThreads) {
+      const int tt = idx / DP, d = idx - tt * DP, t = t0 + tt;
+      double re = 0.0, im = 0.0;
+      if (t < T && d < D) load_y<YS>(a.y, a.layout, b, t, d, T, D, re, im);
+      ytile[idx * 2] = re;
+      ytile[idx * 2 + 1] = im;
+    }
+    __syncthreads();
+    if (tid < kTile) {
+      // frame norm (raw layout): the M-step sees unit-norm observations (cacgmm.py:216)
+      const int t = t0 + tid;
+      double n2 = 0.0;
+      for (int d = 0; d < D; ++d) {
+        const double re = ytile[(tid * DP + d) * 2], im = ytile[(tid * DP + d) * 2 + 1];
+        n2 += re * re + im * im;
+      }
+      const double inv = (a.layout == PBBSS_LAYOUT_TD && a.mode == 0)
+                             ? ((n2 > 0.0) ? 1.0 / n2 : 0.0) : 1.0;
+      for (int k = 0; k < K; ++k) {
+        double w = 0.0, gs = 0.0;
+        if (t < T) {
+          const double gm = a.gamma ? a.gamma[(size_t)b * a.gamma_bstride + (size_t)k * T + t] : 1.0;
+          const double sal = a.saliency ? a.saliency[(size_t)b * T + t] : 1.0;
+          gs = gm * sal;
+          if (a.mode == 0) {
+            const double qq = a.q ? a.q[((size_t)b * K + k) * T + t] : 1.0;
+            w = gs / fmax(qq, 10.0 * kTiny) * inv;  // cacg.py:310, :322
+          } else {
+            w = gs;
+          }
+        }
+        wtile[k * kTile + tid] = w;
+        // class sums, accumulated by the staging thread of the frame and reduced at the end
+        ssum[k] += gs;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int e = tid + r * kGenThreads;
+      if (e < DP * DP) {
+        const int i = e / DP, j = e - i * DP;
+        if (i < D && j < D) {
+          for (int tt = 0; tt < kTile; ++tt) {
+            const double ar = ytile[(tt * DP + i) * 2], ai = ytile[(tt * DP + i) * 2 + 1];
+            const double br = ytile[(tt * DP + j) * 2], bi = ytile[(tt * DP + j) * 2 + 1];
+            const double pr = ar * br + ai * bi;   // y_i conj(y_j)
+            const double pi = ai * br - ar * bi;
+#pragma unroll
+            for (int k = 0; k < kGenMaxK; ++k) {
+              if (k < K) {
+                const double w = wtile[k * kTile + tt];
+                accr[r][k] = fma(w, pr, accr[r][k]);
+                acci[r][k] = fma(w, pi, acci[r][k]);
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+  // class sums: only threads < kTile hold partials
+#pragma unroll
+  for (int k = 0; k < kGenMaxK; ++k) {
+    const double tot = block_sum((k < K) ? ssum[k] : 0.0, red, tid);
+    if (tid == 0 && k < K) csum[k] = tot;
+  }
+  __syncthreads();
+  double tot_abs = 0.0;
+  for (int k = 0; k < K; ++k) tot_abs += fabs(csum[k]);
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int e = tid + r * kGenThreads;
+    if (e < DP * DP) {
+      const int i = e / DP, j = e - i * DP;
+      if (i < D && j < D) {
+#pragma unroll
+        for (int k = 0; k < kGenMaxK; ++k) {
+          if (k < K) {
+            double sc;
+            if (a.mode == 0) sc = (double)D / fmax(csum[k], kTiny);        // cacg.py:316, :327
+            else if (a.mode == 1) sc = 1.0 / fmax(csum[k], 1e-10);         // beamformer.py:123
+            else sc = a.gamma ? 1.0 : 1.0 / (double)T;                     // :114-117
+            double* o = a.out_cov + ((((size_t)b * K + k) * D + i) * D + j) * 2;
+            o[0] = accr[r][k] * sc;
+            o[1] = (i == j) ? 0.0 : acci[r][k] * sc;
+          }
+        }
+      }
+    }
+  }
+  if (tid < K) {
+    if (a.out_sum) a.out_sum[b * K + tid] = csum[tid];
+    if (a.out_weight) {
+      double w;
+      if (a.weight_mode == PBBSS_WEIGHT_UNIFORM) w = 1.0 / K;
+      else if (a.saliency) w = csum[tid] / ((tot_abs == 0.0) ? 1e-10 : tot_abs);  // mm_utils.py:192
+      else w = csum[tid] / (double)T;                                               // :188
+      a.out_weight[b * K + tid] = w;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ Hermitian eigensolver
+struct GenHeev {
+  const double* a;      // c128 (N,D,D)
+  int64_t N;
+  int D;
+  int covariance_norm;  // -1: plain eigh; else PBBSS_COVNORM_* with the floor below
+  double eig_floor;
+  double* out_val;      // (N,D) ascending
+  double* out_vec;      // c128 (N,D,D), eigenvectors in columns
+  int32_t* out_status;  // (N) or null
+};
+
+constexpr int kGenMaxSweeps = 30;
+constexpr double kGenJacobiTol = 1e-29;
+constexpr double kGenJacobiTolLoose = 1e-24;
+
+template <int DP>
+__global__ void __launch_bounds__(kGenThreads) gen_heev_kernel(GenHeev g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* A = reinterpret_cast<double*>(smem);     // [DP][DP][2]
+  double* A2 = A + DP * DP * 2;
+  double* V = A2 + DP * DP * 2;
+  double* V2 = V + DP * DP * 2;
+  double* rot = V2 + DP * DP * 2;                  // [DP][3]: c, (s u) re, im of the pair of index x
+  double* red = rot + DP * 3;                      // [kGenWaves]
+  int* part = reinterpret_cast<int*>(red + kGenWaves);  // [DP] partner of x in this round
+  const int tid = threadIdx.x;
+  const int64_t n = blockIdx.x;
+  const int D = g.D;
+  const int N = D + (D & 1);  // tournament size (even)
+  int st = 0;
+  // load (Hermitian from the upper triangle, like numpy's default UPLO='L' on the C-order
+  // array == LAPACK upper of the transpose; both halves agree for the covariances used here)
+  double tr = 0.0;
+  for (int e = tid; e < DP * DP; e += kGenThreads) {
+    const int i = e / DP, j = e - i * DP;
+    double re = 0.0, im = 0.0;
+    if (i < D && j < D) {
+      const int lo = i < j ? j : i, hi = i < j ? i : j;  // read the LOWER triangle entry (lo,hi)
+      const double* p = g.a + (((size_t)n * D + lo) * D + hi) * 2;
+      re = p[0];
+      im = (i == j) ? 0.0 : ((i > j) ? p[1] : -p[1]);
+      if (i == j) tr += re;
+    }
+    A[e * 2] = re;
+    A[e * 2 + 1] = im;
+    V[e * 2] = (i == j) ? 1.0 : 0.0;
+    V[e * 2 + 1] = 0.0;
+  }
+  tr = block_sum(tr, red, tid);
+  if (g.covariance_norm == PBBSS_COVNORM_TRACE) {  // cacg.py:88-90
+    const double it = 1.0 / fmax(tr, kTiny);
+    __syncthreads();
+    for (int e = tid; e < DP * DP * 2; e += kGenThreads) A[e] *= it;
+  }
+  __syncthreads();
+  double fro2 = 0.0;
+  for (int e = tid; e < DP * DP; e += kGenThreads) fro2 += A[e * 2] * A[e * 2] + A[e * 2 + 1] * A[e * 2 + 1];
+  fro2 = block_sum(fro2, red, tid);
+  if (!isfinite(fro2)) st |= PBBSS_ST_NONFINITE;
+  int sweeps = -1;
+  if (!(fro2 > 0.0) || (st & PBBSS_ST_NONFINITE)) sweeps = 0;
+  for (int sweep = 0; sweeps < 0 && sweep < kGenMaxSweeps; ++sweep) {
+    double off2 = 0.0;
+    for (int e = tid; e < DP * DP; e += kGenThreads) {
+      const int i = e / DP, j = e - i * DP;
+      if (i != j) off2 += A[e * 2] * A[e * 2] + A[e * 2 + 1] * A[e * 2 + 1];
+    }
+    off2 = block_sum(off2, red, tid);
+    if (off2 <= kGenJacobiTol * fro2) {
+      sweeps = sweep;
+      break;
+    }
+    for (int r = 0; r < N - 1; ++r) {
+      // circle method: partner of x in round r
+      if (tid < DP) {
+        int x = tid, y;
+        if (x >= N) y = x;
+        else if (x == N - 1) y = r;
+        else if (x == r) y = N - 1;
+        else {
+          y = (2 * r - x) % (N - 1);
+          if (y < 0) y += N - 1;
+        }
+        part[x] = y;
+        // the smaller index of a live pair computes the rotation for both
+        const int p = x < y ? x : y, q = x < y ? y : x;
+        if (x == p) {
+          double c = 1.0, sr = 0.0, si = 0.0;
+          if (p != q && q < D) {
+            const double app = A[(p * DP + p) * 2], aqq = A[(q * DP + q) * 2];
+            const double xr = A[(p * DP + q) * 2], xi = A[(p * DP + q) * 2 + 1];
+            const double g2 = xr * xr + xi * xi;
+            const double d = aqq - app;
+            const double h2 = fma(d, d, 4.0 * g2);
+            if (g2 > 0.0 && h2 < 1.79e308) {
+              const double rh = fast_rsqrt(h2);
+              const double c2 = fma(0.5 * fabs(d), rh, 0.5);
+              const double rc = fast_rsqrt(c2);
+              c = c2 * rc;
+              const double ig = ((d < 0.0) ? -rh : rh) * rc;
+              sr = xr * ig;
+              si = xi * ig;
+            }
+          }
+          rot[p * 3] = c;
+          rot[p * 3 + 1] = sr;
+          rot[p * 3 + 2] = si;
+          if (q != p && q < DP) {
+            rot[q * 3] = c;
+            rot[q * 3 + 1] = sr;
+            rot[q * 3 + 2] = si;
+          }
+        }
+      }
+      __syncthreads();
+      // rows: B = J^H A   (row p' = c A_p - (s u) A_q ; row q' = conj(s u) A_p + c A_q)
+      for (int e = tid; e < DP * DP; e += kGenThreads) {
+        const int i = e / DP, j = e - i * DP;
+        const int pi = part[i];
+        const double c = rot[i * 3], sr = rot[i * 3 + 1], si = rot[i * 3 + 2];
+        const double ar = A[e * 2], ai = A[e * 2 + 1];
+        const double orr = A[(pi * DP + j) * 2], oii = A[(pi * DP + j) * 2 + 1];
+        double nr, ni;
+        if (i < pi) {
+          nr = c * ar - (sr * orr - si * oii);
+          ni = c * ai - (sr * oii + si * orr);
+        } else if (i > pi) {
+          nr = c * ar + (sr * orr + si * oii);
+          ni = c * ai + (sr * oii - si * orr);
+        } else {
+          nr = ar;
+          ni = ai;
+        }
+        A2[e * 2] = nr;
+        A2[e * 2 + 1] = ni;
+      }
+      __syncthreads();
+      // columns: A' = B J, V' = V J   (col p' = c B_p - conj(s u) B_q ; col q' = (s u) B_p + c B_q)
+      for (int e = tid; e < DP * DP; e += kGenThreads) {
+        const int i = e / DP, j = e - i * DP;
+        const int pj = part[j];
+        const double c = rot[j * 3], sr = rot[j * 3 + 1], si = rot[j * 3 + 2];
+        const double ar = A2[e * 2], ai = A2[e * 2 + 1];
+        const double orr = A2[(i * DP + pj) * 2], oii = A2[(i * DP + pj) * 2 + 1];
+        const double vr = V[e * 2], vi = V[e * 2 + 1];
+        const double wr = V[(i * DP + pj) * 2], wi = V[(i * DP + pj) * 2 + 1];
+        double nr, ni, xr, xi;
+        if (j < pj) {
+          nr = c * ar - (sr * orr + si * oii);
+          ni = c * ai - (sr * oii - si * orr);
+          xr = c * vr - (sr * wr + si * wi);
+          xi = c * vi - (sr * wi - si * wr);
+        } else if (j > pj) {
+          nr = c * ar + (sr * orr - si * oii);
+          ni = c * ai + (sr * oii + si * orr);
+          xr = c * vr + (sr * wr - si * wi);
+          xi = c * vi + (sr * wi + si * wr);
+        } else {
+          nr = ar;
+          ni = ai;
+          xr = vr;
+          xi = vi;
+        }
+        if (i == j) ni = 0.0;
+        A[e * 2] = nr;
+        A[e * 2 + 1] = ni;
+        V2[e * 2] = xr;
+        V2[e * 2 + 1] = xi;
+      }
+      __syncthreads();
+      for (int e = tid; e < DP * DP * 2; e += kGenThreads) V[e] = V2[e];
+      __syncthreads();
+    }
+  }
+  if (sweeps < 0) {
+    double off2 = 0.0;
+    for (int e = tid; e < DP * DP; e += kGenThreads) {
+      const int i = e / DP, j = e - i * DP;
+      if (i != j) off2 += A[e * 2] * A[e * 2] + A[e * 2 + 1] * A[e * 2 + 1];
+    }
+    off2 = block_sum(off2, red, tid);
+    if (!(off2 <= kGenJacobiTolLoose * fro2)) st |= PBBSS_ST_EIG_NOCONV;
+  }
+  __syncthreads();
+  // eigenvalues -> rank (ascending, ties by index), normalisation and floor, outputs
+  double* lam = A2;          // reuse: [DP] eigenvalues, [DP] processed
+  int* rank = part;          // reuse
+  if (tid < D) lam[tid] = A[(tid * DP + tid) * 2];
+  __syncthreads();
+  if (tid < D) {
+    const double l = lam[tid];
+    int rk = 0;
+    double lmax = -1.79e308;
+    for (int m = 0; m < D; ++m) {
+      const double lm = lam[m];
+      rk += (lm < l || (lm == l && m < tid)) ? 1 : 0;
+      lmax = fmax(lmax, lm);
+    }
+    double lout = l;
+    if (g.covariance_norm == PBBSS_COVNORM_EIGENVALUE) {  // cacg.py:112-121
+      lout = l / fmax(lmax, kTiny);
+      if (lout < g.eig_floor) {
+        lout = g.eig_floor;
+        st |= PBBSS_ST_FLOORED;
+      }
+    } else if (g.covariance_norm >= 0) {                   // cacg.py:122-126
+      const double fl = lmax * g.eig_floor;
+      if (lout < fl) {
+        lout = fl;
+        st |= PBBSS_ST_FLOORED;
+      }
+    }
+    if (!isfinite(lout)) st |= PBBSS_ST_NONFINITE;
+    rank[tid] = rk;
+    g.out_val[(size_t)n * D + rk] = lout;
+  }
+  __syncthreads();
+  for (int e = tid; e < DP * DP; e += kGenThreads) {
+    const int i = e / DP, j = e - i * DP;
+    if (i < D && j < D) {
+      double* o = g.out_vec + (((size_t)n * D + i) * D + rank[j]) * 2;
+      o[0] = V[e * 2];
+      o[1] = V[e * 2 + 1];
+    }
+  }
+  if (g.out_status) {
+    // OR of the per-thread status words
+    __shared__ int sst;
+    if (tid == 0) sst = 0;
+    __syncthreads();
+    if (st) atomicOr(&sst, st);
+    __syncthreads();
+    if (tid == 0) g.out_status[n] = sst;
+  }
+}
+
+inline int ok_or_hip() { return hipGetLastError() == hipSuccess ? PBBSS_OK : PBBSS_ERR_HIP; }
+
+template <typename KFN>
+int set_lds(KFN kfn, size_t lds, size_t lds_limit) {
+  if (lds > lds_limit) return PBBSS_ERR_LDS_CAPACITY;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return PBBSS_ERR_HIP;
+  return PBBSS_OK;
+}
+
+}  // namespace
+
+bool gen_supported(int D, int K) { return D >= 2 && D <= kGenMaxD && K >= 1 && K <= kGenMaxK; }
+
+int launch_gen_estep(const void* y, int y_is_c128, int layout, int64_t B, int T, int D, int K,
+                     const double* eigvec, const double* eigval, const double* weight, int64_t wb,
+                     int64_t wk, int64_t wt, const uint8_t* activity, double eps, double* out_aff,
+                     double* out_q, double* out_logpdf, size_t lds_limit, hipStream_t s) {
+  if (!gen_supported(D, K)) return PBBSS_ERR_UNSUPPORTED;
+  GenEstep a{y, layout, B, T, D, K, eigvec, eigval, weight, wb, wk, wt, activity, eps,
+             out_aff, out_q, out_logpdf};
+  const int DP = D <= 16 ? 16 : 32;
+  const size_t lds = ((size_t)K * DP * DP * 2 + K) * sizeof(double);
+  int rc;
+#define PBBSS_GEN_E(DPV, YST)                                                              \
+  {                                                                                        \
+    auto kfn = gen_estep_kernel<DPV, YST>;                                                 \
+    if ((rc = set_lds(kfn, lds, lds_limit)) != PBBSS_OK) return rc;                        \
+    hipLaunchKernelGGL(kfn, dim3((unsigned)B), dim3(kGenThreads), lds, s, a);              \
+  }
+  if (DP == 16) {
+    if (y_is_c128) PBBSS_GEN_E(16, double) else PBBSS_GEN_E(16, float)
+  } else {
+    if (y_is_c128) PBBSS_GEN_E(32, double) else PBBSS_GEN_E(32, float)
+  }
+#undef PBBSS_GEN_E
+  return ok_or_hip();
+}
+
+int launch_gen_cov(const void* y, int y_is_c128, int layout, int64_t B, int T, int D, int K,
+                   const double* gamma, int64_t gamma_bstride, const double* q,
+                   const double* saliency, int mode, int weight_mode, double* out_cov,
+                   double* out_weight, double* out_sum, size_t lds_limit, hipStream_t s) {
+  if (!gen_supported(D, K)) return PBBSS_ERR_UNSUPPORTED;
+  GenCov a{y, layout, B, T, D, K, gamma, gamma_bstride, q, saliency, mode, weight_mode,
+           out_cov, out_weight, out_sum};
+  const int DP = D <= 16 ? 16 : 32;
+  const size_t lds =
+      ((size_t)kTile * DP * 2 + (size_t)kGenMaxK * kTile + kGenWaves + kGenMaxK) * sizeof(double);
+  int rc;
+#define PBBSS_GEN_C(DPV, YST)                                                              \
+  {                                                                                        \
+    auto kfn = gen_cov_kernel<DPV, YST>;                                                   \
+    if ((rc = set_lds(kfn, lds, lds_limit)) != PBBSS_OK) return rc;                        \
+    hipLaunchKernelGGL(kfn, dim3((unsigned)B), dim3(kGenThreads), lds, s, a);              \
+  }
+  if (DP == 16) {
+    if (y_is_c128) PBBSS_GEN_C(16, double) else PBBSS_GEN_C(16, float)
+  } else {
+    if (y_is_c128) PBBSS_GEN_C(32, double) else PBBSS_GEN_C(32, float)
+  }
+#undef PBBSS_GEN_C
+  return ok_or_hip();
+}
+
+int launch_gen_heev(const double* a, int64_t N, int D, int covariance_norm, double eig_floor,
+                    double* out_val, double* out_vec, int32_t* out_status, size_t lds_limit,
+                    hipStream_t s) {
+  if (D < 2 || D > kGenMaxD) return PBBSS_ERR_UNSUPPORTED;
+  GenHeev g{a, N, D, covariance_norm, eig_floor, out_val, out_vec, out_status};
+  const int DP = D <= 16 ? 16 : 32;
+  const size_t lds = ((size_t)4 * DP * DP * 2 + DP * 3 + kGenWaves) * sizeof(double) + DP * sizeof(int);
+  int rc;
+  if (DP == 16) {
+    auto kfn = gen_heev_kernel<16>;
+    if ((rc = set_lds(kfn, lds, lds_limit)) != PBBSS_OK) return rc;
+    hipLaunchKernelGGL(kfn, dim3((unsigned)N), dim3(kGenThreads), lds, s, g);
+  } else {
+    auto kfn = gen_heev_kernel<32>;
+    if ((rc = set_lds(kfn, lds, lds_limit)) != PBBSS_OK) return rc;
+    hipLaunchKernelGGL(kfn, dim3((unsigned)N), dim3(kGenThreads), lds, s, g);
+  }
+  return ok_or_hip();
+}
+
+}  // namespace pbbss
