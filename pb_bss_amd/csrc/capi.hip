@@ -7,6 +7,7 @@
 #include "dhtv.hpp"
 #include "embed.hpp"
 #include "generic.hpp"
+#include "generic_bf.hpp"
 #include "em_launch.hpp"
 
 #define PBBSS_API extern "C" __attribute__((visibility("default")))
@@ -523,6 +524,11 @@ PBBSS_API int pbbss_gev(pbbss_handle_t h, const void* target, const void* noise,
                         int D, void* out_w, int32_t* out_status, void* stream) {
   DeviceGuard device_guard(h);
   if (!h || !target || !noise || !out_w || N <= 0) return PBBSS_ERR_INVALID_ARG;
+  if (D > 8)
+    return pbbss::launch_gen_gev(static_cast<const double*>(target),
+                                 static_cast<const double*>(noise), N, D,
+                                 static_cast<double*>(out_w), out_status, h->cfg.lds_limit,
+                                 as_stream(stream));
   return pbbss::launch_gev(static_cast<const double*>(target), static_cast<const double*>(noise),
                            N, D, static_cast<double*>(out_w), out_status, as_stream(stream));
 }
@@ -531,6 +537,10 @@ PBBSS_API int pbbss_solve(pbbss_handle_t h, const void* A, const void* Bm, int64
                           int M, void* out_x, int32_t* out_status, void* stream) {
   DeviceGuard device_guard(h);
   if (!h || !A || !Bm || !out_x || N <= 0 || M <= 0) return PBBSS_ERR_INVALID_ARG;
+  if (D > 8)
+    return pbbss::launch_gen_solve(static_cast<const double*>(A), static_cast<const double*>(Bm),
+                                   N, D, M, static_cast<double*>(out_x), out_status,
+                                   h->cfg.lds_limit, as_stream(stream));
   if (M > 8) return PBBSS_ERR_UNSUPPORTED;
   return pbbss::launch_solve(static_cast<const double*>(A), static_cast<const double*>(Bm), N, D,
                              M, static_cast<double*>(out_x), out_status, as_stream(stream));
@@ -541,6 +551,13 @@ PBBSS_API int pbbss_mvdr_souden(pbbss_handle_t h, const void* target, const void
                                 void* out_snr_den, int32_t* out_status, void* stream) {
   DeviceGuard device_guard(h);
   if (!h || !target || !noise || !out_mat || N <= 0) return PBBSS_ERR_INVALID_ARG;
+  if (D > 8)
+    return pbbss::launch_gen_souden(static_cast<const double*>(target),
+                                    static_cast<const double*>(noise), N, D, eps, 0,
+                                    static_cast<double*>(out_mat),
+                                    static_cast<double*>(out_snr_num),
+                                    static_cast<double*>(out_snr_den), out_status,
+                                    h->cfg.lds_limit, as_stream(stream));
   return pbbss::launch_mvdr_souden(static_cast<const double*>(target),
                                    static_cast<const double*>(noise), N, D, eps, 0,
                                    static_cast<double*>(out_mat),
@@ -553,6 +570,11 @@ PBBSS_API int pbbss_mvdr(pbbss_handle_t h, const void* atf, const void* noise, i
                          void* out_w, int32_t* out_status, void* stream) {
   DeviceGuard device_guard(h);
   if (!h || !atf || !noise || !out_w || N <= 0) return PBBSS_ERR_INVALID_ARG;
+  if (D > 8)
+    return pbbss::launch_gen_mvdr(static_cast<const double*>(atf),
+                                  static_cast<const double*>(noise), N, D,
+                                  static_cast<double*>(out_w), out_status, h->cfg.lds_limit,
+                                  as_stream(stream));
   return pbbss::launch_mvdr(static_cast<const double*>(atf), static_cast<const double*>(noise), N,
                             D, static_cast<double*>(out_w), out_status, as_stream(stream));
 }
@@ -561,6 +583,9 @@ PBBSS_API int pbbss_ban(pbbss_handle_t h, const void* w, const void* noise, int6
                         void* out_w, void* stream) {
   DeviceGuard device_guard(h);
   if (!h || !w || !noise || !out_w || N <= 0) return PBBSS_ERR_INVALID_ARG;
+  if (D > 8)
+    return pbbss::launch_gen_ban(static_cast<const double*>(w), static_cast<const double*>(noise),
+                                 N, D, static_cast<double*>(out_w), as_stream(stream));
   return pbbss::launch_ban(static_cast<const double*>(w), static_cast<const double*>(noise), N, D,
                            static_cast<double*>(out_w), as_stream(stream));
 }
@@ -659,6 +684,13 @@ PBBSS_API int pbbss_wmwf(pbbss_handle_t h, const void* target, const void* noise
                          void* stream) {
   DeviceGuard device_guard(h);
   if (!h || !target || !noise || !out_mat || N <= 0) return PBBSS_ERR_INVALID_ARG;
+  if (D > 8)
+    return pbbss::launch_gen_souden(static_cast<const double*>(target),
+                                    static_cast<const double*>(noise), N, D, distortion_weight,
+                                    frequency_dependent ? 2 : 1, static_cast<double*>(out_mat),
+                                    static_cast<double*>(out_snr_num),
+                                    static_cast<double*>(out_snr_den), out_status,
+                                    h->cfg.lds_limit, as_stream(stream));
   return pbbss::launch_mvdr_souden(static_cast<const double*>(target),
                                    static_cast<const double*>(noise), N, D, distortion_weight,
                                    frequency_dependent ? 2 : 1, static_cast<double*>(out_mat),

@@ -15,25 +15,16 @@
 // Float64 arithmetic throughout, as the D <= 8 path.
 #include "generic.hpp"
 #include <cmath>
-#include "pbbss_dev.hpp"
+#include "generic_dev.hpp"
 
 namespace pbbss {
 namespace {
 
-constexpr int kGenThreads = 256;
-constexpr int kGenWaves = kGenThreads / kWave;
 constexpr int kGenMaxK = 6;
 constexpr int kTile = 32;  // frames per LDS tile of gen_cov
 
 __device__ __forceinline__ double block_sum(double v, double* red, int tid) {
-  v = wave_sum(v);
-  __syncthreads();
-  if ((tid & 63) == 0) red[tid >> 6] = v;
-  __syncthreads();
-  double s = 0.0;
-#pragma unroll
-  for (int w = 0; w < kGenWaves; ++w) s += red[w];
-  return s;
+  return gen_block_sum(v, red, tid);
 }
 
 template <typename YS>
@@ -319,9 +310,6 @@ struct GenHeev {
   int32_t* out_status;  // (N) or null
 };
 
-constexpr int kGenMaxSweeps = 30;
-constexpr double kGenJacobiTol = 1e-29;
-constexpr double kGenJacobiTolLoose = 1e-24;
 
 template <int DP>
 __global__ void __launch_bounds__(kGenThreads) gen_heev_kernel(GenHeev g) {
@@ -367,130 +355,8 @@ __global__ void __launch_bounds__(kGenThreads) gen_heev_kernel(GenHeev g) {
   for (int e = tid; e < DP * DP; e += kGenThreads) fro2 += A[e * 2] * A[e * 2] + A[e * 2 + 1] * A[e * 2 + 1];
   fro2 = block_sum(fro2, red, tid);
   if (!isfinite(fro2)) st |= PBBSS_ST_NONFINITE;
-  int sweeps = -1;
-  if (!(fro2 > 0.0) || (st & PBBSS_ST_NONFINITE)) sweeps = 0;
-  for (int sweep = 0; sweeps < 0 && sweep < kGenMaxSweeps; ++sweep) {
-    double off2 = 0.0;
-    for (int e = tid; e < DP * DP; e += kGenThreads) {
-      const int i = e / DP, j = e - i * DP;
-      if (i != j) off2 += A[e * 2] * A[e * 2] + A[e * 2 + 1] * A[e * 2 + 1];
-    }
-    off2 = block_sum(off2, red, tid);
-    if (off2 <= kGenJacobiTol * fro2) {
-      sweeps = sweep;
-      break;
-    }
-    for (int r = 0; r < N - 1; ++r) {
-      // circle method: partner of x in round r
-      if (tid < DP) {
-        int x = tid, y;
-        if (x >= N) y = x;
-        else if (x == N - 1) y = r;
-        else if (x == r) y = N - 1;
-        else {
-          y = (2 * r - x) % (N - 1);
-          if (y < 0) y += N - 1;
-        }
-        part[x] = y;
-        // the smaller index of a live pair computes the rotation for both
-        const int p = x < y ? x : y, q = x < y ? y : x;
-        if (x == p) {
-          double c = 1.0, sr = 0.0, si = 0.0;
-          if (p != q && q < D) {
-            const double app = A[(p * DP + p) * 2], aqq = A[(q * DP + q) * 2];
-            const double xr = A[(p * DP + q) * 2], xi = A[(p * DP + q) * 2 + 1];
-            const double g2 = xr * xr + xi * xi;
-            const double d = aqq - app;
-            const double h2 = fma(d, d, 4.0 * g2);
-            if (g2 > 0.0 && h2 < 1.79e308) {
-              const double rh = fast_rsqrt(h2);
-              const double c2 = fma(0.5 * fabs(d), rh, 0.5);
-              const double rc = fast_rsqrt(c2);
-              c = c2 * rc;
-              const double ig = ((d < 0.0) ? -rh : rh) * rc;
-              sr = xr * ig;
-              si = xi * ig;
-            }
-          }
-          rot[p * 3] = c;
-          rot[p * 3 + 1] = sr;
-          rot[p * 3 + 2] = si;
-          if (q != p && q < DP) {
-            rot[q * 3] = c;
-            rot[q * 3 + 1] = sr;
-            rot[q * 3 + 2] = si;
-          }
-        }
-      }
-      __syncthreads();
-      // rows: B = J^H A   (row p' = c A_p - (s u) A_q ; row q' = conj(s u) A_p + c A_q)
-      for (int e = tid; e < DP * DP; e += kGenThreads) {
-        const int i = e / DP, j = e - i * DP;
-        const int pi = part[i];
-        const double c = rot[i * 3], sr = rot[i * 3 + 1], si = rot[i * 3 + 2];
-        const double ar = A[e * 2], ai = A[e * 2 + 1];
-        const double orr = A[(pi * DP + j) * 2], oii = A[(pi * DP + j) * 2 + 1];
-        double nr, ni;
-        if (i < pi) {
-          nr = c * ar - (sr * orr - si * oii);
-          ni = c * ai - (sr * oii + si * orr);
-        } else if (i > pi) {
-          nr = c * ar + (sr * orr + si * oii);
-          ni = c * ai + (sr * oii - si * orr);
-        } else {
-          nr = ar;
-          ni = ai;
-        }
-        A2[e * 2] = nr;
-        A2[e * 2 + 1] = ni;
-      }
-      __syncthreads();
-      // columns: A' = B J, V' = V J   (col p' = c B_p - conj(s u) B_q ; col q' = (s u) B_p + c B_q)
-      for (int e = tid; e < DP * DP; e += kGenThreads) {
-        const int i = e / DP, j = e - i * DP;
-        const int pj = part[j];
-        const double c = rot[j * 3], sr = rot[j * 3 + 1], si = rot[j * 3 + 2];
-        const double ar = A2[e * 2], ai = A2[e * 2 + 1];
-        const double orr = A2[(i * DP + pj) * 2], oii = A2[(i * DP + pj) * 2 + 1];
-        const double vr = V[e * 2], vi = V[e * 2 + 1];
-        const double wr = V[(i * DP + pj) * 2], wi = V[(i * DP + pj) * 2 + 1];
-        double nr, ni, xr, xi;
-        if (j < pj) {
-          nr = c * ar - (sr * orr + si * oii);
-          ni = c * ai - (sr * oii - si * orr);
-          xr = c * vr - (sr * wr + si * wi);
-          xi = c * vi - (sr * wi - si * wr);
-        } else if (j > pj) {
-          nr = c * ar + (sr * orr - si * oii);
-          ni = c * ai + (sr * oii + si * orr);
-          xr = c * vr + (sr * wr - si * wi);
-          xi = c * vi + (sr * wi + si * wr);
-        } else {
-          nr = ar;
-          ni = ai;
-          xr = vr;
-          xi = vi;
-        }
-        if (i == j) ni = 0.0;
-        A[e * 2] = nr;
-        A[e * 2 + 1] = ni;
-        V2[e * 2] = xr;
-        V2[e * 2 + 1] = xi;
-      }
-      __syncthreads();
-      for (int e = tid; e < DP * DP * 2; e += kGenThreads) V[e] = V2[e];
-      __syncthreads();
-    }
-  }
-  if (sweeps < 0) {
-    double off2 = 0.0;
-    for (int e = tid; e < DP * DP; e += kGenThreads) {
-      const int i = e / DP, j = e - i * DP;
-      if (i != j) off2 += A[e * 2] * A[e * 2] + A[e * 2 + 1] * A[e * 2 + 1];
-    }
-    off2 = block_sum(off2, red, tid);
-    if (!(off2 <= kGenJacobiTolLoose * fro2)) st |= PBBSS_ST_EIG_NOCONV;
-  }
+  const GenJacobiScratch scratch{A2, V2, rot, red, part};
+  if (lds_jacobi_heev(A, V, scratch, D, DP, tid) < 0) st |= PBBSS_ST_EIG_NOCONV;
   __syncthreads();
   // eigenvalues -> rank (ascending, ties by index), normalisation and floor, outputs
   double* lam = A2;          // reuse: [DP] eigenvalues, [DP] processed

@@ -87,3 +87,66 @@ def test_psd_and_pca_for_many_sensors():
     np.testing.assert_allclose(cs, 1.0, atol=1e-10)
     s = ex.apply_beamforming_vector(w, X)
     np.testing.assert_allclose(s, ob.apply_bf(w, X128), atol=1e-10)
+
+
+def _psd(rng, F, D, rank=None):
+    r = 2 * D if rank is None else rank
+    a = rng.standard_normal((F, D, r)) + 1j * rng.standard_normal((F, D, r))
+    return a @ a.conj().swapaxes(-1, -2) / r
+
+
+def _cos(a, b):
+    return np.abs(np.einsum('...d,...d->...', a.conj(), b)) / (
+        np.linalg.norm(a, axis=-1) * np.linalg.norm(b, axis=-1))
+
+
+@pytest.mark.parametrize('D', [9, 16, 24, 32])
+def test_beamformers_for_many_sensors(D):
+    from oracle import beamformer as ob
+    from pb_bss_amd import extraction as ex
+    rng = np.random.default_rng(D)
+    F = 11
+    target, noise = _psd(rng, F, D), _psd(rng, F, D) + 0.05 * np.eye(D)
+    # GEV: same eigenvector up to phase, normalised w^H N w = 1
+    w = ex.get_gev_vector(target, noise)
+    np.testing.assert_allclose(_cos(w, ob.gev_vector(target, noise)), 1.0, atol=1e-9)
+    np.testing.assert_allclose(np.einsum('fd,fde,fe->f', w.conj(), noise, w).real, 1.0, atol=1e-9)
+    # MVDR-Souden with automatic and fixed reference channel, wMWF, MVDR, BAN, stable_solve
+    np.testing.assert_allclose(ex.get_mvdr_vector_souden(target, noise),
+                               ob.mvdr_souden(target, noise), rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(ex.get_mvdr_vector_souden(target, noise, ref_channel=D - 1),
+                               ob.mvdr_souden(target, noise, ref_channel=D - 1), rtol=1e-8,
+                               atol=1e-10)
+    np.testing.assert_allclose(ex.get_wmwf_vector(target, noise, reference_channel=0),
+                               ob.wmwf(target, noise, reference_channel=0), rtol=1e-8, atol=1e-10)
+    atf = ob.pca_vector(target)
+    np.testing.assert_allclose(ex.get_mvdr_vector(atf, noise), ob.mvdr(atf, noise), rtol=1e-8,
+                               atol=1e-10)
+    np.testing.assert_allclose(ex.blind_analytic_normalization(w, noise), ob.ban(w, noise),
+                               rtol=1e-10, atol=1e-12)
+    B = rng.standard_normal((F, D, 3)) + 1j * rng.standard_normal((F, D, 3))
+    np.testing.assert_allclose(ex.stable_solve(noise, B), np.linalg.solve(noise, B), rtol=1e-8,
+                               atol=1e-10)
+    # the dispatcher end to end
+    wb = ex.get_bf_vector('gev+ban', target, noise)
+    np.testing.assert_allclose(_cos(wb, ob.bf_vector('gev+ban', target, noise)), 1.0, atol=1e-9)
+
+
+def test_singular_noise_takes_least_squares_branch_for_many_sensors():
+    from oracle import beamformer as ob
+    from pb_bss_amd import extraction as ex
+    rng = np.random.default_rng(3)
+    F, D = 5, 12
+    target = _psd(rng, F, D)
+    noise = _psd(rng, F, D)
+    noise[2] = 0                                  # silent bin: exactly singular
+    B = rng.standard_normal((F, D, 2)) + 1j * rng.standard_normal((F, D, 2))
+    got = ex.stable_solve(noise, B)
+    np.testing.assert_allclose(got, ob.stable_solve(noise, B), rtol=1e-8, atol=1e-10)
+    assert np.abs(got[2]).max() == 0.0            # lstsq of a zero system: minimum norm = 0
+    w = ex.get_mvdr_vector_souden(target, noise, ref_channel=1)
+    np.testing.assert_allclose(w, ob.mvdr_souden(target, noise, ref_channel=1), rtol=1e-8,
+                               atol=1e-10)
+    # GEV on a non-positive-definite noise matrix: ValueError like the Cython path
+    with pytest.raises(ValueError):
+        ex.get_gev_vector(target, noise)
