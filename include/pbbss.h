@@ -64,6 +64,12 @@ const char* pbbss_error_string(int code);
  * threads at the same time (create one per thread, as pb_bss_amd/_lib.py does).  PBBSS_DEBUG
  * in the environment makes pbbss_create report failing HIP calls on stderr. */
 int pbbss_create(pbbss_handle_t* out, int device_id);
+/* Shape range.  2 <= D <= 8 sensors: the fused kernels (one wavefront per D x D matrix; the
+ * whole cACGMM EM loop in one persistent launch).  9 <= D <= 32: the same entry points
+ * (pbbss_cacgmm_fit / _predict, pbbss_cacg_m_step, pbbss_heev_batched, pbbss_psd, pbbss_gev,
+ * pbbss_solve, pbbss_mvdr_souden, pbbss_wmwf, pbbss_mvdr, pbbss_ban) run a generic-size path
+ * (one workgroup per matrix, matrices in LDS; the EM loop enqueues three kernels per iteration;
+ * layout TD only for the fit).  1 <= K <= 6 classes.  Watson / joint models and LCMV: D <= 8. */
 int pbbss_destroy(pbbss_handle_t h);
 
 /* ------------------------------------------------------------------------- */
@@ -168,7 +174,7 @@ int pbbss_cacg_m_step(pbbss_handle_t h, const void* y, int64_t B, int T, int D,
 /* ------------------------------------------------------------------------- */
 /* Batched Hermitian eigendecomposition (numpy.linalg.eigh as used at          */
 /* cacg.py:95 and extraction/beamformer.py:180).  a c128 (N,D,D) -> eigenvalues */
-/* ascending f64 (N,D), eigenvectors c128 (N,D,D) in columns.  D <= 8.         */
+/* ascending f64 (N,D), eigenvectors c128 (N,D,D) in columns.  D <= 32.        */
 /* ------------------------------------------------------------------------- */
 int pbbss_heev_batched(pbbss_handle_t h, const void* a, int64_t N, int D,
                        double* out_eigval, void* out_eigvec,

@@ -144,7 +144,8 @@ PBBSS_API const char* pbbss_error_string(int code) {
     case PBBSS_OK: return "ok";
     case PBBSS_ERR_INVALID_ARG: return "invalid argument";
     case PBBSS_ERR_UNSUPPORTED:
-      return "shape not covered by the compiled kernels (need 2 <= D <= 8, 1 <= K <= 6)";
+      return "shape not covered by the compiled kernels (need 2 <= D <= 32 sensors -- 8 for the "
+             "Watson / joint models and LCMV -- and 1 <= K <= 6 classes)";
     case PBBSS_ERR_HIP: return "HIP runtime error";
     case PBBSS_ERR_LDS_CAPACITY:
       return "observation does not fit the LDS-resident EM kernel (too many frames)";
