@@ -58,6 +58,10 @@ __device__ inline int lds_jacobi_heev(double* A, double* V, const GenJacobiScrat
   fro2 = gen_block_sum(fro2, S.red, tid);
   if (!(fro2 > 0.0) || !isfinite(fro2)) return 0;
   int sweeps = -1;
+  double* Vc = V;      // current eigenvector estimate
+  double* Vn = S.V2;   // next
+  for (int e = tid; e < LD * LD * 2; e += kGenThreads) S.V2[e] = V[e];  // identity padding in both
+  __syncthreads();
   for (int sweep = 0; sweep < kGenMaxSweeps; ++sweep) {
     double off2 = 0.0;
     for (int e = tid; e < LD * LD; e += kGenThreads) {
@@ -111,15 +115,18 @@ __device__ inline int lds_jacobi_heev(double* A, double* V, const GenJacobiScrat
         }
       }
       __syncthreads();
-      // rows: B = J^H A
-      for (int e = tid; e < LD * LD; e += kGenThreads) {
-        const int i = e / LD, j = e - i * LD;
+      // rows: B = J^H A   (only the D x D block is live; the padding stays zero)
+      for (int e0 = tid; e0 < D * D; e0 += kGenThreads) {
+        const int i = e0 / D, j = e0 - i * D;
+        const int e = i * LD + j;
         const int pi = S.part[i];
         const double c = S.rot[i * 3], sr = S.rot[i * 3 + 1], si = S.rot[i * 3 + 2];
         const double ar = A[e * 2], ai = A[e * 2 + 1];
         const double orr = A[(pi * LD + j) * 2], oii = A[(pi * LD + j) * 2 + 1];
         double nr = ar, ni = ai;
-        if (i < pi) {
+        if (pi >= D) {
+          // partner is the dummy index of an odd-sized tournament: identity
+        } else if (i < pi) {
           nr = c * ar - (sr * orr - si * oii);
           ni = c * ai - (sr * oii + si * orr);
         } else if (i > pi) {
@@ -130,17 +137,20 @@ __device__ inline int lds_jacobi_heev(double* A, double* V, const GenJacobiScrat
         S.A2[e * 2 + 1] = ni;
       }
       __syncthreads();
-      // columns: A' = B J, V' = V J
-      for (int e = tid; e < LD * LD; e += kGenThreads) {
-        const int i = e / LD, j = e - i * LD;
+      // columns: A' = B J, V' = V J   (V ping-pongs between the two buffers)
+      for (int e0 = tid; e0 < D * D; e0 += kGenThreads) {
+        const int i = e0 / D, j = e0 - i * D;
+        const int e = i * LD + j;
         const int pj = S.part[j];
         const double c = S.rot[j * 3], sr = S.rot[j * 3 + 1], si = S.rot[j * 3 + 2];
         const double ar = S.A2[e * 2], ai = S.A2[e * 2 + 1];
         const double orr = S.A2[(i * LD + pj) * 2], oii = S.A2[(i * LD + pj) * 2 + 1];
-        const double vr = V[e * 2], vi = V[e * 2 + 1];
-        const double wr = V[(i * LD + pj) * 2], wi = V[(i * LD + pj) * 2 + 1];
+        const double vr = Vc[e * 2], vi = Vc[e * 2 + 1];
+        const double wr = Vc[(i * LD + pj) * 2], wi = Vc[(i * LD + pj) * 2 + 1];
         double nr = ar, ni = ai, xr = vr, xi = vi;
-        if (j < pj) {
+        if (pj >= D) {
+          // dummy partner: identity (and A2 / V hold nothing meaningful in that column)
+        } else if (j < pj) {
           nr = c * ar - (sr * orr + si * oii);
           ni = c * ai - (sr * oii - si * orr);
           xr = c * vr - (sr * wr + si * wi);
@@ -154,12 +164,13 @@ __device__ inline int lds_jacobi_heev(double* A, double* V, const GenJacobiScrat
         if (i == j) ni = 0.0;
         A[e * 2] = nr;
         A[e * 2 + 1] = ni;
-        S.V2[e * 2] = xr;
-        S.V2[e * 2 + 1] = xi;
+        Vn[e * 2] = xr;
+        Vn[e * 2 + 1] = xi;
       }
       __syncthreads();
-      for (int e = tid; e < LD * LD * 2; e += kGenThreads) V[e] = S.V2[e];
-      __syncthreads();
+      double* tswap = Vc;
+      Vc = Vn;
+      Vn = tswap;
     }
   }
   if (sweeps < 0) {
@@ -171,6 +182,10 @@ __device__ inline int lds_jacobi_heev(double* A, double* V, const GenJacobiScrat
     off2 = gen_block_sum(off2, S.red, tid);
     if (off2 <= kGenJacobiTolLoose * fro2) sweeps = kGenMaxSweeps;
   }
+  if (Vc != V) {  // an odd number of rounds left the result in the scratch buffer
+    for (int e = tid; e < LD * LD * 2; e += kGenThreads) V[e] = Vc[e];
+  }
+  __syncthreads();
   return sweeps;
 }
 
