@@ -319,41 +319,60 @@ PBBSS_API int pbbss_cacgmm_fit(pbbss_handle_t h, const void* y, int64_t B, int T
     if (o->layout != PBBSS_LAYOUT_TD) return PBBSS_ERR_UNSUPPORTED;
     hipStream_t s = as_stream(stream);
     const size_t nkt = (size_t)B * K * T;
-    const size_t need = 2 * WorkCarver::pad(nkt * 8) + WorkCarver::pad((size_t)B * K * D * D * 16);
+    const size_t nmat = (size_t)B * K;
+    const size_t need = 2 * WorkCarver::pad(nkt * 8) + 2 * WorkCarver::pad(nmat * D * D * 16) +
+                        WorkCarver::pad(nmat * 8) + WorkCarver::pad(nmat * 4) +
+                        WorkCarver::pad((size_t)B * 4);
     void* wmem = handle_work(h, need);
     if (!wmem) return PBBSS_ERR_HIP;
     WorkCarver wc(wmem);
     double* aff = wc.take<double>(nkt);
     double* qf = wc.take<double>(nkt);
-    double* cov = wc.take<double>((size_t)B * K * D * D * 2);
+    double* cov = wc.take<double>(nmat * D * D * 2);
+    double* inv = wc.take<double>(nmat * D * D * 2);
+    double* inv_logdet = wc.take<double>(nmat);
+    int32_t* inv_ok = wc.take<int32_t>(nmat);
+    int32_t* zero_bin = wc.take<int32_t>((size_t)B);
+    const pbbss::GenInverseState state{inv, inv_logdet, inv_ok};
     TimedRegion tr(h, s);
     int rc;
     if (has_model) {
-      if ((rc = copy_d2d(out_eigvec, in_eigvec, (size_t)B * K * D * D * 16, s)) != PBBSS_OK) return rc;
-      if ((rc = copy_d2d(out_eigval, in_eigval, (size_t)B * K * D * 8, s)) != PBBSS_OK) return rc;
-      if ((rc = copy_d2d(out_weight, in_weight, (size_t)B * K * 8, s)) != PBBSS_OK) return rc;
+      if ((rc = copy_d2d(out_eigvec, in_eigvec, nmat * D * D * 16, s)) != PBBSS_OK) return rc;
+      if ((rc = copy_d2d(out_eigval, in_eigval, nmat * D * 8, s)) != PBBSS_OK) return rc;
+      if ((rc = copy_d2d(out_weight, in_weight, nmat * 8, s)) != PBBSS_OK) return rc;
     }
-    if (hipMemsetAsync(out_status, 0, (size_t)B * K * sizeof(int32_t), s) != hipSuccess) return PBBSS_ERR_HIP;
+    if (hipMemsetAsync(out_status, 0, nmat * sizeof(int32_t), s) != hipSuccess) return PBBSS_ERR_HIP;
     for (int it = 0; it < o->iterations; ++it) {
       const double* g_src = gamma0;
       const double* q_src = nullptr;
       if (it > 0 || has_model) {
+        // from the second iteration on, classes whose inverse was accepted skip (V, lambda)
         rc = pbbss::launch_gen_estep(y, o->y_is_c128, PBBSS_LAYOUT_TD, B, T, D, K,
                                      static_cast<const double*>(out_eigvec), out_eigval,
                                      out_weight, K, 1, 0, activity, o->affiliation_eps, aff, qf,
-                                     nullptr, h->cfg.lds_limit, s);
+                                     nullptr, h->cfg.lds_limit, s, it > 0 ? &state : nullptr);
         if (rc != PBBSS_OK) return rc;
         g_src = aff;
         q_src = qf;
       }
       rc = pbbss::launch_gen_cov(y, o->y_is_c128, PBBSS_LAYOUT_TD, B, T, D, K, g_src,
                                  (int64_t)K * T, q_src, saliency, 0, o->weight_mode, cov,
-                                 out_weight, nullptr, h->cfg.lds_limit, s);
+                                 out_weight, nullptr, h->cfg.lds_limit, s, zero_bin);
       if (rc != PBBSS_OK) return rc;
-      // per-(b,k) status of the LAST iteration (earlier ones are overwritten)
+      const bool last = it + 1 == o->iterations;
+      if (!last && !o->force_eig) {
+        rc = pbbss::launch_gen_inverse(cov, B * K, D, o->eigenvalue_floor, inv, inv_logdet, inv_ok,
+                                       s, zero_bin, K);
+        if (rc != PBBSS_OK) return rc;
+      } else if (!last) {
+        if (hipMemsetAsync(inv_ok, 0, nmat * sizeof(int32_t), s) != hipSuccess) return PBBSS_ERR_HIP;
+      }
+      // the eigendecomposition the caller sees comes from the last iteration; before that it
+      // only runs for the matrices the inverse test rejected.  Status words are those of the
+      // last iteration (earlier ones are overwritten).
       rc = pbbss::launch_gen_heev(cov, B * K, D, o->covariance_norm, o->eigenvalue_floor,
                                   out_eigval, static_cast<double*>(out_eigvec), out_status,
-                                  h->cfg.lds_limit, s);
+                                  h->cfg.lds_limit, s, last ? nullptr : inv_ok);
       if (rc != PBBSS_OK) return rc;
     }
     if (o->final_predict && (out_affiliation || out_quadratic_form)) {

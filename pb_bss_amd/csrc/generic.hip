@@ -52,6 +52,7 @@ struct GenEstep {
   double* out_aff;
   double* out_q;
   double* out_logpdf;
+  GenInverseState st;    // all null: every class comes from (eigvec, eigval)
 };
 
 template <int DP, typename YS>
@@ -66,7 +67,12 @@ __global__ void __launch_bounds__(kGenThreads) gen_estep_kernel(GenEstep a) {
   for (int idx = tid; idx < K * DP * DP; idx += kGenThreads) {
     const int k = idx / (DP * DP), r = idx - k * DP * DP, i = r / DP, j = r - i * DP;
     double sr = 0.0, si = 0.0;
-    if (i < D && j < D) {
+    const bool have_inv = a.st.ok && a.st.ok[b * K + k];
+    if (i < D && j < D && have_inv) {
+      const double* p = a.st.inv + ((((size_t)b * K + k) * D + i) * D + j) * 2;
+      sr = p[0];
+      si = p[1];
+    } else if (i < D && j < D) {
       const double* v = a.eigvec + ((size_t)b * K + k) * D * D * 2;
       const double* lam = a.eigval + ((size_t)b * K + k) * D;
       for (int e = 0; e < D; ++e) {
@@ -82,7 +88,11 @@ __global__ void __launch_bounds__(kGenThreads) gen_estep_kernel(GenEstep a) {
   }
   if (tid < K) {
     double s = 0.0;
-    for (int e = 0; e < D; ++e) s += log(a.eigval[((size_t)b * K + tid) * D + e]);
+    if (a.st.ok && a.st.ok[b * K + tid]) {
+      s = a.st.logdet[b * K + tid];
+    } else {
+      for (int e = 0; e < D; ++e) s += log(a.eigval[((size_t)b * K + tid) * D + e]);
+    }
     logdet[tid] = s;  // cacg.py:151
   }
   __syncthreads();
@@ -106,20 +116,21 @@ __global__ void __launch_bounds__(kGenThreads) gen_estep_kernel(GenEstep a) {
       qv[k] = 0.0;
       if (k < K) {
         const double* A = ainv + (size_t)k * DP * DP * 2;
+        // y^H A y = sum_i A_ii |y_i|^2 + 2 Re sum_i conj(y_i) sum_{j>i} A_ij y_j  (A Hermitian)
         double q = 0.0;
 #pragma unroll
         for (int i = 0; i < DP; ++i) {
           if (i < D) {
-            double ur = 0.0, ui = 0.0;  // (B^-1 y)_i
+            double ur = 0.0, ui = 0.0;
 #pragma unroll
-            for (int j = 0; j < DP; ++j) {
+            for (int j = i + 1; j < DP; ++j) {
               if (j < D) {
                 const double ar = A[(i * DP + j) * 2], ai = A[(i * DP + j) * 2 + 1];
                 ur += ar * yr[j] - ai * yi[j];
                 ui += ar * yi[j] + ai * yr[j];
               }
             }
-            q += yr[i] * ur + yi[i] * ui;  // Re conj(y_i) u_i
+            q += A[(i * DP + i) * 2] * (yr[i] * yr[i] + yi[i] * yi[i]) + 2.0 * (yr[i] * ur + yi[i] * ui);
           }
         }
         q = fmax(fabs(q * inv), kTiny);  // cacg.py:185-199
@@ -169,6 +180,7 @@ struct GenCov {
   double* out_cov;         // c128 (B,K,D,D)
   double* out_weight;      // (B,K) or null
   double* out_sum;         // (B,K) class sums or null
+  int32_t* out_zero;       // (B) or null: 1 when the bin holds an all-zero frame
 };
 
 template <int DP, typename YS>
@@ -179,9 +191,11 @@ __global__ void __launch_bounds__(kGenThreads) gen_cov_kernel(GenCov a) {
   double* wtile = ytile + (size_t)kTile * DP * 2;             // [K][kTile]
   double* red = wtile + (size_t)kGenMaxK * kTile;             // [kGenWaves]
   double* csum = red + kGenWaves;                             // [K]
+  __shared__ int zero_seen;
   const int tid = threadIdx.x;
   const int64_t b = blockIdx.x;
   const int D = a.D, K = a.K, T = a.T;
+  if (tid == 0) zero_seen = 0;
   double accr[R][kGenMaxK], acci[R][kGenMaxK], ssum[kGenMaxK];
 #pragma unroll
   for (int r = 0; r < R; ++r)
@@ -213,6 +227,7 @@ __global__ void __launch_bounds__(kGenThreads) gen_cov_kernel(GenCov a) {
       }
       const double inv = (a.layout == PBBSS_LAYOUT_TD && a.mode == 0)
                              ? ((n2 > 0.0) ? 1.0 / n2 : 0.0) : 1.0;
+      if (t < T && !(n2 > 0.0)) zero_seen = 1;  // benign race: every writer stores 1
       for (int k = 0; k < K; ++k) {
         double w = 0.0, gs = 0.0;
         if (t < T) {
@@ -286,6 +301,7 @@ __global__ void __launch_bounds__(kGenThreads) gen_cov_kernel(GenCov a) {
       }
     }
   }
+  if (tid == 0 && a.out_zero) a.out_zero[b] = zero_seen;
   if (tid < K) {
     if (a.out_sum) a.out_sum[b * K + tid] = csum[tid];
     if (a.out_weight) {
@@ -308,6 +324,7 @@ struct GenHeev {
   double* out_val;      // (N,D) ascending
   double* out_vec;      // c128 (N,D,D), eigenvectors in columns
   int32_t* out_status;  // (N) or null
+  const int32_t* skip;  // (N) or null: nonzero = leave this matrix alone
 };
 
 
@@ -323,6 +340,7 @@ __global__ void __launch_bounds__(kGenThreads) gen_heev_kernel(GenHeev g) {
   int* part = reinterpret_cast<int*>(red + kGenWaves);  // [DP] partner of x in this round
   const int tid = threadIdx.x;
   const int64_t n = blockIdx.x;
+  if (g.skip && g.skip[n]) return;  // uniform over the workgroup
   const int D = g.D;
   const int N = D + (D & 1);  // tournament size (even)
   int st = 0;
@@ -410,6 +428,115 @@ __global__ void __launch_bounds__(kGenThreads) gen_heev_kernel(GenHeev g) {
   }
 }
 
+// ------------------------------------------------------------------ inverse (EM fast path)
+struct GenInv {
+  const double* a;     // c128 (N,D,D)
+  int64_t N;
+  int D;
+  double eig_floor;
+  double* out_inv;     // c128 (N,D,D)
+  double* out_logdet;  // (N)
+  int32_t* out_ok;     // (N)
+  const int32_t* veto; // (N / K) or null: nonzero = never accept (see launch_gen_inverse)
+  int K;
+};
+
+template <int DP>
+__global__ void __launch_bounds__(kGenThreads) gen_inv_kernel(GenInv g) {
+  __shared__ __attribute__((aligned(16))) double A[DP * DP * 2];
+  __shared__ __attribute__((aligned(16))) double rowp[DP * 2];
+  __shared__ __attribute__((aligned(16))) double colp[DP * 2];
+  __shared__ double red[kGenWaves];
+  const int tid = threadIdx.x;
+  const int64_t n = blockIdx.x;
+  const int D = g.D;
+  double tr = 0.0;
+  for (int e = tid; e < DP * DP; e += kGenThreads) {
+    const int i = e / DP, j = e - i * DP;
+    double re = 0.0, im = 0.0;
+    if (i < D && j < D) {  // same triangle as gen_heev
+      const int lo = i < j ? j : i, hi = i < j ? i : j;
+      const double* p = g.a + (((size_t)n * D + lo) * D + hi) * 2;
+      re = p[0];
+      im = (i == j) ? 0.0 : ((i > j) ? p[1] : -p[1]);
+      if (i == j) tr += re;
+    }
+    A[e * 2] = re;
+    A[e * 2 + 1] = im;
+  }
+  tr = block_sum(tr, red, tid);  // ends with a barrier
+  // Gauss-Jordan sweep without pivoting: the pivots of a Hermitian positive definite matrix
+  // are its (positive) Schur complements and their product is the determinant
+  bool ok = true;
+  double logdet = 0.0;
+  for (int p = 0; p < D; ++p) {
+    if (tid < D) {
+      rowp[tid * 2] = A[(p * DP + tid) * 2];
+      rowp[tid * 2 + 1] = A[(p * DP + tid) * 2 + 1];
+      colp[tid * 2] = A[(tid * DP + p) * 2];
+      colp[tid * 2 + 1] = A[(tid * DP + p) * 2 + 1];
+    }
+    __syncthreads();
+    const double piv = rowp[p * 2];
+    if (!(piv > 0.0) || !isfinite(piv)) {  // the same value in every thread
+      ok = false;
+      break;
+    }
+    const double ip = 1.0 / piv;
+    logdet += log(piv);
+    for (int e = tid; e < DP * DP; e += kGenThreads) {
+      const int i = e / DP, j = e - i * DP;
+      if (i < D && j < D) {
+        const double cr = colp[i * 2], ci = colp[i * 2 + 1];
+        const double rr = rowp[j * 2] * ip, ri = rowp[j * 2 + 1] * ip;
+        double xr, xi;
+        if (i == p) {
+          xr = (j == p) ? ip : rr;
+          xi = (j == p) ? 0.0 : ri;
+        } else if (j == p) {
+          xr = -cr * ip;
+          xi = -ci * ip;
+        } else {
+          xr = A[e * 2] - (cr * rr - ci * ri);
+          xi = A[e * 2 + 1] - (cr * ri + ci * rr);
+        }
+        A[e * 2] = xr;
+        A[e * 2 + 1] = xi;
+      }
+    }
+    __syncthreads();
+  }
+  double fro2 = 0.0;
+  if (ok) {
+    for (int e = tid; e < DP * DP; e += kGenThreads) {
+      const int i = e / DP, j = e - i * DP;
+      if (i < D && j < D) fro2 += A[e * 2] * A[e * 2] + A[e * 2 + 1] * A[e * 2 + 1];
+    }
+  }
+  fro2 = block_sum(fro2, red, tid);
+  // lambda_min >= 1 / ||C^-1||_F and lambda_max <= tr C (cacgmm_em.hpp uses the same test)
+  const double bound = tr * sqrt(fro2);
+  ok = ok && isfinite(bound) && (bound * g.eig_floor < 1e-2) && (bound < 1e13);
+  if (g.veto && g.veto[n / g.K]) ok = false;
+  if (ok) {
+    for (int e = tid; e < DP * DP; e += kGenThreads) {
+      const int i = e / DP, j = e - i * DP;
+      if (i < D && j < D) {
+        // average the two triangles: the sweep keeps them conjugate only up to rounding
+        const double re = 0.5 * (A[e * 2] + A[(j * DP + i) * 2]);
+        const double im = 0.5 * (A[e * 2 + 1] - A[(j * DP + i) * 2 + 1]);
+        double* o = g.out_inv + (((size_t)n * D + i) * D + j) * 2;
+        o[0] = re;
+        o[1] = (i == j) ? 0.0 : im;
+      }
+    }
+  }
+  if (tid == 0) {
+    g.out_logdet[n] = logdet;
+    g.out_ok[n] = ok ? 1 : 0;
+  }
+}
+
 inline int ok_or_hip() { return hipGetLastError() == hipSuccess ? PBBSS_OK : PBBSS_ERR_HIP; }
 
 template <typename KFN>
@@ -428,10 +555,11 @@ bool gen_supported(int D, int K) { return D >= 2 && D <= kGenMaxD && K >= 1 && K
 int launch_gen_estep(const void* y, int y_is_c128, int layout, int64_t B, int T, int D, int K,
                      const double* eigvec, const double* eigval, const double* weight, int64_t wb,
                      int64_t wk, int64_t wt, const uint8_t* activity, double eps, double* out_aff,
-                     double* out_q, double* out_logpdf, size_t lds_limit, hipStream_t s) {
+                     double* out_q, double* out_logpdf, size_t lds_limit, hipStream_t s,
+                     const GenInverseState* state) {
   if (!gen_supported(D, K)) return PBBSS_ERR_UNSUPPORTED;
   GenEstep a{y, layout, B, T, D, K, eigvec, eigval, weight, wb, wk, wt, activity, eps,
-             out_aff, out_q, out_logpdf};
+             out_aff, out_q, out_logpdf, state ? *state : GenInverseState{nullptr, nullptr, nullptr}};
   const int DP = D <= 16 ? 16 : 32;
   const size_t lds = ((size_t)K * DP * DP * 2 + K) * sizeof(double);
   int rc;
@@ -453,10 +581,11 @@ int launch_gen_estep(const void* y, int y_is_c128, int layout, int64_t B, int T,
 int launch_gen_cov(const void* y, int y_is_c128, int layout, int64_t B, int T, int D, int K,
                    const double* gamma, int64_t gamma_bstride, const double* q,
                    const double* saliency, int mode, int weight_mode, double* out_cov,
-                   double* out_weight, double* out_sum, size_t lds_limit, hipStream_t s) {
+                   double* out_weight, double* out_sum, size_t lds_limit, hipStream_t s,
+                   int32_t* out_zero) {
   if (!gen_supported(D, K)) return PBBSS_ERR_UNSUPPORTED;
   GenCov a{y, layout, B, T, D, K, gamma, gamma_bstride, q, saliency, mode, weight_mode,
-           out_cov, out_weight, out_sum};
+           out_cov, out_weight, out_sum, out_zero};
   const int DP = D <= 16 ? 16 : 32;
   const size_t lds =
       ((size_t)kTile * DP * 2 + (size_t)kGenMaxK * kTile + kGenWaves + kGenMaxK) * sizeof(double);
@@ -478,9 +607,9 @@ int launch_gen_cov(const void* y, int y_is_c128, int layout, int64_t B, int T, i
 
 int launch_gen_heev(const double* a, int64_t N, int D, int covariance_norm, double eig_floor,
                     double* out_val, double* out_vec, int32_t* out_status, size_t lds_limit,
-                    hipStream_t s) {
+                    hipStream_t s, const int32_t* skip) {
   if (D < 2 || D > kGenMaxD) return PBBSS_ERR_UNSUPPORTED;
-  GenHeev g{a, N, D, covariance_norm, eig_floor, out_val, out_vec, out_status};
+  GenHeev g{a, N, D, covariance_norm, eig_floor, out_val, out_vec, out_status, skip};
   const int DP = D <= 16 ? 16 : 32;
   const size_t lds = ((size_t)4 * DP * DP * 2 + DP * 3 + kGenWaves) * sizeof(double) + DP * sizeof(int);
   int rc;
@@ -492,6 +621,19 @@ int launch_gen_heev(const double* a, int64_t N, int D, int covariance_norm, doub
     auto kfn = gen_heev_kernel<32>;
     if ((rc = set_lds(kfn, lds, lds_limit)) != PBBSS_OK) return rc;
     hipLaunchKernelGGL(kfn, dim3((unsigned)N), dim3(kGenThreads), lds, s, g);
+  }
+  return ok_or_hip();
+}
+
+int launch_gen_inverse(const double* a, int64_t N, int D, double eig_floor, double* out_inv,
+                       double* out_logdet, int32_t* out_ok, hipStream_t s, const int32_t* veto,
+                       int K) {
+  if (D < 2 || D > kGenMaxD || K < 1) return PBBSS_ERR_UNSUPPORTED;
+  GenInv g{a, N, D, eig_floor, out_inv, out_logdet, out_ok, veto, K};
+  if (D <= 16) {
+    hipLaunchKernelGGL(gen_inv_kernel<16>, dim3((unsigned)N), dim3(kGenThreads), 0, s, g);
+  } else {
+    hipLaunchKernelGGL(gen_inv_kernel<32>, dim3((unsigned)N), dim3(kGenThreads), 0, s, g);
   }
   return ok_or_hip();
 }

@@ -10,11 +10,21 @@ constexpr int kGenMaxD = 32;
 
 bool gen_supported(int D, int K);
 
+// Between the iterations of one fit the model of matrix n = b * K + k may travel as
+// B^-1 and log det B instead of (V, lambda): ok[n] != 0 marks the matrices whose inverse
+// was accepted (launch_gen_inverse); the others are read from the eigendecomposition.
+struct GenInverseState {
+  const double* inv;     // c128 (N,D,D)
+  const double* logdet;  // (N)
+  const int32_t* ok;     // (N)
+};
+
 // a2-a4: posteriors / quadratic form / log-pdf from an eigen-parameterised model
 int launch_gen_estep(const void* y, int y_is_c128, int layout, int64_t B, int T, int D, int K,
                      const double* eigvec, const double* eigval, const double* weight, int64_t wb,
                      int64_t wk, int64_t wt, const uint8_t* activity, double eps, double* out_aff,
-                     double* out_q, double* out_logpdf, size_t lds_limit, hipStream_t s);
+                     double* out_q, double* out_logpdf, size_t lds_limit, hipStream_t s,
+                     const GenInverseState* state = nullptr);
 
 // a6 / a10: weighted covariances.  mode 0: M-step (D * sum_t gamma sal / q y y^H / sum gamma sal,
 // observation unit-normalised when layout is TD); mode 1: PSD with the mask normalised by
@@ -23,12 +33,26 @@ int launch_gen_estep(const void* y, int y_is_c128, int layout, int64_t B, int T,
 int launch_gen_cov(const void* y, int y_is_c128, int layout, int64_t B, int T, int D, int K,
                    const double* gamma, int64_t gamma_bstride, const double* q,
                    const double* saliency, int mode, int weight_mode, double* out_cov,
-                   double* out_weight, double* out_sum, size_t lds_limit, hipStream_t s);
+                   double* out_weight, double* out_sum, size_t lds_limit, hipStream_t s,
+                   int32_t* out_zero = nullptr);
 
 // a7: Hermitian eigendecomposition (ascending, eigenvectors in columns).  covariance_norm < 0:
 // plain numpy.linalg.eigh; otherwise the normalisation / floor of from_covariance.
+// skip (nullable): matrices with skip[n] != 0 are left untouched (their inverse was accepted).
 int launch_gen_heev(const double* a, int64_t N, int D, int covariance_norm, double eig_floor,
                     double* out_val, double* out_vec, int32_t* out_status, size_t lds_limit,
-                    hipStream_t s);
+                    hipStream_t s, const int32_t* skip = nullptr);
+
+// Fast path between EM iterations: in-place Gauss-Jordan inverse of the Hermitian positive
+// definite covariance and its log-determinant.  The class log-pdf is invariant to the scale
+// of B, so neither normalisation of cacg.py:82-132 matters here; only the eigenvalue floor
+// does, and ok[n] is set only when tr(C) ||C^-1||_F (an upper bound of the condition number)
+// proves that no eigenvalue would have been floored.  The invariance does not hold for an
+// all-zero frame (its quadratic form is clamped, cacg.py:185-199, so the posterior depends on
+// the normalised determinant): veto[n / K] != 0 (launch_gen_cov's out_zero) rejects every
+// class of such a bin.
+int launch_gen_inverse(const double* a, int64_t N, int D, double eig_floor, double* out_inv,
+                       double* out_logdet, int32_t* out_ok, hipStream_t s,
+                       const int32_t* veto = nullptr, int K = 1);
 
 }  // namespace pbbss
