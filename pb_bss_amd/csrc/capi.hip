@@ -320,7 +320,9 @@ PBBSS_API int pbbss_cacgmm_fit(pbbss_handle_t h, const void* y, int64_t B, int T
     hipStream_t s = as_stream(stream);
     const size_t nkt = (size_t)B * K * T;
     const size_t nmat = (size_t)B * K;
-    const size_t need = 2 * WorkCarver::pad(nkt * 8) + 2 * WorkCarver::pad(nmat * D * D * 16) +
+    const size_t ninv = pbbss::gen_state_doubles((int64_t)nmat, D);
+    const size_t need = 2 * WorkCarver::pad(nkt * 8) + WorkCarver::pad(nmat * D * D * 16) +
+                        WorkCarver::pad(ninv * 8) +
                         WorkCarver::pad(nmat * 8) + WorkCarver::pad(nmat * 4) +
                         WorkCarver::pad((size_t)B * 4);
     void* wmem = handle_work(h, need);
@@ -329,11 +331,12 @@ PBBSS_API int pbbss_cacgmm_fit(pbbss_handle_t h, const void* y, int64_t B, int T
     double* aff = wc.take<double>(nkt);
     double* qf = wc.take<double>(nkt);
     double* cov = wc.take<double>(nmat * D * D * 2);
-    double* inv = wc.take<double>(nmat * D * D * 2);
+    double* inv = wc.take<double>(ninv);
     double* inv_logdet = wc.take<double>(nmat);
     int32_t* inv_ok = wc.take<int32_t>(nmat);
     int32_t* zero_bin = wc.take<int32_t>((size_t)B);
     const pbbss::GenInverseState state{inv, inv_logdet, inv_ok};
+    const pbbss::GenInverseState state_from_eig{inv, inv_logdet, nullptr};
     TimedRegion tr(h, s);
     int rc;
     if (has_model) {
@@ -350,7 +353,7 @@ PBBSS_API int pbbss_cacgmm_fit(pbbss_handle_t h, const void* y, int64_t B, int T
         rc = pbbss::launch_gen_estep(y, o->y_is_c128, PBBSS_LAYOUT_TD, B, T, D, K,
                                      static_cast<const double*>(out_eigvec), out_eigval,
                                      out_weight, K, 1, 0, activity, o->affiliation_eps, aff, qf,
-                                     nullptr, h->cfg.lds_limit, s, it > 0 ? &state : nullptr);
+                                     nullptr, s, it > 0 ? state : state_from_eig);
         if (rc != PBBSS_OK) return rc;
         g_src = aff;
         q_src = qf;
@@ -379,7 +382,7 @@ PBBSS_API int pbbss_cacgmm_fit(pbbss_handle_t h, const void* y, int64_t B, int T
       rc = pbbss::launch_gen_estep(y, o->y_is_c128, PBBSS_LAYOUT_TD, B, T, D, K,
                                    static_cast<const double*>(out_eigvec), out_eigval, out_weight,
                                    K, 1, 0, nullptr, 0.0, out_affiliation, out_quadratic_form,
-                                   nullptr, h->cfg.lds_limit, s);
+                                   nullptr, s, state_from_eig);
       if (rc != PBBSS_OK) return rc;
     }
     return PBBSS_OK;
@@ -429,11 +432,19 @@ PBBSS_API int pbbss_cacgmm_predict(pbbss_handle_t h, const void* y, int64_t B, i
   if (!h || !y || !eigvec || !eigval || !weight || B <= 0 || T <= 0) return PBBSS_ERR_INVALID_ARG;
   if (!out_affiliation && !out_quadratic_form && !out_log_pdf) return PBBSS_ERR_INVALID_ARG;
   if (D > 8) {
+    if (!pbbss::gen_supported(D, K)) return PBBSS_ERR_UNSUPPORTED;
+    const size_t ninv = pbbss::gen_state_doubles(B * K, D);
+    void* wmem = handle_work(h, WorkCarver::pad(ninv * 8) + WorkCarver::pad((size_t)B * K * 8));
+    if (!wmem) return PBBSS_ERR_HIP;
+    WorkCarver wc(wmem);
+    double* inv = wc.take<double>(ninv);
+    double* inv_logdet = wc.take<double>((size_t)B * K);
     TimedRegion tr(h, as_stream(stream));
     return pbbss::launch_gen_estep(y, y_is_c128, layout, B, T, D, K,
                                    static_cast<const double*>(eigvec), eigval, weight, wb, wk, wt,
                                    activity, affiliation_eps, out_affiliation, out_quadratic_form,
-                                   out_log_pdf, h->cfg.lds_limit, as_stream(stream));
+                                   out_log_pdf, as_stream(stream),
+                                   pbbss::GenInverseState{inv, inv_logdet, nullptr});
   }
   if (D < 2 || D > 8 || K < 1 || K > 6) return PBBSS_ERR_UNSUPPORTED;
   pbbss::EmArgs a{};

@@ -21,7 +21,13 @@ namespace pbbss {
 namespace {
 
 constexpr int kGenMaxK = 6;
-constexpr int kTile = 32;  // frames per LDS tile of gen_cov
+constexpr int kTile = 64;  // frames per LDS tile of gen_cov
+
+// doubles of gen_cov's staging area: the frame tile, later the per-thread partial tiles
+__host__ __device__ constexpr size_t gen_cov_stage_doubles(int DP) {
+  const size_t frames = (size_t)kTile * (DP + 1) * 2, parts = (size_t)kGenThreads * 8 * 2;
+  return frames > parts ? frames : parts;
+}
 
 __device__ __forceinline__ double block_sum(double v, double* red, int tid) {
   return gen_block_sum(v, red, tid);
@@ -38,13 +44,17 @@ __device__ __forceinline__ void load_y(const void* y, int layout, int64_t b, int
 }
 
 // ------------------------------------------------------------------ E-step
+// The model reaches the E-step as B_k^-1 and log det B_k in the padded "inverse state"
+// ((N, LD, LD) complex128, LD = gen_state_ld(D), zeros beyond D).  The entries are uniform
+// over a workgroup, so they are fetched with scalar loads (constant address space) and enter
+// the multiply-accumulates as SGPR operands: no LDS traffic, and the vector ALU is the bound.
 struct GenEstep {
   const void* y;
   int layout;
   int64_t B;
   int T, D, K;
-  const double* eigvec;  // c128 (B,K,D,D)
-  const double* eigval;  // (B,K,D)
+  const double* inv;     // c128 (B*K, LD, LD)
+  const double* logdet;  // (B*K)
   const double* weight;
   int64_t wb, wk, wt;
   const uint8_t* activity;
@@ -52,116 +62,126 @@ struct GenEstep {
   double* out_aff;
   double* out_q;
   double* out_logpdf;
-  GenInverseState st;    // all null: every class comes from (eigvec, eigval)
 };
+
+typedef __attribute__((address_space(4))) const double* gen_cptr;
 
 template <int DP, typename YS>
 __global__ void __launch_bounds__(kGenThreads) gen_estep_kernel(GenEstep a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  double* ainv = reinterpret_cast<double*>(smem);           // [K][DP][DP][2]
-  double* logdet = ainv + (size_t)a.K * DP * DP * 2;        // [K]
+  __shared__ double qs[kGenMaxK * kGenThreads];  // [K][thread] quadratic forms (private slots)
   const int tid = threadIdx.x;
-  const int64_t b = blockIdx.x;
+  const int64_t b = blockIdx.y;
   const int D = a.D, K = a.K, T = a.T;
-  // B_k^-1 = V diag(1/lambda) V^H  (the reference's einsum forms the same product first)
-  for (int idx = tid; idx < K * DP * DP; idx += kGenThreads) {
-    const int k = idx / (DP * DP), r = idx - k * DP * DP, i = r / DP, j = r - i * DP;
+  const int t = blockIdx.x * kGenThreads + tid;  // thread = frame
+  const bool valid = t < T;
+  double yr[DP], yi[DP], n2 = 0.0;
+#pragma unroll
+  for (int d = 0; d < DP; ++d) {
+    yr[d] = 0.0;
+    yi[d] = 0.0;
+    if (d < D && valid) {
+      load_y<YS>(a.y, a.layout, b, t, d, T, D, yr[d], yi[d]);
+      n2 += yr[d] * yr[d] + yi[d] * yi[d];
+    }
+  }
+  // raw observations are unit-normalised (zero frames stay zero, utils.py:223-256)
+  const double inv = (a.layout == PBBSS_LAYOUT_TD) ? ((n2 > 0.0) ? 1.0 / n2 : 0.0) : 1.0;
+#pragma unroll 1
+  for (int k = 0; k < K; ++k) {
+    const gen_cptr A = (gen_cptr)(a.inv + ((size_t)b * K + k) * DP * DP * 2);
+    // y^H A y = sum_i A_ii |y_i|^2 + 2 Re sum_i conj(y_i) sum_{j>i} A_ij y_j  (A Hermitian);
+    // no bounds tests: A and y are zero beyond D
+    double q = 0.0;
+#pragma unroll
+    for (int i = 0; i < DP; ++i) {
+      double ur = 0.0, ui = 0.0;
+#pragma unroll
+      for (int j = i + 1; j < DP; ++j) {
+        const double ar = A[(i * DP + j) * 2], ai = A[(i * DP + j) * 2 + 1];
+        ur = fma(ar, yr[j], ur);
+        ur = fma(-ai, yi[j], ur);
+        ui = fma(ar, yi[j], ui);
+        ui = fma(ai, yr[j], ui);
+      }
+      q = fma(A[(i * DP + i) * 2], fma(yr[i], yr[i], yi[i] * yi[i]), q);
+      q = fma(2.0, fma(yr[i], ur, yi[i] * ui), q);
+    }
+    qs[k * kGenThreads + tid] = q;
+  }
+  if (!valid) return;
+  double lp[kGenMaxK], qv[kGenMaxK], mx = -1.79e308;
+#pragma unroll
+  for (int k = 0; k < kGenMaxK; ++k) {
+    lp[k] = -1.79e308;
+    qv[k] = 0.0;
+    if (k < K) {
+      const double q = fmax(fabs(qs[k * kGenThreads + tid] * inv), kTiny);  // cacg.py:185-199
+      qv[k] = q;
+      lp[k] = -(double)D * log(q) - a.logdet[b * K + k];                   // cacg.py:151
+      mx = fmax(mx, lp[k]);
+    }
+  }
+  double g[kGenMaxK], den = 0.0;
+#pragma unroll
+  for (int k = 0; k < kGenMaxK; ++k) {
+    g[k] = 0.0;
+    if (k < K) {
+      double v = exp(lp[k] - mx) * a.weight[b * a.wb + k * a.wk + (int64_t)t * a.wt];
+      if (a.activity) v *= (double)a.activity[((size_t)b * K + k) * T + t];
+      g[k] = v;
+      den += v;
+    }
+  }
+  den = fmax(den, kTiny);
+#pragma unroll
+  for (int k = 0; k < kGenMaxK; ++k) {
+    if (k < K) {
+      double gam = g[k] / den;
+      if (a.eps != 0.0) gam = fmin(fmax(gam, a.eps), 1.0 - a.eps);
+      const size_t idx = ((size_t)b * K + k) * T + t;
+      if (a.out_aff) a.out_aff[idx] = gam;
+      if (a.out_q) a.out_q[idx] = qv[k];
+      if (a.out_logpdf) a.out_logpdf[idx] = lp[k];
+    }
+  }
+}
+
+// (V, lambda) -> inverse state for the matrices not already marked ok (cacg.py:167-183 forms
+// the same product V diag(1/lambda) V^H before the quadratic form)
+struct GenEigToInv {
+  const double* eigvec;  // c128 (N,D,D)
+  const double* eigval;  // (N,D)
+  int D, LD;
+  const int32_t* ok;     // (N) or null
+  double* inv;           // c128 (N,LD,LD)
+  double* logdet;        // (N)
+};
+
+__global__ void __launch_bounds__(kGenThreads) gen_eig_to_inv_kernel(GenEigToInv g) {
+  const int64_t n = blockIdx.x;
+  if (g.ok && g.ok[n]) return;
+  const int tid = threadIdx.x, D = g.D, LD = g.LD;
+  const double* v = g.eigvec + (size_t)n * D * D * 2;
+  const double* lam = g.eigval + (size_t)n * D;
+  for (int e = tid; e < LD * LD; e += kGenThreads) {
+    const int i = e / LD, j = e - i * LD;
     double sr = 0.0, si = 0.0;
-    const bool have_inv = a.st.ok && a.st.ok[b * K + k];
-    if (i < D && j < D && have_inv) {
-      const double* p = a.st.inv + ((((size_t)b * K + k) * D + i) * D + j) * 2;
-      sr = p[0];
-      si = p[1];
-    } else if (i < D && j < D) {
-      const double* v = a.eigvec + ((size_t)b * K + k) * D * D * 2;
-      const double* lam = a.eigval + ((size_t)b * K + k) * D;
-      for (int e = 0; e < D; ++e) {
-        const double il = 1.0 / lam[e];
-        const double ar = v[(i * D + e) * 2], ai = v[(i * D + e) * 2 + 1];
-        const double br = v[(j * D + e) * 2], bi = v[(j * D + e) * 2 + 1];
-        sr += (ar * br + ai * bi) * il;   // V_ie conj(V_je)
+    if (i < D && j < D) {
+      for (int m = 0; m < D; ++m) {
+        const double il = 1.0 / lam[m];
+        const double ar = v[(i * D + m) * 2], ai = v[(i * D + m) * 2 + 1];
+        const double br = v[(j * D + m) * 2], bi = v[(j * D + m) * 2 + 1];
+        sr += (ar * br + ai * bi) * il;   // V_im conj(V_jm)
         si += (ai * br - ar * bi) * il;
       }
     }
-    ainv[idx * 2] = sr;
-    ainv[idx * 2 + 1] = si;
+    g.inv[((size_t)n * LD * LD + e) * 2] = sr;
+    g.inv[((size_t)n * LD * LD + e) * 2 + 1] = si;
   }
-  if (tid < K) {
+  if (tid == 0) {
     double s = 0.0;
-    if (a.st.ok && a.st.ok[b * K + tid]) {
-      s = a.st.logdet[b * K + tid];
-    } else {
-      for (int e = 0; e < D; ++e) s += log(a.eigval[((size_t)b * K + tid) * D + e]);
-    }
-    logdet[tid] = s;  // cacg.py:151
-  }
-  __syncthreads();
-  for (int t = tid; t < T; t += kGenThreads) {
-    double yr[DP], yi[DP], n2 = 0.0;
-#pragma unroll
-    for (int d = 0; d < DP; ++d) {
-      yr[d] = 0.0;
-      yi[d] = 0.0;
-      if (d < D) {
-        load_y<YS>(a.y, a.layout, b, t, d, T, D, yr[d], yi[d]);
-        n2 += yr[d] * yr[d] + yi[d] * yi[d];
-      }
-    }
-    // raw observations are unit-normalised (zero frames stay zero, utils.py:223-256)
-    const double inv = (a.layout == PBBSS_LAYOUT_TD) ? ((n2 > 0.0) ? 1.0 / n2 : 0.0) : 1.0;
-    double lp[kGenMaxK], qv[kGenMaxK], mx = -1.79e308;
-#pragma unroll
-    for (int k = 0; k < kGenMaxK; ++k) {
-      lp[k] = -1.79e308;
-      qv[k] = 0.0;
-      if (k < K) {
-        const double* A = ainv + (size_t)k * DP * DP * 2;
-        // y^H A y = sum_i A_ii |y_i|^2 + 2 Re sum_i conj(y_i) sum_{j>i} A_ij y_j  (A Hermitian)
-        double q = 0.0;
-#pragma unroll
-        for (int i = 0; i < DP; ++i) {
-          if (i < D) {
-            double ur = 0.0, ui = 0.0;
-#pragma unroll
-            for (int j = i + 1; j < DP; ++j) {
-              if (j < D) {
-                const double ar = A[(i * DP + j) * 2], ai = A[(i * DP + j) * 2 + 1];
-                ur += ar * yr[j] - ai * yi[j];
-                ui += ar * yi[j] + ai * yr[j];
-              }
-            }
-            q += A[(i * DP + i) * 2] * (yr[i] * yr[i] + yi[i] * yi[i]) + 2.0 * (yr[i] * ur + yi[i] * ui);
-          }
-        }
-        q = fmax(fabs(q * inv), kTiny);  // cacg.py:185-199
-        qv[k] = q;
-        lp[k] = -(double)D * log(q) - logdet[k];
-        mx = fmax(mx, lp[k]);
-      }
-    }
-    double g[kGenMaxK], den = 0.0;
-#pragma unroll
-    for (int k = 0; k < kGenMaxK; ++k) {
-      g[k] = 0.0;
-      if (k < K) {
-        double v = exp(lp[k] - mx) * a.weight[b * a.wb + k * a.wk + (int64_t)t * a.wt];
-        if (a.activity) v *= (double)a.activity[((size_t)b * K + k) * T + t];
-        g[k] = v;
-        den += v;
-      }
-    }
-    den = fmax(den, kTiny);
-#pragma unroll
-    for (int k = 0; k < kGenMaxK; ++k) {
-      if (k < K) {
-        double gam = g[k] / den;
-        if (a.eps != 0.0) gam = fmin(fmax(gam, a.eps), 1.0 - a.eps);
-        const size_t idx = ((size_t)b * K + k) * T + t;
-        if (a.out_aff) a.out_aff[idx] = gam;
-        if (a.out_q) a.out_q[idx] = qv[k];
-        if (a.out_logpdf) a.out_logpdf[idx] = lp[k];
-      }
-    }
+    for (int m = 0; m < D; ++m) s += log(lam[m]);
+    g.logdet[n] = s;  // cacg.py:151
   }
 }
 
@@ -183,12 +203,26 @@ struct GenCov {
   int32_t* out_zero;       // (B) or null: 1 when the bin holds an all-zero frame
 };
 
-template <int DP, typename YS>
+// Work split of gen_cov: the upper triangle of C (C is Hermitian) is cut into register tiles
+// of kTi x kTj entries; a thread owns one tile for a subset of the frames ("frame group"), so
+// one frame costs kTi + kTj LDS reads for kTi * kTj entries, and the groups are summed in a
+// fixed order at the end.
+constexpr int kTi = 4, kTj = 2, kTe = kTi * kTj;
+
+__device__ __forceinline__ int cov_tile_count(int D) {
+  const int nbi = (D + kTi - 1) / kTi, nbj = (D + kTj - 1) / kTj;
+  int n = 0;
+  for (int bi = 0; bi < nbi; ++bi) n += max(0, nbj - bi * (kTi / kTj));
+  return n;
+}
+
+// KM: compile-time bound of the class count (accumulator registers), 3 or kGenMaxK
+template <int DP, int KM, typename YS>
 __global__ void __launch_bounds__(kGenThreads) gen_cov_kernel(GenCov a) {
-  constexpr int R = (DP * DP + kGenThreads - 1) / kGenThreads;  // entries per thread
+  constexpr int LDY = DP + 1;  // row stride of the frame tile in complex numbers (bank spread)
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  double* ytile = reinterpret_cast<double*>(smem);            // [kTile][DP][2]
-  double* wtile = ytile + (size_t)kTile * DP * 2;             // [K][kTile]
+  double* ytile = reinterpret_cast<double*>(smem);            // [kTile][LDY][2], reused below
+  double* wtile = ytile + gen_cov_stage_doubles(DP);          // [K][kTile]
   double* red = wtile + (size_t)kGenMaxK * kTile;             // [kGenWaves]
   double* csum = red + kGenWaves;                             // [K]
   __shared__ int zero_seen;
@@ -196,25 +230,44 @@ __global__ void __launch_bounds__(kGenThreads) gen_cov_kernel(GenCov a) {
   const int64_t b = blockIdx.x;
   const int D = a.D, K = a.K, T = a.T;
   if (tid == 0) zero_seen = 0;
-  double accr[R][kGenMaxK], acci[R][kGenMaxK], ssum[kGenMaxK];
+  // tile of this thread: tiles (bi, bj) with bj >= bi * kTi / kTj touch the upper triangle
+  const int ntiles = cov_tile_count(D);
+  const int G = min(kGenThreads / ntiles, kTile);  // frame groups
+  const int tl = tid % ntiles, grp = tid / ntiles;
+  const bool active = grp < G;
+  int i0 = 0, j0 = 0;
+  {
+    const int nbj = (D + kTj - 1) / kTj;
+    int r = tl;
+    for (int bi = 0;; ++bi) {
+      const int cnt = nbj - bi * (kTi / kTj);
+      if (r < cnt) {
+        i0 = bi * kTi;
+        j0 = (bi * (kTi / kTj) + r) * kTj;
+        break;
+      }
+      r -= cnt;
+    }
+  }
+  double accr[kTe][KM], acci[kTe][KM], ssum[KM];
 #pragma unroll
-  for (int r = 0; r < R; ++r)
+  for (int e = 0; e < kTe; ++e)
 #pragma unroll
-    for (int k = 0; k < kGenMaxK; ++k) {
-      accr[r][k] = 0.0;
-      acci[r][k] = 0.0;
+    for (int k = 0; k < KM; ++k) {
+      accr[e][k] = 0.0;
+      acci[e][k] = 0.0;
     }
 #pragma unroll
-  for (int k = 0; k < kGenMaxK; ++k) ssum[k] = 0.0;
+  for (int k = 0; k < KM; ++k) ssum[k] = 0.0;
   for (int t0 = 0; t0 < T; t0 += kTile) {
     __syncthreads();
-    // stage: thread (frame, channel pairs) -> normalised y; weights
+    // stage: thread (frame, channel) -> y; weights below
     for (int idx = tid; idx < kTile * DP; idx += kGenThreads) {
       const int tt = idx / DP, d = idx - tt * DP, t = t0 + tt;
       double re = 0.0, im = 0.0;
       if (t < T && d < D) load_y<YS>(a.y, a.layout, b, t, d, T, D, re, im);
-      ytile[idx * 2] = re;
-      ytile[idx * 2 + 1] = im;
+      ytile[(tt * LDY + d) * 2] = re;
+      ytile[(tt * LDY + d) * 2 + 1] = im;
     }
     __syncthreads();
     if (tid < kTile) {
@@ -222,7 +275,7 @@ __global__ void __launch_bounds__(kGenThreads) gen_cov_kernel(GenCov a) {
       const int t = t0 + tid;
       double n2 = 0.0;
       for (int d = 0; d < D; ++d) {
-        const double re = ytile[(tid * DP + d) * 2], im = ytile[(tid * DP + d) * 2 + 1];
+        const double re = ytile[(tid * LDY + d) * 2], im = ytile[(tid * LDY + d) * 2 + 1];
         n2 += re * re + im * im;
       }
       const double inv = (a.layout == PBBSS_LAYOUT_TD && a.mode == 0)
@@ -247,24 +300,32 @@ __global__ void __launch_bounds__(kGenThreads) gen_cov_kernel(GenCov a) {
       }
     }
     __syncthreads();
+    if (active) {
+      for (int tt = grp; tt < kTile; tt += G) {
+        double ar[kTi], ai[kTi], br[kTj], bi[kTj];
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int e = tid + r * kGenThreads;
-      if (e < DP * DP) {
-        const int i = e / DP, j = e - i * DP;
-        if (i < D && j < D) {
-          for (int tt = 0; tt < kTile; ++tt) {
-            const double ar = ytile[(tt * DP + i) * 2], ai = ytile[(tt * DP + i) * 2 + 1];
-            const double br = ytile[(tt * DP + j) * 2], bi = ytile[(tt * DP + j) * 2 + 1];
-            const double pr = ar * br + ai * bi;   // y_i conj(y_j)
-            const double pi = ai * br - ar * bi;
+        for (int x = 0; x < kTi; ++x) {
+          ar[x] = ytile[(tt * LDY + i0 + x) * 2];
+          ai[x] = ytile[(tt * LDY + i0 + x) * 2 + 1];
+        }
 #pragma unroll
-            for (int k = 0; k < kGenMaxK; ++k) {
-              if (k < K) {
-                const double w = wtile[k * kTile + tt];
-                accr[r][k] = fma(w, pr, accr[r][k]);
-                acci[r][k] = fma(w, pi, acci[r][k]);
-              }
+        for (int x = 0; x < kTj; ++x) {
+          br[x] = ytile[(tt * LDY + j0 + x) * 2];
+          bi[x] = ytile[(tt * LDY + j0 + x) * 2 + 1];
+        }
+        double w[KM];
+#pragma unroll
+        for (int k = 0; k < KM; ++k) w[k] = (k < K) ? wtile[k * kTile + tt] : 0.0;
+#pragma unroll
+        for (int e = 0; e < kTe; ++e) {
+          const int x = e / kTj, z = e % kTj;
+          const double pr = ar[x] * br[z] + ai[x] * bi[z];   // y_i conj(y_j)
+          const double pi = ai[x] * br[z] - ar[x] * bi[z];
+#pragma unroll
+          for (int k = 0; k < KM; ++k) {
+            if (k < K) {
+              accr[e][k] = fma(w[k], pr, accr[e][k]);
+              acci[e][k] = fma(w[k], pi, acci[e][k]);
             }
           }
         }
@@ -273,30 +334,63 @@ __global__ void __launch_bounds__(kGenThreads) gen_cov_kernel(GenCov a) {
   }
   // class sums: only threads < kTile hold partials
 #pragma unroll
-  for (int k = 0; k < kGenMaxK; ++k) {
+  for (int k = 0; k < KM; ++k) {
     const double tot = block_sum((k < K) ? ssum[k] : 0.0, red, tid);
     if (tid == 0 && k < K) csum[k] = tot;
   }
   __syncthreads();
   double tot_abs = 0.0;
   for (int k = 0; k < K; ++k) tot_abs += fabs(csum[k]);
+  // frame groups -> one sum per entry, class by class through the (now free) frame tile
+  double* part = ytile;  // [kGenThreads][kTe][2]
 #pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const int e = tid + r * kGenThreads;
-    if (e < DP * DP) {
-      const int i = e / DP, j = e - i * DP;
-      if (i < D && j < D) {
+  for (int k = 0; k < KM; ++k) {
+    if (k < K) {
+      __syncthreads();
+      if (active) {
 #pragma unroll
-        for (int k = 0; k < kGenMaxK; ++k) {
-          if (k < K) {
-            double sc;
-            if (a.mode == 0) sc = (double)D / fmax(csum[k], kTiny);        // cacg.py:316, :327
-            else if (a.mode == 1) sc = 1.0 / fmax(csum[k], 1e-10);         // beamformer.py:123
-            else sc = a.gamma ? 1.0 : 1.0 / (double)T;                     // :114-117
-            double* o = a.out_cov + ((((size_t)b * K + k) * D + i) * D + j) * 2;
-            o[0] = accr[r][k] * sc;
-            o[1] = (i == j) ? 0.0 : acci[r][k] * sc;
+        for (int e = 0; e < kTe; ++e) {
+          part[(tid * kTe + e) * 2] = accr[e][k];
+          part[(tid * kTe + e) * 2 + 1] = acci[e][k];
+        }
+      }
+      __syncthreads();
+      double sc;
+      if (a.mode == 0) sc = (double)D / fmax(csum[k], kTiny);        // cacg.py:316, :327
+      else if (a.mode == 1) sc = 1.0 / fmax(csum[k], 1e-10);         // beamformer.py:123
+      else sc = a.gamma ? 1.0 : 1.0 / (double)T;                     // :114-117
+      for (int o = tid; o < ntiles * kTe; o += kGenThreads) {
+        const int tile = o / kTe, e = o - tile * kTe;
+        // (i, j) of entry e of that tile: recompute the tile origin like above
+        int ti0 = 0, tj0 = 0;
+        {
+          const int nbj = (D + kTj - 1) / kTj;
+          int r = tile;
+          for (int bi = 0;; ++bi) {
+            const int cnt = nbj - bi * (kTi / kTj);
+            if (r < cnt) {
+              ti0 = bi * kTi;
+              tj0 = (bi * (kTi / kTj) + r) * kTj;
+              break;
+            }
+            r -= cnt;
           }
+        }
+        const int i = ti0 + e / kTj, j = tj0 + e % kTj;
+        if (i < D && j < D && i <= j) {
+          double sr = 0.0, si = 0.0;
+          for (int gg = 0; gg < G; ++gg) {
+            sr += part[((gg * ntiles + tile) * kTe + e) * 2];
+            si += part[((gg * ntiles + tile) * kTe + e) * 2 + 1];
+          }
+          sr *= sc;
+          si = (i == j) ? 0.0 : si * sc;
+          double* up = a.out_cov + ((((size_t)b * K + k) * D + i) * D + j) * 2;
+          double* lo = a.out_cov + ((((size_t)b * K + k) * D + j) * D + i) * 2;
+          up[0] = sr;
+          up[1] = si;
+          lo[0] = sr;
+          lo[1] = -si;
         }
       }
     }
@@ -439,6 +533,7 @@ struct GenInv {
   int32_t* out_ok;     // (N)
   const int32_t* veto; // (N / K) or null: nonzero = never accept (see launch_gen_inverse)
   int K;
+  int LD;              // row stride of out_inv (gen_state_ld(D)), zero beyond D
 };
 
 template <int DP>
@@ -519,16 +614,18 @@ __global__ void __launch_bounds__(kGenThreads) gen_inv_kernel(GenInv g) {
   ok = ok && isfinite(bound) && (bound * g.eig_floor < 1e-2) && (bound < 1e13);
   if (g.veto && g.veto[n / g.K]) ok = false;
   if (ok) {
-    for (int e = tid; e < DP * DP; e += kGenThreads) {
-      const int i = e / DP, j = e - i * DP;
+    const int LD = g.LD;
+    for (int e = tid; e < LD * LD; e += kGenThreads) {
+      const int i = e / LD, j = e - i * LD;
+      double re = 0.0, im = 0.0;
       if (i < D && j < D) {
         // average the two triangles: the sweep keeps them conjugate only up to rounding
-        const double re = 0.5 * (A[e * 2] + A[(j * DP + i) * 2]);
-        const double im = 0.5 * (A[e * 2 + 1] - A[(j * DP + i) * 2 + 1]);
-        double* o = g.out_inv + (((size_t)n * D + i) * D + j) * 2;
-        o[0] = re;
-        o[1] = (i == j) ? 0.0 : im;
+        re = 0.5 * (A[(i * DP + j) * 2] + A[(j * DP + i) * 2]);
+        im = (i == j) ? 0.0 : 0.5 * (A[(i * DP + j) * 2 + 1] - A[(j * DP + i) * 2 + 1]);
       }
+      double* o = g.out_inv + ((size_t)n * LD * LD + e) * 2;
+      o[0] = re;
+      o[1] = im;
     }
   }
   if (tid == 0) {
@@ -555,25 +652,27 @@ bool gen_supported(int D, int K) { return D >= 2 && D <= kGenMaxD && K >= 1 && K
 int launch_gen_estep(const void* y, int y_is_c128, int layout, int64_t B, int T, int D, int K,
                      const double* eigvec, const double* eigval, const double* weight, int64_t wb,
                      int64_t wk, int64_t wt, const uint8_t* activity, double eps, double* out_aff,
-                     double* out_q, double* out_logpdf, size_t lds_limit, hipStream_t s,
-                     const GenInverseState* state) {
+                     double* out_q, double* out_logpdf, hipStream_t s,
+                     const GenInverseState& state) {
   if (!gen_supported(D, K)) return PBBSS_ERR_UNSUPPORTED;
-  GenEstep a{y, layout, B, T, D, K, eigvec, eigval, weight, wb, wk, wt, activity, eps,
-             out_aff, out_q, out_logpdf, state ? *state : GenInverseState{nullptr, nullptr, nullptr}};
-  const int DP = D <= 16 ? 16 : 32;
-  const size_t lds = ((size_t)K * DP * DP * 2 + K) * sizeof(double);
-  int rc;
-#define PBBSS_GEN_E(DPV, YST)                                                              \
-  {                                                                                        \
-    auto kfn = gen_estep_kernel<DPV, YST>;                                                 \
-    if ((rc = set_lds(kfn, lds, lds_limit)) != PBBSS_OK) return rc;                        \
-    hipLaunchKernelGGL(kfn, dim3((unsigned)B), dim3(kGenThreads), lds, s, a);              \
+  if (!state.inv || !state.logdet) return PBBSS_ERR_INVALID_ARG;
+  const int DP = gen_state_ld(D);
+  GenEigToInv c{eigvec, eigval, D, DP, state.ok, state.inv, state.logdet};
+  hipLaunchKernelGGL(gen_eig_to_inv_kernel, dim3((unsigned)(B * K)), dim3(kGenThreads), 0, s, c);
+  GenEstep a{y, layout, B, T, D, K, state.inv, state.logdet, weight, wb, wk, wt, activity, eps,
+             out_aff, out_q, out_logpdf};
+  const dim3 grid((unsigned)((T + kGenThreads - 1) / kGenThreads), (unsigned)B);
+  if (B > 65535) return PBBSS_ERR_UNSUPPORTED;
+#define PBBSS_GEN_E(DPV, YST) \
+  hipLaunchKernelGGL((gen_estep_kernel<DPV, YST>), grid, dim3(kGenThreads), 0, s, a);
+#define PBBSS_GEN_ED(DPV) \
+  case DPV: if (y_is_c128) { PBBSS_GEN_E(DPV, double) } else { PBBSS_GEN_E(DPV, float) } break;
+  switch (DP) {
+    PBBSS_GEN_ED(12) PBBSS_GEN_ED(16) PBBSS_GEN_ED(20) PBBSS_GEN_ED(24) PBBSS_GEN_ED(28)
+    PBBSS_GEN_ED(32)
+    default: return PBBSS_ERR_UNSUPPORTED;
   }
-  if (DP == 16) {
-    if (y_is_c128) PBBSS_GEN_E(16, double) else PBBSS_GEN_E(16, float)
-  } else {
-    if (y_is_c128) PBBSS_GEN_E(32, double) else PBBSS_GEN_E(32, float)
-  }
+#undef PBBSS_GEN_ED
 #undef PBBSS_GEN_E
   return ok_or_hip();
 }
@@ -588,19 +687,22 @@ int launch_gen_cov(const void* y, int y_is_c128, int layout, int64_t B, int T, i
            out_cov, out_weight, out_sum, out_zero};
   const int DP = D <= 16 ? 16 : 32;
   const size_t lds =
-      ((size_t)kTile * DP * 2 + (size_t)kGenMaxK * kTile + kGenWaves + kGenMaxK) * sizeof(double);
+      (gen_cov_stage_doubles(DP) + (size_t)kGenMaxK * kTile + kGenWaves + kGenMaxK) * sizeof(double);
   int rc;
-#define PBBSS_GEN_C(DPV, YST)                                                              \
+#define PBBSS_GEN_C(DPV, KMV, YST)                                                         \
   {                                                                                        \
-    auto kfn = gen_cov_kernel<DPV, YST>;                                                   \
+    auto kfn = gen_cov_kernel<DPV, KMV, YST>;                                              \
     if ((rc = set_lds(kfn, lds, lds_limit)) != PBBSS_OK) return rc;                        \
     hipLaunchKernelGGL(kfn, dim3((unsigned)B), dim3(kGenThreads), lds, s, a);              \
   }
+#define PBBSS_GEN_CK(DPV, YST) \
+  if (K <= 3) PBBSS_GEN_C(DPV, 3, YST) else PBBSS_GEN_C(DPV, kGenMaxK, YST)
   if (DP == 16) {
-    if (y_is_c128) PBBSS_GEN_C(16, double) else PBBSS_GEN_C(16, float)
+    if (y_is_c128) { PBBSS_GEN_CK(16, double) } else { PBBSS_GEN_CK(16, float) }
   } else {
-    if (y_is_c128) PBBSS_GEN_C(32, double) else PBBSS_GEN_C(32, float)
+    if (y_is_c128) { PBBSS_GEN_CK(32, double) } else { PBBSS_GEN_CK(32, float) }
   }
+#undef PBBSS_GEN_CK
 #undef PBBSS_GEN_C
   return ok_or_hip();
 }
@@ -629,7 +731,7 @@ int launch_gen_inverse(const double* a, int64_t N, int D, double eig_floor, doub
                        double* out_logdet, int32_t* out_ok, hipStream_t s, const int32_t* veto,
                        int K) {
   if (D < 2 || D > kGenMaxD || K < 1) return PBBSS_ERR_UNSUPPORTED;
-  GenInv g{a, N, D, eig_floor, out_inv, out_logdet, out_ok, veto, K};
+  GenInv g{a, N, D, eig_floor, out_inv, out_logdet, out_ok, veto, K, gen_state_ld(D)};
   if (D <= 16) {
     hipLaunchKernelGGL(gen_inv_kernel<16>, dim3((unsigned)N), dim3(kGenThreads), 0, s, g);
   } else {

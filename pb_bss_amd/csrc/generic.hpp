@@ -10,21 +10,26 @@ constexpr int kGenMaxD = 32;
 
 bool gen_supported(int D, int K);
 
-// Between the iterations of one fit the model of matrix n = b * K + k may travel as
-// B^-1 and log det B instead of (V, lambda): ok[n] != 0 marks the matrices whose inverse
-// was accepted (launch_gen_inverse); the others are read from the eigendecomposition.
+// The E-step consumes the model as the "inverse state": B^-1 (complex128 (N, LD, LD) with
+// LD = gen_state_ld(D), zero beyond D) and log det B of matrix n = b * K + k.  ok (nullable)
+// marks the matrices whose state is already valid (accepted by launch_gen_inverse between two
+// EM iterations); the others are filled from (eigvec, eigval) first.
+inline int gen_state_ld(int D) { return D <= 12 ? 12 : (D + 3) / 4 * 4; }
+inline size_t gen_state_doubles(int64_t N, int D) {
+  return (size_t)N * gen_state_ld(D) * gen_state_ld(D) * 2;
+}
 struct GenInverseState {
-  const double* inv;     // c128 (N,D,D)
-  const double* logdet;  // (N)
-  const int32_t* ok;     // (N)
+  double* inv;           // c128 (N,LD,LD) workspace
+  double* logdet;        // (N) workspace
+  const int32_t* ok;     // (N) or null
 };
 
 // a2-a4: posteriors / quadratic form / log-pdf from an eigen-parameterised model
 int launch_gen_estep(const void* y, int y_is_c128, int layout, int64_t B, int T, int D, int K,
                      const double* eigvec, const double* eigval, const double* weight, int64_t wb,
                      int64_t wk, int64_t wt, const uint8_t* activity, double eps, double* out_aff,
-                     double* out_q, double* out_logpdf, size_t lds_limit, hipStream_t s,
-                     const GenInverseState* state = nullptr);
+                     double* out_q, double* out_logpdf, hipStream_t s,
+                     const GenInverseState& state);
 
 // a6 / a10: weighted covariances.  mode 0: M-step (D * sum_t gamma sal / q y y^H / sum gamma sal,
 // observation unit-normalised when layout is TD); mode 1: PSD with the mask normalised by
