@@ -1,18 +1,24 @@
 // Generic-size path of the cACGMM trainer for 9 <= D <= 32 sensors (the persistent kernel of
 // cacgmm_em.hpp is specialised for D <= 8, where a D x D matrix maps onto one wavefront).
-// Same functions as SURVEY.md section 8a rows a2-a8 / a10, decomposed into three kernels per
-// EM iteration that the C ABI enqueues back to back (no host synchronisation):
-//   gen_estep  one workgroup per frequency bin: B_k^-1 = V diag(1/lambda) V^H built in LDS,
-//              thread = frame: q = y^H B^-1 y (D^2 complex MACs per class against LDS
-//              broadcasts), log-domain softmax            (cacg.py:167-203, mm_utils.py:7-55)
-//   gen_cov    one workgroup per bin: thread = covariance entries (i,j), frames staged
-//              through a 32-frame LDS tile: C_k = sum_t w_kt y_t y_t^H with the M-step or the
-//              PSD normalisation, class weights             (cacg.py:253-342, beamformer.py:59)
-//   gen_heev   one workgroup per matrix: parallel cyclic Jacobi in LDS (D/2 disjoint
-//              rotations per round, ping-pong buffers), ascending eigenvalues, the
-//              reference's normalisation and floor           (cacg.py:82-132)
-// Matrices are padded to DP = 16 or 32 (template) so that register arrays index statically.
-// Float64 arithmetic throughout, as the D <= 8 path.
+// Same functions as SURVEY.md section 8a rows a2-a8 / a10, decomposed into kernels that the
+// C ABI enqueues back to back (no host synchronisation); per EM iteration:
+//   gen_cov    one workgroup per bin: the upper triangle of C_k = sum_t w_kt y_t y_t^H in 4x2
+//              register tiles, frames staged through a 64-frame LDS tile and split over
+//              frame groups; M-step or PSD normalisation, class weights
+//                                                           (cacg.py:253-342, beamformer.py:59)
+//   gen_inv    one workgroup per matrix: Gauss-Jordan inverse + log det in LDS, accepted only
+//              when a condition bound proves that no eigenvalue would be floored (fast path
+//              between iterations, the class log-pdf being invariant to the scale of B)
+//   gen_heev   one workgroup per matrix, skipped where gen_inv succeeded and not the last
+//              iteration: parallel cyclic Jacobi in LDS (D/2 disjoint rotations per round,
+//              ping-pong buffers), ascending eigenvalues, the reference's normalisation and
+//              floor                                        (cacg.py:82-132)
+//   gen_eig_to_inv  (V, lambda) -> B^-1 = V diag(1/lambda) V^H, log det for the other matrices
+//   gen_estep  grid (frames / 256, bins), thread = frame: q = y^H B^-1 y over the upper
+//              triangle with B^-1 fetched by scalar loads (SGPR operands, no LDS), log-domain
+//              softmax                                     (cacg.py:167-203, mm_utils.py:7-55)
+// cov / inv / heev pad matrices to DP = 16 or 32, the E-step to multiples of 4 (templates) so
+// that register arrays index statically.  Float64 arithmetic throughout, as the D <= 8 path.
 #include "generic.hpp"
 #include <cmath>
 #include "generic_dev.hpp"
