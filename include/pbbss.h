@@ -439,6 +439,34 @@ int pbbss_apply_online_beamforming_vector(pbbss_handle_t h, const void* vector,
                                           void* stream);
 
 /* ------------------------------------------------------------------------- */
+/* STFT edge.  The reference has no transform of its own: */
+/* its tests call nara_wpe.utils.stft / istft                                   */
+/* (tests/test_distribution/test_spatial_mm.py:4,17-22,                          */
+/* pb_bss/transform/griffin_lim_module.py:37); these two entry points replace    */
+/* those calls.  The caller passes the windows (device float64): the periodic    */
+/* analysis window for pbbss_stft, the biorthogonal synthesis window             */
+/* w / sum_m w[n + m shift]^2 for pbbss_istft.                                   */
+/* ------------------------------------------------------------------------- */
+/* Number of frames of a (faded, padded) signal of num_samples samples. */
+int pbbss_stft_num_frames(int64_t num_samples, int size, int shift, int window_length,
+                          int fading, int pad);
+/* x (C, N) float32 / float64 -> out complex64 / complex128, T = pbbss_stft_num_frames:
+ * out_layout 0: (C, T, size/2+1) like the reference's stft;
+ * out_layout 1: (size/2+1, T, C), the 'd t f -> f t d' rearrangement the mixture-model
+ *               trainers are fed with (test_spatial_mm.py:41), written directly.
+ * size: power of two, 4..8192; 1 <= window_length <= size; fading: window_length - shift
+ * zeros on both sides; pad: the last partial frame is zero-padded (else dropped). */
+int pbbss_stft(pbbss_handle_t h, const void* x, int x_is_f64, int64_t C, int64_t N, int size,
+               int shift, int window_length, const double* window, int fading, int pad,
+               int out_layout, int out_is_c128, void* out, void* stream);
+/* X (C, T, size/2+1) complex64 / complex128 -> out (C, n_out) float64 with
+ * n_out = T * shift + window_length - shift - (fading ? 2 (window_length - shift) : 0);
+ * frames are added in ascending order (numpy.add.at over the segment view). */
+int pbbss_istft(pbbss_handle_t h, const void* X, int x_is_c128, int64_t C, int T, int size,
+                int shift, int window_length, const double* synthesis_window, int fading,
+                double* out, int64_t n_out, void* stream);
+
+/* ------------------------------------------------------------------------- */
 /* Timing hook for bench.py: runs `fit` with HIP events recorded on `stream`   */
 /* around the EM kernel launch(es) only and returns the elapsed milliseconds   */
 /* of the most recent call (the roofline figure needs the kernel duration on   */

@@ -46,7 +46,7 @@ EXPORTS = (
     'pbbss_lcmv', 'pbbss_phase_correction', 'pbbss_snr_postfilter',
     'pbbss_distortionless_normalization', 'pbbss_zero_degree_normalization',
     'pbbss_condition_covariance', 'pbbss_apply_online_beamforming_vector',
-    'pbbss_set_dhtv_team',
+    'pbbss_set_dhtv_team', 'pbbss_stft_num_frames', 'pbbss_stft', 'pbbss_istft',
 )
 
 EMBED_VMF = 0
@@ -143,6 +143,9 @@ def load():
         lib.pbbss_set_split_tail.argtypes = [vp, i32]
         lib.pbbss_set_dhtv_team.argtypes = [vp, i32]
         lib.pbbss_split_error.argtypes = [vp, ctypes.POINTER(ctypes.c_int)]
+        lib.pbbss_stft_num_frames.argtypes = [i64, i32, i32, i32, i32, i32]
+        lib.pbbss_stft.argtypes = [vp, vp, i32, i64, i64, i32, i32, i32, vp, i32, i32, i32, i32, vp, vp]
+        lib.pbbss_istft.argtypes = [vp, vp, i32, i64, i32, i32, i32, i32, vp, i32, vp, i64, vp]
         lib.pbbss_dhtv_calculate_mapping.argtypes = [vp, vp, i64, i32, i32, i32, vp, i32, i32, vp, vp, vp, vp]
         lib.pbbss_apply_mapping.argtypes = [vp, vp, vp, i64, i32, i32, i32, vp, vp]
         lib.pbbss_cwmm_fit.argtypes = [

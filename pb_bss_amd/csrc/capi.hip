@@ -8,6 +8,7 @@
 #include "embed.hpp"
 #include "generic.hpp"
 #include "generic_bf.hpp"
+#include "stft.hpp"
 #include "em_launch.hpp"
 
 #define PBBSS_API extern "C" __attribute__((visibility("default")))
@@ -1075,4 +1076,43 @@ PBBSS_API int pbbss_apply_online_beamforming_vector(pbbss_handle_t h, const void
   if (!h || !vector || !mix || !out || F <= 0 || T <= 0 || D <= 0) return PBBSS_ERR_INVALID_ARG;
   return pbbss::launch_apply_online(static_cast<const double*>(vector), mix, mix_is_c128, F, T, D,
                                     static_cast<double*>(out), as_stream(stream));
+}
+
+// ---------------------------------------------------------------- STFT edge (row N4)
+PBBSS_API int pbbss_stft_num_frames(int64_t num_samples, int size, int shift, int window_length,
+                                    int fading, int pad) {
+  if (num_samples < 0 || size < 1 || shift < 1 || window_length < 1) return PBBSS_ERR_INVALID_ARG;
+  const int64_t n = num_samples + (fading ? 2 * (int64_t)(window_length - shift) : 0);
+  if (n < window_length) return pad ? 1 : 0;
+  const int64_t rest = n - window_length;
+  const int64_t frames = 1 + (pad ? (rest + shift - 1) / shift : rest / shift);
+  return frames > INT32_MAX ? PBBSS_ERR_UNSUPPORTED : (int)frames;
+}
+
+PBBSS_API int pbbss_stft(pbbss_handle_t h, const void* x, int x_is_f64, int64_t C, int64_t N,
+                         int size, int shift, int window_length, const double* window, int fading,
+                         int pad, int out_layout, int out_is_c128, void* out, void* stream) {
+  DeviceGuard device_guard(h);
+  if (!h || !x || !window || !out || C <= 0 || N <= 0) return PBBSS_ERR_INVALID_ARG;
+  if (fading && window_length < shift) return PBBSS_ERR_INVALID_ARG;
+  const int T = pbbss_stft_num_frames(N, size, shift, window_length, fading, pad);
+  if (T <= 0) return T < 0 ? T : PBBSS_ERR_INVALID_ARG;
+  return pbbss::launch_stft(x, x_is_f64, C, N, size, shift, window_length, window,
+                            fading ? window_length - shift : 0, T, out_layout, out_is_c128, out,
+                            h->cfg.lds_limit, as_stream(stream));
+}
+
+PBBSS_API int pbbss_istft(pbbss_handle_t h, const void* X, int x_is_c128, int64_t C, int T, int size,
+                          int shift, int window_length, const double* synthesis_window, int fading,
+                          double* out, int64_t n_out, void* stream) {
+  DeviceGuard device_guard(h);
+  if (!h || !X || !synthesis_window || !out || C <= 0 || T <= 0) return PBBSS_ERR_INVALID_ARG;
+  if (window_length < shift || shift < 1) return PBBSS_ERR_INVALID_ARG;
+  const int fade = fading ? window_length - shift : 0;
+  if (n_out != (int64_t)T * shift + window_length - shift - 2 * (int64_t)fade) return PBBSS_ERR_INVALID_ARG;
+  void* wmem = handle_work(h, WorkCarver::pad((size_t)C * T * window_length * 8));
+  if (!wmem) return PBBSS_ERR_HIP;
+  return pbbss::launch_istft(X, x_is_c128, C, T, size, shift, window_length, synthesis_window, fade,
+                             static_cast<double*>(wmem), out, n_out, h->cfg.lds_limit,
+                             as_stream(stream));
 }

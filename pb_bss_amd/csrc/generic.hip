@@ -14,7 +14,7 @@
 //              ping-pong buffers), ascending eigenvalues, the reference's normalisation and
 //              floor                                        (cacg.py:82-132)
 //   gen_eig_to_inv  (V, lambda) -> B^-1 = V diag(1/lambda) V^H, log det for the other matrices
-//   gen_estep  grid (frames / 256, bins), thread = frame: q = y^H B^-1 y over the upper
+//   gen_estep  grid (bins, frames / 256), thread = frame: q = y^H B^-1 y over the upper
 //              triangle with B^-1 fetched by scalar loads (SGPR operands, no LDS), log-domain
 //              softmax                                     (cacg.py:167-203, mm_utils.py:7-55)
 // cov / inv / heev pad matrices to DP = 16 or 32, the E-step to multiples of 4 (templates) so
@@ -76,9 +76,9 @@ template <int DP, typename YS>
 __global__ void __launch_bounds__(kGenThreads) gen_estep_kernel(GenEstep a) {
   __shared__ double qs[kGenMaxK * kGenThreads];  // [K][thread] quadratic forms (private slots)
   const int tid = threadIdx.x;
-  const int64_t b = blockIdx.y;
+  const int64_t b = blockIdx.x;
   const int D = a.D, K = a.K, T = a.T;
-  const int t = blockIdx.x * kGenThreads + tid;  // thread = frame
+  const int t = blockIdx.y * kGenThreads + tid;  // thread = frame
   const bool valid = t < T;
   double yr[DP], yi[DP], n2 = 0.0;
 #pragma unroll
@@ -667,8 +667,8 @@ int launch_gen_estep(const void* y, int y_is_c128, int layout, int64_t B, int T,
   hipLaunchKernelGGL(gen_eig_to_inv_kernel, dim3((unsigned)(B * K)), dim3(kGenThreads), 0, s, c);
   GenEstep a{y, layout, B, T, D, K, state.inv, state.logdet, weight, wb, wk, wt, activity, eps,
              out_aff, out_q, out_logpdf};
-  const dim3 grid((unsigned)((T + kGenThreads - 1) / kGenThreads), (unsigned)B);
-  if (B > 65535) return PBBSS_ERR_UNSUPPORTED;
+  const dim3 grid((unsigned)B, (unsigned)((T + kGenThreads - 1) / kGenThreads));
+  if (grid.y > 65535u) return PBBSS_ERR_UNSUPPORTED;
 #define PBBSS_GEN_E(DPV, YST) \
   hipLaunchKernelGGL((gen_estep_kernel<DPV, YST>), grid, dim3(kGenThreads), 0, s, a);
 #define PBBSS_GEN_ED(DPV) \

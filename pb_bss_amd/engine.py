@@ -606,3 +606,50 @@ def apply_online_bf(vector, mix):
         int(mix.dtype == t.complex128), F, T, D, _lib.ptr(out), _lib.stream_ptr(mix.device.index))
     _lib.check(rc, f'apply_online_bf(T={T},F={F},D={D})')
     return out
+
+
+def stft_num_frames(num_samples, size, shift, window_length, fading=True, pad=True):
+    """pbbss_stft_num_frames (host arithmetic only)."""
+    n = _lib.load().pbbss_stft_num_frames(int(num_samples), int(size), int(shift),
+                                          int(window_length), int(bool(fading)), int(bool(pad)))
+    if n < 0:
+        _lib.check(n, f'stft_num_frames(N={num_samples},size={size},shift={shift})')
+    return n
+
+
+def stft(x, size, shift, window, *, fading=True, pad=True, layout=0, out_c128=True):
+    """pbbss_stft.  x (C,N) float32/float64, window (window_length) f64 on the device.
+
+    Returns (C,T,F) [layout 0] or (F,T,C) [layout 1] complex128 / complex64, F = size//2+1."""
+    t = _t()
+    C, N = x.shape
+    wl = int(window.shape[0])
+    T = stft_num_frames(N, size, shift, wl, fading, pad)
+    if T <= 0:
+        raise ValueError(f'stft: no complete frame in {N} samples (size={size}, pad={pad})')
+    F = size // 2 + 1
+    shape = (C, T, F) if layout == 0 else (F, T, C)
+    out = t.empty(shape, dtype=t.complex128 if out_c128 else t.complex64, device=x.device)
+    rc = _lib.load().pbbss_stft(
+        _lib.handle(x.device.index), _lib.ptr(x), int(x.dtype == t.float64), C, N, int(size),
+        int(shift), wl, _lib.ptr(window), int(bool(fading)), int(bool(pad)), int(layout),
+        int(bool(out_c128)), _lib.ptr(out), _lib.stream_ptr(x.device.index))
+    _lib.check(rc, f'stft(C={C},N={N},size={size},shift={shift},window_length={wl})')
+    return out
+
+
+def istft(X, size, shift, synthesis_window, *, fading=True):
+    """pbbss_istft.  X (C,T,F) complex64/complex128 -> (C, n_out) float64."""
+    t = _t()
+    C, T, F = X.shape
+    wl = int(synthesis_window.shape[0])
+    n_out = T * shift + wl - shift - (2 * (wl - shift) if fading else 0)
+    if n_out <= 0:
+        raise ValueError(f'istft: {T} frames give no output samples')
+    out = t.empty((C, n_out), dtype=t.float64, device=X.device)
+    rc = _lib.load().pbbss_istft(
+        _lib.handle(X.device.index), _lib.ptr(X), int(X.dtype == t.complex128), C, T, int(size),
+        int(shift), wl, _lib.ptr(synthesis_window), int(bool(fading)), _lib.ptr(out), n_out,
+        _lib.stream_ptr(X.device.index))
+    _lib.check(rc, f'istft(C={C},T={T},size={size},shift={shift},window_length={wl})')
+    return out

@@ -1,5 +1,6 @@
 """CPU: host-side logic of the drop-in layer that needs no GPU."""
 import numpy as np
+import pytest
 
 from oracle import cacgmm as oc
 
@@ -117,3 +118,27 @@ def test_host_samplers_reproduce_reference_draws():
     y = m.sample(size=(20,))
     assert y.shape == (20, 3)
     np.testing.assert_allclose(y, g['y'], atol=1e-12)
+
+
+def test_transform_windows_match_scipy_and_oracle():
+    """Host side of pb_bss_amd.transform: periodic analysis window and the biorthogonal
+    synthesis window (the only arithmetic done outside the kernels)."""
+    from scipy import signal
+    from oracle import stft as o
+    from pb_bss_amd.transform import analysis_window, biorthogonal_window, stft_frames_to_samples
+    for name, fn in (('blackman', signal.windows.blackman), ('hann', signal.windows.hann),
+                     ('hamming', signal.windows.hamming)):
+        np.testing.assert_allclose(analysis_window(name, 512), fn(513)[:-1], atol=1e-15)
+        np.testing.assert_allclose(analysis_window(name, 400, symmetric_window=True), fn(400),
+                                   atol=1e-15)
+    np.testing.assert_allclose(analysis_window(signal.windows.blackman, 256),
+                               signal.windows.blackman(257)[:-1], atol=0)
+    w = analysis_window('blackman', 1024)
+    s = biorthogonal_window(w, 256)
+    np.testing.assert_allclose(s, o.biorthogonal_window(w, 256), atol=0)
+    # defining property: sum_m w[n + m shift] s[n + m shift] == 1
+    np.testing.assert_allclose((w * s).reshape(4, 256).sum(0), 1.0, atol=1e-14)
+    with pytest.raises(ValueError):
+        biorthogonal_window(analysis_window('hann', 400), 128)
+    assert stft_frames_to_samples(66, 512, 128) == 66 * 128 + 384 - 768
+    assert stft_frames_to_samples(10, 512, 128, fading=False) == 10 * 128 + 384
