@@ -1,0 +1,113 @@
+#!/usr/bin/env python3
+"""Audio in -> audio out on one GPU, nothing but the waveforms crossing PCIe:
+
+    audio (D, samples) --stft('f t d')--> Y (F, T, D) --cACGMM EM--> masks --DHTV alignment-->
+      PSD --'mvdr_souden' | 'gev+ban'--> beamformed STFT (K, T, F) --istft--> audio (K, samples)
+
+    python examples/separate_audio.py --seconds 8 --sensors 6 --sources 2
+
+Synthetic scene: `sources` on/off-modulated noise bursts through random short room filters
+plus sensor noise.  Prints the time per stage and, per source, the correlation of the best
+matching output with the source image at the reference sensor before and after separation.
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def make_scene(rng, seconds, rate, D, S, taps=64, noise=0.03):
+    n = int(seconds * rate)
+    t = np.arange(n) / rate
+    src = []
+    for s in range(S):
+        gate = (np.sin(2 * np.pi * (0.7 + 0.45 * s) * t + 2.0 * s) > -0.2).astype(np.float64)
+        colour = np.convolve(rng.standard_normal(n), rng.standard_normal(8) * np.hanning(8), 'same')
+        src.append(gate * colour)
+    src = np.stack(src)                                                     # (S, n)
+    h = rng.standard_normal((S, D, taps)) * np.exp(-np.arange(taps) / 12.0)
+    images = np.stack([[np.convolve(src[s], h[s, d])[:n] for d in range(D)] for s in range(S)])
+    mix = images.sum(0) + noise * images.std() * rng.standard_normal((D, n))
+    return mix.astype(np.float32), images[:, 0]                             # reference sensor 0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--seconds', type=float, default=8.0)
+    ap.add_argument('--rate', type=int, default=16000)
+    ap.add_argument('--sensors', type=int, default=6)
+    ap.add_argument('--sources', type=int, default=2)
+    ap.add_argument('--size', type=int, default=1024)
+    ap.add_argument('--shift', type=int, default=256)
+    ap.add_argument('--iterations', type=int, default=100)
+    ap.add_argument('--beamformer', default='mvdr_souden',
+                    help="recipe for get_bf_vector; the printed correlation compares with the source "
+                         "image at sensor 0, so it is meaningful for distortionless recipes "
+                         "('mvdr_souden', 'wmwf'), not for 'gev+ban' (free phase per bin)")
+    args = ap.parse_args()
+    import torch
+    from pb_bss_amd.distribution import CACGMMTrainer
+    from pb_bss_amd.extraction import (apply_beamforming_vector, get_bf_vector,
+                                       get_power_spectral_density_matrix)
+    from pb_bss_amd.permutation_alignment import DHTVPermutationAlignment
+    from pb_bss_amd.transform import istft, stft
+
+    rng = np.random.default_rng(0)
+    mix, images = make_scene(rng, args.seconds, args.rate, args.sensors, args.sources)
+    K = args.sources + 1                                                     # + noise class
+    n = mix.shape[-1]
+
+    def run(x):
+        marks = [('start', time.perf_counter())]
+
+        def mark(name):
+            torch.cuda.synchronize()
+            marks.append((name, time.perf_counter()))
+
+        Y = stft(x, args.size, args.shift, layout='f t d', dtype=np.complex64)   # (F, T, D)
+        mark('stft')
+        masks = CACGMMTrainer().fit_predict(Y, num_classes=K, iterations=args.iterations)  # (F,K,T)
+        mark(f'cACGMM x{args.iterations}')
+        solver = DHTVPermutationAlignment.from_stft_size(args.size)
+        kft = solver(masks.transpose(0, 1).contiguous())                     # (K, F, T)
+        mark('DHTV alignment')
+        X = Y.transpose(1, 2).contiguous()                                   # (F, D, T)
+        psd = get_power_spectral_density_matrix(X, kft.transpose(0, 1).contiguous())  # (F,K,D,D)
+        out = []
+        for k in range(K):
+            target = psd[:, k]
+            w = get_bf_vector(args.beamformer, target, psd.sum(1) - target)
+            out.append(apply_beamforming_vector(w, X) * kft[k])             # masked beamformer (F, T)
+        S = torch.stack(out).transpose(1, 2).contiguous()                    # (K, T, F)
+        mark(f'PSD + {args.beamformer} + apply')
+        y = istft(S, args.size, args.shift)[..., :n]                         # (K, samples)
+        mark('istft')
+        return y, marks
+
+    x = torch.from_numpy(mix).cuda()
+    run(x[:, :args.rate])                                                    # warm-up
+    torch.cuda.synchronize()
+    y, marks = run(x)
+    est = y.cpu().numpy()
+    total = marks[-1][1] - marks[0][1]
+    print(f'{args.sensors} sensors x {args.seconds:g} s @ {args.rate} Hz, {K} classes: '
+          f'{total * 1e3:.2f} ms on the device = {args.seconds / total:.0f} x real time')
+    for (_, a), (name, b) in zip(marks[:-1], marks[1:]):
+        print(f'  {name:32s} {(b - a) * 1e3:8.3f} ms')
+
+    def corr(a, b):
+        return abs(np.dot(a, b)) / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30)
+
+    for s in range(args.sources):
+        before = corr(mix[0].astype(np.float64), images[s])
+        after = max(corr(est[k], images[s]) for k in range(K))
+        print(f'  source {s}: correlation with its image at sensor 0: mixture {before:.3f} -> '
+              f'best output {after:.3f}')
+
+
+if __name__ == '__main__':
+    main()
