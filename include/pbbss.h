@@ -69,7 +69,8 @@ int pbbss_create(pbbss_handle_t* out, int device_id);
  * (pbbss_cacgmm_fit / _predict, pbbss_cacg_m_step, pbbss_heev_batched, pbbss_psd, pbbss_gev,
  * pbbss_solve, pbbss_mvdr_souden, pbbss_wmwf, pbbss_mvdr, pbbss_ban) run a generic-size path
  * (one workgroup per matrix, matrices in LDS; the EM loop enqueues three kernels per iteration;
- * layout TD only for the fit).  1 <= K <= 6 classes.  Watson / joint models and LCMV: D <= 8. */
+ * layout TD only for the fit).  1 <= K <= 6 classes on the fused kernels, 7 <= K <= 16 on the
+ * generic-size path at any D.  Watson / joint models and LCMV: D <= 8, K <= 6. */
 int pbbss_destroy(pbbss_handle_t h);
 
 /* ------------------------------------------------------------------------- */

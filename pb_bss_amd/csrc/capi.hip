@@ -146,7 +146,7 @@ PBBSS_API const char* pbbss_error_string(int code) {
     case PBBSS_ERR_INVALID_ARG: return "invalid argument";
     case PBBSS_ERR_UNSUPPORTED:
       return "shape not covered by the compiled kernels (need 2 <= D <= 32 sensors -- 8 for the "
-             "Watson / joint models and LCMV -- and 1 <= K <= 6 classes)";
+             "Watson / joint models and LCMV -- and 1 <= K <= 16 classes, 6 for those models)";
     case PBBSS_ERR_HIP: return "HIP runtime error";
     case PBBSS_ERR_LDS_CAPACITY:
       return "observation does not fit the LDS-resident EM kernel (too many frames)";
@@ -313,8 +313,8 @@ PBBSS_API int pbbss_cacgmm_fit(pbbss_handle_t h, const void* y, int64_t B, int T
   if (!out_eigvec || !out_eigval || !out_weight || !out_status) return PBBSS_ERR_INVALID_ARG;
   if (o->covariance_norm < 0 || o->covariance_norm > 2) return PBBSS_ERR_INVALID_ARG;
   if (o->weight_mode < 0 || o->weight_mode > 1) return PBBSS_ERR_INVALID_ARG;
-  if (D > 8) {
-    // generic-size path (generic.hip): E-step, covariance + weights, eigendecomposition per
+  if (D > 8 || K > 6) {
+    // generic-size path (generic.hip; also more than 6 classes at any D): E-step, covariance + weights, eigendecomposition per
     // iteration, enqueued back to back; the model lives in the caller's output buffers
     if (!pbbss::gen_supported(D, K)) return PBBSS_ERR_UNSUPPORTED;
     if (o->layout != PBBSS_LAYOUT_TD) return PBBSS_ERR_UNSUPPORTED;
@@ -432,7 +432,7 @@ PBBSS_API int pbbss_cacgmm_predict(pbbss_handle_t h, const void* y, int64_t B, i
   DeviceGuard device_guard(h);
   if (!h || !y || !eigvec || !eigval || !weight || B <= 0 || T <= 0) return PBBSS_ERR_INVALID_ARG;
   if (!out_affiliation && !out_quadratic_form && !out_log_pdf) return PBBSS_ERR_INVALID_ARG;
-  if (D > 8) {
+  if (D > 8 || K > 6) {
     if (!pbbss::gen_supported(D, K)) return PBBSS_ERR_UNSUPPORTED;
     const size_t ninv = pbbss::gen_state_doubles(B * K, D);
     void* wmem = handle_work(h, WorkCarver::pad(ninv * 8) + WorkCarver::pad((size_t)B * K * 8));
@@ -480,7 +480,7 @@ PBBSS_API int pbbss_cacg_m_step(pbbss_handle_t h, const void* y, int64_t B, int 
   if (!h || !y || !saliency || B <= 0 || T <= 0) return PBBSS_ERR_INVALID_ARG;
   if (!out_eigvec || !out_eigval || !out_status) return PBBSS_ERR_INVALID_ARG;
   if (covariance_norm < 0 || covariance_norm > 2) return PBBSS_ERR_INVALID_ARG;
-  if (D > 8) {
+  if (D > 8 || K > 6) {
     hipStream_t s = as_stream(stream);
     double* cov = static_cast<double*>(out_cov);
     if (!cov) {
@@ -533,20 +533,11 @@ PBBSS_API int pbbss_psd(pbbss_handle_t h, const void* x, int x_is_c128, int64_t 
   DeviceGuard device_guard(h);
   if (!h || !x || !out || B <= 0 || T <= 0 || K <= 0) return PBBSS_ERR_INVALID_ARG;
   if (!mask && K != 1) return PBBSS_ERR_INVALID_ARG;
-  if (D > 8) {
-    double* o = static_cast<double*>(out);
-    for (int k0 = 0; k0 < K; k0 += 6) {  // chunks of <= 6 sources per launch
-      const int kc = (K - k0 < 6) ? (K - k0) : 6;
-      int rc = pbbss::launch_gen_cov(x, x_is_c128, PBBSS_LAYOUT_DT, B, T, D, kc,
-                                     mask ? mask + (int64_t)k0 * T : nullptr, (int64_t)K * T,
-                                     nullptr, nullptr, (mask && normalize) ? 1 : 2,
-                                     PBBSS_WEIGHT_PER_CLASS_MEAN, o, nullptr, nullptr,
-                                     h->cfg.lds_limit, as_stream(stream));
-      if (rc != PBBSS_OK) return rc;
-      if (K > 6) return PBBSS_ERR_UNSUPPORTED;  // strided output of chunked sources: not yet
-      o += (int64_t)kc * D * D * 2;
-    }
-    return PBBSS_OK;
+  if (D > 8 || K > 6) {
+    return pbbss::launch_gen_cov(x, x_is_c128, PBBSS_LAYOUT_DT, B, T, D, K, mask, (int64_t)K * T,
+                                 nullptr, nullptr, (mask && normalize) ? 1 : 2,
+                                 PBBSS_WEIGHT_PER_CLASS_MEAN, static_cast<double*>(out), nullptr,
+                                 nullptr, h->cfg.lds_limit, as_stream(stream));
   }
   return pbbss::launch_psd(x, x_is_c128, B, T, D, K, mask, normalize, static_cast<double*>(out),
                            h->cfg, as_stream(stream));

@@ -26,7 +26,8 @@
 namespace pbbss {
 namespace {
 
-constexpr int kGenMaxK = 6;
+constexpr int kGenMaxK = 16;   // classes of the generic path
+constexpr int kCovMaxK = 6;    // classes accumulated by one gen_cov launch (register tiles)
 constexpr int kTile = 64;  // frames per LDS tile of gen_cov
 
 // doubles of gen_cov's staging area: the frame tile, later the per-thread partial tiles
@@ -74,7 +75,9 @@ typedef __attribute__((address_space(4))) const double* gen_cptr;
 
 template <int DP, typename YS>
 __global__ void __launch_bounds__(kGenThreads) gen_estep_kernel(GenEstep a) {
-  __shared__ double qs[kGenMaxK * kGenThreads];  // [K][thread] quadratic forms (private slots)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* qs = reinterpret_cast<double*>(smem);   // [K][thread] quadratic forms (private slots)
+  double* ls = qs + (size_t)a.K * kGenThreads;    // [K][thread] log-pdf, then unnormalised posterior
   const int tid = threadIdx.x;
   const int64_t b = blockIdx.x;
   const int D = a.D, K = a.K, T = a.T;
@@ -115,40 +118,34 @@ __global__ void __launch_bounds__(kGenThreads) gen_estep_kernel(GenEstep a) {
     qs[k * kGenThreads + tid] = q;
   }
   if (!valid) return;
-  double lp[kGenMaxK], qv[kGenMaxK], mx = -1.79e308;
-#pragma unroll
-  for (int k = 0; k < kGenMaxK; ++k) {
-    lp[k] = -1.79e308;
-    qv[k] = 0.0;
-    if (k < K) {
-      const double q = fmax(fabs(qs[k * kGenThreads + tid] * inv), kTiny);  // cacg.py:185-199
-      qv[k] = q;
-      lp[k] = -(double)D * log(q) - a.logdet[b * K + k];                   // cacg.py:151
-      mx = fmax(mx, lp[k]);
-    }
+  // softmax over the classes in three rolled passes through the thread's LDS slots (K <= 16
+  // without per-class register arrays)
+  double mx = -1.79e308;
+#pragma unroll 1
+  for (int k = 0; k < K; ++k) {
+    const double q = fmax(fabs(qs[k * kGenThreads + tid] * inv), kTiny);  // cacg.py:185-199
+    const double lp = -(double)D * log(q) - a.logdet[b * K + k];          // cacg.py:151
+    qs[k * kGenThreads + tid] = q;
+    ls[k * kGenThreads + tid] = lp;
+    mx = fmax(mx, lp);
+    if (a.out_logpdf) a.out_logpdf[((size_t)b * K + k) * T + t] = lp;
+    if (a.out_q) a.out_q[((size_t)b * K + k) * T + t] = q;
   }
-  double g[kGenMaxK], den = 0.0;
-#pragma unroll
-  for (int k = 0; k < kGenMaxK; ++k) {
-    g[k] = 0.0;
-    if (k < K) {
-      double v = exp(lp[k] - mx) * a.weight[b * a.wb + k * a.wk + (int64_t)t * a.wt];
-      if (a.activity) v *= (double)a.activity[((size_t)b * K + k) * T + t];
-      g[k] = v;
-      den += v;
-    }
+  if (!a.out_aff) return;
+  double den = 0.0;
+#pragma unroll 1
+  for (int k = 0; k < K; ++k) {
+    double v = exp(ls[k * kGenThreads + tid] - mx) * a.weight[b * a.wb + k * a.wk + (int64_t)t * a.wt];
+    if (a.activity) v *= (double)a.activity[((size_t)b * K + k) * T + t];
+    ls[k * kGenThreads + tid] = v;
+    den += v;
   }
   den = fmax(den, kTiny);
-#pragma unroll
-  for (int k = 0; k < kGenMaxK; ++k) {
-    if (k < K) {
-      double gam = g[k] / den;
-      if (a.eps != 0.0) gam = fmin(fmax(gam, a.eps), 1.0 - a.eps);
-      const size_t idx = ((size_t)b * K + k) * T + t;
-      if (a.out_aff) a.out_aff[idx] = gam;
-      if (a.out_q) a.out_q[idx] = qv[k];
-      if (a.out_logpdf) a.out_logpdf[idx] = lp[k];
-    }
+#pragma unroll 1
+  for (int k = 0; k < K; ++k) {
+    double gam = ls[k * kGenThreads + tid] / den;
+    if (a.eps != 0.0) gam = fmin(fmax(gam, a.eps), 1.0 - a.eps);
+    a.out_aff[((size_t)b * K + k) * T + t] = gam;
   }
 }
 
@@ -207,6 +204,7 @@ struct GenCov {
   double* out_weight;      // (B,K) or null
   double* out_sum;         // (B,K) class sums or null
   int32_t* out_zero;       // (B) or null: 1 when the bin holds an all-zero frame
+  int k0, kc;              // this launch accumulates classes k0 .. k0 + kc - 1 (kc <= KM)
 };
 
 // Work split of gen_cov: the upper triangle of C (C is Hermitian) is cut into register tiles
@@ -222,20 +220,22 @@ __device__ __forceinline__ int cov_tile_count(int D) {
   return n;
 }
 
-// KM: compile-time bound of the class count (accumulator registers), 3 or kGenMaxK
+// KM: compile-time bound of the classes accumulated per launch (accumulator registers), 3 or
+// kCovMaxK; more classes are covered by further launches (k0)
 template <int DP, int KM, typename YS>
 __global__ void __launch_bounds__(kGenThreads) gen_cov_kernel(GenCov a) {
   constexpr int LDY = DP + 1;  // row stride of the frame tile in complex numbers (bank spread)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* ytile = reinterpret_cast<double*>(smem);            // [kTile][LDY][2], reused below
-  double* wtile = ytile + gen_cov_stage_doubles(DP);          // [K][kTile]
-  double* red = wtile + (size_t)kGenMaxK * kTile;             // [kGenWaves]
-  double* csum = red + kGenWaves;                             // [K]
+  double* wtile = ytile + gen_cov_stage_doubles(DP);          // [KM][kTile] weights of the chunk
+  double* spart = wtile + (size_t)kCovMaxK * kTile;           // [K][kTile] class-sum partials
+  double* csum = spart + (size_t)kGenMaxK * kTile;            // [K]
   __shared__ int zero_seen;
   const int tid = threadIdx.x;
   const int64_t b = blockIdx.x;
-  const int D = a.D, K = a.K, T = a.T;
+  const int D = a.D, K = a.K, T = a.T, k0 = a.k0, kc = a.kc;
   if (tid == 0) zero_seen = 0;
+  for (int e = tid; e < K * kTile; e += kGenThreads) spart[e] = 0.0;
   // tile of this thread: tiles (bi, bj) with bj >= bi * kTi / kTj touch the upper triangle
   const int ntiles = cov_tile_count(D);
   const int G = min(kGenThreads / ntiles, kTile);  // frame groups
@@ -255,7 +255,7 @@ __global__ void __launch_bounds__(kGenThreads) gen_cov_kernel(GenCov a) {
       r -= cnt;
     }
   }
-  double accr[kTe][KM], acci[kTe][KM], ssum[KM];
+  double accr[kTe][KM], acci[kTe][KM];
 #pragma unroll
   for (int e = 0; e < kTe; ++e)
 #pragma unroll
@@ -263,8 +263,6 @@ __global__ void __launch_bounds__(kGenThreads) gen_cov_kernel(GenCov a) {
       accr[e][k] = 0.0;
       acci[e][k] = 0.0;
     }
-#pragma unroll
-  for (int k = 0; k < KM; ++k) ssum[k] = 0.0;
   for (int t0 = 0; t0 < T; t0 += kTile) {
     __syncthreads();
     // stage: thread (frame, channel) -> y; weights below
@@ -300,9 +298,10 @@ __global__ void __launch_bounds__(kGenThreads) gen_cov_kernel(GenCov a) {
             w = gs;
           }
         }
-        wtile[k * kTile + tid] = w;
-        // class sums, accumulated by the staging thread of the frame and reduced at the end
-        ssum[k] += gs;
+        if (k >= k0 && k < k0 + kc) wtile[(k - k0) * kTile + tid] = w;
+        // class sums of ALL classes (the saliency form of the weights needs their total),
+        // accumulated by the staging thread of the frame in its own LDS slot
+        spart[k * kTile + tid] += gs;
       }
     }
     __syncthreads();
@@ -321,7 +320,7 @@ __global__ void __launch_bounds__(kGenThreads) gen_cov_kernel(GenCov a) {
         }
         double w[KM];
 #pragma unroll
-        for (int k = 0; k < KM; ++k) w[k] = (k < K) ? wtile[k * kTile + tt] : 0.0;
+        for (int k = 0; k < KM; ++k) w[k] = (k < kc) ? wtile[k * kTile + tt] : 0.0;
 #pragma unroll
         for (int e = 0; e < kTe; ++e) {
           const int x = e / kTj, z = e % kTj;
@@ -329,7 +328,7 @@ __global__ void __launch_bounds__(kGenThreads) gen_cov_kernel(GenCov a) {
           const double pi = ai[x] * br[z] - ar[x] * bi[z];
 #pragma unroll
           for (int k = 0; k < KM; ++k) {
-            if (k < K) {
+            if (k < kc) {
               accr[e][k] = fma(w[k], pr, accr[e][k]);
               acci[e][k] = fma(w[k], pi, acci[e][k]);
             }
@@ -338,11 +337,12 @@ __global__ void __launch_bounds__(kGenThreads) gen_cov_kernel(GenCov a) {
       }
     }
   }
-  // class sums: only threads < kTile hold partials
-#pragma unroll
-  for (int k = 0; k < KM; ++k) {
-    const double tot = block_sum((k < K) ? ssum[k] : 0.0, red, tid);
-    if (tid == 0 && k < K) csum[k] = tot;
+  // class sums: fixed-order sum of the kTile staging slots
+  __syncthreads();
+  if (tid < K) {
+    double tot = 0.0;
+    for (int x = 0; x < kTile; ++x) tot += spart[tid * kTile + x];
+    csum[tid] = tot;
   }
   __syncthreads();
   double tot_abs = 0.0;
@@ -350,14 +350,15 @@ __global__ void __launch_bounds__(kGenThreads) gen_cov_kernel(GenCov a) {
   // frame groups -> one sum per entry, class by class through the (now free) frame tile
   double* part = ytile;  // [kGenThreads][kTe][2]
 #pragma unroll
-  for (int k = 0; k < KM; ++k) {
-    if (k < K) {
+  for (int kk = 0; kk < KM; ++kk) {
+    if (kk < kc) {
+      const int k = k0 + kk;
       __syncthreads();
       if (active) {
 #pragma unroll
         for (int e = 0; e < kTe; ++e) {
-          part[(tid * kTe + e) * 2] = accr[e][k];
-          part[(tid * kTe + e) * 2 + 1] = acci[e][k];
+          part[(tid * kTe + e) * 2] = accr[e][kk];
+          part[(tid * kTe + e) * 2 + 1] = acci[e][kk];
         }
       }
       __syncthreads();
@@ -402,7 +403,7 @@ __global__ void __launch_bounds__(kGenThreads) gen_cov_kernel(GenCov a) {
     }
   }
   if (tid == 0 && a.out_zero) a.out_zero[b] = zero_seen;
-  if (tid < K) {
+  if (tid >= k0 && tid < k0 + kc) {
     if (a.out_sum) a.out_sum[b * K + tid] = csum[tid];
     if (a.out_weight) {
       double w;
@@ -669,8 +670,13 @@ int launch_gen_estep(const void* y, int y_is_c128, int layout, int64_t B, int T,
              out_aff, out_q, out_logpdf};
   const dim3 grid((unsigned)B, (unsigned)((T + kGenThreads - 1) / kGenThreads));
   if (grid.y > 65535u) return PBBSS_ERR_UNSUPPORTED;
-#define PBBSS_GEN_E(DPV, YST) \
-  hipLaunchKernelGGL((gen_estep_kernel<DPV, YST>), grid, dim3(kGenThreads), 0, s, a);
+  const size_t lds = (size_t)2 * K * kGenThreads * sizeof(double);
+#define PBBSS_GEN_E(DPV, YST)                                                              \
+  {                                                                                        \
+    auto kfn = gen_estep_kernel<DPV, YST>;                                                 \
+    if (lds > 32768 && set_lds(kfn, lds, 65536) != PBBSS_OK) return PBBSS_ERR_HIP;         \
+    hipLaunchKernelGGL(kfn, grid, dim3(kGenThreads), lds, s, a);                           \
+  }
 #define PBBSS_GEN_ED(DPV) \
   case DPV: if (y_is_c128) { PBBSS_GEN_E(DPV, double) } else { PBBSS_GEN_E(DPV, float) } break;
   switch (DP) {
@@ -689,11 +695,9 @@ int launch_gen_cov(const void* y, int y_is_c128, int layout, int64_t B, int T, i
                    double* out_weight, double* out_sum, size_t lds_limit, hipStream_t s,
                    int32_t* out_zero) {
   if (!gen_supported(D, K)) return PBBSS_ERR_UNSUPPORTED;
-  GenCov a{y, layout, B, T, D, K, gamma, gamma_bstride, q, saliency, mode, weight_mode,
-           out_cov, out_weight, out_sum, out_zero};
   const int DP = D <= 16 ? 16 : 32;
-  const size_t lds =
-      (gen_cov_stage_doubles(DP) + (size_t)kGenMaxK * kTile + kGenWaves + kGenMaxK) * sizeof(double);
+  const size_t lds = (gen_cov_stage_doubles(DP) + (size_t)kCovMaxK * kTile +
+                      (size_t)kGenMaxK * kTile + kGenMaxK) * sizeof(double);
   int rc;
 #define PBBSS_GEN_C(DPV, KMV, YST)                                                         \
   {                                                                                        \
@@ -702,11 +706,19 @@ int launch_gen_cov(const void* y, int y_is_c128, int layout, int64_t B, int T, i
     hipLaunchKernelGGL(kfn, dim3((unsigned)B), dim3(kGenThreads), lds, s, a);              \
   }
 #define PBBSS_GEN_CK(DPV, YST) \
-  if (K <= 3) PBBSS_GEN_C(DPV, 3, YST) else PBBSS_GEN_C(DPV, kGenMaxK, YST)
-  if (DP == 16) {
-    if (y_is_c128) { PBBSS_GEN_CK(16, double) } else { PBBSS_GEN_CK(16, float) }
-  } else {
-    if (y_is_c128) { PBBSS_GEN_CK(32, double) } else { PBBSS_GEN_CK(32, float) }
+  if (kc <= 3) PBBSS_GEN_C(DPV, 3, YST) else PBBSS_GEN_C(DPV, kCovMaxK, YST)
+  // balanced chunks of at most kCovMaxK classes, e.g. K = 9 -> 5 + 4, K = 7 -> 4 + 3
+  const int nchunk = (K + kCovMaxK - 1) / kCovMaxK;
+  for (int c = 0, k0 = 0; c < nchunk; ++c) {
+    const int kc = (K - k0 + (nchunk - c) - 1) / (nchunk - c);
+    GenCov a{y, layout, B, T, D, K, gamma, gamma_bstride, q, saliency, mode, weight_mode,
+             out_cov, out_weight, out_sum, out_zero, k0, kc};
+    if (DP == 16) {
+      if (y_is_c128) { PBBSS_GEN_CK(16, double) } else { PBBSS_GEN_CK(16, float) }
+    } else {
+      if (y_is_c128) { PBBSS_GEN_CK(32, double) } else { PBBSS_GEN_CK(32, float) }
+    }
+    k0 += kc;
   }
 #undef PBBSS_GEN_CK
 #undef PBBSS_GEN_C

@@ -148,7 +148,7 @@ def test_unsupported_shapes_fail_loudly():
         CACGMMTrainer().fit(x, num_classes=2, iterations=1)  # D = 33 > 32 (generic path limit)
     x = rng.standard_normal((2, 50, 4)) + 1j * rng.standard_normal((2, 50, 4))
     with pytest.raises(NotImplementedError):
-        CACGMMTrainer().fit(x, num_classes=7, iterations=1)  # K = 7 > 6
+        CACGMMTrainer().fit(x, num_classes=17, iterations=1)  # K = 17 > 16
 
 
 # ------------------------------------------------------------------ extraction
