@@ -67,6 +67,31 @@ def test_many_classes(F, T, D, K):
                                ob.psd(X.astype(np.complex128), masks), atol=1e-11)
 
 
+def test_guided_source_separation_shape():
+    """The GSS recipe: many channels, speakers + noise classes, a boolean source activity mask
+    from the diarisation as both initialisation support and E-step constraint
+    (cacgmm.py:150-170, 242-247)."""
+    from oracle import cacgmm as oc, synth
+    from pb_bss_amd.distribution import CACGMMTrainer
+    F, T, D, K = 3, 240, 24, 9
+    Y, _ = synth.make_stft(F, T, D, K, seed=3)
+    Y128 = Y.astype(np.complex128)
+    rng = np.random.default_rng(2)
+    act = np.zeros((K, T), dtype=bool)
+    act[-1] = True                                             # noise class always active
+    for k in range(K - 1):
+        a0 = rng.integers(0, T - 60)
+        act[k, a0:a0 + rng.integers(30, 60)] = True
+    act = np.broadcast_to(act, (F, K, T)).copy()
+    init = act / act.sum(axis=-2, keepdims=True)
+    m = oc.em_fit(Y128, init, iterations=6, source_activity_mask=act)
+    model = CACGMMTrainer().fit(Y, initialization=init, iterations=6, source_activity_mask=act)
+    ref = oc.em_predict(m, Y128, source_activity_mask=act)
+    got = model.predict(Y, source_activity_mask=act)
+    np.testing.assert_allclose(got, ref, atol=1e-7)
+    assert np.all(got[~act] == 0)
+
+
 def test_options_resume_and_complex128_input():
     from oracle import cacgmm as oc, synth
     from pb_bss_amd.distribution import CACGMMTrainer
