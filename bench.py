@@ -102,7 +102,7 @@ def main():
     args = parse()
     import torch
     import torch.distributed as dist
-    from oracle import synth  # input generator shared with the parity tests
+    from pb_bss_amd.testing import synth  # input generator shared with the parity tests
     from pb_bss_amd import _lib, engine
     from pb_bss_amd.sharding import all_gather_bins, shard_bounds
 

@@ -9,7 +9,7 @@ Single GPU:   python examples/separate_batch.py --utterances 4
 N GPUs:       python -m torch.distributed.run --nproc-per-node N examples/separate_batch.py --utterances 8
 
 Everything between the input STFT and the enhanced STFT stays on the device(s).
-Synthetic input (oracle/synth.py generator, shared with the tests).
+Synthetic input (pb_bss_amd/testing/synth.py generator, shared with the tests).
 """
 import argparse
 import os
@@ -84,7 +84,7 @@ def main():
     args = ap.parse_args()
     import torch
     import torch.distributed as dist
-    from oracle import synth  # synthetic input generator only
+    from pb_bss_amd.testing import synth  # synthetic input generator
     use_dist = 'RANK' in os.environ
     if use_dist:
         torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
