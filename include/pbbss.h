@@ -280,6 +280,40 @@ int pbbss_dhtv_calculate_mapping(pbbss_handle_t h, const double* mask, int64_t U
                                  int32_t* out_mapping, int32_t* out_status,
                                  void* stream);
 
+/* ------------------------------------------------------------------------- */
+/* N1  OraclePermutationAlignment.calculate_mapping  permutation_alignment.py:703-786 */
+/*     GreedyPermutationAlignment.calculate_mapping  permutation_alignment.py:592-701 */
+/*     score matrices :380-417 (_ScoreMatrix.cos / multiply / euclidean),          */
+/*     assignment :469-589 (_mapping_from_score_matrix).                           */
+/* One launch scores every (utterance, bin) of `mask` against the same bin of      */
+/* `reference` and assigns the classes.  Both arrays are float64 with contiguous   */
+/* frames; *_strides = element strides of (utterance, class, bin) (HOST arrays of  */
+/* 3), so the greedy solver can pass mask[:, 1:] / mask[:, :-1] without a copy.    */
+/* out_scores f64 (U,F,K,K) [reference class][mask class] or NULL; out_mapping     */
+/* int32 (U,K,map_F): column map_col0 + f gets the permutation of bin f (reverse    */
+/* mapping, as the reference returns it); out_status int32 (U) gets                */
+/* PBBSS_ST_NONFINITE where the reference raises 'score matrix is infeasible'.     */
+/* K <= 8.                                                                          */
+/* ------------------------------------------------------------------------- */
+#define PBBSS_PA_COS 0
+#define PBBSS_PA_MULTIPLY 1
+#define PBBSS_PA_EUCLIDEAN 2
+int pbbss_pa_pairwise_mapping(pbbss_handle_t h, const double* mask, const double* reference,
+                              int64_t U, int K, int64_t F, int T, const int64_t* mask_strides,
+                              const int64_t* reference_strides, int metric, int optimal,
+                              double* out_scores, int32_t* out_mapping, int64_t map_F,
+                              int64_t map_col0, int32_t* out_status, void* stream);
+/* Greedy solver's recursion (:690-699) in place on mapping int32 (U,K,F): column 0 :=  */
+/* identity, then mapping[:, f] = mapping[mapping[:, f-1], f] for f = 1 .. F-1           */
+/* (a prefix scan over permutation compositions).                                         */
+int pbbss_pa_compose_mapping(pbbss_handle_t h, int32_t* mapping, int64_t U, int K, int64_t F,
+                             void* stream);
+/* _mapping_from_score_matrix (:469-589): scores f64 (N,K,K) -> out_mapping int32 (K,N); */
+/* out_status int32 (1) gets PBBSS_ST_NONFINITE for non-finite scores.                    */
+int pbbss_pa_mapping_from_scores(pbbss_handle_t h, const double* scores, int64_t N, int K,
+                                 int optimal, int32_t* out_mapping, int32_t* out_status,
+                                 void* stream);
+
 /* apply_mapping  permutation_alignment.py:54-104:                              */
 /* out[u,k,f,:] = mask[u, mapping[u,k,f], f, :];  mask/out f64 (U,K,F,T).        */
 int pbbss_apply_mapping(pbbss_handle_t h, const double* mask,

@@ -196,6 +196,55 @@ def dhtv_cases():
     _save('dhtv_alignment', **out)
 
 
+def pairwise_alignment_cases():
+    """Greedy / Oracle solvers and _mapping_from_score_matrix of the unmodified reference."""
+    from pb_bss.permutation_alignment import (GreedyPermutationAlignment,
+                                              OraclePermutationAlignment,
+                                              _mapping_from_score_matrix, _ScoreMatrix)
+    rng = np.random.default_rng(11)
+    out = {}
+    for tag, K, F, T in [('k2', 2, 33, 40), ('k3', 3, 65, 50), ('k4', 4, 17, 30)]:
+        act = rng.uniform(size=(K, T)) ** 4
+        ref = act[:, None, :] * rng.uniform(0.5, 1.0, size=(K, F, T)) \
+            + 0.05 * rng.uniform(size=(K, F, T))
+        ref /= ref.sum(0, keepdims=True)
+        perm = np.stack([rng.permutation(K) for _ in range(F)], 1)
+        mask = ref[perm, range(F)] * rng.uniform(0.8, 1.2, size=(K, F, T))
+        mask = mask.astype(np.float32).astype(np.float64)
+        ref = ref.astype(np.float32).astype(np.float64)
+        out[tag + '_mask'] = mask.astype(np.float32)
+        out[tag + '_reference'] = ref.astype(np.float32)
+        for metric in ('cos', 'multiply', 'euclidean'):
+            out[f'{tag}_{metric}_scores'] = getattr(_ScoreMatrix, metric)(mask, ref)
+            out[f'{tag}_{metric}_greedy'] = GreedyPermutationAlignment(
+                similarity_metric=metric).calculate_mapping(mask)
+            for alg in ('greedy', 'optimal'):
+                out[f'{tag}_{metric}_oracle_{alg}'] = OraclePermutationAlignment(
+                    similarity_metric=metric, algorithm=alg).calculate_mapping(mask, ref)
+    # block masks in the style of the class doctests (:628-676, :727-775): exact ties
+    K, F, T = 3, 25, 6
+    blocks = np.zeros((K, F, T))
+    for k in range(K):
+        blocks[k, 5:, 2 * k:2 * k + 2] = 1
+    ref = blocks.copy()
+    perm = np.stack([rng.permutation(K) if 10 <= f < 14 else np.arange(K) for f in range(F)], 1)
+    perm[:, 14:] = np.array([2, 1, 0])[:, None]
+    mask = blocks[perm, range(F)]
+    out['blocks_mask'] = mask
+    out['blocks_reference'] = ref
+    out['blocks_greedy'] = GreedyPermutationAlignment().calculate_mapping(mask)
+    out['blocks_oracle'] = OraclePermutationAlignment().calculate_mapping(mask, ref)
+    out['blocks_greedy_cos'] = GreedyPermutationAlignment('cos').calculate_mapping(mask)
+    out['blocks_oracle_cos_greedy'] = OraclePermutationAlignment('cos', 'greedy') \
+        .calculate_mapping(mask, ref)
+    sc = rng.normal(size=(40, 4, 4))
+    sc[:5] = np.round(sc[:5])  # ties
+    out['scores'] = sc
+    out['scores_greedy'] = _mapping_from_score_matrix(sc, 'greedy')
+    out['scores_optimal'] = _mapping_from_score_matrix(sc, 'optimal')
+    _save('pairwise_alignment', **out)
+
+
 def cwmm_cases():
     from pb_bss.distribution.cwmm import CWMMTrainer
     from pb_bss.distribution.complex_watson import ComplexWatson, ComplexWatsonTrainer
@@ -338,6 +387,7 @@ def main():
     cacg_cases()
     beamformer_cases()
     dhtv_cases()
+    pairwise_alignment_cases()
     cwmm_cases()
     embed_cases()
     beamformer_extra_cases()

@@ -7,7 +7,8 @@ import itertools
 import numpy as np
 
 __all__ = ['alignment_plan', 'mapping_from_score_matrix', 'dhtv_calculate_mapping',
-           'apply_mapping', 'PRESETS']
+           'apply_mapping', 'PRESETS', 'score_matrix', 'mapping_from_score_matrices',
+           'greedy_calculate_mapping', 'oracle_calculate_mapping']
 
 # from_stft_size presets, permutation_alignment.py:164-184
 PRESETS = {
@@ -114,3 +115,49 @@ def apply_mapping(mask, mapping):
     """permutation_alignment.py:54-104: mask (K, F, ...), mapping (K, F)."""
     K, F = mapping.shape
     return mask[mapping, range(F)]
+
+
+def score_matrix(mask, reference_mask, similarity_metric):
+    """permutation_alignment.py:396-417 (_ScoreMatrix.cos / multiply / euclidean) for
+    mask, reference_mask (K, F, T) -> (F, K, K) indexed [bin, reference class, mask class]."""
+    mask = np.asarray(mask, dtype=np.float64)
+    reference_mask = np.asarray(reference_mask, dtype=np.float64)
+    if similarity_metric == 'cos':
+        mask, reference_mask = _unit(mask), _unit(reference_mask)
+    if similarity_metric in ('cos', 'multiply'):
+        return np.einsum('KFT,kFT->FkK', mask, reference_mask)
+    if similarity_metric == 'euclidean':
+        # -sqrt(sum |mask[:, None] - ref[None]|^2, -1).T : (K_mask, k_ref, F) reversed
+        d = np.sqrt(np.sum((mask[:, None] - reference_mask[None]) ** 2, axis=-1))
+        return -np.transpose(d, (2, 1, 0))
+    raise AttributeError(similarity_metric)
+
+
+def mapping_from_score_matrices(scores, algorithm):
+    """permutation_alignment.py:469-589 over a stack (F, K, K) -> (K, F)."""
+    scores = np.asarray(scores)
+    if not np.all(np.isfinite(scores)):
+        raise ValueError('score matrix is infeasible')
+    return np.stack([mapping_from_score_matrix(s, algorithm) for s in scores], axis=1)
+
+
+def greedy_calculate_mapping(mask, similarity_metric='euclidean'):
+    """GreedyPermutationAlignment.calculate_mapping, permutation_alignment.py:614-701:
+    every bin against its lower neighbour with the 'greedy' assignment (:687-688), identity
+    for bin 0 (:690-691), then mapping[:, f] = mapping[mapping[:, f-1], f] (:694-695)."""
+    K, F, T = mask.shape
+    assert K < 10 and F % 2 == 1
+    scores = score_matrix(mask[:, 1:, :], mask[:, :-1, :], similarity_metric)
+    mapping = mapping_from_score_matrices(scores, 'greedy') if F > 1 else np.zeros((K, 0), int)
+    mapping = np.append(np.arange(K, dtype=mapping.dtype)[:, None], mapping, axis=-1)
+    for f in range(1, F):
+        mapping[:, f] = mapping[mapping[:, f - 1], f]
+    return mapping
+
+
+def oracle_calculate_mapping(mask, reference_mask, similarity_metric='euclidean',
+                             algorithm='optimal'):
+    """OraclePermutationAlignment.calculate_mapping, permutation_alignment.py:711-786."""
+    assert mask.shape == reference_mask.shape
+    return mapping_from_score_matrices(score_matrix(mask, reference_mask, similarity_metric),
+                                       algorithm)

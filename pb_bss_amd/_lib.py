@@ -47,6 +47,7 @@ EXPORTS = (
     'pbbss_distortionless_normalization', 'pbbss_zero_degree_normalization',
     'pbbss_condition_covariance', 'pbbss_apply_online_beamforming_vector',
     'pbbss_set_dhtv_team', 'pbbss_stft_num_frames', 'pbbss_stft', 'pbbss_istft',
+    'pbbss_pa_pairwise_mapping', 'pbbss_pa_compose_mapping', 'pbbss_pa_mapping_from_scores',
 )
 
 EMBED_VMF = 0
@@ -148,6 +149,10 @@ def load():
         lib.pbbss_istft.argtypes = [vp, vp, i32, i64, i32, i32, i32, i32, vp, i32, vp, i64, vp]
         lib.pbbss_dhtv_calculate_mapping.argtypes = [vp, vp, i64, i32, i32, i32, vp, i32, i32, vp, vp, vp, vp]
         lib.pbbss_apply_mapping.argtypes = [vp, vp, vp, i64, i32, i32, i32, vp, vp]
+        lib.pbbss_pa_pairwise_mapping.argtypes = [vp, vp, vp, i64, i32, i64, i32, vp, vp, i32, i32,
+                                                  vp, vp, i64, i64, vp, vp]
+        lib.pbbss_pa_compose_mapping.argtypes = [vp, vp, i64, i32, i64, vp]
+        lib.pbbss_pa_mapping_from_scores.argtypes = [vp, vp, i64, i32, i32, vp, vp, vp]
         lib.pbbss_cwmm_fit.argtypes = [
             vp, vp, i64, i32, i32, i32, vp, vp, vp, vp, vp, ctypes.POINTER(CwmmOpts), vp, vp,
             vp, vp, vp, vp, vp, vp, vp]

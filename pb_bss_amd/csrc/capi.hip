@@ -642,6 +642,39 @@ PBBSS_API int pbbss_dhtv_calculate_mapping(pbbss_handle_t h, const double* mask,
                             h->team_bytes, as_stream(stream));
 }
 
+PBBSS_API int pbbss_pa_pairwise_mapping(pbbss_handle_t h, const double* mask,
+                                        const double* reference, int64_t U, int K, int64_t F,
+                                        int T, const int64_t* mask_strides,
+                                        const int64_t* reference_strides, int metric, int optimal,
+                                        double* out_scores, int32_t* out_mapping, int64_t map_F,
+                                        int64_t map_col0, int32_t* out_status, void* stream) {
+  DeviceGuard device_guard(h);
+  if (!h || !mask || !reference || !mask_strides || !reference_strides || !out_mapping ||
+      !out_status)
+    return PBBSS_ERR_INVALID_ARG;
+  if (U <= 0 || F <= 0 || T <= 0 || map_col0 < 0 || map_col0 + F > map_F)
+    return PBBSS_ERR_INVALID_ARG;
+  return pbbss::launch_pa_pair(mask, reference, U, K, F, T, mask_strides, reference_strides,
+                               metric, optimal, out_scores, out_mapping, map_F, map_col0,
+                               out_status, as_stream(stream));
+}
+
+PBBSS_API int pbbss_pa_compose_mapping(pbbss_handle_t h, int32_t* mapping, int64_t U, int K,
+                                       int64_t F, void* stream) {
+  DeviceGuard device_guard(h);
+  if (!h || !mapping || U <= 0 || F <= 0) return PBBSS_ERR_INVALID_ARG;
+  return pbbss::launch_pa_compose(mapping, U, K, F, as_stream(stream));
+}
+
+PBBSS_API int pbbss_pa_mapping_from_scores(pbbss_handle_t h, const double* scores, int64_t N,
+                                           int K, int optimal, int32_t* out_mapping,
+                                           int32_t* out_status, void* stream) {
+  DeviceGuard device_guard(h);
+  if (!h || !scores || !out_mapping || !out_status || N <= 0) return PBBSS_ERR_INVALID_ARG;
+  return pbbss::launch_pa_assign(scores, N, K, optimal, out_mapping, out_status,
+                                 as_stream(stream));
+}
+
 PBBSS_API int pbbss_apply_mapping(pbbss_handle_t h, const double* mask, const int32_t* mapping,
                                   int64_t U, int K, int F, int T, double* out, void* stream) {
   DeviceGuard device_guard(h);

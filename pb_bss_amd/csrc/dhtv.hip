@@ -508,6 +508,228 @@ __global__ void __launch_bounds__(256)
   for (int t = threadIdx.x; t < T; t += blockDim.x) dst[t] = src[t];
 }
 
+// ---------------------------------------------------------------------------------------
+// Pairwise solvers: OraclePermutationAlignment.calculate_mapping (permutation_alignment.py
+// :703-786) and GreedyPermutationAlignment.calculate_mapping (:592-701).  Every bin is
+// independent: one wavefront per (utterance, bin) forms the K x K score matrix of `mask`
+// against `reference` (_ScoreMatrix.cos / multiply / euclidean, :396-417: rows = reference
+// class, columns = mask class) and assigns the classes (:469-589).  The greedy solver's
+// recursion mapping[:, f] = mapping[mapping[:, f-1], f] (:698-699) is a composition of
+// permutations -- associative -- so it runs as one wave scan per utterance.
+// ---------------------------------------------------------------------------------------
+struct PaPairArgs {
+  const double* mask;
+  const double* ref;
+  int64_t m_su, m_sk, m_sf;  // element strides of (utterance, class, bin); frames contiguous
+  int64_t r_su, r_sk, r_sf;
+  int64_t U, F;
+  int T;
+  int metric, optimal;
+  double* scores;     // (U, F, K, K) or null
+  int32_t* mapping;   // (U, K, map_F): column map_col0 + f receives the bin's permutation
+  int64_t map_F, map_col0;
+  int32_t* status;    // (U)
+};
+
+template <int K>
+__global__ void __launch_bounds__(256) pa_pair_kernel(PaPairArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t id = (int64_t)blockIdx.x * 4 + wave;
+  if (id >= a.U * a.F) return;
+  const int64_t u = id / a.F, f = id - u * a.F;
+  const double* m = a.mask + u * a.m_su + f * a.m_sf;
+  const double* r = a.ref + u * a.r_su + f * a.r_sf;
+  const int T = a.T;
+  double nm[K], nr[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) nm[k] = nr[k] = 1.0;
+  if (a.metric == PBBSS_PA_COS) {
+    // _parameterized_vector_norm (:358-377): a / max(||a||, tiny) along the frames
+    double sm[K], sr[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) sm[k] = sr[k] = 0.0;
+    for (int t = lane; t < T; t += kWave) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        double x = m[k * a.m_sk + t], y = r[k * a.r_sk + t];
+        sm[k] = fma(x, x, sm[k]);
+        sr[k] = fma(y, y, sr[k]);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      nm[k] = fmax(sqrt(wave_sum(sm[k])), kTiny);
+      nr[k] = fmax(sqrt(wave_sum(sr[k])), kTiny);
+    }
+  }
+  double sc[K][K];  // [reference class][mask class]
+#pragma unroll
+  for (int i = 0; i < K; ++i)
+#pragma unroll
+    for (int j = 0; j < K; ++j) sc[i][j] = 0.0;
+  for (int t = lane; t < T; t += kWave) {
+    double mv[K], rv[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      mv[k] = m[k * a.m_sk + t];
+      rv[k] = r[k * a.r_sk + t];
+    }
+    if (a.metric == PBBSS_PA_COS) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        mv[k] /= nm[k];
+        rv[k] /= nr[k];
+      }
+    }
+    if (a.metric == PBBSS_PA_EUCLIDEAN) {
+#pragma unroll
+      for (int i = 0; i < K; ++i)
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+          double d = mv[j] - rv[i];
+          sc[i][j] = fma(d, d, sc[i][j]);
+        }
+    } else {
+#pragma unroll
+      for (int i = 0; i < K; ++i)
+#pragma unroll
+        for (int j = 0; j < K; ++j) sc[i][j] = fma(rv[i], mv[j], sc[i][j]);
+    }
+  }
+  bool finite = true;
+#pragma unroll
+  for (int i = 0; i < K; ++i)
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      double v = wave_sum(sc[i][j]);
+      if (a.metric == PBBSS_PA_EUCLIDEAN) v = -sqrt(v);  // distance -> similarity (:412-416)
+      sc[i][j] = v;
+      finite = finite && isfinite(v);
+      if (a.scores && lane == 0) a.scores[((u * a.F + f) * K + i) * K + j] = v;
+    }
+  if (!finite) {  // reference: ValueError('score matrix is infeasible') (:512-514)
+    if (lane == 0) atomicOr(a.status + u, (int32_t)PBBSS_ST_NONFINITE);
+  }
+  int perm[K];
+  assign_classes<K>(sc, a.optimal, perm);
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < K; ++i) a.mapping[(u * K + i) * a.map_F + a.map_col0 + f] = perm[i];
+  }
+}
+
+// permutations of K <= 8 classes packed 4 bits per entry; (x o y)[k] = x[y[k]]
+__device__ __forceinline__ unsigned perm_compose(unsigned x, unsigned y, int K) {
+  unsigned r = 0;
+  for (int k = 0; k < K; ++k) r |= ((x >> (4 * ((y >> (4 * k)) & 15u))) & 15u) << (4 * k);
+  return r;
+}
+
+// Greedy solver, :690-699: column 0 = identity, then mapping[:, f] = mapping[mapping[:, f-1], f]
+// for f = 1 .. F-1, i.e. new_f = M_f o M_{f-1} o ... o M_1.  One wavefront per utterance: each
+// lane composes a contiguous chunk of bins, an inclusive wave scan combines the chunk
+// aggregates, then the lane rewrites its chunk starting from its prefix.
+__global__ void __launch_bounds__(64) pa_compose_kernel(int32_t* mapping, int K, int64_t F) {
+  const int lane = threadIdx.x;
+  int32_t* mp = mapping + (int64_t)blockIdx.x * K * F;
+  unsigned ident = 0;
+  for (int k = 0; k < K; ++k) ident |= (unsigned)k << (4 * k);
+  if (lane == 0)
+    for (int k = 0; k < K; ++k) mp[(int64_t)k * F] = k;
+  const int64_t c = (F - 1 + 63) / 64;
+  const int64_t f0 = 1 + lane * c, f1 = (f0 + c < F) ? f0 + c : F;
+  unsigned agg = ident;
+  for (int64_t f = f0; f < f1; ++f) {
+    unsigned M = 0;
+    for (int k = 0; k < K; ++k) M |= ((unsigned)mp[(int64_t)k * F + f] & 15u) << (4 * k);
+    agg = perm_compose(M, agg, K);
+  }
+  unsigned x = agg;
+  for (int d = 1; d < 64; d <<= 1) {
+    unsigned o = __shfl_up(x, d, 64);
+    if (lane >= d) x = perm_compose(x, o, K);
+  }
+  unsigned cur = __shfl_up(x, 1, 64);
+  if (lane == 0) cur = ident;
+  for (int64_t f = f0; f < f1; ++f) {
+    unsigned M = 0;
+    for (int k = 0; k < K; ++k) M |= ((unsigned)mp[(int64_t)k * F + f] & 15u) << (4 * k);
+    cur = perm_compose(M, cur, K);
+    for (int k = 0; k < K; ++k) mp[(int64_t)k * F + f] = (int32_t)((cur >> (4 * k)) & 15u);
+  }
+}
+
+// _mapping_from_score_matrix (:469-589) on given scores (N, K, K): thread = matrix
+template <int K>
+__global__ void __launch_bounds__(256)
+    pa_assign_kernel(const double* __restrict__ scores, int64_t N, int optimal,
+                     int32_t* __restrict__ mapping, int32_t* __restrict__ status) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  double sc[K][K];
+  bool finite = true;
+#pragma unroll
+  for (int i = 0; i < K; ++i)
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      sc[i][j] = scores[(n * K + i) * K + j];
+      finite = finite && isfinite(sc[i][j]);
+    }
+  if (!finite) atomicOr(status, (int32_t)PBBSS_ST_NONFINITE);
+  int perm[K];
+  assign_classes<K>(sc, optimal, perm);
+#pragma unroll
+  for (int i = 0; i < K; ++i) mapping[(int64_t)i * N + n] = perm[i];
+}
+
+#define PBBSS_PA_SWITCH(K, CASE)                                                               \
+  switch (K) {                                                                                 \
+    CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)                            \
+    default: return PBBSS_ERR_UNSUPPORTED;                                                     \
+  }
+
+int launch_pa_pair(const double* mask, const double* ref, int64_t U, int K, int64_t F, int T,
+                   const int64_t* ms, const int64_t* rs, int metric, int optimal, double* scores,
+                   int32_t* mapping, int64_t map_F, int64_t map_col0, int32_t* status,
+                   hipStream_t s) {
+  if (K < 1 || K > kDhtvMaxK) return PBBSS_ERR_UNSUPPORTED;
+  if (metric < PBBSS_PA_COS || metric > PBBSS_PA_EUCLIDEAN) return PBBSS_ERR_INVALID_ARG;
+  PaPairArgs a{mask, ref, ms[0], ms[1], ms[2], rs[0], rs[1], rs[2], U, F, T, metric, optimal,
+               scores, mapping, map_F, map_col0, status};
+  const int64_t blocks = (U * F + 3) / 4;
+  if (blocks > 2147483647LL) return PBBSS_ERR_UNSUPPORTED;
+#define PBBSS_PA_CASE(KK)                                                                      \
+  case KK:                                                                                     \
+    hipLaunchKernelGGL(pa_pair_kernel<KK>, dim3((unsigned)blocks), dim3(256), 0, s, a);       \
+    break;
+  PBBSS_PA_SWITCH(K, PBBSS_PA_CASE)
+#undef PBBSS_PA_CASE
+  return hipGetLastError() == hipSuccess ? PBBSS_OK : PBBSS_ERR_HIP;
+}
+
+int launch_pa_compose(int32_t* mapping, int64_t U, int K, int64_t F, hipStream_t s) {
+  if (K < 1 || K > kDhtvMaxK) return PBBSS_ERR_UNSUPPORTED;
+  if (U > 2147483647LL) return PBBSS_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(pa_compose_kernel, dim3((unsigned)U), dim3(64), 0, s, mapping, K, F);
+  return hipGetLastError() == hipSuccess ? PBBSS_OK : PBBSS_ERR_HIP;
+}
+
+int launch_pa_assign(const double* scores, int64_t N, int K, int optimal, int32_t* mapping,
+                     int32_t* status, hipStream_t s) {
+  if (K < 1 || K > kDhtvMaxK) return PBBSS_ERR_UNSUPPORTED;
+  const int64_t blocks = (N + 255) / 256;
+  if (blocks > 2147483647LL) return PBBSS_ERR_UNSUPPORTED;
+#define PBBSS_PA_CASE(KK)                                                                      \
+  case KK:                                                                                     \
+    hipLaunchKernelGGL(pa_assign_kernel<KK>, dim3((unsigned)blocks), dim3(256), 0, s, scores,  \
+                       N, optimal, mapping, status);                                           \
+    break;
+  PBBSS_PA_SWITCH(K, PBBSS_PA_CASE)
+#undef PBBSS_PA_CASE
+  return hipGetLastError() == hipSuccess ? PBBSS_OK : PBBSS_ERR_HIP;
+}
+#undef PBBSS_PA_SWITCH
+
 int launch_dhtv(const double* mask, int64_t U, int K, int F, int T, const int32_t* plan, int P,
                 int optimal, double* feat, int32_t* mapping, int32_t* status, size_t lds_limit,
                 int num_cu, int team_size, void* team_buf, size_t team_bytes, hipStream_t s) {

@@ -14,4 +14,12 @@ int launch_dhtv(const double* mask, int64_t U, int K, int F, int T, const int32_
                 int num_cu, int team_size, void* team_buf, size_t team_bytes, hipStream_t s);
 int launch_apply_mapping(const double* mask, const int32_t* mapping, int64_t U, int K, int F,
                          int T, double* out, hipStream_t s);
+// pairwise solvers (Oracle / Greedy alignment) and the assignment on given score matrices
+int launch_pa_pair(const double* mask, const double* ref, int64_t U, int K, int64_t F, int T,
+                   const int64_t* mask_strides, const int64_t* ref_strides, int metric,
+                   int optimal, double* scores, int32_t* mapping, int64_t map_F, int64_t map_col0,
+                   int32_t* status, hipStream_t s);
+int launch_pa_compose(int32_t* mapping, int64_t U, int K, int64_t F, hipStream_t s);
+int launch_pa_assign(const double* scores, int64_t N, int K, int optimal, int32_t* mapping,
+                     int32_t* status, hipStream_t s);
 }  // namespace pbbss

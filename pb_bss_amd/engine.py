@@ -307,6 +307,65 @@ def apply_mapping(mask, mapping):
     return out
 
 
+PA_METRIC = {'cos': 0, 'multiply': 1, 'euclidean': 2}
+
+
+def _strides3(x):
+    """element strides of (utterance, class, bin) of a (U,K,F,T) tensor with contiguous frames"""
+    assert x.stride(-1) == 1 or x.shape[-1] == 1, x.stride()
+    return (ctypes.c_int64 * 3)(x.stride(0), x.stride(1), x.stride(2))
+
+
+def _view_ptr(x):
+    """device pointer of a (possibly strided) view; the strides travel separately"""
+    assert x.is_cuda, x.device
+    return ctypes.c_void_p(x.data_ptr())
+
+
+def pa_pairwise_mapping(mask, reference, metric, optimal, *, mapping=None, col0=0,
+                        want_scores=False):
+    """pbbss_pa_pairwise_mapping: mask / reference (U,K,F,T) f64 views (frames contiguous)
+    -> (mapping int32 (U,K,map_F) with columns col0 .. col0+F-1 filled, scores or None,
+    status (U,))."""
+    t = _t()
+    U, K, F, T = mask.shape
+    assert tuple(reference.shape) == (U, K, F, T), (mask.shape, reference.shape)
+    if mapping is None:
+        mapping = t.empty((U, K, col0 + F), dtype=t.int32, device=mask.device)
+    scores = t.empty((U, F, K, K), dtype=t.float64, device=mask.device) if want_scores else None
+    st = t.zeros((U,), dtype=t.int32, device=mask.device)
+    rc = _lib.load().pbbss_pa_pairwise_mapping(
+        _lib.handle(mask.device.index), _view_ptr(mask), _view_ptr(reference), U, K, F, T,
+        _strides3(mask), _strides3(reference), PA_METRIC[metric], int(bool(optimal)),
+        _lib.ptr(scores) if want_scores else None, _lib.ptr(mapping), int(mapping.shape[-1]),
+        int(col0), _lib.ptr(st), _lib.stream_ptr(mask.device.index))
+    _lib.check(rc, f'pa_pairwise_mapping(U={U},K={K},F={F},T={T},{metric})')
+    return mapping, scores, st
+
+
+def pa_compose_mapping(mapping):
+    """pbbss_pa_compose_mapping, in place on mapping int32 (U,K,F)."""
+    U, K, F = mapping.shape
+    rc = _lib.load().pbbss_pa_compose_mapping(
+        _lib.handle(mapping.device.index), _lib.ptr(mapping), U, K, F,
+        _lib.stream_ptr(mapping.device.index))
+    _lib.check(rc, f'pa_compose_mapping(U={U},K={K},F={F})')
+    return mapping
+
+
+def pa_mapping_from_scores(scores, optimal):
+    """pbbss_pa_mapping_from_scores: scores (N,K,K) f64 -> (mapping int32 (K,N), status (1,))."""
+    t = _t()
+    N, K, _ = scores.shape
+    mapping = t.empty((K, N), dtype=t.int32, device=scores.device)
+    st = t.zeros((1,), dtype=t.int32, device=scores.device)
+    rc = _lib.load().pbbss_pa_mapping_from_scores(
+        _lib.handle(scores.device.index), _lib.ptr(scores), N, K, int(bool(optimal)),
+        _lib.ptr(mapping), _lib.ptr(st), _lib.stream_ptr(scores.device.index))
+    _lib.check(rc, f'pa_mapping_from_scores(N={N},K={K})')
+    return mapping, st
+
+
 def cwmm_fit(y, K, spline, *, gamma0=None, model=None, iterations=100, saliency=None,
              weight_mode=0, final_predict=False, want_log_pdf=False, check_status=True):
     """pbbss_cwmm_fit.  y (B,T,D) complex; gamma0 (B,K,T) f64 or

@@ -7,15 +7,20 @@ examples/mixture_model_example.ipynb): same constructor arguments, presets,
 The whole plan runs in one kernel launch (csrc/dhtv.hip); masks are
 (K, F, T) like the reference, or (..., K, F, T) for batches of utterances.
 
-Device coverage: similarity_metric 'cos' (the default of `from_stft_size`)
-with algorithm 'greedy' (default) or 'optimal'.  Other metrics raise
-NotImplementedError.
+Device coverage: DHTV with similarity_metric 'cos' (the default of
+`from_stft_size`) and algorithm 'greedy' (default) or 'optimal'; other DHTV
+metrics raise NotImplementedError.  `GreedyPermutationAlignment` and
+`OraclePermutationAlignment` (reference :592-786) run every metric
+('cos', 'multiply', 'euclidean') and both assignment algorithms on the device
+(one wavefront per frequency bin; the greedy solver's recursion is a
+permutation prefix scan), as does `_mapping_from_score_matrix`.
 """
 import numpy as np
 
 from . import _lib, engine
 
-__all__ = ['DHTVPermutationAlignment', 'apply_mapping']
+__all__ = ['DHTVPermutationAlignment', 'GreedyPermutationAlignment',
+           'OraclePermutationAlignment', 'apply_mapping']
 
 
 def _interleave(a, b):
@@ -139,4 +144,104 @@ class DHTVPermutationAlignment(_PermutationAlignment):
         if int(st.max().item()) != 0:
             raise ValueError('score matrix is infeasible')  # reference :512-514
         mapping = mapping.reshape(*lead, K, F).to(t.int64)
+        return mapping if like_torch else _lib.to_host(mapping)
+
+
+_METRICS = ('cos', 'multiply', 'euclidean')  # _ScoreMatrix (:380-417)
+
+
+def _check_metric(similarity_metric):
+    if similarity_metric not in _METRICS:
+        # the reference resolves the name with getattr(_ScoreMatrix, name) (:434-449)
+        raise AttributeError(
+            f"type object '_ScoreMatrix' has no attribute {similarity_metric!r}\n"
+            'Suggestions: cos, euclidean, from_name, multiply')
+
+
+def _mapping_from_score_matrix(score_matrix, algorithm='optimal'):
+    """score_matrix (..., K, K) [reference class, mask class] -> reverse mapping (K, ...)
+    (reference :469-589: 'greedy' takes the flat argmax K times, 'optimal' is the brute-force
+    search in itertools.permutations order)."""
+    if algorithm not in ('greedy', 'optimal'):
+        raise ValueError(algorithm)
+    like_torch = _lib.is_torch(score_matrix)
+    t = _lib.torch()
+    sc = _lib.to_device(score_matrix, t.float64)
+    *F, K, K_ = sc.shape
+    assert K == K_, (tuple(sc.shape), K, K_)
+    mapping, st = engine.pa_mapping_from_scores(sc.reshape(-1, K, K).contiguous(),
+                                                optimal=(algorithm == 'optimal'))
+    if int(st.max().item()) != 0:
+        raise ValueError('score matrix is infeasible')
+    mapping = mapping.reshape(K, *F).to(t.int64)
+    return mapping if like_torch else _lib.to_host(mapping)
+
+
+class GreedyPermutationAlignment(_PermutationAlignment):
+    """Aligns every frequency to its lower neighbour and chains the result
+    (reference :592-701).  As in the reference, the neighbour assignment is always the
+    'greedy' one (:688); `algorithm` is stored but not used by `calculate_mapping`."""
+
+    def __init__(self, similarity_metric='euclidean', algorithm='optimal'):
+        if similarity_metric not in _METRICS:
+            raise ValueError(similarity_metric)  # reference :609-612
+        self.similarity_metric = similarity_metric
+        self.algorithm = algorithm
+
+    def calculate_mapping(self, mask):
+        """mask (K, F, T) [or (..., K, F, T)] -> reverse mapping (K, F) int64."""
+        like_torch = _lib.is_torch(mask)
+        t = _lib.torch()
+        m = _lib.to_device(mask, t.float64)
+        if m.is_complex():
+            raise NotImplementedError(m.dtype)
+        *lead, K, F, T = m.shape
+        assert K < 10, (K, 'Sure?')
+        assert F % 2 == 1, (F, 'Sure? Usually F is odd.', tuple(m.shape))
+        m = m.reshape(-1, K, F, T).contiguous()
+        mapping = t.empty((m.shape[0], K, F), dtype=t.int32, device=m.device)
+        if F > 1:
+            _, _, st = engine.pa_pairwise_mapping(m[:, :, 1:], m[:, :, :-1],
+                                                  self.similarity_metric, optimal=False,
+                                                  mapping=mapping, col0=1)
+            if int(st.max().item()) != 0:
+                raise ValueError('score matrix is infeasible')
+        engine.pa_compose_mapping(mapping)
+        mapping = mapping.reshape(*lead, K, F).to(t.int64)
+        return mapping if like_torch else _lib.to_host(mapping)
+
+
+class OraclePermutationAlignment(_PermutationAlignment):
+    """Aligns every frequency of `mask` to the same frequency of `reference_mask`
+    (reference :703-786)."""
+
+    def __init__(self, similarity_metric='euclidean', algorithm='optimal'):
+        assert algorithm in ['greedy', 'optimal'], algorithm
+        _check_metric(similarity_metric)
+        self.similarity_metric = similarity_metric
+        self.algorithm = algorithm
+
+    def calculate_mapping(self, mask, reference_mask):
+        """mask, reference_mask (K, F, T) or (K, T) -> reverse mapping (K, F) / (K,) int64."""
+        like_torch = _lib.is_torch(mask)
+        t = _lib.torch()
+        m = _lib.to_device(mask, t.float64)
+        r = _lib.to_device(reference_mask, t.float64).to(m.device)
+        assert tuple(m.shape) == tuple(r.shape), (tuple(m.shape), tuple(r.shape))
+        if m.is_complex() or r.is_complex():
+            raise NotImplementedError(m.dtype, r.dtype)
+        K, *F, T = m.shape
+        assert K < 10, (K, 'Sure?')
+        if len(F) == 1:
+            assert F[0] % 2 == 1, (F, 'Sure? Usually F is odd.', tuple(m.shape))
+        if len(F) > 1:
+            raise NotImplementedError(
+                'more than one independent axis: reshape to (K, F, T) first')
+        nF = F[0] if F else 1
+        mapping, _, st = engine.pa_pairwise_mapping(
+            m.reshape(1, K, nF, T).contiguous(), r.reshape(1, K, nF, T).contiguous(),
+            self.similarity_metric, optimal=(self.algorithm == 'optimal'))
+        if int(st.max().item()) != 0:
+            raise ValueError('score matrix is infeasible')
+        mapping = mapping.reshape(K, *F).to(t.int64)
         return mapping if like_torch else _lib.to_host(mapping)

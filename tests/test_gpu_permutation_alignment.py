@@ -91,3 +91,84 @@ def test_team_kernel_equals_single_workgroup_kernel_and_oracle(K, F, T, stft):
             assert np.array_equal(solver.calculate_mapping(mask[0]), want[0]), team
     finally:
         engine.set_dhtv_team(0)
+
+
+def test_pairwise_solvers_identical_to_reference():
+    """GreedyPermutationAlignment / OraclePermutationAlignment / _mapping_from_score_matrix on
+    the device against vectors of the real reference: integer mappings must be identical."""
+    from pb_bss_amd.permutation_alignment import (GreedyPermutationAlignment,
+                                                  OraclePermutationAlignment,
+                                                  _mapping_from_score_matrix)
+    from pb_bss_amd import _lib, engine
+    g = np.load(os.path.join(GOLDEN, 'pairwise_alignment.npz'))
+    for tag in ('k2', 'k3', 'k4'):
+        m = g[tag + '_mask'].astype(np.float64)
+        r = g[tag + '_reference'].astype(np.float64)
+        for metric in ('cos', 'multiply', 'euclidean'):
+            _, sc, _ = engine.pa_pairwise_mapping(
+                _lib.to_device(m)[None], _lib.to_device(r)[None], metric, False, want_scores=True)
+            ref_sc = g[f'{tag}_{metric}_scores']
+            assert np.abs(_lib.to_host(sc)[0] - ref_sc).max() < 1e-12 * max(1.0, np.abs(ref_sc).max())
+            mp = GreedyPermutationAlignment(similarity_metric=metric).calculate_mapping(m)
+            assert mp.dtype == np.int64 and (mp == g[f'{tag}_{metric}_greedy']).all(), (tag, metric)
+            for alg in ('greedy', 'optimal'):
+                solver = OraclePermutationAlignment(similarity_metric=metric, algorithm=alg)
+                mo = solver.calculate_mapping(m, r)
+                assert (mo == g[f'{tag}_{metric}_oracle_{alg}']).all(), (tag, metric, alg)
+                assert (solver(m, r) == m[mo, range(m.shape[1])]).all()
+    m, r = g['blocks_mask'], g['blocks_reference']
+    assert (GreedyPermutationAlignment().calculate_mapping(m) == g['blocks_greedy']).all()
+    assert (OraclePermutationAlignment().calculate_mapping(m, r) == g['blocks_oracle']).all()
+    assert (GreedyPermutationAlignment('cos').calculate_mapping(m) == g['blocks_greedy_cos']).all()
+    assert (OraclePermutationAlignment('cos', 'greedy').calculate_mapping(m, r)
+            == g['blocks_oracle_cos_greedy']).all()
+    assert (OraclePermutationAlignment()(m, r) == r).all()
+    for alg in ('greedy', 'optimal'):
+        assert (_mapping_from_score_matrix(g['scores'], alg) == g['scores_' + alg]).all()
+    sm = np.array([[11, 10, 0], [4, 5, 10], [6, 0, 5]])  # doctest, permutation_alignment.py:475-508
+    assert (_mapping_from_score_matrix(sm, 'optimal') == [1, 2, 0]).all()
+    assert (_mapping_from_score_matrix(sm, 'greedy') == [0, 2, 1]).all()
+    with pytest.raises(ValueError, match='infeasible'):
+        _mapping_from_score_matrix(np.array([[1.0, np.nan], [0.0, 1.0]]), 'greedy')
+    with pytest.raises(ValueError, match='infeasible'):
+        OraclePermutationAlignment().calculate_mapping(np.full((2, 3, 4), np.inf), np.zeros((2, 3, 4)))
+    with pytest.raises(ValueError):
+        GreedyPermutationAlignment(similarity_metric='coss')
+    with pytest.raises(AttributeError):
+        OraclePermutationAlignment(similarity_metric='coss')
+
+
+@pytest.mark.parametrize('K,F,T', [(2, 257, 130), (3, 513, 500), (5, 129, 77), (8, 65, 40)])
+def test_pairwise_solvers_match_oracle_at_size(K, F, T):
+    """Config-2-sized masks (and K up to 8, batches, the (K, T) form) against the NumPy oracle;
+    the greedy solver's permutation scan against the sequential recursion."""
+    from pb_bss_amd.permutation_alignment import (GreedyPermutationAlignment,
+                                                  OraclePermutationAlignment)
+    from oracle import permutation_alignment as op
+    rng = np.random.default_rng(K * 1000 + F)
+    ref = rng.uniform(size=(K, 1, T)) ** 4 * rng.uniform(0.5, 1.0, size=(K, F, T)) \
+        + 0.05 * rng.uniform(size=(K, F, T))
+    ref /= ref.sum(0, keepdims=True)
+    perm = np.stack([rng.permutation(K) for _ in range(F)], 1)
+    mask = ref[perm, range(F)] * rng.uniform(0.9, 1.1, size=(K, F, T))
+    for metric in ('cos', 'multiply', 'euclidean'):
+        mg = GreedyPermutationAlignment(similarity_metric=metric).calculate_mapping(mask)
+        assert (mg == op.greedy_calculate_mapping(mask, metric)).all(), metric
+        # every column is a permutation
+        assert (np.sort(mg, axis=0) == np.arange(K)[:, None]).all()
+        algs = ('greedy', 'optimal') if K <= 5 else ('greedy',)
+        for alg in algs:
+            mo = OraclePermutationAlignment(metric, alg).calculate_mapping(mask, ref)
+            assert (mo == op.oracle_calculate_mapping(mask, ref, metric, alg)).all(), (metric, alg)
+    # the oracle solver recovers the permutation that was applied (noise is mild)
+    mo = OraclePermutationAlignment('cos').calculate_mapping(mask, ref) if K <= 5 else \
+        OraclePermutationAlignment('cos', 'greedy').calculate_mapping(mask, ref)
+    assert (np.argsort(perm, axis=0) == mo).all()
+    # batch of utterances on the greedy solver, and the (K, T) form of the oracle solver
+    batch = np.stack([mask, ref, mask[::-1]])
+    mb = GreedyPermutationAlignment('cos').calculate_mapping(batch)
+    for u in range(3):
+        assert (mb[u] == op.greedy_calculate_mapping(batch[u], 'cos')).all()
+    m1 = OraclePermutationAlignment('euclidean', 'greedy').calculate_mapping(mask[:, 0], ref[:, 0])
+    assert m1.shape == (K,)
+    assert (m1 == op.oracle_calculate_mapping(mask[:, :1], ref[:, :1], 'euclidean', 'greedy')[:, 0]).all()

@@ -59,3 +59,12 @@ def test_oracle_equals_live_reference_on_fresh_inputs(ref):
     kft = np.ascontiguousarray(masks.transpose(1, 0, 2))
     np.testing.assert_array_equal(
         op.dhtv_calculate_mapping(kft, solver.alignment_plan), solver.calculate_mapping(kft))
+    for metric in ('cos', 'multiply', 'euclidean'):
+        np.testing.assert_array_equal(
+            op.greedy_calculate_mapping(kft, metric),
+            pa.GreedyPermutationAlignment(similarity_metric=metric).calculate_mapping(kft))
+        shuffled = np.ascontiguousarray(kft[::-1])
+        for alg in ('greedy', 'optimal'):
+            np.testing.assert_array_equal(
+                op.oracle_calculate_mapping(shuffled, kft, metric, alg),
+                pa.OraclePermutationAlignment(metric, alg).calculate_mapping(shuffled, kft))
