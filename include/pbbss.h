@@ -263,20 +263,27 @@ int pbbss_apply_beamforming_vector(pbbss_handle_t h, const void* w,
                                    const void* x, int x_is_c128, int64_t B,
                                    int T, int D, void* out, void* stream);
 
+/* similarity metrics of the permutation solvers (_ScoreMatrix, permutation_alignment.py:380-417) */
+#define PBBSS_PA_COS 0
+#define PBBSS_PA_MULTIPLY 1
+#define PBBSS_PA_EUCLIDEAN 2
+
 /* ------------------------------------------------------------------------- */
 /* N1  DHTVPermutationAlignment.calculate_mapping  permutation_alignment.py:295-355 */
-/*     (similarity_metric='cos'; algorithm 'greedy' (optimal=0) or 'optimal'),  */
+/*     (similarity_metric = metric: PBBSS_PA_COS (the reference's default),     */
+/*     PBBSS_PA_MULTIPLY or PBBSS_PA_EUCLIDEAN; algorithm 'greedy' (optimal=0)  */
+/*     or 'optimal'),                                                            */
 /*     score matrix :380-407, assignment :469-589.                              */
 /* mask f64 (U,K,F,T) (U utterances); plan int32 (P,3) rows (iterations, start, */
 /* end) = DHTVPermutationAlignment.alignment_plan (:204-293), a DEVICE array;    */
-/* scratch f64 (U,K,F,T) receives the aligned unit-norm features; out_mapping    */
+/* scratch f64 (U,K,F,T) receives the aligned features (unit-norm for 'cos'); out_mapping    */
 /* int32 (U,K,F) is the reverse mapping; status int32 (U) gets                    */
 /* PBBSS_ST_NONFINITE where the reference raises 'score matrix is infeasible'.   */
 /* K <= 8.  One launch runs the whole plan.                                       */
 /* ------------------------------------------------------------------------- */
 int pbbss_dhtv_calculate_mapping(pbbss_handle_t h, const double* mask, int64_t U,
                                  int K, int F, int T, const int32_t* plan, int P,
-                                 int optimal, double* scratch,
+                                 int optimal, int metric, double* scratch,
                                  int32_t* out_mapping, int32_t* out_status,
                                  void* stream);
 
@@ -295,9 +302,6 @@ int pbbss_dhtv_calculate_mapping(pbbss_handle_t h, const double* mask, int64_t U
 /* PBBSS_ST_NONFINITE where the reference raises 'score matrix is infeasible'.     */
 /* K <= 8.                                                                          */
 /* ------------------------------------------------------------------------- */
-#define PBBSS_PA_COS 0
-#define PBBSS_PA_MULTIPLY 1
-#define PBBSS_PA_EUCLIDEAN 2
 int pbbss_pa_pairwise_mapping(pbbss_handle_t h, const double* mask, const double* reference,
                               int64_t U, int K, int64_t F, int T, const int64_t* mask_strides,
                               const int64_t* reference_strides, int metric, int optimal,
@@ -407,6 +411,17 @@ int pbbss_vmfmm_fit(pbbss_handle_t h, const void* y, int64_t B, int64_t N, int E
                     double* out_mean, double* out_concentration,
                     double* out_weight, double* out_affiliation,
                     double* out_log_pdf, void* stream);
+
+/* N3 (sibling)  GMMTrainer.fit / fit_predict, GMM.predict  distribution/gmm.py:17-171 for  */
+/* covariance_type = 'spherical' (SphericalGaussian, gaussian.py:100-137, 152-193): the same */
+/* loop on the RAW rows of y (B,N,E).  in/out_covariance (B,K) = the scalar variances;        */
+/* fixed_covariance (B,K) or NULL (gmm.py:160-167).  Otherwise as pbbss_vmfmm_fit.            */
+int pbbss_gmm_fit(pbbss_handle_t h, const void* y, int64_t B, int64_t N, int E, int K,
+                  const double* gamma0, const double* in_mean, const double* in_covariance,
+                  const double* in_weight, const double* saliency,
+                  const double* fixed_covariance, const pbbss_mix_opts* o, double* out_mean,
+                  double* out_covariance, double* out_weight, double* out_affiliation,
+                  double* out_log_pdf, void* stream);
 
 /* N3  GCACGMMTrainer.fit / GCACGMM.predict  distribution/gcacgmm.py:47-333 and    */
 /*     VMFCACGMMTrainer.fit / VMFCACGMM.predict  distribution/vmfcacgmm.py:43-301. */

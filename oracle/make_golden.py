@@ -193,6 +193,11 @@ def dhtv_cases():
         out[tag + '_aligned_sum'] = solver.apply_mapping(m64, out[tag + '_mapping']).sum(-1)
         solver.algorithm = 'optimal'
         out[tag + '_mapping_optimal'] = solver.calculate_mapping(m64)
+        for metric in ('multiply', 'euclidean'):
+            for alg in ('greedy', 'optimal'):
+                sv = DHTVPermutationAlignment.from_stft_size(size, metric)
+                sv.algorithm = alg
+                out[f'{tag}_mapping_{metric}_{alg}'] = sv.calculate_mapping(m64)
     _save('dhtv_alignment', **out)
 
 
@@ -243,6 +248,34 @@ def pairwise_alignment_cases():
     out['scores_greedy'] = _mapping_from_score_matrix(sc, 'greedy')
     out['scores_optimal'] = _mapping_from_score_matrix(sc, 'optimal')
     _save('pairwise_alignment', **out)
+
+
+def gmm_cases():
+    """GMMTrainer (spherical covariances) of the unmodified reference."""
+    from pb_bss.distribution import GMMTrainer
+    Y, e, init = synth.make_joint(5, 90, 3, 3, 12, seed=17)
+    e64 = (1.5 * e + 0.3).astype(np.float32).astype(np.float64)  # not unit-norm, not centred
+    flat = e64.reshape(-1, 12)
+    i0 = init.transpose(1, 0, 2).reshape(3, -1)
+    m = GMMTrainer().fit(flat, initialization=i0, iterations=8, covariance_type='spherical')
+    _save('gmm_n450_e12_k3', y=e64.reshape(-1, 12).astype(np.float32), init=i0, iterations=8,
+          mean=m.gaussian.mean, covariance=m.gaussian.covariance, weight=m.weight,
+          affiliation=m.predict(flat))
+    # NB the reference's SphericalGaussian.log_pdf does not broadcast over independent axes
+    # (gaussian.py:110-113 flattens the log-determinant), so GMMTrainer is pinned on flat data
+    sal = np.abs(Y[..., 0]).astype(np.float64).reshape(-1)
+    fixed = np.array([0.05, 0.2, 0.1])
+    out = dict(y=flat.astype(np.float32), init=i0, saliency=sal, iterations=5, fixed=fixed)
+    for tag, kw in [('sal', dict(saliency=sal)),
+                    ('uniform', dict(weight_constant_axis=-2)),
+                    ('fixed', dict(fixed_covariance=fixed))]:
+        m = GMMTrainer().fit(flat, initialization=i0, iterations=5,
+                             covariance_type='spherical', **kw)
+        out.update({f'{tag}_mean': m.gaussian.mean, f'{tag}_covariance': m.gaussian.covariance,
+                    f'{tag}_weight': m.weight, f'{tag}_affiliation': m.predict(flat)})
+    out['fit_predict'] = GMMTrainer().fit_predict(flat, initialization=i0, iterations=3,
+                                                  covariance_type='spherical')
+    _save('gmm_variants_n450_e12_k3', **out)
 
 
 def cwmm_cases():
@@ -388,6 +421,7 @@ def main():
     beamformer_cases()
     dhtv_cases()
     pairwise_alignment_cases()
+    gmm_cases()
     cwmm_cases()
     embed_cases()
     beamformer_extra_cases()

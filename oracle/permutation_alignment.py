@@ -87,20 +87,32 @@ def mapping_from_score_matrix(score, algorithm='greedy'):
     raise ValueError(algorithm)
 
 
-def dhtv_calculate_mapping(mask, plan, algorithm='greedy'):
-    """permutation_alignment.py:295-355 with similarity_metric='cos'.
-    mask (K, F, T) -> reverse mapping (K, F)."""
+def dhtv_calculate_mapping(mask, plan, algorithm='greedy', similarity_metric='cos'):
+    """permutation_alignment.py:295-355.  mask (K, F, T) -> reverse mapping (K, F).
+    'cos': unit-norm features and centroid, scored with `multiply` (:155-160, :309-312,
+    :337-341); 'multiply' / 'euclidean': raw features and centroid."""
     K, F, _ = mask.shape
     assert F % 2 == 1, (F, 'Sure? Usually F is odd.')
-    feat = _unit(np.array(mask, dtype=np.float64))
+    cos = similarity_metric == 'cos'
+    feat = np.array(mask, dtype=np.float64)
+    if cos:
+        feat = _unit(feat)
     mapping = np.repeat(np.arange(K)[:, None], F, axis=1)
     ident = np.arange(K)
     for iterations, start, end in plan:
         for _ in range(iterations):
-            cent = _unit(np.mean(feat[:, start:end, :], axis=1))
+            cent = np.mean(feat[:, start:end, :], axis=1)
+            if cos:
+                cent = _unit(cent)
             changed = False
             for f in range(start, end):
-                score = np.einsum('KT,kT->kK', feat[:, f, :], cent)
+                if similarity_metric == 'euclidean':
+                    score = -np.sqrt(np.sum(
+                        (feat[:, None, f, :] - cent[None]) ** 2, axis=-1)).T
+                elif similarity_metric in ('cos', 'multiply'):
+                    score = np.einsum('KT,kT->kK', feat[:, f, :], cent)
+                else:
+                    raise AttributeError(similarity_metric)
                 perm = mapping_from_score_matrix(score, algorithm)
                 if not (perm == ident).all():
                     changed = True

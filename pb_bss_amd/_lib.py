@@ -48,6 +48,7 @@ EXPORTS = (
     'pbbss_condition_covariance', 'pbbss_apply_online_beamforming_vector',
     'pbbss_set_dhtv_team', 'pbbss_stft_num_frames', 'pbbss_stft', 'pbbss_istft',
     'pbbss_pa_pairwise_mapping', 'pbbss_pa_compose_mapping', 'pbbss_pa_mapping_from_scores',
+    'pbbss_gmm_fit',
 )
 
 EMBED_VMF = 0
@@ -147,7 +148,7 @@ def load():
         lib.pbbss_stft_num_frames.argtypes = [i64, i32, i32, i32, i32, i32]
         lib.pbbss_stft.argtypes = [vp, vp, i32, i64, i64, i32, i32, i32, vp, i32, i32, i32, i32, vp, vp]
         lib.pbbss_istft.argtypes = [vp, vp, i32, i64, i32, i32, i32, i32, vp, i32, vp, i64, vp]
-        lib.pbbss_dhtv_calculate_mapping.argtypes = [vp, vp, i64, i32, i32, i32, vp, i32, i32, vp, vp, vp, vp]
+        lib.pbbss_dhtv_calculate_mapping.argtypes = [vp, vp, i64, i32, i32, i32, vp, i32, i32, i32, vp, vp, vp, vp]
         lib.pbbss_apply_mapping.argtypes = [vp, vp, vp, i64, i32, i32, i32, vp, vp]
         lib.pbbss_pa_pairwise_mapping.argtypes = [vp, vp, vp, i64, i32, i64, i32, vp, vp, i32, i32,
                                                   vp, vp, i64, i64, vp, vp]
@@ -180,6 +181,8 @@ def load():
                                         vp, vp, vp]
         lib.pbbss_vmfmm_fit.argtypes = [vp, vp, i64, i64, i32, i32, vp, vp, vp, vp, vp,
                                         ctypes.POINTER(MixOpts), vp, vp, vp, vp, vp, vp]
+        lib.pbbss_gmm_fit.argtypes = [vp, vp, i64, i64, i32, i32, vp, vp, vp, vp, vp, vp,
+                                      ctypes.POINTER(MixOpts), vp, vp, vp, vp, vp, vp]
         lib.pbbss_joint_fit.argtypes = [vp, vp, vp, i64, i32, i32, i32, i32, vp, vp, vp, vp, vp,
                                         vp, vp, ctypes.POINTER(MixOpts), vp, vp, vp, vp, vp, vp,
                                         vp, vp]

@@ -632,12 +632,12 @@ PBBSS_API int pbbss_apply_beamforming_vector(pbbss_handle_t h, const void* w, co
 
 PBBSS_API int pbbss_dhtv_calculate_mapping(pbbss_handle_t h, const double* mask, int64_t U, int K,
                                            int F, int T, const int32_t* plan, int P, int optimal,
-                                           double* scratch, int32_t* out_mapping,
+                                           int metric, double* scratch, int32_t* out_mapping,
                                            int32_t* out_status, void* stream) {
   DeviceGuard device_guard(h);
   if (!h || !mask || !plan || !scratch || !out_mapping || !out_status) return PBBSS_ERR_INVALID_ARG;
   if (U <= 0 || F <= 0 || T <= 0 || P <= 0) return PBBSS_ERR_INVALID_ARG;
-  return pbbss::launch_dhtv(mask, U, K, F, T, plan, P, optimal, scratch, out_mapping, out_status,
+  return pbbss::launch_dhtv(mask, U, K, F, T, plan, P, optimal, metric, scratch, out_mapping, out_status,
                             h->cfg.lds_limit, h->cfg.num_cu, h->dhtv_team, h->team_buf,
                             h->team_bytes, as_stream(stream));
 }
@@ -819,21 +819,25 @@ PBBSS_API int pbbss_embed_fit(pbbss_handle_t h, const void* y, int y_is_f64, int
                                  out_scale, nullptr, nullptr, nullptr, 0, s);
 }
 
-PBBSS_API int pbbss_vmfmm_fit(pbbss_handle_t h, const void* y, int64_t B, int64_t N, int E, int K,
-                              const double* gamma0, const double* in_mean,
-                              const double* in_concentration, const double* in_weight,
-                              const double* saliency, const pbbss_mix_opts* o, double* out_mean,
-                              double* out_concentration, double* out_weight,
-                              double* out_affiliation, double* out_log_pdf, void* stream) {
-  DeviceGuard device_guard(h);
+// EM loop shared by the two real-embedding mixtures: kind = PBBSS_EMBED_VMF (rows unit-normalised
+// first, vmfmm.py:76-78) or PBBSS_EMBED_GAUSS_SPHERICAL (gmm.py:126-171, covariance_type
+// 'spherical'; fixed_scale = fixed_covariance (B,K) or null).
+static int embed_mixture_fit(pbbss_handle_t h, int kind, const void* y, int64_t B, int64_t N, int E,
+                             int K, const double* gamma0, const double* in_mean,
+                             const double* in_scale, const double* in_weight,
+                             const double* saliency, const double* fixed_scale,
+                             const pbbss_mix_opts* o, double* out_mean, double* out_scale,
+                             double* out_weight, double* out_affiliation, double* out_log_pdf,
+                             void* stream) {
   if (!h || !y || !o) return PBBSS_ERR_INVALID_ARG;
   if (!embed_shape_ok(B, N, E, K)) return PBBSS_ERR_UNSUPPORTED;
   if (o->iterations < 0 || o->weight_mode < 0 || o->weight_mode > 1) return PBBSS_ERR_INVALID_ARG;
   const bool has_gamma = gamma0 != nullptr;
-  const bool has_model = in_mean && in_concentration && in_weight;
+  const bool has_model = in_mean && in_scale && in_weight;
   if (has_gamma == has_model) return PBBSS_ERR_INVALID_ARG;
   if ((o->iterations == 0) != has_model) return PBBSS_ERR_INVALID_ARG;  // vmfmm.py:70-74
-  if (!out_mean || !out_concentration || !out_weight) return PBBSS_ERR_INVALID_ARG;
+  if (!out_mean || !out_scale || !out_weight) return PBBSS_ERR_INVALID_ARG;
+  const bool vmf = (kind == PBBSS_EMBED_VMF);
   hipStream_t s = as_stream(stream);
   const size_t nyz = (size_t)B * N * E;
   const size_t np = pbbss::embed_partial_doubles(B, N, E, K, nullptr);
@@ -842,43 +846,78 @@ PBBSS_API int pbbss_vmfmm_fit(pbbss_handle_t h, const void* y, int64_t B, int64_
   void* w = handle_work(h, need);
   if (!w) return PBBSS_ERR_HIP;
   WorkCarver wc(w);
-  double* yd = wc.take<double>(nyz);
-  double* yr = wc.take<double>(nyz);
+  double* yd = wc.take<double>(nyz);  // (B,E,N): float64 unit rows (vMF) / input type (Gauss)
+  double* yr = wc.take<double>(nyz);  // (B,N,E) float64 unit rows (vMF only)
   double* aff = wc.take<double>((size_t)B * K * N);
   double* part = wc.take<double>(np);
   double* offset = wc.take<double>((size_t)B * K);
   double* prec = wc.take<double>((size_t)B * K);
+  // the E-step reads the transposed copy, the M-step the row-major one: the normalised float64
+  // pair for the vMF mixture, the caller's array (and type) for the Gaussian one
+  const int e_f64 = vmf ? 1 : o->embedding_is_f64;
+  const void* fit_y = vmf ? static_cast<const void*>(yr) : y;
   TimedRegion tr(h, s);
-  int rc = pbbss::launch_embed_prepare(y, o->embedding_is_f64, B, N, E, 1, yd, yr, s);
+  int rc = pbbss::launch_embed_prepare(y, o->embedding_is_f64, B, N, E, vmf ? 1 : 0, yd,
+                                       vmf ? yr : nullptr, s);
   if (rc != PBBSS_OK) return rc;
   if (has_model) {
     if ((rc = copy_d2d(out_mean, in_mean, (size_t)B * K * E * 8, s)) != PBBSS_OK) return rc;
-    if ((rc = copy_d2d(out_concentration, in_concentration, (size_t)B * K * 8, s)) != PBBSS_OK) return rc;
+    if ((rc = copy_d2d(out_scale, in_scale, (size_t)B * K * 8, s)) != PBBSS_OK) return rc;
     if ((rc = copy_d2d(out_weight, in_weight, (size_t)B * K * 8, s)) != PBBSS_OK) return rc;
   }
   for (int it = 0; it < o->iterations; ++it) {
     const double* src = gamma0;
-    if (it > 0) {  // vmfmm.py:137-138 (offsets come from the previous M-step's finalize)
-      rc = pbbss::launch_embed_estep(PBBSS_EMBED_VMF, yd, 1, B, N, E, K, out_mean, prec, offset,
+    if (it > 0) {  // vmfmm.py:137-138 / gmm.py:129-130 (offsets: previous M-step's finalize)
+      rc = pbbss::launch_embed_estep(kind, yd, e_f64, B, N, E, K, out_mean, prec, offset,
                                      out_weight, 1.0, N, nullptr, aff, s);
       if (rc != PBBSS_OK) return rc;
       src = aff;
     }
-    rc = pbbss::launch_embed_fit(PBBSS_EMBED_VMF, yr, 1, B, N, E, K, src, N, saliency,
+    rc = pbbss::launch_embed_fit(kind, fit_y, e_f64, B, N, E, K, src, N, saliency,
                                  o->min_concentration, o->max_concentration, o->weight_mode, part,
-                                 out_mean, out_concentration, out_weight, offset, prec, 0, s);
+                                 out_mean, out_scale, out_weight, offset, prec, 0, s);
     if (rc != PBBSS_OK) return rc;
+    if (fixed_scale) {  // gmm.py:160-167
+      if ((rc = copy_d2d(out_scale, fixed_scale, (size_t)B * K * 8, s)) != PBBSS_OK) return rc;
+      rc = pbbss::launch_embed_offsets(kind, B * K, E, out_scale, offset, prec, s);
+      if (rc != PBBSS_OK) return rc;
+    }
   }
   if (o->final_predict && (out_affiliation || out_log_pdf)) {
     if (o->iterations == 0) {
-      rc = pbbss::launch_embed_offsets(PBBSS_EMBED_VMF, B * K, E, out_concentration, offset, prec, s);
+      rc = pbbss::launch_embed_offsets(kind, B * K, E, out_scale, offset, prec, s);
       if (rc != PBBSS_OK) return rc;
     }
-    rc = pbbss::launch_embed_estep(PBBSS_EMBED_VMF, yd, 1, B, N, E, K, out_mean, prec, offset,
+    rc = pbbss::launch_embed_estep(kind, yd, e_f64, B, N, E, K, out_mean, prec, offset,
                                    out_weight, 1.0, N, out_log_pdf, out_affiliation, s);
     if (rc != PBBSS_OK) return rc;
   }
   return PBBSS_OK;
+}
+
+PBBSS_API int pbbss_vmfmm_fit(pbbss_handle_t h, const void* y, int64_t B, int64_t N, int E, int K,
+                              const double* gamma0, const double* in_mean,
+                              const double* in_concentration, const double* in_weight,
+                              const double* saliency, const pbbss_mix_opts* o, double* out_mean,
+                              double* out_concentration, double* out_weight,
+                              double* out_affiliation, double* out_log_pdf, void* stream) {
+  DeviceGuard device_guard(h);
+  return embed_mixture_fit(h, PBBSS_EMBED_VMF, y, B, N, E, K, gamma0, in_mean, in_concentration,
+                           in_weight, saliency, nullptr, o, out_mean, out_concentration,
+                           out_weight, out_affiliation, out_log_pdf, stream);
+}
+
+PBBSS_API int pbbss_gmm_fit(pbbss_handle_t h, const void* y, int64_t B, int64_t N, int E, int K,
+                            const double* gamma0, const double* in_mean,
+                            const double* in_covariance, const double* in_weight,
+                            const double* saliency, const double* fixed_covariance,
+                            const pbbss_mix_opts* o, double* out_mean, double* out_covariance,
+                            double* out_weight, double* out_affiliation, double* out_log_pdf,
+                            void* stream) {
+  DeviceGuard device_guard(h);
+  return embed_mixture_fit(h, PBBSS_EMBED_GAUSS_SPHERICAL, y, B, N, E, K, gamma0, in_mean,
+                           in_covariance, in_weight, saliency, fixed_covariance, o, out_mean,
+                           out_covariance, out_weight, out_affiliation, out_log_pdf, stream);
 }
 
 PBBSS_API int pbbss_joint_fit(pbbss_handle_t h, const void* observation, const void* embedding,

@@ -121,7 +121,7 @@ template <int K>
 __global__ void __launch_bounds__(kDhtvThreads)
     dhtv_kernel(const double* __restrict__ mask, double* __restrict__ feat_all,
                 int32_t* __restrict__ mapping_all, const int32_t* __restrict__ plan, int P, int F,
-                int T, int optimal, int32_t* __restrict__ status) {
+                int T, int optimal, int metric, int32_t* __restrict__ status) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* cent = reinterpret_cast<double*>(smem);  // [K][T]
   double* red = cent + (size_t)K * T;              // [kDhtvWaves]
@@ -143,7 +143,8 @@ __global__ void __launch_bounds__(kDhtvThreads)
     }
     ss = wave_sum(ss);
     if (!isfinite(ss)) nonfinite = 1;
-    double inv = 1.0 / fmax(sqrt(ss), kTiny);
+    // 'cos': unit-norm rows; other metrics: features = mask.copy() (:309-312)
+    double inv = (metric == PBBSS_PA_COS) ? 1.0 / fmax(sqrt(ss), kTiny) : 1.0;
     double* dst = feat + (int64_t)row * T;
     for (int t = lane; t < T; t += kWave) dst[t] = src[t] * inv;
   }
@@ -171,7 +172,7 @@ __global__ void __launch_bounds__(kDhtvThreads)
         cent[col] = (((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]))) * inv_n;
       }
       __syncthreads();
-      for (int k = 0; k < K; ++k) {
+      for (int k = 0; k < K && metric == PBBSS_PA_COS; ++k) {  // :337-341
         double ss = 0.0;
         for (int t = tid; t < T; t += kDhtvThreads) {
           double v = cent[k * T + t];
@@ -203,15 +204,27 @@ __global__ void __launch_bounds__(kDhtvThreads)
             for (int k = 0; k < K; ++k) {
               double v = feat[((int64_t)k * F + f) * T + tc];
               fv[u][k] = ok ? v : 0.0;
-              cv[u][k] = cent[k * T + tc];
+              cv[u][k] = ok ? cent[k * T + tc] : 0.0;
             }
           }
+          if (metric == PBBSS_PA_EUCLIDEAN) {
 #pragma unroll
-          for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < 4; ++u)
 #pragma unroll
-            for (int a = 0; a < K; ++a)
+              for (int a = 0; a < K; ++a)
 #pragma unroll
-              for (int b = 0; b < K; ++b) sc[a][b] = fma(cv[u][a], fv[u][b], sc[a][b]);
+                for (int b = 0; b < K; ++b) {
+                  double d = fv[u][b] - cv[u][a];
+                  sc[a][b] = fma(d, d, sc[a][b]);
+                }
+          } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+              for (int a = 0; a < K; ++a)
+#pragma unroll
+                for (int b = 0; b < K; ++b) sc[a][b] = fma(cv[u][a], fv[u][b], sc[a][b]);
+          }
         }
         bool finite = true;
 #pragma unroll
@@ -219,6 +232,7 @@ __global__ void __launch_bounds__(kDhtvThreads)
 #pragma unroll
           for (int b = 0; b < K; ++b) {
             sc[a][b] = wave_sum(sc[a][b]);
+            if (metric == PBBSS_PA_EUCLIDEAN) sc[a][b] = -sqrt(sc[a][b]);  // :412-416
             finite = finite && isfinite(sc[a][b]);
           }
         if (!finite) nonfinite = 1;  // reference: ValueError('score matrix is infeasible')
@@ -327,7 +341,7 @@ template <int K>
 __global__ void __launch_bounds__(kDhtvThreads)
     dhtv_team_kernel(const double* __restrict__ mask, double* feat_all, int32_t* mapping_all,
                      const int32_t* __restrict__ plan, int P, int F, int T, int optimal,
-                     int32_t* status, int G, double* part_all, unsigned* ctrl_all) {
+                     int metric, int32_t* status, int G, double* part_all, unsigned* ctrl_all) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* cent = reinterpret_cast<double*>(smem);  // [K][T]
   double* red = cent + (size_t)K * T;              // [kDhtvWaves]
@@ -354,7 +368,8 @@ __global__ void __launch_bounds__(kDhtvThreads)
     }
     ss = wave_sum(ss);
     if (!isfinite(ss)) nonfinite = 1;
-    double inv = 1.0 / fmax(sqrt(ss), kTiny);
+    // 'cos': unit-norm rows; other metrics: features = mask.copy() (:309-312)
+    double inv = (metric == PBBSS_PA_COS) ? 1.0 / fmax(sqrt(ss), kTiny) : 1.0;
     double* dst = feat + (int64_t)row * T;
     for (int t = lane; t < T; t += kWave) st_sc1(dst + t, src[t] * inv);
   }
@@ -396,7 +411,7 @@ __global__ void __launch_bounds__(kDhtvThreads)
         cent[col] = sacc * inv_n;
       }
       __syncthreads();
-      for (int k = 0; k < K; ++k) {
+      for (int k = 0; k < K && metric == PBBSS_PA_COS; ++k) {  // :337-341
         double ss = 0.0;
         for (int t = tid; t < T; t += kDhtvThreads) {
           double v = cent[k * T + t];
@@ -426,15 +441,27 @@ __global__ void __launch_bounds__(kDhtvThreads)
             for (int k = 0; k < K; ++k) {
               double v = ld_sc1(feat + ((int64_t)k * F + f) * T + tc);
               fv[x][k] = ok ? v : 0.0;
-              cv[x][k] = cent[k * T + tc];
+              cv[x][k] = ok ? cent[k * T + tc] : 0.0;
             }
           }
+          if (metric == PBBSS_PA_EUCLIDEAN) {
 #pragma unroll
-          for (int x = 0; x < 4; ++x)
+            for (int x = 0; x < 4; ++x)
 #pragma unroll
-            for (int a = 0; a < K; ++a)
+              for (int a = 0; a < K; ++a)
 #pragma unroll
-              for (int b = 0; b < K; ++b) sc[a][b] = fma(cv[x][a], fv[x][b], sc[a][b]);
+                for (int b = 0; b < K; ++b) {
+                  double d = fv[x][b] - cv[x][a];
+                  sc[a][b] = fma(d, d, sc[a][b]);
+                }
+          } else {
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+#pragma unroll
+              for (int a = 0; a < K; ++a)
+#pragma unroll
+                for (int b = 0; b < K; ++b) sc[a][b] = fma(cv[x][a], fv[x][b], sc[a][b]);
+          }
         }
         bool finite = true;
 #pragma unroll
@@ -442,6 +469,7 @@ __global__ void __launch_bounds__(kDhtvThreads)
 #pragma unroll
           for (int b = 0; b < K; ++b) {
             sc[a][b] = wave_sum(sc[a][b]);
+            if (metric == PBBSS_PA_EUCLIDEAN) sc[a][b] = -sqrt(sc[a][b]);  // :412-416
             finite = finite && isfinite(sc[a][b]);
           }
         if (!finite) nonfinite = 1;
@@ -731,9 +759,11 @@ int launch_pa_assign(const double* scores, int64_t N, int K, int optimal, int32_
 #undef PBBSS_PA_SWITCH
 
 int launch_dhtv(const double* mask, int64_t U, int K, int F, int T, const int32_t* plan, int P,
-                int optimal, double* feat, int32_t* mapping, int32_t* status, size_t lds_limit,
+                int optimal, int metric, double* feat, int32_t* mapping, int32_t* status,
+                size_t lds_limit,
                 int num_cu, int team_size, void* team_buf, size_t team_bytes, hipStream_t s) {
   if (K < 1 || K > kDhtvMaxK) return PBBSS_ERR_UNSUPPORTED;
+  if (metric < PBBSS_PA_COS || metric > PBBSS_PA_EUCLIDEAN) return PBBSS_ERR_INVALID_ARG;
   size_t lds = ((size_t)K * T + kDhtvWaves) * sizeof(double) + 16;
   if (lds > lds_limit) return PBBSS_ERR_LDS_CAPACITY;
   // team size: all U * G workgroups must be co-resident (one 1024-thread workgroup per CU)
@@ -761,14 +791,14 @@ int launch_dhtv(const double* mask, int64_t U, int K, int F, int T, const int32_
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
         return PBBSS_ERR_HIP;                                                                   \
       hipLaunchKernelGGL(kfn, dim3((unsigned)(U * G)), dim3(kDhtvThreads), lds, s, mask, feat,  \
-                         mapping, plan, P, F, T, optimal, status, G, part, ctrl);               \
+                         mapping, plan, P, F, T, optimal, metric, status, G, part, ctrl);               \
     } else {                                                                                    \
       auto kfn = dhtv_kernel<KK>;                                                               \
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                               \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
         return PBBSS_ERR_HIP;                                                                   \
       hipLaunchKernelGGL(kfn, dim3((unsigned)U), dim3(kDhtvThreads), lds, s, mask, feat,        \
-                         mapping, plan, P, F, T, optimal, status);                              \
+                         mapping, plan, P, F, T, optimal, metric, status);                        \
     }                                                                                           \
   } break;
   switch (K) {

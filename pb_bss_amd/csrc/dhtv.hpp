@@ -10,8 +10,8 @@ namespace pbbss {
 // null / too small / team_size <= 1 selects the one-workgroup-per-utterance kernel.
 constexpr int kDhtvTeamMax = 32;
 int launch_dhtv(const double* mask, int64_t U, int K, int F, int T, const int32_t* plan, int P,
-                int optimal, double* feat, int32_t* mapping, int32_t* status, size_t lds_limit,
-                int num_cu, int team_size, void* team_buf, size_t team_bytes, hipStream_t s);
+                int optimal, int metric, double* feat, int32_t* mapping, int32_t* status,
+                size_t lds_limit, int num_cu, int team_size, void* team_buf, size_t team_bytes, hipStream_t s);
 int launch_apply_mapping(const double* mask, const int32_t* mapping, int64_t U, int K, int F,
                          int T, double* out, hipStream_t s);
 // pairwise solvers (Oracle / Greedy alignment) and the assignment on given score matrices

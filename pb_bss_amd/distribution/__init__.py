@@ -12,13 +12,14 @@ from .cwmm import CWMM, CWMMTrainer
 from .von_mises_fisher import VonMisesFisher, VonMisesFisherTrainer
 from .vmfmm import VMFMM, VMFMMTrainer
 from .gaussian import SphericalGaussian, GaussianTrainer
+from .gmm import GMM, GMMTrainer
 from .gcacgmm import GCACGMM, GCACGMMTrainer
 from .vmfcacgmm import VMFCACGMM, VMFCACGMMTrainer
 
 __all__ = [
     'CACGMM', 'CACGMMTrainer', 'CWMM', 'CWMMTrainer',
     'VonMisesFisher', 'VonMisesFisherTrainer', 'VMFMM', 'VMFMMTrainer',
-    'SphericalGaussian', 'GaussianTrainer', 'GCACGMM', 'GCACGMMTrainer',
+    'SphericalGaussian', 'GaussianTrainer', 'GMM', 'GMMTrainer', 'GCACGMM', 'GCACGMMTrainer',
     'VMFCACGMM', 'VMFCACGMMTrainer',
     'ComplexWatson', 'ComplexWatsonTrainer',
     'ComplexAngularCentralGaussian', 'ComplexAngularCentralGaussianTrainer',

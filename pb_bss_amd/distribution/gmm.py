@@ -1,0 +1,158 @@
+"""Gaussian mixture model on real embeddings on the HIP embedding kernels.
+Mirrors pb_bss/distribution/gmm.py:16-171: `GMM` (weight, gaussian; predict) and
+`GMMTrainer` (fit / fit_predict) for covariance_type='spherical' -- the covariance
+model the joint GCACGMM uses (gcacgmm.py:141).  'full' / 'diagonal' covariances are
+not on the device path (NotImplementedError); BinaryGMM wraps sklearn's KMeans and
+is out of scope.
+
+The whole EM loop is one C-ABI call (`pbbss_gmm_fit`): the same E-step / M-step
+kernels as the vMF mixture, on the raw (not row-normalised) embedding.
+"""
+from dataclasses import dataclass
+from operator import xor
+
+import numpy as np
+
+from .. import _lib, engine
+from .gaussian import SphericalGaussian
+from .utils import _ProbabilisticModel, as_result
+
+__all__ = ['GMM', 'GMMTrainer']
+
+
+_CLASS, _UNIFORM, _ONES = range(3)
+
+
+def _weight_kind(weight_constant_axis, ndim):
+    """How estimate_mixture_weight (mixture_model_utils.py:133-203) is driven:
+    (-1,) / -1: per-class weights (K, 1); int -2: the constant 1/K (:180-183);
+    tuple (-2,) -- the default of fit_predict --: the general path averages over the class
+    axis and L1-normalises along it, i.e. a (1, N) array of ones (:192-201).  Weights that
+    are constant over the classes cancel in the posterior, so both run as the uniform mode."""
+    axis = weight_constant_axis
+    if isinstance(axis, list):
+        axis = tuple(axis)
+    if isinstance(axis, int):
+        if axis % ndim - ndim == -2:
+            return _UNIFORM
+        axis = (axis,)
+    norm = tuple(a % ndim - ndim for a in axis)
+    if norm == (-1,):
+        return _CLASS
+    if norm == (-2,):
+        return _ONES
+    raise NotImplementedError(
+        f'weight_constant_axis={weight_constant_axis!r}: the device loop covers (-1,), (-2,) '
+        'and -2')
+
+
+def _check_covariance_type(covariance_type):
+    if covariance_type == 'spherical':
+        return
+    if covariance_type in ('full', 'diagonal'):
+        raise NotImplementedError(
+            f"covariance_type={covariance_type!r}: only 'spherical' runs on the device")
+    raise ValueError(f"Unknown covariance type '{covariance_type}'.")
+
+
+@dataclass
+class GMM(_ProbabilisticModel):
+    weight: np.ndarray = None  # (..., K, 1)
+    gaussian: SphericalGaussian = None
+
+    def predict(self, x):
+        """x (..., N, D) real -> affiliations (..., K, N) (:21-25)."""
+        like_torch = _lib.is_torch(x)
+        t = _lib.torch()
+        x = _lib.to_device(x)
+        assert not x.is_complex(), x.dtype
+        *indep, N, E = x.shape
+        mean = _lib.to_device(self.gaussian.mean, t.float64).to(x.device)
+        K = mean.shape[-2]
+        cov = _lib.to_device(self.gaussian.covariance, t.float64).to(x.device)
+        w = _lib.to_device(self.weight, t.float64).to(x.device)
+        if w.shape[-1] != 1:
+            # (..., 1, N): constant over the classes (weight_constant_axis=(-2,)), cancels in
+            # the posterior (mixture_model_utils.py:37-47) -- evaluated with uniform weights
+            if w.shape[-2] != 1:
+                raise NotImplementedError(f'frame-dependent class weights {tuple(w.shape)}')
+            w = t.full((K, 1), 1.0 / K, dtype=t.float64, device=x.device)
+        model = (mean.expand(*indep, K, E).reshape(-1, K, E).contiguous(),
+                 cov.expand(*indep, K).reshape(-1, K).contiguous(),
+                 w.expand(*indep, K, 1).reshape(-1, K).contiguous())
+        r = engine.gmm_fit(x.reshape(-1, N, E), K, model=model, iterations=0,
+                           final_predict=True)
+        return as_result(r['affiliation'].reshape(*indep, K, N), like_torch)
+
+
+class GMMTrainer:
+    def __init__(self, eps=1e-10):
+        self.eps = eps
+        self.log_likelihood_history = []
+
+    def fit(self, y, initialization=None, num_classes=None, iterations=100, *, saliency=None,
+            weight_constant_axis=(-1,), covariance_type='full', fixed_covariance=None):
+        """y (..., N, D) real; initialization (..., K, N); saliency (..., N);
+        fixed_covariance (..., K) (:33-95)."""
+        assert xor(initialization is None, num_classes is None), (
+            "Incompatible input combination. "
+            "Exactly one of the two inputs has to be None: "
+            f"{initialization is None} xor {num_classes is None}"
+        )
+        _check_covariance_type(covariance_type)
+        like_torch = _lib.is_torch(y)
+        t = _lib.torch()
+        y = _lib.to_device(y)
+        assert not y.is_complex(), y.dtype
+        *indep, N, E = y.shape
+        indep = tuple(indep)
+        if initialization is None:
+            init = np.random.uniform(size=(*indep, num_classes, N))  # global RNG (:72-77)
+            init /= np.einsum('...kn->...n', init)[..., None, :]
+            gamma0 = _lib.to_device(init, t.float64).to(y.device)
+        else:
+            gamma0 = _lib.to_device(initialization, t.float64).to(y.device)
+            num_classes = gamma0.shape[-2]
+            gamma0 = gamma0.expand(*indep, num_classes, N)
+        K = num_classes
+        kind = _weight_kind(weight_constant_axis, len(indep) + 2)
+        mode = _lib.WEIGHT_PER_CLASS_MEAN if kind == _CLASS else _lib.WEIGHT_UNIFORM
+        sal = None
+        if saliency is not None:  # None: ones (:79-80), which the kernels assume anyway
+            sal = _lib.to_device(saliency, t.float64).to(y.device).expand(*indep, N)
+            sal = sal.reshape(-1, N).contiguous()
+            if kind == _ONES and not bool((sal > 0).all().item()):
+                raise NotImplementedError(
+                    'weight_constant_axis=(-2,) with zero saliency entries (zero weights)')
+        fixed = None
+        if fixed_covariance is not None:
+            fixed = _lib.to_device(fixed_covariance, t.float64).to(y.device)
+            assert tuple(fixed.shape) == (*indep, K), (
+                f'{tuple(fixed.shape)} != {(*indep, K)}')  # :161-163
+            fixed = fixed.reshape(-1, K).contiguous()
+        if iterations <= 0:
+            return None  # the reference's loop body never runs (:127-141)
+        r = engine.gmm_fit(y.reshape(-1, N, E), K, gamma0=gamma0.reshape(-1, K, N).contiguous(),
+                           iterations=iterations, saliency=sal, weight_mode=mode,
+                           fixed_covariance=fixed)
+        if kind == _UNIFORM:
+            weight = t.full((K, 1), 1.0 / K, dtype=t.float64, device=y.device)
+        elif kind == _ONES:
+            weight = t.ones((*indep, 1, N), dtype=t.float64, device=y.device)
+        else:
+            weight = r['weight'].reshape(*indep, K, 1)
+        return GMM(
+            weight=as_result(weight, like_torch),
+            gaussian=SphericalGaussian(
+                mean=as_result(r['mean'].reshape(*indep, K, E), like_torch),
+                covariance=as_result(r['covariance'].reshape(*indep, K), like_torch)))
+
+    def fit_predict(self, y, initialization=None, num_classes=None, iterations=100, *,
+                    saliency=None, weight_constant_axis=(-2,), covariance_type='full',
+                    fixed_covariance=None):
+        """Fit a model. Then just return the posterior affiliations (:97-119)."""
+        model = self.fit(y=y, initialization=initialization, num_classes=num_classes,
+                         iterations=iterations, saliency=saliency,
+                         weight_constant_axis=weight_constant_axis,
+                         covariance_type=covariance_type, fixed_covariance=fixed_covariance)
+        return model.predict(y)

@@ -279,7 +279,7 @@ def last_kernel_ms(device_index=None):
     return float(ms.value)
 
 
-def dhtv_calculate_mapping(mask, plan, optimal=False):
+def dhtv_calculate_mapping(mask, plan, optimal=False, metric='cos'):
     """pbbss_dhtv_calculate_mapping: mask (U,K,F,T) f64, plan int32 (P,3) on the
     device -> (mapping int32 (U,K,F), aligned unit-norm features (U,K,F,T), status (U,))."""
     t = _t()
@@ -289,7 +289,7 @@ def dhtv_calculate_mapping(mask, plan, optimal=False):
     st = t.zeros((U,), dtype=t.int32, device=mask.device)
     rc = _lib.load().pbbss_dhtv_calculate_mapping(
         _lib.handle(mask.device.index), _lib.ptr(mask), U, K, F, T, _lib.ptr(plan),
-        int(plan.shape[0]), int(bool(optimal)), _lib.ptr(feat), _lib.ptr(mapping),
+        int(plan.shape[0]), int(bool(optimal)), PA_METRIC[metric], _lib.ptr(feat), _lib.ptr(mapping),
         _lib.ptr(st), _lib.stream_ptr(mask.device.index))
     _lib.check(rc, f'dhtv_calculate_mapping(U={U},K={K},F={F},T={T})')
     return mapping, feat, st
@@ -520,6 +520,41 @@ def vmfmm_fit(y, K, *, gamma0=None, model=None, iterations=100, saliency=None, w
         _lib.stream_ptr(dev.index))
     _lib.check(rc, f'vmfmm_fit(B={B},N={N},E={E},K={K})')
     return dict(mean=mean, concentration=conc, weight=weight, affiliation=aff, log_pdf=lp)
+
+
+def gmm_fit(y, K, *, gamma0=None, model=None, iterations=100, saliency=None, weight_mode=0,
+            fixed_covariance=None, final_predict=False, want_log_pdf=False):
+    """pbbss_gmm_fit (spherical covariances).  y (B,N,E) real, used as given (no row
+    normalisation); gamma0 (B,K,N) f64 or (iterations=0) model=(mean (B,K,E),
+    covariance (B,K), weight (B,K)); fixed_covariance (B,K) or None."""
+    t = _t()
+    y = _real_embedding(y)
+    dev = y.device
+    B, N, E = y.shape
+    f64 = t.float64
+    opts = _lib.MixOpts(iterations=int(iterations), kind=_lib.EMBED_GAUSS_SPHERICAL,
+                        weight_mode=int(weight_mode), embedding_is_f64=int(y.dtype == f64),
+                        final_predict=int(bool(final_predict or want_log_pdf)))
+    mean = t.empty((B, K, E), dtype=f64, device=dev)
+    cov = t.empty((B, K), dtype=f64, device=dev)
+    weight = t.empty((B, K), dtype=f64, device=dev)
+    aff = t.empty((B, K, N), dtype=f64, device=dev) if final_predict else None
+    lp = t.empty((B, K, N), dtype=f64, device=dev) if want_log_pdf else None
+    in_mean = in_cov = in_w = None
+    if model is not None:
+        in_mean, in_cov, in_w = model
+        assert in_mean.shape == (B, K, E) and in_cov.shape == (B, K) and in_w.shape == (B, K)
+    else:
+        assert gamma0.shape == (B, K, N) and gamma0.dtype == f64
+    if fixed_covariance is not None:
+        assert fixed_covariance.shape == (B, K) and fixed_covariance.dtype == f64
+    rc = _lib.load().pbbss_gmm_fit(
+        _lib.handle(dev.index), _lib.ptr(y), B, N, E, K, _lib.ptr(gamma0), _lib.ptr(in_mean),
+        _lib.ptr(in_cov), _lib.ptr(in_w), _lib.ptr(saliency), _lib.ptr(fixed_covariance),
+        ctypes.byref(opts), _lib.ptr(mean), _lib.ptr(cov), _lib.ptr(weight), _lib.ptr(aff),
+        _lib.ptr(lp), _lib.stream_ptr(dev.index))
+    _lib.check(rc, f'gmm_fit(B={B},N={N},E={E},K={K})')
+    return dict(mean=mean, covariance=cov, weight=weight, affiliation=aff, log_pdf=lp)
 
 
 def joint_weight_shape(weight_mode, F, K, T):

@@ -7,11 +7,10 @@ examples/mixture_model_example.ipynb): same constructor arguments, presets,
 The whole plan runs in one kernel launch (csrc/dhtv.hip); masks are
 (K, F, T) like the reference, or (..., K, F, T) for batches of utterances.
 
-Device coverage: DHTV with similarity_metric 'cos' (the default of
-`from_stft_size`) and algorithm 'greedy' (default) or 'optimal'; other DHTV
-metrics raise NotImplementedError.  `GreedyPermutationAlignment` and
-`OraclePermutationAlignment` (reference :592-786) run every metric
-('cos', 'multiply', 'euclidean') and both assignment algorithms on the device
+Device coverage: every similarity metric of the reference ('cos' -- the default of
+`from_stft_size` --, 'multiply', 'euclidean') and both assignment algorithms
+('greedy', 'optimal') for DHTV, `GreedyPermutationAlignment` and
+`OraclePermutationAlignment` (reference :592-786), all on the device
 (one wavefront per frequency bin; the greedy solver's recursion is a
 permutation prefix scan), as does `_mapping_from_score_matrix`.
 """
@@ -124,10 +123,7 @@ class DHTVPermutationAlignment(_PermutationAlignment):
         """mask (K, F, T) [or (..., K, F, T)] -> reverse mapping (K, F) int64."""
         if plot:
             raise NotImplementedError('plot=True needs paderbox; use the reference for plots')
-        if self.similarity_metric != 'cos':
-            raise NotImplementedError(
-                f'similarity_metric={self.similarity_metric!r}: only the default '
-                "'cos' runs on the device")
+        _check_metric(self.similarity_metric)
         if self.algorithm not in ('greedy', 'optimal'):
             raise ValueError(self.algorithm)
         like_torch = _lib.is_torch(mask)
@@ -140,7 +136,7 @@ class DHTVPermutationAlignment(_PermutationAlignment):
         assert plan[:, 2].max() <= F and plan[:, 1].min() >= 0, (plan, F)
         mapping, _, st = engine.dhtv_calculate_mapping(
             m.reshape(-1, K, F, T).contiguous(), _lib.to_device(plan).to(m.device),
-            optimal=(self.algorithm == 'optimal'))
+            optimal=(self.algorithm == 'optimal'), metric=self.similarity_metric)
         if int(st.max().item()) != 0:
             raise ValueError('score matrix is infeasible')  # reference :512-514
         mapping = mapping.reshape(*lead, K, F).to(t.int64)

@@ -25,10 +25,16 @@ def test_dhtv_mapping_identical_to_reference():
         assert (aligned == mask[mapping, range(mask.shape[1])]).all()
         solver.algorithm = 'optimal'
         assert (solver.calculate_mapping(mask) == g[tag + '_mapping_optimal']).all()
+        for metric in ('multiply', 'euclidean'):
+            for alg in ('greedy', 'optimal'):
+                sv = DHTVPermutationAlignment.from_stft_size(size, metric)
+                sv.algorithm = alg
+                assert (sv.calculate_mapping(mask) == g[f'{tag}_mapping_{metric}_{alg}']).all()
 
 
 def test_dhtv_batch_and_plan_doctests():
     from pb_bss_amd.permutation_alignment import DHTVPermutationAlignment
+    from pb_bss_amd import engine
     from oracle import permutation_alignment as op
     assert DHTVPermutationAlignment.from_stft_size(512).alignment_plan == [
         [20, 70, 170], [2, 90, 190], [2, 50, 150], [2, 110, 210], [2, 30, 130],
@@ -50,8 +56,21 @@ def test_dhtv_batch_and_plan_doctests():
     plan = op.alignment_plan(512, **op.PRESETS[512])
     for u in range(U):
         assert (mapping[u] == op.dhtv_calculate_mapping(masks[u], plan)).all()
-    with pytest.raises(NotImplementedError):
-        DHTVPermutationAlignment.from_stft_size(512, 'euclidean').calculate_mapping(masks[0])
+    # every metric of the reference, on noisy masks where the metrics disagree
+    noisy = rng.uniform(size=(2, K, F, T)) ** 2
+    seen = []
+    for metric in ('cos', 'multiply', 'euclidean'):
+        for team in (1, 0):
+            engine.set_dhtv_team(team)
+            mp = DHTVPermutationAlignment.from_stft_size(512, metric).calculate_mapping(noisy)
+            for u in range(2):
+                assert (mp[u] == op.dhtv_calculate_mapping(noisy[u], plan, 'greedy', metric)).all(), \
+                    (metric, team, u)
+        seen.append(mp)
+    engine.set_dhtv_team(0)
+    assert any((seen[0] != x).any() for x in seen[1:])
+    with pytest.raises(AttributeError):
+        DHTVPermutationAlignment.from_stft_size(512, 'coss').calculate_mapping(masks[0])
 
 
 def test_em_masks_align_end_to_end():
