@@ -27,3 +27,23 @@ for U in (1, 2, 4, 8, 16, 64):
     print(f'device DHTV U={U}: {dt*1e3:.3f} ms per call, {dt/U*1e3:.3f} ms/utterance')
 t0 = time.perf_counter(); ref = op.dhtv_calculate_mapping(pm, solver.alignment_plan); dt = time.perf_counter() - t0
 print(f'NumPy oracle: {dt*1e3:.1f} ms/utterance; identical mapping: {(ref == _lib.to_host(mapping[0])).all()}')
+
+# ---- pairwise solvers (greedy / oracle), every metric ----------------------------------------
+from pb_bss_amd.permutation_alignment import GreedyPermutationAlignment, OraclePermutationAlignment
+md, rd = _lib.to_device(pm), _lib.to_device(mask)
+for metric in ('cos', 'multiply', 'euclidean'):
+    g, o = GreedyPermutationAlignment(metric), OraclePermutationAlignment(metric)
+    g.calculate_mapping(md); o.calculate_mapping(md, rd)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(10):
+        mg = g.calculate_mapping(md)
+    torch.cuda.synchronize(); tg = (time.perf_counter() - t0) / 10
+    t0 = time.perf_counter()
+    for _ in range(10):
+        mo = o.calculate_mapping(md, rd)
+    torch.cuda.synchronize(); to = (time.perf_counter() - t0) / 10
+    t0 = time.perf_counter(); rg = op.greedy_calculate_mapping(pm, metric); tcg = time.perf_counter() - t0
+    t0 = time.perf_counter(); ro = op.oracle_calculate_mapping(pm, mask, metric); tco = time.perf_counter() - t0
+    print(f'{metric:10s} greedy: device {tg*1e3:.3f} ms, NumPy oracle {tcg*1e3:.1f} ms, identical '
+          f'{(rg == mg.cpu().numpy()).all()};  oracle solver: device {to*1e3:.3f} ms, NumPy {tco*1e3:.1f} ms, '
+          f'identical {(ro == mo.cpu().numpy()).all()}')
