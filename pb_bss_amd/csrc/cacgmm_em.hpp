@@ -1167,6 +1167,82 @@ struct EmKernel {
     __syncthreads();
   }
 
+  // Distributed factorisation of a split problem: after the exchange every member holds the
+  // same totals, but instead of all G members factoring all K classes (K waves x ~500
+  // instructions on CUs that already host two full workgroups) member k factors class k
+  // alone and publishes the packed inverse, determinant, weight and status through a second
+  // L2 slab; the others only read K * (NA + 5) doubles.  Same hand-off protocol as above,
+  // second counter at xcount[16 + prob], double-buffered by iteration parity (a member can
+  // only reach the same parity again after two further full exchanges, i.e. after every
+  // member has read this one).
+  static constexpr int kSlab2Len = NA + 5;
+  static __host__ __device__ size_t split_slab_doubles(int nprob, int G) {
+    return (size_t)2 * nprob * G * kSlabLen + (size_t)2 * nprob * K * kSlab2Len;
+  }
+
+  static __device__ void split_publish_model(const EmArgs& a, const Lds& L, int prob, int nprob,
+                                             int g, int it, int tid) {
+    const int G = a.split_groups;
+    double* base = a.xslab + (size_t)2 * nprob * G * kSlabLen;
+    double* slabs = base + ((size_t)(it & 1) * nprob + prob) * (size_t)K * kSlab2Len;
+    if (g < K) {
+      double* mine = slabs + (size_t)g * kSlab2Len;
+      for (int idx = tid; idx < kSlab2Len; idx += kEmThreads) {
+        double v;
+        if (idx < NA) {
+          v = L.apack[g * NA + idx];
+        } else if (idx == NA) {
+          v = L.detm[g];
+        } else if (idx == NA + 1) {
+          v = L.rdet[g];
+        } else if (idx == NA + 2) {
+          v = (double)L.dete[g];
+        } else if (idx == NA + 3) {
+          v = L.wgt[g];
+        } else {
+          v = (double)L.status[g];
+        }
+        __hip_atomic_store(mine + idx, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    if (tid == 0) {
+      unsigned* cnt = a.xcount + 16 + prob;
+      if (g < K) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned target = (unsigned)K * (unsigned)(it + 1);
+      unsigned spins = 0;
+      while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > kSpinLimit) {
+          atomicExch(a.xerror, 1);
+          break;
+        }
+      }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < K * kSlab2Len; idx += kEmThreads) {
+      const int k = idx / kSlab2Len, e = idx - k * kSlab2Len;
+      if (k == g) continue;  // this member's own class is already in LDS
+      const double v =
+          __hip_atomic_load(slabs + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (e < NA) {
+        L.apack[k * NA + e] = v;
+      } else if (e == NA) {
+        L.detm[k] = v;
+      } else if (e == NA + 1) {
+        L.rdet[k] = v;
+      } else if (e == NA + 2) {
+        L.dete[k] = (int)v;
+      } else if (e == NA + 3) {
+        L.wgt[k] = v;
+      } else {
+        L.status[k] = (int)v;  // cumulative in the publisher
+      }
+    }
+    __syncthreads();
+  }
+
   static __device__ void run_split(const EmArgs& ga, char* smem) {
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1235,17 +1311,28 @@ struct EmKernel {
       split_exchange(a, L, prob, nprob, g, it, tid);
       PBBSS_STICK(4)
       const bool last = (it == a.iterations - 1);
-      // every workgroup factors the same totals; only group 0 writes the model
-      EmArgs fa = a;
-      if (g != 0) {
-        fa.out_eigvec = nullptr;
-        fa.out_eigval = nullptr;
-        fa.out_cov = nullptr;
+      if (G >= K) {
+        // member k factors class k (and writes that class of the model), then publishes it.
+        // On the LAST wave: with 64-frame windows the E phase runs on wave 0 alone, and the
+        // co-resident full workgroups are slowed by the most loaded SIMD, not by the total.
+        if (g < K && wave == kEmWaves - 1) factor_class(a, L, b, g, lane, last);
+        PBBSS_STICK(5)
+        __syncthreads();
+        split_publish_model(a, L, prob, nprob, g, it, tid);
+        PBBSS_STICK(6)
+      } else {
+        // every workgroup factors the same totals; only group 0 writes the model
+        EmArgs fa = a;
+        if (g != 0) {
+          fa.out_eigvec = nullptr;
+          fa.out_eigval = nullptr;
+          fa.out_cov = nullptr;
+        }
+        for (int k = wave; k < K; k += kEmWaves) factor_class(fa, L, b, k, lane, last);
+        PBBSS_STICK(5)
+        __syncthreads();
+        PBBSS_STICK(6)
       }
-      for (int k = wave; k < K; k += kEmWaves) factor_class(fa, L, b, k, lane, last);
-      PBBSS_STICK(5)
-      __syncthreads();
-      PBBSS_STICK(6)
     }
 #ifdef PBBSS_PHASE_PROFILE
     // split launches report into the second half of the counter buffer: [32 + wave*8 + i]

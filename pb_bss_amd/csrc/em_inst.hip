@@ -42,7 +42,7 @@ static int launch_split(EmArgs a, int64_t b_first, int r, const EmLaunchCfg& cfg
   const int window = cfg.split_window > 256 ? 256 : cfg.split_window;  // one E pass per window
   const int G = (a.T + window - 1) / window;
   const size_t lds = Kern::lds_bytes(window);
-  const size_t slab_bytes = (size_t)2 * r * G * Kern::kSlabLen * sizeof(double);
+  const size_t slab_bytes = Kern::split_slab_doubles(r, G) * sizeof(double);
   const size_t head = 256;  // counters (r uint) + error word
   if (head + slab_bytes > cfg.xbuf_bytes) return PBBSS_ERR_UNSUPPORTED;
   auto kfn = cacgmm_em_split_kernel<PBBSS_EM_D, K, YS>;
@@ -75,8 +75,9 @@ static int launch_one(const EmArgs& a, const EmLaunchCfg& cfg, hipStream_t strea
   const int64_t r = a.B % cfg.num_cu;
   const int window = cfg.split_window > 256 ? 256 : cfg.split_window;
   const size_t slab_need =
-      256 + (size_t)2 * r * ((a.T + window - 1) / window) *
-                EmKernel<PBBSS_EM_D, K, YS, false>::kSlabLen * sizeof(double);
+      256 + EmKernel<PBBSS_EM_D, K, YS, false>::split_slab_doubles((int)r, (a.T + window - 1) /
+                                                                               window) *
+                sizeof(double);
   const bool split = cfg.allow_split && a.iterations > 0 && a.B > cfg.num_cu &&
                      a.B <= 3 * (int64_t)cfg.num_cu && r >= 1 && r <= kSplitMaxProblems &&
                      a.T >= 2 * cfg.split_window && a.wt == 0 && slab_need <= cfg.xbuf_bytes;
