@@ -614,92 +614,6 @@ struct EmKernel {
 #endif
   }
 
-  // ---- phase M, entry-parallel form (members of a split group) ----------------------------
-  // lane = Hermitian entry (a, b) = (lane >> 3, lane & 7): a == b the diagonal, a < b Re C_ab,
-  // a > b Im C_ba; no cross-lane reduction at all.  Only waves 1 and 2 take part (frames
-  // interleaved between them): a member's E phase runs on wave 0 and its factorisation on
-  // wave 3, and the full workgroups that share the CU are slowed by the most loaded SIMD.
-  // Partial sums -> mpart[2][K][64]; phase_m_entries_combine adds them in a fixed order.
-  static constexpr int kMEntryWaves = 2;
-  static __host__ __device__ size_t split_extra_lds() {
-    return (size_t)kMEntryWaves * K * 64 * sizeof(double);
-  }
-
-  static __device__ void phase_m_entries(const EmArgs& a, const Lds& L, double* mpart, int wave,
-                                         int lane) {
-    if (wave < 1 || wave > kMEntryWaves) return;
-    lane = opaque(lane);
-    const int ea = lane >> 3, eb = lane & 7;
-    const bool valid = ea < D && eb < D;
-    const int ca = valid ? ea : 0, cb = valid ? eb : 0;
-    const bool lower = ea > eb;
-    // P entry = x1 x2 + x3 x4 with (x1..x4) = (re_a, re_b, im_a, im_b) for a <= b
-    // [re: Re y_a conj(y_b); diagonal: |y_a|^2] and (im_b, re_a, -re_b, im_a) for a > b
-    // [Im y_b conj(y_a), the (i, j) = (b, a) pair of phase_m]
-    const int oa = (ca >> 1) * L.Tp * 4 + (ca & 1) * 2;  // ybuf: [DP][Tp][4] = (re, im, re, im)
-    const int ob = (cb >> 1) * L.Tp * 4 + (cb & 1) * 2;
-    const int o1 = lower ? ob + 1 : oa;
-    const int o2 = lower ? oa : ob;
-    const int o3 = lower ? ob : oa + 1;
-    const int o4 = lower ? oa + 1 : ob + 1;
-    const double s3 = lower ? -1.0 : 1.0;
-    double acc[K];
-#pragma unroll
-    for (int k = 0; k < K; ++k) acc[k] = 0.0;
-    // four frames per trip, all their LDS reads issued before the first FMA: a one-frame loop
-    // is a chain of LDS round trips (measured: the member became the critical path)
-    constexpr int U = 4;
-    for (int t0 = wave - 1; t0 < a.T; t0 += U * kMEntryWaves) {
-      YS y1[U], y2[U], y3[U], y4[U];
-      double w[U][K];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int t = t0 + u * kMEntryWaves;
-        const bool ok = t < a.T;
-        const int tc = ok ? t : 0;
-        y1[u] = L.ybuf[o1 + tc * 4];
-        y2[u] = L.ybuf[o2 + tc * 4];
-        y3[u] = L.ybuf[o3 + tc * 4];
-        y4[u] = L.ybuf[o4 + tc * 4];
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-          const double wv = L.wbuf[(size_t)k * L.Tp + tc];
-          w[u][k] = ok ? wv : 0.0;
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const double p = fma(s3 * (double)y3[u], (double)y4[u], (double)y1[u] * (double)y2[u]);
-#pragma unroll
-        for (int k = 0; k < K; ++k) acc[k] = fma(w[u][k], p, acc[k]);
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < K; ++k) mpart[((wave - 1) * K + k) * 64 + lane] = acc[k];
-  }
-
-  static __device__ void phase_m_entries_combine(const Lds& L, const double* mpart, int tid) {
-    for (int idx = tid; idx < K * 64; idx += kEmThreads) {
-      const int k = idx >> 6, l = idx & 63;
-      const int ea = l >> 3, eb = l & 7;
-      if (ea >= D || eb >= D) continue;
-      double v = 0.0;
-#pragma unroll
-      for (int w = 0; w < kMEntryWaves; ++w) v += mpart[(w * K + k) * 64 + l];
-      if (ea == eb) {
-        double* cc = L.cmat + (((size_t)k * D + ea) * D + ea) * 2;
-        cc[0] = v;
-        cc[1] = 0.0;
-      } else if (ea < eb) {
-        L.cmat[(((size_t)k * D + ea) * D + eb) * 2] = v;
-        L.cmat[(((size_t)k * D + eb) * D + ea) * 2] = v;
-      } else {  // Im C_ij with (i, j) = (eb, ea), i < j;  C_ji = conj(C_ij)
-        L.cmat[(((size_t)k * D + eb) * D + ea) * 2 + 1] = v;
-        L.cmat[(((size_t)k * D + ea) * D + eb) * 2 + 1] = -v;
-      }
-    }
-  }
-
   // packed index of pair (i < j)
   static __device__ __forceinline__ int pair_index(int i, int j) {
     return i * D - (i * (i + 1)) / 2 + (j - i - 1);
@@ -1350,7 +1264,6 @@ struct EmKernel {
     EmArgs a = ga;  // this workgroup's window
     a.T = min(ga.split_window, ga.T_total - tf);
     const Lds L = carve(smem, ga.split_window, nullptr);
-    double* mpart = reinterpret_cast<double*>(smem + lds_bytes(ga.split_window));
 #ifdef PBBSS_PHASE_PROFILE
     unsigned long long spc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long stprev = __builtin_readcyclecounter();
@@ -1387,10 +1300,13 @@ struct EmKernel {
         __syncthreads();
         PBBSS_STICK(2)
       }
-      phase_m_entries(a, L, mpart, wave, lane);
+      switch (wave) {
+        case 0: phase_m<0>(a, L, lane); break;
+        case 1: phase_m<1>(a, L, lane); break;
+        case 2: phase_m<2>(a, L, lane); break;
+        default: phase_m<3>(a, L, lane); break;
+      }
       PBBSS_STICK(3)
-      __syncthreads();
-      phase_m_entries_combine(L, mpart, tid);
       __syncthreads();
       split_exchange(a, L, prob, nprob, g, it, tid);
       PBBSS_STICK(4)

@@ -41,7 +41,7 @@ static int launch_split(EmArgs a, int64_t b_first, int r, const EmLaunchCfg& cfg
   using Kern = EmKernel<PBBSS_EM_D, K, YS, false>;
   const int window = cfg.split_window > 256 ? 256 : cfg.split_window;  // one E pass per window
   const int G = (a.T + window - 1) / window;
-  const size_t lds = Kern::lds_bytes(window) + Kern::split_extra_lds();  // + entry-parallel M partials
+  const size_t lds = Kern::lds_bytes(window);
   const size_t slab_bytes = Kern::split_slab_doubles(r, G) * sizeof(double);
   const size_t head = 256;  // counters (r uint) + error word
   if (head + slab_bytes > cfg.xbuf_bytes) return PBBSS_ERR_UNSUPPORTED;
