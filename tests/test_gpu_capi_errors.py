@@ -57,6 +57,33 @@ def test_invalid_arguments_return_codes_not_crashes():
     a = torch.zeros((3, 5, 2), dtype=torch.complex128, device='cuda')
     assert lib.pbbss_lcmv(h, _lib.ptr(a), _lib.ptr(a), _lib.ptr(a), 5, 2, 3, _lib.ptr(a), None,
                           stream) == _lib.ERR_INVALID_ARG
+    # permutation solvers: K <= 8, metric in range, mapping window inside the output row
+    mk = torch.rand((1, 9, 5, 16), dtype=torch.float64, device='cuda')
+    mp = torch.zeros((1, 9, 5), dtype=torch.int32, device='cuda')
+    ps = torch.zeros((1,), dtype=torch.int32, device='cuda')
+    i64x3 = ctypes.c_int64 * 3
+
+    def pair(KK=3, metric=0, col0=0, F=5, map_F=5, strides=i64x3(9 * 5 * 16, 5 * 16, 16)):
+        return lib.pbbss_pa_pairwise_mapping(h, _lib.ptr(mk), _lib.ptr(mk), 1, KK, F, 16, strides,
+                                             strides, metric, 0, None, _lib.ptr(mp), map_F, col0,
+                                             _lib.ptr(ps), stream)
+    assert pair(KK=9) == _lib.ERR_UNSUPPORTED
+    assert pair(metric=3) == _lib.ERR_INVALID_ARG
+    assert pair(col0=1) == _lib.ERR_INVALID_ARG             # 1 + 5 columns do not fit 5
+    assert pair(strides=None) == _lib.ERR_INVALID_ARG
+    assert pair() == _lib.OK
+    assert lib.pbbss_pa_compose_mapping(h, None, 1, 3, 5, stream) == _lib.ERR_INVALID_ARG
+    assert lib.pbbss_pa_compose_mapping(h, _lib.ptr(mp), 1, 9, 5, stream) == _lib.ERR_UNSUPPORTED
+    assert lib.pbbss_pa_mapping_from_scores(h, _lib.ptr(mk), 0, 3, 0, _lib.ptr(mp), _lib.ptr(ps),
+                                            stream) == _lib.ERR_INVALID_ARG
+    # Gaussian mixture: same argument rules as the vMF mixture (affiliations xor model)
+    mo = _lib.MixOpts(iterations=2, kind=_lib.EMBED_GAUSS_SPHERICAL)
+    ge = torch.rand((1, 10, 4), dtype=torch.float32, device='cuda')
+    gm = torch.zeros((1, 2, 4), dtype=torch.float64, device='cuda')
+    gc = torch.ones((1, 2), dtype=torch.float64, device='cuda')
+    assert lib.pbbss_gmm_fit(h, _lib.ptr(ge), 1, 10, 4, 2, None, None, None, None, None, None,
+                             ctypes.byref(mo), _lib.ptr(gm), _lib.ptr(gc), _lib.ptr(gc), None,
+                             None, stream) == _lib.ERR_INVALID_ARG
     torch.cuda.synchronize()
     assert fit() == _lib.OK                                   # the handle is still usable
 
