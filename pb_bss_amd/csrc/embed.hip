@@ -151,7 +151,7 @@ __global__ void __launch_bounds__(kThreads)
     acc[k] = 0.0;
     pk[k] = pr[k];
   }
-  constexpr int U = 8;  // loads in flight per lane
+  constexpr int U = 8;  // loads in flight per lane (16 measured: no gain)
   for (int d0 = 0; d0 < E; d0 += U) {
     double v[U];
 #pragma unroll
@@ -206,7 +206,8 @@ __global__ void __launch_bounds__(kThreads)
 //         the finalize turns it into the variance about the new mean without a second pass over
 //         the embedding; with c within the data's spread there is no cancellation to speak of.
 // part layout: [b][chunk][k][E+1]  (slot E = S0); PASS 2 writes S2' to part2 (same layout)
-constexpr int kFitThreads = 1024;  // 16 waves: one workgroup per CU keeps 1024 loads in flight
+constexpr int kFitThreads = 1024;  // 16 waves: one workgroup per CU
+constexpr int kFitUnroll = 16;     // x 16 loads in flight per thread
 
 template <int K, typename TS, int PASS>
 __global__ void __launch_bounds__(kFitThreads)
@@ -236,41 +237,57 @@ __global__ void __launch_bounds__(kFitThreads)
     if (PASS == 2 && active)
       mu[k] = shift_first_row ? (double)yr[(size_t)b * N * E + d] : mean[((size_t)b * K + k) * E + d];
   }
-  if (active) {
-    constexpr int U = 4;
-    const TS* base = yr + (size_t)b * N * E;
-    for (int64_t n = n0 + s; n < n1; n += (int64_t)U * S) {
-      double yv[U], sv[U], w[U][K];
+  // Per trip the workgroup covers U * S samples.  Their class weights affiliation * saliency
+  // (vmfmm.py:167) are staged through LDS first: every one of the E threads of a sample needs
+  // the same K values, and as global loads those were E-fold redundant requests on the L1
+  // (K + 1 of the K + 2 loads per element).
+  constexpr int U = kFitUnroll;  // loads in flight per thread: the sweep is latency-bound (1 workgroup per CU)
+  double* wst = red2 + (size_t)S * K * E;  // [U * S][K]
+  const TS* base = yr + (size_t)b * N * E;
+  const int SU = U * S;
+  for (int64_t nb = n0; nb < n1; nb += SU) {
+    for (int i = tid; i < SU * K; i += kFitThreads) {
+      const int k = i / SU, smp = i - k * SU;  // consecutive lanes = consecutive samples
+      const int64_t nn = nb + smp;
+      double wv = 0.0;
+      if (nn < n1) {
+        wv = aff[aff_index(b, k, nn, K, N, Tin)];
+        if (sal) wv *= sal[(size_t)b * N + nn];
+      }
+      wst[smp * K + k] = wv;
+    }
+    __syncthreads();
+    if (active) {
+      TS yv[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int64_t nn = n + (int64_t)u * S;
-        const bool ok = nn < n1;
-        const int64_t nc = ok ? nn : n;
-        yv[u] = (double)base[(size_t)nc * E + d];
-        sv[u] = ok ? (sal ? sal[(size_t)b * N + nc] : 1.0) : 0.0;
-#pragma unroll
-        for (int k = 0; k < K; ++k) w[u][k] = aff[aff_index(b, k, nc, K, N, Tin)];
+        const int64_t nn = nb + s + (int64_t)u * S;
+        const int64_t nc = (nn < n1) ? nn : nb;  // staged weight is 0 there
+        yv[u] = base[(size_t)nc * E + d];
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-          const double wk = w[u][k] * sv[u];  // affiliation * saliency (vmfmm.py:167)
+          const double wk = wst[(s + u * S) * K + k];
           if (PASS == 0 || PASS == 2) {
-            acc[k] = fma(wk, yv[u], acc[k]);
+            acc[k] = fma(wk, (double)yv[u], acc[k]);
             acc0[k] += wk;
           }
           if (PASS == 1) {
-            const double df = yv[u] - mu[k];
+            const double df = (double)yv[u] - mu[k];
             acc[k] = fma(wk * df, df, acc[k]);
           }
           if (PASS == 2) {
-            const double df = yv[u] - mu[k];
+            const double df = (double)yv[u] - mu[k];
             acc2[k] = fma(wk * df, df, acc2[k]);
           }
         }
       }
     }
+    __syncthreads();
+  }
+  if (active) {
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       red[(s * K + k) * E + d] = acc[k];
@@ -572,7 +589,9 @@ inline int ok_or_hip() { return hipGetLastError() == hipSuccess ? PBBSS_OK : PBB
 // slot-reduction buffer stays within 48 KiB of LDS
 int fit_slots(int E, int K) {
   int S = kFitThreads / E;
-  const int cap = 3072 / (K * (E + 1));  // two slot-reduction buffers (single-pass Gaussian) in 48 KiB
+  // two slot-reduction buffers (single-pass Gaussian), the slot sums and the weight staging of
+  // kFitUnroll trips within the 64 KiB of dynamic LDS a launch gets without an attribute
+  const int cap = 8000 / (K * (2 * E + 1 + kFitUnroll));
   if (S > cap) S = cap;
   return S < 1 ? 1 : S;
 }
@@ -667,7 +686,7 @@ int fit_go(int kind, const void* yr, int64_t B, int64_t N, int E, const double* 
   int64_t L = (N + C - 1) / C;
   L = (L + S - 1) / S * S;
   const size_t Wv = (size_t)K * (E + 1);
-  const size_t lds_fit = (2 * (size_t)S * K * E + (size_t)S * K) * sizeof(double);
+  const size_t lds_fit = (2 * (size_t)S * K * E + (size_t)S * K + (size_t)kFitUnroll * S * K) * sizeof(double);  // + weight staging
   const size_t lds_fin = (Wv + (Wv < (size_t)kFinThreads ? (kFinThreads / Wv) * Wv : 0)) * sizeof(double);
   dim3 grid((unsigned)C, (unsigned)B);
   if (kind == PBBSS_EMBED_GAUSS_SPHERICAL && single_pass != 0) {
