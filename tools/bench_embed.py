@@ -9,7 +9,7 @@ import numpy as np, torch
 from oracle import embed as oe, synth
 from pb_bss_amd import _lib, engine
 
-F, T, D, K, E = 513, 500, 8, 3, 40
+F, T, D, K, E = int(os.environ.get('BENCH_F', '513')), 500, 8, 3, 40  # BENCH_F=512: no remainder bin
 Y, e, init = synth.make_joint(F, T, D, K, E, seed=0)
 yd, ed, gd = _lib.to_device(Y), _lib.to_device(e), _lib.to_device(init)
 flat = ed.reshape(1, F * T, E)
