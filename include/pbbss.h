@@ -384,6 +384,26 @@ int pbbss_embed_fit(pbbss_handle_t h, const void* y, int y_is_f64, int64_t B,
                     double max_concentration, double* out_mean,
                     double* out_scale, void* stream);
 
+/* ------------------------------------------------------------------------- */
+/* N3 (sibling)  Full-covariance Gaussians  distribution/gaussian.py:17-56,        */
+/* 152-193 (Gaussian, GaussianTrainer._fit with covariance_type='full').           */
+/* y (B,N,E) real row-major, float32 / float64; 1 <= E <= 63.                      */
+/* fit: weights (B,K,N) f64 per-class saliencies -> out_mean (B,K,E),              */
+/*      out_covariance (B,K,E,E) (weighted scatter about the mean on the FP64      */
+/*      matrix pipe).                                                              */
+/* log_pdf: mean (B,K,E), covariance (B,K,E,E) -> out (B,K,N) f64, evaluated as    */
+/*      the reference writes it (precision Cholesky of sklearn applied as          */
+/*      P (y - mean), gaussian.py:46-50); out_status int32 (1) gets                */
+/*      PBBSS_ST_NOT_POSDEF where numpy.linalg.cholesky would raise.  K <= 64.     */
+/* ------------------------------------------------------------------------- */
+int pbbss_gauss_full_fit(pbbss_handle_t h, const void* y, int y_is_f64, int64_t B, int64_t N,
+                         int E, int K, const double* weights, double* out_mean,
+                         double* out_covariance, void* stream);
+int pbbss_gauss_full_log_pdf(pbbss_handle_t h, const void* y, int y_is_f64, int64_t B,
+                             int64_t N, int E, int K, const double* mean,
+                             const double* covariance, double* out_log_pdf,
+                             int32_t* out_status, void* stream);
+
 typedef struct pbbss_mix_opts {
   int32_t iterations;       /* EM iterations; 0 = E-step only with the given model */
   int32_t kind;             /* PBBSS_EMBED_* of the spectral half (joint models)   */

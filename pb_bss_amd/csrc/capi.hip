@@ -6,6 +6,7 @@
 #include "beamform.hpp"
 #include "dhtv.hpp"
 #include "embed.hpp"
+#include "gauss_full.hpp"
 #include "generic.hpp"
 #include "generic_bf.hpp"
 #include "stft.hpp"
@@ -817,6 +818,44 @@ PBBSS_API int pbbss_embed_fit(pbbss_handle_t h, const void* y, int y_is_f64, int
   return pbbss::launch_embed_fit(kind, yr, yr_f64, B, N, E, K, weights, N, nullptr,
                                  min_concentration, max_concentration, -1, part, out_mean,
                                  out_scale, nullptr, nullptr, nullptr, 0, s);
+}
+
+PBBSS_API int pbbss_gauss_full_fit(pbbss_handle_t h, const void* y, int y_is_f64, int64_t B,
+                                   int64_t N, int E, int K, const double* weights,
+                                   double* out_mean, double* out_covariance, void* stream) {
+  DeviceGuard device_guard(h);
+  if (!h || !y || !weights || !out_mean || !out_covariance || B <= 0 || N <= 0)
+    return PBBSS_ERR_INVALID_ARG;
+  if (E < 1 || E > pbbss::kGaussFullMaxE || K < 1) return PBBSS_ERR_UNSUPPORTED;
+  const size_t np = pbbss::gauss_full_partial_doubles(B, N, E, K);
+  void* w = handle_work(h, WorkCarver::pad(np * 8));
+  if (!w) return PBBSS_ERR_HIP;
+  TimedRegion tr(h, as_stream(stream));
+  return pbbss::launch_gauss_full_fit(y, y_is_f64, B, N, E, K, weights, static_cast<double*>(w),
+                                      out_mean, out_covariance, nullptr, nullptr, nullptr,
+                                      as_stream(stream));
+}
+
+PBBSS_API int pbbss_gauss_full_log_pdf(pbbss_handle_t h, const void* y, int y_is_f64, int64_t B,
+                                       int64_t N, int E, int K, const double* mean,
+                                       const double* covariance, double* out_log_pdf,
+                                       int32_t* out_status, void* stream) {
+  DeviceGuard device_guard(h);
+  if (!h || !y || !mean || !covariance || !out_log_pdf || !out_status || B <= 0 || N <= 0)
+    return PBBSS_ERR_INVALID_ARG;
+  if (E < 1 || E > pbbss::kGaussFullMaxE || K < 1 || K > 64) return PBBSS_ERR_UNSUPPORTED;
+  const size_t nm = (size_t)B * K * E * E;
+  void* w = handle_work(h, WorkCarver::pad(nm * 8) + WorkCarver::pad((size_t)B * K * 8));
+  if (!w) return PBBSS_ERR_HIP;
+  WorkCarver wc(w);
+  double* mq = wc.take<double>(nm);
+  double* off = wc.take<double>((size_t)B * K);
+  hipStream_t s = as_stream(stream);
+  TimedRegion tr(h, s);
+  int rc = pbbss::launch_gauss_full_factor(covariance, B * K, E, mq, off, out_status, s);
+  if (rc != PBBSS_OK) return rc;
+  return pbbss::launch_gauss_full_logpdf(y, y_is_f64, B, N, E, K, mean, mq, off, nullptr,
+                                         out_log_pdf, nullptr, s);
 }
 
 // EM loop shared by the two real-embedding mixtures: kind = PBBSS_EMBED_VMF (rows unit-normalised

@@ -1,7 +1,10 @@
-"""Spherical Gaussian on the HIP embedding kernels (csrc/embed.hip): the spectral
-half of GCACGMM.  Mirrors pb_bss/distribution/gaussian.py:100-193 for
-covariance_type='spherical' (the default of GCACGMMTrainer, gcacgmm.py:141).
-'full' / 'diagonal' covariances are not on the device path of this round.
+"""Gaussians on real embeddings on the device.  Mirrors pb_bss/distribution/gaussian.py:
+`SphericalGaussian` (:100-137; csrc/embed.hip -- the spectral half of GCACGMM, the default of
+GCACGMMTrainer, gcacgmm.py:141), `Gaussian` with a full covariance (:17-56; csrc/gauss_full.hip:
+weighted scatter on the FP64 matrix pipe, workgroup Cholesky, MFMA quadratic forms) and
+`GaussianTrainer` (:140-193) for covariance_type 'spherical' and 'full'.  'diagonal' is not
+on the device path (the reference's DiagonalGaussian.log_pdf feeds the (K, D) precisions to
+einsum as one matrix, :87-91).
 """
 from dataclasses import dataclass
 
@@ -10,7 +13,7 @@ import numpy as np
 from .. import _lib, engine
 from .utils import _ProbabilisticModel, as_result
 
-__all__ = ['SphericalGaussian', 'GaussianTrainer']
+__all__ = ['Gaussian', 'SphericalGaussian', 'GaussianTrainer']
 
 
 @dataclass
@@ -56,18 +59,71 @@ class SphericalGaussian(_ProbabilisticModel):
         return as_result(out.reshape(*shape, N), like_torch)
 
 
+@dataclass
+class Gaussian(_ProbabilisticModel):
+    mean: np.ndarray = None        # (..., D)
+    covariance: np.ndarray = None  # (..., D, D)
+
+    @property
+    def precision_cholesky(self):
+        """sklearn's 'full' precision Cholesky (gaussian.py:26-30): P = L^-T for cov = L L^T."""
+        cov = self.covariance
+        if _lib.is_torch(cov):
+            t = _lib.torch()
+            chol = t.linalg.cholesky(cov)
+            eye = t.eye(cov.shape[-1], dtype=cov.dtype, device=cov.device).expand_as(cov)
+            return t.linalg.solve_triangular(chol, eye, upper=False).transpose(-1, -2)
+        chol = np.linalg.cholesky(cov)
+        return np.swapaxes(np.linalg.inv(chol), -1, -2)
+
+    @property
+    def log_det_precision_cholesky(self):
+        pc = self.precision_cholesky
+        d = pc.diagonal(dim1=-2, dim2=-1) if _lib.is_torch(pc) else np.diagonal(pc, axis1=-2, axis2=-1)
+        return d.log().sum(-1) if _lib.is_torch(pc) else np.sum(np.log(d), axis=-1)
+
+    def log_pdf(self, y):
+        """y (..., N, D) -> (..., N), evaluated as the reference writes it (:35-56)."""
+        like_torch = _lib.is_torch(y)
+        t = _lib.torch()
+        y = _lib.to_device(y)
+        assert not y.is_complex(), y.dtype
+        N, E = y.shape[-2:]
+        mean = _lib.to_device(self.mean, t.float64).to(y.device)
+        cov = _lib.to_device(self.covariance, t.float64).to(y.device)
+        lead = tuple(mean.shape[:-1])
+        y_lead = tuple(y.shape[:-2])
+        K = int(np.prod(lead)) if lead else 1
+        if all(s == 1 for s in y_lead) and K <= 64:
+            out, st = engine.gauss_full_log_pdf(y.reshape(1, N, E),
+                                                mean.reshape(1, K, E).contiguous(),
+                                                cov.reshape(1, K, E, E).contiguous())
+            shape = lead
+        else:
+            shape = np.broadcast_shapes(y_lead, lead)
+            out, st = engine.gauss_full_log_pdf(
+                y.expand(*shape, N, E).reshape(-1, N, E).contiguous(),
+                mean.expand(*shape, E).reshape(-1, 1, E).contiguous(),
+                cov.expand(*shape, E, E).reshape(-1, 1, E, E).contiguous())
+        if int(st.item()) != 0:
+            raise np.linalg.LinAlgError('Matrix is not positive definite')  # np.linalg.cholesky
+        return as_result(out.reshape(*shape, N), like_torch)
+
+
 class GaussianTrainer:
     def fit(self, y, saliency=None, covariance_type='full'):
         """y (..., N, D) real, saliency (..., N) (:140-150)."""
         return self._fit(y, saliency=saliency, covariance_type=covariance_type)
 
     def _fit(self, y, saliency, covariance_type):
-        """(:152-193) for covariance_type='spherical'."""
-        if covariance_type != 'spherical':
-            if covariance_type in ('full', 'diagonal'):
+        """(:152-193) for covariance_type 'spherical' and 'full'."""
+        if covariance_type not in ('spherical', 'full'):
+            if covariance_type == 'diagonal':
                 raise NotImplementedError(
-                    f"covariance_type={covariance_type!r}: only 'spherical' runs on the device")
+                    "covariance_type='diagonal': 'spherical' and 'full' run on the device")
             raise ValueError(f"Unknown covariance type '{covariance_type}'.")
+        if covariance_type == 'full':
+            return self._fit_full(y, saliency)
         like_torch = _lib.is_torch(y)
         t = _lib.torch()
         y = _lib.to_device(y)
@@ -88,3 +144,25 @@ class GaussianTrainer:
                 sal.expand(*lead, N).reshape(-1, 1, N).contiguous())
         return SphericalGaussian(mean=as_result(mean.reshape(*lead, E), like_torch),
                                  covariance=as_result(cov.reshape(lead), like_torch))
+
+    def _fit_full(self, y, saliency):
+        like_torch = _lib.is_torch(y)
+        t = _lib.torch()
+        y = _lib.to_device(y)
+        assert not y.is_complex(), y.dtype
+        N, E = y.shape[-2:]
+        if saliency is None:
+            sal = t.ones(y.shape[:-1], dtype=t.float64, device=y.device)
+        else:
+            sal = _lib.to_device(saliency, t.float64).to(y.device)
+        lead = np.broadcast_shapes(tuple(y.shape[:-2]), tuple(sal.shape[:-1]))
+        K = int(np.prod(lead)) if lead else 1
+        if all(s == 1 for s in y.shape[:-2]):
+            mean, cov = engine.gauss_full_fit(y.reshape(1, N, E),
+                                              sal.expand(*lead, N).reshape(1, K, N).contiguous())
+        else:
+            mean, cov = engine.gauss_full_fit(
+                y.expand(*lead, N, E).reshape(-1, N, E).contiguous(),
+                sal.expand(*lead, N).reshape(-1, 1, N).contiguous())
+        return Gaussian(mean=as_result(mean.reshape(*lead, E), like_torch),
+                        covariance=as_result(cov.reshape(*lead, E, E), like_torch))

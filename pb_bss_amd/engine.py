@@ -522,6 +522,39 @@ def vmfmm_fit(y, K, *, gamma0=None, model=None, iterations=100, saliency=None, w
     return dict(mean=mean, concentration=conc, weight=weight, affiliation=aff, log_pdf=lp)
 
 
+def gauss_full_fit(y, weights):
+    """pbbss_gauss_full_fit.  y (B,N,E) real; weights (B,K,N) f64 -> (mean (B,K,E), cov (B,K,E,E))."""
+    t = _t()
+    y = _real_embedding(y)
+    B, N, E = y.shape
+    K = weights.shape[1]
+    assert weights.shape == (B, K, N) and weights.dtype == t.float64, (weights.shape, y.shape)
+    mean = t.empty((B, K, E), dtype=t.float64, device=y.device)
+    cov = t.empty((B, K, E, E), dtype=t.float64, device=y.device)
+    rc = _lib.load().pbbss_gauss_full_fit(
+        _lib.handle(y.device.index), _lib.ptr(y), int(y.dtype == t.float64), B, N, E, K,
+        _lib.ptr(weights), _lib.ptr(mean), _lib.ptr(cov), _lib.stream_ptr(y.device.index))
+    _lib.check(rc, f'gauss_full_fit(B={B},N={N},E={E},K={K})')
+    return mean, cov
+
+
+def gauss_full_log_pdf(y, mean, cov):
+    """pbbss_gauss_full_log_pdf.  y (B,N,E); mean (B,K,E); cov (B,K,E,E) -> ((B,K,N), status)."""
+    t = _t()
+    y = _real_embedding(y)
+    B, N, E = y.shape
+    K = mean.shape[1]
+    assert mean.shape == (B, K, E) and cov.shape == (B, K, E, E), (mean.shape, cov.shape)
+    out = t.empty((B, K, N), dtype=t.float64, device=y.device)
+    st = t.zeros((1,), dtype=t.int32, device=y.device)
+    rc = _lib.load().pbbss_gauss_full_log_pdf(
+        _lib.handle(y.device.index), _lib.ptr(y), int(y.dtype == t.float64), B, N, E, K,
+        _lib.ptr(mean), _lib.ptr(cov), _lib.ptr(out), _lib.ptr(st),
+        _lib.stream_ptr(y.device.index))
+    _lib.check(rc, f'gauss_full_log_pdf(B={B},N={N},E={E},K={K})')
+    return out, st
+
+
 def gmm_fit(y, K, *, gamma0=None, model=None, iterations=100, saliency=None, weight_mode=0,
             fixed_covariance=None, final_predict=False, want_log_pdf=False):
     """pbbss_gmm_fit (spherical covariances).  y (B,N,E) real, used as given (no row

@@ -45,8 +45,12 @@ def test_single_fits_and_log_pdf_match_reference(dtype):
     np.testing.assert_allclose(m.mean, g['spherical_mean'], atol=1e-13)
     np.testing.assert_allclose(m.covariance, g['spherical_covariance'], rtol=1e-11)
     np.testing.assert_allclose(m.log_pdf(y), g['spherical_log_pdf'], rtol=1e-10, atol=1e-9)
+    f = GaussianTrainer()._fit(y, saliency=sal, covariance_type='full')  # FP64 MFMA scatter
+    np.testing.assert_allclose(f.mean, g['full_mean'], atol=1e-12)
+    np.testing.assert_allclose(f.covariance, g['full_covariance'], atol=1e-12)
+    np.testing.assert_allclose(f.log_pdf(y), g['full_log_pdf'], rtol=1e-9, atol=1e-8)
     with pytest.raises(NotImplementedError):
-        GaussianTrainer()._fit(y, saliency=sal, covariance_type='full')
+        GaussianTrainer()._fit(y, saliency=sal, covariance_type='diagonal')
 
 
 def test_vmfmm_matches_reference_flat_and_independent_axes():
@@ -255,3 +259,38 @@ def test_gmm_shapes_against_oracle(F, N, E, K):
     i1 /= np.einsum('...kn->...n', i1)[..., None, :]
     o1 = oe.gmm_fit(y64, i1, 3)
     np.testing.assert_allclose(m1.gaussian.mean, o1['mean'], atol=1e-9)
+
+
+@pytest.mark.parametrize('N,E,K', [(20000, 40, 3), (333, 5, 2), (1000, 16, 6), (4100, 63, 1),
+                                   (70, 17, 4)])
+def test_gaussian_full_covariance_against_oracle(N, E, K):
+    """GaussianTrainer(covariance_type='full') / Gaussian.log_pdf on the matrix pipe against the
+    NumPy oracle (which is pinned to the reference by embed_single_fits): every tile count
+    (E + 1 <= 16, 32, 48, 64), ragged sample counts, float32 / float64 input, no saliency."""
+    from oracle import embed as oe
+    from pb_bss_amd.distribution import Gaussian, GaussianTrainer
+    rng = np.random.default_rng(N + E)
+    A = 0.6 * np.eye(E) + 0.4 * rng.normal(size=(E, E)) / np.sqrt(E)  # cond(cov) ~ 1e2
+    y32 = (rng.normal(size=(N, E)) @ A + rng.normal(size=E) * 3).astype(np.float32)
+    w = rng.uniform(size=(K, N)) ** 2
+    for y in (y32, y32.astype(np.float64)):
+        y64 = y.astype(np.float64)
+        m = GaussianTrainer().fit(y[None], saliency=w, covariance_type='full')
+        assert isinstance(m, Gaussian) and m.covariance.shape == (K, E, E)
+        om, oc = oe.gaussian_fit(y64[None], w, 'full')
+        scale = np.abs(oc).max()
+        np.testing.assert_allclose(m.mean, om, atol=1e-11)
+        np.testing.assert_allclose(m.covariance, oc, atol=1e-11 * scale)
+        assert (m.covariance == np.swapaxes(m.covariance, -1, -2)).all()
+        lp = m.log_pdf(y[None])
+        ref = oe.gaussian_log_pdf(y64[None], om, oc, 'full')
+        np.testing.assert_allclose(lp, ref, rtol=1e-9, atol=1e-7)  # cond(cov) * eps * |lp|
+        np.testing.assert_allclose(m.log_det_precision_cholesky,
+                                   np.sum(np.log(np.diagonal(np.swapaxes(np.linalg.inv(
+                                       np.linalg.cholesky(oc)), -1, -2), axis1=-2, axis2=-1)), -1),
+                                   rtol=1e-10)
+    m1 = GaussianTrainer().fit(y32, covariance_type='full')          # saliency None
+    o1 = oe.gaussian_fit(y32.astype(np.float64), None, 'full')
+    np.testing.assert_allclose(m1.covariance, o1[1], atol=1e-11 * np.abs(o1[1]).max())
+    with pytest.raises(np.linalg.LinAlgError):
+        Gaussian(mean=np.zeros(E), covariance=-np.eye(E)).log_pdf(y32)
