@@ -394,7 +394,7 @@ int pbbss_embed_fit(pbbss_handle_t h, const void* y, int y_is_f64, int64_t B,
 /* log_pdf: mean (B,K,E), covariance (B,K,E,E) -> out (B,K,N) f64, evaluated as    */
 /*      the reference writes it (precision Cholesky of sklearn applied as          */
 /*      P (y - mean), gaussian.py:46-50); out_status int32 (1) gets                */
-/*      PBBSS_ST_NOT_POSDEF where numpy.linalg.cholesky would raise.  K <= 64.     */
+/*      PBBSS_ST_NOT_POSDEF where the Cholesky factorisation fails.  K <= 64.       */
 /* ------------------------------------------------------------------------- */
 int pbbss_gauss_full_fit(pbbss_handle_t h, const void* y, int y_is_f64, int64_t B, int64_t N,
                          int E, int K, const double* weights, double* out_mean,
@@ -417,6 +417,19 @@ typedef struct pbbss_mix_opts {
   double affiliation_eps, eigenvalue_floor;
   double spatial_weight, spectral_weight;
 } pbbss_mix_opts;
+
+/* GMMTrainer.fit / fit_predict, GMM.predict (distribution/gmm.py:17-171) with               */
+/* covariance_type='full' (its default): arguments as pbbss_gmm_fit below, with              */
+/* in/out_covariance and fixed_covariance (B,K,E,E); E <= 63.  out_status int32 (1) gets     */
+/* PBBSS_ST_NOT_POSDEF if a class covariance stops being positive definite (the reference    */
+/* raises sklearn's ValueError from its precision Cholesky, gaussian.py:26).                  */
+int pbbss_gmm_full_fit(pbbss_handle_t h, const void* y, int64_t B, int64_t N, int E, int K,
+                       const double* gamma0, const double* in_mean,
+                       const double* in_covariance, const double* in_weight,
+                       const double* saliency, const double* fixed_covariance,
+                       const pbbss_mix_opts* opts, double* out_mean, double* out_covariance,
+                       double* out_weight, double* out_affiliation, double* out_log_pdf,
+                       int32_t* out_status, void* stream);
 
 /* N2  VMFMMTrainer.fit / fit_predict, VMFMM.predict  distribution/vmfmm.py:19-172. */
 /* y (B,N,E) real, raw (rows are unit-normalised here, vmfmm.py:76-78).           */

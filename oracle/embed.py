@@ -137,24 +137,25 @@ def gaussian_log_pdf(y, mean, covariance, covariance_type='spherical'):
 
 
 # ---------------------------------------------------------------- Gaussian mixture
-def gmm_predict(model, y):
-    """gmm.py:21-25 ('spherical')."""
-    lp = gaussian_log_pdf(y[..., None, :, :], model['mean'], model['covariance'])
+def gmm_predict(model, y, covariance_type='spherical'):
+    """gmm.py:21-25."""
+    lp = gaussian_log_pdf(y[..., None, :, :], model['mean'], model['covariance'], covariance_type)
     return oc.log_pdf_to_affiliation(model['weight'], lp)
 
 
 def gmm_fit(y, initialization, iterations=100, saliency=None, weight_constant_axis=(-1,),
-            fixed_covariance=None):
-    """GMMTrainer.fit, gmm.py:33-171, covariance_type='spherical', given initialization."""
+            fixed_covariance=None, covariance_type='spherical'):
+    """GMMTrainer.fit, gmm.py:33-171, given initialization ('spherical' or 'full')."""
     if saliency is None:
         saliency = np.ones_like(initialization[..., 0, :])  # :79-80
     aff = initialization
     model = None
     for _ in range(iterations):
         if model is not None:
-            aff = gmm_predict(model, y)  # :129-130
+            aff = gmm_predict(model, y, covariance_type)  # :129-130
         weight = oc.estimate_mixture_weight(aff, saliency, weight_constant_axis)  # :152-156
-        mean, cov = gaussian_fit(y[..., None, :, :], aff * saliency[..., None, :])  # :158-162
+        mean, cov = gaussian_fit(y[..., None, :, :], aff * saliency[..., None, :],
+                                 covariance_type)  # :158-162
         if fixed_covariance is not None:
             assert fixed_covariance.shape == cov.shape
             cov = fixed_covariance  # :164-171

@@ -276,6 +276,16 @@ def gmm_cases():
     out['fit_predict'] = GMMTrainer().fit_predict(flat, initialization=i0, iterations=3,
                                                   covariance_type='spherical')
     _save('gmm_variants_n450_e12_k3', **out)
+    # full covariances (the default covariance_type)
+    m = GMMTrainer().fit(flat, initialization=i0, iterations=6)
+    fixed_full = np.stack([np.eye(12) * v + 0.01 for v in (0.05, 0.2, 0.1)])
+    mf = GMMTrainer().fit(flat, initialization=i0, iterations=4, saliency=sal,
+                          fixed_covariance=fixed_full)
+    _save('gmm_full_n450_e12_k3', y=flat.astype(np.float32), init=i0, iterations=6,
+          mean=m.gaussian.mean, covariance=m.gaussian.covariance, weight=m.weight,
+          affiliation=m.predict(flat), saliency=sal, fixed=fixed_full,
+          fixed_mean=mf.gaussian.mean, fixed_weight=mf.weight, fixed_affiliation=mf.predict(flat),
+          fit_predict=GMMTrainer().fit_predict(flat, initialization=i0, iterations=3))
 
 
 def cwmm_cases():

@@ -49,6 +49,7 @@ EXPORTS = (
     'pbbss_set_dhtv_team', 'pbbss_stft_num_frames', 'pbbss_stft', 'pbbss_istft',
     'pbbss_pa_pairwise_mapping', 'pbbss_pa_compose_mapping', 'pbbss_pa_mapping_from_scores',
     'pbbss_gmm_fit', 'pbbss_gauss_full_fit', 'pbbss_gauss_full_log_pdf',
+    'pbbss_gmm_full_fit',
 )
 
 EMBED_VMF = 0
@@ -181,6 +182,8 @@ def load():
                                         vp, vp, vp]
         lib.pbbss_vmfmm_fit.argtypes = [vp, vp, i64, i64, i32, i32, vp, vp, vp, vp, vp,
                                         ctypes.POINTER(MixOpts), vp, vp, vp, vp, vp, vp]
+        lib.pbbss_gmm_full_fit.argtypes = [vp, vp, i64, i64, i32, i32, vp, vp, vp, vp, vp, vp,
+                                           ctypes.POINTER(MixOpts), vp, vp, vp, vp, vp, vp, vp]
         lib.pbbss_gauss_full_fit.argtypes = [vp, vp, i32, i64, i64, i32, i32, vp, vp, vp, vp]
         lib.pbbss_gauss_full_log_pdf.argtypes = [vp, vp, i32, i64, i64, i32, i32, vp, vp, vp, vp, vp]
         lib.pbbss_gmm_fit.argtypes = [vp, vp, i64, i64, i32, i32, vp, vp, vp, vp, vp, vp,

@@ -831,9 +831,9 @@ PBBSS_API int pbbss_gauss_full_fit(pbbss_handle_t h, const void* y, int y_is_f64
   void* w = handle_work(h, WorkCarver::pad(np * 8));
   if (!w) return PBBSS_ERR_HIP;
   TimedRegion tr(h, as_stream(stream));
-  return pbbss::launch_gauss_full_fit(y, y_is_f64, B, N, E, K, weights, static_cast<double*>(w),
-                                      out_mean, out_covariance, nullptr, nullptr, nullptr,
-                                      as_stream(stream));
+  return pbbss::launch_gauss_full_fit(y, y_is_f64, B, N, E, K, weights, nullptr,
+                                      static_cast<double*>(w), out_mean, out_covariance, nullptr,
+                                      nullptr, nullptr, nullptr, as_stream(stream));
 }
 
 PBBSS_API int pbbss_gauss_full_log_pdf(pbbss_handle_t h, const void* y, int y_is_f64, int64_t B,
@@ -856,6 +856,74 @@ PBBSS_API int pbbss_gauss_full_log_pdf(pbbss_handle_t h, const void* y, int y_is
   if (rc != PBBSS_OK) return rc;
   return pbbss::launch_gauss_full_logpdf(y, y_is_f64, B, N, E, K, mean, mq, off, nullptr,
                                          out_log_pdf, nullptr, s);
+}
+
+PBBSS_API int pbbss_gmm_full_fit(pbbss_handle_t h, const void* y, int64_t B, int64_t N, int E,
+                                 int K, const double* gamma0, const double* in_mean,
+                                 const double* in_covariance, const double* in_weight,
+                                 const double* saliency, const double* fixed_covariance,
+                                 const pbbss_mix_opts* o, double* out_mean,
+                                 double* out_covariance, double* out_weight,
+                                 double* out_affiliation, double* out_log_pdf,
+                                 int32_t* out_status, void* stream) {
+  DeviceGuard device_guard(h);
+  if (!h || !y || !o || !out_status || B <= 0 || N <= 0) return PBBSS_ERR_INVALID_ARG;
+  if (E < 1 || E > pbbss::kGaussFullMaxE || K < 1 || K > 64) return PBBSS_ERR_UNSUPPORTED;
+  if (o->iterations < 0 || o->weight_mode < 0 || o->weight_mode > 1) return PBBSS_ERR_INVALID_ARG;
+  const bool has_gamma = gamma0 != nullptr;
+  const bool has_model = in_mean && in_covariance && in_weight;
+  if (has_gamma == has_model) return PBBSS_ERR_INVALID_ARG;
+  if ((o->iterations == 0) != has_model) return PBBSS_ERR_INVALID_ARG;
+  if (!out_mean || !out_covariance || !out_weight) return PBBSS_ERR_INVALID_ARG;
+  hipStream_t s = as_stream(stream);
+  const size_t np = pbbss::gauss_full_partial_doubles(B, N, E, K);
+  const size_t nm = (size_t)B * K * E * E;
+  void* w = handle_work(h, WorkCarver::pad(np * 8) + WorkCarver::pad(nm * 8) +
+                               WorkCarver::pad((size_t)B * K * N * 8) +
+                               2 * WorkCarver::pad((size_t)B * K * 8));
+  if (!w) return PBBSS_ERR_HIP;
+  WorkCarver wc(w);
+  double* part = wc.take<double>(np);
+  double* mq = wc.take<double>(nm);
+  double* aff = wc.take<double>((size_t)B * K * N);
+  double* off = wc.take<double>((size_t)B * K);
+  double* s0 = wc.take<double>((size_t)B * K);
+  const int f64 = o->embedding_is_f64;
+  TimedRegion tr(h, s);
+  int rc;
+  if (has_model) {
+    if ((rc = copy_d2d(out_mean, in_mean, (size_t)B * K * E * 8, s)) != PBBSS_OK) return rc;
+    if ((rc = copy_d2d(out_covariance, in_covariance, nm * 8, s)) != PBBSS_OK) return rc;
+    if ((rc = copy_d2d(out_weight, in_weight, (size_t)B * K * 8, s)) != PBBSS_OK) return rc;
+    rc = pbbss::launch_gauss_full_factor(out_covariance, B * K, E, mq, off, out_status, s);
+    if (rc != PBBSS_OK) return rc;
+  }
+  for (int it = 0; it < o->iterations; ++it) {
+    const double* src = gamma0;
+    if (it > 0) {  // gmm.py:129-130
+      rc = pbbss::launch_gauss_full_logpdf(y, f64, B, N, E, K, out_mean, mq, off, out_weight,
+                                           nullptr, aff, s);
+      if (rc != PBBSS_OK) return rc;
+      src = aff;
+    }
+    rc = pbbss::launch_gauss_full_fit(y, f64, B, N, E, K, src, saliency, part, out_mean,
+                                      out_covariance, fixed_covariance ? nullptr : mq,
+                                      fixed_covariance ? nullptr : off, s0, out_status, s);
+    if (rc != PBBSS_OK) return rc;
+    rc = pbbss::launch_gauss_full_weights(s0, B, K, o->weight_mode, out_weight, s);
+    if (rc != PBBSS_OK) return rc;
+    if (fixed_covariance) {  // gmm.py:160-167
+      if ((rc = copy_d2d(out_covariance, fixed_covariance, nm * 8, s)) != PBBSS_OK) return rc;
+      rc = pbbss::launch_gauss_full_factor(out_covariance, B * K, E, mq, off, out_status, s);
+      if (rc != PBBSS_OK) return rc;
+    }
+  }
+  if (o->final_predict && (out_affiliation || out_log_pdf)) {
+    rc = pbbss::launch_gauss_full_logpdf(y, f64, B, N, E, K, out_mean, mq, off, out_weight,
+                                         out_log_pdf, out_affiliation, s);
+    if (rc != PBBSS_OK) return rc;
+  }
+  return PBBSS_OK;
 }
 
 // EM loop shared by the two real-embedding mixtures: kind = PBBSS_EMBED_VMF (rows unit-normalised

@@ -42,8 +42,8 @@ inline int gf_ok() { return hipGetLastError() == hipSuccess ? PBBSS_OK : PBBSS_E
 template <int NT, typename TS>
 __global__ void __launch_bounds__(kGfThreads)
     gf_scatter_kernel(const TS* __restrict__ y, int64_t N, int E, int K,
-                      const double* __restrict__ aff, int C, int64_t Lw,
-                      double* __restrict__ part) {
+                      const double* __restrict__ aff, const double* __restrict__ sal, int C,
+                      int64_t Lw, double* __restrict__ part) {
   constexpr int NTT = NT * (NT + 1) / 2;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -66,7 +66,8 @@ __global__ void __launch_bounds__(kGfThreads)
   for (int64_t n = n0 + smp; n < n1 + smp; n += 4) {  // the four lane groups stay together
     const bool ok = n < n1;
     const int64_t nc = ok ? n : n0;
-    const double w = ok ? wk[nc] : 0.0;
+    double w = ok ? wk[nc] : 0.0;
+    if (sal) w *= sal[(size_t)b * N + nc];  // affiliation * saliency (gmm.py:160)
     double v[NT], a[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -173,7 +174,8 @@ template <int NT, typename TS>
 __global__ void __launch_bounds__(kGfThreads)
     gf_finalize_kernel(const double* __restrict__ part, int NP, const TS* __restrict__ y, int64_t N,
                        int E, int K, double* __restrict__ out_mean, double* __restrict__ out_cov,
-                       double* out_mq, double* out_offset, int32_t* out_status) {
+                       double* out_mq, double* out_offset, double* out_s0,
+                       int32_t* out_status) {
   constexpr int NTT = NT * (NT + 1) / 2;
   constexpr int P = 16 * NT;
   extern __shared__ double sm[];
@@ -216,6 +218,7 @@ __global__ void __launch_bounds__(kGfThreads)
   const TS* yb = y + (size_t)b * N * E;
   const double s0 = G[E * (P + 1) + E];
   const double den = fmax(s0, kTiny);  // gaussian.py:160-163
+  if (out_s0 && tid == 0) out_s0[(size_t)b * K + k] = s0;
   double* mean = out_mean + ((size_t)b * K + k) * E;
   double* cov = out_cov + ((size_t)b * K + k) * (size_t)E * E;
   for (int d = tid; d < E; d += kGfThreads) mean[d] = (double)yb[d] + G[E * (P + 1) + d] / den;
@@ -329,6 +332,21 @@ __global__ void __launch_bounds__(kGfThreads)
   }
 }
 
+// estimate_mixture_weight with saliency (mixture_model_utils.py:192-201): L1 unit norm of the
+// masked affiliation sums over the classes, eps 'where' 1e-10; mode 1: uniform 1 / K
+__global__ void gf_weights_kernel(const double* s0, int64_t B, int K, int mode, double* out) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  if (mode == 1) {
+    for (int k = 0; k < K; ++k) out[b * K + k] = 1.0 / K;
+    return;
+  }
+  double t = 0.0;
+  for (int k = 0; k < K; ++k) t += fabs(s0[b * K + k]);
+  if (t == 0.0) t = 1e-10;
+  for (int k = 0; k < K; ++k) out[b * K + k] = s0[b * K + k] / t;
+}
+
 int gf_chunks(int64_t B, int K, int64_t N) {
   // ~1024 waves in flight in total, at least 64 samples per wave
   int64_t c = 256 / (B * K < 256 ? B * K : 256);
@@ -338,15 +356,16 @@ int gf_chunks(int64_t B, int K, int64_t N) {
 }
 
 template <int NT, typename TS>
-int gf_fit_go(const void* y, int64_t B, int64_t N, int E, int K, const double* w, double* part,
-              double* out_mean, double* out_cov, double* out_mq, double* out_offset,
-              int32_t* out_status, hipStream_t s) {
+int gf_fit_go(const void* y, int64_t B, int64_t N, int E, int K, const double* w,
+              const double* sal, double* part, double* out_mean, double* out_cov, double* out_mq,
+              double* out_offset, double* out_s0, int32_t* out_status, hipStream_t s) {
   constexpr int P = 16 * NT;
   const int C = gf_chunks(B, K, N);
   int64_t Lw = (N + (int64_t)C * kGfWaves - 1) / ((int64_t)C * kGfWaves);
   Lw = (Lw + 3) / 4 * 4;
   hipLaunchKernelGGL((gf_scatter_kernel<NT, TS>), dim3((unsigned)C, (unsigned)K, (unsigned)B),
-                     dim3(kGfThreads), 0, s, static_cast<const TS*>(y), N, E, K, w, C, Lw, part);
+                     dim3(kGfThreads), 0, s, static_cast<const TS*>(y), N, E, K, w, sal, C, Lw,
+                     part);
   size_t ldsd = (size_t)P * (P + 1);
   if (out_mq && 2 * (size_t)E * (E + 1) > ldsd) ldsd = 2 * (size_t)E * (E + 1);
   const size_t lds = ldsd * sizeof(double);
@@ -356,7 +375,7 @@ int gf_fit_go(const void* y, int64_t B, int64_t N, int E, int K, const double* w
     return PBBSS_ERR_HIP;
   hipLaunchKernelGGL(kfn, dim3((unsigned)K, (unsigned)B), dim3(kGfThreads), lds, s, part,
                      C * kGfWaves, static_cast<const TS*>(y), N, E, K, out_mean, out_cov, out_mq,
-                     out_offset, out_status);
+                     out_offset, out_s0, out_status);
   return gf_ok();
 }
 
@@ -393,12 +412,20 @@ size_t gauss_full_partial_doubles(int64_t B, int64_t N, int E, int K) {
   }
 
 int launch_gauss_full_fit(const void* y, int y_is_f64, int64_t B, int64_t N, int E, int K,
-                          const double* weights, double* part, double* out_mean, double* out_cov,
-                          double* out_mq, double* out_offset, int32_t* out_status, hipStream_t s) {
+                          const double* weights, const double* sal, double* part,
+                          double* out_mean, double* out_cov, double* out_mq, double* out_offset,
+                          double* out_s0, int32_t* out_status, hipStream_t s) {
   if (E < 1 || E > kGaussFullMaxE || K < 1 || B < 1 || B > 65535 || K > 65535)
     return PBBSS_ERR_UNSUPPORTED;
-  PBBSS_GF_DISPATCH(gf_fit_go, y, B, N, E, K, weights, part, out_mean, out_cov, out_mq,
-                    out_offset, out_status, s)
+  PBBSS_GF_DISPATCH(gf_fit_go, y, B, N, E, K, weights, sal, part, out_mean, out_cov, out_mq,
+                    out_offset, out_s0, out_status, s)
+}
+
+int launch_gauss_full_weights(const double* s0, int64_t B, int K, int mode, double* out_weight,
+                              hipStream_t s) {
+  hipLaunchKernelGGL(gf_weights_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s, s0, B, K,
+                     mode, out_weight);
+  return gf_ok();
 }
 
 int launch_gauss_full_factor(const double* cov, int64_t BK, int E, double* out_mq,

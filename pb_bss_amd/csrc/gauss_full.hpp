@@ -15,9 +15,15 @@ size_t gauss_full_partial_doubles(int64_t B, int64_t N, int E, int K);
 // weights (B,K,N) -> out_mean (B,K,E), out_cov (B,K,E,E); with out_mq / out_offset non-null also
 // the factorisation the log-pdf needs (Mq = X X^T, X = L^-1; offset = -E/2 ln 2pi - sum ln L_dd)
 // and PBBSS_ST_NOT_POSDEF or-ed into *out_status where a covariance is not positive definite.
+// sal (B,N) or null multiplies the weights (affiliation * saliency); out_s0 (B,K) or null
+// receives the weight sums (for the mixture weights).
 int launch_gauss_full_fit(const void* y, int y_is_f64, int64_t B, int64_t N, int E, int K,
-                          const double* weights, double* part, double* out_mean, double* out_cov,
-                          double* out_mq, double* out_offset, int32_t* out_status, hipStream_t s);
+                          const double* weights, const double* sal, double* part,
+                          double* out_mean, double* out_cov, double* out_mq, double* out_offset,
+                          double* out_s0, int32_t* out_status, hipStream_t s);
+// mixture weights from the weight sums: mode 0 L1-normalised over the classes, 1 uniform
+int launch_gauss_full_weights(const double* s0, int64_t B, int K, int mode, double* out_weight,
+                              hipStream_t s);
 // the same factorisation for given covariances (BK matrices)
 int launch_gauss_full_factor(const double* cov, int64_t BK, int E, double* out_mq,
                              double* out_offset, int32_t* out_status, hipStream_t s);

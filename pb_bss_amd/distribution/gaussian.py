@@ -106,7 +106,9 @@ class Gaussian(_ProbabilisticModel):
                 mean.expand(*shape, E).reshape(-1, 1, E).contiguous(),
                 cov.expand(*shape, E, E).reshape(-1, 1, E, E).contiguous())
         if int(st.item()) != 0:
-            raise np.linalg.LinAlgError('Matrix is not positive definite')  # np.linalg.cholesky
+            raise ValueError(  # sklearn's _compute_precision_cholesky (gaussian.py:26)
+                'Fitting the mixture model failed because some components have ill-defined empirical '
+                'covariance (not positive definite)')
         return as_result(out.reshape(*shape, N), like_torch)
 
 

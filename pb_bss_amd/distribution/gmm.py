@@ -1,12 +1,12 @@
 """Gaussian mixture model on real embeddings on the HIP embedding kernels.
 Mirrors pb_bss/distribution/gmm.py:16-171: `GMM` (weight, gaussian; predict) and
-`GMMTrainer` (fit / fit_predict) for covariance_type='spherical' -- the covariance
-model the joint GCACGMM uses (gcacgmm.py:141).  'full' / 'diagonal' covariances are
-not on the device path (NotImplementedError); BinaryGMM wraps sklearn's KMeans and
-is out of scope.
+`GMMTrainer` (fit / fit_predict) for covariance_type 'full' (the reference's default;
+FP64 matrix-pipe kernels of csrc/gauss_full.hip, D <= 63) and 'spherical' (the covariance
+model the joint GCACGMM uses, gcacgmm.py:141; the vMF mixture's E-step / M-step kernels on the
+raw embedding).  'diagonal' is not on the device path (NotImplementedError); BinaryGMM wraps
+sklearn's KMeans and is out of scope.
 
-The whole EM loop is one C-ABI call (`pbbss_gmm_fit`): the same E-step / M-step
-kernels as the vMF mixture, on the raw (not row-normalised) embedding.
+The whole EM loop is one C-ABI call (`pbbss_gmm_full_fit` / `pbbss_gmm_fit`).
 """
 from dataclasses import dataclass
 from operator import xor
@@ -14,7 +14,7 @@ from operator import xor
 import numpy as np
 
 from .. import _lib, engine
-from .gaussian import SphericalGaussian
+from .gaussian import Gaussian, SphericalGaussian
 from .utils import _ProbabilisticModel, as_result
 
 __all__ = ['GMM', 'GMMTrainer']
@@ -47,18 +47,18 @@ def _weight_kind(weight_constant_axis, ndim):
 
 
 def _check_covariance_type(covariance_type):
-    if covariance_type == 'spherical':
+    if covariance_type in ('spherical', 'full'):
         return
-    if covariance_type in ('full', 'diagonal'):
+    if covariance_type == 'diagonal':
         raise NotImplementedError(
-            f"covariance_type={covariance_type!r}: only 'spherical' runs on the device")
+            "covariance_type='diagonal': 'full' and 'spherical' run on the device")
     raise ValueError(f"Unknown covariance type '{covariance_type}'.")
 
 
 @dataclass
 class GMM(_ProbabilisticModel):
     weight: np.ndarray = None  # (..., K, 1)
-    gaussian: SphericalGaussian = None
+    gaussian: object = None  # Gaussian (full covariance) or SphericalGaussian
 
     def predict(self, x):
         """x (..., N, D) real -> affiliations (..., K, N) (:21-25)."""
@@ -70,6 +70,7 @@ class GMM(_ProbabilisticModel):
         mean = _lib.to_device(self.gaussian.mean, t.float64).to(x.device)
         K = mean.shape[-2]
         cov = _lib.to_device(self.gaussian.covariance, t.float64).to(x.device)
+        full = isinstance(self.gaussian, Gaussian)
         w = _lib.to_device(self.weight, t.float64).to(x.device)
         if w.shape[-1] != 1:
             # (..., 1, N): constant over the classes (weight_constant_axis=(-2,)), cancels in
@@ -77,11 +78,20 @@ class GMM(_ProbabilisticModel):
             if w.shape[-2] != 1:
                 raise NotImplementedError(f'frame-dependent class weights {tuple(w.shape)}')
             w = t.full((K, 1), 1.0 / K, dtype=t.float64, device=x.device)
+        cshape = (E, E) if full else ()
         model = (mean.expand(*indep, K, E).reshape(-1, K, E).contiguous(),
-                 cov.expand(*indep, K).reshape(-1, K).contiguous(),
+                 cov.expand(*indep, K, *cshape).reshape(-1, K, *cshape).contiguous(),
                  w.expand(*indep, K, 1).reshape(-1, K).contiguous())
-        r = engine.gmm_fit(x.reshape(-1, N, E), K, model=model, iterations=0,
-                           final_predict=True)
+        if full:
+            r = engine.gmm_full_fit(x.reshape(-1, N, E), K, model=model, iterations=0,
+                                    final_predict=True)
+            if int(r['status'].item()) != 0:
+                raise ValueError(  # sklearn's _compute_precision_cholesky (gaussian.py:26)
+                    'Fitting the mixture model failed because some components have ill-defined empirical '
+                'covariance (not positive definite)')
+        else:
+            r = engine.gmm_fit(x.reshape(-1, N, E), K, model=model, iterations=0,
+                               final_predict=True)
         return as_result(r['affiliation'].reshape(*indep, K, N), like_torch)
 
 
@@ -124,28 +134,35 @@ class GMMTrainer:
             if kind == _ONES and not bool((sal > 0).all().item()):
                 raise NotImplementedError(
                     'weight_constant_axis=(-2,) with zero saliency entries (zero weights)')
+        full = covariance_type == 'full'
+        cshape = (E, E) if full else ()
         fixed = None
         if fixed_covariance is not None:
             fixed = _lib.to_device(fixed_covariance, t.float64).to(y.device)
-            assert tuple(fixed.shape) == (*indep, K), (
-                f'{tuple(fixed.shape)} != {(*indep, K)}')  # :161-163
-            fixed = fixed.reshape(-1, K).contiguous()
+            assert tuple(fixed.shape) == (*indep, K, *cshape), (
+                f'{tuple(fixed.shape)} != {(*indep, K, *cshape)}')  # :161-163
+            fixed = fixed.reshape(-1, K, *cshape).contiguous()
         if iterations <= 0:
             return None  # the reference's loop body never runs (:127-141)
-        r = engine.gmm_fit(y.reshape(-1, N, E), K, gamma0=gamma0.reshape(-1, K, N).contiguous(),
-                           iterations=iterations, saliency=sal, weight_mode=mode,
-                           fixed_covariance=fixed)
+        fit = engine.gmm_full_fit if full else engine.gmm_fit
+        r = fit(y.reshape(-1, N, E), K, gamma0=gamma0.reshape(-1, K, N).contiguous(),
+                iterations=iterations, saliency=sal, weight_mode=mode, fixed_covariance=fixed)
+        if full and int(r['status'].item()) != 0:
+            raise ValueError(  # sklearn's _compute_precision_cholesky (gaussian.py:26)
+                'Fitting the mixture model failed because some components have ill-defined empirical '
+                'covariance (not positive definite)')
         if kind == _UNIFORM:
             weight = t.full((K, 1), 1.0 / K, dtype=t.float64, device=y.device)
         elif kind == _ONES:
             weight = t.ones((*indep, 1, N), dtype=t.float64, device=y.device)
         else:
             weight = r['weight'].reshape(*indep, K, 1)
+        cls = Gaussian if full else SphericalGaussian
         return GMM(
             weight=as_result(weight, like_torch),
-            gaussian=SphericalGaussian(
+            gaussian=cls(
                 mean=as_result(r['mean'].reshape(*indep, K, E), like_torch),
-                covariance=as_result(r['covariance'].reshape(*indep, K), like_torch)))
+                covariance=as_result(r['covariance'].reshape(*indep, K, *cshape), like_torch)))
 
     def fit_predict(self, y, initialization=None, num_classes=None, iterations=100, *,
                     saliency=None, weight_constant_axis=(-2,), covariance_type='full',

@@ -590,6 +590,41 @@ def gmm_fit(y, K, *, gamma0=None, model=None, iterations=100, saliency=None, wei
     return dict(mean=mean, covariance=cov, weight=weight, affiliation=aff, log_pdf=lp)
 
 
+def gmm_full_fit(y, K, *, gamma0=None, model=None, iterations=100, saliency=None, weight_mode=0,
+                 fixed_covariance=None, final_predict=False, want_log_pdf=False):
+    """pbbss_gmm_full_fit (full covariances, E <= 63).  As gmm_fit with covariance (B,K,E,E).
+    Returns the status word too (non-zero: a covariance was not positive definite)."""
+    t = _t()
+    y = _real_embedding(y)
+    dev = y.device
+    B, N, E = y.shape
+    f64 = t.float64
+    opts = _lib.MixOpts(iterations=int(iterations), kind=_lib.EMBED_GAUSS_SPHERICAL,
+                        weight_mode=int(weight_mode), embedding_is_f64=int(y.dtype == f64),
+                        final_predict=int(bool(final_predict or want_log_pdf)))
+    mean = t.empty((B, K, E), dtype=f64, device=dev)
+    cov = t.empty((B, K, E, E), dtype=f64, device=dev)
+    weight = t.empty((B, K), dtype=f64, device=dev)
+    aff = t.empty((B, K, N), dtype=f64, device=dev) if final_predict else None
+    lp = t.empty((B, K, N), dtype=f64, device=dev) if want_log_pdf else None
+    st = t.zeros((1,), dtype=t.int32, device=dev)
+    in_mean = in_cov = in_w = None
+    if model is not None:
+        in_mean, in_cov, in_w = model
+        assert in_mean.shape == (B, K, E) and in_cov.shape == (B, K, E, E) and in_w.shape == (B, K)
+    else:
+        assert gamma0.shape == (B, K, N) and gamma0.dtype == f64
+    if fixed_covariance is not None:
+        assert fixed_covariance.shape == (B, K, E, E) and fixed_covariance.dtype == f64
+    rc = _lib.load().pbbss_gmm_full_fit(
+        _lib.handle(dev.index), _lib.ptr(y), B, N, E, K, _lib.ptr(gamma0), _lib.ptr(in_mean),
+        _lib.ptr(in_cov), _lib.ptr(in_w), _lib.ptr(saliency), _lib.ptr(fixed_covariance),
+        ctypes.byref(opts), _lib.ptr(mean), _lib.ptr(cov), _lib.ptr(weight), _lib.ptr(aff),
+        _lib.ptr(lp), _lib.ptr(st), _lib.stream_ptr(dev.index))
+    _lib.check(rc, f'gmm_full_fit(B={B},N={N},E={E},K={K})')
+    return dict(mean=mean, covariance=cov, weight=weight, affiliation=aff, log_pdf=lp, status=st)
+
+
 def joint_weight_shape(weight_mode, F, K, T):
     return {_lib.JOINT_WEIGHT_FK: (F, K), _lib.JOINT_WEIGHT_UNIFORM: (), _lib.JOINT_WEIGHT_K: (K,),
             _lib.JOINT_WEIGHT_KT: (K, T), _lib.JOINT_WEIGHT_CONST: ()}[weight_mode]

@@ -217,7 +217,7 @@ def test_gmm_matches_reference():
     assert m.weight.shape == (1, 450) and (m.weight == 1).all()
     np.testing.assert_allclose(m.predict(y), g['fit_predict'], atol=1e-9)
     with pytest.raises(NotImplementedError):
-        GMMTrainer().fit(y, initialization=g['init'], iterations=2)  # default 'full'
+        GMMTrainer().fit(y, initialization=g['init'], iterations=2, covariance_type='diagonal')
     with pytest.raises(ValueError):
         GMMTrainer().fit(y, initialization=g['init'], iterations=2, covariance_type='round')
     with pytest.raises(AssertionError):
@@ -292,5 +292,54 @@ def test_gaussian_full_covariance_against_oracle(N, E, K):
     m1 = GaussianTrainer().fit(y32, covariance_type='full')          # saliency None
     o1 = oe.gaussian_fit(y32.astype(np.float64), None, 'full')
     np.testing.assert_allclose(m1.covariance, o1[1], atol=1e-11 * np.abs(o1[1]).max())
-    with pytest.raises(np.linalg.LinAlgError):
+    with pytest.raises(ValueError, match='ill-defined'):  # sklearn's error in the reference
         Gaussian(mean=np.zeros(E), covariance=-np.eye(E)).log_pdf(y32)
+
+
+def test_gmm_full_covariance_matches_reference_and_oracle():
+    """GMMTrainer with its default covariance_type='full' (FP64 matrix-pipe kernels) against the
+    fixture of the real reference, and a larger batched problem against the NumPy oracle."""
+    from oracle import embed as oe
+    from pb_bss_amd.distribution import GMM, GMMTrainer, Gaussian
+    g = load('gmm_full_n450_e12_k3')
+    for dtype in (np.float32, np.float64):
+        y = g['y'].astype(dtype)
+        m = GMMTrainer().fit(y, initialization=g['init'], iterations=int(g['iterations']))
+        assert isinstance(m, GMM) and isinstance(m.gaussian, Gaussian)
+        assert m.gaussian.covariance.shape == (3, 12, 12) and m.weight.shape == (3, 1)
+        np.testing.assert_allclose(m.gaussian.mean, g['mean'], atol=1e-9)
+        np.testing.assert_allclose(m.gaussian.covariance, g['covariance'], atol=1e-9)
+        np.testing.assert_allclose(m.weight, g['weight'], atol=1e-9)
+        np.testing.assert_allclose(m.predict(y), g['affiliation'], atol=1e-7)
+    y = g['y'].astype(np.float64)
+    m = GMMTrainer().fit(y, initialization=g['init'], iterations=4, saliency=g['saliency'],
+                         fixed_covariance=g['fixed'])
+    np.testing.assert_allclose(m.gaussian.mean, g['fixed_mean'], atol=1e-9)
+    np.testing.assert_allclose(m.weight, g['fixed_weight'], atol=1e-9)
+    assert (m.gaussian.covariance == g['fixed']).all()
+    np.testing.assert_allclose(m.predict(y), g['fixed_affiliation'], atol=1e-7)
+    np.testing.assert_allclose(
+        GMMTrainer().fit_predict(y, initialization=g['init'], iterations=3), g['fit_predict'],
+        atol=1e-7)
+    # batch of mixtures, config-5-sized embedding dimension
+    rng = np.random.default_rng(8)
+    F, N, E, K = 3, 6000, 40, 3
+    centers = rng.normal(size=(F, K, E)) * 1.5
+    lab = rng.integers(K, size=(F, N))
+    yb = (np.take_along_axis(centers, lab[..., None], 1) + rng.normal(size=(F, N, E))).astype(np.float32)
+    init = rng.uniform(size=(F, K, N))
+    init /= init.sum(-2, keepdims=True)
+    yb64 = yb.astype(np.float64)
+    o = oe.gmm_fit(yb64, init, 5, covariance_type='full')
+    mb = GMMTrainer().fit(yb, initialization=init, iterations=5)
+    np.testing.assert_allclose(mb.gaussian.mean, o['mean'], atol=1e-8)
+    np.testing.assert_allclose(mb.gaussian.covariance, o['covariance'], atol=1e-8)
+    np.testing.assert_allclose(mb.weight, o['weight'], atol=1e-9)
+    np.testing.assert_allclose(mb.predict(yb), oe.gmm_predict(o, yb64, 'full'), atol=1e-6)
+    # a class that collapses onto a single point has a singular covariance: ValueError like
+    # sklearn's precision Cholesky in the reference
+    bad = np.zeros((2, 50))
+    bad[0, 0] = 1.0
+    bad[1, 1:] = 1.0
+    with pytest.raises(ValueError, match='ill-defined'):
+        GMMTrainer().fit(yb[0, :50], initialization=bad, iterations=2)
