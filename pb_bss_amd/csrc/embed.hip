@@ -153,9 +153,15 @@ __global__ void __launch_bounds__(kThreads)
   }
   constexpr int U = 8;  // loads in flight per lane (16 measured: no gain)
   for (int d0 = 0; d0 < E; d0 += U) {
+    // unconditional loads at clamped rows, masked afterwards: a guarded load whose value is
+    // converted inside the guard compiles to branch + load + s_waitcnt vmcnt(0) -- the eight
+    // "loads in flight" were eight serial memory round trips
+    TS raw[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) raw[u] = col[(size_t)((d0 + u < E) ? d0 + u : E - 1) * N];
     double v[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) v[u] = (d0 + u < E) ? (double)col[(size_t)(d0 + u) * N] : 0.0;
+    for (int u = 0; u < U; ++u) v[u] = (d0 + u < E) ? (double)raw[u] : 0.0;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if (d0 + u < E) {

@@ -63,29 +63,63 @@ __global__ void __launch_bounds__(kGfThreads)
   for (int x = 0; x < NTT; ++x) acc[x] = double4_t{0.0, 0.0, 0.0, 0.0};
   const int64_t n0 = ((int64_t)c * kGfWaves + wave) * Lw;
   const int64_t n1 = (n0 + Lw < N) ? n0 + Lw : N;
-  for (int64_t n = n0 + smp; n < n1 + smp; n += 4) {  // the four lane groups stay together
-    const bool ok = n < n1;
-    const int64_t nc = ok ? n : n0;
-    double w = ok ? wk[nc] : 0.0;
-    if (sal) w *= sal[(size_t)b * N + nc];  // affiliation * saliency (gmm.py:160)
-    double v[NT], a[NT];
+  // U groups of four samples per trip.  Software-pipelined: the loads of trip t + 1 are issued
+  // before the tiles of trip t (one wave per SIMD: nothing else hides the HBM round trip; a
+  // load-then-compute loop ran at 6 TFLOP/s of tiles, with all loads of a trip up front 13).
+  constexpr int U = 4;
+  // Loads are UNCONDITIONAL at clamped addresses and land in raw registers; masks and
+  // arithmetic are applied when the values are consumed.  (A guarded load whose value is
+  // converted inside the guard compiles to branch + load + s_waitcnt vmcnt(0): one full memory
+  // round trip per element.)
+  const double* salb = sal ? sal + (size_t)b * N : wk;  // dummy pointer keeps the load uniform
+  const double salmask = sal ? 1.0 : 0.0;
+  int dimc[NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const int dim = 16 * t + i;
-      double z = 0.0;
-      if (dim < E) z = (double)yb[(size_t)nc * E + dim] - shift[t];
-      if (dim == E) z = 1.0;
-      v[t] = ok ? z : 0.0;
-      a[t] = w * v[t];
+  for (int t = 0; t < NT; ++t) dimc[t] = (16 * t + i < E) ? 16 * t + i : 0;
+  double wn[U], sn[U];
+  TS rn[U][NT];
+  auto fetch = [&](int64_t nb) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t n = nb + 4 * u + smp;
+      const int64_t nc = (n < n1) ? n : n0;
+      wn[u] = wk[nc];
+      sn[u] = salb[nc];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) rn[u][t] = yb[(size_t)nc * E + dimc[t]];
     }
-    int x = 0;
+  };
+  if (n0 < n1) fetch(n0);
+  for (int64_t nb = n0; nb < n1; nb += 4 * U) {  // the four lane groups stay together
+    double w[U], v[U][NT];
 #pragma unroll
-    for (int ti = 0; ti < NT; ++ti)
+    for (int u = 0; u < U; ++u) {
+      const bool ok = nb + 4 * u + smp < n1;
+      // affiliation * saliency (gmm.py:160); without saliency the factor is exactly 1
+      const double sv = salmask * sn[u] + (1.0 - salmask);
+      w[u] = ok ? wn[u] * sv : 0.0;
 #pragma unroll
-      for (int tj = ti; tj < NT; ++tj) {
-        acc[x] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ti], v[tj], acc[x], 0, 0, 0);
-        ++x;
+      for (int t = 0; t < NT; ++t) {
+        const int dim = 16 * t + i;
+        double z = (double)rn[u][t] - shift[t];
+        z = (dim < E) ? z : ((dim == E) ? 1.0 : 0.0);
+        v[u][t] = ok ? z : 0.0;
       }
+    }
+    if (nb + 4 * U < n1) fetch(nb + 4 * U);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int x = 0;
+#pragma unroll
+      for (int ti = 0; ti < NT; ++ti) {
+        const double a = w[u] * v[u][ti];
+#pragma unroll
+        for (int tj = ti; tj < NT; ++tj) {
+          acc[x] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, v[u][tj], acc[x], 0, 0, 0);
+          ++x;
+        }
+      }
+    }
   }
   double* dst = part + ((((size_t)b * K + k) * C + c) * kGfWaves + wave) * (size_t)NTT * 256;
 #pragma unroll
@@ -95,41 +129,84 @@ __global__ void __launch_bounds__(kGfThreads)
 }
 
 // ------------------------------------------------------------------ small dense helpers (LDS)
-// In-place lower Cholesky of the E x E matrix a (row stride ld).  Returns 0 or 1 + the index of
-// the first non-positive pivot (LAPACK dpotrf INFO), uniform over the workgroup.
+// In-place lower Cholesky of the E x E matrix a (row stride ld; only the lower triangle is
+// read).  Returns 0 or 1 + the index of the first non-positive pivot (LAPACK dpotrf INFO),
+// uniform over the workgroup.
+// Right-looking with the trailing matrix in REGISTERS: thread t owns the lower-triangle
+// elements t, t + 256, ... (row-major), LDS only carries the pivot columns -- element (r, c)
+// is published when its column becomes the next pivot column -- so a step is two independent
+// LDS reads per owned element and ONE barrier (an in-place LDS update was three barriers and
+// a chain of read-modify-writes per step: 85 us for E = 40).
 __device__ int gf_cholesky(double* a, int E, int ld, int tid, int* info_sm) {
+  constexpr int Q = (64 * 65 / 2 + kGfThreads - 1) / kGfThreads;  // E <= 64
+  const int ntri = E * (E + 1) / 2;
+  int er[Q], ec[Q];
+  double val[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    const int idx = tid + q * kGfThreads;
+    int r = (int)((sqrt(8.0 * idx + 1.0) - 1.0) * 0.5);
+    while (r * (r + 1) / 2 > idx) --r;
+    while ((r + 1) * (r + 2) / 2 <= idx) ++r;
+    er[q] = (idx < ntri) ? r : -1;
+    ec[q] = idx - r * (r + 1) / 2;
+    val[q] = (idx < ntri) ? a[r * ld + ec[q]] : 0.0;
+  }
   if (tid == 0) *info_sm = 0;
-  __syncthreads();
+  __syncthreads();  // everyone holds its elements; column 0 of `a` is the first pivot column
   for (int j = 0; j < E; ++j) {
-    if (tid == 0) {
-      const double d = a[j * ld + j];
-      if (!(d > 0.0) || !(d < 1.79e308)) {
-        if (*info_sm == 0) *info_sm = j + 1;
-        a[j * ld + j] = 1.0;
-      } else {
-        a[j * ld + j] = sqrt(d);
+    double d = a[j * ld + j];
+    if (!(d > 0.0) || !(d < 1.79e308)) {
+      if (tid == 0 && *info_sm == 0) *info_sm = j + 1;
+      d = 1.0;
+    }
+    const double inv_d = 1.0 / d;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      if (er[q] >= 0 && ec[q] > j) {
+        val[q] = fma(-(a[er[q] * ld + j] * inv_d), a[ec[q] * ld + j], val[q]);
+        if (ec[q] == j + 1) a[er[q] * ld + j + 1] = val[q];  // next pivot column
       }
     }
     __syncthreads();
-    const double piv = a[j * ld + j];
-    for (int r = j + 1 + tid; r < E; r += kGfThreads) a[r * ld + j] /= piv;
-    __syncthreads();
-    const int m = E - j - 1;  // trailing update of the lower triangle
-    for (int idx = tid; idx < m * m; idx += kGfThreads) {
-      const int r = j + 1 + idx / m, cc = j + 1 + idx % m;
-      if (cc <= r) a[r * ld + cc] -= a[r * ld + j] * a[cc * ld + j];
-    }
-    __syncthreads();
   }
+  // scale the pivot columns: L_rj = a_rj / sqrt(a_jj), L_jj = sqrt(a_jj)
+  double out[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    out[q] = 0.0;
+    if (er[q] >= 0) {
+      const double dj = a[ec[q] * ld + ec[q]];
+      const double piv = sqrt((dj > 0.0 && dj < 1.79e308) ? dj : 1.0);
+      out[q] = (er[q] == ec[q]) ? piv : a[er[q] * ld + ec[q]] / piv;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < Q; ++q)
+    if (er[q] >= 0) a[er[q] * ld + ec[q]] = out[q];
+  __syncthreads();
   return *info_sm;
 }
 
-// x = L^-1 (lower), one thread per column, forward substitution
+// x = L^-1 (lower), one thread per column, forward substitution.  The inner products are taken
+// in chunks of eight INDEPENDENT operand pairs (clamped indices, masked products): a plain
+// m-loop is a chain of LDS round trips (~60 us for E = 40).
 __device__ void gf_tri_inverse(const double* l, double* x, int E, int ld, int tid) {
   for (int cidx = tid; cidx < E; cidx += kGfThreads) {
     for (int r = 0; r < E; ++r) {
       double s = (r == cidx) ? 1.0 : 0.0;
-      for (int m = cidx; m < r; ++m) s -= l[r * ld + m] * x[m * ld + cidx];
+      for (int m0 = cidx; m0 < r; m0 += 8) {
+        double lv[8], xv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int m = (m0 + u < r) ? m0 + u : cidx;
+          lv[u] = l[r * ld + m];
+          xv[u] = x[m * ld + cidx];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s -= (m0 + u < r) ? lv[u] * xv[u] : 0.0;
+      }
       x[r * ld + cidx] = (r < cidx) ? 0.0 : s / l[r * ld + r];
     }
   }
@@ -155,24 +232,59 @@ __device__ int gf_factor(const double* cov, int E, double* lds, int* info_sm, do
     const int r = idx / E, cc = idx % E;
     double s = 0.0;
     const int m1 = (r < cc) ? r : cc;  // X is lower triangular: X_rm = 0 for m > r
-    for (int m = 0; m <= m1; ++m) s += x[r * ld + m] * x[cc * ld + m];
+    for (int m0 = 0; m0 <= m1; m0 += 8) {
+      double av[8], bv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int m = (m0 + u <= m1) ? m0 + u : 0;
+        av[u] = x[r * ld + m];
+        bv[u] = x[cc * ld + m];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += (m0 + u <= m1) ? av[u] * bv[u] : 0.0;
+    }
     out_mq[(size_t)r * E + cc] = s;
   }
-  if (tid == 0) {
-    double sl = 0.0;
-    for (int d = 0; d < E; ++d) sl += log(l[d * ld + d]);
-    *out_offset = -0.5 * E * kLn2PiGf - sl;  // sum_d ln P_dd = -sum_d ln L_dd
+  if (tid < kWave) {  // E <= 63: one wavefront sums the log-pivots
+    double sl = (tid < E) ? log(l[tid * ld + tid]) : 0.0;
+    sl = wave_sum(sl);
+    if (tid == 0) *out_offset = -0.5 * E * kLn2PiGf - sl;  // sum_d ln P_dd = -sum_d ln L_dd
   }
   __syncthreads();
   return info;
 }
 
 // ------------------------------------------------------------------ finalize
-// One workgroup per (b, k): ordered sum of the NP wave partials (slot-parallel like the other
-// finalize kernels), G -> mean, covariance (gaussian.py:155-190), optionally the factorisation.
+// Stage 1, grid (tile, K, B): ordered sum of the NP wave partials of one tile, one element per
+// thread, eight loads in flight.  (One workgroup per class walking all partials of all tiles
+// was a 250 us chain of L2 round trips.)
+__global__ void __launch_bounds__(kGfThreads)
+    gf_reduce_kernel(const double* __restrict__ part, int NP, int NTT, int K,
+                     double* __restrict__ gsum) {
+  const int x = blockIdx.x, k = blockIdx.y;
+  const int64_t b = blockIdx.z;
+  const int e = threadIdx.x;
+  const double* p = part + (((size_t)b * K + k) * NP) * (size_t)NTT * 256 + (size_t)x * 256 + e;
+  const size_t stride = (size_t)NTT * 256;
+  double t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int q = 0;
+  for (; q + 7 < NP; q += 8) {
+    double a[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] = p[(size_t)(q + u) * stride];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] += a[u];
+  }
+  for (; q < NP; ++q) t[0] += p[(size_t)q * stride];
+  gsum[(((size_t)b * K + k) * NTT + x) * 256 + e] =
+      ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+}
+
+// Stage 2, one workgroup per (b, k): G -> mean, covariance (gaussian.py:155-190), optionally the
+// factorisation.
 template <int NT, typename TS>
 __global__ void __launch_bounds__(kGfThreads)
-    gf_finalize_kernel(const double* __restrict__ part, int NP, const TS* __restrict__ y, int64_t N,
+    gf_finalize_kernel(const double* __restrict__ gsum, const TS* __restrict__ y, int64_t N,
                        int E, int K, double* __restrict__ out_mean, double* __restrict__ out_cov,
                        double* out_mq, double* out_offset, double* out_s0,
                        int32_t* out_status) {
@@ -181,24 +293,13 @@ __global__ void __launch_bounds__(kGfThreads)
   extern __shared__ double sm[];
   double* G = sm;  // [P][P + 1]
   __shared__ int info_sm;
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = threadIdx.x;
   const int k = blockIdx.x;
   const int64_t b = blockIdx.y;
-  const double* pb = part + (((size_t)b * K + k) * NP) * (size_t)NTT * 256;
+  const double* pb = gsum + ((size_t)b * K + k) * (size_t)NTT * 256;
   // element e of a tile: e = r * 64 + l  ->  row 4 r + l / 16, column l % 16
   for (int idx = tid; idx < NTT * 256; idx += kGfThreads) {
-    double t[4] = {0.0, 0.0, 0.0, 0.0};
-    int p = 0;
-    for (; p + 3 < NP; p += 4) {
-      double a0 = pb[(size_t)p * NTT * 256 + idx], a1 = pb[(size_t)(p + 1) * NTT * 256 + idx];
-      double a2 = pb[(size_t)(p + 2) * NTT * 256 + idx], a3 = pb[(size_t)(p + 3) * NTT * 256 + idx];
-      t[0] += a0;
-      t[1] += a1;
-      t[2] += a2;
-      t[3] += a3;
-    }
-    for (; p < NP; ++p) t[0] += pb[(size_t)p * NTT * 256 + idx];
-    const double tot = (t[0] + t[1]) + (t[2] + t[3]);
+    const double tot = pb[idx];
     const int x = idx >> 8, e = idx & 255;
     int ti = 0, tj = 0, cnt = 0;  // x-th tile of the upper triangle, row-major
     for (int a = 0; a < NT; ++a)
@@ -242,7 +343,6 @@ __global__ void __launch_bounds__(kGfThreads)
                          out_offset + (size_t)b * K + k, tid);
     if (info && tid == 0 && out_status) atomicOr(out_status, (int32_t)PBBSS_ST_NOT_POSDEF);
   }
-  (void)lane;
 }
 
 // factorisation of given covariances: one workgroup per (b, k)
@@ -259,11 +359,13 @@ __global__ void __launch_bounds__(kGfThreads)
 
 // ------------------------------------------------------------------ log-pdf / E-step (MFMA)
 // One wavefront per 16 samples and class: Z = Mq_k D^T by 16x16x4 tiles (A = Mq block, B = the
-// samples' centred vectors), q_n = sum_i d_ni Z_in; D staged per workgroup in LDS.
-// grid (ceil(N / 64), B): a workgroup = 4 waves = 64 samples; classes looped.
+// samples' centred vectors), q_n = sum_i d_ni Z_in.  A workgroup (4 waves) walks `tiles` blocks
+// of 64 samples per class with Mq_k staged ONCE in LDS (reloading the 18 KB matrix for every 64
+// samples made this kernel L2-bound); the centred block D is staged per tile.
+// grid (ceil(N / (64 tiles)), B).
 template <int NT, typename TS>
 __global__ void __launch_bounds__(kGfThreads)
-    gf_logpdf_kernel(const TS* __restrict__ y, int64_t N, int E, int K,
+    gf_logpdf_kernel(const TS* __restrict__ y, int64_t N, int E, int K, int tiles,
                      const double* __restrict__ mean, const double* __restrict__ mq,
                      const double* __restrict__ offset, const double* __restrict__ weight,
                      double* __restrict__ out_lp, double* __restrict__ out_aff) {
@@ -271,63 +373,99 @@ __global__ void __launch_bounds__(kGfThreads)
   extern __shared__ double sm[];
   double* M = sm;                    // [P][P + 1]  Mq_k, zero padded
   double* Dm = sm + P * (P + 1);     // [64][P + 1] centred samples, zero padded
-  double* lp = Dm + 64 * (P + 1);    // [K][64]
+  double* lp = Dm + 64 * (P + 1);    // [K][64 tiles]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t b = blockIdx.y;
-  const int64_t nb = (int64_t)blockIdx.x * 64;
+  const int64_t nb0 = (int64_t)blockIdx.x * 64 * tiles;
+  const int S = 64 * tiles;
   const TS* yb = y + (size_t)b * N * E;
+  const int i = lane & 15, g = lane >> 4;
   for (int k = 0; k < K; ++k) {
     const double* mu = mean + ((size_t)b * K + k) * E;
     const double* mk = mq + ((size_t)b * K + k) * (size_t)E * E;
+    const double off = offset[(size_t)b * K + k];
     __syncthreads();
-    for (int idx = tid; idx < P * P; idx += kGfThreads) {
-      const int r = idx / P, cc = idx % P;
-      M[r * (P + 1) + cc] = (r < E && cc < E) ? mk[(size_t)r * E + cc] : 0.0;
-    }
-    for (int idx = tid; idx < 64 * P; idx += kGfThreads) {
-      const int s = idx / P, d = idx % P;
-      const int64_t n = nb + s;
-      Dm[s * (P + 1) + d] = (n < N && d < E) ? (double)yb[(size_t)n * E + d] - mu[d] : 0.0;
-    }
-    __syncthreads();
-    // wave w: samples 16 w .. 16 w + 15; lane: i = l % 16, g = l / 16
-    const int i = lane & 15, g = lane >> 4;
-    const double* ds = Dm + (16 * wave) * (P + 1);
-    double qpart = 0.0;
+    {
+      constexpr int R = P * P / kGfThreads;
+      double raw[R];
 #pragma unroll
-    for (int ti = 0; ti < NT; ++ti) {
-      double4_t z = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int kk = 0; kk < P; kk += 4) {
-        const double a = M[(16 * ti + i) * (P + 1) + kk + g];  // A[i][k = g]
-        const double bv = ds[i * (P + 1) + kk + g];            // B[k = g][j = i]: sample i, dim kk+g
-        z = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv, z, 0, 0, 0);
+      for (int q = 0; q < R; ++q) {
+        const int idx = tid + q * kGfThreads;
+        const int r = idx / P, cc = idx % P;
+        raw[q] = mk[(size_t)((r < E) ? r : 0) * E + ((cc < E) ? cc : 0)];
       }
-      // z[r] = Z[out dim 16 ti + 4 r + g][sample i]
 #pragma unroll
-      for (int r = 0; r < 4; ++r) qpart = fma(ds[i * (P + 1) + 16 * ti + 4 * r + g], z[r], qpart);
+      for (int q = 0; q < R; ++q) {
+        const int idx = tid + q * kGfThreads;
+        const int r = idx / P, cc = idx % P;
+        M[r * (P + 1) + cc] = (r < E && cc < E) ? raw[q] : 0.0;
+      }
     }
-    qpart += __shfl_xor(qpart, 16, 64);
-    qpart += __shfl_xor(qpart, 32, 64);
-    if (g == 0) lp[k * 64 + 16 * wave + i] = offset[(size_t)b * K + k] - 0.5 * qpart;
+    for (int tl = 0; tl < tiles; ++tl) {
+      const int64_t nb = nb0 + 64 * tl;
+      if (nb >= N) break;  // uniform
+      __syncthreads();     // the previous tile's MFMA reads of Dm are done (and M is complete)
+      {  // unconditional loads at clamped addresses first, masks afterwards (see the scatter)
+        constexpr int R = 64 * P / kGfThreads;
+        TS raw[R];
+        double mus[R];
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+          const int idx = tid + q * kGfThreads;
+          const int sidx = idx / P, d = idx % P;
+          const int64_t n = nb + sidx;
+          const int64_t ncl = (n < N) ? n : N - 1;
+          const int dcl = (d < E) ? d : 0;
+          raw[q] = yb[(size_t)ncl * E + dcl];
+          mus[q] = mu[dcl];
+        }
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+          const int idx = tid + q * kGfThreads;
+          const int sidx = idx / P, d = idx % P;
+          const bool ok = (nb + sidx < N) && (d < E);
+          Dm[sidx * (P + 1) + d] = ok ? (double)raw[q] - mus[q] : 0.0;
+        }
+      }
+      __syncthreads();
+      // wave w: samples 16 w .. 16 w + 15 of the tile; lane: i = l % 16, g = l / 16
+      const double* ds = Dm + (16 * wave) * (P + 1);
+      double qpart = 0.0;
+#pragma unroll
+      for (int ti = 0; ti < NT; ++ti) {
+        double4_t z = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < P; kk += 4) {
+          const double a = M[(16 * ti + i) * (P + 1) + kk + g];  // A[i][k = g]
+          const double bv = ds[i * (P + 1) + kk + g];            // B[k = g][j = i]
+          z = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv, z, 0, 0, 0);
+        }
+        // z[r] = Z[out dim 16 ti + 4 r + g][sample i]
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          qpart = fma(ds[i * (P + 1) + 16 * ti + 4 * r + g], z[r], qpart);
+      }
+      qpart += __shfl_xor(qpart, 16, 64);
+      qpart += __shfl_xor(qpart, 32, 64);
+      if (g == 0) lp[k * S + 64 * tl + 16 * wave + i] = off - 0.5 * qpart;
+    }
   }
   __syncthreads();
-  if (tid < 64) {
-    const int64_t n = nb + tid;
-    if (n < N) {
-      double mx = -1.79e308;
-      for (int k = 0; k < K; ++k) mx = fmax(mx, lp[k * 64 + tid]);
-      if (out_lp)
-        for (int k = 0; k < K; ++k) out_lp[((size_t)b * K + k) * N + n] = lp[k * 64 + tid];
-      if (out_aff) {  // mixture_model_utils.py:30-47, affiliation_eps = 0
-        double den = 0.0;
-        for (int k = 0; k < K; ++k) den += exp(lp[k * 64 + tid] - mx) * weight[(size_t)b * K + k];
-        den = fmax(den, kTiny);
-        for (int k = 0; k < K; ++k)
-          out_aff[((size_t)b * K + k) * N + n] =
-              exp(lp[k * 64 + tid] - mx) * weight[(size_t)b * K + k] / den;
-      }
+  for (int sidx = tid; sidx < S; sidx += kGfThreads) {
+    const int64_t n = nb0 + sidx;
+    if (n >= N) continue;
+    double mx = -1.79e308;
+    for (int k = 0; k < K; ++k) mx = fmax(mx, lp[k * S + sidx]);
+    if (out_lp)
+      for (int k = 0; k < K; ++k) out_lp[((size_t)b * K + k) * N + n] = lp[k * S + sidx];
+    if (out_aff) {  // mixture_model_utils.py:30-47, affiliation_eps = 0
+      double den = 0.0;
+      for (int k = 0; k < K; ++k) den += exp(lp[k * S + sidx] - mx) * weight[(size_t)b * K + k];
+      den = fmax(den, kTiny);
+      for (int k = 0; k < K; ++k)
+        out_aff[((size_t)b * K + k) * N + n] =
+            exp(lp[k * S + sidx] - mx) * weight[(size_t)b * K + k] / den;
     }
   }
 }
@@ -373,9 +511,13 @@ int gf_fit_go(const void* y, int64_t B, int64_t N, int E, int K, const double* w
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return PBBSS_ERR_HIP;
-  hipLaunchKernelGGL(kfn, dim3((unsigned)K, (unsigned)B), dim3(kGfThreads), lds, s, part,
-                     C * kGfWaves, static_cast<const TS*>(y), N, E, K, out_mean, out_cov, out_mq,
-                     out_offset, out_s0, out_status);
+  constexpr int NTT = NT * (NT + 1) / 2;
+  double* gsum = part + (size_t)B * K * C * kGfWaves * NTT * 256;  // behind the wave partials
+  hipLaunchKernelGGL(gf_reduce_kernel, dim3((unsigned)NTT, (unsigned)K, (unsigned)B),
+                     dim3(kGfThreads), 0, s, part, C * kGfWaves, NTT, K, gsum);
+  hipLaunchKernelGGL(kfn, dim3((unsigned)K, (unsigned)B), dim3(kGfThreads), lds, s, gsum,
+                     static_cast<const TS*>(y), N, E, K, out_mean, out_cov, out_mq, out_offset,
+                     out_s0, out_status);
   return gf_ok();
 }
 
@@ -384,13 +526,19 @@ int gf_logpdf_go(const void* y, int64_t B, int64_t N, int E, int K, const double
                  const double* mq, const double* offset, const double* weight, double* out_lp,
                  double* out_aff, hipStream_t s) {
   constexpr int P = 16 * NT;
-  const size_t lds = ((size_t)P * (P + 1) + 64 * (size_t)(P + 1) + (size_t)K * 64) * sizeof(double);
+  int tiles = 64 / K;  // K * tiles * 64 log-pdfs staged per workgroup: at most 32 KiB
+  if (tiles > 4) tiles = 4;  // 256 samples per workgroup: ~4 workgroups per CU overlap load and MFMA
+  if (tiles < 1) tiles = 1;
+  const size_t lds =
+      ((size_t)P * (P + 1) + 64 * (size_t)(P + 1) + (size_t)K * 64 * tiles) * sizeof(double);
   auto kfn = gf_logpdf_kernel<NT, TS>;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return PBBSS_ERR_HIP;
-  hipLaunchKernelGGL(kfn, dim3((unsigned)((N + 63) / 64), (unsigned)B), dim3(kGfThreads), lds, s,
-                     static_cast<const TS*>(y), N, E, K, mean, mq, offset, weight, out_lp, out_aff);
+  const int64_t per = 64 * (int64_t)tiles;
+  hipLaunchKernelGGL(kfn, dim3((unsigned)((N + per - 1) / per), (unsigned)B), dim3(kGfThreads),
+                     lds, s, static_cast<const TS*>(y), N, E, K, tiles, mean, mq, offset, weight,
+                     out_lp, out_aff);
   return gf_ok();
 }
 
@@ -399,7 +547,7 @@ int gf_logpdf_go(const void* y, int64_t B, int64_t N, int E, int K, const double
 size_t gauss_full_partial_doubles(int64_t B, int64_t N, int E, int K) {
   const int NT = (E + 1 + 15) / 16;
   const int C = gf_chunks(B, K, N);
-  return (size_t)B * K * C * kGfWaves * (size_t)(NT * (NT + 1) / 2) * 256;
+  return (size_t)B * K * (C * kGfWaves + 1) * (size_t)(NT * (NT + 1) / 2) * 256;  // + tile sums
 }
 
 #define PBBSS_GF_DISPATCH(FN, ...)                                                      \
