@@ -83,13 +83,27 @@ __global__ void __launch_bounds__(kGenThreads) gen_estep_kernel(GenEstep a) {
   const int D = a.D, K = a.K, T = a.T;
   const int t = blockIdx.y * kGenThreads + tid;  // thread = frame
   const bool valid = t < T;
+  // unconditional loads at clamped indices into raw registers, masks afterwards: a guarded load
+  // that is converted inside its guard compiles to branch + load + s_waitcnt vmcnt(0), i.e. D
+  // serial memory round trips per frame (found in the ISA of the embedding E-step)
   double yr[DP], yi[DP], n2 = 0.0;
+  {
+    const int tc = valid ? t : 0;
+    YS rr[DP], ri[DP];
 #pragma unroll
-  for (int d = 0; d < DP; ++d) {
-    yr[d] = 0.0;
-    yi[d] = 0.0;
-    if (d < D && valid) {
-      load_y<YS>(a.y, a.layout, b, t, d, T, D, yr[d], yi[d]);
+    for (int d = 0; d < DP; ++d) {
+      const int dc = (d < D) ? d : 0;
+      const size_t idx = (a.layout == PBBSS_LAYOUT_TD) ? ((size_t)b * T + tc) * D + dc
+                                                       : ((size_t)b * D + dc) * T + tc;
+      const YS* p = static_cast<const YS*>(a.y) + 2 * idx;
+      rr[d] = p[0];
+      ri[d] = p[1];
+    }
+#pragma unroll
+    for (int d = 0; d < DP; ++d) {
+      const bool ok = d < D && valid;
+      yr[d] = ok ? (double)rr[d] : 0.0;
+      yi[d] = ok ? (double)ri[d] : 0.0;
       n2 += yr[d] * yr[d] + yi[d] * yi[d];
     }
   }
