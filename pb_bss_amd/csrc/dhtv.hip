@@ -394,8 +394,13 @@ __global__ void __launch_bounds__(kDhtvThreads)
           double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
           int f = f0;
           for (; f + 8 <= f1; f += 8, p += 8 * (int64_t)T) {
+            // all eight (atomic, hence program-ordered) loads first, then the adds: written as
+            // load-add pairs every add waits for its own L2 round trip
+            double a[8];
 #pragma unroll
-            for (int x = 0; x < 8; ++x) s[x] += ld_sc1(p + x * (int64_t)T);
+            for (int x = 0; x < 8; ++x) a[x] = ld_sc1(p + x * (int64_t)T);
+#pragma unroll
+            for (int x = 0; x < 8; ++x) s[x] += a[x];
           }
           for (; f < f1; ++f, p += T) s[0] += ld_sc1(p);
           st_sc1(part + (int64_t)c * KT + col,
@@ -407,7 +412,15 @@ __global__ void __launch_bounds__(kDhtvThreads)
       // ---- centroid = ordered sum of the chunk partials, mean, unit norm per class
       for (int col = tid; col < KT; col += kDhtvThreads) {
         double sacc = 0.0;
-        for (int c = 0; c < NCH; ++c) sacc += ld_sc1(part + (int64_t)c * KT + col);
+        int c = 0;
+        for (; c + 4 <= NCH; c += 4) {  // same summation order, four round trips overlapped
+          double a[4];
+#pragma unroll
+          for (int x = 0; x < 4; ++x) a[x] = ld_sc1(part + (int64_t)(c + x) * KT + col);
+#pragma unroll
+          for (int x = 0; x < 4; ++x) sacc += a[x];
+        }
+        for (; c < NCH; ++c) sacc += ld_sc1(part + (int64_t)c * KT + col);
         cent[col] = sacc * inv_n;
       }
       __syncthreads();
@@ -433,14 +446,20 @@ __global__ void __launch_bounds__(kDhtvThreads)
         for (int t0 = lane; t0 < T; t0 += 4 * kWave) {
           double fv[4][K], cv[4][K];
 #pragma unroll
+          for (int x = 0; x < 4; ++x) {  // raw loads first (clamped frames), masks afterwards
+            const int t = t0 + x * kWave;
+            const int tc = (t < T) ? t : lane;
+#pragma unroll
+            for (int k = 0; k < K; ++k) fv[x][k] = ld_sc1(feat + ((int64_t)k * F + f) * T + tc);
+          }
+#pragma unroll
           for (int x = 0; x < 4; ++x) {
             const int t = t0 + x * kWave;
             const bool ok = t < T;
             const int tc = ok ? t : lane;
 #pragma unroll
             for (int k = 0; k < K; ++k) {
-              double v = ld_sc1(feat + ((int64_t)k * F + f) * T + tc);
-              fv[x][k] = ok ? v : 0.0;
+              fv[x][k] = ok ? fv[x][k] : 0.0;
               cv[x][k] = ok ? cent[k * T + tc] : 0.0;
             }
           }
