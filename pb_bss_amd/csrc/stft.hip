@@ -100,20 +100,33 @@ __global__ void __launch_bounds__(kStftThreads) stft_kernel(StftArgs g) {
     __syncthreads();      // roots ready / previous frame fully written out
     const int64_t s0 = (int64_t)t * g.shift - g.fade;
     for (int n = tid; n < M; n += kStftThreads) {
-      double v[2];
+      // unconditional loads at clamped indices, masks afterwards (a guarded load that is used
+      // inside its guard waits for its own memory round trip)
+      bool ok[2];
+      int64_t sc[2];
+      int wc[2];
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int m = 2 * n + h;
         const int64_t si = s0 + m;
-        double xv = 0.0;
-        if (m < g.wl && si >= 0 && si < g.N) {
-          xv = g.x_is_f64 ? static_cast<const double*>(g.x)[c * g.N + si]
-                          : (double)static_cast<const float*>(g.x)[c * g.N + si];
-          xv *= g.window[m];
-        }
-        v[h] = xv;
+        ok[h] = m < g.wl && si >= 0 && si < g.N;
+        sc[h] = ok[h] ? si : 0;
+        wc[h] = ok[h] ? m : 0;
       }
-      bufa[n] = {v[0], v[1]};
+      double xv[2], wv[2];
+      if (g.x_is_f64) {
+        const double* xp = static_cast<const double*>(g.x) + c * g.N;
+        xv[0] = xp[sc[0]];
+        xv[1] = xp[sc[1]];
+      } else {
+        const float* xp = static_cast<const float*>(g.x) + c * g.N;
+        const float f0 = xp[sc[0]], f1 = xp[sc[1]];
+        xv[0] = (double)f0;
+        xv[1] = (double)f1;
+      }
+      wv[0] = g.window[wc[0]];
+      wv[1] = g.window[wc[1]];
+      bufa[n] = {ok[0] ? xv[0] * wv[0] : 0.0, ok[1] ? xv[1] * wv[1] : 0.0};
     }
     __syncthreads();
     const Cplx* Z = stockham<-1>(bufa, bufb, roots, M, tid);
