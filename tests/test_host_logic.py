@@ -142,3 +142,49 @@ def test_transform_windows_match_scipy_and_oracle():
         biorthogonal_window(analysis_window('hann', 400), 128)
     assert stft_frames_to_samples(66, 512, 128) == 66 * 128 + 384 - 768
     assert stft_frames_to_samples(10, 512, 128, fading=False) == 10 * 128 + 384
+
+
+def test_gmm_and_alignment_argument_mapping():
+    """Pure host logic of the GMM / permutation-solver mirrors: how weight_constant_axis,
+    covariance_type and similarity_metric map onto the device modes, and the errors the
+    reference raises for bad values."""
+    from pb_bss_amd.distribution import gmm
+    from pb_bss_amd import permutation_alignment as pa
+    assert gmm._weight_kind((-1,), 2) == gmm._CLASS
+    assert gmm._weight_kind(-1, 3) == gmm._CLASS
+    assert gmm._weight_kind([1], 2) == gmm._CLASS       # axis 1 of (K, N) is the sample axis
+    assert gmm._weight_kind(-2, 2) == gmm._UNIFORM      # int -2: the constant 1 / K
+    assert gmm._weight_kind((-2,), 2) == gmm._ONES      # tuple (-2,): a (1, N) array of ones
+    assert gmm._weight_kind((0,), 2) == gmm._ONES
+    with pytest.raises(NotImplementedError):
+        gmm._weight_kind((-3,), 3)
+    gmm._check_covariance_type('full')
+    gmm._check_covariance_type('spherical')
+    with pytest.raises(NotImplementedError):
+        gmm._check_covariance_type('diagonal')
+    with pytest.raises(ValueError, match="Unknown covariance type 'round'"):
+        gmm._check_covariance_type('round')
+    for metric in ('cos', 'multiply', 'euclidean'):
+        pa._check_metric(metric)
+        pa.GreedyPermutationAlignment(similarity_metric=metric)
+        pa.OraclePermutationAlignment(similarity_metric=metric, algorithm='greedy')
+    with pytest.raises(AttributeError, match='Suggestions: cos, euclidean'):
+        pa._check_metric('coss')            # getattr(_ScoreMatrix, 'coss') in the reference
+    with pytest.raises(ValueError):
+        pa.GreedyPermutationAlignment(similarity_metric='coss')
+    with pytest.raises(AssertionError):
+        pa.OraclePermutationAlignment(algorithm='hungarian')
+    # the greedy solver's recursion as a composition of permutations (what the device scans)
+    from oracle import permutation_alignment as op
+    rng = np.random.default_rng(2)
+    K, F = 4, 33
+    step = np.stack([rng.permutation(K) for _ in range(F)], 1)
+    step[:, 0] = np.arange(K)
+    seq = step.copy()
+    for f in range(1, F):
+        seq[:, f] = seq[seq[:, f - 1], f]       # permutation_alignment.py:698-699
+    comp = np.arange(K)
+    for f in range(1, F):
+        comp = step[comp, f]                    # M_f o (M_{f-1} o ... o M_1)
+        assert (comp == seq[:, f]).all()
+    assert op.greedy_calculate_mapping(rng.uniform(size=(3, 1, 5))).tolist() == [[0], [1], [2]]
