@@ -68,3 +68,32 @@ def test_oracle_equals_live_reference_on_fresh_inputs(ref):
             np.testing.assert_array_equal(
                 op.oracle_calculate_mapping(shuffled, kft, metric, alg),
                 pa.OraclePermutationAlignment(metric, alg).calculate_mapping(shuffled, kft))
+
+
+def test_oracle_gmm_equals_live_reference_on_fresh_inputs(ref):
+    """GMMTrainer (covariance_type 'full' -- its default -- and 'spherical') and the Gaussian
+    single fits of the unmodified reference against the NumPy oracle on freshly drawn data."""
+    dist, _, _ = ref
+    from oracle import embed as oe
+    rng = np.random.default_rng(4321)
+    N, E, K = 700, 9, 3
+    centers = rng.normal(size=(K, E)) * 2
+    y = centers[rng.integers(K, size=N)] + rng.normal(size=(N, E))
+    init = rng.uniform(size=(K, N))
+    init /= init.sum(0, keepdims=True)
+    sal = rng.uniform(0.2, 1.0, size=N)
+    for ct in ('full', 'spherical'):
+        m = dist.GMMTrainer().fit(y, initialization=init, iterations=5, saliency=sal,
+                                  covariance_type=ct)
+        o = oe.gmm_fit(y, init, 5, saliency=sal, covariance_type=ct)
+        np.testing.assert_allclose(o['mean'], m.gaussian.mean, atol=1e-11)
+        np.testing.assert_allclose(o['covariance'], m.gaussian.covariance, atol=1e-11)
+        np.testing.assert_allclose(o['weight'], m.weight, atol=1e-12)
+        np.testing.assert_allclose(oe.gmm_predict(o, y, ct), m.predict(y), atol=1e-10)
+    w = rng.uniform(size=(K, N))
+    g = dist.GaussianTrainer()._fit(y[None], saliency=w, covariance_type='full')
+    om, oc = oe.gaussian_fit(y[None], w, 'full')
+    np.testing.assert_allclose(om, g.mean, atol=1e-12)
+    np.testing.assert_allclose(oc, g.covariance, atol=1e-12)
+    np.testing.assert_allclose(oe.gaussian_log_pdf(y[None], om, oc, 'full'), g.log_pdf(y[None]),
+                               rtol=1e-10, atol=1e-9)
