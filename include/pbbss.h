@@ -560,8 +560,11 @@ int pbbss_set_timing(pbbss_handle_t h, int enable);
  * (e.g. 513 = 2 * 256 + 1 frequency bins) the r remainder problems are run as "split"
  * groups -- several workgroups share one problem's frames and exchange partial sums
  * through L2 -- concurrently on an internal side stream, so that no CU hosts an extra
- * full workgroup.  pbbss_split_error reads (synchronously) whether a bounded
- * inter-workgroup wait ever timed out (0 = never). */
+ * full workgroup.  A bounded inter-workgroup wait that times out (peers not co-resident under
+ * heavy contention) never hangs: it sets PBBSS_ST_NONFINITE | PBBSS_ST_EIG_NOCONV in the status
+ * words of the launch's split problems (the Python layer then raises like the reference's
+ * finiteness assert) and a sticky flag that pbbss_split_error reads synchronously (0 = no
+ * wait of this handle ever timed out). */
 int pbbss_set_split_tail(pbbss_handle_t h, int enable);
 /* pbbss_dhtv_calculate_mapping: workgroups that share ONE utterance (team kernel, used for
  * few utterances where a single workgroup is bound by one CU's L2 latency): 0 = automatic

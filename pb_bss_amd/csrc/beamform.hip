@@ -488,9 +488,13 @@ __global__ void __launch_bounds__(kEmThreads, 3)
       default: Kern::template phase_m<3>(a, L, lane); break;
     }
     __syncthreads();
-    for (int e = tid; e < K * D * D * 2; e += kEmThreads) {
-      int k = e / (D * D * 2), r = e % (D * D * 2);
-      out[b * out_bstride + (int64_t)k * D * D * 2 + r] = L.cmat[e];
+    for (int e = tid; e < K * D * D; e += kEmThreads) {
+      const int k = e / (D * D), ij = e % (D * D);
+      double re, im;
+      Kern::cov_entry(L, k, ij / D, ij % D, re, im);
+      double* o = out + b * out_bstride + ((int64_t)k * D * D + ij) * 2;
+      o[0] = re;
+      o[1] = im;
     }
   }
 }

@@ -68,7 +68,7 @@ struct EmArgs {
   int64_t b_first;    // first problem handled by this launch
   double* xslab;      // [2][n_problems][G][slab_len] partial sums exchanged through L2
   unsigned* xcount;   // [n_problems] arrival counters (zeroed before the launch)
-  int* xerror;        // set to 1 if a bounded spin ran out
+  int* xerror;        // [0] set to 1 if a bounded spin of THIS launch ran out; [16] sticky copy
   int split_prio;     // s_setprio level of the split waves (0..3)
   // options
   int iterations;
@@ -111,7 +111,10 @@ struct EmKernel {
   static constexpr int NA = D * D;  // packed reals of one Hermitian matrix
   static constexpr int NDW = (D + kEmWaves - 1) / kEmWaves;     // diag entries per wave (max)
   static constexpr int NOW = (NOFF + kEmWaves - 1) / kEmWaves;  // off-diag pairs per wave (max)
-  static constexpr int kOperandChunk = 2;  // pairs of A_k operands per prefetch stage of the E phase
+#ifndef PBBSS_E_CHUNK
+#define PBBSS_E_CHUNK 1
+#endif
+  static constexpr int kOperandChunk = PBBSS_E_CHUNK;  // pairs of A_k operands per prefetch stage of the E phase
   using YS4 = typename std::conditional<std::is_same<YS, float>::value, float4, double4>::type;
   using YS2 = typename std::conditional<std::is_same<YS, float>::value, float2, double2>::type;
 
@@ -119,7 +122,7 @@ struct EmKernel {
     YS* ybuf;        // [DP][Tp][4]   channel pairs, frame contiguous
     double* inv_n2;  // [Tp]
     double* wbuf;    // [K][Tp]       M-step weights
-    double* cmat;    // [K][D][D][2]  covariance sums
+    double* cpack;   // [K][NA]       covariance sums, packed like apack: diag, then (Re, Im) per pair i<j
     double* apack;   // [K][NA]       A_k packed for the dot with P: diag, then (2Re, 2Im) per pair
     double* wgt;     // [K]           mixture weights
     double* detm;    // [K]           det B_k mantissa
@@ -138,8 +141,8 @@ struct EmKernel {
   }
   static __host__ __device__ size_t small_bytes() {
     size_t n = 0;
-    n += (size_t)K * D * D * 16;
-    n += (size_t)K * NA * 8;
+    n += (size_t)K * NA * 8;        // cpack
+    n += (size_t)K * NA * 8;        // apack
     n += (size_t)K * 8 * 4;         // wgt, detm, rdet, ssum
     n += (size_t)kEmWaves * K * 8;  // red
     n += (size_t)K * 4 * 2 + 16;    // dete, status, flags
@@ -165,8 +168,8 @@ struct EmKernel {
     L.wbuf = reinterpret_cast<double*>(f);
     f += (size_t)K * L.Tp * 8;
     if (!SPILL) p = f;
-    L.cmat = reinterpret_cast<double*>(p);
-    p += (size_t)K * D * D * 16;
+    L.cpack = reinterpret_cast<double*>(p);
+    p += (size_t)K * NA * 8;
     L.apack = reinterpret_cast<double*>(p);
     p += (size_t)K * NA * 8;
     L.wgt = reinterpret_cast<double*>(p);
@@ -295,14 +298,17 @@ struct EmKernel {
   //     cacgmm.py:59) and are read with strides from HBM; otherwise the
   //     per-class weights in LDS are used.  (A runtime flag here makes hipcc
   //     unswitch the frame loop and spill ~300 VGPRs, hence a template.)
-  template <bool FINAL, bool TW, bool JOINT = false>
+  // PAIR: frames are taken two per lane (512 per pass) while more than 256 remain -- every A_k
+  //     operand fetched from LDS then feeds two frames -- and one per lane for the rest
+  //     (T = 500: one paired pass; T <= 256: one single pass).
+  template <bool FINAL, bool TW, bool JOINT = false, bool PAIR = false>
   static __device__ void phase_e(const EmArgs& a, const Lds& L, int64_t b, int tid, int wave,
                                  int lane, double eps, int tf = 0,
                                  const JointExtras* jx = nullptr) {
     tid = opaque(tid);
     lane = opaque(lane);
     const int TS = t_stride(a);
-    constexpr int NF = 1;  // frames per lane per pass (NF=2 shares A_k operand loads but makes hipcc 7.2 spill)
+    static_assert(!JOINT || !PAIR, "joint E-step is written for one frame per lane");
     double s[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) s[k] = 0.0;
@@ -310,7 +316,8 @@ struct EmKernel {
 #pragma unroll
     for (int k = 0; k < K; ++k)
       jlogdet[k] = JOINT ? log(L.detm[k]) + (double)L.dete[k] * 0.6931471805599453 : 0.0;
-    for (int t0 = 0; t0 < a.T; t0 += NF * kEmThreads) {
+    auto pass = [&](int t0, auto nfc) {
+      constexpr int NF = decltype(nfc)::value;  // frames per lane in this pass
       int tt[NF];
       bool ok[NF];
       double re[NF][D], im[NF][D], q[NF][K];
@@ -381,7 +388,13 @@ struct EmKernel {
               }
             }
           });
-          asm volatile("" ::: "memory");
+          // tie the partial sums to the stage boundary (pure arithmetic is not ordered by the
+          // memory clobber: left alone the FMAs sink below later fetches and the operands spill)
+#pragma unroll
+          for (int f = 0; f < NF; ++f) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) asm volatile("" : "+v"(q[f][k])::"memory");
+          }
           __builtin_amdgcn_sched_barrier(0);
         });
       }
@@ -399,7 +412,6 @@ struct EmKernel {
       if constexpr (JOINT) {
         // log-domain softmax of the weighted sum of spatial and spectral log-pdfs
         // (gcacgmm.py:108-115 -> mixture_model_utils.py:30-53)
-        static_assert(NF == 1, "joint E-step is written for one frame per lane");
         const int t = tt[0];
         const double inv = L.inv_n2[t];
         double lps[K], lp[K], mx = -1.79e308;
@@ -512,6 +524,13 @@ struct EmKernel {
         }
       }
       }  // !JOINT
+    };
+    {
+      int t0 = 0;
+      if constexpr (PAIR) {
+        for (; a.T - t0 > kEmThreads; t0 += 2 * kEmThreads) pass(t0, std::integral_constant<int, 2>{});
+      }
+      for (; t0 < a.T; t0 += kEmThreads) pass(t0, std::integral_constant<int, 1>{});
     }
     if constexpr (!FINAL) {
 #pragma unroll
@@ -536,11 +555,12 @@ struct EmKernel {
     double acc[NACC];
 #pragma unroll
     for (int x = 0; x < NACC; ++x) acc[x] = 0.0;
-    for (int t0 = 0; t0 < a.T; t0 += kWave) {
-      const int t = t0 + lane;
-      const bool ok = t < a.T;
-      const int tc = ok ? t : a.T - 1;
+    auto trip = [&](int t0, auto fullc) {
+      constexpr bool FULL = fullc;
       double re[D], im[D], w[K];
+      const int t = t0 + lane;
+      const bool ok = FULL || t < a.T;
+      const int tc = ok ? t : a.T - 1;
       load_frame(L, tc, re, im);
 #pragma unroll
       for (int k = 0; k < K; ++k) w[k] = ok ? L.wbuf[(size_t)k * L.Tp + tc] : 0.0;
@@ -567,15 +587,19 @@ struct EmKernel {
           }
         }
       });
-    }
+    };
+    for (int t0 = 0; t0 < a.T; t0 += kWave) trip(t0, std::false_type{});
 #ifdef PBBSS_PHASE_PROFILE
-    unsigned long long tm0 = __builtin_readcyclecounter();
+    unsigned long long tm0 = __builtin_readcyclecounter(), tm1 = tm0;
 #endif
     // halving butterfly over the 64 frame-lanes; 16 lanes each store NACC/16 totals
     wave_reduce_scatter<NACC>(acc, lane);
 #ifdef PBBSS_PHASE_PROFILE
-    unsigned long long tm1 = __builtin_readcyclecounter();
+    tm1 = __builtin_readcyclecounter();
 #endif
+    // write-back in the packed order of apack (diag i -> i, pair p -> D + 2p + {Re, Im}): a few
+    // integer operations per value; the consumers (factor_class, split_exchange, psd read-out)
+    // unpack with pair_index()
     if ((lane & 3) == 0) {
       const int base = reduce_scatter_base<NACC>(lane);
 #pragma unroll
@@ -583,24 +607,10 @@ struct EmKernel {
         const int idx = base + m;
         if (idx < K * NSLOT) {
           const int k = idx / NSLOT, s = idx % NSLOT;
-          if (s < NDW) {
-            const int i = s * kEmWaves + W;
-            if (i < D) {
-              double* cc = L.cmat + (((size_t)k * D + i) * D + i) * 2;
-              cc[0] = acc[m];
-              cc[1] = 0.0;
-            }
-          } else {
-            const int p = ((s - NDW) >> 1) * kEmWaves + W;
-            if (p < NOFF) {
-              const int i = kTriTable<D>.i[p], j = kTriTable<D>.j[p];
-              const bool is_im = ((s - NDW) & 1) != 0;
-              // C_ij gets +v (re) / +v (im); C_ji = conj(C_ij)
-              L.cmat[(((size_t)k * D + i) * D + j) * 2 + (is_im ? 1 : 0)] = acc[m];
-              L.cmat[(((size_t)k * D + j) * D + i) * 2 + (is_im ? 1 : 0)] =
-                  is_im ? -acc[m] : acc[m];
-            }
-          }
+          const bool dg = s < NDW;
+          const int u = dg ? s * kEmWaves + W : ((s - NDW) >> 1) * kEmWaves + W;  // diag i / pair p
+          const int e = dg ? u : D + 2 * u + ((s - NDW) & 1);
+          if (u < (dg ? D : NOFF)) L.cpack[k * NA + e] = acc[m];
         }
       }
     }
@@ -617,6 +627,20 @@ struct EmKernel {
   // packed index of pair (i < j)
   static __device__ __forceinline__ int pair_index(int i, int j) {
     return i * D - (i * (i + 1)) / 2 + (j - i - 1);
+  }
+
+  // covariance sum C_k[i][j] from the packed LDS array (C_ji = conj(C_ij))
+  static __device__ __forceinline__ void cov_entry(const Lds& L, int k, int i, int j, double& re,
+                                                   double& im) {
+    if (i == j) {
+      re = L.cpack[k * NA + i];
+      im = 0.0;
+    } else {
+      const int lo = min(i, j), hi = max(i, j);
+      const double2 v = *reinterpret_cast<const double2*>(L.cpack + k * NA + D + 2 * pair_index(lo, hi));
+      re = v.x;
+      im = (i < j) ? v.y : -v.y;
+    }
   }
 
   // store Hermitian G (lane = entry) as the dot-ready A_k
@@ -681,32 +705,34 @@ struct EmKernel {
     const double scale = (double)D / fmax(S, kTiny);  // cacg.py:316, :327
     double are = 0.0, aim = 0.0;
     if (valid) {
-      const double* cm = L.cmat + (((size_t)k * D + c.i) * D + c.j) * 2;
-      are = cm[0] * scale;
-      aim = cm[1] * scale;
+      cov_entry(L, k, c.i, c.j, are, aim);
+      are *= scale;
+      aim *= scale;
     }
     int st = 0;
-    const bool finite_in = isfinite(are) && isfinite(aim);
-    if (wave_or(finite_in ? 0 : 1)) st |= PBBSS_ST_NONFINITE;  // cacg.py:333
+    // Non-finite input (cacg.py:333) is detected on the slow path only: a NaN / Inf anywhere in a
+    // Hermitian matrix reaches a later Gauss-Jordan pivot (a_jj -= a_ji a_ij / d), which fails the
+    // pivot test below and sends the class to the exact eigen path, where the flag is raised.
     if (last && a.out_cov && valid) {
       double* oc = a.out_cov + ((((size_t)b * K + k) * D + c.i) * D + c.j) * 2;
       oc[0] = are;
       oc[1] = aim;
     }
-    bool need_eig = last || a.force_eig || (st & PBBSS_ST_NONFINITE) || (*L.flags & 1);
+    bool need_eig = last || a.force_eig || (*L.flags & 1);
     if (!need_eig) {
       double gre = are, gim = aim;
       ScaledReal det;
+      // trace of C: independent of the inversion, so its reduction fills the sweep's stalls
+      double trc = wave_sum((valid && c.i == c.j) ? are : 0.0);
       int info = wave_hpd_inverse<D>(gre, gim, c, det);
       bool ok = (info == 0);
       if (ok) {
         // lambda_min >= 1/||A^-1||_F and lambda_max <= tr C: if even this pessimistic
-        // ratio stays clear of the floor, no eigenvalue is floored (cacg.py:112-126)
-        double trc = (valid && c.i == c.j) ? are : 0.0;
-        double fro2 = valid ? gre * gre + gim * gim : 0.0;
-        wave_sum2(trc, fro2);
-        double bound = trc * sqrt(fro2);
-        ok = isfinite(bound) && (bound * a.eig_floor < 1e-2) && (bound < 1e13);
+        // ratio stays clear of the floor, no eigenvalue is floored (cacg.py:112-126).
+        // Compared as squares (no square root): bound^2 = tr^2 * ||A^-1||_F^2.
+        double fro2 = wave_sum(valid ? gre * gre + gim * gim : 0.0);
+        const double bound2 = trc * trc * fro2;
+        ok = isfinite(bound2) && (bound2 * (a.eig_floor * a.eig_floor) < 1e-4) && (bound2 < 1e26);
         if (ok) {
           store_apack(L, k, c, gre, gim);
           if (lane == 0) {
@@ -720,6 +746,10 @@ struct EmKernel {
         need_eig = true;
         st |= PBBSS_ST_SLOWPATH;
       }
+    }
+    if (need_eig) {
+      const bool finite_in = isfinite(are) && isfinite(aim);
+      if (wave_or(finite_in ? 0 : 1)) st |= PBBSS_ST_NONFINITE;  // cacg.py:333
     }
     if (need_eig) {
       if (a.covariance_norm == PBBSS_COVNORM_TRACE) {  // cacg.py:88-90
@@ -1083,6 +1113,16 @@ struct EmKernel {
   static constexpr int kSlabLen = K * NA + K + 1;
   static constexpr unsigned kSpinLimit = 20000000u;  // ~2 s of polling before giving up
 
+  // A bounded spin ran out (the peers of this group are not co-resident, e.g. under heavy
+  // contention from other kernels): the sums of this problem are incomplete from here on.  The
+  // per-launch word poisons the status output of every split problem of the launch (see the end
+  // of run_split: order-independent atomic ORs onto status words zeroed before the launch), the
+  // sticky word backs pbbss_split_error().
+  static __device__ void split_timeout(const EmArgs& a) {
+    atomicExch(a.xerror, 1);
+    atomicExch(a.xerror + 16, 1);
+  }
+
   static __device__ void split_exchange(const EmArgs& a, const Lds& L, int prob, int nprob, int g,
                                         int it, int tid) {
     const int G = a.split_groups;
@@ -1091,14 +1131,7 @@ struct EmKernel {
     for (int idx = tid; idx < kSlabLen; idx += kEmThreads) {
       double v;
       if (idx < K * NA) {
-        const int k = idx / NA, e = idx % NA;
-        if (e < D) {
-          v = L.cmat[(((size_t)k * D + e) * D + e) * 2];
-        } else {
-          const int p = (e - D) >> 1;
-          const int i = kTriTable<D>.i[p], j = kTriTable<D>.j[p];
-          v = L.cmat[(((size_t)k * D + i) * D + j) * 2 + ((e - D) & 1)];
-        }
+        v = L.cpack[idx];  // slab order = packed order
       } else if (idx < K * NA + K) {
         const int k = idx - K * NA;
         v = 0.0;
@@ -1120,7 +1153,7 @@ struct EmKernel {
       while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
         __builtin_amdgcn_s_sleep(1);
         if (++spins > kSpinLimit) {
-          atomicExch(a.xerror, 1);
+          split_timeout(a);
           break;
         }
       }
@@ -1143,18 +1176,7 @@ struct EmKernel {
         for (int u = 0; u < 8; ++u) tot += (g0 + u < G) ? part[u] : 0.0;
       }
       if (idx < K * NA) {
-        const int k = idx / NA, e = idx % NA;
-        if (e < D) {
-          double* c = L.cmat + (((size_t)k * D + e) * D + e) * 2;
-          c[0] = tot;
-          c[1] = 0.0;
-        } else {
-          const int p = (e - D) >> 1;
-          const int i = kTriTable<D>.i[p], j = kTriTable<D>.j[p];
-          const int im = (e - D) & 1;
-          L.cmat[(((size_t)k * D + i) * D + j) * 2 + im] = tot;
-          L.cmat[(((size_t)k * D + j) * D + i) * 2 + im] = im ? -tot : tot;
-        }
+        L.cpack[idx] = tot;
       } else if (idx < K * NA + K) {
         const int k = idx - K * NA;
         L.red[k] = tot;  // wave 0's slot carries the total, the others are cleared
@@ -1215,7 +1237,7 @@ struct EmKernel {
       while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
         __builtin_amdgcn_s_sleep(1);
         if (++spins > kSpinLimit) {
-          atomicExch(a.xerror, 1);
+          split_timeout(a);
           break;
         }
       }
@@ -1340,12 +1362,16 @@ struct EmKernel {
       for (int i = 0; i < 8; ++i) atomicAdd(ga.prof + 32 + wave * 8 + i, spc[i]);
     }
 #endif
-    if (tid < K && g == 0) {
-      if (a.out_weight && a.iterations > 0) a.out_weight[(size_t)b * K + tid] = L.wgt[tid];
-      // a timed-out inter-workgroup wait invalidates the result: report it as a failed solve
+    if (tid < K) {
+      if (g == 0 && a.out_weight && a.iterations > 0) a.out_weight[(size_t)b * K + tid] = L.wgt[tid];
+      // A timed-out inter-workgroup wait invalidates the result: EVERY member that sees the
+      // per-launch error word reports the solve as failed (NONFINITE -> the host raises), with
+      // atomic ORs onto status words the launcher zeroed, so no ordering between the members'
+      // exits is assumed.  Member 0 also contributes the regular status bits.
       const int xerr = __hip_atomic_load(a.xerror, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (a.out_status)
-        a.out_status[(size_t)b * K + tid] = L.status[tid] | (xerr ? PBBSS_ST_EIG_NOCONV : 0);
+      const int bits = (g == 0 ? L.status[tid] : 0) |
+                       (xerr ? (PBBSS_ST_EIG_NOCONV | PBBSS_ST_NONFINITE) : 0);
+      if (a.out_status && bits) atomicOr(a.out_status + (size_t)b * K + tid, bits);
     }
     if (a.final_predict) phase_e<true, false>(a, L, b, tid, wave, lane, a.final_eps, tf);
   }
@@ -1386,7 +1412,7 @@ struct EmKernel {
       PBBSS_TICK(0)
       for (int it = 0; it < a.iterations; ++it) {
         if (it > 0 || model_in) {
-          phase_e<false, false>(a, L, b, tid, wave, lane, a.aff_eps);
+          phase_e<false, false, false, true>(a, L, b, tid, wave, lane, a.aff_eps);
           PBBSS_TICK(1)
           __syncthreads();
           PBBSS_TICK(2)
@@ -1440,6 +1466,7 @@ __global__ void __launch_bounds__(kEmThreads, em_waves_per_simd(K)) cacgmm_em_ke
   extern __shared__ __attribute__((aligned(16))) char smem[];
   EmKernel<D, K, YS, SPILL>::run(a, smem);
 }
+
 
 template <int D, int K, typename YS>
 __global__ void __launch_bounds__(kEmThreads, em_waves_per_simd(K))

@@ -158,6 +158,17 @@ PBBSS_API const char* pbbss_error_string(int code) {
 PBBSS_API int pbbss_create(pbbss_handle_t* out, int device_id) {
   if (!out) return PBBSS_ERR_INVALID_ARG;
   const bool dbg = getenv("PBBSS_DEBUG") != nullptr;
+  // bind to device_id for the allocations below, then give the caller its current device back
+  // (every other entry point uses DeviceGuard; a lazily created handle must not move the
+  // process's current device)
+  int prev_device = -1;
+  (void)hipGetDevice(&prev_device);
+  struct Restore {
+    int dev;
+    ~Restore() {
+      if (dev >= 0) (void)hipSetDevice(dev);
+    }
+  } restore{prev_device};
   hipError_t e0 = hipSetDevice(device_id);
   if (dbg) fprintf(stderr, "pbbss: hipSetDevice(%d) rc=%d (%s)\n", device_id, (int)e0, hipGetErrorString(e0));
   if (e0 != hipSuccess) return PBBSS_ERR_HIP;
@@ -264,7 +275,7 @@ PBBSS_API int pbbss_split_error(pbbss_handle_t h, int* out_flag) {
   DeviceGuard device_guard(h);
   if (!h || !out_flag) return PBBSS_ERR_INVALID_ARG;
   int v = 0;
-  if (hipMemcpy(&v, h->cfg.xbuf + 128, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)
+  if (hipMemcpy(&v, h->cfg.xbuf + 192, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)
     return PBBSS_ERR_HIP;
   *out_flag = v;
   return PBBSS_OK;

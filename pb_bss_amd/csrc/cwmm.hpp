@@ -233,10 +233,10 @@ struct WatsonKernel {
     }
     double are = 0.0, aim = 0.0;
     if (valid) {
-      const double* cm = L.cmat + (((size_t)k * D + c.i) * D + c.j) * 2;
       const double scale = 1.0 / S;  // complex_watson.py:311 (no floor in the reference)
-      are = cm[0] * scale;
-      aim = cm[1] * scale;
+      Base::cov_entry(L, k, c.i, c.j, are, aim);
+      are *= scale;
+      aim *= scale;
     }
     int st = 0;
     if (wave_or((isfinite(are) && isfinite(aim)) ? 0 : 1)) st |= PBBSS_ST_NONFINITE;

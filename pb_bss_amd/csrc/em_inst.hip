@@ -59,7 +59,13 @@ static int launch_split(EmArgs a, int64_t b_first, int r, const EmLaunchCfg& cfg
   a.xslab = reinterpret_cast<double*>(cfg.xbuf + head);
   if (hipEventRecord(cfg.ev_fork, stream) != hipSuccess) return PBBSS_ERR_HIP;
   if (hipStreamWaitEvent(cfg.side_stream, cfg.ev_fork, 0) != hipSuccess) return PBBSS_ERR_HIP;
-  if (hipMemsetAsync(cfg.xbuf, 0, head, cfg.side_stream) != hipSuccess) return PBBSS_ERR_HIP;
+  // counters + the per-launch error word; the sticky error word at byte 192 is never cleared
+  if (hipMemsetAsync(cfg.xbuf, 0, 192, cfg.side_stream) != hipSuccess) return PBBSS_ERR_HIP;
+  // status words of the split problems: the members OR their bits in (order-independent)
+  if (a.out_status &&
+      hipMemsetAsync(a.out_status + b_first * K, 0, (size_t)r * K * sizeof(int32_t),
+                     cfg.side_stream) != hipSuccess)
+    return PBBSS_ERR_HIP;
   hipLaunchKernelGGL(kfn, dim3((unsigned)(r * G)), dim3(kEmThreads), lds, cfg.side_stream, a);
   if (hipGetLastError() != hipSuccess) return PBBSS_ERR_HIP;
   if (hipEventRecord(cfg.ev_join, cfg.side_stream) != hipSuccess) return PBBSS_ERR_HIP;
@@ -94,6 +100,12 @@ static int launch_one(const EmArgs& a, const EmLaunchCfg& cfg, hipStream_t strea
 
 template <typename YS>
 static int launch_k(int K, const EmArgs& a, const EmLaunchCfg& cfg, hipStream_t stream) {
+#ifdef PBBSS_EM_DEV_ONLY_K  // kernel-development builds: one (K, float) instantiation, 10x faster to compile
+  if constexpr (std::is_same<YS, float>::value) {
+    if (K == PBBSS_EM_DEV_ONLY_K) return launch_one<PBBSS_EM_DEV_ONLY_K, float>(a, cfg, stream);
+  }
+  return PBBSS_ERR_UNSUPPORTED;
+#else
   switch (K) {
     case 1: return launch_one<1, YS>(a, cfg, stream);
     case 2: return launch_one<2, YS>(a, cfg, stream);
@@ -103,6 +115,7 @@ static int launch_k(int K, const EmArgs& a, const EmLaunchCfg& cfg, hipStream_t 
     case 6: return launch_one<6, YS>(a, cfg, stream);
     default: return PBBSS_ERR_UNSUPPORTED;
   }
+#endif
 }
 
 #define PBBSS_CAT2(a, b) a##b

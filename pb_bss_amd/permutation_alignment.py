@@ -29,21 +29,41 @@ def _interleave(a, b):
     return out
 
 
+def _is_complex(x):
+    return x.is_complex() if _lib.is_torch(x) else np.iscomplexobj(x)
+
+
 def apply_mapping(mask, mapping):
     """mask (K, F, ...) [or (..., K, F, T)], reverse mapping (K, F): frequency-aligned
-    mask, `mask[mapping, range(F)]` in the reference (permutation_alignment.py:54-104)."""
+    mask, `mask[mapping, range(F)]` in the reference (permutation_alignment.py:54-104).
+
+    Like the reference's fancy indexing this is a pure gather, so any dtype comes back
+    unchanged: complex input (an STFT aligned with the masks' mapping) travels through the
+    float64 kernel as (re, im) pairs, float32 / integer input is widened and narrowed again
+    (exact for a gather)."""
     like_torch = _lib.is_torch(mask)
     t = _lib.torch()
-    m = _lib.to_device(mask, t.float64)
-    mp = _lib.to_device(mapping).to(m.device).to(t.int32)
+    m = _lib.to_device(mask)
+    in_dtype = m.dtype
     if m.ndim == 2:  # (K, F): trailing axis of length 1
         m = m[..., None]
+    if m.is_complex():
+        m = t.view_as_real(m.to(t.complex128).contiguous())
+        m = m.reshape(*m.shape[:-2], m.shape[-2] * 2)  # (..., K, F, 2 T) float64
+    else:
+        if m.dtype == t.int64 and m.numel() and int(m.abs().max().item()) >= 2 ** 53:
+            raise NotImplementedError('int64 values beyond 2**53 do not survive the float64 gather')
+        m = m.to(t.float64)
+    mp = _lib.to_device(mapping).to(m.device).to(t.int32)
     *lead, K, F, T = m.shape
     assert K < 20, (K, mapping.shape)
     assert tuple(mp.shape[-2:]) == (K, F), (mask.shape, mapping.shape)
     out = engine.apply_mapping(m.reshape(-1, K, F, T).contiguous(),
                                mp.expand(*lead, K, F).reshape(-1, K, F).contiguous())
     out = out.reshape(*lead, K, F, T)
+    if in_dtype.is_complex:
+        out = t.view_as_complex(out.reshape(*lead, K, F, T // 2, 2).contiguous())
+    out = out.to(in_dtype)
     if np.ndim(mask) == 2:
         out = out[..., 0]
     return out if like_torch else _lib.to_host(out)
@@ -128,6 +148,8 @@ class DHTVPermutationAlignment(_PermutationAlignment):
             raise ValueError(self.algorithm)
         like_torch = _lib.is_torch(mask)
         t = _lib.torch()
+        if _is_complex(mask):
+            raise NotImplementedError(mask.dtype)  # reference :447-448 (a float64 cast would drop Im)
         m = _lib.to_device(mask, t.float64)
         *lead, K, F, T = m.shape
         assert F % 2 == 1, (F, 'Sure? Usually F is odd.')
@@ -188,9 +210,9 @@ class GreedyPermutationAlignment(_PermutationAlignment):
         """mask (K, F, T) [or (..., K, F, T)] -> reverse mapping (K, F) int64."""
         like_torch = _lib.is_torch(mask)
         t = _lib.torch()
+        if _is_complex(mask):
+            raise NotImplementedError(mask.dtype)  # reference _calculate_score_matrix :447-448
         m = _lib.to_device(mask, t.float64)
-        if m.is_complex():
-            raise NotImplementedError(m.dtype)
         *lead, K, F, T = m.shape
         assert K < 10, (K, 'Sure?')
         assert F % 2 == 1, (F, 'Sure? Usually F is odd.', tuple(m.shape))
@@ -221,11 +243,11 @@ class OraclePermutationAlignment(_PermutationAlignment):
         """mask, reference_mask (K, F, T) or (K, T) -> reverse mapping (K, F) / (K,) int64."""
         like_torch = _lib.is_torch(mask)
         t = _lib.torch()
+        if _is_complex(mask) or _is_complex(reference_mask):
+            raise NotImplementedError(mask.dtype, reference_mask.dtype)  # reference :447-448
         m = _lib.to_device(mask, t.float64)
         r = _lib.to_device(reference_mask, t.float64).to(m.device)
         assert tuple(m.shape) == tuple(r.shape), (tuple(m.shape), tuple(r.shape))
-        if m.is_complex() or r.is_complex():
-            raise NotImplementedError(m.dtype, r.dtype)
         K, *F, T = m.shape
         assert K < 10, (K, 'Sure?')
         if len(F) == 1:

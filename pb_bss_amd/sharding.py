@@ -74,19 +74,47 @@ def fit_predict_sharded(y, initialization, iterations=100, *, bin_axis=-3,
     from . import _lib
     from .distribution import CACGMMTrainer
     assert 'inline_permutation_aligner' not in fit_kwargs or \
-        fit_kwargs['inline_permutation_aligner'] is None
+        fit_kwargs['inline_permutation_aligner'] is None, \
+        'inline_permutation_aligner couples the frequency bins: not shardable by bins'
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     nd_y = y.ndim
     f_axis_y = bin_axis % nd_y
+    assert f_axis_y <= nd_y - 3, (bin_axis, tuple(y.shape), 'bin_axis must be an independent axis')
     F = y.shape[f_axis_y]
+    # weights shared across the sharded axis would need an all-reduce per EM iteration
+    # (mixture_model_utils.py:133-203): with y (..., F, T, D) the affiliation is (..., F, K, T),
+    # i.e. the bin axis sits at f_axis_y - nd_y (same negative index in both arrays)
+    wca = fit_kwargs.get('weight_constant_axis', (-1,))
+    wca = (wca,) if isinstance(wca, int) else tuple(wca)
+    assert all(a % nd_y != f_axis_y for a in wca), (
+        wca, 'weight_constant_axis contains the sharded bin axis: bins are not independent')
     lo, hi = shard_bounds(F, world, rank)
-    sl_y = [slice(None)] * nd_y
-    sl_y[f_axis_y] = slice(lo, hi)
-    sl_i = [slice(None)] * initialization.ndim
-    sl_i[bin_axis % initialization.ndim] = slice(lo, hi)
-    y_loc = _lib.to_device(y[tuple(sl_y)])
-    i_loc = _lib.to_device(initialization[tuple(sl_i)])
-    masks = CACGMMTrainer().fit_predict(y_loc, initialization=i_loc,
-                                        iterations=iterations, **fit_kwargs)
-    return all_gather_bins(masks, F, bin_axis=bin_axis % masks.ndim, group=group)
+
+    def block(x, axis_from_end):
+        """Slice this rank's bins out of an array whose bin axis is `axis_from_end` (negative)."""
+        if x is None or x.ndim < -axis_from_end or x.shape[axis_from_end] == 1:
+            return x  # absent, or broadcast along the bins
+        sl = [slice(None)] * x.ndim
+        sl[axis_from_end] = slice(lo, hi)
+        return x[tuple(sl)]
+
+    neg = f_axis_y - nd_y               # bin axis of y (..., F, T, D) and of (..., F, K, T)
+    y_loc = block(y, neg)
+    i_loc = block(initialization, neg)
+    kwargs = dict(fit_kwargs)
+    if kwargs.get('saliency') is not None:              # (..., F, T): one axis fewer
+        kwargs['saliency'] = block(kwargs['saliency'], neg + 1)
+    if kwargs.get('source_activity_mask') is not None:  # (..., F, K, T)
+        kwargs['source_activity_mask'] = block(kwargs['source_activity_mask'], neg)
+    K = initialization.shape[-2]
+    if hi > lo:
+        masks = CACGMMTrainer().fit_predict(_lib.to_device(y_loc), initialization=_lib.to_device(i_loc),
+                                            iterations=iterations, **kwargs)
+    else:
+        # more ranks than bins: this rank owns nothing and contributes an empty block
+        t = _lib.torch()
+        shape = list(y.shape[:-2]) + [K, y.shape[-2]]
+        shape[f_axis_y] = 0
+        masks = t.empty(shape, dtype=t.float64, device=t.device('cuda', t.cuda.current_device()))
+    return all_gather_bins(masks, F, bin_axis=f_axis_y, group=group)

@@ -16,9 +16,11 @@ NAMES = ['load/init', 'E', 'E-barrier+sums', 'M', 'M-barrier', 'factor', 'factor
 
 def main():
     nutt = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+    nb = int(sys.argv[2]) if len(sys.argv) > 2 else 513 * nutt  # bins actually used (e.g. 512: no tail)
     iters = 100
     Y = np.concatenate([synth.make_stft(513, 500, 8, 3, seed=s)[0] for s in range(nutt)])
     g = np.concatenate([synth.make_stft(513, 500, 8, 3, seed=s)[1] for s in range(nutt)])
+    Y, g = Y[:nb], g[:nb]
     y, g0 = _lib.to_device(Y), _lib.to_device(g)
     cnt = torch.zeros(72, dtype=torch.int64, device='cuda')
     h = _lib.handle()
@@ -33,10 +35,10 @@ def main():
     cs = call[32:64].reshape(4, 8)
     if call[66] > 0:
         print(f'  phase M (wave 0): butterfly {call[64]/call[66]:.0f} ticks, write-back {call[65]/call[66]:.0f} ticks per call')
-    nwg = min(513 * nutt, 256 * 3)
+    nwg = min(nb, 256 * 3)
     print(f'utterances {nutt}: kernel {ms:.3f} ms, {nutt*iters/ms*1e3:.0f} utt-iter/s; cycles per workgroup-iteration '
           f'(avg over {nwg} workgroups, s_memtime ticks):')
-    per = c / (513 * nutt) / iters  # per problem-iteration
+    per = c / nb / iters  # per problem-iteration
     for w in range(4):
         print(f'  wave {w}: ' + ', '.join(f'{n} {per[w, i]:.0f}' for i, n in enumerate(NAMES)))
     tot = per[0].sum()

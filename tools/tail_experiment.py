@@ -9,7 +9,8 @@ from pb_bss_amd import _lib, engine
 Y, init = synth.make_stft(513, 500, 8, 3, seed=0)
 Y = np.concatenate([Y, Y]); init = np.concatenate([init, init])
 engine.set_timing(True)
-for nb in (256, 384, 500, 512, 513, 514, 600, 700, 768, 769, 1026):
+BINS = [int(x) for x in sys.argv[1:]] or [256, 384, 500, 512, 513, 514, 600, 700, 768, 769, 1026]
+for nb in BINS:
     y, g = _lib.to_device(Y[:nb]), _lib.to_device(init[:nb])
     ts = []
     for _ in range(4):
