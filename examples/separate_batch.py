@@ -21,53 +21,18 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def separate_by_utterance(Y, init, iterations, stft_size, group=None):
-    """Utterance-level data parallelism (preferable when U >= ranks): every rank
-    runs the whole chain on its own block of utterances with NO collective in between and the
-    results are all-gathered once at the end."""
-    import torch.distributed as dist
-    from pb_bss_amd.sharding import all_gather_bins, shard_bounds
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
-    U = Y.shape[0]
-    assert U >= world, (U, world)
-    lo, hi = shard_bounds(U, world, rank)
-    out = separate(Y[lo:hi], init[lo:hi], iterations, stft_size, group=None, sharded=False)
-    return {k: all_gather_bins(v.contiguous(), U, bin_axis=0, group=group) for k, v in out.items()}
-
-
-def separate(Y, init, iterations, stft_size, group=None, sharded=True):
-    """Y (U, F, T, D) complex torch-CUDA or NumPy; init (U, F, K, T).
-    Returns dict(masks (U, K, F, T) aligned, enhanced (U, K, F, T), mapping)."""
+def separate(Y, init, iterations, stft_size, group=None, sharded=True, shard='bins'):
+    """Y (U, F, T, D) complex torch-CUDA or NumPy; init (U, F, K, T).  Thin wrapper over
+    `pb_bss_amd.pipeline.separate` (the chain itself lives in the package so that bench.py,
+    this example and the tests run the same code); gathers the outputs on every rank."""
     import torch
     import torch.distributed as dist
-    from pb_bss_amd import _lib
-    from pb_bss_amd.distribution import CACGMMTrainer
-    from pb_bss_amd.extraction import (apply_beamforming_vector, get_bf_vector,
-                                       get_power_spectral_density_matrix)
-    from pb_bss_amd.permutation_alignment import DHTVPermutationAlignment
-    from pb_bss_amd.sharding import fit_predict_sharded
-
+    from pb_bss_amd import _lib, pipeline
     Y = _lib.to_device(Y)
     init = _lib.to_device(init, torch.float64)
-    if sharded and dist.is_available() and dist.is_initialized():
-        masks = fit_predict_sharded(Y, init, iterations=iterations, bin_axis=-3, group=group)
-    else:
-        masks = CACGMMTrainer().fit_predict(Y, initialization=init, iterations=iterations)
-    kft = masks.transpose(-3, -2).contiguous()                      # (U, K, F, T)
-    solver = DHTVPermutationAlignment.from_stft_size(stft_size)
-    mapping = solver.calculate_mapping(kft)
-    aligned = solver.apply_mapping(kft, mapping)                    # (U, K, F, T)
-    X = Y.transpose(-2, -1).contiguous()                            # (U, F, D, T)
-    psd = get_power_spectral_density_matrix(X, aligned.transpose(-3, -2).contiguous())  # (U,F,K,D,D)
-    K = psd.shape[-3]
-    enhanced = []
-    for k in range(K):
-        target = psd[..., k, :, :]
-        noise = psd.sum(dim=-3) - target
-        w = get_bf_vector('gev+ban', target, noise)                 # (U, F, D)
-        enhanced.append(apply_beamforming_vector(w, X))             # (U, F, T)
-    return dict(masks=aligned, enhanced=torch.stack(enhanced, dim=1),
-                mapping=_lib.to_device(mapping) if not _lib.is_torch(mapping) else mapping)
+    multi = sharded and dist.is_available() and dist.is_initialized()
+    return pipeline.separate(Y, init, iterations, stft_size, shard=shard if multi else None,
+                             group=group, gather_output=True)
 
 
 def main():
@@ -97,13 +62,10 @@ def main():
     init = np.stack([d[1] for d in data])
     from pb_bss_amd import _lib
     Yd, initd = _lib.to_device(Y), _lib.to_device(init)
-    separate(Yd[:1], initd[:1], 2, stft_size)  # warm-up
+    separate(Yd[:1], initd[:1], 2, stft_size, sharded=False)  # warm-up
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    if use_dist and args.shard == 'utterances':
-        out = separate_by_utterance(Yd, initd, args.iterations, stft_size)
-    else:
-        out = separate(Yd, initd, args.iterations, stft_size)
+    out = separate(Yd, initd, args.iterations, stft_size, shard=args.shard)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if rank == 0:

@@ -679,6 +679,17 @@ struct EmKernel {
     lane = opaque(lane);
     const LaneIJ c = lane_ij(lane);
     const bool valid = c.i < D && c.j < D;
+#ifdef PBBSS_PHASE_PROFILE
+    unsigned long long fs[6] = {0, 0, 0, 0, 0, 0};
+    int fsn = 0;
+#define PBBSS_FSTAMP fs[fsn++] = __builtin_readcyclecounter();
+    PBBSS_FSTAMP
+#else
+#define PBBSS_FSTAMP
+#endif
+    // covariance entry of this lane first: the LDS round trip overlaps the class sums below
+    double are = 0.0, aim = 0.0;
+    if (valid) cov_entry(L, k, c.i, c.j, are, aim);
     // class sums of the E phase (per-wave partials in L.red) -> sum_t gamma_kt and the
     // new mixture weight (mixture_model_utils.py:133-203); done here by the wave that
     // owns class k instead of a separate single-thread step between two barriers
@@ -691,24 +702,11 @@ struct EmKernel {
       tot += fabs(sk);
       S = (kk == k) ? sk : S;
     }
-    if (lane == 0) {
-      double wnew;
-      if (a.weight_mode == PBBSS_WEIGHT_UNIFORM) {
-        wnew = 1.0 / K;  // :180-183
-      } else if (a.saliency) {
-        wnew = S / ((tot == 0.0) ? 1e-10 : tot);  // :192-201
-      } else {
-        wnew = S / (double)t_stride(a);  // :188
-      }
-      L.wgt[k] = wnew;
-    }
-    const double scale = (double)D / fmax(S, kTiny);  // cacg.py:316, :327
-    double are = 0.0, aim = 0.0;
-    if (valid) {
-      cov_entry(L, k, c.i, c.j, are, aim);
-      are *= scale;
-      aim *= scale;
-    }
+    // D / max(S, tiny) (cacg.py:316, :327) by a Newton-refined reciprocal (~1 ulp) instead of an
+    // IEEE division sequence: this sits on the serial path of every iteration
+    const double scale = (double)D * fast_rcp(fmax(S, kTiny));
+    are *= scale;
+    aim *= scale;
     int st = 0;
     // Non-finite input (cacg.py:333) is detected on the slow path only: a NaN / Inf anywhere in a
     // Hermitian matrix reaches a later Gauss-Jordan pivot (a_jj -= a_ji a_ij / d), which fails the
@@ -719,6 +717,7 @@ struct EmKernel {
       oc[1] = aim;
     }
     bool need_eig = last || a.force_eig || (*L.flags & 1);
+    PBBSS_FSTAMP
     if (!need_eig) {
       double gre = are, gim = aim;
       ScaledReal det;
@@ -726,26 +725,36 @@ struct EmKernel {
       double trc = wave_sum((valid && c.i == c.j) ? are : 0.0);
       int info = wave_hpd_inverse<D>(gre, gim, c, det);
       bool ok = (info == 0);
+      PBBSS_FSTAMP
       if (ok) {
+        // the result is stored right away (the slow path below overwrites it in the rare case
+        // the bound fails), so the stores overlap the reduction of the bound
+        store_apack(L, k, c, gre, gim);
+        if (lane == 0) {
+          L.detm[k] = det.m;
+          L.rdet[k] = fast_rcp(det.m);  // mantissa in [0.5, 1)
+          L.dete[k] = det.e;
+        }
         // lambda_min >= 1/||A^-1||_F and lambda_max <= tr C: if even this pessimistic
         // ratio stays clear of the floor, no eigenvalue is floored (cacg.py:112-126).
         // Compared as squares (no square root): bound^2 = tr^2 * ||A^-1||_F^2.
         double fro2 = wave_sum(valid ? gre * gre + gim * gim : 0.0);
         const double bound2 = trc * trc * fro2;
         ok = isfinite(bound2) && (bound2 * (a.eig_floor * a.eig_floor) < 1e-4) && (bound2 < 1e26);
-        if (ok) {
-          store_apack(L, k, c, gre, gim);
-          if (lane == 0) {
-            L.detm[k] = det.m;
-            L.rdet[k] = 1.0 / det.m;
-            L.dete[k] = det.e;
-          }
-        }
       }
       if (!ok) {
         need_eig = true;
         st |= PBBSS_ST_SLOWPATH;
       }
+      PBBSS_FSTAMP
+#ifdef PBBSS_PHASE_PROFILE
+      if (a.prof && lane == 0 && k == 0 && !need_eig) {
+        atomicAdd(a.prof + 67, fs[1] - fs[0]);  // sums, scale, load
+        atomicAdd(a.prof + 68, fs[2] - fs[1]);  // trace + Gauss-Jordan
+        atomicAdd(a.prof + 69, fs[3] - fs[2]);  // bound, store
+        atomicAdd(a.prof + 70, 1ull);
+      }
+#endif
     }
     if (need_eig) {
       const bool finite_in = isfinite(are) && isfinite(aim);
@@ -806,7 +815,19 @@ struct EmKernel {
         L.dete[k] = det.e;
       }
     }
-    if (lane == 0) L.status[k] |= st;
+    if (lane == 0) {
+      L.status[k] |= st;
+      // new mixture weight (off the serial path of the factorisation)
+      double wnew;
+      if (a.weight_mode == PBBSS_WEIGHT_UNIFORM) {
+        wnew = 1.0 / K;  // mixture_model_utils.py:180-183
+      } else if (a.saliency) {
+        wnew = S / ((tot == 0.0) ? 1e-10 : tot);  // :192-201
+      } else {
+        wnew = S / (double)t_stride(a);  // :188
+      }
+      L.wgt[k] = wnew;
+    }
   }
 
   // model (V, lambda) given by the caller -> A_k, det  (cacgmm.py:229-234)

@@ -63,41 +63,45 @@ __device__ __forceinline__ int wave_cholesky(double& are, double& aim, LaneIJ c,
 // Per sweep: one SGPR broadcast of the pivot and ONE parallel cross-lane hop
 // (row element a_pj and column element a_ip) -- about a third of the dependent
 // hops of Cholesky + triangular inverse + Gram product.  det(A) = prod d_p is
-// returned as mantissa/exponent; info = 0 or 1 + index of the first bad pivot.
+// returned as mantissa/exponent; info = 0, or 1 if some pivot was bad.
 // ---------------------------------------------------------------------------
 template <int D>
 __device__ __forceinline__ int wave_hpd_inverse(double& are, double& aim, LaneIJ c,
                                                 ScaledReal& det) {
-  int info = 0;
+  // One fused update per column p:  a' = a~ - (col~ * row~) / d  with
+  //   a~_ij  = 0 on row p and column p, a_ij elsewhere
+  //   col~_i = -1 on row p,    a_ip elsewhere
+  //   row~_j = +1 on column p, a_pj elsewhere
+  // which reproduces the four rules above (a_pp <- 1/d, row/d, -col/d, a_ij - a_ip a_pj/d) as
+  // straight-line code: the selects and the complex product wait only for the cross-lane round
+  // trip, so after the Newton-refined reciprocal of the pivot ONE fma per component remains on
+  // the serial path.  A bad pivot (non-positive / non-finite) only raises a flag -- the sweep
+  // runs on with garbage that the caller discards (exact eigen path).  Returns 0 or 1.
+  bool bad = false;
   det.m = 1.0;
   det.e = 0;
 #pragma unroll
   for (int p = 0; p < D; ++p) {
-    double d = lane_bcast_const(are, ij_lane(p, p));
-    bool good = (d > 0.0) && (d < 1.79e308);
-    if (!good && info == 0) info = p + 1;
-    double ds = good ? d : 1.0;
+    const double rr = lane_get(are, ij_lane(p, c.j)), ri = lane_get(aim, ij_lane(p, c.j));  // a_pj
+    const double cr = lane_get(are, ij_lane(c.i, p)), ci = lane_get(aim, ij_lane(c.i, p));  // a_ip
+    const double d = lane_bcast_const(are, ij_lane(p, p));
+    bad |= !((d > 0.0) && (d < 1.79e308));
     int ex;
-    det.m *= frexp(ds, &ex);  // mantissas in [0.5, 1): D <= 8 factors cannot underflow
+    det.m *= frexp(d, &ex);  // mantissas in [0.5, 1): D <= 8 factors cannot underflow
     det.e += ex;
-    double inv = fast_rcp(ds);
-    double rr = lane_get(are, ij_lane(p, c.j)), ri = lane_get(aim, ij_lane(p, c.j));  // a_pj
-    double cr = lane_get(are, ij_lane(c.i, p)), ci = lane_get(aim, ij_lane(c.i, p));  // a_ip
+    const double inv = fast_rcp(d);
     const bool ip = (c.i == p), jp = (c.j == p);
-    // branch-free form of the four update rules
-    double tr = (cr * rr - ci * ri) * inv, ti = (cr * ri + ci * rr) * inv;
-    double row_r = rr * inv, row_i = ri * inv;      // i == p, j != p
-    double col_r = -cr * inv, col_i = -ci * inv;    // j == p, i != p
-    double gen_r = are - tr, gen_i = aim - ti;      // i != p, j != p
-    double nr = ip ? (jp ? inv : row_r) : (jp ? col_r : gen_r);
-    double ni = ip ? (jp ? 0.0 : row_i) : (jp ? col_i : gen_i);
-    are = nr;
-    aim = ni;
+    const double br = (ip || jp) ? 0.0 : are, bi = (ip || jp) ? 0.0 : aim;
+    const double xr = ip ? -1.0 : cr, xi = ip ? 0.0 : ci;
+    const double yr = jp ? 1.0 : rr, yi = jp ? 0.0 : ri;
+    const double tr = xr * yr - xi * yi, ti = xr * yi + xi * yr;
+    are = fma(-tr, inv, br);
+    aim = fma(-ti, inv, bi);
   }
   int e2;
   det.m = frexp(det.m, &e2);
   det.e += e2;
-  return info;
+  return bad ? 1 : 0;
 }
 
 // X = L^-1 for lower-triangular L (row-oriented forward substitution on I).

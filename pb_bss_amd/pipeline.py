@@ -1,0 +1,149 @@
+"""Mask-based separation of a batch of utterances (the shape of BASELINE config 3).
+
+    STFT batch (U, F, T, D)
+      --cACGMM EM--------------------------------->  masks (U, F, K, T)
+      --[RCCL all-gather of the masks when the bins are sharded]
+      --DHTV permutation alignment---------------->  mapping (U, K, F), aligned masks (U, K, F, T)
+      --PSD per class, 'gev+ban' beamformer-------->  w (U, K, F, D)
+      --apply------------------------------------->  enhanced (U, K, F, T)
+
+The chain is the reference's canonical recipe (examples/mixture_model_example.ipynb cells
+11-12, tests/test_distribution/test_spatial_mm.py:43-49: `CACGMMTrainer.fit` -> `predict` ->
+`DHTVPermutationAlignment.from_stft_size(...)(...)` -> `get_power_spectral_density_matrix` ->
+`get_bf_vector('gev+ban', target, noise)` -> `apply_beamforming_vector`), stated once here so
+that the benchmark, the example and the tests run the same code.
+
+Multi-GPU (one process per GPU, torch.distributed):
+
+* ``shard='bins'``: every rank owns a contiguous block of frequency bins of EVERY utterance
+  (the EM needs no collective); the masks are all-gathered once (float32 on request: half
+  the xGMI bytes), each rank computes the DHTV mapping of its share of the utterances and
+  the tiny (U, K, F) mappings are all-gathered; alignment, PSD, beamformer and apply then run
+  on the rank's own bins.  The enhanced signals stay sharded by bins unless ``gather_output``.
+* ``shard='utterances'``: whole utterances per rank, no collective until the optional final
+  gather (preferable once there are at least as many utterances as GPUs).
+
+The device stages are passed in through ``ops`` so that the CPU tests can run this very
+orchestration (slicing, gathers, trimming) under gloo with NumPy stand-ins for the kernels.
+"""
+import numpy as np
+
+from .sharding import all_gather_bins, shard_bounds
+
+__all__ = ['separate', 'device_ops']
+
+
+class device_ops:
+    """The device implementation of the five stages (torch CUDA tensors in and out)."""
+
+    @staticmethod
+    def em_masks(Y, init, iterations):
+        from .distribution import CACGMMTrainer
+        return CACGMMTrainer().fit_predict(Y, initialization=init, iterations=iterations)
+
+    @staticmethod
+    def dhtv_mapping(mask_kft, stft_size):
+        from .permutation_alignment import DHTVPermutationAlignment
+        return DHTVPermutationAlignment.from_stft_size(stft_size).calculate_mapping(mask_kft)
+
+    @staticmethod
+    def apply_mapping(mask_kft, mapping):
+        from .permutation_alignment import apply_mapping
+        return apply_mapping(mask_kft, mapping)
+
+    @staticmethod
+    def psd(X, mask_fkt):
+        from .extraction import get_power_spectral_density_matrix
+        return get_power_spectral_density_matrix(X, mask_fkt)
+
+    @staticmethod
+    def gev_ban(target, noise):
+        from .extraction import get_bf_vector
+        return get_bf_vector('gev+ban', target, noise)
+
+    @staticmethod
+    def apply_bf(w, X):
+        from .extraction import apply_beamforming_vector
+        return apply_beamforming_vector(w, X)
+
+
+def _chain_after_masks(Y, masks_fkt, mapping, ops):
+    """Alignment -> PSD -> gev+ban -> apply for utterances / bins that are local.
+    Y (U, F, T, D), masks_fkt (U, F, K, T), mapping (U, K, F) for the same bins."""
+    import torch
+    kft = masks_fkt.transpose(-3, -2).contiguous()                    # (U, K, F, T)
+    aligned = ops.apply_mapping(kft, mapping)                         # (U, K, F, T)
+    X = Y.transpose(-2, -1).contiguous()                              # (U, F, D, T)
+    psd = ops.psd(X, aligned.transpose(-3, -2).contiguous())          # (U, F, K, D, D)
+    K = psd.shape[-3]
+    total = psd.sum(dim=-3)
+    target = psd.movedim(-3, 0).contiguous()                          # (K, U, F, D, D)
+    noise = (total.unsqueeze(0) - target).contiguous()
+    w = ops.gev_ban(target, noise)                                    # (K, U, F, D)
+    enhanced = torch.stack([ops.apply_bf(w[k], X) for k in range(K)], dim=1)  # (U, K, F, T)
+    return aligned, w.movedim(0, 1).contiguous(), enhanced
+
+
+def separate(Y, init, iterations=100, stft_size=None, *, shard=None, group=None,
+             mask_gather_dtype=None, gather_output=False, ops=device_ops):
+    """Y (U, F, T, D) complex, init (U, F, K, T): run the chain above.
+
+    shard: None (single process), 'bins' or 'utterances' (torch.distributed initialised).
+    Returns dict(masks (U, K, F', T) aligned, enhanced (U, K, F', T), bf_vector (U, K, F', D),
+    mapping (U, K, F)); F' = the rank's own bins for shard='bins' without gather_output, U the
+    rank's own utterances for shard='utterances' without gather_output.
+    """
+    import torch
+    U, F, T, D = Y.shape
+    if stft_size is None:
+        stft_size = 2 * (F - 1)
+    if shard is None:
+        masks = ops.em_masks(Y, init, iterations)                     # (U, F, K, T)
+        mapping = ops.dhtv_mapping(masks.transpose(-3, -2).contiguous(), stft_size)
+        aligned, w, enhanced = _chain_after_masks(Y, masks, mapping, ops)
+        return dict(masks=aligned, enhanced=enhanced, bf_vector=w, mapping=mapping)
+
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if shard == 'utterances':
+        assert U >= world, (U, world, 'fewer utterances than ranks: shard the bins instead')
+        lo, hi = shard_bounds(U, world, rank)
+        out = separate(Y[lo:hi], init[lo:hi], iterations, stft_size, ops=ops)
+        if gather_output:
+            out = {k: all_gather_bins(v.contiguous(), U, bin_axis=0, group=group)
+                   for k, v in out.items()}
+        return out
+    assert shard == 'bins', shard
+
+    lo, hi = shard_bounds(F, world, rank)
+    Y_loc = Y[:, lo:hi].contiguous()
+    if hi > lo:
+        masks_loc = ops.em_masks(Y_loc, init[:, lo:hi].contiguous(), iterations)  # (U, F_loc, K, T)
+    else:  # more ranks than bins
+        masks_loc = torch.empty((U, 0, init.shape[-2], T), dtype=torch.float64, device=Y.device)
+    # ---- the one real exchange step of the path: masks of all bins on every rank ----------
+    send = masks_loc if mask_gather_dtype is None else masks_loc.to(mask_gather_dtype)
+    masks_all = all_gather_bins(send, F, bin_axis=1, group=group).to(masks_loc.dtype)
+    # ---- DHTV needs all bins of an utterance; utterances are independent: each rank solves
+    #      its share and the (U, K, F) integer mappings are all-gathered (a few KB each) --------
+    ulo, uhi = shard_bounds(U, world, rank)
+    K = masks_all.shape[-2]
+    if uhi > ulo:
+        map_loc = ops.dhtv_mapping(masks_all[ulo:uhi].transpose(-3, -2).contiguous(), stft_size)
+        map_loc = map_loc.to(torch.int64).reshape(uhi - ulo, K, F)
+    else:
+        map_loc = torch.empty((0, K, F), dtype=torch.int64, device=Y.device)
+    mapping = all_gather_bins(map_loc, U, bin_axis=0, group=group)     # (U, K, F)
+    # ---- everything downstream is per bin: own bins only --------------------------------------
+    if hi > lo:
+        # own bins of the (own-precision) masks: bit-identical to an unsharded run
+        aligned, w, enhanced = _chain_after_masks(Y_loc, masks_loc, mapping[..., lo:hi].contiguous(), ops)
+    else:
+        aligned = torch.empty((U, K, 0, T), dtype=masks_loc.dtype, device=Y.device)
+        w = torch.empty((U, K, 0, D), dtype=torch.complex128, device=Y.device)
+        enhanced = torch.empty((U, K, 0, T), dtype=torch.complex128, device=Y.device)
+    out = dict(masks=aligned, enhanced=enhanced, bf_vector=w, mapping=mapping)
+    if gather_output:
+        for key in ('masks', 'enhanced', 'bf_vector'):
+            out[key] = all_gather_bins(out[key].contiguous(), F, bin_axis=2, group=group)
+    return out

@@ -39,3 +39,49 @@ def test_batch_pipeline_matches_oracle_chain():
             s = ob.apply_bf(w, X)
             # GEV vectors carry an arbitrary phase per frequency: compare magnitudes
             assert np.abs(np.abs(s) - np.abs(enhanced[u, k])).max() < 1e-7 * np.abs(s).max()
+
+
+def _phase_aligned_error(got, ref):
+    """max |got e^{-i phi} - ref| / max |ref| with one phase per (class, bin): a GEV
+    beamformer is defined up to a unit-modulus factor per frequency (LAPACK's choice of
+    eigenvector phase), so the complex outputs are compared after removing exactly that."""
+    inner = (got * np.conj(ref)).sum(-1, keepdims=True)
+    phase = inner / np.maximum(np.abs(inner), 1e-300)
+    return np.abs(got * np.conj(phase) - ref).max() / np.abs(ref).max()
+
+
+def test_config3_chain_full_size_utterances_match_oracle_chain():
+    """BASELINE configs[2] at its real per-utterance size (F=513, T=500, D=8, K=3): four
+    utterances through pb_bss_amd.pipeline.separate (EM -> DHTV -> PSD -> gev+ban -> apply)
+    against the same chain assembled from the NumPy oracles -- masks, permutation mapping,
+    beamformer (|cos|) and the COMPLEX enhanced signals up to the per-bin GEV phase."""
+    from oracle import beamformer as ob, cacgmm as oc, permutation_alignment as op, synth
+    from pb_bss_amd import _lib, pipeline
+    U, F, T, D, K, iters = 4, 513, 500, 8, 3, 20
+    data = [synth.make_stft(F, T, D, K, seed=u) for u in range(U)]
+    Y = np.stack([d[0] for d in data])
+    init = np.stack([d[1] for d in data])
+    out = pipeline.separate(_lib.to_device(Y), _lib.to_device(init), iters, 1024)
+    masks = _lib.to_host(out['masks'])
+    enhanced = _lib.to_host(out['enhanced'])
+    w_dev = _lib.to_host(out['bf_vector'])
+    mapping_dev = _lib.to_host(out['mapping'])
+    assert masks.shape == (U, K, F, T) and enhanced.shape == (U, K, F, T)
+    plan = op.alignment_plan(1024, **op.PRESETS[1024])
+    for u in range(U):
+        Y128 = Y[u].astype(np.complex128)
+        ref = oc.em_predict(oc.em_fit(Y128, init[u], iterations=iters), Y128)  # (F, K, T)
+        kft = ref.transpose(1, 0, 2)
+        mapping = op.dhtv_calculate_mapping(kft, plan)
+        assert (mapping == mapping_dev[u]).all()
+        aligned = op.apply_mapping(kft, mapping)
+        assert np.abs(aligned - masks[u]).max() < 1e-9
+        X = Y128.transpose(0, 2, 1)
+        psd = ob.psd(X, aligned.transpose(1, 0, 2))
+        for k in range(K):
+            w = ob.bf_vector('gev+ban', psd[:, k], psd.sum(1) - psd[:, k])
+            cos = np.abs((np.conj(w) * w_dev[u, k]).sum(-1)) / (
+                np.linalg.norm(w, axis=-1) * np.linalg.norm(w_dev[u, k], axis=-1))
+            assert np.abs(cos - 1).max() < 1e-9
+            s = ob.apply_bf(w, X)
+            assert _phase_aligned_error(enhanced[u, k], s) < 1e-8

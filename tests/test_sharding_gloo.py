@@ -55,3 +55,102 @@ def test_all_gather_bins_world2(F):
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), F, ret), nprocs=world, join=True)
     assert dict(ret) == {0: True, 1: True}
+
+
+# ---------------------------------------------------------------------------------------------
+# The config-3 chain (pb_bss_amd.pipeline.separate) under gloo: the REAL orchestration code --
+# bin / utterance slicing, mask all-gather (also in float32), per-rank DHTV shares, mapping
+# gather, per-bin extraction, output gather -- with the NumPy oracle standing in for the five
+# device stages.  Sharded runs must reproduce the single-process run.
+class _oracle_ops:
+    """pb_bss_amd.pipeline.device_ops with oracle bodies (CPU torch tensors in and out)."""
+
+    @staticmethod
+    def em_masks(Y, init, iterations):
+        from oracle import cacgmm as oc
+        out = []
+        for y, g in zip(Y.numpy(), init.numpy()):
+            y128 = y.astype(np.complex128)
+            out.append(oc.em_predict(oc.em_fit(y128, g, iterations=iterations), y128))
+        return torch.from_numpy(np.stack(out))
+
+    @staticmethod
+    def dhtv_mapping(mask_kft, stft_size):
+        from oracle import permutation_alignment as op
+        plan = op.alignment_plan(stft_size, **op.PRESETS[stft_size])
+        return torch.from_numpy(np.stack([op.dhtv_calculate_mapping(m, plan)
+                                          for m in mask_kft.numpy()]))
+
+    @staticmethod
+    def apply_mapping(mask_kft, mapping):
+        from oracle import permutation_alignment as op
+        return torch.from_numpy(np.stack([op.apply_mapping(m, p)
+                                          for m, p in zip(mask_kft.numpy(), mapping.numpy())]))
+
+    @staticmethod
+    def psd(X, mask_fkt):
+        from oracle import beamformer as ob
+        return torch.from_numpy(np.stack([ob.psd(x.astype(np.complex128), m)
+                                          for x, m in zip(X.numpy(), mask_fkt.numpy())]))
+
+    @staticmethod
+    def gev_ban(target, noise):
+        from oracle import beamformer as ob
+        t, n = target.numpy(), noise.numpy()
+        D = t.shape[-1]
+        w = ob.bf_vector('gev+ban', t.reshape(-1, D, D), n.reshape(-1, D, D))
+        # GEV vectors carry an arbitrary phase: fix it (first sensor real, positive) so that
+        # sharded and unsharded runs can be compared entry by entry
+        w = w * np.exp(-1j * np.angle(w[..., :1]))
+        return torch.from_numpy(w.reshape(t.shape[:-1]))
+
+    @staticmethod
+    def apply_bf(w, X):
+        from oracle import beamformer as ob
+        return torch.from_numpy(ob.apply_bf(w.numpy(), X.numpy().astype(np.complex128)))
+
+
+def _pipeline_inputs(U=3, F=257, T=40, D=3, K=2):
+    from pb_bss_amd.testing import synth
+    data = [synth.make_stft(F, T, D, K, seed=70 + u) for u in range(U)]
+    return (torch.from_numpy(np.stack([d[0] for d in data])),
+            torch.from_numpy(np.stack([d[1] for d in data])))
+
+
+def _pipeline_worker(rank, world, port, shard, gather_dtype, ret):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from pb_bss_amd import pipeline
+        Y, init = _pipeline_inputs()
+        ref = pipeline.separate(Y, init, 3, 512, ops=_oracle_ops)
+        got = pipeline.separate(Y, init, 3, 512, shard=shard, gather_output=True,
+                                mask_gather_dtype=gather_dtype, ops=_oracle_ops)
+        ok = all(got[k].shape == ref[k].shape for k in ref)
+        ok = ok and bool((got['mapping'] == ref['mapping']).all())
+        for k in ('masks', 'enhanced', 'bf_vector'):
+            ok = ok and float((got[k] - ref[k]).abs().max()) < 1e-12
+        # without the output gather every rank holds exactly its own block
+        loc = pipeline.separate(Y, init, 3, 512, shard=shard, mask_gather_dtype=gather_dtype,
+                                ops=_oracle_ops)
+        if shard == 'bins':
+            lo, hi = shard_bounds(Y.shape[1], world, rank)
+            ok = ok and float((loc['enhanced'] - ref['enhanced'][:, :, lo:hi]).abs().max()) < 1e-12
+        else:
+            lo, hi = shard_bounds(Y.shape[0], world, rank)
+            ok = ok and float((loc['enhanced'] - ref['enhanced'][lo:hi]).abs().max()) < 1e-12
+        ret[rank] = ok
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('shard,gather_dtype', [('bins', None), ('bins', torch.float32),
+                                                ('utterances', None)])
+def test_config3_chain_sharded_equals_single_process(shard, gather_dtype):
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_pipeline_worker, args=(world, _free_port(), shard, gather_dtype, ret),
+             nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}

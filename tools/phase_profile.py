@@ -33,6 +33,8 @@ def main():
     call = cnt.cpu().numpy().astype(np.float64)
     c = call[:32].reshape(4, 8)
     cs = call[32:64].reshape(4, 8)
+    if call[70] > 0:
+        print(f'  phase F (class 0, fast path): sums+scale+load {call[67]/call[70]:.0f}, trace+Gauss-Jordan {call[68]/call[70]:.0f}, bound+store {call[69]/call[70]:.0f} ticks per call')
     if call[66] > 0:
         print(f'  phase M (wave 0): butterfly {call[64]/call[66]:.0f} ticks, write-back {call[65]/call[66]:.0f} ticks per call')
     nwg = min(nb, 256 * 3)

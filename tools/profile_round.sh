@@ -12,7 +12,7 @@ cd /tmp && export TMPDIR=/tmp
 rm -rf "$OUT/prof_$TAG"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_$TAG/trace" -o p -- $CMD \
   > "$OUT/prof_$TAG.log" 2>&1
-for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU" \
+for grp in "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU" "SQ_WAVE_CYCLES" \
            "SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY" \
            "SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_LDS"; do
   name=$(echo "$grp" | tr ' ' '_' | cut -c1-40)
@@ -20,5 +20,5 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_
     >> "$OUT/prof_$TAG.log" 2>&1
 done
 cd "$ROOT"
-python tools/rocprof_csv_summary.py "$OUT/prof_$TAG" "$CMD" > "$OUT/${TAG}_profile.txt"
+python tools/rocprof_csv_summary.py "$OUT/prof_$TAG" "$CMD" "$(python bench.py --print-source-sha)" > "$OUT/${TAG}_profile.txt"
 cat "$OUT/${TAG}_profile.txt"
