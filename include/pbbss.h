@@ -204,6 +204,23 @@ int pbbss_gev(pbbss_handle_t h, const void* target, const void* noise,
               int64_t N, int D, void* out_w, int32_t* out_status, void* stream);
 
 /* ------------------------------------------------------------------------- */
+/* a11 (use_eig=True)  general, non-Hermitian GEV                              */
+/*     extraction/beamformer.py:352-358 -> cythonized/c_eig.pyx:14-123 (zggev) */
+/*     extraction/beamformer.py:367-411 (scipy.linalg.eig fallback)            */
+/* target, noise (N,D,D) c128, ANY complex matrices with invertible noise (no   */
+/* Hermitian / definiteness assumption).  out_w (N,D): UNIT-2-NORM right        */
+/* eigenvector of the eigenvalue numpy.argmax would pick (largest real part,    */
+/* ties by imaginary part), arbitrary phase -- the reference's normalisation on */
+/* this path, not zhegvd's w^H Phi_nn w = 1.  out_lambda (N) c128 or NULL: that  */
+/* eigenvalue.  status: PBBSS_ST_SINGULAR (noise exactly singular),             */
+/* PBBSS_ST_EIG_NOCONV (the .pyx's "The QZ iteration failed"), PBBSS_ST_NONFINITE. */
+/* 1 <= D <= 32.                                                                */
+/* ------------------------------------------------------------------------- */
+int pbbss_gev_general(pbbss_handle_t h, const void* target, const void* noise,
+                      int64_t N, int D, void* out_w, void* out_lambda,
+                      int32_t* out_status, void* stream);
+
+/* ------------------------------------------------------------------------- */
 /* Batched complex solve  A X = Bm  (numpy.linalg.solve inside stable_solve,   */
 /* math/solve.py:20-114; extraction/beamformer.py:250,277,682).  A (N,D,D),    */
 /* Bm (N,D,M) c128, M <= D.  LU with partial pivoting.  status PBBSS_ST_SINGULAR */

@@ -48,6 +48,27 @@ def gev_vector(target_psd, noise_psd):
     return out.reshape(shape[:-1])
 
 
+def gev_vector_eig(target_psd, noise_psd, return_eigenvalue=False):
+    """`get_gev_vector(..., use_eig=True)`: extraction/beamformer.py:352-358 ->
+    cythonized/c_eig.pyx:14-123 (zggev, eigenvalues alpha/beta, eigenvectors renormalised to unit
+    2-norm :121) or, without the compiled module, :367-411 with scipy.linalg.eig (also unit
+    2-norm).  Both pick numpy.argmax of the COMPLEX eigenvalues (real part first, then imaginary)
+    and make no Hermitian / definiteness assumption.  Phase of the vector: arbitrary."""
+    D = target_psd.shape[-1]
+    shape = target_psd.shape
+    t = target_psd.reshape(-1, D, D)
+    n = noise_psd.reshape(-1, D, D)
+    out = np.empty((t.shape[0], D), dtype=np.complex128)
+    lam = np.empty(t.shape[0], dtype=np.complex128)
+    for f in range(t.shape[0]):
+        vals, vecs = scipy.linalg.eig(t[f], n[f])
+        k = int(np.argmax(vals))
+        out[f] = vecs[:, k] / np.linalg.norm(vecs[:, k])
+        lam[f] = vals[k]
+    out = out.reshape(shape[:-1])
+    return (out, lam.reshape(shape[:-2])) if return_eigenvalue else out
+
+
 def stable_solve(A, B):
     """math/solve.py:20-114: batched solve, per-matrix lstsq on singular ones."""
     A = np.asarray(A)

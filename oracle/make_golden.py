@@ -422,10 +422,55 @@ def sampler_cases():
           eigvec=m.covariance_eigenvectors, eigval=m.covariance_eigenvalues, y=y)
 
 
+def gev_eig_cases():
+    """`get_gev_vector(..., use_eig=True)`: the zggev module compiled from the reference's own
+    c_eig.pyx (oracle/refshim.py:build_cython) AND the scipy.linalg.eig fallback loop, on
+    Hermitian-definite pencils, on a Hermitian pencil whose noise matrix is indefinite, and on
+    pencils that are not Hermitian at all."""
+    import pb_bss.extraction.beamformer as bf
+    assert bf.c_eig_available and bf.c_gev_available, 'build the .pyx first (refshim.load_cython)'
+    rng = np.random.default_rng(23)
+
+    def cn(*s):
+        return rng.standard_normal(s) + 1j * rng.standard_normal(s)
+
+    out = {}
+    for tag, F, D in (('hpd_d6', 17, 6), ('hpd_d8', 9, 8), ('hpd_d3', 5, 3)):
+        X, Nn = cn(F, D, 4 * D), cn(F, D, 5 * D)
+        out[tag + '_target'] = X @ X.conj().swapaxes(-1, -2)
+        out[tag + '_noise'] = Nn @ Nn.conj().swapaxes(-1, -2)
+    X = cn(7, 5, 12)
+    H = cn(7, 5, 5)
+    out['indef_d5_target'] = X @ X.conj().swapaxes(-1, -2)
+    out['indef_d5_noise'] = H + H.conj().swapaxes(-1, -2)          # Hermitian, indefinite
+    out['general_d6_target'] = cn(11, 6, 6)                          # not Hermitian
+    out['general_d6_noise'] = cn(11, 6, 6) + 3 * np.eye(6)
+    out['general_d2_target'] = cn(4, 2, 2)
+    out['general_d2_noise'] = cn(4, 2, 2) + 2 * np.eye(2)
+    for tag in sorted({k.rsplit('_', 1)[0] for k in out}):
+        t, n = out[tag + '_target'], out[tag + '_noise']
+        out[tag + '_w_cython'] = bf.get_gev_vector(t, n, use_eig=True)        # c_eig.pyx / zggev
+        out[tag + '_w_scipy'] = bf._get_gev_vector(t, n, use_eig=True)       # scipy.linalg.eig loop
+        vals, _ = bf._cythonized_eig(t, n)
+        out[tag + '_lambda'] = vals[np.arange(t.shape[0]), np.argmax(vals, axis=1)]
+    # the Hermitian-definite solver of the compiled get_gev_vector.pyx (zhegvd) on the same pencil
+    out['hpd_d6_w_zhegvd'] = bf.get_gev_vector(out['hpd_d6_target'], out['hpd_d6_noise'])
+    _save('gev_use_eig', **out)
+
+
 def main():
+    """python -m oracle.make_golden            -> every fixture of the pure-Python reference
+    python -m oracle.make_golden gev_eig    -> tests/golden/gev_use_eig.npz only (own process:
+    the reference's Cython modules must be injected BEFORE pb_bss.extraction.beamformer is
+    imported, and the other fixtures are defined as the Cython-less reference's output)."""
+    import sys
     os.makedirs(OUT, exist_ok=True)
-    refshim.load()
     warnings.filterwarnings('ignore', category=DeprecationWarning)
+    if sys.argv[1:] == ['gev_eig']:
+        refshim.load_cython()
+        gev_eig_cases()
+        return
+    refshim.load()
     cacgmm_cases()
     cacg_cases()
     beamformer_cases()

@@ -11,9 +11,12 @@ both sides, a periodic window (``window(window_length + 1)[:-1]``), frames every
 samples with the last one zero-padded (``pad=True``) or dropped, ``numpy.fft.rfft(n=size)``;
 the inverse multiplies ``irfft`` frames by the biorthogonal synthesis window
 ``w / sum_m w[n + m shift]^2`` and overlap-adds.  PARITY UNPINNED against nara_wpe itself (it
-cannot be imported here); the restatement is pinned instead by numpy.fft as ground truth for
-every frame, by perfect reconstruction istft(stft(x)) == x, and by a known-answer sinusoid
-(tests/test_oracle_golden.py::test_stft_oracle_properties).
+cannot be imported here, and the reference holds no STFT vector of its own); the restatement is
+pinned instead (i) by two independent third-party implementations with matched window, padding
+and hop -- scipy.signal.stft and torch.stft, tests/test_oracle_golden.py::
+test_stft_oracle_against_scipy_and_torch --, (ii) by numpy.fft as ground truth for every frame, by
+perfect reconstruction istft(stft(x)) == x and by a known-answer sinusoid
+(::test_stft_oracle_properties).
 """
 import numpy as np
 

@@ -9,6 +9,9 @@ int launch_heev(const double* a, int64_t N, int D, double* val, double* vec, int
                 hipStream_t s);
 int launch_gev(const double* t, const double* nn, int64_t N, int D, double* w, int32_t* st,
                hipStream_t s);
+// gev_general.hip: non-Hermitian generalized eigenproblem (use_eig=True)
+int launch_gev_general(const double* t, const double* nn, int64_t N, int D, double* w,
+                       double* lambda, int32_t* st, hipStream_t s);
 int launch_solve(const double* A, const double* Bm, int64_t N, int D, int M, double* x,
                  int32_t* st, hipStream_t s);
 int launch_mvdr_souden(const double* t, const double* nn, int64_t N, int D, double eps, int mode,

@@ -568,6 +568,17 @@ PBBSS_API int pbbss_gev(pbbss_handle_t h, const void* target, const void* noise,
                            N, D, static_cast<double*>(out_w), out_status, as_stream(stream));
 }
 
+PBBSS_API int pbbss_gev_general(pbbss_handle_t h, const void* target, const void* noise,
+                                int64_t N, int D, void* out_w, void* out_lambda,
+                                int32_t* out_status, void* stream) {
+  DeviceGuard device_guard(h);
+  if (!h || !target || !noise || !out_w || N <= 0) return PBBSS_ERR_INVALID_ARG;
+  return pbbss::launch_gev_general(static_cast<const double*>(target),
+                                   static_cast<const double*>(noise), N, D,
+                                   static_cast<double*>(out_w), static_cast<double*>(out_lambda),
+                                   out_status, as_stream(stream));
+}
+
 PBBSS_API int pbbss_solve(pbbss_handle_t h, const void* A, const void* Bm, int64_t N, int D,
                           int M, void* out_x, int32_t* out_status, void* stream) {
   DeviceGuard device_guard(h);

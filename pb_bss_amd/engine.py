@@ -200,6 +200,22 @@ def gev(target, noise):
     return w, st
 
 
+def gev_general(target, noise, want_eigenvalue=False):
+    """pbbss_gev_general: (N,D,D) c128 x2, no Hermitian assumption -> (w (N,D) unit norm,
+    eigenvalue (N,) c128 or None, status (N,))."""
+    t = _t()
+    N, D, _ = target.shape
+    w = t.empty((N, D), dtype=t.complex128, device=target.device)
+    lam = t.empty((N,), dtype=t.complex128, device=target.device) if want_eigenvalue else None
+    st = t.zeros((N,), dtype=t.int32, device=target.device)
+    rc = _lib.load().pbbss_gev_general(
+        _lib.handle(target.device.index), _lib.ptr(target), _lib.ptr(noise), N, D, _lib.ptr(w),
+        _lib.ptr(lam) if lam is not None else None, _lib.ptr(st),
+        _lib.stream_ptr(target.device.index))
+    _lib.check(rc, f'gev_general(N={N},D={D})')
+    return w, lam, st
+
+
 def solve(A, Bm):
     """pbbss_solve: A (N,D,D), Bm (N,D,M) c128 -> (X, status)."""
     t = _t()

@@ -130,15 +130,19 @@ def get_mvdr_vector(atf_vector, noise_psd_matrix):
 
 def get_gev_vector(target_psd_matrix, noise_psd_matrix, force_cython=False,
                    use_eig=False):
-    """Principal generalised eigenvector of (target, noise), normalised like
-    LAPACK zhegvd (w^H Phi_nn w = 1).  Reference: beamformer.py:292-364 and
-    cythonized/get_gev_vector.pyx:42-150.
+    """GEV beamforming vector.  Reference: beamformer.py:292-364.
 
-    `force_cython` / `use_eig` are accepted for signature compatibility: there
-    is one native solver here (Cholesky reduction + Jacobi, Hermitian-definite).
-    A noise PSD that is not positive definite raises ValueError under
-    force_cython (the .pyx message) and numpy.linalg.LinAlgError otherwise
-    (what the reference's SciPy fallback, :395-410, ends with).
+    use_eig=False (default): principal generalised eigenvector of the Hermitian-definite
+    pencil, normalised like LAPACK zhegvd (w^H Phi_nn w = 1) -- cythonized/
+    get_gev_vector.pyx:42-150 / the `eigh` fallback :367-411.  A noise PSD that is not
+    positive definite raises ValueError under force_cython (the .pyx message) and
+    numpy.linalg.LinAlgError otherwise (what the reference's SciPy fallback ends with).
+
+    use_eig=True: the `eig` path (c_eig.pyx:14-123 zggev / scipy.linalg.eig, :352-358,
+    :395-410): NO Hermitian or definiteness assumption, the eigenvalue numpy.argmax picks among
+    the complex eigenvalues, UNIT-2-NORM eigenvector (the reference's normalisation on this
+    path).  Like the reference it "crashes less often": only an exactly singular noise matrix
+    or a failed QR iteration raise.
     """
     assert noise_psd_matrix is not None
     like_torch = _lib.is_torch(target_psd_matrix)
@@ -147,6 +151,24 @@ def get_gev_vector(target_psd_matrix, noise_psd_matrix, force_cython=False,
     D = a.shape[-1]
     assert D == a.shape[-2], a.shape
     assert a.shape == b.shape, (a.shape, b.shape)
+    if use_eig:
+        w, _, st = engine.gev_general(a.reshape(-1, D, D).contiguous(),
+                                      b.reshape(-1, D, D).contiguous())
+        bad = (st != 0).nonzero()
+        if bad.numel():
+            f = int(bad[0].item())
+            code = int(st[f].item())
+            if code & _lib.ST_EIG_NOCONV:
+                msg = ('The QZ iteration failed.  No eigenvectors have been calculated '
+                       f'for frequency {f}')  # c_eig.pyx:104-108
+                if force_cython:
+                    raise ValueError(msg)
+            elif code & _lib.ST_SINGULAR:
+                msg = f'noise PSD matrix of frequency {f} is exactly singular'
+            else:
+                msg = f'non-finite eigenvalue for frequency {f}'
+            raise np.linalg.LinAlgError(f'Error for frequency {f}\n{msg}')  # :403-407
+        return _res(w.reshape(a.shape[:-1]), like_torch)
     w, st = engine.gev(a.reshape(-1, D, D).contiguous(), b.reshape(-1, D, D).contiguous())
     bad = (st != 0).nonzero()
     if bad.numel():

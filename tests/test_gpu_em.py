@@ -78,16 +78,19 @@ def test_config1_plumbing_shape():
 
 
 def test_config2_full_100_iterations():
-    """BASELINE config 2 (the headline): F=513, T=500, D=8, K=3, 100 iterations,
-    masks within 1e-5 max-abs of the float64 reference path."""
+    """BASELINE config 2 (the headline): F=513, T=500, D=8, K=3, 100 iterations.
+    The contract (BASELINE north_star) is 1e-5 max-abs against the float64 reference path; the
+    measured error is ~2e-11, so the assertion sits at 1e-8 -- three decades of regression
+    head-room are kept, not six."""
     from oracle import synth
+    CONTRACT_TOL = 1e-5
     Y, init = synth.make_stft(513, 500, 8, 3, seed=0)
     m, mask = _oracle_fit(Y, init, 100)
     r = _device_fit(Y, init, 100)
     err = np.abs(_host(r['affiliation']) - mask).max()
-    assert err < 1e-5, err
+    assert err < 1e-8 < CONTRACT_TOL, err
     cov = _cov(_host(r['eigvec']), _host(r['eigval']))
-    assert np.abs(cov - _cov(m['eigvec'], m['eigval'])).max() < 1e-5
+    assert np.abs(cov - _cov(m['eigvec'], m['eigval'])).max() < 1e-8
 
 
 def test_force_eig_equals_fast_path():
@@ -116,6 +119,37 @@ def test_rank_deficient_hits_floor():
     # float64 implementations agree only to ~1e-6 per step here.
     assert np.abs(_host(r['eigval']) - m['eigval']).max() < 1e-4
     assert np.abs(_host(r['affiliation']) - mask).max() < 1e-3
+    # ... but the DECISION "this eigenvalue is floored" must agree bin by bin, class by class and
+    # eigenvalue by eigenvalue: the reference leaves exactly eigenvalue_floor (1e-10) in the
+    # floored slots (cacg.py:121), and the device status bit must be set for exactly the
+    # (bin, class) pairs that contain one
+    floored_ref = (m['eigval'] == 1e-10)
+    floored_dev = (_host(r['eigval']) == 1e-10)
+    assert (floored_ref == floored_dev).all()
+    assert floored_ref.any(-1).all()
+    assert ((st & _lib.ST_FLOORED) != 0).tolist() == floored_ref.any(-1).tolist()
+
+
+def test_floor_decision_matches_reference_on_mixed_conditioning():
+    """Bins of full rank next to rank-deficient ones in ONE launch: the floored / not-floored
+    decision (status bit and the eigenvalue slots equal to the floor) matches the oracle per
+    (bin, class); well-conditioned bins stay on the Gauss-Jordan fast path (no SLOWPATH bit)."""
+    from oracle import synth
+    from pb_bss_amd import _lib
+    Ya, ia = synth.make_rank_deficient(5, 200, 6, 2, rank=3, seed=7)
+    Yb, ib = synth.make_stft(6, 200, 6, 2, seed=8)
+    Y = np.concatenate([Ya, Yb, Ya[:2]])
+    init = np.concatenate([ia, ib, ia[:2]])
+    m, mask = _oracle_fit(Y, init, 4)
+    r = _device_fit(Y, init, 4)
+    st = _host(r['status'])
+    floored_ref = (m['eigval'] == 1e-10)
+    assert ((_host(r['eigval']) == 1e-10) == floored_ref).all()
+    assert (((st & _lib.ST_FLOORED) != 0) == floored_ref.any(-1)).all()
+    assert floored_ref[:5].all(-1).sum() == 0 and floored_ref[:5].any(-1).all()
+    assert not floored_ref[5:11].any()
+    assert ((st[5:11] & _lib.ST_SLOWPATH) == 0).all()
+    assert np.abs(_host(r['affiliation'])[5:11] - mask[5:11]).max() < 1e-9
 
 
 def test_white_noise_worst_conditioning():

@@ -145,3 +145,51 @@ def test_mvdr_souden_known_answer_and_stable_solve():
     assert np.abs(w.imag).max() == 0
     X = ex.stable_solve(g['solve_A'], g['solve_B'])
     assert np.abs(X - g['solve_X']).max() < 1e-9  # incl. the singular ones (lstsq branch)
+
+
+GEV_EIG_TAGS = ('hpd_d6', 'hpd_d8', 'hpd_d3', 'indef_d5', 'general_d6', 'general_d2')
+
+
+@pytest.mark.parametrize('tag', GEV_EIG_TAGS)
+def test_gev_use_eig_matches_reference(tag):
+    """get_gev_vector(use_eig=True) on the device against the reference's zggev module
+    (c_eig.pyx, compiled from /root/reference) and its scipy.linalg.eig loop: unit-norm
+    eigenvector of numpy.argmax(eigenvalues), no Hermitian / definiteness assumption."""
+    from pb_bss_amd import _lib, engine
+    from pb_bss_amd.extraction import get_gev_vector
+    g = load('gev_use_eig')
+    t, n = g[tag + '_target'], g[tag + '_noise']
+    w = get_gev_vector(t, n, use_eig=True)
+    assert w.shape == t.shape[:-1]
+    assert np.abs(np.linalg.norm(w, axis=-1) - 1).max() < 1e-12        # unit 2-norm, not w^H N w = 1
+    for ref in ('_w_cython', '_w_scipy'):
+        assert np.abs(cos_sim(w, g[tag + ref]) - 1).max() < 1e-9, ref
+    _, lam, st = engine.gev_general(_lib.to_device(t), _lib.to_device(n), want_eigenvalue=True)
+    assert int(st.abs().max().item()) == 0
+    lam = _lib.to_host(lam)
+    assert np.abs(lam - g[tag + '_lambda']).max() < 1e-9 * np.abs(lam).max()
+    # leading axes are flattened like everywhere else
+    w2 = get_gev_vector(t[None], n[None], use_eig=True)
+    assert w2.shape == (1,) + t.shape[:-1]
+
+
+def test_gev_use_eig_differs_from_default_only_in_scale_on_hpd_pencils():
+    from pb_bss_amd.extraction import get_gev_vector
+    g = load('gev_use_eig')
+    t, n = g['hpd_d6_target'], g['hpd_d6_noise']
+    w_eig = get_gev_vector(t, n, use_eig=True)
+    w_def = get_gev_vector(t, n)
+    assert np.abs(cos_sim(w_eig, w_def) - 1).max() < 1e-9
+    q = np.einsum('fd,fde,fe->f', w_def.conj(), n, w_def).real
+    assert np.abs(q - 1).max() < 1e-9                                  # zhegvd normalisation
+    assert np.abs(cos_sim(w_def, g['hpd_d6_w_zhegvd']) - 1).max() < 1e-9
+
+
+def test_gev_use_eig_singular_noise_raises():
+    from pb_bss_amd.extraction import get_gev_vector
+    rng = np.random.default_rng(3)
+    t = rng.standard_normal((3, 4, 4)) + 1j * rng.standard_normal((3, 4, 4))
+    n = np.tile(np.eye(4, dtype=np.complex128), (3, 1, 1))
+    n[1] = 0
+    with pytest.raises(np.linalg.LinAlgError):
+        get_gev_vector(t, n, use_eig=True)

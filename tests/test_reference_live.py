@@ -97,3 +97,40 @@ def test_oracle_gmm_equals_live_reference_on_fresh_inputs(ref):
     np.testing.assert_allclose(oc, g.covariance, atol=1e-12)
     np.testing.assert_allclose(oe.gaussian_log_pdf(y[None], om, oc, 'full'), g.log_pdf(y[None]),
                                rtol=1e-10, atol=1e-9)
+
+
+def test_gev_use_eig_fixture_equals_reference_cython_modules():
+    """The reference's two native files compile out of tree (oracle/refshim.py:build_cython ->
+    oracle/_ref/); with them injected, `get_gev_vector(use_eig=True)` runs c_eig.pyx (zggev) and
+    the default path get_gev_vector.pyx (zhegvd).  The committed fixture is what they produce
+    today, and the oracle agrees with them on fresh pencils.  Runs in a subprocess: the modules
+    must be injected before pb_bss.extraction.beamformer is imported."""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys, warnings
+import numpy as np
+warnings.simplefilter('ignore')
+from oracle import refshim, beamformer as ob
+refshim.load_cython()
+import pb_bss.extraction.beamformer as bf
+assert bf.c_gev_available and bf.c_eig_available
+g = np.load(os.path.join('tests', 'golden', 'gev_use_eig.npz'))
+cos = lambda a, b: np.abs((a.conj() * b).sum(-1)) / np.linalg.norm(a, axis=-1) / np.linalg.norm(b, axis=-1)
+for tag in ('hpd_d6', 'indef_d5', 'general_d6'):
+    w = bf.get_gev_vector(g[tag + '_target'], g[tag + '_noise'], use_eig=True)
+    assert np.abs(cos(w, g[tag + '_w_cython']) - 1).max() < 1e-12, tag
+rng = np.random.default_rng(99)
+A = rng.standard_normal((6, 5, 5)) + 1j * rng.standard_normal((6, 5, 5))
+B = rng.standard_normal((6, 5, 5)) + 1j * rng.standard_normal((6, 5, 5)) + 2 * np.eye(5)
+assert np.abs(cos(bf.get_gev_vector(A, B, use_eig=True), ob.gev_vector_eig(A, B)) - 1).max() < 1e-12
+X = rng.standard_normal((6, 5, 20)) + 1j * rng.standard_normal((6, 5, 20))
+P = X @ X.conj().swapaxes(-1, -2)
+Q = P + np.eye(5)
+assert np.abs(cos(bf.get_gev_vector(P, Q), ob.gev_vector(P, Q)) - 1).max() < 1e-12   # zhegvd module
+print('OK')
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, '-c', code], cwd=root, capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0 and 'OK' in out.stdout, out.stderr[-2000:]
