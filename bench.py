@@ -69,6 +69,9 @@ def parse():
     p.add_argument('--utterances', type=int, default=64, help='config3 batch size')
     p.add_argument('--mask-gather', choices=['f64', 'f32'], default='f64',
                    help='config3 --shard bins: dtype of the mask all-gather')
+    p.add_argument('--comm', choices=['torch', 'native'], default='torch',
+                   help='mask all-gather through torch.distributed (RCCL) or through the '
+                        'library\'s own RCCL communicator (C ABI pbbss_allgather_masks)')
     p.add_argument('--print-source-sha', action='store_true',
                    help='print the hash of the EM kernel sources (tools/profile_round.sh stamps '
                         'it into the profile summaries) and exit')
@@ -221,6 +224,8 @@ def cpu_baseline_em(Y0, init0, iters):
 def emit(line, use_dist):
     import torch.distributed as dist
     if use_dist:
+        from pb_bss_amd import sharding
+        sharding.destroy_native_comm()
         dist.destroy_process_group()
     if line is not None:
         # RCCL writes a version banner through C stdio; when stdout is a pipe it sits in libc's
@@ -250,6 +255,9 @@ def setup(args):
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         dist.init_process_group('nccl', device_id=dev)
+        if args.comm == 'native':
+            from pb_bss_amd import sharding
+            sharding.init_native_comm(device_index=local_rank)
     return world, rank, local_rank, dev, use_dist
 
 
@@ -448,7 +456,7 @@ def main():
                             'complex64 STFT resident in HBM, fit_predict',
                 'em_iterations_per_step': args.iters, 'utterances': world,
                 'sharding': (f'frequency bins, {n_loc} of {F} per rank per utterance; RCCL mask '
-                             'all-gather per step, in stream order after the EM kernel') if use_dist else 'none (1 GPU)',
+                             'all-gather per step (' + args.comm + ' communicator), in stream order after the EM kernel') if use_dist else 'none (1 GPU)',
             },
             'roofline': roofline_block(kernel_ms, world * n_loc, args.iters),
         }

@@ -572,6 +572,38 @@ int pbbss_istft(pbbss_handle_t h, const void* X, int x_is_c128, int64_t C, int T
 /* of the most recent call (the roofline figure needs the kernel duration on   */
 /* the launch stream; torch.cuda.Event only sees torch's current stream).      */
 /* ------------------------------------------------------------------------- */
+/* ------------------------------------------------------------------------- */
+/* (e)  Multi-GPU: frequency bins sharded over the GPUs of one node, ONE        */
+/* exchange step -- the all-gather of the posterior masks before permutation    */
+/* alignment (permutation_alignment.py:334 needs all bins of an utterance;      */
+/* the EM itself needs no collective under weight_constant_axis=(-1,),          */
+/* cacgmm.py:151, :204).  One process per GPU; the RCCL communicator lives in   */
+/* the handle.  Rank 0 calls pbbss_comm_unique_id (128 bytes), the host carries */
+/* the id to the other ranks (MPI, a file, a socket, torch.distributed ...),    */
+/* every rank calls pbbss_comm_create.  RCCL is dlopen()ed on first use:        */
+/* PBBSS_ERR_UNSUPPORTED where librccl is absent.                               */
+/*                                                                             */
+/* pbbss_shard_bounds: the contiguous block [start, stop) of `total_bins` owned */
+/* by `rank` (sizes differ by at most one: 513 over 8 ranks = 65 + 7 x 64).     */
+/* pbbss_allgather_masks: local (outer, stop - start, inner) -> out (outer,     */
+/* total_bins, inner) on every rank; elem_bytes 8 (float64) or 4 (float32);     */
+/* e.g. masks (U, F_local, K, T): outer = U, inner = K * T.  Enqueued on        */
+/* `stream`: pad to the largest block, one ncclAllGather, trim.                 */
+/* pbbss_allgather_unpack: the trimming half on its own (gathered = (world,     */
+/* outer, ceil(total_bins / world), inner)) for hosts that bring their own      */
+/* collective.                                                                 */
+/* ------------------------------------------------------------------------- */
+int pbbss_comm_unique_id(void* out_id_128_bytes);
+int pbbss_comm_create(pbbss_handle_t h, const void* unique_id, int world_size, int rank);
+int pbbss_comm_destroy(pbbss_handle_t h);
+int pbbss_shard_bounds(int64_t total_bins, int world_size, int rank, int64_t* out_start,
+                       int64_t* out_stop);
+int pbbss_allgather_masks(pbbss_handle_t h, const void* local, int elem_bytes, int64_t outer,
+                          int64_t total_bins, int64_t inner, void* out, void* stream);
+int pbbss_allgather_unpack(pbbss_handle_t h, const void* gathered, int elem_bytes,
+                           int world_size, int64_t outer, int64_t total_bins, int64_t inner,
+                           void* out, void* stream);
+
 int pbbss_set_timing(pbbss_handle_t h, int enable);
 /* Tail handling of pbbss_cacgmm_fit (on by default): when B = m * CUs + r with 1 <= r <= 8
  * (e.g. 513 = 2 * 256 + 1 frequency bins) the r remainder problems are run as "split"

@@ -37,6 +37,8 @@ EXPORTS = (
     'pbbss_version', 'pbbss_error_string', 'pbbss_create', 'pbbss_destroy',
     'pbbss_normalize_observation', 'pbbss_cacgmm_fit', 'pbbss_cacgmm_predict',
     'pbbss_cacg_m_step', 'pbbss_heev_batched', 'pbbss_psd', 'pbbss_gev', 'pbbss_gev_general',
+    'pbbss_comm_unique_id', 'pbbss_comm_create', 'pbbss_comm_destroy', 'pbbss_shard_bounds',
+    'pbbss_allgather_masks', 'pbbss_allgather_unpack',
     'pbbss_solve', 'pbbss_mvdr_souden', 'pbbss_mvdr', 'pbbss_ban',
     'pbbss_apply_beamforming_vector', 'pbbss_set_timing',
     'pbbss_last_kernel_ms', 'pbbss_set_phase_profile',
@@ -172,6 +174,12 @@ def load():
         lib.pbbss_psd.argtypes = [vp, vp, i32, i64, i32, i32, i32, vp, i32, vp, vp]
         lib.pbbss_gev.argtypes = [vp, vp, vp, i64, i32, vp, vp, vp]
         lib.pbbss_gev_general.argtypes = [vp, vp, vp, i64, i32, vp, vp, vp, vp]
+        lib.pbbss_comm_unique_id.argtypes = [vp]
+        lib.pbbss_comm_create.argtypes = [vp, vp, i32, i32]
+        lib.pbbss_comm_destroy.argtypes = [vp]
+        lib.pbbss_shard_bounds.argtypes = [i64, i32, i32, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
+        lib.pbbss_allgather_masks.argtypes = [vp, vp, i32, i64, i64, i64, vp, vp]
+        lib.pbbss_allgather_unpack.argtypes = [vp, vp, i32, i32, i64, i64, i64, vp, vp]
         lib.pbbss_solve.argtypes = [vp, vp, vp, i64, i32, i32, vp, vp, vp]
         lib.pbbss_mvdr_souden.argtypes = [vp, vp, vp, i64, i32, dbl, vp, vp, vp, vp, vp]
         lib.pbbss_mvdr.argtypes = [vp, vp, vp, i64, i32, vp, vp, vp]

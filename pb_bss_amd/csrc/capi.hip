@@ -11,6 +11,7 @@
 #include "generic_bf.hpp"
 #include "stft.hpp"
 #include "em_launch.hpp"
+#include "comm.hpp"
 
 #define PBBSS_API extern "C" __attribute__((visibility("default")))
 
@@ -21,6 +22,8 @@ struct pbbss_handle_s {
   size_t scratch_bytes;
   void* work;         // second grow-only slab: workspaces of the multi-kernel mixture loops
   size_t work_bytes;
+  void* comm;         // RCCL communicator of pbbss_comm_create (one rank = this process), or null
+  int comm_world, comm_rank;
   void* team_buf;     // control words + centroid partials of the DHTV team kernel
   size_t team_bytes;
   int dhtv_team;      // workgroups per utterance (0 = default, 1 = one-workgroup kernel)
@@ -219,6 +222,9 @@ PBBSS_API int pbbss_create(pbbss_handle_t* out, int device_id) {
     h->team_bytes = 0;
   }
   h->dhtv_team = 0;
+  h->comm = nullptr;
+  h->comm_world = 1;
+  h->comm_rank = 0;
   if (const char* tv = getenv("PBBSS_DHTV_TEAM")) h->dhtv_team = atoi(tv);
   h->prof = nullptr;
   h->timing = 0;
@@ -237,6 +243,7 @@ PBBSS_API int pbbss_destroy(pbbss_handle_t h) {
   (void)hipEventDestroy(h->ev1);
   if (h->scratch) (void)hipFree(h->scratch);
   if (h->work) (void)hipFree(h->work);
+  if (h->comm) (void)pbbss::comm_destroy(h->comm);
   if (h->team_buf) (void)hipFree(h->team_buf);
   if (h->cfg.xbuf) (void)hipFree(h->cfg.xbuf);
   if (h->cfg.side_stream) (void)hipStreamDestroy(h->cfg.side_stream);
@@ -244,6 +251,87 @@ PBBSS_API int pbbss_destroy(pbbss_handle_t h) {
   (void)hipEventDestroy(h->cfg.ev_join);
   delete h;
   return PBBSS_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Multi-GPU: RCCL communicator in the handle + the mask all-gather (comm.hip)
+// ---------------------------------------------------------------------------
+PBBSS_API int pbbss_comm_unique_id(void* out_id) {
+  if (!out_id) return PBBSS_ERR_INVALID_ARG;
+  return pbbss::comm_unique_id(out_id);
+}
+
+PBBSS_API int pbbss_comm_create(pbbss_handle_t h, const void* unique_id, int world_size, int rank) {
+  DeviceGuard device_guard(h);
+  if (!h || !unique_id || world_size < 1 || rank < 0 || rank >= world_size)
+    return PBBSS_ERR_INVALID_ARG;
+  if (h->comm) return PBBSS_ERR_INVALID_ARG;  // one communicator per handle
+  void* c = nullptr;
+  const int rc = pbbss::comm_create(unique_id, world_size, rank, &c);
+  if (rc != PBBSS_OK) return rc;
+  h->comm = c;
+  h->comm_world = world_size;
+  h->comm_rank = rank;
+  return PBBSS_OK;
+}
+
+PBBSS_API int pbbss_comm_destroy(pbbss_handle_t h) {
+  DeviceGuard device_guard(h);
+  if (!h) return PBBSS_ERR_INVALID_ARG;
+  const int rc = pbbss::comm_destroy(h->comm);
+  h->comm = nullptr;
+  h->comm_world = 1;
+  h->comm_rank = 0;
+  return rc;
+}
+
+PBBSS_API int pbbss_shard_bounds(int64_t total_bins, int world_size, int rank, int64_t* out_start,
+                                 int64_t* out_stop) {
+  if (total_bins < 0 || world_size < 1 || rank < 0 || rank >= world_size || !out_start || !out_stop)
+    return PBBSS_ERR_INVALID_ARG;
+  const int64_t base = total_bins / world_size, extra = total_bins % world_size;
+  *out_start = rank * base + (rank < extra ? rank : extra);
+  *out_stop = *out_start + base + (rank < extra ? 1 : 0);
+  return PBBSS_OK;
+}
+
+PBBSS_API int pbbss_allgather_unpack(pbbss_handle_t h, const void* gathered, int elem_bytes,
+                                     int world_size, int64_t outer, int64_t total_bins,
+                                     int64_t inner, void* out, void* stream) {
+  DeviceGuard device_guard(h);
+  if (!h || !gathered || !out || world_size < 1 || outer < 0 || total_bins < 0 || inner < 0)
+    return PBBSS_ERR_INVALID_ARG;
+  if (elem_bytes != 4 && elem_bytes != 8) return PBBSS_ERR_UNSUPPORTED;
+  return pbbss::launch_allgather_unpack(gathered, elem_bytes, world_size, outer, total_bins, inner,
+                                        out, as_stream(stream));
+}
+
+PBBSS_API int pbbss_allgather_masks(pbbss_handle_t h, const void* local, int elem_bytes,
+                                    int64_t outer, int64_t total_bins, int64_t inner, void* out,
+                                    void* stream) {
+  DeviceGuard device_guard(h);
+  if (!h || !out || outer < 0 || total_bins < 0 || inner < 0) return PBBSS_ERR_INVALID_ARG;
+  if (elem_bytes != 4 && elem_bytes != 8) return PBBSS_ERR_UNSUPPORTED;
+  if (!h->comm) return PBBSS_ERR_INVALID_ARG;  // pbbss_comm_create first
+  const int world = h->comm_world;
+  int64_t lo = 0, hi = 0;
+  (void)pbbss_shard_bounds(total_bins, world, h->comm_rank, &lo, &hi);
+  const int64_t nloc = hi - lo, pad = (total_bins + world - 1) / world;
+  if (nloc > 0 && !local) return PBBSS_ERR_INVALID_ARG;
+  const size_t block = (size_t)outer * pad * inner * elem_bytes;
+  if (block == 0) return PBBSS_OK;
+  void* w = handle_work(h, WorkCarver::pad(block) + WorkCarver::pad(block * world));
+  if (!w) return PBBSS_ERR_HIP;
+  WorkCarver wc(w);
+  char* packed = wc.take<char>(block);
+  char* gathered = wc.take<char>(block * world);
+  hipStream_t s = as_stream(stream);
+  int rc = pbbss::launch_allgather_pack(local, elem_bytes, outer, nloc, pad, inner, packed, s);
+  if (rc != PBBSS_OK) return rc;
+  rc = pbbss::comm_all_gather_bytes(h->comm, packed, gathered, block, s);
+  if (rc != PBBSS_OK) return rc;
+  return pbbss::launch_allgather_unpack(gathered, elem_bytes, world, outer, total_bins, inner, out,
+                                        s);
 }
 
 PBBSS_API int pbbss_set_timing(pbbss_handle_t h, int enable) {

@@ -20,7 +20,11 @@ there are at least as many utterances as GPUs.
 """
 import numpy as np
 
-__all__ = ['shard_bounds', 'shard_sizes', 'all_gather_bins', 'fit_predict_sharded']
+__all__ = ['shard_bounds', 'shard_sizes', 'all_gather_bins', 'fit_predict_sharded',
+           'init_native_comm', 'destroy_native_comm']
+
+# device index -> (world, rank) of the RCCL communicator created in the library handle
+_NATIVE_COMM = {}
 
 
 def shard_sizes(num_bins, world_size):
@@ -37,12 +41,76 @@ def shard_bounds(num_bins, world_size, rank):
     return start, start + sizes[rank]
 
 
+def init_native_comm(group=None, device_index=None):
+    """Create the library's own RCCL communicator for this rank (C ABI `pbbss_comm_create`,
+    csrc/comm.hip): rank 0 draws the 128-byte unique id, torch.distributed (any backend) carries
+    it to the other ranks -- the only thing the Python host contributes; a C++ / Go / Java host
+    would use MPI or a socket.  Afterwards `all_gather_bins` on CUDA tensors goes through
+    `pbbss_allgather_masks` instead of torch.distributed."""
+    import ctypes
+    import torch
+    import torch.distributed as dist
+    from . import _lib
+    if device_index is None:
+        device_index = torch.cuda.current_device()
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    uid = ctypes.create_string_buffer(128)
+    if rank == 0:
+        _lib.check(_lib.load().pbbss_comm_unique_id(uid), 'comm_unique_id')
+    box = [bytes(uid.raw)]
+    dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0,
+                               group=group)
+    _lib.check(_lib.load().pbbss_comm_create(_lib.handle(device_index), box[0], world, rank),
+               'comm_create')
+    _NATIVE_COMM[device_index] = (world, rank)
+
+
+def destroy_native_comm(device_index=None):
+    import torch
+    from . import _lib
+    if device_index is None:
+        device_index = torch.cuda.current_device()
+    if _NATIVE_COMM.pop(device_index, None) is not None:
+        _lib.check(_lib.load().pbbss_comm_destroy(_lib.handle(device_index)), 'comm_destroy')
+
+
+def _native_all_gather(local, num_bins, bin_axis):
+    """`pbbss_allgather_masks`: (outer, n_local, inner) -> (outer, num_bins, inner), any 4- or
+    8-byte element type (the kernels only move bits), complex128 as pairs of float64."""
+    import torch
+    from . import _lib
+    x = local.contiguous()
+    if x.dtype == torch.complex128:
+        full = _native_all_gather(torch.view_as_real(x), num_bins, bin_axis)
+        return torch.view_as_complex(full.contiguous())
+    shape = list(x.shape)
+    outer = int(np.prod(shape[:bin_axis], dtype=np.int64))
+    inner = int(np.prod(shape[bin_axis + 1:], dtype=np.int64))
+    out_shape = shape[:bin_axis] + [num_bins] + shape[bin_axis + 1:]
+    out = torch.empty(out_shape, dtype=x.dtype, device=x.device)
+    rc = _lib.load().pbbss_allgather_masks(
+        _lib.handle(x.device.index), _lib.ptr(x) if x.numel() else None, x.element_size(), outer,
+        num_bins, inner, _lib.ptr(out), _lib.stream_ptr(x.device.index))
+    _lib.check(rc, f'allgather_masks(outer={outer}, bins={num_bins}, inner={inner})')
+    return out
+
+
 def all_gather_bins(local, num_bins, bin_axis=0, group=None):
     """All-gather a tensor sharded along `bin_axis` into the full (num_bins, ...)
     tensor on every rank.  `local` holds this rank's block (shard_bounds).
-    Works for CUDA tensors (RCCL) and CPU tensors (gloo)."""
+    CUDA tensors go through the library's own RCCL communicator when `init_native_comm` has
+    created one (C ABI `pbbss_allgather_masks`), otherwise -- and for CPU tensors (gloo) --
+    through torch.distributed; both pad to the largest block, gather once and trim."""
     import torch
     import torch.distributed as dist
+    bin_axis = bin_axis % local.ndim
+    if (local.is_cuda and group is None and local.device.index in _NATIVE_COMM
+            and local.element_size() in (4, 8, 16) and
+            (local.element_size() != 16 or local.dtype == torch.complex128)):
+        world, rank = _NATIVE_COMM[local.device.index]
+        assert local.shape[bin_axis] == shard_sizes(num_bins, world)[rank], (
+            local.shape, shard_sizes(num_bins, world), rank)
+        return _native_all_gather(local, num_bins, bin_axis)
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     sizes = shard_sizes(num_bins, world)

@@ -85,3 +85,19 @@ def test_product_package_does_not_import_oracle():
                     src = fh.read()
                 assert not re.search(r'^\s*(from|import)\s+oracle\b', src, re.M), f
                 assert '/root/reference' not in src, f
+
+
+def test_shard_bounds_c_abi_matches_python():
+    """pbbss_shard_bounds (pure host code, no GPU needed) == pb_bss_amd.sharding.shard_bounds."""
+    import ctypes
+    from pb_bss_amd import _lib
+    from pb_bss_amd.sharding import shard_bounds
+    lib = _lib.load()
+    for F in (0, 1, 5, 8, 129, 257, 513):
+        for world in (1, 2, 3, 8, 16):
+            for rank in range(world):
+                lo, hi = ctypes.c_int64(-1), ctypes.c_int64(-1)
+                assert lib.pbbss_shard_bounds(F, world, rank, ctypes.byref(lo), ctypes.byref(hi)) == 0
+                assert (lo.value, hi.value) == shard_bounds(F, world, rank), (F, world, rank)
+    bad = ctypes.c_int64(0)
+    assert lib.pbbss_shard_bounds(5, 2, 2, ctypes.byref(bad), ctypes.byref(bad)) != 0
