@@ -384,6 +384,11 @@ int pbbss_cwmm_fit(pbbss_handle_t h, const void* y, int64_t B, int T, int D, int
 /* ------------------------------------------------------------------------- */
 #define PBBSS_EMBED_VMF 0             /* VonMisesFisher                       */
 #define PBBSS_EMBED_GAUSS_SPHERICAL 1 /* SphericalGaussian                    */
+#define PBBSS_EMBED_GAUSS_FULL 2      /* Gaussian (pbbss_joint_fit; single fits: pbbss_gauss_full_*) */
+#define PBBSS_EMBED_GAUSS_DIAG 3      /* DiagonalGaussian: `scale` (K,E) per-dimension variances,
+                                       * B = 1; the log-pdf is evaluated AS THE REFERENCE WRITES
+                                       * IT (gaussian.py:76-97 hands the (K,E) precision array to
+                                       * einsum as one K x E matrix shared by all classes) */
 
 /* VonMisesFisher.log_pdf (von_mises_fisher.py:62-78; rows are unit-normalised   */
 /* first) / SphericalGaussian.log_pdf (gaussian.py:116-137): out (B,K,N) f64.    */
@@ -395,6 +400,17 @@ int pbbss_embed_log_pdf(pbbss_handle_t h, const void* y, int y_is_f64, int64_t B
 /* the row normalisation of .fit, :105-107) / GaussianTrainer._fit with           */
 /* covariance_type='spherical' (gaussian.py:152-193).  weights (B,K,N) f64 are    */
 /* the per-class saliencies.  out_mean (B,K,E), out_scale (B,K).                  */
+/* estimate_mixture_weight (distribution/mixture_model_utils.py:133-203) with reductions    */
+/* over independent axes -- the options that couple frequency bins (weight_constant_axis    */
+/* containing -3 ...): affiliation (Bo, Bi, K, N) f64, saliency (Bo, Bi, N) or NULL;          */
+/* reduce_inner: average over Bi, reduce_n: over N (keepdims) -> out (Bo, Bi', K, N').        */
+/* No saliency: mean (:188); saliency: masked sums L1-normalised over the classes with the   */
+/* reference's `where(norm == 0, 1e-10)` (:190-201).  Serves the step-wise fit.               */
+int pbbss_estimate_mixture_weight(pbbss_handle_t h, const double* affiliation,
+                                  const double* saliency, int64_t Bo, int64_t Bi, int K,
+                                  int64_t N, int reduce_inner, int reduce_n,
+                                  double* out_weight, void* stream);
+
 int pbbss_embed_fit(pbbss_handle_t h, const void* y, int y_is_f64, int64_t B,
                     int64_t N, int E, int K, int kind, int normalize,
                     const double* weights, double min_concentration,
@@ -484,10 +500,15 @@ int pbbss_gmm_fit(pbbss_handle_t h, const void* y, int64_t B, int64_t N, int E, 
 #define PBBSS_JOINT_WEIGHT_KT 3       /* (-3,)        -> weight (K,T)          */
 #define PBBSS_JOINT_WEIGHT_CONST 4    /* (-3,-2,-1)   -> weight (1) = 1        */
 /* Initialisation: gamma0 (F,K,T), or (iterations == 0) a model (in_eigvec c128    */
-/* (F,K,D,D), in_eigval (F,K,D), in_weight (shape above), in_mean (K,E), in_scale  */
-/* (K)).  With gamma0, a non-NULL in_scale is the `fixed_covariance` of            */
-/* gcacgmm.py:305-312.  saliency (F,T) or NULL.  Outputs as the inputs' shapes;    */
-/* out_status int32 (F,K); out_affiliation (F,K,T) = model.predict (final_predict). */
+/* (F,K,D,D), in_eigval (F,K,D), in_weight (shape above), in_mean (K,E), in_scale). */
+/* in_scale / out_scale by opts->kind: VMF concentration (K); GAUSS_SPHERICAL       */
+/* variance (K); GAUSS_DIAG per-dimension variances (K,E); GAUSS_FULL covariance    */
+/* (K,E,E), E <= 63 (`covariance_type` of GCACGMMTrainer.fit, gcacgmm.py:141,       */
+/* :297-303 -> GaussianTrainer._fit, gaussian.py:152-193).  With gamma0, a non-NULL */
+/* in_scale is the `fixed_covariance` of gcacgmm.py:305-312.  saliency (F,T) or     */
+/* NULL.  Outputs as the inputs' shapes; out_status int32 (F,K), for GAUSS_FULL     */
+/* word 0 also carries PBBSS_ST_NOT_POSDEF of the spectral covariances;             */
+/* out_affiliation (F,K,T) = model.predict (final_predict).                         */
 int pbbss_joint_fit(pbbss_handle_t h, const void* observation,
                     const void* embedding, int64_t F, int T, int D, int E, int K,
                     const double* gamma0, const void* in_eigvec,

@@ -422,6 +422,36 @@ def sampler_cases():
           eigvec=m.covariance_eigenvectors, eigval=m.covariance_eigenvalues, y=y)
 
 
+def joint_covariance_cases():
+    """GCACGMMTrainer(covariance_type='full' | 'diagonal') (gcacgmm.py:141, :297-303 ->
+    GaussianTrainer._fit, gaussian.py:152-193): same layout as the 'embed_gcacgmm_*' fixtures."""
+    from pb_bss.distribution import GCACGMMTrainer
+    Y, e, init = synth.make_joint(6, 80, 4, 3, 10, seed=3)
+    Y128, e64 = Y.astype(np.complex128), e.astype(np.float64)
+    rng = np.random.default_rng(77)
+    A = rng.standard_normal((3, 10, 10))
+    fixed_full = A @ A.swapaxes(-1, -2) / 10 + np.eye(10)
+    for name, kw in [
+            ('embed_gcacgmm_full', dict(covariance_type='full')),
+            ('embed_gcacgmm_diagonal', dict(covariance_type='diagonal')),
+            ('embed_gcacgmm_full_weights', dict(covariance_type='full', spatial_weight=0.7,
+                                                spectral_weight=1.3, weight_constant_axis=(-3,))),
+            ('embed_gcacgmm_diagonal_pa', dict(covariance_type='diagonal',
+                                               inline_permutation_alignment=True,
+                                               weight_constant_axis=(-3, -1))),
+            ('embed_gcacgmm_full_fixed', dict(covariance_type='full',
+                                              fixed_covariance=fixed_full))]:
+        m = GCACGMMTrainer().fit(Y128, e64, initialization=init, iterations=5, **kw)
+        kw_repr = {k: v for k, v in kw.items() if k != 'fixed_covariance'}
+        extra = {}
+        if 'fixed_covariance' in kw:
+            extra['fixed_covariance'] = kw['fixed_covariance']
+        _save(name, Y=Y, embedding=e, init=init, iterations=5, kwargs=np.array(repr(kw_repr)),
+              weight=np.asarray(m.weight), mean=m.gaussian.mean, covariance=m.gaussian.covariance,
+              eigvec=m.cacg.covariance_eigenvectors, eigval=m.cacg.covariance_eigenvalues,
+              affiliation=m.predict(Y128, e64), **extra)
+
+
 def gev_eig_cases():
     """`get_gev_vector(..., use_eig=True)`: the zggev module compiled from the reference's own
     c_eig.pyx (oracle/refshim.py:build_cython) AND the scipy.linalg.eig fallback loop, on
@@ -460,12 +490,17 @@ def gev_eig_cases():
 
 def main():
     """python -m oracle.make_golden            -> every fixture of the pure-Python reference
+    python -m oracle.make_golden joint_cov  -> tests/golden/embed_gcacgmm_{full,diagonal}*.npz
     python -m oracle.make_golden gev_eig    -> tests/golden/gev_use_eig.npz only (own process:
     the reference's Cython modules must be injected BEFORE pb_bss.extraction.beamformer is
     imported, and the other fixtures are defined as the Cython-less reference's output)."""
     import sys
     os.makedirs(OUT, exist_ok=True)
     warnings.filterwarnings('ignore', category=DeprecationWarning)
+    if sys.argv[1:] == ['joint_cov']:
+        refshim.load()
+        joint_covariance_cases()
+        return
     if sys.argv[1:] == ['gev_eig']:
         refshim.load_cython()
         gev_eig_cases()

@@ -38,7 +38,7 @@ EXPORTS = (
     'pbbss_normalize_observation', 'pbbss_cacgmm_fit', 'pbbss_cacgmm_predict',
     'pbbss_cacg_m_step', 'pbbss_heev_batched', 'pbbss_psd', 'pbbss_gev', 'pbbss_gev_general',
     'pbbss_comm_unique_id', 'pbbss_comm_create', 'pbbss_comm_destroy', 'pbbss_shard_bounds',
-    'pbbss_allgather_masks', 'pbbss_allgather_unpack',
+    'pbbss_allgather_masks', 'pbbss_allgather_unpack', 'pbbss_estimate_mixture_weight',
     'pbbss_solve', 'pbbss_mvdr_souden', 'pbbss_mvdr', 'pbbss_ban',
     'pbbss_apply_beamforming_vector', 'pbbss_set_timing',
     'pbbss_last_kernel_ms', 'pbbss_set_phase_profile',
@@ -56,6 +56,8 @@ EXPORTS = (
 
 EMBED_VMF = 0
 EMBED_GAUSS_SPHERICAL = 1
+EMBED_GAUSS_FULL = 2
+EMBED_GAUSS_DIAG = 3
 # weight_constant_axis of the joint models -> PBBSS_JOINT_WEIGHT_*
 JOINT_WEIGHT_FK, JOINT_WEIGHT_UNIFORM, JOINT_WEIGHT_K, JOINT_WEIGHT_KT, JOINT_WEIGHT_CONST = range(5)
 
@@ -174,6 +176,7 @@ def load():
         lib.pbbss_psd.argtypes = [vp, vp, i32, i64, i32, i32, i32, vp, i32, vp, vp]
         lib.pbbss_gev.argtypes = [vp, vp, vp, i64, i32, vp, vp, vp]
         lib.pbbss_gev_general.argtypes = [vp, vp, vp, i64, i32, vp, vp, vp, vp]
+        lib.pbbss_estimate_mixture_weight.argtypes = [vp, vp, vp, i64, i64, i32, i64, i32, i32, vp, vp]
         lib.pbbss_comm_unique_id.argtypes = [vp]
         lib.pbbss_comm_create.argtypes = [vp, vp, i32, i32]
         lib.pbbss_comm_destroy.argtypes = [vp]

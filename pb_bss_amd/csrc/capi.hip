@@ -894,10 +894,31 @@ PBBSS_API int pbbss_embed_log_pdf(pbbss_handle_t h, const void* y, int y_is_f64,
   double* prec = wc.take<double>((size_t)B * K);
   int rc = pbbss::launch_embed_prepare(y, y_is_f64, B, N, E, 0, yd, nullptr, s);
   if (rc != PBBSS_OK) return rc;
+  if (kind == PBBSS_EMBED_GAUSS_DIAG) {
+    if (B != 1) return PBBSS_ERR_UNSUPPORTED;  // the reference's DiagonalGaussian has no batch axis
+    void* cw = handle_scratch(h, pbbss::diag_consts_doubles(K, E) * 8);
+    if (!cw) return PBBSS_ERR_HIP;
+    return pbbss::launch_diag_estep(yd, y_is_f64, N, E, K, mean, scale, 1.0, N,
+                                    static_cast<double*>(cw), out_log_pdf, s);
+  }
   rc = pbbss::launch_embed_offsets(kind, B * K, E, scale, offset, prec, s);
   if (rc != PBBSS_OK) return rc;
   return pbbss::launch_embed_estep(kind, yd, y_is_f64, B, N, E, K, mean, prec, offset, nullptr,
                                    1.0, N, out_log_pdf, nullptr, s);
+}
+
+PBBSS_API int pbbss_estimate_mixture_weight(pbbss_handle_t h, const double* affiliation,
+                                            const double* saliency, int64_t Bo, int64_t Bi, int K,
+                                            int64_t N, int reduce_inner, int reduce_n,
+                                            double* out_weight, void* stream) {
+  DeviceGuard device_guard(h);
+  if (!h || !affiliation || !out_weight || Bo <= 0 || Bi <= 0 || N <= 0) return PBBSS_ERR_INVALID_ARG;
+  if (K < 1 || K > 64) return PBBSS_ERR_UNSUPPORTED;
+  void* w = handle_work(h, WorkCarver::pad(pbbss::mixture_weight_tmp_doubles(Bo, Bi, K, N, reduce_n) * 8));
+  if (!w) return PBBSS_ERR_HIP;
+  return pbbss::launch_mixture_weight(affiliation, saliency, Bo, Bi, K, N, reduce_inner ? 1 : 0,
+                                      reduce_n ? 1 : 0, static_cast<double*>(w), out_weight,
+                                      as_stream(stream));
 }
 
 PBBSS_API int pbbss_embed_fit(pbbss_handle_t h, const void* y, int y_is_f64, int64_t B, int64_t N,
@@ -1151,7 +1172,12 @@ PBBSS_API int pbbss_joint_fit(pbbss_handle_t h, const void* observation, const v
   const int64_t N = F * (int64_t)T;
   if (!embed_shape_ok(1, N, E, K)) return PBBSS_ERR_UNSUPPORTED;
   if (o->iterations < 0 || o->weight_mode < 0 || o->weight_mode > 4) return PBBSS_ERR_INVALID_ARG;
-  if (o->kind != PBBSS_EMBED_VMF && o->kind != PBBSS_EMBED_GAUSS_SPHERICAL) return PBBSS_ERR_UNSUPPORTED;
+  if (o->kind < PBBSS_EMBED_VMF || o->kind > PBBSS_EMBED_GAUSS_DIAG) return PBBSS_ERR_UNSUPPORTED;
+  const bool g_full = o->kind == PBBSS_EMBED_GAUSS_FULL, g_diag = o->kind == PBBSS_EMBED_GAUSS_DIAG;
+  if (g_full && E > pbbss::kGaussFullMaxE) return PBBSS_ERR_UNSUPPORTED;
+  // scalars per class of the spectral model's second parameter: concentration / variance (1),
+  // per-dimension variances (E), covariance matrix (E * E)
+  const size_t nscale = g_full ? (size_t)K * E * E : (g_diag ? (size_t)K * E : (size_t)K);
   if (o->covariance_norm < 0 || o->covariance_norm > 2) return PBBSS_ERR_INVALID_ARG;
   const bool has_gamma = gamma0 != nullptr;
   const bool has_model = in_eigvec && in_eigval && in_weight && in_mean && in_scale;
@@ -1172,9 +1198,15 @@ PBBSS_API int pbbss_joint_fit(pbbss_handle_t h, const void* observation, const v
   const size_t np = pbbss::embed_partial_doubles(1, N, E, K, nullptr);
   const size_t nfkt = (size_t)F * K * T;
   const size_t nstate = (size_t)F * K * (D * D + 2);
+  const size_t ngp = g_full ? pbbss::gauss_full_partial_doubles(1, N, E, K) : 0;
+  const size_t nconst = g_diag ? pbbss::diag_consts_doubles(K, E) : 0;
   const size_t need = WorkCarver::pad((size_t)E * N * esz) + 2 * WorkCarver::pad(nfkt * 8) +
                       WorkCarver::pad(np * 8) + 2 * WorkCarver::pad((size_t)K * 8) +
-                      WorkCarver::pad((size_t)F * K * 8) + WorkCarver::pad(nstate * 8);
+                      WorkCarver::pad((size_t)F * K * 8) + WorkCarver::pad(nstate * 8) +
+                      (g_full ? 2 * WorkCarver::pad(nfkt * 8) + WorkCarver::pad(ngp * 8) +
+                                    WorkCarver::pad((size_t)K * E * E * 8)
+                              : 0) +
+                      WorkCarver::pad(nconst * 8) + WorkCarver::pad(64);
   void* w = handle_work(h, need);
   if (!w) return PBBSS_ERR_HIP;
   WorkCarver wc(w);
@@ -1186,6 +1218,13 @@ PBBSS_API int pbbss_joint_fit(pbbss_handle_t h, const void* observation, const v
   double* prec = wc.take<double>(K);
   double* tmp = wc.take<double>((size_t)F * K);
   double* jstate = wc.take<double>(nstate);
+  double* wkn = g_full ? wc.take<double>(nfkt) : nullptr;    // (K, F*T) class weights
+  double* lpkn = g_full ? wc.take<double>(nfkt) : nullptr;   // (K, F*T) log-pdf
+  double* gpart = g_full ? wc.take<double>(ngp) : nullptr;
+  double* mq = g_full ? wc.take<double>((size_t)K * E * E) : nullptr;
+  double* dconst = g_diag ? wc.take<double>(nconst) : nullptr;
+  int32_t* gst = reinterpret_cast<int32_t*>(wc.take<char>(64));  // status of the spectral half
+  if (hipMemsetAsync(gst, 0, 64, as_stream(stream)) != hipSuccess) return PBBSS_ERR_HIP;
   TimedRegion tr(h, s);
   int rc = pbbss::launch_embed_prepare(embedding, o->embedding_is_f64, 1, N, E, 0, yd, nullptr, s);
   if (rc != PBBSS_OK) return rc;
@@ -1194,11 +1233,25 @@ PBBSS_API int pbbss_joint_fit(pbbss_handle_t h, const void* observation, const v
     if ((rc = copy_d2d(out_eigval, in_eigval, (size_t)F * K * D * 8, s)) != PBBSS_OK) return rc;
     if ((rc = copy_d2d(out_weight, in_weight, wcount * 8, s)) != PBBSS_OK) return rc;
     if ((rc = copy_d2d(out_mean, in_mean, (size_t)K * E * 8, s)) != PBBSS_OK) return rc;
-    if ((rc = copy_d2d(out_scale, in_scale, (size_t)K * 8, s)) != PBBSS_OK) return rc;
+    if ((rc = copy_d2d(out_scale, in_scale, nscale * 8, s)) != PBBSS_OK) return rc;
   }
   // spectral log-pdf (times spectral_weight) of every point, laid out (F,K,T)
   const bool fixed_scale = in_scale && has_gamma;
+  bool mq_fresh = false;  // the full-covariance M-step also leaves the factorisation behind
   auto spectral = [&]() -> int {
+    if (g_diag)
+      return pbbss::launch_diag_estep(yd, o->embedding_is_f64, N, E, K, out_mean, out_scale,
+                                      o->spectral_weight, T, dconst, slp, s);
+    if (g_full) {
+      int r = PBBSS_OK;
+      if (!mq_fresh || fixed_scale)
+        r = pbbss::launch_gauss_full_factor(out_scale, K, E, mq, offset, gst, s);
+      if (r != PBBSS_OK) return r;
+      r = pbbss::launch_gauss_full_logpdf(embedding, o->embedding_is_f64, 1, N, E, K, out_mean, mq,
+                                          offset, nullptr, lpkn, nullptr, s);
+      if (r != PBBSS_OK) return r;
+      return pbbss::launch_kn_to_fkt(lpkn, o->spectral_weight, F, K, T, slp, s);
+    }
     if (fixed_scale || o->iterations == 0) {  // otherwise the M-step finalize wrote them
       int r = pbbss::launch_embed_offsets(o->kind, K, E, out_scale, offset, prec, s);
       if (r != PBBSS_OK) return r;
@@ -1269,18 +1322,32 @@ PBBSS_API int pbbss_joint_fit(pbbss_handle_t h, const void* observation, const v
       rc = pbbss::launch_joint_weight(o->weight_mode, src, saliency, F, K, T, tmp, out_weight, s);
       if (rc != PBBSS_OK) return rc;
     }
-    rc = pbbss::launch_embed_fit(o->kind, embedding, o->embedding_is_f64, 1, N, E, K, src, T,
-                                 saliency, o->min_concentration, o->max_concentration, -1, part,
-                                 out_mean, out_scale, nullptr, offset, prec, it == 0 ? 2 : 1, s);
+    if (g_full) {
+      // GaussianTrainer._fit(covariance_type='full') on the (1, F*T, E) embedding with the masked
+      // affiliations as (K, F*T) class weights (gcacgmm.py:297-307); the kernel leaves mean,
+      // covariance and the factorisation the next E-step needs
+      if ((rc = pbbss::launch_fkt_to_kn(src, saliency, F, K, T, wkn, s)) != PBBSS_OK) return rc;
+      rc = pbbss::launch_gauss_full_fit(embedding, o->embedding_is_f64, 1, N, E, K, wkn, nullptr,
+                                        gpart, out_mean, out_scale, mq, offset, nullptr, gst, s);
+      mq_fresh = true;
+    } else {
+      rc = pbbss::launch_embed_fit(o->kind, embedding, o->embedding_is_f64, 1, N, E, K, src, T,
+                                   saliency, o->min_concentration, o->max_concentration, -1, part,
+                                   out_mean, out_scale, nullptr, g_diag ? nullptr : offset,
+                                   g_diag ? nullptr : prec, it == 0 ? 2 : 1, s);
+    }
     if (rc != PBBSS_OK) return rc;
     if (fixed_scale) {  // fixed_covariance (gcacgmm.py:305-312)
-      if ((rc = copy_d2d(out_scale, in_scale, (size_t)K * 8, s)) != PBBSS_OK) return rc;
+      if ((rc = copy_d2d(out_scale, in_scale, nscale * 8, s)) != PBBSS_OK) return rc;
     }
   }
   if (o->final_predict && out_affiliation) {
     if ((rc = spectral()) != PBBSS_OK) return rc;
     if ((rc = joint(0, out_affiliation, 0, nullptr, nullptr, 0)) != PBBSS_OK) return rc;
   }
+  // a spectral covariance that stopped being positive definite (the reference raises from
+  // sklearn's precision Cholesky, gaussian.py:26): PBBSS_ST_NOT_POSDEF in status word 0
+  if (g_full) return pbbss::launch_or_status(gst, out_status, s);
   return PBBSS_OK;
 }
 

@@ -408,6 +408,10 @@ __global__ void __launch_bounds__(kFinThreads)
         for (int d = lane; d < E; d += kWave) out_mean[((size_t)b * K + k) * E + d] = row[d] / den;
         if (lane == 0) den_buf[b * K + k] = den;
       }
+    } else if (KIND == PBBSS_EMBED_GAUSS_DIAG) {
+      // 'diagonal' (gaussian.py:176-179): one variance per dimension, out_scale (B, K, E)
+      const double den = den_buf[b * K + k];
+      for (int d = lane; d < E; d += kWave) out_scale[((size_t)b * K + k) * E + d] = row[d] / den;
     } else {
       double t = 0.0;
       for (int d = lane; d < E; d += kWave) t += row[d];
@@ -703,6 +707,92 @@ int estep_k(int K, const void* yd, int64_t B, int64_t N, int E, const double* me
 #undef PBBSS_ESTEP_CASE
 }
 
+// ---------------------------------------------------------------- diagonal Gaussian E-step
+// DiagonalGaussian.log_pdf AS WRITTEN in the reference (gaussian.py:76-97): the (K, E) array
+// of 1/sqrt(variance) is handed to einsum('...dD,...nD->...nd') as ONE K x E matrix shared by
+// all classes, i.e.
+//   white[k, n, j] = sum_e pc[j, e] (y[n, e] - mean[k, e])          j = 0..K-1
+//   log_pdf[k, n]  = -E/2 ln 2pi + sum_e ln pc[k, e] - 1/2 sum_j white[k, n, j]^2
+// (not the textbook per-class whitening; the drop-in reproduces what the reference computes).
+// With u_j(n) = sum_e pc[j, e] y[n, e] and c[j, k] = sum_e pc[j, e] mean[k, e]:
+//   white[k, n, j] = u_j(n) - c[j, k].
+// consts layout: pc (K, E) | off (K) | c (K, K)
+__global__ void __launch_bounds__(kThreads) diag_consts_kernel(const double* mean,
+                                                               const double* cov, int K, int E,
+                                                               double* consts) {
+  double* pc = consts;
+  double* off = consts + (size_t)K * E;
+  double* cm = off + K;
+  for (int i = threadIdx.x; i < K * E; i += kThreads) pc[i] = 1.0 / sqrt(cov[i]);
+  __syncthreads();
+  for (int i = threadIdx.x; i < K; i += kThreads) {
+    double t = 0.0;
+    for (int e = 0; e < E; ++e) t += log(pc[i * E + e]);
+    off[i] = -0.5 * E * kLn2Pi + t;
+  }
+  for (int i = threadIdx.x; i < K * K; i += kThreads) {
+    const int j = i / K, k = i - j * K;
+    double t = 0.0;
+    for (int e = 0; e < E; ++e) t = fma(pc[j * E + e], mean[k * E + e], t);
+    cm[j * K + k] = t;
+  }
+}
+
+template <typename TS>
+__global__ void __launch_bounds__(kThreads) diag_estep_kernel(const TS* yd, int64_t N, int E,
+                                                              int K, const double* consts,
+                                                              double out_scale, int64_t Tin,
+                                                              double* out_lp) {
+  extern __shared__ double sm[];  // pc (K, E) | off (K) | c (K, K)
+  const int nconst = K * E + K + K * K;
+  for (int i = threadIdx.x; i < nconst; i += kThreads) sm[i] = consts[i];
+  __syncthreads();
+  const double* pc = sm;
+  const double* off = sm + K * E;
+  const double* cm = off + K;
+  const int64_t n = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (n >= N) return;
+  double u[kEmbedMaxK];
+  for (int j = 0; j < K; ++j) u[j] = 0.0;
+  for (int e = 0; e < E; ++e) {
+    const double yv = (double)yd[(size_t)e * N + n];
+    for (int j = 0; j < K; ++j) u[j] = fma(pc[j * E + e], yv, u[j]);
+  }
+  for (int k = 0; k < K; ++k) {
+    double q = 0.0;
+    for (int j = 0; j < K; ++j) {
+      const double w = u[j] - cm[j * K + k];
+      q = fma(w, w, q);
+    }
+    out_lp[aff_index(0, k, n, K, N, Tin)] = out_scale * (off[k] - 0.5 * q);
+  }
+}
+
+// ---------------------------------------------------------------- layout changes for the
+// full-covariance kernels (gauss_full.hip works on (K, N) arrays, the joint models on (F, K, T))
+// w[k, f*T + t] = aff[f, k, t] * (sal ? sal[f, t] : 1)      'fkt->k,ft' (gcacgmm.py:298-302)
+__global__ void __launch_bounds__(kThreads) fkt_to_kn_kernel(const double* aff, const double* sal,
+                                                             int64_t F, int K, int T,
+                                                             double* out) {
+  const int64_t total = F * K * T;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * kThreads) {
+    const int64_t t = i % T, k = (i / T) % K, f = i / ((int64_t)T * K);
+    out[(size_t)k * F * T + f * T + t] = aff[i] * (sal ? sal[f * T + t] : 1.0);
+  }
+}
+// out[f, k, t] = scale * lp[k, f*T + t]
+__global__ void __launch_bounds__(kThreads) kn_to_fkt_kernel(const double* lp, double scale,
+                                                             int64_t F, int K, int T,
+                                                             double* out) {
+  const int64_t total = F * K * T;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * kThreads) {
+    const int64_t t = i % T, k = (i / T) % K, f = i / ((int64_t)T * K);
+    out[i] = scale * lp[(size_t)k * F * T + f * T + t];
+  }
+}
+
 template <int K, typename TS>
 int fit_go(int kind, const void* yr, int64_t B, int64_t N, int E, const double* aff, int64_t Tin,
            const double* sal, double cmin, double cmax, int weight_mode, double* part,
@@ -747,6 +837,12 @@ int fit_go(int kind, const void* yr, int64_t B, int64_t N, int E, const double* 
   hipLaunchKernelGGL((embed_fit_kernel<K, TS, 1>), grid, dim3(kFitThreads), lds_fit, s,
                      static_cast<const TS*>(yr), N, E, S, C, L, aff, Tin, sal, out_mean, part,
                      (double*)nullptr, 0);
+  if (kind == PBBSS_EMBED_GAUSS_DIAG) {
+    hipLaunchKernelGGL((embed_finalize_kernel<PBBSS_EMBED_GAUSS_DIAG, 1>), dim3((unsigned)B),
+                       dim3(kFinThreads), lds_fin, s, part, C, E, K, cmin, cmax, -1, den_buf,
+                       out_mean, out_scale, (double*)nullptr, (double*)nullptr, (double*)nullptr);
+    return ok_or_hip();
+  }
   hipLaunchKernelGGL((embed_finalize_kernel<PBBSS_EMBED_GAUSS_SPHERICAL, 1>), dim3((unsigned)B),
                      dim3(kFinThreads), lds_fin, s, part, C, E, K, cmin, cmax, -1, den_buf, out_mean,
                      out_scale, (double*)nullptr, out_offset, out_prec);
@@ -797,7 +893,9 @@ int launch_embed_fit(int kind, const void* yr, int y_is_f64, int64_t B, int64_t 
                      double* out_weight, double* out_offset, double* out_prec, int single_pass,
                      hipStream_t s) {
   if (E < 1 || E > kEmbedMaxE || B > 65535) return PBBSS_ERR_UNSUPPORTED;
-  if (kind != PBBSS_EMBED_VMF && kind != PBBSS_EMBED_GAUSS_SPHERICAL) return PBBSS_ERR_UNSUPPORTED;
+  if (kind != PBBSS_EMBED_VMF && kind != PBBSS_EMBED_GAUSS_SPHERICAL && kind != PBBSS_EMBED_GAUSS_DIAG)
+    return PBBSS_ERR_UNSUPPORTED;
+  if (kind == PBBSS_EMBED_GAUSS_DIAG) single_pass = 0;  // two sweeps, as the reference
   return y_is_f64 ? fit_k<double>(K, kind, yr, B, N, E, aff, Tin, sal, cmin, cmax, weight_mode,
                                   part, out_mean, out_scale, out_weight, out_offset, out_prec,
                                   single_pass, s)
@@ -832,6 +930,51 @@ int launch_joint_weight(int mode, const double* aff, const double* sal, int64_t 
       break;
     default: return PBBSS_ERR_INVALID_ARG;
   }
+  return ok_or_hip();
+}
+
+namespace {
+__global__ void or_status_kernel(const int32_t* src, int32_t* dst) { dst[0] |= src[0]; }
+}  // namespace
+int launch_or_status(const int32_t* src, int32_t* dst, hipStream_t s) {
+  hipLaunchKernelGGL(or_status_kernel, dim3(1), dim3(1), 0, s, src, dst);
+  return ok_or_hip();
+}
+
+size_t diag_consts_doubles(int K, int E) { return (size_t)K * E + K + (size_t)K * K; }
+
+int launch_diag_estep(const void* yd, int y_is_f64, int64_t N, int E, int K, const double* mean,
+                      const double* cov, double out_scale, int64_t Tin, double* consts,
+                      double* out_lp, hipStream_t s) {
+  if (E < 1 || E > kEmbedMaxE || K < 1 || K > kEmbedMaxK) return PBBSS_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(diag_consts_kernel, dim3(1), dim3(kThreads), 0, s, mean, cov, K, E, consts);
+  const size_t lds = diag_consts_doubles(K, E) * sizeof(double);
+  const unsigned grid = (unsigned)((N + kThreads - 1) / kThreads);
+  if (y_is_f64) {
+    hipLaunchKernelGGL(diag_estep_kernel<double>, dim3(grid), dim3(kThreads), lds, s,
+                       static_cast<const double*>(yd), N, E, K, consts, out_scale, Tin, out_lp);
+  } else {
+    hipLaunchKernelGGL(diag_estep_kernel<float>, dim3(grid), dim3(kThreads), lds, s,
+                       static_cast<const float*>(yd), N, E, K, consts, out_scale, Tin, out_lp);
+  }
+  return ok_or_hip();
+}
+
+int launch_fkt_to_kn(const double* aff, const double* sal, int64_t F, int K, int T, double* out,
+                     hipStream_t s) {
+  const int64_t total = F * K * T;
+  const unsigned grid = (unsigned)((total + kThreads - 1) / kThreads < 4096 ? (total + kThreads - 1) / kThreads : 4096);
+  hipLaunchKernelGGL(fkt_to_kn_kernel, dim3(grid ? grid : 1), dim3(kThreads), 0, s, aff, sal, F, K,
+                     T, out);
+  return ok_or_hip();
+}
+
+int launch_kn_to_fkt(const double* lp, double scale, int64_t F, int K, int T, double* out,
+                     hipStream_t s) {
+  const int64_t total = F * K * T;
+  const unsigned grid = (unsigned)((total + kThreads - 1) / kThreads < 4096 ? (total + kThreads - 1) / kThreads : 4096);
+  hipLaunchKernelGGL(kn_to_fkt_kernel, dim3(grid ? grid : 1), dim3(kThreads), 0, s, lp, scale, F, K,
+                     T, out);
   return ok_or_hip();
 }
 

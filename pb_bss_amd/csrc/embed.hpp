@@ -61,4 +61,28 @@ int launch_embed_fit(int kind, const void* yr, int y_is_f64, int64_t B, int64_t 
 int launch_joint_weight(int mode, const double* aff, const double* sal, int64_t F, int K, int T,
                         double* tmp, double* out_weight, hipStream_t s);
 
+// DiagonalGaussian.log_pdf as the reference writes it (gaussian.py:76-97, see embed.hip):
+// yd (E, N) transposed copy, mean / cov (K, E); out index as launch_embed_estep (b = 0);
+// consts: diag_consts_doubles() of scratch.
+size_t diag_consts_doubles(int K, int E);
+int launch_diag_estep(const void* yd, int y_is_f64, int64_t N, int E, int K, const double* mean,
+                      const double* cov, double out_scale, int64_t Tin, double* consts,
+                      double* out_lp, hipStream_t s);
+// (F, K, T) <-> (K, F*T) for the full-covariance kernels of gauss_full.hip
+int launch_fkt_to_kn(const double* aff, const double* sal, int64_t F, int K, int T, double* out,
+                     hipStream_t s);
+int launch_kn_to_fkt(const double* lp, double scale, int64_t F, int K, int T, double* out,
+                     hipStream_t s);
+
+// dst[0] |= src[0] (spectral-half status of the joint fit)
+int launch_or_status(const int32_t* src, int32_t* dst, hipStream_t s);
+
+// mixw.hip: estimate_mixture_weight (mixture_model_utils.py:133-203) with reductions over
+// independent axes; affiliation (Bo, Bi, K, N), saliency (Bo, Bi, N) or null -> out
+// (Bo, red_inner ? 1 : Bi, K, red_n ? 1 : N); tmp: mixture_weight_tmp_doubles() of scratch.
+size_t mixture_weight_tmp_doubles(int64_t Bo, int64_t Bi, int K, int64_t N, int red_n);
+int launch_mixture_weight(const double* aff, const double* sal, int64_t Bo, int64_t Bi, int K,
+                          int64_t N, int red_inner, int red_n, double* tmp, double* out,
+                          hipStream_t s);
+
 }  // namespace pbbss

@@ -1,0 +1,140 @@
+// estimate_mixture_weight on the device (distribution/mixture_model_utils.py:133-203) for the
+// options that couple problems: weight_constant_axis containing independent axes (e.g. (-3,):
+// weights shared by all frequency bins, (-3, -1): one weight per class for the whole utterance).
+// The fused EM kernel owns the per-bin cases ((-1,) and -2); this file serves the step-wise fit
+// (CACGMMTrainer._fit_stepwise), which otherwise would have to bring the affiliations to the
+// host every iteration.
+//
+//   affiliation (Bo, Bi, K, N) float64, saliency (Bo, Bi, N) or null
+//   reduce over Bi (red_inner: the trailing independent axes in weight_constant_axis) and / or
+//   over N (red_n: -1 in weight_constant_axis), keepdims:
+//     no saliency: mean over the reduced axes                                   (:188)
+//     saliency   : sum of affiliation * saliency over the reduced axes, then L1-normalised over
+//                  the classes with `where(norm == 0, 1e-10, norm)`             (:190-201)
+//   out (Bo, Bi', K, N'), Bi' = red_inner ? 1 : Bi, N' = red_n ? 1 : N.
+// Two launches, fixed summation order (bit-reproducible): rows (one workgroup per problem:
+// sums over N) and finish (sums over Bi, normalisation over the classes).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "embed.hpp"
+#include "pbbss_dev.hpp"
+
+namespace pbbss {
+namespace {
+constexpr int kT = 256;
+
+// tmp (Bo*Bi, K, N1): per problem the (saliency-weighted) affiliation, summed over N if red_n
+__global__ void __launch_bounds__(kT) mixw_rows_kernel(const double* __restrict__ aff,
+                                                       const double* __restrict__ sal, int K,
+                                                       int64_t N, int red_n,
+                                                       double* __restrict__ tmp) {
+  const int64_t b = blockIdx.x;
+  const double* a = aff + b * K * N;
+  const double* s = sal ? sal + b * N : nullptr;
+  __shared__ double red[kT / kWave];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (!red_n) {
+    for (int64_t i = threadIdx.x; i < (int64_t)K * N; i += kT)
+      tmp[b * K * N + i] = a[i] * (s ? s[i % N] : 1.0);
+    return;
+  }
+  for (int k = 0; k < K; ++k) {
+    double acc = 0.0;
+    for (int64_t n = threadIdx.x; n < N; n += kT) acc += a[(int64_t)k * N + n] * (s ? s[n] : 1.0);
+    acc = wave_sum(acc);
+    __syncthreads();
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double t = 0.0;
+      for (int w = 0; w < kT / kWave; ++w) t += red[w];
+      tmp[b * K + k] = t;
+    }
+  }
+}
+
+// out (Bo, Bi2, K, N1) from tmp (Bo, Bi, K, N1): sum over Bi if red_inner, then normalise
+__global__ void __launch_bounds__(kT) mixw_finish_kernel(const double* __restrict__ tmp,
+                                                         int64_t Bi, int K, int64_t N1,
+                                                         int red_inner, int has_sal, double count,
+                                                         double* __restrict__ out) {
+  const int64_t Bi2 = red_inner ? 1 : Bi;
+  const int64_t bo = blockIdx.x / Bi2, b2 = blockIdx.x % Bi2;
+  extern __shared__ double sm[];  // [K] class totals when N1 == 1
+  if (N1 == 1) {
+    // parallel over bi, block reduction per class
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ double red[kT / kWave];
+    for (int k = 0; k < K; ++k) {
+      double acc = 0.0;
+      if (red_inner) {
+        for (int64_t bi = threadIdx.x; bi < Bi; bi += kT) acc += tmp[(bo * Bi + bi) * K + k];
+      } else if (threadIdx.x == 0) {
+        acc = tmp[(bo * Bi + b2) * K + k];
+      }
+      acc = wave_sum(acc);
+      __syncthreads();
+      if (lane == 0) red[wave] = acc;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < kT / kWave; ++w) t += red[w];
+        sm[k] = t;
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < K) {
+      double v = sm[threadIdx.x];
+      if (has_sal) {
+        double nrm = 0.0;
+        for (int k = 0; k < K; ++k) nrm += fabs(sm[k]);
+        v /= (nrm == 0.0) ? 1e-10 : nrm;
+      } else {
+        v /= count;
+      }
+      out[(bo * Bi2 + b2) * K + threadIdx.x] = v;
+    }
+    return;
+  }
+  // N1 == N: thread = frame, loop over the classes (and the reduced problems)
+  for (int64_t n = threadIdx.x; n < N1; n += kT) {
+    double nrm = 0.0;
+    for (int pass = 0; pass < 2; ++pass) {  // pass 0: class norm (saliency only), pass 1: write
+      if (pass == 0 && !has_sal) continue;
+      for (int k = 0; k < K; ++k) {
+        double v = 0.0;
+        if (red_inner) {
+          for (int64_t bi = 0; bi < Bi; ++bi) v += tmp[((bo * Bi + bi) * K + k) * N1 + n];
+        } else {
+          v = tmp[((bo * Bi + b2) * K + k) * N1 + n];
+        }
+        if (pass == 0) {
+          nrm += fabs(v);
+        } else {
+          out[((bo * Bi2 + b2) * K + k) * N1 + n] =
+              has_sal ? v / ((nrm == 0.0) ? 1e-10 : nrm) : v / count;
+        }
+      }
+    }
+  }
+}
+}  // namespace
+
+size_t mixture_weight_tmp_doubles(int64_t Bo, int64_t Bi, int K, int64_t N, int red_n) {
+  return (size_t)Bo * Bi * K * (red_n ? 1 : N);
+}
+
+int launch_mixture_weight(const double* aff, const double* sal, int64_t Bo, int64_t Bi, int K,
+                          int64_t N, int red_inner, int red_n, double* tmp, double* out,
+                          hipStream_t s) {
+  const int64_t N1 = red_n ? 1 : N;
+  hipLaunchKernelGGL(mixw_rows_kernel, dim3((unsigned)(Bo * Bi)), dim3(kT), 0, s, aff, sal, K, N,
+                     red_n, tmp);
+  const double count = (red_n ? (double)N : 1.0) * (red_inner ? (double)Bi : 1.0);
+  const int64_t Bi2 = red_inner ? 1 : Bi;
+  hipLaunchKernelGGL(mixw_finish_kernel, dim3((unsigned)(Bo * Bi2)), dim3(kT), K * sizeof(double),
+                     s, tmp, Bi, K, N1, red_inner, sal ? 1 : 0, count, out);
+  return hipGetLastError() == hipSuccess ? PBBSS_OK : PBBSS_ERR_HIP;
+}
+
+}  // namespace pbbss

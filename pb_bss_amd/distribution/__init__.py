@@ -11,7 +11,7 @@ from .complex_watson import ComplexWatson, ComplexWatsonTrainer
 from .cwmm import CWMM, CWMMTrainer
 from .von_mises_fisher import VonMisesFisher, VonMisesFisherTrainer
 from .vmfmm import VMFMM, VMFMMTrainer
-from .gaussian import Gaussian, SphericalGaussian, GaussianTrainer
+from .gaussian import DiagonalGaussian, Gaussian, SphericalGaussian, GaussianTrainer
 from .gmm import GMM, GMMTrainer
 from .gcacgmm import GCACGMM, GCACGMMTrainer
 from .vmfcacgmm import VMFCACGMM, VMFCACGMMTrainer
@@ -19,7 +19,7 @@ from .vmfcacgmm import VMFCACGMM, VMFCACGMMTrainer
 __all__ = [
     'CACGMM', 'CACGMMTrainer', 'CWMM', 'CWMMTrainer',
     'VonMisesFisher', 'VonMisesFisherTrainer', 'VMFMM', 'VMFMMTrainer',
-    'Gaussian', 'SphericalGaussian', 'GaussianTrainer', 'GMM', 'GMMTrainer', 'GCACGMM', 'GCACGMMTrainer',
+    'Gaussian', 'DiagonalGaussian', 'SphericalGaussian', 'GaussianTrainer', 'GMM', 'GMMTrainer', 'GCACGMM', 'GCACGMMTrainer',
     'VMFCACGMM', 'VMFCACGMMTrainer',
     'ComplexWatson', 'ComplexWatsonTrainer',
     'ComplexAngularCentralGaussian', 'ComplexAngularCentralGaussianTrainer',

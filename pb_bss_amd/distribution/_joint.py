@@ -64,7 +64,9 @@ def fit(kind, observation, embedding, initialization, num_classes, iterations, s
     fixed = None
     if fixed_scale is not None:
         fixed = _lib.to_device(fixed_scale, t.float64).to(obs.device).contiguous()
-        assert fixed.shape == (K,), f'{tuple(fixed.shape)} != {(K,)}'  # gcacgmm.py:306-308
+        E = emb.shape[-1]
+        want = {_lib.EMBED_GAUSS_FULL: (K, E, E), _lib.EMBED_GAUSS_DIAG: (K, E)}.get(kind, (K,))
+        assert tuple(fixed.shape) == want, f'{tuple(fixed.shape)} != {want}'  # gcacgmm.py:306-308
     r = engine.joint_fit(
         obs, emb, K, kind, gamma0=gamma0, iterations=iterations, saliency=sal,
         weight_mode=weight_mode(weight_constant_axis),

@@ -298,69 +298,105 @@ class CACGMMTrainer:
         return out
 
     # --------------------------------------------------------------- stepwise
+    @staticmethod
+    def _device_weight(aff, sal, weight_constant_axis, indep):
+        """estimate_mixture_weight (mixture_model_utils.py:133-203) on the device for the
+        axis sets that occur in practice: the trailing `r` independent axes and / or the frame
+        axis.  aff (*indep, K, N) device tensor, sal (*indep, N) or None.
+        Returns the reference-shaped weight (keepdims) as a device tensor, or None if the axis
+        set is not of that form (the caller then takes the host formula)."""
+        nd = len(indep) + 2
+        axes = ((weight_constant_axis,) if isinstance(weight_constant_axis, int)
+                else tuple(weight_constant_axis))
+        axes = sorted({a % nd for a in axes})
+        if nd - 2 in axes:  # the class axis: only the scalar form -2 is defined (handled earlier)
+            return None
+        red_n = (nd - 1) in axes
+        ind_axes = [a for a in axes if a < nd - 2]
+        r = len(ind_axes)
+        if ind_axes != list(range(nd - 2 - r, nd - 2)):
+            return None  # not a trailing block of independent axes
+        K, N = aff.shape[-2:]
+        Bi = int(np.prod(indep[len(indep) - r:], dtype=np.int64)) if r else 1
+        Bo = int(np.prod(indep[:len(indep) - r], dtype=np.int64)) if len(indep) > r else 1
+        a4 = aff.reshape(Bo, Bi, K, N).contiguous()
+        s3 = None if sal is None else sal.reshape(Bo, Bi, N).contiguous()
+        w = engine.estimate_mixture_weight(a4, s3, reduce_inner=r > 0, reduce_n=red_n)
+        shape = list(indep[:len(indep) - r]) + [1] * r + [K, 1 if red_n else N]
+        return w.reshape(shape)
+
     def _fit_stepwise(self, yb, indep, K, gamma0, model, iterations, saliency,
                       sal, act, weight_constant_axis, covariance_norm,
                       affiliation_eps, eigenvalue_floor, hermitize, aligner,
                       like_torch):
-        """The reference loop (cacgmm.py:252-278) with device E/M steps."""
+        """The reference loop (cacgmm.py:252-278) for the options that couple frequency bins
+        (weight_constant_axis with independent axes, inline_permutation_aligner), one E-step
+        and one M-step launch per iteration with the cross-bin reduction
+        (`pbbss_estimate_mixture_weight`) and, optionally, the device permutation aligner in
+        between.  Everything stays on the device: no host round trip inside the loop.
+        (`hermitize` is accepted for signature compatibility: the device M-step accumulates the
+        Hermitian-packed covariance, which is Hermitian by construction.)"""
         t = _lib.torch()
         B, N, D = yb.shape
+        dev = yb.device
         # normalise in float64 (the reference keeps the input precision; with
         # complex64 input that alone costs 6e-8 per step, SURVEY.md section 7)
         yn = engine.normalize_observation(yb.to(t.complex128))  # (B, D, N)
         shape = (*indep, K, N)
+        sal_dev = None
+        if saliency is not None:
+            sal_dev = _lib.to_device(saliency, t.float64).to(dev).expand(*indep, N).contiguous()
+        vec = val = weight = None
         if model is None:
-            aff = _lib.to_host(gamma0.reshape(shape))
-            q = np.ones(shape, dtype=np.float64)
+            aff = gamma0.reshape(shape).to(t.float64).contiguous()
+            q = t.ones(shape, dtype=t.float64, device=dev)
         else:
-            model = CACGMM(
-                weight=_lib.to_host(_lib.to_device(model.weight, t.float64)),
-                cacg=ComplexAngularCentralGaussian(
-                    covariance_eigenvectors=_lib.to_host(_lib.to_device(
-                        model.cacg.covariance_eigenvectors, t.complex128)),
-                    covariance_eigenvalues=_lib.to_host(_lib.to_device(
-                        model.cacg.covariance_eigenvalues, t.float64))))
-        sal_host = None if saliency is None else np.broadcast_to(
-            _lib.to_host(_lib.to_device(saliency, t.float64)), (*indep, N))
+            vec = _lib.to_device(model.cacg.covariance_eigenvectors, t.complex128).to(dev)
+            val = _lib.to_device(model.cacg.covariance_eigenvalues, t.float64).to(dev)
+            weight = _lib.to_device(model.weight, t.float64).to(dev)
+        device_aligner = aligner is not None and type(aligner).__module__.startswith('pb_bss_amd')
         for _ in range(iterations):
-            if model is not None:
-                vec = _lib.to_device(model.cacg.covariance_eigenvectors, t.complex128)
-                val = _lib.to_device(model.cacg.covariance_eigenvalues, t.float64)
-                w = _weight_for_predict(model.weight, indep, K, N, yn.device)
-                d_aff, d_q, _ = engine.em_predict(
+            if vec is not None:
+                w = _weight_for_predict(weight, indep, K, N, dev)
+                aff, q, _ = engine.em_predict(
                     yn, vec.expand(*indep, K, D, D).reshape(B, K, D, D).contiguous(),
                     val.expand(*indep, K, D).reshape(B, K, D).contiguous(), w,
                     activity=act, layout=_lib.LAYOUT_DT,
                     affiliation_eps=affiliation_eps, want_q=True)
-                aff = _lib.to_host(d_aff).reshape(shape)
-                q = _lib.to_host(d_q).reshape(shape)
+                aff, q = aff.reshape(shape), q.reshape(shape)
                 if aligner is not None:
-                    aff, q = apply_inline_permutation_alignment(
-                        affiliation=aff, quadratic_form=q,
-                        weight_constant_axis=weight_constant_axis, aligner=aligner)
-            weight = estimate_mixture_weight(
-                affiliation=aff, saliency=sal_host,
-                weight_constant_axis=weight_constant_axis)
-            masked = aff if sal_host is None else aff * sal_host[..., None, :]
+                    if device_aligner:
+                        aff, q = apply_inline_permutation_alignment(
+                            affiliation=aff, quadratic_form=q,
+                            weight_constant_axis=weight_constant_axis, aligner=aligner)
+                    else:  # a foreign (NumPy) aligner object: the one host excursion left
+                        a_h, q_h = apply_inline_permutation_alignment(
+                            affiliation=_lib.to_host(aff), quadratic_form=_lib.to_host(q),
+                            weight_constant_axis=weight_constant_axis, aligner=aligner)
+                        aff = _lib.to_device(a_h, t.float64, device=dev)
+                        q = _lib.to_device(q_h, t.float64, device=dev)
+            weight = None
+            if isinstance(weight_constant_axis, int) and \
+                    weight_constant_axis % len(shape) - len(shape) == -2:
+                weight = t.full((K, 1), 1.0 / K, dtype=t.float64, device=dev)  # :180-183
+            else:
+                weight = self._device_weight(aff, sal_dev, weight_constant_axis, indep)
+            if weight is None:  # exotic axis sets: the NumPy formula
+                weight = _lib.to_device(estimate_mixture_weight(
+                    affiliation=_lib.to_host(aff),
+                    saliency=None if sal_dev is None else _lib.to_host(sal_dev),
+                    weight_constant_axis=weight_constant_axis), t.float64, device=dev)
+            masked = aff if sal_dev is None else aff * sal_dev[..., None, :]
             vec, val, _, _ = engine.cacg_m_step(
-                yn, _lib.to_device(np.ascontiguousarray(masked).reshape(B, K, N)),
-                _lib.to_device(np.ascontiguousarray(q).reshape(B, K, N)),
+                yn, masked.reshape(B, K, N).contiguous(), q.reshape(B, K, N).contiguous(),
                 layout=_lib.LAYOUT_DT, covariance_norm=covariance_norm,
                 eigenvalue_floor=eigenvalue_floor)
-            model = CACGMM(
-                weight=weight,
-                cacg=ComplexAngularCentralGaussian(
-                    covariance_eigenvectors=_lib.to_host(vec).reshape(*indep, K, D, D),
-                    covariance_eigenvalues=_lib.to_host(val).reshape(*indep, K, D)))
-        if like_torch:
-            model = CACGMM(
-                weight=_lib.to_device(model.weight),
-                cacg=ComplexAngularCentralGaussian(
-                    covariance_eigenvectors=_lib.to_device(
-                        model.cacg.covariance_eigenvectors),
-                    covariance_eigenvalues=_lib.to_device(
-                        model.cacg.covariance_eigenvalues)))
-        return model
+            vec, val = vec.reshape(*indep, K, D, D), val.reshape(*indep, K, D)
+        return CACGMM(
+            weight=as_result(weight, like_torch),
+            cacg=ComplexAngularCentralGaussian(
+                covariance_eigenvectors=as_result(vec, like_torch),
+                covariance_eigenvalues=as_result(val, like_torch)))
 
     def fit_predict(
             self,

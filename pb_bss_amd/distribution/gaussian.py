@@ -2,9 +2,10 @@
 `SphericalGaussian` (:100-137; csrc/embed.hip -- the spectral half of GCACGMM, the default of
 GCACGMMTrainer, gcacgmm.py:141), `Gaussian` with a full covariance (:17-56; csrc/gauss_full.hip:
 weighted scatter on the FP64 matrix pipe, workgroup Cholesky, MFMA quadratic forms) and
-`GaussianTrainer` (:140-193) for covariance_type 'spherical' and 'full'.  'diagonal' is not
-on the device path (the reference's DiagonalGaussian.log_pdf feeds the (K, D) precisions to
-einsum as one matrix, :87-91).
+`GaussianTrainer` (:140-193) for covariance_type 'spherical', 'diagonal' and 'full'.
+`DiagonalGaussian` (:58-97) evaluates its log-pdf exactly as the reference writes it: the
+(K, D) precisions are fed to einsum as ONE K x D matrix shared by all classes (:87-91), which is
+what `GCACGMMTrainer(covariance_type='diagonal')` therefore optimises there -- and here.
 """
 from dataclasses import dataclass
 
@@ -13,7 +14,7 @@ import numpy as np
 from .. import _lib, engine
 from .utils import _ProbabilisticModel, as_result
 
-__all__ = ['Gaussian', 'SphericalGaussian', 'GaussianTrainer']
+__all__ = ['Gaussian', 'DiagonalGaussian', 'SphericalGaussian', 'GaussianTrainer']
 
 
 @dataclass
@@ -57,6 +58,41 @@ class SphericalGaussian(_ProbabilisticModel):
             mean.expand(*shape, E).reshape(-1, 1, E).contiguous(),
             cov.expand(*shape).reshape(-1, 1).contiguous())
         return as_result(out.reshape(*shape, N), like_torch)
+
+
+@dataclass
+class DiagonalGaussian(_ProbabilisticModel):
+    mean: np.ndarray = None        # (K, D)
+    covariance: np.ndarray = None  # (K, D)
+
+    @property
+    def precision_cholesky(self):
+        c = self.covariance
+        return c.rsqrt() if _lib.is_torch(c) else 1.0 / np.sqrt(c)
+
+    @property
+    def log_det_precision_cholesky(self):
+        pc = self.precision_cholesky
+        return pc.log().sum(-1) if _lib.is_torch(pc) else np.sum(np.log(pc), axis=-1)
+
+    def log_pdf(self, y):
+        """y (1, N, D) [or (N, D)] -> (K, N), as written in the reference (:76-97): the whitening
+        uses the (K, D) precision array as one matrix, white[k, n, j] = sum_d pc[j, d] (y[n, d] -
+        mean[k, d]) -- which, like there, needs a 2-D (K, D) model."""
+        like_torch = _lib.is_torch(y)
+        t = _lib.torch()
+        y = _lib.to_device(y)
+        assert not y.is_complex(), y.dtype
+        N, E = y.shape[-2:]
+        assert all(s == 1 for s in y.shape[:-2]), y.shape
+        mean = _lib.to_device(self.mean, t.float64).to(y.device)
+        cov = _lib.to_device(self.covariance, t.float64).to(y.device)
+        assert mean.ndim == 2 and tuple(cov.shape) == tuple(mean.shape), (mean.shape, cov.shape)
+        K = mean.shape[0]
+        out = engine.embed_log_pdf(y.reshape(1, N, E), _lib.EMBED_GAUSS_DIAG,
+                                   mean.reshape(1, K, E).contiguous(),
+                                   cov.reshape(1, K, E).contiguous())
+        return as_result(out.reshape(K, N), like_torch)
 
 
 @dataclass
@@ -118,14 +154,13 @@ class GaussianTrainer:
         return self._fit(y, saliency=saliency, covariance_type=covariance_type)
 
     def _fit(self, y, saliency, covariance_type):
-        """(:152-193) for covariance_type 'spherical' and 'full'."""
-        if covariance_type not in ('spherical', 'full'):
-            if covariance_type == 'diagonal':
-                raise NotImplementedError(
-                    "covariance_type='diagonal': 'spherical' and 'full' run on the device")
+        """(:152-193) for covariance_type 'spherical', 'diagonal' and 'full'."""
+        if covariance_type not in ('spherical', 'diagonal', 'full'):
             raise ValueError(f"Unknown covariance type '{covariance_type}'.")
         if covariance_type == 'full':
             return self._fit_full(y, saliency)
+        kind = (_lib.EMBED_GAUSS_DIAG if covariance_type == 'diagonal'
+                else _lib.EMBED_GAUSS_SPHERICAL)
         like_torch = _lib.is_torch(y)
         t = _lib.torch()
         y = _lib.to_device(y)
@@ -138,12 +173,15 @@ class GaussianTrainer:
         lead = np.broadcast_shapes(tuple(y.shape[:-2]), tuple(sal.shape[:-1]))
         K = int(np.prod(lead)) if lead else 1
         if all(s == 1 for s in y.shape[:-2]) and K <= 6:
-            mean, cov = engine.embed_fit(y.reshape(1, N, E), _lib.EMBED_GAUSS_SPHERICAL,
+            mean, cov = engine.embed_fit(y.reshape(1, N, E), kind,
                                          sal.expand(*lead, N).reshape(1, K, N).contiguous())
         else:
             mean, cov = engine.embed_fit(
-                y.expand(*lead, N, E).reshape(-1, N, E).contiguous(), _lib.EMBED_GAUSS_SPHERICAL,
+                y.expand(*lead, N, E).reshape(-1, N, E).contiguous(), kind,
                 sal.expand(*lead, N).reshape(-1, 1, N).contiguous())
+        if covariance_type == 'diagonal':
+            return DiagonalGaussian(mean=as_result(mean.reshape(*lead, E), like_torch),
+                                    covariance=as_result(cov.reshape(*lead, E), like_torch))
         return SphericalGaussian(mean=as_result(mean.reshape(*lead, E), like_torch),
                                  covariance=as_result(cov.reshape(lead), like_torch))
 

@@ -2,7 +2,9 @@
 embeddings + spatial observations, Drude 2019) on the HIP engine.
 
 Mirrors pb_bss/distribution/gcacgmm.py:38-333: `GCACGMM` (predict) and
-`GCACGMMTrainer` (fit / fit_predict), no independent axes, spherical Gaussians.
+`GCACGMMTrainer` (fit / fit_predict), no independent axes; covariance_type 'spherical' (the
+default, csrc/embed.hip), 'diagonal' (as the reference writes its log-pdf) and 'full'
+(csrc/gauss_full.hip on the FP64 matrix pipe).
 """
 from dataclasses import dataclass
 from operator import xor
@@ -13,7 +15,18 @@ import numpy as np
 from .. import _lib
 from . import _joint
 from .complex_angular_central_gaussian import ComplexAngularCentralGaussian
-from .gaussian import SphericalGaussian
+from .gaussian import DiagonalGaussian, Gaussian, SphericalGaussian
+
+_KIND = {'spherical': _lib.EMBED_GAUSS_SPHERICAL, 'diagonal': _lib.EMBED_GAUSS_DIAG,
+         'full': _lib.EMBED_GAUSS_FULL}
+_CLASS = {'spherical': SphericalGaussian, 'diagonal': DiagonalGaussian, 'full': Gaussian}
+
+
+def _kind_of(gaussian):
+    for name, cls in _CLASS.items():
+        if isinstance(gaussian, cls):
+            return _KIND[name]
+    raise TypeError(type(gaussian))
 from .utils import _ProbabilisticModel, as_result
 
 __all__ = ['GCACGMM', 'GCACGMMTrainer']
@@ -23,7 +36,7 @@ __all__ = ['GCACGMM', 'GCACGMMTrainer']
 class GCACGMM(_ProbabilisticModel):
     weight: Any = None  # Shape (), (K,), (F, K), (K, T)
     weight_constant_axis: tuple = None
-    gaussian: Any = None  # SphericalGaussian
+    gaussian: Any = None  # Gaussian, DiagonalGaussian, or SphericalGaussian
     cacg: ComplexAngularCentralGaussian = None
     spatial_weight: float = 1.
     spectral_weight: float = 1.
@@ -31,7 +44,7 @@ class GCACGMM(_ProbabilisticModel):
     def predict(self, observation, embedding):
         """observation (F, T, D) complex, embedding (F, T, E) real -> affiliation (F, K, T)
         (:47-64)."""
-        return _joint.predict(_lib.EMBED_GAUSS_SPHERICAL, self, self.gaussian.mean,
+        return _joint.predict(_kind_of(self.gaussian), self, self.gaussian.mean,
                               self.gaussian.covariance, observation, embedding)
 
 
@@ -47,13 +60,10 @@ class GCACGMMTrainer:
             "Exactly one of the two inputs has to be None: "
             f"{initialization is None} xor {num_classes is None}"
         )
-        if covariance_type != 'spherical':
-            if covariance_type in ('full', 'diagonal'):
-                raise NotImplementedError(
-                    f"covariance_type={covariance_type!r}: only 'spherical' runs on the device")
-            raise ValueError(f"Unknown covariance type '{covariance_type}'.")
+        if covariance_type not in _KIND:
+            raise ValueError(f"Unknown covariance type '{covariance_type}'.")  # gaussian.py:184
         r, like_torch = _joint.fit(
-            _lib.EMBED_GAUSS_SPHERICAL, observation, embedding, initialization, num_classes,
+            _KIND[covariance_type], observation, embedding, initialization, num_classes,
             iterations, saliency, covariance_norm=covariance_norm,
             eigenvalue_floor=eigenvalue_floor, affiliation_eps=affiliation_eps,
             weight_constant_axis=weight_constant_axis, spatial_weight=spatial_weight,
@@ -66,8 +76,8 @@ class GCACGMMTrainer:
             weight=_joint.weight_of(r, mode, K, like_torch),
             weight_constant_axis=tuple(weight_constant_axis) if not isinstance(
                 weight_constant_axis, int) else (weight_constant_axis,),
-            gaussian=SphericalGaussian(mean=as_result(r['mean'], like_torch),
-                                       covariance=as_result(r['scale'], like_torch)),
+            gaussian=_CLASS[covariance_type](mean=as_result(r['mean'], like_torch),
+                                             covariance=as_result(r['scale'], like_torch)),
             cacg=_joint.cacg_of(r, like_torch),
             spatial_weight=spatial_weight, spectral_weight=spectral_weight)
 

@@ -75,10 +75,13 @@ def apply_inline_permutation_alignment(affiliation, *, quadratic_form=None,
            f'(weight_constant_axis={weight_constant_axis}).')
     assert affiliation.ndim == 3, msg
     assert weight_constant_axis in ((-3,), (-3, -1), -3), msg
-    kft = affiliation.transpose(1, 0, 2)
+    def swap(x):  # (F, K, T) <-> (K, F, T) for NumPy arrays and torch tensors alike
+        return x.permute(1, 0, 2).contiguous() if hasattr(x, 'permute') else x.transpose(1, 0, 2)
+
+    kft = swap(affiliation)
     mapping = aligner.calculate_mapping(kft)
-    aligned = aligner.apply_mapping(kft, mapping).transpose(1, 0, 2)
+    aligned = swap(aligner.apply_mapping(kft, mapping))
     if quadratic_form is None:
         return aligned
-    q = aligner.apply_mapping(quadratic_form.transpose(1, 0, 2), mapping)
-    return aligned, q.transpose(1, 0, 2)
+    q = aligner.apply_mapping(swap(quadratic_form), mapping)
+    return aligned, swap(q)

@@ -487,14 +487,16 @@ def embed_log_pdf(y, kind, mean, scale):
 
 def embed_fit(y, kind, weights, *, normalize=False, min_concentration=1e-10,
               max_concentration=500.):
-    """pbbss_embed_fit.  y (B,N,E) real; weights (B,K,N) f64 -> mean (B,K,E), scale (B,K)."""
+    """pbbss_embed_fit.  y (B,N,E) real; weights (B,K,N) f64 -> mean (B,K,E), scale (B,K)
+    ((B,K,E) per-dimension variances for EMBED_GAUSS_DIAG)."""
     t = _t()
     y = _real_embedding(y)
     B, N, E = y.shape
     K = weights.shape[1]
     assert weights.shape == (B, K, N) and weights.dtype == t.float64
     mean = t.empty((B, K, E), dtype=t.float64, device=y.device)
-    scale = t.empty((B, K), dtype=t.float64, device=y.device)
+    scale = t.empty((B, K, E) if kind == _lib.EMBED_GAUSS_DIAG else (B, K), dtype=t.float64,
+                    device=y.device)
     rc = _lib.load().pbbss_embed_fit(
         _lib.handle(y.device.index), _lib.ptr(y), int(y.dtype == t.float64), B, N, E, K, int(kind),
         int(bool(normalize)), _lib.ptr(weights), float(min_concentration),
@@ -641,6 +643,21 @@ def gmm_full_fit(y, K, *, gamma0=None, model=None, iterations=100, saliency=None
     return dict(mean=mean, covariance=cov, weight=weight, affiliation=aff, log_pdf=lp, status=st)
 
 
+def estimate_mixture_weight(affiliation, saliency, reduce_inner, reduce_n):
+    """pbbss_estimate_mixture_weight: affiliation (Bo, Bi, K, N) f64, saliency (Bo, Bi, N) or
+    None -> (Bo, 1 if reduce_inner else Bi, K, 1 if reduce_n else N)."""
+    t = _t()
+    Bo, Bi, K, N = affiliation.shape
+    out = t.empty((Bo, 1 if reduce_inner else Bi, K, 1 if reduce_n else N), dtype=t.float64,
+                  device=affiliation.device)
+    rc = _lib.load().pbbss_estimate_mixture_weight(
+        _lib.handle(affiliation.device.index), _lib.ptr(affiliation), _lib.ptr(saliency), Bo, Bi, K,
+        N, int(bool(reduce_inner)), int(bool(reduce_n)), _lib.ptr(out),
+        _lib.stream_ptr(affiliation.device.index))
+    _lib.check(rc, f'estimate_mixture_weight(Bo={Bo},Bi={Bi},K={K},N={N})')
+    return out
+
+
 def joint_weight_shape(weight_mode, F, K, T):
     return {_lib.JOINT_WEIGHT_FK: (F, K), _lib.JOINT_WEIGHT_UNIFORM: (), _lib.JOINT_WEIGHT_K: (K,),
             _lib.JOINT_WEIGHT_KT: (K, T), _lib.JOINT_WEIGHT_CONST: ()}[weight_mode]
@@ -652,7 +669,9 @@ def joint_fit(observation, embedding, K, kind, *, gamma0=None, model=None, itera
               min_concentration=1e-10, max_concentration=500., fixed_scale=None,
               final_predict=False, check_status=True):
     """pbbss_joint_fit.  observation (F,T,D) complex, embedding (F,T,E) real;
-    gamma0 (F,K,T) f64 or (iterations=0) model=(eigvec, eigval, weight, mean (K,E), scale (K))."""
+    gamma0 (F,K,T) f64 or (iterations=0) model=(eigvec, eigval, weight, mean (K,E), scale);
+    scale: (K,) concentration / spherical variance, (K,E) diagonal variances, (K,E,E) full
+    covariance, by `kind`."""
     t = _t()
     embedding = _real_embedding(embedding)
     dev = observation.device
@@ -676,7 +695,8 @@ def joint_fit(observation, embedding, K, kind, *, gamma0=None, model=None, itera
     eigval = t.empty((F, K, D), dtype=f64, device=dev)
     weight = t.empty(wshape, dtype=f64, device=dev)
     mean = t.empty((K, E), dtype=f64, device=dev)
-    scale = t.empty((K,), dtype=f64, device=dev)
+    scale_shape = {_lib.EMBED_GAUSS_FULL: (K, E, E), _lib.EMBED_GAUSS_DIAG: (K, E)}.get(kind, (K,))
+    scale = t.empty(scale_shape, dtype=f64, device=dev)
     status = t.zeros((F, K), dtype=t.int32, device=dev)
     aff = t.empty((F, K, T), dtype=f64, device=dev) if final_predict else None
     in_vec = in_val = in_w = in_mean = None
@@ -684,7 +704,8 @@ def joint_fit(observation, embedding, K, kind, *, gamma0=None, model=None, itera
     if model is not None:
         in_vec, in_val, in_w, in_mean, in_scale = model
         assert in_vec.shape == (F, K, D, D) and in_val.shape == (F, K, D)
-        assert tuple(in_w.shape) == tuple(wshape) and in_mean.shape == (K, E) and in_scale.shape == (K,)
+        assert tuple(in_w.shape) == tuple(wshape) and in_mean.shape == (K, E)
+        assert tuple(in_scale.shape) == scale_shape, (tuple(in_scale.shape), scale_shape)
     else:
         assert gamma0.shape == (F, K, T) and gamma0.dtype == f64
     rc = _lib.load().pbbss_joint_fit(
@@ -694,6 +715,10 @@ def joint_fit(observation, embedding, K, kind, *, gamma0=None, model=None, itera
         _lib.ptr(eigval), _lib.ptr(weight), _lib.ptr(mean), _lib.ptr(scale), _lib.ptr(status),
         _lib.ptr(aff), _lib.stream_ptr(dev.index))
     _lib.check(rc, f'joint_fit(F={F},T={T},D={D},E={E},K={K})')
+    if kind == _lib.EMBED_GAUSS_FULL and int(status[0, 0].item()) & _lib.ST_NOT_POSDEF:
+        raise ValueError(  # sklearn's _compute_precision_cholesky via gaussian.py:26
+            'Fitting the mixture model failed because some components have ill-defined empirical '
+            'covariance (not positive definite)')
     if check_status and iterations > 0:
         _status_raise_em(status, 'joint model fit')
     return dict(eigvec=eigvec, eigval=eigval, weight=weight, mean=mean, scale=scale,

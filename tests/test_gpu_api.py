@@ -340,3 +340,82 @@ def test_remaining_beamformer_functions_match_reference():
     assert w[1, 0] == -1
     with pytest.raises(NotImplementedError):
         ex.get_lcmv_vector_souden(g['target'], g['target'], g['noise'])
+
+
+# ------------------------------------------------------------------ step-wise fit on the device
+def _oracle_stepwise(Y128, init, iters, weight_constant_axis, saliency=None, plan=None):
+    """The reference loop (cacgmm.py:252-278) from oracle pieces, optionally with an inline
+    DHTV aligner (mixture_model_utils.py:264-306)."""
+    from oracle import cacgmm as oc, permutation_alignment as op
+    yn = oc.normalize_observation(Y128)
+    aff, q, model = init, np.ones_like(init), None
+    for _ in range(iters):
+        if model is not None:
+            aff, q, _ = oc.e_step(yn, model['weight'], model['eigvec'], model['eigval'],
+                                  affiliation_eps=1e-10)
+            if plan is not None:
+                kft = aff.transpose(1, 0, 2)
+                mapping = op.dhtv_calculate_mapping(kft, plan)
+                aff = op.apply_mapping(kft, mapping).transpose(1, 0, 2)
+                q = op.apply_mapping(q.transpose(1, 0, 2), mapping).transpose(1, 0, 2)
+        w, vec, lam = oc.m_step(yn, q, aff, saliency=saliency,
+                                weight_constant_axis=weight_constant_axis)
+        model = dict(weight=w, eigvec=vec, eigval=lam)
+    return model
+
+
+@pytest.mark.parametrize('axis,with_sal', [((-3,), False), ((-3, -1), False), ((-3,), True),
+                                           ((-3, -1), True)])
+def test_stepwise_fit_on_device_matches_oracle(axis, with_sal):
+    """weight_constant_axis with the frequency axis: E-step, cross-bin weight reduction
+    (pbbss_estimate_mixture_weight) and M-step per iteration, all on the device."""
+    from oracle import cacgmm as oc, synth
+    from pb_bss_amd.distribution import CACGMMTrainer
+    Y, init = synth.make_stft(33, 120, 6, 3, seed=31)
+    Y128 = Y.astype(np.complex128)
+    sal = np.abs(Y128[..., 0]) if with_sal else None
+    ref = _oracle_stepwise(Y128, init, 5, axis, saliency=sal)
+    m = CACGMMTrainer().fit(Y, initialization=init, iterations=5, weight_constant_axis=axis,
+                            saliency=sal)
+    assert m.weight.shape == ref['weight'].shape
+    assert np.abs(m.weight - ref['weight']).max() < 1e-10
+    assert np.abs(m.predict(Y) - oc.em_predict(ref, Y128)).max() < 1e-8
+
+
+def test_stepwise_fit_with_device_inline_aligner_matches_oracle():
+    """inline_permutation_aligner = the DEVICE DHTV solver: no host round trip in the loop; same
+    trajectory as the reference loop with the (NumPy) DHTV aligner."""
+    from oracle import cacgmm as oc, permutation_alignment as op, synth
+    from pb_bss_amd.distribution import CACGMMTrainer
+    from pb_bss_amd.permutation_alignment import DHTVPermutationAlignment
+    F = 65
+    Y, init = synth.make_stft(F, 150, 4, 2, seed=12)
+    Y128 = Y.astype(np.complex128)
+    kw = dict(stft_size=2 * (F - 1), segment_start=10, segment_width=20, segment_shift=5,
+              main_iterations=8, sub_iterations=2)
+    solver = DHTVPermutationAlignment(**kw)
+    plan = np.asarray(solver.alignment_plan)
+    ref = _oracle_stepwise(Y128, init, 4, (-3,), plan=plan)
+    m = CACGMMTrainer().fit(Y, initialization=init, iterations=4, weight_constant_axis=(-3,),
+                            inline_permutation_aligner=solver)
+    assert np.abs(m.weight - ref['weight']).max() < 1e-9
+    assert np.abs(m.predict(Y) - oc.em_predict(ref, Y128)).max() < 1e-7
+
+
+def test_estimate_mixture_weight_kernel_against_numpy():
+    import torch
+    from pb_bss_amd import _lib, engine
+    from pb_bss_amd.distribution.mixture_model_utils import estimate_mixture_weight
+    rng = np.random.default_rng(1)
+    aff = rng.uniform(size=(3, 7, 4, 50))
+    aff /= aff.sum(-2, keepdims=True)
+    sal = rng.uniform(size=(3, 7, 50))
+    sal[1, 2] = 0
+    for red_inner, red_n, axes in ((True, False, (-3,)), (True, True, (-3, -1)),
+                                   (False, True, (-1,))):
+        for s in (None, sal):
+            want = estimate_mixture_weight(aff, s, axes)
+            got = engine.estimate_mixture_weight(
+                _lib.to_device(aff), None if s is None else _lib.to_device(s), red_inner, red_n)
+            assert tuple(got.shape) == want.shape
+            assert np.abs(_lib.to_host(got) - want).max() < 1e-13

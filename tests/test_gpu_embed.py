@@ -49,8 +49,12 @@ def test_single_fits_and_log_pdf_match_reference(dtype):
     np.testing.assert_allclose(f.mean, g['full_mean'], atol=1e-12)
     np.testing.assert_allclose(f.covariance, g['full_covariance'], atol=1e-12)
     np.testing.assert_allclose(f.log_pdf(y), g['full_log_pdf'], rtol=1e-9, atol=1e-8)
-    with pytest.raises(NotImplementedError):
-        GaussianTrainer()._fit(y, saliency=sal, covariance_type='diagonal')
+    d = GaussianTrainer()._fit(y, saliency=sal, covariance_type='diagonal')
+    np.testing.assert_allclose(d.mean, g['diagonal_mean'], atol=1e-12)
+    np.testing.assert_allclose(d.covariance, g['diagonal_covariance'], rtol=1e-10)
+    np.testing.assert_allclose(d.log_pdf(y), g['diagonal_log_pdf'], rtol=1e-10, atol=1e-9)
+    with pytest.raises(ValueError):
+        GaussianTrainer()._fit(y, saliency=sal, covariance_type='tied')
 
 
 def test_vmfmm_matches_reference_flat_and_independent_axes():
@@ -117,7 +121,11 @@ def test_vmfmm_torch_in_torch_out_and_uniform_weight():
 
 
 JOINT = [('embed_gcacgmm_spherical', 'gaussian'), ('embed_gcacgmm_weights', 'gaussian'),
-         ('embed_gcacgmm_inline_pa', 'gaussian'), ('embed_vmfcacgmm', 'vmf')]
+         ('embed_gcacgmm_inline_pa', 'gaussian'), ('embed_vmfcacgmm', 'vmf'),
+         # covariance_type='full' / 'diagonal' (gcacgmm.py:141): fixtures from the live reference
+         ('embed_gcacgmm_full', 'gaussian'), ('embed_gcacgmm_diagonal', 'gaussian'),
+         ('embed_gcacgmm_full_weights', 'gaussian'), ('embed_gcacgmm_diagonal_pa', 'gaussian'),
+         ('embed_gcacgmm_full_fixed', 'gaussian')]
 
 
 @pytest.mark.parametrize('name,kind', JOINT)
@@ -125,6 +133,8 @@ def test_joint_models_match_reference(name, kind):
     from pb_bss_amd.distribution import GCACGMMTrainer, VMFCACGMMTrainer
     g = load(name)
     kw = ast.literal_eval(str(g['kwargs']))
+    if 'fixed_covariance' in g.files:
+        kw['fixed_covariance'] = g['fixed_covariance']
     trainer = GCACGMMTrainer() if kind == 'gaussian' else VMFCACGMMTrainer()
     model = trainer.fit(g['Y'], g['embedding'], initialization=g['init'],
                         iterations=int(g['iterations']), **kw)
@@ -141,6 +151,42 @@ def test_joint_models_match_reference(name, kind):
     aff = model.predict(g['Y'], g['embedding'])
     assert aff.shape == g['affiliation'].shape
     assert np.abs(aff - g['affiliation']).max() < 1e-7
+    if kind == 'gaussian':
+        from pb_bss_amd.distribution import DiagonalGaussian, Gaussian, SphericalGaussian
+        want = {'full': Gaussian, 'diagonal': DiagonalGaussian}.get(kw.get('covariance_type'),
+                                                                    SphericalGaussian)
+        assert type(model.gaussian) is want
+
+
+def test_diagonal_gaussian_single_fit_and_log_pdf_match_reference():
+    """GaussianTrainer._fit(covariance_type='diagonal') and DiagonalGaussian.log_pdf -- the
+    latter exactly as the reference evaluates it (gaussian.py:87-91)."""
+    from pb_bss_amd.distribution import DiagonalGaussian, GaussianTrainer
+    g = load('embed_single_fits')
+    y = g['y'].astype(np.float64)
+    m = GaussianTrainer()._fit(y[None], saliency=g['saliency'], covariance_type='diagonal')
+    assert isinstance(m, DiagonalGaussian)
+    np.testing.assert_allclose(m.mean, g['diagonal_mean'], atol=1e-11)
+    np.testing.assert_allclose(m.covariance, g['diagonal_covariance'], rtol=1e-10)
+    lp = DiagonalGaussian(mean=g['diagonal_mean'], covariance=g['diagonal_covariance']).log_pdf(y[None])
+    np.testing.assert_allclose(lp, g['diagonal_log_pdf'], rtol=1e-10, atol=1e-9)
+
+
+def test_gcacgmm_full_config5_shape_against_oracle():
+    """BASELINE config 5 shape (8 mics, K=3, 40-dim embeddings) with a full-covariance spectral
+    model: MFMA scatter / quadratic forms behind the joint EM loop."""
+    from pb_bss_amd.distribution import GCACGMMTrainer
+    from oracle import embed as oe, synth
+    F, T, D, K, E = 24, 300, 8, 3, 40
+    Y, e, init = synth.make_joint(F, T, D, K, E, seed=9)
+    Y128, e64 = Y.astype(np.complex128), e.astype(np.float64)
+    for ct in ('full', 'diagonal'):
+        ref = oe.joint_fit('gaussian', Y128, e64, init, 4, covariance_type=ct)
+        model = GCACGMMTrainer().fit(Y, e, initialization=init, iterations=4, covariance_type=ct)
+        np.testing.assert_allclose(model.gaussian.mean, ref['mean'], atol=1e-8)
+        np.testing.assert_allclose(model.gaussian.covariance, ref['covariance'], rtol=1e-6, atol=1e-9)
+        aff = model.predict(Y, e)
+        assert np.abs(aff - oe.joint_model_predict(ref, Y128, e64)).max() < 1e-6, ct
 
 
 @pytest.mark.parametrize('kind,kw', [
@@ -177,8 +223,11 @@ def test_joint_fixed_covariance_and_errors():
                        fixed_covariance=fixed)
     np.testing.assert_allclose(model.gaussian.covariance, fixed)
     np.testing.assert_allclose(model.gaussian.mean, ref['mean'], atol=1e-9)
-    with pytest.raises(NotImplementedError):
-        GCACGMMTrainer().fit(Y, e, initialization=init, iterations=2, covariance_type='full')
+    with pytest.raises(ValueError):  # gaussian.py:184 "Unknown covariance type"
+        GCACGMMTrainer().fit(Y, e, initialization=init, iterations=2, covariance_type='tied')
+    with pytest.raises(AssertionError):  # fixed covariance of the wrong shape (gcacgmm.py:306)
+        GCACGMMTrainer().fit(Y, e, initialization=init, iterations=2, covariance_type='full',
+                             fixed_covariance=fixed)
     with pytest.raises(AssertionError):
         GCACGMMTrainer().fit(Y, e, initialization=init, num_classes=2)
 
