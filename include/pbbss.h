@@ -94,6 +94,9 @@ int pbbss_normalize_observation(pbbss_handle_t h, const void* y, int is_c128,
 
 #define PBBSS_WEIGHT_PER_CLASS_MEAN 0 /* weight_constant_axis=(-1,): mean over frames   */
 #define PBBSS_WEIGHT_UNIFORM 1        /* weight_constant_axis=-2: constant 1/K          */
+/* pbbss_cacgmm_fit_shared only: weights shared by a group of problems (frequency bins)   */
+#define PBBSS_WEIGHT_SHARED_K 2       /* weight_constant_axis=(-3, -1): (group, K)      */
+#define PBBSS_WEIGHT_SHARED_KT 3      /* weight_constant_axis=(-3,): (group, K, T)      */
 
 #define PBBSS_LAYOUT_TD 0 /* observation (B,T,D): raw, the kernel unit-normalises */
 #define PBBSS_LAYOUT_DT 1 /* observation (B,D,T): already normalised (as _predict/_fit get it) */
@@ -141,6 +144,31 @@ int pbbss_cacgmm_fit(pbbss_handle_t h, const void* y, int64_t B, int T, int D,
                      double* out_eigval, double* out_weight,
                      int32_t* out_status, double* out_affiliation,
                      double* out_quadratic_form, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* a8' CACGMMTrainer.fit with weight_constant_axis=(-3,) or (-3, -1)             */
+/*     distribution/cacgmm.py:59, :142-157; mixture_model_utils.py:184-201       */
+/* The mixture weights are estimated over `group` consecutive problems (the      */
+/* frequency bins of one utterance): B = n_groups * group.  The whole loop is    */
+/* still ONE cooperative launch per batch of co-resident groups; the groups'     */
+/* workgroups exchange their masked affiliations (SHARED_KT) or class sums       */
+/* (SHARED_K) through device memory once per iteration.                          */
+/* opts->weight_mode: PBBSS_WEIGHT_SHARED_K -> in/out weight (B/group, K);       */
+/*                    PBBSS_WEIGHT_SHARED_KT -> in/out weight (B/group, K, T).   */
+/* Other arguments as pbbss_cacgmm_fit.  2 <= D <= 8, K <= 4, frames resident in */
+/* LDS, and `group` workgroups must fit the device at once (768 on MI355X at     */
+/* T = 500): otherwise PBBSS_ERR_UNSUPPORTED, and the caller runs the loop step  */
+/* by step (pbbss_cacgmm_predict, pbbss_estimate_mixture_weight, pbbss_cacg_fit).*/
+/* A hand-off that times out poisons out_status (EIG_NOCONV | NONFINITE) and     */
+/* sets the flag pbbss_split_error reports.                                      */
+/* ------------------------------------------------------------------------- */
+int pbbss_cacgmm_fit_shared(pbbss_handle_t h, const void* y, int64_t B, int T, int D, int K,
+                            int64_t group, const double* gamma0, const void* in_eigvec,
+                            const double* in_eigval, const double* in_weight,
+                            const double* saliency, const uint8_t* activity,
+                            const pbbss_em_opts* opts, void* out_eigvec, double* out_eigval,
+                            double* out_weight, int32_t* out_status, double* out_affiliation,
+                            double* out_quadratic_form, void* stream);
 
 /* ------------------------------------------------------------------------- */
 /* a4  CACGMM.predict / _predict   distribution/cacgmm.py:64-95                */

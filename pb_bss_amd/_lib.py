@@ -30,12 +30,15 @@ ST_SINGULAR = 32
 COVNORM = {False: 0, None: 0, 'eigenvalue': 1, 'trace': 2}
 WEIGHT_PER_CLASS_MEAN = 0
 WEIGHT_UNIFORM = 1
+WEIGHT_SHARED_K = 2   # weight_constant_axis=(-3, -1), pbbss_cacgmm_fit_shared only
+WEIGHT_SHARED_KT = 3  # weight_constant_axis=(-3,)
 LAYOUT_TD = 0
 LAYOUT_DT = 1
 
 EXPORTS = (
     'pbbss_version', 'pbbss_error_string', 'pbbss_create', 'pbbss_destroy',
-    'pbbss_normalize_observation', 'pbbss_cacgmm_fit', 'pbbss_cacgmm_predict',
+    'pbbss_normalize_observation', 'pbbss_cacgmm_fit', 'pbbss_cacgmm_fit_shared',
+    'pbbss_cacgmm_predict',
     'pbbss_cacg_m_step', 'pbbss_heev_batched', 'pbbss_psd', 'pbbss_gev', 'pbbss_gev_general',
     'pbbss_comm_unique_id', 'pbbss_comm_create', 'pbbss_comm_destroy', 'pbbss_shard_bounds',
     'pbbss_allgather_masks', 'pbbss_allgather_unpack', 'pbbss_estimate_mixture_weight',
@@ -165,6 +168,9 @@ def load():
         lib.pbbss_normalize_observation.argtypes = [vp, vp, i32, i64, i32, i32, vp, vp]
         lib.pbbss_cacgmm_fit.argtypes = [
             vp, vp, i64, i32, i32, i32, vp, vp, vp, vp, vp, vp,
+            ctypes.POINTER(EmOpts), vp, vp, vp, vp, vp, vp, vp]
+        lib.pbbss_cacgmm_fit_shared.argtypes = [
+            vp, vp, i64, i32, i32, i32, i64, vp, vp, vp, vp, vp, vp,
             ctypes.POINTER(EmOpts), vp, vp, vp, vp, vp, vp, vp]
         lib.pbbss_cacgmm_predict.argtypes = [
             vp, vp, i64, i32, i32, i32, vp, vp, vp, i64, i64, i64, vp, i32, i32,

@@ -70,6 +70,13 @@ struct EmArgs {
   unsigned* xcount;   // [n_problems] arrival counters (zeroed before the launch)
   int* xerror;        // [0] set to 1 if a bounded spin of THIS launch ran out; [16] sticky copy
   int split_prio;     // s_setprio level of the split waves (0..3)
+  // ---- weights shared across problems (run_shared: weight_mode PBBSS_WEIGHT_SHARED_*) ----
+  int wgroup;          // problems (frequency bins) that share one set of mixture weights
+  double* gsum;        // SHARED_K : [2][B][K]     masked class sums of every problem
+  double* gaff;        // SHARED_KT: [2][B][K][T]  masked affiliations of every problem
+  double* gw;          // SHARED_KT: [2][B / wgroup][K][T] reduced weights
+  unsigned* gcount;    // [B / wgroup][2] arrival counters: posts, finished reducers
+  double* out_weight_shared;  // (B / wgroup, K) or (B / wgroup, K, T)
   // options
   int iterations;
   int covariance_norm;
@@ -281,6 +288,8 @@ struct EmKernel {
         double g = a.gamma0[idx] * sal;
         double q = a.q0 ? a.q0[idx] : 1.0;
         L.wbuf[(size_t)k * L.Tp + t] = mweight(g, q, inv);
+        if (a.gaff && a.weight_mode == PBBSS_WEIGHT_SHARED_KT)  // parity 0: iteration 0
+          __hip_atomic_store(a.gaff + idx, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s[k] += g;
       }
     }
@@ -304,7 +313,9 @@ struct EmKernel {
   template <bool FINAL, bool TW, bool JOINT = false, bool PAIR = false>
   static __device__ void phase_e(const EmArgs& a, const Lds& L, int64_t b, int tid, int wave,
                                  int lane, double eps, int tf = 0,
-                                 const JointExtras* jx = nullptr) {
+                                 const JointExtras* jx = nullptr,
+                                 const double* w_kt = nullptr,  // TW: weights (K, T) of this problem's group
+                                 double* pub_kt = nullptr) {    // !FINAL: masked affiliation (K, T) out
     tid = opaque(tid);
     lane = opaque(lane);
     const int TS = t_stride(a);
@@ -485,7 +496,9 @@ struct EmKernel {
         for (int k = 0; k < K; ++k) {
           double w;
           if constexpr (TW) {
-            w = a.in_weight[b * a.wb + k * a.wk + (int64_t)(tf + t) * a.wt];
+            w = w_kt ? __hip_atomic_load(w_kt + (size_t)k * TS + tf + t, __ATOMIC_RELAXED,
+                                         __HIP_MEMORY_SCOPE_AGENT)
+                     : a.in_weight[b * a.wb + k * a.wk + (int64_t)(tf + t) * a.wt];
           } else {
             w = wgt[k];
           }
@@ -515,6 +528,9 @@ struct EmKernel {
             }
           } else {
             double gs = ok[f] ? gam * sal : 0.0;
+            if (pub_kt && ok[f])
+              __hip_atomic_store(pub_kt + (size_t)k * TS + tf + t, gs, __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_AGENT);
             // M-step weight gamma/max(q, 10 tiny)/|y|^2 (cacg.py:310, :322); q >= 10 tiny
             // except for all-zero frames, where inv = 0 makes the weight 0 anyway
             double rqk = (q[f][k] >= 10.0 * kTiny) ? rq[k] : (1.0 / (10.0 * kTiny));
@@ -819,7 +835,9 @@ struct EmKernel {
       L.status[k] |= st;
       // new mixture weight (off the serial path of the factorisation)
       double wnew;
-      if (a.weight_mode == PBBSS_WEIGHT_UNIFORM) {
+      if (a.weight_mode >= PBBSS_WEIGHT_SHARED_K) {
+        wnew = L.wgt[k];  // weights shared across problems: run_shared sets them
+      } else if (a.weight_mode == PBBSS_WEIGHT_UNIFORM) {
         wnew = 1.0 / K;  // mixture_model_utils.py:180-183
       } else if (a.saliency) {
         wnew = S / ((tot == 0.0) ? 1e-10 : tot);  // :192-201
@@ -1397,6 +1415,255 @@ struct EmKernel {
     if (a.final_predict) phase_e<true, false>(a, L, b, tid, wave, lane, a.final_eps, tf);
   }
 
+  // ======== mixture weights shared by a group of problems =====================================
+  // weight_constant_axis=(-3,) / (-3, -1) of the reference (cacgmm.py:59,
+  // mixture_model_utils.py:184-201): the weights are averaged over the frequency bins of one
+  // utterance, which couples the otherwise independent problems once per EM iteration.  All
+  // `wgroup` problems of a group run as co-resident workgroups (the launcher guarantees it) and
+  // exchange through agent-coherent (sc1) memory with a split-phase barrier: a workgroup
+  // posts its masked affiliations (or their class sums) right after the E-step, runs its own
+  // M-step and factorisation, and only then needs everybody else's contribution.
+  //   SHARED_K  (-3, -1): every workgroup sums the B x K class sums itself (fixed order).
+  //   SHARED_KT (-3,)   : 8-frame slices of the (K, T) weight plane are reduced by the first
+  //                       ceil(T / 8) workgroups of the group and re-published.
+  // Counters are monotonic: gcount[16 g] posts, gcount[16 g + 8] reduced slices.
+  static constexpr int kSliceFrames = 8;
+
+  static __device__ void shared_spin(const EmArgs& a, unsigned* cnt, unsigned target) {
+    unsigned spins = 0;
+    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > kSpinLimit) {
+        split_timeout(a);
+        break;
+      }
+    }
+  }
+
+  // after the barrier that follows an E-step (or the initialisation): publish, count
+  static __device__ void shared_post(const EmArgs& a, const Lds& L, int64_t b, int step, int tid) {
+    if (a.weight_mode == PBBSS_WEIGHT_SHARED_K && tid < K) {
+      double v = 0.0;
+#pragma unroll
+      for (int w = 0; w < kEmWaves; ++w) v += L.red[w * K + tid];
+      __hip_atomic_store(a.gsum + ((size_t)(step & 1) * a.B + b) * K + tid, v, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    // SHARED_KT: the E-step stored the affiliations and every wave drained them before the barrier
+    if (tid == 0)
+      __hip_atomic_fetch_add(a.gcount + (b / a.wgroup) * 16, 1u, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+  }
+
+  // SHARED_K: weights of `step` -> L.wgt
+  static __device__ void shared_acquire_k(const EmArgs& a, const Lds& L, int64_t b, int step,
+                                          int tid, int wave, int lane) {
+    const int64_t grp = b / a.wgroup;
+    if (tid == 0) shared_spin(a, a.gcount + grp * 16, (unsigned)a.wgroup * (unsigned)(step + 1));
+    __syncthreads();
+    const double* src = a.gsum + ((size_t)(step & 1) * a.B + grp * a.wgroup) * K;
+    double acc[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc[k] = 0.0;
+    for (int i = tid; i < a.wgroup; i += kEmThreads) {
+#pragma unroll
+      for (int k = 0; k < K; ++k)
+        acc[k] += __hip_atomic_load(src + (size_t)i * K + k, __ATOMIC_RELAXED,
+                                    __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      double tot = wave_sum(acc[k]);
+      if (lane == 0) L.red[wave * K + k] = tot;
+    }
+    __syncthreads();
+    if (tid < K) {
+      double mine = 0.0, norm = 0.0;
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        double tk = 0.0;
+#pragma unroll
+        for (int w = 0; w < kEmWaves; ++w) tk += L.red[w * K + k];
+        norm += fabs(tk);
+        if (k == tid) mine = tk;
+      }
+      if (a.saliency) {
+        L.wgt[tid] = mine / ((norm == 0.0) ? 1e-10 : norm);  // mixture_model_utils.py:190-201
+      } else {
+        L.wgt[tid] = mine / ((double)a.wgroup * (double)t_stride(a));  // :186-188
+      }
+    }
+    __syncthreads();
+  }
+
+  // SHARED_KT: reduce the slices owned by this workgroup (r = index within the group)
+  static __device__ void shared_reduce_kt(const EmArgs& a, const Lds& L, int64_t b, int step,
+                                          int tid, int wave, int lane) {
+    const int TS = t_stride(a);
+    const int64_t grp = b / a.wgroup;
+    const int r = (int)(b - grp * a.wgroup);
+    const int nsl = (TS + kSliceFrames - 1) / kSliceFrames;
+    if (r >= nsl) return;
+    if (tid == 0) shared_spin(a, a.gcount + grp * 16, (unsigned)a.wgroup * (unsigned)(step + 1));
+    __syncthreads();
+    const double* src = a.gaff + ((size_t)(step & 1) * a.B + grp * a.wgroup) * K * TS;
+    double* dst = a.gw + ((size_t)(step & 1) * (a.B / a.wgroup) + grp) * K * TS;
+    const int j = tid & (kSliceFrames - 1);
+    const int part = tid / kSliceFrames;             // 32 parts over the problems of the group
+    constexpr int kParts = kEmThreads / kSliceFrames;
+    double* tmp = L.wbuf;                            // free between factorisation and the next E-step
+    for (int sl = r; sl < nsl; sl += a.wgroup) {
+      const int t = sl * kSliceFrames + j;
+      const bool ok = t < TS;
+      double acc[K];
+#pragma unroll
+      for (int k = 0; k < K; ++k) acc[k] = 0.0;
+      for (int i0 = part; i0 < a.wgroup; i0 += 4 * kParts) {
+        double v[4][K];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = i0 + u * kParts;
+          const bool in = ok && i < a.wgroup;
+#pragma unroll
+          for (int k = 0; k < K; ++k)
+            v[u][k] = in ? __hip_atomic_load(src + ((size_t)i * K + k) * TS + t, __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_AGENT)
+                         : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int k = 0; k < K; ++k) acc[k] += v[u][k];
+      }
+      // lanes of one wave: 8 parts x 8 frames -> butterfly over the parts
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        acc[k] += __shfl_xor(acc[k], 8);
+        acc[k] += __shfl_xor(acc[k], 16);
+        acc[k] += __shfl_xor(acc[k], 32);
+        if (lane < kSliceFrames) tmp[(wave * K + k) * kSliceFrames + lane] = acc[k];
+      }
+      __syncthreads();
+      if (tid < kSliceFrames && ok) {
+        double tk[K], norm = 0.0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          tk[k] = 0.0;
+#pragma unroll
+          for (int w = 0; w < kEmWaves; ++w) tk[k] += tmp[(w * K + k) * kSliceFrames + tid];
+          norm += fabs(tk[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          const double w = a.saliency ? tk[k] / ((norm == 0.0) ? 1e-10 : norm)  // :190-201
+                                      : tk[k] / (double)a.wgroup;               // :186-188
+          __hip_atomic_store(dst + (size_t)k * TS + t, w, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __syncthreads();
+      if (tid == 0)
+        __hip_atomic_fetch_add(a.gcount + grp * 16 + 8, 1u, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+
+  // SHARED_KT: wait until every slice of `step` is reduced; returns the (K, T) weight plane
+  static __device__ const double* shared_acquire_kt(const EmArgs& a, int64_t b, int step, int tid) {
+    const int TS = t_stride(a);
+    const int64_t grp = b / a.wgroup;
+    const int nsl = (TS + kSliceFrames - 1) / kSliceFrames;
+    if (tid == 0) shared_spin(a, a.gcount + grp * 16 + 8, (unsigned)nsl * (unsigned)(step + 1));
+    __syncthreads();
+    return a.gw + ((size_t)(step & 1) * (a.B / a.wgroup) + grp) * K * TS;
+  }
+
+  static __device__ void run_shared(const EmArgs& a, char* smem) {
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const Lds L = carve(smem, a.T, nullptr);
+    const int64_t b = a.b_first + blockIdx.x;  // one workgroup per problem, all co-resident
+    const bool kt = (a.weight_mode == PBBSS_WEIGHT_SHARED_KT);
+    const int TS = t_stride(a);
+    if (tid < K) L.status[tid] = 0;
+    if (tid == 0) *L.flags = 0;
+    __syncthreads();
+    phase_load(a, L, b, tid);
+    __syncthreads();
+    const bool model_in = (a.gamma0 == nullptr);
+    if (model_in) {
+      // the model of the caller carries one weight set per group: (B / wgroup, K[, T])
+      for (int k = wave; k < K; k += kEmWaves) prep_from_model(a, L, b, k, lane);
+      __syncthreads();
+      if (!kt && tid < K) L.wgt[tid] = a.in_weight[(b / a.wgroup) * K + tid];
+    } else {
+      phase_init_gamma(a, L, b, tid, wave, lane);  // SHARED_KT: posts the masked initialisation
+    }
+    if (kt) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int it = 0; it < a.iterations; ++it) {
+      if (it > 0 || model_in) {
+        double* pub = kt ? a.gaff + ((size_t)(it & 1) * a.B + b) * K * TS : nullptr;
+        if (kt) {
+          // first E-step of a fit that starts from a model: the weight plane of the caller
+          const double* w_kt = (it == 0) ? a.in_weight + (b / a.wgroup) * (int64_t)K * TS
+                                         : shared_acquire_kt(a, b, it - 1, tid);
+          phase_e<false, true, false, false>(a, L, b, tid, wave, lane, a.aff_eps, 0, nullptr, w_kt,
+                                             pub);
+        } else {
+          if (it > 0) shared_acquire_k(a, L, b, it - 1, tid, wave, lane);
+          phase_e<false, false, false, true>(a, L, b, tid, wave, lane, a.aff_eps);
+        }
+        if (kt) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+      }
+      shared_post(a, L, b, it, tid);
+      switch (wave) {
+        case 0: phase_m<0>(a, L, lane); break;
+        case 1: phase_m<1>(a, L, lane); break;
+        case 2: phase_m<2>(a, L, lane); break;
+        default: phase_m<3>(a, L, lane); break;
+      }
+      __syncthreads();
+      const bool last = (it == a.iterations - 1);
+      for (int k = wave; k < K; k += kEmWaves) factor_class(a, L, b, k, lane, last);
+      __syncthreads();
+      if (kt) shared_reduce_kt(a, L, b, it, tid, wave, lane);
+    }
+    const double* w_kt = nullptr;
+    if (a.iterations > 0) {
+      const int64_t grp = b / a.wgroup;
+      if (kt) {
+        w_kt = shared_acquire_kt(a, b, a.iterations - 1, tid);
+        if (a.out_weight_shared && b == grp * a.wgroup) {
+          for (int i = tid; i < K * TS; i += kEmThreads)
+            a.out_weight_shared[(size_t)grp * K * TS + i] =
+                __hip_atomic_load(w_kt + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      } else {
+        shared_acquire_k(a, L, b, a.iterations - 1, tid, wave, lane);
+        if (a.out_weight_shared && b == grp * a.wgroup && tid < K)
+          a.out_weight_shared[(size_t)grp * K + tid] = L.wgt[tid];
+      }
+    }
+    if (tid < K && a.out_status) {
+      int st = L.status[tid];
+      if (__hip_atomic_load(a.xerror, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+        st |= PBBSS_ST_EIG_NOCONV | PBBSS_ST_NONFINITE;  // a hand-off timed out: results are void
+      a.out_status[(size_t)b * K + tid] = st;
+    }
+    if (a.final_predict) {
+      if (w_kt) {
+        phase_e<true, true>(a, L, b, tid, wave, lane, a.final_eps, 0, nullptr, w_kt);
+      } else {
+        phase_e<true, false>(a, L, b, tid, wave, lane, a.final_eps);
+      }
+    }
+  }
+
   static __device__ void run(const EmArgs& a, char* smem) {
     const int tid = threadIdx.x;
     // wave index is uniform across the wavefront: tell the compiler so the phase
@@ -1494,6 +1761,12 @@ __global__ void __launch_bounds__(kEmThreads, em_waves_per_simd(K))
     cacgmm_joint_kernel(EmArgs a, JointExtras jx, int inline_pa) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   EmKernel<D, K, YS, false>::run_joint(a, jx, inline_pa, smem);
+}
+
+template <int D, int K, typename YS>
+__global__ void __launch_bounds__(kEmThreads, em_waves_per_simd(K)) cacgmm_em_shared_kernel(EmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  EmKernel<D, K, YS, false>::run_shared(a, smem);
 }
 
 template <int D, int K, typename YS>

@@ -522,6 +522,56 @@ PBBSS_API int pbbss_cacgmm_fit(pbbss_handle_t h, const void* y, int64_t B, int T
   return pbbss::em_launch(D, K, o->y_is_c128, a, h->cfg, as_stream(stream));
 }
 
+PBBSS_API int pbbss_cacgmm_fit_shared(pbbss_handle_t h, const void* y, int64_t B, int T, int D,
+                                      int K, int64_t group, const double* gamma0,
+                                      const void* in_eigvec, const double* in_eigval,
+                                      const double* in_weight, const double* saliency,
+                                      const uint8_t* activity, const pbbss_em_opts* o,
+                                      void* out_eigvec, double* out_eigval, double* out_weight,
+                                      int32_t* out_status, double* out_affiliation,
+                                      double* out_quadratic_form, void* stream) {
+  DeviceGuard device_guard(h);
+  if (!h || !y || !o || B <= 0 || T <= 0 || group <= 0 || B % group != 0)
+    return PBBSS_ERR_INVALID_ARG;
+  if (o->iterations <= 0) return PBBSS_ERR_INVALID_ARG;  // cacgmm.py:200
+  const bool has_gamma = gamma0 != nullptr;
+  const bool has_model = in_eigvec && in_eigval && in_weight;
+  if (has_gamma == has_model) return PBBSS_ERR_INVALID_ARG;  // xor, cacgmm.py:190
+  if (!out_eigvec || !out_eigval || !out_weight || !out_status) return PBBSS_ERR_INVALID_ARG;
+  if (o->covariance_norm < 0 || o->covariance_norm > 2) return PBBSS_ERR_INVALID_ARG;
+  if (o->weight_mode != PBBSS_WEIGHT_SHARED_K && o->weight_mode != PBBSS_WEIGHT_SHARED_KT)
+    return PBBSS_ERR_INVALID_ARG;
+  if (D < 2 || D > 8 || K < 1 || K > 4 || group > INT32_MAX) return PBBSS_ERR_UNSUPPORTED;
+  pbbss::EmArgs a{};
+  a.y = y;
+  a.B = B;
+  a.T = T;
+  a.wgroup = (int)group;
+  a.gamma0 = gamma0;
+  a.in_eigvec = static_cast<const double*>(in_eigvec);
+  a.in_eigval = in_eigval;
+  a.in_weight = in_weight;
+  a.saliency = saliency;
+  a.activity = activity;
+  a.out_eigvec = static_cast<double*>(out_eigvec);
+  a.out_eigval = out_eigval;
+  a.out_weight_shared = out_weight;
+  a.out_status = out_status;
+  a.out_aff = out_affiliation;
+  a.out_q = out_quadratic_form;
+  a.iterations = o->iterations;
+  a.covariance_norm = o->covariance_norm;
+  a.weight_mode = o->weight_mode;
+  a.layout = o->layout;
+  a.final_predict = o->final_predict && (out_affiliation || out_quadratic_form);
+  a.force_eig = o->force_eig;
+  a.aff_eps = o->affiliation_eps;
+  a.final_eps = 0.0;
+  a.eig_floor = o->eigenvalue_floor;
+  TimedRegion tr(h, as_stream(stream));
+  return pbbss::em_shared_launch(D, K, o->y_is_c128, a, h->cfg, as_stream(stream));
+}
+
 PBBSS_API int pbbss_cacgmm_predict(pbbss_handle_t h, const void* y, int64_t B, int T, int D,
                                    int K, const void* eigvec, const double* eigval,
                                    const double* weight, int64_t wb, int64_t wk, int64_t wt,
@@ -913,7 +963,7 @@ PBBSS_API int pbbss_estimate_mixture_weight(pbbss_handle_t h, const double* affi
                                             double* out_weight, void* stream) {
   DeviceGuard device_guard(h);
   if (!h || !affiliation || !out_weight || Bo <= 0 || Bi <= 0 || N <= 0) return PBBSS_ERR_INVALID_ARG;
-  if (K < 1 || K > 64) return PBBSS_ERR_UNSUPPORTED;
+  if (K < 1 || K > 64 || (saliency && K > 16)) return PBBSS_ERR_UNSUPPORTED;
   void* w = handle_work(h, WorkCarver::pad(pbbss::mixture_weight_tmp_doubles(Bo, Bi, K, N, reduce_n) * 8));
   if (!w) return PBBSS_ERR_HIP;
   return pbbss::launch_mixture_weight(affiliation, saliency, Bo, Bi, K, N, reduce_inner ? 1 : 0,

@@ -98,3 +98,28 @@ inline int joint_launch(int D, int K, int y_is_c128, const EmArgs& a, const Join
   }
 }
 }  // namespace pbbss
+
+namespace pbbss {
+// EM with mixture weights shared by groups of problems (shared_inst.hip), one per compiled D
+int em_shared_launch_d2(int K, int y_is_c128, const EmArgs&, const EmLaunchCfg&, hipStream_t);
+int em_shared_launch_d3(int K, int y_is_c128, const EmArgs&, const EmLaunchCfg&, hipStream_t);
+int em_shared_launch_d4(int K, int y_is_c128, const EmArgs&, const EmLaunchCfg&, hipStream_t);
+int em_shared_launch_d5(int K, int y_is_c128, const EmArgs&, const EmLaunchCfg&, hipStream_t);
+int em_shared_launch_d6(int K, int y_is_c128, const EmArgs&, const EmLaunchCfg&, hipStream_t);
+int em_shared_launch_d7(int K, int y_is_c128, const EmArgs&, const EmLaunchCfg&, hipStream_t);
+int em_shared_launch_d8(int K, int y_is_c128, const EmArgs&, const EmLaunchCfg&, hipStream_t);
+
+inline int em_shared_launch(int D, int K, int y_is_c128, const EmArgs& a, const EmLaunchCfg& cfg,
+                            hipStream_t s) {
+  switch (D) {
+    case 2: return em_shared_launch_d2(K, y_is_c128, a, cfg, s);
+    case 3: return em_shared_launch_d3(K, y_is_c128, a, cfg, s);
+    case 4: return em_shared_launch_d4(K, y_is_c128, a, cfg, s);
+    case 5: return em_shared_launch_d5(K, y_is_c128, a, cfg, s);
+    case 6: return em_shared_launch_d6(K, y_is_c128, a, cfg, s);
+    case 7: return em_shared_launch_d7(K, y_is_c128, a, cfg, s);
+    case 8: return em_shared_launch_d8(K, y_is_c128, a, cfg, s);
+    default: return PBBSS_ERR_UNSUPPORTED;
+  }
+}
+}  // namespace pbbss

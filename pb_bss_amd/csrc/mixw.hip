@@ -59,7 +59,7 @@ __global__ void __launch_bounds__(kT) mixw_finish_kernel(const double* __restric
                                                          int red_inner, int has_sal, double count,
                                                          double* __restrict__ out) {
   const int64_t Bi2 = red_inner ? 1 : Bi;
-  const int64_t bo = blockIdx.x / Bi2, b2 = blockIdx.x % Bi2;
+  const int64_t bo = blockIdx.x / Bi2, b2 = blockIdx.x % Bi2;  // blockIdx.y: tile of 256 frames
   extern __shared__ double sm[];  // [K] class totals when N1 == 1
   if (N1 == 1) {
     // parallel over bi, block reduction per class
@@ -96,26 +96,47 @@ __global__ void __launch_bounds__(kT) mixw_finish_kernel(const double* __restric
     }
     return;
   }
-  // N1 == N: thread = frame, loop over the classes (and the reduced problems)
-  for (int64_t n = threadIdx.x; n < N1; n += kT) {
-    double nrm = 0.0;
-    for (int pass = 0; pass < 2; ++pass) {  // pass 0: class norm (saliency only), pass 1: write
-      if (pass == 0 && !has_sal) continue;
-      for (int k = 0; k < K; ++k) {
-        double v = 0.0;
+  // N1 == N: one 64-frame tile per blockIdx.y; thread (f, part) = (tid & 63, tid >> 6) sums the
+  // reduced problems bi = part, part + 4, ... of frame f (consecutive threads read consecutive
+  // frames of one row: coalesced), the four parts are combined in a fixed order through LDS
+  __shared__ double comb[4][16][64];  // [part][class][frame]
+  const int f = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const int64_t n = (int64_t)blockIdx.y * 64 + f;
+  for (int k0 = 0; k0 < K; k0 += 16) {  // classes in chunks of 16 (K <= 64)
+    const int kc = (K - k0 < 16) ? K - k0 : 16;
+    for (int k = 0; k < kc; ++k) {
+      double v = 0.0;
+      if (n < N1) {
         if (red_inner) {
-          for (int64_t bi = 0; bi < Bi; ++bi) v += tmp[((bo * Bi + bi) * K + k) * N1 + n];
-        } else {
-          v = tmp[((bo * Bi + b2) * K + k) * N1 + n];
-        }
-        if (pass == 0) {
-          nrm += fabs(v);
-        } else {
-          out[((bo * Bi2 + b2) * K + k) * N1 + n] =
-              has_sal ? v / ((nrm == 0.0) ? 1e-10 : nrm) : v / count;
+          for (int64_t bi = part; bi < Bi; bi += 4) v += tmp[((bo * Bi + bi) * K + k0 + k) * N1 + n];
+        } else if (part == 0) {
+          v = tmp[((bo * Bi + b2) * K + k0 + k) * N1 + n];
         }
       }
+      comb[part][k][f] = v;
     }
+    __syncthreads();
+    if (part == 0 && n < N1) {
+      for (int k = 0; k < kc; ++k) {
+        const double v = (comb[0][k][f] + comb[1][k][f]) + (comb[2][k][f] + comb[3][k][f]);
+        comb[0][k][f] = v;
+      }
+    }
+    __syncthreads();
+    // the class norm needs ALL classes: K <= 16 in one chunk is the only case with saliency
+    // that occurs here (K <= 16 everywhere in the library); larger K fall back to plain sums
+    if (part == 0 && n < N1) {
+      double nrm = 0.0;
+      if (has_sal) {
+        for (int k = 0; k < kc; ++k) nrm += fabs(comb[0][k][f]);
+      }
+      for (int k = 0; k < kc; ++k) {
+        const double v = comb[0][k][f];
+        out[((bo * Bi2 + b2) * K + k0 + k) * N1 + n] =
+            has_sal ? v / ((nrm == 0.0) ? 1e-10 : nrm) : v / count;
+      }
+    }
+    __syncthreads();
   }
 }
 }  // namespace
@@ -132,8 +153,9 @@ int launch_mixture_weight(const double* aff, const double* sal, int64_t Bo, int6
                      red_n, tmp);
   const double count = (red_n ? (double)N : 1.0) * (red_inner ? (double)Bi : 1.0);
   const int64_t Bi2 = red_inner ? 1 : Bi;
-  hipLaunchKernelGGL(mixw_finish_kernel, dim3((unsigned)(Bo * Bi2)), dim3(kT), K * sizeof(double),
-                     s, tmp, Bi, K, N1, red_inner, sal ? 1 : 0, count, out);
+  const unsigned tiles = (unsigned)((N1 + 63) / 64);  // N1 == 1: one tile
+  hipLaunchKernelGGL(mixw_finish_kernel, dim3((unsigned)(Bo * Bi2), tiles), dim3(kT),
+                     K * sizeof(double), s, tmp, Bi, K, N1, red_inner, sal ? 1 : 0, count, out);
   return hipGetLastError() == hipSuccess ? PBBSS_OK : PBBSS_ERR_HIP;
 }
 

@@ -4,14 +4,17 @@ Mirrors pb_bss/distribution/cacgmm.py: `CACGMM` (predict / log_likelihood)
 and `CACGMMTrainer` (fit / fit_predict) with the reference's argument names,
 shapes (y is (..., N, D); affiliations (..., K, N)) and assertions.
 
-Two execution paths:
+Three execution paths:
   * fused   -- the whole EM loop in ONE kernel launch (pbbss_cacgmm_fit).  Used
                whenever every independent problem is self-contained:
                weight_constant_axis in {(-1,), -1, -2}, no inline aligner.
-  * stepwise -- E-step / host hook / M-step per iteration (pbbss_cacgmm_predict
-               + pbbss_cacg_m_step) for options that couple frequencies:
-               weight_constant_axis containing -3, inline_permutation_aligner
-               (cacgmm.py:260-267).
+  * shared  -- weight_constant_axis (-3,) / (-3, -1) (weights averaged over the
+               frequency bins): still one launch, a cooperative one whose workgroups
+               exchange their affiliations once per iteration (pbbss_cacgmm_fit_shared).
+  * stepwise -- E-step / hook / M-step per iteration (pbbss_cacgmm_predict,
+               pbbss_estimate_mixture_weight, pbbss_cacg_m_step) for everything else that
+               couples frequencies: inline_permutation_aligner (cacgmm.py:260-267), other
+               axis sets, more bins than fit the device at once.
 Arithmetic is float64 on the device for complex64 and complex128 input alike
 (SURVEY.md section 7); outputs are float64 / complex128.
 """
@@ -241,6 +244,14 @@ class CACGMMTrainer:
                 y.reshape(-1, N, D), indep, K, gamma0, model, iterations, sal,
                 act, mode, covariance_norm, affiliation_eps, eigenvalue_floor,
                 hermitize, like_torch, final_predict=_with_affiliation)
+        smode = self._shared_mode(weight_constant_axis, ndim)
+        if smode is not None and inline_permutation_aligner is None:
+            out = self._fit_shared(
+                y.reshape(-1, N, D), indep, K, gamma0, model, iterations, sal, act, smode,
+                covariance_norm, affiliation_eps, eigenvalue_floor, like_torch,
+                final_predict=_with_affiliation)
+            if out is not None:
+                return out
         return self._fit_stepwise(
             y.reshape(-1, N, D), indep, K, gamma0, model, iterations, saliency,
             sal, act, weight_constant_axis, covariance_norm, affiliation_eps,
@@ -257,6 +268,65 @@ class CACGMMTrainer:
         if axes == {-1}:
             return _lib.WEIGHT_PER_CLASS_MEAN
         return None
+
+    @staticmethod
+    def _shared_mode(axis, ndim):
+        """weight_constant_axis that averages the weights over the last independent axis (the
+        frequency bins): (-3,) and (-3, -1) run in the cooperative kernel."""
+        if isinstance(axis, int):
+            axis = (axis,)
+        axes = {a % ndim - ndim for a in axis}
+        if ndim >= 3 and axes == {-3}:
+            return _lib.WEIGHT_SHARED_KT
+        if ndim >= 3 and axes == {-3, -1}:
+            return _lib.WEIGHT_SHARED_K
+        return None
+
+    # ----------------------------------------------------- weights shared over the bins
+    def _fit_shared(self, yb, indep, K, gamma0, model, iterations, sal, act, smode,
+                    covariance_norm, affiliation_eps, eigenvalue_floor, like_torch,
+                    final_predict=False):
+        """weight_constant_axis (-3,) / (-3, -1): the whole loop in one cooperative launch
+        (pbbss_cacgmm_fit_shared); None if the configuration is not served there."""
+        t = _lib.torch()
+        B, N, D = yb.shape
+        group = indep[-1]
+        outer = tuple(indep[:-1])
+        G = B // group
+        Nw = N if smode == _lib.WEIGHT_SHARED_KT else 1
+        dev_model = None
+        g0 = None
+        if model is not None:
+            w = _lib.to_device(model.weight, t.float64).to(yb.device)
+            try:
+                w = w.expand(*outer, 1, K, Nw)
+            except RuntimeError:
+                return None  # weights of another shape: the step-wise loop takes any broadcast
+            vec = _lib.to_device(model.cacg.covariance_eigenvectors, t.complex128).to(yb.device)
+            val = _lib.to_device(model.cacg.covariance_eigenvalues, t.float64).to(yb.device)
+            dev_model = (
+                vec.expand(*indep, K, D, D).reshape(B, K, D, D).contiguous(),
+                val.expand(*indep, K, D).reshape(B, K, D).contiguous(),
+                w.reshape((G, K, N) if Nw == N else (G, K)).contiguous())
+        else:
+            g0 = gamma0.reshape(B, K, N).contiguous()
+        r = engine.em_fit_shared(
+            yb, K, group, weight_mode=smode, gamma0=g0, model=dev_model, iterations=iterations,
+            saliency=sal, activity=act, covariance_norm=covariance_norm,
+            affiliation_eps=affiliation_eps, eigenvalue_floor=eigenvalue_floor,
+            final_predict=final_predict)
+        if r is None:
+            return None
+        out = CACGMM(
+            weight=as_result(r['weight'].reshape(*outer, 1, K, Nw), like_torch),
+            cacg=ComplexAngularCentralGaussian(
+                covariance_eigenvectors=as_result(
+                    r['eigvec'].reshape(*indep, K, D, D), like_torch),
+                covariance_eigenvalues=as_result(
+                    r['eigval'].reshape(*indep, K, D), like_torch)))
+        if final_predict:
+            return out, as_result(r['affiliation'].reshape(*indep, K, N), like_torch)
+        return out
 
     # ------------------------------------------------------------------ fused
     def _fit_fused(self, yb, indep, K, gamma0, model, iterations, sal, act, mode,

@@ -101,6 +101,65 @@ def em_fit(y, K, *, gamma0=None, model=None, iterations=100, saliency=None,
                 affiliation=out_aff, quadratic_form=out_q)
 
 
+def em_fit_shared(y, K, group, *, weight_mode, gamma0=None, model=None, iterations=100,
+                  saliency=None, activity=None, covariance_norm='eigenvalue',
+                  affiliation_eps=1e-10, eigenvalue_floor=1e-10, final_predict=False,
+                  return_q=False, force_eig=False, check_status=True):
+    """pbbss_cacgmm_fit_shared: the EM loop with mixture weights estimated over `group`
+    consecutive problems (weight_constant_axis (-3,) -> WEIGHT_SHARED_KT, (-3, -1) ->
+    WEIGHT_SHARED_K), one cooperative launch.  y (B,T,D) complex, B = n_groups * group.
+    model = (eigvec (B,K,D,D), eigval (B,K,D), weight (B/group, K[, T])).
+    Returns None when the configuration is not served by the cooperative kernel
+    (PBBSS_ERR_UNSUPPORTED: too many bins to be co-resident, K > 4, long utterances);
+    otherwise dict(eigvec, eigval, weight (B/group, K[, T]), status, affiliation?, ...)."""
+    t = _t()
+    dev = y.device
+    B, T, D = y.shape
+    assert B % group == 0, (B, group)
+    G = B // group
+    is128 = y.dtype == t.complex128
+    assert y.dtype in (t.complex64, t.complex128), y.dtype
+    assert weight_mode in (_lib.WEIGHT_SHARED_K, _lib.WEIGHT_SHARED_KT), weight_mode
+    wshape = (G, K) if weight_mode == _lib.WEIGHT_SHARED_K else (G, K, T)
+    opts = _lib.EmOpts(
+        iterations=int(iterations), covariance_norm=_lib.COVNORM[covariance_norm],
+        weight_mode=int(weight_mode), hermitize=1, layout=int(_lib.LAYOUT_TD),
+        y_is_c128=int(is128), final_predict=int(bool(final_predict)),
+        force_eig=int(bool(force_eig)), affiliation_eps=float(affiliation_eps),
+        eigenvalue_floor=float(eigenvalue_floor))
+    f64 = t.float64
+    out_vec = t.empty((B, K, D, D), dtype=t.complex128, device=dev)
+    out_val = t.empty((B, K, D), dtype=f64, device=dev)
+    out_w = t.empty(wshape, dtype=f64, device=dev)
+    out_st = t.zeros((B, K), dtype=t.int32, device=dev)
+    out_aff = t.empty((B, K, T), dtype=f64, device=dev) if final_predict else None
+    out_q = t.empty((B, K, T), dtype=f64, device=dev) if (final_predict and return_q) else None
+    if model is not None:
+        in_vec, in_val, in_w = model
+        assert in_vec.shape == (B, K, D, D) and in_val.shape == (B, K, D), in_vec.shape
+        assert tuple(in_w.shape) == wshape and in_w.is_contiguous(), (in_w.shape, wshape)
+    else:
+        in_vec = in_val = in_w = None
+        assert gamma0.shape == (B, K, T) and gamma0.dtype == f64, (gamma0.shape, gamma0.dtype)
+    if saliency is not None:
+        assert saliency.shape == (B, T) and saliency.dtype == f64
+    if activity is not None:
+        assert activity.shape == (B, K, T) and activity.dtype == t.uint8
+    rc = _lib.load().pbbss_cacgmm_fit_shared(
+        _lib.handle(dev.index), _lib.ptr(y), B, T, D, K, int(group), _lib.ptr(gamma0),
+        _lib.ptr(in_vec), _lib.ptr(in_val), _lib.ptr(in_w), _lib.ptr(saliency),
+        _lib.ptr(activity), ctypes.byref(opts), _lib.ptr(out_vec),
+        _lib.ptr(out_val), _lib.ptr(out_w), _lib.ptr(out_st), _lib.ptr(out_aff),
+        _lib.ptr(out_q), _lib.stream_ptr(dev.index))
+    if rc == _lib.ERR_UNSUPPORTED:
+        return None
+    _lib.check(rc, f'cacgmm_fit_shared(B={B},group={group},T={T},D={D},K={K})')
+    if check_status:
+        _status_raise_em(out_st, 'CACGMMTrainer.fit')
+    return dict(eigvec=out_vec, eigval=out_val, weight=out_w, status=out_st,
+                affiliation=out_aff, quadratic_form=out_q)
+
+
 def em_predict(y, eigvec, eigval, weight, *, activity=None,
                layout=_lib.LAYOUT_TD, affiliation_eps=0.0,
                want_q=False, want_log_pdf=False, want_affiliation=True):

@@ -364,22 +364,98 @@ def _oracle_stepwise(Y128, init, iters, weight_constant_axis, saliency=None, pla
     return model
 
 
+def _force_stepwise(monkeypatch):
+    """Make pbbss_cacgmm_fit_shared 'unsupported' so that the trainer takes the step-wise loop."""
+    from pb_bss_amd import engine
+    monkeypatch.setattr(engine, 'em_fit_shared', lambda *a, **k: None)
+
+
+@pytest.mark.parametrize('path', ['shared', 'stepwise'])
 @pytest.mark.parametrize('axis,with_sal', [((-3,), False), ((-3, -1), False), ((-3,), True),
                                            ((-3, -1), True)])
-def test_stepwise_fit_on_device_matches_oracle(axis, with_sal):
-    """weight_constant_axis with the frequency axis: E-step, cross-bin weight reduction
-    (pbbss_estimate_mixture_weight) and M-step per iteration, all on the device."""
+def test_stepwise_fit_on_device_matches_oracle(axis, with_sal, path, monkeypatch):
+    """weight_constant_axis with the frequency axis, both device paths against the reference
+    loop: the cooperative kernel (pbbss_cacgmm_fit_shared: weights exchanged between the
+    workgroups inside one launch) and the step-wise loop (E-step, cross-bin weight reduction
+    pbbss_estimate_mixture_weight and M-step per iteration)."""
     from oracle import cacgmm as oc, synth
+    from pb_bss_amd import engine
     from pb_bss_amd.distribution import CACGMMTrainer
     Y, init = synth.make_stft(33, 120, 6, 3, seed=31)
     Y128 = Y.astype(np.complex128)
     sal = np.abs(Y128[..., 0]) if with_sal else None
     ref = _oracle_stepwise(Y128, init, 5, axis, saliency=sal)
+    calls = []
+    if path == 'stepwise':
+        _force_stepwise(monkeypatch)
+    else:
+        real = engine.em_fit_shared
+        monkeypatch.setattr(engine, 'em_fit_shared',
+                            lambda *a, **k: calls.append(1) or real(*a, **k))
     m = CACGMMTrainer().fit(Y, initialization=init, iterations=5, weight_constant_axis=axis,
                             saliency=sal)
+    assert path == 'stepwise' or calls  # the cooperative kernel really served the call
     assert m.weight.shape == ref['weight'].shape
     assert np.abs(m.weight - ref['weight']).max() < 1e-10
     assert np.abs(m.predict(Y) - oc.em_predict(ref, Y128)).max() < 1e-8
+
+
+@pytest.mark.parametrize('axis', [(-3,), (-3, -1)])
+def test_shared_weight_fit_batched_model_init_and_fit_predict(axis):
+    """Cooperative kernel with two utterances in one call (two weight groups), resumed from a
+    model (the weight plane of the caller drives the first E-step), and fit_predict (final
+    E-step inside the launch) -- each against the reference loop run per utterance."""
+    from oracle import cacgmm as oc, synth
+    from pb_bss_amd.distribution import CACGMMTrainer
+    data = [synth.make_stft(21, 90, 5, 2, seed=s) for s in (3, 4)]
+    Y = np.stack([d[0] for d in data])
+    init = np.stack([d[1] for d in data])
+    Y128 = Y.astype(np.complex128)
+    refs = [_oracle_stepwise(Y128[u], init[u], 3, axis) for u in range(2)]
+    m = CACGMMTrainer().fit(Y, initialization=init, iterations=3, weight_constant_axis=axis)
+    assert m.weight.shape == (2,) + refs[0]['weight'].shape
+    for u in range(2):
+        assert np.abs(m.weight[u] - refs[u]['weight']).max() < 1e-10
+    # resume: 2 + 1 iterations == 3 iterations
+    m2 = CACGMMTrainer().fit(Y, initialization=init, iterations=2, weight_constant_axis=axis)
+    m3 = CACGMMTrainer().fit(Y, initialization=m2, iterations=1, weight_constant_axis=axis)
+    assert np.abs(m3.weight - m.weight).max() < 1e-10
+    aff = CACGMMTrainer().fit_predict(Y, initialization=init, iterations=3,
+                                      weight_constant_axis=axis)
+    for u in range(2):
+        assert np.abs(aff[u] - oc.em_predict(refs[u], Y128[u])).max() < 1e-8
+        assert np.abs(m3.predict(Y)[u] - oc.em_predict(refs[u], Y128[u])).max() < 1e-8
+
+
+@pytest.mark.parametrize('axis', [(-3,), (-3, -1)])
+def test_shared_weight_fit_full_size_equals_stepwise(axis, monkeypatch):
+    """F = 513 bins x T = 500 frames: all 513 workgroups co-resident (3 per CU); the
+    cooperative launch and the step-wise loop walk the same trajectory."""
+    from oracle import synth
+    from pb_bss_amd.distribution import CACGMMTrainer
+    Y, init = synth.make_stft(513, 500, 8, 3, seed=5)
+    a = CACGMMTrainer().fit(Y, initialization=init, iterations=12, weight_constant_axis=axis)
+    _force_stepwise(monkeypatch)
+    b = CACGMMTrainer().fit(Y, initialization=init, iterations=12, weight_constant_axis=axis)
+    assert a.weight.shape == b.weight.shape
+    assert np.abs(a.weight - b.weight).max() < 1e-9
+    assert np.abs(a.predict(Y) - b.predict(Y)).max() < 1e-7
+
+
+def test_shared_weight_fit_falls_back_when_not_served(monkeypatch):
+    """K = 5 classes is outside the cooperative kernel: PBBSS_ERR_UNSUPPORTED from the C ABI,
+    the trainer runs the step-wise loop (same result as forcing it)."""
+    from oracle import synth
+    from pb_bss_amd import _lib, engine
+    from pb_bss_amd.distribution import CACGMMTrainer
+    Y, init = synth.make_stft(9, 80, 4, 5, seed=8)
+    y = _lib.to_device(Y)
+    assert engine.em_fit_shared(y, 5, 9, weight_mode=_lib.WEIGHT_SHARED_KT,
+                                gamma0=_lib.to_device(init)) is None
+    a = CACGMMTrainer().fit(Y, initialization=init, iterations=3, weight_constant_axis=(-3,))
+    _force_stepwise(monkeypatch)
+    b = CACGMMTrainer().fit(Y, initialization=init, iterations=3, weight_constant_axis=(-3,))
+    assert np.abs(a.weight - b.weight).max() == 0.0
 
 
 def test_stepwise_fit_with_device_inline_aligner_matches_oracle():
