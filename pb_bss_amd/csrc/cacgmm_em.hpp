@@ -121,6 +121,12 @@ struct EmKernel {
 #ifndef PBBSS_E_CHUNK
 #define PBBSS_E_CHUNK 1
 #endif
+#ifndef PBBSS_E_DPP
+#define PBBSS_E_DPP 1
+#endif
+#ifndef PBBSS_E_PAIR
+#define PBBSS_E_PAIR 0
+#endif
   static constexpr int kOperandChunk = PBBSS_E_CHUNK;  // pairs of A_k operands per prefetch stage of the E phase
   using YS4 = typename std::conditional<std::is_same<YS, float>::value, float4, double4>::type;
   using YS2 = typename std::conditional<std::is_same<YS, float>::value, float2, double2>::type;
@@ -346,6 +352,48 @@ struct EmKernel {
       // (uniform address = broadcast read) BEFORE the FMAs of chunk c issue, so
       // the LDS latency hides behind float64 work; compiler fences pin that
       // order (left alone hipcc loads just-in-time and stalls on every read).
+#if PBBSS_E_DPP
+      {
+        // A_k as DPP operands: lane l keeps apack[k][16 g + (l & 15)] (one conflict-free
+        // ds_read_b64 per 16 operands instead of one broadcast read per operand), and every
+        // FMA of the dot product <A_k, P> picks its operand out of that register with
+        // row_newbcast -- no LDS traffic inside the dot product, no operand staging.
+        constexpr int NG = (NA + 15) / 16;
+        double areg[K][NG];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+#pragma unroll
+          for (int g = 0; g < NG; ++g) {
+            const int e = 16 * g + (lane & 15);
+            areg[k][g] = L.apack[k * NA + (e < NA ? e : NA - 1)];
+          }
+        }
+        static_for<0, D>([&](auto ic) {
+          constexpr int i = ic;
+#pragma unroll
+          for (int f = 0; f < NF; ++f) {
+            const double dg = re[f][i] * re[f][i] + im[f][i] * im[f][i];
+#pragma unroll
+            for (int k = 0; k < K; ++k) fmac_row_bcast<i % 16>(q[f][k], areg[k][i / 16], dg);
+          }
+        });
+        static_for<0, NOFF>([&](auto pc) {
+          constexpr int p = pc;
+          constexpr int i = tri_i<D>(p), j = tri_j<D>(p);
+          constexpr int e0 = D + 2 * p, e1 = e0 + 1;
+#pragma unroll
+          for (int f = 0; f < NF; ++f) {
+            const double pr = re[f][i] * re[f][j] + im[f][i] * im[f][j];   // Re y_i conj(y_j)
+            const double pim = im[f][i] * re[f][j] - re[f][i] * im[f][j];  // Im y_i conj(y_j)
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+              fmac_row_bcast<e0 % 16>(q[f][k], areg[k][e0 / 16], pr);
+              fmac_row_bcast<e1 % 16>(q[f][k], areg[k][e1 / 16], pim);
+            }
+          }
+        });
+      }
+#else
       {
         constexpr int NCH = (NOFF + kOperandChunk - 1) / kOperandChunk;
         double op[2][kOperandChunk][K][2];
@@ -409,6 +457,7 @@ struct EmKernel {
           __builtin_amdgcn_sched_barrier(0);
         });
       }
+#endif
       // per-class constants (fetched here, not at phase entry: keeping them live
       // across the operand loop costs spills)
       double detm[K], rdet[K], wgt[K];
@@ -1615,7 +1664,7 @@ struct EmKernel {
                                              pub);
         } else {
           if (it > 0) shared_acquire_k(a, L, b, it - 1, tid, wave, lane);
-          phase_e<false, false, false, true>(a, L, b, tid, wave, lane, a.aff_eps);
+          phase_e<false, false, false, PBBSS_E_PAIR != 0>(a, L, b, tid, wave, lane, a.aff_eps);
         }
         if (kt) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -1700,7 +1749,7 @@ struct EmKernel {
       PBBSS_TICK(0)
       for (int it = 0; it < a.iterations; ++it) {
         if (it > 0 || model_in) {
-          phase_e<false, false, false, true>(a, L, b, tid, wave, lane, a.aff_eps);
+          phase_e<false, false, false, PBBSS_E_PAIR != 0>(a, L, b, tid, wave, lane, a.aff_eps);
           PBBSS_TICK(1)
           __syncthreads();
           PBBSS_TICK(2)

@@ -22,6 +22,7 @@
 #include "generic.hpp"
 #include <cmath>
 #include "generic_dev.hpp"
+#include <type_traits>
 
 namespace pbbss {
 namespace {
@@ -71,7 +72,23 @@ struct GenEstep {
   double* out_logpdf;
 };
 
-typedef __attribute__((address_space(4))) const double* gen_cptr;
+// static group stream of the E-step operands: row i (diagonal .. DP - 1) has ceil((DP - i) / 8)
+// groups of eight complex entries
+template <int DP>
+constexpr int gen_e_groups_before(int row) {
+  int n = 0;
+  for (int i = 0; i < row; ++i) n += (DP - i + 7) / 8;
+  return n;
+}
+template <int DP>
+constexpr int gen_e_row_of(int n) {
+  int i = 0;
+  while (n >= (DP - i + 7) / 8) {
+    n -= (DP - i + 7) / 8;
+    ++i;
+  }
+  return i;
+}
 
 template <int DP, typename YS>
 __global__ void __launch_bounds__(kGenThreads) gen_estep_kernel(GenEstep a) {
@@ -90,12 +107,14 @@ __global__ void __launch_bounds__(kGenThreads) gen_estep_kernel(GenEstep a) {
   {
     const int tc = valid ? t : 0;
     YS rr[DP], ri[DP];
+    // element strides of (frame, channel) in either layout: no per-channel layout branch
+    const size_t st = (a.layout == PBBSS_LAYOUT_TD) ? (size_t)D : 1;
+    const size_t sd = (a.layout == PBBSS_LAYOUT_TD) ? 1 : (size_t)T;
+    const YS* base = static_cast<const YS*>(a.y) + 2 * ((size_t)b * T * D + (size_t)tc * st);
 #pragma unroll
     for (int d = 0; d < DP; ++d) {
       const int dc = (d < D) ? d : 0;
-      const size_t idx = (a.layout == PBBSS_LAYOUT_TD) ? ((size_t)b * T + tc) * D + dc
-                                                       : ((size_t)b * D + dc) * T + tc;
-      const YS* p = static_cast<const YS*>(a.y) + 2 * idx;
+      const YS* p = base + 2 * ((size_t)dc * sd);
       rr[d] = p[0];
       ri[d] = p[1];
     }
@@ -109,25 +128,60 @@ __global__ void __launch_bounds__(kGenThreads) gen_estep_kernel(GenEstep a) {
   }
   // raw observations are unit-normalised (zero frames stay zero, utils.py:223-256)
   const double inv = (a.layout == PBBSS_LAYOUT_TD) ? ((n2 > 0.0) ? 1.0 / n2 : 0.0) : 1.0;
+  // y^H A y = sum_i A_ii |y_i|^2 + 2 Re sum_i conj(y_i) sum_{j>i} A_ij y_j  (A Hermitian).
+  // Operand feed: row i of A_k from the diagonal on is contiguous in the state and is cut into
+  // groups of eight complex entries; lane l loads double (l & 15) of a group, so one VGPR pair
+  // carries the group in each of the four rows of 16 lanes and the FMAs pick their operand
+  // with row_newbcast (fmac_row_bcast): one coalesced 128-byte load per 32 FMAs instead of a
+  // scalar load or an LDS broadcast per operand.  The groups of a class form one static stream
+  // (rows in order), fetched kAhead groups in front of the FMAs through a register ring; the
+  // scheduling barrier keeps hipcc from sinking the loads back to their first use.  No bounds
+  // tests: A and y are zero beyond D, the lane index is clamped to the matrix.
+  const int l16 = tid & 15;
+  constexpr int NGT = gen_e_groups_before<DP>(DP);  // groups of one class
+  constexpr int kAhead = (NGT < 6) ? NGT : 6, kRing = kAhead + 1;
+  double ring[kRing];
+  auto load_group = [&](const double* A, auto nc) {
+    constexpr int n = nc;
+    constexpr int i = gen_e_row_of<DP>(n), g = n - gen_e_groups_before<DP>(i);
+    const int idx = 2 * (i * DP + i) + 16 * g + l16;
+    ring[n % kRing] = A[idx < 2 * DP * DP ? idx : 2 * DP * DP - 1];
+  };
+  {
+    const double* A0 = a.inv + (size_t)b * K * DP * DP * 2;
+    static_for<0, kAhead>([&](auto nc) { load_group(A0, nc); });
+  }
 #pragma unroll 1
   for (int k = 0; k < K; ++k) {
-    const gen_cptr A = (gen_cptr)(a.inv + ((size_t)b * K + k) * DP * DP * 2);
-    // y^H A y = sum_i A_ii |y_i|^2 + 2 Re sum_i conj(y_i) sum_{j>i} A_ij y_j  (A Hermitian);
-    // no bounds tests: A and y are zero beyond D
+    const double* A = a.inv + ((size_t)b * K + k) * DP * DP * 2;
     double q = 0.0;
-#pragma unroll
-    for (int i = 0; i < DP; ++i) {
-      double ur = 0.0, ui = 0.0;
-#pragma unroll
-      for (int j = i + 1; j < DP; ++j) {
-        const double ar = A[(i * DP + j) * 2], ai = A[(i * DP + j) * 2 + 1];
-        ur = fma(ar, yr[j], ur);
-        ur = fma(-ai, yi[j], ur);
-        ui = fma(ar, yi[j], ui);
-        ui = fma(ai, yr[j], ui);
+    double ura = 0.0, urb = 0.0, uia = 0.0, uib = 0.0;  // Re u = ura - urb, Im u = uia + uib
+    static_for<0, NGT>([&](auto nc) {
+      constexpr int n = nc;
+      constexpr int i = gen_e_row_of<DP>(n), g = n - gen_e_groups_before<DP>(i);
+      constexpr int ng = (DP - i + 7) / 8;
+      if constexpr (n + kAhead < NGT) load_group(A, std::integral_constant<int, n + kAhead>{});
+      __builtin_amdgcn_sched_barrier(0);
+      const double grp = ring[n % kRing];
+      if constexpr (g == 0) {
+        ura = urb = uia = uib = 0.0;
+        fmac_row_bcast<0>(q, grp, fma(yr[i], yr[i], yi[i] * yi[i]));
       }
-      q = fma(A[(i * DP + i) * 2], fma(yr[i], yr[i], yi[i] * yi[i]), q);
-      q = fma(2.0, fma(yr[i], ur, yi[i] * ui), q);
+      static_for<0, 8>([&](auto cc) {
+        constexpr int c = cc, j = i + 8 * g + c;
+        if constexpr (j > i && j < DP) {
+          fmac_row_bcast<2 * c>(ura, grp, yr[j]);
+          fmac_row_bcast<2 * c + 1>(urb, grp, yi[j]);
+          fmac_row_bcast<2 * c>(uia, grp, yi[j]);
+          fmac_row_bcast<2 * c + 1>(uib, grp, yr[j]);
+        }
+      });
+      if constexpr (g == ng - 1) q = fma(2.0, fma(yr[i], ura - urb, yi[i] * (uia + uib)), q);
+    });
+    __builtin_amdgcn_sched_barrier(0);
+    {  // first groups of the next class (the last class re-reads its own: harmless)
+      const double* An = a.inv + ((size_t)b * K + (k + 1 < K ? k + 1 : k)) * DP * DP * 2;
+      static_for<0, kAhead>([&](auto nc) { load_group(An, nc); });
     }
     qs[k * kGenThreads + tid] = q;
   }

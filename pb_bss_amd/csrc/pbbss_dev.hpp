@@ -291,6 +291,20 @@ __device__ __forceinline__ void wave_sum2(double& a, double& b) {
   b = wave_sum(b);
 }
 
+// acc += a16[lane N of this lane's row of 16] * y   (DP-ALU DPP, gfx90a+: a float64 FMA may take
+// src0 through row_newbcast).  One VGPR pair whose 4 rows hold the same 16 values thereby serves
+// as 16 wave-uniform operands -- cheaper than an LDS broadcast read or an SGPR per operand
+// (tools/ubench/dpp_fmac.hip: same issue rate as the plain v_fmac_f64).  All 64 lanes must be
+// active.  `a16` must not have been written by a VALU instruction in the two preceding issue
+// slots (DPP read-after-VALU-write hazard; the operand registers are filled by LDS loads).
+template <int N>
+__device__ __forceinline__ void fmac_row_bcast(double& acc, double a16, double y) {
+  static_assert(N >= 0 && N < 16, "lane within the row");
+  asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+      : "+v"(acc)
+      : "v"(a16), "v"(y), "n"(N));
+}
+
 // 1/x to ~1 ulp for finite normal x: hardware estimate + two Newton steps
 // (5 VALU instructions instead of the ~11 of an IEEE-correct division).
 __device__ __forceinline__ double fast_rcp(double x) {
