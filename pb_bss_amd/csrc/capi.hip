@@ -424,18 +424,19 @@ PBBSS_API int pbbss_cacgmm_fit(pbbss_handle_t h, const void* y, int64_t B, int T
     const size_t ninv = pbbss::gen_state_doubles((int64_t)nmat, D);
     const size_t need = 2 * WorkCarver::pad(nkt * 8) + WorkCarver::pad(nmat * D * D * 16) +
                         WorkCarver::pad(ninv * 8) +
-                        WorkCarver::pad(nmat * 8) + WorkCarver::pad(nmat * 4) +
+                        2 * WorkCarver::pad(nmat * 8) + WorkCarver::pad(nmat * 4) +
                         WorkCarver::pad((size_t)B * 4);
     void* wmem = handle_work(h, need);
     if (!wmem) return PBBSS_ERR_HIP;
     WorkCarver wc(wmem);
     double* aff = wc.take<double>(nkt);
-    double* qf = wc.take<double>(nkt);
+    double* mw = wc.take<double>(nkt);  // M-step weights gamma sal / q / |y|^2 of every frame
     double* cov = wc.take<double>(nmat * D * D * 2);
     double* inv = wc.take<double>(ninv);
     double* inv_logdet = wc.take<double>(nmat);
     int32_t* inv_ok = wc.take<int32_t>(nmat);
     int32_t* zero_bin = wc.take<int32_t>((size_t)B);
+    double* csum = wc.take<double>(nmat);
     const pbbss::GenInverseState state{inv, inv_logdet, inv_ok};
     const pbbss::GenInverseState state_from_eig{inv, inv_logdet, nullptr};
     TimedRegion tr(h, s);
@@ -446,22 +447,27 @@ PBBSS_API int pbbss_cacgmm_fit(pbbss_handle_t h, const void* y, int64_t B, int T
       if ((rc = copy_d2d(out_weight, in_weight, nmat * 8, s)) != PBBSS_OK) return rc;
     }
     if (hipMemsetAsync(out_status, 0, nmat * sizeof(int32_t), s) != hipSuccess) return PBBSS_ERR_HIP;
+    // bins with an all-zero frame (flagged by the E-step / the initial weights) never take
+    // the inverse fast path
+    if (hipMemsetAsync(zero_bin, 0, (size_t)B * sizeof(int32_t), s) != hipSuccess) return PBBSS_ERR_HIP;
     for (int it = 0; it < o->iterations; ++it) {
       const double* g_src = gamma0;
-      const double* q_src = nullptr;
       if (it > 0 || has_model) {
         // from the second iteration on, classes whose inverse was accepted skip (V, lambda)
         rc = pbbss::launch_gen_estep(y, o->y_is_c128, PBBSS_LAYOUT_TD, B, T, D, K,
                                      static_cast<const double*>(out_eigvec), out_eigval,
-                                     out_weight, K, 1, 0, activity, o->affiliation_eps, aff, qf,
-                                     nullptr, s, it > 0 ? state : state_from_eig);
+                                     out_weight, K, 1, 0, activity, o->affiliation_eps, aff,
+                                     nullptr, nullptr, s, it > 0 ? state : state_from_eig,
+                                     saliency, mw, zero_bin);
         if (rc != PBBSS_OK) return rc;
         g_src = aff;
-        q_src = qf;
+      } else {
+        rc = pbbss::launch_gen_init_weights(y, o->y_is_c128, B, T, D, K, gamma0, saliency, mw,
+                                            zero_bin, s);
+        if (rc != PBBSS_OK) return rc;
       }
-      rc = pbbss::launch_gen_cov(y, o->y_is_c128, PBBSS_LAYOUT_TD, B, T, D, K, g_src,
-                                 (int64_t)K * T, q_src, saliency, 0, o->weight_mode, cov,
-                                 out_weight, nullptr, h->cfg.lds_limit, s, zero_bin);
+      rc = pbbss::launch_gen_mstep_cov(y, o->y_is_c128, B, T, D, K, mw, g_src, saliency,
+                                       o->weight_mode, csum, cov, out_weight, s);
       if (rc != PBBSS_OK) return rc;
       const bool last = it + 1 == o->iterations;
       if (!last && !o->force_eig) {

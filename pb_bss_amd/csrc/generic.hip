@@ -70,6 +70,11 @@ struct GenEstep {
   double* out_aff;
   double* out_q;
   double* out_logpdf;
+  // EM loop only: the M-step weight gamma sal / max(q, 10 tiny) / |y|^2 of every frame
+  // (cacg.py:310, :322) for gen_cov2, and the all-zero-frame flag of the bin
+  const double* saliency;  // (B,T) or null
+  double* out_mweight;     // (B,K,T) or null
+  int32_t* out_zero;       // (B) or null: set to 1 where a frame is all-zero
 };
 
 // static group stream of the E-step operands: row i (diagonal .. DP - 1) has ceil((DP - i) / 8)
@@ -100,21 +105,21 @@ __global__ void __launch_bounds__(kGenThreads) gen_estep_kernel(GenEstep a) {
   const int D = a.D, K = a.K, T = a.T;
   const int t = blockIdx.y * kGenThreads + tid;  // thread = frame
   const bool valid = t < T;
-  // unconditional loads at clamped indices into raw registers, masks afterwards: a guarded load
-  // that is converted inside its guard compiles to branch + load + s_waitcnt vmcnt(0), i.e. D
-  // serial memory round trips per frame (found in the ISA of the embedding E-step)
   double yr[DP], yi[DP], n2 = 0.0;
   {
+    // unconditional loads at clamped indices into raw registers, masks afterwards (a guarded
+    // load that is converted inside its guard compiles to branch + load + s_waitcnt vmcnt(0):
+    // D serial round trips).  (B, T, D) input is read with a lane stride of D
+    // complex numbers; staging it through LDS in coalesced slabs was measured and is slower
+    // (105 vs 101 us at D = 29, 75 vs 66 us at D = 24: the lines are L2 hits either way).
     const int tc = valid ? t : 0;
     YS rr[DP], ri[DP];
-    // element strides of (frame, channel) in either layout: no per-channel layout branch
     const size_t st = (a.layout == PBBSS_LAYOUT_TD) ? (size_t)D : 1;
     const size_t sd = (a.layout == PBBSS_LAYOUT_TD) ? 1 : (size_t)T;
     const YS* base = static_cast<const YS*>(a.y) + 2 * ((size_t)b * T * D + (size_t)tc * st);
 #pragma unroll
     for (int d = 0; d < DP; ++d) {
-      const int dc = (d < D) ? d : 0;
-      const YS* p = base + 2 * ((size_t)dc * sd);
+      const YS* p = base + 2 * ((size_t)((d < D) ? d : 0) * sd);
       rr[d] = p[0];
       ri[d] = p[1];
     }
@@ -214,7 +219,13 @@ __global__ void __launch_bounds__(kGenThreads) gen_estep_kernel(GenEstep a) {
     double gam = ls[k * kGenThreads + tid] / den;
     if (a.eps != 0.0) gam = fmin(fmax(gam, a.eps), 1.0 - a.eps);
     a.out_aff[((size_t)b * K + k) * T + t] = gam;
+    if (a.out_mweight) {
+      const double sal = a.saliency ? a.saliency[(size_t)b * T + t] : 1.0;
+      a.out_mweight[((size_t)b * K + k) * T + t] =
+          gam * sal / fmax(qs[k * kGenThreads + tid], 10.0 * kTiny) * inv;
+    }
   }
+  if (a.out_zero && a.layout == PBBSS_LAYOUT_TD && !(n2 > 0.0)) a.out_zero[b] = 1;
 }
 
 // (V, lambda) -> inverse state for the matrices not already marked ok (cacg.py:167-183 forms
@@ -483,6 +494,202 @@ __global__ void __launch_bounds__(kGenThreads) gen_cov_kernel(GenCov a) {
   }
 }
 
+// ------------------------------------------------------------------ M-step covariances (EM loop)
+// C_k = D / (sum_t g_kt) * sum_t w_kt y_t y_t^H with the weights w of the E-step above
+// (cacg.py:310-327), on raw (B, T, D) observations.  Matrix-free on the vector ALU with DPP
+// operands: a wavefront owns an 8 x 16 block of C (rows i = 8 I + m, columns j = 16 J + c) and
+// takes FOUR frames per instruction -- lane (r, c) = (frame of the quad, column):
+//     own  : w_k(t_r) conj(y_j(t_r))   in the lane's registers
+//     bcast: y_i(t_r) for the eight rows = 16 scalars of frame t_r in ONE register (lane c of
+//            the row of 16 lanes holds scalar 16 I + c of the frame), read by the FMAs through
+//            row_newbcast (pbbss_dev.hpp: fmac_row_bcast)
+// i.e. per quad one complex load, one scalar load and K weights per lane, then 32 K FMAs; no
+// LDS, no barrier, no cross-lane traffic inside the loop.  The four frame rows of a lane
+// column are summed at the end, the four waves of the workgroup (frame quarters) through LDS
+// in a fixed order.  Units (I, J) cover the upper triangle: I <= 2 J + 1.
+struct GenCov2 {
+  const void* y;
+  int64_t B;
+  int T, D, K;
+  const double* mweight;  // (B,K,T)
+  const double* csum;     // (B,K) class sums sum_t gamma sal
+  double* out_cov;        // c128 (B,K,D,D)
+  int k0, kc;             // classes of this launch (kc <= KM)
+  int NI;                 // row slabs: ceil(D / 8)
+};
+
+template <int KM, typename YS>
+__global__ void __launch_bounds__(kGenThreads) gen_cov2_kernel(GenCov2 a) {
+  using YS2 = typename std::conditional<std::is_same<YS, float>::value, float2, double2>::type;
+  __shared__ double part[kGenWaves][KM][8][16][2];
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63, r = lane >> 4, c = lane & 15;
+  const int64_t b = blockIdx.x;
+  const int D = a.D, K = a.K, T = a.T, kc = a.kc;
+  int I = blockIdx.y, J = 0;
+  for (;; ++J) {
+    const int cnt = min(2 * J + 2, a.NI);
+    if (I < cnt) break;
+    I -= cnt;
+  }
+  const int j = 16 * J + c, sidx = 16 * I + c;
+  const bool jv = j < D, sv = sidx < 2 * D;
+  const YS2* ybase = static_cast<const YS2*>(a.y) + (size_t)b * T * D;
+  const double* wbase = a.mweight + ((size_t)b * K + a.k0) * T;
+  const int nquad = (T + 3) / 4, qw = (nquad + kGenWaves - 1) / kGenWaves;
+  const int q0 = wave * qw, q1 = min(q0 + qw, nquad);
+  // raw loads at clamped addresses, masks when the values are used (a load inside its guard
+  // compiles to a branch and a full wait per load)
+  struct In {
+    YS2 own;
+    YS bc;
+    double w[KM];
+    bool tv;
+  };
+  const int jc = jv ? j : 0, sc = sv ? sidx : 0;
+  auto load = [&](int q) {
+    const int t = 4 * q + r;
+    In x;
+    x.tv = q < q1 && t < T;  // an invalid frame contributes through w = 0 only
+    const int tc = x.tv ? t : 0;
+    const YS2* fr = ybase + (size_t)tc * D;
+    x.own = fr[jc];
+    x.bc = reinterpret_cast<const YS*>(fr)[sc];
+#pragma unroll
+    for (int k = 0; k < KM; ++k) x.w[k] = wbase[(size_t)(k < kc ? k : 0) * T + tc];
+    return x;
+  };
+  double accr[8][KM], acci[8][KM];
+#pragma unroll
+  for (int m = 0; m < 8; ++m)
+#pragma unroll
+    for (int k = 0; k < KM; ++k) accr[m][k] = acci[m][k] = 0.0;
+  In cur = load(q0);
+  for (int q = q0; q < q1; ++q) {
+    const In nxt = load(q + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    const double zr = jv ? (double)cur.own.x : 0.0, zi = jv ? (double)cur.own.y : 0.0;
+    double breg = sv ? (double)cur.bc : 0.0;
+    double u[KM], v[KM], nv[KM];
+#pragma unroll
+    for (int k = 0; k < KM; ++k) {
+      const double wk = (cur.tv && k < kc) ? cur.w[k] : 0.0;
+      u[k] = wk * zr;
+      v[k] = wk * zi;
+      nv[k] = -v[k];
+    }
+    // breg was just written by the vector ALU: two wait states before a DPP read of it
+    asm volatile("s_nop 1" : "+v"(breg));
+    static_for<0, 8>([&](auto mc) {
+      constexpr int m = mc;
+#pragma unroll
+      for (int k = 0; k < KM; ++k) {
+        // C_ij += w y_i conj(y_j): Re = re_i re_j + im_i im_j, Im = im_i re_j - re_i im_j
+        fmac_row_bcast<2 * m>(accr[m][k], breg, u[k]);
+        fmac_row_bcast<2 * m + 1>(accr[m][k], breg, v[k]);
+        fmac_row_bcast<2 * m + 1>(acci[m][k], breg, u[k]);
+        fmac_row_bcast<2 * m>(acci[m][k], breg, nv[k]);
+      }
+    });
+    cur = nxt;
+  }
+  // four frame rows of the wave, then the four waves
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+#pragma unroll
+    for (int k = 0; k < KM; ++k) {
+      double xr = accr[m][k], xi = acci[m][k];
+      xr += __shfl_xor(xr, 16);
+      xi += __shfl_xor(xi, 16);
+      xr += __shfl_xor(xr, 32);
+      xi += __shfl_xor(xi, 32);
+      if (r == 0) {
+        part[wave][k][m][c][0] = xr;
+        part[wave][k][m][c][1] = xi;
+      }
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < kc * 128; e += kGenThreads) {
+    const int k = e >> 7, m = (e >> 4) & 7, cc = e & 15;
+    const int i = 8 * I + m, jj = 16 * J + cc;
+    if (i < D && jj < D && i <= jj) {
+      double sr = 0.0, si = 0.0;
+#pragma unroll
+      for (int w = 0; w < kGenWaves; ++w) {
+        sr += part[w][k][m][cc][0];
+        si += part[w][k][m][cc][1];
+      }
+      const double sc = (double)D / fmax(a.csum[b * K + a.k0 + k], kTiny);  // cacg.py:316, :327
+      sr *= sc;
+      si = (i == jj) ? 0.0 : si * sc;
+      double* up = a.out_cov + ((((size_t)b * K + a.k0 + k) * D + i) * D + jj) * 2;
+      double* lo = a.out_cov + ((((size_t)b * K + a.k0 + k) * D + jj) * D + i) * 2;
+      up[0] = sr;
+      up[1] = si;
+      lo[0] = sr;
+      lo[1] = -si;
+    }
+  }
+}
+
+// class sums sum_t gamma_kt sal_t and the mixture weights (mixture_model_utils.py:180-201)
+__global__ void __launch_bounds__(kGenThreads) gen_csum_kernel(const double* gamma,
+                                                               const double* saliency, int K,
+                                                               int T, int weight_mode,
+                                                               double* out_sum,
+                                                               double* out_weight) {
+  __shared__ double red[kGenWaves];
+  __shared__ double cs[kGenMaxK];
+  const int tid = threadIdx.x;
+  const int64_t b = blockIdx.x;
+  for (int k = 0; k < K; ++k) {
+    double acc = 0.0;
+    for (int t = tid; t < T; t += kGenThreads)
+      acc += gamma[((size_t)b * K + k) * T + t] * (saliency ? saliency[(size_t)b * T + t] : 1.0);
+    acc = block_sum(acc, red, tid);
+    if (tid == 0) cs[k] = acc;
+    __syncthreads();
+  }
+  if (tid < K) {
+    double tot_abs = 0.0;
+    for (int k = 0; k < K; ++k) tot_abs += fabs(cs[k]);
+    out_sum[b * K + tid] = cs[tid];
+    if (out_weight) {
+      double w;
+      if (weight_mode == PBBSS_WEIGHT_UNIFORM) w = 1.0 / K;
+      else if (saliency) w = cs[tid] / ((tot_abs == 0.0) ? 1e-10 : tot_abs);  // mm_utils.py:192
+      else w = cs[tid] / (double)T;                                             // :188
+      out_weight[b * K + tid] = w;
+    }
+  }
+}
+
+// M-step weights of an affiliation initialisation (first iteration: quadratic form = 1,
+// cacgmm.py:211-228): w = gamma0 sal / |y|^2, and the all-zero-frame flag
+template <typename YS>
+__global__ void __launch_bounds__(kGenThreads) gen_init_weight_kernel(
+    const void* y, int T, int D, int K, const double* gamma0, const double* saliency,
+    double* out_mweight, int32_t* out_zero) {
+  const int64_t b = blockIdx.x;
+  const int t = blockIdx.y * kGenThreads + threadIdx.x;
+  if (t >= T) return;
+  const YS* fr = static_cast<const YS*>(y) + 2 * ((size_t)b * T + t) * D;
+  double n2 = 0.0;
+  for (int d = 0; d < D; ++d) {
+    const double re = (double)fr[2 * d], im = (double)fr[2 * d + 1];
+    n2 += re * re + im * im;
+  }
+  const double inv = (n2 > 0.0) ? 1.0 / n2 : 0.0;
+  if (!(n2 > 0.0) && out_zero) out_zero[b] = 1;
+  const double sal = saliency ? saliency[(size_t)b * T + t] : 1.0;
+  for (int k = 0; k < K; ++k) {
+    const size_t idx = ((size_t)b * K + k) * T + t;
+    out_mweight[idx] = gamma0[idx] * sal * inv;
+  }
+}
+
 // ------------------------------------------------------------------ Hermitian eigensolver
 struct GenHeev {
   const double* a;      // c128 (N,D,D)
@@ -497,16 +704,20 @@ struct GenHeev {
 };
 
 
-template <int DP>
-__global__ void __launch_bounds__(kGenThreads) gen_heev_kernel(GenHeev g) {
+// NT threads per matrix: one entry of the D x D block per thread at D = 32 (NT = 1024) -- the
+// solver is a chain of ~200 rounds of three barriers each, and LDS (64 KB per matrix at DP = 32)
+// admits only two workgroups per CU, so the waves that hide its latency must come from within
+// the workgroup.
+template <int DP, int NT>
+__global__ void __launch_bounds__(NT) gen_heev_kernel(GenHeev g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* A = reinterpret_cast<double*>(smem);     // [DP][DP][2]
   double* A2 = A + DP * DP * 2;
   double* V = A2 + DP * DP * 2;
   double* V2 = V + DP * DP * 2;
   double* rot = V2 + DP * DP * 2;                  // [DP][3]: c, (s u) re, im of the pair of index x
-  double* red = rot + DP * 3;                      // [kGenWaves]
-  int* part = reinterpret_cast<int*>(red + kGenWaves);  // [DP] partner of x in this round
+  double* red = rot + DP * 3;                      // [NT / 64]
+  int* part = reinterpret_cast<int*>(red + NT / kWave);  // [DP] partner of x in this round
   const int tid = threadIdx.x;
   const int64_t n = blockIdx.x;
   if (g.skip && g.skip[n]) return;  // uniform over the workgroup
@@ -516,7 +727,7 @@ __global__ void __launch_bounds__(kGenThreads) gen_heev_kernel(GenHeev g) {
   // load (Hermitian from the upper triangle, like numpy's default UPLO='L' on the C-order
   // array == LAPACK upper of the transpose; both halves agree for the covariances used here)
   double tr = 0.0;
-  for (int e = tid; e < DP * DP; e += kGenThreads) {
+  for (int e = tid; e < DP * DP; e += NT) {
     const int i = e / DP, j = e - i * DP;
     double re = 0.0, im = 0.0;
     if (i < D && j < D) {
@@ -531,19 +742,19 @@ __global__ void __launch_bounds__(kGenThreads) gen_heev_kernel(GenHeev g) {
     V[e * 2] = (i == j) ? 1.0 : 0.0;
     V[e * 2 + 1] = 0.0;
   }
-  tr = block_sum(tr, red, tid);
+  tr = gen_block_sum<NT>(tr, red, tid);
   if (g.covariance_norm == PBBSS_COVNORM_TRACE) {  // cacg.py:88-90
     const double it = 1.0 / fmax(tr, kTiny);
     __syncthreads();
-    for (int e = tid; e < DP * DP * 2; e += kGenThreads) A[e] *= it;
+    for (int e = tid; e < DP * DP * 2; e += NT) A[e] *= it;
   }
   __syncthreads();
   double fro2 = 0.0;
-  for (int e = tid; e < DP * DP; e += kGenThreads) fro2 += A[e * 2] * A[e * 2] + A[e * 2 + 1] * A[e * 2 + 1];
-  fro2 = block_sum(fro2, red, tid);
+  for (int e = tid; e < DP * DP; e += NT) fro2 += A[e * 2] * A[e * 2] + A[e * 2 + 1] * A[e * 2 + 1];
+  fro2 = gen_block_sum<NT>(fro2, red, tid);
   if (!isfinite(fro2)) st |= PBBSS_ST_NONFINITE;
   const GenJacobiScratch scratch{A2, V2, rot, red, part};
-  if (lds_jacobi_heev(A, V, scratch, D, DP, tid) < 0) st |= PBBSS_ST_EIG_NOCONV;
+  if (lds_jacobi_heev<NT>(A, V, scratch, D, DP, tid) < 0) st |= PBBSS_ST_EIG_NOCONV;
   __syncthreads();
   // eigenvalues -> rank (ascending, ties by index), normalisation and floor, outputs
   double* lam = A2;          // reuse: [DP] eigenvalues, [DP] processed
@@ -578,7 +789,7 @@ __global__ void __launch_bounds__(kGenThreads) gen_heev_kernel(GenHeev g) {
     g.out_val[(size_t)n * D + rk] = lout;
   }
   __syncthreads();
-  for (int e = tid; e < DP * DP; e += kGenThreads) {
+  for (int e = tid; e < DP * DP; e += NT) {
     const int i = e / DP, j = e - i * DP;
     if (i < D && j < D) {
       double* o = g.out_vec + (((size_t)n * D + i) * D + rank[j]) * 2;
@@ -611,79 +822,125 @@ struct GenInv {
   int LD;              // row stride of out_inv (gen_state_ld(D)), zero beyond D
 };
 
+// The matrix lives in REGISTERS for the whole sweep: thread (bi, bj) owns the BS x BS block of
+// entries (bi BS + r, bj BS + c) (BS = 2 for DP > 16: 256 threads x 4 entries at DP = 32); per
+// pivot only the pivot row and column travel through LDS (double-buffered by pivot parity:
+// one barrier per pivot), instead of the whole matrix being read and written there.
 template <int DP>
 __global__ void __launch_bounds__(kGenThreads) gen_inv_kernel(GenInv g) {
-  __shared__ __attribute__((aligned(16))) double A[DP * DP * 2];
-  __shared__ __attribute__((aligned(16))) double rowp[DP * 2];
-  __shared__ __attribute__((aligned(16))) double colp[DP * 2];
+  constexpr int BS = (DP > 16) ? 2 : 1;
+  constexpr int NBK = DP / BS;  // blocks per dimension
+  static_assert(NBK * NBK <= kGenThreads && DP % BS == 0, "one block per thread");
+  __shared__ __attribute__((aligned(16))) double A[DP * DP * 2];  // only for the final symmetrisation
+  __shared__ __attribute__((aligned(16))) double rowp[2][DP * 2];
+  __shared__ __attribute__((aligned(16))) double colp[2][DP * 2];
   __shared__ double red[kGenWaves];
   const int tid = threadIdx.x;
   const int64_t n = blockIdx.x;
   const int D = g.D;
+  const bool owner = tid < NBK * NBK;
+  const int bi = owner ? tid / NBK : 0, bj = owner ? tid % NBK : 0;
+  double ar[BS][BS], ai[BS][BS];
   double tr = 0.0;
-  for (int e = tid; e < DP * DP; e += kGenThreads) {
-    const int i = e / DP, j = e - i * DP;
-    double re = 0.0, im = 0.0;
-    if (i < D && j < D) {  // same triangle as gen_heev
-      const int lo = i < j ? j : i, hi = i < j ? i : j;
-      const double* p = g.a + (((size_t)n * D + lo) * D + hi) * 2;
-      re = p[0];
-      im = (i == j) ? 0.0 : ((i > j) ? p[1] : -p[1]);
-      if (i == j) tr += re;
+#pragma unroll
+  for (int r = 0; r < BS; ++r) {
+#pragma unroll
+    for (int c = 0; c < BS; ++c) {
+      const int i = bi * BS + r, j = bj * BS + c;
+      double re = 0.0, im = 0.0;
+      if (owner && i < D && j < D) {  // same triangle as gen_heev
+        const int lo = i < j ? j : i, hi = i < j ? i : j;
+        const double* p = g.a + (((size_t)n * D + lo) * D + hi) * 2;
+        re = p[0];
+        im = (i == j) ? 0.0 : ((i > j) ? p[1] : -p[1]);
+        if (i == j) tr += re;
+      }
+      ar[r][c] = re;
+      ai[r][c] = im;
     }
-    A[e * 2] = re;
-    A[e * 2 + 1] = im;
   }
   tr = block_sum(tr, red, tid);  // ends with a barrier
   // Gauss-Jordan sweep without pivoting: the pivots of a Hermitian positive definite matrix
   // are its (positive) Schur complements and their product is the determinant
   bool ok = true;
   double logdet = 0.0;
-  for (int p = 0; p < D; ++p) {
-    if (tid < D) {
-      rowp[tid * 2] = A[(p * DP + tid) * 2];
-      rowp[tid * 2 + 1] = A[(p * DP + tid) * 2 + 1];
-      colp[tid * 2] = A[(tid * DP + p) * 2];
-      colp[tid * 2 + 1] = A[(tid * DP + p) * 2 + 1];
-    }
-    __syncthreads();
-    const double piv = rowp[p * 2];
-    if (!(piv > 0.0) || !isfinite(piv)) {  // the same value in every thread
-      ok = false;
-      break;
-    }
-    const double ip = 1.0 / piv;
-    logdet += log(piv);
-    for (int e = tid; e < DP * DP; e += kGenThreads) {
-      const int i = e / DP, j = e - i * DP;
-      if (i < D && j < D) {
-        const double cr = colp[i * 2], ci = colp[i * 2 + 1];
-        const double rr = rowp[j * 2] * ip, ri = rowp[j * 2 + 1] * ip;
-        double xr, xi;
-        if (i == p) {
-          xr = (j == p) ? ip : rr;
-          xi = (j == p) ? 0.0 : ri;
-        } else if (j == p) {
-          xr = -cr * ip;
-          xi = -ci * ip;
-        } else {
-          xr = A[e * 2] - (cr * rr - ci * ri);
-          xi = A[e * 2 + 1] - (cr * ri + ci * rr);
+  // pivot p = pb BS + pr: pr is a compile-time constant of the unrolled inner loop, so that
+  // the owner's register arrays are indexed statically (a runtime row select is turned into an
+  // indexed scratch access by hipcc)
+  for (int pb = 0; pb < NBK; ++pb) {
+    static_for<0, BS>([&](auto prc) {
+      constexpr int pr = prc;
+      const int p = pb * BS + pr;
+      if (p >= D || !ok) return;  // uniform over the workgroup
+      double* rp = rowp[p & 1];
+      double* cp = colp[p & 1];
+      if (owner && bi == pb) {
+#pragma unroll
+        for (int c = 0; c < BS; ++c) {
+          rp[(bj * BS + c) * 2] = ar[pr][c];
+          rp[(bj * BS + c) * 2 + 1] = ai[pr][c];
         }
-        A[e * 2] = xr;
-        A[e * 2 + 1] = xi;
       }
-    }
-    __syncthreads();
+      if (owner && bj == pb) {
+#pragma unroll
+        for (int r = 0; r < BS; ++r) {
+          cp[(bi * BS + r) * 2] = ar[r][pr];
+          cp[(bi * BS + r) * 2 + 1] = ai[r][pr];
+        }
+      }
+      __syncthreads();
+      const double piv = rp[p * 2];
+      if (!(piv > 0.0) || !isfinite(piv)) {  // the same value in every thread
+        ok = false;
+        return;
+      }
+      const double ip = 1.0 / piv;
+      if (tid == 0) logdet += log(piv);
+#pragma unroll
+      for (int r = 0; r < BS; ++r) {
+        const int i = bi * BS + r;
+        const double cr = cp[i * 2], ci = cp[i * 2 + 1];
+#pragma unroll
+        for (int c = 0; c < BS; ++c) {
+          const int j = bj * BS + c;
+          const double rr = rp[j * 2] * ip, ri = rp[j * 2 + 1] * ip;
+          double xr, xi;
+          if (i == p) {
+            xr = (j == p) ? ip : rr;
+            xi = (j == p) ? 0.0 : ri;
+          } else if (j == p) {
+            xr = -cr * ip;
+            xi = -ci * ip;
+          } else {
+            xr = ar[r][c] - (cr * rr - ci * ri);
+            xi = ai[r][c] - (cr * ri + ci * rr);
+          }
+          if (i < D && j < D) {
+            ar[r][c] = xr;
+            ai[r][c] = xi;
+          }
+        }
+      }
+    });
   }
   double fro2 = 0.0;
-  if (ok) {
-    for (int e = tid; e < DP * DP; e += kGenThreads) {
-      const int i = e / DP, j = e - i * DP;
-      if (i < D && j < D) fro2 += A[e * 2] * A[e * 2] + A[e * 2 + 1] * A[e * 2 + 1];
-    }
+  if (ok && owner) {
+#pragma unroll
+    for (int r = 0; r < BS; ++r)
+#pragma unroll
+      for (int c = 0; c < BS; ++c) fro2 += ar[r][c] * ar[r][c] + ai[r][c] * ai[r][c];
   }
-  fro2 = block_sum(fro2, red, tid);
+  if (owner) {
+#pragma unroll
+    for (int r = 0; r < BS; ++r)
+#pragma unroll
+      for (int c = 0; c < BS; ++c) {
+        const int e = (bi * BS + r) * DP + bj * BS + c;
+        A[e * 2] = ar[r][c];
+        A[e * 2 + 1] = ai[r][c];
+      }
+  }
+  fro2 = block_sum(fro2, red, tid);  // barrier: A complete
   // lambda_min >= 1 / ||C^-1||_F and lambda_max <= tr C (cacgmm_em.hpp uses the same test)
   const double bound = tr * sqrt(fro2);
   ok = ok && isfinite(bound) && (bound * g.eig_floor < 1e-2) && (bound < 1e13);
@@ -728,21 +985,22 @@ int launch_gen_estep(const void* y, int y_is_c128, int layout, int64_t B, int T,
                      const double* eigvec, const double* eigval, const double* weight, int64_t wb,
                      int64_t wk, int64_t wt, const uint8_t* activity, double eps, double* out_aff,
                      double* out_q, double* out_logpdf, hipStream_t s,
-                     const GenInverseState& state) {
+                     const GenInverseState& state, const double* saliency, double* out_mweight,
+                     int32_t* out_zero) {
   if (!gen_supported(D, K)) return PBBSS_ERR_UNSUPPORTED;
   if (!state.inv || !state.logdet) return PBBSS_ERR_INVALID_ARG;
   const int DP = gen_state_ld(D);
   GenEigToInv c{eigvec, eigval, D, DP, state.ok, state.inv, state.logdet};
   hipLaunchKernelGGL(gen_eig_to_inv_kernel, dim3((unsigned)(B * K)), dim3(kGenThreads), 0, s, c);
   GenEstep a{y, layout, B, T, D, K, state.inv, state.logdet, weight, wb, wk, wt, activity, eps,
-             out_aff, out_q, out_logpdf};
+             out_aff, out_q, out_logpdf, saliency, out_mweight, out_zero};
   const dim3 grid((unsigned)B, (unsigned)((T + kGenThreads - 1) / kGenThreads));
   if (grid.y > 65535u) return PBBSS_ERR_UNSUPPORTED;
-  const size_t lds = (size_t)2 * K * kGenThreads * sizeof(double);
+  const size_t lds = (size_t)2 * K * kGenThreads * sizeof(double);  // softmax slots [2][K][thread]
 #define PBBSS_GEN_E(DPV, YST)                                                              \
   {                                                                                        \
     auto kfn = gen_estep_kernel<DPV, YST>;                                                 \
-    if (lds > 32768 && set_lds(kfn, lds, 65536) != PBBSS_OK) return PBBSS_ERR_HIP;         \
+    if (lds > 32768 && set_lds(kfn, lds, 131072) != PBBSS_OK) return PBBSS_ERR_HIP;        \
     hipLaunchKernelGGL(kfn, grid, dim3(kGenThreads), lds, s, a);                           \
   }
 #define PBBSS_GEN_ED(DPV) \
@@ -793,23 +1051,68 @@ int launch_gen_cov(const void* y, int y_is_c128, int layout, int64_t B, int T, i
   return ok_or_hip();
 }
 
+int launch_gen_init_weights(const void* y, int y_is_c128, int64_t B, int T, int D, int K,
+                            const double* gamma0, const double* saliency, double* out_mweight,
+                            int32_t* out_zero, hipStream_t s) {
+  if (!gen_supported(D, K)) return PBBSS_ERR_UNSUPPORTED;
+  const dim3 grid((unsigned)B, (unsigned)((T + kGenThreads - 1) / kGenThreads));
+  if (grid.y > 65535u) return PBBSS_ERR_UNSUPPORTED;
+  if (y_is_c128)
+    hipLaunchKernelGGL(gen_init_weight_kernel<double>, grid, dim3(kGenThreads), 0, s, y, T, D, K,
+                       gamma0, saliency, out_mweight, out_zero);
+  else
+    hipLaunchKernelGGL(gen_init_weight_kernel<float>, grid, dim3(kGenThreads), 0, s, y, T, D, K,
+                       gamma0, saliency, out_mweight, out_zero);
+  return ok_or_hip();
+}
+
+int launch_gen_mstep_cov(const void* y, int y_is_c128, int64_t B, int T, int D, int K,
+                         const double* mweight, const double* gamma, const double* saliency,
+                         int weight_mode, double* csum, double* out_cov, double* out_weight,
+                         hipStream_t s) {
+  if (!gen_supported(D, K)) return PBBSS_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(gen_csum_kernel, dim3((unsigned)B), dim3(kGenThreads), 0, s, gamma, saliency,
+                     K, T, weight_mode, csum, out_weight);
+  const int NI = (D + 7) / 8, NJ = (D + 15) / 16;
+  int units = 0;
+  for (int J = 0; J < NJ; ++J) units += (2 * J + 2 < NI) ? 2 * J + 2 : NI;
+  const dim3 grid((unsigned)B, (unsigned)units);
+  // balanced chunks of at most kCovMaxK classes, like launch_gen_cov
+  const int nchunk = (K + kCovMaxK - 1) / kCovMaxK;
+  for (int c = 0, k0 = 0; c < nchunk; ++c) {
+    const int kc = (K - k0 + (nchunk - c) - 1) / (nchunk - c);
+    GenCov2 a{y, B, T, D, K, mweight, csum, out_cov, k0, kc, NI};
+    if (kc <= 3) {
+      if (y_is_c128) hipLaunchKernelGGL((gen_cov2_kernel<3, double>), grid, dim3(kGenThreads), 0, s, a);
+      else hipLaunchKernelGGL((gen_cov2_kernel<3, float>), grid, dim3(kGenThreads), 0, s, a);
+    } else {
+      if (y_is_c128) hipLaunchKernelGGL((gen_cov2_kernel<kCovMaxK, double>), grid, dim3(kGenThreads), 0, s, a);
+      else hipLaunchKernelGGL((gen_cov2_kernel<kCovMaxK, float>), grid, dim3(kGenThreads), 0, s, a);
+    }
+    k0 += kc;
+  }
+  return ok_or_hip();
+}
+
 int launch_gen_heev(const double* a, int64_t N, int D, int covariance_norm, double eig_floor,
                     double* out_val, double* out_vec, int32_t* out_status, size_t lds_limit,
                     hipStream_t s, const int32_t* skip) {
   if (D < 2 || D > kGenMaxD) return PBBSS_ERR_UNSUPPORTED;
   GenHeev g{a, N, D, covariance_norm, eig_floor, out_val, out_vec, out_status, skip};
-  const int DP = D <= 16 ? 16 : 32;
-  const size_t lds = ((size_t)4 * DP * DP * 2 + DP * 3 + kGenWaves) * sizeof(double) + DP * sizeof(int);
+  const int DP = D <= 16 ? 16 : (D <= 24 ? 24 : 32);
   int rc;
-  if (DP == 16) {
-    auto kfn = gen_heev_kernel<16>;
-    if ((rc = set_lds(kfn, lds, lds_limit)) != PBBSS_OK) return rc;
-    hipLaunchKernelGGL(kfn, dim3((unsigned)N), dim3(kGenThreads), lds, s, g);
-  } else {
-    auto kfn = gen_heev_kernel<32>;
-    if ((rc = set_lds(kfn, lds, lds_limit)) != PBBSS_OK) return rc;
-    hipLaunchKernelGGL(kfn, dim3((unsigned)N), dim3(kGenThreads), lds, s, g);
+#define PBBSS_GEN_H(DPV, NTV)                                                                  \
+  {                                                                                            \
+    const size_t lds = ((size_t)4 * DPV * DPV * 2 + DPV * 3 + NTV / 64) * sizeof(double) +    \
+                       DPV * sizeof(int);                                                      \
+    auto kfn = gen_heev_kernel<DPV, NTV>;                                                      \
+    if ((rc = set_lds(kfn, lds, lds_limit)) != PBBSS_OK) return rc;                            \
+    hipLaunchKernelGGL(kfn, dim3((unsigned)N), dim3(NTV), lds, s, g);                          \
   }
+  if (DP == 16) PBBSS_GEN_H(16, 256)
+  else if (DP == 24) PBBSS_GEN_H(24, 576)
+  else PBBSS_GEN_H(32, 1024)
+#undef PBBSS_GEN_H
   return ok_or_hip();
 }
 
@@ -820,6 +1123,8 @@ int launch_gen_inverse(const double* a, int64_t N, int D, double eig_floor, doub
   GenInv g{a, N, D, eig_floor, out_inv, out_logdet, out_ok, veto, K, gen_state_ld(D)};
   if (D <= 16) {
     hipLaunchKernelGGL(gen_inv_kernel<16>, dim3((unsigned)N), dim3(kGenThreads), 0, s, g);
+  } else if (D <= 24) {
+    hipLaunchKernelGGL(gen_inv_kernel<24>, dim3((unsigned)N), dim3(kGenThreads), 0, s, g);
   } else {
     hipLaunchKernelGGL(gen_inv_kernel<32>, dim3((unsigned)N), dim3(kGenThreads), 0, s, g);
   }

@@ -29,7 +29,22 @@ int launch_gen_estep(const void* y, int y_is_c128, int layout, int64_t B, int T,
                      const double* eigvec, const double* eigval, const double* weight, int64_t wb,
                      int64_t wk, int64_t wt, const uint8_t* activity, double eps, double* out_aff,
                      double* out_q, double* out_logpdf, hipStream_t s,
-                     const GenInverseState& state);
+                     const GenInverseState& state, const double* saliency = nullptr,
+                     double* out_mweight = nullptr, int32_t* out_zero = nullptr);
+
+// EM loop, (B, T, D) observations: the M-step as three small steps around the E-step.
+//   launch_gen_estep(..., saliency, out_mweight, out_zero) leaves the per-frame M-step weights
+//   gamma sal / max(q, 10 tiny) / |y|^2 (cacg.py:310, :322) and flags bins with all-zero frames;
+//   launch_gen_init_weights does the same for an affiliation initialisation (q = 1);
+//   launch_gen_mstep_cov: class sums + mixture weights (a5), then C_k = D sum_t w y y^H / sum
+//   (a6) on the DPP-operand kernel gen_cov2 (csum: (B,K) workspace).
+int launch_gen_init_weights(const void* y, int y_is_c128, int64_t B, int T, int D, int K,
+                            const double* gamma0, const double* saliency, double* out_mweight,
+                            int32_t* out_zero, hipStream_t s);
+int launch_gen_mstep_cov(const void* y, int y_is_c128, int64_t B, int T, int D, int K,
+                         const double* mweight, const double* gamma, const double* saliency,
+                         int weight_mode, double* csum, double* out_cov, double* out_weight,
+                         hipStream_t s);
 
 // a6 / a10: weighted covariances.  mode 0: M-step (D * sum_t gamma sal / q y y^H / sum gamma sal,
 // observation unit-normalised when layout is TD); mode 1: PSD with the mask normalised by

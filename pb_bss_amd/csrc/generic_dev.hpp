@@ -14,6 +14,9 @@ constexpr int kGenMaxSweeps = 30;
 constexpr double kGenJacobiTol = 1e-29;       // off-diagonal Frobenius^2 / total Frobenius^2
 constexpr double kGenJacobiTolLoose = 1e-24;  // accepted if the sweep budget runs out
 
+// NT: threads of the workgroup (kGenThreads everywhere except the eigensolver kernel, which
+// runs up to 1024 threads per matrix); red holds NT / 64 doubles
+template <int NT = kGenThreads>
 __device__ __forceinline__ double gen_block_sum(double v, double* red, int tid) {
   v = wave_sum(v);
   __syncthreads();
@@ -21,11 +24,11 @@ __device__ __forceinline__ double gen_block_sum(double v, double* red, int tid) 
   __syncthreads();
   double s = 0.0;
 #pragma unroll
-  for (int w = 0; w < kGenWaves; ++w) s += red[w];
+  for (int w = 0; w < NT / kWave; ++w) s += red[w];
   return s;
 }
 
-// Scratch of the Jacobi solver: A2, V2 (LD*LD*2 doubles each), rot (3 LD), red (kGenWaves),
+// Scratch of the Jacobi solver: A2, V2 (LD*LD*2 doubles each), rot (3 LD), red (threads / 64),
 // part (LD ints)
 struct GenJacobiScratch {
   double* A2;
@@ -38,10 +41,11 @@ struct GenJacobiScratch {
 // Hermitian A (D x D) -> diagonal (eigenvalues on the diagonal of A, unsorted), V = eigenvectors
 // in columns.  Parallel cyclic Jacobi, circle-method pairing, ping-pong buffers.
 // Returns the number of sweeps, or -1 if not converged (even to the loose tolerance).
+template <int NT = kGenThreads>
 __device__ inline int lds_jacobi_heev(double* A, double* V, const GenJacobiScratch& S, int D,
                                       int LD, int tid) {
   const int N = D + (D & 1);
-  for (int e = tid; e < LD * LD; e += kGenThreads) {
+  for (int e = tid; e < LD * LD; e += NT) {
     const int i = e / LD, j = e - i * LD;
     V[e * 2] = (i == j) ? 1.0 : 0.0;
     V[e * 2 + 1] = 0.0;
@@ -54,21 +58,32 @@ __device__ inline int lds_jacobi_heev(double* A, double* V, const GenJacobiScrat
   }
   __syncthreads();
   double fro2 = 0.0;
-  for (int e = tid; e < LD * LD; e += kGenThreads) fro2 += A[e * 2] * A[e * 2] + A[e * 2 + 1] * A[e * 2 + 1];
-  fro2 = gen_block_sum(fro2, S.red, tid);
+  for (int e = tid; e < LD * LD; e += NT) fro2 += A[e * 2] * A[e * 2] + A[e * 2 + 1] * A[e * 2 + 1];
+  fro2 = gen_block_sum<NT>(fro2, S.red, tid);
   if (!(fro2 > 0.0) || !isfinite(fro2)) return 0;
   int sweeps = -1;
   double* Vc = V;      // current eigenvector estimate
   double* Vn = S.V2;   // next
-  for (int e = tid; e < LD * LD * 2; e += kGenThreads) S.V2[e] = V[e];  // identity padding in both
+  for (int e = tid; e < LD * LD * 2; e += NT) S.V2[e] = V[e];  // identity padding in both
   __syncthreads();
+  // the entries of this thread in the two update passes (fixed for the whole solve: the
+  // index arithmetic -- two integer divisions per entry and pass -- is hoisted out of the
+  // ~200 rounds)
+  constexpr int kOwn = (32 * 32 + NT - 1) / NT;  // D <= 32 (generic.hpp: kGenMaxD)
+  int own_i[kOwn], own_j[kOwn];
+#pragma unroll
+  for (int m = 0; m < kOwn; ++m) {
+    const int e0 = tid + m * NT;
+    own_i[m] = (e0 < D * D) ? e0 / D : -1;
+    own_j[m] = (e0 < D * D) ? e0 - own_i[m] * D : 0;
+  }
   for (int sweep = 0; sweep < kGenMaxSweeps; ++sweep) {
     double off2 = 0.0;
-    for (int e = tid; e < LD * LD; e += kGenThreads) {
+    for (int e = tid; e < LD * LD; e += NT) {
       const int i = e / LD, j = e - i * LD;
       if (i != j) off2 += A[e * 2] * A[e * 2] + A[e * 2 + 1] * A[e * 2 + 1];
     }
-    off2 = gen_block_sum(off2, S.red, tid);
+    off2 = gen_block_sum<NT>(off2, S.red, tid);
     if (off2 <= kGenJacobiTol * fro2) {
       sweeps = sweep;
       break;
@@ -116,8 +131,10 @@ __device__ inline int lds_jacobi_heev(double* A, double* V, const GenJacobiScrat
       }
       __syncthreads();
       // rows: B = J^H A   (only the D x D block is live; the padding stays zero)
-      for (int e0 = tid; e0 < D * D; e0 += kGenThreads) {
-        const int i = e0 / D, j = e0 - i * D;
+#pragma unroll
+      for (int m = 0; m < kOwn; ++m) {
+        const int i = own_i[m], j = own_j[m];
+        if (i < 0) continue;
         const int e = i * LD + j;
         const int pi = S.part[i];
         const double c = S.rot[i * 3], sr = S.rot[i * 3 + 1], si = S.rot[i * 3 + 2];
@@ -138,8 +155,10 @@ __device__ inline int lds_jacobi_heev(double* A, double* V, const GenJacobiScrat
       }
       __syncthreads();
       // columns: A' = B J, V' = V J   (V ping-pongs between the two buffers)
-      for (int e0 = tid; e0 < D * D; e0 += kGenThreads) {
-        const int i = e0 / D, j = e0 - i * D;
+#pragma unroll
+      for (int m = 0; m < kOwn; ++m) {
+        const int i = own_i[m], j = own_j[m];
+        if (i < 0) continue;
         const int e = i * LD + j;
         const int pj = S.part[j];
         const double c = S.rot[j * 3], sr = S.rot[j * 3 + 1], si = S.rot[j * 3 + 2];
@@ -175,15 +194,15 @@ __device__ inline int lds_jacobi_heev(double* A, double* V, const GenJacobiScrat
   }
   if (sweeps < 0) {
     double off2 = 0.0;
-    for (int e = tid; e < LD * LD; e += kGenThreads) {
+    for (int e = tid; e < LD * LD; e += NT) {
       const int i = e / LD, j = e - i * LD;
       if (i != j) off2 += A[e * 2] * A[e * 2] + A[e * 2 + 1] * A[e * 2 + 1];
     }
-    off2 = gen_block_sum(off2, S.red, tid);
+    off2 = gen_block_sum<NT>(off2, S.red, tid);
     if (off2 <= kGenJacobiTolLoose * fro2) sweeps = kGenMaxSweeps;
   }
   if (Vc != V) {  // an odd number of rounds left the result in the scratch buffer
-    for (int e = tid; e < LD * LD * 2; e += kGenThreads) V[e] = Vc[e];
+    for (int e = tid; e < LD * LD * 2; e += NT) V[e] = Vc[e];
   }
   __syncthreads();
   return sweeps;
