@@ -565,10 +565,7 @@ __global__ void __launch_bounds__(kGenThreads) gen_cov2_kernel(GenCov2 a) {
   for (int m = 0; m < 8; ++m)
 #pragma unroll
     for (int k = 0; k < KM; ++k) accr[m][k] = acci[m][k] = 0.0;
-  In cur = load(q0);
-  for (int q = q0; q < q1; ++q) {
-    const In nxt = load(q + 1);
-    __builtin_amdgcn_sched_barrier(0);
+  auto accumulate = [&](const In& cur) {
     const double zr = jv ? (double)cur.own.x : 0.0, zi = jv ? (double)cur.own.y : 0.0;
     double breg = sv ? (double)cur.bc : 0.0;
     double u[KM], v[KM], nv[KM];
@@ -592,7 +589,17 @@ __global__ void __launch_bounds__(kGenThreads) gen_cov2_kernel(GenCov2 a) {
         fmac_row_bcast<2 * m>(acci[m][k], breg, nv[k]);
       }
     });
-    cur = nxt;
+  };
+  // two quads per trip with ping-pong operand sets: a rolled `cur = nxt` makes the compiler
+  // wait for the loads it has just issued before it can copy the registers
+  In qa = load(q0), qb;
+  for (int q = q0; q < q1; q += 2) {
+    qb = load(q + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    accumulate(qa);
+    qa = load(q + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    if (q + 1 < q1) accumulate(qb);  // uniform over the wave
   }
   // four frame rows of the wave, then the four waves
 #pragma unroll
