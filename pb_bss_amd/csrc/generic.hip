@@ -22,6 +22,7 @@
 #include "generic.hpp"
 #include <cmath>
 #include "generic_dev.hpp"
+#include <cstdlib>
 #include <type_traits>
 
 namespace pbbss {
@@ -815,6 +816,312 @@ __global__ void __launch_bounds__(NT) gen_heev_kernel(GenHeev g) {
   }
 }
 
+// ------------------------------------------------------------------ Hermitian eigensolver, QL
+// One WAVEFRONT per matrix: Householder reduction to a real symmetric tridiagonal matrix
+// (LAPACK zhetd2's recurrences, reflectors H_k = I - tau_k v_k v_k^H kept below the
+// subdiagonal), implicit-shift QL on (d, e) with the rotations accumulated in a REAL matrix Z
+// (EISPACK tql2 / Numerical Recipes tqli), back-transformation V = H_0 ... H_{n-3} Z with one
+// eigenvector per lane in registers, then the ordering / normalisation / floor of
+// from_covariance (cacg.py:82-132).  ~5x fewer flops than the cyclic Jacobi of gen_heev_kernel
+// and no workgroup barrier (a 64-thread workgroup's barrier is a wait, not a rendezvous); LDS
+// per matrix: A n (n + 1) complex + Z n (n + 1) real + vectors = 21 KB at n = 29, seven
+// matrices per CU.  Lane = column / row index; n <= DP <= 32 (DP sizes the register arrays).
+template <int DP>
+__global__ void __launch_bounds__(kWave) gen_heev_ql_kernel(GenHeev g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x;
+  const int64_t nm = blockIdx.x;
+  if (g.skip && g.skip[nm]) return;  // uniform over the workgroup
+  const int n = g.D, LD = n + 1;
+  double* A = reinterpret_cast<double*>(smem);  // [n][LD][2]
+  double* Zt = A + (size_t)n * LD * 2;          // [n][LD]   Zt[col][row]
+  double* dv = Zt + (size_t)n * LD;             // [DP + 1] diagonal
+  double* ev = dv + DP + 1;                     // [DP + 1] subdiagonal, e[k] couples k and k + 1
+  double* tauv = ev + DP + 1;                   // [DP][2]
+  double* vbuf = tauv + 2 * DP;                 // [DP][2] reflector of the current step
+  double* wbuf = vbuf + 2 * DP;                 // [DP][2]
+  int st = 0;
+  // ---- load (lower triangle, like gen_heev_kernel), optional trace normalisation
+  double tr = 0.0;
+  for (int e = lane; e < n * n; e += kWave) {
+    const int i = e / n, j = e - i * n;
+    const int lo = i < j ? j : i, hi = i < j ? i : j;
+    const double* p = g.a + (((size_t)nm * n + lo) * n + hi) * 2;
+    const double re = p[0];
+    const double im = (i == j) ? 0.0 : ((i > j) ? p[1] : -p[1]);
+    if (i == j) tr += re;
+    A[(i * LD + j) * 2] = re;
+    A[(i * LD + j) * 2 + 1] = im;
+    Zt[i * LD + j] = (i == j) ? 1.0 : 0.0;
+  }
+  tr = wave_sum(tr);
+  __syncthreads();
+  double fro2 = 0.0;
+  {
+    const double it = (g.covariance_norm == PBBSS_COVNORM_TRACE) ? 1.0 / fmax(tr, kTiny) : 1.0;  // cacg.py:88-90
+    for (int e = lane; e < n * n; e += kWave) {
+      const int i = e / n, j = e - i * n;
+      const double re = A[(i * LD + j) * 2] * it, im = A[(i * LD + j) * 2 + 1] * it;
+      A[(i * LD + j) * 2] = re;
+      A[(i * LD + j) * 2 + 1] = im;
+      fro2 += re * re + im * im;
+    }
+  }
+  fro2 = wave_sum(fro2);
+  if (!isfinite(fro2)) st |= PBBSS_ST_NONFINITE;
+  __syncthreads();
+  const bool solve = (fro2 > 0.0) && isfinite(fro2);
+  if (lane < n) {  // a zero / non-finite matrix is returned as its diagonal with V = I
+    dv[lane] = A[(lane * LD + lane) * 2];
+    ev[lane] = 0.0;
+  }
+  __syncthreads();
+  // ---- Householder tridiagonalisation: T = Q^H A Q, Q = H_0 H_1 ... H_{n-2}
+  for (int k = 0; solve && k + 1 < n; ++k) {
+    const bool below = lane > k && lane < n;        // rows k+1 .. n-1
+    const bool tail = lane > k + 1 && lane < n;     // rows k+2 .. n-1
+    const double xr = below ? A[(lane * LD + k) * 2] : 0.0;
+    const double xi = below ? A[(lane * LD + k) * 2 + 1] : 0.0;
+    const double ar = A[((k + 1) * LD + k) * 2], ai = A[((k + 1) * LD + k) * 2 + 1];
+    const double xn2 = wave_sum(tail ? xr * xr + xi * xi : 0.0);
+    double tr_ = 0.0, ti_ = 0.0, beta = ar, vr = 0.0, vi = 0.0;
+    if (!(xn2 == 0.0 && ai == 0.0)) {  // zlarfg
+      beta = -copysign(sqrt(ar * ar + ai * ai + xn2), ar);
+      tr_ = (beta - ar) / beta;
+      ti_ = -ai / beta;
+      const double dr = ar - beta, di = ai, den = dr * dr + di * di;
+      const double sr = dr / den, si = -di / den;  // 1 / (alpha - beta)
+      vr = tail ? xr * sr - xi * si : 0.0;
+      vi = tail ? xr * si + xi * sr : 0.0;
+    }
+    if (lane == k + 1) {
+      vr = 1.0;
+      vi = 0.0;
+    }
+    if (lane < DP) {
+      vbuf[lane * 2] = vr;
+      vbuf[lane * 2 + 1] = vi;
+    }
+    if (tail) {  // keep the reflector for the back-transformation
+      A[(lane * LD + k) * 2] = vr;
+      A[(lane * LD + k) * 2 + 1] = vi;
+    }
+    if (lane == 0) {
+      ev[k] = beta;
+      dv[k] = A[(k * LD + k) * 2];
+      tauv[k * 2] = tr_;
+      tauv[k * 2 + 1] = ti_;
+    }
+    __syncthreads();
+    if (tr_ != 0.0 || ti_ != 0.0) {  // uniform
+      // p = tau A22 v, row `lane` through the Hermitian mirror A[lane][j] = conj(A[j][lane])
+      double pr = 0.0, pi = 0.0;
+      for (int j = k + 1; j < n; ++j) {
+        const double ajr = below ? A[(j * LD + lane) * 2] : 0.0;
+        const double aji = below ? A[(j * LD + lane) * 2 + 1] : 0.0;
+        const double ur = vbuf[j * 2], ui = vbuf[j * 2 + 1];
+        pr += ajr * ur + aji * ui;   // conj(a) * u
+        pi += ajr * ui - aji * ur;
+      }
+      {
+        const double qr = tr_ * pr - ti_ * pi, qi = tr_ * pi + ti_ * pr;
+        pr = qr;
+        pi = qi;
+      }
+      // w = p - 1/2 tau (p^H v) v
+      double dr = below ? pr * vr + pi * vi : 0.0;  // conj(p) v
+      double di = below ? pr * vi - pi * vr : 0.0;
+      dr = wave_sum(dr);
+      di = wave_sum(di);
+      const double hr = -0.5 * (tr_ * dr - ti_ * di), hi = -0.5 * (tr_ * di + ti_ * dr);
+      const double wr = pr + hr * vr - hi * vi, wi = pi + hr * vi + hi * vr;
+      if (lane < DP) {
+        wbuf[lane * 2] = below ? wr : 0.0;
+        wbuf[lane * 2 + 1] = below ? wi : 0.0;
+      }
+      __syncthreads();
+      // A22 -= v w^H + w v^H, lane = column
+      if (below) {
+        for (int r = k + 1; r < n; ++r) {
+          const double ur = vbuf[r * 2], ui = vbuf[r * 2 + 1];
+          const double sr = wbuf[r * 2], si = wbuf[r * 2 + 1];
+          double* a = A + (r * LD + lane) * 2;
+          // v_r conj(w_c) + w_r conj(v_c)
+          a[0] -= ur * wr + ui * wi + sr * vr + si * vi;
+          a[1] -= ui * wr - ur * wi + si * vr - sr * vi;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (lane == 0) {
+    dv[n - 1] = A[((n - 1) * LD + n - 1) * 2];
+    ev[n - 1] = 0.0;
+  }
+  __syncthreads();
+  // ---- implicit-shift QL on (d, e).  d and e live in REGISTERS (lane i holds d[i], e[i]); the
+  // scalar recurrences run redundantly in all lanes on values fetched with v_readlane (the
+  // index is wave-uniform), so the serial chain never waits for LDS; lane = row of Z applies
+  // the rotations (one LDS read and one write per rotation: the column shared by two
+  // consecutive rotations stays in a register).
+  double dreg = (lane < n) ? dv[lane] : 0.0, ereg = (lane < n) ? ev[lane] : 0.0;
+  bool failed = false;
+  for (int l = 0; solve && l < n; ++l) {
+    int iter = 0;
+    for (;;) {
+      // first negligible subdiagonal at or after l: lane m tests e[m], one ballot
+      int m;
+      {
+        const double dnext = __shfl_down(dreg, 1);
+        bool neg = false;
+        if (lane >= l && lane + 1 < n) {
+          const double dd = fabs(dreg) + fabs(dnext);
+          neg = (fabs(ereg) + dd == dd);
+        }
+        const unsigned long long mask = __ballot(neg);
+        m = __builtin_amdgcn_readfirstlane(mask ? (int)__builtin_ctzll(mask) : n - 1);
+      }
+      if (m == l) break;
+      if (++iter > 60) {
+        failed = true;
+        break;
+      }
+      const double dl = lane_bcast_const(dreg, l), el = lane_bcast_const(ereg, l);
+      double gg = (lane_bcast_const(dreg, l + 1) - dl) / (2.0 * el);
+      double r = sqrt(gg * gg + 1.0);
+      gg = lane_bcast_const(dreg, m) - dl + el / (gg + copysign(r, gg));
+      double s = 1.0, c = 1.0, p = 0.0;
+      const int zl = (lane < n) ? lane : 0;
+      double zc = Zt[m * LD + zl];        // column i + 1 of Z, carried
+      double zi = Zt[(m - 1) * LD + zl];  // column i, fetched one rotation ahead of its use
+      int i = m - 1;
+      bool under = false;
+      double ei = lane_bcast_const(ereg, i), di = lane_bcast_const(dreg, i);
+      double di1 = lane_bcast_const(dreg, m);
+      for (; i >= l; --i) {
+        // operands of the NEXT rotation first: they do not depend on the chain below (entries
+        // below i + 1 are not written during this sweep)
+        const int inx = (i > 0) ? i - 1 : 0;
+        const double ei_n = lane_bcast_const(ereg, inx), di_n = lane_bcast_const(dreg, inx);
+        const double znext = Zt[inx * LD + zl];
+        const double f = s * ei, b = c * ei;
+        // r = hypot(f, g), s = f / r, c = g / r through ONE Newton-refined reciprocal square
+        // root, branch-free: this scalar recurrence is the serial chain of the whole solver
+        const double h2 = fma(f, f, gg * gg);
+        const double rinv = fast_rsqrt(fmax(h2, 1e-300));
+        r = h2 * rinv;
+        if (lane == i + 1) ereg = r;
+        if (r == 0.0) {  // recover from underflow (f = g = 0): restart this eigenvalue
+          if (lane == i + 1) dreg = di1 - p;
+          if (lane == m) ereg = 0.0;
+          under = true;
+          break;
+        }
+        s = f * rinv;
+        c = gg * rinv;
+        gg = di1 - p;
+        r = fma(di - gg, s, 2.0 * c * b);
+        p = s * r;
+        if (lane == i + 1) dreg = gg + p;
+        gg = fma(c, r, -b);
+        if (lane < n) Zt[(i + 1) * LD + lane] = fma(s, zi, c * zc);
+        zc = fma(c, zi, -s * zc);
+        zi = znext;
+        di1 = di;
+        di = di_n;
+        ei = ei_n;
+      }
+      if (lane < n) Zt[(under ? i + 1 : l) * LD + lane] = zc;  // the carried column goes home
+      if (under) continue;
+      if (lane == l) {
+        dreg -= p;
+        ereg = gg;
+      }
+      if (lane == m) ereg = 0.0;
+    }
+    if (failed) break;
+  }
+  if (failed) st |= PBBSS_ST_EIG_NOCONV;
+  __syncthreads();
+  // ---- eigenvector `lane`: x = H_0 ... H_{n-3} Z[:, lane] (H_{n-2} has v = e_{n-1}: a phase)
+  double xre[DP], xim[DP];
+#pragma unroll
+  for (int r = 0; r < DP; ++r) {
+    xre[r] = (r < n && lane < n) ? Zt[lane * LD + r] : 0.0;
+    xim[r] = 0.0;
+  }
+  for (int k = n - 2; solve && k >= 0; --k) {
+    const double tr_ = tauv[k * 2], ti_ = tauv[k * 2 + 1];
+    if (tr_ == 0.0 && ti_ == 0.0) continue;  // uniform
+    // v_k: 1 at k + 1, A[r][k] below, 0 above; s = v^H x
+    // the reflector is fetched ONCE, lane r taking v_k[r] (1 at k + 1, A[r][k] below, 0
+    // above), and handed to the FMAs through v_readlane (r is a compile-time constant of the
+    // unrolled loops, the value arrives as an SGPR operand): no LDS round trip per row, no
+    // operand arrays next to the 2 DP registers of the eigenvector
+    const bool on = lane > k + 1 && lane < n;
+    const double are = A[((on ? lane : n - 1) * LD + k) * 2];
+    const double aim = A[((on ? lane : n - 1) * LD + k) * 2 + 1];
+    const double vre = (lane == k + 1) ? 1.0 : (on ? are : 0.0);
+    const double vim = on ? aim : 0.0;
+    double sr = 0.0, si = 0.0;
+#pragma unroll
+    for (int r = 1; r < DP; ++r) {
+      const double ur = lane_bcast_const(vre, r), ui = lane_bcast_const(vim, r);
+      sr += ur * xre[r] + ui * xim[r];
+      si += ur * xim[r] - ui * xre[r];
+    }
+    const double qr = tr_ * sr - ti_ * si, qi = tr_ * si + ti_ * sr;  // tau (v^H x)
+#pragma unroll
+    for (int r = 1; r < DP; ++r) {
+      const double ur = lane_bcast_const(vre, r), ui = lane_bcast_const(vim, r);
+      xre[r] -= ur * qr - ui * qi;
+      xim[r] -= ur * qi + ui * qr;
+    }
+  }
+  // ---- eigenvalues -> rank (ascending, ties by index), normalisation and floor, outputs
+  int rk = 0;
+  double lmax = -1.79e308;
+  for (int m = 0; m < n; ++m) {  // all lanes: the broadcast needs the whole wave
+    const double lm = lane_bcast_const(dreg, m);
+    rk += (lm < dreg || (lm == dreg && m < lane)) ? 1 : 0;
+    lmax = fmax(lmax, lm);
+  }
+  if (lane < n) {
+    const double l = dreg;
+    double lout = l;
+    if (g.covariance_norm == PBBSS_COVNORM_EIGENVALUE) {  // cacg.py:112-121
+      lout = l / fmax(lmax, kTiny);
+      if (lout < g.eig_floor) {
+        lout = g.eig_floor;
+        st |= PBBSS_ST_FLOORED;
+      }
+    } else if (g.covariance_norm >= 0) {                   // cacg.py:122-126
+      const double fl = lmax * g.eig_floor;
+      if (lout < fl) {
+        lout = fl;
+        st |= PBBSS_ST_FLOORED;
+      }
+    }
+    if (!isfinite(lout)) st |= PBBSS_ST_NONFINITE;
+    g.out_val[(size_t)nm * n + rk] = lout;
+#pragma unroll
+    for (int r = 0; r < DP; ++r) {
+      if (r < n) {
+        double* o = g.out_vec + (((size_t)nm * n + r) * n + rk) * 2;
+        o[0] = xre[r];
+        o[1] = xim[r];
+      }
+    }
+  }
+  if (g.out_status) {
+    // OR over the wave
+    int acc = st;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc |= __shfl_xor(acc, off);
+    if (lane == 0) g.out_status[nm] = acc;
+  }
+}
+
 // ------------------------------------------------------------------ inverse (EM fast path)
 struct GenInv {
   const double* a;     // c128 (N,D,D)
@@ -1084,19 +1391,14 @@ int launch_gen_mstep_cov(const void* y, int y_is_c128, int64_t B, int T, int D, 
   int units = 0;
   for (int J = 0; J < NJ; ++J) units += (2 * J + 2 < NI) ? 2 * J + 2 : NI;
   const dim3 grid((unsigned)B, (unsigned)units);
-  // balanced chunks of at most kCovMaxK classes, like launch_gen_cov
-  const int nchunk = (K + kCovMaxK - 1) / kCovMaxK;
-  for (int c = 0, k0 = 0; c < nchunk; ++c) {
-    const int kc = (K - k0 + (nchunk - c) - 1) / (nchunk - c);
+  // three classes per launch (48 accumulator registers per lane: three waves per SIMD; six
+  // classes at once need 256 VGPRs and leave one wave per SIMD); more classes = more launches
+  constexpr int kChunk = 3;
+  for (int k0 = 0; k0 < K; k0 += kChunk) {
+    const int kc = (K - k0 < kChunk) ? K - k0 : kChunk;
     GenCov2 a{y, B, T, D, K, mweight, csum, out_cov, k0, kc, NI};
-    if (kc <= 3) {
-      if (y_is_c128) hipLaunchKernelGGL((gen_cov2_kernel<3, double>), grid, dim3(kGenThreads), 0, s, a);
-      else hipLaunchKernelGGL((gen_cov2_kernel<3, float>), grid, dim3(kGenThreads), 0, s, a);
-    } else {
-      if (y_is_c128) hipLaunchKernelGGL((gen_cov2_kernel<kCovMaxK, double>), grid, dim3(kGenThreads), 0, s, a);
-      else hipLaunchKernelGGL((gen_cov2_kernel<kCovMaxK, float>), grid, dim3(kGenThreads), 0, s, a);
-    }
-    k0 += kc;
+    if (y_is_c128) hipLaunchKernelGGL((gen_cov2_kernel<kChunk, double>), grid, dim3(kGenThreads), 0, s, a);
+    else hipLaunchKernelGGL((gen_cov2_kernel<kChunk, float>), grid, dim3(kGenThreads), 0, s, a);
   }
   return ok_or_hip();
 }
@@ -1108,6 +1410,24 @@ int launch_gen_heev(const double* a, int64_t N, int D, int covariance_norm, doub
   GenHeev g{a, N, D, covariance_norm, eig_floor, out_val, out_vec, out_status, skip};
   const int DP = D <= 16 ? 16 : (D <= 24 ? 24 : 32);
   int rc;
+  static const bool use_jacobi = [] {
+    const char* v = getenv("PBBSS_GEN_HEEV");
+    return v && v[0] == 'j';
+  }();
+  if (!use_jacobi) {  // tridiagonal QL, one wavefront per matrix
+    const size_t lds = ((size_t)D * (D + 1) * 3 + 2 * (DP + 1) + 6 * DP) * sizeof(double);
+#define PBBSS_GEN_Q(DPV)                                                          \
+  {                                                                               \
+    auto kfn = gen_heev_ql_kernel<DPV>;                                           \
+    if ((rc = set_lds(kfn, lds, lds_limit)) != PBBSS_OK) return rc;               \
+    hipLaunchKernelGGL(kfn, dim3((unsigned)N), dim3(kWave), lds, s, g);           \
+  }
+    if (DP == 16) PBBSS_GEN_Q(16)
+    else if (DP == 24) PBBSS_GEN_Q(24)
+    else PBBSS_GEN_Q(32)
+#undef PBBSS_GEN_Q
+    return ok_or_hip();
+  }
 #define PBBSS_GEN_H(DPV, NTV)                                                                  \
   {                                                                                            \
     const size_t lds = ((size_t)4 * DPV * DPV * 2 + DPV * 3 + NTV / 64) * sizeof(double) +    \
