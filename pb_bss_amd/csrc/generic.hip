@@ -871,213 +871,9 @@ __global__ void __launch_bounds__(kWave) gen_heev_ql_kernel(GenHeev g) {
   if (!isfinite(fro2)) st |= PBBSS_ST_NONFINITE;
   __syncthreads();
   const bool solve = (fro2 > 0.0) && isfinite(fro2);
-  if (lane < n) {  // a zero / non-finite matrix is returned as its diagonal with V = I
-    dv[lane] = A[(lane * LD + lane) * 2];
-    ev[lane] = 0.0;
-  }
-  __syncthreads();
-  // ---- Householder tridiagonalisation: T = Q^H A Q, Q = H_0 H_1 ... H_{n-2}
-  for (int k = 0; solve && k + 1 < n; ++k) {
-    const bool below = lane > k && lane < n;        // rows k+1 .. n-1
-    const bool tail = lane > k + 1 && lane < n;     // rows k+2 .. n-1
-    const double xr = below ? A[(lane * LD + k) * 2] : 0.0;
-    const double xi = below ? A[(lane * LD + k) * 2 + 1] : 0.0;
-    const double ar = A[((k + 1) * LD + k) * 2], ai = A[((k + 1) * LD + k) * 2 + 1];
-    const double xn2 = wave_sum(tail ? xr * xr + xi * xi : 0.0);
-    double tr_ = 0.0, ti_ = 0.0, beta = ar, vr = 0.0, vi = 0.0;
-    if (!(xn2 == 0.0 && ai == 0.0)) {  // zlarfg
-      beta = -copysign(sqrt(ar * ar + ai * ai + xn2), ar);
-      tr_ = (beta - ar) / beta;
-      ti_ = -ai / beta;
-      const double dr = ar - beta, di = ai, den = dr * dr + di * di;
-      const double sr = dr / den, si = -di / den;  // 1 / (alpha - beta)
-      vr = tail ? xr * sr - xi * si : 0.0;
-      vi = tail ? xr * si + xi * sr : 0.0;
-    }
-    if (lane == k + 1) {
-      vr = 1.0;
-      vi = 0.0;
-    }
-    if (lane < DP) {
-      vbuf[lane * 2] = vr;
-      vbuf[lane * 2 + 1] = vi;
-    }
-    if (tail) {  // keep the reflector for the back-transformation
-      A[(lane * LD + k) * 2] = vr;
-      A[(lane * LD + k) * 2 + 1] = vi;
-    }
-    if (lane == 0) {
-      ev[k] = beta;
-      dv[k] = A[(k * LD + k) * 2];
-      tauv[k * 2] = tr_;
-      tauv[k * 2 + 1] = ti_;
-    }
-    __syncthreads();
-    if (tr_ != 0.0 || ti_ != 0.0) {  // uniform
-      // p = tau A22 v, row `lane` through the Hermitian mirror A[lane][j] = conj(A[j][lane])
-      double pr = 0.0, pi = 0.0;
-      for (int j = k + 1; j < n; ++j) {
-        const double ajr = below ? A[(j * LD + lane) * 2] : 0.0;
-        const double aji = below ? A[(j * LD + lane) * 2 + 1] : 0.0;
-        const double ur = vbuf[j * 2], ui = vbuf[j * 2 + 1];
-        pr += ajr * ur + aji * ui;   // conj(a) * u
-        pi += ajr * ui - aji * ur;
-      }
-      {
-        const double qr = tr_ * pr - ti_ * pi, qi = tr_ * pi + ti_ * pr;
-        pr = qr;
-        pi = qi;
-      }
-      // w = p - 1/2 tau (p^H v) v
-      double dr = below ? pr * vr + pi * vi : 0.0;  // conj(p) v
-      double di = below ? pr * vi - pi * vr : 0.0;
-      dr = wave_sum(dr);
-      di = wave_sum(di);
-      const double hr = -0.5 * (tr_ * dr - ti_ * di), hi = -0.5 * (tr_ * di + ti_ * dr);
-      const double wr = pr + hr * vr - hi * vi, wi = pi + hr * vi + hi * vr;
-      if (lane < DP) {
-        wbuf[lane * 2] = below ? wr : 0.0;
-        wbuf[lane * 2 + 1] = below ? wi : 0.0;
-      }
-      __syncthreads();
-      // A22 -= v w^H + w v^H, lane = column
-      if (below) {
-        for (int r = k + 1; r < n; ++r) {
-          const double ur = vbuf[r * 2], ui = vbuf[r * 2 + 1];
-          const double sr = wbuf[r * 2], si = wbuf[r * 2 + 1];
-          double* a = A + (r * LD + lane) * 2;
-          // v_r conj(w_c) + w_r conj(v_c)
-          a[0] -= ur * wr + ui * wi + sr * vr + si * vi;
-          a[1] -= ui * wr - ur * wi + si * vr - sr * vi;
-        }
-      }
-      __syncthreads();
-    }
-  }
-  if (lane == 0) {
-    dv[n - 1] = A[((n - 1) * LD + n - 1) * 2];
-    ev[n - 1] = 0.0;
-  }
-  __syncthreads();
-  // ---- implicit-shift QL on (d, e).  d and e live in REGISTERS (lane i holds d[i], e[i]); the
-  // scalar recurrences run redundantly in all lanes on values fetched with v_readlane (the
-  // index is wave-uniform), so the serial chain never waits for LDS; lane = row of Z applies
-  // the rotations (one LDS read and one write per rotation: the column shared by two
-  // consecutive rotations stays in a register).
-  double dreg = (lane < n) ? dv[lane] : 0.0, ereg = (lane < n) ? ev[lane] : 0.0;
-  bool failed = false;
-  for (int l = 0; solve && l < n; ++l) {
-    int iter = 0;
-    for (;;) {
-      // first negligible subdiagonal at or after l: lane m tests e[m], one ballot
-      int m;
-      {
-        const double dnext = __shfl_down(dreg, 1);
-        bool neg = false;
-        if (lane >= l && lane + 1 < n) {
-          const double dd = fabs(dreg) + fabs(dnext);
-          neg = (fabs(ereg) + dd == dd);
-        }
-        const unsigned long long mask = __ballot(neg);
-        m = __builtin_amdgcn_readfirstlane(mask ? (int)__builtin_ctzll(mask) : n - 1);
-      }
-      if (m == l) break;
-      if (++iter > 60) {
-        failed = true;
-        break;
-      }
-      const double dl = lane_bcast_const(dreg, l), el = lane_bcast_const(ereg, l);
-      double gg = (lane_bcast_const(dreg, l + 1) - dl) / (2.0 * el);
-      double r = sqrt(gg * gg + 1.0);
-      gg = lane_bcast_const(dreg, m) - dl + el / (gg + copysign(r, gg));
-      double s = 1.0, c = 1.0, p = 0.0;
-      const int zl = (lane < n) ? lane : 0;
-      double zc = Zt[m * LD + zl];        // column i + 1 of Z, carried
-      double zi = Zt[(m - 1) * LD + zl];  // column i, fetched one rotation ahead of its use
-      int i = m - 1;
-      bool under = false;
-      double ei = lane_bcast_const(ereg, i), di = lane_bcast_const(dreg, i);
-      double di1 = lane_bcast_const(dreg, m);
-      for (; i >= l; --i) {
-        // operands of the NEXT rotation first: they do not depend on the chain below (entries
-        // below i + 1 are not written during this sweep)
-        const int inx = (i > 0) ? i - 1 : 0;
-        const double ei_n = lane_bcast_const(ereg, inx), di_n = lane_bcast_const(dreg, inx);
-        const double znext = Zt[inx * LD + zl];
-        const double f = s * ei, b = c * ei;
-        // r = hypot(f, g), s = f / r, c = g / r through ONE Newton-refined reciprocal square
-        // root, branch-free: this scalar recurrence is the serial chain of the whole solver
-        const double h2 = fma(f, f, gg * gg);
-        const double rinv = fast_rsqrt(fmax(h2, 1e-300));
-        r = h2 * rinv;
-        if (lane == i + 1) ereg = r;
-        if (r == 0.0) {  // recover from underflow (f = g = 0): restart this eigenvalue
-          if (lane == i + 1) dreg = di1 - p;
-          if (lane == m) ereg = 0.0;
-          under = true;
-          break;
-        }
-        s = f * rinv;
-        c = gg * rinv;
-        gg = di1 - p;
-        r = fma(di - gg, s, 2.0 * c * b);
-        p = s * r;
-        if (lane == i + 1) dreg = gg + p;
-        gg = fma(c, r, -b);
-        if (lane < n) Zt[(i + 1) * LD + lane] = fma(s, zi, c * zc);
-        zc = fma(c, zi, -s * zc);
-        zi = znext;
-        di1 = di;
-        di = di_n;
-        ei = ei_n;
-      }
-      if (lane < n) Zt[(under ? i + 1 : l) * LD + lane] = zc;  // the carried column goes home
-      if (under) continue;
-      if (lane == l) {
-        dreg -= p;
-        ereg = gg;
-      }
-      if (lane == m) ereg = 0.0;
-    }
-    if (failed) break;
-  }
-  if (failed) st |= PBBSS_ST_EIG_NOCONV;
-  __syncthreads();
-  // ---- eigenvector `lane`: x = H_0 ... H_{n-3} Z[:, lane] (H_{n-2} has v = e_{n-1}: a phase)
-  double xre[DP], xim[DP];
-#pragma unroll
-  for (int r = 0; r < DP; ++r) {
-    xre[r] = (r < n && lane < n) ? Zt[lane * LD + r] : 0.0;
-    xim[r] = 0.0;
-  }
-  for (int k = n - 2; solve && k >= 0; --k) {
-    const double tr_ = tauv[k * 2], ti_ = tauv[k * 2 + 1];
-    if (tr_ == 0.0 && ti_ == 0.0) continue;  // uniform
-    // v_k: 1 at k + 1, A[r][k] below, 0 above; s = v^H x
-    // the reflector is fetched ONCE, lane r taking v_k[r] (1 at k + 1, A[r][k] below, 0
-    // above), and handed to the FMAs through v_readlane (r is a compile-time constant of the
-    // unrolled loops, the value arrives as an SGPR operand): no LDS round trip per row, no
-    // operand arrays next to the 2 DP registers of the eigenvector
-    const bool on = lane > k + 1 && lane < n;
-    const double are = A[((on ? lane : n - 1) * LD + k) * 2];
-    const double aim = A[((on ? lane : n - 1) * LD + k) * 2 + 1];
-    const double vre = (lane == k + 1) ? 1.0 : (on ? are : 0.0);
-    const double vim = on ? aim : 0.0;
-    double sr = 0.0, si = 0.0;
-#pragma unroll
-    for (int r = 1; r < DP; ++r) {
-      const double ur = lane_bcast_const(vre, r), ui = lane_bcast_const(vim, r);
-      sr += ur * xre[r] + ui * xim[r];
-      si += ur * xim[r] - ui * xre[r];
-    }
-    const double qr = tr_ * sr - ti_ * si, qi = tr_ * si + ti_ * sr;  // tau (v^H x)
-#pragma unroll
-    for (int r = 1; r < DP; ++r) {
-      const double ur = lane_bcast_const(vre, r), ui = lane_bcast_const(vim, r);
-      xre[r] -= ur * qr - ui * qi;
-      xim[r] -= ur * qi + ui * qr;
-    }
-  }
+  double dreg, xre[DP], xim[DP];
+  if (wave_heev_ql<DP>(A, LD, Zt, LD, dv, ev, tauv, vbuf, wbuf, n, lane, solve, dreg, xre, xim))
+    st |= PBBSS_ST_EIG_NOCONV;
   // ---- eigenvalues -> rank (ascending, ties by index), normalisation and floor, outputs
   int rk = 0;
   double lmax = -1.79e308;

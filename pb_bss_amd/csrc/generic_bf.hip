@@ -299,16 +299,70 @@ __global__ void __launch_bounds__(kGenThreads)
     }
   }
   __syncthreads();
-  if (lds_jacobi_heev(w.G, w.V, w.S, D, LD, tid) < 0) st |= PBBSS_ST_EIG_NOCONV;
-  __syncthreads();
+  // eigendecomposition of G.  D > 20: tridiagonal QL by the first wavefront (generic_dev.hpp;
+  // 1.94 -> 1.71 ms for the 513 bins of a D = 29 chain), only the principal eigenvector is kept
+  // and written to column 0 of V.  Smaller matrices: the 256-thread Jacobi is faster here (this
+  // kernel holds one workgroup per CU either way: 0.58 vs 0.70 ms at D = 16).
   int col = 0;
-  double best = -1.79e308;
-  for (int m = 0; m < D; ++m) {
-    const double lam = w.G[(m * LD + m) * 2];
-    if (lam > best || (lam == best)) {  // ascending order, ties by index: the last maximum
-      best = lam;
-      col = m;
+  if (D <= 20) {
+    if (lds_jacobi_heev(w.G, w.V, w.S, D, LD, tid) < 0) st |= PBBSS_ST_EIG_NOCONV;
+    __syncthreads();
+    double best = -1.79e308;
+    for (int m = 0; m < D; ++m) {
+      const double lam = w.G[(m * LD + m) * 2];
+      if (lam >= best) {  // ascending order, ties by index: the last maximum
+        best = lam;
+        col = m;
+      }
     }
+  } else if (tid < kWave) {
+    const int lane = tid;
+    double* Zt = w.T2;                  // [D][LD] real
+    double* dv = w.T2 + LD * LD;        // the rest of T2 holds the vectors of the solver
+    double* ev = dv + LD + 1;
+    double* tauv = ev + LD + 1;
+    double* vbuf = tauv + 2 * LD;
+    double* wbuf = vbuf + 2 * LD;
+    for (int e = lane; e < D * LD; e += kWave) Zt[e] = ((e / LD) == (e % LD)) ? 1.0 : 0.0;
+    wave_lds_fence();
+    double fro2 = 0.0;
+    for (int e = lane; e < D * D; e += kWave) {
+      const int i = e / D, j = e - i * D;
+      fro2 += w.G[(i * LD + j) * 2] * w.G[(i * LD + j) * 2] + w.G[(i * LD + j) * 2 + 1] * w.G[(i * LD + j) * 2 + 1];
+    }
+    fro2 = wave_sum(fro2);
+    double lam, xre[LD], xim[LD];
+    if (wave_heev_ql<LD>(w.G, LD, Zt, LD, dv, ev, tauv, vbuf, wbuf, D, lane,
+                         (fro2 > 0.0) && isfinite(fro2), lam, xre, xim))
+      st |= PBBSS_ST_EIG_NOCONV;
+    // ascending order, ties by index: the last maximum
+    int top = 0;
+    double best = -1.79e308;
+    for (int m = 0; m < D; ++m) {
+      const double lm = lane_bcast_const(lam, m);
+      if (lm >= best) {
+        best = lm;
+        top = m;
+      }
+    }
+    if (lane == top) {
+#pragma unroll
+      for (int r = 0; r < LD; ++r) {
+        if (r < D) {
+          w.V[(r * LD) * 2] = xre[r];
+          w.V[(r * LD) * 2 + 1] = xim[r];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  {  // OR of the per-thread status words of the first wavefront into every thread's copy
+    __shared__ int sst;
+    if (tid == 0) sst = 0;
+    __syncthreads();
+    if (st) atomicOr(&sst, st);
+    __syncthreads();
+    st = sst;
   }
   for (int i = tid; i < D; i += kGenThreads) {  // w_i = sum_m conj(X_mi) u_m
     double sr = 0.0, si = 0.0;
