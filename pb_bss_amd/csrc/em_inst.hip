@@ -2,6 +2,7 @@
 // heavy persistent-EM template instantiates in parallel under `make -j`.
 #include "cacgmm_em.hpp"
 #include "em_launch.hpp"
+#include <cstdlib>
 
 #ifndef PBBSS_EM_D
 #error "compile with -DPBBSS_EM_D=<sensors>"
@@ -15,13 +16,24 @@ static int launch_variant(EmArgs a, const EmLaunchCfg& cfg, hipStream_t stream) 
   const size_t lds = Kern::lds_bytes(a.T);
   if (lds > cfg.lds_limit) return PBBSS_ERR_LDS_CAPACITY;
   auto kfn = cacgmm_em_kernel<PBBSS_EM_D, K, YS, SPILL>;
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-    return PBBSS_ERR_HIP;
-  int occ = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn, kEmThreads, lds) != hipSuccess)
-    return PBBSS_ERR_HIP;
-  if (occ < 1) occ = 1;
+  // the attribute and the occupancy query are host round trips of several microseconds each:
+  // once per (instantiation, LDS size), not once per launch (the GPU idles meanwhile)
+  static thread_local size_t cached_lds = 0;
+  static thread_local int cached_occ = 0, cached_dev = -1;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (cached_lds != lds || cached_dev != dev) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return PBBSS_ERR_HIP;
+    int q = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, kfn, kEmThreads, lds) != hipSuccess)
+      return PBBSS_ERR_HIP;
+    cached_occ = q < 1 ? 1 : q;
+    cached_lds = lds;
+    cached_dev = dev;
+  }
+  const int occ = cached_occ;
   int64_t grid = (int64_t)cfg.num_cu * occ;
   if (grid > a.B) grid = a.B;
   if (SPILL) {
@@ -37,7 +49,7 @@ static int launch_variant(EmArgs a, const EmLaunchCfg& cfg, hipStream_t stream) 
 // concurrent with the main launch (fork/join through events).
 template <int K, typename YS>
 static int launch_split(EmArgs a, int64_t b_first, int r, const EmLaunchCfg& cfg,
-                        hipStream_t stream) {
+                        hipStream_t stream, bool fork_recorded = false) {
   using Kern = EmKernel<PBBSS_EM_D, K, YS, false>;
   const int window = cfg.split_window > 256 ? 256 : cfg.split_window;  // one E pass per window
   const int G = (a.T + window - 1) / window;
@@ -46,9 +58,17 @@ static int launch_split(EmArgs a, int64_t b_first, int r, const EmLaunchCfg& cfg
   const size_t head = 256;  // counters (r uint) + error word
   if (head + slab_bytes > cfg.xbuf_bytes) return PBBSS_ERR_UNSUPPORTED;
   auto kfn = cacgmm_em_split_kernel<PBBSS_EM_D, K, YS>;
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-    return PBBSS_ERR_HIP;
+  static thread_local size_t cached_lds = 0;
+  static thread_local int cached_dev = -1;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (cached_lds != lds || cached_dev != dev) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return PBBSS_ERR_HIP;
+    cached_lds = lds;
+    cached_dev = dev;
+  }
   a.T_total = a.T;
   a.split_groups = G;
   a.split_window = window;
@@ -57,7 +77,8 @@ static int launch_split(EmArgs a, int64_t b_first, int r, const EmLaunchCfg& cfg
   a.xcount = reinterpret_cast<unsigned*>(cfg.xbuf);
   a.xerror = reinterpret_cast<int*>(cfg.xbuf + 128);
   a.xslab = reinterpret_cast<double*>(cfg.xbuf + head);
-  if (hipEventRecord(cfg.ev_fork, stream) != hipSuccess) return PBBSS_ERR_HIP;
+  // fork: everything enqueued on `stream` before the event (the inputs) precedes the side stream
+  if (!fork_recorded && hipEventRecord(cfg.ev_fork, stream) != hipSuccess) return PBBSS_ERR_HIP;
   if (hipStreamWaitEvent(cfg.side_stream, cfg.ev_fork, 0) != hipSuccess) return PBBSS_ERR_HIP;
   // counters + the per-launch error word; the sticky error word at byte 192 is never cleared
   if (hipMemsetAsync(cfg.xbuf, 0, 192, cfg.side_stream) != hipSuccess) return PBBSS_ERR_HIP;
@@ -90,10 +111,27 @@ static int launch_one(const EmArgs& a, const EmLaunchCfg& cfg, hipStream_t strea
   if (!split) return launch_variant<K, YS, false>(a, cfg, stream);
   EmArgs main_a = a;
   main_a.B = a.B - r;
-  int rc = launch_split<K, YS>(a, a.B - r, (int)r, cfg, stream);
-  if (rc != PBBSS_OK) return rc;
-  rc = launch_variant<K, YS, false>(main_a, cfg, stream);
-  if (rc != PBBSS_OK) return rc;
+  // The main launch goes out FIRST: the side-stream preparation of the split groups (fork event,
+  // two memsets, launch) is a dozen host calls during which the device would otherwise idle; the
+  // members are independent of the main workgroups and finish long before them.
+  // (PBBSS_SPLIT_FIRST=1 restores the old order for A/B runs.)
+  static const bool split_first = [] {
+    const char* v = getenv("PBBSS_SPLIT_FIRST");
+    return v && v[0] == '1';
+  }();
+  int rc;
+  if (split_first) {
+    rc = launch_split<K, YS>(a, a.B - r, (int)r, cfg, stream);
+    if (rc != PBBSS_OK) return rc;
+    rc = launch_variant<K, YS, false>(main_a, cfg, stream);
+    if (rc != PBBSS_OK) return rc;
+  } else {
+    if (hipEventRecord(cfg.ev_fork, stream) != hipSuccess) return PBBSS_ERR_HIP;
+    rc = launch_variant<K, YS, false>(main_a, cfg, stream);
+    if (rc != PBBSS_OK) return rc;
+    rc = launch_split<K, YS>(a, a.B - r, (int)r, cfg, stream, /*fork_recorded=*/true);
+    if (rc != PBBSS_OK) return rc;
+  }
   if (hipStreamWaitEvent(stream, cfg.ev_join, 0) != hipSuccess) return PBBSS_ERR_HIP;
   return PBBSS_OK;
 }

@@ -75,7 +75,7 @@ def em_fit(y, K, *, gamma0=None, model=None, iterations=100, saliency=None,
     out_vec = t.empty((B, K, D, D), dtype=t.complex128, device=dev)
     out_val = t.empty((B, K, D), dtype=f64, device=dev)
     out_w = t.empty((B, K), dtype=f64, device=dev)
-    out_st = t.zeros((B, K), dtype=t.int32, device=dev)
+    out_st = t.empty((B, K), dtype=t.int32, device=dev)  # every row is written by the library
     out_aff = t.empty((B, K, T), dtype=f64, device=dev) if final_predict else None
     out_q = t.empty((B, K, T), dtype=f64, device=dev) if (final_predict and return_q) else None
     if model is not None:
