@@ -255,7 +255,8 @@ def test_long_utterance_spills_frames_to_hbm():
     assert np.abs(_host(r['affiliation']) - mask).max() < 1e-9
 
 
-@pytest.mark.parametrize('F,T,D,K', [(257, 200, 4, 2), (258, 130, 8, 3), (513, 300, 6, 4)])
+@pytest.mark.parametrize('F,T,D,K', [(257, 200, 4, 2), (258, 130, 8, 3), (513, 300, 6, 4),
+                                     (520, 500, 8, 3)])  # 520 = 8 utterances x 65 bins: rank 0 of 8
 def test_split_tail_equals_plain_launch(F, T, D, K):
     """B = m*256 + r: the r remainder problems run as split groups (several
     workgroups share one bin's frames and exchange partial sums through L2).
