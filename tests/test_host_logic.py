@@ -42,6 +42,28 @@ def test_weight_mode_mapping():
     assert wm(-3, 3) is None
 
 
+def test_shared_weight_mode_mapping():
+    """weight_constant_axis sets that average the weights over the last independent axis (the
+    frequency bins) go to the cooperative kernel (pbbss_cacgmm_fit_shared); everything else that
+    couples bins stays with the step-wise loop."""
+    from pb_bss_amd import _lib
+    from pb_bss_amd.distribution.cacgmm import CACGMMTrainer
+    sm = CACGMMTrainer._shared_mode
+    assert sm((-3,), 3) == _lib.WEIGHT_SHARED_KT
+    assert sm(-3, 3) == _lib.WEIGHT_SHARED_KT
+    assert sm((0,), 3) == _lib.WEIGHT_SHARED_KT
+    assert sm((-3, -1), 3) == _lib.WEIGHT_SHARED_K
+    assert sm([-1, -3], 4) == _lib.WEIGHT_SHARED_K
+    assert sm((1, 3), 4) == _lib.WEIGHT_SHARED_K            # positive axes of a (U, F, K, T) posterior
+    assert sm((-1,), 3) is None and sm(-2, 3) is None        # per-bin modes: the fused kernel
+    assert sm((-4,), 4) is None and sm((-4, -3), 4) is None  # over utterances: step-wise loop
+    assert sm((-3,), 2) is None                              # no independent axis at all
+    assert _lib.WEIGHT_SHARED_K == 2 and _lib.WEIGHT_SHARED_KT == 3  # include/pbbss.h
+    header = open(__import__('os').path.join(
+        __import__('os').path.dirname(__import__('os').path.dirname(__file__)), 'include', 'pbbss.h')).read()
+    assert '#define PBBSS_WEIGHT_SHARED_K 2' in header and '#define PBBSS_WEIGHT_SHARED_KT 3' in header
+
+
 def test_model_containers_roundtrip():
     from pb_bss_amd.distribution import CACGMM, ComplexAngularCentralGaussian
     m = CACGMM(weight=np.ones((2, 1)),
