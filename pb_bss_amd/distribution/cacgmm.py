@@ -168,6 +168,7 @@ class CACGMMTrainer:
             eigenvalue_floor=1e-10,
             inline_permutation_aligner=None,
             _with_affiliation=False,
+            _weight_hook=None,
     ):
         """Same contract as the reference (cacgmm.py:142-280).
 
@@ -227,7 +228,9 @@ class CACGMMTrainer:
 
         ndim = len(indep) + 2
         mode = self._weight_mode(weight_constant_axis, ndim)
-        fused = (mode is not None and inline_permutation_aligner is None)
+        # _weight_hook (sharding.shared_weight_allreduce): the mixture weights are estimated over
+        # bins that live on other ranks too -> step-wise loop with the hook between E and M
+        fused = (mode is not None and inline_permutation_aligner is None and _weight_hook is None)
         if fused and model is not None:
             # a resumed model must carry per-class weights the kernel can hold
             w = model.weight
@@ -245,7 +248,7 @@ class CACGMMTrainer:
                 act, mode, covariance_norm, affiliation_eps, eigenvalue_floor,
                 hermitize, like_torch, final_predict=_with_affiliation)
         smode = self._shared_mode(weight_constant_axis, ndim)
-        if smode is not None and inline_permutation_aligner is None:
+        if smode is not None and inline_permutation_aligner is None and _weight_hook is None:
             out = self._fit_shared(
                 y.reshape(-1, N, D), indep, K, gamma0, model, iterations, sal, act, smode,
                 covariance_norm, affiliation_eps, eigenvalue_floor, like_torch,
@@ -255,7 +258,8 @@ class CACGMMTrainer:
         return self._fit_stepwise(
             y.reshape(-1, N, D), indep, K, gamma0, model, iterations, saliency,
             sal, act, weight_constant_axis, covariance_norm, affiliation_eps,
-            eigenvalue_floor, hermitize, inline_permutation_aligner, like_torch)
+            eigenvalue_floor, hermitize, inline_permutation_aligner, like_torch,
+            weight_hook=_weight_hook)
 
     @staticmethod
     def _weight_mode(axis, ndim):
@@ -398,7 +402,7 @@ class CACGMMTrainer:
     def _fit_stepwise(self, yb, indep, K, gamma0, model, iterations, saliency,
                       sal, act, weight_constant_axis, covariance_norm,
                       affiliation_eps, eigenvalue_floor, hermitize, aligner,
-                      like_torch):
+                      like_torch, weight_hook=None):
         """The reference loop (cacgmm.py:252-278) for the options that couple frequency bins
         (weight_constant_axis with independent axes, inline_permutation_aligner), one E-step
         and one M-step launch per iteration with the cross-bin reduction
@@ -446,7 +450,9 @@ class CACGMMTrainer:
                         aff = _lib.to_device(a_h, t.float64, device=dev)
                         q = _lib.to_device(q_h, t.float64, device=dev)
             weight = None
-            if isinstance(weight_constant_axis, int) and \
+            if weight_hook is not None:
+                weight = weight_hook(aff, sal_dev)  # e.g. an all-reduce over the ranks' bins
+            elif isinstance(weight_constant_axis, int) and \
                     weight_constant_axis % len(shape) - len(shape) == -2:
                 weight = t.full((K, 1), 1.0 / K, dtype=t.float64, device=dev)  # :180-183
             else:
@@ -483,6 +489,7 @@ class CACGMMTrainer:
             affiliation_eps=1e-10,
             eigenvalue_floor=1e-10,
             inline_permutation_aligner=None,
+            _weight_hook=None,
     ):
         """Fit a model, then return the posterior affiliations
         (reference: cacgmm.py:282-313)."""
@@ -494,7 +501,7 @@ class CACGMMTrainer:
             covariance_norm=covariance_norm, affiliation_eps=affiliation_eps,
             eigenvalue_floor=eigenvalue_floor,
             inline_permutation_aligner=inline_permutation_aligner,
-            _with_affiliation=True)
+            _with_affiliation=True, _weight_hook=_weight_hook)
         if isinstance(model, tuple):
             # fused path: the kernel's final E-step IS model.predict(y) (new weights,
             # affiliation_eps = 0, no activity mask) -- no second launch, no re-upload

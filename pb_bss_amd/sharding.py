@@ -127,6 +127,46 @@ def all_gather_bins(local, num_bins, bin_axis=0, group=None):
     return full.movedim(0, bin_axis)
 
 
+def shared_weight_allreduce(weight_constant_axis, total_bins, bin_axis=-3, group=None):
+    """Hook for `CACGMMTrainer.fit(_weight_hook=...)` when `weight_constant_axis` contains the
+    SHARDED bin axis: estimate_mixture_weight (mixture_model_utils.py:133-203) over the bins of
+    all ranks -- the local (saliency-masked) sums, ONE small all-reduce per EM iteration
+    (K x T float64 for weight_constant_axis=(-3,)), then the reference's normalisation with the
+    GLOBAL bin count.  Works on whatever device the affiliations live on (device tensors with
+    nccl / RCCL, CPU tensors with gloo)."""
+    import torch
+    import torch.distributed as dist
+    axes_in = (weight_constant_axis,) if isinstance(weight_constant_axis, int) \
+        else tuple(weight_constant_axis)
+
+    def hook(aff, sal):
+        nd = aff.ndim
+        axes = tuple(sorted({a % nd for a in axes_in}))
+        assert (nd - 2) not in axes, 'the class axis cannot be averaged with others'
+        b_ax = bin_axis % nd
+        assert b_ax in axes, (weight_constant_axis, bin_axis)
+        masked = aff if sal is None else aff * sal[..., None, :]
+        s = masked.sum(dim=axes, keepdim=True)
+        if dist.is_available() and dist.is_initialized():
+            dist.all_reduce(s, group=group)
+        if sal is None:                                  # :186-188: a mean
+            count = 1
+            for a in axes:
+                count *= total_bins if a == b_ax else aff.shape[a]
+            return s / count
+        norm = s.abs().sum(dim=-2, keepdim=True)         # :190-201: L1 over the classes
+        return s / torch.where(norm == 0, torch.full_like(norm, 1e-10), norm)
+
+    def idle(shape, dtype, device, iterations):
+        """A rank without bins still takes part in every iteration's all-reduce."""
+        if dist.is_available() and dist.is_initialized():
+            for _ in range(iterations):
+                dist.all_reduce(torch.zeros(shape, dtype=dtype, device=device), group=group)
+
+    hook.idle = idle
+    return hook
+
+
 def fit_predict_sharded(y, initialization, iterations=100, *, bin_axis=-3,
                         group=None, **fit_kwargs):
     """Sharded `CACGMMTrainer.fit_predict`: every rank passes the FULL problem
@@ -135,8 +175,10 @@ def fit_predict_sharded(y, initialization, iterations=100, *, bin_axis=-3,
     every rank returns the complete (..., F, K, T) affiliations, ready for
     permutation alignment.
 
-    Only options that keep bins independent are allowed (no -3 in
-    weight_constant_axis, no inline_permutation_aligner).
+    `weight_constant_axis` may contain the sharded bin axis ((-3,), (-3, -1): weights
+    averaged over the bins of ALL ranks): the fit then runs step by step with one small
+    all-reduce per iteration (`shared_weight_allreduce`).  An inline permutation aligner
+    needs every bin on one device and is not shardable by bins.
     """
     import torch.distributed as dist
     from . import _lib
@@ -155,8 +197,11 @@ def fit_predict_sharded(y, initialization, iterations=100, *, bin_axis=-3,
     # i.e. the bin axis sits at f_axis_y - nd_y (same negative index in both arrays)
     wca = fit_kwargs.get('weight_constant_axis', (-1,))
     wca = (wca,) if isinstance(wca, int) else tuple(wca)
-    assert all(a % nd_y != f_axis_y for a in wca), (
-        wca, 'weight_constant_axis contains the sharded bin axis: bins are not independent')
+    coupled = any(a % nd_y == f_axis_y for a in wca)
+    hook = None
+    if coupled:
+        assert not (len(wca) == 1 and wca[0] % nd_y - nd_y == -2), wca
+        hook = shared_weight_allreduce(wca, F, bin_axis=f_axis_y - nd_y, group=group)
     lo, hi = shard_bounds(F, world, rank)
 
     def block(x, axis_from_end):
@@ -176,10 +221,18 @@ def fit_predict_sharded(y, initialization, iterations=100, *, bin_axis=-3,
     if kwargs.get('source_activity_mask') is not None:  # (..., F, K, T)
         kwargs['source_activity_mask'] = block(kwargs['source_activity_mask'], neg)
     K = initialization.shape[-2]
+    if hook is not None:
+        kwargs['_weight_hook'] = hook
     if hi > lo:
         masks = CACGMMTrainer().fit_predict(_lib.to_device(y_loc), initialization=_lib.to_device(i_loc),
                                             iterations=iterations, **kwargs)
     else:
+        if hook is not None:  # keep the collective schedule of the other ranks
+            t = _lib.torch()
+            nd_a = initialization.ndim
+            red = sorted({a % nd_a for a in wca})
+            shape = [1 if ax in red else n for ax, n in enumerate(initialization.shape)]
+            hook.idle(shape, t.float64, t.device('cuda', t.cuda.current_device()), iterations)
         # more ranks than bins: this rank owns nothing and contributes an empty block
         t = _lib.torch()
         shape = list(y.shape[:-2]) + [K, y.shape[-2]]

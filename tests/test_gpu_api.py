@@ -442,6 +442,36 @@ def test_shared_weight_fit_full_size_equals_stepwise(axis, monkeypatch):
     assert np.abs(a.predict(Y) - b.predict(Y)).max() < 1e-7
 
 
+@pytest.mark.parametrize('axis,with_sal', [((-3,), False), ((-3, -1), True)])
+def test_sharded_fit_with_weights_shared_over_the_sharded_bins(axis, with_sal):
+    """weight_constant_axis containing the sharded bin axis: fit_predict_sharded runs the
+    step-wise loop with the all-reduce hook between E and M.  One rank here (the hook's
+    world-size-2 arithmetic is covered on CPU, tests/test_sharding_gloo.py): same masks as the
+    unsharded cooperative-kernel fit."""
+    import torch.distributed as dist
+    from oracle import synth
+    from pb_bss_amd import sharding
+    from pb_bss_amd.distribution import CACGMMTrainer
+    Y, init = synth.make_stft(19, 100, 5, 3, seed=41)
+    sal = np.abs(Y[..., 0]).astype(np.float64) if with_sal else None
+    ref = CACGMMTrainer().fit_predict(Y, initialization=init, iterations=4,
+                                      weight_constant_axis=axis, saliency=sal)
+    created = False
+    if not dist.is_initialized():
+        import os
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        dist.init_process_group('gloo', rank=0, world_size=1)
+        created = True
+    try:
+        got = sharding.fit_predict_sharded(Y, init, 4, weight_constant_axis=axis, saliency=sal)
+    finally:
+        if created:
+            dist.destroy_process_group()
+    from pb_bss_amd import _lib
+    assert np.abs(_lib.to_host(got) - ref).max() < 1e-9
+
+
 def test_shared_weight_fit_falls_back_when_not_served(monkeypatch):
     """K = 5 classes is outside the cooperative kernel: PBBSS_ERR_UNSUPPORTED from the C ABI,
     the trainer runs the step-wise loop (same result as forcing it)."""

@@ -154,3 +154,51 @@ def test_config3_chain_sharded_equals_single_process(shard, gather_dtype):
     mp.spawn(_pipeline_worker, args=(world, _free_port(), shard, gather_dtype, ret),
              nprocs=world, join=True)
     assert dict(ret) == {0: True, 1: True}
+
+
+# ---------------------------------------------------------------------------------------------
+# weight_constant_axis containing the SHARDED bin axis: the all-reduce hook between the E- and
+# the M-step (sharding.shared_weight_allreduce) must reproduce estimate_mixture_weight on the
+# full array, with and without a saliency, on every rank (CPU tensors over gloo here; the same
+# code all-reduces device tensors over RCCL).
+def _hook_worker(rank, world, port, ret):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from pb_bss_amd.distribution.mixture_model_utils import estimate_mixture_weight
+        from pb_bss_amd.sharding import shared_weight_allreduce
+        rng = np.random.default_rng(3)
+        U, F, K, T = 2, 7, 3, 11
+        aff = rng.uniform(size=(U, F, K, T))
+        aff /= aff.sum(axis=-2, keepdims=True)
+        sal = rng.uniform(size=(U, F, T))
+        sal[0, :, 4] = 0.0  # a frame that is masked out in every bin: the `where(norm == 0)` branch
+        lo, hi = shard_bounds(F, world, rank)
+        ok = True
+        for axis in ((-3,), (-3, -1), [-1, -3]):
+            for with_sal in (False, True):
+                hook = shared_weight_allreduce(axis, F, bin_axis=-3)
+                got = hook(torch.from_numpy(aff[:, lo:hi].copy()),
+                           torch.from_numpy(sal[:, lo:hi].copy()) if with_sal else None)
+                ref = estimate_mixture_weight(aff, sal if with_sal else None,
+                                              weight_constant_axis=tuple(axis))
+                ok = ok and got.shape == ref.shape and bool(np.abs(got.numpy() - ref).max() < 1e-14)
+        # a rank without bins keeps the collective schedule
+        hook = shared_weight_allreduce((-3,), F, bin_axis=-3)
+        if rank == 0:
+            w = hook(torch.from_numpy(aff.copy()), None)
+            ok = ok and bool(np.abs(w.numpy() - aff.mean(axis=-3, keepdims=True)).max() < 1e-14)
+        else:
+            hook.idle((U, 1, K, T), torch.float64, 'cpu', 1)
+        ret[rank] = ok
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shared_weight_allreduce_hook_world2():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_hook_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}
