@@ -1006,25 +1006,30 @@ __global__ void __launch_bounds__(kGenThreads) gen_inv_kernel(GenInv g) {
       }
       const double ip = 1.0 / piv;
       if (tid == 0) logdet += log(piv);
+      // One straight-line update per entry, a' = a~ - (col~ . row~) / piv with a~ = 0 on row /
+      // column p, col~_i = -1 on row p and row~_j = +1 on column p: it reproduces the four
+      // textbook rules (pivot -> 1/piv, pivot row -> row/piv, pivot column -> -col/piv, rest
+      // -> Schur update) without branches (wave_la.hpp uses the same form for D <= 8)
+      double rr[BS], ri[BS];
+#pragma unroll
+      for (int c = 0; c < BS; ++c) {
+        const int j = bj * BS + c;
+        const bool jp = (j == p);
+        rr[c] = (jp ? 1.0 : rp[j * 2]) * ip;
+        ri[c] = (jp ? 0.0 : rp[j * 2 + 1]) * ip;
+      }
 #pragma unroll
       for (int r = 0; r < BS; ++r) {
         const int i = bi * BS + r;
-        const double cr = cp[i * 2], ci = cp[i * 2 + 1];
+        const bool irow = (i == p);
+        const double cr = irow ? -1.0 : cp[i * 2], ci = irow ? 0.0 : cp[i * 2 + 1];
 #pragma unroll
         for (int c = 0; c < BS; ++c) {
           const int j = bj * BS + c;
-          const double rr = rp[j * 2] * ip, ri = rp[j * 2 + 1] * ip;
-          double xr, xi;
-          if (i == p) {
-            xr = (j == p) ? ip : rr;
-            xi = (j == p) ? 0.0 : ri;
-          } else if (j == p) {
-            xr = -cr * ip;
-            xi = -ci * ip;
-          } else {
-            xr = ar[r][c] - (cr * rr - ci * ri);
-            xi = ai[r][c] - (cr * ri + ci * rr);
-          }
+          const bool keep = !(irow || j == p);
+          const double br = keep ? ar[r][c] : 0.0, bim = keep ? ai[r][c] : 0.0;
+          const double xr = br - (cr * rr[c] - ci * ri[c]);
+          const double xi = bim - (cr * ri[c] + ci * rr[c]);
           if (i < D && j < D) {
             ar[r][c] = xr;
             ai[r][c] = xi;
