@@ -944,6 +944,8 @@ __global__ void __launch_bounds__(kGenThreads) gen_inv_kernel(GenInv g) {
   __shared__ __attribute__((aligned(16))) double A[DP * DP * 2];  // only for the final symmetrisation
   __shared__ __attribute__((aligned(16))) double rowp[2][DP * 2];
   __shared__ __attribute__((aligned(16))) double colp[2][DP * 2];
+  __shared__ double pivinv[2];  // reciprocal of the current pivot, by pivot parity
+  __shared__ double pivs[DP];   // the pivots, for the log-determinant
   __shared__ double red[kGenWaves];
   const int tid = threadIdx.x;
   const int64_t n = blockIdx.x;
@@ -973,10 +975,21 @@ __global__ void __launch_bounds__(kGenThreads) gen_inv_kernel(GenInv g) {
   // Gauss-Jordan sweep without pivoting: the pivots of a Hermitian positive definite matrix
   // are its (positive) Schur complements and their product is the determinant
   bool ok = true;
-  double logdet = 0.0;
   // pivot p = pb BS + pr: pr is a compile-time constant of the unrolled inner loop, so that
   // the owner's register arrays are indexed statically (a runtime row select is turned into an
   // indexed scratch access by hipcc)
+  // Everything that is not the complex multiply-add of an entry is hoisted out of the sweep: the
+  // reciprocal of the pivot is computed by the thread that owns it and travels with the pivot
+  // row, the logarithms of the determinant are taken after the sweep (one pivot per thread), the
+  // padding masks are loop invariants (57.5 -> 51.9 us at D = 29, 22.4 -> 15.7 us at D <= 16).
+  // Measured and not adopted: 2 x 2 block pivots (half the publish / barrier / read round trips,
+  // 60.7 us) and one wavefront per matrix with 4 x 4 register blocks (53.0 us, 25.7 us at
+  // D <= 16); without the sweep the kernel takes 13.5 us.
+  bool live[BS][BS];
+#pragma unroll
+  for (int r = 0; r < BS; ++r)
+#pragma unroll
+    for (int c = 0; c < BS; ++c) live[r][c] = (bi * BS + r < D) && (bj * BS + c < D);
   for (int pb = 0; pb < NBK; ++pb) {
     static_for<0, BS>([&](auto prc) {
       constexpr int pr = prc;
@@ -990,6 +1003,12 @@ __global__ void __launch_bounds__(kGenThreads) gen_inv_kernel(GenInv g) {
           rp[(bj * BS + c) * 2] = ar[pr][c];
           rp[(bj * BS + c) * 2 + 1] = ai[pr][c];
         }
+        if (bj == pb) {  // owner of the pivot: its reciprocal (0 flags a bad pivot) and its value
+          const double piv = ar[pr][pr];
+          const bool good = (piv > 0.0) && isfinite(piv);
+          pivinv[p & 1] = good ? 1.0 / piv : 0.0;
+          pivs[p] = piv;
+        }
       }
       if (owner && bj == pb) {
 #pragma unroll
@@ -999,13 +1018,11 @@ __global__ void __launch_bounds__(kGenThreads) gen_inv_kernel(GenInv g) {
         }
       }
       __syncthreads();
-      const double piv = rp[p * 2];
-      if (!(piv > 0.0) || !isfinite(piv)) {  // the same value in every thread
+      const double ip = pivinv[p & 1];
+      if (ip == 0.0) {  // the same value in every thread
         ok = false;
         return;
       }
-      const double ip = 1.0 / piv;
-      if (tid == 0) logdet += log(piv);
       // One straight-line update per entry, a' = a~ - (col~ . row~) / piv with a~ = 0 on row /
       // column p, col~_i = -1 on row p and row~_j = +1 on column p: it reproduces the four
       // textbook rules (pivot -> 1/piv, pivot row -> row/piv, pivot column -> -col/piv, rest
@@ -1030,13 +1047,19 @@ __global__ void __launch_bounds__(kGenThreads) gen_inv_kernel(GenInv g) {
           const double br = keep ? ar[r][c] : 0.0, bim = keep ? ai[r][c] : 0.0;
           const double xr = br - (cr * rr[c] - ci * ri[c]);
           const double xi = bim - (cr * ri[c] + ci * rr[c]);
-          if (i < D && j < D) {
-            ar[r][c] = xr;
-            ai[r][c] = xi;
-          }
+          ar[r][c] = live[r][c] ? xr : 0.0;
+          ai[r][c] = live[r][c] ? xi : 0.0;
         }
       }
     });
+  }
+  // log det = sum of the logarithms of the pivots, in pivot order
+  double logdet = 0.0;
+  __syncthreads();
+  if (ok && tid < D) pivs[tid] = log(pivs[tid]);
+  __syncthreads();
+  if (ok && tid == 0) {
+    for (int q = 0; q < D; ++q) logdet += pivs[q];
   }
   double fro2 = 0.0;
   if (ok && owner) {
