@@ -422,10 +422,12 @@ PBBSS_API int pbbss_cacgmm_fit(pbbss_handle_t h, const void* y, int64_t B, int T
     const size_t nkt = (size_t)B * K * T;
     const size_t nmat = (size_t)B * K;
     const size_t ninv = pbbss::gen_state_doubles((int64_t)nmat, D);
+    const size_t ny = (size_t)B * T * D * (o->y_is_c128 ? 16 : 8);
+    const bool transpose = B <= 65535;  // frame-contiguous copy for the E-steps of the loop
     const size_t need = 2 * WorkCarver::pad(nkt * 8) + WorkCarver::pad(nmat * D * D * 16) +
                         WorkCarver::pad(ninv * 8) +
                         2 * WorkCarver::pad(nmat * 8) + WorkCarver::pad(nmat * 4) +
-                        WorkCarver::pad((size_t)B * 4);
+                        WorkCarver::pad((size_t)B * 4) + (transpose ? WorkCarver::pad(ny) : 0);
     void* wmem = handle_work(h, need);
     if (!wmem) return PBBSS_ERR_HIP;
     WorkCarver wc(wmem);
@@ -437,6 +439,7 @@ PBBSS_API int pbbss_cacgmm_fit(pbbss_handle_t h, const void* y, int64_t B, int T
     int32_t* inv_ok = wc.take<int32_t>(nmat);
     int32_t* zero_bin = wc.take<int32_t>((size_t)B);
     double* csum = wc.take<double>(nmat);
+    char* yt = transpose ? wc.take<char>(ny) : nullptr;
     const pbbss::GenInverseState state{inv, inv_logdet, inv_ok};
     const pbbss::GenInverseState state_from_eig{inv, inv_logdet, nullptr};
     TimedRegion tr(h, s);
@@ -450,15 +453,24 @@ PBBSS_API int pbbss_cacgmm_fit(pbbss_handle_t h, const void* y, int64_t B, int T
     // bins with an all-zero frame (flagged by the E-step / the initial weights) never take
     // the inverse fast path
     if (hipMemsetAsync(zero_bin, 0, (size_t)B * sizeof(int32_t), s) != hipSuccess) return PBBSS_ERR_HIP;
+    // E-steps read a (B, D, T) copy of the raw observation (lane = frame is then the contiguous
+    // axis); the covariance kernel keeps the caller's (B, T, D) array (its lanes span the channels)
+    const void* y_e = y;
+    int layout_e = PBBSS_LAYOUT_TD;
+    if (transpose && (o->iterations > 1 || has_model || o->final_predict)) {
+      if ((rc = pbbss::launch_gen_transpose(y, o->y_is_c128, B, T, D, yt, s)) != PBBSS_OK) return rc;
+      y_e = yt;
+      layout_e = PBBSS_LAYOUT_DT;
+    }
     for (int it = 0; it < o->iterations; ++it) {
       const double* g_src = gamma0;
       if (it > 0 || has_model) {
         // from the second iteration on, classes whose inverse was accepted skip (V, lambda)
-        rc = pbbss::launch_gen_estep(y, o->y_is_c128, PBBSS_LAYOUT_TD, B, T, D, K,
+        rc = pbbss::launch_gen_estep(y_e, o->y_is_c128, layout_e, B, T, D, K,
                                      static_cast<const double*>(out_eigvec), out_eigval,
                                      out_weight, K, 1, 0, activity, o->affiliation_eps, aff,
                                      nullptr, nullptr, s, it > 0 ? state : state_from_eig,
-                                     saliency, mw, zero_bin);
+                                     saliency, mw, zero_bin, /*raw_dt=*/1);
         if (rc != PBBSS_OK) return rc;
         g_src = aff;
       } else {
@@ -486,10 +498,11 @@ PBBSS_API int pbbss_cacgmm_fit(pbbss_handle_t h, const void* y, int64_t B, int T
       if (rc != PBBSS_OK) return rc;
     }
     if (o->final_predict && (out_affiliation || out_quadratic_form)) {
-      rc = pbbss::launch_gen_estep(y, o->y_is_c128, PBBSS_LAYOUT_TD, B, T, D, K,
+      rc = pbbss::launch_gen_estep(y_e, o->y_is_c128, layout_e, B, T, D, K,
                                    static_cast<const double*>(out_eigvec), out_eigval, out_weight,
                                    K, 1, 0, nullptr, 0.0, out_affiliation, out_quadratic_form,
-                                   nullptr, s, state_from_eig);
+                                   nullptr, s, state_from_eig, nullptr, nullptr, nullptr,
+                                   /*raw_dt=*/1);
       if (rc != PBBSS_OK) return rc;
     }
     return PBBSS_OK;

@@ -76,6 +76,7 @@ struct GenEstep {
   const double* saliency;  // (B,T) or null
   double* out_mweight;     // (B,K,T) or null
   int32_t* out_zero;       // (B) or null: set to 1 where a frame is all-zero
+  int raw;                 // 1: the observation is raw (unit-normalised here) whatever its layout
 };
 
 // static group stream of the E-step operands: row i (diagonal .. DP - 1) has ceil((DP - i) / 8)
@@ -133,7 +134,7 @@ __global__ void __launch_bounds__(kGenThreads) gen_estep_kernel(GenEstep a) {
     }
   }
   // raw observations are unit-normalised (zero frames stay zero, utils.py:223-256)
-  const double inv = (a.layout == PBBSS_LAYOUT_TD) ? ((n2 > 0.0) ? 1.0 / n2 : 0.0) : 1.0;
+  const double inv = a.raw ? ((n2 > 0.0) ? 1.0 / n2 : 0.0) : 1.0;
   // y^H A y = sum_i A_ii |y_i|^2 + 2 Re sum_i conj(y_i) sum_{j>i} A_ij y_j  (A Hermitian).
   // Operand feed: row i of A_k from the diagonal on is contiguous in the state and is cut into
   // groups of eight complex entries; lane l loads double (l & 15) of a group, so one VGPR pair
@@ -226,7 +227,7 @@ __global__ void __launch_bounds__(kGenThreads) gen_estep_kernel(GenEstep a) {
           gam * sal / fmax(qs[k * kGenThreads + tid], 10.0 * kTiny) * inv;
     }
   }
-  if (a.out_zero && a.layout == PBBSS_LAYOUT_TD && !(n2 > 0.0)) a.out_zero[b] = 1;
+  if (a.out_zero && a.raw && !(n2 > 0.0)) a.out_zero[b] = 1;
 }
 
 // (V, lambda) -> inverse state for the matrices not already marked ok (cacg.py:167-183 forms
@@ -1124,14 +1125,15 @@ int launch_gen_estep(const void* y, int y_is_c128, int layout, int64_t B, int T,
                      int64_t wk, int64_t wt, const uint8_t* activity, double eps, double* out_aff,
                      double* out_q, double* out_logpdf, hipStream_t s,
                      const GenInverseState& state, const double* saliency, double* out_mweight,
-                     int32_t* out_zero) {
+                     int32_t* out_zero, int raw_dt) {
   if (!gen_supported(D, K)) return PBBSS_ERR_UNSUPPORTED;
   if (!state.inv || !state.logdet) return PBBSS_ERR_INVALID_ARG;
   const int DP = gen_state_ld(D);
   GenEigToInv c{eigvec, eigval, D, DP, state.ok, state.inv, state.logdet};
   hipLaunchKernelGGL(gen_eig_to_inv_kernel, dim3((unsigned)(B * K)), dim3(kGenThreads), 0, s, c);
   GenEstep a{y, layout, B, T, D, K, state.inv, state.logdet, weight, wb, wk, wt, activity, eps,
-             out_aff, out_q, out_logpdf, saliency, out_mweight, out_zero};
+             out_aff, out_q, out_logpdf, saliency, out_mweight, out_zero,
+             (layout == PBBSS_LAYOUT_TD || raw_dt) ? 1 : 0};
   const dim3 grid((unsigned)B, (unsigned)((T + kGenThreads - 1) / kGenThreads));
   if (grid.y > 65535u) return PBBSS_ERR_UNSUPPORTED;
   const size_t lds = (size_t)2 * K * kGenThreads * sizeof(double);  // softmax slots [2][K][thread]
@@ -1186,6 +1188,49 @@ int launch_gen_cov(const void* y, int y_is_c128, int layout, int64_t B, int T, i
   }
 #undef PBBSS_GEN_CK
 #undef PBBSS_GEN_C
+  return ok_or_hip();
+}
+
+namespace {
+// (B, T, D) -> (B, D, T), values untouched: the E-step of the EM loop reads the observation with
+// lane = frame, which on the raw layout is a stride of D complex numbers per lane (every load
+// instruction touches 64 cache lines and the 15 KB footprint of a wave does not survive in L1:
+// 18 500 of a wave's 63 000 cycles at D = 29 were this load phase); transposed once per fit, the
+// frame axis is contiguous and every iteration's loads are coalesced.
+template <typename YS2>
+__global__ void __launch_bounds__(kGenThreads) gen_transpose_kernel(const YS2* y, int T, int D,
+                                                                  YS2* out) {
+  __shared__ YS2 tile[64][33];
+  const int64_t b = blockIdx.y;
+  const int t0 = blockIdx.x * 64;
+  const YS2* src = y + (size_t)b * T * D;
+  YS2* dst = out + (size_t)b * D * T;
+  for (int d0 = 0; d0 < D; d0 += 32) {
+    const int nd = min(32, D - d0);
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * nd; i += kGenThreads) {
+      const int f = i / nd, c = i - f * nd;
+      if (t0 + f < T) tile[f][c] = src[(size_t)(t0 + f) * D + d0 + c];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * nd; i += kGenThreads) {
+      const int c = i >> 6, f = i & 63;
+      if (t0 + f < T) dst[(size_t)(d0 + c) * T + t0 + f] = tile[f][c];
+    }
+  }
+}
+}  // namespace
+
+int launch_gen_transpose(const void* y, int y_is_c128, int64_t B, int T, int D, void* out,
+                         hipStream_t s) {
+  if (B > 65535) return PBBSS_ERR_UNSUPPORTED;
+  const dim3 grid((unsigned)((T + 63) / 64), (unsigned)B);
+  if (y_is_c128)
+    hipLaunchKernelGGL(gen_transpose_kernel<double2>, grid, dim3(kGenThreads), 0, s,
+                       static_cast<const double2*>(y), T, D, static_cast<double2*>(out));
+  else
+    hipLaunchKernelGGL(gen_transpose_kernel<float2>, grid, dim3(kGenThreads), 0, s,
+                       static_cast<const float2*>(y), T, D, static_cast<float2*>(out));
   return ok_or_hip();
 }
 

@@ -30,7 +30,12 @@ int launch_gen_estep(const void* y, int y_is_c128, int layout, int64_t B, int T,
                      int64_t wk, int64_t wt, const uint8_t* activity, double eps, double* out_aff,
                      double* out_q, double* out_logpdf, hipStream_t s,
                      const GenInverseState& state, const double* saliency = nullptr,
-                     double* out_mweight = nullptr, int32_t* out_zero = nullptr);
+                     double* out_mweight = nullptr, int32_t* out_zero = nullptr,
+                     int raw_dt = 0);  // raw_dt: layout DT holds RAW values (transposed copy)
+
+// (B, T, D) -> (B, D, T) copy of the raw observation for the E-steps of the EM loop
+int launch_gen_transpose(const void* y, int y_is_c128, int64_t B, int T, int D, void* out,
+                         hipStream_t s);
 
 // EM loop, (B, T, D) observations: the M-step as three small steps around the E-step.
 //   launch_gen_estep(..., saliency, out_mweight, out_zero) leaves the per-frame M-step weights
