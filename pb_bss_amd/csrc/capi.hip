@@ -457,7 +457,7 @@ PBBSS_API int pbbss_cacgmm_fit(pbbss_handle_t h, const void* y, int64_t B, int T
     // axis); the covariance kernel keeps the caller's (B, T, D) array (its lanes span the channels)
     const void* y_e = y;
     int layout_e = PBBSS_LAYOUT_TD;
-    if (transpose && (o->iterations > 1 || has_model || o->final_predict)) {
+    if (transpose) {
       if ((rc = pbbss::launch_gen_transpose(y, o->y_is_c128, B, T, D, yt, s)) != PBBSS_OK) return rc;
       y_e = yt;
       layout_e = PBBSS_LAYOUT_DT;
@@ -474,8 +474,8 @@ PBBSS_API int pbbss_cacgmm_fit(pbbss_handle_t h, const void* y, int64_t B, int T
         if (rc != PBBSS_OK) return rc;
         g_src = aff;
       } else {
-        rc = pbbss::launch_gen_init_weights(y, o->y_is_c128, B, T, D, K, gamma0, saliency, mw,
-                                            zero_bin, s);
+        rc = pbbss::launch_gen_init_weights(y_e, o->y_is_c128, layout_e, B, T, D, K, gamma0,
+                                            saliency, mw, zero_bin, s);
         if (rc != PBBSS_OK) return rc;
       }
       rc = pbbss::launch_gen_mstep_cov(y, o->y_is_c128, B, T, D, K, mw, g_src, saliency,

@@ -679,15 +679,18 @@ __global__ void __launch_bounds__(kGenThreads) gen_csum_kernel(const double* gam
 // cacgmm.py:211-228): w = gamma0 sal / |y|^2, and the all-zero-frame flag
 template <typename YS>
 __global__ void __launch_bounds__(kGenThreads) gen_init_weight_kernel(
-    const void* y, int T, int D, int K, const double* gamma0, const double* saliency,
+    const void* y, int layout, int T, int D, int K, const double* gamma0, const double* saliency,
     double* out_mweight, int32_t* out_zero) {
   const int64_t b = blockIdx.x;
   const int t = blockIdx.y * kGenThreads + threadIdx.x;
   if (t >= T) return;
-  const YS* fr = static_cast<const YS*>(y) + 2 * ((size_t)b * T + t) * D;
+  // element strides of (frame, channel): (B, T, D) or the frame-contiguous (B, D, T) copy
+  const size_t st = (layout == PBBSS_LAYOUT_TD) ? (size_t)D : 1;
+  const size_t sd = (layout == PBBSS_LAYOUT_TD) ? 1 : (size_t)T;
+  const YS* fr = static_cast<const YS*>(y) + 2 * ((size_t)b * T * D + (size_t)t * st);
   double n2 = 0.0;
   for (int d = 0; d < D; ++d) {
-    const double re = (double)fr[2 * d], im = (double)fr[2 * d + 1];
+    const double re = (double)fr[2 * d * sd], im = (double)fr[2 * d * sd + 1];
     n2 += re * re + im * im;
   }
   const double inv = (n2 > 0.0) ? 1.0 / n2 : 0.0;
@@ -1234,18 +1237,18 @@ int launch_gen_transpose(const void* y, int y_is_c128, int64_t B, int T, int D, 
   return ok_or_hip();
 }
 
-int launch_gen_init_weights(const void* y, int y_is_c128, int64_t B, int T, int D, int K,
+int launch_gen_init_weights(const void* y, int y_is_c128, int layout, int64_t B, int T, int D, int K,
                             const double* gamma0, const double* saliency, double* out_mweight,
                             int32_t* out_zero, hipStream_t s) {
   if (!gen_supported(D, K)) return PBBSS_ERR_UNSUPPORTED;
   const dim3 grid((unsigned)B, (unsigned)((T + kGenThreads - 1) / kGenThreads));
   if (grid.y > 65535u) return PBBSS_ERR_UNSUPPORTED;
   if (y_is_c128)
-    hipLaunchKernelGGL(gen_init_weight_kernel<double>, grid, dim3(kGenThreads), 0, s, y, T, D, K,
-                       gamma0, saliency, out_mweight, out_zero);
+    hipLaunchKernelGGL(gen_init_weight_kernel<double>, grid, dim3(kGenThreads), 0, s, y, layout, T, D,
+                       K, gamma0, saliency, out_mweight, out_zero);
   else
-    hipLaunchKernelGGL(gen_init_weight_kernel<float>, grid, dim3(kGenThreads), 0, s, y, T, D, K,
-                       gamma0, saliency, out_mweight, out_zero);
+    hipLaunchKernelGGL(gen_init_weight_kernel<float>, grid, dim3(kGenThreads), 0, s, y, layout, T, D,
+                       K, gamma0, saliency, out_mweight, out_zero);
   return ok_or_hip();
 }
 

@@ -43,7 +43,7 @@ int launch_gen_transpose(const void* y, int y_is_c128, int64_t B, int T, int D, 
 //   launch_gen_init_weights does the same for an affiliation initialisation (q = 1);
 //   launch_gen_mstep_cov: class sums + mixture weights (a5), then C_k = D sum_t w y y^H / sum
 //   (a6) on the DPP-operand kernel gen_cov2 (csum: (B,K) workspace).
-int launch_gen_init_weights(const void* y, int y_is_c128, int64_t B, int T, int D, int K,
+int launch_gen_init_weights(const void* y, int y_is_c128, int layout, int64_t B, int T, int D, int K,
                             const double* gamma0, const double* saliency, double* out_mweight,
                             int32_t* out_zero, hipStream_t s);
 int launch_gen_mstep_cov(const void* y, int y_is_c128, int64_t B, int T, int D, int K,
