@@ -120,7 +120,7 @@ struct WatsonKernel {
       const int t = ok ? tt : a.T - 1;
       double re[D], im[D], q[K];
       Base::load_frame(L, t, re, im);
-      Base::quad_forms_pipelined(L, re, im, q);  // |m_k^H y|^2 = <m_k m_k^H, P_t>
+      mode_forms(L, lane, re, im, q);  // |m_k^H y|^2
       const double inv = L.inv_n2[t];
       double lp[K], mx = -1.79e308;
 #pragma unroll
@@ -193,9 +193,40 @@ struct WatsonKernel {
     double gre = mre_i * mre_j + mim_i * mim_j;
     double gim = mim_i * mre_j - mre_i * mim_j;
     Base::store_apack(L, k, c, gre, gim);
+    // the mode itself, interleaved (Re m_0, Im m_0, Re m_1, ...), for the E phase: parked in
+    // this class's slice of the covariance-sum array, which is free between the factorisation
+    // (its last reader) and the next M phase (which rewrites all of it); 2 D <= D^2 doubles
+    if (c.j == 0 && c.i < D) {
+      L.cpack[k * NA + 2 * c.i] = mre_i;
+      L.cpack[k * NA + 2 * c.i + 1] = mim_i;
+    }
     if (lane == 0) {
       L.detm[k] = kappa;
       L.rdet[k] = watson_log_norm<D>(kappa);
+    }
+  }
+
+  // |m_k^H y|^2 for all classes.  The rank-one structure is used directly -- D complex
+  // multiply-adds per class instead of the D^2 real ones of <m m^H, P> plus the outer product P
+  // -- with the 2 D <= 16 components of m_k as DPP operands of ONE register per class
+  // (pbbss_dev.hpp: fmac_row_bcast; lane l holds component l & 15 of the interleaved mode).
+  static __device__ __forceinline__ void mode_forms(const Lds& L, int lane, const double (&re)[D],
+                                                    const double (&im)[D], double (&q)[K]) {
+    static_assert(2 * D <= 16, "one DPP operand register per class");
+    const int comp = ((lane & 15) < 2 * D) ? (lane & 15) : 0;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const double m = L.cpack[k * NA + comp];
+      double ur = 0.0, ui = 0.0, vi = 0.0;  // conj(m) y = (ur) + i (ui - vi)
+      static_for<0, D>([&](auto dc) {
+        constexpr int d = dc;
+        fmac_row_bcast<2 * d>(ur, m, re[d]);      // Re m_d Re y_d
+        fmac_row_bcast<2 * d + 1>(ur, m, im[d]);  // Im m_d Im y_d
+        fmac_row_bcast<2 * d>(ui, m, im[d]);      // Re m_d Im y_d
+        fmac_row_bcast<2 * d + 1>(vi, m, re[d]);  // Im m_d Re y_d
+      });
+      const double w = ui - vi;
+      q[k] = fma(ur, ur, w * w);
     }
   }
 
