@@ -11,7 +11,7 @@ namespace pbbss {
 
 template <int K, typename YS, bool SPILL>
 static int cw_launch_variant(WatsonArgs wa, const EmLaunchCfg& cfg, hipStream_t stream) {
-  using Kern = EmKernel<PBBSS_EM_D, K, YS, SPILL>;
+  using Kern = WatsonKernel<PBBSS_EM_D, K, YS, SPILL>;
   const size_t lds = Kern::lds_bytes(wa.em.T);
   if (lds > cfg.lds_limit) return PBBSS_ERR_LDS_CAPACITY;
   auto kfn = cwmm_em_kernel<PBBSS_EM_D, K, YS, SPILL>;
@@ -25,7 +25,7 @@ static int cw_launch_variant(WatsonArgs wa, const EmLaunchCfg& cfg, hipStream_t 
   int64_t grid = (int64_t)cfg.num_cu * occ;
   if (grid > wa.em.B) grid = wa.em.B;
   if (SPILL) {
-    wa.em.scratch_stride = Kern::scratch_bytes(wa.em.T);
+    wa.em.scratch_stride = Kern::Base::scratch_bytes(wa.em.T);
     wa.em.scratch =
         static_cast<char*>(cfg.get_scratch(cfg.scratch_ctx, wa.em.scratch_stride * grid));
     if (!wa.em.scratch) return PBBSS_ERR_HIP;
@@ -36,7 +36,7 @@ static int cw_launch_variant(WatsonArgs wa, const EmLaunchCfg& cfg, hipStream_t 
 
 template <int K, typename YS>
 static int cw_launch_one(const WatsonArgs& wa, const EmLaunchCfg& cfg, hipStream_t stream) {
-  if (EmKernel<PBBSS_EM_D, K, YS, false>::lds_bytes(wa.em.T) <= cfg.lds_limit)
+  if (WatsonKernel<PBBSS_EM_D, K, YS, false>::lds_bytes(wa.em.T) <= cfg.lds_limit)
     return cw_launch_variant<K, YS, false>(wa, cfg, stream);
   return cw_launch_variant<K, YS, true>(wa, cfg, stream);
 }

@@ -34,55 +34,80 @@ struct WatsonArgs {
   double* out_conc;          // (B,K)
 };
 
-// ln 1F1(1; D; kappa): series for small kappa, closed form
-//   1F1(1; D; k) = (D-1)! k^-(D-1) (e^k - sum_{r<=D-2} k^r / r!)   otherwise.
+// ln n!, n <= 8 (the sensor counts of the fused kernels)
+__device__ __forceinline__ constexpr double ln_factorial(int n) {
+  constexpr double t[9] = {0.0, 0.0, 0.6931471805599453, 1.791759469228055, 3.1780538303479458,
+                           4.787491742782046, 6.579251212010101, 8.525161361065415,
+                           10.60460290274525};
+  return t[n];
+}
+
+// ln 1F1(1; D; kappa) = ln sum_m kappa^m / (D)_m.  kappa < 8: the series itself, 48 terms with
+// compile-time reciprocals (term 48 is < 1e-19 of the sum for D >= 2; the round-1 loop divided
+// per term and ran to 100 terms at kappa = 25: a 7 us serial chain inside every factorisation).
+// Otherwise the closed form
+//   1F1(1; D; k) = (D-1)! k^-(D-1) (e^k - sum_{r<=D-2} k^r / r!),
+// whose subtraction keeps >= 14 digits from kappa = 3 on (checked against mpmath, D = 2..8).
 template <int D>
 __device__ __forceinline__ double log_hyp1f1_1_D(double kappa) {
-  if (kappa < 25.0) {
+  static_assert(D >= 2 && D <= 9, "ln_factorial table");
+  if (kappa < 8.0) {
     double s = 1.0, term = 1.0;
-    for (int m = 1; m < 400; ++m) {
-      term *= kappa / (double)(D + m - 1);
+    static_for<1, 49>([&](auto mc) {
+      constexpr int m = decltype(mc)::value;
+      term *= kappa * (1.0 / (double)(D + m - 1));
       s += term;
-      if (term < 1e-18 * s) break;
-    }
+    });
     return log(s);
   }
-  double ssum = 0.0, term = 1.0, lfact = 0.0;
-#pragma unroll
-  for (int r = 0; r < D - 1; ++r) {
-    if (r > 0) {
-      term *= kappa / (double)r;
-      lfact += log((double)r);  // ln (D-2)! after the loop, need ln (D-1)! below
-    }
+  double ssum = 1.0, term = 1.0;
+  static_for<1, D - 1>([&](auto rc) {
+    constexpr int r = decltype(rc)::value;
+    term *= kappa * (1.0 / (double)r);
     ssum += term;
-  }
-  lfact += (D >= 2) ? log((double)(D - 1)) : 0.0;  // ln (D-1)!
-  return lfact - (double)(D - 1) * log(kappa) + kappa + log1p(-exp(-kappa) * ssum);
+  });
+  return ln_factorial(D - 1) - (double)(D - 1) * log(kappa) + kappa + log1p(-exp(-kappa) * ssum);
 }
 
 // ln c(kappa) as complex_watson.py:157-168
 template <int D>
 __device__ __forceinline__ double watson_log_norm(double kappa) {
-  double lfact = 0.0;
-#pragma unroll
-  for (int r = 2; r <= D - 1; ++r) lfact += log((double)r);
-  return log(2.0) + (double)D * 1.1447298858494002 /* ln pi */ - lfact + log_hyp1f1_1_D<D>(kappa);
+  return 0.6931471805599453 + (double)D * 1.1447298858494002 /* ln pi */ - ln_factorial(D - 1) +
+         log_hyp1f1_1_D<D>(kappa);
 }
 
+constexpr int kWatsonKnotTable = 64;  // every S-th knot of the spline, staged in LDS
+
 // scipy.interpolate.interp1d(kind='quadratic', bounds_error=False, fill_value=(0, max))
-// == BSpline(t, c, k=2) evaluated with de Boor inside [ev_min, ev_max]
-__device__ __forceinline__ double watson_concentration(const WatsonArgs& a, double ev) {
+// == BSpline(t, c, k=2) evaluated with de Boor inside [ev_min, ev_max].  Called by a whole
+// wavefront with a wave-uniform `ev`: the knot interval is found by a two-level 64-way search
+// (level 1 = `knot1`, every S-th knot, in LDS; level 2 = one global load per lane) instead of
+// a binary search (10 dependent global loads for the reference's 1000 markers).
+__device__ __forceinline__ double watson_concentration(const WatsonArgs& a, const double* knot1,
+                                                       double ev, int lane) {
   if (!(ev >= a.ev_min)) return 0.0;  // also NaN -> 0 like fill_value below the range
   if (ev > a.ev_max) return a.max_concentration;
   constexpr int k = 2;
   const int n = a.n_coef;
-  // largest i in [k, n-1] with t[i] <= ev
-  int lo = k, hi = n - 1;
-  while (lo < hi) {
-    int mid = (lo + hi + 1) >> 1;
-    if (a.spline_t[mid] <= ev) lo = mid; else hi = mid - 1;
+  const int S = (n - k + kWatsonKnotTable - 1) / kWatsonKnotTable;
+  // largest i in [k, n-1] with t[i] <= ev (the knots ascend: the votes form a prefix)
+  int i;
+  if (S <= kWave) {
+    const unsigned long long v1 = __ballot(k + lane * S < n && knot1[lane] <= ev);
+    const int base = k + max(__popcll(v1) - 1, 0) * S;
+    const bool in2 = lane < S && base + lane < n;
+    const double t2 = a.spline_t[in2 ? base + lane : base];
+    const unsigned long long v2 = __ballot(in2 && t2 <= ev);
+    i = base + max(__popcll(v2) - 1, 0);
+  } else {
+    int lo = k, hi = n - 1;
+    while (lo < hi) {
+      int mid = (lo + hi + 1) >> 1;
+      if (a.spline_t[mid] <= ev) lo = mid; else hi = mid - 1;
+    }
+    i = lo;
   }
-  const int i = lo;
+  i = __builtin_amdgcn_readfirstlane(i);
   double d[k + 1];
 #pragma unroll
   for (int j = 0; j <= k; ++j) d[j] = a.spline_c[j + i - k];
@@ -135,11 +160,11 @@ struct WatsonKernel {
         g[k] = exp(lp[k] - mx) * w;  // mixture_model_utils.py:32-37
         den += g[k];
       }
-      den = fmax(den, kTiny);
+      const double rden = 1.0 / fmax(den, kTiny);
       const double sal = (!FINAL && a.saliency) ? a.saliency[(size_t)b * a.T + t] : 1.0;
 #pragma unroll
       for (int k = 0; k < K; ++k) {
-        double gam = g[k] / den;
+        double gam = g[k] * rden;
         if constexpr (FINAL) {
           if (ok) {
             size_t idx = ((size_t)b * K + k) * a.T + t;
@@ -185,15 +210,10 @@ struct WatsonKernel {
     }
   }
 
-  // mode vector on lanes (i, 0..) -> A_k = m m^H packed; kappa, ln c
+  // mode vector on lanes (i, 0) -> LDS; kappa, ln c
   static __device__ __forceinline__ void set_class(const Lds& L, int k, int lane, LaneIJ c,
-                                                   double mre_i, double mim_i, double mre_j,
-                                                   double mim_j, double kappa) {
-    // A_ij = m_i conj(m_j)
-    double gre = mre_i * mre_j + mim_i * mim_j;
-    double gim = mim_i * mre_j - mre_i * mim_j;
-    Base::store_apack(L, k, c, gre, gim);
-    // the mode itself, interleaved (Re m_0, Im m_0, Re m_1, ...), for the E phase: parked in
+                                                   double mre_i, double mim_i, double kappa) {
+    // interleaved (Re m_0, Im m_0, Re m_1, ...) for the E phase's DPP operand register: parked in
     // this class's slice of the covariance-sum array, which is free between the factorisation
     // (its last reader) and the next M phase (which rewrites all of it); 2 D <= D^2 doubles
     if (c.j == 0 && c.i < D) {
@@ -235,9 +255,9 @@ struct WatsonKernel {
   // first (B = V'^H C V'), which is nearly diagonal once EM settles, so the cyclic Jacobi
   // converges in fewer sweeps; V = V' W.  Same eigenpairs to rounding; the eigenvector phase
   // is free and cancels in m m^H.  `warm` is false on the first iteration.
-  static __device__ void factor_class(const WatsonArgs& wa, const Lds& L, int64_t b, int k,
-                                      int lane, bool last, bool warm, double& pvre,
-                                      double& pvim) {
+  static __device__ void factor_class(const WatsonArgs& wa, const Lds& L, const double* knot1,
+                                      int64_t b, int k, int lane, bool last, bool warm,
+                                      double& pvre, double& pvim) {
     lane = opaque(lane);
     const EmArgs& a = wa.em;
     const LaneIJ c = lane_ij(lane);
@@ -273,6 +293,9 @@ struct WatsonKernel {
     if (wave_or((isfinite(are) && isfinite(aim)) ? 0 : 1)) st |= PBBSS_ST_NONFINITE;
     double vre, vim;
     int sweeps;
+#if defined(PBBSS_CW_KNOCK) && PBBSS_CW_KNOCK == 9
+    long long f0 = wall_clock64(), f1 = f0, f2 = f0;
+#endif
     if (warm && !(st & PBBSS_ST_NONFINITE)) {
       double hre, him, tre, tim, bre, bim;
       wave_adjoint(pvre, pvim, c, hre, him);               // V'^H
@@ -286,7 +309,13 @@ struct WatsonKernel {
         bim = 0.0;
       }
       double wre, wim;
+#if defined(PBBSS_CW_KNOCK) && PBBSS_CW_KNOCK == 9
+      f1 = wall_clock64();
+#endif
       sweeps = wave_jacobi_heev<D>(bre, bim, c, wre, wim);
+#if defined(PBBSS_CW_KNOCK) && PBBSS_CW_KNOCK == 9
+      f2 = wall_clock64();
+#endif
       wave_matmul<D>(pvre, pvim, wre, wim, c, vre, vim);   // V = V' W
       are = bre;
       aim = bim;
@@ -309,11 +338,16 @@ struct WatsonKernel {
         lmax = lm;
       }
     }
-    const double kappa = watson_concentration(wa, lmax);
+#if defined(PBBSS_CW_KNOCK) && PBBSS_CW_KNOCK == 9
+    long long f3 = wall_clock64();
+#endif
+    const double kappa = watson_concentration(wa, knot1, lmax, lane);
+#if defined(PBBSS_CW_KNOCK) && PBBSS_CW_KNOCK == 9
+    long long f4 = wall_clock64();
+#endif
     // mode components for this lane's row and column index
     double mre_i = lane_get(vre, ij_lane(c.i, col)), mim_i = lane_get(vim, ij_lane(c.i, col));
-    double mre_j = lane_get(vre, ij_lane(c.j, col)), mim_j = lane_get(vim, ij_lane(c.j, col));
-    set_class(L, k, lane, c, mre_i, mim_i, mre_j, mim_j, kappa);
+    set_class(L, k, lane, c, mre_i, mim_i, kappa);
     if (last) {
       if (c.j == 0 && c.i < D && wa.out_mode) {
         double* o = wa.out_mode + (((size_t)b * K + k) * D + c.i) * 2;
@@ -323,23 +357,29 @@ struct WatsonKernel {
       if (lane == 0 && wa.out_conc) wa.out_conc[(size_t)b * K + k] = kappa;
     }
     if (lane == 0) L.status[k] |= st;
+#if defined(PBBSS_CW_KNOCK) && PBBSS_CW_KNOCK == 9
+    long long f5 = wall_clock64();
+    if (b == 3 && lane == 0 && k == 1)
+      printf("F: sweeps %d rotate-in %lld jacobi %lld back+sort %lld conc %lld setclass %lld kappa %g\n",
+             sweeps, f1 - f0, f2 - f1, f3 - f2, f4 - f3, f5 - f4, kappa);
+#endif
   }
 
   static __device__ void prep_from_model(const WatsonArgs& wa, const Lds& L, int64_t b, int k,
                                          int lane) {
     const EmArgs& a = wa.em;
     const LaneIJ c = lane_ij(lane);
-    double mre_i = 0, mim_i = 0, mre_j = 0, mim_j = 0;
+    double mre_i = 0, mim_i = 0;
     if (c.i < D) {
       mre_i = wa.in_mode[(((size_t)b * K + k) * D + c.i) * 2];
       mim_i = wa.in_mode[(((size_t)b * K + k) * D + c.i) * 2 + 1];
     }
-    if (c.j < D) {
-      mre_j = wa.in_mode[(((size_t)b * K + k) * D + c.j) * 2];
-      mim_j = wa.in_mode[(((size_t)b * K + k) * D + c.j) * 2 + 1];
-    }
-    set_class(L, k, lane, c, mre_i, mim_i, mre_j, mim_j, wa.in_conc[(size_t)b * K + k]);
+    set_class(L, k, lane, c, mre_i, mim_i, wa.in_conc[(size_t)b * K + k]);
     if (lane == 0) L.wgt[k] = a.in_weight ? a.in_weight[b * a.wb + k * a.wk] : 1.0 / K;
+  }
+
+  static __host__ __device__ size_t lds_bytes(int T) {
+    return Base::lds_bytes(T) + kWatsonKnotTable * sizeof(double);
   }
 
   static __device__ void run(const WatsonArgs& wa, char* smem) {
@@ -349,6 +389,11 @@ struct WatsonKernel {
     const int lane = tid & 63;
     const Lds L = Base::carve(
         smem, a.T, SPILL ? a.scratch + (size_t)blockIdx.x * a.scratch_stride : nullptr);
+    double* knot1 = reinterpret_cast<double*>(smem + Base::lds_bytes(a.T));
+    if (tid < kWatsonKnotTable && wa.spline_t && wa.n_coef > 2) {  // predict carries no spline
+      const int S = (wa.n_coef - 2 + kWatsonKnotTable - 1) / kWatsonKnotTable;
+      knot1[tid] = wa.spline_t[min(2 + tid * S, wa.n_coef - 1)];
+    }
     for (int64_t b = blockIdx.x; b < a.B; b += gridDim.x) {
       __syncthreads();
       if (tid < K) L.status[tid] = 0;
@@ -365,10 +410,24 @@ struct WatsonKernel {
       __syncthreads();
       double pvre = 0.0, pvim = 0.0;  // previous eigenvectors of class `wave` (K <= 4 <= waves)
       for (int it = 0; it < a.iterations; ++it) {
-        if (it > 0 || model_in) {
+#ifdef PBBSS_CW_KNOCK  // development builds: skip one phase after the first iterations (timing)
+        const bool ko = it >= 3 && !(it == a.iterations - 1);
+#else
+        constexpr bool ko = false;
+        constexpr int PBBSS_CW_KNOCK = 0;
+#endif
+#if defined(PBBSS_CW_KNOCK) && PBBSS_CW_KNOCK == 9
+        static_assert(true, "");
+        long long c0 = wall_clock64();
+#endif
+        if ((it > 0 || model_in) && !(ko && PBBSS_CW_KNOCK == 1)) {
           phase_e<false>(wa, L, b, tid, wave, lane);
           __syncthreads();
         }
+#if defined(PBBSS_CW_KNOCK) && PBBSS_CW_KNOCK == 9
+        long long c1 = wall_clock64();
+#endif
+        if (!(ko && PBBSS_CW_KNOCK == 2))
         switch (wave) {
           case 0: Base::template phase_m<0>(a, L, lane); break;
           case 1: Base::template phase_m<1>(a, L, lane); break;
@@ -378,8 +437,20 @@ struct WatsonKernel {
         __syncthreads();
         const bool last = (it == a.iterations - 1);
         static_assert(K <= kEmWaves, "one class per wave: the warm start lives in its registers");
-        if (wave < K) factor_class(wa, L, b, wave, lane, last, it > 0, pvre, pvim);
+#if defined(PBBSS_CW_KNOCK) && PBBSS_CW_KNOCK == 9
+        long long c2 = wall_clock64();
+#endif
+        if (wave < K && !(ko && PBBSS_CW_KNOCK == 3))
+          factor_class(wa, L, knot1, b, wave, lane, last, it > 0, pvre, pvim);
+#if defined(PBBSS_CW_KNOCK) && PBBSS_CW_KNOCK == 9
+        long long c3 = wall_clock64();
+#endif
         __syncthreads();
+#if defined(PBBSS_CW_KNOCK) && PBBSS_CW_KNOCK == 9
+        long long c4 = wall_clock64();
+        if (it >= 50 && it < 53 && b == 3 && lane == 0 && wave < 3)
+          printf("it %d wave %d: E %lld M %lld F %lld wait %lld (10 ns ticks)\n", it, wave, c1 - c0, c2 - c1, c3 - c2, c4 - c3);
+#endif
       }
       if (tid < K) {
         if (a.out_weight && a.iterations > 0) a.out_weight[(size_t)b * K + tid] = L.wgt[tid];

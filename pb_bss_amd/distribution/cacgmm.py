@@ -34,7 +34,7 @@ from .mixture_model_utils import (
     apply_inline_permutation_alignment,
     estimate_mixture_weight,
 )
-from .utils import _ProbabilisticModel, as_result
+from .utils import _ProbabilisticModel, as_result, reference_single, to_single
 
 __all__ = ['CACGMM', 'CACGMMTrainer', 'normalize_observation', 'sample_cacgmm']
 
@@ -99,25 +99,38 @@ class CACGMM(_ProbabilisticModel):
         """y (..., N, D) -> affiliation (..., K, N); affiliation_eps = 0.
         Reference: cacgmm.py:64-71."""
         like_torch = _lib.is_torch(y)
+        single = self._single_with(y)
         y = _complex_device(y)
         *indep, N, D = y.shape
         aff, q, _ = self._device_e_step(y.reshape(-1, N, D), tuple(indep), N,
                                         _lib.LAYOUT_TD, source_activity_mask,
                                         0.0, want_q=return_quadratic_form)
+        if single:
+            aff, q = to_single(aff), to_single(q)
         if return_quadratic_form:
             return as_result(aff, like_torch), as_result(q, like_torch)
         return as_result(aff, like_torch)
+
+    def _single_with(self, y):
+        """Result dtype 'reference': the posterior of single-precision observations under a
+        single-precision cACG is float32 whatever the weight's dtype -- the reference
+        multiplies the weight in place (mixture_model_utils.py:37)."""
+        return reference_single(y, self.cacg.covariance_eigenvectors,
+                                self.cacg.covariance_eigenvalues)
 
     def _predict(self, y, source_activity_mask=None, affiliation_eps=0.):
         """y normalised (..., D, N).  Returns (affiliation, quadratic_form,
         log_pdf), each (..., K, N).  Reference: cacgmm.py:73-95."""
         like_torch = _lib.is_torch(y)
+        single = self._single_with(y)
         y = _complex_device(y)
         *indep, D, N = y.shape
         aff, q, lp = self._device_e_step(y.reshape(-1, D, N), tuple(indep), N,
                                          _lib.LAYOUT_DT, source_activity_mask,
                                          affiliation_eps, want_q=True,
                                          want_log_pdf=True)
+        if single:
+            aff, q, lp = to_single(aff), to_single(q), to_single(lp)
         return (as_result(aff, like_torch), as_result(q, like_torch),
                 as_result(lp, like_torch))
 
@@ -184,6 +197,14 @@ class CACGMMTrainer:
         )
         like_torch = _lib.is_torch(y)
         t = _lib.torch()
+        # result dtype 'reference': an array initialisation is cast to y.real.dtype
+        # (cacgmm.py:226-227), a model keeps its own, random affiliations are float64
+        # (:208); a saliency enters the M step as it is (:336-339)
+        if isinstance(initialization, CACGMM):
+            single = reference_single(y, initialization.cacg.covariance_eigenvectors,
+                                      initialization.cacg.covariance_eigenvalues, saliency)
+        else:
+            single = initialization is not None and reference_single(y, saliency)
         y = _complex_device(y)
         assert y.shape[-1] > 1, y.shape
         assert iterations > 0, iterations
@@ -243,10 +264,10 @@ class CACGMMTrainer:
             sal = sal.reshape(-1, N).contiguous()
 
         if fused:
-            return self._fit_fused(
+            return self._rounded(self._fit_fused(
                 y.reshape(-1, N, D), indep, K, gamma0, model, iterations, sal,
                 act, mode, covariance_norm, affiliation_eps, eigenvalue_floor,
-                hermitize, like_torch, final_predict=_with_affiliation)
+                hermitize, like_torch, final_predict=_with_affiliation), single, mode)
         smode = self._shared_mode(weight_constant_axis, ndim)
         if smode is not None and inline_permutation_aligner is None and _weight_hook is None:
             out = self._fit_shared(
@@ -254,12 +275,31 @@ class CACGMMTrainer:
                 covariance_norm, affiliation_eps, eigenvalue_floor, like_torch,
                 final_predict=_with_affiliation)
             if out is not None:
-                return out
-        return self._fit_stepwise(
+                return self._rounded(out, single, mode)
+        return self._rounded(self._fit_stepwise(
             y.reshape(-1, N, D), indep, K, gamma0, model, iterations, saliency,
             sal, act, weight_constant_axis, covariance_norm, affiliation_eps,
             eigenvalue_floor, hermitize, inline_permutation_aligner, like_torch,
-            weight_hook=_weight_hook)
+            weight_hook=_weight_hook), single, mode)
+
+    @staticmethod
+    def _rounded(out, single, mode):
+        """Result dtype 'reference' and single-precision operands: round the float64 results
+        to what the reference returns (float32 weights / eigenvalues / masks, complex64
+        eigenvectors; the constant 1/K weight of weight_constant_axis=-2 stays float64,
+        mixture_model_utils.py:180-183)."""
+        if not single:
+            return out
+        model, aff = out if isinstance(out, tuple) else (out, None)
+        uniform = mode == _lib.WEIGHT_UNIFORM
+        model = CACGMM(
+            weight=model.weight if uniform else to_single(model.weight),
+            cacg=ComplexAngularCentralGaussian(
+                covariance_eigenvectors=to_single(model.cacg.covariance_eigenvectors),
+                covariance_eigenvalues=to_single(model.cacg.covariance_eigenvalues)))
+        if aff is None:
+            return model
+        return model, to_single(aff)
 
     @staticmethod
     def _weight_mode(axis, ndim):

@@ -4,7 +4,9 @@ Mirrors pb_bss/distribution/utils.py:118-220 (`_ProbabilisticModel`): nested
 to_dict / from_dict and an AttributeError that suggests close field names.
 Host-side only; no numerics.
 """
+import contextlib
 import difflib
+import os
 from dataclasses import fields, is_dataclass
 
 import numpy as np
@@ -40,3 +42,57 @@ def as_result(x, like_torch):
     if x is None:
         return None
     return x if like_torch else _lib.to_host(x)
+
+
+# ---- result dtypes -----------------------------------------------------------------------
+# The device arithmetic is float64 throughout.  The reference computes in the precision of
+# its operands (cacgmm.py:226-227: an ndarray initialisation is cast to y.real.dtype, so
+# complex64 observations give a float32 / complex64 model and float32 masks).  'reference'
+# rounds the RESULTS to those dtypes; 'float64' (default) returns the working precision.
+_RESULT_DTYPES = ('float64', 'reference')
+_result_dtype = os.environ.get('PBBSS_RESULT_DTYPE', 'float64')
+assert _result_dtype in _RESULT_DTYPES, _result_dtype
+
+
+def set_result_dtype(mode):
+    """'float64': every result in the device's working precision; 'reference': the dtypes
+    the reference returns for the same operands (single precision results for complex64
+    observations with an array / single-precision-model initialisation).  Returns the
+    previous setting."""
+    global _result_dtype
+    assert mode in _RESULT_DTYPES, (mode, _RESULT_DTYPES)
+    old, _result_dtype = _result_dtype, mode
+    return old
+
+
+@contextlib.contextmanager
+def result_dtype(mode):
+    old = set_result_dtype(mode)
+    try:
+        yield
+    finally:
+        set_result_dtype(old)
+
+
+def _is_single(x):
+    """float32 / complex64 operand (NumPy or torch)?"""
+    return str(x.dtype).rsplit('.', 1)[-1] in ('float32', 'complex64', 'float16')
+
+
+def reference_single(*operands):
+    """True when the reference would carry these operands (None = absent) in single
+    precision and the 'reference' result dtype is selected."""
+    if _result_dtype != 'reference':
+        return False
+    return all(_is_single(x) for x in operands if x is not None)
+
+
+def to_single(x):
+    """float64 -> float32 / complex128 -> complex64 (NumPy or torch; None passes)."""
+    if x is None:
+        return None
+    if _lib.is_torch(x):
+        t = _lib.torch()
+        return x.to(t.complex64 if x.is_complex() else t.float32)
+    x = np.asarray(x)
+    return x.astype(np.complex64 if np.iscomplexobj(x) else np.float32)

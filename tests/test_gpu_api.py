@@ -525,3 +525,44 @@ def test_estimate_mixture_weight_kernel_against_numpy():
                 _lib.to_device(aff), None if s is None else _lib.to_device(s), red_inner, red_n)
             assert tuple(got.shape) == want.shape
             assert np.abs(_lib.to_host(got) - want).max() < 1e-13
+
+
+def test_result_dtype_reference_follows_the_reference_operand_rules():
+    """The reference computes in the precision of its operands (cacgmm.py:226-227); the table
+    below was read off the unmodified reference (complex64 observations, 2 iterations)."""
+    import pb_bss_amd
+    from pb_bss_amd.distribution import CACGMMTrainer
+    rng = np.random.default_rng(0)
+    F, T, D, K = 3, 40, 4, 2
+    y64 = rng.standard_normal((F, T, D)) + 1j * rng.standard_normal((F, T, D))
+    y = y64.astype(np.complex64)
+    g = rng.uniform(size=(F, K, T))
+    g /= g.sum(-2, keepdims=True)
+    np.random.seed(0)
+    wide = CACGMMTrainer().fit(y, initialization=g, iterations=2)
+    assert wide.weight.dtype == np.float64 and wide.predict(y).dtype == np.float64
+    with pb_bss_amd.result_dtype('reference'):
+        table = {   # case: (weight, eigenvectors, eigenvalues, predict(y))
+            'array64': (dict(initialization=g), 'f4', 'c8', 'f4', 'f4'),
+            'array32': (dict(initialization=g.astype(np.float32)), 'f4', 'c8', 'f4', 'f4'),
+            'random': (dict(num_classes=K), 'f8', 'c16', 'f8', 'f8'),
+            'saliency64': (dict(initialization=g, saliency=np.ones((F, T))), 'f8', 'c16', 'f8', 'f8'),
+            'uniform': (dict(initialization=g, weight_constant_axis=-2), 'f8', 'c8', 'f4', 'f4'),
+            'shared': (dict(initialization=g, weight_constant_axis=(-3,)), 'f4', 'c8', 'f4', 'f4'),
+        }
+        for name, (kw, w, vec, val, pred) in table.items():
+            m = CACGMMTrainer().fit(y, iterations=2, **kw)
+            got = (m.weight.dtype, m.cacg.covariance_eigenvectors.dtype,
+                   m.cacg.covariance_eigenvalues.dtype, m.predict(y).dtype)
+            assert got == tuple(np.dtype(x) for x in (w, vec, val, pred)), (name, got)
+            assert m.predict(y64).dtype == np.float64, name     # wide observations promote
+            again = CACGMMTrainer().fit(y, initialization=m, iterations=1)
+            assert again.cacg.covariance_eigenvectors.dtype == np.dtype(vec), name
+            aff = CACGMMTrainer().fit_predict(y, iterations=2, **kw)
+            assert aff.dtype == np.dtype(pred), (name, aff.dtype)
+        m = CACGMMTrainer().fit(y, initialization=g, iterations=2)
+    # rounding only: the single-precision results are the float64 ones to float32 accuracy
+    np.testing.assert_allclose(m.cacg.covariance_eigenvalues, wide.cacg.covariance_eigenvalues,
+                               rtol=1e-6)
+    np.testing.assert_allclose(m.weight, wide.weight, rtol=1e-6)
+    assert pb_bss_amd.set_result_dtype('float64') == 'float64'

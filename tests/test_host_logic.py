@@ -210,3 +210,22 @@ def test_gmm_and_alignment_argument_mapping():
         comp = step[comp, f]                    # M_f o (M_{f-1} o ... o M_1)
         assert (comp == seq[:, f]).all()
     assert op.greedy_calculate_mapping(rng.uniform(size=(3, 1, 5))).tolist() == [[0], [1], [2]]
+
+
+def test_result_dtype_switch_and_rounding_helpers():
+    import pb_bss_amd
+    from pb_bss_amd.distribution.utils import reference_single, to_single
+    y32 = np.zeros(3, np.complex64)
+    assert not reference_single(y32)                      # default: working precision
+    with pb_bss_amd.result_dtype('reference'):
+        assert reference_single(y32, None, np.zeros(2, np.float32))
+        assert not reference_single(y32, np.zeros(2))
+        assert not reference_single(np.zeros(3, np.complex128))
+        with pytest.raises(AssertionError):
+            pb_bss_amd.set_result_dtype('float16')
+    assert not reference_single(y32)
+    assert to_single(None) is None
+    assert to_single(np.ones(2)).dtype == np.float32
+    assert to_single(np.ones(2, np.complex128)).dtype == np.complex64
+    import torch
+    assert to_single(torch.ones(2, dtype=torch.complex128)).dtype == torch.complex64
