@@ -129,88 +129,105 @@ __global__ void __launch_bounds__(kGfThreads)
 }
 
 // ------------------------------------------------------------------ small dense helpers (LDS)
-// In-place lower Cholesky of the E x E matrix a (row stride ld; only the lower triangle is
-// read).  Returns 0 or 1 + the index of the first non-positive pivot (LAPACK dpotrf INFO),
-// uniform over the workgroup.
-// Right-looking with the trailing matrix in REGISTERS: thread t owns the lower-triangle
-// elements t, t + 256, ... (row-major), LDS only carries the pivot columns -- element (r, c)
-// is published when its column becomes the next pivot column -- so a step is two independent
-// LDS reads per owned element and ONE barrier (an in-place LDS update was three barriers and
-// a chain of read-modify-writes per step: 85 us for E = 40).
-__device__ int gf_cholesky(double* a, int E, int ld, int tid, int* info_sm) {
-  constexpr int Q = (64 * 65 / 2 + kGfThreads - 1) / kGfThreads;  // E <= 64
+// Cholesky AND the inverse of its factor in one elimination.  With A = L_u D L_u^T (unit lower
+// L_u, pivots D) the Cholesky factor is L = L_u D^1/2 and X = L^-1 = D^-1/2 L_u^-1; eliminating
+// on [A | I] turns the identity into M = L_u^-1 with the SAME multipliers as the trailing update.
+// Thread t owns the lower-triangle positions t, t + 256, ... (row-major) of BOTH triangles in
+// registers: `val` (trailing matrix, live while j < c) and `mv` (M, live while c <= j < r), so
+// at step j a position does exactly one update  x -= (a_rj / d_j) * other  with
+// other = a_cj (pivot column, trailing part) or m_jc (row j of M, final since step j - 1).
+// LDS only carries what other threads read: the pivot columns of A (published when the column
+// becomes the next pivot column) and the rows of M (published when the row becomes final) --
+// one barrier per step, every load unconditional (clamped index, masked use) so the loads of a
+// step are issued back to back.  Round 1 ran Cholesky (23 us for E = 40), then a forward
+// substitution with one thread per column (30 us) behind it.
+// On return: a[j][j] = pivots d_j, x[r][c] (c <= r) = X = L^-1.  Returns 0 or 1 + the index of
+// the first non-positive pivot (LAPACK dpotrf INFO), uniform over the workgroup.
+template <int Q>  // owned positions per thread: Q * kGfThreads >= E (E + 1) / 2
+__device__ int gf_chol_inverse_q(double* a, double* x, int E, int ld, int tid, int* info_sm) {
   const int ntri = E * (E + 1) / 2;
+  double* pinv = x + 1;  // 1 / d_j in x[0][1 + j]: row 0 of the (lower-triangular) result is x[0][0]
   int er[Q], ec[Q];
-  double val[Q];
+  double val[Q], mv[Q];
 #pragma unroll
   for (int q = 0; q < Q; ++q) {
     const int idx = tid + q * kGfThreads;
     int r = (int)((sqrt(8.0 * idx + 1.0) - 1.0) * 0.5);
     while (r * (r + 1) / 2 > idx) --r;
     while ((r + 1) * (r + 2) / 2 <= idx) ++r;
-    er[q] = (idx < ntri) ? r : -1;
-    ec[q] = idx - r * (r + 1) / 2;
-    val[q] = (idx < ntri) ? a[r * ld + ec[q]] : 0.0;
+    const bool in = idx < ntri;
+    er[q] = in ? r : 0;            // padding slots sit on (0, 0): never updated (no j < 0)
+    ec[q] = in ? idx - r * (r + 1) / 2 : 0;
+    val[q] = in ? a[r * ld + ec[q]] : 0.0;
+    mv[q] = (er[q] == ec[q]) ? 1.0 : 0.0;
+    if (in && er[q] == 0) {
+      x[0] = 1.0;  // row 0 of M is final from the start
+      const bool bad = !(val[q] > 0.0) || !(val[q] < 1.79e308);
+      *info_sm = bad ? 1 : 0;
+      pinv[0] = bad ? 1.0 : 1.0 / val[q];
+    }
   }
-  if (tid == 0) *info_sm = 0;
   __syncthreads();  // everyone holds its elements; column 0 of `a` is the first pivot column
   for (int j = 0; j < E; ++j) {
-    double d = a[j * ld + j];
-    if (!(d > 0.0) || !(d < 1.79e308)) {
-      if (tid == 0 && *info_sm == 0) *info_sm = j + 1;
-      d = 1.0;
-    }
-    const double inv_d = 1.0 / d;
+    const double inv_d = pinv[j];
+    double arj[Q], oth[Q];
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
-      if (er[q] >= 0 && ec[q] > j) {
-        val[q] = fma(-(a[er[q] * ld + j] * inv_d), a[ec[q] * ld + j], val[q]);
-        if (ec[q] == j + 1) a[er[q] * ld + j + 1] = val[q];  // next pivot column
+      arj[q] = a[er[q] * ld + j];
+      // j < c: a_cj of the pivot column; otherwise m_jc (zero-filled above the diagonal of M
+      // is never read: c <= j there)
+      oth[q] = (j < ec[q]) ? a[ec[q] * ld + j] : x[j * ld + ec[q]];
+    }
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const double upd = (arj[q] * inv_d) * oth[q];
+      const bool trailing = j < ec[q];               // implies j < r
+      const bool inverse = !trailing && j < er[q];   // c <= j < r
+      val[q] = trailing ? val[q] - upd : val[q];
+      mv[q] = inverse ? mv[q] - upd : mv[q];
+      if (trailing && ec[q] == j + 1) {
+        a[er[q] * ld + j + 1] = val[q];  // next pivot column
+        if (er[q] == j + 1) {
+          // ... and its pivot's reciprocal, by the one thread that owns it: the division
+          // overlaps this wavefront's other positions instead of heading everybody's next step
+          const bool bad = !(val[q] > 0.0) || !(val[q] < 1.79e308);
+          if (bad && *info_sm == 0) *info_sm = j + 2;
+          pinv[j + 1] = bad ? 1.0 : 1.0 / val[q];
+        }
       }
+      if (er[q] == j + 1) x[er[q] * ld + ec[q]] = mv[q];  // row j + 1 of M is final
     }
     __syncthreads();
   }
-  // scale the pivot columns: L_rj = a_rj / sqrt(a_jj), L_jj = sqrt(a_jj)
-  double out[Q];
+  // X = D^-1/2 M
 #pragma unroll
   for (int q = 0; q < Q; ++q) {
-    out[q] = 0.0;
-    if (er[q] >= 0) {
-      const double dj = a[ec[q] * ld + ec[q]];
-      const double piv = sqrt((dj > 0.0 && dj < 1.79e308) ? dj : 1.0);
-      out[q] = (er[q] == ec[q]) ? piv : a[er[q] * ld + ec[q]] / piv;
-    }
+    const double dj = a[er[q] * ld + er[q]];
+    const double piv = sqrt((dj > 0.0 && dj < 1.79e308) ? dj : 1.0);
+    mv[q] = mv[q] / piv;
   }
   __syncthreads();
 #pragma unroll
   for (int q = 0; q < Q; ++q)
-    if (er[q] >= 0) a[er[q] * ld + ec[q]] = out[q];
+    if (tid + q * kGfThreads < ntri) x[er[q] * ld + ec[q]] = mv[q];
   __syncthreads();
   return *info_sm;
 }
 
-// x = L^-1 (lower), one thread per column, forward substitution.  The inner products are taken
-// in chunks of eight INDEPENDENT operand pairs (clamped indices, masked products): a plain
-// m-loop is a chain of LDS round trips (~60 us for E = 40).
-__device__ void gf_tri_inverse(const double* l, double* x, int E, int ld, int tid) {
-  for (int cidx = tid; cidx < E; cidx += kGfThreads) {
-    for (int r = 0; r < E; ++r) {
-      double s = (r == cidx) ? 1.0 : 0.0;
-      for (int m0 = cidx; m0 < r; m0 += 8) {
-        double lv[8], xv[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int m = (m0 + u < r) ? m0 + u : cidx;
-          lv[u] = l[r * ld + m];
-          xv[u] = x[m * ld + cidx];
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) s -= (m0 + u < r) ? lv[u] * xv[u] : 0.0;
-      }
-      x[r * ld + cidx] = (r < cidx) ? 0.0 : s / l[r * ld + r];
-    }
+// every masked-off position still costs its instruction slots, so the elimination is compiled
+// for the number of positions a thread really owns (E = 40: 4 instead of the 9 of E = 63)
+__device__ int gf_chol_inverse(double* a, double* x, int E, int ld, int tid, int* info_sm) {
+  const int q = (E * (E + 1) / 2 + kGfThreads - 1) / kGfThreads;
+  switch (q) {
+    case 1: return gf_chol_inverse_q<1>(a, x, E, ld, tid, info_sm);
+    case 2: return gf_chol_inverse_q<2>(a, x, E, ld, tid, info_sm);
+    case 3: return gf_chol_inverse_q<3>(a, x, E, ld, tid, info_sm);
+    case 4: return gf_chol_inverse_q<4>(a, x, E, ld, tid, info_sm);
+    case 5: return gf_chol_inverse_q<5>(a, x, E, ld, tid, info_sm);
+    case 6: return gf_chol_inverse_q<6>(a, x, E, ld, tid, info_sm);
+    case 7: return gf_chol_inverse_q<7>(a, x, E, ld, tid, info_sm);
+    default: return gf_chol_inverse_q<8>(a, x, E, ld, tid, info_sm);  // E <= 63
   }
-  __syncthreads();
 }
 
 // cov (E x E, global) -> Mq = X X^T (global, E x E) and offset = -E/2 ln 2pi - sum ln L_dd;
@@ -226,27 +243,27 @@ __device__ int gf_factor(const double* cov, int E, double* lds, int* info_sm, do
     l[r * ld + cc] = (cc <= r) ? cov[(size_t)r * E + cc] : 0.0;
   }
   __syncthreads();
-  const int info = gf_cholesky(l, E, ld, tid, info_sm);
-  gf_tri_inverse(l, x, E, ld, tid);
+#ifdef PBBSS_GF_STAMP
+  long long g0 = wall_clock64();
+#endif
+  const int info = gf_chol_inverse(l, x, E, ld, tid, info_sm);
+#ifdef PBBSS_GF_STAMP
+  long long g1 = wall_clock64(), g2 = g1;
+#endif
+  // the E-step consumes the whitening matrix itself: P = X^T = L^-T (upper triangular; the
+  // reference's precision_cholesky, gaussian.py:26-30), q = |P d|^2
   for (int idx = tid; idx < E * E; idx += kGfThreads) {
     const int r = idx / E, cc = idx % E;
-    double s = 0.0;
-    const int m1 = (r < cc) ? r : cc;  // X is lower triangular: X_rm = 0 for m > r
-    for (int m0 = 0; m0 <= m1; m0 += 8) {
-      double av[8], bv[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int m = (m0 + u <= m1) ? m0 + u : 0;
-        av[u] = x[r * ld + m];
-        bv[u] = x[cc * ld + m];
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) s += (m0 + u <= m1) ? av[u] * bv[u] : 0.0;
-    }
-    out_mq[(size_t)r * E + cc] = s;
+    out_mq[(size_t)r * E + cc] = (cc >= r) ? x[cc * ld + r] : 0.0;
   }
+#ifdef PBBSS_GF_STAMP
+  __syncthreads();
+  long long g3 = wall_clock64();
+  if (tid == 0 && blockIdx.x == 0 && blockIdx.y == 0)
+    printf("gf_factor: cholesky %lld tri_inverse %lld xxt %lld (10 ns)\n", g1 - g0, g2 - g1, g3 - g2);
+#endif
   if (tid < kWave) {  // E <= 63: one wavefront sums the log-pivots
-    double sl = (tid < E) ? log(l[tid * ld + tid]) : 0.0;
+    double sl = (tid < E) ? 0.5 * log(l[tid * ld + tid]) : 0.0;  // ln L_dd = ln sqrt(d)
     sl = wave_sum(sl);
     if (tid == 0) *out_offset = -0.5 * E * kLn2PiGf - sl;  // sum_d ln P_dd = -sum_d ln L_dd
   }
@@ -296,6 +313,9 @@ __global__ void __launch_bounds__(kGfThreads)
   const int tid = threadIdx.x;
   const int k = blockIdx.x;
   const int64_t b = blockIdx.y;
+#ifdef PBBSS_GF_STAMP
+  long long h0 = wall_clock64();
+#endif
   const double* pb = gsum + ((size_t)b * K + k) * (size_t)NTT * 256;
   // element e of a tile: e = r * 64 + l  ->  row 4 r + l / 16, column l % 16
   for (int idx = tid; idx < NTT * 256; idx += kGfThreads) {
@@ -337,6 +357,9 @@ __global__ void __launch_bounds__(kGfThreads)
     }
   }
   __syncthreads();
+#ifdef PBBSS_GF_STAMP
+  if (tid == 0 && k == 0 && b == 0) printf("gf_finalize: gather+cov %lld (10 ns)\n", wall_clock64() - h0);
+#endif
   if (out_mq) {
     __threadfence_block();
     int info = gf_factor(cov, E, sm, &info_sm, out_mq + ((size_t)b * K + k) * (size_t)E * E,
@@ -436,15 +459,14 @@ __global__ void __launch_bounds__(kGfThreads)
       for (int ti = 0; ti < NT; ++ti) {
         double4_t z = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int kk = 0; kk < P; kk += 4) {
+        for (int kk = 16 * ti; kk < P; kk += 4) {  // P_k is upper triangular: columns >= rows
           const double a = M[(16 * ti + i) * (P + 1) + kk + g];  // A[i][k = g]
           const double bv = ds[i * (P + 1) + kk + g];            // B[k = g][j = i]
           z = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv, z, 0, 0, 0);
         }
-        // z[r] = Z[out dim 16 ti + 4 r + g][sample i]
+        // z[r] = (P_k d)[out dim 16 ti + 4 r + g] of sample i
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          qpart = fma(ds[i * (P + 1) + 16 * ti + 4 * r + g], z[r], qpart);
+        for (int r = 0; r < 4; ++r) qpart = fma(z[r], z[r], qpart);
       }
       qpart += __shfl_xor(qpart, 16, 64);
       qpart += __shfl_xor(qpart, 32, 64);
