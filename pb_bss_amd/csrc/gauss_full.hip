@@ -20,7 +20,7 @@
 // Factorisation and log-pdf as the reference writes them:  cov = L L^T (Cholesky, lower),
 // X = L^-1,  "precision Cholesky" P = X^T,  white_n = P (y_n - mean)  (gaussian.py:46-50: the
 // einsum applies P, not P^T),  log_pdf = -E/2 ln 2pi + sum_d ln P_dd - 1/2 |white_n|^2, i.e.
-// the quadratic form of  Mq = P^T P = X X^T.
+// the quadratic form of  P^T P = X X^T.  The kernels keep P itself (upper triangular).
 #include <hip/hip_runtime.h>
 #include "gauss_full.hpp"
 #include "pbbss_dev.hpp"
@@ -37,8 +37,8 @@ constexpr double kLn2PiGf = 1.8378770664093453;
 inline int gf_ok() { return hipGetLastError() == hipSuccess ? PBBSS_OK : PBBSS_ERR_HIP; }
 
 // ------------------------------------------------------------------ scatter (MFMA)
-// grid (C, K, B); every wave of a workgroup owns a contiguous run of samples and writes its own
-// partial: part[((b K + k) C 4 + c 4 + wave)][tile][r * 64 + lane], tiles (ti <= tj) row-major.
+// grid (C, K, B); every wave of a workgroup owns a contiguous run of samples; the workgroup
+// writes one partial: part[(b K + k) C + c][tile][r * 64 + lane], tiles (ti <= tj) row-major.
 template <int NT, typename TS>
 __global__ void __launch_bounds__(kGfThreads)
     gf_scatter_kernel(const TS* __restrict__ y, int64_t N, int E, int K,
@@ -121,11 +121,29 @@ __global__ void __launch_bounds__(kGfThreads)
       }
     }
   }
-  double* dst = part + ((((size_t)b * K + k) * C + c) * kGfWaves + wave) * (size_t)NTT * 256;
+  // the four wave partials of the workgroup are combined through LDS (fixed order) before they
+  // leave the CU: a quarter of the partial traffic for the ordered reduction that follows
+  extern __shared__ double red[];  // [kGfWaves - 1][NTT][256]
+  if (wave > 0) {
+    double* rw = red + (size_t)(wave - 1) * NTT * 256;
 #pragma unroll
-  for (int x = 0; x < NTT; ++x)
+    for (int x = 0; x < NTT; ++x)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) dst[(size_t)x * 256 + r * 64 + lane] = acc[x][r];
+      for (int r = 0; r < 4; ++r) rw[x * 256 + r * 64 + lane] = acc[x][r];
+  }
+  __syncthreads();
+  if (wave == 0) {
+    double* dst = part + (((size_t)b * K + k) * C + c) * (size_t)NTT * 256;
+#pragma unroll
+    for (int x = 0; x < NTT; ++x)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        double t = acc[x][r];
+#pragma unroll
+        for (int w = 0; w < kGfWaves - 1; ++w) t += red[((size_t)w * NTT + x) * 256 + r * 64 + lane];
+        dst[(size_t)x * 256 + r * 64 + lane] = t;
+      }
+  }
 }
 
 // ------------------------------------------------------------------ small dense helpers (LDS)
@@ -230,7 +248,8 @@ __device__ int gf_chol_inverse(double* a, double* x, int E, int ld, int tid, int
   }
 }
 
-// cov (E x E, global) -> Mq = X X^T (global, E x E) and offset = -E/2 ln 2pi - sum ln L_dd;
+// cov (E x E, global) -> P = L^-T (global, E x E, upper triangular; parameter `out_mq`) and
+// offset = -E/2 ln 2pi - sum ln L_dd;
 // lds: 2 E (E + 1) doubles + 1 int.  Returns the Cholesky info.
 __device__ int gf_factor(const double* cov, int E, double* lds, int* info_sm, double* out_mq,
                          double* out_offset, int tid) {
@@ -381,96 +400,152 @@ __global__ void __launch_bounds__(kGfThreads)
 }
 
 // ------------------------------------------------------------------ log-pdf / E-step (MFMA)
-// One wavefront per 16 samples and class: Z = Mq_k D^T by 16x16x4 tiles (A = Mq block, B = the
-// samples' centred vectors), q_n = sum_i d_ni Z_in.  A workgroup (4 waves) walks `tiles` blocks
-// of 64 samples per class with Mq_k staged ONCE in LDS (reloading the 18 KB matrix for every 64
-// samples made this kernel L2-bound); the centred block D is staged per tile.
-// grid (ceil(N / (64 tiles)), B).
+// q_n = |P_k (y_n - mu_k)|^2 with the upper-triangular whitening matrix P_k = L_k^-T that the
+// factorisation leaves behind (the reference's precision_cholesky, gaussian.py:26-56), on the
+// FP64 matrix pipe: per 16 samples and class the product Z = [P_k | -P_k (mu_k - c)] [y - c; 1]
+// as 16x16x4 tiles, zero tiles below the diagonal skipped (24 instead of 36 MFMA at P = 48).
+//   * B operand = the samples.  Lane (i = l % 16, g = l / 16) needs y[n0 + i][kk + g] for every
+//     chunk kk: it loads those NK values straight from global memory into registers (a sample
+//     row is consumed completely by the NK loads of a lane quartet, so every fetched line is
+//     used), subtracts the common shift c = mean of class 0 (keeps the augmented form free of
+//     cancellation) and keeps them for ALL classes and row tiles -- no LDS staging of the
+//     samples, no barrier inside the sample loop, the loads of the next group are issued before
+//     the MFMAs of the current one.  Round 1 staged the centred block per class through LDS:
+//     K global reads of y and two barriers per 64 samples.
+//   * A operand = [P_k | -P_k (mu_k - c)], `KC` classes at a time staged in LDS ONCE per
+//     workgroup (S = 64 * groups samples).
+// The log-pdfs of a workgroup's samples are parked in LDS ([K][S]) for the softmax at the end.
+// grid (ceil(N / S), B).
 template <int NT, typename TS>
 __global__ void __launch_bounds__(kGfThreads)
-    gf_logpdf_kernel(const TS* __restrict__ y, int64_t N, int E, int K, int tiles,
+    gf_logpdf_kernel(const TS* __restrict__ y, int64_t N, int E, int K, int KC, int groups,
                      const double* __restrict__ mean, const double* __restrict__ mq,
                      const double* __restrict__ offset, const double* __restrict__ weight,
                      double* __restrict__ out_lp, double* __restrict__ out_aff) {
   constexpr int P = 16 * NT;
+  constexpr int NK = P / 4;
   extern __shared__ double sm[];
-  double* M = sm;                    // [P][P + 1]  Mq_k, zero padded
-  double* Dm = sm + P * (P + 1);     // [64][P + 1] centred samples, zero padded
-  double* lp = Dm + 64 * (P + 1);    // [K][64 tiles]
+  double* A = sm;                                 // [KC][P][P + 1]
+  double* lp = sm + (size_t)KC * P * (P + 1);     // [K][S]
+  double* dmu = lp + (size_t)K * 64 * groups;     // [KC][P]
+  double* colE = dmu + (size_t)KC * P;            // [KC][P]
+  double* offs = colE + (size_t)KC * P;           // [KC]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t b = blockIdx.y;
-  const int64_t nb0 = (int64_t)blockIdx.x * 64 * tiles;
-  const int S = 64 * tiles;
+  const int S = 64 * groups;
+  const int64_t nb0 = (int64_t)blockIdx.x * S;
   const TS* yb = y + (size_t)b * N * E;
   const int i = lane & 15, g = lane >> 4;
-  for (int k = 0; k < K; ++k) {
-    const double* mu = mean + ((size_t)b * K + k) * E;
-    const double* mk = mq + ((size_t)b * K + k) * (size_t)E * E;
-    const double off = offset[(size_t)b * K + k];
-    __syncthreads();
-    {
+  const double* cm = mean + (size_t)b * K * E;  // the shift: mean of class 0
+  double creg[NK];
+  int dcl[NK];
+#pragma unroll
+  for (int c = 0; c < NK; ++c) {
+    const int d = 4 * c + g;
+    dcl[c] = (d < E) ? d : 0;
+    creg[c] = cm[dcl[c]];
+  }
+  auto fetch = [&](int gi, TS (&raw)[NK]) {
+    const int64_t n = nb0 + 16 * (gi * kGfWaves + wave) + i;
+    const TS* row = yb + (size_t)((n < N) ? n : N - 1) * E;
+#pragma unroll
+    for (int c = 0; c < NK; ++c) raw[c] = row[dcl[c]];
+  };
+  for (int k0 = 0; k0 < K; k0 += KC) {
+    const int kcn = (K - k0 < KC) ? K - k0 : KC;
+    __syncthreads();  // the previous chunk's MFMA reads of A are done
+    // every load of the staging below is independent and issued in batches: a plain strided
+    // loop is one L2 round trip per trip (27 of them for three 48 x 48 matrices)
+    for (int kc = 0; kc < kcn; ++kc) {
+      const double* mk = mq + ((size_t)b * K + k0 + kc) * (size_t)E * E;
       constexpr int R = P * P / kGfThreads;
-      double raw[R];
+      double rawa[R];
 #pragma unroll
       for (int q = 0; q < R; ++q) {
         const int idx = tid + q * kGfThreads;
         const int r = idx / P, cc = idx % P;
-        raw[q] = mk[(size_t)((r < E) ? r : 0) * E + ((cc < E) ? cc : 0)];
+        rawa[q] = mk[(size_t)((r < E) ? r : 0) * E + ((cc < E) ? cc : 0)];
       }
 #pragma unroll
       for (int q = 0; q < R; ++q) {
         const int idx = tid + q * kGfThreads;
         const int r = idx / P, cc = idx % P;
-        M[r * (P + 1) + cc] = (r < E && cc < E) ? raw[q] : 0.0;
+        A[((size_t)kc * P + r) * (P + 1) + cc] = (r < E && cc < E) ? rawa[q] : 0.0;
       }
     }
-    for (int tl = 0; tl < tiles; ++tl) {
-      const int64_t nb = nb0 + 64 * tl;
-      if (nb >= N) break;  // uniform
-      __syncthreads();     // the previous tile's MFMA reads of Dm are done (and M is complete)
-      {  // unconditional loads at clamped addresses first, masks afterwards (see the scatter)
-        constexpr int R = 64 * P / kGfThreads;
-        TS raw[R];
-        double mus[R];
+    for (int idx = tid; idx < kcn * E; idx += kGfThreads) {  // mu_k - c
+      const int kc = idx / E, cc = idx % E;
+      dmu[kc * P + cc] = mean[((size_t)b * K + k0 + kc) * E + cc] - cm[cc];
+    }
+    if (tid < kcn) offs[tid] = offset[(size_t)b * K + k0 + tid];
+    __syncthreads();
+    for (int idx = tid; idx < kcn * E; idx += kGfThreads) {  // column E: -P_k (mu_k - c)
+      const int kc = idx / E, r = idx % E;
+      const double* ar = A + ((size_t)kc * P + r) * (P + 1);
+      const double* dm = dmu + kc * P;
+      double acc = 0.0;
+      for (int c0 = r; c0 < E; c0 += 8) {
+        double av[8], dv[8];
 #pragma unroll
-        for (int q = 0; q < R; ++q) {
-          const int idx = tid + q * kGfThreads;
-          const int sidx = idx / P, d = idx % P;
-          const int64_t n = nb + sidx;
-          const int64_t ncl = (n < N) ? n : N - 1;
-          const int dcl = (d < E) ? d : 0;
-          raw[q] = yb[(size_t)ncl * E + dcl];
-          mus[q] = mu[dcl];
+        for (int u = 0; u < 8; ++u) {
+          const int cc = (c0 + u < E) ? c0 + u : r;
+          av[u] = ar[cc];
+          dv[u] = dm[cc];
         }
 #pragma unroll
-        for (int q = 0; q < R; ++q) {
-          const int idx = tid + q * kGfThreads;
-          const int sidx = idx / P, d = idx % P;
-          const bool ok = (nb + sidx < N) && (d < E);
-          Dm[sidx * (P + 1) + d] = ok ? (double)raw[q] - mus[q] : 0.0;
-        }
+        for (int u = 0; u < 8; ++u) acc += (c0 + u < E) ? av[u] * dv[u] : 0.0;
       }
-      __syncthreads();
-      // wave w: samples 16 w .. 16 w + 15 of the tile; lane: i = l % 16, g = l / 16
-      const double* ds = Dm + (16 * wave) * (P + 1);
-      double qpart = 0.0;
+      colE[idx] = -acc;
+    }
+    __syncthreads();  // column E is written only after every product above has read its row
+    for (int idx = tid; idx < kcn * E; idx += kGfThreads)
+      A[((size_t)(idx / E) * P + idx % E) * (P + 1) + E] = colE[idx];
+    __syncthreads();
+    TS raw[NK];
+    fetch(0, raw);
+    for (int gi = 0; gi < groups; ++gi) {
+      const int64_t n0 = nb0 + 16 * (gi * kGfWaves + wave);
+      if (n0 >= N) break;  // wave-uniform
+      double bv[NK];
 #pragma unroll
-      for (int ti = 0; ti < NT; ++ti) {
-        double4_t z = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int kk = 16 * ti; kk < P; kk += 4) {  // P_k is upper triangular: columns >= rows
-          const double a = M[(16 * ti + i) * (P + 1) + kk + g];  // A[i][k = g]
-          const double bv = ds[i * (P + 1) + kk + g];            // B[k = g][j = i]
-          z = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv, z, 0, 0, 0);
-        }
-        // z[r] = (P_k d)[out dim 16 ti + 4 r + g] of sample i
-#pragma unroll
-        for (int r = 0; r < 4; ++r) qpart = fma(z[r], z[r], qpart);
+      for (int c = 0; c < NK; ++c) {
+        const int d = 4 * c + g;
+        bv[c] = (d < E) ? (double)raw[c] - creg[c] : ((d == E) ? 1.0 : 0.0);
       }
-      qpart += __shfl_xor(qpart, 16, 64);
-      qpart += __shfl_xor(qpart, 32, 64);
-      if (g == 0) lp[k * S + 64 * tl + 16 * wave + i] = off - 0.5 * qpart;
+      if (gi + 1 < groups) fetch(gi + 1, raw);  // in flight during this group's MFMAs
+      for (int kc = 0; kc < kcn; ++kc) {
+        const double* ak = A + (size_t)kc * P * (P + 1);
+        // all A operands of the class first (one batch of LDS reads, nothing waits inside the
+        // MFMA sequence), then the NT row tiles as independent accumulator chains interleaved
+        // chunk by chunk: consecutive MFMAs never depend on each other
+        double av[NT][NK];
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+          for (int c = 4 * ti; c < NK; ++c)  // upper triangular: column chunks >= the row tile
+            av[ti][c] = ak[(16 * ti + i) * (P + 1) + 4 * c + g];  // A[i][k = g]
+        double4_t z[NT];
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti) z[ti] = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int c = 0; c < NK; ++c)
+#pragma unroll
+          for (int ti = 0; ti < NT; ++ti)
+            if (c >= 4 * ti)
+              z[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ti][c], bv[c], z[ti], 0, 0, 0);
+        // z[ti][r] = (P_k (y - mu_k))[out dim 16 ti + 4 r + g] of sample i
+        double qpart = 0.0;
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) qpart = fma(z[ti][r], z[ti][r], qpart);
+        qpart += __shfl_xor(qpart, 16, 64);
+        qpart += __shfl_xor(qpart, 32, 64);
+        if (g == 0)
+          lp[(size_t)(k0 + kc) * S + 16 * (gi * kGfWaves + wave) + i] =
+              offs[kc] - 0.5 * qpart;
+      }
     }
   }
   __syncthreads();
@@ -523,9 +598,10 @@ int gf_fit_go(const void* y, int64_t B, int64_t N, int E, int K, const double* w
   const int C = gf_chunks(B, K, N);
   int64_t Lw = (N + (int64_t)C * kGfWaves - 1) / ((int64_t)C * kGfWaves);
   Lw = (Lw + 3) / 4 * 4;
+  constexpr int NTT = NT * (NT + 1) / 2;
   hipLaunchKernelGGL((gf_scatter_kernel<NT, TS>), dim3((unsigned)C, (unsigned)K, (unsigned)B),
-                     dim3(kGfThreads), 0, s, static_cast<const TS*>(y), N, E, K, w, sal, C, Lw,
-                     part);
+                     dim3(kGfThreads), (kGfWaves - 1) * NTT * 256 * sizeof(double), s,
+                     static_cast<const TS*>(y), N, E, K, w, sal, C, Lw, part);
   size_t ldsd = (size_t)P * (P + 1);
   if (out_mq && 2 * (size_t)E * (E + 1) > ldsd) ldsd = 2 * (size_t)E * (E + 1);
   const size_t lds = ldsd * sizeof(double);
@@ -533,10 +609,9 @@ int gf_fit_go(const void* y, int64_t B, int64_t N, int E, int K, const double* w
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return PBBSS_ERR_HIP;
-  constexpr int NTT = NT * (NT + 1) / 2;
-  double* gsum = part + (size_t)B * K * C * kGfWaves * NTT * 256;  // behind the wave partials
+  double* gsum = part + (size_t)B * K * C * NTT * 256;  // behind the workgroup partials
   hipLaunchKernelGGL(gf_reduce_kernel, dim3((unsigned)NTT, (unsigned)K, (unsigned)B),
-                     dim3(kGfThreads), 0, s, part, C * kGfWaves, NTT, K, gsum);
+                     dim3(kGfThreads), 0, s, part, C, NTT, K, gsum);
   hipLaunchKernelGGL(kfn, dim3((unsigned)K, (unsigned)B), dim3(kGfThreads), lds, s, gsum,
                      static_cast<const TS*>(y), N, E, K, out_mean, out_cov, out_mq, out_offset,
                      out_s0, out_status);
@@ -548,19 +623,26 @@ int gf_logpdf_go(const void* y, int64_t B, int64_t N, int E, int K, const double
                  const double* mq, const double* offset, const double* weight, double* out_lp,
                  double* out_aff, hipStream_t s) {
   constexpr int P = 16 * NT;
-  int tiles = 64 / K;  // K * tiles * 64 log-pdfs staged per workgroup: at most 32 KiB
-  if (tiles > 4) tiles = 4;  // 256 samples per workgroup: ~4 workgroups per CU overlap load and MFMA
-  if (tiles < 1) tiles = 1;
+  // classes staged per pass: whitening matrices within 64 KiB of LDS
+  int KC = (int)((64 * 1024) / (sizeof(double) * P * (P + 1)));
+  if (KC > K) KC = K;
+  if (KC < 1) KC = 1;
+  // samples per workgroup: 512 (two workgroups per CU cover 256 500 samples in one round) unless
+  // the parked log-pdfs [K][S] would exceed 32 KiB
+  int groups = (int)(32 * 1024 / (sizeof(double) * 64 * (size_t)K));
+  if (groups > 8) groups = 8;
+  if (groups < 1) groups = 1;
   const size_t lds =
-      ((size_t)P * (P + 1) + 64 * (size_t)(P + 1) + (size_t)K * 64 * tiles) * sizeof(double);
+      ((size_t)KC * P * (P + 1) + (size_t)K * 64 * groups + (size_t)KC * (2 * P + 1)) *
+      sizeof(double);
   auto kfn = gf_logpdf_kernel<NT, TS>;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return PBBSS_ERR_HIP;
-  const int64_t per = 64 * (int64_t)tiles;
+  const int64_t per = 64 * (int64_t)groups;
   hipLaunchKernelGGL(kfn, dim3((unsigned)((N + per - 1) / per), (unsigned)B), dim3(kGfThreads),
-                     lds, s, static_cast<const TS*>(y), N, E, K, tiles, mean, mq, offset, weight,
-                     out_lp, out_aff);
+                     lds, s, static_cast<const TS*>(y), N, E, K, KC, groups, mean, mq, offset,
+                     weight, out_lp, out_aff);
   return gf_ok();
 }
 
@@ -569,7 +651,7 @@ int gf_logpdf_go(const void* y, int64_t B, int64_t N, int E, int K, const double
 size_t gauss_full_partial_doubles(int64_t B, int64_t N, int E, int K) {
   const int NT = (E + 1 + 15) / 16;
   const int C = gf_chunks(B, K, N);
-  return (size_t)B * K * (C * kGfWaves + 1) * (size_t)(NT * (NT + 1) / 2) * 256;  // + tile sums
+  return (size_t)B * K * (C + 1) * (size_t)(NT * (NT + 1) / 2) * 256;  // + tile sums
 }
 
 #define PBBSS_GF_DISPATCH(FN, ...)                                                      \
