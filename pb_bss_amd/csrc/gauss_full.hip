@@ -22,6 +22,7 @@
 // einsum applies P, not P^T),  log_pdf = -E/2 ln 2pi + sum_d ln P_dd - 1/2 |white_n|^2, i.e.
 // the quadratic form of  P^T P = X X^T.  The kernels keep P itself (upper triangular).
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "gauss_full.hpp"
 #include "pbbss_dev.hpp"
 
@@ -167,12 +168,16 @@ __device__ int gf_chol_inverse_q(double* a, double* x, int E, int ld, int tid, i
   double* pinv = x + 1;  // 1 / d_j in x[0][1 + j]: row 0 of the (lower-triangular) result is x[0][0]
   int er[Q], ec[Q];
   double val[Q], mv[Q];
-#pragma unroll
-  for (int q = 0; q < Q; ++q) {
-    const int idx = tid + q * kGfThreads;
+  auto row_of = [](int idx) {
     int r = (int)((sqrt(8.0 * idx + 1.0) - 1.0) * 0.5);
     while (r * (r + 1) / 2 > idx) --r;
     while ((r + 1) * (r + 2) / 2 <= idx) ++r;
+    return r;
+  };
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    const int idx = tid + q * kGfThreads;
+    const int r = row_of(idx);
     const bool in = idx < ntri;
     er[q] = in ? r : 0;            // padding slots sit on (0, 0): never updated (no j < 0)
     ec[q] = in ? idx - r * (r + 1) / 2 : 0;
@@ -583,8 +588,14 @@ __global__ void gf_weights_kernel(const double* s0, int64_t B, int K, int mode, 
 }
 
 int gf_chunks(int64_t B, int K, int64_t N) {
-  // ~1024 waves in flight in total, at least 64 samples per wave
-  int64_t c = 256 / (B * K < 256 ? B * K : 256);
+  // two workgroups per CU (one wave's loads and operand arithmetic run under the other's MFMAs:
+  // 75 -> 68 us for the scatter at N = 256 500, K = 3; three or four are slower again), at
+  // least 64 samples per wave.  PBBSS_GF_CHUNK_MUL overrides the factor for A/B runs.
+  static const int mul = [] {
+    const char* v = getenv("PBBSS_GF_CHUNK_MUL");
+    return (v && atoi(v) > 0) ? atoi(v) : 2;
+  }();
+  int64_t c = 256 * mul / (B * K < 256 ? B * K : 256);
   const int64_t maxc = (N + 4 * 64 - 1) / (4 * 64);
   if (c > maxc) c = maxc;
   return (int)(c < 1 ? 1 : c);
