@@ -311,11 +311,14 @@ def test_gmm_shapes_against_oracle(F, N, E, K):
 
 
 @pytest.mark.parametrize('N,E,K', [(20000, 40, 3), (333, 5, 2), (1000, 16, 6), (4100, 63, 1),
-                                   (70, 17, 4)])
+                                   (70, 17, 4), (600, 50, 3), (900, 10, 40), (500, 47, 2)])
 def test_gaussian_full_covariance_against_oracle(N, E, K):
     """GaussianTrainer(covariance_type='full') / Gaussian.log_pdf on the matrix pipe against the
     NumPy oracle (which is pinned to the reference by embed_single_fits): every tile count
-    (E + 1 <= 16, 32, 48, 64), ragged sample counts, float32 / float64 input, no saliency."""
+    (E + 1 <= 16, 32, 48, 64; E + 1 = 48 exactly), ragged sample counts, float32 / float64
+    input, no saliency; class counts beyond one LDS pass of whitening matrices (E = 50: one
+    class per pass; K = 40: two passes, one sample group per wave) and every per-thread
+    position count of the factorisation (E = 5 ... 63)."""
     from oracle import embed as oe
     from pb_bss_amd.distribution import Gaussian, GaussianTrainer
     rng = np.random.default_rng(N + E)
