@@ -106,6 +106,10 @@ struct JointExtras {
   // class weights of weight_constant_axis=(-1,) (gcacgmm.py:291-295): w[b,k] = sum_t masked
   // affiliation / sum over k, written by the workgroup that owns bin b (may alias a.in_weight)
   double* weight_fk_out;
+  // Remainder problems of a launch (B = m * CUs + r): blocks >= main_grid are MEMBERS, G of
+  // them share one of the r problems [a.b_first, a.b_first + r) by frame windows (run_joint_member);
+  // 0: every block is a full workgroup.
+  int main_grid;
 };
 
 // SPILL=false: observation, norms and M-step weights live in LDS (the fast path).
@@ -1113,9 +1117,14 @@ struct EmKernel {
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
+    if (jx0.main_grid > 0 && (int)blockIdx.x >= jx0.main_grid) {
+      run_joint_member(a, jx0, smem);
+      return;
+    }
+    const int bstride = jx0.main_grid > 0 ? jx0.main_grid : (int)gridDim.x;
     const Lds L = carve(smem, a.T);
     int* perm = reinterpret_cast<int*>(smem + lds_bytes(a.T));
-    for (int64_t b = blockIdx.x; b < a.B; b += gridDim.x) {
+    for (int64_t b = blockIdx.x; b < a.B; b += bstride) {
       __syncthreads();
       if (tid < K) L.status[tid] = 0;
       if (tid == 0) *L.flags = 0;
@@ -1275,6 +1284,149 @@ struct EmKernel {
       }
     }
     __syncthreads();
+  }
+
+  // ---- remainder problems of the one-iteration joint launch ---------------------------------
+  // 513 bins on 256 CUs put a third full workgroup on one CU, and a one-iteration launch pays
+  // that tail EVERY iteration (34 us per launch against ~20 us for a workgroup's own work).
+  // The r remainder problems are therefore cut into G frame windows handled by small member
+  // workgroups in the same grid (blocks >= main_grid): window load, E-step (affiliations and
+  // q of the window go to HBM as usual), partial covariance sums -> an L2 slab (sc1 stores,
+  // the protocol of split_exchange), then ONE arrival on a counter.  Nobody waits: the member
+  // that arrives last sums the G slabs in a fixed order, factors the classes and writes the
+  // state; the others are done.  No co-residency requirement, no spin, and the result does not
+  // depend on which member happens to be last.  The last member also resets the counter.
+  static constexpr int kJointCounterBase = 24;  // xcount[24 + prob]; [0, 24) belong to run_split
+
+  static __device__ void run_joint_member(const EmArgs& ga, const JointExtras& jx0, char* smem) {
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int G = ga.split_groups;
+    const int m = (int)blockIdx.x - jx0.main_grid;
+    const int prob = m / G, g = m % G;
+    const int64_t b = ga.b_first + prob;
+    const int tf = g * ga.split_window;
+    EmArgs a = ga;  // this workgroup's window
+    a.T = min(ga.split_window, ga.T_total - tf);
+    const Lds L = carve(smem, ga.split_window, nullptr);
+    int* lastflag = reinterpret_cast<int*>(smem + lds_bytes(ga.split_window));
+    if (tid < K) L.status[tid] = 0;
+    if (tid == 0) *L.flags = 0;
+    __syncthreads();
+    phase_load(a, L, b, tid, tf);
+    __syncthreads();
+    for (int k = wave; k < K; k += kEmWaves) {
+      if (jx0.state_in) {
+        const double* st = jx0.state_in + ((size_t)b * K + k) * (NA + 2);
+        for (int i = lane; i < NA; i += kWave) L.apack[k * NA + i] = st[i];
+        if (lane == 0) {
+          const double dm = st[NA];
+          L.detm[k] = dm;
+          L.rdet[k] = 1.0 / dm;
+          L.dete[k] = (int)st[NA + 1];
+        }
+      } else {
+        prep_from_model(a, L, b, k, lane);
+      }
+    }
+    __syncthreads();
+    JointExtras jx = jx0;
+    jx.perm = nullptr;
+    const bool owns = (wave << 6) < a.T;  // windows are <= 256 frames: one E pass
+    if (a.iterations == 0) {
+      if (owns) phase_e<true, true, true>(a, L, b, tid, wave, lane, a.final_eps, tf, &jx);
+      return;
+    }
+    if (owns) {
+      phase_e<false, true, true>(a, L, b, tid, wave, lane, a.aff_eps, tf, &jx);
+    } else if (lane < K) {
+      L.red[wave * K + lane] = 0.0;
+    }
+    __syncthreads();
+    switch (wave) {
+      case 0: phase_m<0>(a, L, lane); break;
+      case 1: phase_m<1>(a, L, lane); break;
+      case 2: phase_m<2>(a, L, lane); break;
+      default: phase_m<3>(a, L, lane); break;
+    }
+    __syncthreads();
+    double* slabs = ga.xslab + (size_t)prob * G * kSlabLen;
+    double* mine = slabs + (size_t)g * kSlabLen;
+    for (int idx = tid; idx < kSlabLen; idx += kEmThreads) {
+      double v;
+      if (idx < K * NA) {
+        v = L.cpack[idx];
+      } else if (idx < K * NA + K) {
+        const int k = idx - K * NA;
+        v = 0.0;
+#pragma unroll
+        for (int w = 0; w < kEmWaves; ++w) v += L.red[w * K + k];
+      } else {
+        v = (double)(*L.flags & 1);
+      }
+      __hip_atomic_store(mine + idx, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its stores
+    __syncthreads();
+    if (tid == 0) {
+      unsigned* cnt = ga.xcount + kJointCounterBase + prob;
+      const unsigned before =
+          __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = (before == (unsigned)(G - 1));
+      if (last) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *lastflag = last;
+    }
+    __syncthreads();
+    if (!*lastflag) return;
+    for (int idx = tid; idx < kSlabLen; idx += kEmThreads) {
+      double tot = 0.0;
+      for (int g0 = 0; g0 < G; g0 += 8) {
+        double part[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int gg = (g0 + u < G) ? g0 + u : g;
+          part[u] = __hip_atomic_load(slabs + (size_t)gg * kSlabLen + idx, __ATOMIC_RELAXED,
+                                      __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) tot += (g0 + u < G) ? part[u] : 0.0;
+      }
+      if (idx < K * NA) {
+        L.cpack[idx] = tot;
+      } else if (idx < K * NA + K) {
+        const int k = idx - K * NA;
+        L.red[k] = tot;
+#pragma unroll
+        for (int w = 1; w < kEmWaves; ++w) L.red[w * K + k] = 0.0;
+      } else {
+        if (tot > 0.0) *L.flags |= 1;
+      }
+    }
+    __syncthreads();
+    if (jx0.weight_fk_out && tid == 0) {
+      double v[K], tot = 0.0;
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        v[k] = L.red[k];
+        tot += v[k];
+      }
+#pragma unroll
+      for (int k = 0; k < K; ++k) jx0.weight_fk_out[(size_t)b * K + k] = v[k] / tot;
+    }
+    for (int k = wave; k < K; k += kEmWaves) {
+      factor_class(a, L, b, k, lane, jx0.emit_model != 0);
+      if (jx0.state_out) {
+        double* st = jx0.state_out + ((size_t)b * K + k) * (NA + 2);
+        for (int i = lane; i < NA; i += kWave) st[i] = L.apack[k * NA + i];
+        if (lane == 0) {
+          st[NA] = L.detm[k];
+          st[NA + 1] = (double)L.dete[k];
+        }
+      }
+    }
+    __syncthreads();
+    if (tid < K && a.out_status) a.out_status[(size_t)b * K + tid] = L.status[tid];
   }
 
   // Distributed factorisation of a split problem: after the exchange every member holds the

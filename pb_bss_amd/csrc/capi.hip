@@ -210,6 +210,12 @@ PBBSS_API int pbbss_create(pbbss_handle_t* out, int device_id) {
       return PBBSS_ERR_HIP;
     }
     h->cfg.xbuf = static_cast<char*>(xb);
+    // arrival counters / error words start at zero (the joint launch's members reset their
+    // counter themselves; the EM split launch clears its own before every launch)
+    if (hipMemset(xb, 0, 256) != hipSuccess) {
+      delete h;
+      return PBBSS_ERR_HIP;
+    }
   }
   h->scratch = nullptr;
   h->scratch_bytes = 0;

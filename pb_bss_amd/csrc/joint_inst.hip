@@ -23,9 +23,38 @@ static int launch_joint(const EmArgs& a, const JointExtras& jx, int inline_pa,
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn, kEmThreads, lds) != hipSuccess)
     return PBBSS_ERR_HIP;
   if (occ < 1) occ = 1;
+  // Tail handling (the rule of launch_one in em_inst.hip): with B = m * num_cu + r (small r) the
+  // r extra problems would put one more full workgroup on r CUs and set the time of EVERY
+  // one-iteration launch; they run as member workgroups on frame windows instead
+  // (run_joint_member; no spinning, the last arriver finishes the problem).
+  const int64_t r = a.B % cfg.num_cu;
+  const int window = cfg.split_window > 256 ? 256 : cfg.split_window;
+  const int G = (a.T + window - 1) / window;
+  const size_t slab_need = 256 + (size_t)r * G * Kern::kSlabLen * sizeof(double);
+  const bool members = cfg.allow_split && !inline_pa && occ >= 3 && a.B > cfg.num_cu &&
+                       a.B <= 2 * (int64_t)cfg.num_cu + kSplitMaxProblems && r >= 1 &&
+                       r <= kSplitMaxProblems && a.T >= 2 * window && slab_need <= cfg.xbuf_bytes;
+  if (members) {  // pbbss_set_split_tail(h, 0) turns them off (A/B runs, tests)
+    EmArgs ma = a;
+    JointExtras mj = jx;
+    ma.B = a.B - r;
+    ma.T_total = a.T;
+    ma.split_groups = G;
+    ma.split_window = window;
+    ma.b_first = a.B - r;
+    ma.xcount = reinterpret_cast<unsigned*>(cfg.xbuf);
+    ma.xerror = reinterpret_cast<int*>(cfg.xbuf + 128);
+    ma.xslab = reinterpret_cast<double*>(cfg.xbuf + 256);
+    mj.main_grid = (int)ma.B;  // <= 2 workgroups per CU: every main problem has its own block
+    hipLaunchKernelGGL(kfn, dim3((unsigned)(ma.B + r * G)), dim3(kEmThreads), lds, stream, ma, mj,
+                       inline_pa);
+    return hipGetLastError() == hipSuccess ? PBBSS_OK : PBBSS_ERR_HIP;
+  }
   int64_t grid = (int64_t)cfg.num_cu * occ;
   if (grid > a.B) grid = a.B;
-  hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(kEmThreads), lds, stream, a, jx, inline_pa);
+  JointExtras pj = jx;
+  pj.main_grid = 0;
+  hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(kEmThreads), lds, stream, a, pj, inline_pa);
   return hipGetLastError() == hipSuccess ? PBBSS_OK : PBBSS_ERR_HIP;
 }
 

@@ -395,3 +395,35 @@ def test_gmm_full_covariance_matches_reference_and_oracle():
     bad[1, 1:] = 1.0
     with pytest.raises(ValueError, match='ill-defined'):
         GMMTrainer().fit(yb[0, :50], initialization=bad, iterations=2)
+
+
+@pytest.mark.parametrize('kind', ['gaussian', 'vmf'])
+def test_joint_remainder_bins_as_member_workgroups(kind):
+    """B = CUs + r bins: the r remainder bins of every one-iteration joint launch run as member
+    workgroups on frame windows (run_joint_member: partial sums through L2, the last arriver
+    factors).  Same masks and model as the plain launch (split handling off) and as the oracle;
+    258 bins = 256 CUs + 2 on an MI355X, 300 frames = four full windows and one of 44."""
+    from pb_bss_amd import engine
+    from pb_bss_amd.distribution import GCACGMMTrainer, VMFCACGMMTrainer
+    from oracle import embed as oe, synth
+    F, T, D, K, E = 258, 300, 4, 3, 12
+    Y, e, init = synth.make_joint(F, T, D, K, E, seed=21)
+    sal = np.random.default_rng(2).uniform(0.2, 1.0, size=(F, T))
+    trainer = GCACGMMTrainer() if kind == 'gaussian' else VMFCACGMMTrainer()
+    out = {}
+    try:
+        for split in (True, False):
+            engine.set_split_tail(split)
+            model = trainer.fit(Y, e, initialization=init, iterations=5, saliency=sal)
+            out[split] = (model, model.predict(Y, e))
+    finally:
+        engine.set_split_tail(True)
+    on, off = out[True], out[False]
+    assert np.abs(on[1] - off[1]).max() < 1e-9
+    np.testing.assert_allclose(on[0].cacg.covariance_eigenvalues, off[0].cacg.covariance_eigenvalues,
+                               rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(on[0].weight, off[0].weight, atol=1e-12)
+    ref = oe.joint_fit(kind, Y.astype(np.complex128), e.astype(np.float64), init, 5, saliency=sal)
+    want = oe.joint_model_predict(ref, Y.astype(np.complex128), e.astype(np.float64))
+    assert np.abs(on[1] - want).max() < 1e-6
+    assert np.abs(on[1][-2:] - want[-2:]).max() < 1e-6   # the two member-handled bins
