@@ -63,6 +63,10 @@ __global__ void __launch_bounds__(kLaThreads) heev_kernel(const double* a, int64
                                                           double* out_val, double* out_vec,
                                                           int32_t* status) {
   const int lane = threadIdx.x & 63;
+  // per-round lane bookkeeping of the Jacobi, once per workgroup (wave_la.hpp)
+  __shared__ uint32_t jtab[jacobi_table_dwords<D>()];
+  if (threadIdx.x < kWave) jacobi_table_build<D>(jtab, lane);
+  __syncthreads();
   const int64_t n = (int64_t)blockIdx.x * kLaWaves + (threadIdx.x >> 6);
   if (n >= N) return;  // wave-uniform
   const LaneIJ c = lane_ij(lane);
@@ -75,7 +79,7 @@ __global__ void __launch_bounds__(kLaThreads) heev_kernel(const double* a, int64
     are = p[0];
     aim = (c.i == c.j) ? 0.0 : ((c.i > c.j) ? p[1] : -p[1]);
   }
-  int sweeps = wave_jacobi_heev<D>(are, aim, c, vre, vim);
+  int sweeps = wave_jacobi_heev_tab<D>(are, aim, c, vre, vim, jtab, lane);
   double lam = lane_get(are, ij_lane(c.j, c.j));
   int rank = wave_sort_rank<D>(lam, c);
   if (c.i < D && c.j < D) {
@@ -95,6 +99,9 @@ __global__ void __launch_bounds__(kLaThreads) gev_kernel(const double* target,
                                                          const double* noise, int64_t N,
                                                          double* out_w, int32_t* status) {
   const int lane = threadIdx.x & 63;
+  __shared__ uint32_t jtab[jacobi_table_dwords<D>()];
+  if (threadIdx.x < kWave) jacobi_table_build<D>(jtab, lane);
+  __syncthreads();
   const int64_t n = (int64_t)blockIdx.x * kLaWaves + (threadIdx.x >> 6);
   if (n >= N) return;
   const LaneIJ c = lane_ij(lane);
@@ -128,7 +135,7 @@ __global__ void __launch_bounds__(kLaThreads) gev_kernel(const double* target,
   mre = 0.5 * (mre + mtre);
   mim = 0.5 * (mim + mtim);
   double vre, vim;
-  int sweeps = wave_jacobi_heev<D>(mre, mim, c, vre, vim);
+  int sweeps = wave_jacobi_heev_tab<D>(mre, mim, c, vre, vim, jtab, lane);
   if (sweeps < 0) st |= PBBSS_ST_EIG_NOCONV;
   double lam = lane_get(mre, ij_lane(c.j, c.j));
   int rank = wave_sort_rank<D>(lam, c);

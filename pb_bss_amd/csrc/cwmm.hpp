@@ -256,8 +256,8 @@ struct WatsonKernel {
   // converges in fewer sweeps; V = V' W.  Same eigenpairs to rounding; the eigenvector phase
   // is free and cancels in m m^H.  `warm` is false on the first iteration.
   static __device__ void factor_class(const WatsonArgs& wa, const Lds& L, const double* knot1,
-                                      int64_t b, int k, int lane, bool last, bool warm,
-                                      double& pvre, double& pvim) {
+                                      const uint32_t* jtab, int64_t b, int k, int lane,
+                                      bool last, bool warm, double& pvre, double& pvim) {
     lane = opaque(lane);
     const EmArgs& a = wa.em;
     const LaneIJ c = lane_ij(lane);
@@ -312,7 +312,7 @@ struct WatsonKernel {
 #if defined(PBBSS_CW_KNOCK) && PBBSS_CW_KNOCK == 9
       f1 = wall_clock64();
 #endif
-      sweeps = wave_jacobi_heev<D>(bre, bim, c, wre, wim);
+      sweeps = wave_jacobi_heev_tab<D>(bre, bim, c, wre, wim, jtab, lane);
 #if defined(PBBSS_CW_KNOCK) && PBBSS_CW_KNOCK == 9
       f2 = wall_clock64();
 #endif
@@ -320,7 +320,7 @@ struct WatsonKernel {
       are = bre;
       aim = bim;
     } else {
-      sweeps = wave_jacobi_heev<D>(are, aim, c, vre, vim);
+      sweeps = wave_jacobi_heev_tab<D>(are, aim, c, vre, vim, jtab, lane);
     }
     if (sweeps < 0) st |= PBBSS_ST_EIG_NOCONV;
     pvre = valid ? vre : 0.0;
@@ -379,7 +379,8 @@ struct WatsonKernel {
   }
 
   static __host__ __device__ size_t lds_bytes(int T) {
-    return Base::lds_bytes(T) + kWatsonKnotTable * sizeof(double);
+    return Base::lds_bytes(T) + kWatsonKnotTable * sizeof(double) +
+           jacobi_table_dwords<D>() * sizeof(uint32_t);
   }
 
   static __device__ void run(const WatsonArgs& wa, char* smem) {
@@ -390,6 +391,8 @@ struct WatsonKernel {
     const Lds L = Base::carve(
         smem, a.T, SPILL ? a.scratch + (size_t)blockIdx.x * a.scratch_stride : nullptr);
     double* knot1 = reinterpret_cast<double*>(smem + Base::lds_bytes(a.T));
+    uint32_t* jtab = reinterpret_cast<uint32_t*>(knot1 + kWatsonKnotTable);
+    if (wave == 0) jacobi_table_build<D>(jtab, lane);  // visible after the loop's first barrier
     if (tid < kWatsonKnotTable && wa.spline_t && wa.n_coef > 2) {  // predict carries no spline
       const int S = (wa.n_coef - 2 + kWatsonKnotTable - 1) / kWatsonKnotTable;
       knot1[tid] = wa.spline_t[min(2 + tid * S, wa.n_coef - 1)];
@@ -441,7 +444,7 @@ struct WatsonKernel {
         long long c2 = wall_clock64();
 #endif
         if (wave < K && !(ko && PBBSS_CW_KNOCK == 3))
-          factor_class(wa, L, knot1, b, wave, lane, last, it > 0, pvre, pvim);
+          factor_class(wa, L, knot1, jtab, b, wave, lane, last, it > 0, pvre, pvim);
 #if defined(PBBSS_CW_KNOCK) && PBBSS_CW_KNOCK == 9
         long long c3 = wall_clock64();
 #endif

@@ -292,6 +292,160 @@ __device__ __forceinline__ int wave_jacobi_heev(double& are, double& aim, LaneIJ
   return sweeps;
 }
 
+// ---------------------------------------------------------------------------
+// The same Jacobi with the per-round lane bookkeeping taken from a table.
+// A round of wave_jacobi_heev is bound by its instruction count, not by its cross-lane hops
+// (a one-batch variant with MORE instructions was slower), and about a quarter of
+// those instructions recompute what depends on (round, lane) alone: the tournament partners,
+// the pair's (p, q), the source lanes of the thirteen exchanges and their byte addresses.
+// jacobi_table_build writes them once per kernel -- per round and lane two dwords:
+//   w0 = byte addresses (lane * 4, as ds_bpermute takes them) of (p,p) | (q,q) | (p,q) |
+//        (partner row, j);   w1 = byte address of (i, partner column) | flags << 8
+//        (1: pair live, 2: this lane's row is the pair's p, 4: its column is the pair's p)
+// -- and wave_jacobi_heev_tab reads them back with one ds_read_b64 per round.  The arithmetic
+// is that of wave_jacobi_heev, statement by statement: identical results.
+// ---------------------------------------------------------------------------
+template <int D>
+constexpr int jacobi_table_dwords() {
+  return (D + (D & 1) - 1) * kWave * 2;
+}
+
+template <int D>
+__device__ __forceinline__ void jacobi_table_build(uint32_t* tab, int lane) {
+  constexpr int N = D + (D & 1);
+  const LaneIJ c = lane_ij(lane);
+  for (int r = 0; r < N - 1; ++r) {
+    auto partner = [&](int x) -> int {
+      if (x >= N) return x;
+      if (x == N - 1) return r;
+      if (x == r) return N - 1;
+      int y = 2 * r - x;
+      y %= (N - 1);
+      if (y < 0) y += N - 1;
+      return y;
+    };
+    const int pi_ = partner(c.i), pj = partner(c.j);
+    const int p = min(c.i, pi_), q = max(c.i, pi_);
+    const bool live = (q < D) && (p != q);
+    const int ps = live ? p : 0, qs = live ? q : 0;
+    const uint32_t w0 = (uint32_t)(4 * ij_lane(ps, ps)) | (uint32_t)(4 * ij_lane(qs, qs)) << 8 |
+                        (uint32_t)(4 * ij_lane(ps, qs)) << 16 |
+                        (uint32_t)(4 * ij_lane(pi_ < 8 ? pi_ : c.i, c.j)) << 24;
+    const uint32_t flags = (live ? 1u : 0u) | ((c.i < pi_) ? 2u : 0u) | ((c.j < pj) ? 4u : 0u);
+    const uint32_t w1 = (uint32_t)(4 * ij_lane(c.i, pj < 8 ? pj : c.j)) | flags << 8;
+    tab[(r * kWave + lane) * 2] = w0;
+    tab[(r * kWave + lane) * 2 + 1] = w1;
+  }
+}
+
+// value of lane (byte_addr / 4)
+__device__ __forceinline__ double lane_get_addr(double v, int byte_addr) {
+  F64Bits u;
+  u.d = v;
+  u.i[0] = __builtin_amdgcn_ds_bpermute(byte_addr, u.i[0]);
+  u.i[1] = __builtin_amdgcn_ds_bpermute(byte_addr, u.i[1]);
+  return u.d;
+}
+
+template <int D>
+__device__ __forceinline__ int wave_jacobi_heev_tab(double& are, double& aim, LaneIJ c,
+                                                    double& vre, double& vim, const uint32_t* tab,
+                                                    int lane) {
+  constexpr int N = D + (D & 1);
+  const bool valid = (c.i < D) && (c.j < D);
+  if (!valid) {
+    are = 0.0;
+    aim = 0.0;
+  }
+  if (c.i == c.j) aim = 0.0;
+  vre = (c.i == c.j) ? 1.0 : 0.0;
+  vim = 0.0;
+  const double fro2 = wave_sum(are * are + aim * aim);
+  if (!(fro2 > 0.0)) return 0;
+  const int jj = 4 * ij_lane(c.j, c.j);
+  const uint2* tb = reinterpret_cast<const uint2*>(tab) + lane;
+  int sweeps = -1;
+  for (int sweep = 0; sweep < kJacobiMaxSweeps; ++sweep) {
+    double off2 = wave_sum((c.i != c.j) ? (are * are + aim * aim) : 0.0);
+    if (off2 <= kJacobiTol * fro2) {
+      sweeps = sweep;
+      break;
+    }
+#pragma unroll 1
+    for (int r = 0; r < N - 1; ++r) {
+      const uint2 e = tb[r * kWave];
+      const int a_pp = e.x & 0xff, a_qq = (e.x >> 8) & 0xff, a_pq = (e.x >> 16) & 0xff;
+      const int a_row = e.x >> 24, a_col = e.y & 0xff;
+      const bool live = (e.y & 0x100) != 0, row_is_p = (e.y & 0x200) != 0;
+      const bool col_is_p = (e.y & 0x400) != 0;
+      double app = lane_get_addr(are, a_pp);
+      double aqq = lane_get_addr(are, a_qq);
+      double xr = lane_get_addr(are, a_pq);
+      double xi = lane_get_addr(aim, a_pq);
+      double g2 = xr * xr + xi * xi;
+      double cs = 1.0, sur = 0.0, sui = 0.0;  // c, s*u (u = a_pq/|a_pq|)
+      if (live && g2 > 0.0) {
+        const double d = aqq - app;
+        const double h2 = fma(d, d, 4.0 * g2);
+        if (h2 > 0.0 && h2 < 1.79e308) {
+          const double rh = fast_rsqrt(h2);
+          const double c2 = fma(0.5 * fabs(d), rh, 0.5);
+          const double rc = fast_rsqrt(c2);  // c2 in [0.5, 1]
+          cs = c2 * rc;
+          const double ig = ((d < 0.0) ? -rh : rh) * rc;
+          sur = xr * ig;
+          sui = xi * ig;
+        }
+      }
+      double cc = lane_get_addr(cs, jj);
+      double cur = lane_get_addr(sur, jj);
+      double cui = lane_get_addr(sui, jj);
+      {
+        double orr = lane_get_addr(are, a_row);
+        double oii = lane_get_addr(aim, a_row);
+        double nr, ni;
+        if (row_is_p) {
+          nr = cs * are - (sur * orr - sui * oii);
+          ni = cs * aim - (sur * oii + sui * orr);
+        } else {
+          nr = cs * are + (sur * orr + sui * oii);
+          ni = cs * aim + (sur * oii - sui * orr);
+        }
+        are = nr;
+        aim = ni;
+      }
+      {
+        double orr = lane_get_addr(are, a_col);
+        double oii = lane_get_addr(aim, a_col);
+        double vor = lane_get_addr(vre, a_col);
+        double voi = lane_get_addr(vim, a_col);
+        double nr, ni, wr, wi;
+        if (col_is_p) {
+          nr = cc * are - (cur * orr + cui * oii);
+          ni = cc * aim - (cur * oii - cui * orr);
+          wr = cc * vre - (cur * vor + cui * voi);
+          wi = cc * vim - (cur * voi - cui * vor);
+        } else {
+          nr = cc * are + (cur * orr - cui * oii);
+          ni = cc * aim + (cur * oii + cui * orr);
+          wr = cc * vre + (cur * vor - cui * voi);
+          wi = cc * vim + (cur * voi + cui * vor);
+        }
+        are = nr;
+        aim = ni;
+        vre = wr;
+        vim = wi;
+      }
+      if (c.i == c.j) aim = 0.0;
+    }
+  }
+  if (sweeps < 0) {
+    double off2 = wave_sum((c.i != c.j) ? (are * are + aim * aim) : 0.0);
+    if (off2 <= kJacobiTolLoose * fro2) sweeps = kJacobiMaxSweeps;
+  }
+  return sweeps;
+}
+
 // rank of eigenvalue j among the D eigenvalues (ascending, ties by index):
 // column j of V belongs at sorted position rank.  lam = value on lane (j,j)
 // already broadcast down the column (every lane holds lambda of ITS column j).
