@@ -1154,24 +1154,27 @@ static int embed_mixture_fit(pbbss_handle_t h, int kind, const void* y, int64_t 
   hipStream_t s = as_stream(stream);
   const size_t nyz = (size_t)B * N * E;
   const size_t np = pbbss::embed_partial_doubles(B, N, E, K, nullptr);
-  const size_t need = 2 * WorkCarver::pad(nyz * 8) + WorkCarver::pad((size_t)B * K * N * 8) +
-                      WorkCarver::pad(np * 8) + 2 * WorkCarver::pad((size_t)B * K * 8);
+  const size_t need = WorkCarver::pad(nyz * 8) + WorkCarver::pad((size_t)B * N * 8) +
+                      WorkCarver::pad((size_t)B * K * N * 8) + WorkCarver::pad(np * 8) +
+                      2 * WorkCarver::pad((size_t)B * K * 8);
   void* w = handle_work(h, need);
   if (!w) return PBBSS_ERR_HIP;
   WorkCarver wc(w);
-  double* yd = wc.take<double>(nyz);  // (B,E,N): float64 unit rows (vMF) / input type (Gauss)
-  double* yr = wc.take<double>(nyz);  // (B,N,E) float64 unit rows (vMF only)
+  double* yd = wc.take<double>(nyz);  // (B,E,N) transposed copy in the INPUT type
+  double* rowscale = wc.take<double>((size_t)B * N);  // vMF: 1 / |y_n| (vmfmm.py:76-78)
   double* aff = wc.take<double>((size_t)B * K * N);
   double* part = wc.take<double>(np);
   double* offset = wc.take<double>((size_t)B * K);
   double* prec = wc.take<double>((size_t)B * K);
-  // the E-step reads the transposed copy, the M-step the row-major one: the normalised float64
-  // pair for the vMF mixture, the caller's array (and type) for the Gaussian one
-  const int e_f64 = vmf ? 1 : o->embedding_is_f64;
-  const void* fit_y = vmf ? static_cast<const void*>(yr) : y;
+  // The E-step reads the transposed copy, the M-step the caller's row-major array, both in the
+  // caller's type.  The vMF mixture works on unit rows: the E-step normalises its dot products
+  // itself, the M-step takes 1 / |y_n| from `rowscale` -- round 1 kept two normalised float64
+  // copies instead and streamed 2 x 82 MB per iteration where a float32 embedding has 2 x 41.
+  const int e_f64 = o->embedding_is_f64;
+  const void* fit_y = y;
   TimedRegion tr(h, s);
-  int rc = pbbss::launch_embed_prepare(y, o->embedding_is_f64, B, N, E, vmf ? 1 : 0, yd,
-                                       vmf ? yr : nullptr, s);
+  int rc = pbbss::launch_embed_prepare(y, o->embedding_is_f64, B, N, E, 0, yd, nullptr, s,
+                                       vmf ? rowscale : nullptr);
   if (rc != PBBSS_OK) return rc;
   if (has_model) {
     if ((rc = copy_d2d(out_mean, in_mean, (size_t)B * K * E * 8, s)) != PBBSS_OK) return rc;
@@ -1188,7 +1191,8 @@ static int embed_mixture_fit(pbbss_handle_t h, int kind, const void* y, int64_t 
     }
     rc = pbbss::launch_embed_fit(kind, fit_y, e_f64, B, N, E, K, src, N, saliency,
                                  o->min_concentration, o->max_concentration, o->weight_mode, part,
-                                 out_mean, out_scale, out_weight, offset, prec, 0, s);
+                                 out_mean, out_scale, out_weight, offset, prec, 0, s,
+                                 vmf ? rowscale : nullptr);
     if (rc != PBBSS_OK) return rc;
     if (fixed_scale) {  // gmm.py:160-167
       if ((rc = copy_d2d(out_scale, fixed_scale, (size_t)B * K * 8, s)) != PBBSS_OK) return rc;

@@ -33,9 +33,12 @@ __device__ __forceinline__ size_t aff_index(int64_t b, int k, int64_t n, int K, 
 // ---------------------------------------------------------------- prepare
 // One workgroup: R rows of one mixture staged in LDS (row stride E+1), optional
 // unit-norm scaling, written out transposed (and row-major when normalising).
+// NORMALIZE = false with `rowscale`: the copy stays raw and 1 / max(|y_n|, tiny) goes to
+// rowscale[b][n] -- the vMF mixture applies it on the fly instead of reading float64 copies.
 template <typename TS, bool NORMALIZE>
 __global__ void __launch_bounds__(kThreads) embed_prepare_kernel(const TS* y, int64_t N, int E,
-                                                                 int R, void* yd_, double* yr) {
+                                                                 int R, void* yd_, double* yr,
+                                                                 double* rowscale) {
   using OUT = typename std::conditional<NORMALIZE, double, TS>::type;
   extern __shared__ double sm[];
   double* tile = sm;                // [R][E+1]
@@ -62,6 +65,11 @@ __global__ void __launch_bounds__(kThreads) embed_prepare_kernel(const TS* y, in
       int r = i / E, d = i - r * E;
       dst[i] = tile[r * (E + 1) + d] * scale[r];
     }
+  }
+  if (!NORMALIZE && rowscale && tid < rows) {
+    double n2 = 0.0;
+    for (int d = 0; d < E; ++d) n2 = fma(tile[tid * (E + 1) + d], tile[tid * (E + 1) + d], n2);
+    rowscale[(size_t)b * N + n0 + tid] = 1.0 / fmax(sqrt(n2), kTiny);  // vmfmm.py:76-78
   }
   OUT* yd = static_cast<OUT*>(yd_) + (size_t)b * E * N + n0;
   for (int i = tid; i < rows * E; i += kThreads) {
@@ -219,7 +227,7 @@ template <int K, typename TS, int PASS>
 __global__ void __launch_bounds__(kFitThreads)
     embed_fit_kernel(const TS* yr, int64_t N, int E, int S, int C, int64_t L, const double* aff,
                      int64_t Tin, const double* sal, const double* mean, double* part,
-                     double* part2, int shift_first_row) {
+                     double* part2, int shift_first_row, const double* rowscale) {
   extern __shared__ double sm[];
   double* red = sm;               // [S][K][E]
   double* red0 = sm + S * K * E;  // [S][K]
@@ -251,16 +259,28 @@ __global__ void __launch_bounds__(kFitThreads)
   double* wst = red2 + (size_t)S * K * E;  // [U * S][K]
   const TS* base = yr + (size_t)b * N * E;
   const int SU = U * S;
+  // rowscale (vMF mixture): the rows are used as y_n * rowscale[n] (unit norm, vmfmm.py:76-78)
+  // without a normalised copy of the embedding -- the scale rides on the staged weights of the
+  // first moments; the weight sums S0 need the plain weights and are collected by the staging
+  // loop itself (a conditional second read inside the accumulation loop cost 6x the kernel)
+  double s0acc[K];  // rowscale: this thread's share of S0[k], collected while staging
+#pragma unroll
+  for (int k = 0; k < K; ++k) s0acc[k] = 0.0;
   for (int64_t nb = n0; nb < n1; nb += SU) {
     for (int i = tid; i < SU * K; i += kFitThreads) {
       const int k = i / SU, smp = i - k * SU;  // consecutive lanes = consecutive samples
       const int64_t nn = nb + smp;
-      double wv = 0.0;
+      double wv = 0.0, sc = 1.0;
       if (nn < n1) {
         wv = aff[aff_index(b, k, nn, K, N, Tin)];
         if (sal) wv *= sal[(size_t)b * N + nn];
+        if (rowscale) sc = rowscale[(size_t)b * N + nn];
       }
-      wst[smp * K + k] = wv;
+      wst[smp * K + k] = wv * sc;
+      if (rowscale) {
+#pragma unroll
+        for (int kk = 0; kk < K; ++kk) s0acc[kk] += (kk == k) ? wv : 0.0;
+      }
     }
     __syncthreads();
     if (active) {
@@ -278,7 +298,7 @@ __global__ void __launch_bounds__(kFitThreads)
           const double wk = wst[(s + u * S) * K + k];
           if (PASS == 0 || PASS == 2) {
             acc[k] = fma(wk, (double)yv[u], acc[k]);
-            acc0[k] += wk;
+            acc0[k] += wk;  // (with rowscale: scaled, unused -- S0 comes from the staging loop)
           }
           if (PASS == 1) {
             const double df = (double)yv[u] - mu[k];
@@ -314,7 +334,20 @@ __global__ void __launch_bounds__(kFitThreads)
       part2[((size_t)b * C + c) * K * (E + 1) + k * (E + 1) + dd] = t2;
     }
   }
-  if (PASS != 1 && tid < K) {
+  if (rowscale) {  // S0 from the plain weights: wave sums, then the 16 waves in order
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const double t = wave_sum(s0acc[k]);
+      if ((tid & (kWave - 1)) == 0) wst[(tid / kWave) * K + k] = t;
+    }
+    __syncthreads();
+    if (tid < K) {
+      double t = 0.0;
+      for (int w = 0; w < kFitThreads / kWave; ++w) t += wst[w * K + tid];
+      dst[tid * (E + 1) + E] = t;
+    }
+  } else if (PASS != 1 && tid < K) {
     double t = 0.0;
     for (int ss = 0; ss < S; ++ss) t += red0[ss * K + tid];
     dst[tid * (E + 1) + E] = t;
@@ -647,7 +680,7 @@ size_t embed_partial_doubles(int64_t B, int64_t N, int E, int K, int* chunks_out
 }
 
 int launch_embed_prepare(const void* y, int y_is_f64, int64_t B, int64_t N, int E, int normalize,
-                         void* yd, double* yr, hipStream_t s) {
+                         void* yd, double* yr, hipStream_t s, double* rowscale) {
   if (E < 1 || E > kEmbedMaxE || B > 65535) return PBBSS_ERR_UNSUPPORTED;
   int R = 4096 / (E + 1);
   if (R > 64) R = 64;
@@ -657,17 +690,17 @@ int launch_embed_prepare(const void* y, int y_is_f64, int64_t B, int64_t N, int 
   if (normalize) {
     if (y_is_f64)
       hipLaunchKernelGGL((embed_prepare_kernel<double, true>), grid, dim3(kThreads), lds, s,
-                         static_cast<const double*>(y), N, E, R, yd, yr);
+                         static_cast<const double*>(y), N, E, R, yd, yr, rowscale);
     else
       hipLaunchKernelGGL((embed_prepare_kernel<float, true>), grid, dim3(kThreads), lds, s,
-                         static_cast<const float*>(y), N, E, R, yd, yr);
+                         static_cast<const float*>(y), N, E, R, yd, yr, rowscale);
   } else {
     if (y_is_f64)
       hipLaunchKernelGGL((embed_prepare_kernel<double, false>), grid, dim3(kThreads), lds, s,
-                         static_cast<const double*>(y), N, E, R, yd, yr);
+                         static_cast<const double*>(y), N, E, R, yd, yr, rowscale);
     else
       hipLaunchKernelGGL((embed_prepare_kernel<float, false>), grid, dim3(kThreads), lds, s,
-                         static_cast<const float*>(y), N, E, R, yd, yr);
+                         static_cast<const float*>(y), N, E, R, yd, yr, rowscale);
   }
   return ok_or_hip();
 }
@@ -797,7 +830,7 @@ template <int K, typename TS>
 int fit_go(int kind, const void* yr, int64_t B, int64_t N, int E, const double* aff, int64_t Tin,
            const double* sal, double cmin, double cmax, int weight_mode, double* part,
            double* out_mean, double* out_scale, double* out_weight, double* out_offset,
-           double* out_prec, int single_pass, hipStream_t s) {
+           double* out_prec, int single_pass, const double* rowscale, hipStream_t s) {
   int C = 0;
   const size_t np = embed_partial_doubles(B, N, E, K, &C);
   double* den_buf = part + np - (size_t)B * K;
@@ -814,7 +847,7 @@ int fit_go(int kind, const void* yr, int64_t B, int64_t N, int E, const double* 
     const int first = single_pass == 2;
     hipLaunchKernelGGL((embed_fit_kernel<K, TS, 2>), grid, dim3(kFitThreads), lds_fit, s,
                        static_cast<const TS*>(yr), N, E, S, C, L, aff, Tin, sal, out_mean, part,
-                       part2, first);
+                       part2, first, (const double*)nullptr);
     hipLaunchKernelGGL(embed_finalize_single_kernel, dim3((unsigned)B), dim3(kFinThreads),
                        (2 * Wv + (2 * Wv < (size_t)kFinThreads ? (size_t)kFinThreads : 0)) * sizeof(double),
                        s, part, part2, C, E, K, yr,
@@ -824,7 +857,7 @@ int fit_go(int kind, const void* yr, int64_t B, int64_t N, int E, const double* 
   }
   hipLaunchKernelGGL((embed_fit_kernel<K, TS, 0>), grid, dim3(kFitThreads), lds_fit, s,
                      static_cast<const TS*>(yr), N, E, S, C, L, aff, Tin, sal,
-                     (const double*)nullptr, part, (double*)nullptr, 0);
+                     (const double*)nullptr, part, (double*)nullptr, 0, rowscale);
   if (kind == PBBSS_EMBED_VMF) {
     hipLaunchKernelGGL((embed_finalize_kernel<PBBSS_EMBED_VMF, 0>), dim3((unsigned)B),
                        dim3(kFinThreads), lds_fin, s, part, C, E, K, cmin, cmax, weight_mode,
@@ -836,7 +869,7 @@ int fit_go(int kind, const void* yr, int64_t B, int64_t N, int E, const double* 
                      out_mean, out_scale, out_weight, (double*)nullptr, (double*)nullptr);
   hipLaunchKernelGGL((embed_fit_kernel<K, TS, 1>), grid, dim3(kFitThreads), lds_fit, s,
                      static_cast<const TS*>(yr), N, E, S, C, L, aff, Tin, sal, out_mean, part,
-                     (double*)nullptr, 0);
+                     (double*)nullptr, 0, (const double*)nullptr);
   if (kind == PBBSS_EMBED_GAUSS_DIAG) {
     hipLaunchKernelGGL((embed_finalize_kernel<PBBSS_EMBED_GAUSS_DIAG, 1>), dim3((unsigned)B),
                        dim3(kFinThreads), lds_fin, s, part, C, E, K, cmin, cmax, -1, den_buf,
@@ -853,9 +886,9 @@ template <typename TS>
 int fit_k(int K, int kind, const void* yr, int64_t B, int64_t N, int E, const double* aff,
           int64_t Tin, const double* sal, double cmin, double cmax, int weight_mode, double* part,
           double* out_mean, double* out_scale, double* out_weight, double* out_offset,
-          double* out_prec, int single_pass, hipStream_t s) {
+          double* out_prec, int single_pass, const double* rowscale, hipStream_t s) {
 #define PBBSS_FIT_CASE(KK) \
-  case KK: return fit_go<KK, TS>(kind, yr, B, N, E, aff, Tin, sal, cmin, cmax, weight_mode, part, out_mean, out_scale, out_weight, out_offset, out_prec, single_pass, s);
+  case KK: return fit_go<KK, TS>(kind, yr, B, N, E, aff, Tin, sal, cmin, cmax, weight_mode, part, out_mean, out_scale, out_weight, out_offset, out_prec, single_pass, rowscale, s);
   switch (K) {
     PBBSS_FIT_CASE(1) PBBSS_FIT_CASE(2) PBBSS_FIT_CASE(3)
     PBBSS_FIT_CASE(4) PBBSS_FIT_CASE(5) PBBSS_FIT_CASE(6)
@@ -891,17 +924,18 @@ int launch_embed_fit(int kind, const void* yr, int y_is_f64, int64_t B, int64_t 
                      const double* aff, int64_t Tin, const double* sal, double cmin, double cmax,
                      int weight_mode, double* part, double* out_mean, double* out_scale,
                      double* out_weight, double* out_offset, double* out_prec, int single_pass,
-                     hipStream_t s) {
+                     hipStream_t s, const double* rowscale) {
   if (E < 1 || E > kEmbedMaxE || B > 65535) return PBBSS_ERR_UNSUPPORTED;
   if (kind != PBBSS_EMBED_VMF && kind != PBBSS_EMBED_GAUSS_SPHERICAL && kind != PBBSS_EMBED_GAUSS_DIAG)
     return PBBSS_ERR_UNSUPPORTED;
+  if (rowscale && kind != PBBSS_EMBED_VMF) return PBBSS_ERR_INVALID_ARG;
   if (kind == PBBSS_EMBED_GAUSS_DIAG) single_pass = 0;  // two sweeps, as the reference
   return y_is_f64 ? fit_k<double>(K, kind, yr, B, N, E, aff, Tin, sal, cmin, cmax, weight_mode,
                                   part, out_mean, out_scale, out_weight, out_offset, out_prec,
-                                  single_pass, s)
+                                  single_pass, rowscale, s)
                   : fit_k<float>(K, kind, yr, B, N, E, aff, Tin, sal, cmin, cmax, weight_mode,
                                  part, out_mean, out_scale, out_weight, out_offset, out_prec,
-                                 single_pass, s);
+                                 single_pass, rowscale, s);
 }
 
 int launch_joint_weight(int mode, const double* aff, const double* sal, int64_t F, int K, int T,

@@ -16,8 +16,10 @@ size_t embed_partial_doubles(int64_t B, int64_t N, int E, int K, int* chunks_out
 
 // y (B,N,E) row-major -> yd (B,E,N); NORMALIZE: rows scaled to unit norm
 // (von_mises_fisher.py:105-107) and ALSO written row-major to yr (float64).
+// normalize = 0 with `rowscale` (B,N): raw copy plus 1 / max(|y_n|, tiny) per row, for callers
+// that apply the unit-norm scaling on the fly (the vMF mixture loop).
 int launch_embed_prepare(const void* y, int y_is_f64, int64_t B, int64_t N, int E, int normalize,
-                         void* yd, double* yr, hipStream_t s);
+                         void* yd, double* yr, hipStream_t s, double* rowscale = nullptr);
 
 // offset_k of the class log-pdfs: vMF  -log_norm(kappa)        (von_mises_fisher.py:33-44)
 //                                 Gauss -E/2 ln 2pi + E ln(1/sqrt(cov)) (gaussian.py:108-137)
@@ -49,7 +51,8 @@ int launch_embed_fit(int kind, const void* yr, int y_is_f64, int64_t B, int64_t 
                      const double* aff, int64_t Tin, const double* sal, double cmin, double cmax,
                      int weight_mode, double* part, double* out_mean, double* out_scale,
                      double* out_weight, double* out_offset, double* out_prec, int single_pass,
-                     hipStream_t s);
+                     hipStream_t s, const double* rowscale = nullptr);  // rowscale: vMF only, rows
+                                                                       // are used as y_n * rowscale[n]
 
 // masked affiliation sums of the joint models (gcacgmm.py:286-295): aff (F,K,T), sal (F,T)
 //   mode 0 'fk' (-1,): w[f,k] = sum_t / sum_k sum_t          -> (F,K)
