@@ -359,6 +359,8 @@ __global__ void __launch_bounds__(kFitThreads)
 // (slot = chunk index mod nslot, then over slots), then the model and -- so that the
 // next E-step needs no separate launch -- the log-pdf offsets / precisions.
 constexpr int kFinThreads = 1024;
+constexpr int kFinLoads = 32;  // chunk partials in flight per thread (power of two): the partials were
+                               // written by other XCDs, every dependent round is a ~2 us trip to the memory side
 
 __device__ __forceinline__ double vmf_offset(int E, double conc, int lane) {
   // -log_norm = -(E/2 ln 2pi + ln ive(nu, k) + (|k| - nu ln k)) = -(E/2 ln 2pi + ln(I_nu(k)/k^nu))
@@ -390,20 +392,26 @@ __global__ void __launch_bounds__(kFinThreads)
     const int slot = tid / W;
     const int i = tid - slot * W;
     if (slot < nslot) {
-      double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
-      int c = slot;
-      for (; c + 3 * nslot < C; c += 4 * nslot) {
-        double a0 = pb[(size_t)c * W + i];
-        double a1 = pb[(size_t)(c + nslot) * W + i];
-        double a2 = pb[(size_t)(c + 2 * nslot) * W + i];
-        double a3 = pb[(size_t)(c + 3 * nslot) * W + i];
-        t0 += a0;
-        t1 += a1;
-        t2 += a2;
-        t3 += a3;
+      // kFinLoads partials in flight per thread: the kernel is ONE workgroup walking C partials
+      // through dependent L2 round trips (four in flight: 8 rounds = 10 us of a 39 us iteration)
+      double t[kFinLoads];
+#pragma unroll
+      for (int u = 0; u < kFinLoads; ++u) t[u] = 0.0;
+      for (int c = slot; c < C; c += kFinLoads * nslot) {
+        double a[kFinLoads];
+#pragma unroll
+        for (int u = 0; u < kFinLoads; ++u) {
+          const int cc = c + u * nslot;
+          a[u] = pb[(size_t)(cc < C ? cc : slot) * W + i];  // clamped, masked below
+        }
+#pragma unroll
+        for (int u = 0; u < kFinLoads; ++u) t[u] += (c + u * nslot < C) ? a[u] : 0.0;
       }
-      for (; c < C; c += nslot) t0 += pb[(size_t)c * W + i];
-      red[slot * W + i] = (t0 + t1) + (t2 + t3);
+#pragma unroll
+      for (int w = kFinLoads / 2; w >= 1; w /= 2)
+#pragma unroll
+        for (int u = 0; u < w; ++u) t[u] += t[u + w];
+      red[slot * W + i] = t[0];
     }
     __syncthreads();
     for (int j = tid; j < W; j += kFinThreads) {
@@ -505,17 +513,24 @@ __global__ void __launch_bounds__(kFinThreads)
     const int i = tid - slot * 2 * W;
     if (slot < nslot) {
       const double* p = (i < W ? part : part2) + (size_t)b * C * W + (i < W ? i : i - W);
-      double t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      int c = slot;
-      for (; c + 7 * nslot < C; c += 8 * nslot) {
-        double a[8];
+      double t[kFinLoads];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) a[u] = p[(size_t)(c + u * nslot) * W];
+      for (int u = 0; u < kFinLoads; ++u) t[u] = 0.0;
+      for (int c = slot; c < C; c += kFinLoads * nslot) {
+        double a[kFinLoads];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) t[u] += a[u];
+        for (int u = 0; u < kFinLoads; ++u) {
+          const int cc = c + u * nslot;
+          a[u] = p[(size_t)(cc < C ? cc : slot) * W];
+        }
+#pragma unroll
+        for (int u = 0; u < kFinLoads; ++u) t[u] += (c + u * nslot < C) ? a[u] : 0.0;
       }
-      for (; c < C; c += nslot) t[0] += p[(size_t)c * W];
-      red[slot * 2 * W + i] = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+#pragma unroll
+      for (int w = kFinLoads / 2; w >= 1; w /= 2)
+#pragma unroll
+        for (int u = 0; u < w; ++u) t[u] += t[u + w];
+      red[slot * 2 * W + i] = t[0];
     }
     __syncthreads();
     for (int j = tid; j < 2 * W; j += kFinThreads) {
