@@ -397,12 +397,15 @@ def test_gmm_full_covariance_matches_reference_and_oracle():
         GMMTrainer().fit(yb[0, :50], initialization=bad, iterations=2)
 
 
-@pytest.mark.parametrize('kind', ['gaussian', 'vmf'])
-def test_joint_remainder_bins_as_member_workgroups(kind):
+@pytest.mark.parametrize('kind,kw', [('gaussian', {}), ('vmf', {}),
+                                     ('gaussian', dict(weight_constant_axis=(-3,))),
+                                     ('vmf', dict(weight_constant_axis=(-3, -1)))])
+def test_joint_remainder_bins_as_member_workgroups(kind, kw):
     """B = CUs + r bins: the r remainder bins of every one-iteration joint launch run as member
     workgroups on frame windows (run_joint_member: partial sums through L2, the last arriver
     factors).  Same masks and model as the plain launch (split handling off) and as the oracle;
-    258 bins = 256 CUs + 2 on an MI355X, 300 frames = four full windows and one of 44."""
+    258 bins = 256 CUs + 2 on an MI355X, 300 frames = four full windows and one of 44; per-class
+    weights per bin, per frame (shared over the bins) and per utterance."""
     from pb_bss_amd import engine
     from pb_bss_amd.distribution import GCACGMMTrainer, VMFCACGMMTrainer
     from oracle import embed as oe, synth
@@ -414,7 +417,7 @@ def test_joint_remainder_bins_as_member_workgroups(kind):
     try:
         for split in (True, False):
             engine.set_split_tail(split)
-            model = trainer.fit(Y, e, initialization=init, iterations=5, saliency=sal)
+            model = trainer.fit(Y, e, initialization=init, iterations=5, saliency=sal, **kw)
             out[split] = (model, model.predict(Y, e))
     finally:
         engine.set_split_tail(True)
@@ -423,7 +426,8 @@ def test_joint_remainder_bins_as_member_workgroups(kind):
     np.testing.assert_allclose(on[0].cacg.covariance_eigenvalues, off[0].cacg.covariance_eigenvalues,
                                rtol=1e-9, atol=1e-12)
     np.testing.assert_allclose(on[0].weight, off[0].weight, atol=1e-12)
-    ref = oe.joint_fit(kind, Y.astype(np.complex128), e.astype(np.float64), init, 5, saliency=sal)
+    ref = oe.joint_fit(kind, Y.astype(np.complex128), e.astype(np.float64), init, 5, saliency=sal,
+                       **kw)
     want = oe.joint_model_predict(ref, Y.astype(np.complex128), e.astype(np.float64))
     assert np.abs(on[1] - want).max() < 1e-6
     assert np.abs(on[1][-2:] - want[-2:]).max() < 1e-6   # the two member-handled bins
