@@ -1,5 +1,6 @@
 // Joint spatial+spectral E/M step of the cACG half (gcacgmm.py / vmfcacgmm.py), one
 // translation unit per sensor count D (-DPBBSS_EM_D=<D>) like em_inst.hip.
+#include <cstdlib>
 #include "cacgmm_em.hpp"
 #include "em_launch.hpp"
 
@@ -13,7 +14,13 @@ template <int K, typename YS>
 static int launch_joint(const EmArgs& a, const JointExtras& jx, int inline_pa,
                         const EmLaunchCfg& cfg, hipStream_t stream) {
   using Kern = EmKernel<PBBSS_EM_D, K, YS, false>;
-  const size_t lds = Kern::lds_bytes(a.T) + 64;  // + class permutation of the inline PA
+  size_t lds = Kern::lds_bytes(a.T) + 64;  // + class permutation of the inline PA
+  // development knob: request at least this much LDS (e.g. 56000 pins two workgroups per CU)
+  static const size_t lds_pad = [] {
+    const char* v = getenv("PBBSS_JOINT_LDS_PAD");
+    return v ? (size_t)atol(v) : (size_t)0;
+  }();
+  if (lds < lds_pad) lds = lds_pad;
   if (lds > cfg.lds_limit) return PBBSS_ERR_LDS_CAPACITY;
   auto kfn = cacgmm_joint_kernel<PBBSS_EM_D, K, YS>;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
