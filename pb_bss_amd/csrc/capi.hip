@@ -213,6 +213,10 @@ PBBSS_API int pbbss_create(pbbss_handle_t* out, int device_id) {
     // arrival counters / error words start at zero (the joint launch's members reset their
     // counter themselves; the EM split launch clears its own before every launch)
     if (hipMemset(xb, 0, 256) != hipSuccess) {
+      (void)hipFree(xb);
+      (void)hipStreamDestroy(h->cfg.side_stream);
+      (void)hipEventDestroy(h->cfg.ev_fork);
+      (void)hipEventDestroy(h->cfg.ev_join);
       delete h;
       return PBBSS_ERR_HIP;
     }
