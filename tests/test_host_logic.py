@@ -229,3 +229,31 @@ def test_result_dtype_switch_and_rounding_helpers():
     assert to_single(np.ones(2, np.complex128)).dtype == np.complex64
     import torch
     assert to_single(torch.ones(2, dtype=torch.complex128)).dtype == torch.complex64
+
+
+def test_reference_dtype_rounding_of_a_fitted_model():
+    """CACGMMTrainer._rounded (result dtype 'reference'): float32 / complex64 fields, the constant
+    1/K weight of weight_constant_axis=-2 stays float64, the affiliation of the (model,
+    affiliation) form is rounded too; `single=False` passes everything through."""
+    from pb_bss_amd import _lib
+    from pb_bss_amd.distribution import CACGMM, CACGMMTrainer
+    from pb_bss_amd.distribution.complex_angular_central_gaussian import (
+        ComplexAngularCentralGaussian)
+    F, K, D, T = 2, 3, 4, 5
+    rng = np.random.default_rng(0)
+    model = CACGMM(
+        weight=np.full((F, K, 1), 1 / K),
+        cacg=ComplexAngularCentralGaussian(
+            covariance_eigenvectors=rng.normal(size=(F, K, D, D)) + 1j * rng.normal(size=(F, K, D, D)),
+            covariance_eigenvalues=rng.uniform(size=(F, K, D))))
+    aff = rng.uniform(size=(F, K, T))
+    assert CACGMMTrainer._rounded(model, False, _lib.WEIGHT_UNIFORM) is model
+    m = CACGMMTrainer._rounded(model, True, None)
+    assert (m.weight.dtype, m.cacg.covariance_eigenvectors.dtype,
+            m.cacg.covariance_eigenvalues.dtype) == (np.float32, np.complex64, np.float32)
+    np.testing.assert_allclose(m.cacg.covariance_eigenvalues, model.cacg.covariance_eigenvalues,
+                               rtol=1e-6)
+    m, a = CACGMMTrainer._rounded((model, aff), True, _lib.WEIGHT_UNIFORM)
+    assert m.weight.dtype == np.float64 and a.dtype == np.float32
+    assert m.cacg.covariance_eigenvectors.dtype == np.complex64
+    assert model.weight.dtype == np.float64                 # the input model is left alone
