@@ -477,6 +477,12 @@ typedef struct pbbss_mix_opts {
   double min_concentration, max_concentration;
   double affiliation_eps, eigenvalue_floor;
   double spatial_weight, spectral_weight;
+  int32_t sharded;          /* pbbss_joint_fit: the call holds ONE RANK'S block of the frequency  */
+                            /* bins; the spectral M-step sums (gaussian.py:152-193,  */
+                            /* von_mises_fisher.py:122-144) and bin-constant class weights are   */
+                            /* all-reduced over the communicator of pbbss_comm_create, in stream */
+                            /* order.  Not for PBBSS_EMBED_GAUSS_FULL.                           */
+  int32_t reserved;
 } pbbss_mix_opts;
 
 /* GMMTrainer.fit / fit_predict, GMM.predict (distribution/gmm.py:17-171) with               */
@@ -640,11 +646,18 @@ int pbbss_istft(pbbss_handle_t h, const void* X, int x_is_c128, int64_t C, int T
 /* `stream`: pad to the largest block, one ncclAllGather, trim.                 */
 /* pbbss_allgather_unpack: the trimming half on its own (gathered = (world,     */
 /* outer, ceil(total_bins / world), inner)) for hosts that bring their own      */
-/* collective.                                                                 */
+/* collective.  The pack / gather buffers belong to the communicator (released  */
+/* by pbbss_comm_destroy); collectives of one handle must be enqueued in the     */
+/* same order on every rank (RCCL's rule), i.e. from one host thread per handle. */
+/* pbbss_comm_info: world size and rank as RCCL itself reports them              */
+/* (ncclCommCount / ncclCommUserRank) -- for logs that prove how many GPUs took  */
+/* part.  The same communicator carries the all-reduce of sharded joint fits     */
+/* (pbbss_mix_opts.sharded).                                                     */
 /* ------------------------------------------------------------------------- */
 int pbbss_comm_unique_id(void* out_id_128_bytes);
 int pbbss_comm_create(pbbss_handle_t h, const void* unique_id, int world_size, int rank);
 int pbbss_comm_destroy(pbbss_handle_t h);
+int pbbss_comm_info(pbbss_handle_t h, int* out_world_size, int* out_rank);
 int pbbss_shard_bounds(int64_t total_bins, int world_size, int rank, int64_t* out_start,
                        int64_t* out_stop);
 int pbbss_allgather_masks(pbbss_handle_t h, const void* local, int elem_bytes, int64_t outer,

@@ -40,7 +40,8 @@ EXPORTS = (
     'pbbss_normalize_observation', 'pbbss_cacgmm_fit', 'pbbss_cacgmm_fit_shared',
     'pbbss_cacgmm_predict',
     'pbbss_cacg_m_step', 'pbbss_heev_batched', 'pbbss_psd', 'pbbss_gev', 'pbbss_gev_general',
-    'pbbss_comm_unique_id', 'pbbss_comm_create', 'pbbss_comm_destroy', 'pbbss_shard_bounds',
+    'pbbss_comm_unique_id', 'pbbss_comm_create', 'pbbss_comm_destroy', 'pbbss_comm_info',
+    'pbbss_shard_bounds',
     'pbbss_allgather_masks', 'pbbss_allgather_unpack', 'pbbss_estimate_mixture_weight',
     'pbbss_solve', 'pbbss_mvdr_souden', 'pbbss_mvdr', 'pbbss_ban',
     'pbbss_apply_beamforming_vector', 'pbbss_set_timing',
@@ -113,6 +114,8 @@ class MixOpts(ctypes.Structure):
         ('eigenvalue_floor', ctypes.c_double),
         ('spatial_weight', ctypes.c_double),
         ('spectral_weight', ctypes.c_double),
+        ('sharded', ctypes.c_int32),
+        ('reserved', ctypes.c_int32),
     ]
 
 
@@ -186,6 +189,7 @@ def load():
         lib.pbbss_comm_unique_id.argtypes = [vp]
         lib.pbbss_comm_create.argtypes = [vp, vp, i32, i32]
         lib.pbbss_comm_destroy.argtypes = [vp]
+        lib.pbbss_comm_info.argtypes = [vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
         lib.pbbss_shard_bounds.argtypes = [i64, i32, i32, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
         lib.pbbss_allgather_masks.argtypes = [vp, vp, i32, i64, i64, i64, vp, vp]
         lib.pbbss_allgather_unpack.argtypes = [vp, vp, i32, i32, i64, i64, i64, vp, vp]

@@ -24,6 +24,8 @@ struct pbbss_handle_s {
   size_t work_bytes;
   void* comm;         // RCCL communicator of pbbss_comm_create (one rank = this process), or null
   int comm_world, comm_rank;
+  void* comm_buf;     // pack / gather buffers of pbbss_allgather_masks: owned by the communicator,
+  size_t comm_bytes;  // never shared with the work slab (a collective may still be in flight)
   void* team_buf;     // control words + centroid partials of the DHTV team kernel
   size_t team_bytes;
   int dhtv_team;      // workgroups per utterance (0 = default, 1 = one-workgroup kernel)
@@ -235,6 +237,8 @@ PBBSS_API int pbbss_create(pbbss_handle_t* out, int device_id) {
   h->comm = nullptr;
   h->comm_world = 1;
   h->comm_rank = 0;
+  h->comm_buf = nullptr;
+  h->comm_bytes = 0;
   if (const char* tv = getenv("PBBSS_DHTV_TEAM")) h->dhtv_team = atoi(tv);
   h->prof = nullptr;
   h->timing = 0;
@@ -254,6 +258,7 @@ PBBSS_API int pbbss_destroy(pbbss_handle_t h) {
   if (h->scratch) (void)hipFree(h->scratch);
   if (h->work) (void)hipFree(h->work);
   if (h->comm) (void)pbbss::comm_destroy(h->comm);
+  if (h->comm_buf) (void)hipFree(h->comm_buf);
   if (h->team_buf) (void)hipFree(h->team_buf);
   if (h->cfg.xbuf) (void)hipFree(h->cfg.xbuf);
   if (h->cfg.side_stream) (void)hipStreamDestroy(h->cfg.side_stream);
@@ -288,11 +293,22 @@ PBBSS_API int pbbss_comm_create(pbbss_handle_t h, const void* unique_id, int wor
 PBBSS_API int pbbss_comm_destroy(pbbss_handle_t h) {
   DeviceGuard device_guard(h);
   if (!h) return PBBSS_ERR_INVALID_ARG;
+  // collectives enqueued on any stream of this device finish before their buffers go away
+  if (h->comm) (void)hipDeviceSynchronize();
   const int rc = pbbss::comm_destroy(h->comm);
   h->comm = nullptr;
   h->comm_world = 1;
   h->comm_rank = 0;
+  if (h->comm_buf) (void)hipFree(h->comm_buf);
+  h->comm_buf = nullptr;
+  h->comm_bytes = 0;
   return rc;
+}
+
+PBBSS_API int pbbss_comm_info(pbbss_handle_t h, int* out_world_size, int* out_rank) {
+  if (!h || !out_world_size || !out_rank) return PBBSS_ERR_INVALID_ARG;
+  if (!h->comm) return PBBSS_ERR_INVALID_ARG;  // pbbss_comm_create first
+  return pbbss::comm_query(h->comm, out_world_size, out_rank);
 }
 
 PBBSS_API int pbbss_shard_bounds(int64_t total_bins, int world_size, int rank, int64_t* out_start,
@@ -330,9 +346,24 @@ PBBSS_API int pbbss_allgather_masks(pbbss_handle_t h, const void* local, int ele
   if (nloc > 0 && !local) return PBBSS_ERR_INVALID_ARG;
   const size_t block = (size_t)outer * pad * inner * elem_bytes;
   if (block == 0) return PBBSS_OK;
-  void* w = handle_work(h, WorkCarver::pad(block) + WorkCarver::pad(block * world));
-  if (!w) return PBBSS_ERR_HIP;
-  WorkCarver wc(w);
+  // The pack / gather buffers belong to the communicator (grow-only, released by
+  // pbbss_comm_destroy / pbbss_destroy): the work slab may be re-carved or reallocated by the next
+  // library call on another stream while this collective is still in flight.
+  const size_t need = WorkCarver::pad(block) + WorkCarver::pad(block * world);
+  if (need > h->comm_bytes) {
+    if (h->comm_buf) {
+      if (hipDeviceSynchronize() != hipSuccess) return PBBSS_ERR_HIP;
+      (void)hipFree(h->comm_buf);
+      h->comm_buf = nullptr;
+      h->comm_bytes = 0;
+    }
+    if (hipMalloc(&h->comm_buf, need) != hipSuccess) {
+      h->comm_buf = nullptr;
+      return PBBSS_ERR_HIP;
+    }
+    h->comm_bytes = need;
+  }
+  WorkCarver wc(h->comm_buf);
   char* packed = wc.take<char>(block);
   char* gathered = wc.take<char>(block * world);
   hipStream_t s = as_stream(stream);
@@ -1258,6 +1289,19 @@ PBBSS_API int pbbss_joint_fit(pbbss_handle_t h, const void* observation, const v
   if (o->kind < PBBSS_EMBED_VMF || o->kind > PBBSS_EMBED_GAUSS_DIAG) return PBBSS_ERR_UNSUPPORTED;
   const bool g_full = o->kind == PBBSS_EMBED_GAUSS_FULL, g_diag = o->kind == PBBSS_EMBED_GAUSS_DIAG;
   if (g_full && E > pbbss::kGaussFullMaxE) return PBBSS_ERR_UNSUPPORTED;
+  // opts->sharded: this call holds ONE RANK'S BLOCK of the frequency bins; the spectral M-step
+  // sums and the bin-constant class weights are summed over the communicator of the handle, in
+  // stream order (no host round trip inside the loop).  The full-covariance scatter takes its
+  // shift from the first local point, which differs from rank to rank: not served.
+  const bool sharded = o->sharded != 0 && o->iterations > 0;
+  if (sharded && !h->comm) return PBBSS_ERR_INVALID_ARG;  // pbbss_comm_create first
+  if (sharded && g_full) return PBBSS_ERR_UNSUPPORTED;
+  pbbss::PartialReduce all_ranks{
+      [](void* ctx, double* buf, size_t count, hipStream_t st) -> int {
+        return pbbss::comm_all_reduce_f64(static_cast<pbbss_handle_t>(ctx)->comm, buf, count, st);
+      },
+      h};
+  const pbbss::PartialReduce* reduce = sharded ? &all_ranks : nullptr;
   // scalars per class of the spectral model's second parameter: concentration / variance (1),
   // per-dimension variances (E), covariance matrix (E * E)
   const size_t nscale = g_full ? (size_t)K * E * E : (g_diag ? (size_t)K * E : (size_t)K);
@@ -1402,7 +1446,8 @@ PBBSS_API int pbbss_joint_fit(pbbss_handle_t h, const void* observation, const v
       src = aff;
     }
     if (it == 0 || o->weight_mode != PBBSS_JOINT_WEIGHT_FK) {  // 'fk' weights: joint kernel
-      rc = pbbss::launch_joint_weight(o->weight_mode, src, saliency, F, K, T, tmp, out_weight, s);
+      rc = pbbss::launch_joint_weight(o->weight_mode, src, saliency, F, K, T, tmp, out_weight, s,
+                                      reduce);
       if (rc != PBBSS_OK) return rc;
     }
     if (g_full) {
@@ -1417,7 +1462,7 @@ PBBSS_API int pbbss_joint_fit(pbbss_handle_t h, const void* observation, const v
       rc = pbbss::launch_embed_fit(o->kind, embedding, o->embedding_is_f64, 1, N, E, K, src, T,
                                    saliency, o->min_concentration, o->max_concentration, -1, part,
                                    out_mean, out_scale, nullptr, g_diag ? nullptr : offset,
-                                   g_diag ? nullptr : prec, it == 0 ? 2 : 1, s);
+                                   g_diag ? nullptr : prec, it == 0 ? 2 : 1, s, nullptr, reduce);
     }
     if (rc != PBBSS_OK) return rc;
     if (fixed_scale) {  // fixed_covariance (gcacgmm.py:305-312)

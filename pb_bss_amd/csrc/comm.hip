@@ -31,6 +31,8 @@ typedef int (*GetUniqueIdFn)(UniqueId*);
 typedef int (*CommInitRankFn)(void**, int, UniqueId, int);
 typedef int (*CommDestroyFn)(void*);
 typedef int (*AllGatherFn)(const void*, void*, size_t, int, void*, hipStream_t);
+typedef int (*AllReduceFn)(const void*, void*, size_t, int, int, void*, hipStream_t);  // :611
+typedef int (*CommCountFn)(void*, int*);                                               // :378
 
 struct Rccl {
   void* lib = nullptr;
@@ -38,6 +40,8 @@ struct Rccl {
   CommInitRankFn comm_init_rank = nullptr;
   CommDestroyFn comm_destroy = nullptr;
   AllGatherFn all_gather = nullptr;
+  AllReduceFn all_reduce = nullptr;
+  CommCountFn comm_count = nullptr, comm_user_rank = nullptr;
   bool ok = false;
 };
 
@@ -53,7 +57,10 @@ Rccl& rccl() {
     x.comm_init_rank = reinterpret_cast<CommInitRankFn>(dlsym(x.lib, "ncclCommInitRank"));
     x.comm_destroy = reinterpret_cast<CommDestroyFn>(dlsym(x.lib, "ncclCommDestroy"));
     x.all_gather = reinterpret_cast<AllGatherFn>(dlsym(x.lib, "ncclAllGather"));
-    x.ok = x.get_unique_id && x.comm_init_rank && x.comm_destroy && x.all_gather;
+    x.all_reduce = reinterpret_cast<AllReduceFn>(dlsym(x.lib, "ncclAllReduce"));
+    x.comm_count = reinterpret_cast<CommCountFn>(dlsym(x.lib, "ncclCommCount"));
+    x.comm_user_rank = reinterpret_cast<CommCountFn>(dlsym(x.lib, "ncclCommUserRank"));
+    x.ok = x.get_unique_id && x.comm_init_rank && x.comm_destroy && x.all_gather && x.all_reduce;
     return x;
   }();
   return r;
@@ -163,6 +170,26 @@ int comm_all_gather_bytes(void* comm, const void* send, void* recv, size_t bytes
   return rccl().all_gather(send, recv, bytes_per_rank, /*ncclUint8*/ 1, comm, s) == 0
              ? PBBSS_OK
              : PBBSS_ERR_HIP;
+}
+
+// in-place sum of `count` float64 over the ranks (ncclFloat64 = 8, ncclSum = 0): every rank ends
+// up with bit-identical values, which is what keeps the replicated spectral models of a sharded
+// joint fit consistent
+int comm_all_reduce_f64(void* comm, double* buf, size_t count, hipStream_t s) {
+  if (!rccl().ok || !comm) return PBBSS_ERR_UNSUPPORTED;
+  if (count == 0) return PBBSS_OK;
+  return rccl().all_reduce(buf, buf, count, /*ncclFloat64*/ 8, /*ncclSum*/ 0, comm, s) == 0
+             ? PBBSS_OK
+             : PBBSS_ERR_HIP;
+}
+
+// what RCCL itself reports for the communicator (not what the caller passed to comm_create)
+int comm_query(void* comm, int* world, int* rank) {
+  if (!rccl().ok || !comm || !rccl().comm_count || !rccl().comm_user_rank)
+    return PBBSS_ERR_UNSUPPORTED;
+  if (rccl().comm_count(comm, world) != 0 || rccl().comm_user_rank(comm, rank) != 0)
+    return PBBSS_ERR_HIP;
+  return PBBSS_OK;
 }
 
 }  // namespace pbbss

@@ -609,7 +609,8 @@ __global__ void __launch_bounds__(kThreads)
   }
 }
 
-__global__ void joint_rows_to_class_kernel(const double* tmp, int64_t F, int K, double* out) {
+__global__ void joint_rows_to_class_kernel(const double* tmp, int64_t F, int K, int normalize,
+                                           double* out) {
   // single workgroup: (-3,-1): sum over f of the row sums, normalised over k
   __shared__ double red[kThreads / kWave][kEmbedMaxK];
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
@@ -634,14 +635,24 @@ __global__ void joint_rows_to_class_kernel(const double* tmp, int64_t F, int K, 
       for (int w = 0; w < kThreads / kWave; ++w) v[k] += red[w][k];
       tot += v[k];
     }
-    for (int k = 0; k < K; ++k) out[k] = v[k] / tot;
+    for (int k = 0; k < K; ++k) out[k] = normalize ? v[k] / tot : v[k];
   }
+}
+
+// out (K, T) raw class sums -> normalised over the classes, per column (after an all-reduce of
+// the sums of a sharded fit)
+__global__ void __launch_bounds__(kThreads) joint_normalize_kernel(double* out, int K, int T) {
+  const int t = blockIdx.x * kThreads + threadIdx.x;
+  if (t >= T) return;
+  double tot = 0.0;
+  for (int k = 0; k < K; ++k) tot += out[(size_t)k * T + t];
+  for (int k = 0; k < K; ++k) out[(size_t)k * T + t] /= tot;
 }
 
 // mode 3 (-3,): thread t: sum over f, normalised over k  -> (K,T)
 __global__ void __launch_bounds__(kThreads)
     joint_colsum_kernel(const double* aff, const double* sal, int64_t F, int K, int T,
-                        double* out) {
+                        int normalize, double* out) {
   const int t = blockIdx.x * kThreads + threadIdx.x;
   if (t >= T) return;
   double s[kEmbedMaxK];
@@ -659,7 +670,7 @@ __global__ void __launch_bounds__(kThreads)
     if (k < K) tot += s[k];
 #pragma unroll
   for (int k = 0; k < kEmbedMaxK; ++k)
-    if (k < K) out[(size_t)k * T + t] = s[k] / tot;
+    if (k < K) out[(size_t)k * T + t] = normalize ? s[k] / tot : s[k];
 }
 
 __global__ void joint_fill_kernel(double* out, double v) { out[0] = v; }
@@ -845,9 +856,17 @@ template <int K, typename TS>
 int fit_go(int kind, const void* yr, int64_t B, int64_t N, int E, const double* aff, int64_t Tin,
            const double* sal, double cmin, double cmax, int weight_mode, double* part,
            double* out_mean, double* out_scale, double* out_weight, double* out_offset,
-           double* out_prec, int single_pass, const double* rowscale, hipStream_t s) {
+           double* out_prec, int single_pass, const double* rowscale, hipStream_t s,
+           const PartialReduce* reduce) {
   int C = 0;
   const size_t np = embed_partial_doubles(B, N, E, K, &C);
+  const size_t nsum = (size_t)B * C * K * (E + 1);  // one set of chunk partials
+  auto all_ranks = [&](double* buf, size_t count) -> int {
+    return reduce ? reduce->fn(reduce->ctx, buf, count, s) : PBBSS_OK;
+  };
+  // the first-row shift of the one-sweep variance differs from rank to rank: sharded fits take
+  // the previous mean (identical on all ranks) or, before there is one, two sweeps
+  if (reduce && single_pass == 2) single_pass = 0;
   double* den_buf = part + np - (size_t)B * K;
   const int S = fit_slots(E, K);
   int64_t L = (N + C - 1) / C;
@@ -863,6 +882,7 @@ int fit_go(int kind, const void* yr, int64_t B, int64_t N, int E, const double* 
     hipLaunchKernelGGL((embed_fit_kernel<K, TS, 2>), grid, dim3(kFitThreads), lds_fit, s,
                        static_cast<const TS*>(yr), N, E, S, C, L, aff, Tin, sal, out_mean, part,
                        part2, first, (const double*)nullptr);
+    if (int rc = all_ranks(part, 2 * nsum); rc != PBBSS_OK) return rc;  // part2 follows part
     hipLaunchKernelGGL(embed_finalize_single_kernel, dim3((unsigned)B), dim3(kFinThreads),
                        (2 * Wv + (2 * Wv < (size_t)kFinThreads ? (size_t)kFinThreads : 0)) * sizeof(double),
                        s, part, part2, C, E, K, yr,
@@ -873,6 +893,7 @@ int fit_go(int kind, const void* yr, int64_t B, int64_t N, int E, const double* 
   hipLaunchKernelGGL((embed_fit_kernel<K, TS, 0>), grid, dim3(kFitThreads), lds_fit, s,
                      static_cast<const TS*>(yr), N, E, S, C, L, aff, Tin, sal,
                      (const double*)nullptr, part, (double*)nullptr, 0, rowscale);
+  if (int rc = all_ranks(part, nsum); rc != PBBSS_OK) return rc;
   if (kind == PBBSS_EMBED_VMF) {
     hipLaunchKernelGGL((embed_finalize_kernel<PBBSS_EMBED_VMF, 0>), dim3((unsigned)B),
                        dim3(kFinThreads), lds_fin, s, part, C, E, K, cmin, cmax, weight_mode,
@@ -885,6 +906,7 @@ int fit_go(int kind, const void* yr, int64_t B, int64_t N, int E, const double* 
   hipLaunchKernelGGL((embed_fit_kernel<K, TS, 1>), grid, dim3(kFitThreads), lds_fit, s,
                      static_cast<const TS*>(yr), N, E, S, C, L, aff, Tin, sal, out_mean, part,
                      (double*)nullptr, 0, (const double*)nullptr);
+  if (int rc = all_ranks(part, nsum); rc != PBBSS_OK) return rc;
   if (kind == PBBSS_EMBED_GAUSS_DIAG) {
     hipLaunchKernelGGL((embed_finalize_kernel<PBBSS_EMBED_GAUSS_DIAG, 1>), dim3((unsigned)B),
                        dim3(kFinThreads), lds_fin, s, part, C, E, K, cmin, cmax, -1, den_buf,
@@ -901,9 +923,10 @@ template <typename TS>
 int fit_k(int K, int kind, const void* yr, int64_t B, int64_t N, int E, const double* aff,
           int64_t Tin, const double* sal, double cmin, double cmax, int weight_mode, double* part,
           double* out_mean, double* out_scale, double* out_weight, double* out_offset,
-          double* out_prec, int single_pass, const double* rowscale, hipStream_t s) {
+          double* out_prec, int single_pass, const double* rowscale, hipStream_t s,
+          const PartialReduce* reduce) {
 #define PBBSS_FIT_CASE(KK) \
-  case KK: return fit_go<KK, TS>(kind, yr, B, N, E, aff, Tin, sal, cmin, cmax, weight_mode, part, out_mean, out_scale, out_weight, out_offset, out_prec, single_pass, rowscale, s);
+  case KK: return fit_go<KK, TS>(kind, yr, B, N, E, aff, Tin, sal, cmin, cmax, weight_mode, part, out_mean, out_scale, out_weight, out_offset, out_prec, single_pass, rowscale, s, reduce);
   switch (K) {
     PBBSS_FIT_CASE(1) PBBSS_FIT_CASE(2) PBBSS_FIT_CASE(3)
     PBBSS_FIT_CASE(4) PBBSS_FIT_CASE(5) PBBSS_FIT_CASE(6)
@@ -939,7 +962,7 @@ int launch_embed_fit(int kind, const void* yr, int y_is_f64, int64_t B, int64_t 
                      const double* aff, int64_t Tin, const double* sal, double cmin, double cmax,
                      int weight_mode, double* part, double* out_mean, double* out_scale,
                      double* out_weight, double* out_offset, double* out_prec, int single_pass,
-                     hipStream_t s, const double* rowscale) {
+                     hipStream_t s, const double* rowscale, const PartialReduce* reduce) {
   if (E < 1 || E > kEmbedMaxE || B > 65535) return PBBSS_ERR_UNSUPPORTED;
   if (kind != PBBSS_EMBED_VMF && kind != PBBSS_EMBED_GAUSS_SPHERICAL && kind != PBBSS_EMBED_GAUSS_DIAG)
     return PBBSS_ERR_UNSUPPORTED;
@@ -947,14 +970,15 @@ int launch_embed_fit(int kind, const void* yr, int y_is_f64, int64_t B, int64_t 
   if (kind == PBBSS_EMBED_GAUSS_DIAG) single_pass = 0;  // two sweeps, as the reference
   return y_is_f64 ? fit_k<double>(K, kind, yr, B, N, E, aff, Tin, sal, cmin, cmax, weight_mode,
                                   part, out_mean, out_scale, out_weight, out_offset, out_prec,
-                                  single_pass, rowscale, s)
+                                  single_pass, rowscale, s, reduce)
                   : fit_k<float>(K, kind, yr, B, N, E, aff, Tin, sal, cmin, cmax, weight_mode,
                                  part, out_mean, out_scale, out_weight, out_offset, out_prec,
-                                 single_pass, rowscale, s);
+                                 single_pass, rowscale, s, reduce);
 }
 
 int launch_joint_weight(int mode, const double* aff, const double* sal, int64_t F, int K, int T,
-                        double* tmp, double* out_weight, hipStream_t s) {
+                        double* tmp, double* out_weight, hipStream_t s,
+                        const PartialReduce* reduce) {
   if (K < 1 || K > kEmbedMaxK) return PBBSS_ERR_UNSUPPORTED;
   switch (mode) {
     case 0:
@@ -968,11 +992,21 @@ int launch_joint_weight(int mode, const double* aff, const double* sal, int64_t 
       hipLaunchKernelGGL(joint_rowsum_kernel, dim3((unsigned)F), dim3(kThreads), 0, s, aff, sal, K,
                          T, 0, tmp, out_weight);
       hipLaunchKernelGGL(joint_rows_to_class_kernel, dim3(1), dim3(kThreads), 0, s, tmp, F, K,
-                         out_weight);
+                         reduce ? 0 : 1, out_weight);
+      if (reduce) {
+        if (int rc = reduce->fn(reduce->ctx, out_weight, (size_t)K, s); rc != PBBSS_OK) return rc;
+        hipLaunchKernelGGL(joint_normalize_kernel, dim3(1), dim3(kThreads), 0, s, out_weight, K, 1);
+      }
       break;
     case 3:
       hipLaunchKernelGGL(joint_colsum_kernel, dim3((unsigned)((T + kThreads - 1) / kThreads)),
-                         dim3(kThreads), 0, s, aff, sal, F, K, T, out_weight);
+                         dim3(kThreads), 0, s, aff, sal, F, K, T, reduce ? 0 : 1, out_weight);
+      if (reduce) {
+        if (int rc = reduce->fn(reduce->ctx, out_weight, (size_t)K * T, s); rc != PBBSS_OK)
+          return rc;
+        hipLaunchKernelGGL(joint_normalize_kernel, dim3((unsigned)((T + kThreads - 1) / kThreads)),
+                           dim3(kThreads), 0, s, out_weight, K, T);
+      }
       break;
     case 4:
       hipLaunchKernelGGL(joint_fill_kernel, dim3(1), dim3(1), 0, s, out_weight, 1.0);

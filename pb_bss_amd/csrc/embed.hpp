@@ -11,6 +11,14 @@ namespace pbbss {
 constexpr int kEmbedMaxK = 6;     // classes (same bound as the spatial kernels)
 constexpr int kEmbedMaxE = 256;   // embedding dimension (one workgroup row of the fit kernel)
 
+// Sharded fits (the points of ONE mixture spread over several GPUs): called between the kernel
+// that writes per-chunk partial sums and the kernel that finalises them, to sum the partials over
+// the ranks in place (capi.hip binds it to an ncclAllReduce on the launch stream).
+struct PartialReduce {
+  int (*fn)(void* ctx, double* buf, size_t count, hipStream_t s);
+  void* ctx;
+};
+
 // bytes of the (B, E, N) transposed copy / of the fit partial sums
 size_t embed_partial_doubles(int64_t B, int64_t N, int E, int K, int* chunks_out);
 
@@ -51,8 +59,8 @@ int launch_embed_fit(int kind, const void* yr, int y_is_f64, int64_t B, int64_t 
                      const double* aff, int64_t Tin, const double* sal, double cmin, double cmax,
                      int weight_mode, double* part, double* out_mean, double* out_scale,
                      double* out_weight, double* out_offset, double* out_prec, int single_pass,
-                     hipStream_t s, const double* rowscale = nullptr);  // rowscale: vMF only, rows
-                                                                       // are used as y_n * rowscale[n]
+                     hipStream_t s, const double* rowscale = nullptr,  // rowscale: vMF only, rows
+                     const PartialReduce* reduce = nullptr);           // are used as y_n * rowscale[n]
 
 // masked affiliation sums of the joint models (gcacgmm.py:286-295): aff (F,K,T), sal (F,T)
 //   mode 0 'fk' (-1,): w[f,k] = sum_t / sum_k sum_t          -> (F,K)
@@ -61,8 +69,11 @@ int launch_embed_fit(int kind, const void* yr, int y_is_f64, int64_t B, int64_t 
 //   mode 3 'kt' (-3,) : sum_f / sum_k sum_f                   -> (K,T)
 //   mode 4 ''         : 1                                     -> (1)
 // tmp: F*K doubles of scratch.
+// reduce != null (bins sharded over ranks): the sums of modes 2 / 3 are all-reduced before they
+// are normalised over the classes.
 int launch_joint_weight(int mode, const double* aff, const double* sal, int64_t F, int K, int T,
-                        double* tmp, double* out_weight, hipStream_t s);
+                        double* tmp, double* out_weight, hipStream_t s,
+                        const PartialReduce* reduce = nullptr);
 
 // DiagonalGaussian.log_pdf as the reference writes it (gaussian.py:76-97, see embed.hip):
 // yd (E, N) transposed copy, mean / cov (K, E); out index as launch_embed_estep (b = 0);

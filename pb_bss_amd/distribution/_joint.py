@@ -10,6 +10,26 @@ from .complex_angular_central_gaussian import ComplexAngularCentralGaussian
 from .utils import as_result
 
 
+import contextlib
+import threading
+
+_tls = threading.local()
+
+
+@contextlib.contextmanager
+def sharded_bins(enabled=True):
+    """Inside this context `fit` treats the observation / embedding it is given as ONE RANK'S
+    BLOCK of frequency bins: the spectral M-step sums and the bin-constant mixture weights are
+    all-reduced over the library communicator (`pbbss_mix_opts.sharded`).  Used by
+    `sharding.fit_predict_sharded_joint`."""
+    old = getattr(_tls, 'sharded', False)
+    _tls.sharded = bool(enabled)
+    try:
+        yield
+    finally:
+        _tls.sharded = old
+
+
 def weight_mode(weight_constant_axis):
     """gcacgmm.py:158-162: axes refer to the (F, K, T) affiliation."""
     if isinstance(weight_constant_axis, int):
@@ -74,7 +94,7 @@ def fit(kind, observation, embedding, initialization, num_classes, iterations, s
         affiliation_eps=affiliation_eps, spatial_weight=spatial_weight,
         spectral_weight=spectral_weight, inline_pa=inline_permutation_alignment,
         min_concentration=min_concentration, max_concentration=max_concentration,
-        fixed_scale=fixed)
+        fixed_scale=fixed, sharded=getattr(_tls, 'sharded', False))
     return r, like_torch
 
 

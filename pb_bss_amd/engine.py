@@ -726,7 +726,7 @@ def joint_fit(observation, embedding, K, kind, *, gamma0=None, model=None, itera
               saliency=None, weight_mode=0, covariance_norm=1, eigenvalue_floor=1e-10,
               affiliation_eps=1e-10, spatial_weight=1., spectral_weight=1., inline_pa=False,
               min_concentration=1e-10, max_concentration=500., fixed_scale=None,
-              final_predict=False, check_status=True):
+              final_predict=False, check_status=True, sharded=False):
     """pbbss_joint_fit.  observation (F,T,D) complex, embedding (F,T,E) real;
     gamma0 (F,K,T) f64 or (iterations=0) model=(eigvec, eigval, weight, mean (K,E), scale);
     scale: (K,) concentration / spherical variance, (K,E) diagonal variances, (K,E,E) full
@@ -748,7 +748,7 @@ def joint_fit(observation, embedding, K, kind, *, gamma0=None, model=None, itera
                         affiliation_eps=float(affiliation_eps),
                         eigenvalue_floor=float(eigenvalue_floor),
                         spatial_weight=float(spatial_weight),
-                        spectral_weight=float(spectral_weight))
+                        spectral_weight=float(spectral_weight), sharded=int(bool(sharded)))
     wshape = joint_weight_shape(weight_mode, F, K, T)
     eigvec = t.empty((F, K, D, D), dtype=t.complex128, device=dev)
     eigval = t.empty((F, K, D), dtype=f64, device=dev)

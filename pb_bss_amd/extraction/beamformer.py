@@ -221,6 +221,21 @@ def _select_reference_channel(num, den, eps):
     return int(np.argmax(snr.real))
 
 
+def _select_reference_channel_sharded(num, den, eps, shard_group):
+    """The same selection when the frequency bins are sharded over the ranks of a
+    torch.distributed group: the SNR of :616-620 sums over ALL bins, so
+    the local sums -- 2 x D complex numbers per problem -- are all-reduced before the division.
+    num/den: (..., F_local, D) tensors; returns an int array of shape (...)."""
+    from ..sharding import all_reduce_sum
+    t = _lib.torch()
+    s = t.stack([num.sum(dim=-2), den.sum(dim=-2)])          # (2, ..., D)
+    s = all_reduce_sum(s, None if shard_group is True else shard_group)
+    s = s.cpu().numpy() if s.is_cuda else s.numpy()
+    snr = s[0] / np.maximum(s[1], eps)
+    assert np.all(np.isfinite(snr)), snr
+    return np.argmax(snr.real, axis=-1)
+
+
 def get_optimal_reference_channel(w_mat, target_psd_matrix, noise_psd_matrix, eps=None):
     """Reference channel maximising the post-filter SNR summed over ALL
     frequencies.  Reference: beamformer.py:601-624."""
@@ -242,11 +257,15 @@ def get_optimal_reference_channel(w_mat, target_psd_matrix, noise_psd_matrix, ep
 
 
 def get_mvdr_vector_souden(target_psd_matrix, noise_psd_matrix, ref_channel=None,
-                           eps=None, return_ref_channel=False):
+                           eps=None, return_ref_channel=False, *, shard_group=None):
     """MVDR beamformer in the Souden formulation.  Reference:
     beamformer.py:627-698.  (..., bins, sensors, sensors) -> (..., bins, sensors).
     The automatic reference channel needs exactly 3 dims (bins first) because
-    its SNR estimate sums over all frequencies."""
+    its SNR estimate sums over all frequencies.
+
+    shard_group (extension): the bins axis holds only THIS RANK'S block of frequency bins of a
+    torch.distributed group (True = the default group); the automatic reference channel is then
+    chosen from the SNR summed over the bins of all ranks (one all-reduce of 2 x D numbers)."""
     assert noise_psd_matrix is not None
     like_torch = _lib.is_torch(target_psd_matrix)
     tp = _c128(target_psd_matrix)
@@ -264,7 +283,10 @@ def get_mvdr_vector_souden(target_psd_matrix, noise_psd_matrix, ref_channel=None
                 'has 3 ndims (frequency x sensors x sensors). '
                 'Considering an independent dim in the SNR estimate is not '
                 'unique.')
-        ref_channel = _select_reference_channel(_lib.to_host(num), _lib.to_host(den), eps)
+        if shard_group is not None:
+            ref_channel = int(_select_reference_channel_sharded(num, den, eps, shard_group))
+        else:
+            ref_channel = _select_reference_channel(_lib.to_host(num), _lib.to_host(den), eps)
     assert np.isscalar(ref_channel), ref_channel
     w = mat.reshape(*tp.shape)[..., ref_channel]
     if return_ref_channel:

@@ -62,14 +62,51 @@ class device_ops:
         return get_bf_vector('gev+ban', target, noise)
 
     @staticmethod
+    def mvdr_souden(target, noise, shard_group=None):
+        """target / noise (..., F_local, D, D) -> w (..., F_local, D); the reference channel of
+        every leading problem maximises the SNR summed over ALL bins (beamformer.py:601-624,
+        :627-698): under bin sharding the 2 x D sums per problem are all-reduced once."""
+        from . import _lib, engine
+        from .extraction.beamformer import (_select_reference_channel,
+                                            _select_reference_channel_sharded)
+        t = _lib.torch()
+        *lead, Fl, D, _ = target.shape
+        eps = np.finfo(np.float64).tiny
+        mat, num, den, _ = engine.mvdr_souden(
+            target.to(t.complex128).reshape(-1, D, D).contiguous(),
+            noise.to(t.complex128).expand(target.shape).reshape(-1, D, D).contiguous(), eps)
+        num, den = num.reshape(*lead, Fl, D), den.reshape(*lead, Fl, D)
+        if shard_group is not None:
+            ref = _select_reference_channel_sharded(num, den, eps, shard_group)
+        else:
+            nh, dh = _lib.to_host(num), _lib.to_host(den)
+            ref = np.empty(tuple(lead), dtype=np.int64)
+            for idx in np.ndindex(*lead):
+                ref[idx] = _select_reference_channel(nh[idx], dh[idx], eps)
+        return select_column(mat.reshape(*lead, Fl, D, D), ref)
+
+    @staticmethod
     def apply_bf(w, X):
         from .extraction import apply_beamforming_vector
         return apply_beamforming_vector(w, X)
 
 
-def _chain_after_masks(Y, masks_fkt, mapping, ops):
-    """Alignment -> PSD -> gev+ban -> apply for utterances / bins that are local.
-    Y (U, F, T, D), masks_fkt (U, F, K, T), mapping (U, K, F) for the same bins."""
+def select_column(mat, ref):
+    """mat (..., F, D, D), ref int array (...): column ref[...] of every matrix -> (..., F, D)."""
+    import torch
+    *lead, Fl, D, _ = mat.shape
+    idx = torch.as_tensor(np.asarray(ref), device=mat.device).reshape(*lead, 1, 1, 1)
+    return torch.gather(mat, -1, idx.expand(*lead, Fl, D, 1)).squeeze(-1)
+
+
+BEAMFORMERS = ('gev+ban', 'mvdr_souden')
+
+
+def _chain_after_masks(Y, masks_fkt, mapping, ops, beamformer='gev+ban', shard_group=None):
+    """Alignment -> PSD -> beamformer -> apply for utterances / bins that are local.
+    Y (U, F, T, D), masks_fkt (U, F, K, T), mapping (U, K, F) for the same bins.
+    shard_group: F holds one rank's block of bins ('mvdr_souden' then all-reduces the SNR sums
+    of its reference-channel choice over that group; True = the default group)."""
     import torch
     kft = masks_fkt.transpose(-3, -2).contiguous()                    # (U, K, F, T)
     aligned = ops.apply_mapping(kft, mapping)                         # (U, K, F, T)
@@ -79,14 +116,23 @@ def _chain_after_masks(Y, masks_fkt, mapping, ops):
     total = psd.sum(dim=-3)
     target = psd.movedim(-3, 0).contiguous()                          # (K, U, F, D, D)
     noise = (total.unsqueeze(0) - target).contiguous()
-    w = ops.gev_ban(target, noise)                                    # (K, U, F, D)
+    if beamformer == 'gev+ban':
+        w = ops.gev_ban(target, noise)                                # (K, U, F, D)
+    elif beamformer == 'mvdr_souden':
+        w = ops.mvdr_souden(target, noise, shard_group)
+    else:
+        raise ValueError(f'beamformer={beamformer!r}: one of {BEAMFORMERS}')
     enhanced = torch.stack([ops.apply_bf(w[k], X) for k in range(K)], dim=1)  # (U, K, F, T)
     return aligned, w.movedim(0, 1).contiguous(), enhanced
 
 
 def separate(Y, init, iterations=100, stft_size=None, *, shard=None, group=None,
-             mask_gather_dtype=None, gather_output=False, ops=device_ops):
+             mask_gather_dtype=None, gather_output=False, ops=device_ops, beamformer='gev+ban'):
     """Y (U, F, T, D) complex, init (U, F, K, T): run the chain above.
+
+    beamformer: 'gev+ban' (the reference's canonical recipe) or 'mvdr_souden' with the automatic
+    reference channel (beamformer.py:627-698) -- the one extraction step that couples the bins:
+    with shard='bins' its per-problem SNR sums are all-reduced over the group.
 
     shard: None (single process), 'bins' or 'utterances' (torch.distributed initialised).
     Returns dict(masks (U, K, F', T) aligned, enhanced (U, K, F', T), bf_vector (U, K, F', D),
@@ -100,7 +146,7 @@ def separate(Y, init, iterations=100, stft_size=None, *, shard=None, group=None,
     if shard is None:
         masks = ops.em_masks(Y, init, iterations)                     # (U, F, K, T)
         mapping = ops.dhtv_mapping(masks.transpose(-3, -2).contiguous(), stft_size)
-        aligned, w, enhanced = _chain_after_masks(Y, masks, mapping, ops)
+        aligned, w, enhanced = _chain_after_masks(Y, masks, mapping, ops, beamformer)
         return dict(masks=aligned, enhanced=enhanced, bf_vector=w, mapping=mapping)
 
     import torch.distributed as dist
@@ -108,7 +154,7 @@ def separate(Y, init, iterations=100, stft_size=None, *, shard=None, group=None,
     if shard == 'utterances':
         assert U >= world, (U, world, 'fewer utterances than ranks: shard the bins instead')
         lo, hi = shard_bounds(U, world, rank)
-        out = separate(Y[lo:hi], init[lo:hi], iterations, stft_size, ops=ops)
+        out = separate(Y[lo:hi], init[lo:hi], iterations, stft_size, ops=ops, beamformer=beamformer)
         if gather_output:
             out = {k: all_gather_bins(v.contiguous(), U, bin_axis=0, group=group)
                    for k, v in out.items()}
@@ -135,10 +181,18 @@ def separate(Y, init, iterations=100, stft_size=None, *, shard=None, group=None,
         map_loc = torch.empty((0, K, F), dtype=torch.int64, device=Y.device)
     mapping = all_gather_bins(map_loc, U, bin_axis=0, group=group)     # (U, K, F)
     # ---- everything downstream is per bin: own bins only --------------------------------------
+    sg = True if group is None else group
     if hi > lo:
-        # own bins of the (own-precision) masks: bit-identical to an unsharded run
-        aligned, w, enhanced = _chain_after_masks(Y_loc, masks_loc, mapping[..., lo:hi].contiguous(), ops)
+        # own bins of the (own-precision) masks; with the float64 gather the mapping -- and with it
+        # every output -- is bit-identical to an unsharded run (a float32 gather rounds the masks
+        # the DHTV scores are computed from: near-tied scores may then pick another permutation)
+        aligned, w, enhanced = _chain_after_masks(Y_loc, masks_loc, mapping[..., lo:hi].contiguous(),
+                                                  ops, beamformer, sg)
     else:
+        if beamformer == 'mvdr_souden':  # keep the collective schedule of the other ranks
+            from .sharding import all_reduce_sum
+            all_reduce_sum(torch.zeros((2, K, U, D), dtype=torch.complex128, device=Y.device),
+                           None if sg is True else sg)
         aligned = torch.empty((U, K, 0, T), dtype=masks_loc.dtype, device=Y.device)
         w = torch.empty((U, K, 0, D), dtype=torch.complex128, device=Y.device)
         enhanced = torch.empty((U, K, 0, T), dtype=torch.complex128, device=Y.device)

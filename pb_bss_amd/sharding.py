@@ -20,10 +20,13 @@ there are at least as many utterances as GPUs.
 """
 import numpy as np
 
-__all__ = ['shard_bounds', 'shard_sizes', 'all_gather_bins', 'fit_predict_sharded',
+__all__ = ['shard_bounds', 'shard_sizes', 'all_gather_bins', 'all_reduce_sum', 'fit_predict_sharded',
+           'fit_predict_sharded_joint', 'native_comm',
            'init_native_comm', 'destroy_native_comm']
 
-# device index -> (world, rank) of the RCCL communicator created in the library handle
+# device index -> (world, rank, group) of the RCCL communicator created in the library handle;
+# `group` is the torch.distributed group it was built for (None = the world): all_gather_bins
+# takes the native path only for calls on that very group
 _NATIVE_COMM = {}
 
 
@@ -53,6 +56,9 @@ def init_native_comm(group=None, device_index=None):
     from . import _lib
     if device_index is None:
         device_index = torch.cuda.current_device()
+    if device_index in _NATIVE_COMM:
+        raise RuntimeError('this device already holds a library communicator (one per handle): '
+                           'call destroy_native_comm() first')
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     uid = ctypes.create_string_buffer(128)
     if rank == 0:
@@ -62,7 +68,15 @@ def init_native_comm(group=None, device_index=None):
                                group=group)
     _lib.check(_lib.load().pbbss_comm_create(_lib.handle(device_index), box[0], world, rank),
                'comm_create')
-    _NATIVE_COMM[device_index] = (world, rank)
+    _NATIVE_COMM[device_index] = (world, rank, group)
+
+
+def native_comm(device_index=None):
+    """(world, rank, group) of the library communicator of this device, or None."""
+    import torch
+    if device_index is None:
+        device_index = torch.cuda.current_device()
+    return _NATIVE_COMM.get(device_index)
 
 
 def destroy_native_comm(device_index=None):
@@ -104,10 +118,11 @@ def all_gather_bins(local, num_bins, bin_axis=0, group=None):
     import torch
     import torch.distributed as dist
     bin_axis = bin_axis % local.ndim
-    if (local.is_cuda and group is None and local.device.index in _NATIVE_COMM
+    if (local.is_cuda and local.device.index in _NATIVE_COMM
+            and _NATIVE_COMM[local.device.index][2] is group
             and local.element_size() in (4, 8, 16) and
             (local.element_size() != 16 or local.dtype == torch.complex128)):
-        world, rank = _NATIVE_COMM[local.device.index]
+        world, rank, _ = _NATIVE_COMM[local.device.index]
         assert local.shape[bin_axis] == shard_sizes(num_bins, world)[rank], (
             local.shape, shard_sizes(num_bins, world), rank)
         return _native_all_gather(local, num_bins, bin_axis)
@@ -167,24 +182,60 @@ def shared_weight_allreduce(weight_constant_axis, total_bins, bin_axis=-3, group
     return hook
 
 
-def fit_predict_sharded(y, initialization, iterations=100, *, bin_axis=-3,
+def all_reduce_sum(x, group=None):
+    """Sum a small tensor over the ranks (in place, returned).  Complex tensors travel as
+    (re, im) pairs; without an initialised process group (single process) this is the
+    identity.  Used for the cross-bin reductions of SURVEY section 8e: the D-vector of the
+    MVDR-Souden reference-channel SNR (beamformer.py:601-624) and the shared mixture weights."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return x
+    if x.is_complex():
+        r = torch.view_as_real(x.contiguous()).contiguous()
+        dist.all_reduce(r, group=group)
+        return torch.view_as_complex(r)
+    dist.all_reduce(x, group=group)
+    return x
+
+
+def _bin_block(x, axis_from_end, lo, hi):
+    """Slice bins [lo, hi) out of an array whose bin axis is `axis_from_end` (negative);
+    arrays that are absent or broadcast along the bins pass through."""
+    if x is None or x.ndim < -axis_from_end or x.shape[axis_from_end] == 1:
+        return x
+    sl = [slice(None)] * x.ndim
+    sl[axis_from_end] = slice(lo, hi)
+    return x[tuple(sl)]
+
+
+def fit_predict_sharded(y, initialization, iterations=100, *, trainer=None, bin_axis=-3,
                         group=None, **fit_kwargs):
-    """Sharded `CACGMMTrainer.fit_predict`: every rank passes the FULL problem
-    description (y (..., F, T, D), initialization (..., F, K, T)); each fits
-    only its own block of frequency bins and the masks are all-gathered, so
-    every rank returns the complete (..., F, K, T) affiliations, ready for
-    permutation alignment.
+    """Sharded `fit_predict` of a per-bin mixture trainer: every rank passes the FULL problem
+    description (y (..., F, T, D), initialization (..., F, K, T)); each fits only its own block
+    of frequency bins and the masks are all-gathered, so every rank returns the complete
+    (..., F, K, T) affiliations, ready for permutation alignment.
+
+    `trainer`: an instance (or class) of `CACGMMTrainer` (default), `CWMMTrainer` (BASELINE
+    configs[3], reference cwmm.py:76-149: every bin is an independent Watson mixture) or
+    `VMFMMTrainer` / `GMMTrainer` (independent leading axes, vmfmm.py:124-172).  The joint
+    spatial + spectral trainers couple the bins through ONE spectral mixture: see
+    `fit_predict_sharded_joint`.
 
     `weight_constant_axis` may contain the sharded bin axis ((-3,), (-3, -1): weights
-    averaged over the bins of ALL ranks): the fit then runs step by step with one small
-    all-reduce per iteration (`shared_weight_allreduce`).  An inline permutation aligner
-    needs every bin on one device and is not shardable by bins.
+    averaged over the bins of ALL ranks; CACGMMTrainer only): the fit then runs step by step
+    with one small all-reduce per iteration (`shared_weight_allreduce`).  An inline
+    permutation aligner needs every bin on one device and is not shardable by bins.
     """
     import torch.distributed as dist
     from . import _lib
     from .distribution import CACGMMTrainer
-    assert 'inline_permutation_aligner' not in fit_kwargs or \
-        fit_kwargs['inline_permutation_aligner'] is None, \
+    if trainer is None:
+        trainer = CACGMMTrainer()
+    elif isinstance(trainer, type):
+        trainer = trainer()
+    is_cacgmm = isinstance(trainer, CACGMMTrainer)
+    assert fit_kwargs.get('inline_permutation_aligner') is None, \
         'inline_permutation_aligner couples the frequency bins: not shardable by bins'
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
@@ -200,42 +251,85 @@ def fit_predict_sharded(y, initialization, iterations=100, *, bin_axis=-3,
     coupled = any(a % nd_y == f_axis_y for a in wca)
     hook = None
     if coupled:
+        if not is_cacgmm:
+            raise NotImplementedError(
+                f'{type(trainer).__name__}: mixture weights shared over the sharded axis need a '
+                'collective inside the EM loop, which only CACGMMTrainer provides')
         assert not (len(wca) == 1 and wca[0] % nd_y - nd_y == -2), wca
         hook = shared_weight_allreduce(wca, F, bin_axis=f_axis_y - nd_y, group=group)
     lo, hi = shard_bounds(F, world, rank)
-
-    def block(x, axis_from_end):
-        """Slice this rank's bins out of an array whose bin axis is `axis_from_end` (negative)."""
-        if x is None or x.ndim < -axis_from_end or x.shape[axis_from_end] == 1:
-            return x  # absent, or broadcast along the bins
-        sl = [slice(None)] * x.ndim
-        sl[axis_from_end] = slice(lo, hi)
-        return x[tuple(sl)]
-
     neg = f_axis_y - nd_y               # bin axis of y (..., F, T, D) and of (..., F, K, T)
-    y_loc = block(y, neg)
-    i_loc = block(initialization, neg)
+    y_loc = _bin_block(y, neg, lo, hi)
+    i_loc = _bin_block(initialization, neg, lo, hi)
     kwargs = dict(fit_kwargs)
     if kwargs.get('saliency') is not None:              # (..., F, T): one axis fewer
-        kwargs['saliency'] = block(kwargs['saliency'], neg + 1)
+        kwargs['saliency'] = _bin_block(kwargs['saliency'], neg + 1, lo, hi)
     if kwargs.get('source_activity_mask') is not None:  # (..., F, K, T)
-        kwargs['source_activity_mask'] = block(kwargs['source_activity_mask'], neg)
+        kwargs['source_activity_mask'] = _bin_block(kwargs['source_activity_mask'], neg, lo, hi)
     K = initialization.shape[-2]
     if hook is not None:
         kwargs['_weight_hook'] = hook
+    # the library's trainers take device tensors; a CPU stand-in (the gloo tests run this very
+    # function with oracle-backed trainers) says so with a `_to_device` of its own
+    prep = getattr(trainer, '_to_device', _lib.to_device)
+    t = _lib.torch()
     if hi > lo:
-        masks = CACGMMTrainer().fit_predict(_lib.to_device(y_loc), initialization=_lib.to_device(i_loc),
-                                            iterations=iterations, **kwargs)
+        masks = trainer.fit_predict(prep(y_loc), initialization=prep(i_loc),
+                                    iterations=iterations, **kwargs)
     else:
+        dev = y.device if (isinstance(y, t.Tensor) and not hasattr(trainer, '_to_device')
+                           and y.is_cuda) else (
+            t.device('cpu') if hasattr(trainer, '_to_device')
+            else t.device('cuda', t.cuda.current_device()))
         if hook is not None:  # keep the collective schedule of the other ranks
-            t = _lib.torch()
             nd_a = initialization.ndim
             red = sorted({a % nd_a for a in wca})
             shape = [1 if ax in red else n for ax, n in enumerate(initialization.shape)]
-            hook.idle(shape, t.float64, t.device('cuda', t.cuda.current_device()), iterations)
+            hook.idle(shape, t.float64, dev, iterations)
         # more ranks than bins: this rank owns nothing and contributes an empty block
-        t = _lib.torch()
         shape = list(y.shape[:-2]) + [K, y.shape[-2]]
         shape[f_axis_y] = 0
-        masks = t.empty(shape, dtype=t.float64, device=t.device('cuda', t.cuda.current_device()))
+        masks = t.empty(shape, dtype=t.float64, device=dev)
     return all_gather_bins(masks, F, bin_axis=f_axis_y, group=group)
+
+
+def fit_predict_sharded_joint(trainer, observation, embedding, initialization, iterations=100, *,
+                              group=None, **fit_kwargs):
+    """Sharded `fit_predict` of the joint spatial + spectral trainers (`GCACGMMTrainer`,
+    `VMFCACGMMTrainer`; BASELINE configs[4], reference gcacgmm.py:121-225, vmfcacgmm.py:34-301).
+
+    observation (F, T, D), embedding (F, T, E), initialization (F, K, T): every rank passes the
+    full arrays and fits its own block of frequency bins.  The cACG half is per bin; the spectral
+    half is ONE mixture over all F*T points, so its M-step sums (K x (E + 1) numbers per chunk of
+    points, gaussian.py:152-193 / von_mises_fisher.py:122-144) are summed over the ranks once per
+    EM iteration -- an `ncclAllReduce` the LIBRARY enqueues on the caller's stream between the
+    partial-sum kernel and the finalize kernel (C ABI `pbbss_mix_opts.sharded`, communicator of
+    `init_native_comm`): no host round trip inside the loop, and every rank ends up with
+    bit-identical spectral parameters.  Mixture weights that are constant over the bins
+    ((-3, -1), (-3,)) are reduced the same way.  Returns the gathered (F, K, T) affiliations.
+    """
+    import torch.distributed as dist
+    from . import _lib
+    if isinstance(trainer, type):
+        trainer = trainer()
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    t = _lib.torch()
+    dev = t.cuda.current_device()
+    if world > 1:
+        comm = native_comm(dev)
+        assert comm is not None and comm[2] is group and comm[0] == world, (
+            'fit_predict_sharded_joint needs the library communicator of this group: call '
+            'sharding.init_native_comm(group) first')
+    F = observation.shape[0]
+    lo, hi = shard_bounds(F, world, rank)
+    assert hi > lo, ('a rank without bins cannot take part in the in-library all-reduce', F, world)
+    kwargs = dict(fit_kwargs)
+    if kwargs.get('saliency') is not None:
+        kwargs['saliency'] = _bin_block(kwargs['saliency'], -2, lo, hi)
+    from .distribution import _joint
+    with _joint.sharded_bins(world > 1):
+        masks = trainer.fit_predict(
+            _lib.to_device(observation[lo:hi]), _lib.to_device(embedding[lo:hi]),
+            initialization=_lib.to_device(initialization[lo:hi]), iterations=iterations, **kwargs)
+    return all_gather_bins(masks, F, bin_axis=0, group=group)

@@ -202,3 +202,205 @@ def test_shared_weight_allreduce_hook_world2():
     ret = mgr.dict()
     mp.spawn(_hook_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
     assert dict(ret) == {0: True, 1: True}
+
+
+# ---------------------------------------------------------------------------------------------
+# MVDR-Souden with the automatic reference channel under bin sharding: the SNR of
+# beamformer.py:616-620 sums over ALL bins, so the per-problem sums are all-reduced
+# (pipeline.separate(beamformer='mvdr_souden'), extraction.get_mvdr_vector_souden(shard_group=)).
+class _oracle_ops_souden(_oracle_ops):
+    @staticmethod
+    def mvdr_souden(target, noise, shard_group=None):
+        """Same contract as device_ops.mvdr_souden, oracle arithmetic: Phi_nn^-1 Phi_xx / tr per
+        bin (beamformer.py:627-698), the reference channel from the (all-reduced) SNR sums."""
+        from oracle import beamformer as ob
+        from pb_bss_amd.extraction.beamformer import _select_reference_channel_sharded
+        from pb_bss_amd.pipeline import select_column
+        t, n = target.numpy(), np.broadcast_to(noise.numpy(), target.shape)
+        eps = np.finfo(np.float64).tiny
+        phi = ob.stable_solve(n, t)
+        lam = np.trace(phi, axis1=-1, axis2=-2)[..., None, None]
+        mat = phi / np.maximum(lam.real, eps)
+        num = np.einsum('...fdr,...fde,...fer->...fr', mat.conj(), t, mat)
+        den = np.einsum('...fdr,...fde,...fer->...fr', mat.conj(), n, mat)
+        ref = _select_reference_channel_sharded(
+            torch.from_numpy(num), torch.from_numpy(den), eps,
+            shard_group if shard_group is not None else None) if shard_group is not None else \
+            np.argmax((num.sum(-2) / np.maximum(den.sum(-2), eps)).real, axis=-1)
+        return select_column(torch.from_numpy(mat), ref)
+
+
+def _souden_worker(rank, world, port, ret):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from oracle import beamformer as ob
+        from pb_bss_amd import pipeline
+        Y, init = _pipeline_inputs(U=2, F=257, T=30, D=3, K=2)
+        ref = pipeline.separate(Y, init, 3, 512, ops=_oracle_ops_souden, beamformer='mvdr_souden')
+        ok = True
+        for shard in ('bins', 'utterances'):
+            got = pipeline.separate(Y, init, 3, 512, shard=shard, gather_output=True,
+                                    ops=_oracle_ops_souden, beamformer='mvdr_souden')
+            ok = ok and bool((got['mapping'] == ref['mapping']).all())
+            for k in ('masks', 'enhanced', 'bf_vector'):
+                ok = ok and float((got[k] - ref[k]).abs().max()) < 1e-12
+        # ... and the unsharded stand-in is the reference function itself, problem by problem
+        X = Y.numpy().astype(np.complex128).transpose(0, 1, 3, 2)
+        aligned = ref['masks'].numpy()                                   # (U, K, F, T)
+        for u in range(X.shape[0]):
+            psd = ob.psd(X[u], aligned[u].transpose(1, 0, 2))            # (F, K, D, D)
+            for k in range(psd.shape[1]):
+                w = ob.mvdr_souden(psd[:, k], psd.sum(1) - psd[:, k])
+                ok = ok and float(np.abs(w - ref['bf_vector'][u, k].numpy()).max()) < 1e-10
+        ret[rank] = ok
+    finally:
+        dist.destroy_process_group()
+
+
+def test_mvdr_souden_reference_channel_allreduce_world2():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_souden_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}
+
+
+# ---------------------------------------------------------------------------------------------
+# sharding.fit_predict_sharded with trainers other than CACGMMTrainer (BASELINE configs[3]:
+# complex-Watson / vMF mixtures): the REAL function -- slicing of y / initialization / saliency,
+# the empty-shard branch, the gather -- with oracle-backed stand-ins for the device trainers.
+class _OracleCWMMTrainer:
+    _to_device = staticmethod(lambda x: x)  # CPU stand-in: tensors stay where they are
+
+    def fit_predict(self, y, initialization, iterations, saliency=None,
+                    weight_constant_axis=(-1,)):
+        from oracle import cwmm as ow
+        y128 = y.numpy().astype(np.complex128)
+        m = ow.cwmm_fit(y128, initialization.numpy(), iterations=iterations,
+                        saliency=None if saliency is None else saliency.numpy(),
+                        weight_constant_axis=weight_constant_axis, spline_markers=200)
+        return torch.from_numpy(ow.cwmm_predict(m, y128))
+
+
+class _OracleVMFMMTrainer:
+    _to_device = staticmethod(lambda x: x)
+
+    def fit_predict(self, y, initialization, iterations, saliency=None,
+                    weight_constant_axis=(-1,)):
+        from oracle import embed as oe
+        m = oe.vmfmm_fit(y.numpy(), initialization.numpy(), iterations=iterations,
+                         saliency=None if saliency is None else saliency.numpy(),
+                         weight_constant_axis=weight_constant_axis)
+        return torch.from_numpy(oe.vmfmm_predict(m, y.numpy()))
+
+
+def _trainer_worker(rank, world, port, ret):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from pb_bss_amd.sharding import fit_predict_sharded
+        from pb_bss_amd.testing import synth
+        ok = True
+        # Watson mixture: bins are independent problems (cwmm.py:76-149)
+        Y, init = synth.make_stft(9, 50, 4, 2, seed=5)
+        sal = np.random.default_rng(1).uniform(0.5, 1.0, size=(9, 50))
+        for kw in ({}, {'saliency': torch.from_numpy(sal)}):
+            full = _OracleCWMMTrainer().fit_predict(torch.from_numpy(Y), torch.from_numpy(init), 3, **kw)
+            got = fit_predict_sharded(torch.from_numpy(Y), torch.from_numpy(init), 3,
+                                      trainer=_OracleCWMMTrainer(), **kw)
+            ok = ok and got.shape == full.shape and float((got - full).abs().max()) < 1e-12
+        # more ranks than bins: rank 1 owns nothing
+        got = fit_predict_sharded(torch.from_numpy(Y[:1]), torch.from_numpy(init[:1]), 2,
+                                  trainer=_OracleCWMMTrainer)
+        full = _OracleCWMMTrainer().fit_predict(torch.from_numpy(Y[:1]), torch.from_numpy(init[:1]), 2)
+        ok = ok and float((got - full).abs().max()) < 1e-12
+        # vMF mixture with an independent leading axis (vmfmm.py:124-172): (B, N, E), (B, K, N)
+        rng = np.random.default_rng(2)
+        emb = rng.standard_normal((5, 40, 6))
+        ini = rng.uniform(size=(5, 3, 40))
+        ini /= ini.sum(axis=1, keepdims=True)
+        full = _OracleVMFMMTrainer().fit_predict(torch.from_numpy(emb), torch.from_numpy(ini), 3)
+        got = fit_predict_sharded(torch.from_numpy(emb), torch.from_numpy(ini), 3,
+                                  trainer=_OracleVMFMMTrainer(), bin_axis=0)
+        ok = ok and float((got - full).abs().max()) < 1e-12
+        # weights shared over the sharded axis need a collective only CACGMMTrainer has
+        try:
+            fit_predict_sharded(torch.from_numpy(Y), torch.from_numpy(init), 2,
+                                trainer=_OracleCWMMTrainer(), weight_constant_axis=(-3,))
+            ok = False
+        except NotImplementedError:
+            pass
+        ret[rank] = ok
+    finally:
+        dist.destroy_process_group()
+
+
+def test_fit_predict_sharded_other_trainers_world2():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_trainer_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}
+
+
+# ---------------------------------------------------------------------------------------------
+# Joint spatial + spectral models under bin sharding (BASELINE configs[4]): the spectral half
+# is ONE mixture over all F*T points, so its M-step sums are all-reduced once per EM iteration
+# (in the library: ncclAllReduce between the partial-sum kernel and the finalize kernel,
+# pbbss_mix_opts.sharded).  This test pins the DECOMPOSITION the kernels rely on -- local
+# weighted sums (S0, S1, then S2 about the global mean), one all-reduce each, the reference's
+# formulas on the totals -- against the oracle's unsharded joint fit, over gloo.
+def _joint_worker(rank, world, port, ret):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from oracle import cacgmm as oc, embed as oe
+        from pb_bss_amd.sharding import all_reduce_sum
+        from pb_bss_amd.testing import synth
+        F, T, D, K, E = 7, 40, 3, 2, 5
+        Y, emb, init = synth.make_joint(F, T, D, K, E, seed=3, embedding_dtype=np.float64)
+        Y = Y.astype(np.complex128)
+        ref = oe.joint_fit('gaussian', Y, emb, init, iterations=4)
+        ref_aff = oe.joint_model_predict(ref, Y, emb)
+        lo, hi = shard_bounds(F, world, rank)
+        yn, e_loc = oe.unit_rows(Y[lo:hi]), emb[lo:hi]
+        aff, q, model = init[lo:hi], np.ones_like(init[lo:hi]), None
+        for _ in range(4):
+            if model is not None:
+                aff, q = oe.joint_predict(model, yn, e_loc, 1e-10, False)
+            masked = aff                                                  # saliency = 1
+            flat = e_loc.reshape(-1, E)
+            mk = masked.transpose(1, 0, 2).reshape(K, -1)
+            s01 = torch.from_numpy(np.concatenate([mk.sum(-1, keepdims=True), mk @ flat], axis=1))
+            s01 = all_reduce_sum(s01).numpy()                             # (K, 1 + E) totals
+            mean = s01[:, 1:] / np.maximum(s01[:, :1], np.finfo(np.float64).tiny)
+            s2 = torch.from_numpy(np.einsum('kn,kne->k', mk, (flat[None] - mean[:, None]) ** 2))
+            s2 = all_reduce_sum(s2).numpy()
+            cov = s2 / (np.maximum(s01[:, 0], np.finfo(np.float64).tiny) * E)
+            eigvec, eigval = oc.cacg_m_step(np.swapaxes(yn[..., None, :, :], -1, -2), masked, q,
+                                            eigenvalue_floor=1e-10)
+            model = dict(kind='gaussian', weight=oe.joint_weight(masked, (-1,)),
+                         weight_constant_axis=(-1,), spatial_weight=1., spectral_weight=1.,
+                         mean=mean, covariance=cov, covariance_type='spherical',
+                         eigvec=eigvec, eigval=eigval)
+        got = oe.joint_predict(model, yn, e_loc)[0]
+        ok = float(np.abs(got - ref_aff[lo:hi]).max()) < 1e-10
+        ok = ok and float(np.abs(model['mean'] - ref['mean']).max()) < 1e-12
+        ok = ok and float(np.abs(model['covariance'] - ref['covariance']).max()) < 1e-12
+        full = all_gather_bins(torch.from_numpy(got), F, bin_axis=0).numpy()
+        ok = ok and float(np.abs(full - ref_aff).max()) < 1e-10
+        ret[rank] = ok
+    finally:
+        dist.destroy_process_group()
+
+
+def test_joint_model_spectral_sums_allreduce_world2():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_joint_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}
