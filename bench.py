@@ -9,31 +9,45 @@ EM iterations followed by the final E-step (fit_predict), with the complex64
 observation already resident in HBM.  At N GPUs the job is N utterances
 (weak scaling): every rank owns a contiguous block of ~513/N frequency bins of
 EVERY utterance, runs the EM with no collective in the loop, and the posterior
-masks are all-gathered over RCCL/xGMI at the end of each step (inside the timed region) (what
-permutation alignment needs).  value = N * iters * K / max-over-ranks time.
+masks are all-gathered over RCCL/xGMI at the end of each step (inside the timed
+region) -- what permutation alignment needs.  value = N * iters * K / max-over-ranks time.
 
-The JSON line also carries
+The ONE JSON line also carries
   roofline     -- the resource that bounds the dominant kernel: float64 VALU
                   (useful flops of the kernel's algorithm over its duration,
                   measured with HIP events on the launch stream inside the
                   library, against the 78.6 TFLOP/s FP64 vector peak); the
                   SURVEY.md section 8d contract figure -- algorithmic HBM bytes
                   8*F*T*D per EM iteration against 8 TB/s -- rides along as
-                  roofline.hbm_contract.  `traffic` (PMC FETCH_SIZE+WRITE_SIZE)
-                  is only reported when a committed profile was taken from
-                  exactly the kernel sources of this tree (source hash);
+                  roofline.hbm_contract.  `traffic` / `clock_ghz` (PMC) are only
+                  reported from a committed profile taken from exactly the kernel
+                  sources of this tree (source hash) AND whose kernel-trace median
+                  does not exceed this run's ms_per_step by more than 2 %;
+  sustained    -- the same step repeated for >= --sustained-s seconds after the K
+                  timed steps (DVFS give-back, and the driver's GPU-busy sampler
+                  gets something to see);
+  comm         -- (N > 1 or under torch.distributed.run) what RCCL saw: backend,
+                  world size, bytes gathered per step, gather time;
+  verify       -- device vs oracle after all iterations on bins drawn from EVERY
+                  rank's shard of EVERY utterance, and a checksum proving that all
+                  ranks hold bit-identical gathered masks;
   cpu_baseline -- the reference itself (kind "reference") when /root/reference
                   is importable, else the NumPy oracle (kind "port"), timed on
                   this host on a bounded sample (rank 0, N = 1 only);
-  mask_max_abs_err -- device vs oracle after all iterations on a bin subset.
+  config3      -- BASELINE configs[2] in the same run: a batch of 64 utterances
+                  through EM -> mask all-gather -> DHTV alignment -> PSD -> gev+ban
+                  -> apply (pb_bss_amd/pipeline.py), strong scaling: at N > 1 once
+                  with the bins and once with the utterances sharded over the ranks
+                  (`--config3 off` skips it);
+  f32          -- (when the library carries it) the reference-precision packed-FP32
+                  instantiation of the EM kernel as a second, separately labelled
+                  measurement; never the headline.
 
-`--workload config3` runs BASELINE configs[2] instead: a batch of 64 utterances
-through EM -> mask all-gather -> DHTV alignment -> PSD -> gev+ban -> apply
-(pb_bss_amd/pipeline.py), bins (`--shard bins`) or utterances (`--shard
-utterances`) sharded over the ranks; one JSON line, strong scaling.
+`--workload config3` prints the config-3 measurement as the primary line instead.
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -46,6 +60,7 @@ sys.path.insert(0, ROOT)
 F, T, D, K = 513, 500, 8, 3
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8 TB/s spec
 FP64_VALU_PEAK_TF = 78.6  # MI355X FP64 vector peak
+FP32_VALU_PEAK_TF = 157.3  # MI355X FP32 vector peak (packed)
 # float64 flops per frame per EM iteration (DESIGN.md "work model"):
 #   outer product P (E phase) 192 + (M phase) 192, q_k 2*D*D*K, acc 2*D*D*K, softmax ~100
 FLOPS_PER_FRAME_ITER = 2 * 192 + 2 * (2 * D * D * K) + 100
@@ -60,18 +75,37 @@ def parse():
     p.add_argument('--cpu-iters', type=int, default=100,
                    help='EM iterations of the CPU baseline sample (0 = skip)')
     p.add_argument('--check-bins', type=int, default=24,
-                   help='bins of utterance 0 checked against the oracle (0 = skip)')
+                   help='bins checked against the oracle per utterance at N = 1; at N > 1 '
+                        'max(3, check_bins / N^2) bins of EVERY rank\'s shard of EVERY utterance '
+                        '(0 = skip)')
+    p.add_argument('--preheat-s', type=float, default=1.0,
+                   help='seconds of untimed back-to-back steps BEFORE the W warm-up steps: from idle '
+                        'the chip needs tens of launches to ramp its shader clock up (rocprofv3 '
+                        'kernel trace: 1.83 -> 1.61 ms over the first 30 launches), a 30 ms timed '
+                        'region would otherwise measure the ramp, not the kernel; reported in the '
+                        'line as `preheat` (0 = off)')
+    p.add_argument('--sustained-s', type=float, default=2.0,
+                   help='seconds of back-to-back steps after the timed region (0 = skip)')
     p.add_argument('--workload', choices=['config2', 'config3'], default='config2',
-                   help='config2: BASELINE configs[1] (headline); config3: configs[2], the batch '
-                        'of utterances through EM + alignment + gev+ban')
+                   help='config2: BASELINE configs[1] (headline, with the config-3 legs inside the '
+                        'same line); config3: configs[2] as the primary line')
+    p.add_argument('--config3', choices=['auto', 'off'], default='auto',
+                   help='auto: also run BASELINE configs[2] (64 utterances through the chain) and '
+                        'carry it in the line -- at N > 1 with the bins and with the utterances '
+                        'sharded; off: headline only')
+    p.add_argument('--config3-steps', type=int, default=5)
     p.add_argument('--shard', choices=['bins', 'utterances'], default='bins',
-                   help='config3 with N > 1: what is sharded over the ranks')
+                   help='--workload config3 with N > 1: what is sharded over the ranks')
     p.add_argument('--utterances', type=int, default=64, help='config3 batch size')
     p.add_argument('--mask-gather', choices=['f64', 'f32'], default='f64',
-                   help='config3 --shard bins: dtype of the mask all-gather')
+                   help='config3, bins sharded: dtype of the mask all-gather')
+    p.add_argument('--beamformer', choices=['gev+ban', 'mvdr_souden'], default='gev+ban',
+                   help='config3 extraction stage')
     p.add_argument('--comm', choices=['torch', 'native'], default='torch',
                    help='mask all-gather through torch.distributed (RCCL) or through the '
                         'library\'s own RCCL communicator (C ABI pbbss_allgather_masks)')
+    p.add_argument('--f32', choices=['auto', 'off'], default='auto',
+                   help='auto: also measure the packed-FP32 instantiation when the library has it')
     p.add_argument('--print-source-sha', action='store_true',
                    help='print the hash of the EM kernel sources (tools/profile_round.sh stamps '
                         'it into the profile summaries) and exit')
@@ -104,69 +138,83 @@ def matching_profile():
     return None
 
 
-def pmc_traffic():
-    """HBM bytes per launch (main + concurrent split kernel) from the rocprofv3 PMC passes of
-    this same command (tools/profile_round.sh -> profiles/rNN_x_profile.txt):
-    (FETCH_SIZE + WRITE_SIZE) KiB.  PMC passes cannot run inside the timed bench, so the
-    figure is read back from a committed summary -- and only from one taken from exactly the
-    kernel sources of this tree; otherwise (None, reason)."""
-    path = matching_profile()
-    if path is None:
-        return None, ('no committed profile carries kernel_source_sha ' + kernel_source_sha() +
-                      ' (re-run tools/profile_round.sh on this tree)')
-    kib = 0.0
+def read_profile(path):
+    """Rows of a tools/profile_round.sh summary: {'pmc': {(kernel, counter): mean}, 'trace':
+    {'median_us', 'min_us', 'n'} of the measured EM-kernel launches, 'clock_ghz'}."""
+    out = {'pmc': {}, 'trace': None, 'clock_ghz': None}
     for line in open(path):
         parts = [x.strip() for x in line.split('|')]
-        if len(parts) == 4 and parts[1] in ('FETCH_SIZE', 'WRITE_SIZE'):
-            kib += float(parts[3])
+        if len(parts) == 4 and parts[1].isupper() and parts[2].isdigit():
+            try:
+                out['pmc'][(parts[0], parts[1])] = float(parts[3])
+            except ValueError:
+                pass
+        elif len(parts) == 5 and parts[0] == 'em_kernel_trace_us':
+            out['trace'] = {'median_us': float(parts[1]), 'min_us': float(parts[2]),
+                            'max_us': float(parts[3]), 'n': int(parts[4])}
+        elif len(parts) == 2 and parts[0] == 'main_clock_ghz':
+            out['clock_ghz'] = float(parts[1])
+    return out
+
+
+def pmc_evidence(ms_per_step):
+    """-> (traffic_bytes or None, clock_ghz or None, source / reason).  PMC passes cannot run
+    inside the timed bench, so the figures are read back from a committed summary -- only from one
+    taken from exactly the kernel sources of this tree, and only if that profile's own kernel
+    trace is consistent with this run: its median EM-kernel duration must not exceed this run's
+    ms_per_step by more than 2 % (a trace slower than the un-profiled step is not evidence)."""
+    path = matching_profile()
+    if path is None:
+        return None, None, ('no committed profile carries kernel_source_sha ' + kernel_source_sha() +
+                            ' (re-run tools/profile_round.sh on this tree)')
+    name = 'profiles/' + os.path.basename(path)
+    prof = read_profile(path)
+    if prof['trace'] is None:
+        return None, None, name + ' holds no em_kernel_trace_us row (old format)'
+    med_ms = prof['trace']['median_us'] * 1e-3
+    if ms_per_step is not None and med_ms > 1.02 * ms_per_step:
+        return None, None, (f'{name}: kernel-trace median {med_ms:.4f} ms exceeds this run\'s '
+                            f'ms_per_step {ms_per_step:.4f} by more than 2 %: not used as evidence')
+    kib = sum(v for (k, c), v in prof['pmc'].items() if c in ('FETCH_SIZE', 'WRITE_SIZE'))
     if kib == 0.0:
-        return None, 'profiles/' + os.path.basename(path) + ' holds no FETCH_SIZE / WRITE_SIZE rows'
-    return kib * 1024.0, ('profiles/' + os.path.basename(path) +
-                          ': FETCH_SIZE + WRITE_SIZE of both kernels, separate --pmc passes; the '
-                          'loads are 8 B/lane (not the 16 B/lane case the guide calibrates to x2): '
-                          'calibrated on the kernel itself -- compulsory reads (Y + initialisation) '
-                          '22.6 MB vs 21.2 MB counted')
+        return None, prof['clock_ghz'], name + ' holds no FETCH_SIZE / WRITE_SIZE rows'
+    fetch = sum(v for (k, c), v in prof['pmc'].items() if c == 'FETCH_SIZE') * 1024.0
+    compulsory = 8.0 * F * T * D + 8.0 * F * K * T  # one read of Y (complex64) + the initialisation
+    return kib * 1024.0, prof['clock_ghz'], (
+        f'{name}: FETCH_SIZE + WRITE_SIZE, separate --pmc passes, per launch; kernel-trace median '
+        f'{med_ms:.4f} ms over {prof["trace"]["n"]} measured launches; reads counted '
+        f'{fetch / 1e6:.1f} MB vs {compulsory / 1e6:.1f} MB compulsory (Y + initialisation)')
 
 
-def pmc_clock_ghz():
-    """Shader clock during the profiled EM kernel: GRBM_GUI_ACTIVE (one counter per XCD, summed
-    by rocprofv3) / 8 XCDs / kernel duration of that pass.  None without a matching profile."""
-    path = matching_profile()
-    if path is None:
-        return None
-    for line in open(path):
-        parts = [x.strip() for x in line.split('|')]
-        if len(parts) == 2 and parts[0] == 'main_clock_ghz':
-            return float(parts[1])
-    return None
-
-
-def roofline_block(kernel_ms, bins, iters, world_note=''):
+def roofline_block(kernel_ms, bins, iters, ms_per_step=None, world_note='', peak_tf=FP64_VALU_PEAK_TF,
+                   bound='fp64_valu', kernel='cacgmm_em_kernel<8,3,float,false>'):
     """roofline object for the EM kernel: float64 VALU is what bounds it (the observation is
-    LDS-resident, HBM traffic is 0.03x the contract figure), the section-8d HBM contract figure
+    LDS-resident, HBM traffic is 0.02x the contract figure), the section-8d HBM contract figure
     rides along."""
     avg_kernel_s = kernel_ms * 1e-3
     alg_bytes = 8.0 * bins * T * D * iters
     hbm = alg_bytes / avg_kernel_s / 1e9
     tflops = FLOPS_PER_FRAME_ITER * bins * T * iters / avg_kernel_s / 1e12
-    traffic, traffic_src = pmc_traffic() if (bins == F and iters == 100) else (
-        None, 'PMC traffic is only collected for the single-utterance headline command')
-    clock = pmc_clock_ghz()
+    if bins == F and iters == 100 and bound == 'fp64_valu':
+        traffic, clock, traffic_src = pmc_evidence(ms_per_step)
+    else:
+        traffic, clock, traffic_src = None, None, \
+            'PMC traffic is only collected for the single-utterance headline command'
     return {
-        'bound': 'fp64_valu', 'achieved': tflops, 'peak': FP64_VALU_PEAK_TF, 'unit': 'TFLOP/s',
-        'frac': tflops / FP64_VALU_PEAK_TF, 'traffic': traffic, 'traffic_source': traffic_src,
-        'kernel': 'cacgmm_em_kernel<8,3,float,false> (+ concurrent cacgmm_em_split_kernel for the '
-                  'remainder bins of a launch; kernel_ms brackets both)' + world_note,
+        'bound': bound, 'achieved': tflops, 'peak': peak_tf, 'unit': 'TFLOP/s',
+        'frac': tflops / peak_tf, 'traffic': traffic, 'traffic_source': traffic_src,
+        'kernel': kernel + ' (the remainder bins of a launch ride in the same grid as member '
+                           'workgroups; kernel_ms brackets the launch)' + world_note,
         'kernel_ms': kernel_ms,
         'flops_per_frame_iter': FLOPS_PER_FRAME_ITER,
-        'flops_note': 'useful float64 flops of the kernel\'s algorithm per frame and EM iteration: '
+        'flops_note': 'useful flops of the kernel\'s algorithm per frame and EM iteration: '
                       'Hermitian outer product P in the E phase (192) and again in the M phase '
                       '(192, it cannot stay resident: 256 KB per bin), q_k = <A_k, P> (2 D^2 K), '
                       'C_k += w_k P (2 D^2 K), softmax (~100)',
-        'peak_note': 'MI355X FP64 vector peak at 2.4 GHz; under this load the chip sustains '
-                     'clock_ghz (power management), see frac_at_sustained_clock',
+        'peak_note': 'MI355X vector peak of this arithmetic type at 2.4 GHz; under this load the '
+                     'chip sustains clock_ghz (power management), see frac_at_sustained_clock',
         'clock_ghz': clock,
-        'frac_at_sustained_clock': None if not clock else tflops / (FP64_VALU_PEAK_TF * clock / 2.4),
+        'frac_at_sustained_clock': None if not clock else tflops / (peak_tf * clock / 2.4),
         'hbm_contract': {
             'bound': 'hbm', 'achieved': hbm, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
             'frac': hbm / HBM_PEAK_GBS, 'algorithmic_bytes_per_launch': alg_bytes,
@@ -261,172 +309,144 @@ def setup(args):
     return world, rank, local_rank, dev, use_dist
 
 
-def timed(step, args, use_dist, dev):
-    """W warm-up steps, then EXACTLY K steps between barrier + synchronize; max over ranks."""
+def fence(use_dist):
     import torch
     import torch.distributed as dist
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize()
 
-    def fence():
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+def max_over_ranks(x, use_dist, dev):
+    import torch
+    import torch.distributed as dist
+    if not use_dist:
+        return x
+    tt = torch.tensor([x], dtype=torch.float64, device=dev)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    return float(tt.item())
+
+
+def preheat(step, seconds, use_dist, dev):
+    """Untimed steps until `seconds` have passed on the slowest rank (every rank runs the same
+    count: the step may contain a collective).  -> {'seconds', 'steps'} or None."""
+    if seconds <= 0:
+        return None
+    fence(use_dist)
+    t0 = time.perf_counter()
+    for _ in range(5):
         step()
-    fence()
+    fence(use_dist)
+    per = max_over_ranks((time.perf_counter() - t0) / 5, use_dist, dev)
+    n = max(0, int(math.ceil(seconds / max(per, 1e-6))) - 5)
+    for _ in range(n):
+        step()
+    fence(use_dist)
+    return {'seconds': time.perf_counter() - t0, 'steps': n + 5,
+            'note': 'untimed clock ramp before the W warm-up steps (--preheat-s)'}
+
+
+def timed(step, steps, warmup, use_dist, dev):
+    """W warm-up steps, then EXACTLY K steps between barrier + synchronize; max over ranks."""
+    for _ in range(warmup):
+        step()
+    fence(use_dist)
     t0 = time.perf_counter()
     last = None
     kernel_ms = 0.0
-    for _ in range(args.steps):
+    for _ in range(steps):
         last = step()
-        kernel_ms += last['kernel_ms']
-    fence()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    return elapsed, kernel_ms / args.steps, last
+        kernel_ms += last.get('kernel_ms', 0.0)
+    fence(use_dist)
+    elapsed = max_over_ranks(time.perf_counter() - t0, use_dist, dev)
+    return elapsed, kernel_ms / max(steps, 1), last
 
 
-def main_config3(args):
-    """BASELINE configs[2]: `--utterances` utterances of config 2 through the whole chain."""
+def sustained(step, seconds, ms_per_step, min_steps, use_dist, dev):
+    """The same step back to back for >= `seconds` (every rank runs the same count: the step may
+    contain a collective)."""
+    if seconds <= 0:
+        return None
+    n = max(min_steps, int(math.ceil(seconds * 1e3 / max(ms_per_step, 1e-3))))
+    fence(use_dist)
+    t0 = time.perf_counter()
+    kms = 0.0
+    for _ in range(n):
+        kms += step().get('kernel_ms', 0.0)
+    fence(use_dist)
+    el = max_over_ranks(time.perf_counter() - t0, use_dist, dev)
+    return {'seconds': el, 'steps': n, 'ms_per_step': el / n * 1e3, 'kernel_ms': kms / n,
+            'note': 'run right after the timed steps; a higher ms_per_step than the timed region '
+                    'is the chip\'s power management giving clock back under a sustained load'}
+
+
+def checksum(x):
+    """Three float64 numbers that pin a tensor bit for bit in practice (sum, sum of squares,
+    position-weighted sum) -- compared across ranks to prove they hold identical gathered data."""
     import torch
-    from pb_bss_amd.testing import synth
-    from pb_bss_amd import _lib, engine, pipeline
-    world, rank, local_rank, dev, use_dist = setup(args)
-    U = args.utterances
-    data = [synth.make_stft(F, T, D, K, seed=u) for u in range(U)]
-    Y = _lib.to_device(np.stack([d[0] for d in data]))          # (U, F, T, D) complex64
-    init = _lib.to_device(np.stack([d[1] for d in data]))       # (U, F, K, T) float64
-    shard = args.shard if use_dist and world > 1 else None
-    gdt = torch.float32 if args.mask_gather == 'f32' else None
-    engine.set_timing(True, local_rank)
-
-    def step():
-        out = pipeline.separate(Y, init, args.iters, 2 * (F - 1), shard=shard,
-                                mask_gather_dtype=gdt)
-        out['kernel_ms'] = 0.0  # per-stage times are taken in a separate, untimed pass below
-        return out
-
-    elapsed, _, out = timed(step, args, use_dist, dev)
-    line = None
-    if rank == 0:
-        # untimed pass with a synchronisation after every stage: where the step time goes
-        stages = {}
-        if shard is None:
-            from pb_bss_amd.pipeline import device_ops as ops, _chain_after_masks
-
-            def lap(name, fn):
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                r = fn()
-                torch.cuda.synchronize()
-                stages[name] = (time.perf_counter() - t1) * 1e3
-                return r
-            masks = lap('em_fit_predict_ms', lambda: ops.em_masks(Y, init, args.iters))
-            em_kernel_ms = engine.last_kernel_ms(local_rank)
-            mapping = lap('dhtv_mapping_ms', lambda: ops.dhtv_mapping(
-                masks.transpose(-3, -2).contiguous(), 2 * (F - 1)))
-            lap('align_psd_gev_ban_apply_ms', lambda: _chain_after_masks(Y, masks, mapping, ops))
-        else:
-            em_kernel_ms = None
-        res = {
-            'metric': 'cACGMM EM iterations/sec on F=513,T=500,D=8,K=3',
-            'value': U * args.iters * args.steps / elapsed,
-            'unit': 'EM iterations/s (utterance-iterations, whole job; every step also runs DHTV '
-                    'alignment, PSD, gev+ban and apply for all utterances)',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': elapsed / args.steps * 1e3,
-            'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
-            'dtype': 'f64', 'data': 'synthetic',
-            'config': {
-                'workload': f'BASELINE configs[2]: batch of {U} utterances, 8-mic 3-source cACGMM '
-                            f'(F=513 T=500 D=8 K=3, {args.iters} EM iterations) + DHTV permutation '
-                            f'alignment + PSD + gev+ban beamformer + apply, complex64 STFTs resident '
-                            f'in HBM',
-                'utterances': U, 'em_iterations_per_step': args.iters,
-                'sharding': ('none (1 GPU)' if shard is None else
-                             f'{shard} over {world} ranks' +
-                             (f'; one RCCL all-gather of the masks ({args.mask_gather}) + one of the '
-                              f'(U, K, F) mappings per step' if shard == 'bins' else
-                              '; no collective')),
-                'utterances_per_s': U * args.steps / elapsed,
-            },
-            'stage_ms_untimed_pass': stages or None,
-        }
-        if em_kernel_ms:
-            res['roofline'] = roofline_block(em_kernel_ms, U * F, args.iters,
-                                             f'; here one launch over {U * F} bins, three workgroups per CU')
-        if args.check_bins:
-            from oracle import cacgmm as oc, permutation_alignment as op
-            nb = min(args.check_bins, F)
-            Y0 = data[0][0][:nb].astype(np.complex128)
-            ref = oc.em_predict(oc.em_fit(Y0, data[0][1][:nb], iterations=args.iters), Y0)  # (nb,K,T)
-            mapping0 = _lib.to_host(out['mapping'])[0]                                      # (K, F)
-            got = _lib.to_host(out['masks'])[0]                                             # (K, F', T)
-            # undo the alignment on the checked bins: aligned[k, f] = masks[mapping[k, f], f]
-            err = 0.0
-            for f in range(min(nb, got.shape[1])):
-                err = max(err, float(np.abs(got[:, f] - ref[f][mapping0[:, f]]).max()))
-            res['mask_max_abs_err'] = err
-            res['mask_err_bins_checked'] = nb
-        if world == 1 and args.cpu_iters > 0:
-            from oracle import beamformer as ob, cacgmm as oc, permutation_alignment as op
-            Y128 = data[0][0].astype(np.complex128)
-            t1 = time.perf_counter()
-            m = oc.em_predict(oc.em_fit(Y128, data[0][1], iterations=args.cpu_iters), Y128)
-            kft = m.transpose(1, 0, 2)
-            plan = op.alignment_plan(2 * (F - 1), **op.PRESETS[2 * (F - 1)])
-            al = op.apply_mapping(kft, op.dhtv_calculate_mapping(kft, plan))
-            X = Y128.transpose(0, 2, 1)
-            psd = ob.psd(X, al.transpose(1, 0, 2))
-            for k in range(K):
-                ob.apply_bf(ob.bf_vector('gev+ban', psd[:, k], psd.sum(1) - psd[:, k]), X)
-            dt = time.perf_counter() - t1
-            res['cpu_baseline'] = {
-                'value': args.cpu_iters / dt, 'unit': 'EM iterations/s', 'cores': 1, 'kind': 'port',
-                'sample': f'NumPy oracle chain (EM {args.cpu_iters} iterations + DHTV + gev+ban + '
-                          f'apply) on ONE of the {U} utterances, {dt:.1f} s; host has '
-                          f'{os.cpu_count()} logical cores',
-            }
-        line = json.dumps(res)
-    emit(line, use_dist)
+    v = x.reshape(-1).to(torch.float64)
+    w = (torch.arange(v.numel(), device=v.device, dtype=torch.float64) % 1021.0) + 1.0
+    return torch.stack([v.sum(), (v * v).sum(), (v * w).sum()])
 
 
-def main():
-    args = parse()
-    if args.print_source_sha:
-        print(kernel_source_sha())
-        return
-    if args.workload == 'config3':
-        return main_config3(args)
+def identical_on_all_ranks(x, use_dist, world):
     import torch
     import torch.distributed as dist
+    c = checksum(x)
+    if not use_dist:
+        return True
+    allc = torch.empty((world, 3), dtype=torch.float64, device=c.device)
+    dist.all_gather_into_tensor(allc, c.unsqueeze(0).contiguous())
+    return bool((allc == allc[0:1]).all().item())
+
+
+def spread(lo, hi, n):
+    """n bins of [lo, hi) including the first and the last."""
+    if hi - lo <= n:
+        return list(range(lo, hi))
+    return sorted({lo + int(round(i * (hi - 1 - lo) / (n - 1))) for i in range(n)})
+
+
+def comm_block(args, use_dist, world, bytes_per_rank_step, gather_ms, what):
+    if not use_dist:
+        return None
+    import ctypes
+    import torch.distributed as dist
+    from pb_bss_amd import _lib, sharding
+    blk = {'backend': dist.get_backend(), 'world_size': dist.get_world_size(),
+           'communicator': args.comm, 'what': what,
+           'bytes_received_per_rank_per_step': bytes_per_rank_step, 'gather_ms': gather_ms}
+    if gather_ms:
+        blk['gather_GBps_per_rank'] = bytes_per_rank_step / (gather_ms * 1e-3) / 1e9
+    if args.comm == 'native' and sharding.native_comm() is not None:
+        w, r = ctypes.c_int(-1), ctypes.c_int(-1)
+        if _lib.load().pbbss_comm_info(_lib.handle(), ctypes.byref(w), ctypes.byref(r)) == 0:
+            blk['rccl_comm_count'] = w.value  # ncclCommCount of the library's communicator
+    return blk
+
+
+# ------------------------------------------------------------------------------------------
+# headline: BASELINE configs[1]
+# ------------------------------------------------------------------------------------------
+def run_headline(args, world, rank, local_rank, dev, use_dist, precision='f64'):
+    import torch
     from pb_bss_amd.testing import synth  # input generator shared with the parity tests
     from pb_bss_amd import _lib, engine
     from pb_bss_amd.sharding import all_gather_bins, shard_bounds
-    world, rank, local_rank, dev, use_dist = setup(args)
 
     # ---- workload: `world` utterances, this rank's block of bins of each ----
     lo, hi = shard_bounds(F, world, rank)
-    ys, inits = [], []
-    Y0 = init0 = None
-    for u in range(world):
-        Y, init = synth.make_stft(F, T, D, K, seed=u)
-        if u == 0:
-            Y0, init0 = Y, init
-        ys.append(Y[lo:hi])
-        inits.append(init[lo:hi])
-    y = _lib.to_device(np.concatenate(ys))        # (world*(hi-lo), T, D) complex64
-    g0 = _lib.to_device(np.concatenate(inits))    # (world*(hi-lo), K, T) float64
+    data = [synth.make_stft(F, T, D, K, seed=u) for u in range(world)]
+    y = _lib.to_device(np.concatenate([d[0][lo:hi] for d in data]))   # (world*(hi-lo), T, D) c64
+    g0 = _lib.to_device(np.concatenate([d[1][lo:hi] for d in data]))  # (world*(hi-lo), K, T) f64
     n_loc = hi - lo
     engine.set_timing(True, local_rank)
+    fit_kw = {} if precision == 'f64' else {'precision': 'f32'}
 
     def step():
         r = engine.em_fit(y, K, gamma0=g0, iterations=args.iters, final_predict=True,
-                          check_status=False)
+                          check_status=False, **fit_kw)
         ms = engine.last_kernel_ms(local_rank)  # HIP events on the launch stream
         masks = r['affiliation'].reshape(world, n_loc, K, T)
         if use_dist:
@@ -438,45 +458,367 @@ def main():
             masks = all_gather_bins(masks, F, bin_axis=1)
         return {'masks': masks, 'kernel_ms': ms, 'r': r}
 
-    elapsed, kernel_ms, last = timed(step, args, use_dist, dev)
+    ph = preheat(step, args.preheat_s, use_dist, dev)
+    elapsed, kernel_ms, last = timed(step, args.steps, args.warmup, use_dist, dev)
+    ms_per_step = elapsed / args.steps * 1e3
+    sus = sustained(step, args.sustained_s, ms_per_step, args.steps, use_dist, dev)
     masks, r = last['masks'], last['r']
 
+    # ---- the exchange step on its own (untimed region): HIP events around the gather ----
+    gather_ms = None
+    if use_dist:
+        loc = r['affiliation'].reshape(world, n_loc, K, T)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        fence(use_dist)
+        e0.record()
+        for _ in range(10):
+            all_gather_bins(loc, F, bin_axis=1)
+        e1.record()
+        torch.cuda.synchronize()
+        gather_ms = max_over_ranks(e0.elapsed_time(e1) / 10, use_dist, dev)
+    same = identical_on_all_ranks(masks, use_dist, world)
+    st = _lib.to_host(r['status'])
+    status_or = int(np.bitwise_or.reduce(st.ravel()))
+    if use_dist:
+        tt = torch.tensor([status_or], dtype=torch.int64, device=dev)
+        import torch.distributed as dist
+        dist.all_reduce(tt, op=dist.ReduceOp.BOR)
+        status_or = int(tt.item())
+    if rank != 0:
+        return None
+
+    arith = 'f64' if precision == 'f64' else 'f32'
+    out = {
+        'metric': 'cACGMM EM iterations/sec on F=513,T=500,D=8,K=3',
+        'value': world * args.iters * args.steps / elapsed,
+        'unit': 'EM iterations/s (utterance-iterations, whole job)',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': ms_per_step,
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': arith, 'data': 'synthetic',
+        'config': {
+            'workload': 'BASELINE configs[1]: 8-mic 3-source cACGMM, F=513 T=500 D=8 K=3, '
+                        'complex64 STFT resident in HBM, fit_predict' +
+                        ('' if precision == 'f64' else
+                         ' -- REFERENCE-PRECISION instantiation: packed-FP32 E/M phases (the '
+                         'reference\'s own arithmetic for complex64 input + ndarray '
+                         'initialisation, cacgmm.py:226-227), float64 class sums and '
+                         'factorisation; NOT the headline'),
+            'em_iterations_per_step': args.iters, 'utterances': world,
+            'sharding': (f'frequency bins, {n_loc} of {F} per rank per utterance; RCCL mask '
+                         'all-gather per step (' + args.comm + ' communicator), in stream order '
+                         'after the EM kernel') if use_dist else 'none (1 GPU)',
+        },
+        'status_bits_or': status_or,
+        'preheat': ph,
+        'sustained': sus,
+    }
+    if precision == 'f64':
+        out['roofline'] = roofline_block(kernel_ms, world * n_loc, args.iters, ms_per_step)
+    else:
+        out['roofline'] = roofline_block(
+            kernel_ms, world * n_loc, args.iters, ms_per_step, peak_tf=FP32_VALU_PEAK_TF,
+            bound='fp32_valu', kernel='cacgmm_em32_kernel<8,3>')
+    if sus:
+        out['sustained']['value'] = world * args.iters * sus['steps'] / sus['seconds']
+    cb = comm_block(args, use_dist, world, (world * F * K * T * 8) * (world - 1) // max(world, 1),
+                    gather_ms, f'all-gather of the posterior masks ({world} utterances x {F} bins x '
+                               f'{K} x {T} float64) once per step')
+    if cb:
+        out['comm'] = cb
+    # ---- parity: bins of EVERY rank's shard of EVERY utterance (oracle = checker only) ----
+    if args.check_bins:
+        from oracle import cacgmm as oc
+        nb = args.check_bins if world == 1 else max(3, args.check_bins // (world * world))
+        got_all = _lib.to_host(masks)                              # (world, F, K, T) gathered
+        worst, per_shard, nchk = 0.0, [0.0] * world, 0
+        tol = 1e-5
+        for u in range(world):
+            sel = []
+            for rr in range(world):
+                slo, shi = shard_bounds(F, world, rr)
+                sel += [(rr, f) for f in spread(slo, shi, nb)]
+            fs = [f for _, f in sel]
+            Y128 = data[u][0][fs].astype(np.complex128)
+            if precision == 'f64':
+                ref = oc.em_predict(oc.em_fit(Y128, data[u][1][fs], iterations=args.iters), Y128)
+            else:
+                ref = None
+            for j, (rr, f) in enumerate(sel):
+                if ref is None:
+                    continue
+                e = float(np.abs(got_all[u, f] - ref[j]).max())
+                per_shard[rr] = max(per_shard[rr], e)
+                worst = max(worst, e)
+            nchk += len(sel)
+        out['mask_max_abs_err'] = worst
+        out['mask_err_bins_checked'] = nchk
+        out['verify'] = {
+            'bins_checked': nchk, 'bins_per_shard_per_utterance': nb, 'utterances_checked': world,
+            'max_abs_err_per_rank_shard': per_shard, 'tolerance': tol,
+            'ok': bool(worst < tol),
+            'includes_remainder_bin': True,
+            'gathered_masks_identical_on_all_ranks': same,
+            'what': 'posterior masks after all EM iterations vs the float64 NumPy oracle on bins '
+                    'drawn from every rank\'s shard (first, last and evenly spaced bins) of every '
+                    'utterance; checksum of the gathered tensor compared across ranks',
+        }
+    return out, data[0]
+
+
+# ------------------------------------------------------------------------------------------
+# BASELINE configs[2]: a batch of utterances through the whole chain
+# ------------------------------------------------------------------------------------------
+def make_batch(U):
+    """U seeded utterances of config 2 (seed = utterance index), generated on a few threads."""
+    from concurrent.futures import ThreadPoolExecutor
+    from pb_bss_amd.testing import synth
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        return list(ex.map(lambda u: synth.make_stft(F, T, D, K, seed=u), range(U)))
+
+
+_ORACLE_CACHE = {}
+
+
+def oracle_bins(data, u, fs, iters):
+    """Oracle masks (nb, K, T) of bins `fs` of utterance u after `iters` iterations (cached:
+    the bins- and the utterances-sharded legs check the same bins)."""
+    from oracle import cacgmm as oc
+    key = (u, tuple(fs), iters)
+    if key not in _ORACLE_CACHE:
+        Y128 = data[u][0][fs].astype(np.complex128)
+        _ORACLE_CACHE[key] = oc.em_predict(oc.em_fit(Y128, data[u][1][fs], iterations=iters), Y128)
+    return _ORACLE_CACHE[key]
+
+
+def config3_leg(args, data, Y, init, shard, world, rank, dev, use_dist, steps, warmup):
+    """One measurement of pipeline.separate on the whole batch; returns the result dict on rank 0."""
+    import torch
+    from pb_bss_amd import _lib, pipeline
+    from pb_bss_amd.sharding import shard_bounds
+    U = Y.shape[0]
+    gdt = torch.float32 if args.mask_gather == 'f32' else None
+
+    def step():
+        return pipeline.separate(Y, init, args.iters, 2 * (F - 1), shard=shard,
+                                 mask_gather_dtype=gdt, beamformer=args.beamformer)
+
+    elapsed, _, _ = timed(step, steps, warmup, use_dist, dev)
+    # ---- untimed verification pass: outputs of ALL ranks gathered ----
+    out = pipeline.separate(Y, init, args.iters, 2 * (F - 1), shard=shard, mask_gather_dtype=gdt,
+                            beamformer=args.beamformer, gather_output=shard is not None)
+    map_same = identical_on_all_ranks(out['mapping'], use_dist and shard is not None, world)
+    enh_same = identical_on_all_ranks(torch.view_as_real(out['enhanced'].contiguous()),
+                                      use_dist and shard is not None, world)
+    if rank != 0:
+        return None
+    res = {
+        'value': U * args.iters * steps / elapsed,
+        'unit': 'EM iterations/s (utterance-iterations, whole job; every step also runs DHTV '
+                'alignment, PSD, ' + args.beamformer + ' and apply for all utterances)',
+        'ms_per_step': elapsed / steps * 1e3, 'steps': steps, 'warmup': warmup,
+        'utterances_per_s': U * steps / elapsed, 'scaling': 'strong', 'n_gpus': world,
+        'sharding': ('none (1 GPU)' if shard is None else
+                     f'{shard} over {world} ranks' +
+                     (f'; one RCCL all-gather of the masks ({args.mask_gather}) + one of the '
+                      f'(U, K, F) mappings per step' +
+                      ('; one all-reduce of the Souden reference-channel sums'
+                       if args.beamformer == 'mvdr_souden' else '')
+                      if shard == 'bins' else '; no collective')),
+    }
+    if shard == 'bins' and use_dist:
+        per_rank = U * F * K * T * (4 if gdt is not None else 8) * (world - 1) // world
+        res['comm'] = comm_block(args, use_dist, world, per_rank, None,
+                                 'mask all-gather + (U, K, F) int64 mapping all-gather per step')
+    if args.check_bins:
+        from oracle import beamformer as ob
+        # one utterance of every rank's utterance share, bins of every rank's bin shard
+        us = sorted({shard_bounds(U, world, rr)[0] for rr in range(world)} | {U - 1})
+        if world == 1:
+            us = sorted({0, U - 1})
+        nb = max(2, 12 // world)
+        fs = sorted({f for rr in range(world) for f in spread(*shard_bounds(F, world, rr), nb)})
+        mapping = _lib.to_host(out['mapping'])                     # (U, K, F)
+        got = _lib.to_host(out['masks'])                           # (U, K, F, T) aligned
+        enh = _lib.to_host(out['enhanced'])                        # (U, K, F, T) complex
+        m_err = e_err = 0.0
+        perm_ok = True
+        for u in us:
+            ref = oracle_bins(data, u, fs, args.iters)             # (nb, K, T)
+            X = data[u][0][fs].astype(np.complex128).transpose(0, 2, 1)
+            al = np.stack([ref[j][mapping[u][:, f]] for j, f in enumerate(fs)])   # (nb, K, T)
+            for j, f in enumerate(fs):
+                perm_ok = perm_ok and sorted(mapping[u][:, f].tolist()) == list(range(K))
+                m_err = max(m_err, float(np.abs(got[u][:, f] - al[j]).max()))
+            if args.beamformer == 'gev+ban':
+                psd = ob.psd(X, al)                                # (nb, K, D, D)
+                for k in range(K):
+                    w = ob.bf_vector('gev+ban', psd[:, k], psd.sum(1) - psd[:, k])
+                    s = np.abs(ob.apply_bf(w, X))                  # GEV phase is arbitrary: moduli
+                    d = np.abs(np.abs(enh[u][k][fs]) - s).max() / max(float(s.max()), 1e-300)
+                    e_err = max(e_err, float(d))
+        res['verify'] = {
+            'utterances_checked': us, 'bins_checked_per_utterance': fs,
+            'mask_max_abs_err': m_err, 'enhanced_modulus_max_rel_err':
+                e_err if args.beamformer == 'gev+ban' else None,
+            'mapping_columns_are_permutations': perm_ok,
+            'mapping_identical_on_all_ranks': map_same,
+            'enhanced_identical_on_all_ranks': enh_same,
+            'tolerance': 1e-5, 'ok': bool(m_err < 1e-5 and e_err < 1e-5 and perm_ok and map_same),
+            'what': 'aligned masks of bins from every rank\'s bin shard, of one utterance of every '
+                    'rank\'s utterance share, vs the NumPy oracle EM with the device mapping '
+                    'applied; |enhanced| vs the oracle PSD -> gev+ban -> apply on those bins',
+        }
+        res['_mapping_checksum'] = [float(v) for v in checksum(out['mapping']).tolist()]
+    return res
+
+
+def run_config3(args, world, rank, local_rank, dev, use_dist, primary=False):
+    """All config-3 legs of this run -> dict (rank 0) or None."""
+    from pb_bss_amd import _lib
+    U = args.utterances
+    data = make_batch(U)
+    Y = _lib.to_device(np.stack([d[0] for d in data]))          # (U, F, T, D) complex64
+    init = _lib.to_device(np.stack([d[1] for d in data]))       # (U, F, K, T) float64
+    steps = args.steps if primary else args.config3_steps
+    warmup = args.warmup if primary else 1
+    legs = {}
+    if use_dist and world > 1:
+        shards = [args.shard] if primary else ['bins', 'utterances']
+        for sh in shards:
+            legs[sh] = config3_leg(args, data, Y, init, sh, world, rank, dev, use_dist, steps, warmup)
+    else:
+        legs['single'] = config3_leg(args, data, Y, init, None, world, rank, dev, use_dist, steps,
+                                     warmup)
+    if rank != 0:
+        return None, data
+    blk = {
+        'workload': f'BASELINE configs[2]: batch of {U} utterances, 8-mic 3-source cACGMM '
+                    f'(F=513 T=500 D=8 K=3, {args.iters} EM iterations) + DHTV permutation '
+                    f'alignment + PSD + {args.beamformer} beamformer + apply, complex64 STFTs '
+                    f'resident in HBM',
+        'utterances': U, 'em_iterations_per_step': args.iters, 'scaling': 'strong',
+    }
+    sums = {k: v.pop('_mapping_checksum', None) for k, v in legs.items() if v}
+    if len(sums) == 2 and all(sums.values()):
+        a, b = list(sums.values())
+        blk['mapping_identical_across_shardings'] = bool(a == b)
+    blk.update(legs)
+    return blk, data
+
+
+def config3_stage_times(args, Y, init, local_rank):
+    """Untimed pass with a synchronisation after every stage: where the step time goes (1 GPU)."""
+    import torch
+    from pb_bss_amd import engine
+    from pb_bss_amd.pipeline import device_ops as ops, _chain_after_masks
+    stages = {}
+
+    def lap(name, fn):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        r = fn()
+        torch.cuda.synchronize()
+        stages[name] = (time.perf_counter() - t1) * 1e3
+        return r
+    masks = lap('em_fit_predict_ms', lambda: ops.em_masks(Y, init, args.iters))
+    em_kernel_ms = engine.last_kernel_ms(local_rank)
+    mapping = lap('dhtv_mapping_ms', lambda: ops.dhtv_mapping(
+        masks.transpose(-3, -2).contiguous(), 2 * (F - 1)))
+    lap('align_psd_bf_apply_ms', lambda: _chain_after_masks(Y, masks, mapping, ops, args.beamformer))
+    return stages, em_kernel_ms
+
+
+def main_config3(args):
+    """`--workload config3`: BASELINE configs[2] as the primary line."""
+    from pb_bss_amd import _lib, engine
+    world, rank, local_rank, dev, use_dist = setup(args)
+    engine.set_timing(True, local_rank)
+    blk, data = run_config3(args, world, rank, local_rank, dev, use_dist, primary=True)
     line = None
     if rank == 0:
-        out = {
+        leg = next(v for k, v in blk.items() if isinstance(v, dict) and 'value' in v)
+        res = {
             'metric': 'cACGMM EM iterations/sec on F=513,T=500,D=8,K=3',
-            'value': world * args.iters * args.steps / elapsed,
-            'unit': 'EM iterations/s (utterance-iterations, whole job)',
+            'value': leg['value'], 'unit': leg['unit'],
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': elapsed / args.steps * 1e3,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'ms_per_step': leg['ms_per_step'],
+            'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
             'dtype': 'f64', 'data': 'synthetic',
-            'config': {
-                'workload': 'BASELINE configs[1]: 8-mic 3-source cACGMM, F=513 T=500 D=8 K=3, '
-                            'complex64 STFT resident in HBM, fit_predict',
-                'em_iterations_per_step': args.iters, 'utterances': world,
-                'sharding': (f'frequency bins, {n_loc} of {F} per rank per utterance; RCCL mask '
-                             'all-gather per step (' + args.comm + ' communicator), in stream order after the EM kernel') if use_dist else 'none (1 GPU)',
-            },
-            'roofline': roofline_block(kernel_ms, world * n_loc, args.iters),
+            'config': {'workload': blk['workload'], 'utterances': blk['utterances'],
+                       'em_iterations_per_step': args.iters, 'sharding': leg['sharding'],
+                       'utterances_per_s': leg['utterances_per_s']},
         }
-        st = _lib.to_host(r['status'])
-        out['status_bits_or'] = int(np.bitwise_or.reduce(st.ravel()))
-        # ---- parity on a bin subset of utterance 0 (oracle = checker only) ----
-        if args.check_bins and lo == 0:
-            from oracle import cacgmm as oc
-            nb = min(args.check_bins, n_loc)
-            Y128 = Y0[:nb].astype(np.complex128)
-            m = oc.em_fit(Y128, init0[:nb], iterations=args.iters)
-            ref = oc.em_predict(m, Y128)
-            got = _lib.to_host(masks[0, :nb])
-            out['mask_max_abs_err'] = float(np.abs(got - ref).max())
-            out['mask_err_bins_checked'] = nb
+        for k in ('verify', 'comm'):
+            if k in leg:
+                res[k] = leg[k]
+        if 'verify' in leg:
+            res['mask_max_abs_err'] = leg['verify']['mask_max_abs_err']
+        if world == 1:
+            U = args.utterances
+            Y = _lib.to_device(np.stack([d[0] for d in data]))
+            init = _lib.to_device(np.stack([d[1] for d in data]))
+            stages, em_kernel_ms = config3_stage_times(args, Y, init, local_rank)
+            res['stage_ms_untimed_pass'] = stages
+            if em_kernel_ms:
+                res['roofline'] = roofline_block(
+                    em_kernel_ms, U * F, args.iters, None,
+                    f'; here one launch over {U * F} bins, three workgroups per CU')
+            if args.cpu_iters > 0:
+                from oracle import beamformer as ob, cacgmm as oc, permutation_alignment as op
+                Y128 = data[0][0].astype(np.complex128)
+                t1 = time.perf_counter()
+                m = oc.em_predict(oc.em_fit(Y128, data[0][1], iterations=args.cpu_iters), Y128)
+                kft = m.transpose(1, 0, 2)
+                plan = op.alignment_plan(2 * (F - 1), **op.PRESETS[2 * (F - 1)])
+                al = op.apply_mapping(kft, op.dhtv_calculate_mapping(kft, plan))
+                X = Y128.transpose(0, 2, 1)
+                psd = ob.psd(X, al.transpose(1, 0, 2))
+                for k in range(K):
+                    ob.apply_bf(ob.bf_vector('gev+ban', psd[:, k], psd.sum(1) - psd[:, k]), X)
+                dt = time.perf_counter() - t1
+                res['cpu_baseline'] = {
+                    'value': args.cpu_iters / dt, 'unit': 'EM iterations/s', 'cores': 1, 'kind': 'port',
+                    'sample': f'NumPy oracle chain (EM {args.cpu_iters} iterations + DHTV + gev+ban + '
+                              f'apply) on ONE of the {U} utterances, {dt:.1f} s; host has '
+                              f'{os.cpu_count()} logical cores',
+                }
+        line = json.dumps(res)
+    emit(line, use_dist)
+
+
+def has_f32():
+    from pb_bss_amd import _lib
+    return hasattr(_lib.load(), 'pbbss_cacgmm_fit32')
+
+
+def main():
+    args = parse()
+    if args.print_source_sha:
+        print(kernel_source_sha())
+        return
+    if args.workload == 'config3':
+        return main_config3(args)
+    world, rank, local_rank, dev, use_dist = setup(args)
+    res = run_headline(args, world, rank, local_rank, dev, use_dist)
+    out = None
+    if rank == 0:
+        out, (Y0, init0) = res
         # ---- CPU baseline on this host, bounded sample ------------------------
         if world == 1 and args.cpu_iters > 0:
             out['cpu_baseline'] = cpu_baseline_em(Y0, init0, args.cpu_iters)
-        line = json.dumps(out)
-    emit(line, use_dist)
+    if args.f32 == 'auto' and has_f32():
+        r32 = run_headline(args, world, rank, local_rank, dev, use_dist, precision='f32')
+        if rank == 0:
+            f32, _ = r32
+            out['f32'] = {k: f32[k] for k in ('value', 'unit', 'ms_per_step', 'dtype', 'config',
+                                              'roofline', 'status_bits_or', 'sustained')
+                          if k in f32}
+    if args.config3 == 'auto':
+        blk, _ = run_config3(args, world, rank, local_rank, dev, use_dist)
+        if rank == 0:
+            out['config3'] = blk
+    emit(json.dumps(out) if rank == 0 else None, use_dist)
 
 
 if __name__ == '__main__':

@@ -68,8 +68,12 @@ struct EmArgs {
   int64_t b_first;    // first problem handled by this launch
   double* xslab;      // [2][n_problems][G][slab_len] partial sums exchanged through L2
   unsigned* xcount;   // [n_problems] arrival counters (zeroed before the launch)
-  int* xerror;        // [0] set to 1 if a bounded spin of THIS launch ran out; [16] sticky copy
+  int* xerror;        // [0] set to `xepoch` if a bounded spin of THIS launch ran out; [16] sticky copy
+  int xepoch;         // launch stamp of the split protocol (0: the word is cleared by the launcher)
   int split_prio;     // s_setprio level of the split waves (0..3)
+  // Split groups INSIDE the main launch: blocks >= main_grid are the members of the remainder
+  // problems (one launch, one stream, nothing to fork or join); 0: every block is a full workgroup.
+  int main_grid;
   // ---- weights shared across problems (run_shared: weight_mode PBBSS_WEIGHT_SHARED_*) ----
   int wgroup;          // problems (frequency bins) that share one set of mixture weights
   double* gsum;        // SHARED_K : [2][B][K]     masked class sums of every problem
@@ -1216,8 +1220,14 @@ struct EmKernel {
   // of run_split: order-independent atomic ORs onto status words zeroed before the launch), the
   // sticky word backs pbbss_split_error().
   static __device__ void split_timeout(const EmArgs& a) {
-    atomicExch(a.xerror, 1);
+    atomicExch(a.xerror, a.xepoch ? a.xepoch : 1);
     atomicExch(a.xerror + 16, 1);
+  }
+  // did a bounded spin of THIS launch run out?  (launches stamp the word with their epoch, so it
+  // never has to be cleared between launches; xepoch == 0: the launcher zeroes it)
+  static __device__ bool split_failed(const EmArgs& a) {
+    const int v = __hip_atomic_load(a.xerror, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return a.xepoch ? (v == a.xepoch) : (v != 0);
   }
 
   static __device__ void split_exchange(const EmArgs& a, const Lds& L, int prob, int nprob, int g,
@@ -1505,13 +1515,15 @@ struct EmKernel {
     __syncthreads();
   }
 
-  static __device__ void run_split(const EmArgs& ga, char* smem) {
+  // mblock / nblocks: index of this member workgroup among the member workgroups of the launch
+  // (the whole grid of the stand-alone split kernel; the blocks behind main_grid of the EM kernel)
+  static __device__ void run_split(const EmArgs& ga, char* smem, int mblock, int nblocks) {
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     const int G = ga.split_groups;
-    const int prob = blockIdx.x / G, g = blockIdx.x % G;
-    const int nprob = gridDim.x / G;
+    const int prob = mblock / G, g = mblock % G;
+    const int nprob = nblocks / G;
     const int64_t b = ga.b_first + prob;
     const int tf = g * ga.split_window;
     // The split waves sit on CUs that also host two full workgroups; their work is a
@@ -1538,7 +1550,13 @@ struct EmKernel {
 #else
 #define PBBSS_STICK(i)
 #endif
-    if (tid < K) L.status[tid] = 0;
+    if (tid < K) {
+      L.status[tid] = 0;
+      // the members OR their bits into the status words at the end (order-independent); member 0
+      // zeroes them first -- a member that OR-ed a time-out in before this store is not lost:
+      // member 0 sees the same stamped error word at its own end and ORs the poison in again
+      if (g == 0 && a.out_status) a.out_status[(size_t)b * K + tid] = 0;
+    }
     if (tid == 0) *L.flags = 0;
     __syncthreads();
     phase_load(a, L, b, tid, tf);
@@ -1608,12 +1626,24 @@ struct EmKernel {
       // per-launch error word reports the solve as failed (NONFINITE -> the host raises), with
       // atomic ORs onto status words the launcher zeroed, so no ordering between the members'
       // exits is assumed.  Member 0 also contributes the regular status bits.
-      const int xerr = __hip_atomic_load(a.xerror, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const int bits = (g == 0 ? L.status[tid] : 0) |
-                       (xerr ? (PBBSS_ST_EIG_NOCONV | PBBSS_ST_NONFINITE) : 0);
+                       (split_failed(a) ? (PBBSS_ST_EIG_NOCONV | PBBSS_ST_NONFINITE) : 0);
       if (a.out_status && bits) atomicOr(a.out_status + (size_t)b * K + tid, bits);
     }
     if (a.final_predict) phase_e<true, false>(a, L, b, tid, wave, lane, a.final_eps, tf);
+    // Every member is past its last wait on the two arrival counters of this problem: the member
+    // that leaves last puts them back to zero, so the next launch needs no memset in front of it
+    // (xcount[8 + prob] counts the leavers).
+    if (tid == 0) {
+      unsigned* ex = a.xcount + 8 + prob;
+      const unsigned before =
+          __hip_atomic_fetch_add(ex, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (before == (unsigned)(G - 1)) {
+        __hip_atomic_store(a.xcount + prob, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(a.xcount + 16 + prob, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(ex, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
   }
 
   // ======== mixture weights shared by a group of problems =====================================
@@ -1852,7 +1882,7 @@ struct EmKernel {
     }
     if (tid < K && a.out_status) {
       int st = L.status[tid];
-      if (__hip_atomic_load(a.xerror, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+      if (split_failed(a))
         st |= PBBSS_ST_EIG_NOCONV | PBBSS_ST_NONFINITE;  // a hand-off timed out: results are void
       a.out_status[(size_t)b * K + tid] = st;
     }
@@ -1871,6 +1901,13 @@ struct EmKernel {
     // dispatch below is a scalar branch, not four exec-masked code paths
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
+    if constexpr (!SPILL) {
+      if (a.main_grid > 0 && (int)blockIdx.x >= a.main_grid) {
+        run_split(a, smem, (int)blockIdx.x - a.main_grid, (int)gridDim.x - a.main_grid);
+        return;
+      }
+    }
+    const int bstride = a.main_grid > 0 ? a.main_grid : (int)gridDim.x;
     const Lds L = carve(smem, a.T, SPILL ? a.scratch + (size_t)blockIdx.x * a.scratch_stride : nullptr);
 #ifdef PBBSS_PHASE_PROFILE
     unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1884,7 +1921,7 @@ struct EmKernel {
 #else
 #define PBBSS_TICK(i)
 #endif
-    for (int64_t b = blockIdx.x; b < a.B; b += gridDim.x) {
+    for (int64_t b = blockIdx.x; b < a.B; b += bstride) {
       __syncthreads();  // previous problem fully retired before LDS is reused
       if (tid < K) L.status[tid] = 0;
       if (tid == 0) *L.flags = 0;
@@ -1973,7 +2010,7 @@ __global__ void __launch_bounds__(kEmThreads, em_waves_per_simd(K)) cacgmm_em_sh
 template <int D, int K, typename YS>
 __global__ void __launch_bounds__(kEmThreads, em_waves_per_simd(K)) cacgmm_em_split_kernel(EmArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  EmKernel<D, K, YS, false>::run_split(a, smem);
+  EmKernel<D, K, YS, false>::run_split(a, smem, (int)blockIdx.x, (int)gridDim.x);
 }
 
 }  // namespace pbbss

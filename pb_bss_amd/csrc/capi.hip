@@ -24,6 +24,7 @@ struct pbbss_handle_s {
   size_t work_bytes;
   void* comm;         // RCCL communicator of pbbss_comm_create (one rank = this process), or null
   int comm_world, comm_rank;
+  int split_epoch;    // launch stamp of the split protocol (em_inst.hip: next_split_epoch)
   void* comm_buf;     // pack / gather buffers of pbbss_allgather_masks: owned by the communicator,
   size_t comm_bytes;  // never shared with the work slab (a collective may still be in flight)
   void* team_buf;     // control words + centroid partials of the DHTV team kernel
@@ -195,6 +196,10 @@ PBBSS_API int pbbss_create(pbbss_handle_t* out, int device_id) {
   h->cfg.split_window = pbbss::kSplitWindow;
   h->cfg.split_prio = 1;
   if (const char* p = getenv("PBBSS_SPLIT_PRIO")) h->cfg.split_prio = atoi(p);
+  h->cfg.split_inline = 1;
+  if (const char* p = getenv("PBBSS_SPLIT_INLINE")) h->cfg.split_inline = atoi(p) != 0;
+  h->split_epoch = 1;
+  h->cfg.split_epoch = &h->split_epoch;
   if (const char* w = getenv("PBBSS_SPLIT_WINDOW")) {
     int v = atoi(w);
     if (v >= 64 && v % 64 == 0) h->cfg.split_window = v;

@@ -20,6 +20,9 @@ struct EmLaunchCfg {
   int allow_split;   // 0 disables the split variant (tests / debugging)
   int split_window;  // frames per workgroup of a split problem (multiple of 64)
   int split_prio;    // s_setprio level of the split waves
+  int split_inline;  // 1: the split groups are member workgroups of the main launch (default);
+                     // 0: a second kernel on the side stream (PBBSS_SPLIT_INLINE=0, for A/B runs)
+  int* split_epoch;  // host counter stamping the launches of the split protocol
 };
 
 constexpr int kSplitWindow = 64;      // default frames per workgroup of a split problem

@@ -80,3 +80,111 @@ def test_allgather_without_comm_is_an_error():
     rc = _lib.load().pbbss_allgather_masks(_lib.handle(0), _lib.ptr(x), 8, 1, 2, 3, _lib.ptr(out),
                                            _lib.stream_ptr(0))
     assert rc != 0
+
+
+# ---------------------------------------------------------------------------------------------
+# The sharded paths of round 3 at world size 1 (the one GPU the suite has): every collective is
+# really enqueued on RCCL -- the mask all-gather, the all-reduce of the joint models' spectral
+# M-step sums inside pbbss_joint_fit (pbbss_mix_opts.sharded), the all-reduce of the Souden
+# reference-channel sums -- and must be the identity on the result.
+@pytest.fixture
+def world1_nccl():
+    import torch
+    import torch.distributed as dist
+    from pb_bss_amd import sharding
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29534')
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    sharding.init_native_comm()
+    try:
+        yield
+    finally:
+        sharding.destroy_native_comm()
+        if created:
+            dist.destroy_process_group()
+
+
+def test_comm_info_reports_what_rccl_sees(world1_nccl):
+    from pb_bss_amd import _lib
+    w, r = ctypes.c_int(-1), ctypes.c_int(-1)
+    assert _lib.load().pbbss_comm_info(_lib.handle(0), ctypes.byref(w), ctypes.byref(r)) == 0
+    assert (w.value, r.value) == (1, 0)
+
+
+@pytest.mark.parametrize('kind,kw', [
+    ('gaussian', dict()),
+    ('gaussian', dict(weight_constant_axis=(-3, -1))),
+    ('gaussian', dict(weight_constant_axis=(-3,), covariance_type='diagonal')),
+    ('vmf', dict(weight_constant_axis=(-3, -1), max_concentration=80.)),
+])
+def test_sharded_joint_fit_world1_equals_oracle(world1_nccl, kind, kw):
+    """fit_predict_sharded_joint: bins sliced, pbbss_joint_fit with opts.sharded = 1 (two-sweep
+    first iteration, ncclAllReduce between partial sums and finalize, reduced class weights),
+    masks gathered -- against the oracle's unsharded joint fit."""
+    from pb_bss_amd.distribution import GCACGMMTrainer, VMFCACGMMTrainer
+    from pb_bss_amd.distribution import _joint
+    from pb_bss_amd import sharding
+    from oracle import embed as oe, synth
+    F, T, D, K, E = 12, 200, 4, 3, 16
+    Y, e, init = synth.make_joint(F, T, D, K, E, seed=11)
+    sal = np.random.default_rng(1).uniform(0.2, 1.0, size=(F, T))
+    trainer = GCACGMMTrainer() if kind == 'gaussian' else VMFCACGMMTrainer()
+    # world size 1 would skip the in-library collective: force the sharded code path
+    real = _joint.sharded_bins
+    _joint.sharded_bins = lambda enabled=True: real(True)
+    try:
+        masks = sharding.fit_predict_sharded_joint(trainer, Y, e, init, iterations=6,
+                                                   saliency=sal, **kw)
+    finally:
+        _joint.sharded_bins = real
+    ref = oe.joint_fit(kind, Y.astype(np.complex128), e.astype(np.float64), init, 6,
+                       saliency=sal, **kw)
+    want = oe.joint_model_predict(ref, Y.astype(np.complex128), e.astype(np.float64))
+    from pb_bss_amd import _lib
+    got = _lib.to_host(masks)
+    assert got.shape == (F, K, T)
+    assert np.abs(got - want).max() < 1e-6
+
+
+def test_sharded_joint_without_communicator_or_full_covariance_is_refused():
+    from pb_bss_amd.distribution import GCACGMMTrainer, _joint
+    from pb_bss_amd import _lib
+    from oracle import synth
+    Y, e, init = synth.make_joint(4, 80, 3, 2, 8, seed=1)
+    with _joint.sharded_bins(True):
+        with pytest.raises(_lib.PbbssError):  # no pbbss_comm_create on this handle
+            GCACGMMTrainer().fit(Y, e, initialization=init, iterations=2)
+
+
+def test_fit_predict_sharded_watson_and_souden_world1(world1_nccl):
+    """BASELINE configs[3] under the sharded entry points: CWMMTrainer through
+    fit_predict_sharded, then MVDR-Souden with the reference-channel sums all-reduced."""
+    from pb_bss_amd.distribution import CWMMTrainer
+    from pb_bss_amd import _lib, extraction as ex, pipeline, sharding
+    from oracle import beamformer as ob, cwmm as ow, synth
+    F, T, D, K = 17, 300, 6, 3
+    Y, init = synth.make_stft(F, T, D, K, seed=4)
+    Y128 = Y.astype(np.complex128)
+    masks = sharding.fit_predict_sharded(_lib.to_device(Y), _lib.to_device(init), 10,
+                                         trainer=CWMMTrainer())
+    ref = ow.cwmm_predict(ow.cwmm_fit(Y128, init, iterations=10), Y128)
+    assert np.abs(_lib.to_host(masks) - ref).max() < 1e-7
+    psd = ex.get_power_spectral_density_matrix(_lib.to_device(Y).transpose(-1, -2).contiguous(), masks)
+    psd_ref = ob.psd(Y128.transpose(0, 2, 1), ref)
+    w, ch = ex.get_mvdr_vector_souden(psd[:, 0], psd[:, 1] + psd[:, 2], return_ref_channel=True,
+                                      shard_group=True)
+    w_ref, ch_ref = ob.mvdr_souden(psd_ref[:, 0], psd_ref[:, 1] + psd_ref[:, 2],
+                                   return_ref_channel=True)
+    assert ch == ch_ref
+    assert np.abs(_lib.to_host(w) - w_ref).max() < 1e-6 * np.abs(w_ref).max()
+    # the batched stage of pipeline.separate(beamformer='mvdr_souden'): (K, U, F, D, D)
+    tgt = psd.movedim(1, 0).unsqueeze(1).contiguous()
+    noi = (psd.sum(dim=1).unsqueeze(0).unsqueeze(0) - tgt).contiguous()
+    wb = _lib.to_host(pipeline.device_ops.mvdr_souden(tgt, noi, True))
+    wl = _lib.to_host(pipeline.device_ops.mvdr_souden(tgt, noi, None))
+    assert np.abs(wb - wl).max() == 0.0
+    for k in range(K):
+        w_k = ob.mvdr_souden(psd_ref[:, k], psd_ref.sum(1) - psd_ref[:, k])
+        assert np.abs(wb[k, 0] - w_k).max() < 1e-6 * np.abs(w_k).max()
