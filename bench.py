@@ -789,7 +789,7 @@ def main_config3(args):
 
 def has_f32():
     from pb_bss_amd import _lib
-    return hasattr(_lib.load(), 'pbbss_cacgmm_fit32')
+    return _lib.load().pbbss_version() >= 300
 
 
 def main():

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define PBBSS_VERSION 100 /* 0.1.0 */
+#define PBBSS_VERSION 300 /* 0.3.0: pbbss_em_opts.precision, pbbss_mix_opts.sharded, pbbss_comm_info */
 
 /* ---- error codes --------------------------------------------------------- */
 #define PBBSS_OK 0
@@ -115,7 +115,22 @@ typedef struct pbbss_em_opts {
                             /* fast path); for tests                             */
   double affiliation_eps;   /* clip of the posteriors inside the loop (1e-10)    */
   double eigenvalue_floor;  /* relative eigenvalue floor (1e-10)                 */
+  int32_t precision;        /* PBBSS_PRECISION_* of the E / M phases (pbbss_cacgmm_fit) */
+  int32_t reserved;
 } pbbss_em_opts;
+
+/* Arithmetic of the E and M phases of pbbss_cacgmm_fit.                                */
+/* F64 (default): float64 throughout, for complex64 and complex128 observations.        */
+/* F32: "reference precision" -- what the reference itself computes in for a complex64   */
+/* observation with an ndarray initialisation (cacgmm.py:226-227: the initialisation is  */
+/* cast to y.real.dtype, every einsum then runs in complex64 / float32): quadratic       */
+/* forms, posteriors and covariance sums in packed float32 (csrc/cacgmm_em32.hpp), class */
+/* sums, factorisation, eigenvalue floor and the returned model in float64.  complex64   */
+/* input, 2 <= D <= 8, K <= 4, frames resident in LDS, no source_activity_mask, no        */
+/* quadratic-form output: otherwise PBBSS_ERR_UNSUPPORTED (the caller uses F64, which    */
+/* is a superset in accuracy).                                                           */
+#define PBBSS_PRECISION_F64 0
+#define PBBSS_PRECISION_F32 1
 
 /* ------------------------------------------------------------------------- */
 /* a8  CACGMMTrainer.fit / fit_predict   distribution/cacgmm.py:142-313        */

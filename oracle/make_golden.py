@@ -488,8 +488,34 @@ def gev_eig_cases():
     _save('gev_use_eig', **out)
 
 
+def cacgmm_single_precision_cases():
+    """The reference's OWN single-precision path: a complex64 observation with an ndarray
+    initialisation runs the whole EM in complex64 / float32 (cacgmm.py:226-227).  These fixtures
+    pin the packed-FP32 kernel (pbbss_em_opts.precision = F32) per step -- EM trajectories are
+    chaotic, single precision cannot be compared over many iterations."""
+    from pb_bss.distribution import CACGMMTrainer
+    out = {}
+    for tag, F, T, D, K in (('a', 12, 300, 8, 3), ('b', 6, 140, 4, 2), ('c', 5, 500, 6, 4)):
+        Y, init = synth.make_stft(F, T, D, K, seed=40 + F)
+        assert Y.dtype == np.complex64
+        for iters in (1, 2):
+            model = CACGMMTrainer().fit(Y, initialization=init, iterations=iters)
+            aff = model.predict(Y)
+            assert aff.dtype == np.float32 and model.cacg.covariance_eigenvalues.dtype == np.float32
+            m64 = CACGMMTrainer().fit(Y.astype(np.complex128), initialization=init,
+                                      iterations=iters)
+            out[f'{tag}_aff32_it{iters}'] = aff
+            out[f'{tag}_cov32_it{iters}'] = model.cacg.covariance
+            out[f'{tag}_weight32_it{iters}'] = model.weight
+            out[f'{tag}_aff64_it{iters}'] = m64.predict(Y.astype(np.complex128))
+        out[f'{tag}_Y'] = Y
+        out[f'{tag}_init'] = init
+    _save('cacgmm_single_precision_path', **out)
+
+
 def main():
     """python -m oracle.make_golden            -> every fixture of the pure-Python reference
+    python -m oracle.make_golden f32        -> tests/golden/cacgmm_single_precision_path.npz
     python -m oracle.make_golden joint_cov  -> tests/golden/embed_gcacgmm_{full,diagonal}*.npz
     python -m oracle.make_golden gev_eig    -> tests/golden/gev_use_eig.npz only (own process:
     the reference's Cython modules must be injected BEFORE pb_bss.extraction.beamformer is
@@ -501,12 +527,17 @@ def main():
         refshim.load()
         joint_covariance_cases()
         return
+    if sys.argv[1:] == ['f32']:
+        refshim.load()
+        cacgmm_single_precision_cases()
+        return
     if sys.argv[1:] == ['gev_eig']:
         refshim.load_cython()
         gev_eig_cases()
         return
     refshim.load()
     cacgmm_cases()
+    cacgmm_single_precision_cases()
     cacg_cases()
     beamformer_cases()
     dhtv_cases()

@@ -7,6 +7,7 @@ The Python signatures mirror fgnt/pb_bss; the arithmetic runs in hand-written
 HIP kernels (pb_bss_amd/csrc) behind the C ABI of include/pbbss.h.
 """
 from . import distribution, extraction  # noqa: F401
-from .distribution.utils import result_dtype, set_result_dtype  # noqa: F401
+from .distribution.utils import (arithmetic, result_dtype, set_arithmetic,  # noqa: F401
+                                 set_result_dtype)
 
 __version__ = '0.1.0'

@@ -79,7 +79,12 @@ class EmOpts(ctypes.Structure):
         ('force_eig', ctypes.c_int32),
         ('affiliation_eps', ctypes.c_double),
         ('eigenvalue_floor', ctypes.c_double),
+        ('precision', ctypes.c_int32),
+        ('reserved', ctypes.c_int32),
     ]
+
+
+PRECISION = {'f64': 0, 'float64': 0, None: 0, 'f32': 1, 'float32': 1}
 
 
 class CwmmOpts(ctypes.Structure):

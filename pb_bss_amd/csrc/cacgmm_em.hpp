@@ -71,9 +71,10 @@ struct EmArgs {
   int* xerror;        // [0] set to `xepoch` if a bounded spin of THIS launch ran out; [16] sticky copy
   int xepoch;         // launch stamp of the split protocol (0: the word is cleared by the launcher)
   int split_prio;     // s_setprio level of the split waves (0..3)
-  // Split groups INSIDE the main launch: blocks >= main_grid are the members of the remainder
-  // problems (one launch, one stream, nothing to fork or join); 0: every block is a full workgroup.
+  // packed-FP32 kernel (cacgmm_em32.hpp): blocks >= main_grid are the member workgroups of the
+  // remainder problems, in the same grid; 0: every block is a full workgroup
   int main_grid;
+  float* a32;         // packed-FP32 kernel: [grid][K][NAP] float32 operand rows (A_k), L2-resident
   // ---- weights shared across problems (run_shared: weight_mode PBBSS_WEIGHT_SHARED_*) ----
   int wgroup;          // problems (frequency bins) that share one set of mixture weights
   double* gsum;        // SHARED_K : [2][B][K]     masked class sums of every problem
@@ -177,6 +178,18 @@ struct EmKernel {
     return SPILL ? ((frame_bytes(T) + 255) & ~(size_t)255) : 0;
   }
 
+  // the small (frame-independent) arrays alone, at p (the packed-FP32 kernel keeps its own
+  // frame arrays and reuses the float64 factorisation / exchange code on these)
+  static __device__ Lds carve_small(char* p, int Tp) {
+    Lds L;
+    L.Tp = Tp;
+    L.ybuf = nullptr;
+    L.inv_n2 = nullptr;
+    L.wbuf = nullptr;
+    carve_small_into(L, p);
+    return L;
+  }
+
   static __device__ Lds carve(char* base, int T, char* scratch = nullptr) {
     Lds L;
     L.Tp = (T + 1) & ~1;
@@ -189,6 +202,11 @@ struct EmKernel {
     L.wbuf = reinterpret_cast<double*>(f);
     f += (size_t)K * L.Tp * 8;
     if (!SPILL) p = f;
+    carve_small_into(L, p);
+    return L;
+  }
+
+  static __device__ __forceinline__ void carve_small_into(Lds& L, char* p) {
     L.cpack = reinterpret_cast<double*>(p);
     p += (size_t)K * NA * 8;
     L.apack = reinterpret_cast<double*>(p);
@@ -208,7 +226,6 @@ struct EmKernel {
     L.status = reinterpret_cast<int*>(p);
     p += K * 4;
     L.flags = reinterpret_cast<int*>(p);
-    return L;
   }
 
   // row stride of the (B,K,T)/(B,T) arrays and first global frame of this workgroup
@@ -1901,13 +1918,10 @@ struct EmKernel {
     // dispatch below is a scalar branch, not four exec-masked code paths
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
-    if constexpr (!SPILL) {
-      if (a.main_grid > 0 && (int)blockIdx.x >= a.main_grid) {
-        run_split(a, smem, (int)blockIdx.x - a.main_grid, (int)gridDim.x - a.main_grid);
-        return;
-      }
-    }
-    const int bstride = a.main_grid > 0 ? a.main_grid : (int)gridDim.x;
+    // (The split groups of the remainder problems are a SECOND kernel on a side stream, not blocks
+    // of this grid: with run_split compiled into this function -- inlined or called -- hipcc's
+    // register allocation of the main loop degrades from 9 to 76 spilled VGPRs, 1.475 -> 1.65 ms
+    // per fit on one box, profiles/r03_a_member_modes.txt.)
     const Lds L = carve(smem, a.T, SPILL ? a.scratch + (size_t)blockIdx.x * a.scratch_stride : nullptr);
 #ifdef PBBSS_PHASE_PROFILE
     unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1921,7 +1935,7 @@ struct EmKernel {
 #else
 #define PBBSS_TICK(i)
 #endif
-    for (int64_t b = blockIdx.x; b < a.B; b += bstride) {
+    for (int64_t b = blockIdx.x; b < a.B; b += gridDim.x) {
       __syncthreads();  // previous problem fully retired before LDS is reused
       if (tid < K) L.status[tid] = 0;
       if (tid == 0) *L.flags = 0;

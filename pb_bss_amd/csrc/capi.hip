@@ -196,8 +196,6 @@ PBBSS_API int pbbss_create(pbbss_handle_t* out, int device_id) {
   h->cfg.split_window = pbbss::kSplitWindow;
   h->cfg.split_prio = 1;
   if (const char* p = getenv("PBBSS_SPLIT_PRIO")) h->cfg.split_prio = atoi(p);
-  h->cfg.split_inline = 1;
-  if (const char* p = getenv("PBBSS_SPLIT_INLINE")) h->cfg.split_inline = atoi(p) != 0;
   h->split_epoch = 1;
   h->cfg.split_epoch = &h->split_epoch;
   if (const char* w = getenv("PBBSS_SPLIT_WINDOW")) {
@@ -459,6 +457,9 @@ PBBSS_API int pbbss_cacgmm_fit(pbbss_handle_t h, const void* y, int64_t B, int T
   if (!out_eigvec || !out_eigval || !out_weight || !out_status) return PBBSS_ERR_INVALID_ARG;
   if (o->covariance_norm < 0 || o->covariance_norm > 2) return PBBSS_ERR_INVALID_ARG;
   if (o->weight_mode < 0 || o->weight_mode > 1) return PBBSS_ERR_INVALID_ARG;
+  if (o->precision != PBBSS_PRECISION_F64 && o->precision != PBBSS_PRECISION_F32)
+    return PBBSS_ERR_INVALID_ARG;
+  if (o->precision == PBBSS_PRECISION_F32 && (D > 8 || K > 4)) return PBBSS_ERR_UNSUPPORTED;
   if (D > 8 || K > 6) {
     // generic-size path (generic.hip; also more than 6 classes at any D): E-step, covariance + weights, eigendecomposition per
     // iteration, enqueued back to back; the model lives in the caller's output buffers
@@ -554,6 +555,8 @@ PBBSS_API int pbbss_cacgmm_fit(pbbss_handle_t h, const void* y, int64_t B, int T
     return PBBSS_OK;
   }
   if (D < 2 || D > 8 || K < 1 || K > 6) return PBBSS_ERR_UNSUPPORTED;
+  const bool f32 = o->precision == PBBSS_PRECISION_F32;
+  if (f32 && (o->y_is_c128 || K > 4 || activity || out_quadratic_form)) return PBBSS_ERR_UNSUPPORTED;
   pbbss::EmArgs a{};
   a.y = y;
   a.B = B;
@@ -584,6 +587,12 @@ PBBSS_API int pbbss_cacgmm_fit(pbbss_handle_t h, const void* y, int64_t B, int T
   a.eig_floor = o->eigenvalue_floor;
   a.prof = h->prof;
   TimedRegion tr(h, as_stream(stream));
+  if (f32) {
+    const int rc = pbbss::em32_launch(D, K, a, h->cfg, as_stream(stream));
+    // a long utterance does not fit the LDS-resident packed kernel: say "unsupported", the
+    // float64 kernel (which has an HBM-scratch variant) serves it
+    return rc == PBBSS_ERR_LDS_CAPACITY ? PBBSS_ERR_UNSUPPORTED : rc;
+  }
   return pbbss::em_launch(D, K, o->y_is_c128, a, h->cfg, as_stream(stream));
 }
 

@@ -2,49 +2,13 @@
 // heavy persistent-EM template instantiates in parallel under `make -j`.
 #include "cacgmm_em.hpp"
 #include "em_launch.hpp"
-#include <atomic>
 #include <cstdlib>
-#include <mutex>
-#include <vector>
 
 #ifndef PBBSS_EM_D
 #error "compile with -DPBBSS_EM_D=<sensors>"
 #endif
 
 namespace pbbss {
-
-// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per function and device, shared by all host
-// threads: keep a process-wide monotonic maximum per (function, device) and only ever raise it.
-static bool raise_lds_attribute(const void* fn, size_t lds) {
-  constexpr int kMaxDev = 64;
-  struct Slot {
-    const void* fn;
-    std::atomic<size_t> have[kMaxDev];
-  };
-  static std::mutex mu;
-  static std::vector<Slot*> slots;
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  if (dev < 0 || dev >= kMaxDev)
-    return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
-  Slot* sl = nullptr;
-  {
-    std::lock_guard<std::mutex> g(mu);
-    for (Slot* x : slots)
-      if (x->fn == fn) sl = x;
-    if (!sl) {
-      sl = new Slot();
-      sl->fn = fn;
-      for (auto& h : sl->have) h.store(0);
-      slots.push_back(sl);
-    }
-    if (sl->have[dev].load() >= lds) return true;
-    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return false;
-    sl->have[dev].store(lds);
-  }
-  return true;
-}
 
 // workgroups of the EM kernel per CU at this LDS request (cached per thread: a host round trip)
 template <int K, typename YS, bool SPILL>
@@ -66,7 +30,7 @@ static int em_occupancy(size_t lds) {
 }
 
 template <int K, typename YS, bool SPILL>
-static int launch_variant(EmArgs a, const EmLaunchCfg& cfg, hipStream_t stream, int members = 0) {
+static int launch_variant(EmArgs a, const EmLaunchCfg& cfg, hipStream_t stream) {
   using Kern = EmKernel<PBBSS_EM_D, K, YS, SPILL>;
   const size_t lds = Kern::lds_bytes(a.T);
   if (lds > cfg.lds_limit) return PBBSS_ERR_LDS_CAPACITY;
@@ -80,10 +44,6 @@ static int launch_variant(EmArgs a, const EmLaunchCfg& cfg, hipStream_t stream, 
   if (occ < 1) return PBBSS_ERR_HIP;
   int64_t grid = (int64_t)cfg.num_cu * occ;
   if (grid > a.B) grid = a.B;
-  if (members > 0) {  // split groups of the remainder problems ride behind the full workgroups
-    a.main_grid = (int)grid;
-    grid += members;
-  }
   if (SPILL) {
     a.scratch_stride = Kern::scratch_bytes(a.T);
     a.scratch = static_cast<char*>(cfg.get_scratch(cfg.scratch_ctx, a.scratch_stride * grid));
@@ -91,14 +51,6 @@ static int launch_variant(EmArgs a, const EmLaunchCfg& cfg, hipStream_t stream, 
   }
   hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(kEmThreads), lds, stream, a);
   return hipGetLastError() == hipSuccess ? PBBSS_OK : PBBSS_ERR_HIP;
-}
-
-// launch stamp of the split protocol: never 0 (= "launcher clears the word") nor 1 (what the
-// cooperative shared-weight kernel writes)
-static int next_split_epoch(const EmLaunchCfg& cfg) {
-  int& e = *cfg.split_epoch;
-  e = (e >= 0x7ffffff0 || e < 2) ? 2 : e + 1;
-  return e;
 }
 
 // Remainder problems [b_first, b_first + r) as split groups on the side stream,
@@ -151,33 +103,6 @@ static int launch_one(const EmArgs& a, const EmLaunchCfg& cfg, hipStream_t strea
                      a.B <= 3 * (int64_t)cfg.num_cu && r >= 1 && r <= kSplitMaxProblems &&
                      a.T >= 2 * cfg.split_window && a.wt == 0 && slab_need <= cfg.xbuf_bytes;
   if (!split) return launch_variant<K, YS, false>(a, cfg, stream);
-  // members need a free occupancy slot next to the full workgroups (T = 500: three per CU, two
-  // taken); otherwise they would only start when a full workgroup retires
-  const size_t lds_main = EmKernel<PBBSS_EM_D, K, YS, false>::lds_bytes(a.T);
-  if (cfg.split_inline &&
-      !raise_lds_attribute(reinterpret_cast<const void*>(cacgmm_em_kernel<PBBSS_EM_D, K, YS, false>),
-                           lds_main))
-    return PBBSS_ERR_HIP;
-  const int occ_main = cfg.split_inline ? em_occupancy<K, YS, false>(lds_main) : 0;
-  if (cfg.split_inline && (a.B - r) <= (int64_t)cfg.num_cu * (occ_main - 1)) {
-    // ONE launch on the caller's stream: the G member workgroups of each remainder problem sit
-    // behind the full workgroups in the same grid (they take the third occupancy slot of a few
-    // CUs).  Nothing to fork or join, no side stream to keep off the caller's hardware queue, and a
-    // profiler sees one kernel.
-    const int G = (a.T + window - 1) / window;
-    EmArgs ia = a;
-    ia.B = a.B - r;
-    ia.T_total = a.T;
-    ia.split_groups = G;
-    ia.split_window = window;
-    ia.split_prio = cfg.split_prio;
-    ia.b_first = a.B - r;
-    ia.xcount = reinterpret_cast<unsigned*>(cfg.xbuf);
-    ia.xerror = reinterpret_cast<int*>(cfg.xbuf + 128);
-    ia.xslab = reinterpret_cast<double*>(cfg.xbuf + 256);
-    ia.xepoch = next_split_epoch(cfg);
-    return launch_variant<K, YS, false>(ia, cfg, stream, (int)r * G);
-  }
   EmArgs main_a = a;
   main_a.B = a.B - r;
   // The main launch goes out FIRST: the side-stream preparation of the split groups (fork event,

@@ -1,6 +1,9 @@
 // Host-side dispatch of the persistent EM kernel over (D, K, storage type).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
+#include <mutex>
+#include <vector>
 #include "cacgmm_em.hpp"
 #include "cwmm.hpp"
 
@@ -20,10 +23,51 @@ struct EmLaunchCfg {
   int allow_split;   // 0 disables the split variant (tests / debugging)
   int split_window;  // frames per workgroup of a split problem (multiple of 64)
   int split_prio;    // s_setprio level of the split waves
-  int split_inline;  // 1: the split groups are member workgroups of the main launch (default);
-                     // 0: a second kernel on the side stream (PBBSS_SPLIT_INLINE=0, for A/B runs)
   int* split_epoch;  // host counter stamping the launches of the split protocol
 };
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per function and device, shared by all host
+// threads: keep a process-wide monotonic maximum per (function, device) and only ever raise it.
+inline bool raise_lds_attribute(const void* fn, size_t lds) {
+  constexpr int kMaxDev = 64;
+  struct Slot {
+    const void* fn;
+    std::atomic<size_t> have[kMaxDev];
+  };
+  static std::mutex mu;
+  static std::vector<Slot*> slots;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= kMaxDev)
+    return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+  Slot* sl = nullptr;
+  {
+    std::lock_guard<std::mutex> g(mu);
+    for (Slot* x : slots)
+      if (x->fn == fn) sl = x;
+    if (!sl) {
+      sl = new Slot();
+      sl->fn = fn;
+      for (auto& h : sl->have) h.store(0);
+      slots.push_back(sl);
+    }
+    if (sl->have[dev].load() >= lds) return true;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return false;
+    sl->have[dev].store(lds);
+  }
+  return true;
+}
+
+
+// launch stamp of the split protocol: never 0 (= "launcher clears the word") nor 1 (what the
+// cooperative shared-weight kernel writes)
+inline int next_split_epoch(const EmLaunchCfg& cfg) {
+  int& e = *cfg.split_epoch;
+  e = (e >= 0x7ffffff0 || e < 2) ? 2 : e + 1;
+  return e;
+}
+
 
 constexpr int kSplitWindow = 64;      // default frames per workgroup of a split problem
 constexpr int kSplitMaxProblems = 8;  // at most this many remainder problems are split
@@ -51,6 +95,28 @@ inline int em_launch(int D, int K, int y_is_c128, const EmArgs& a, const EmLaunc
   }
 }
 
+
+// packed-FP32 (reference-precision) EM kernels (em32_inst.hip), one per compiled D; complex64 only
+int em32_launch_d2(int K, const EmArgs&, const EmLaunchCfg&, hipStream_t);
+int em32_launch_d3(int K, const EmArgs&, const EmLaunchCfg&, hipStream_t);
+int em32_launch_d4(int K, const EmArgs&, const EmLaunchCfg&, hipStream_t);
+int em32_launch_d5(int K, const EmArgs&, const EmLaunchCfg&, hipStream_t);
+int em32_launch_d6(int K, const EmArgs&, const EmLaunchCfg&, hipStream_t);
+int em32_launch_d7(int K, const EmArgs&, const EmLaunchCfg&, hipStream_t);
+int em32_launch_d8(int K, const EmArgs&, const EmLaunchCfg&, hipStream_t);
+
+inline int em32_launch(int D, int K, const EmArgs& a, const EmLaunchCfg& cfg, hipStream_t s) {
+  switch (D) {
+    case 2: return em32_launch_d2(K, a, cfg, s);
+    case 3: return em32_launch_d3(K, a, cfg, s);
+    case 4: return em32_launch_d4(K, a, cfg, s);
+    case 5: return em32_launch_d5(K, a, cfg, s);
+    case 6: return em32_launch_d6(K, a, cfg, s);
+    case 7: return em32_launch_d7(K, a, cfg, s);
+    case 8: return em32_launch_d8(K, a, cfg, s);
+    default: return PBBSS_ERR_UNSUPPORTED;
+  }
+}
 
 // complex-Watson mixture kernels (cw_inst.hip), one per compiled D
 int cw_launch_d2(int K, int y_is_c128, const WatsonArgs&, const EmLaunchCfg&, hipStream_t);

@@ -34,7 +34,8 @@ from .mixture_model_utils import (
     apply_inline_permutation_alignment,
     estimate_mixture_weight,
 )
-from .utils import _ProbabilisticModel, as_result, reference_single, to_single
+from .utils import (_ProbabilisticModel, as_result, reference_arithmetic, reference_single,
+                    to_single)
 
 __all__ = ['CACGMM', 'CACGMMTrainer', 'normalize_observation', 'sample_cacgmm']
 
@@ -197,6 +198,12 @@ class CACGMMTrainer:
         )
         like_torch = _lib.is_torch(y)
         t = _lib.torch()
+        # arithmetic 'reference': a complex64 observation with an array initialisation is what the
+        # reference computes in single precision (cacgmm.py:226-227) -> packed-FP32 kernel
+        packed32 = (reference_arithmetic() and initialization is not None
+                    and not isinstance(initialization, CACGMM)
+                    and str(y.dtype).rsplit('.', 1)[-1] == 'complex64'
+                    and source_activity_mask is None)
         # result dtype 'reference': an array initialisation is cast to y.real.dtype
         # (cacgmm.py:226-227), a model keeps its own, random affiliations are float64
         # (:208); a saliency enters the M step as it is (:336-339)
@@ -264,6 +271,15 @@ class CACGMMTrainer:
             sal = sal.reshape(-1, N).contiguous()
 
         if fused:
+            if packed32 and D <= 8 and K <= 4:
+                try:
+                    return self._rounded(self._fit_fused(
+                        y.reshape(-1, N, D), indep, K, gamma0, model, iterations, sal,
+                        act, mode, covariance_norm, affiliation_eps, eigenvalue_floor,
+                        hermitize, like_torch, final_predict=_with_affiliation,
+                        precision='f32'), single, mode)
+                except NotImplementedError:
+                    pass  # e.g. an utterance too long for the LDS-resident kernel: float64 serves it
             return self._rounded(self._fit_fused(
                 y.reshape(-1, N, D), indep, K, gamma0, model, iterations, sal,
                 act, mode, covariance_norm, affiliation_eps, eigenvalue_floor,
@@ -375,7 +391,7 @@ class CACGMMTrainer:
     # ------------------------------------------------------------------ fused
     def _fit_fused(self, yb, indep, K, gamma0, model, iterations, sal, act, mode,
                    covariance_norm, affiliation_eps, eigenvalue_floor, hermitize,
-                   like_torch, final_predict=False):
+                   like_torch, final_predict=False, precision='f64'):
         t = _lib.torch()
         B, N, D = yb.shape
         dev_model = None
@@ -395,7 +411,7 @@ class CACGMMTrainer:
             saliency=sal, activity=act, covariance_norm=covariance_norm,
             weight_mode=mode, affiliation_eps=affiliation_eps,
             eigenvalue_floor=eigenvalue_floor, hermitize=hermitize,
-            layout=_lib.LAYOUT_TD, final_predict=final_predict)
+            layout=_lib.LAYOUT_TD, final_predict=final_predict, precision=precision)
         if mode == _lib.WEIGHT_UNIFORM:
             weight = t.full((K, 1), 1.0 / K, dtype=t.float64, device=yb.device)
         else:

@@ -74,6 +74,38 @@ def result_dtype(mode):
         set_result_dtype(old)
 
 
+# ---- arithmetic of the cACGMM trainer ------------------------------------------------------
+# 'float64' (default): the float64 kernel for every input.  'reference': where the reference
+# itself computes in single precision -- a complex64 observation with an array initialisation
+# (cacgmm.py:226-227) -- use the packed-FP32 kernel (csrc/cacgmm_em32.hpp: E / M phases in
+# float32, class sums and factorisation in float64); anything that kernel does not serve
+# (complex128, K > 4, long utterances, activity masks, bin-coupled weights) runs in float64.
+_ARITHMETICS = ('float64', 'reference')
+_arithmetic = os.environ.get('PBBSS_ARITHMETIC', 'float64')
+assert _arithmetic in _ARITHMETICS, _arithmetic
+
+
+def set_arithmetic(mode):
+    """Select the arithmetic of `CACGMMTrainer.fit`; returns the previous setting."""
+    global _arithmetic
+    assert mode in _ARITHMETICS, (mode, _ARITHMETICS)
+    old, _arithmetic = _arithmetic, mode
+    return old
+
+
+@contextlib.contextmanager
+def arithmetic(mode):
+    old = set_arithmetic(mode)
+    try:
+        yield
+    finally:
+        set_arithmetic(old)
+
+
+def reference_arithmetic():
+    return _arithmetic == 'reference'
+
+
 def _is_single(x):
     """float32 / complex64 operand (NumPy or torch)?"""
     return str(x.dtype).rsplit('.', 1)[-1] in ('float32', 'complex64', 'float16')

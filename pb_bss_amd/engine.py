@@ -49,8 +49,10 @@ def em_fit(y, K, *, gamma0=None, model=None, iterations=100, saliency=None,
            activity=None, covariance_norm='eigenvalue', weight_mode=0,
            affiliation_eps=1e-10, eigenvalue_floor=1e-10, hermitize=True,
            layout=_lib.LAYOUT_TD, final_predict=False, return_q=False,
-           force_eig=False, check_status=True):
+           force_eig=False, check_status=True, precision='f64'):
     """pbbss_cacgmm_fit.  y (B,T,D) [layout TD] or (B,D,T) [layout DT] complex.
+    precision 'f32': the packed-FP32 "reference precision" kernel (complex64 y, D <= 8, K <= 4,
+    LDS-resident frames, no activity mask) -- NotImplementedError where it does not apply.
 
     gamma0 (B,K,T) f64, or model=(eigvec (B,K,D,D) c128, eigval (B,K,D), weight (B,K)).
     Returns dict(eigvec, eigval, weight (B,K), status, affiliation?, quadratic_form?).
@@ -70,7 +72,7 @@ def em_fit(y, K, *, gamma0=None, model=None, iterations=100, saliency=None,
         layout=int(layout), y_is_c128=int(is128),
         final_predict=int(bool(final_predict)), force_eig=int(bool(force_eig)),
         affiliation_eps=float(affiliation_eps),
-        eigenvalue_floor=float(eigenvalue_floor))
+        eigenvalue_floor=float(eigenvalue_floor), precision=_lib.PRECISION[precision])
     f64 = t.float64
     out_vec = t.empty((B, K, D, D), dtype=t.complex128, device=dev)
     out_val = t.empty((B, K, D), dtype=f64, device=dev)

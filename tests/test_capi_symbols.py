@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     assert sorted(_lib.EXPORTS) == names
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.pbbss_version() == 100
+    assert lib.pbbss_version() == 300
     assert lib.pbbss_error_string(0) == b'ok'
     assert b'shape' in lib.pbbss_error_string(-2)
 
@@ -58,9 +58,14 @@ def test_constants_match_header():
 def test_em_opts_struct_layout():
     import ctypes
     from pb_bss_amd import _lib
-    # 8 int32 + 2 double, naturally aligned: 48 bytes like the C struct
-    assert ctypes.sizeof(_lib.EmOpts) == 48
+    # 8 int32 + 2 double + 2 int32 (precision, reserved), naturally aligned: 56 bytes like the
+    # C struct
+    assert ctypes.sizeof(_lib.EmOpts) == 56
     assert _lib.EmOpts.affiliation_eps.offset == 32
+    assert _lib.EmOpts.precision.offset == 48
+    # pbbss_mix_opts: 8 int32 + 6 double + 2 int32 (sharded, reserved)
+    assert ctypes.sizeof(_lib.MixOpts) == 88
+    assert _lib.MixOpts.sharded.offset == 80
 
 
 def test_no_cpu_fallback_without_gpu():
