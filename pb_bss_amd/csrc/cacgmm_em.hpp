@@ -74,7 +74,6 @@ struct EmArgs {
   // packed-FP32 kernel (cacgmm_em32.hpp): blocks >= main_grid are the member workgroups of the
   // remainder problems, in the same grid; 0: every block is a full workgroup
   int main_grid;
-  float* a32;         // packed-FP32 kernel: [grid][K][NAP] float32 operand rows (A_k), L2-resident
   // ---- weights shared across problems (run_shared: weight_mode PBBSS_WEIGHT_SHARED_*) ----
   int wgroup;          // problems (frequency bins) that share one set of mixture weights
   double* gsum;        // SHARED_K : [2][B][K]     masked class sums of every problem

@@ -20,13 +20,17 @@
 //    and the covariance update keeps (Re C_ij, Im C_ij) in one accumulator pair:
 //        (Re C, Im C) += w * (Re P, Im P).
 //    Lane = frame in both phases, half the accumulator registers of a frame-packed layout.
-//  * Operand feed of the E phase: A_k is wave-uniform, so it belongs in SGPRs.  VOP3P has no DPP
-//    (the float64 kernel's row_newbcast trick does not exist for packed math), but a packed FMA
-//    takes a 64-bit SGPR pair as src0.  After the factorisation the wave that owns class k writes
-//    A_k as float32 into a per-workgroup slot in global memory (L2-resident, 768 B), and the E
-//    phase streams it with s_load_dwordx8 (glc: the scalar cache still holds the previous
-//    iteration's line) in chunks of eight operands, the next chunk in flight under the FMAs of
-//    the current one -- the scalar unit feeds the vector unit, no LDS traffic, no VGPRs.
+//  * Operand feed of the E phase: A_k is wave-uniform.  VOP3P has no DPP (the float64 kernel's
+//    row_newbcast trick does not exist for packed math).  After the factorisation the wave that
+//    owns class k leaves A_k as float32 in LDS (K x 64 floats), and the E phase fetches it with
+//    broadcast ds_read_b128 (all lanes one address: conflict-free, four operands per read) in
+//    chunks of eight operands, the next chunk in flight under the FMAs of the current one; every
+//    operand pair feeds two frames per lane.  48 reads per wave and iteration keep the LDS pipe
+//    at about a quarter of its capacity.  (First version: SGPR operands streamed with
+//    s_load_dwordx8 ... glc from an L2-resident slot -- correct, and the natural home of uniform
+//    operands, but scalar loads return out of order, so only lgkmcnt(0) can be waited for and
+//    the L2 round trip of every chunk was exposed: the E phase took 3x the M phase,
+//    profiles/r03_b_f32_experiments.txt.)
 //  * y is kept PRE-NORMALISED in LDS (float32, 32 KB at T = 500, D = 8): no widening, no
 //    1 / |y|^2 factor anywhere; M-step weights as float32 (K padded to 4 per frame, one
 //    ds_write_b128 / ds_read_b128 per frame).
@@ -47,20 +51,8 @@ typedef float f32x8 __attribute__((ext_vector_type(8)));
 constexpr float kTiny32 = 1.17549435e-38f;  // np.finfo(np.float32).tiny
 
 // ---- packed-FP32 building blocks ------------------------------------------------------------
-// acc += a * p, a = SGPR pair (two consecutive operands of the stream)
-__device__ __forceinline__ void pkfma_s(f32x2& acc, f32x2 a, f32x2 p) {
-  asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc) : "s"(a), "v"(p));
-}
-// acc += a[HI] * p: both halves take the same dword of the SGPR pair
-template <int HI>
-__device__ __forceinline__ void pkfma_s_bcast(f32x2& acc, f32x2 a, f32x2 p) {
-  if constexpr (HI == 0) {
-    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "s"(a), "v"(p));
-  } else {
-    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "s"(a), "v"(p));
-  }
-}
-// the same with a VGPR pair (per-lane M-step weights of two classes in one pair)
+// acc += w[HI] * p: both halves take the same dword of the VGPR pair w (per-lane M-step weights of
+// two classes in one pair; a broadcast-read operand pair of the E phase)
 template <int HI>
 __device__ __forceinline__ void pkfma_v_bcast(f32x2& acc, f32x2 w, f32x2 p) {
   if constexpr (HI == 0) {
@@ -87,26 +79,6 @@ __device__ __forceinline__ f32x2 pair_of(f32x8 v) {
 template <int H>
 __device__ __forceinline__ f32x2 pair_of(f32x4 v) {
   return __builtin_shufflevector(v, v, 2 * H, 2 * H + 1);
-}
-
-// eight consecutive operands -> SGPRs; glc: miss in the scalar cache (it may hold the line the
-// previous EM iteration read from the same address).  The result is valid after s_wait8.
-// (the operand index is an immediate offset of the instruction: one base pointer serves the whole
-// stream -- per-load pointers were hoisted out of the EM loop by LICM and came back as spills)
-template <int FLOAT_OFFSET>
-__device__ __forceinline__ f32x8 s_load8(const float* uniform_base) {
-  f32x8 v;
-  asm volatile("s_load_dwordx8 %0, %1, %2 glc" : "=s"(v) : "s"(uniform_base), "n"(FLOAT_OFFSET * 4));
-  return v;
-}
-template <int K>
-__device__ __forceinline__ void s_wait8(f32x8 (&v)[K]) {
-  static_assert(K >= 1 && K <= 4, "classes of the packed-FP32 kernel");
-  if constexpr (K == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v[0]));
-  if constexpr (K == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v[0]), "+s"(v[1]));
-  if constexpr (K == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v[0]), "+s"(v[1]), "+s"(v[2]));
-  if constexpr (K == 4)
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v[0]), "+s"(v[1]), "+s"(v[2]), "+s"(v[3]));
 }
 
 // ---- 32-bit cross-lane helpers (wave_reduce_scatter of pbbss_dev.hpp on single registers) -----
@@ -189,7 +161,7 @@ struct EmKernel32 {
   static constexpr int NDW = Base::NDW, NOW = Base::NOW, NSLOT = Base::NSLOT, NACC = Base::NACC;
   static constexpr int DPAD = (D + 1) & ~1;                 // diagonal block of the operand row, even
   static constexpr int NA32 = DPAD + 2 * NOFF;              // operands of one class
-  static constexpr int NAP = (NA32 + 7) & ~7;               // row stride: whole s_load_dwordx8 chunks
+  static constexpr int NAP = (NA32 + 7) & ~7;               // row stride: whole chunks of eight operands
   static constexpr int NCH = NAP / 8;
   static constexpr int KP = K <= 2 ? 2 : 4;                 // M-step weights of a frame: one vector
 
@@ -197,6 +169,7 @@ struct EmKernel32 {
     BLds b;     // the float64 small arrays of the float64 kernel (frame arrays unused)
     float* y;   // [DP][Tp][4]  pre-normalised channel pairs (re_a, im_a, re_b, im_b), frame contiguous
     float* w;   // [Tp][KP]     M-step weights gamma / q
+    float* a32; // [K][NAP]     A_k as float32 operand rows: [diagonal (DPAD) | (2 Re, 2 Im) pairs]
     int Tp;
   };
 
@@ -205,16 +178,16 @@ struct EmKernel32 {
     return (size_t)DP * Tp * 16 + Tp * KP * 4;
   }
   static __host__ __device__ size_t lds_bytes(int T) {
-    return (Base::small_bytes() + frame_bytes(T) + 15) & ~(size_t)15;
+    return (Base::small_bytes() + frame_bytes(T) + (size_t)K * NAP * 4 + 15) & ~(size_t)15;
   }
-  static __host__ __device__ size_t slot_floats() { return (size_t)K * NAP; }
 
   static __device__ Lds carve(char* base, int T) {
     Lds L;
     L.Tp = (T + 1) & ~1;
     L.y = reinterpret_cast<float*>(base);
     L.w = L.y + (size_t)DP * L.Tp * 4;
-    L.b = Base::carve_small(reinterpret_cast<char*>(L.w + (size_t)L.Tp * KP), L.Tp);
+    L.a32 = L.w + (size_t)L.Tp * KP;  // Tp even, KP even: 16-byte aligned when Tp * KP % 4 == 0
+    L.b = Base::carve_small(reinterpret_cast<char*>(L.a32 + (size_t)K * NAP), L.Tp);
     return L;
   }
 
@@ -305,8 +278,8 @@ struct EmKernel32 {
 
   // ---- phase E ---------------------------------------------------------------------------------
   template <bool FINAL>
-  static __device__ void phase_e(const EmArgs& a, const Lds& L, const float* a32, int64_t b, int tid,
-                                 int wave, int lane, float eps, int tf = 0) {
+  static __device__ void phase_e(const EmArgs& a, const Lds& L, int64_t b, int tid, int wave,
+                                 int lane, float eps, int tf = 0) {
     tid = opaque(tid);
     lane = opaque(lane);
     const int TS = Base::t_stride(a);
@@ -328,24 +301,29 @@ struct EmKernel32 {
 #pragma unroll
         for (int k = 0; k < K; ++k) q2[f][k] = f32x2{0.f, 0.f};
       }
-      // operand stream: chunk c + 1 is requested right after chunk c has landed and BEFORE the
-      // FMAs of chunk c issue (scalar loads return out of order: lgkmcnt(0) is the only safe wait,
-      // so nothing else may be in flight at a wait)
-      f32x8 ch[2][K];
-      static_for<0, K>([&](auto kc) {
-        constexpr int k = kc;
-        ch[0][k] = s_load8<k * NAP>(a32);
-      });
+      // operand stream: broadcast reads of chunk c + 1 are issued BEFORE the FMAs of chunk c (LDS
+      // returns in order, the compiler's lgkmcnt bookkeeping overlaps them); scheduling barriers
+      // pin that order, the partial sums are tied to the stage boundary (cacgmm_em.hpp, code
+      // generation note iv: pure arithmetic is not ordered by memory clobbers)
+      const f32x4* a4 = reinterpret_cast<const f32x4*>(L.a32);
+      f32x4 ch[2][K][2];
+      auto fetch = [&](auto cc, auto bb) {
+        constexpr int c = cc, bsel = bb;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          ch[bsel][k][0] = a4[(k * NAP + 8 * c) / 4];
+          ch[bsel][k][1] = a4[(k * NAP + 8 * c) / 4 + 1];
+        }
+      };
+      fetch(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+      asm volatile("" ::: "memory");
       static_for<0, NCH>([&](auto cc) {
         constexpr int c = cc;
         constexpr int cur = c & 1;
-        s_wait8<K>(ch[cur]);
-        if constexpr (c + 1 < NCH) {
-          static_for<0, K>([&](auto kc) {
-            constexpr int k = kc;
-            ch[1 - cur][k] = s_load8<k * NAP + 8 * (c + 1)>(a32);
-          });
-        }
+        if constexpr (c + 1 < NCH)
+          fetch(std::integral_constant<int, c + 1>{}, std::integral_constant<int, 1 - cur>{});
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
         static_for<0, 4>([&](auto hc) {
           constexpr int h = hc;            // operand pair h of the chunk
           constexpr int e = 8 * c + 2 * h;  // first operand index of the pair
@@ -360,7 +338,8 @@ struct EmKernel32 {
                   const f32x2 yi = chan<i>(yv[f]);
                   const f32x2 dg = yi * yi;
 #pragma unroll
-                  for (int k = 0; k < K; ++k) pkfma_s_bcast<u>(q2[f][k], pair_of<h>(ch[cur][k]), dg);
+                  for (int k = 0; k < K; ++k)
+                    pkfma_v_bcast<u>(q2[f][k], pair_of<h % 2>(ch[cur][k][h / 2]), dg);
                 }
               }
             });
@@ -371,10 +350,17 @@ struct EmKernel32 {
             for (int f = 0; f < NF; ++f) {
               const f32x2 P = herm_pair(chan<i>(yv[f]), chan<j>(yv[f]));
 #pragma unroll
-              for (int k = 0; k < K; ++k) pkfma_s(q2[f][k], pair_of<h>(ch[cur][k]), P);
+              for (int k = 0; k < K; ++k)
+                q2[f][k] = __builtin_elementwise_fma(pair_of<h % 2>(ch[cur][k][h / 2]), P, q2[f][k]);
             }
           }
         });
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+#pragma unroll
+          for (int k = 0; k < K; ++k) asm volatile("" : "+v"(q2[f][k])::"memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
       });
       // per-class constants of the softmax (float64 in LDS, written by the factorisation)
       float rdet[K], wgt[K];
@@ -473,45 +459,71 @@ struct EmKernel32 {
     f32x2 acc[K * NPK];
 #pragma unroll
     for (int x = 0; x < K * NPK; ++x) acc[x] = f32x2{0.f, 0.f};
-    for (int t0 = 0; t0 < a.T; t0 += kWave) {
+    // One trip = 64 frames (lane = frame); frames beyond T are read at a clamped address with their
+    // weights zeroed (no guarded loads).  (A software-pipelined version -- ping-pong operand
+    // sets, the loads of trip n + 1 issued before the FMAs of trip n -- measured 3 % SLOWER on
+    // one box, profiles/r03_b_f32_experiments.txt: two workgroups per CU already cover the LDS
+    // latency, the extra live registers and scheduling barriers cost more.)
+    struct Trip {
+      f32x4 yv[DP];
+      f32x2 wp[KP / 2];
+    };
+    auto fetch = [&](Trip& tr, int t0) {
       const int t = t0 + lane;
       const bool ok = t < a.T;
       const int tc = ok ? t : a.T - 1;
-      f32x4 yv[DP];
-      load_frame(L, tc, yv);
-      // weights at the clamped frame, masked afterwards (no guarded loads)
-      f32x2 wp[KP / 2];
+      load_frame(L, tc, tr.yv);
       if constexpr (KP == 2) {
-        wp[0] = *reinterpret_cast<const f32x2*>(L.w + (size_t)tc * KP);
+        tr.wp[0] = *reinterpret_cast<const f32x2*>(L.w + (size_t)tc * KP);
       } else {
         const f32x4 wv = *reinterpret_cast<const f32x4*>(L.w + (size_t)tc * KP);
-        wp[0] = pair_of<0>(wv);
-        wp[1] = pair_of<1>(wv);
+        tr.wp[0] = pair_of<0>(wv);
+        tr.wp[1] = pair_of<1>(wv);
       }
 #pragma unroll
-      for (int x = 0; x < KP / 2; ++x) wp[x] = ok ? wp[x] : f32x2{0.f, 0.f};
+      for (int x = 0; x < KP / 2; ++x) tr.wp[x] = ok ? tr.wp[x] : f32x2{0.f, 0.f};
+    };
+    auto accumulate = [&](const Trip& tr) {
+      // all Hermitian products of the trip first (independent two-instruction chains the scheduler
+      // can interleave), then the K x (diagonals + pairs) multiply-adds
+      f32x2 dgv[NDW > 0 ? NDW : 1], pv[NOW > 0 ? NOW : 1];
       static_for<0, D>([&](auto ic) {
         constexpr int i = ic;
         if constexpr (i % kEmWaves == W) {
-          const f32x2 yi = chan<i>(yv);
-          const f32x2 dg = yi * yi;
-          static_for<0, K>([&](auto kc) {
-            constexpr int k = kc;
-            pkfma_v_bcast<k % 2>(acc[k * NPK + i / kEmWaves], wp[k / 2], dg);
-          });
+          const f32x2 yi = chan<i>(tr.yv);
+          dgv[i / kEmWaves] = yi * yi;
         }
       });
       static_for<0, NOFF>([&](auto pc) {
         constexpr int p = pc;
         if constexpr (p % kEmWaves == W) {
           constexpr int i = tri_i<D>(p), j = tri_j<D>(p);
-          const f32x2 P = herm_pair(chan<i>(yv), chan<j>(yv));
+          pv[p / kEmWaves] = herm_pair(chan<i>(tr.yv), chan<j>(tr.yv));
+        }
+      });
+      static_for<0, D>([&](auto ic) {
+        constexpr int i = ic;
+        if constexpr (i % kEmWaves == W) {
           static_for<0, K>([&](auto kc) {
             constexpr int k = kc;
-            pkfma_v_bcast<k % 2>(acc[k * NPK + NDW + p / kEmWaves], wp[k / 2], P);
+            pkfma_v_bcast<k % 2>(acc[k * NPK + i / kEmWaves], tr.wp[k / 2], dgv[i / kEmWaves]);
           });
         }
       });
+      static_for<0, NOFF>([&](auto pc) {
+        constexpr int p = pc;
+        if constexpr (p % kEmWaves == W) {
+          static_for<0, K>([&](auto kc) {
+            constexpr int k = kc;
+            pkfma_v_bcast<k % 2>(acc[k * NPK + NDW + p / kEmWaves], tr.wp[k / 2], pv[p / kEmWaves]);
+          });
+        }
+      });
+    };
+    for (int t0 = 0; t0 < a.T; t0 += kWave) {
+      Trip tr;
+      fetch(tr, t0);
+      accumulate(tr);
     }
     // flatten to the slot order of the float64 kernel: per class NDW diagonals, then (Re, Im) pairs
     float flat[NACC];
@@ -553,24 +565,23 @@ struct EmKernel32 {
     }
   }
 
-  // ---- A_k (float64, LDS, packed as apack) -> float32 operand row of class k in the slot -------
-  static __device__ __forceinline__ void publish_class(const Lds& L, float* slot, int k, int lane) {
+  // ---- A_k (float64, LDS, packed as apack) -> float32 operand row of class k (LDS) -------------
+  static __device__ __forceinline__ void publish_class(const Lds& L, int k, int lane) {
     for (int i = lane; i < NA; i += kWave) {
       const int i32 = (i < D) ? i : i + (DPAD - D);
-      slot[k * NAP + i32] = (float)L.b.apack[k * NA + i];
+      L.a32[k * NAP + i32] = (float)L.b.apack[k * NA + i];
     }
   }
-  static __device__ __forceinline__ void publish_all(const Lds& L, float* slot, int tid) {
+  static __device__ __forceinline__ void publish_all(const Lds& L, int tid) {
     for (int x = tid; x < K * NA; x += kEmThreads) {
       const int k = x / NA, i = x - k * NA;
       const int i32 = (i < D) ? i : i + (DPAD - D);
-      slot[k * NAP + i32] = (float)L.b.apack[x];
+      L.a32[k * NAP + i32] = (float)L.b.apack[x];
     }
   }
 
   // ---- member workgroup of a remainder problem (run_split of cacgmm_em.hpp, packed phases) -----
-  static __device__ void run_member(const EmArgs& ga, char* smem, int mblock, int nblocks,
-                                    float* slot) {
+  static __device__ void run_member(const EmArgs& ga, char* smem, int mblock, int nblocks) {
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
@@ -595,8 +606,7 @@ struct EmKernel32 {
     if (model_in) {
       for (int k = wave; k < K; k += kEmWaves) Base::prep_from_model(a, L.b, b, k, lane);
       __syncthreads();
-      publish_all(L, slot, tid);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      publish_all(L, tid);
     } else {
       phase_init_gamma(a, L, b, tid, wave, lane, tf);
     }
@@ -604,7 +614,7 @@ struct EmKernel32 {
     for (int it = 0; it < a.iterations; ++it) {
       if (it > 0 || model_in) {
         if ((wave << 6) < a.T) {  // windows are <= 256 frames: one E pass
-          phase_e<false>(a, L, slot, b, tid, wave, lane, (float)a.aff_eps, tf);
+          phase_e<false>(a, L, b, tid, wave, lane, (float)a.aff_eps, tf);
         } else if (lane < K) {
           L.b.red[wave * K + lane] = 0.0;
         }
@@ -628,8 +638,7 @@ struct EmKernel32 {
         for (int k = wave; k < K; k += kEmWaves) Base::factor_class(fa, L.b, b, k, lane, last);
         __syncthreads();
       }
-      publish_all(L, slot, tid);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      publish_all(L, tid);
       __syncthreads();
     }
     if (tid < K) {
@@ -638,7 +647,7 @@ struct EmKernel32 {
                        (Base::split_failed(a) ? (PBBSS_ST_EIG_NOCONV | PBBSS_ST_NONFINITE) : 0);
       if (a.out_status && bits) atomicOr(a.out_status + (size_t)b * K + tid, bits);
     }
-    if (a.final_predict) phase_e<true>(a, L, slot, b, tid, wave, lane, (float)a.final_eps, tf);
+    if (a.final_predict) phase_e<true>(a, L, b, tid, wave, lane, (float)a.final_eps, tf);
     if (tid == 0) {  // the member that leaves last zeroes the arrival counters of the problem
       unsigned* ex = a.xcount + 8 + prob;
       const unsigned before =
@@ -655,13 +664,24 @@ struct EmKernel32 {
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
-    float* slot = a.a32 + (size_t)blockIdx.x * slot_floats();
     if (a.main_grid > 0 && (int)blockIdx.x >= a.main_grid) {
-      run_member(a, smem, (int)blockIdx.x - a.main_grid, (int)gridDim.x - a.main_grid, slot);
+      run_member(a, smem, (int)blockIdx.x - a.main_grid, (int)gridDim.x - a.main_grid);
       return;
     }
     const int bstride = a.main_grid > 0 ? a.main_grid : (int)gridDim.x;
     const Lds L = carve(smem, a.T);
+#ifdef PBBSS_PHASE_PROFILE
+    unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = __builtin_readcyclecounter();
+#define PBBSS_TICK32(i)                                      \
+  {                                                          \
+    unsigned long long tn = __builtin_readcyclecounter();    \
+    pc[i] += tn - tprev;                                     \
+    tprev = tn;                                              \
+  }
+#else
+#define PBBSS_TICK32(i)
+#endif
     for (int64_t b = blockIdx.x; b < a.B; b += bstride) {
       __syncthreads();  // previous problem fully retired before LDS is reused
       if (tid < K) L.b.status[tid] = 0;
@@ -673,35 +693,46 @@ struct EmKernel32 {
       if (model_in) {
         for (int k = wave; k < K; k += kEmWaves) {
           Base::prep_from_model(a, L.b, b, k, lane);
-          publish_class(L, slot, k, lane);
+          publish_class(L, k, lane);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       } else {
         phase_init_gamma(a, L, b, tid, wave, lane);
       }
       __syncthreads();
+      PBBSS_TICK32(0)
       for (int it = 0; it < a.iterations; ++it) {
         if (it > 0 || model_in) {
-          phase_e<false>(a, L, slot, b, tid, wave, lane, (float)a.aff_eps);
+          phase_e<false>(a, L, b, tid, wave, lane, (float)a.aff_eps);
+          PBBSS_TICK32(1)
           __syncthreads();
+          PBBSS_TICK32(2)
         }
         phase_m_dispatch(a, L, wave, lane);
+        PBBSS_TICK32(3)
         __syncthreads();
+        PBBSS_TICK32(4)
         const bool last = (it == a.iterations - 1);
         for (int k = wave; k < K; k += kEmWaves) {
           Base::factor_class(a, L.b, b, k, lane, last);
-          publish_class(L, slot, k, lane);  // same wave wrote apack of class k: wave-ordered LDS
+          publish_class(L, k, lane);  // same wave wrote apack of class k: wave-ordered LDS
         }
-        // the operand rows must be in L2 before any wave of the workgroup starts the next E phase
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PBBSS_TICK32(5)
         __syncthreads();
+        PBBSS_TICK32(6)
       }
       if (tid < K) {
         if (a.out_weight && a.iterations > 0) a.out_weight[(size_t)b * K + tid] = L.b.wgt[tid];
         if (a.out_status) a.out_status[(size_t)b * K + tid] = L.b.status[tid];
       }
-      if (a.final_predict) phase_e<true>(a, L, slot, b, tid, wave, lane, (float)a.final_eps);
+      if (a.final_predict) phase_e<true>(a, L, b, tid, wave, lane, (float)a.final_eps);
+      PBBSS_TICK32(7)
     }
+#ifdef PBBSS_PHASE_PROFILE
+    // [wave][8] cycle sums over all workgroups (same slots as the float64 kernel)
+    if (a.prof && lane == 0) {
+      for (int i = 0; i < 8; ++i) atomicAdd(a.prof + wave * 8 + i, pc[i]);
+    }
+#endif
   }
 };
 

@@ -58,9 +58,6 @@ static int launch32(EmArgs a, const EmLaunchCfg& cfg, hipStream_t stream) {
   } else if (grid > a.B) {
     grid = a.B;
   }
-  a.a32 = static_cast<float*>(
-      cfg.get_scratch(cfg.scratch_ctx, (size_t)grid * Kern::slot_floats() * sizeof(float)));
-  if (!a.a32) return PBBSS_ERR_HIP;
   hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(kEmThreads), lds, stream, a);
   return hipGetLastError() == hipSuccess ? PBBSS_OK : PBBSS_ERR_HIP;
 }

@@ -15,6 +15,10 @@ NAMES = ['load/init', 'E', 'E-barrier+sums', 'M', 'M-barrier', 'factor', 'factor
 
 
 def main():
+    f32 = '--f32' in sys.argv
+    if f32:
+        sys.argv.remove('--f32')
+    kw = {'precision': 'f32'} if f32 else {}
     nutt = int(sys.argv[1]) if len(sys.argv) > 1 else 1
     nb = int(sys.argv[2]) if len(sys.argv) > 2 else 513 * nutt  # bins actually used (e.g. 512: no tail)
     iters = 100
@@ -26,9 +30,9 @@ def main():
     h = _lib.handle()
     _lib.load().pbbss_set_phase_profile(h, ctypes.c_void_p(cnt.data_ptr()))
     engine.set_timing(True)
-    engine.em_fit(y, 3, gamma0=g0, iterations=iters, final_predict=True)  # warm-up
+    engine.em_fit(y, 3, gamma0=g0, iterations=iters, final_predict=True, **kw)  # warm-up
     cnt.zero_()
-    engine.em_fit(y, 3, gamma0=g0, iterations=iters, final_predict=True)
+    engine.em_fit(y, 3, gamma0=g0, iterations=iters, final_predict=True, **kw)
     ms = engine.last_kernel_ms()
     call = cnt.cpu().numpy().astype(np.float64)
     c = call[:32].reshape(4, 8)
