@@ -477,6 +477,16 @@ def run_headline(args, world, rank, local_rank, dev, use_dist, precision='f64'):
         torch.cuda.synchronize()
         gather_ms = max_over_ranks(e0.elapsed_time(e1) / 10, use_dist, dev)
     same = identical_on_all_ranks(masks, use_dist, world)
+    got2 = None
+    if precision != 'f64' and args.check_bins:
+        # per-step check of the single-precision kernel (see the verification below): two
+        # iterations from the same initialisation, a separate untimed launch on every rank
+        r2 = engine.em_fit(y, K, gamma0=g0, iterations=2, final_predict=True, check_status=False,
+                           **fit_kw)
+        m2 = r2['affiliation'].reshape(world, n_loc, K, T)
+        if use_dist:
+            m2 = all_gather_bins(m2, F, bin_axis=1)
+        got2 = _lib.to_host(m2)
     st = _lib.to_host(r['status'])
     status_or = int(np.bitwise_or.reduce(st.ravel()))
     if use_dist:
@@ -542,12 +552,18 @@ def run_headline(args, world, rank, local_rank, dev, use_dist, precision='f64'):
             Y128 = data[u][0][fs].astype(np.complex128)
             if precision == 'f64':
                 ref = oc.em_predict(oc.em_fit(Y128, data[u][1][fs], iterations=args.iters), Y128)
+                got_u = got_all[u]
             else:
-                ref = None
+                # single precision cannot be compared over a 100-iteration trajectory (SURVEY 7:
+                # the reference's own float32 path drifts 2e-2 from its float64 path): the packed
+                # kernel is checked per step -- two iterations from the same initialisation, in a
+                # separate untimed launch over this rank's full problem set -- with the tolerance
+                # of the parity tests
+                ref = oc.em_predict(oc.em_fit(Y128, data[u][1][fs], iterations=2), Y128)
+                got_u = got2[u]
+                tol = 2e-4
             for j, (rr, f) in enumerate(sel):
-                if ref is None:
-                    continue
-                e = float(np.abs(got_all[u, f] - ref[j]).max())
+                e = float(np.abs(got_u[f] - ref[j]).max())
                 per_shard[rr] = max(per_shard[rr], e)
                 worst = max(worst, e)
             nchk += len(sel)
@@ -559,9 +575,12 @@ def run_headline(args, world, rank, local_rank, dev, use_dist, precision='f64'):
             'ok': bool(worst < tol),
             'includes_remainder_bin': True,
             'gathered_masks_identical_on_all_ranks': same,
-            'what': 'posterior masks after all EM iterations vs the float64 NumPy oracle on bins '
-                    'drawn from every rank\'s shard (first, last and evenly spaced bins) of every '
-                    'utterance; checksum of the gathered tensor compared across ranks',
+            'what': ('posterior masks after all EM iterations' if precision == 'f64' else
+                     'posterior masks after TWO EM iterations from the same initialisation (per-step '
+                     'check of the single-precision kernel; separate untimed launch)') +
+                    ' vs the float64 NumPy oracle on bins drawn from every rank\'s shard (first, '
+                    'last and evenly spaced bins) of every utterance; checksum of the gathered '
+                    'tensor compared across ranks',
         }
     return out, data[0]
 
@@ -812,7 +831,7 @@ def main():
         if rank == 0:
             f32, _ = r32
             out['f32'] = {k: f32[k] for k in ('value', 'unit', 'ms_per_step', 'dtype', 'config',
-                                              'roofline', 'status_bits_or', 'sustained')
+                                              'roofline', 'status_bits_or', 'sustained', 'verify')
                           if k in f32}
     if args.config3 == 'auto':
         blk, _ = run_config3(args, world, rank, local_rank, dev, use_dist)
