@@ -489,11 +489,12 @@ def run_headline(args, world, rank, local_rank, dev, use_dist, precision='f64'):
         got2 = _lib.to_host(m2)
     st = _lib.to_host(r['status'])
     status_or = int(np.bitwise_or.reduce(st.ravel()))
-    if use_dist:
-        tt = torch.tensor([status_or], dtype=torch.int64, device=dev)
+    if use_dist:  # NCCL has no bitwise-or reduction: gather the words, OR them here
         import torch.distributed as dist
-        dist.all_reduce(tt, op=dist.ReduceOp.BOR)
-        status_or = int(tt.item())
+        tt = torch.tensor([status_or], dtype=torch.int64, device=dev)
+        allst = torch.empty((world,), dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(allst, tt)
+        status_or = int(np.bitwise_or.reduce(_lib.to_host(allst)))
     if rank != 0:
         return None
 

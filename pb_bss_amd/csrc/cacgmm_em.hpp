@@ -129,9 +129,6 @@ struct EmKernel {
 #ifndef PBBSS_E_CHUNK
 #define PBBSS_E_CHUNK 1
 #endif
-#ifndef PBBSS_E_DPP
-#define PBBSS_E_DPP 1
-#endif
 #ifndef PBBSS_E_PAIR
 #define PBBSS_E_PAIR 0
 #endif
@@ -371,12 +368,7 @@ struct EmKernel {
 #pragma unroll
         for (int k = 0; k < K; ++k) q[f][k] = 0.0;
       }
-      // q_k = <A_k, P>: diagonal, then the strict upper triangle in chunks of
-      // kOperandChunk pairs.  The A_k operands of chunk c+1 are fetched from LDS
-      // (uniform address = broadcast read) BEFORE the FMAs of chunk c issue, so
-      // the LDS latency hides behind float64 work; compiler fences pin that
-      // order (left alone hipcc loads just-in-time and stalls on every read).
-#if PBBSS_E_DPP
+      // q_k = <A_k, P>: diagonal, then the strict upper triangle
       {
         // A_k as DPP operands: lane l keeps apack[k][16 g + (l & 15)] (one conflict-free
         // ds_read_b64 per 16 operands instead of one broadcast read per operand), and every
@@ -417,71 +409,6 @@ struct EmKernel {
           }
         });
       }
-#else
-      {
-        constexpr int NCH = (NOFF + kOperandChunk - 1) / kOperandChunk;
-        double op[2][kOperandChunk][K][2];
-        auto fetch = [&](auto cc, auto bb) {
-          constexpr int c = cc, bsel = bb;
-#pragma unroll
-          for (int x = 0; x < kOperandChunk; ++x) {
-            if (c * kOperandChunk + x < NOFF) {
-#pragma unroll
-              for (int k = 0; k < K; ++k) {
-                op[bsel][x][k][0] = L.apack[k * NA + D + 2 * (c * kOperandChunk + x)];
-                op[bsel][x][k][1] = L.apack[k * NA + D + 2 * (c * kOperandChunk + x) + 1];
-              }
-            }
-          }
-        };
-        if constexpr (NCH > 0) fetch(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
-        asm volatile("" ::: "memory");
-        static_for<0, D>([&](auto ic) {
-          constexpr int i = ic;
-          double ad[K];
-#pragma unroll
-          for (int k = 0; k < K; ++k) ad[k] = L.apack[k * NA + i];
-#pragma unroll
-          for (int f = 0; f < NF; ++f) {
-            double dg = re[f][i] * re[f][i] + im[f][i] * im[f][i];
-#pragma unroll
-            for (int k = 0; k < K; ++k) q[f][k] = fma(ad[k], dg, q[f][k]);
-          }
-        });
-        static_for<0, NCH>([&](auto cc) {
-          constexpr int c = cc;
-          constexpr int cur = c & 1;
-          if constexpr (c + 1 < NCH) {
-            fetch(std::integral_constant<int, c + 1>{}, std::integral_constant<int, 1 - cur>{});
-          }
-          asm volatile("" ::: "memory");
-          __builtin_amdgcn_sched_barrier(0);
-          static_for<0, kOperandChunk>([&](auto xc) {
-            constexpr int x = xc;
-            constexpr int p = c * kOperandChunk + x;
-            if constexpr (p < NOFF) {
-              constexpr int i = tri_i<D>(p), j = tri_j<D>(p);
-#pragma unroll
-              for (int f = 0; f < NF; ++f) {
-                double pr = re[f][i] * re[f][j] + im[f][i] * im[f][j];   // Re y_i conj(y_j)
-                double pim = im[f][i] * re[f][j] - re[f][i] * im[f][j];  // Im y_i conj(y_j)
-#pragma unroll
-                for (int k = 0; k < K; ++k)
-                  q[f][k] = fma(op[cur][x][k][0], pr, fma(op[cur][x][k][1], pim, q[f][k]));
-              }
-            }
-          });
-          // tie the partial sums to the stage boundary (pure arithmetic is not ordered by the
-          // memory clobber: left alone the FMAs sink below later fetches and the operands spill)
-#pragma unroll
-          for (int f = 0; f < NF; ++f) {
-#pragma unroll
-            for (int k = 0; k < K; ++k) asm volatile("" : "+v"(q[f][k])::"memory");
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        });
-      }
-#endif
       // per-class constants (fetched here, not at phase entry: keeping them live
       // across the operand loop costs spills)
       double detm[K], rdet[K], wgt[K];

@@ -293,9 +293,6 @@ struct WatsonKernel {
     if (wave_or((isfinite(are) && isfinite(aim)) ? 0 : 1)) st |= PBBSS_ST_NONFINITE;
     double vre, vim;
     int sweeps;
-#if defined(PBBSS_CW_KNOCK) && PBBSS_CW_KNOCK == 9
-    long long f0 = wall_clock64(), f1 = f0, f2 = f0;
-#endif
     if (warm && !(st & PBBSS_ST_NONFINITE)) {
       double hre, him, tre, tim, bre, bim;
       wave_adjoint(pvre, pvim, c, hre, him);               // V'^H
@@ -309,13 +306,7 @@ struct WatsonKernel {
         bim = 0.0;
       }
       double wre, wim;
-#if defined(PBBSS_CW_KNOCK) && PBBSS_CW_KNOCK == 9
-      f1 = wall_clock64();
-#endif
       sweeps = wave_jacobi_heev_tab<D>(bre, bim, c, wre, wim, jtab, lane);
-#if defined(PBBSS_CW_KNOCK) && PBBSS_CW_KNOCK == 9
-      f2 = wall_clock64();
-#endif
       wave_matmul<D>(pvre, pvim, wre, wim, c, vre, vim);   // V = V' W
       are = bre;
       aim = bim;
@@ -338,13 +329,7 @@ struct WatsonKernel {
         lmax = lm;
       }
     }
-#if defined(PBBSS_CW_KNOCK) && PBBSS_CW_KNOCK == 9
-    long long f3 = wall_clock64();
-#endif
     const double kappa = watson_concentration(wa, knot1, lmax, lane);
-#if defined(PBBSS_CW_KNOCK) && PBBSS_CW_KNOCK == 9
-    long long f4 = wall_clock64();
-#endif
     // mode components for this lane's row and column index
     double mre_i = lane_get(vre, ij_lane(c.i, col)), mim_i = lane_get(vim, ij_lane(c.i, col));
     set_class(L, k, lane, c, mre_i, mim_i, kappa);
@@ -357,12 +342,6 @@ struct WatsonKernel {
       if (lane == 0 && wa.out_conc) wa.out_conc[(size_t)b * K + k] = kappa;
     }
     if (lane == 0) L.status[k] |= st;
-#if defined(PBBSS_CW_KNOCK) && PBBSS_CW_KNOCK == 9
-    long long f5 = wall_clock64();
-    if (b == 3 && lane == 0 && k == 1)
-      printf("F: sweeps %d rotate-in %lld jacobi %lld back+sort %lld conc %lld setclass %lld kappa %g\n",
-             sweeps, f1 - f0, f2 - f1, f3 - f2, f4 - f3, f5 - f4, kappa);
-#endif
   }
 
   static __device__ void prep_from_model(const WatsonArgs& wa, const Lds& L, int64_t b, int k,
@@ -413,24 +392,10 @@ struct WatsonKernel {
       __syncthreads();
       double pvre = 0.0, pvim = 0.0;  // previous eigenvectors of class `wave` (K <= 4 <= waves)
       for (int it = 0; it < a.iterations; ++it) {
-#ifdef PBBSS_CW_KNOCK  // development builds: skip one phase after the first iterations (timing)
-        const bool ko = it >= 3 && !(it == a.iterations - 1);
-#else
-        constexpr bool ko = false;
-        constexpr int PBBSS_CW_KNOCK = 0;
-#endif
-#if defined(PBBSS_CW_KNOCK) && PBBSS_CW_KNOCK == 9
-        static_assert(true, "");
-        long long c0 = wall_clock64();
-#endif
-        if ((it > 0 || model_in) && !(ko && PBBSS_CW_KNOCK == 1)) {
+        if (it > 0 || model_in) {
           phase_e<false>(wa, L, b, tid, wave, lane);
           __syncthreads();
         }
-#if defined(PBBSS_CW_KNOCK) && PBBSS_CW_KNOCK == 9
-        long long c1 = wall_clock64();
-#endif
-        if (!(ko && PBBSS_CW_KNOCK == 2))
         switch (wave) {
           case 0: Base::template phase_m<0>(a, L, lane); break;
           case 1: Base::template phase_m<1>(a, L, lane); break;
@@ -440,20 +405,9 @@ struct WatsonKernel {
         __syncthreads();
         const bool last = (it == a.iterations - 1);
         static_assert(K <= kEmWaves, "one class per wave: the warm start lives in its registers");
-#if defined(PBBSS_CW_KNOCK) && PBBSS_CW_KNOCK == 9
-        long long c2 = wall_clock64();
-#endif
-        if (wave < K && !(ko && PBBSS_CW_KNOCK == 3))
+        if (wave < K)
           factor_class(wa, L, knot1, jtab, b, wave, lane, last, it > 0, pvre, pvim);
-#if defined(PBBSS_CW_KNOCK) && PBBSS_CW_KNOCK == 9
-        long long c3 = wall_clock64();
-#endif
         __syncthreads();
-#if defined(PBBSS_CW_KNOCK) && PBBSS_CW_KNOCK == 9
-        long long c4 = wall_clock64();
-        if (it >= 50 && it < 53 && b == 3 && lane == 0 && wave < 3)
-          printf("it %d wave %d: E %lld M %lld F %lld wait %lld (10 ns ticks)\n", it, wave, c1 - c0, c2 - c1, c3 - c2, c4 - c3);
-#endif
       }
       if (tid < K) {
         if (a.out_weight && a.iterations > 0) a.out_weight[(size_t)b * K + tid] = L.wgt[tid];

@@ -28,9 +28,9 @@ def main(root, cmd, sha='', steps=25):
     if sha:
         # bench.py only reads PMC figures from a summary whose hash matches the tree it runs in
         print(f'# kernel_source_sha: {sha}')
-    print('# (F=513 T=500 D=8 K=3, 100 EM iterations + final E-step per step; each step = ONE '
-          'cacgmm_em_kernel launch: 512 full workgroups + the 8 member workgroups of bin 512 in the '
-          'same grid)')
+    print('# (F=513 T=500 D=8 K=3, 100 EM iterations + final E-step per step; each step = '
+          'cacgmm_em_kernel (512 bins, the caller\'s stream) + cacgmm_em_split_kernel (bin 512 as 8 '
+          'member workgroups, side stream) concurrently; the HIP events bracket both)')
     un = None
     try:
         with open(os.path.join(root, 'unprofiled.json')) as f:
@@ -62,7 +62,15 @@ def main(root, cmd, sha='', steps=25):
         res = {k: rows[-1].get(k) for k in (
             'Grid_Size_X', 'Workgroup_Size_X', 'LDS_Block_Size', 'Scratch_Size', 'VGPR_Count',
             'Accum_VGPR_Count', 'SGPR_Count')}
-        print('# dispatch resources:', res)
+        print('# dispatch resources (EM kernel):', res)
+        srows = [r for r in csv.DictReader(open(f)) if short(r['Kernel_Name']) == 'split']
+        srows.sort(key=lambda r: int(r['Start_Timestamp']))
+        sd = [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3 for r in srows][-steps:]
+        if sd:
+            print('# concurrent split kernel of the remainder bin, same launches: '
+                  'split_kernel_trace_us | median | min | max | n')
+            print(f'split_kernel_trace_us | {statistics.median(sd):.1f} | {min(sd):.1f} | '
+                  f'{max(sd):.1f} | {len(sd)}')
     for f in glob.glob(os.path.join(root, 'trace', '**', '*kernel_stats.csv'), recursive=True):
         print('# rocprofv3 --stats of the whole pass (ALL launches, pre-heat included): '
               'name | calls | avg_us | min_us | max_us | pct')
