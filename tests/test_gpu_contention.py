@@ -1,0 +1,120 @@
+"""GPU: the spin-wait protocols under contention for compute units.
+
+The split groups of the remainder bin (L2 slabs + arrival counters), the cooperative
+shared-weight kernel (split-phase grid barrier) and the packed-FP32 kernel's in-grid members all
+wait for peer workgroups with BOUNDED spins that poison the status words instead of hanging.  On
+an otherwise idle GPU the peers are always co-resident; the multi-rank situation -- a second
+handle / host thread, an RCCL collective in flight -- is what this file provokes: several such
+fits run CONCURRENTLY from different host threads (one library handle and one stream each), and
+every result must equal the one obtained alone, with clean status words and no sticky time-out
+flag (pbbss_split_error)."""
+import os
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_threads(jobs):
+    """jobs: list of callables; each runs on its own host thread (own handle) and torch stream."""
+    import torch
+    out, errs = [None] * len(jobs), []
+
+    def work(i):
+        try:
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                out[i] = jobs[i]()
+                s.synchronize()
+        except Exception as e:  # noqa: BLE001
+            errs.append((i, repr(e)))
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(len(jobs))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    assert not any(t.is_alive() for t in th), 'a concurrent fit did not finish'
+    assert not errs, errs
+    return out
+
+
+def test_split_tail_shared_weight_and_packed_fits_concurrently():
+    from pb_bss_amd import _lib, engine
+    from pb_bss_amd.testing import synth
+    F, T, D, K, iters, reps = 513, 500, 8, 3, 12, 6
+    Y, init = synth.make_stft(F, T, D, K, seed=0)
+    Y2, init2 = synth.make_stft(F, T, D, K, seed=1)
+    y, g0 = _lib.to_device(Y), _lib.to_device(init)
+    y2, g2 = _lib.to_device(Y2), _lib.to_device(init2)
+
+    def split_fit():       # 512 full workgroups + 8 split-group members (side stream of the handle)
+        r = None
+        for _ in range(reps):
+            r = engine.em_fit(y, K, gamma0=g0, iterations=iters, final_predict=True)
+        return _lib.to_host(r['affiliation']), _lib.to_host(r['status']), engine.split_error()
+
+    def shared_fit():      # cooperative launch: 513 workgroups wait for each other every iteration
+        r = None
+        for _ in range(reps):
+            r = engine.em_fit_shared(y2, K, F, weight_mode=_lib.WEIGHT_SHARED_K, gamma0=g2,
+                                     iterations=iters, final_predict=True)
+            assert r is not None
+        return _lib.to_host(r['affiliation']), _lib.to_host(r['status']), engine.split_error()
+
+    def packed_fit():      # packed-FP32 kernel: the members of bin 512 sit inside the grid
+        r = None
+        for _ in range(reps):
+            r = engine.em_fit(y, K, gamma0=g0, iterations=iters, final_predict=True,
+                              precision='f32')
+        return _lib.to_host(r['affiliation']), _lib.to_host(r['status']), engine.split_error()
+
+    alone = [split_fit(), shared_fit(), packed_fit()]
+    together = _run_threads([split_fit, shared_fit, packed_fit])
+    for name, a, b in zip(('split-tail', 'shared-weight', 'packed-FP32'), alone, together):
+        assert b[2] == 0, f'{name}: a bounded spin ran out under contention'
+        assert int(b[1].max()) & 3 == 0, f'{name}: poisoned status words'
+        # same arithmetic, same summation orders: bit-identical whoever else runs
+        assert np.array_equal(a[0], b[0]), (name, np.abs(a[0] - b[0]).max())
+
+
+def test_split_tail_fit_with_an_rccl_gather_in_flight():
+    """The exchange step of the sharded path on one stream while the EM (split groups on the
+    handle's side stream) runs on another, both ways round, many times."""
+    import torch
+    import torch.distributed as dist
+    from pb_bss_amd import _lib, engine, sharding
+    from pb_bss_amd.testing import synth
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29535')
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        F, T, D, K = 513, 500, 8, 3
+        Y, init = synth.make_stft(F, T, D, K, seed=2)
+        y, g0 = _lib.to_device(Y), _lib.to_device(init)
+        ref = engine.em_fit(y, K, gamma0=g0, iterations=10, final_predict=True)
+        ref_aff = _lib.to_host(ref['affiliation'])
+        big = torch.randn(64, F, K, T, dtype=torch.float64, device='cuda')  # 394 MB gather
+
+        def fits():
+            r = None
+            for _ in range(8):
+                r = engine.em_fit(y, K, gamma0=g0, iterations=10, final_predict=True)
+            return _lib.to_host(r['affiliation']), _lib.to_host(r['status']), engine.split_error()
+
+        def gathers():
+            out = None
+            for _ in range(8):
+                out = sharding.all_gather_bins(big, F, bin_axis=1)
+            return bool((out == big).all().item())
+
+        (aff, st, err), ok = _run_threads([fits, gathers])
+        assert ok and err == 0 and int(st.max()) & 3 == 0
+        assert np.array_equal(aff, ref_aff)
+    finally:
+        if created:
+            dist.destroy_process_group()
