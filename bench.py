@@ -203,8 +203,10 @@ def roofline_block(kernel_ms, bins, iters, ms_per_step=None, world_note='', peak
     return {
         'bound': bound, 'achieved': tflops, 'peak': peak_tf, 'unit': 'TFLOP/s',
         'frac': tflops / peak_tf, 'traffic': traffic, 'traffic_source': traffic_src,
-        'kernel': kernel + ' (the remainder bins of a launch ride in the same grid as member '
-                           'workgroups; kernel_ms brackets the launch)' + world_note,
+        'kernel': kernel + ' (kernel_ms = duration of this kernel, HIP events attached to its '
+                           'dispatch; the remainder bin of a launch runs as member workgroups -- a '
+                           'concurrent, shorter cacgmm_em_split_kernel on a side stream for float64, '
+                           'blocks of the same grid for the packed kernel)' + world_note,
         'kernel_ms': kernel_ms,
         'flops_per_frame_iter': FLOPS_PER_FRAME_ITER,
         'flops_note': 'useful flops of the kernel\'s algorithm per frame and EM iteration: '
@@ -347,23 +349,34 @@ def preheat(step, seconds, use_dist, dev):
             'note': 'untimed clock ramp before the W warm-up steps (--preheat-s)'}
 
 
-def timed(step, steps, warmup, use_dist, dev):
+def run_steps(step, n, read_ms):
+    """n steps; with read_ms the kernel time of EVERY one of them is collected -- two launches
+    late inside the loop, the last two after it -- without ever draining the queue.  -> (last
+    result, summed kernel ms)."""
+    last, kms = None, 0.0
+    for i in range(n):
+        last = step()
+        if read_ms is not None and i >= 2:
+            kms += read_ms(2)
+    if read_ms is not None:
+        for lag in range(min(n, 2) - 1, -1, -1):
+            kms += read_ms(lag)
+    return last, kms
+
+
+def timed(step, steps, warmup, use_dist, dev, read_ms=None):
     """W warm-up steps, then EXACTLY K steps between barrier + synchronize; max over ranks."""
     for _ in range(warmup):
         step()
     fence(use_dist)
     t0 = time.perf_counter()
-    last = None
-    kernel_ms = 0.0
-    for _ in range(steps):
-        last = step()
-        kernel_ms += last.get('kernel_ms', 0.0)
+    last, kernel_ms = run_steps(step, steps, read_ms)
     fence(use_dist)
     elapsed = max_over_ranks(time.perf_counter() - t0, use_dist, dev)
     return elapsed, kernel_ms / max(steps, 1), last
 
 
-def sustained(step, seconds, ms_per_step, min_steps, use_dist, dev):
+def sustained(step, seconds, ms_per_step, min_steps, use_dist, dev, read_ms=None):
     """The same step back to back for >= `seconds` (every rank runs the same count: the step may
     contain a collective)."""
     if seconds <= 0:
@@ -371,9 +384,7 @@ def sustained(step, seconds, ms_per_step, min_steps, use_dist, dev):
     n = max(min_steps, int(math.ceil(seconds * 1e3 / max(ms_per_step, 1e-3))))
     fence(use_dist)
     t0 = time.perf_counter()
-    kms = 0.0
-    for _ in range(n):
-        kms += step().get('kernel_ms', 0.0)
+    _, kms = run_steps(step, n, read_ms)
     fence(use_dist)
     el = max_over_ranks(time.perf_counter() - t0, use_dist, dev)
     return {'seconds': el, 'steps': n, 'ms_per_step': el / n * 1e3, 'kernel_ms': kms / n,
@@ -447,7 +458,6 @@ def run_headline(args, world, rank, local_rank, dev, use_dist, precision='f64'):
     def step():
         r = engine.em_fit(y, K, gamma0=g0, iterations=args.iters, final_predict=True,
                           check_status=False, **fit_kw)
-        ms = engine.last_kernel_ms(local_rank)  # HIP events on the launch stream
         masks = r['affiliation'].reshape(world, n_loc, K, T)
         if use_dist:
             # the one exchange step of the path: all-gather the masks over RCCL/xGMI, in stream
@@ -456,12 +466,16 @@ def run_headline(args, world, rank, local_rank, dev, use_dist, precision='f64'):
             # kernel's workgroups are being placed skews their distribution for the whole
             # launch -- 1.71 -> 2.45 ms per EM kernel with one rank.)
             masks = all_gather_bins(masks, F, bin_axis=1)
-        return {'masks': masks, 'kernel_ms': ms, 'r': r}
+        return {'masks': masks, 'r': r}
 
+    # HIP events on the dispatch of the EM kernel (library, launch stream), read TWO launches late:
+    # reading the most recent launch would drain the queue every step and put the host's launch
+    # latency (~30 us) on the device's critical path
+    read_ms = lambda lag: engine.last_kernel_ms(local_rank, lag)  # noqa: E731
     ph = preheat(step, args.preheat_s, use_dist, dev)
-    elapsed, kernel_ms, last = timed(step, args.steps, args.warmup, use_dist, dev)
+    elapsed, kernel_ms, last = timed(step, args.steps, args.warmup, use_dist, dev, read_ms)
     ms_per_step = elapsed / args.steps * 1e3
-    sus = sustained(step, args.sustained_s, ms_per_step, args.steps, use_dist, dev)
+    sus = sustained(step, args.sustained_s, ms_per_step, args.steps, use_dist, dev, read_ms)
     masks, r = last['masks'], last['r']
 
     # ---- the exchange step on its own (untimed region): HIP events around the gather ----

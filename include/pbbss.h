@@ -702,6 +702,12 @@ int pbbss_split_error(pbbss_handle_t h, int* out_flag);
  * with -DPBBSS_PHASE_PROFILE (`make prof`), ignored otherwise.  NULL disables. */
 int pbbss_set_phase_profile(pbbss_handle_t h, void* dev_counters);
 int pbbss_last_kernel_ms(pbbss_handle_t h, float* out_ms);
+/* Duration of the timed region `lag` launches ago (0 = the most recent one = pbbss_last_kernel_ms;
+ * up to 3).  Waits only for THAT launch: a caller that reads lag = 2 after every launch keeps two
+ * launches queued behind the running one, whereas reading the most recent one drains the queue and
+ * exposes the host's launch latency on the device (~30 us per step, tools/launch_gap.py).  For
+ * pbbss_cacgmm_fit the region is the EM kernel itself (events attached to its dispatch). */
+int pbbss_kernel_ms_lagged(pbbss_handle_t h, int lag, float* out_ms);
 
 #ifdef __cplusplus
 }

@@ -45,7 +45,7 @@ EXPORTS = (
     'pbbss_allgather_masks', 'pbbss_allgather_unpack', 'pbbss_estimate_mixture_weight',
     'pbbss_solve', 'pbbss_mvdr_souden', 'pbbss_mvdr', 'pbbss_ban',
     'pbbss_apply_beamforming_vector', 'pbbss_set_timing',
-    'pbbss_last_kernel_ms', 'pbbss_set_phase_profile',
+    'pbbss_last_kernel_ms', 'pbbss_kernel_ms_lagged', 'pbbss_set_phase_profile',
     'pbbss_dhtv_calculate_mapping', 'pbbss_apply_mapping', 'pbbss_cwmm_fit',
     'pbbss_wmwf', 'pbbss_set_split_tail', 'pbbss_split_error',
     'pbbss_embed_log_pdf', 'pbbss_embed_fit', 'pbbss_vmfmm_fit', 'pbbss_joint_fit',
@@ -157,6 +157,7 @@ def load():
         lib.pbbss_destroy.argtypes = [vp]
         lib.pbbss_set_timing.argtypes = [vp, i32]
         lib.pbbss_last_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
+        lib.pbbss_kernel_ms_lagged.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_float)]
         lib.pbbss_set_phase_profile.argtypes = [vp, vp]
         lib.pbbss_set_split_tail.argtypes = [vp, i32]
         lib.pbbss_set_dhtv_team.argtypes = [vp, i32]

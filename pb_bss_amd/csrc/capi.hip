@@ -33,7 +33,11 @@ struct pbbss_handle_s {
   unsigned long long* prof;
   int timing;
   float last_ms;
-  hipEvent_t ev0, ev1;
+  // timed regions record into a ring of event pairs, so that a caller can read the duration of an
+  // OLDER launch without draining the queue (pbbss_kernel_ms_lagged)
+  static constexpr int kTimingRing = 4;
+  hipEvent_t ring0[kTimingRing], ring1[kTimingRing];
+  unsigned ring_seq;  // timed regions started so far
 };
 
 namespace {
@@ -136,11 +140,15 @@ struct DeviceGuard {
 struct TimedRegion {
   pbbss_handle_t h;
   hipStream_t s;
+  int slot = 0;
   TimedRegion(pbbss_handle_t h_, hipStream_t s_) : h(h_), s(s_) {
-    if (h->timing) (void)hipEventRecord(h->ev0, s);
+    if (h->timing) {
+      slot = (int)(h->ring_seq++ % pbbss_handle_s::kTimingRing);
+      (void)hipEventRecord(h->ring0[slot], s);
+    }
   }
   ~TimedRegion() {
-    if (h->timing) (void)hipEventRecord(h->ev1, s);
+    if (h->timing) (void)hipEventRecord(h->ring1[slot], s);
   }
 };
 }  // namespace
@@ -198,6 +206,8 @@ PBBSS_API int pbbss_create(pbbss_handle_t* out, int device_id) {
   if (const char* p = getenv("PBBSS_SPLIT_PRIO")) h->cfg.split_prio = atoi(p);
   h->split_epoch = 1;
   h->cfg.split_epoch = &h->split_epoch;
+  h->cfg.ev_t0 = nullptr;
+  h->cfg.ev_t1 = nullptr;
   if (const char* w = getenv("PBBSS_SPLIT_WINDOW")) {
     int v = atoi(w);
     if (v >= 64 && v % 64 == 0) h->cfg.split_window = v;
@@ -246,9 +256,12 @@ PBBSS_API int pbbss_create(pbbss_handle_t* out, int device_id) {
   h->prof = nullptr;
   h->timing = 0;
   h->last_ms = 0.f;
-  if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
-    delete h;
-    return PBBSS_ERR_HIP;
+  h->ring_seq = 0;
+  for (int i = 0; i < pbbss_handle_s::kTimingRing; ++i) {
+    if (hipEventCreate(&h->ring0[i]) != hipSuccess || hipEventCreate(&h->ring1[i]) != hipSuccess) {
+      delete h;
+      return PBBSS_ERR_HIP;
+    }
   }
   *out = h;
   return PBBSS_OK;
@@ -256,8 +269,10 @@ PBBSS_API int pbbss_create(pbbss_handle_t* out, int device_id) {
 
 PBBSS_API int pbbss_destroy(pbbss_handle_t h) {
   if (!h) return PBBSS_ERR_INVALID_ARG;
-  (void)hipEventDestroy(h->ev0);
-  (void)hipEventDestroy(h->ev1);
+  for (int i = 0; i < pbbss_handle_s::kTimingRing; ++i) {
+    (void)hipEventDestroy(h->ring0[i]);
+    (void)hipEventDestroy(h->ring1[i]);
+  }
   if (h->scratch) (void)hipFree(h->scratch);
   if (h->work) (void)hipFree(h->work);
   if (h->comm) (void)pbbss::comm_destroy(h->comm);
@@ -413,14 +428,22 @@ PBBSS_API int pbbss_split_error(pbbss_handle_t h, int* out_flag) {
   return PBBSS_OK;
 }
 
-PBBSS_API int pbbss_last_kernel_ms(pbbss_handle_t h, float* out_ms) {
+PBBSS_API int pbbss_kernel_ms_lagged(pbbss_handle_t h, int lag, float* out_ms) {
   DeviceGuard device_guard(h);
   if (!h || !out_ms) return PBBSS_ERR_INVALID_ARG;
   if (!h->timing) return PBBSS_ERR_INVALID_ARG;
-  if (hipEventSynchronize(h->ev1) != hipSuccess) return PBBSS_ERR_HIP;
-  if (hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1) != hipSuccess) return PBBSS_ERR_HIP;
+  if (lag < 0 || lag >= pbbss_handle_s::kTimingRing || (unsigned)lag >= h->ring_seq)
+    return PBBSS_ERR_INVALID_ARG;
+  const int slot = (int)((h->ring_seq - 1 - (unsigned)lag) % pbbss_handle_s::kTimingRing);
+  if (hipEventSynchronize(h->ring1[slot]) != hipSuccess) return PBBSS_ERR_HIP;
+  if (hipEventElapsedTime(&h->last_ms, h->ring0[slot], h->ring1[slot]) != hipSuccess)
+    return PBBSS_ERR_HIP;
   *out_ms = h->last_ms;
   return PBBSS_OK;
+}
+
+PBBSS_API int pbbss_last_kernel_ms(pbbss_handle_t h, float* out_ms) {
+  return pbbss_kernel_ms_lagged(h, 0, out_ms);
 }
 
 PBBSS_API int pbbss_normalize_observation(pbbss_handle_t h, const void* y, int is_c128,
@@ -586,14 +609,22 @@ PBBSS_API int pbbss_cacgmm_fit(pbbss_handle_t h, const void* y, int64_t B, int T
   a.final_eps = 0.0;  // model.predict: affiliation_eps = 0 (cacgmm.py:73)
   a.eig_floor = o->eigenvalue_floor;
   a.prof = h->prof;
-  TimedRegion tr(h, as_stream(stream));
+  // timing of the fused EM launch: events on the kernel dispatch itself (em_launch.hpp), the
+  // duration of the EM kernel as a kernel trace sees it (the split kernel of a remainder bin runs
+  // concurrently on the side stream and is shorter)
+  pbbss::EmLaunchCfg cfg = h->cfg;
+  if (h->timing) {
+    const int slot = (int)(h->ring_seq++ % pbbss_handle_s::kTimingRing);
+    cfg.ev_t0 = h->ring0[slot];
+    cfg.ev_t1 = h->ring1[slot];
+  }
   if (f32) {
-    const int rc = pbbss::em32_launch(D, K, a, h->cfg, as_stream(stream));
+    const int rc = pbbss::em32_launch(D, K, a, cfg, as_stream(stream));
     // a long utterance does not fit the LDS-resident packed kernel: say "unsupported", the
     // float64 kernel (which has an HBM-scratch variant) serves it
     return rc == PBBSS_ERR_LDS_CAPACITY ? PBBSS_ERR_UNSUPPORTED : rc;
   }
-  return pbbss::em_launch(D, K, o->y_is_c128, a, h->cfg, as_stream(stream));
+  return pbbss::em_launch(D, K, o->y_is_c128, a, cfg, as_stream(stream));
 }
 
 PBBSS_API int pbbss_cacgmm_fit_shared(pbbss_handle_t h, const void* y, int64_t B, int T, int D,

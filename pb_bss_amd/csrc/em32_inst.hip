@@ -58,7 +58,12 @@ static int launch32(EmArgs a, const EmLaunchCfg& cfg, hipStream_t stream) {
   } else if (grid > a.B) {
     grid = a.B;
   }
-  hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(kEmThreads), lds, stream, a);
+  if (cfg.ev_t0) {
+    hipExtLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(kEmThreads), lds, stream, cfg.ev_t0,
+                          cfg.ev_t1, 0, a);
+  } else {
+    hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(kEmThreads), lds, stream, a);
+  }
   return hipGetLastError() == hipSuccess ? PBBSS_OK : PBBSS_ERR_HIP;
 }
 

@@ -2,7 +2,6 @@
 // heavy persistent-EM template instantiates in parallel under `make -j`.
 #include "cacgmm_em.hpp"
 #include "em_launch.hpp"
-#include <cstdlib>
 
 #ifndef PBBSS_EM_D
 #error "compile with -DPBBSS_EM_D=<sensors>"
@@ -49,7 +48,12 @@ static int launch_variant(EmArgs a, const EmLaunchCfg& cfg, hipStream_t stream) 
     a.scratch = static_cast<char*>(cfg.get_scratch(cfg.scratch_ctx, a.scratch_stride * grid));
     if (!a.scratch) return PBBSS_ERR_HIP;
   }
-  hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(kEmThreads), lds, stream, a);
+  if (cfg.ev_t0) {
+    hipExtLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(kEmThreads), lds, stream, cfg.ev_t0,
+                          cfg.ev_t1, 0, a);
+  } else {
+    hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(kEmThreads), lds, stream, a);
+  }
   return hipGetLastError() == hipSuccess ? PBBSS_OK : PBBSS_ERR_HIP;
 }
 
@@ -57,7 +61,7 @@ static int launch_variant(EmArgs a, const EmLaunchCfg& cfg, hipStream_t stream) 
 // concurrent with the main launch (fork/join through events).
 template <int K, typename YS>
 static int launch_split(EmArgs a, int64_t b_first, int r, const EmLaunchCfg& cfg,
-                        hipStream_t stream, bool fork_recorded = false) {
+                        hipStream_t stream) {
   using Kern = EmKernel<PBBSS_EM_D, K, YS, false>;
   const int window = cfg.split_window > 256 ? 256 : cfg.split_window;  // one E pass per window
   const int G = (a.T + window - 1) / window;
@@ -76,7 +80,6 @@ static int launch_split(EmArgs a, int64_t b_first, int r, const EmLaunchCfg& cfg
   a.xerror = reinterpret_cast<int*>(cfg.xbuf + 128);
   a.xslab = reinterpret_cast<double*>(cfg.xbuf + head);
   // fork: everything enqueued on `stream` before the event (the inputs) precedes the side stream
-  if (!fork_recorded && hipEventRecord(cfg.ev_fork, stream) != hipSuccess) return PBBSS_ERR_HIP;
   if (hipStreamWaitEvent(cfg.side_stream, cfg.ev_fork, 0) != hipSuccess) return PBBSS_ERR_HIP;
   // no memsets: the arrival counters are put back to zero by the last member to leave, the error
   // word is stamped with this launch's epoch, member 0 zeroes the status words of its problem
@@ -105,27 +108,16 @@ static int launch_one(const EmArgs& a, const EmLaunchCfg& cfg, hipStream_t strea
   if (!split) return launch_variant<K, YS, false>(a, cfg, stream);
   EmArgs main_a = a;
   main_a.B = a.B - r;
-  // The main launch goes out FIRST: the side-stream preparation of the split groups (fork event,
-  // two memsets, launch) is a dozen host calls during which the device would otherwise idle; the
-  // members are independent of the main workgroups and finish long before them.
-  // (PBBSS_SPLIT_FIRST=1 restores the old order for A/B runs.)
-  static const bool split_first = [] {
-    const char* v = getenv("PBBSS_SPLIT_FIRST");
-    return v && v[0] == '1';
-  }();
-  int rc;
-  if (split_first) {
-    rc = launch_split<K, YS>(a, a.B - r, (int)r, cfg, stream);
-    if (rc != PBBSS_OK) return rc;
-    rc = launch_variant<K, YS, false>(main_a, cfg, stream);
-    if (rc != PBBSS_OK) return rc;
-  } else {
-    if (hipEventRecord(cfg.ev_fork, stream) != hipSuccess) return PBBSS_ERR_HIP;
-    rc = launch_variant<K, YS, false>(main_a, cfg, stream);
-    if (rc != PBBSS_OK) return rc;
-    rc = launch_split<K, YS>(a, a.B - r, (int)r, cfg, stream, /*fork_recorded=*/true);
-    if (rc != PBBSS_OK) return rc;
-  }
+  // The main launch goes out FIRST: the side-stream preparation of the split groups (fork wait,
+  // launch, join record) is a handful of host calls during which the device would otherwise idle;
+  // the members are independent of the main workgroups and finish long before them.
+  // (hipExtAnyOrderLaunch -- the split kernel as a barrier-less packet of the SAME queue -- would
+  // need neither stream nor events, but is documented as unsupported on gfx9.)
+  if (hipEventRecord(cfg.ev_fork, stream) != hipSuccess) return PBBSS_ERR_HIP;
+  int rc = launch_variant<K, YS, false>(main_a, cfg, stream);
+  if (rc != PBBSS_OK) return rc;
+  rc = launch_split<K, YS>(a, a.B - r, (int)r, cfg, stream);
+  if (rc != PBBSS_OK) return rc;
   if (hipStreamWaitEvent(stream, cfg.ev_join, 0) != hipSuccess) return PBBSS_ERR_HIP;
   return PBBSS_OK;
 }

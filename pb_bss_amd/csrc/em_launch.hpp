@@ -1,6 +1,7 @@
 // Host-side dispatch of the persistent EM kernel over (D, K, storage type).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <atomic>
 #include <mutex>
 #include <vector>
@@ -24,6 +25,11 @@ struct EmLaunchCfg {
   int split_window;  // frames per workgroup of a split problem (multiple of 64)
   int split_prio;    // s_setprio level of the split waves
   int* split_epoch;  // host counter stamping the launches of the split protocol
+  // kernel timing (pbbss_set_timing): start / stop events attached to the DISPATCH of the EM kernel
+  // itself (hipExtLaunchKernelGGL: timestamps of the kernel's own completion signal) instead of
+  // two hipEventRecord packets around the call -- those cost ~30 us of queue time per step
+  // (tools/launch_gap.py).  Null: timing off.
+  hipEvent_t ev_t0, ev_t1;
 };
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per function and device, shared by all host

@@ -349,10 +349,13 @@ def set_timing(enable, device_index=None):
     _lib.check(_lib.load().pbbss_set_timing(_lib.handle(device_index), int(enable)), 'set_timing')
 
 
-def last_kernel_ms(device_index=None):
+def last_kernel_ms(device_index=None, lag=0):
+    """Duration of the timed region `lag` launches ago (0 = the most recent: waits for it).  Read
+    with lag = 2 inside a loop of launches, the queue keeps two launches behind the running one
+    (pbbss_kernel_ms_lagged)."""
     ms = ctypes.c_float()
-    _lib.check(_lib.load().pbbss_last_kernel_ms(_lib.handle(device_index), ctypes.byref(ms)),
-               'last_kernel_ms')
+    _lib.check(_lib.load().pbbss_kernel_ms_lagged(_lib.handle(device_index), int(lag),
+                                                  ctypes.byref(ms)), 'kernel_ms_lagged')
     return float(ms.value)
 
 
