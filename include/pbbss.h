@@ -454,6 +454,17 @@ int pbbss_estimate_mixture_weight(pbbss_handle_t h, const double* affiliation,
                                   int64_t N, int reduce_inner, int reduce_n,
                                   double* out_weight, void* stream);
 
+/* a3 as a stand-alone step: log_pdf_to_affiliation (mixture_model_utils.py:7-55) for the     */
+/* step-wise loops of the mixtures whose E-step is not fused with it (weight_constant_axis    */
+/* sets beyond the fused loops, frame-varying weights, diagonal covariances).  log_pdf        */
+/* (B,K,N) f64; the weight of (b,k,n) is weight[b*wb + k*wk + n*wn] -- a zero stride          */
+/* broadcasts, so (B,K,1), (K,1), (B,1,N), (1,K,N) ... arrays are passed as they are;         */
+/* activity uint8 (B,K,N) or NULL; affiliation_eps clips without re-normalisation (:50-53).  */
+int pbbss_log_pdf_to_affiliation(pbbss_handle_t h, const double* log_pdf, int64_t B, int K,
+                                 int64_t N, const double* weight, int64_t wb, int64_t wk,
+                                 int64_t wn, const uint8_t* activity, double affiliation_eps,
+                                 double* out_affiliation, void* stream);
+
 int pbbss_embed_fit(pbbss_handle_t h, const void* y, int y_is_f64, int64_t B,
                     int64_t N, int E, int K, int kind, int normalize,
                     const double* weights, double min_concentration,

@@ -1076,6 +1076,19 @@ PBBSS_API int pbbss_estimate_mixture_weight(pbbss_handle_t h, const double* affi
                                       as_stream(stream));
 }
 
+PBBSS_API int pbbss_log_pdf_to_affiliation(pbbss_handle_t h, const double* log_pdf, int64_t B, int K,
+                                           int64_t N, const double* weight, int64_t wb, int64_t wk,
+                                           int64_t wn, const uint8_t* activity,
+                                           double affiliation_eps, double* out_affiliation,
+                                           void* stream) {
+  DeviceGuard device_guard(h);
+  if (!h || !log_pdf || !weight || !out_affiliation || B <= 0 || N <= 0 || K < 1)
+    return PBBSS_ERR_INVALID_ARG;
+  if (wb < 0 || wk < 0 || wn < 0) return PBBSS_ERR_INVALID_ARG;
+  return pbbss::launch_log_pdf_to_affiliation(log_pdf, B, K, N, weight, wb, wk, wn, activity,
+                                              affiliation_eps, out_affiliation, as_stream(stream));
+}
+
 PBBSS_API int pbbss_embed_fit(pbbss_handle_t h, const void* y, int y_is_f64, int64_t B, int64_t N,
                               int E, int K, int kind, int normalize, const double* weights,
                               double min_concentration, double max_concentration,

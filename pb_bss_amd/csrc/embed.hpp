@@ -99,4 +99,10 @@ int launch_mixture_weight(const double* aff, const double* sal, int64_t Bo, int6
                           int64_t N, int red_inner, int red_n, double* tmp, double* out,
                           hipStream_t s);
 
+// mixw.hip: log_pdf_to_affiliation (mixture_model_utils.py:7-55): lp (B,K,N); the weight of
+// (b,k,n) at w[b*wb + k*wk + n*wn] (a zero stride broadcasts); act (B,K,N) uint8 or null.
+int launch_log_pdf_to_affiliation(const double* lp, int64_t B, int K, int64_t N, const double* w,
+                                  int64_t wb, int64_t wk, int64_t wn, const uint8_t* act,
+                                  double eps, double* out, hipStream_t s);
+
 }  // namespace pbbss

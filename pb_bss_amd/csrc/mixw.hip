@@ -141,6 +141,36 @@ __global__ void __launch_bounds__(kT) mixw_finish_kernel(const double* __restric
 }
 }  // namespace
 
+// log_pdf_to_affiliation (mixture_model_utils.py:7-55) as a stand-alone step for the models
+// whose E-step is not fused with it: thread = (problem, sample), the class log-pdfs of a sample
+// are read three times (max, normaliser, result) -- K is small and the rows are L2-resident.
+__global__ void __launch_bounds__(kT) lp_to_aff_kernel(const double* __restrict__ lp,
+                                                       const double* __restrict__ w, int64_t wb,
+                                                       int64_t wk, int64_t wn,
+                                                       const uint8_t* __restrict__ act, int K,
+                                                       int64_t N, double eps,
+                                                       double* __restrict__ out) {
+  const int64_t b = blockIdx.y;
+  const int64_t n = (int64_t)blockIdx.x * kT + threadIdx.x;
+  if (n >= N) return;
+  const double* p = lp + b * K * N + n;
+  double mx = -1.79e308;
+  for (int k = 0; k < K; ++k) mx = fmax(mx, p[(int64_t)k * N]);  // :32
+  auto term = [&](int k) {
+    double v = exp(p[(int64_t)k * N] - mx) * w[b * wb + k * wk + n * wn];  // :34-37
+    if (act) v *= (double)act[(b * K + k) * N + n];                        // :41
+    return v;
+  };
+  double den = 0.0;
+  for (int k = 0; k < K; ++k) den += term(k);
+  den = fmax(den, kTiny);  // :43-47
+  for (int k = 0; k < K; ++k) {
+    double g = term(k) / den;
+    if (eps != 0.0) g = fmin(fmax(g, eps), 1.0 - eps);  // :50-53, no renormalisation
+    out[(b * K + k) * N + n] = g;
+  }
+}
+
 size_t mixture_weight_tmp_doubles(int64_t Bo, int64_t Bi, int K, int64_t N, int red_n) {
   return (size_t)Bo * Bi * K * (red_n ? 1 : N);
 }
@@ -156,6 +186,16 @@ int launch_mixture_weight(const double* aff, const double* sal, int64_t Bo, int6
   const unsigned tiles = (unsigned)((N1 + 63) / 64);  // N1 == 1: one tile
   hipLaunchKernelGGL(mixw_finish_kernel, dim3((unsigned)(Bo * Bi2), tiles), dim3(kT),
                      K * sizeof(double), s, tmp, Bi, K, N1, red_inner, sal ? 1 : 0, count, out);
+  return hipGetLastError() == hipSuccess ? PBBSS_OK : PBBSS_ERR_HIP;
+}
+
+int launch_log_pdf_to_affiliation(const double* lp, int64_t B, int K, int64_t N, const double* w,
+                                  int64_t wb, int64_t wk, int64_t wn, const uint8_t* act,
+                                  double eps, double* out, hipStream_t s) {
+  if (B <= 0 || N <= 0) return PBBSS_OK;
+  if (B > 65535) return PBBSS_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(lp_to_aff_kernel, dim3((unsigned)((N + kT - 1) / kT), (unsigned)B), dim3(kT),
+                     0, s, lp, w, wb, wk, wn, act, K, N, eps, out);
   return hipGetLastError() == hipSuccess ? PBBSS_OK : PBBSS_ERR_HIP;
 }
 

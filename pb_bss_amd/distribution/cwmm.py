@@ -51,6 +51,26 @@ class CWMM(_ProbabilisticModel):
         assert y.dtype in (t.complex64, t.complex128), y.dtype
         *indep, N, D = y.shape
         K = self.complex_watson.mode.shape[-2]
+        w = _lib.to_device(self.weight, t.float64).to(y.device)
+        if w.shape[-1] != 1:
+            # frame-varying weights (weight_constant_axis without -1, reference :40-52 with a
+            # (..., K, N) weight): class log-pdfs, then the general softmax step
+            yb = y.reshape(-1, N, D).contiguous()
+            B = yb.shape[0]
+            mode = _lib.to_device(self.complex_watson.mode, t.complex128).to(y.device)
+            conc = _lib.to_device(self.complex_watson.concentration, t.float64).to(y.device)
+            r = engine.cwmm_fit(
+                yb, K, None,
+                model=(mode.expand(*indep, K, D).reshape(B, K, D).contiguous(),
+                       conc.expand(*indep, K).reshape(B, K).contiguous(),
+                       t.ones((B, K), dtype=t.float64, device=y.device)),
+                iterations=0, want_log_pdf=True)
+            while w.ndim < len(indep) + 2:
+                w = w.unsqueeze(0)
+            w = (w.expand(*indep, *w.shape[-2:]).reshape(-1, *w.shape[-2:])
+                 if any(a != 1 for a in w.shape[:-2]) else w.reshape(1, *w.shape[-2:]))
+            aff = engine.log_pdf_to_affiliation(r['log_pdf'], w)
+            return as_result(aff.reshape(*indep, K, N), like_torch)
         dev_model = _model_to_device(self, tuple(indep), K, D, y.device)
         r = engine.cwmm_fit(y.reshape(-1, N, D).contiguous(), K, None, model=dev_model,
                             iterations=0, final_predict=True)
@@ -132,49 +152,50 @@ class CWMMTrainer:
 
     def _fit_stepwise(self, yb, indep, K, gamma0, iterations, saliency, sal,
                       weight_constant_axis, aligner, spline, like_torch):
-        """The reference loop (:151-182) with device E/M steps and the host hook."""
+        """The reference loop (:151-182) for the options that couple the bins
+        (`weight_constant_axis` with independent axes, frame-varying weights, an inline aligner),
+        every step a device kernel: class log-pdfs (`pbbss_cwmm_fit`, iterations = 0), the
+        softmax with the reference-shaped weight (`pbbss_log_pdf_to_affiliation`), the weight
+        reduction (`pbbss_estimate_mixture_weight`) and the M-step (`pbbss_cwmm_fit`,
+        iterations = 1).  Nothing returns to the host inside the loop, except for a foreign
+        (NumPy) aligner object."""
+        from . import _embed_stepwise as sw
         t = _lib.torch()
         B, N, D = yb.shape
         shape = (*indep, K, N)
-        aff = _lib.to_host(gamma0.reshape(shape))
-        sal_host = np.ones((*indep, N)) if saliency is None else np.broadcast_to(
-            _lib.to_host(_lib.to_device(saliency, t.float64)), (*indep, N))
-        model = None
+        aff = gamma0.reshape(shape).contiguous()
+        sal_dev = None if sal is None else sal.reshape(*indep, N)
+        ones_w = t.ones((B, K), dtype=t.float64, device=yb.device)
+        mode = conc = weight = None
         for _ in range(iterations):
-            if model is not None:
-                w = np.broadcast_to(model['weight'], (*indep, K, model['weight'].shape[-1]))
-                if w.shape[-1] != 1:
-                    raise NotImplementedError(
-                        'frame-varying mixture weights (weight_constant_axis without -1) '
-                        'are not supported by the Watson kernel')
-                r = engine.cwmm_fit(
-                    yb, K, None, model=(_lib.to_device(model['mode']),
-                                        _lib.to_device(model['concentration']),
-                                        _lib.to_device(np.ascontiguousarray(w[..., 0]).reshape(B, K))),
-                    iterations=0, final_predict=True)
-                aff = _lib.to_host(r['affiliation']).reshape(shape)
+            if mode is not None:
+                r = engine.cwmm_fit(yb, K, None, model=(mode, conc, ones_w), iterations=0,
+                                    want_log_pdf=True)
+                w = weight
+                while w.ndim < len(shape):
+                    w = w.unsqueeze(0)
+                w = (w.expand(*indep, *w.shape[-2:]).reshape(-1, *w.shape[-2:])
+                     if any(a != 1 for a in w.shape[:-2]) else w.reshape(1, *w.shape[-2:]))
+                aff = engine.log_pdf_to_affiliation(r['log_pdf'], w).reshape(shape)
                 if aligner is not None:
-                    aff = apply_inline_permutation_alignment(
-                        affiliation=aff, weight_constant_axis=weight_constant_axis,
-                        aligner=aligner)
-            weight = estimate_mixture_weight(aff, sal_host, weight_constant_axis)
-            masked = aff * sal_host[..., None, :]
-            r = engine.cwmm_fit(
-                yb, K, spline,
-                gamma0=_lib.to_device(np.ascontiguousarray(masked).reshape(B, K, N)),
-                iterations=1)
-            model = dict(weight=weight, mode=_lib.to_host(r['mode']),
-                         concentration=_lib.to_host(r['concentration']))
-        out = CWMM(weight=model['weight'],
-                   complex_watson=ComplexWatson(
-                       mode=model['mode'].reshape(*indep, K, D),
-                       concentration=model['concentration'].reshape(*indep, K)))
-        if like_torch:
-            out = CWMM(weight=_lib.to_device(out.weight),
-                       complex_watson=ComplexWatson(
-                           mode=_lib.to_device(out.complex_watson.mode),
-                           concentration=_lib.to_device(out.complex_watson.concentration)))
-        return out
+                    if type(aligner).__module__.startswith('pb_bss_amd'):
+                        aff = apply_inline_permutation_alignment(
+                            affiliation=aff, weight_constant_axis=weight_constant_axis,
+                            aligner=aligner).contiguous()
+                    else:  # a foreign (NumPy) aligner object: the one host excursion left
+                        aff = _lib.to_device(apply_inline_permutation_alignment(
+                            affiliation=_lib.to_host(aff),
+                            weight_constant_axis=weight_constant_axis, aligner=aligner),
+                            t.float64).to(yb.device).contiguous()
+            weight = sw.device_weight(aff, sal_dev, weight_constant_axis, indep)
+            masked = aff if sal_dev is None else aff * sal_dev[..., None, :]
+            r = engine.cwmm_fit(yb, K, spline, gamma0=masked.reshape(B, K, N).contiguous(),
+                                iterations=1)
+            mode, conc = r['mode'], r['concentration']
+        return CWMM(weight=as_result(weight, like_torch),
+                    complex_watson=ComplexWatson(
+                        mode=as_result(mode.reshape(*indep, K, D), like_torch),
+                        concentration=as_result(conc.reshape(*indep, K), like_torch)))
 
     def fit_predict(self, y, initialization=None, num_classes=None, iterations=100, *,
                     saliency=None, weight_constant_axis=(-1,), affiliation_eps=0,

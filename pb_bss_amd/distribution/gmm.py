@@ -3,10 +3,11 @@ Mirrors pb_bss/distribution/gmm.py:16-171: `GMM` (weight, gaussian; predict) and
 `GMMTrainer` (fit / fit_predict) for covariance_type 'full' (the reference's default;
 FP64 matrix-pipe kernels of csrc/gauss_full.hip, D <= 63) and 'spherical' (the covariance
 model the joint GCACGMM uses, gcacgmm.py:141; the vMF mixture's E-step / M-step kernels on the
-raw embedding).  'diagonal' is not on the device path (NotImplementedError); BinaryGMM wraps
-sklearn's KMeans and is out of scope.
-
-The whole EM loop is one C-ABI call (`pbbss_gmm_full_fit` / `pbbss_gmm_fit`).
+raw embedding): the whole EM loop is one C-ABI call (`pbbss_gmm_full_fit` / `pbbss_gmm_fit`).
+covariance_type 'diagonal' and the `weight_constant_axis` sets beyond (-1,), (-2,), -2 run the
+reference's loop step by step on the device (`_embed_stepwise.py`: log-pdf, softmax, weight and
+single-Gaussian fit kernels, no host round trip inside the loop).  BinaryGMM wraps sklearn's
+KMeans and is out of scope.
 """
 from dataclasses import dataclass
 from operator import xor
@@ -14,7 +15,7 @@ from operator import xor
 import numpy as np
 
 from .. import _lib, engine
-from .gaussian import Gaussian, SphericalGaussian
+from .gaussian import DiagonalGaussian, Gaussian, SphericalGaussian
 from .utils import _ProbabilisticModel, as_result
 
 __all__ = ['GMM', 'GMMTrainer']
@@ -41,18 +42,22 @@ def _weight_kind(weight_constant_axis, ndim):
         return _CLASS
     if norm == (-2,):
         return _ONES
-    raise NotImplementedError(
-        f'weight_constant_axis={weight_constant_axis!r}: the device loop covers (-1,), (-2,) '
-        'and -2')
+    return None  # any other axis set: the step-wise device loop (_embed_stepwise.py)
 
 
 def _check_covariance_type(covariance_type):
-    if covariance_type in ('spherical', 'full'):
-        return
-    if covariance_type == 'diagonal':
-        raise NotImplementedError(
-            "covariance_type='diagonal': 'full' and 'spherical' run on the device")
-    raise ValueError(f"Unknown covariance type '{covariance_type}'.")
+    if covariance_type not in ('spherical', 'diagonal', 'full'):
+        raise ValueError(f"Unknown covariance type '{covariance_type}'.")  # gaussian.py:184
+
+
+_CLS = {'full': Gaussian, 'diagonal': DiagonalGaussian, 'spherical': SphericalGaussian}
+
+
+def _kind_of(gaussian):
+    for name, cls in _CLS.items():
+        if type(gaussian) is cls:
+            return name
+    raise TypeError(type(gaussian))
 
 
 @dataclass
@@ -70,8 +75,20 @@ class GMM(_ProbabilisticModel):
         mean = _lib.to_device(self.gaussian.mean, t.float64).to(x.device)
         K = mean.shape[-2]
         cov = _lib.to_device(self.gaussian.covariance, t.float64).to(x.device)
-        full = isinstance(self.gaussian, Gaussian)
+        kind = _kind_of(self.gaussian)
+        full = kind == 'full'
         w = _lib.to_device(self.weight, t.float64).to(x.device)
+        general = kind == 'diagonal' or (w.shape[-1] != 1 and w.shape[-2] != 1) or (
+            w.ndim > 2 and any(a != 1 for a in w.shape[:-2]) and w.shape[-1] != 1)
+        if general:
+            # diagonal covariances / weights that vary over classes AND frames: the general
+            # log-pdf + softmax steps
+            from . import _embed_stepwise as sw
+            cs = {'full': (E, E), 'diagonal': (E,), 'spherical': ()}[kind]
+            aff = sw.affiliation(
+                kind, x.reshape(-1, N, E), mean.expand(*indep, K, E).reshape(-1, K, E).contiguous(),
+                cov.expand(*indep, K, *cs).reshape(-1, K, *cs).contiguous(), w, tuple(indep), K, N)
+            return as_result(aff.reshape(*indep, K, N), like_torch)
         if w.shape[-1] != 1:
             # (..., 1, N): constant over the classes (weight_constant_axis=(-2,)), cancels in
             # the posterior (mixture_model_utils.py:37-47) -- evaluated with uniform weights
@@ -126,6 +143,23 @@ class GMMTrainer:
             gamma0 = gamma0.expand(*indep, num_classes, N)
         K = num_classes
         kind = _weight_kind(weight_constant_axis, len(indep) + 2)
+        if kind is None or covariance_type == 'diagonal':
+            if iterations <= 0:
+                return None
+            from . import _embed_stepwise as sw
+            cs = {'full': (E, E), 'diagonal': (E,), 'spherical': ()}[covariance_type]
+            fixed = None
+            if fixed_covariance is not None:
+                fixed = _lib.to_device(fixed_covariance, t.float64).to(y.device)
+                assert tuple(fixed.shape) == (*indep, K, *cs), (
+                    f'{tuple(fixed.shape)} != {(*indep, K, *cs)}')  # :161-163
+            r = sw.fit(covariance_type, y, gamma0.contiguous(), iterations, saliency,
+                       weight_constant_axis, fixed_scale=fixed)
+            return GMM(
+                weight=as_result(r['weight'], like_torch),
+                gaussian=_CLS[covariance_type](
+                    mean=as_result(r['mean'].reshape(*indep, K, E), like_torch),
+                    covariance=as_result(r['scale'].reshape(*indep, K, *cs), like_torch)))
         mode = _lib.WEIGHT_PER_CLASS_MEAN if kind == _CLASS else _lib.WEIGHT_UNIFORM
         sal = None
         if saliency is not None:  # None: ones (:79-80), which the kernels assume anyway

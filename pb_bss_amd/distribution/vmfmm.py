@@ -29,8 +29,7 @@ def _weight_mode(weight_constant_axis, ndim):
         weight_constant_axis = (weight_constant_axis,)
     if tuple(a % ndim - ndim for a in weight_constant_axis) == (-1,):
         return _lib.WEIGHT_PER_CLASS_MEAN
-    raise NotImplementedError(
-        f'weight_constant_axis={weight_constant_axis!r}: the device loop covers (-1,) and -2')
+    return None  # any other axis set: the step-wise device loop (_embed_stepwise.py)
 
 
 @dataclass
@@ -49,7 +48,14 @@ class VMFMM(_ProbabilisticModel):
         K = mean.shape[-2]
         conc = _lib.to_device(self.vmf.concentration, t.float64).to(y.device)
         w = _lib.to_device(self.weight, t.float64).to(y.device)
-        assert w.shape[-1] == 1, w.shape
+        if w.shape[-1] != 1 or (w.ndim > 2 and tuple(w.shape[:-2]) != tuple(indep)
+                                and any(a != 1 for a in w.shape[:-2])):
+            # frame-varying weights (weight_constant_axis without -1): the general softmax step
+            from . import _embed_stepwise as sw
+            aff = sw.affiliation(
+                'vmf', y.reshape(-1, N, E), mean.expand(*indep, K, E).reshape(-1, K, E).contiguous(),
+                conc.expand(*indep, K).reshape(-1, K).contiguous(), w, tuple(indep), K, N)
+            return as_result(aff.reshape(*indep, K, N), like_torch)
         model = (mean.expand(*indep, K, E).reshape(-1, K, E).contiguous(),
                  conc.expand(*indep, K).reshape(-1, K).contiguous(),
                  w.expand(*indep, K, 1).reshape(-1, K).contiguous())
@@ -89,6 +95,15 @@ class VMFMMTrainer:
         K = num_classes
         assert iterations > 0, iterations
         mode = _weight_mode(weight_constant_axis, len(indep) + 2)
+        if mode is None:
+            from . import _embed_stepwise as sw
+            r = sw.fit('vmf', y, gamma0.contiguous(), iterations, saliency, weight_constant_axis,
+                       min_concentration=min_concentration, max_concentration=max_concentration)
+            return VMFMM(
+                weight=as_result(r['weight'], like_torch),
+                vmf=VonMisesFisher(
+                    mean=as_result(r['mean'].reshape(*indep, K, E), like_torch),
+                    concentration=as_result(r['scale'].reshape(*indep, K), like_torch)))
         sal = None
         if saliency is not None:
             sal = _lib.to_device(saliency, t.float64).to(y.device).expand(*indep, N)

@@ -722,6 +722,28 @@ def estimate_mixture_weight(affiliation, saliency, reduce_inner, reduce_n):
     return out
 
 
+def log_pdf_to_affiliation(log_pdf, weight, activity=None, affiliation_eps=0.):
+    """pbbss_log_pdf_to_affiliation: log_pdf (B,K,N) f64; weight a tensor that broadcasts against
+    it -- (B,K,1), (K,1), (1,K,N), (B,1,N) ...: singleton axes become zero strides -> (B,K,N)."""
+    t = _t()
+    B, K, N = log_pdf.shape
+    w = weight.to(t.float64)
+    while w.ndim < 3:
+        w = w.unsqueeze(0)
+    assert w.ndim == 3 and all(a in (1, b) for a, b in zip(w.shape, (B, K, N))), (w.shape, (B, K, N))
+    w = w.contiguous()
+    st = [0 if w.shape[i] == 1 else w.stride(i) for i in range(3)]
+    out = t.empty((B, K, N), dtype=t.float64, device=log_pdf.device)
+    if activity is not None:
+        assert activity.shape == (B, K, N) and activity.dtype == t.uint8
+    rc = _lib.load().pbbss_log_pdf_to_affiliation(
+        _lib.handle(log_pdf.device.index), _lib.ptr(log_pdf.contiguous()), B, K, N, _lib.ptr(w),
+        st[0], st[1], st[2], _lib.ptr(activity), float(affiliation_eps), _lib.ptr(out),
+        _lib.stream_ptr(log_pdf.device.index))
+    _lib.check(rc, f'log_pdf_to_affiliation(B={B},K={K},N={N})')
+    return out
+
+
 def joint_weight_shape(weight_mode, F, K, T):
     return {_lib.JOINT_WEIGHT_FK: (F, K), _lib.JOINT_WEIGHT_UNIFORM: (), _lib.JOINT_WEIGHT_K: (K,),
             _lib.JOINT_WEIGHT_KT: (K, T), _lib.JOINT_WEIGHT_CONST: ()}[weight_mode]

@@ -100,3 +100,22 @@ def test_cwmm_stepwise_shared_weights():
     assert m.weight.shape == ref['weight'].shape == (1, 2, 1)
     assert np.abs(m.weight - ref['weight']).max() < 1e-10
     assert np.abs(m.complex_watson.concentration - ref['concentration']).max() < 1e-8
+
+
+@pytest.mark.parametrize('with_sal', [False, True])
+def test_cwmm_frame_varying_weights_on_the_device(with_sal):
+    """weight_constant_axis=(-3,): weights (1, K, N) shared by the bins but varying over the
+    frames (reference cwmm.py:151-182 with mixture_model_utils.py:184-201) -- the step-wise loop
+    stays on the device (log-pdf kernel + pbbss_log_pdf_to_affiliation + weight reduction)."""
+    from pb_bss_amd.distribution import CWMMTrainer
+    from oracle import cwmm as ow, synth
+    Y, init = synth.make_stft(7, 90, 5, 3, seed=14)
+    Y128 = Y.astype(np.complex128)
+    sal = np.random.default_rng(2).uniform(0.3, 1.0, size=(7, 90)) if with_sal else None
+    m = CWMMTrainer().fit(Y, initialization=init, iterations=4, weight_constant_axis=(-3,),
+                          saliency=sal)
+    ref = ow.cwmm_fit(Y128, init, iterations=4, weight_constant_axis=(-3,), saliency=sal)
+    assert m.weight.shape == ref['weight'].shape == (1, 3, 90)
+    assert np.abs(m.weight - ref['weight']).max() < 1e-10
+    assert np.abs(m.complex_watson.concentration - ref['concentration']).max() < 1e-7
+    assert np.abs(m.predict(Y) - ow.cwmm_predict(ref, Y128)).max() < 1e-8

@@ -99,6 +99,41 @@ def test_oracle_gmm_equals_live_reference_on_fresh_inputs(ref):
                                rtol=1e-10, atol=1e-9)
 
 
+def test_oracle_mixture_weight_axes_equal_live_reference(ref):
+    """The options the step-wise device loop serves (tests/test_gpu_embed_stepwise.py compares it
+    with the oracle): weight_constant_axis sets over an independent axis for VMFMM / GMM and
+    covariance_type='diagonal' -- oracle == unmodified reference on fresh inputs."""
+    from pb_bss.distribution import GMMTrainer, VMFMMTrainer
+    from oracle import embed as oe
+    rng = np.random.default_rng(11)
+    y = rng.standard_normal((3, 120, 5)) + rng.integers(0, 3, size=(3, 120, 1)) * 2.0
+    init = rng.uniform(size=(3, 3, 120))
+    init /= init.sum(axis=1, keepdims=True)
+    sal = rng.uniform(0.2, 1.0, size=(3, 120))
+    for axis in ((-3,), (-3, -1)):
+        m = VMFMMTrainer().fit(y, initialization=init, iterations=3, saliency=sal,
+                               weight_constant_axis=axis)
+        o = oe.vmfmm_fit(y, init, iterations=3, saliency=sal, weight_constant_axis=axis)
+        assert np.abs(m.weight - o['weight']).max() < 1e-12
+        assert np.abs(m.vmf.mean - o['mean']).max() < 1e-12
+        for cov in ('full',):  # SphericalGaussian.log_pdf does not broadcast over independent
+            # axes in the reference (gaussian.py:110-113): 'spherical' is pinned on flat data only
+            g = GMMTrainer().fit(y, initialization=init, iterations=3, saliency=sal,
+                                 weight_constant_axis=axis, covariance_type=cov)
+            og = oe.gmm_fit(y, init, iterations=3, saliency=sal, weight_constant_axis=axis,
+                            covariance_type=cov)
+            assert np.abs(g.weight - og['weight']).max() < 1e-12
+            assert np.abs(g.gaussian.covariance - og['covariance']).max() < 1e-10
+    for axis in ((-1,), (-2,), -2):
+        g = GMMTrainer().fit(y[0], initialization=init[0], iterations=3, saliency=sal[0],
+                             weight_constant_axis=axis, covariance_type='diagonal')
+        og = oe.gmm_fit(y[0], init[0], iterations=3, saliency=sal[0], weight_constant_axis=axis,
+                        covariance_type='diagonal')
+        assert np.abs(g.gaussian.mean - og['mean']).max() < 1e-12
+        assert np.abs(g.gaussian.covariance - og['covariance']).max() < 1e-12
+        assert np.abs(g.predict(y[0]) - oe.gmm_predict(og, y[0], 'diagonal')).max() < 1e-10
+
+
 def test_gev_use_eig_fixture_equals_reference_cython_modules():
     """The reference's two native files compile out of tree (oracle/refshim.py:build_cython ->
     oracle/_ref/); with them injected, `get_gev_vector(use_eig=True)` runs c_eig.pyx (zggev) and
