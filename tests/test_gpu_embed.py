@@ -265,8 +265,6 @@ def test_gmm_matches_reference():
                          covariance_type='spherical')
     assert m.weight.shape == (1, 450) and (m.weight == 1).all()
     np.testing.assert_allclose(m.predict(y), g['fit_predict'], atol=1e-9)
-    with pytest.raises(NotImplementedError):
-        GMMTrainer().fit(y, initialization=g['init'], iterations=2, covariance_type='diagonal')
     with pytest.raises(ValueError):
         GMMTrainer().fit(y, initialization=g['init'], iterations=2, covariance_type='round')
     with pytest.raises(AssertionError):

@@ -178,12 +178,10 @@ def test_gmm_and_alignment_argument_mapping():
     assert gmm._weight_kind(-2, 2) == gmm._UNIFORM      # int -2: the constant 1 / K
     assert gmm._weight_kind((-2,), 2) == gmm._ONES      # tuple (-2,): a (1, N) array of ones
     assert gmm._weight_kind((0,), 2) == gmm._ONES
-    with pytest.raises(NotImplementedError):
-        gmm._weight_kind((-3,), 3)
+    assert gmm._weight_kind((-3,), 3) is None           # -> the step-wise device loop
     gmm._check_covariance_type('full')
     gmm._check_covariance_type('spherical')
-    with pytest.raises(NotImplementedError):
-        gmm._check_covariance_type('diagonal')
+    gmm._check_covariance_type('diagonal')              # served by the step-wise device loop
     with pytest.raises(ValueError, match="Unknown covariance type 'round'"):
         gmm._check_covariance_type('round')
     for metric in ('cos', 'multiply', 'euclidean'):
