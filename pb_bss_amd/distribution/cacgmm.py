@@ -452,6 +452,8 @@ class CACGMMTrainer:
         a4 = aff.reshape(Bo, Bi, K, N).contiguous()
         s3 = None if sal is None else sal.reshape(Bo, Bi, N).contiguous()
         w = engine.estimate_mixture_weight(a4, s3, reduce_inner=r > 0, reduce_n=red_n)
+        if w is None:  # not served (saliency with K > 16): the caller takes the host formula
+            return None
         shape = list(indep[:len(indep) - r]) + [1] * r + [K, 1 if red_n else N]
         return w.reshape(shape)
 

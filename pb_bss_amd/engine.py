@@ -709,7 +709,8 @@ def gmm_full_fit(y, K, *, gamma0=None, model=None, iterations=100, saliency=None
 
 def estimate_mixture_weight(affiliation, saliency, reduce_inner, reduce_n):
     """pbbss_estimate_mixture_weight: affiliation (Bo, Bi, K, N) f64, saliency (Bo, Bi, N) or
-    None -> (Bo, 1 if reduce_inner else Bi, K, 1 if reduce_n else N)."""
+    None -> (Bo, 1 if reduce_inner else Bi, K, 1 if reduce_n else N); None where the kernel does
+    not serve the shape (a saliency with more than 16 classes): the caller takes the host formula."""
     t = _t()
     Bo, Bi, K, N = affiliation.shape
     out = t.empty((Bo, 1 if reduce_inner else Bi, K, 1 if reduce_n else N), dtype=t.float64,
@@ -718,6 +719,8 @@ def estimate_mixture_weight(affiliation, saliency, reduce_inner, reduce_n):
         _lib.handle(affiliation.device.index), _lib.ptr(affiliation), _lib.ptr(saliency), Bo, Bi, K,
         N, int(bool(reduce_inner)), int(bool(reduce_n)), _lib.ptr(out),
         _lib.stream_ptr(affiliation.device.index))
+    if rc == _lib.ERR_UNSUPPORTED:
+        return None
     _lib.check(rc, f'estimate_mixture_weight(Bo={Bo},Bi={Bi},K={K},N={N})')
     return out
 

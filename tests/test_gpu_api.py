@@ -566,3 +566,18 @@ def test_result_dtype_reference_follows_the_reference_operand_rules():
                                rtol=1e-6)
     np.testing.assert_allclose(m.weight, wide.weight, rtol=1e-6)
     assert pb_bss_amd.set_result_dtype('float64') == 'float64'
+
+
+def test_stepwise_weights_with_saliency_and_many_classes_fall_back_to_the_host_formula():
+    """K = 17 with a saliency and bin-coupled weights: pbbss_estimate_mixture_weight does not
+    serve it (PBBSS_ERR_UNSUPPORTED) -- the trainer must take the NumPy formula, not raise."""
+    from oracle import synth
+    from pb_bss_amd import _lib, engine
+    from pb_bss_amd.distribution.cacgmm import CACGMMTrainer
+    rng = np.random.default_rng(0)
+    aff = rng.uniform(size=(2, 3, 17, 40))
+    aff /= aff.sum(axis=-2, keepdims=True)
+    sal = rng.uniform(size=(2, 3, 40))
+    assert engine.estimate_mixture_weight(_lib.to_device(aff), _lib.to_device(sal), True, True) is None
+    assert CACGMMTrainer._device_weight(_lib.to_device(aff), _lib.to_device(sal), (-3, -1),
+                                        (2, 3)) is None
