@@ -74,6 +74,8 @@ struct EmArgs {
   // packed-FP32 kernel (cacgmm_em32.hpp): blocks >= main_grid are the member workgroups of the
   // remainder problems, in the same grid; 0: every block is a full workgroup
   int main_grid;
+  unsigned lds_given;  // dynamic LDS bytes of the launch (checked by the debug build only)
+  unsigned xbuf_given; // bytes of the exchange buffer behind xcount (debug build)
   // ---- weights shared across problems (run_shared: weight_mode PBBSS_WEIGHT_SHARED_*) ----
   int wgroup;          // problems (frequency bins) that share one set of mixture weights
   double* gsum;        // SHARED_K : [2][B][K]     masked class sums of every problem
@@ -114,6 +116,8 @@ struct JointExtras {
   // them share one of the r problems [a.b_first, a.b_first + r) by frame windows (run_joint_member);
   // 0: every block is a full workgroup.
   int main_grid;
+  unsigned lds_given;  // dynamic LDS bytes of the launch (checked by the debug build only)
+  unsigned xbuf_given; // bytes of the exchange buffer behind xcount (debug build)
 };
 
 // SPILL=false: observation, norms and M-step weights live in LDS (the fast path).
@@ -232,6 +236,7 @@ struct EmKernel {
   // ---- observation frame t from LDS, widened to float64 -------------------
   static __device__ __forceinline__ void load_frame(const Lds& L, int t, double (&re)[D],
                                                     double (&im)[D]) {
+    PBBSS_DEV_ASSERT(t >= 0 && t < L.Tp);
     static_for<0, DP>([&](auto dpc) {
       constexpr int dp = dpc;
       YS4 v = *reinterpret_cast<const YS4*>(L.ybuf + ((size_t)dp * L.Tp + t) * 4);
@@ -1178,6 +1183,9 @@ struct EmKernel {
     const int G = a.split_groups;
     double* slabs = a.xslab + ((size_t)(it & 1) * nprob + prob) * (size_t)G * kSlabLen;
     double* mine = slabs + (size_t)g * kSlabLen;
+    PBBSS_DEV_ASSERT(a.xbuf_given == 0 ||
+                     (size_t)(reinterpret_cast<char*>(slabs + (size_t)G * kSlabLen) -
+                              reinterpret_cast<char*>(a.xcount)) <= a.xbuf_given);
     for (int idx = tid; idx < kSlabLen; idx += kEmThreads) {
       double v;
       if (idx < K * NA) {
@@ -1848,6 +1856,7 @@ struct EmKernel {
     // of this grid: with run_split compiled into this function -- inlined or called -- hipcc's
     // register allocation of the main loop degrades from 9 to 76 spilled VGPRs, 1.475 -> 1.65 ms
     // per fit on one box, profiles/r03_a_member_modes.txt.)
+    PBBSS_DEV_ASSERT(a.lds_given == 0 || lds_bytes(a.T) <= a.lds_given);
     const Lds L = carve(smem, a.T, SPILL ? a.scratch + (size_t)blockIdx.x * a.scratch_stride : nullptr);
 #ifdef PBBSS_PHASE_PROFILE
     unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};

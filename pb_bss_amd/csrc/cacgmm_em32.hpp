@@ -196,6 +196,7 @@ struct EmKernel32 {
     return pair_of<I % 2>(yv[I / 2]);
   }
   static __device__ __forceinline__ void load_frame(const Lds& L, int t, f32x4 (&yv)[DP]) {
+    PBBSS_DEV_ASSERT(t >= 0 && t < L.Tp);
 #pragma unroll
     for (int dp = 0; dp < DP; ++dp)
       yv[dp] = *reinterpret_cast<const f32x4*>(L.y + ((size_t)dp * L.Tp + t) * 4);
@@ -669,6 +670,7 @@ struct EmKernel32 {
       return;
     }
     const int bstride = a.main_grid > 0 ? a.main_grid : (int)gridDim.x;
+    PBBSS_DEV_ASSERT(a.lds_given == 0 || lds_bytes(a.T) <= a.lds_given);
     const Lds L = carve(smem, a.T);
 #ifdef PBBSS_PHASE_PROFILE
     unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};

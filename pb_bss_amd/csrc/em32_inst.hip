@@ -58,6 +58,8 @@ static int launch32(EmArgs a, const EmLaunchCfg& cfg, hipStream_t stream) {
   } else if (grid > a.B) {
     grid = a.B;
   }
+  a.lds_given = (unsigned)lds;
+  if (a.xcount) a.xbuf_given = (unsigned)cfg.xbuf_bytes;
   if (cfg.ev_t0) {
     hipExtLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(kEmThreads), lds, stream, cfg.ev_t0,
                           cfg.ev_t1, 0, a);

@@ -48,6 +48,8 @@ static int launch_variant(EmArgs a, const EmLaunchCfg& cfg, hipStream_t stream) 
     a.scratch = static_cast<char*>(cfg.get_scratch(cfg.scratch_ctx, a.scratch_stride * grid));
     if (!a.scratch) return PBBSS_ERR_HIP;
   }
+  a.lds_given = (unsigned)lds;
+  if (a.xcount) a.xbuf_given = (unsigned)cfg.xbuf_bytes;
   if (cfg.ev_t0) {
     hipExtLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(kEmThreads), lds, stream, cfg.ev_t0,
                           cfg.ev_t1, 0, a);
@@ -84,6 +86,7 @@ static int launch_split(EmArgs a, int64_t b_first, int r, const EmLaunchCfg& cfg
   // no memsets: the arrival counters are put back to zero by the last member to leave, the error
   // word is stamped with this launch's epoch, member 0 zeroes the status words of its problem
   a.xepoch = next_split_epoch(cfg);
+  a.xbuf_given = (unsigned)cfg.xbuf_bytes;
   hipLaunchKernelGGL(kfn, dim3((unsigned)(r * G)), dim3(kEmThreads), lds, cfg.side_stream, a);
   if (hipGetLastError() != hipSuccess) return PBBSS_ERR_HIP;
   if (hipEventRecord(cfg.ev_join, cfg.side_stream) != hipSuccess) return PBBSS_ERR_HIP;

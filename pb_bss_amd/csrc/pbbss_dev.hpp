@@ -6,6 +6,17 @@
 #include <type_traits>
 #include <utility>
 
+// Device-side checks of the debug build (make debug: -DPBBSS_DEBUG_ASSERT): a failed check traps
+// the wavefront, the launch then fails with hipErrorLaunchFailure instead of corrupting memory.
+#ifdef PBBSS_DEBUG_ASSERT
+#define PBBSS_DEV_ASSERT(cond)           \
+  do {                                   \
+    if (!(cond)) __builtin_trap();       \
+  } while (0)
+#else
+#define PBBSS_DEV_ASSERT(cond) ((void)0)
+#endif
+
 namespace pbbss {
 
 constexpr int kWave = 64;       // CDNA wavefront width
