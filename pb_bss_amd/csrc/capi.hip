@@ -1247,34 +1247,50 @@ static int embed_mixture_fit(pbbss_handle_t h, int kind, const void* y, int64_t 
   hipStream_t s = as_stream(stream);
   const size_t nyz = (size_t)B * N * E;
   const size_t np = pbbss::embed_partial_doubles(B, N, E, K, nullptr);
-  const size_t need = WorkCarver::pad(nyz * 8) + WorkCarver::pad((size_t)B * N * 8) +
-                      WorkCarver::pad((size_t)B * K * N * 8) + WorkCarver::pad(np * 8) +
+  // vMF mixture: ONE pass over the embedding per iteration (vmf_em_kernel, embed.hip) where the
+  // LDS tile fits; the two-kernel path (transposed copy for the E-step, row-major sweep for the
+  // M-step) otherwise, for the Gaussian mixture and for the log-pdf output
+  const size_t npf = vmf ? pbbss::vmf_fused_partial_doubles(B, N, E, K, o->embedding_is_f64) : 0;
+  const bool fused = npf > 0;
+  const bool need_copy = !fused || (o->final_predict && out_log_pdf);
+  const size_t need = (need_copy ? WorkCarver::pad(nyz * 8) + WorkCarver::pad((size_t)B * N * 8) : 0) +
+                      (fused ? 0 : WorkCarver::pad((size_t)B * K * N * 8)) +
+                      WorkCarver::pad((np > npf ? np : npf) * 8) +
                       2 * WorkCarver::pad((size_t)B * K * 8);
   void* w = handle_work(h, need);
   if (!w) return PBBSS_ERR_HIP;
   WorkCarver wc(w);
-  double* yd = wc.take<double>(nyz);  // (B,E,N) transposed copy in the INPUT type
-  double* rowscale = wc.take<double>((size_t)B * N);  // vMF: 1 / |y_n| (vmfmm.py:76-78)
-  double* aff = wc.take<double>((size_t)B * K * N);
-  double* part = wc.take<double>(np);
+  double* yd = need_copy ? wc.take<double>(nyz) : nullptr;  // (B,E,N) transposed copy, INPUT type
+  double* rowscale = need_copy ? wc.take<double>((size_t)B * N) : nullptr;  // vMF: 1 / |y_n|
+  double* aff = fused ? nullptr : wc.take<double>((size_t)B * K * N);
+  double* part = wc.take<double>(np > npf ? np : npf);
   double* offset = wc.take<double>((size_t)B * K);
   double* prec = wc.take<double>((size_t)B * K);
-  // The E-step reads the transposed copy, the M-step the caller's row-major array, both in the
-  // caller's type.  The vMF mixture works on unit rows: the E-step normalises its dot products
-  // itself, the M-step takes 1 / |y_n| from `rowscale` -- round 1 kept two normalised float64
-  // copies instead and streamed 2 x 82 MB per iteration where a float32 embedding has 2 x 41.
+  // Two-kernel path: the E-step reads the transposed copy, the M-step the caller's row-major
+  // array, both in the caller's type.  The vMF mixture works on unit rows: the E-step normalises
+  // its dot products itself, the M-step takes 1 / |y_n| from `rowscale`.
   const int e_f64 = o->embedding_is_f64;
   const void* fit_y = y;
   TimedRegion tr(h, s);
-  int rc = pbbss::launch_embed_prepare(y, o->embedding_is_f64, B, N, E, 0, yd, nullptr, s,
-                                       vmf ? rowscale : nullptr);
-  if (rc != PBBSS_OK) return rc;
+  int rc = PBBSS_OK;
+  if (need_copy) {
+    rc = pbbss::launch_embed_prepare(y, o->embedding_is_f64, B, N, E, 0, yd, nullptr, s,
+                                     vmf ? rowscale : nullptr);
+    if (rc != PBBSS_OK) return rc;
+  }
   if (has_model) {
     if ((rc = copy_d2d(out_mean, in_mean, (size_t)B * K * E * 8, s)) != PBBSS_OK) return rc;
     if ((rc = copy_d2d(out_scale, in_scale, (size_t)B * K * 8, s)) != PBBSS_OK) return rc;
     if ((rc = copy_d2d(out_weight, in_weight, (size_t)B * K * 8, s)) != PBBSS_OK) return rc;
   }
   for (int it = 0; it < o->iterations; ++it) {
+    if (fused) {  // vmfmm.py:131-172: E-step with the previous model (or the initialisation), M-step
+      rc = pbbss::launch_vmf_em(y, e_f64, B, N, E, K, it == 0 ? gamma0 : nullptr, saliency,
+                                o->min_concentration, o->max_concentration, o->weight_mode, part,
+                                out_mean, out_scale, out_weight, offset, prec, nullptr, 1, s);
+      if (rc != PBBSS_OK) return rc;
+      continue;
+    }
     const double* src = gamma0;
     if (it > 0) {  // vmfmm.py:137-138 / gmm.py:129-130 (offsets: previous M-step's finalize)
       rc = pbbss::launch_embed_estep(kind, yd, e_f64, B, N, E, K, out_mean, prec, offset,
@@ -1297,6 +1313,11 @@ static int embed_mixture_fit(pbbss_handle_t h, int kind, const void* y, int64_t 
     if (o->iterations == 0) {
       rc = pbbss::launch_embed_offsets(kind, B * K, E, out_scale, offset, prec, s);
       if (rc != PBBSS_OK) return rc;
+    }
+    if (fused && !out_log_pdf) {
+      return pbbss::launch_vmf_em(y, e_f64, B, N, E, K, nullptr, nullptr, o->min_concentration,
+                                  o->max_concentration, o->weight_mode, part, out_mean, out_scale,
+                                  out_weight, offset, prec, out_affiliation, 0, s);
     }
     rc = pbbss::launch_embed_estep(kind, yd, e_f64, B, N, E, K, out_mean, prec, offset,
                                    out_weight, 1.0, N, out_log_pdf, out_affiliation, s);

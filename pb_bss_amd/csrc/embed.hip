@@ -354,6 +354,217 @@ __global__ void __launch_bounds__(kFitThreads)
   }
 }
 
+// ---------------------------------------------------------------- fused E + M sweep (vMF mixture)
+// Round 3: ONE pass over the embedding per EM iteration.  The E-step of iteration i and the
+// M-step partial sums of iteration i consume the same rows, so a workgroup stages a tile of R
+// consecutive rows of the caller's row-major (N, E) array in LDS (one contiguous, fully coalesced
+// block of R * E elements; LDS row stride E | 1: odd, conflict-free both ways) and uses it twice:
+//   E  thread = row: |y_n|, the K dot products with the class means, softmax -> w_k(n) = gamma_k(n)
+//      * saliency(n) and 1 / |y_n| into LDS (the first iteration takes gamma from the caller's
+//      initialisation instead; the last call may also write the affiliations)
+//   M  thread = (row slot s, dimension d): S1[k][d] += w_k(n) y[n][d] / |y_n|, S0[k] += w_k(n)
+// then the slots are folded through LDS and the workgroup writes ONE chunk partial in exactly the
+// layout of embed_fit_kernel -- embed_finalize_kernel is reused unchanged.  No transposed copy, no
+// row-scale array, no (B, K, N) affiliation round trip through HBM between the two steps: 41 MB
+// instead of 2 x 41 + 2 x 6 MB per iteration for N = 256 500, E = 40 float32.
+constexpr int kFusedThreads = 256;
+
+template <int K, typename TS, bool VEC>
+__global__ void __launch_bounds__(kFusedThreads)
+    vmf_em_kernel(const TS* __restrict__ y, int64_t N, int E, int R, int C, int64_t L,
+                  const double* __restrict__ gamma, const double* __restrict__ mean,
+                  const double* __restrict__ prec, const double* __restrict__ offset,
+                  const double* __restrict__ weight, const double* __restrict__ sal,
+                  double* __restrict__ part, double* __restrict__ out_aff) {
+  extern __shared__ __attribute__((aligned(16))) char smraw[];
+  constexpr int KW = (K + 1) & ~1;  // class weights of a row padded to whole 16-byte reads
+  const int ES = E | 1;             // LDS row stride (odd)
+  const int S = kFusedThreads / E;  // row slots of the M part (E <= 256: S >= 1)
+  double* affw = reinterpret_cast<double*>(smraw);  // [R][KW]  gamma * saliency / |y_n|
+  double* red = affw + (size_t)R * KW;              // [S][K][E]
+  double* red0 = red + (size_t)S * K * E;           // [waves][K]
+  TS* tile = reinterpret_cast<TS*>(red0 + (kFusedThreads / kWave) * K);  // [R][ES]
+  const int64_t b = blockIdx.y;
+  const int c = blockIdx.x;
+  const int tid = threadIdx.x;
+  // class means / constants of the E part are wave-uniform: read through the scalar cache
+  // (s_load, SGPR operands of the FMAs) straight from the model arrays -- no LDS copy, no
+  // broadcast reads (the LDS pipe is what bounds this kernel: tile in, tile out twice)
+  const double* mu = mean ? mean + (size_t)b * K * E : nullptr;
+  const int s = tid / E, d = tid - s * E;
+  const bool active = s < S;
+  double acc[K], s0[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    acc[k] = 0.0;
+    s0[k] = 0.0;
+  }
+  const int64_t n0 = (int64_t)c * L;
+  const int64_t n1 = (n0 + L < N) ? (n0 + L) : N;
+  // Tile load: the R rows of a tile are ONE contiguous block of rows * E elements.  With VEC
+  // (E a multiple of the 16-byte vector: the usual case) a thread fetches kVU 16-byte vectors --
+  // the whole tile is in flight at once -- and the NEXT tile's vectors are requested before the
+  // current tile is consumed (registers), so the memory latency of a tile hides behind the E and M
+  // parts of its predecessor.  (Eight 4-byte loads per thread and batch were five dependent
+  // memory round trips per tile: 24 us per sweep)
+  constexpr int VW = 16 / (int)sizeof(TS);
+  typedef TS VecT __attribute__((ext_vector_type(VW)));
+  constexpr int kVU = 12;  // vectors per thread: covers R * E <= 12 * 256 * VW elements
+  const bool vec = VEC && (R * E <= kVU * kFusedThreads * VW);
+  VecT pre[kVU];
+  auto request = [&](int64_t nb2) {  // issue the loads of the tile that starts at row nb2
+    const int rows2 = (int)((n1 - nb2 < R) ? (n1 - nb2) : R);
+    const int nv = rows2 * E / VW;
+    const VecT* base = reinterpret_cast<const VecT*>(y + ((size_t)b * N + nb2) * E);
+#pragma unroll
+    for (int u = 0; u < kVU; ++u) {
+      const int i = tid + u * kFusedThreads;
+      pre[u] = base[i < nv ? i : (nv > 0 ? nv - 1 : 0)];  // clamped, masked at the LDS store
+    }
+  };
+  if (vec && n0 < n1) request(n0);
+  for (int64_t nb = n0; nb < n1; nb += R) {
+    const int rows = (int)((n1 - nb < R) ? (n1 - nb) : R);
+    __syncthreads();  // previous tile fully consumed
+    if (vec) {
+      const int nv = rows * E / VW;
+#pragma unroll
+      for (int u = 0; u < kVU; ++u) {
+        const int i = tid + u * kFusedThreads;
+        if (i < nv) {
+          const int e0 = i * VW;
+          const int r = e0 / E;
+          TS* dst = tile + (size_t)r * ES + (e0 - r * E);
+#pragma unroll
+          for (int x = 0; x < VW; ++x) dst[x] = pre[u][x];
+        }
+      }
+      if (nb + R < n1) request(nb + R);
+    } else {  // generic: 4- / 8-byte loads, eight in flight per thread
+      const TS* base = y + ((size_t)b * N + nb) * E;
+      const int total = rows * E;
+      constexpr int U = 8;
+      for (int i0 = tid; i0 < total; i0 += U * kFusedThreads) {
+        TS raw[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int i = i0 + u * kFusedThreads;
+          raw[u] = base[i < total ? i : total - 1];  // clamped, masked below (no guarded loads)
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int i = i0 + u * kFusedThreads;
+          if (i < total) {
+            const int r = i / E;
+            tile[(size_t)r * ES + (i - r * E)] = raw[u];
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // ---- E part: thread = row
+    if (tid < R) {
+      double w[K];
+#pragma unroll
+      for (int k = 0; k < K; ++k) w[k] = 0.0;
+      if (tid < rows) {
+        const TS* row = tile + (size_t)tid * ES;
+        const int64_t n = nb + tid;
+        double n2 = 0.0, dot[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) dot[k] = 0.0;
+        if (mu) {
+          for (int e = 0; e < E; ++e) {
+            const double v = (double)row[e];
+            n2 = fma(v, v, n2);
+#pragma unroll
+            for (int k = 0; k < K; ++k) dot[k] = fma(v, mu[k * E + e], dot[k]);
+          }
+        } else {
+          for (int e = 0; e < E; ++e) {
+            const double v = (double)row[e];
+            n2 = fma(v, v, n2);
+          }
+        }
+        const double inv = 1.0 / fmax(sqrt(n2), kTiny);  // unit rows, vmfmm.py:76-78
+        double g[K];
+        if (gamma) {
+#pragma unroll
+          for (int k = 0; k < K; ++k) g[k] = gamma[((size_t)b * K + k) * N + n];
+        } else {
+          double lp[K], mx = -1.79e308;
+#pragma unroll
+          for (int k = 0; k < K; ++k) {
+            lp[k] = fma(prec[b * K + k], dot[k] * inv, offset[b * K + k]);  // von_mises_fisher.py:71-77
+            mx = fmax(mx, lp[k]);
+          }
+          double den = 0.0;
+#pragma unroll
+          for (int k = 0; k < K; ++k) {
+            g[k] = exp(lp[k] - mx) * (weight ? weight[b * K + k] : 1.0);  // mixture_model_utils.py:30-47
+            den += g[k];
+          }
+          den = fmax(den, kTiny);
+#pragma unroll
+          for (int k = 0; k < K; ++k) g[k] /= den;
+        }
+        if (out_aff) {
+#pragma unroll
+          for (int k = 0; k < K; ++k) out_aff[((size_t)b * K + k) * N + n] = g[k];
+        }
+        const double sv = sal ? sal[(size_t)b * N + n] : 1.0;  // vmfmm.py:167
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          const double wk = g[k] * sv;
+          s0[k] += wk;          // S0 takes the plain weights
+          w[k] = wk * inv;      // the first moments take unit rows: the scale rides on the weight
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < KW; ++k) affw[tid * KW + k] = (k < K) ? w[k < K ? k : 0] : 0.0;
+    }
+    __syncthreads();
+    // ---- M part: thread = (slot, dimension)
+    if (active) {
+      for (int r = s; r < rows; r += S) {
+        const double v = (double)tile[(size_t)r * ES + d];
+        double wk[KW];
+#pragma unroll
+        for (int k = 0; k < KW; k += 2) {
+          const double2 p2 = *reinterpret_cast<const double2*>(affw + r * KW + k);
+          wk[k] = p2.x;
+          wk[k + 1] = p2.y;
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[k] = fma(wk[k], v, acc[k]);
+      }
+    }
+  }
+  __syncthreads();
+  if (active) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) red[((size_t)s * K + k) * E + d] = acc[k];
+  }
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const double t = wave_sum(s0[k]);
+    if ((tid & (kWave - 1)) == 0) red0[(tid / kWave) * K + k] = t;
+  }
+  __syncthreads();
+  double* dst = part + ((size_t)b * C + c) * K * (E + 1);
+  for (int i = tid; i < K * E; i += kFusedThreads) {
+    const int k = i / E, dd = i - k * E;
+    double t = 0.0;
+    for (int ss = 0; ss < S; ++ss) t += red[((size_t)ss * K + k) * E + dd];
+    dst[k * (E + 1) + dd] = t;
+  }
+  if (tid < K) {
+    double t = 0.0;
+    for (int w = 0; w < kFusedThreads / kWave; ++w) t += red0[w * K + tid];
+    dst[tid * (E + 1) + E] = t;
+  }
+}
+
 // ---------------------------------------------------------------- M-step finalize
 // One 1024-thread workgroup per mixture: ordered two-level sum over the chunk partials
 // (slot = chunk index mod nslot, then over slots), then the model and -- so that the
@@ -974,6 +1185,95 @@ int launch_embed_fit(int kind, const void* yr, int y_is_f64, int64_t B, int64_t 
                   : fit_k<float>(K, kind, yr, B, N, E, aff, Tin, sal, cmin, cmax, weight_mode,
                                  part, out_mean, out_scale, out_weight, out_offset, out_prec,
                                  single_pass, rowscale, s, reduce);
+}
+
+// ---- fused vMF sweep (vmf_em_kernel) + finalize: one EM iteration of the vMF mixture ----------
+namespace {
+struct FusedPlan {
+  int R, C;
+  int64_t L;
+  size_t lds;
+  bool ok;
+};
+FusedPlan fused_plan(int64_t B, int64_t N, int E, int K, int y_is_f64) {
+  FusedPlan p{};
+  const size_t esz = y_is_f64 ? 8 : 4;
+  const int ES = E | 1;
+  const int S = kFusedThreads / E;
+  for (int R : {256, 128, 64}) {
+    const int KW = (K + 1) & ~1;
+    const size_t lds = ((size_t)R * KW + (size_t)S * K * E + (size_t)(kFusedThreads / kWave) * K) * 8 +
+                       (size_t)R * ES * esz;
+    if (lds <= 64 * 1024) {
+      p.R = R;
+      p.lds = lds;
+      p.ok = true;
+      break;
+    }
+  }
+  if (!p.ok || E > kFusedThreads) {
+    p.ok = false;
+    return p;
+  }
+  // ~two workgroups per CU in total (256 / 384 / 768 / 1024 measured slower: 35.9 / 35.9 / 35.5 /
+  // 40.5 against 32.0 us per iteration at N = 256 500, E = 40)
+  int64_t want = 512 / (B < 512 ? B : 512);
+  if (want < 1) want = 1;
+  int64_t maxc = (N + p.R - 1) / p.R;
+  p.C = (int)(want < maxc ? want : maxc);
+  p.L = (N + p.C - 1) / p.C;
+  p.L = (p.L + p.R - 1) / p.R * p.R;
+  return p;
+}
+}  // namespace
+
+size_t vmf_fused_partial_doubles(int64_t B, int64_t N, int E, int K, int y_is_f64) {
+  const FusedPlan p = fused_plan(B, N, E, K, y_is_f64);
+  if (!p.ok) return 0;
+  return (size_t)B * p.C * K * (E + 1) + (size_t)B * K;  // chunk partials, den
+}
+
+int launch_vmf_em(const void* y, int y_is_f64, int64_t B, int64_t N, int E, int K,
+                  const double* gamma, const double* sal, double cmin, double cmax,
+                  int weight_mode, double* part, double* mean, double* conc, double* weight,
+                  double* offset, double* prec, double* out_aff, int accumulate, hipStream_t s) {
+  const FusedPlan p = fused_plan(B, N, E, K, y_is_f64);
+  if (!p.ok || B > 65535 || K < 1 || K > kEmbedMaxK) return PBBSS_ERR_UNSUPPORTED;
+  dim3 grid((unsigned)p.C, (unsigned)B);
+  // 16-byte vector loads need E * sizeof(element) to be a multiple of 16 (rows then start on a
+  // vector boundary, the tile base is R-row aligned) and a 16-byte aligned array
+  const int vw = y_is_f64 ? 2 : 4;
+  const bool vec = (E % vw == 0) && (reinterpret_cast<uintptr_t>(y) % 16 == 0);
+#define PBBSS_VMF_GO(KK, TT, VV)                                                                  \
+  hipLaunchKernelGGL((vmf_em_kernel<KK, TT, VV>), grid, dim3(kFusedThreads), p.lds, s,            \
+                     static_cast<const TT*>(y), N, E, p.R, p.C, p.L, gamma, mean, prec, offset,   \
+                     weight, sal, part, out_aff)
+#define PBBSS_VMF_EM(KK)                                                                          \
+  case KK:                                                                                        \
+    if (y_is_f64) {                                                                               \
+      if (vec) PBBSS_VMF_GO(KK, double, true); else PBBSS_VMF_GO(KK, double, false);              \
+    } else {                                                                                      \
+      if (vec) PBBSS_VMF_GO(KK, float, true); else PBBSS_VMF_GO(KK, float, false);                \
+    }                                                                                             \
+    break;
+  switch (K) {
+    PBBSS_VMF_EM(1) PBBSS_VMF_EM(2) PBBSS_VMF_EM(3) PBBSS_VMF_EM(4) PBBSS_VMF_EM(5) PBBSS_VMF_EM(6)
+    default: return PBBSS_ERR_UNSUPPORTED;
+  }
+#undef PBBSS_VMF_EM
+#undef PBBSS_VMF_GO
+  if (hipGetLastError() != hipSuccess) return PBBSS_ERR_HIP;
+  if (!accumulate) return PBBSS_OK;  // predict only: the partials are not used
+  const size_t Wv = (size_t)K * (E + 1);
+  const size_t lds_fin = (Wv + (Wv < (size_t)kFinThreads ? (kFinThreads / Wv) * Wv : 0)) * sizeof(double);
+  // (A first reduction level inside the sweep -- the last workgroup of every group of 32 chunks
+  // sums the group's partials, the finalize then reads 16 instead of 512 -- was built and
+  // measured: the sweep grew by the 4 us the finalize lost, 32.5 vs 32.0 us per iteration.)
+  double* den_buf = part + (size_t)B * p.C * K * (E + 1);
+  hipLaunchKernelGGL((embed_finalize_kernel<PBBSS_EMBED_VMF, 0>), dim3((unsigned)B),
+                     dim3(kFinThreads), lds_fin, s, part, p.C, E, K, cmin, cmax, weight_mode,
+                     den_buf, mean, conc, weight, offset, prec);
+  return ok_or_hip();
 }
 
 int launch_joint_weight(int mode, const double* aff, const double* sal, int64_t F, int K, int T,

@@ -62,6 +62,19 @@ int launch_embed_fit(int kind, const void* yr, int y_is_f64, int64_t B, int64_t 
                      hipStream_t s, const double* rowscale = nullptr,  // rowscale: vMF only, rows
                      const PartialReduce* reduce = nullptr);           // are used as y_n * rowscale[n]
 
+// ONE EM iteration of the vMF mixture in one pass over the row-major embedding (vmf_em_kernel:
+// E-step and M-step partial sums on the same LDS tile) + the ordered finalize.  gamma (B,K,N):
+// affiliations of the first iteration (then mean / prec / offset / weight are not read), or
+// null: the E-step uses the current model (mean (B,K,E), prec = concentration, offset =
+// -log_norm, weight (B,K)).  out_aff (B,K,N) or null: the affiliations of this sweep.
+// accumulate = 0: E-step only (predict).  part: vmf_fused_partial_doubles() doubles (0: the shape
+// is not served -- E > 256 or the tile does not fit -- and the caller uses the two-kernel path).
+size_t vmf_fused_partial_doubles(int64_t B, int64_t N, int E, int K, int y_is_f64);
+int launch_vmf_em(const void* y, int y_is_f64, int64_t B, int64_t N, int E, int K,
+                  const double* gamma, const double* sal, double cmin, double cmax,
+                  int weight_mode, double* part, double* mean, double* conc, double* weight,
+                  double* offset, double* prec, double* out_aff, int accumulate, hipStream_t s);
+
 // masked affiliation sums of the joint models (gcacgmm.py:286-295): aff (F,K,T), sal (F,T)
 //   mode 0 'fk' (-1,): w[f,k] = sum_t / sum_k sum_t          -> (F,K)
 //   mode 1 uniform    : 1/K                                   -> (1)

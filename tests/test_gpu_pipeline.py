@@ -85,3 +85,37 @@ def test_config3_chain_full_size_utterances_match_oracle_chain():
             assert np.abs(cos - 1).max() < 1e-9
             s = ob.apply_bf(w, X)
             assert _phase_aligned_error(enhanced[u, k], s) < 1e-8
+
+
+def test_pipeline_with_mvdr_souden_matches_oracle_chain():
+    """pipeline.separate(beamformer='mvdr_souden'): EM -> DHTV -> PSD -> MVDR-Souden with the
+    automatic reference channel (beamformer.py:627-698, :601-624; the batched device stage picks
+    the channel per (class, utterance) from the SNR summed over all bins) -> apply.  MVDR has no
+    phase ambiguity: the complex outputs are compared directly."""
+    from oracle import beamformer as ob, cacgmm as oc, permutation_alignment as op, synth
+    from pb_bss_amd import _lib, pipeline
+    U, F, T, D, K, iters = 3, 257, 120, 5, 3, 6
+    data = [synth.make_stft(F, T, D, K, seed=60 + u) for u in range(U)]
+    Y = np.stack([d[0] for d in data])
+    init = np.stack([d[1] for d in data])
+    out = pipeline.separate(_lib.to_device(Y), _lib.to_device(init), iters, 512,
+                            beamformer='mvdr_souden')
+    w_dev = _lib.to_host(out['bf_vector'])       # (U, K, F, D)
+    s_dev = _lib.to_host(out['enhanced'])        # (U, K, F, T)
+    plan = op.alignment_plan(512, **op.PRESETS[512])
+    for u in range(U):
+        Y128 = Y[u].astype(np.complex128)
+        ref = oc.em_predict(oc.em_fit(Y128, init[u], iterations=iters), Y128)
+        kft = ref.transpose(1, 0, 2)
+        mapping = op.dhtv_calculate_mapping(kft, plan)
+        assert (mapping == _lib.to_host(out['mapping'])[u]).all()
+        aligned = op.apply_mapping(kft, mapping)
+        X = Y128.transpose(0, 2, 1)
+        psd = ob.psd(X, aligned.transpose(1, 0, 2))
+        for k in range(K):
+            w = ob.mvdr_souden(psd[:, k], psd.sum(1) - psd[:, k])
+            assert np.abs(w - w_dev[u, k]).max() < 1e-7 * np.abs(w).max()
+            s = ob.apply_bf(w, X)
+            assert np.abs(s - s_dev[u, k]).max() < 1e-7 * np.abs(s).max()
+    with pytest.raises(ValueError):
+        pipeline.separate(_lib.to_device(Y), _lib.to_device(init), 2, 512, beamformer='lcmv')
