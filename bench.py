@@ -317,6 +317,13 @@ def setup(args):
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     assert world == args.gpus, (world, args.gpus)
+    # PBBSS_BENCH_ONE_DEVICE=1 (development only): every rank on GPU 0 with the gloo backend -- a
+    # FUNCTIONAL rehearsal of the N > 1 control flow (sharding, gathers, verification, JSON) on a
+    # one-GPU box, where RCCL refuses two ranks on one device; the figures of such a run mean
+    # nothing and the line says so (`rehearsal`)
+    one_dev = os.environ.get('PBBSS_BENCH_ONE_DEVICE') == '1'
+    if one_dev:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     # under torch.distributed.run (RANK set) always go through RCCL, also for 1 rank
@@ -324,7 +331,10 @@ def setup(args):
     if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
-        dist.init_process_group('nccl', device_id=dev)
+        if one_dev:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=dev)
         if args.comm == 'native':
             from pb_bss_amd import sharding
             sharding.init_native_comm(device_index=local_rank)
@@ -874,6 +884,9 @@ def main():
         blk, _ = run_config3(args, world, rank, local_rank, dev, use_dist)
         if rank == 0:
             out['config3'] = blk
+    if rank == 0 and os.environ.get('PBBSS_BENCH_ONE_DEVICE') == '1':
+        out['rehearsal'] = ('PBBSS_BENCH_ONE_DEVICE=1: all ranks shared GPU 0 over gloo -- a '
+                            'functional rehearsal of the multi-rank path, not a measurement')
     emit(json.dumps(out) if rank == 0 else None, use_dist)
 
 
