@@ -426,40 +426,81 @@ struct EmKernel {
         wgt[k] = L.wgt[k];
       }
       if constexpr (JOINT) {
-        // log-domain softmax of the weighted sum of spatial and spectral log-pdfs
+        // softmax of the weighted sum of spatial and spectral log-pdfs
         // (gcacgmm.py:108-115 -> mixture_model_utils.py:30-53)
         const int t = tt[0];
         const double inv = L.inv_n2[t];
-        double lps[K], lp[K], mx = -1.79e308;
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-          double qq = fmax(fabs(q[0][k] * inv), kTiny);  // cacg.py:185-199
-          q[0][k] = qq;
-          lps[k] = -(double)D * log(qq) - jlogdet[k];
-        }
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-          double sp = lps[k];
-          if (jx->perm) {
-            const int pk = jx->perm[k];
-#pragma unroll
-            for (int j = 0; j < K; ++j) sp = (pk == j) ? lps[j] : sp;
-          }
-          lp[k] = jx->spatial_weight * sp + jx->extra_logpdf[((size_t)b * K + k) * TS + tf + t];
-          mx = fmax(mx, lp[k]);
-        }
         double g[K], den = 0.0;
+        if (jx->spatial_weight == 1.0) {
+          // spatial_weight = 1 (the default): exp(spatial log-pdf) = 1 / (det_k q_k^D) in the
+          // mantissa / exponent form of the persistent kernel -- no logarithm; only the exponents
+          // and the spectral log-pdf enter the max-shift (the mantissa factor lies in [1, 2^(D+1)]):
+          //   g_k = rdet_k rm_k^D * exp((ex_k ln 2 + spectral_k) - max) * w_k
+          double val[K], tk[K];
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-          double w = TW ? a.in_weight[b * a.wb + k * a.wk + (int64_t)(tf + t) * a.wt] : wgt[k];
-          g[k] = exp(lp[k] - mx) * w;
-          den += g[k];
+          for (int k = 0; k < K; ++k) {
+            const double qq = fmax(fabs(q[0][k] * inv), kTiny);  // cacg.py:185-199
+            q[0][k] = qq;
+            int e;
+            const double m = frexp(qq, &e);
+            const double rm = fast_rcp(m);
+            val[k] = rdet[k] * ipow<D>(rm);
+            tk[k] = -(double)(e * D + dete[k]) * 0.6931471805599453;
+          }
+          double lt[K], vsel[K], mx = -1.79e308;
+#pragma unroll
+          for (int k = 0; k < K; ++k) {
+            double sv = val[k], st = tk[k];
+            if (jx->perm) {
+              const int pk = jx->perm[k];
+#pragma unroll
+              for (int j = 0; j < K; ++j) {
+                sv = (pk == j) ? val[j] : sv;
+                st = (pk == j) ? tk[j] : st;
+              }
+            }
+            vsel[k] = sv;
+            lt[k] = st + jx->extra_logpdf[((size_t)b * K + k) * TS + tf + t];
+            mx = fmax(mx, lt[k]);
+          }
+#pragma unroll
+          for (int k = 0; k < K; ++k) {
+            const double w = TW ? a.in_weight[b * a.wb + k * a.wk + (int64_t)(tf + t) * a.wt] : wgt[k];
+            g[k] = vsel[k] * exp(lt[k] - mx) * w;
+            den += g[k];
+          }
+        } else {
+          double lps[K], lp[K], mx = -1.79e308;
+#pragma unroll
+          for (int k = 0; k < K; ++k) {
+            double qq = fmax(fabs(q[0][k] * inv), kTiny);  // cacg.py:185-199
+            q[0][k] = qq;
+            lps[k] = -(double)D * log(qq) - jlogdet[k];
+          }
+#pragma unroll
+          for (int k = 0; k < K; ++k) {
+            double sp = lps[k];
+            if (jx->perm) {
+              const int pk = jx->perm[k];
+#pragma unroll
+              for (int j = 0; j < K; ++j) sp = (pk == j) ? lps[j] : sp;
+            }
+            lp[k] = jx->spatial_weight * sp + jx->extra_logpdf[((size_t)b * K + k) * TS + tf + t];
+            mx = fmax(mx, lp[k]);
+          }
+#pragma unroll
+          for (int k = 0; k < K; ++k) {
+            double w = TW ? a.in_weight[b * a.wb + k * a.wk + (int64_t)(tf + t) * a.wt] : wgt[k];
+            g[k] = exp(lp[k] - mx) * w;
+            den += g[k];
+          }
         }
         den = fmax(den, kTiny);
+        const double rden = fast_rcp(den);  // one reciprocal instead of K divisions
         const double sal = (!FINAL && a.saliency) ? a.saliency[(size_t)b * TS + tf + t] : 1.0;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-          double gam = g[k] / den;
+          double gam = g[k] * rden;
           if (eps != 0.0) gam = fmin(fmax(gam, eps), 1.0 - eps);
           size_t idx = ((size_t)b * K + k) * TS + tf + t;
           if (ok[0]) {

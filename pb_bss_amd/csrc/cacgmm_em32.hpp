@@ -591,7 +591,12 @@ struct EmKernel32 {
     const int nprob = nblocks / G;
     const int64_t b = ga.b_first + prob;
     const int tf = g * ga.split_window;
-    if (ga.split_prio == 1) __builtin_amdgcn_s_setprio(1);
+    switch (ga.split_prio) {
+      case 1: __builtin_amdgcn_s_setprio(1); break;
+      case 2: __builtin_amdgcn_s_setprio(2); break;
+      case 3: __builtin_amdgcn_s_setprio(3); break;
+      default: break;
+    }
     EmArgs a = ga;  // this workgroup's window
     a.T = min(ga.split_window, ga.T_total - tf);
     const Lds L = carve(smem, ga.split_window);

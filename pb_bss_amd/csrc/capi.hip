@@ -202,8 +202,15 @@ PBBSS_API int pbbss_create(pbbss_handle_t* out, int device_id) {
   h->cfg.scratch_ctx = h;
   h->cfg.allow_split = 1;
   h->cfg.split_window = pbbss::kSplitWindow;
+  // wave priority of the remainder bin's member workgroups (s_setprio): 1, above the full
+  // workgroups.  At priority 0 the MAIN kernel gets faster (1.43 -> 1.37 ms; with the full
+  // workgroups raised to 1 even 1.26 ms, the 512-bin time) but the members then only harvest idle
+  // issue slots and need 1.72 ms for their 100 iterations: the step waits for them
+  // (profiles/r03_g_member_priority.txt).  The packed-FP32 kernel's members sit in the same grid,
+  // where the kernel time shows it directly: 1.05 ms at 1, 1.29 ms at 0.
   h->cfg.split_prio = 1;
-  if (const char* p = getenv("PBBSS_SPLIT_PRIO")) h->cfg.split_prio = atoi(p);
+  h->cfg.split_prio32 = 1;
+  if (const char* p = getenv("PBBSS_SPLIT_PRIO")) h->cfg.split_prio = h->cfg.split_prio32 = atoi(p);
   h->split_epoch = 1;
   h->cfg.split_epoch = &h->split_epoch;
   h->cfg.ev_t0 = nullptr;

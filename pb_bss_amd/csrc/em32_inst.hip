@@ -49,7 +49,7 @@ static int launch32(EmArgs a, const EmLaunchCfg& cfg, hipStream_t stream) {
     a.T_total = a.T;
     a.split_groups = G;
     a.split_window = window;
-    a.split_prio = cfg.split_prio;
+    a.split_prio = cfg.split_prio32;
     a.b_first = a.B;
     a.xcount = reinterpret_cast<unsigned*>(cfg.xbuf);
     a.xerror = reinterpret_cast<int*>(cfg.xbuf + 128);

@@ -23,7 +23,8 @@ struct EmLaunchCfg {
   size_t xbuf_bytes;
   int allow_split;   // 0 disables the split variant (tests / debugging)
   int split_window;  // frames per workgroup of a split problem (multiple of 64)
-  int split_prio;    // s_setprio level of the split waves
+  int split_prio;    // s_setprio level of the split waves (float64 kernels)
+  int split_prio32;  // ... of the packed-FP32 kernel's member workgroups
   int* split_epoch;  // host counter stamping the launches of the split protocol
   // kernel timing (pbbss_set_timing): start / stop events attached to the DISPATCH of the EM kernel
   // itself (hipExtLaunchKernelGGL: timestamps of the kernel's own completion signal) instead of
