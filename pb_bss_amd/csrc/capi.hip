@@ -419,7 +419,8 @@ PBBSS_API int pbbss_set_split_tail(pbbss_handle_t h, int enable) {
 }
 
 PBBSS_API int pbbss_set_dhtv_team(pbbss_handle_t h, int workgroups_per_utterance) {
-  if (!h || workgroups_per_utterance < 0 || workgroups_per_utterance > pbbss::kDhtvTeamMax)
+  if (!h || workgroups_per_utterance < -pbbss::kDhtvTeamMax || workgroups_per_utterance > 64 ||
+      workgroups_per_utterance == -1)
     return PBBSS_ERR_INVALID_ARG;
   h->dhtv_team = workgroups_per_utterance;
   return PBBSS_OK;

@@ -542,6 +542,436 @@ __global__ void __launch_bounds__(kDhtvThreads)
                              (int32_t)(xerr ? PBBSS_ST_EIG_NOCONV : 0));
 }
 
+// ---------------------------------------------------------------------------------------
+// Frame-slice variant: the features never move.
+//
+// The two kernels above permute feature rows in memory, so every iteration pays L2 round
+// trips for data other workgroups wrote (team kernel: two team barriers and four dependent
+// round trips, ~20 us per plan iteration).  Here the G workgroups of an utterance split the
+// FRAME axis instead of the bins: workgroup g owns frames [g*TS, (g+1)*TS), TS = 16*NFR, of
+// EVERY bin, reads them from the (read-only) mask once per segment and keeps them in
+// registers -- 16-lane row = bin of the segment (32 per pass), lane = NFR frames.  Then
+//   * the time centroid of its frames is LOCAL (sum over the segment's bins, no exchange);
+//   * the K x K scores and the centroid norms are sums over frames: each workgroup publishes
+//     its partial (bins x K*K + K doubles), ONE team barrier, and every workgroup adds the G
+//     partials in the same order and solves every assignment itself -- all workgroups reach
+//     identical permutations, the "anything changed" decision needs no flag;
+//   * a permutation is a register shuffle in the owning wave plus a 4-bit-per-class word in
+//     LDS (the composite mapping); features are written out once, at the end.
+// One exchange hop per plan iteration instead of four.  'cos': the centroid norm is applied
+// to the summed score (score * 1/max(||c||, tiny)) instead of to the centroid before the dot
+// product -- same value up to one rounding.
+// The exchange area is the head of the utterance's feature scratch (dead until the final
+// write): 2 parities x G x (K + F*K*K) doubles.
+// ---------------------------------------------------------------------------------------
+constexpr int kSliceThreads = 512;  // 8 waves: 256 VGPRs per lane keep the window in registers
+constexpr int kSliceWaves = kSliceThreads / kWave;
+constexpr int kSliceBins = kSliceThreads / 16;  // bins per pass: one per 16-lane row
+
+template <int K>
+__device__ __forceinline__ int pack_identity() {
+  int m = 0;
+#pragma unroll
+  for (int a = 0; a < K; ++a) m |= a << (4 * a);
+  return m;
+}
+
+// Lane layout: 16-lane row = one bin, the row's lanes = 16 consecutive frames, NFR frames per
+// lane (t = t0 + l + 16 j): the frame sums of the scores stay inside a row (DPP only, no
+// permlane swaps), 32 bins per pass.
+template <int K, int NFR>
+struct SliceCfg {
+  static constexpr int KK = K * K;
+  static constexpr int NS = ((KK + 3) / 4) * 4;  // scores per row reduce-scatter
+  static constexpr int QS = NS / 4;
+  static constexpr int NC = K * NFR;             // centroid values per lane (NFR % 4 == 0)
+  static constexpr int QC = NC / 4;
+  static constexpr int kRegDoubles = 48;         // register-resident window budget
+  static constexpr int MAXP = (kRegDoubles / NC) < 1 ? 1 : ((kRegDoubles / NC) > 4 ? 4 : (kRegDoubles / NC));
+  static constexpr int TS = 16 * NFR;
+};
+
+// sum over the 16 lanes of a row, halving: on return v[0 .. N/4) hold the totals of the original
+// indices (N/4) * (b2 + 2*b3) + m (b_i = lane bit i; the 4 lanes of a quad hold the same values)
+template <int N>
+__device__ __forceinline__ void row_reduce_scatter(double (&v)[N]) {
+  static_assert(N % 4 == 0, "pad to a multiple of 4");
+  {
+    constexpr int H = N / 2;
+#pragma unroll
+    for (int n = 0; n < H; ++n) {
+      double lo = v[n], hi = v[n + H];
+      double recv = dpp_f64<kDppRowRor8, 0x3>(lo, lo);
+      recv = dpp_f64<kDppRowRor8, 0xC>(recv, hi);
+      double keep = dpp_f64<kDppQuadIdent, 0xC>(lo, hi);
+      v[n] = keep + recv;
+    }
+  }
+  constexpr int Q = N / 4;
+#pragma unroll
+  for (int n = 0; n < Q; ++n) {
+    double lo = v[n], hi = v[n + Q];
+    double recv = dpp_f64<kDppRowRor12, 0x5>(lo, lo);
+    recv = dpp_f64<kDppRowRor4, 0xA>(recv, hi);
+    double keep = dpp_f64<kDppQuadIdent, 0xA>(lo, hi);
+    v[n] = keep + recv;
+  }
+#pragma unroll
+  for (int n = 0; n < Q; ++n) v[n] += dpp_f64<kDppQuadXor2, 0xF>(v[n], v[n]);
+#pragma unroll
+  for (int n = 0; n < Q; ++n) v[n] += dpp_f64<kDppQuadXor1, 0xF>(v[n], v[n]);
+}
+// sum over the four rows of a wave (lane bits 5, 4), halving: v[0 .. N/4) = totals of the original
+// indices (N/4) * (b4 + 2*b5) + m
+template <int N>
+__device__ __forceinline__ void rows_reduce_scatter(double (&v)[N]) {
+  static_assert(N % 4 == 0, "pad to a multiple of 4");
+  {
+    constexpr int H = N / 2;
+#pragma unroll
+    for (int n = 0; n < H; ++n) {
+      double lo = v[n], hi = v[n + H];
+      swap32_f64(lo, hi);
+      v[n] = lo + hi;
+    }
+  }
+  constexpr int Q = N / 4;
+#pragma unroll
+  for (int n = 0; n < Q; ++n) {
+    double lo = v[n], hi = v[n + Q];
+    swap16_f64(lo, hi);
+    v[n] = lo + hi;
+  }
+}
+__device__ __forceinline__ double row_sum(double v) {
+  v += dpp_f64<kDppQuadXor1, 0xF>(v, v);
+  v += dpp_f64<kDppQuadXor2, 0xF>(v, v);
+  v += dpp_f64<kDppRowHalfMirror, 0xF>(v, v);
+  v += dpp_f64<kDppRowMirror, 0xF>(v, v);
+  return v;
+}
+
+__host__ __device__ inline size_t slice_entries(int K, int F) {
+  return (((size_t)K + (size_t)F * K * K) + 7) & ~(size_t)7;
+}
+// LDS: centroid [K][TS], row scales [K][F], union{wave sums [waves][K][TS], summed entries},
+// composite mapping [F], last permutation [F]
+inline size_t slice_lds_bytes(int K, int NFR, int F) {
+  const size_t TS = (size_t)16 * NFR;
+  const size_t uni = (size_t)kSliceWaves * K * TS > slice_entries(K, F) ? (size_t)kSliceWaves * K * TS
+                                                                        : slice_entries(K, F);
+  return ((size_t)K * TS + (size_t)K * F + uni) * sizeof(double) + 2 * (size_t)F * sizeof(int) + 16;
+}
+
+template <int K, int NFR>
+__global__ void __launch_bounds__(kSliceThreads)
+    dhtv_slice_kernel(const double* __restrict__ mask, double* feat_all, int32_t* mapping_all,
+                      const int32_t* __restrict__ plan, int P, int F, int T, int optimal,
+                      int metric, int32_t* status, int G, unsigned* ctrl_all) {
+  using C = SliceCfg<K, NFR>;
+  constexpr int KK = C::KK, NS = C::NS, QS = C::QS, NC = C::NC, QC = C::QC, MAXP = C::MAXP,
+                TS = C::TS;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l = lane & 15, q = lane >> 4;  // frame lane inside the row, row (= bin) inside the wave
+  const int rowid = wave * 4 + q;          // bin slot of this row inside a pass
+  const int64_t u = blockIdx.x / G;
+  const int g = blockIdx.x % G;
+  const int t0 = g * TS;
+  const double* m = mask + u * (int64_t)K * F * T;
+  double* feat = feat_all + u * (int64_t)K * F * T;
+  int32_t* mapping = mapping_all + u * (int64_t)K * F;
+  unsigned* ctrl = ctrl_all + u * 4;
+  const size_t NE = slice_entries(K, F);
+  const size_t uni_n = (size_t)kSliceWaves * K * TS > NE ? (size_t)kSliceWaves * K * TS : NE;
+  double* cent = reinterpret_cast<double*>(smem);  // [K][TS]
+  double* inv = cent + (size_t)K * TS;             // [K][F]
+  double* uni = inv + (size_t)K * F;               // wave sums | summed exchange entries
+  int* mapw = reinterpret_cast<int*>(uni + uni_n);  // [F] composite mapping, 4 bits per class
+  int* lastp = mapw + F;                            // [F] permutation of the last assignment (0 = none)
+  double* xch = feat;                               // [2][G][NE]
+  unsigned target = 0;
+  int hop = 0;
+  int nonfinite = 0;
+  const bool cos = metric == PBBSS_PA_COS;
+
+  // frames of this lane (clamped address + validity)
+  int tc[NFR];
+  bool tok[NFR];
+#pragma unroll
+  for (int j = 0; j < NFR; ++j) {
+    const int t = t0 + l + 16 * j;
+    tok[j] = t < T;
+    tc[j] = tok[j] ? t : T - 1;
+  }
+
+  // sum over the G partials of entries [0, n): every workgroup, same order
+  auto gather = [&](int par, int n) {
+    const double* base = xch + (size_t)par * G * NE;
+    for (int e = tid; e < n; e += kSliceThreads) {
+      double s = 0.0;
+      int gg = 0;
+      for (; gg + 8 <= G; gg += 8) {
+        double a[8];
+#pragma unroll
+        for (int x = 0; x < 8; ++x) a[x] = ld_sc1(base + (size_t)(gg + x) * NE + e);
+#pragma unroll
+        for (int x = 0; x < 8; ++x) s += a[x];
+      }
+      for (; gg < G; ++gg) s += ld_sc1(base + (size_t)gg * NE + e);
+      uni[e] = s;
+    }
+  };
+
+  // ---- row norms over all frames (:310, :358-377): partial sums of squares, one hop
+  {
+    double* mine = xch + ((size_t)(hop & 1) * G + g) * NE;
+    const int rows = K * F;
+    for (int r0 = 0; r0 < rows; r0 += 4 * kSliceBins) {
+      double ss[4];
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {  // four rows per lane row in flight
+        const int r = r0 + x * kSliceBins + rowid;
+        const int rc = r < rows ? r : rows - 1;
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < NFR; ++j) {
+          const double w = m[(int64_t)rc * T + tc[j]];
+          acc += tok[j] ? w * w : 0.0;
+        }
+        ss[x] = acc;
+      }
+      row_reduce_scatter<4>(ss);  // lane quad (l >> 2) holds row x = l >> 2
+      const int r = r0 + (l >> 2) * kSliceBins + rowid;
+      if ((l & 3) == 0 && r < rows) st_sc1(mine + r, ss[0]);
+    }
+    for (int f = tid; f < F; f += kSliceThreads) {
+      mapw[f] = pack_identity<K>();
+      lastp[f] = 0;
+    }
+    team_barrier(ctrl, target, G, tid);
+    gather(hop & 1, rows);
+    ++hop;
+    __syncthreads();
+    for (int r = tid; r < rows; r += kSliceThreads) {
+      const double ss = uni[r];
+      if (!isfinite(ss)) nonfinite = 1;
+      // 'cos': unit-norm rows; other metrics: features = mask.copy() (:309-312)
+      inv[r] = cos ? 1.0 / fmax(sqrt(ss), kTiny) : 1.0;
+    }
+    __syncthreads();
+  }
+
+  // features of bin f (composite mapping applied), this lane's frames
+  auto load_bin = [&](int f, bool valid, double (&out)[K][NFR]) {
+    const int fc = valid ? f : 0;
+    const int mw = mapw[fc];
+#pragma unroll
+    for (int a = 0; a < K; ++a) {
+      const int ka = (mw >> (4 * a)) & 15;
+      const double* row = m + ((int64_t)ka * F + fc) * T;
+#pragma unroll
+      for (int j = 0; j < NFR; ++j) out[a][j] = row[tc[j]];
+    }
+#pragma unroll
+    for (int a = 0; a < K; ++a) {
+      const int ka = (mw >> (4 * a)) & 15;
+      const double sc = inv[ka * F + fc];
+#pragma unroll
+      for (int j = 0; j < NFR; ++j) out[a][j] = (valid && tok[j]) ? out[a][j] * sc : 0.0;
+    }
+  };
+
+  for (int seg = 0; seg < P; ++seg) {
+    const int iterations = plan[3 * seg], start = plan[3 * seg + 1], end = plan[3 * seg + 2];
+    const int nb = end - start;
+    if (nb <= 0) continue;
+    const double inv_n = 1.0 / (double)nb;
+    const int npass = (nb + kSliceBins - 1) / kSliceBins;
+    // register-resident part of the window
+    double fv[MAXP][K][NFR];
+#pragma unroll
+    for (int p = 0; p < MAXP; ++p) {
+      const int f = start + p * kSliceBins + rowid;
+      load_bin(f, f < end, fv[p]);
+    }
+    for (int it = 0; it < iterations; ++it) {
+      double* mine = xch + ((size_t)(hop & 1) * G + g) * NE;
+      // ---- time centroid of my frames: sum over the segment's bins (:334-336), local
+      {
+        double cs[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) cs[c] = 0.0;
+#pragma unroll
+        for (int p = 0; p < MAXP; ++p)
+#pragma unroll
+          for (int a = 0; a < K; ++a)
+#pragma unroll
+            for (int j = 0; j < NFR; ++j) cs[a * NFR + j] += fv[p][a][j];
+        for (int p = MAXP; p < npass; ++p) {
+          const int f = start + p * kSliceBins + rowid;
+          double x[K][NFR];
+          load_bin(f, f < end, x);
+#pragma unroll
+          for (int a = 0; a < K; ++a)
+#pragma unroll
+            for (int j = 0; j < NFR; ++j) cs[a * NFR + j] += x[a][j];
+        }
+        rows_reduce_scatter<NC>(cs);  // the wave's four bins; row q keeps values QC*q + i
+#pragma unroll
+        for (int i = 0; i < QC; ++i) {
+          const int c = QC * q + i, a = c / NFR, j = c - a * NFR;
+          uni[((size_t)wave * K + a) * TS + l + 16 * j] = cs[i];
+        }
+      }
+      __syncthreads();
+      for (int c = tid; c < K * TS; c += kSliceThreads) {
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < kSliceWaves; ++w) s += uni[(size_t)w * K * TS + c];
+        cent[c] = s * inv_n;
+      }
+      __syncthreads();
+      if (wave < K) {  // partial squared norm of class `wave`'s centroid (:337-341)
+        double ss = 0.0;
+        for (int t = lane; t < TS; t += kWave) {
+          const double w = cent[wave * TS + t];
+          ss += w * w;
+        }
+        ss = wave_sum(ss);
+        if (lane == 0) st_sc1(mine + wave, ss);
+      }
+      // ---- partial scores of every bin of the segment over my frames
+      auto score_bin = [&](int f, const double (&x)[K][NFR]) {
+        double v[NS];
+#pragma unroll
+        for (int e = 0; e < NS; ++e) v[e] = 0.0;
+#pragma unroll
+        for (int a = 0; a < K; ++a)
+#pragma unroll
+          for (int b = 0; b < K; ++b)
+#pragma unroll
+            for (int j = 0; j < NFR; ++j) {
+              if (metric == PBBSS_PA_EUCLIDEAN) {
+                // padded frames hold zeros on both sides
+                const double d = x[b][j] - cent[a * TS + l + 16 * j];
+                v[a * K + b] = fma(d, d, v[a * K + b]);
+              } else {
+                v[a * K + b] = fma(cent[a * TS + l + 16 * j], x[b][j], v[a * K + b]);
+              }
+            }
+        row_reduce_scatter<NS>(v);
+        const int e0 = QS * ((l >> 2) & 3);
+        if ((l & 3) == 0 && f < end) {
+#pragma unroll
+          for (int r = 0; r < QS; ++r)
+            if (e0 + r < KK) st_sc1(mine + K + (size_t)(f - start) * KK + e0 + r, v[r]);
+        }
+      };
+#pragma unroll
+      for (int p = 0; p < MAXP; ++p) {
+        const int f = start + p * kSliceBins + rowid;
+        if (p < npass) score_bin(f, fv[p]);
+      }
+      for (int p = MAXP; p < npass; ++p) {
+        const int f = start + p * kSliceBins + rowid;
+        double x[K][NFR];
+        load_bin(f, f < end, x);
+        score_bin(f, x);
+      }
+      // ---- the one exchange hop of the iteration
+      team_barrier(ctrl, target, G, tid);
+      gather(hop & 1, K + nb * KK);
+      ++hop;
+      __syncthreads();
+      // ---- every workgroup solves every assignment of the segment (:342-350)
+      int changed = 0;
+      for (int i = tid; i < nb; i += kSliceThreads) {
+        const int f = start + i;
+        double sc[K][K];
+        bool finite = true;
+#pragma unroll
+        for (int a = 0; a < K; ++a) {
+          const double rn = cos ? 1.0 / fmax(sqrt(uni[a]), kTiny) : 1.0;
+#pragma unroll
+          for (int b = 0; b < K; ++b) {
+            double x = uni[K + (size_t)i * KK + a * K + b];
+            x = (metric == PBBSS_PA_EUCLIDEAN) ? -sqrt(x) : x * rn;  // :412-416
+            finite = finite && isfinite(x);
+            sc[a][b] = x;
+          }
+        }
+        if (!finite) nonfinite = 1;  // reference: ValueError('score matrix is infeasible')
+        int perm[K];
+        assign_classes<K>(sc, optimal, perm);
+        int pk = 0, nm = 0;
+        const int mw = mapw[f];
+        bool ident = true;
+#pragma unroll
+        for (int a = 0; a < K; ++a) {
+          ident = ident && (perm[a] == a);
+          pk |= perm[a] << (4 * a);
+          nm |= ((mw >> (4 * perm[a])) & 15) << (4 * a);  // mapping[:, f] = mapping[perm, f]
+        }
+        lastp[f] = ident ? 0 : pk;
+        if (!ident) {
+          mapw[f] = nm;
+          changed = 1;
+        }
+      }
+      const int any = __syncthreads_or(changed);
+      if (!any) break;  // nothing_changed (:352-353)
+      // features[:, f, :] = features[perm, f, :] for the register-resident bins
+#pragma unroll
+      for (int p = 0; p < MAXP; ++p) {
+        const int f = start + p * kSliceBins + rowid;
+        const int lp = (f < end) ? lastp[f] : 0;
+        if (lp != 0) {
+          double y[K][NFR];
+#pragma unroll
+          for (int a = 0; a < K; ++a) {
+            const int pa = (lp >> (4 * a)) & 15;
+#pragma unroll
+            for (int j = 0; j < NFR; ++j) {
+              double x = fv[p][0][j];
+#pragma unroll
+              for (int k = 1; k < K; ++k) x = (pa == k) ? fv[p][k][j] : x;
+              y[a][j] = x;
+            }
+          }
+#pragma unroll
+          for (int a = 0; a < K; ++a)
+#pragma unroll
+            for (int j = 0; j < NFR; ++j) fv[p][a][j] = y[a][j];
+        }
+      }
+    }
+  }
+  // ---- outputs: reverse mapping, aligned features (the exchange area dies here)
+  team_barrier(ctrl, target, G, tid);
+  if (g == 0)
+    for (int i = tid; i < K * F; i += kSliceThreads) {
+      const int a = i / F, f = i - a * F;
+      mapping[i] = (mapw[f] >> (4 * a)) & 15;
+    }
+  for (int f0 = 0; f0 < F; f0 += kSliceBins) {
+    const int f = f0 + rowid;
+    double x[K][NFR];
+    load_bin(f, f < F, x);
+    if (f < F) {
+#pragma unroll
+      for (int a = 0; a < K; ++a)
+#pragma unroll
+        for (int j = 0; j < NFR; ++j)
+          if (tok[j]) feat[((int64_t)a * F + f) * T + t0 + l + 16 * j] = x[a][j];
+    }
+  }
+  const unsigned xerr = __hip_atomic_load(ctrl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if ((nonfinite || xerr) && lane == 0)
+    atomicOr(status + u, (int32_t)(nonfinite ? PBBSS_ST_NONFINITE : 0) |
+                             (int32_t)(xerr ? PBBSS_ST_EIG_NOCONV : 0));
+}
+
 // mask (U,K,F,T) gathered along the class axis: out[u,k,f,:] = mask[u,mapping[u,k,f],f,:]
 __global__ void __launch_bounds__(256)
     apply_mapping_kernel(const double* __restrict__ mask, const int32_t* __restrict__ mapping,
@@ -777,17 +1207,78 @@ int launch_pa_assign(const double* scores, int64_t N, int K, int optimal, int32_
 }
 #undef PBBSS_PA_SWITCH
 
+// frame-slice kernel: launches when the shape admits it (returns false otherwise)
+template <int K, int NF>
+static bool slice_launch_one(const double* mask, int64_t U, int F, int T, const int32_t* plan, int P,
+                             int optimal, int metric, double* feat, int32_t* mapping,
+                             int32_t* status, int G, size_t lds, unsigned* ctrl, hipStream_t s,
+                             int* rc) {
+  auto kfn = dhtv_slice_kernel<K, NF>;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+    *rc = PBBSS_ERR_HIP;
+    return true;
+  }
+  hipLaunchKernelGGL(kfn, dim3((unsigned)(U * G)), dim3(kSliceThreads), lds, s, mask, feat, mapping,
+                     plan, P, F, T, optimal, metric, status, G, ctrl);
+  *rc = hipGetLastError() == hipSuccess ? PBBSS_OK : PBBSS_ERR_HIP;
+  return true;
+}
+
+static bool launch_slice(const double* mask, int64_t U, int K, int F, int T, const int32_t* plan,
+                         int P, int optimal, int metric, double* feat, int32_t* mapping,
+                         int32_t* status, size_t lds_limit, int num_cu, int want_team,
+                         unsigned* ctrl, hipStream_t s, int* rc) {
+  if (K > 5) return false;  // K*K scores per bin live in registers through the butterfly
+  for (int NF = 4; NF <= 8; NF *= 2) {  // frames per lane; 16 * NF frames per workgroup
+    if (K * NF > 24) break;
+    const int G = (T + 16 * NF - 1) / (16 * NF);
+    if (G < 2) break;
+    if (want_team >= 2 && G > want_team && NF < 8 && K * NF * 2 <= 24) continue;
+    if ((int64_t)G * U > num_cu) continue;  // the team must be co-resident
+    const size_t lds = slice_lds_bytes(K, NF, F);
+    if (lds > lds_limit) continue;
+    // exchange area inside the utterance's feature scratch
+    if (2 * (size_t)G * slice_entries(K, F) > (size_t)K * F * T) continue;
+#define PBBSS_SLICE_CASE(KK, NN)                                                               \
+  if (K == KK && NF == NN)                                                                     \
+    return slice_launch_one<KK, NN>(mask, U, F, T, plan, P, optimal, metric, feat, mapping,    \
+                                    status, G, lds, ctrl, s, rc);
+    PBBSS_SLICE_CASE(1, 4) PBBSS_SLICE_CASE(1, 8)
+    PBBSS_SLICE_CASE(2, 4) PBBSS_SLICE_CASE(2, 8)
+    PBBSS_SLICE_CASE(3, 4) PBBSS_SLICE_CASE(3, 8)
+    PBBSS_SLICE_CASE(4, 4)
+    PBBSS_SLICE_CASE(5, 4)
+#undef PBBSS_SLICE_CASE
+  }
+  return false;
+}
+
+// team_size: 0 automatic; 1 one workgroup per utterance; >= 2 frame-slice kernel with at most
+// that many workgroups per utterance (as far as 256 frames per workgroup allow);
+// <= -2 the bin-chunk team kernel with |team_size| workgroups (kept for A/B and for shapes the
+// frame-slice kernel does not take: K > 5, fewer than 128 frames, no room for the exchange area).
 int launch_dhtv(const double* mask, int64_t U, int K, int F, int T, const int32_t* plan, int P,
                 int optimal, int metric, double* feat, int32_t* mapping, int32_t* status,
                 size_t lds_limit,
                 int num_cu, int team_size, void* team_buf, size_t team_bytes, hipStream_t s) {
   if (K < 1 || K > kDhtvMaxK) return PBBSS_ERR_UNSUPPORTED;
   if (metric < PBBSS_PA_COS || metric > PBBSS_PA_EUCLIDEAN) return PBBSS_ERR_INVALID_ARG;
+  const size_t ctrl_bytes = (size_t)U * 4 * sizeof(unsigned);
+  const size_t ctrl_pad = (ctrl_bytes + 255) & ~(size_t)255;
+  unsigned* ctrl = static_cast<unsigned*>(team_buf);
+  if (team_buf && ctrl_pad <= team_bytes && (team_size == 0 || team_size >= 2)) {
+    if (hipMemsetAsync(ctrl, 0, ctrl_bytes, s) != hipSuccess) return PBBSS_ERR_HIP;
+    int rc = PBBSS_OK;
+    if (launch_slice(mask, U, K, F, T, plan, P, optimal, metric, feat, mapping, status, lds_limit,
+                     num_cu, team_size, ctrl, s, &rc))
+      return rc;
+  }
   size_t lds = ((size_t)K * T + kDhtvWaves) * sizeof(double) + 16;
   if (lds > lds_limit) return PBBSS_ERR_LDS_CAPACITY;
   // team size: all U * G workgroups must be co-resident (one 1024-thread workgroup per CU)
   const int ncb = (K * T + kDhtvThreads - 1) / kDhtvThreads;
-  int G = team_size;
+  int G = team_size < 0 ? -team_size : team_size;
   if (G <= 0) {  // default ~ 32 / sqrt(U): measured optimum 16 for 1..4 utterances, 8 for 16, 4 for 64
     G = 16;
     while (G > 2 && (int64_t)G * G * U > 1024) --G;
@@ -795,11 +1286,8 @@ int launch_dhtv(const double* mask, int64_t U, int K, int F, int T, const int32_
   if (G > kDhtvTeamMax) G = kDhtvTeamMax;
   if ((int64_t)G * U > num_cu) G = (int)(num_cu / U);
   G = (G / ncb) * ncb;                                    // whole bin chunks per column block
-  const size_t ctrl_bytes = (size_t)U * 4 * sizeof(unsigned);
-  const size_t ctrl_pad = (ctrl_bytes + 255) & ~(size_t)255;
   const size_t part_bytes = (size_t)U * (G > 0 ? G / ncb : 0) * K * T * sizeof(double);
   const bool team = team_buf && G >= 2 * ncb && ctrl_pad + part_bytes <= team_bytes;
-  unsigned* ctrl = static_cast<unsigned*>(team_buf);
   double* part = reinterpret_cast<double*>(static_cast<char*>(team_buf) + ctrl_pad);
   if (team && hipMemsetAsync(ctrl, 0, ctrl_bytes, s) != hipSuccess) return PBBSS_ERR_HIP;
 #define PBBSS_DHTV_CASE(KK)                                                                     \

@@ -103,11 +103,61 @@ def test_team_kernel_equals_single_workgroup_kernel_and_oracle(K, F, T, stft):
     solver = DHTVPermutationAlignment.from_stft_size(stft)
     want = np.stack([op.dhtv_calculate_mapping(mask[u], solver.alignment_plan) for u in range(2)])
     try:
-        for team in (1, 2, 5, 16, 32, 0):
+        # 1: one workgroup; >= 2: frame-slice kernel; <= -2: bin-chunk team kernel
+        for team in (1, 2, 5, 16, 32, 0, -2, -5, -16, -32):
             engine.set_dhtv_team(team)
             got = solver.calculate_mapping(mask)
             assert np.array_equal(got, want), team
             assert np.array_equal(solver.calculate_mapping(mask[0]), want[0]), team
+    finally:
+        engine.set_dhtv_team(0)
+
+
+@pytest.mark.parametrize('K,F,T,plan', [
+    (3, 257, 200, [[20, 0, 257]]),                      # full-width window: streamed passes
+    (5, 129, 333, [[6, 10, 90], [2, 0, 60], [2, 50, 129]]),  # 25 scores per bin, ragged frames
+    (2, 65, 1000, [[4, 0, 65], [3, 5, 6]]),             # one-bin segment, 16 slices
+    (4, 257, 128, [[20, 70, 170], [2, 0, 110], [2, 150, 257]]),
+])
+def test_frame_slice_kernel_shapes_metrics_and_features(K, F, T, plan):
+    """frame-slice kernel (pbbss_set_dhtv_team >= 2): every metric and both solvers against
+    the oracle, the aligned unit-norm features it leaves in the scratch, several team sizes"""
+    from pb_bss_amd import _lib, engine
+    from oracle import permutation_alignment as op
+    rng = np.random.default_rng(K * 1000 + T)
+    U = 2
+    act = rng.uniform(size=(U, K, 1, T)) ** 4
+    mask = act * rng.uniform(0.3, 1.0, size=(U, K, F, T)) + 0.1 * rng.uniform(size=(U, K, F, T))
+    for u in range(U):
+        for f in range(F):
+            mask[u, :, f] = mask[u, rng.permutation(K), f]
+    md = _lib.to_device(mask)
+    pd = _lib.to_device(np.asarray(plan, np.int32))
+    try:
+        for team in (2, 4, 64):
+            engine.set_dhtv_team(team)
+            for metric in ('cos', 'multiply', 'euclidean'):
+                for optimal in (False, True):
+                    mapping, feat, st = engine.dhtv_calculate_mapping(md, pd, optimal, metric)
+                    assert (_lib.to_host(st) == 0).all()
+                    got, fh = _lib.to_host(mapping), _lib.to_host(feat)
+                    for u in range(U):
+                        want = op.dhtv_calculate_mapping(
+                            mask[u], plan, 'optimal' if optimal else 'greedy', metric)
+                        assert np.array_equal(got[u], want), (team, metric, optimal, u)
+                        al = mask[u][want, range(F)]
+                        if metric == 'cos':
+                            al = al / np.maximum(np.linalg.norm(al, axis=-1, keepdims=True),
+                                                 np.finfo(np.float64).tiny)
+                        assert np.abs(fh[u] - al).max() < 1e-14 * max(1.0, np.abs(al).max()), \
+                            (team, metric)
+        # a non-finite mask entry is reported like the reference's 'score matrix is infeasible'
+        bad = mask.copy()
+        bad[1, 0, plan[0][1], 3] = np.nan
+        engine.set_dhtv_team(4)
+        _, _, st = engine.dhtv_calculate_mapping(_lib.to_device(bad), pd)
+        st = _lib.to_host(st)
+        assert st[0] == 0 and st[1] != 0
     finally:
         engine.set_dhtv_team(0)
 
