@@ -703,9 +703,12 @@ int pbbss_set_timing(pbbss_handle_t h, int enable);
  * finiteness assert) and a sticky flag that pbbss_split_error reads synchronously (0 = no
  * wait of this handle ever timed out). */
 int pbbss_set_split_tail(pbbss_handle_t h, int enable);
-/* pbbss_dhtv_calculate_mapping: workgroups that share ONE utterance (team kernel, used for
- * few utterances where a single workgroup is bound by one CU's L2 latency): 0 = automatic
- * (default), 1 = always one workgroup per utterance, 2..32 = fixed team size. */
+/* pbbss_dhtv_calculate_mapping: workgroups that share ONE utterance (used for few utterances,
+ * where a single workgroup is bound by one CU's L2 latency): 0 = automatic (default: the
+ * frame-slice kernel where it fits -- K <= 5, more than 64 frames, all teams co-resident --
+ * else the bin-chunk team kernel / one workgroup per utterance), 1 = always one workgroup per
+ * utterance, >= 2 = frame-slice kernel with at most that many workgroups per utterance (64 or
+ * 128 frames each), -2..-32 = bin-chunk team kernel of that size (A/B). */
 int pbbss_set_dhtv_team(pbbss_handle_t h, int workgroups_per_utterance);
 int pbbss_split_error(pbbss_handle_t h, int* out_flag);
 /* Development aid: device buffer of 64 uint64 receiving per-phase shader-cycle sums

@@ -557,12 +557,21 @@ __global__ void __launch_bounds__(kDhtvThreads)
 //     partials in the same order and solves every assignment itself -- all workgroups reach
 //     identical permutations, the "anything changed" decision needs no flag;
 //   * a permutation is a register shuffle in the owning wave plus a 4-bit-per-class word in
-//     LDS (the composite mapping); features are written out once, at the end.
+//     LDS (the composite mapping).
 // One exchange hop per plan iteration instead of four.  'cos': the centroid norm is applied
 // to the summed score (score * 1/max(||c||, tiny)) instead of to the centroid before the dot
 // product -- same value up to one rounding.
-// The exchange area is the head of the utterance's feature scratch (dead until the final
-// write): 2 parities x G x (K + F*K*K) doubles.
+// The row scales come from dhtv_rowscale_kernel (whole chip, one wavefront per row) and the
+// aligned features are written by dhtv_features_kernel afterwards: inside this kernel both were
+// 25 + 31 us on G compute units.  The exchange area is the head of the utterance's feature
+// scratch (dead until dhtv_features_kernel): 2 parities x G x (K + F*K*K) doubles.
+//
+// Measured and rejected (profiles/r03_h_dhtv.txt): the exchange without a barrier (every double
+// as two 64-bit words carrying a sequence number, readers polling the data itself) -- the
+// polling traffic costs more than the barrier saves; 8-lane rows x 8 consecutive frames (half
+// the butterflies, but 64-byte per-lane reads and an eight-row centroid reduction); confining a
+// team to one XCD (blockIdx % 8): agent-scope accesses do not get faster, workgroup-scope ones
+// (sc0) are served by the CU's L1 and never see the peers' stores.
 // ---------------------------------------------------------------------------------------
 constexpr int kSliceThreads = 512;  // 8 waves: 256 VGPRs per lane keep the window in registers
 constexpr int kSliceWaves = kSliceThreads / kWave;
@@ -663,11 +672,53 @@ inline size_t slice_lds_bytes(int K, int NFR, int F) {
   return ((size_t)K * TS + (size_t)K * F + uni) * sizeof(double) + 2 * (size_t)F * sizeof(int) + 16;
 }
 
+// 1 / max(||mask[u,k,f,:]||, tiny) per row ('cos'; 1 otherwise) -- :310, :358-377 -- one wavefront
+// per row, the whole chip instead of the G workgroups of the slice kernel
+__global__ void __launch_bounds__(256)
+    dhtv_rowscale_kernel(const double* __restrict__ mask, int64_t rows, int T, int KF, int cos,
+                         double* __restrict__ scale, int32_t* __restrict__ status) {
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (r >= rows) return;
+  const double* src = mask + r * T;
+  double s[4] = {0, 0, 0, 0};
+  int t = lane;
+  for (; t + 3 * kWave < T; t += 4 * kWave) {
+    double a[4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x) a[x] = src[t + x * kWave];
+#pragma unroll
+    for (int x = 0; x < 4; ++x) s[x] = fma(a[x], a[x], s[x]);
+  }
+  for (; t < T; t += kWave) s[0] = fma(src[t], src[t], s[0]);
+  const double ss = wave_sum((s[0] + s[1]) + (s[2] + s[3]));
+  if (lane == 0) {
+    if (!isfinite(ss)) atomicOr(status + r / KF, (int32_t)PBBSS_ST_NONFINITE);
+    scale[r] = cos ? 1.0 / fmax(sqrt(ss), kTiny) : 1.0;
+  }
+}
+
+// aligned features out[u,a,f,:] = mask[u,mapping[u,a,f],f,:] * scale (:348-350 applied at once)
+__global__ void __launch_bounds__(256)
+    dhtv_features_kernel(const double* __restrict__ mask, const int32_t* __restrict__ mapping,
+                         const double* __restrict__ scale, int K, int F, int T,
+                         double* __restrict__ out) {
+  const int64_t row = blockIdx.x;  // (u, a, f)
+  const int64_t u = row / ((int64_t)K * F);
+  const int f = (int)(row % F);
+  const int64_t srow = (u * K + mapping[row]) * F + f;
+  const double sc = scale[srow];
+  const double* src = mask + srow * (int64_t)T;
+  double* dst = out + row * (int64_t)T;
+  for (int t = threadIdx.x; t < T; t += blockDim.x) dst[t] = src[t] * sc;
+}
+
 template <int K, int NFR>
 __global__ void __launch_bounds__(kSliceThreads)
-    dhtv_slice_kernel(const double* __restrict__ mask, double* feat_all, int32_t* mapping_all,
-                      const int32_t* __restrict__ plan, int P, int F, int T, int optimal,
-                      int metric, int32_t* status, int G, unsigned* ctrl_all) {
+    dhtv_slice_kernel(const double* __restrict__ mask, const double* __restrict__ scale_all,
+                      double* feat_all, int32_t* mapping_all, const int32_t* __restrict__ plan,
+                      int P, int F, int T, int optimal, int metric, int32_t* status, int G,
+                      unsigned* ctrl_all) {
   using C = SliceCfg<K, NFR>;
   constexpr int KK = C::KK, NS = C::NS, QS = C::QS, NC = C::NC, QC = C::QC, MAXP = C::MAXP,
                 TS = C::TS;
@@ -723,41 +774,13 @@ __global__ void __launch_bounds__(kSliceThreads)
     }
   };
 
-  // ---- row norms over all frames (:310, :358-377): partial sums of squares, one hop
+  // row scales (1 / max(||row||, tiny) for 'cos') from dhtv_rowscale_kernel
   {
-    double* mine = xch + ((size_t)(hop & 1) * G + g) * NE;
-    const int rows = K * F;
-    for (int r0 = 0; r0 < rows; r0 += 4 * kSliceBins) {
-      double ss[4];
-#pragma unroll
-      for (int x = 0; x < 4; ++x) {  // four rows per lane row in flight
-        const int r = r0 + x * kSliceBins + rowid;
-        const int rc = r < rows ? r : rows - 1;
-        double acc = 0.0;
-#pragma unroll
-        for (int j = 0; j < NFR; ++j) {
-          const double w = m[(int64_t)rc * T + tc[j]];
-          acc += tok[j] ? w * w : 0.0;
-        }
-        ss[x] = acc;
-      }
-      row_reduce_scatter<4>(ss);  // lane quad (l >> 2) holds row x = l >> 2
-      const int r = r0 + (l >> 2) * kSliceBins + rowid;
-      if ((l & 3) == 0 && r < rows) st_sc1(mine + r, ss[0]);
-    }
+    const double* scale = scale_all + u * (int64_t)K * F;
+    for (int r = tid; r < K * F; r += kSliceThreads) inv[r] = scale[r];
     for (int f = tid; f < F; f += kSliceThreads) {
       mapw[f] = pack_identity<K>();
       lastp[f] = 0;
-    }
-    team_barrier(ctrl, target, G, tid);
-    gather(hop & 1, rows);
-    ++hop;
-    __syncthreads();
-    for (int r = tid; r < rows; r += kSliceThreads) {
-      const double ss = uni[r];
-      if (!isfinite(ss)) nonfinite = 1;
-      // 'cos': unit-norm rows; other metrics: features = mask.copy() (:309-312)
-      inv[r] = cos ? 1.0 / fmax(sqrt(ss), kTiny) : 1.0;
     }
     __syncthreads();
   }
@@ -947,25 +970,13 @@ __global__ void __launch_bounds__(kSliceThreads)
       }
     }
   }
-  // ---- outputs: reverse mapping, aligned features (the exchange area dies here)
-  team_barrier(ctrl, target, G, tid);
+  // ---- output: the reverse mapping (dhtv_features_kernel then writes the aligned features over
+  // the exchange area)
   if (g == 0)
     for (int i = tid; i < K * F; i += kSliceThreads) {
       const int a = i / F, f = i - a * F;
       mapping[i] = (mapw[f] >> (4 * a)) & 15;
     }
-  for (int f0 = 0; f0 < F; f0 += kSliceBins) {
-    const int f = f0 + rowid;
-    double x[K][NFR];
-    load_bin(f, f < F, x);
-    if (f < F) {
-#pragma unroll
-      for (int a = 0; a < K; ++a)
-#pragma unroll
-        for (int j = 0; j < NFR; ++j)
-          if (tok[j]) feat[((int64_t)a * F + f) * T + t0 + l + 16 * j] = x[a][j];
-    }
-  }
   const unsigned xerr = __hip_atomic_load(ctrl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if ((nonfinite || xerr) && lane == 0)
     atomicOr(status + u, (int32_t)(nonfinite ? PBBSS_ST_NONFINITE : 0) |
@@ -1211,16 +1222,22 @@ int launch_pa_assign(const double* scores, int64_t N, int K, int optimal, int32_
 template <int K, int NF>
 static bool slice_launch_one(const double* mask, int64_t U, int F, int T, const int32_t* plan, int P,
                              int optimal, int metric, double* feat, int32_t* mapping,
-                             int32_t* status, int G, size_t lds, unsigned* ctrl, hipStream_t s,
-                             int* rc) {
+                             int32_t* status, int G, size_t lds, unsigned* ctrl, double* scale,
+                             hipStream_t s, int* rc) {
   auto kfn = dhtv_slice_kernel<K, NF>;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
     *rc = PBBSS_ERR_HIP;
     return true;
   }
-  hipLaunchKernelGGL(kfn, dim3((unsigned)(U * G)), dim3(kSliceThreads), lds, s, mask, feat, mapping,
-                     plan, P, F, T, optimal, metric, status, G, ctrl);
+  // row scales on the whole chip -> the plan on G workgroups per utterance -> aligned features
+  const int64_t rows = U * K * F;
+  hipLaunchKernelGGL(dhtv_rowscale_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, mask,
+                     rows, T, K * F, metric == PBBSS_PA_COS ? 1 : 0, scale, status);
+  hipLaunchKernelGGL(kfn, dim3((unsigned)(U * G)), dim3(kSliceThreads), lds, s, mask, scale, feat,
+                     mapping, plan, P, F, T, optimal, metric, status, G, ctrl);
+  hipLaunchKernelGGL(dhtv_features_kernel, dim3((unsigned)rows), dim3(256), 0, s, mask, mapping,
+                     scale, K, F, T, feat);
   *rc = hipGetLastError() == hipSuccess ? PBBSS_OK : PBBSS_ERR_HIP;
   return true;
 }
@@ -1228,8 +1245,9 @@ static bool slice_launch_one(const double* mask, int64_t U, int F, int T, const 
 static bool launch_slice(const double* mask, int64_t U, int K, int F, int T, const int32_t* plan,
                          int P, int optimal, int metric, double* feat, int32_t* mapping,
                          int32_t* status, size_t lds_limit, int num_cu, int want_team,
-                         unsigned* ctrl, hipStream_t s, int* rc) {
+                         unsigned* ctrl, double* scale, hipStream_t s, int* rc) {
   if (K > 5) return false;  // K*K scores per bin live in registers through the butterfly
+  if (U * K * F > 2147483647LL) return false;
   for (int NF = 4; NF <= 8; NF *= 2) {  // frames per lane; 16 * NF frames per workgroup
     if (K * NF > 24) break;
     const int G = (T + 16 * NF - 1) / (16 * NF);
@@ -1243,7 +1261,7 @@ static bool launch_slice(const double* mask, int64_t U, int K, int F, int T, con
 #define PBBSS_SLICE_CASE(KK, NN)                                                               \
   if (K == KK && NF == NN)                                                                     \
     return slice_launch_one<KK, NN>(mask, U, F, T, plan, P, optimal, metric, feat, mapping,    \
-                                    status, G, lds, ctrl, s, rc);
+                                    status, G, lds, ctrl, scale, s, rc);
     PBBSS_SLICE_CASE(1, 4) PBBSS_SLICE_CASE(1, 8)
     PBBSS_SLICE_CASE(2, 4) PBBSS_SLICE_CASE(2, 8)
     PBBSS_SLICE_CASE(3, 4) PBBSS_SLICE_CASE(3, 8)
@@ -1267,11 +1285,14 @@ int launch_dhtv(const double* mask, int64_t U, int K, int F, int T, const int32_
   const size_t ctrl_bytes = (size_t)U * 4 * sizeof(unsigned);
   const size_t ctrl_pad = (ctrl_bytes + 255) & ~(size_t)255;
   unsigned* ctrl = static_cast<unsigned*>(team_buf);
-  if (team_buf && ctrl_pad <= team_bytes && (team_size == 0 || team_size >= 2)) {
+  // team buffer: [control words][row scales of the frame-slice path]
+  const size_t scale_bytes = (size_t)U * K * F * sizeof(double);
+  if (team_buf && ctrl_pad + scale_bytes <= team_bytes && (team_size == 0 || team_size >= 2)) {
     if (hipMemsetAsync(ctrl, 0, ctrl_bytes, s) != hipSuccess) return PBBSS_ERR_HIP;
     int rc = PBBSS_OK;
     if (launch_slice(mask, U, K, F, T, plan, P, optimal, metric, feat, mapping, status, lds_limit,
-                     num_cu, team_size, ctrl, s, &rc))
+                     num_cu, team_size, ctrl,
+                     reinterpret_cast<double*>(static_cast<char*>(team_buf) + ctrl_pad), s, &rc))
       return rc;
   }
   size_t lds = ((size_t)K * T + kDhtvWaves) * sizeof(double) + 16;

@@ -513,7 +513,8 @@ def set_split_tail(enable, device_index=None):
 
 
 def set_dhtv_team(workgroups_per_utterance, device_index=None):
-    """pbbss_set_dhtv_team: 0 automatic, 1 one workgroup per utterance, 2..32 fixed team."""
+    """pbbss_set_dhtv_team: 0 automatic, 1 one workgroup per utterance, >= 2 frame-slice kernel,
+    -2..-32 bin-chunk team kernel of that size."""
     _lib.check(_lib.load().pbbss_set_dhtv_team(_lib.handle(device_index),
                                                int(workgroups_per_utterance)), 'set_dhtv_team')
 

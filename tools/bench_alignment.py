@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Timing of the device DHTV permutation alignment vs the NumPy oracle
-(K=3, F=513, T=500: the masks of BASELINE config 2)."""
+(K=3, F=513, T=500: the masks of BASELINE config 2; PBBSS_BENCH_T=1000: config 1)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -9,7 +9,8 @@ from pb_bss_amd import _lib, engine
 from pb_bss_amd.permutation_alignment import DHTVPermutationAlignment
 
 rng = np.random.default_rng(0)
-K, F, T = 3, 513, 500
+K, F = 3, 513
+T = int(os.environ.get('PBBSS_BENCH_T', '500'))
 act = rng.uniform(size=(K, T)) ** 4
 mask = act[:, None, :] * rng.uniform(0.5, 1.0, size=(K, F, T)) + 0.05 * rng.uniform(size=(K, F, T))
 mask /= mask.sum(0, keepdims=True)
