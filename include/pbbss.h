@@ -398,7 +398,9 @@ int pbbss_apply_mapping(pbbss_handle_t h, const double* mask,
 /* max_concentration (the reference's fill_value).  saliency f64 (B,T) or NULL.   */
 /* Outputs: mode c128 (B,K,D), concentration f64 (B,K), weight f64 (B,K),        */
 /* status int32 (B,K); optional affiliation / log_pdf f64 (B,K,T) from the final  */
-/* E-step (final_predict).  2 <= D <= 8, K <= 4.                                  */
+/* E-step (final_predict).  2 <= D <= 8 and K <= 4: one fused persistent kernel;   */
+/* up to D = 32 sensors / K = 16 classes: generic-size kernels, one launch group   */
+/* per iteration (csrc/generic_watson.hip).                                       */
 /* ------------------------------------------------------------------------- */
 typedef struct pbbss_cwmm_opts {
   int32_t iterations;

@@ -975,6 +975,72 @@ PBBSS_API int pbbss_cwmm_fit(pbbss_handle_t h, const void* y, int64_t B, int T, 
   if (o->iterations > 0 && (!out_mode || !out_concentration || !out_weight))
     return PBBSS_ERR_INVALID_ARG;
   if (o->weight_mode < 0 || o->weight_mode > 1) return PBBSS_ERR_INVALID_ARG;
+  if (D > 8 || K > 4) {
+    // generic-size path (generic_watson.hip): per iteration class log-pdfs -> softmax with the
+    // weights -> masked covariance of the unit-norm frames + weights -> eigh -> principal pair,
+    // concentration, ln c; enqueued back to back, the model lives in the work area
+    if (!pbbss::gen_supported(D, K) || B > 65535) return PBBSS_ERR_UNSUPPORTED;
+    hipStream_t s = as_stream(stream);
+    const size_t nkt = (size_t)B * K * T, nmat = (size_t)B * K;
+    const size_t need = 2 * WorkCarver::pad(nkt * 8) + 2 * WorkCarver::pad(nmat * D * D * 16) +
+                        WorkCarver::pad(nmat * D * 8) + WorkCarver::pad(nmat * D * 16) +
+                        3 * WorkCarver::pad(nmat * 8) + WorkCarver::pad(nmat * 4);
+    void* wmem = handle_work(h, need);
+    if (!wmem) return PBBSS_ERR_HIP;
+    WorkCarver wc(wmem);
+    double* aff = wc.take<double>(nkt);
+    double* lp = wc.take<double>(nkt);
+    double* cov = wc.take<double>(nmat * D * D * 2);
+    double* evec = wc.take<double>(nmat * D * D * 2);
+    double* eval = wc.take<double>(nmat * D);
+    double* mode_w = wc.take<double>(nmat * D * 2);
+    double* conc_w = wc.take<double>(nmat);
+    double* weight_w = wc.take<double>(nmat);
+    double* lognorm = wc.take<double>(nmat);
+    int32_t* status_w = wc.take<int32_t>(nmat);
+    double* mode = out_mode ? static_cast<double*>(out_mode) : mode_w;
+    double* conc = out_concentration ? out_concentration : conc_w;
+    double* weight = out_weight ? out_weight : weight_w;
+    int32_t* status = out_status ? out_status : status_w;
+    const pbbss::GenWatsonSpline sp{spline_t, spline_c, o->n_coef, o->ev_min, o->ev_max,
+                                    o->max_concentration};
+    TimedRegion tr(h, s);
+    int rc;
+    if (hipMemsetAsync(status, 0, nmat * sizeof(int32_t), s) != hipSuccess) return PBBSS_ERR_HIP;
+    if (has_model) {
+      if ((rc = copy_d2d(mode, in_mode, nmat * D * 16, s)) != PBBSS_OK) return rc;
+      if ((rc = copy_d2d(conc, in_concentration, nmat * 8, s)) != PBBSS_OK) return rc;
+      if ((rc = copy_d2d(weight, in_weight, nmat * 8, s)) != PBBSS_OK) return rc;
+      if ((rc = pbbss::launch_gen_watson_lognorm(conc, (int64_t)nmat, D, lognorm, s)) != PBBSS_OK)
+        return rc;
+    }
+    auto e_step = [&](double* out_lp, double* out_aff) {
+      int r = pbbss::launch_gen_watson_logpdf(y, o->y_is_c128, B, T, D, K, mode, conc, lognorm,
+                                              out_lp, s);
+      if (r != PBBSS_OK || !out_aff) return r;
+      return pbbss::launch_log_pdf_to_affiliation(out_lp, B, K, T, weight, K, 1, 0, nullptr, 0.0,
+                                                  out_aff, s);
+    };
+    for (int it = 0; it < o->iterations; ++it) {
+      const double* g_src = gamma0;
+      if (it > 0 || has_model) {
+        if ((rc = e_step(lp, aff)) != PBBSS_OK) return rc;
+        g_src = aff;
+      }
+      rc = pbbss::launch_gen_cov(y, o->y_is_c128, PBBSS_LAYOUT_TD, B, T, D, K, g_src,
+                                 (int64_t)K * T, nullptr, saliency, /*mode=*/3, o->weight_mode, cov,
+                                 weight, nullptr, h->cfg.lds_limit, s);
+      if (rc != PBBSS_OK) return rc;
+      rc = pbbss::launch_gen_heev(cov, (int64_t)nmat, D, -1, 0.0, eval, evec, status,
+                                  h->cfg.lds_limit, s);
+      if (rc != PBBSS_OK) return rc;
+      rc = pbbss::launch_gen_watson_finish(eval, evec, (int64_t)nmat, D, sp, mode, conc, lognorm, s);
+      if (rc != PBBSS_OK) return rc;
+    }
+    if (o->final_predict && (out_affiliation || out_log_pdf))
+      return e_step(out_log_pdf ? out_log_pdf : lp, out_affiliation);
+    return PBBSS_OK;
+  }
   if (D < 2 || D > 8 || K < 1 || K > 4) return PBBSS_ERR_UNSUPPORTED;
   pbbss::WatsonArgs wa{};
   wa.em.y = y;
@@ -1369,7 +1435,11 @@ PBBSS_API int pbbss_joint_fit(pbbss_handle_t h, const void* observation, const v
                               int32_t* out_status, double* out_affiliation, void* stream) {
   DeviceGuard device_guard(h);
   if (!h || !observation || !embedding || !o || F <= 0 || T <= 0) return PBBSS_ERR_INVALID_ARG;
-  if (D < 2 || D > 8 || K < 1 || K > 6) return PBBSS_ERR_UNSUPPORTED;
+  // 9 <= D <= 32: the spatial half runs on the generic-size kernels (generic.hip), one E-step
+  // and one M-step launch group per iteration around the same spectral kernels
+  const bool gen = D > 8;
+  if (D < 2 || K < 1 || K > 6 || (gen && !pbbss::gen_supported(D, K))) return PBBSS_ERR_UNSUPPORTED;
+  if (gen && (o->inline_pa || F > 65535)) return PBBSS_ERR_UNSUPPORTED;
   const int64_t N = F * (int64_t)T;
   if (!embed_shape_ok(1, N, E, K)) return PBBSS_ERR_UNSUPPORTED;
   if (o->iterations < 0 || o->weight_mode < 0 || o->weight_mode > 4) return PBBSS_ERR_INVALID_ARG;
@@ -1414,7 +1484,14 @@ PBBSS_API int pbbss_joint_fit(pbbss_handle_t h, const void* observation, const v
   const size_t nstate = (size_t)F * K * (D * D + 2);
   const size_t ngp = g_full ? pbbss::gauss_full_partial_doubles(1, N, E, K) : 0;
   const size_t nconst = g_diag ? pbbss::diag_consts_doubles(K, E) : 0;
-  const size_t need = WorkCarver::pad((size_t)E * N * esz) + 2 * WorkCarver::pad(nfkt * 8) +
+  const size_t nmat = (size_t)F * K;
+  const size_t ninv = gen ? pbbss::gen_state_doubles((int64_t)nmat, D) : 0;
+  const size_t nyt = gen ? (size_t)F * T * D * (o->obs_is_c128 ? 16 : 8) : 0;
+  const size_t need_gen =
+      gen ? WorkCarver::pad(nfkt * 8) + WorkCarver::pad(nmat * D * D * 16) + WorkCarver::pad(ninv * 8) +
+                2 * WorkCarver::pad(nmat * 8) + WorkCarver::pad((size_t)F * 4) + WorkCarver::pad(nyt)
+          : 0;
+  const size_t need = need_gen + WorkCarver::pad((size_t)E * N * esz) + 2 * WorkCarver::pad(nfkt * 8) +
                       WorkCarver::pad(np * 8) + 2 * WorkCarver::pad((size_t)K * 8) +
                       WorkCarver::pad((size_t)F * K * 8) + WorkCarver::pad(nstate * 8) +
                       (g_full ? 2 * WorkCarver::pad(nfkt * 8) + WorkCarver::pad(ngp * 8) +
@@ -1438,6 +1515,15 @@ PBBSS_API int pbbss_joint_fit(pbbss_handle_t h, const void* observation, const v
   double* mq = g_full ? wc.take<double>((size_t)K * E * E) : nullptr;
   double* dconst = g_diag ? wc.take<double>(nconst) : nullptr;
   int32_t* gst = reinterpret_cast<int32_t*>(wc.take<char>(64));  // status of the spectral half
+  // generic-size spatial half: M-step weights, covariances, inverse state, class sums, zero-frame
+  // flags, frame-contiguous copy of the observation
+  double* g_mw = gen ? wc.take<double>(nfkt) : nullptr;
+  double* g_cov = gen ? wc.take<double>(nmat * D * D * 2) : nullptr;
+  double* g_inv = gen ? wc.take<double>(ninv) : nullptr;
+  double* g_logdet = gen ? wc.take<double>(nmat) : nullptr;
+  double* g_csum = gen ? wc.take<double>(nmat) : nullptr;
+  int32_t* g_zero = gen ? wc.take<int32_t>((size_t)F) : nullptr;
+  char* g_yt = gen ? wc.take<char>(nyt) : nullptr;
   if (hipMemsetAsync(gst, 0, 64, as_stream(stream)) != hipSuccess) return PBBSS_ERR_HIP;
   TimedRegion tr(h, s);
   int rc = pbbss::launch_embed_prepare(embedding, o->embedding_is_f64, 1, N, E, 0, yd, nullptr, s);
@@ -1473,8 +1559,39 @@ PBBSS_API int pbbss_joint_fit(pbbss_handle_t h, const void* observation, const v
     return pbbss::launch_embed_estep(o->kind, yd, o->embedding_is_f64, 1, N, E, K, out_mean, prec,
                                      offset, nullptr, o->spectral_weight, T, slp, nullptr, s);
   };
+  // generic-size spatial half: the posteriors of the current model (E-step of gcacgmm.py:66-117
+  // with the spectral log-pdf as the extra exponent), then the cACG M-step from them
+  const pbbss::GenInverseState g_state{g_inv, g_logdet, nullptr};
+  auto gen_m_step = [&](const double* gam, bool fk_weights) -> int {
+    int r = pbbss::launch_gen_mstep_cov(observation, o->obs_is_c128, F, T, D, K, g_mw, gam, saliency,
+                                        PBBSS_WEIGHT_PER_CLASS_MEAN, g_csum, g_cov,
+                                        fk_weights ? out_weight : tmp, s);
+    if (r != PBBSS_OK) return r;
+    return pbbss::launch_gen_heev(g_cov, (int64_t)nmat, D, o->covariance_norm, o->eigenvalue_floor,
+                                  out_eigval, static_cast<double*>(out_eigvec), out_status,
+                                  h->cfg.lds_limit, s);
+  };
+  auto gen_e_step = [&](double* aff_out, double eps, bool for_m_step) -> int {
+    return pbbss::launch_gen_estep(g_yt, o->obs_is_c128, PBBSS_LAYOUT_DT, F, T, D, K,
+                                   static_cast<const double*>(out_eigvec), out_eigval, out_weight,
+                                   wb, wk, wt, nullptr, eps, aff_out, nullptr, nullptr, s, g_state,
+                                   saliency, for_m_step ? g_mw : nullptr,
+                                   for_m_step ? g_zero : nullptr, /*raw_dt=*/1, slp,
+                                   o->spatial_weight);
+  };
+  if (gen) {
+    if ((rc = pbbss::launch_gen_transpose(observation, o->obs_is_c128, F, T, D, g_yt, s)) != PBBSS_OK)
+      return rc;
+    if (hipMemsetAsync(out_status, 0, nmat * sizeof(int32_t), s) != hipSuccess) return PBBSS_ERR_HIP;
+    if (hipMemsetAsync(g_zero, 0, (size_t)F * sizeof(int32_t), s) != hipSuccess) return PBBSS_ERR_HIP;
+  }
   auto joint = [&](int iterations, double* aff_out, int inline_pa, const double* state_in,
                    double* state_out, int emit_model) -> int {
+    if (gen) {
+      int r = gen_e_step(aff_out, iterations > 0 ? o->affiliation_eps : 0.0, iterations > 0);
+      if (r != PBBSS_OK || iterations == 0) return r;
+      return gen_m_step(aff_out, o->weight_mode == PBBSS_JOINT_WEIGHT_FK);
+    }
     pbbss::EmArgs a{};
     a.y = observation;
     a.B = F;
@@ -1504,7 +1621,12 @@ PBBSS_API int pbbss_joint_fit(pbbss_handle_t h, const void* observation, const v
   };
   for (int it = 0; it < o->iterations; ++it) {
     const double* src = gamma0;
-    if (it == 0) {
+    if (it == 0 && gen) {
+      rc = pbbss::launch_gen_init_weights(g_yt, o->obs_is_c128, PBBSS_LAYOUT_DT, F, T, D, K, gamma0,
+                                          saliency, g_mw, g_zero, s);
+      if (rc != PBBSS_OK) return rc;
+      if ((rc = gen_m_step(gamma0, false)) != PBBSS_OK) return rc;
+    } else if (it == 0) {
       // first M-step from the initial affiliations, quadratic form = 1 (gcacgmm.py:194-196)
       pbbss::EmArgs a{};
       a.y = observation;

@@ -676,7 +676,11 @@ inline size_t slice_lds_bytes(int K, int NFR, int F) {
 // per row, the whole chip instead of the G workgroups of the slice kernel
 __global__ void __launch_bounds__(256)
     dhtv_rowscale_kernel(const double* __restrict__ mask, int64_t rows, int T, int KF, int cos,
-                         double* __restrict__ scale, int32_t* __restrict__ status) {
+                         double* __restrict__ scale, int32_t* __restrict__ status,
+                         unsigned* __restrict__ ctrl, int nctrl) {
+  // the slice kernel's control words start at zero (saves a memset launch in front)
+  if (blockIdx.x == 0)
+    for (int i = threadIdx.x; i < nctrl; i += blockDim.x) ctrl[i] = 0u;
   const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (r >= rows) return;
@@ -1233,7 +1237,7 @@ static bool slice_launch_one(const double* mask, int64_t U, int F, int T, const 
   // row scales on the whole chip -> the plan on G workgroups per utterance -> aligned features
   const int64_t rows = U * K * F;
   hipLaunchKernelGGL(dhtv_rowscale_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, mask,
-                     rows, T, K * F, metric == PBBSS_PA_COS ? 1 : 0, scale, status);
+                     rows, T, K * F, metric == PBBSS_PA_COS ? 1 : 0, scale, status, ctrl, (int)(4 * U));
   hipLaunchKernelGGL(kfn, dim3((unsigned)(U * G)), dim3(kSliceThreads), lds, s, mask, scale, feat,
                      mapping, plan, P, F, T, optimal, metric, status, G, ctrl);
   hipLaunchKernelGGL(dhtv_features_kernel, dim3((unsigned)rows), dim3(256), 0, s, mask, mapping,
@@ -1288,7 +1292,6 @@ int launch_dhtv(const double* mask, int64_t U, int K, int F, int T, const int32_
   // team buffer: [control words][row scales of the frame-slice path]
   const size_t scale_bytes = (size_t)U * K * F * sizeof(double);
   if (team_buf && ctrl_pad + scale_bytes <= team_bytes && (team_size == 0 || team_size >= 2)) {
-    if (hipMemsetAsync(ctrl, 0, ctrl_bytes, s) != hipSuccess) return PBBSS_ERR_HIP;
     int rc = PBBSS_OK;
     if (launch_slice(mask, U, K, F, T, plan, P, optimal, metric, feat, mapping, status, lds_limit,
                      num_cu, team_size, ctrl,

@@ -77,6 +77,10 @@ struct GenEstep {
   double* out_mweight;     // (B,K,T) or null
   int32_t* out_zero;       // (B) or null: set to 1 where a frame is all-zero
   int raw;                 // 1: the observation is raw (unit-normalised here) whatever its layout
+  // joint spatial + spectral models (gcacgmm.py:66-117): the posterior's exponent is
+  // spatial_scale * log-pdf + extra[b,k,t]; out_logpdf / out_q stay the spatial quantities
+  const double* extra;     // (B,K,T) or null
+  double spatial_scale;
 };
 
 // static group stream of the E-step operands: row i (diagonal .. DP - 1) has ceil((DP - i) / 8)
@@ -201,9 +205,10 @@ __global__ void __launch_bounds__(kGenThreads) gen_estep_kernel(GenEstep a) {
     const double q = fmax(fabs(qs[k * kGenThreads + tid] * inv), kTiny);  // cacg.py:185-199
     const double lp = -(double)D * log(q) - a.logdet[b * K + k];          // cacg.py:151
     qs[k * kGenThreads + tid] = q;
-    ls[k * kGenThreads + tid] = lp;
-    mx = fmax(mx, lp);
     if (a.out_logpdf) a.out_logpdf[((size_t)b * K + k) * T + t] = lp;
+    const double le = a.extra ? fma(a.spatial_scale, lp, a.extra[((size_t)b * K + k) * T + t]) : lp;
+    ls[k * kGenThreads + tid] = le;
+    mx = fmax(mx, le);
     if (a.out_q) a.out_q[((size_t)b * K + k) * T + t] = q;
   }
   if (!a.out_aff) return;
@@ -279,7 +284,8 @@ struct GenCov {
   int64_t gamma_bstride;
   const double* q;         // (B,K,T) or null (ones)
   const double* saliency;  // (B,T) or null
-  int mode;                // 0 M-step (cacg.py:310-327), 1 PSD normalised mask, 2 PSD plain sums
+  int mode;                // 0 M-step (cacg.py:310-327), 1 PSD normalised mask, 2 PSD plain sums,
+                           // 3 Watson M-step (unit-norm frames, mask gamma sal, / sum of the mask)
   int weight_mode;
   double* out_cov;         // c128 (B,K,D,D)
   double* out_weight;      // (B,K) or null
@@ -363,7 +369,7 @@ __global__ void __launch_bounds__(kGenThreads) gen_cov_kernel(GenCov a) {
         const double re = ytile[(tid * LDY + d) * 2], im = ytile[(tid * LDY + d) * 2 + 1];
         n2 += re * re + im * im;
       }
-      const double inv = (a.layout == PBBSS_LAYOUT_TD && a.mode == 0)
+      const double inv = (a.layout == PBBSS_LAYOUT_TD && (a.mode == 0 || a.mode == 3))
                              ? ((n2 > 0.0) ? 1.0 / n2 : 0.0) : 1.0;
       if (t < T && !(n2 > 0.0)) zero_seen = 1;  // benign race: every writer stores 1
       for (int k = 0; k < K; ++k) {
@@ -375,6 +381,8 @@ __global__ void __launch_bounds__(kGenThreads) gen_cov_kernel(GenCov a) {
           if (a.mode == 0) {
             const double qq = a.q ? a.q[((size_t)b * K + k) * T + t] : 1.0;
             w = gs / fmax(qq, 10.0 * kTiny) * inv;  // cacg.py:310, :322
+          } else if (a.mode == 3) {
+            w = gs * inv;  // complex_watson.py:279-281, :306-313: unit-norm frames
           } else {
             w = gs;
           }
@@ -446,6 +454,7 @@ __global__ void __launch_bounds__(kGenThreads) gen_cov_kernel(GenCov a) {
       double sc;
       if (a.mode == 0) sc = (double)D / fmax(csum[k], kTiny);        // cacg.py:316, :327
       else if (a.mode == 1) sc = 1.0 / fmax(csum[k], 1e-10);         // beamformer.py:123
+      else if (a.mode == 3) sc = 1.0 / fmax(csum[k], kTiny);         // complex_watson.py:313
       else sc = a.gamma ? 1.0 : 1.0 / (double)T;                     // :114-117
       for (int o = tid; o < ntiles * kTe; o += kGenThreads) {
         const int tile = o / kTe, e = o - tile * kTe;
@@ -1128,7 +1137,7 @@ int launch_gen_estep(const void* y, int y_is_c128, int layout, int64_t B, int T,
                      int64_t wk, int64_t wt, const uint8_t* activity, double eps, double* out_aff,
                      double* out_q, double* out_logpdf, hipStream_t s,
                      const GenInverseState& state, const double* saliency, double* out_mweight,
-                     int32_t* out_zero, int raw_dt) {
+                     int32_t* out_zero, int raw_dt, const double* extra, double spatial_scale) {
   if (!gen_supported(D, K)) return PBBSS_ERR_UNSUPPORTED;
   if (!state.inv || !state.logdet) return PBBSS_ERR_INVALID_ARG;
   const int DP = gen_state_ld(D);
@@ -1136,7 +1145,7 @@ int launch_gen_estep(const void* y, int y_is_c128, int layout, int64_t B, int T,
   hipLaunchKernelGGL(gen_eig_to_inv_kernel, dim3((unsigned)(B * K)), dim3(kGenThreads), 0, s, c);
   GenEstep a{y, layout, B, T, D, K, state.inv, state.logdet, weight, wb, wk, wt, activity, eps,
              out_aff, out_q, out_logpdf, saliency, out_mweight, out_zero,
-             (layout == PBBSS_LAYOUT_TD || raw_dt) ? 1 : 0};
+             (layout == PBBSS_LAYOUT_TD || raw_dt) ? 1 : 0, extra, spatial_scale};
   const dim3 grid((unsigned)B, (unsigned)((T + kGenThreads - 1) / kGenThreads));
   if (grid.y > 65535u) return PBBSS_ERR_UNSUPPORTED;
   const size_t lds = (size_t)2 * K * kGenThreads * sizeof(double);  // softmax slots [2][K][thread]

@@ -31,7 +31,10 @@ int launch_gen_estep(const void* y, int y_is_c128, int layout, int64_t B, int T,
                      double* out_q, double* out_logpdf, hipStream_t s,
                      const GenInverseState& state, const double* saliency = nullptr,
                      double* out_mweight = nullptr, int32_t* out_zero = nullptr,
-                     int raw_dt = 0);  // raw_dt: layout DT holds RAW values (transposed copy)
+                     int raw_dt = 0,  // raw_dt: layout DT holds RAW values (transposed copy)
+                     // joint spatial + spectral models: posterior exponent = spatial_scale *
+                     // log-pdf + extra[b,k,t] (gcacgmm.py:66-117)
+                     const double* extra = nullptr, double spatial_scale = 1.0);
 
 // (B, T, D) -> (B, D, T) copy of the raw observation for the E-steps of the EM loop
 int launch_gen_transpose(const void* y, int y_is_c128, int64_t B, int T, int D, void* out,
@@ -53,8 +56,10 @@ int launch_gen_mstep_cov(const void* y, int y_is_c128, int64_t B, int T, int D, 
 
 // a6 / a10: weighted covariances.  mode 0: M-step (D * sum_t gamma sal / q y y^H / sum gamma sal,
 // observation unit-normalised when layout is TD); mode 1: PSD with the mask normalised by
-// max(sum_t mask, 1e-10); mode 2: PSD plain sums (/T without a mask).  out_weight: mixture
-// weights of the M-step (a5), out_sum: class sums.
+// max(sum_t mask, 1e-10); mode 2: PSD plain sums (/T without a mask); mode 3: Watson M-step
+// (complex_watson.py:300-315 with the mask gamma sal of cwmm.py:217-240: unit-norm frames when
+// layout is TD, divided by the class sum).  out_weight: mixture weights of the M-step (a5),
+// out_sum: class sums.
 int launch_gen_cov(const void* y, int y_is_c128, int layout, int64_t B, int T, int D, int K,
                    const double* gamma, int64_t gamma_bstride, const double* q,
                    const double* saliency, int mode, int weight_mode, double* out_cov,
@@ -79,5 +84,25 @@ int launch_gen_heev(const double* a, int64_t N, int D, int covariance_norm, doub
 int launch_gen_inverse(const double* a, int64_t N, int D, double eig_floor, double* out_inv,
                        double* out_logdet, int32_t* out_ok, hipStream_t s,
                        const int32_t* veto = nullptr, int K = 1);
+
+// ---- complex-Watson mixture at generic sizes (generic_watson.hip; cwmm.py, complex_watson.py)
+struct GenWatsonSpline {
+  const double* t;  // knots (n_coef + 3), device
+  const double* c;  // coefficients (n_coef), device
+  int n_coef;
+  double ev_min, ev_max, max_concentration;
+};
+// class log-pdfs kappa |w^H y|^2 / |y|^2 - ln c(kappa) (complex_watson.py:73-88) of the raw
+// (B, T, D) observation; mode c128 (B,K,D), conc / lognorm (B,K); out (B,K,T)
+int launch_gen_watson_logpdf(const void* y, int y_is_c128, int64_t B, int T, int D, int K,
+                             const double* mode, const double* conc, const double* lognorm,
+                             double* out_logpdf, hipStream_t s);
+// ln c(kappa) = ln(2 pi^D / (D-1)! 1F1(1; D; kappa)) (complex_watson.py:157-168)
+int launch_gen_watson_lognorm(const double* conc, int64_t N, int D, double* out, hipStream_t s);
+// principal eigenpair (ascending eigh output) -> mode, concentration through the inverse
+// hypergeometric-ratio spline (complex_watson.py:238-271, :314), ln c of it
+int launch_gen_watson_finish(const double* eigval, const double* eigvec, int64_t N, int D,
+                             const GenWatsonSpline& sp, double* out_mode, double* out_conc,
+                             double* out_lognorm, hipStream_t s);
 
 }  // namespace pbbss

@@ -198,3 +198,88 @@ def test_singular_noise_takes_least_squares_branch_for_many_sensors():
     # GEV on a non-positive-definite noise matrix: ValueError like the Cython path
     with pytest.raises(ValueError):
         ex.get_gev_vector(target, noise)
+
+
+def _cos_sim(a, b):
+    num = np.abs(np.einsum('...d,...d', a.conj(), b))
+    return num / (np.linalg.norm(a, axis=-1) * np.linalg.norm(b, axis=-1))
+
+
+@pytest.mark.parametrize('F,T,D,K,with_sal', [
+    (6, 300, 12, 8, False),   # D = 12, K = 8
+    (3, 200, 29, 3, True),
+    (5, 257, 6, 7, False),    # few sensors, more classes than the fused kernel takes
+    (4, 150, 16, 2, True),
+    (2, 130, 32, 5, False),
+])
+def test_watson_mixture_at_generic_sizes(F, T, D, K, with_sal):
+    """CWMMTrainer / CWMM.predict beyond the fused kernel's D <= 8, K <= 4
+    (csrc/generic_watson.hip) against the oracle's reference loop."""
+    from pb_bss_amd.distribution import CWMMTrainer
+    from oracle import cwmm as ow, synth
+    Y, init = synth.make_stft(F, T, D, K, seed=D * 10 + K)
+    Y128 = Y.astype(np.complex128)
+    sal = np.random.default_rng(D).uniform(0.2, 1.0, size=(F, T)) if with_sal else None
+    for iterations in (1, 5):
+        model = CWMMTrainer().fit(Y, initialization=init, iterations=iterations, saliency=sal)
+        ref = ow.cwmm_fit(Y128, init, iterations=iterations, saliency=sal)
+        tol = 1e-9 if iterations == 1 else 1e-6
+        assert model.complex_watson.mode.shape == (F, K, D)
+        np.testing.assert_allclose(model.complex_watson.concentration, ref['concentration'],
+                                   rtol=tol, atol=tol)
+        np.testing.assert_allclose(model.weight, ref['weight'], atol=tol)
+        assert np.abs(_cos_sim(model.complex_watson.mode, ref['mode']) - 1).max() < tol
+        aff = model.predict(Y)
+        assert aff.shape == (F, K, T)
+        assert np.abs(aff - ow.cwmm_predict(ref, Y128)).max() < 100 * tol
+    # bins coupled through the weights: the step-wise loop on the same kernels
+    m2 = CWMMTrainer().fit(Y, initialization=init, iterations=3, weight_constant_axis=(-3, -1))
+    r2 = ow.cwmm_fit(Y128, init, iterations=3, weight_constant_axis=(-3, -1))
+    assert np.abs(m2.predict(Y) - ow.cwmm_predict(r2, Y128)).max() < 1e-6
+
+
+def test_watson_log_norm_for_many_sensors():
+    """ln c(kappa) of the generic path (series of 1F1(1; D; kappa), all terms positive) against
+    scipy over the whole range of the concentration spline."""
+    from pb_bss_amd import _lib
+    from pb_bss_amd.distribution import CWMM, ComplexWatson
+    from oracle import cwmm as ow
+    rng = np.random.default_rng(0)
+    for D in (9, 16, 32):
+        conc = np.concatenate([[0.0, 1e-3, 0.5, 7.9, 8.0, 60.0, 499.0, 500.0],
+                               rng.uniform(0, 500, size=8)])
+        K = conc.size
+        mode = rng.standard_normal((K, D)) + 1j * rng.standard_normal((K, D))
+        mode /= np.linalg.norm(mode, axis=-1, keepdims=True)
+        y = rng.standard_normal((1, 40, D)) + 1j * rng.standard_normal((1, 40, D))
+        model = CWMM(weight=np.full((K, 1), 1.0 / K),
+                     complex_watson=ComplexWatson(mode=mode, concentration=conc))
+        aff = model.predict(y)
+        want = ow.cwmm_predict(dict(weight=model.weight, mode=mode, concentration=conc), y)
+        assert np.abs(aff - want).max() < 1e-9, D
+
+
+@pytest.mark.parametrize('kind,D,K,kw', [
+    ('gaussian', 12, 6, {}),
+    ('gaussian', 16, 3, dict(weight_constant_axis=(-3, -1), spectral_weight=0.5)),
+    ('gaussian', 9, 4, dict(weight_constant_axis=(-1,))),
+    ('gaussian', 24, 2, dict(covariance_type='full')),
+    ('vmf', 12, 3, dict(weight_constant_axis=(-3, -1), max_concentration=80.)),
+])
+def test_joint_models_at_generic_sizes(kind, D, K, kw):
+    """GCACGMM / VMFCACGMM with more than 8 sensors: the spatial half on the generic-size kernels
+    (E-step with the spectral log-pdf as extra exponent, covariance, eigh), same spectral kernels."""
+    from pb_bss_amd.distribution import GCACGMMTrainer, VMFCACGMMTrainer
+    from oracle import embed as oe, synth
+    F, T, E = 7, 260, 20
+    Y, e, init = synth.make_joint(F, T, D, K, E, seed=D + K)
+    sal = np.random.default_rng(1).uniform(0.2, 1.0, size=(F, T))
+    trainer = GCACGMMTrainer() if kind == 'gaussian' else VMFCACGMMTrainer()
+    Y128, e64 = Y.astype(np.complex128), e.astype(np.float64)
+    for iterations in (2, 6):
+        model = trainer.fit(Y, e, initialization=init, iterations=iterations, saliency=sal, **kw)
+        ref = oe.joint_fit(kind, Y128, e64, init, iterations, saliency=sal, **kw)
+        want = oe.joint_model_predict(ref, Y128, e64)
+        masks = model.predict(Y, e)
+        assert masks.shape == (F, K, T)
+        assert np.abs(masks - want).max() < (1e-8 if iterations == 2 else 1e-6), iterations
