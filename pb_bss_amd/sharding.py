@@ -21,6 +21,7 @@ there are at least as many utterances as GPUs.
 import numpy as np
 
 __all__ = ['shard_bounds', 'shard_sizes', 'all_gather_bins', 'all_reduce_sum', 'fit_predict_sharded',
+           'sharded_inline_aligner',
            'fit_predict_sharded_joint', 'native_comm',
            'init_native_comm', 'destroy_native_comm']
 
@@ -199,6 +200,58 @@ def all_reduce_sum(x, group=None):
     return x
 
 
+class sharded_inline_aligner:
+    """An `inline_permutation_aligner` under bin sharding.  The reference hands the solver the
+    affiliations of ALL bins after every E-step (cacgmm.py:260-267, mixture_model_utils.py:264-306):
+    `calculate_mapping` all-gathers the ranks' (K, F_local, T) blocks, every rank solves the full
+    (K, F) mapping from bit-identical inputs (so all ranks hold the same mapping without a second
+    collective) and keeps the columns of its own block; `apply_mapping` then acts on the local
+    block.  One mask all-gather per EM iteration -- the same traffic as the final gather of
+    `fit_predict_sharded`.  Wraps the library's device aligners (tensors stay on the device) as
+    well as foreign NumPy aligner objects (one host excursion per iteration, as unsharded)."""
+
+    def __init__(self, aligner, total_bins, group=None):
+        import torch.distributed as dist
+        self.aligner = aligner
+        self.F = total_bins
+        self.group = group
+        self.lo, self.hi = shard_bounds(total_bins, dist.get_world_size(group), dist.get_rank(group))
+        self._device = type(aligner).__module__.startswith('pb_bss_amd')
+
+    def calculate_mapping(self, kft):
+        from . import _lib
+        t = _lib.torch()
+        is_tensor = isinstance(kft, t.Tensor)
+        local = kft if is_tensor else t.from_numpy(np.ascontiguousarray(kft))
+        full = all_gather_bins(local.contiguous(), self.F, bin_axis=1, group=self.group)
+        if self._device:
+            mapping = self.aligner.calculate_mapping(full)
+        else:
+            mapping = self.aligner.calculate_mapping(
+                full.cpu().numpy() if is_tensor else full.numpy())
+        block = mapping[:, self.lo:self.hi]
+        if isinstance(block, t.Tensor):
+            return block.contiguous()
+        block = np.ascontiguousarray(block)
+        return t.from_numpy(block).to(kft.device) if is_tensor else block
+
+    def apply_mapping(self, x, mapping):
+        from . import _lib
+        t = _lib.torch()
+        if self._device or not isinstance(x, t.Tensor):
+            return self.aligner.apply_mapping(x, mapping)
+        out = self.aligner.apply_mapping(x.cpu().numpy(), mapping.cpu().numpy())
+        return t.from_numpy(np.ascontiguousarray(out)).to(x.device)
+
+    def idle(self, K, T, dtype, device, count):
+        """A rank without bins keeps the collective schedule: `count` gathers of an empty block."""
+        from . import _lib
+        t = _lib.torch()
+        for _ in range(count):
+            all_gather_bins(t.empty((K, 0, T), dtype=dtype, device=device), self.F, bin_axis=1,
+                            group=self.group)
+
+
 def _bin_block(x, axis_from_end, lo, hi):
     """Slice bins [lo, hi) out of an array whose bin axis is `axis_from_end` (negative);
     arrays that are absent or broadcast along the bins pass through."""
@@ -224,8 +277,10 @@ def fit_predict_sharded(y, initialization, iterations=100, *, trainer=None, bin_
 
     `weight_constant_axis` may contain the sharded bin axis ((-3,), (-3, -1): weights
     averaged over the bins of ALL ranks; CACGMMTrainer only): the fit then runs step by step
-    with one small all-reduce per iteration (`shared_weight_allreduce`).  An inline
-    permutation aligner needs every bin on one device and is not shardable by bins.
+    with one small all-reduce per iteration (`shared_weight_allreduce`).
+    `inline_permutation_aligner` (needs such bin-constant weights, as in the reference): the
+    solver is wrapped in `sharded_inline_aligner` -- one mask all-gather per EM iteration, every
+    rank solves the full mapping and applies the columns of its own block (CACGMMTrainer, 3-D y).
     """
     import torch.distributed as dist
     from . import _lib
@@ -235,8 +290,7 @@ def fit_predict_sharded(y, initialization, iterations=100, *, trainer=None, bin_
     elif isinstance(trainer, type):
         trainer = trainer()
     is_cacgmm = isinstance(trainer, CACGMMTrainer)
-    assert fit_kwargs.get('inline_permutation_aligner') is None, \
-        'inline_permutation_aligner couples the frequency bins: not shardable by bins'
+    aligner = fit_kwargs.get('inline_permutation_aligner')
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     nd_y = y.ndim
@@ -257,6 +311,12 @@ def fit_predict_sharded(y, initialization, iterations=100, *, trainer=None, bin_
                 'collective inside the EM loop, which only CACGMMTrainer provides')
         assert not (len(wca) == 1 and wca[0] % nd_y - nd_y == -2), wca
         hook = shared_weight_allreduce(wca, F, bin_axis=f_axis_y - nd_y, group=group)
+    if aligner is not None:
+        # mixture_model_utils.py:264-306: 3-D affiliations and frequency-constant weights
+        assert is_cacgmm and nd_y == 3 and coupled, (
+            'inline_permutation_aligner under bin sharding: CACGMMTrainer, y (F, T, D) and a '
+            f'weight_constant_axis that contains the bin axis (got {wca}, y.ndim = {nd_y})')
+        aligner = sharded_inline_aligner(aligner, F, group=group)
     lo, hi = shard_bounds(F, world, rank)
     neg = f_axis_y - nd_y               # bin axis of y (..., F, T, D) and of (..., F, K, T)
     y_loc = _bin_block(y, neg, lo, hi)
@@ -269,6 +329,8 @@ def fit_predict_sharded(y, initialization, iterations=100, *, trainer=None, bin_
     K = initialization.shape[-2]
     if hook is not None:
         kwargs['_weight_hook'] = hook
+    if aligner is not None:
+        kwargs['inline_permutation_aligner'] = aligner
     # the library's trainers take device tensors; a CPU stand-in (the gloo tests run this very
     # function with oracle-backed trainers) says so with a `_to_device` of its own
     prep = getattr(trainer, '_to_device', _lib.to_device)
@@ -286,6 +348,8 @@ def fit_predict_sharded(y, initialization, iterations=100, *, trainer=None, bin_
             red = sorted({a % nd_a for a in wca})
             shape = [1 if ax in red else n for ax, n in enumerate(initialization.shape)]
             hook.idle(shape, t.float64, dev, iterations)
+        if aligner is not None:  # one gather per E-step: every iteration but the first
+            aligner.idle(K, y.shape[-2], t.float64, dev, max(iterations - 1, 0))
         # more ranks than bins: this rank owns nothing and contributes an empty block
         shape = list(y.shape[:-2]) + [K, y.shape[-2]]
         shape[f_axis_y] = 0

@@ -188,3 +188,26 @@ def test_fit_predict_sharded_watson_and_souden_world1(world1_nccl):
     for k in range(K):
         w_k = ob.mvdr_souden(psd_ref[:, k], psd_ref.sum(1) - psd_ref[:, k])
         assert np.abs(wb[k, 0] - w_k).max() < 1e-6 * np.abs(w_k).max()
+
+
+def test_fit_predict_sharded_inline_aligner_world1(world1_nccl):
+    """inline_permutation_aligner under bin sharding (sharding.sharded_inline_aligner): one mask
+    all-gather per EM iteration through RCCL, the full mapping solved on the device, the local
+    columns applied -- at world size 1 the result must equal the unsharded stepwise fit."""
+    from pb_bss_amd import sharding
+    from pb_bss_amd.distribution import CACGMMTrainer
+    from pb_bss_amd.permutation_alignment import DHTVPermutationAlignment
+    from oracle import synth
+    F, T, D, K = 257, 90, 4, 2
+    Y, init = synth.make_stft(F, T, D, K, seed=21)
+    rng = np.random.default_rng(2)
+    for f in range(F):  # a permuted initialisation gives the aligner something to do
+        init[f] = init[f, rng.permutation(K)]
+    aligner = DHTVPermutationAlignment.from_stft_size(512)
+    kw = dict(iterations=4, weight_constant_axis=(-3,), inline_permutation_aligner=aligner)
+    want = CACGMMTrainer().fit_predict(Y, initialization=init, **kw)
+    got = sharding.fit_predict_sharded(Y, init, **kw)
+    assert got.shape == (F, K, T)
+    assert np.abs(got.cpu().numpy() - want).max() < 1e-12
+    with pytest.raises(AssertionError):  # needs frequency-constant weights, as the reference
+        sharding.fit_predict_sharded(Y, init, iterations=2, inline_permutation_aligner=aligner)
