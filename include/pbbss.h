@@ -72,8 +72,8 @@ int pbbss_create(pbbss_handle_t* out, int device_id);
  * layout TD only for the fit).  1 <= K <= 6 classes on the fused kernels, 7 <= K <= 16 on the
  * generic-size path at any D.  Watson mixture (pbbss_cwmm_fit): fused kernel for D <= 8, K <= 4,
  * generic-size path up to D = 32, K = 16.  Joint models (pbbss_joint_fit): D <= 32 (the spatial
- * half of 9 <= D <= 32 on the generic-size kernels, no inline permutation alignment there),
- * K <= 6 (bound of the spectral kernels).  LCMV: D <= 8. */
+ * half of 9 <= D <= 32, or of 7..8 classes, on the generic-size kernels, no inline permutation
+ * alignment there), K <= 8 (bound of the spectral kernels).  LCMV: D <= 8. */
 int pbbss_destroy(pbbss_handle_t h);
 
 /* ------------------------------------------------------------------------- */
@@ -428,7 +428,7 @@ int pbbss_cwmm_fit(pbbss_handle_t h, const void* y, int64_t B, int T, int D, int
 /* N2/N3  Real-embedding mixture components: von Mises-Fisher and spherical      */
 /* Gaussian (distribution/von_mises_fisher.py:33-144, gaussian.py:100-193).      */
 /* y (B,N,E) real, row-major, float32 or float64 (y_is_f64); 1 <= E <= 256,      */
-/* K <= 6.  `scale` (B,K) is the vMF concentration or the spherical covariance.   */
+/* K <= 8.  `scale` (B,K) is the vMF concentration or the spherical covariance.   */
 /* ------------------------------------------------------------------------- */
 #define PBBSS_EMBED_VMF 0             /* VonMisesFisher                       */
 #define PBBSS_EMBED_GAUSS_SPHERICAL 1 /* SphericalGaussian                    */

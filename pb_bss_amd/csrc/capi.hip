@@ -1435,10 +1435,12 @@ PBBSS_API int pbbss_joint_fit(pbbss_handle_t h, const void* observation, const v
                               int32_t* out_status, double* out_affiliation, void* stream) {
   DeviceGuard device_guard(h);
   if (!h || !observation || !embedding || !o || F <= 0 || T <= 0) return PBBSS_ERR_INVALID_ARG;
-  // 9 <= D <= 32: the spatial half runs on the generic-size kernels (generic.hip), one E-step
-  // and one M-step launch group per iteration around the same spectral kernels
-  const bool gen = D > 8;
-  if (D < 2 || K < 1 || K > 6 || (gen && !pbbss::gen_supported(D, K))) return PBBSS_ERR_UNSUPPORTED;
+  // 9 <= D <= 32 or 7..8 classes: the spatial half runs on the generic-size kernels
+  // (generic.hip), one E-step and one M-step launch group per iteration around the same spectral
+  // kernels
+  const bool gen = D > 8 || K > 6;
+  if (D < 2 || K < 1 || K > pbbss::kEmbedMaxK || (gen && !pbbss::gen_supported(D, K)))
+    return PBBSS_ERR_UNSUPPORTED;
   if (gen && (o->inline_pa || F > 65535)) return PBBSS_ERR_UNSUPPORTED;
   const int64_t N = F * (int64_t)T;
   if (!embed_shape_ok(1, N, E, K)) return PBBSS_ERR_UNSUPPORTED;

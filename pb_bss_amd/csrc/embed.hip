@@ -972,6 +972,7 @@ int estep_k(int K, const void* yd, int64_t B, int64_t N, int E, const double* me
   switch (K) {
     PBBSS_ESTEP_CASE(1) PBBSS_ESTEP_CASE(2) PBBSS_ESTEP_CASE(3)
     PBBSS_ESTEP_CASE(4) PBBSS_ESTEP_CASE(5) PBBSS_ESTEP_CASE(6)
+    PBBSS_ESTEP_CASE(7) PBBSS_ESTEP_CASE(8)
     default: return PBBSS_ERR_UNSUPPORTED;
   }
 #undef PBBSS_ESTEP_CASE
@@ -1141,6 +1142,7 @@ int fit_k(int K, int kind, const void* yr, int64_t B, int64_t N, int E, const do
   switch (K) {
     PBBSS_FIT_CASE(1) PBBSS_FIT_CASE(2) PBBSS_FIT_CASE(3)
     PBBSS_FIT_CASE(4) PBBSS_FIT_CASE(5) PBBSS_FIT_CASE(6)
+    PBBSS_FIT_CASE(7) PBBSS_FIT_CASE(8)
     default: return PBBSS_ERR_UNSUPPORTED;
   }
 #undef PBBSS_FIT_CASE
@@ -1258,6 +1260,7 @@ int launch_vmf_em(const void* y, int y_is_f64, int64_t B, int64_t N, int E, int 
     break;
   switch (K) {
     PBBSS_VMF_EM(1) PBBSS_VMF_EM(2) PBBSS_VMF_EM(3) PBBSS_VMF_EM(4) PBBSS_VMF_EM(5) PBBSS_VMF_EM(6)
+    PBBSS_VMF_EM(7) PBBSS_VMF_EM(8)
     default: return PBBSS_ERR_UNSUPPORTED;
   }
 #undef PBBSS_VMF_EM

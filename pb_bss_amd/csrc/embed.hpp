@@ -8,7 +8,7 @@
 
 namespace pbbss {
 
-constexpr int kEmbedMaxK = 6;     // classes (same bound as the spatial kernels)
+constexpr int kEmbedMaxK = 8;     // classes (the fused spatial kernels take 6; 7 and 8 pair with the generic-size path)
 constexpr int kEmbedMaxE = 256;   // embedding dimension (one workgroup row of the fit kernel)
 
 // Sharded fits (the points of ONE mixture spread over several GPUs): called between the kernel

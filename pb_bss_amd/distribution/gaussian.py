@@ -47,7 +47,7 @@ class SphericalGaussian(_ProbabilisticModel):
         lead = tuple(mean.shape[:-1])
         y_lead = tuple(y.shape[:-2])
         K = int(np.prod(lead)) if lead else 1
-        if all(s == 1 for s in y_lead) and K <= 6:
+        if all(s == 1 for s in y_lead) and K <= 8:
             out = engine.embed_log_pdf(y.reshape(1, N, E), _lib.EMBED_GAUSS_SPHERICAL,
                                        mean.reshape(1, K, E).contiguous(),
                                        cov.reshape(1, K).contiguous())
@@ -172,7 +172,7 @@ class GaussianTrainer:
             sal = _lib.to_device(saliency, t.float64).to(y.device)
         lead = np.broadcast_shapes(tuple(y.shape[:-2]), tuple(sal.shape[:-1]))
         K = int(np.prod(lead)) if lead else 1
-        if all(s == 1 for s in y.shape[:-2]) and K <= 6:
+        if all(s == 1 for s in y.shape[:-2]) and K <= 8:
             mean, cov = engine.embed_fit(y.reshape(1, N, E), kind,
                                          sal.expand(*lead, N).reshape(1, K, N).contiguous())
         else:

@@ -43,7 +43,7 @@ class VonMisesFisher(_ProbabilisticModel):
         if all(s == 1 for s in y_lead):
             # every model is evaluated on the same N points: one mixture with prod(lead) classes
             K = int(np.prod(lead)) if lead else 1
-            if K <= 6:
+            if K <= 8:
                 out = engine.embed_log_pdf(
                     y.reshape(1, N, E), _lib.EMBED_VMF,
                     mean.reshape(1, K, E).to(y.device).contiguous(),
@@ -96,7 +96,7 @@ class VonMisesFisherTrainer:
         else:
             sal = _lib.to_device(saliency, t.float64).to(y.device)
         lead = np.broadcast_shapes(tuple(y.shape[:-2]), tuple(sal.shape[:-1]))
-        if all(s == 1 for s in y.shape[:-2]) and int(np.prod(lead)) <= 6:
+        if all(s == 1 for s in y.shape[:-2]) and int(np.prod(lead)) <= 8:
             K = int(np.prod(lead)) if lead else 1
             mean, conc = engine.embed_fit(
                 y.reshape(1, N, E), _lib.EMBED_VMF,

@@ -81,9 +81,9 @@ def test_vmfmm_matches_reference_flat_and_independent_axes():
 
 
 @pytest.mark.parametrize('N,E,K', [(1000, 2, 2), (4099, 3, 4), (30000, 40, 3), (2500, 64, 6),
-                                   (700, 100, 2), (5, 7, 1)])
+                                   (700, 100, 2), (5, 7, 1), (6000, 40, 8), (3001, 12, 7)])
 def test_vmfmm_shapes_against_oracle(N, E, K):
-    """odd sample counts, one sample per workgroup slot, E not dividing 256, K = 1..6"""
+    """odd sample counts, one sample per workgroup slot, E not dividing 256, K = 1..8"""
     from pb_bss_amd.distribution import VMFMMTrainer
     from oracle import embed as oe
     rng = np.random.default_rng(N + E)
@@ -271,7 +271,7 @@ def test_gmm_matches_reference():
         GMMTrainer().fit(y, initialization=g['init'], num_classes=3, covariance_type='spherical')
 
 
-@pytest.mark.parametrize('F,N,E,K', [(1, 20000, 40, 3), (7, 333, 5, 2), (3, 1000, 16, 6)])
+@pytest.mark.parametrize('F,N,E,K', [(1, 20000, 40, 3), (7, 333, 5, 2), (3, 1000, 16, 6), (2, 1500, 10, 8)])
 def test_gmm_shapes_against_oracle(F, N, E, K):
     """Larger / batched problems (independent leading axis) against the NumPy oracle; torch in,
     torch out; num_classes initialisation draws from the global NumPy RNG like the reference."""
