@@ -1441,7 +1441,7 @@ PBBSS_API int pbbss_joint_fit(pbbss_handle_t h, const void* observation, const v
   const bool gen = D > 8 || K > 6;
   if (D < 2 || K < 1 || K > pbbss::kEmbedMaxK || (gen && !pbbss::gen_supported(D, K)))
     return PBBSS_ERR_UNSUPPORTED;
-  if (gen && (o->inline_pa || F > 65535)) return PBBSS_ERR_UNSUPPORTED;
+  if (gen && (F > 65535 || (o->inline_pa && K > 6))) return PBBSS_ERR_UNSUPPORTED;
   const int64_t N = F * (int64_t)T;
   if (!embed_shape_ok(1, N, E, K)) return PBBSS_ERR_UNSUPPORTED;
   if (o->iterations < 0 || o->weight_mode < 0 || o->weight_mode > 4) return PBBSS_ERR_INVALID_ARG;
@@ -1490,7 +1490,8 @@ PBBSS_API int pbbss_joint_fit(pbbss_handle_t h, const void* observation, const v
   const size_t ninv = gen ? pbbss::gen_state_doubles((int64_t)nmat, D) : 0;
   const size_t nyt = gen ? (size_t)F * T * D * (o->obs_is_c128 ? 16 : 8) : 0;
   const size_t need_gen =
-      gen ? WorkCarver::pad(nfkt * 8) + WorkCarver::pad(nmat * D * D * 16) + WorkCarver::pad(ninv * 8) +
+      gen ? (o->inline_pa ? 3 : 1) * WorkCarver::pad(nfkt * 8) + WorkCarver::pad(nmat * D * D * 16) +
+                WorkCarver::pad(ninv * 8) +
                 2 * WorkCarver::pad(nmat * 8) + WorkCarver::pad((size_t)F * 4) + WorkCarver::pad(nyt)
           : 0;
   const size_t need = need_gen + WorkCarver::pad((size_t)E * N * esz) + 2 * WorkCarver::pad(nfkt * 8) +
@@ -1526,6 +1527,8 @@ PBBSS_API int pbbss_joint_fit(pbbss_handle_t h, const void* observation, const v
   double* g_csum = gen ? wc.take<double>(nmat) : nullptr;
   int32_t* g_zero = gen ? wc.take<int32_t>((size_t)F) : nullptr;
   char* g_yt = gen ? wc.take<char>(nyt) : nullptr;
+  double* g_lp = (gen && o->inline_pa) ? wc.take<double>(nfkt) : nullptr;  // spatial log-pdf
+  double* g_q = (gen && o->inline_pa) ? wc.take<double>(nfkt) : nullptr;   // quadratic forms
   if (hipMemsetAsync(gst, 0, 64, as_stream(stream)) != hipSuccess) return PBBSS_ERR_HIP;
   TimedRegion tr(h, s);
   int rc = pbbss::launch_embed_prepare(embedding, o->embedding_is_f64, 1, N, E, 0, yd, nullptr, s);
@@ -1573,7 +1576,19 @@ PBBSS_API int pbbss_joint_fit(pbbss_handle_t h, const void* observation, const v
                                   out_eigval, static_cast<double*>(out_eigvec), out_status,
                                   h->cfg.lds_limit, s);
   };
-  auto gen_e_step = [&](double* aff_out, double eps, bool for_m_step) -> int {
+  auto gen_e_step = [&](double* aff_out, double eps, bool for_m_step, int inline_pa) -> int {
+    if (inline_pa) {
+      // spatial log-pdf and quadratic forms first, then the per-bin permutation search
+      int r = pbbss::launch_gen_estep(g_yt, o->obs_is_c128, PBBSS_LAYOUT_DT, F, T, D, K,
+                                      static_cast<const double*>(out_eigvec), out_eigval, out_weight,
+                                      wb, wk, wt, nullptr, 0.0, nullptr, g_q, g_lp, s, g_state,
+                                      nullptr, nullptr, nullptr, /*raw_dt=*/1);
+      if (r != PBBSS_OK) return r;
+      return pbbss::launch_gen_joint_pa(g_yt, o->obs_is_c128, F, T, D, K, g_lp, g_q, slp,
+                                        o->spatial_weight, out_weight, wb, wk, wt, saliency, eps,
+                                        aff_out, for_m_step ? g_mw : nullptr,
+                                        for_m_step ? g_zero : nullptr, s);
+    }
     return pbbss::launch_gen_estep(g_yt, o->obs_is_c128, PBBSS_LAYOUT_DT, F, T, D, K,
                                    static_cast<const double*>(out_eigvec), out_eigval, out_weight,
                                    wb, wk, wt, nullptr, eps, aff_out, nullptr, nullptr, s, g_state,
@@ -1590,7 +1605,8 @@ PBBSS_API int pbbss_joint_fit(pbbss_handle_t h, const void* observation, const v
   auto joint = [&](int iterations, double* aff_out, int inline_pa, const double* state_in,
                    double* state_out, int emit_model) -> int {
     if (gen) {
-      int r = gen_e_step(aff_out, iterations > 0 ? o->affiliation_eps : 0.0, iterations > 0);
+      int r = gen_e_step(aff_out, iterations > 0 ? o->affiliation_eps : 0.0, iterations > 0,
+                         inline_pa);
       if (r != PBBSS_OK || iterations == 0) return r;
       return gen_m_step(aff_out, o->weight_mode == PBBSS_JOINT_WEIGHT_FK);
     }

@@ -1204,6 +1204,160 @@ int launch_gen_cov(const void* y, int y_is_c128, int layout, int64_t B, int T, i
 }
 
 namespace {
+// Inline permutation alignment of the joint models at generic sizes
+// (mixture_model_utils.py:58-130; the fused kernel's phase_joint_pa does the same for D <= 8):
+// per bin the class permutation of the (weighted) spatial log-pdf that maximises
+// sum_{k,t} softmax_k(lp)(t) lp_k(t), lp = spatial[perm] + spectral (no mixture weights),
+// itertools.permutations order, the first strict maximum wins; then the posterior with that
+// permutation (log_pdf_to_affiliation with the weights) and the cACG M-step weights
+// gamma sal / max(q, 10 tiny) / |y|^2 -- q stays in the spatial model's class order, as the
+// reference hands predict's quadratic form to the M-step unpermuted (gcacgmm.py:98-117).
+constexpr int kPaMaxK = 6;    // 720 permutations
+constexpr int kPaBatch = 8;   // permutations scored per block reduction
+struct GenJointPa {
+  const void* yt;            // (B, D, T) raw observation (frame-contiguous copy)
+  int T, D, K;
+  const double* lp_spatial;  // (B,K,T) cACG log-pdf (gen_estep out_logpdf)
+  const double* q;           // (B,K,T) quadratic forms
+  const double* extra;       // (B,K,T) spectral log-pdf, already times spectral_weight
+  double spatial_scale;
+  const double* weight;
+  int64_t wb, wk, wt;
+  const double* saliency;    // (B,T) or null
+  double eps;
+  double* out_aff;           // (B,K,T)
+  double* out_mweight;       // (B,K,T) or null
+  int32_t* out_zero;         // (B) or null
+};
+
+__device__ __forceinline__ void pa_nth_permutation(int p, int K, int* perm) {
+  int fact = 1;
+  for (int i = 2; i < K; ++i) fact *= i;  // (K-1)!
+  unsigned used = 0;
+  for (int i = 0; i < K; ++i) {
+    const int d = p / fact;
+    p -= d * fact;
+    if (i < K - 1) fact /= (K - 1 - i);
+    int pick = 0;
+    for (int c = 0, seen = 0; c < K; ++c) {
+      if (!(used >> c & 1)) {
+        if (seen == d) pick = c;
+        ++seen;
+      }
+    }
+    used |= 1u << pick;
+    perm[i] = pick;
+  }
+}
+
+template <typename YS>
+__global__ void __launch_bounds__(kGenThreads) gen_joint_pa_kernel(GenJointPa a) {
+  __shared__ double red[kGenWaves][kPaBatch];
+  __shared__ int best_perm[kPaMaxK];
+  __shared__ int zero_seen;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t b = blockIdx.x;
+  const int K = a.K, T = a.T, D = a.D;
+  const double* sp = a.lp_spatial + (size_t)b * K * T;
+  const double* ex = a.extra + (size_t)b * K * T;
+  if (tid == 0) zero_seen = 0;
+  int nperm = 1;
+  for (int i = 2; i <= K; ++i) nperm *= i;
+  double best = -INFINITY;
+  int best_p = 0;
+  for (int p0 = 0; p0 < nperm; p0 += kPaBatch) {
+    double part[kPaBatch];
+#pragma unroll
+    for (int x = 0; x < kPaBatch; ++x) part[x] = 0.0;
+    for (int x = 0; x < kPaBatch && p0 + x < nperm; ++x) {
+      int perm[kPaMaxK];
+      pa_nth_permutation(p0 + x, K, perm);
+      double acc = 0.0;
+      for (int t = tid; t < T; t += kGenThreads) {
+        double lp[kPaMaxK], mx = -1.79e308;
+        for (int k = 0; k < K; ++k) {
+          lp[k] = fma(a.spatial_scale, sp[(size_t)perm[k] * T + t], ex[(size_t)k * T + t]);
+          mx = fmax(mx, lp[k]);
+        }
+        double den = 0.0, num = 0.0;
+        for (int k = 0; k < K; ++k) {
+          const double e = exp(lp[k] - mx);
+          den += e;
+          num = fma(e, lp[k], num);
+        }
+        acc += num / fmax(den, kTiny);
+      }
+      part[x] = acc;
+    }
+    __syncthreads();  // the previous batch's reads of red are done
+#pragma unroll
+    for (int x = 0; x < kPaBatch; ++x) {
+      const double v = wave_sum(part[x]);
+      if (lane == 0) red[wave][x] = v;
+    }
+    __syncthreads();
+    for (int x = 0; x < kPaBatch && p0 + x < nperm; ++x) {
+      double tot = 0.0;
+      for (int w = 0; w < kGenWaves; ++w) tot += red[w][x];
+      if (tot > best) {  // strict: the first maximiser wins, as in the reference loop
+        best = tot;
+        best_p = p0 + x;
+      }
+    }
+  }
+  if (tid == 0) pa_nth_permutation(best_p, K, best_perm);
+  __syncthreads();
+  const YS* y = static_cast<const YS*>(a.yt) + (size_t)b * D * T * 2;
+  for (int t = tid; t < T; t += kGenThreads) {
+    double n2 = 0.0;
+    for (int d = 0; d < D; ++d) {
+      const double re = (double)y[((size_t)d * T + t) * 2], im = (double)y[((size_t)d * T + t) * 2 + 1];
+      n2 += re * re + im * im;
+    }
+    const double inv = (n2 > 0.0) ? 1.0 / n2 : 0.0;
+    if (!(n2 > 0.0)) zero_seen = 1;  // benign race: every writer stores 1
+    double lp[kPaMaxK], mx = -1.79e308;
+    for (int k = 0; k < K; ++k) {
+      lp[k] = fma(a.spatial_scale, sp[(size_t)best_perm[k] * T + t], ex[(size_t)k * T + t]);
+      mx = fmax(mx, lp[k]);
+    }
+    double v[kPaMaxK], den = 0.0;
+    for (int k = 0; k < K; ++k) {
+      v[k] = exp(lp[k] - mx) * a.weight[b * a.wb + k * a.wk + (int64_t)t * a.wt];
+      den += v[k];
+    }
+    den = fmax(den, kTiny);
+    const double sal = a.saliency ? a.saliency[(size_t)b * T + t] : 1.0;
+    for (int k = 0; k < K; ++k) {
+      double gam = v[k] / den;
+      if (a.eps != 0.0) gam = fmin(fmax(gam, a.eps), 1.0 - a.eps);
+      a.out_aff[((size_t)b * K + k) * T + t] = gam;
+      if (a.out_mweight)
+        a.out_mweight[((size_t)b * K + k) * T + t] =
+            gam * sal / fmax(a.q[((size_t)b * K + k) * T + t], 10.0 * kTiny) * inv;
+    }
+  }
+  __syncthreads();
+  if (tid == 0 && a.out_zero && zero_seen) a.out_zero[b] = 1;
+}
+}  // namespace
+
+int launch_gen_joint_pa(const void* yt, int y_is_c128, int64_t B, int T, int D, int K,
+                        const double* lp_spatial, const double* q, const double* extra,
+                        double spatial_scale, const double* weight, int64_t wb, int64_t wk,
+                        int64_t wt, const double* saliency, double eps, double* out_aff,
+                        double* out_mweight, int32_t* out_zero, hipStream_t s) {
+  if (K < 1 || K > kPaMaxK || B > 2147483647LL) return PBBSS_ERR_UNSUPPORTED;
+  GenJointPa a{yt, T, D, K, lp_spatial, q, extra, spatial_scale, weight, wb, wk, wt, saliency, eps,
+               out_aff, out_mweight, out_zero};
+  if (y_is_c128)
+    hipLaunchKernelGGL(gen_joint_pa_kernel<double>, dim3((unsigned)B), dim3(kGenThreads), 0, s, a);
+  else
+    hipLaunchKernelGGL(gen_joint_pa_kernel<float>, dim3((unsigned)B), dim3(kGenThreads), 0, s, a);
+  return ok_or_hip();
+}
+
+namespace {
 // (B, T, D) -> (B, D, T), values untouched: the E-step of the EM loop reads the observation with
 // lane = frame, which on the raw layout is a stride of D complex numbers per lane (every load
 // instruction touches 64 cache lines and the 15 KB footprint of a wave does not survive in L1:

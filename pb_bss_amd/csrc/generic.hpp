@@ -36,6 +36,16 @@ int launch_gen_estep(const void* y, int y_is_c128, int layout, int64_t B, int T,
                      // log-pdf + extra[b,k,t] (gcacgmm.py:66-117)
                      const double* extra = nullptr, double spatial_scale = 1.0);
 
+// Joint models with inline permutation alignment (mixture_model_utils.py:58-130): from the
+// spatial log-pdf / quadratic forms of launch_gen_estep (out_logpdf, out_q) and the spectral
+// log-pdf `extra`, the best class permutation per bin, the posterior and the cACG M-step weights.
+// yt: the (B, D, T) copy of the raw observation.  K <= 6.
+int launch_gen_joint_pa(const void* yt, int y_is_c128, int64_t B, int T, int D, int K,
+                        const double* lp_spatial, const double* q, const double* extra,
+                        double spatial_scale, const double* weight, int64_t wb, int64_t wk,
+                        int64_t wt, const double* saliency, double eps, double* out_aff,
+                        double* out_mweight, int32_t* out_zero, hipStream_t s);
+
 // (B, T, D) -> (B, D, T) copy of the raw observation for the E-steps of the EM loop
 int launch_gen_transpose(const void* y, int y_is_c128, int64_t B, int T, int D, void* out,
                          hipStream_t s);

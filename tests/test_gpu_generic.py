@@ -268,6 +268,9 @@ def test_watson_log_norm_for_many_sensors():
     ('gaussian', 12, 8, {}),                                  # D = 12, K = 8
     ('gaussian', 6, 7, dict(weight_constant_axis=(-3,))),     # few sensors, 7 classes
     ('vmf', 5, 8, dict(max_concentration=80.)),
+    ('gaussian', 12, 3, dict(weight_constant_axis=(-3,), inline_permutation_alignment=True)),
+    ('vmf', 9, 4, dict(weight_constant_axis=(-3, -1), inline_permutation_alignment=True,
+                       max_concentration=80.)),
 ])
 def test_joint_models_at_generic_sizes(kind, D, K, kw):
     """GCACGMM / VMFCACGMM with more than 8 sensors: the spatial half on the generic-size kernels
