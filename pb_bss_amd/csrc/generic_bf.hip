@@ -201,42 +201,67 @@ __global__ void __launch_bounds__(kGenThreads)
   if (status && tid == 0) status[n] = sing ? PBBSS_ST_SINGULAR : 0;
 }
 
-// one thread per bin: w * | sqrt(w^H P P w) / |w^H P w| |
-__global__ void gen_ban_kernel(const double* wv, const double* noise, int64_t N, int D, double* out) {
-  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// one wavefront per bin, lane = row: w * | sqrt(w^H P P w) / |w^H P w| |  (one thread per bin
+// walked D^2 dependent loads: 0.23 ms for the 513 bins of a D = 29 utterance)
+__global__ void __launch_bounds__(256)
+    gen_ban_kernel(const double* wv, const double* noise, int64_t N, int D, double* out) {
+  const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
   if (n >= N) return;
   const double* P = noise + (size_t)n * D * D * 2;
   const double* w = wv + (size_t)n * D * 2;
-  double nr = 0.0, ni = 0.0, dr = 0.0, di = 0.0;
-  for (int b = 0; b < D; ++b) {
-    double ur = 0.0, ui = 0.0, vr = 0.0, vi = 0.0;  // u_b = (P w)_b, v_b = (w^H P)_b
-    for (int c = 0; c < D; ++c) {
-      const double pr = P[(b * D + c) * 2], pi = P[(b * D + c) * 2 + 1];
-      ur += pr * w[c * 2] - pi * w[c * 2 + 1];
-      ui += pr * w[c * 2 + 1] + pi * w[c * 2];
-      const double qr = P[(c * D + b) * 2], qi = P[(c * D + b) * 2 + 1];
-      vr += w[c * 2] * qr + w[c * 2 + 1] * qi;
-      vi += w[c * 2] * qi - w[c * 2 + 1] * qr;
-    }
-    nr += vr * ur - vi * ui;
-    ni += vr * ui + vi * ur;
-    dr += w[b * 2] * ur + w[b * 2 + 1] * ui;
-    di += w[b * 2] * ui - w[b * 2 + 1] * ur;
+  const int b = lane < D ? lane : 0;
+  double ur = 0.0, ui = 0.0, vr = 0.0, vi = 0.0;  // u_b = (P w)_b, v_b = (w^H P)_b
+  for (int c = 0; c < D; ++c) {
+    const double wr = w[c * 2], wi = w[c * 2 + 1];
+    const double pr = P[(b * D + c) * 2], pi = P[(b * D + c) * 2 + 1];
+    ur += pr * wr - pi * wi;
+    ui += pr * wi + pi * wr;
+    const double qr = P[(c * D + b) * 2], qi = P[(c * D + b) * 2 + 1];
+    vr += wr * qr + wi * qi;
+    vi += wr * qi - wi * qr;
   }
+  const bool on = lane < D;
+  const double wbr = w[b * 2], wbi = w[b * 2 + 1];
+  double nr = on ? vr * ur - vi * ui : 0.0, ni = on ? vr * ui + vi * ur : 0.0;
+  double dr = on ? wbr * ur + wbi * ui : 0.0, di = on ? wbr * ui - wbi * ur : 0.0;
+  nr = wave_sum(nr);
+  ni = wave_sum(ni);
+  dr = wave_sum(dr);
+  di = wave_sum(di);
   const double dabs = sqrt(dr * dr + di * di);
   const double scale = (dabs != 0.0) ? sqrt(sqrt(nr * nr + ni * ni)) / dabs : 0.0;
-  for (int d = 0; d < D; ++d) {
-    out[((size_t)n * D + d) * 2] = w[d * 2] * scale;
-    out[((size_t)n * D + d) * 2 + 1] = w[d * 2 + 1] * scale;
+  if (on) {
+    out[((size_t)n * D + b) * 2] = wbr * scale;
+    out[((size_t)n * D + b) * 2 + 1] = wbi * scale;
   }
 }
 
 // principal generalised eigenvector, w^H N w = 1 (zhegvd ITYPE=1): N = L L^H,
-// M = L^-1 T L^-H, top eigenvector u of M, w = L^-H u
+// M = L^-1 T L^-H, top eigenvector u of M, w = L^-H u.
+// LDS: THREE matrix slots instead of the nine of the common work area, so that three workgroups
+// share a compute unit and the 513 pencils of an utterance run in one round (the kernel is a
+// chain of latency-bound steps -- Cholesky, substitution, two products, the eigensolver on one
+// wavefront --: 1.1 ms at one workgroup per CU, round 2):
+//   slot 0  N -> L (Cholesky in place) -> X T (L is dead once X = L^-1 exists) -> solver scratch
+//   slot 1  X = L^-1
+//   slot 2  T -> M = (X T) X^H (T is dead once X T exists)
+// The eigensolver is the tridiagonal QL of generic_dev.hpp on the first wavefront for every size
+// (the 256-thread Jacobi needs three more matrix slots); only the principal eigenvector is kept.
+constexpr size_t kGevBytes =
+    (size_t)(3 * kMat + 2 * LD + kGenWaves) * sizeof(double) + (LD + 4) * sizeof(int);
+
 __global__ void __launch_bounds__(kGenThreads)
     gen_gev_kernel(const double* target, const double* noise, int D, double* out_w, int32_t* status) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const Work w = carve(smem);
+  double* A = reinterpret_cast<double*>(smem);  // slot 0
+  double* X = A + kMat;                         // slot 1
+  double* B0 = X + kMat;                        // slot 2
+  double* T2 = A;                               // X T, later the solver's scratch
+  double* G = B0;                               // M
+  double* vtop = B0 + kMat;                     // [LD][2] principal eigenvector
+  double* red = vtop + 2 * LD;                  // [kGenWaves]
+  int* flag = reinterpret_cast<int*>(red + kGenWaves);
   const int tid = threadIdx.x;
   const int64_t n = blockIdx.x;
   int st = 0;
@@ -256,69 +281,53 @@ __global__ void __launch_bounds__(kGenThreads)
       ni = (i == j) ? 0.0 : ((i < j) ? q[1] : -q[1]);
       if (!isfinite(tr) || !isfinite(ti) || !isfinite(nr) || !isfinite(ni)) bad = 1.0;
     }
-    w.B0[e * 2] = tr;
-    w.B0[e * 2 + 1] = ti;
-    w.A[e * 2] = nr;
-    w.A[e * 2 + 1] = ni;
+    B0[e * 2] = tr;
+    B0[e * 2 + 1] = ti;
+    A[e * 2] = nr;
+    A[e * 2 + 1] = ni;
   }
-  if (gen_block_sum(bad, w.S.red, tid) > 0.0) st |= PBBSS_ST_NONFINITE;
+  if (gen_block_sum(bad, red, tid) > 0.0) st |= PBBSS_ST_NONFINITE;
   __syncthreads();
-  const int info = lds_cholesky(w.A, D, LD, w.flag, tid);
+  const int info = lds_cholesky(A, D, LD, flag, tid);
   if (info != 0) st |= PBBSS_ST_NOT_POSDEF | (info << 8);
   // X = L^-1: forward substitution on the identity, one thread per column
-  for (int e = tid; e < kMat; e += kGenThreads) w.B[e] = 0.0;
+  for (int e = tid; e < kMat; e += kGenThreads) X[e] = 0.0;
   __syncthreads();
   if (info == 0) {
     for (int c = tid; c < D; c += kGenThreads) {
       for (int i = c; i < D; ++i) {
         double sr = (i == c) ? 1.0 : 0.0, si = 0.0;
         for (int m = c; m < i; ++m) {
-          const double lr = w.A[(i * LD + m) * 2], li = w.A[(i * LD + m) * 2 + 1];
-          const double xr = w.B[(m * LD + c) * 2], xi = w.B[(m * LD + c) * 2 + 1];
+          const double lr = A[(i * LD + m) * 2], li = A[(i * LD + m) * 2 + 1];
+          const double xr = X[(m * LD + c) * 2], xi = X[(m * LD + c) * 2 + 1];
           sr -= lr * xr - li * xi;
           si -= lr * xi + li * xr;
         }
-        const double d = w.A[(i * LD + i) * 2];
-        w.B[(i * LD + c) * 2] = sr / d;
-        w.B[(i * LD + c) * 2 + 1] = si / d;
+        const double d = A[(i * LD + i) * 2];
+        X[(i * LD + c) * 2] = sr / d;
+        X[(i * LD + c) * 2 + 1] = si / d;
       }
     }
   }
   __syncthreads();
-  lds_matmul(w.B, w.B0, w.T2, D, LD, tid);               // X T
-  lds_matmul(w.T2, w.B, w.G, D, LD, tid, false, true);   // (X T) X^H
-  for (int e = tid; e < D * D; e += kGenThreads) {        // symmetrise rounding noise
+  lds_matmul(X, B0, T2, D, LD, tid);               // X T   (overwrites L)
+  lds_matmul(T2, X, G, D, LD, tid, false, true);   // (X T) X^H   (overwrites T)
+  for (int e = tid; e < D * D; e += kGenThreads) {  // symmetrise rounding noise
     const int i = e / D, j = e - i * D;
     if (i < j) {
-      const double mr = 0.5 * (w.G[(i * LD + j) * 2] + w.G[(j * LD + i) * 2]);
-      const double mi = 0.5 * (w.G[(i * LD + j) * 2 + 1] - w.G[(j * LD + i) * 2 + 1]);
-      w.G[(i * LD + j) * 2] = mr;
-      w.G[(i * LD + j) * 2 + 1] = mi;
-      w.G[(j * LD + i) * 2] = mr;
-      w.G[(j * LD + i) * 2 + 1] = -mi;
+      const double mr = 0.5 * (G[(i * LD + j) * 2] + G[(j * LD + i) * 2]);
+      const double mi = 0.5 * (G[(i * LD + j) * 2 + 1] - G[(j * LD + i) * 2 + 1]);
+      G[(i * LD + j) * 2] = mr;
+      G[(i * LD + j) * 2 + 1] = mi;
+      G[(j * LD + i) * 2] = mr;
+      G[(j * LD + i) * 2 + 1] = -mi;
     }
   }
   __syncthreads();
-  // eigendecomposition of G.  D > 20: tridiagonal QL by the first wavefront (generic_dev.hpp;
-  // 1.94 -> 1.71 ms for the 513 bins of a D = 29 chain), only the principal eigenvector is kept
-  // and written to column 0 of V.  Smaller matrices: the 256-thread Jacobi is faster here (this
-  // kernel holds one workgroup per CU either way: 0.58 vs 0.70 ms at D = 16).
-  int col = 0;
-  if (D <= 20) {
-    if (lds_jacobi_heev(w.G, w.V, w.S, D, LD, tid) < 0) st |= PBBSS_ST_EIG_NOCONV;
-    __syncthreads();
-    double best = -1.79e308;
-    for (int m = 0; m < D; ++m) {
-      const double lam = w.G[(m * LD + m) * 2];
-      if (lam >= best) {  // ascending order, ties by index: the last maximum
-        best = lam;
-        col = m;
-      }
-    }
-  } else if (tid < kWave) {
+  if (tid < kWave) {
     const int lane = tid;
-    double* Zt = w.T2;                  // [D][LD] real
-    double* dv = w.T2 + LD * LD;        // the rest of T2 holds the vectors of the solver
+    double* Zt = T2;                  // [D][LD] real
+    double* dv = T2 + LD * LD;        // the rest of the slot holds the vectors of the solver
     double* ev = dv + LD + 1;
     double* tauv = ev + LD + 1;
     double* vbuf = tauv + 2 * LD;
@@ -328,11 +337,11 @@ __global__ void __launch_bounds__(kGenThreads)
     double fro2 = 0.0;
     for (int e = lane; e < D * D; e += kWave) {
       const int i = e / D, j = e - i * D;
-      fro2 += w.G[(i * LD + j) * 2] * w.G[(i * LD + j) * 2] + w.G[(i * LD + j) * 2 + 1] * w.G[(i * LD + j) * 2 + 1];
+      fro2 += G[(i * LD + j) * 2] * G[(i * LD + j) * 2] + G[(i * LD + j) * 2 + 1] * G[(i * LD + j) * 2 + 1];
     }
     fro2 = wave_sum(fro2);
     double lam, xre[LD], xim[LD];
-    if (wave_heev_ql<LD>(w.G, LD, Zt, LD, dv, ev, tauv, vbuf, wbuf, D, lane,
+    if (wave_heev_ql<LD>(G, LD, Zt, LD, dv, ev, tauv, vbuf, wbuf, D, lane,
                          (fro2 > 0.0) && isfinite(fro2), lam, xre, xim))
       st |= PBBSS_ST_EIG_NOCONV;
     // ascending order, ties by index: the last maximum
@@ -349,8 +358,8 @@ __global__ void __launch_bounds__(kGenThreads)
 #pragma unroll
       for (int r = 0; r < LD; ++r) {
         if (r < D) {
-          w.V[(r * LD) * 2] = xre[r];
-          w.V[(r * LD) * 2 + 1] = xim[r];
+          vtop[r * 2] = xre[r];
+          vtop[r * 2 + 1] = xim[r];
         }
       }
     }
@@ -367,8 +376,8 @@ __global__ void __launch_bounds__(kGenThreads)
   for (int i = tid; i < D; i += kGenThreads) {  // w_i = sum_m conj(X_mi) u_m
     double sr = 0.0, si = 0.0;
     for (int m = 0; m < D; ++m) {
-      const double ar = w.B[(m * LD + i) * 2], ai = w.B[(m * LD + i) * 2 + 1];
-      const double ur = w.V[(m * LD + col) * 2], ui = w.V[(m * LD + col) * 2 + 1];
+      const double ar = X[(m * LD + i) * 2], ai = X[(m * LD + i) * 2 + 1];
+      const double ur = vtop[m * 2], ui = vtop[m * 2 + 1];
       sr += ar * ur + ai * ui;
       si += ar * ui - ai * ur;
     }
@@ -423,7 +432,7 @@ int launch_gen_mvdr(const double* atf, const double* nn, int64_t N, int D, doubl
 }
 
 int launch_gen_ban(const double* w, const double* nn, int64_t N, int D, double* out, hipStream_t s) {
-  hipLaunchKernelGGL(gen_ban_kernel, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, s, w, nn, N, D,
+  hipLaunchKernelGGL(gen_ban_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, w, nn, N, D,
                      out);
   return ok_or_hip();
 }
@@ -431,9 +440,11 @@ int launch_gen_ban(const double* w, const double* nn, int64_t N, int D, double* 
 int launch_gen_gev(const double* t, const double* nn, int64_t N, int D, double* w, int32_t* st,
                    size_t lds_limit, hipStream_t s) {
   if (D < 2 || D > LD) return PBBSS_ERR_UNSUPPORTED;
-  int rc = prep(gen_gev_kernel, lds_limit);
-  if (rc != PBBSS_OK) return rc;
-  hipLaunchKernelGGL(gen_gev_kernel, dim3((unsigned)N), dim3(kGenThreads), kWorkBytes, s, t, nn, D,
+  if (kGevBytes > lds_limit) return PBBSS_ERR_LDS_CAPACITY;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(gen_gev_kernel),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGevBytes) != hipSuccess)
+    return PBBSS_ERR_HIP;
+  hipLaunchKernelGGL(gen_gev_kernel, dim3((unsigned)N), dim3(kGenThreads), kGevBytes, s, t, nn, D,
                      w, st);
   return ok_or_hip();
 }
