@@ -706,7 +706,9 @@ int pbbss_set_timing(pbbss_handle_t h, int enable);
  * heavy contention) never hangs: it sets PBBSS_ST_NONFINITE | PBBSS_ST_EIG_NOCONV in the status
  * words of the launch's split problems (the Python layer then raises like the reference's
  * finiteness assert) and a sticky flag that pbbss_split_error reads synchronously (0 = no
- * wait of this handle ever timed out). */
+ * wait of this handle ever timed out).  The same switch governs the generic-size path
+ * (9 <= D <= 32 or K > 6): there the r <= CUs / 16 remainder bins run as their own chain of
+ * launches on the side stream, forked and joined once per fit (no inter-workgroup waits). */
 int pbbss_set_split_tail(pbbss_handle_t h, int enable);
 /* pbbss_dhtv_calculate_mapping: workgroups that share ONE utterance (used for few utterances,
  * where a single workgroup is bound by one CU's L2 latency): 0 = automatic (default: the

@@ -518,72 +518,112 @@ PBBSS_API int pbbss_cacgmm_fit(pbbss_handle_t h, const void* y, int64_t B, int T
     int32_t* zero_bin = wc.take<int32_t>((size_t)B);
     double* csum = wc.take<double>(nmat);
     char* yt = transpose ? wc.take<char>(ny) : nullptr;
-    const pbbss::GenInverseState state{inv, inv_logdet, inv_ok};
-    const pbbss::GenInverseState state_from_eig{inv, inv_logdet, nullptr};
     TimedRegion tr(h, s);
-    int rc;
-    if (has_model) {
-      if ((rc = copy_d2d(out_eigvec, in_eigvec, nmat * D * D * 16, s)) != PBBSS_OK) return rc;
-      if ((rc = copy_d2d(out_eigval, in_eigval, nmat * D * 8, s)) != PBBSS_OK) return rc;
-      if ((rc = copy_d2d(out_weight, in_weight, nmat * 8, s)) != PBBSS_OK) return rc;
-    }
-    if (hipMemsetAsync(out_status, 0, nmat * sizeof(int32_t), s) != hipSuccess) return PBBSS_ERR_HIP;
-    // bins with an all-zero frame (flagged by the E-step / the initial weights) never take
-    // the inverse fast path
-    if (hipMemsetAsync(zero_bin, 0, (size_t)B * sizeof(int32_t), s) != hipSuccess) return PBBSS_ERR_HIP;
-    // E-steps read a (B, D, T) copy of the raw observation (lane = frame is then the contiguous
-    // axis); the covariance kernel keeps the caller's (B, T, D) array (its lanes span the channels)
-    const void* y_e = y;
-    int layout_e = PBBSS_LAYOUT_TD;
-    if (transpose) {
-      if ((rc = pbbss::launch_gen_transpose(y, o->y_is_c128, B, T, D, yt, s)) != PBBSS_OK) return rc;
-      y_e = yt;
-      layout_e = PBBSS_LAYOUT_DT;
-    }
-    for (int it = 0; it < o->iterations; ++it) {
-      const double* g_src = gamma0;
-      if (it > 0 || has_model) {
-        // from the second iteration on, classes whose inverse was accepted skip (V, lambda)
-        rc = pbbss::launch_gen_estep(y_e, o->y_is_c128, layout_e, B, T, D, K,
-                                     static_cast<const double*>(out_eigvec), out_eigval,
-                                     out_weight, K, 1, 0, activity, o->affiliation_eps, aff,
-                                     nullptr, nullptr, s, it > 0 ? state : state_from_eig,
-                                     saliency, mw, zero_bin, /*raw_dt=*/1);
+    const size_t ysz = o->y_is_c128 ? 16 : 8;
+    const size_t ld2 = pbbss::gen_state_doubles(1, D);
+    // One chain of launches for the bins [b0, b0 + nb): every array is sliced along the bins
+    // (nothing couples them under the per-bin weight modes of this entry point).
+    auto chain = [&](int64_t b0, int64_t nb, hipStream_t st) -> int {
+      const size_t m0 = (size_t)b0 * K, nm = (size_t)nb * K;
+      const char* y_c = static_cast<const char*>(y) + (size_t)b0 * T * D * ysz;
+      const double* gamma0_c = gamma0 ? gamma0 + m0 * T : nullptr;
+      const double* sal_c = saliency ? saliency + (size_t)b0 * T : nullptr;
+      const uint8_t* act_c = activity ? activity + m0 * T : nullptr;
+      double* evec_c = static_cast<double*>(out_eigvec) + m0 * D * D * 2;
+      double* eval_c = out_eigval + m0 * D;
+      double* w_c = out_weight + m0;
+      int32_t* st_c = out_status + m0;
+      double* aff_c = aff + m0 * T;
+      double* mw_c = mw + m0 * T;
+      double* cov_c = cov + m0 * D * D * 2;
+      double* csum_c = csum + m0;
+      int32_t* zero_c = zero_bin + b0;
+      int32_t* ok_c = inv_ok + m0;
+      const pbbss::GenInverseState state{inv + m0 * ld2, inv_logdet + m0, ok_c};
+      const pbbss::GenInverseState state_from_eig{inv + m0 * ld2, inv_logdet + m0, nullptr};
+      int rc;
+      if (has_model) {
+        if ((rc = copy_d2d(evec_c, static_cast<const double*>(in_eigvec) + m0 * D * D * 2,
+                           nm * D * D * 16, st)) != PBBSS_OK) return rc;
+        if ((rc = copy_d2d(eval_c, in_eigval + m0 * D, nm * D * 8, st)) != PBBSS_OK) return rc;
+        if ((rc = copy_d2d(w_c, in_weight + m0, nm * 8, st)) != PBBSS_OK) return rc;
+      }
+      if (hipMemsetAsync(st_c, 0, nm * sizeof(int32_t), st) != hipSuccess) return PBBSS_ERR_HIP;
+      // bins with an all-zero frame (flagged by the E-step / the initial weights) never take
+      // the inverse fast path
+      if (hipMemsetAsync(zero_c, 0, (size_t)nb * sizeof(int32_t), st) != hipSuccess) return PBBSS_ERR_HIP;
+      // E-steps read a (B, D, T) copy of the raw observation (lane = frame is then the contiguous
+      // axis); the covariance kernel keeps the caller's (B, T, D) array (its lanes span the channels)
+      const void* y_e = y_c;
+      int layout_e = PBBSS_LAYOUT_TD;
+      if (transpose) {
+        char* yt_c = yt + (size_t)b0 * T * D * ysz;
+        if ((rc = pbbss::launch_gen_transpose(y_c, o->y_is_c128, nb, T, D, yt_c, st)) != PBBSS_OK) return rc;
+        y_e = yt_c;
+        layout_e = PBBSS_LAYOUT_DT;
+      }
+      for (int it = 0; it < o->iterations; ++it) {
+        const double* g_src = gamma0_c;
+        if (it > 0 || has_model) {
+          // from the second iteration on, classes whose inverse was accepted skip (V, lambda)
+          rc = pbbss::launch_gen_estep(y_e, o->y_is_c128, layout_e, nb, T, D, K, evec_c, eval_c, w_c,
+                                       K, 1, 0, act_c, o->affiliation_eps, aff_c, nullptr, nullptr,
+                                       st, it > 0 ? state : state_from_eig, sal_c, mw_c, zero_c,
+                                       /*raw_dt=*/1);
+          if (rc != PBBSS_OK) return rc;
+          g_src = aff_c;
+        } else {
+          rc = pbbss::launch_gen_init_weights(y_e, o->y_is_c128, layout_e, nb, T, D, K, gamma0_c,
+                                              sal_c, mw_c, zero_c, st);
+          if (rc != PBBSS_OK) return rc;
+        }
+        rc = pbbss::launch_gen_mstep_cov(y_c, o->y_is_c128, nb, T, D, K, mw_c, g_src, sal_c,
+                                         o->weight_mode, csum_c, cov_c, w_c, st);
         if (rc != PBBSS_OK) return rc;
-        g_src = aff;
-      } else {
-        rc = pbbss::launch_gen_init_weights(y_e, o->y_is_c128, layout_e, B, T, D, K, gamma0,
-                                            saliency, mw, zero_bin, s);
+        const bool last = it + 1 == o->iterations;
+        if (!last && !o->force_eig) {
+          rc = pbbss::launch_gen_inverse(cov_c, (int64_t)nm, D, o->eigenvalue_floor, state.inv,
+                                         state.logdet, ok_c, st, zero_c, K);
+          if (rc != PBBSS_OK) return rc;
+        } else if (!last) {
+          if (hipMemsetAsync(ok_c, 0, nm * sizeof(int32_t), st) != hipSuccess) return PBBSS_ERR_HIP;
+        }
+        // the eigendecomposition the caller sees comes from the last iteration; before that it
+        // only runs for the matrices the inverse test rejected.  Status words are those of the
+        // last iteration (earlier ones are overwritten).
+        rc = pbbss::launch_gen_heev(cov_c, (int64_t)nm, D, o->covariance_norm, o->eigenvalue_floor,
+                                    eval_c, evec_c, st_c, h->cfg.lds_limit, st, last ? nullptr : ok_c);
         if (rc != PBBSS_OK) return rc;
       }
-      rc = pbbss::launch_gen_mstep_cov(y, o->y_is_c128, B, T, D, K, mw, g_src, saliency,
-                                       o->weight_mode, csum, cov, out_weight, s);
-      if (rc != PBBSS_OK) return rc;
-      const bool last = it + 1 == o->iterations;
-      if (!last && !o->force_eig) {
-        rc = pbbss::launch_gen_inverse(cov, B * K, D, o->eigenvalue_floor, inv, inv_logdet, inv_ok,
-                                       s, zero_bin, K);
+      if (o->final_predict && (out_affiliation || out_quadratic_form)) {
+        rc = pbbss::launch_gen_estep(y_e, o->y_is_c128, layout_e, nb, T, D, K, evec_c, eval_c, w_c, K,
+                                     1, 0, nullptr, 0.0,
+                                     out_affiliation ? out_affiliation + m0 * T : nullptr,
+                                     out_quadratic_form ? out_quadratic_form + m0 * T : nullptr,
+                                     nullptr, st, state_from_eig, nullptr, nullptr, nullptr,
+                                     /*raw_dt=*/1);
         if (rc != PBBSS_OK) return rc;
-      } else if (!last) {
-        if (hipMemsetAsync(inv_ok, 0, nmat * sizeof(int32_t), s) != hipSuccess) return PBBSS_ERR_HIP;
       }
-      // the eigendecomposition the caller sees comes from the last iteration; before that it
-      // only runs for the matrices the inverse test rejected.  Status words are those of the
-      // last iteration (earlier ones are overwritten).
-      rc = pbbss::launch_gen_heev(cov, B * K, D, o->covariance_norm, o->eigenvalue_floor,
-                                  out_eigval, static_cast<double*>(out_eigvec), out_status,
-                                  h->cfg.lds_limit, s, last ? nullptr : inv_ok);
-      if (rc != PBBSS_OK) return rc;
-    }
-    if (o->final_predict && (out_affiliation || out_quadratic_form)) {
-      rc = pbbss::launch_gen_estep(y_e, o->y_is_c128, layout_e, B, T, D, K,
-                                   static_cast<const double*>(out_eigvec), out_eigval, out_weight,
-                                   K, 1, 0, nullptr, 0.0, out_affiliation, out_quadratic_form,
-                                   nullptr, s, state_from_eig, nullptr, nullptr, nullptr,
-                                   /*raw_dt=*/1);
-      if (rc != PBBSS_OK) return rc;
-    }
-    return PBBSS_OK;
+      return PBBSS_OK;
+    };
+    // 2^n + 1 bins (every standard STFT size): the last bin turns a whole number of residency
+    // rounds into that number plus one straggler in EVERY kernel of the loop (513 bins x 8
+    // E-step wavefronts = 4104 on 4096 slots; 513 x 6 covariance workgroups on 768 slots).  A few
+    // remainder bins therefore run as their own chain on the side stream, concurrently with the
+    // main chain -- forked once, joined once: the bins do not interact inside the loop.
+    const int64_t per_round = h->cfg.num_cu > 0 ? h->cfg.num_cu : 256;
+    const int64_t rem = B % per_round;
+    const bool peel = h->cfg.side_stream && h->cfg.allow_split && B > per_round && rem > 0 &&
+                      rem * 16 <= per_round;
+    if (!peel) return chain(0, B, s);
+    if (hipEventRecord(h->cfg.ev_fork, s) != hipSuccess) return PBBSS_ERR_HIP;
+    if (hipStreamWaitEvent(h->cfg.side_stream, h->cfg.ev_fork, 0) != hipSuccess) return PBBSS_ERR_HIP;
+    int rc = chain(0, B - rem, s);
+    const int rc2 = chain(B - rem, rem, h->cfg.side_stream);
+    // join even after an error on one side: the caller's stream must cover everything enqueued
+    if (hipEventRecord(h->cfg.ev_join, h->cfg.side_stream) != hipSuccess) return PBBSS_ERR_HIP;
+    if (hipStreamWaitEvent(s, h->cfg.ev_join, 0) != hipSuccess) return PBBSS_ERR_HIP;
+    return rc != PBBSS_OK ? rc : rc2;
   }
   if (D < 2 || D > 8 || K < 1 || K > 6) return PBBSS_ERR_UNSUPPORTED;
   const bool f32 = o->precision == PBBSS_PRECISION_F32;

@@ -44,6 +44,36 @@ def test_single_step_and_trajectory(F, T, D, K):
         np.testing.assert_allclose(model.predict(Y), oc.em_predict(m, Y128), atol=tol)
 
 
+def test_remainder_bins_run_as_a_side_chain():
+    """2^n + 1 bins: the bins beyond a multiple of the CU count run as their own chain of launches
+    on the side stream (pbbss_cacgmm_fit, generic-size path); same results as one chain
+    (pbbss_set_split_tail(0)) and as the oracle, with saliency, activity mask and a model resume."""
+    from oracle import cacgmm as oc, synth
+    from pb_bss_amd import engine
+    from pb_bss_amd.distribution import CACGMMTrainer
+    F, T, D, K = 257 + 2, 60, 9, 2
+    Y, init = synth.make_stft(F, T, D, K, seed=7)
+    Y128 = Y.astype(np.complex128)
+    sal = np.random.default_rng(0).uniform(0.2, 1.0, size=(F, T))
+    kw = dict(iterations=4, saliency=sal)
+    ref = oc.em_fit(Y128, init, **kw)
+    got = {}
+    try:
+        for split in (1, 0):
+            engine.set_split_tail(split)
+            model = CACGMMTrainer().fit(Y, initialization=init, **kw)
+            got[split] = (model.weight, model.cacg.covariance, model.predict(Y))
+            resumed = CACGMMTrainer().fit(Y, initialization=model, iterations=2, saliency=sal)
+            got[split] += (resumed.predict(Y),)
+    finally:
+        engine.set_split_tail(1)
+    for a, b in zip(got[1], got[0]):
+        assert np.array_equal(a, b)  # same kernels on the same bins: bit-identical
+    np.testing.assert_allclose(got[1][0], ref['weight'], atol=1e-8)
+    np.testing.assert_allclose(got[1][1], _cov(ref['eigvec'], ref['eigval']), atol=1e-8)
+    np.testing.assert_allclose(got[1][2], oc.em_predict(ref, Y128), atol=1e-8)
+
+
 @pytest.mark.parametrize('F,T,D,K', [(4, 200, 6, 7), (3, 260, 12, 9), (2, 300, 9, 16), (3, 150, 24, 8)])
 def test_many_classes(F, T, D, K):
     """7 <= K <= 16 classes run on the generic path at any D (class chunks of <= 6 in gen_cov,
