@@ -84,22 +84,50 @@ __global__ void __launch_bounds__(kThreads) embed_prepare_kernel(const TS* y, in
 // ln( I_nu(x) / x^nu ) by the ascending series (all terms positive), summed in the
 // log domain by one wavefront:  sum_m (x^2/4)^m / (m! Gamma(m+nu+1)) * 2^-nu.
 __device__ double wave_log_bessel_over_power(double nu, double x, int lane) {
+  const double q = 0.25 * x * x;
   const double lx = 2.0 * log(x) - 1.3862943611198906;  // ln(x^2 / 4)
   const int M = (int)ceil(fmin(x, 1.0e6)) + 48;        // terms fall by > 4x per step past m = x
-  // lane owns the terms [m0, m0 + R): ln t_m0 from lgamma, then
-  // ln t_(m+1) = ln t_m + ln(x^2/4) - ln(m+1) - ln(m+1+nu); running log-sum-exp per lane
+  // lane owns the terms [m0, m0 + R): ln t_m0 from lgamma, then the block's sum RELATIVE to its
+  // first term by the linear recurrence t_(m+1) / t_m = (x^2/4) / ((m+1)(m+1+nu)) -- no logarithm
+  // or exponential per term (they were a serial chain of ~150 instructions per term on the one
+  // wavefront the M-step finalize waits for).  Blocks longer than 16 terms (x > 1000) re-anchor
+  // in the log domain so that the running product cannot overflow.
   const int R = (M + kWave - 1) / kWave;
   const int m0 = lane * R;
   double lt = (m0 ? (double)m0 * lx : 0.0) - lgamma((double)m0 + 1.0) - lgamma((double)m0 + nu + 1.0);
-  double mx = lt, sum = 1.0;
+  double mx = lt, sum = 0.0;   // block total = exp(mx) * sum
+  double p = 1.0, s = 1.0;     // running term and partial sum relative to the anchor term
   for (int r = 1; r < R; ++r) {
     const double m1 = (double)(m0 + r);
-    lt += lx - log(m1) - log(m1 + nu);
-    if (lt > mx) {
-      sum = sum * exp(mx - lt) + 1.0;
-      mx = lt;
+    p *= q / (m1 * (m1 + nu));
+    s += p;
+    if ((r & 15) == 15) {      // re-anchor: fold the partial sum into (mx, sum), restart at term r
+      const double la = lt + log(s - p);  // the terms before r
+      const double lp = lt + log(p);      // term r itself becomes the new anchor
+      if (sum == 0.0) {
+        mx = la;
+        sum = 1.0;
+      } else if (la > mx) {
+        sum = sum * exp(mx - la) + 1.0;
+        mx = la;
+      } else {
+        sum += exp(la - mx);
+      }
+      lt = lp;
+      p = 1.0;
+      s = 1.0;
+    }
+  }
+  {
+    const double la = lt + log(s);
+    if (sum == 0.0) {
+      mx = la;
+      sum = 1.0;
+    } else if (la > mx) {
+      sum = sum * exp(mx - la) + 1.0;
+      mx = la;
     } else {
-      sum += exp(lt - mx);
+      sum += exp(la - mx);
     }
   }
   const double gmx = wave_max(mx);
