@@ -34,11 +34,63 @@ static int cw_launch_variant(WatsonArgs wa, const EmLaunchCfg& cfg, hipStream_t 
   return hipGetLastError() == hipSuccess ? PBBSS_OK : PBBSS_ERR_HIP;
 }
 
+// Remainder problems [b_first, b_first + r) as split groups on the side stream, concurrent with
+// the main launch (em_inst.hip: launch_split; same exchange buffer, counters and epoch protocol).
+template <int K, typename YS>
+static int cw_launch_split(WatsonArgs wa, int64_t b_first, int r, const EmLaunchCfg& cfg) {
+  using Base = EmKernel<PBBSS_EM_D, K, YS, false>;
+  EmArgs& a = wa.em;
+  const int window = cfg.split_window > 256 ? 256 : cfg.split_window;
+  const int G = (a.T + window - 1) / window;
+  const size_t lds = WatsonSplit<PBBSS_EM_D, K, YS>::lds_bytes(window);
+  const size_t slab_bytes = Base::split_slab_doubles(r, G) * sizeof(double);
+  const size_t head = 256;
+  if (head + slab_bytes > cfg.xbuf_bytes) return PBBSS_ERR_UNSUPPORTED;
+  auto kfn = cwmm_em_split_kernel<PBBSS_EM_D, K, YS>;
+  if (!raise_lds_attribute(reinterpret_cast<const void*>(kfn), lds)) return PBBSS_ERR_HIP;
+  a.T_total = a.T;
+  a.split_groups = G;
+  a.split_window = window;
+  a.split_prio = cfg.split_prio;
+  a.b_first = b_first;
+  a.xcount = reinterpret_cast<unsigned*>(cfg.xbuf);
+  a.xerror = reinterpret_cast<int*>(cfg.xbuf + 128);
+  a.xslab = reinterpret_cast<double*>(cfg.xbuf + head);
+  if (hipStreamWaitEvent(cfg.side_stream, cfg.ev_fork, 0) != hipSuccess) return PBBSS_ERR_HIP;
+  a.xepoch = next_split_epoch(cfg);
+  a.xbuf_given = (unsigned)cfg.xbuf_bytes;
+  hipLaunchKernelGGL(kfn, dim3((unsigned)(r * G)), dim3(kEmThreads), lds, cfg.side_stream, wa);
+  if (hipGetLastError() != hipSuccess) return PBBSS_ERR_HIP;
+  if (hipEventRecord(cfg.ev_join, cfg.side_stream) != hipSuccess) return PBBSS_ERR_HIP;
+  return PBBSS_OK;
+}
+
 template <int K, typename YS>
 static int cw_launch_one(const WatsonArgs& wa, const EmLaunchCfg& cfg, hipStream_t stream) {
-  if (WatsonKernel<PBBSS_EM_D, K, YS, false>::lds_bytes(wa.em.T) <= cfg.lds_limit)
-    return cw_launch_variant<K, YS, false>(wa, cfg, stream);
-  return cw_launch_variant<K, YS, true>(wa, cfg, stream);
+  if (WatsonKernel<PBBSS_EM_D, K, YS, false>::lds_bytes(wa.em.T) > cfg.lds_limit)
+    return cw_launch_variant<K, YS, true>(wa, cfg, stream);
+  // 2^n + 1 bins: the r remainder problems would put one more full workgroup on r compute units
+  // and set the kernel time (257 bins: +24 %); G small member workgroups per problem instead
+  const EmArgs& a = wa.em;
+  const int64_t r = a.B % cfg.num_cu;
+  const int window = cfg.split_window > 256 ? 256 : cfg.split_window;
+  const size_t slab_need =
+      256 + EmKernel<PBBSS_EM_D, K, YS, false>::split_slab_doubles((int)r, (a.T + window - 1) / window) *
+                sizeof(double);
+  const bool split = cfg.allow_split && cfg.side_stream && cfg.xbuf && a.iterations > 0 &&
+                     a.B > cfg.num_cu && a.B <= 3 * (int64_t)cfg.num_cu && r >= 1 &&
+                     r <= kSplitMaxProblems && a.T >= 2 * cfg.split_window && a.wt == 0 &&
+                     slab_need <= cfg.xbuf_bytes;
+  if (!split) return cw_launch_variant<K, YS, false>(wa, cfg, stream);
+  WatsonArgs main_wa = wa;
+  main_wa.em.B = a.B - r;
+  if (hipEventRecord(cfg.ev_fork, stream) != hipSuccess) return PBBSS_ERR_HIP;
+  int rc = cw_launch_variant<K, YS, false>(main_wa, cfg, stream);
+  if (rc != PBBSS_OK) return rc;
+  rc = cw_launch_split<K, YS>(wa, a.B - r, (int)r, cfg);
+  if (rc != PBBSS_OK) return rc;
+  if (hipStreamWaitEvent(stream, cfg.ev_join, 0) != hipSuccess) return PBBSS_ERR_HIP;
+  return PBBSS_OK;
 }
 
 template <typename YS>

@@ -130,12 +130,15 @@ struct WatsonKernel {
   static constexpr int NA = Base::NA;
   // L.detm[k] holds kappa_k, L.rdet[k] holds ln c(kappa_k)
 
+  // tf: first frame of this workgroup's window (split groups); the (B, K, T) / (B, T) arrays are
+  // indexed with the whole problem's row stride
   template <bool FINAL>
   static __device__ void phase_e(const WatsonArgs& wa, const Lds& L, int64_t b, int tid, int wave,
-                                 int lane) {
+                                 int lane, int tf = 0) {
     tid = opaque(tid);
     lane = opaque(lane);
     const EmArgs& a = wa.em;
+    const int TS = Base::t_stride(a);
     double s[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) s[k] = 0.0;
@@ -161,13 +164,13 @@ struct WatsonKernel {
         den += g[k];
       }
       const double rden = 1.0 / fmax(den, kTiny);
-      const double sal = (!FINAL && a.saliency) ? a.saliency[(size_t)b * a.T + t] : 1.0;
+      const double sal = (!FINAL && a.saliency) ? a.saliency[(size_t)b * TS + tf + t] : 1.0;
 #pragma unroll
       for (int k = 0; k < K; ++k) {
         double gam = g[k] * rden;
         if constexpr (FINAL) {
           if (ok) {
-            size_t idx = ((size_t)b * K + k) * a.T + t;
+            size_t idx = ((size_t)b * K + k) * TS + tf + t;
             if (a.out_aff) a.out_aff[idx] = gam;
             if (a.out_logpdf) a.out_logpdf[idx] = lp[k];
           }
@@ -189,16 +192,17 @@ struct WatsonKernel {
 
   // affiliation initialisation -> M-step weights (cwmm.py:162-163 with saliency)
   static __device__ void phase_init_gamma(const EmArgs& a, const Lds& L, int64_t b, int tid,
-                                          int wave, int lane) {
+                                          int wave, int lane, int tf = 0) {
+    const int TS = Base::t_stride(a);
     double s[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) s[k] = 0.0;
     for (int t = tid; t < a.T; t += kEmThreads) {
-      double sal = a.saliency ? a.saliency[(size_t)b * a.T + t] : 1.0;
+      double sal = a.saliency ? a.saliency[(size_t)b * TS + tf + t] : 1.0;
       double inv = L.inv_n2[t];
 #pragma unroll
       for (int k = 0; k < K; ++k) {
-        double g = a.gamma0[((size_t)b * K + k) * a.T + t] * sal;
+        double g = a.gamma0[((size_t)b * K + k) * TS + tf + t] * sal;
         L.wbuf[(size_t)k * L.Tp + t] = g * inv;
         s[k] += g;
       }
@@ -422,6 +426,119 @@ template <int D, int K, typename YS, bool SPILL>
 __global__ void __launch_bounds__(kEmThreads, em_waves_per_simd(K)) cwmm_em_kernel(WatsonArgs wa) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   WatsonKernel<D, K, YS, SPILL>::run(wa, smem);
+}
+
+// Remainder problems of 2^n + 1-bin utterances as split groups, the scheme of the cACGMM kernel
+// (cacgmm_em.hpp: run_split): G member workgroups share one bin's frames (windows of
+// `split_window` frames), run E and M on their window, exchange the packed covariance sums and
+// class sums through L2 slabs (EmKernel::split_exchange -- the M-phase accumulators are the same
+// arrays) and then EVERY member factors every class from the identical totals: mode, kappa and
+// ln c need no hand-off, the factorisation of a class sits on one wavefront either way.  Only
+// member 0 writes the model.
+template <int D, int K, typename YS>
+struct WatsonSplit {
+  using W = WatsonKernel<D, K, YS, false>;
+  using Base = typename W::Base;
+  using Lds = typename W::Lds;
+
+  static __host__ __device__ size_t lds_bytes(int window) { return W::lds_bytes(window); }
+
+  static __device__ void run(const WatsonArgs& gwa, char* smem, int mblock, int nblocks) {
+    const EmArgs& ga = gwa.em;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int G = ga.split_groups;
+    const int prob = mblock / G, g = mblock % G;
+    const int nprob = nblocks / G;
+    const int64_t b = ga.b_first + prob;
+    const int tf = g * ga.split_window;
+    switch (ga.split_prio) {
+      case 1: __builtin_amdgcn_s_setprio(1); break;
+      case 2: __builtin_amdgcn_s_setprio(2); break;
+      case 3: __builtin_amdgcn_s_setprio(3); break;
+      default: break;
+    }
+    WatsonArgs wa = gwa;  // this workgroup's window; only member 0 writes the model
+    EmArgs& a = wa.em;
+    a.T = min(ga.split_window, ga.T_total - tf);
+    if (g != 0) {
+      wa.out_mode = nullptr;
+      wa.out_conc = nullptr;
+    }
+    const Lds L = Base::carve(smem, ga.split_window, nullptr);
+    double* knot1 = reinterpret_cast<double*>(smem + Base::lds_bytes(ga.split_window));
+    uint32_t* jtab = reinterpret_cast<uint32_t*>(knot1 + kWatsonKnotTable);
+    if (wave == 0) jacobi_table_build<D>(jtab, lane);
+    if (tid < kWatsonKnotTable && wa.spline_t && wa.n_coef > 2) {
+      const int S = (wa.n_coef - 2 + kWatsonKnotTable - 1) / kWatsonKnotTable;
+      knot1[tid] = wa.spline_t[min(2 + tid * S, wa.n_coef - 1)];
+    }
+    if (tid < K) {
+      L.status[tid] = 0;
+      // the members OR their bits into the status words at the end; member 0 zeroes them first
+      // (a poison bit OR-ed in before this store is OR-ed in again by member 0 at its own end)
+      if (g == 0 && a.out_status) a.out_status[(size_t)b * K + tid] = 0;
+    }
+    if (tid == 0) *L.flags = 0;
+    __syncthreads();
+    Base::phase_load(a, L, b, tid, tf);
+    __syncthreads();
+    const bool model_in = (a.gamma0 == nullptr);
+    if (model_in) {
+      for (int k = wave; k < K; k += kEmWaves) W::prep_from_model(wa, L, b, k, lane);
+    } else {
+      W::phase_init_gamma(a, L, b, tid, wave, lane, tf);
+    }
+    __syncthreads();
+    double pvre = 0.0, pvim = 0.0;
+    for (int it = 0; it < a.iterations; ++it) {
+      if (it > 0 || model_in) {
+        // windows are <= 256 frames: waves that own no frame skip the phase
+        if ((wave << 6) < a.T) {
+          W::template phase_e<false>(wa, L, b, tid, wave, lane, tf);
+        } else if (lane < K) {
+          L.red[wave * K + lane] = 0.0;
+        }
+        __syncthreads();
+      }
+      switch (wave) {
+        case 0: Base::template phase_m<0>(a, L, lane); break;
+        case 1: Base::template phase_m<1>(a, L, lane); break;
+        case 2: Base::template phase_m<2>(a, L, lane); break;
+        default: Base::template phase_m<3>(a, L, lane); break;
+      }
+      __syncthreads();
+      Base::split_exchange(a, L, prob, nprob, g, it, tid);
+      const bool last = (it == a.iterations - 1);
+      if (wave < K) W::factor_class(wa, L, knot1, jtab, b, wave, lane, last, it > 0, pvre, pvim);
+      __syncthreads();
+    }
+    if (tid < K) {
+      if (g == 0 && a.out_weight && a.iterations > 0) a.out_weight[(size_t)b * K + tid] = L.wgt[tid];
+      const int bits = (g == 0 ? L.status[tid] : 0) |
+                       (Base::split_failed(a) ? (PBBSS_ST_EIG_NOCONV | PBBSS_ST_NONFINITE) : 0);
+      if (a.out_status && bits) atomicOr(a.out_status + (size_t)b * K + tid, bits);
+    }
+    if (a.final_predict) W::template phase_e<true>(wa, L, b, tid, wave, lane, tf);
+    // the member that leaves last puts the problem's arrival counter back to zero
+    if (tid == 0) {
+      unsigned* ex = a.xcount + 8 + prob;
+      const unsigned before =
+          __hip_atomic_fetch_add(ex, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (before == (unsigned)(G - 1)) {
+        __hip_atomic_store(a.xcount + prob, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(a.xcount + 16 + prob, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(ex, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+};
+
+template <int D, int K, typename YS>
+__global__ void __launch_bounds__(kEmThreads, em_waves_per_simd(K)) cwmm_em_split_kernel(WatsonArgs wa) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  WatsonSplit<D, K, YS>::run(wa, smem, blockIdx.x, gridDim.x);
 }
 
 }  // namespace pbbss

@@ -119,3 +119,28 @@ def test_cwmm_frame_varying_weights_on_the_device(with_sal):
     assert np.abs(m.weight - ref['weight']).max() < 1e-10
     assert np.abs(m.complex_watson.concentration - ref['concentration']).max() < 1e-7
     assert np.abs(m.predict(Y) - ow.cwmm_predict(ref, Y128)).max() < 1e-8
+
+
+@pytest.mark.parametrize('F,T,D,K,with_sal', [(257, 200, 4, 2, False), (259, 150, 6, 3, True)])
+def test_cwmm_remainder_bins_as_split_groups(F, T, D, K, with_sal):
+    """2^n + 1 bins: the bins beyond a multiple of the CU count run as split groups on the side
+    stream (csrc/cwmm.hpp: WatsonSplit) -- same model as the one-launch fit
+    (pbbss_set_split_tail(0)) to rounding of the frame sums, and as the oracle."""
+    from pb_bss_amd import engine
+    from pb_bss_amd.distribution import CWMMTrainer
+    from oracle import cwmm as ow, synth
+    Y, init = synth.make_stft(F, T, D, K, seed=F + D)
+    Y128 = Y.astype(np.complex128)
+    sal = np.random.default_rng(F).uniform(0.2, 1.0, size=(F, T)) if with_sal else None
+    ref = ow.cwmm_fit(Y128, init, iterations=6, saliency=sal)
+    want = ow.cwmm_predict(ref, Y128)
+    got = {}
+    try:
+        for split in (1, 0):
+            engine.set_split_tail(split)
+            got[split] = CWMMTrainer().fit_predict(Y, initialization=init, iterations=6, saliency=sal)
+    finally:
+        engine.set_split_tail(1)
+    assert np.abs(got[1] - want).max() < 1e-7
+    assert np.abs(got[1] - got[0]).max() < 1e-9
+    assert np.abs(got[1][256:] - want[256:]).max() < 1e-7  # the split bins themselves
