@@ -291,6 +291,39 @@ def pcie_inclusive(Y0, init0, iters, reps=10):
                     'never reported as `value`'}
 
 
+def single_utterance_chain(Y0, init0, iters, beamformer, reps=10):
+    """Latency of the chain a caller runs on ONE utterance with everything resident in HBM: EM fit +
+    predict, DHTV permutation alignment of the masks, PSD -> beamformer -> apply.  Wall clock per
+    stage with a synchronisation in between (so the stages add up to slightly more than a chained
+    call); a secondary figure next to `value`."""
+    import torch
+    from pb_bss_amd import _lib
+    from pb_bss_amd.pipeline import device_ops as ops, _chain_after_masks
+    Y = _lib.to_device(Y0)[None]
+    init = _lib.to_device(init0)[None]
+    Fb = Y.shape[-3]
+    stages = {'em_fit_predict_ms': [], 'dhtv_mapping_ms': [], 'align_psd_bf_apply_ms': []}
+
+    def lap(name, fn):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        r = fn()
+        torch.cuda.synchronize()
+        stages[name].append((time.perf_counter() - t1) * 1e3)
+        return r
+    for _ in range(reps + 2):
+        masks = lap('em_fit_predict_ms', lambda: ops.em_masks(Y, init, iters))
+        mapping = lap('dhtv_mapping_ms', lambda: ops.dhtv_mapping(
+            masks.transpose(-3, -2).contiguous(), 2 * (Fb - 1)))
+        lap('align_psd_bf_apply_ms', lambda: _chain_after_masks(Y, masks, mapping, ops, beamformer))
+    med = {k: float(np.median(v[2:])) for k, v in stages.items()}
+    med['total_ms'] = float(sum(med.values()))
+    med['what'] = ('one utterance, inputs resident in HBM, median of %d runs per stage with a '
+                   'synchronisation after each: EM (%d iterations) + predict, DHTV alignment of the '
+                   'masks, alignment + PSD + %s + apply' % (reps, iters, beamformer))
+    return med
+
+
 def emit(line, use_dist):
     import torch.distributed as dist
     if use_dist:
@@ -870,6 +903,8 @@ def main():
         out, (Y0, init0) = res
         if world == 1:
             out['host_numpy_in_out'] = pcie_inclusive(Y0, init0, args.iters)
+            out['single_utterance_chain'] = single_utterance_chain(Y0, init0, args.iters,
+                                                                   args.beamformer)
         # ---- CPU baseline on this host, bounded sample ------------------------
         if world == 1 and args.cpu_iters > 0:
             out['cpu_baseline'] = cpu_baseline_em(Y0, init0, args.cpu_iters)
