@@ -82,6 +82,9 @@ class _PermutationAlignment:
         return apply_mapping(mask, mapping)
 
 
+_DEVICE_PLANS = {}  # (plan bytes, device) -> int32 (P, 3) device tensor
+
+
 class DHTVPermutationAlignment(_PermutationAlignment):
     """Segment-wise centroid alignment (reference :133-355; does not solve the
     global permutation problem)."""
@@ -156,8 +159,15 @@ class DHTVPermutationAlignment(_PermutationAlignment):
         assert K < 10, (K, 'Sure?')
         plan = np.asarray(self.alignment_plan, dtype=np.int32)
         assert plan[:, 2].max() <= F and plan[:, 1].min() >= 0, (plan, F)
+        # the plan is a few hundred bytes: upload it once per (plan, device), not per call
+        key = (plan.tobytes(), str(m.device))
+        plan_dev = _DEVICE_PLANS.get(key)
+        if plan_dev is None:
+            if len(_DEVICE_PLANS) > 64:
+                _DEVICE_PLANS.clear()
+            plan_dev = _DEVICE_PLANS[key] = _lib.to_device(plan).to(m.device)
         mapping, _, st = engine.dhtv_calculate_mapping(
-            m.reshape(-1, K, F, T).contiguous(), _lib.to_device(plan).to(m.device),
+            m.reshape(-1, K, F, T).contiguous(), plan_dev,
             optimal=(self.algorithm == 'optimal'), metric=self.similarity_metric)
         if int(st.max().item()) != 0:
             raise ValueError('score matrix is infeasible')  # reference :512-514
