@@ -1257,7 +1257,10 @@ static bool launch_slice(const double* mask, int64_t U, int K, int F, int T, con
     const int G = (T + 16 * NF - 1) / (16 * NF);
     if (G < 2) break;
     if (want_team >= 2 && G > want_team && NF < 8 && K * NF * 2 <= 24) continue;
-    if ((int64_t)G * U > num_cu) continue;  // the team must be co-resident
+    // every team must be co-resident (one 512-thread workgroup per compute unit): leave half the
+    // chip as margin once many teams are in flight -- a batch that large is served well enough
+    // by one workgroup per utterance
+    if ((int64_t)G * U > (U <= 4 ? num_cu : num_cu / 2)) continue;
     const size_t lds = slice_lds_bytes(K, NF, F);
     if (lds > lds_limit) continue;
     // exchange area inside the utterance's feature scratch
