@@ -810,7 +810,9 @@ __global__ void __launch_bounds__(kSliceThreads)
   };
 
   for (int seg = 0; seg < P; ++seg) {
-    const int iterations = plan[3 * seg], start = plan[3 * seg + 1], end = plan[3 * seg + 2];
+    // segments are clipped to the bins that exist (the Python layer asserts it; a raw C caller may not)
+    const int iterations = plan[3 * seg], start = max(plan[3 * seg + 1], 0),
+              end = min(plan[3 * seg + 2], F);
     const int nb = end - start;
     if (nb <= 0) continue;
     const double inv_n = 1.0 / (double)nb;
