@@ -144,3 +144,24 @@ def test_cwmm_remainder_bins_as_split_groups(F, T, D, K, with_sal):
     assert np.abs(got[1] - want).max() < 1e-7
     assert np.abs(got[1] - got[0]).max() < 1e-9
     assert np.abs(got[1][256:] - want[256:]).max() < 1e-7  # the split bins themselves
+
+
+def test_cwmm_config4_full_size():
+    """BASELINE configs[3] at its full size: 6-mic array, F = 257, T = 800, K = 3 (257 = 256 + 1
+    bins: the last one runs as split groups), Watson trainer -> MVDR-Souden, against the oracle."""
+    from pb_bss_amd.distribution import CWMMTrainer
+    from pb_bss_amd import extraction as ex
+    from oracle import beamformer as ob, cwmm as ow, synth
+    F, T, D, K = 257, 800, 6, 3
+    Y, init = synth.make_stft(F, T, D, K, seed=14)
+    Y128 = Y.astype(np.complex128)
+    masks = CWMMTrainer().fit_predict(Y, initialization=init, iterations=12)
+    ref = ow.cwmm_predict(ow.cwmm_fit(Y128, init, iterations=12), Y128)
+    assert masks.shape == (F, K, T)
+    assert np.abs(masks - ref).max() < 1e-6
+    assert np.abs(masks[256] - ref[256]).max() < 1e-6
+    psd = ex.get_power_spectral_density_matrix(Y.transpose(0, 2, 1), masks)
+    psd_ref = ob.psd(Y128.transpose(0, 2, 1), ref)
+    w = ex.get_mvdr_vector_souden(psd[:, 0], psd[:, 1] + psd[:, 2])
+    w_ref = ob.mvdr_souden(psd_ref[:, 0], psd_ref[:, 1] + psd_ref[:, 2])
+    assert np.abs(w - w_ref).max() < 1e-5 * np.abs(w_ref).max()

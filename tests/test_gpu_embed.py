@@ -429,3 +429,22 @@ def test_joint_remainder_bins_as_member_workgroups(kind, kw):
     want = oe.joint_model_predict(ref, Y.astype(np.complex128), e.astype(np.float64))
     assert np.abs(on[1] - want).max() < 1e-6
     assert np.abs(on[1][-2:] - want[-2:]).max() < 1e-6   # the two member-handled bins
+
+
+@pytest.mark.parametrize('kind', ['gaussian', 'vmf'])
+def test_joint_models_config5_full_size(kind):
+    """BASELINE configs[4] at its full size: F = 513, T = 500, 8 mics, K = 3, 40-dim embeddings
+    (256 500 points in ONE spectral mixture; the 513th bin as member workgroups), 4 EM
+    iterations against the oracle's reference loop."""
+    from pb_bss_amd.distribution import GCACGMMTrainer, VMFCACGMMTrainer
+    from oracle import embed as oe, synth
+    F, T, D, K, E = 513, 500, 8, 3, 40
+    Y, e, init = synth.make_joint(F, T, D, K, E, seed=3)
+    trainer = GCACGMMTrainer() if kind == 'gaussian' else VMFCACGMMTrainer()
+    kw = {} if kind == 'gaussian' else dict(max_concentration=80.)
+    masks = trainer.fit_predict(Y, e, initialization=init, iterations=4, **kw)
+    ref = oe.joint_fit(kind, Y.astype(np.complex128), e.astype(np.float64), init, 4, **kw)
+    want = oe.joint_model_predict(ref, Y.astype(np.complex128), e.astype(np.float64))
+    assert masks.shape == (F, K, T)
+    assert np.abs(masks - want).max() < 1e-6
+    assert np.abs(masks[512] - want[512]).max() < 1e-6
