@@ -78,7 +78,7 @@ def test_split_tail_shared_weight_and_packed_fits_concurrently():
         # case, also here) or poison the status words, which the Python layer raises on.
         try:
             return shared_fit()
-        except RuntimeError as e:
+        except (RuntimeError, AssertionError) as e:  # the status check of the Python layer
             return ('flagged', repr(e))
 
     alone = [split_fit(), shared_fit(), packed_fit()]
@@ -94,7 +94,7 @@ def test_split_tail_shared_weight_and_packed_fits_concurrently():
     together = _run_threads([split_fit, shared_job, packed_fit])
     for name, a, b in zip(('split-tail', 'shared-weight', 'packed-FP32'), alone, together):
         if name == 'shared-weight' and isinstance(b[0], str):
-            continue  # reported, not hidden (seen about once in thirty runs of the whole suite)
+            continue  # reported, not hidden (happens in a fraction of the runs of this scenario)
         if name == 'shared-weight' and (b[2] != 0 or int(b[1].max()) & 3):
             continue  # the same report through the status words / sticky flag
         assert b[2] == 0, f'{name}: a bounded spin ran out under contention'
