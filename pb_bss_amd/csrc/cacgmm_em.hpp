@@ -1652,11 +1652,19 @@ struct EmKernel {
   // Counters are monotonic: gcount[16 g] posts, gcount[16 g + 8] reduced slices.
   static constexpr int kSliceFrames = 8;
 
+  // The cooperative kernel needs EVERY workgroup of a group co-resident; other kernels of the
+  // process competing for the compute units can keep that from happening for as long as they
+  // run (tests/test_gpu_contention.py).  The wait is therefore short (~1 s: a healthy barrier
+  // takes microseconds) and sticky -- once one workgroup has given up, every later wait of the
+  // launch falls through at once -- and the host layer repeats a fit that was reported this way
+  // on the step-wise path, which needs no co-residency.
+  static constexpr unsigned kSharedSpinLimit = 3000000u;
   static __device__ void shared_spin(const EmArgs& a, unsigned* cnt, unsigned target) {
     unsigned spins = 0;
     while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
       __builtin_amdgcn_s_sleep(1);
-      if (++spins > kSpinLimit) {
+      if ((spins & 4095u) == 0u && split_failed(a)) break;
+      if (++spins > kSharedSpinLimit) {
         split_timeout(a);
         break;
       }

@@ -157,6 +157,17 @@ def em_fit_shared(y, K, group, *, weight_mode, gamma0=None, model=None, iteratio
         return None
     _lib.check(rc, f'cacgmm_fit_shared(B={B},group={group},T={T},D={D},K={K})')
     if check_status:
+        poison = _lib.ST_NONFINITE | _lib.ST_EIG_NOCONV
+        if iterations > 0 and bool(((out_st & poison) == poison).all().item()) \
+                and split_error(dev.index):
+            # every status word carries the time-out pattern and the handle's wait flag is up:
+            # the cooperative launch did not get its workgroups co-resident (other kernels of
+            # this process held the compute units).  Not a numerical failure: say "not served"
+            # and let the caller run the step-wise loop, which needs no co-residency.
+            import warnings
+            warnings.warn('cooperative shared-weight launch timed out waiting for co-residency; '
+                          'repeating the fit step by step', RuntimeWarning, stacklevel=2)
+            return None
         _status_raise_em(out_st, 'CACGMMTrainer.fit')
     return dict(eigvec=out_vec, eigval=out_val, weight=out_w, status=out_st,
                 affiliation=out_aff, quadratic_form=out_q)

@@ -73,13 +73,21 @@ def test_split_tail_shared_weight_and_packed_fits_concurrently():
 
     def shared_job():
         # The cooperative kernel needs all 513 workgroups co-resident.  With two other kernels
-        # competing for the compute units that can take arbitrarily long; the contract is that it
-        # never hangs and is never silently wrong: the bounded waits either succeed (the normal
-        # case, also here) or poison the status words, which the Python layer raises on.
-        try:
-            return shared_fit()
-        except (RuntimeError, AssertionError) as e:  # the status check of the Python layer
-            return ('flagged', repr(e))
+        # competing for the compute units that fails in a fraction of the runs; the contract is
+        # that it never hangs and is never silently wrong: the bounded (~1 s, sticky) wait poisons
+        # the status words, `engine.em_fit_shared` recognises the pattern and returns None
+        # ("not served") and the trainer repeats the fit step by step.  This job calls the engine
+        # directly, so it reports which of the two happened.
+        import warnings
+        r = None
+        for _ in range(reps):
+            with warnings.catch_warnings():
+                warnings.simplefilter('ignore', RuntimeWarning)
+                r = engine.em_fit_shared(y2, K, F, weight_mode=_lib.WEIGHT_SHARED_K, gamma0=g2,
+                                         iterations=iters, final_predict=True)
+            if r is None:
+                return ('not served', None, 0)
+        return _lib.to_host(r['affiliation']), _lib.to_host(r['status']), engine.split_error()
 
     alone = [split_fit(), shared_fit(), packed_fit()]
     # (1) the two protocols that only need their 8 member workgroups co-resident, two handles each
@@ -94,9 +102,7 @@ def test_split_tail_shared_weight_and_packed_fits_concurrently():
     together = _run_threads([split_fit, shared_job, packed_fit])
     for name, a, b in zip(('split-tail', 'shared-weight', 'packed-FP32'), alone, together):
         if name == 'shared-weight' and isinstance(b[0], str):
-            continue  # reported, not hidden (happens in a fraction of the runs of this scenario)
-        if name == 'shared-weight' and (b[2] != 0 or int(b[1].max()) & 3):
-            continue  # the same report through the status words / sticky flag
+            continue  # reported as "not served" (a fraction of the runs of this scenario)
         assert b[2] == 0, f'{name}: a bounded spin ran out under contention'
         assert int(b[1].max()) & 3 == 0, f'{name}: poisoned status words'
         assert np.array_equal(a[0], b[0]), (name, np.abs(a[0] - b[0]).max())
@@ -140,3 +146,35 @@ def test_split_tail_fit_with_an_rccl_gather_in_flight():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_shared_weight_trainer_falls_back_when_the_cooperative_launch_is_not_served():
+    """The trainer-level view of the same situation: CACGMMTrainer.fit with bin-constant weights
+    while two other fits hammer the GPU -- whichever way the cooperative launch goes, the model
+    equals the solo result to rounding (cooperative kernel and step-wise loop agree to 1e-10)."""
+    import warnings
+    from pb_bss_amd import _lib
+    from pb_bss_amd.distribution import CACGMMTrainer
+    from pb_bss_amd.testing import synth
+    F, T, D, K, iters = 513, 500, 8, 3, 8
+    Y, init = synth.make_stft(F, T, D, K, seed=5)
+    y, g0 = _lib.to_device(Y), _lib.to_device(init)
+    kw = dict(initialization=g0, iterations=iters, weight_constant_axis=(-3, -1))
+
+    def shared_trainer():
+        out = None
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore', RuntimeWarning)
+            for _ in range(4):
+                out = CACGMMTrainer().fit_predict(y, **kw)
+        return _lib.to_host(out)
+
+    def other():
+        out = None
+        for _ in range(6):
+            out = CACGMMTrainer().fit_predict(y, initialization=g0, iterations=12)
+        return _lib.to_host(out)
+
+    alone = shared_trainer()
+    together = _run_threads([other, shared_trainer, other])
+    assert np.abs(together[1] - alone).max() < 1e-8
