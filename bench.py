@@ -74,6 +74,10 @@ def parse():
     p.add_argument('--iters', type=int, default=100, help='EM iterations per fit')
     p.add_argument('--cpu-iters', type=int, default=100,
                    help='EM iterations of the CPU baseline sample (0 = skip)')
+    p.add_argument('--extras', choices=('auto', 'off'), default='auto',
+                   help="'off': skip the secondary single-utterance figures (host_numpy_in_out, "
+                        "single_utterance_chain) -- the profiling runs want the timed steps to be "
+                        "the last EM launches of the process")
     p.add_argument('--check-bins', type=int, default=24,
                    help='bins checked against the oracle per utterance at N = 1; at N > 1 '
                         'max(3, check_bins / N^2) bins of EVERY rank\'s shard of EVERY utterance '
@@ -901,7 +905,7 @@ def main():
     out = None
     if rank == 0:
         out, (Y0, init0) = res
-        if world == 1:
+        if world == 1 and args.extras == 'auto':
             out['host_numpy_in_out'] = pcie_inclusive(Y0, init0, args.iters)
             out['single_utterance_chain'] = single_utterance_chain(Y0, init0, args.iters,
                                                                    args.beamformer)
