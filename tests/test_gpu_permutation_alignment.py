@@ -118,6 +118,8 @@ def test_team_kernel_equals_single_workgroup_kernel_and_oracle(K, F, T, stft):
     (5, 129, 333, [[6, 10, 90], [2, 0, 60], [2, 50, 129]]),  # 25 scores per bin, ragged frames
     (2, 65, 1000, [[4, 0, 65], [3, 5, 6]]),             # one-bin segment, 16 slices
     (4, 257, 128, [[20, 70, 170], [2, 0, 110], [2, 150, 257]]),
+    (1, 65, 200, [[3, 0, 65]]),                          # one class: nothing to permute
+    (3, 33, 65, [[5, 0, 33], [2, 3, 20]]),              # second workgroup holds ONE frame
 ])
 def test_frame_slice_kernel_shapes_metrics_and_features(K, F, T, plan):
     """frame-slice kernel (pbbss_set_dhtv_team >= 2): every metric and both solvers against
