@@ -298,6 +298,8 @@ def test_watson_log_norm_for_many_sensors():
     ('gaussian', 12, 8, {}),                                  # D = 12, K = 8
     ('gaussian', 6, 7, dict(weight_constant_axis=(-3,))),     # few sensors, 7 classes
     ('vmf', 5, 8, dict(max_concentration=80.)),
+    ('gaussian', 10, 2, dict(weight_constant_axis=(-2,))),      # uniform class weights
+    ('gaussian', 11, 3, dict(weight_constant_axis=(-3, -2, -1), covariance_type='diagonal')),
     ('gaussian', 12, 3, dict(weight_constant_axis=(-3,), inline_permutation_alignment=True)),
     ('vmf', 9, 4, dict(weight_constant_axis=(-3, -1), inline_permutation_alignment=True,
                        max_concentration=80.)),
