@@ -1527,6 +1527,7 @@ PBBSS_API int pbbss_joint_fit(pbbss_handle_t h, const void* observation, const v
   const size_t ngp = g_full ? pbbss::gauss_full_partial_doubles(1, N, E, K) : 0;
   const size_t nconst = g_diag ? pbbss::diag_consts_doubles(K, E) : 0;
   const size_t nmat = (size_t)F * K;
+  const size_t ntmp = pbbss::joint_weight_tmp_doubles(o->weight_mode, F, K, T);
   const size_t ninv = gen ? pbbss::gen_state_doubles((int64_t)nmat, D) : 0;
   const size_t nyt = gen ? (size_t)F * T * D * (o->obs_is_c128 ? 16 : 8) : 0;
   const size_t need_gen =
@@ -1536,7 +1537,7 @@ PBBSS_API int pbbss_joint_fit(pbbss_handle_t h, const void* observation, const v
           : 0;
   const size_t need = need_gen + WorkCarver::pad((size_t)E * N * esz) + 2 * WorkCarver::pad(nfkt * 8) +
                       WorkCarver::pad(np * 8) + 2 * WorkCarver::pad((size_t)K * 8) +
-                      WorkCarver::pad((size_t)F * K * 8) + WorkCarver::pad(nstate * 8) +
+                      WorkCarver::pad(ntmp * 8) + WorkCarver::pad(nstate * 8) +
                       (g_full ? 2 * WorkCarver::pad(nfkt * 8) + WorkCarver::pad(ngp * 8) +
                                     WorkCarver::pad((size_t)K * E * E * 8)
                               : 0) +
@@ -1550,7 +1551,7 @@ PBBSS_API int pbbss_joint_fit(pbbss_handle_t h, const void* observation, const v
   double* part = wc.take<double>(np);
   double* offset = wc.take<double>(K);
   double* prec = wc.take<double>(K);
-  double* tmp = wc.take<double>((size_t)F * K);
+  double* tmp = wc.take<double>(ntmp);
   double* jstate = wc.take<double>(nstate);
   double* wkn = g_full ? wc.take<double>(nfkt) : nullptr;    // (K, F*T) class weights
   double* lpkn = g_full ? wc.take<double>(nfkt) : nullptr;   // (K, F*T) log-pdf

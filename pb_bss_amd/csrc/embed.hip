@@ -888,25 +888,66 @@ __global__ void __launch_bounds__(kThreads) joint_normalize_kernel(double* out, 
   for (int k = 0; k < K; ++k) out[(size_t)k * T + t] /= tot;
 }
 
-// mode 3 (-3,): thread t: sum over f, normalised over k  -> (K,T)
+// mode 3 (-3,): sum over f, normalised over k  -> (K,T). One thread per frame walking all bins
+// is 4 workgroups at T = 1000 and 445 us of load latency; the bins are cut into kColSlices
+// slices (grid.y), the slice sums go to tmp (slice, K, T) and a second small kernel adds them
+// in slice order and normalises.
 __global__ void __launch_bounds__(kThreads)
-    joint_colsum_kernel(const double* aff, const double* sal, int64_t F, int K, int T,
-                        int normalize, double* out) {
+    joint_colsum_part_kernel(const double* aff, const double* sal, int64_t F, int K, int T,
+                             double* part) {
   const int t = blockIdx.x * kThreads + threadIdx.x;
   if (t >= T) return;
+  const int64_t per = (F + gridDim.y - 1) / gridDim.y;
+  const int64_t f0 = per * blockIdx.y;
+  const int64_t f1 = f0 + per < F ? f0 + per : F;
   double s[kEmbedMaxK];
 #pragma unroll
   for (int k = 0; k < kEmbedMaxK; ++k) s[k] = 0.0;
-  for (int64_t f = 0; f < F; ++f) {
+  for (int64_t f = f0; f < f1; ++f) {
     const double sv = sal ? sal[(size_t)f * T + t] : 1.0;
 #pragma unroll
     for (int k = 0; k < kEmbedMaxK; ++k)
       if (k < K) s[k] += aff[((size_t)f * K + k) * T + t] * sv;
   }
-  double tot = 0.0;
 #pragma unroll
   for (int k = 0; k < kEmbedMaxK; ++k)
-    if (k < K) tot += s[k];
+    if (k < K) part[((size_t)blockIdx.y * K + k) * T + t] = s[k];
+}
+
+// 32 frames x 8 slice groups per workgroup: every thread adds its group's slices (c = g, g + 8,
+// ...), the groups meet in LDS and are added in group order.
+constexpr int kColFinFrames = 32;
+constexpr int kColFinGroups = kThreads / kColFinFrames;
+__global__ void __launch_bounds__(kThreads)
+    joint_colsum_fin_kernel(const double* part, int slices, int K, int T, int normalize,
+                            double* out) {
+  __shared__ double red[kColFinGroups][kEmbedMaxK][kColFinFrames];
+  const int tl = threadIdx.x % kColFinFrames, g = threadIdx.x / kColFinFrames;
+  const int t = blockIdx.x * kColFinFrames + tl;
+  double s[kEmbedMaxK];
+#pragma unroll
+  for (int k = 0; k < kEmbedMaxK; ++k) s[k] = 0.0;
+  if (t < T) {
+    for (int c = g; c < slices; c += kColFinGroups) {
+#pragma unroll
+      for (int k = 0; k < kEmbedMaxK; ++k)
+        if (k < K) s[k] += part[((size_t)c * K + k) * T + t];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < kEmbedMaxK; ++k) red[g][k][tl] = s[k];
+  __syncthreads();
+  if (g != 0 || t >= T) return;
+  double tot = 0.0;
+#pragma unroll
+  for (int k = 0; k < kEmbedMaxK; ++k) {
+    if (k < K) {
+      double v = 0.0;
+      for (int gg = 0; gg < kColFinGroups; ++gg) v += red[gg][k][tl];
+      s[k] = v;
+      tot += v;
+    }
+  }
 #pragma unroll
   for (int k = 0; k < kEmbedMaxK; ++k)
     if (k < K) out[(size_t)k * T + t] = normalize ? s[k] / tot : s[k];
@@ -1307,6 +1348,14 @@ int launch_vmf_em(const void* y, int y_is_f64, int64_t B, int64_t N, int E, int 
   return ok_or_hip();
 }
 
+static int joint_colsum_slices(int64_t F) { return F < 64 ? (int)(F < 1 ? 1 : F) : 64; }
+
+size_t joint_weight_tmp_doubles(int mode, int64_t F, int K, int T) {
+  const size_t rows = (size_t)F * K;
+  const size_t cols = mode == 3 ? (size_t)joint_colsum_slices(F) * K * T : 0;
+  return rows > cols ? rows : cols;
+}
+
 int launch_joint_weight(int mode, const double* aff, const double* sal, int64_t F, int K, int T,
                         double* tmp, double* out_weight, hipStream_t s,
                         const PartialReduce* reduce) {
@@ -1330,8 +1379,14 @@ int launch_joint_weight(int mode, const double* aff, const double* sal, int64_t 
       }
       break;
     case 3:
-      hipLaunchKernelGGL(joint_colsum_kernel, dim3((unsigned)((T + kThreads - 1) / kThreads)),
-                         dim3(kThreads), 0, s, aff, sal, F, K, T, reduce ? 0 : 1, out_weight);
+    {
+      const int slices = joint_colsum_slices(F);
+      const unsigned gx = (unsigned)((T + kThreads - 1) / kThreads);
+      hipLaunchKernelGGL(joint_colsum_part_kernel, dim3(gx, (unsigned)slices), dim3(kThreads), 0, s,
+                         aff, sal, F, K, T, tmp);
+      hipLaunchKernelGGL(joint_colsum_fin_kernel,
+                         dim3((unsigned)((T + kColFinFrames - 1) / kColFinFrames)), dim3(kThreads), 0,
+                         s, tmp, slices, K, T, reduce ? 0 : 1, out_weight);
       if (reduce) {
         if (int rc = reduce->fn(reduce->ctx, out_weight, (size_t)K * T, s); rc != PBBSS_OK)
           return rc;
@@ -1339,6 +1394,7 @@ int launch_joint_weight(int mode, const double* aff, const double* sal, int64_t 
                            dim3(kThreads), 0, s, out_weight, K, T);
       }
       break;
+    }
     case 4:
       hipLaunchKernelGGL(joint_fill_kernel, dim3(1), dim3(1), 0, s, out_weight, 1.0);
       break;

@@ -81,9 +81,10 @@ int launch_vmf_em(const void* y, int y_is_f64, int64_t B, int64_t N, int E, int 
 //   mode 2 'k' (-3,-1): sum_ft / sum_k sum_ft                 -> (K)
 //   mode 3 'kt' (-3,) : sum_f / sum_k sum_f                   -> (K,T)
 //   mode 4 ''         : 1                                     -> (1)
-// tmp: F*K doubles of scratch.
+// tmp: joint_weight_tmp_doubles(mode, F, K, T) doubles of scratch.
 // reduce != null (bins sharded over ranks): the sums of modes 2 / 3 are all-reduced before they
 // are normalised over the classes.
+size_t joint_weight_tmp_doubles(int mode, int64_t F, int K, int T);
 int launch_joint_weight(int mode, const double* aff, const double* sal, int64_t F, int K, int T,
                         double* tmp, double* out_weight, hipStream_t s,
                         const PartialReduce* reduce = nullptr);
