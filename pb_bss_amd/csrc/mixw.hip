@@ -53,13 +53,16 @@ __global__ void __launch_bounds__(kT) mixw_rows_kernel(const double* __restrict_
   }
 }
 
-// out (Bo, Bi2, K, N1) from tmp (Bo, Bi, K, N1): sum over Bi if red_inner, then normalise
+// out (Bo, Bi2, K, N1) from tmp (Bo, Bi, K, N1): sum over Bi if red_inner, then normalise.
+// kFinFrames frames per workgroup (blockIdx.y), kT / kFinFrames partial sums per frame: 8 x 32
+// when the inner problems are summed, 64 x 4 (one part at work) when they are only normalised.
+template <int kFinFrames>
 __global__ void __launch_bounds__(kT) mixw_finish_kernel(const double* __restrict__ tmp,
                                                          int64_t Bi, int K, int64_t N1,
                                                          int red_inner, int has_sal, double count,
                                                          double* __restrict__ out) {
   const int64_t Bi2 = red_inner ? 1 : Bi;
-  const int64_t bo = blockIdx.x / Bi2, b2 = blockIdx.x % Bi2;  // blockIdx.y: tile of 256 frames
+  const int64_t bo = blockIdx.x / Bi2, b2 = blockIdx.x % Bi2;  // blockIdx.y: tile of frames
   extern __shared__ double sm[];  // [K] class totals when N1 == 1
   if (N1 == 1) {
     // parallel over bi, block reduction per class
@@ -96,39 +99,46 @@ __global__ void __launch_bounds__(kT) mixw_finish_kernel(const double* __restric
     }
     return;
   }
-  // N1 == N: one 64-frame tile per blockIdx.y; thread (f, part) = (tid & 63, tid >> 6) sums the
-  // reduced problems bi = part, part + 4, ... of frame f (consecutive threads read consecutive
-  // frames of one row: coalesced), the four parts are combined in a fixed order through LDS
-  __shared__ double comb[4][16][64];  // [part][class][frame]
-  const int f = threadIdx.x & 63, part = threadIdx.x >> 6;
-  const int64_t n = (int64_t)blockIdx.y * 64 + f;
+  // N1 == N: one kFinFrames-frame tile per blockIdx.y; thread (f, part) sums the reduced problems
+  // bi = part, part + kFinParts, ... of frame f for all classes of the chunk at once (K loads in
+  // flight per trip: the loop is a chain of L2 round trips, 513 bins over 4 parts and one class
+  // at a time were ~400 of them), the parts are combined in part order through LDS
+  constexpr int kFinParts = kT / kFinFrames;
+  __shared__ double comb[kFinParts][16][kFinFrames];  // [part][class][frame]
+  const int f = threadIdx.x % kFinFrames, part = threadIdx.x / kFinFrames;
+  const int64_t n = (int64_t)blockIdx.y * kFinFrames + f;
   for (int k0 = 0; k0 < K; k0 += 16) {  // classes in chunks of 16 (K <= 64)
     const int kc = (K - k0 < 16) ? K - k0 : 16;
-    for (int k = 0; k < kc; ++k) {
-      double v = 0.0;
-      if (n < N1) {
-        if (red_inner) {
-          for (int64_t bi = part; bi < Bi; bi += 4) v += tmp[((bo * Bi + bi) * K + k0 + k) * N1 + n];
-        } else if (part == 0) {
-          v = tmp[((bo * Bi + b2) * K + k0 + k) * N1 + n];
+    double acc[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[k] = 0.0;
+    if (n < N1) {
+      if (red_inner) {
+        for (int64_t bi = part; bi < Bi; bi += kFinParts) {
+          const double* row = tmp + ((bo * Bi + bi) * K + k0) * N1 + n;
+#pragma unroll
+          for (int k = 0; k < 16; ++k)
+            if (k < kc) acc[k] += row[(int64_t)k * N1];
         }
-      }
-      comb[part][k][f] = v;
-    }
-    __syncthreads();
-    if (part == 0 && n < N1) {
-      for (int k = 0; k < kc; ++k) {
-        const double v = (comb[0][k][f] + comb[1][k][f]) + (comb[2][k][f] + comb[3][k][f]);
-        comb[0][k][f] = v;
+      } else if (part == 0) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+          if (k < kc) acc[k] = tmp[((bo * Bi + b2) * K + k0 + k) * N1 + n];
       }
     }
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+      if (k < kc) comb[part][k][f] = acc[k];
     __syncthreads();
     // the class norm needs ALL classes: K <= 16 in one chunk is the only case with saliency
     // that occurs here (K <= 16 everywhere in the library); larger K fall back to plain sums
     if (part == 0 && n < N1) {
       double nrm = 0.0;
-      if (has_sal) {
-        for (int k = 0; k < kc; ++k) nrm += fabs(comb[0][k][f]);
+      for (int k = 0; k < kc; ++k) {
+        double v = 0.0;
+        for (int pp = 0; pp < kFinParts; ++pp) v += comb[pp][k][f];
+        comb[0][k][f] = v;
+        nrm += fabs(v);
       }
       for (int k = 0; k < kc; ++k) {
         const double v = comb[0][k][f];
@@ -183,9 +193,11 @@ int launch_mixture_weight(const double* aff, const double* sal, int64_t Bo, int6
                      red_n, tmp);
   const double count = (red_n ? (double)N : 1.0) * (red_inner ? (double)Bi : 1.0);
   const int64_t Bi2 = red_inner ? 1 : Bi;
-  const unsigned tiles = (unsigned)((N1 + 63) / 64);  // N1 == 1: one tile
-  hipLaunchKernelGGL(mixw_finish_kernel, dim3((unsigned)(Bo * Bi2), tiles), dim3(kT),
-                     K * sizeof(double), s, tmp, Bi, K, N1, red_inner, sal ? 1 : 0, count, out);
+  const int frames = red_inner ? 8 : 64;
+  const unsigned tiles = (unsigned)((N1 + frames - 1) / frames);  // N1 == 1: one tile
+  auto kfn = red_inner ? mixw_finish_kernel<8> : mixw_finish_kernel<64>;
+  hipLaunchKernelGGL(kfn, dim3((unsigned)(Bo * Bi2), tiles), dim3(kT), K * sizeof(double), s, tmp,
+                     Bi, K, N1, red_inner, sal ? 1 : 0, count, out);
   return hipGetLastError() == hipSuccess ? PBBSS_OK : PBBSS_ERR_HIP;
 }
 

@@ -527,6 +527,35 @@ def test_estimate_mixture_weight_kernel_against_numpy():
             assert np.abs(_lib.to_host(got) - want).max() < 1e-13
 
 
+def test_phase_correction_at_utterance_size():
+    """2-D input scans along the frequency axis (one workgroup, chunked scan): 513 bins, a bin
+    count that leaves the last threads without a chunk, and one bin short of a full chunk."""
+    from oracle import beamformer as ob
+    from pb_bss_amd import extraction as ex
+    rng = np.random.default_rng(5)
+    for F, D in ((513, 6), (300, 8), (2, 3), (1026, 2)):
+        w = rng.standard_normal((F, D)) + 1j * rng.standard_normal((F, D))
+        np.testing.assert_allclose(ex.phase_correction(w), ob.phase_correction(w), rtol=1e-11,
+                                   atol=1e-12)
+
+
+def test_mixture_weight_at_utterance_size():
+    """513 bins x 997 frames (ragged last frame tile): summed over the bins, and per bin."""
+    from pb_bss_amd import _lib, engine
+    from pb_bss_amd.distribution.mixture_model_utils import estimate_mixture_weight
+    rng = np.random.default_rng(2)
+    aff = rng.uniform(size=(1, 513, 3, 997))
+    aff /= aff.sum(-2, keepdims=True)
+    sal = rng.uniform(size=(1, 513, 997))
+    for red_inner, red_n, axes in ((True, False, (-3,)), (False, False, ())):
+        for s in (None, sal):
+            want = estimate_mixture_weight(aff[0], None if s is None else s[0], axes)
+            got = engine.estimate_mixture_weight(
+                _lib.to_device(aff), None if s is None else _lib.to_device(s), red_inner, red_n)
+            assert got.numel() == want.size
+            assert np.abs(_lib.to_host(got).reshape(want.shape) - want).max() < 1e-12
+
+
 def test_result_dtype_reference_follows_the_reference_operand_rules():
     """The reference computes in the precision of its operands (cacgmm.py:226-227); the table
     below was read off the unmodified reference (complex64 observations, 2 iterations)."""

@@ -36,6 +36,15 @@ for T in (500, 1000):
     al = DHTVPermutationAlignment.from_stft_size(1024)
     timed(f'DHTV calculate_mapping K=3 F=513 T={T}', lambda: al.calculate_mapping(m))
 
+from pb_bss_amd import engine
+aff = rng.uniform(size=(1, 513, 3, 1000)); aff /= aff.sum(-2, keepdims=True)
+affd = _lib.to_device(aff)
+timed('estimate_mixture_weight (513, 3, 1000) -> (3, 1000), classes summed over the bins',
+      lambda: engine.estimate_mixture_weight(affd, None, True, False))
+
+wv = _lib.to_device(rng.standard_normal((513, 8)) + 1j * rng.standard_normal((513, 8)))
+timed('phase_correction (513, 8)', lambda: ex.phase_correction(wv))
+
 Y, init = synth.make_stft(257, 800, 6, 3, seed=0)
 y, g0 = _lib.to_device(Y), _lib.to_device(init)
 timed('CWMM configs[3] F=257 T=800 D=6 K=3, 100 iterations + predict',
