@@ -39,6 +39,7 @@ extern "C" {
 #define PBBSS_ERR_UNSUPPORTED (-2)   /* shape outside the compiled kernels    */
 #define PBBSS_ERR_HIP (-3)           /* a HIP runtime call failed             */
 #define PBBSS_ERR_LDS_CAPACITY (-4)  /* T too large for the LDS-resident path */
+#define PBBSS_ERR_INTERNAL (-5)      /* workspace accounting mismatch (a bug) */
 
 /* ---- per-problem status bits (int32 status arrays) ------------------------ */
 #define PBBSS_ST_NONFINITE 1u      /* non-finite covariance / eigenvalues

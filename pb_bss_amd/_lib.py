@@ -19,6 +19,7 @@ ERR_INVALID_ARG = -1
 ERR_UNSUPPORTED = -2
 ERR_HIP = -3
 ERR_LDS_CAPACITY = -4
+ERR_INTERNAL = -5
 
 ST_NONFINITE = 1
 ST_EIG_NOCONV = 2

@@ -80,7 +80,9 @@ void* handle_work(pbbss_handle_t h, size_t bytes) {
 struct WorkCarver {
   char* base;
   size_t off = 0;
-  explicit WorkCarver(void* b) : base(static_cast<char*>(b)) {}
+  size_t limit;  // bytes the caller asked handle_work for; fits() checks the pieces against it
+  explicit WorkCarver(void* b, size_t bytes = ~(size_t)0) : base(static_cast<char*>(b)), limit(bytes) {}
+  bool fits() const { return off <= limit; }
   static size_t pad(size_t n) { return (n + 255) & ~(size_t)255; }
   template <typename T>
   T* take(size_t count) {
@@ -160,11 +162,12 @@ PBBSS_API const char* pbbss_error_string(int code) {
     case PBBSS_OK: return "ok";
     case PBBSS_ERR_INVALID_ARG: return "invalid argument";
     case PBBSS_ERR_UNSUPPORTED:
-      return "shape not covered by the compiled kernels (need 2 <= D <= 32 sensors -- 8 for the "
-             "Watson / joint models and LCMV -- and 1 <= K <= 16 classes, 6 for those models)";
+      return "shape not covered by the compiled kernels (2 <= D <= 32 sensors, 8 for LCMV; the "
+             "class range of every entry point is stated in pbbss.h)";
     case PBBSS_ERR_HIP: return "HIP runtime error";
     case PBBSS_ERR_LDS_CAPACITY:
       return "observation does not fit the LDS-resident EM kernel (too many frames)";
+    case PBBSS_ERR_INTERNAL: return "workspace accounting mismatch inside the library (a bug)";
     default: return "unknown error";
   }
 }
@@ -508,7 +511,7 @@ PBBSS_API int pbbss_cacgmm_fit(pbbss_handle_t h, const void* y, int64_t B, int T
                         WorkCarver::pad((size_t)B * 4) + (transpose ? WorkCarver::pad(ny) : 0);
     void* wmem = handle_work(h, need);
     if (!wmem) return PBBSS_ERR_HIP;
-    WorkCarver wc(wmem);
+    WorkCarver wc(wmem, need);
     double* aff = wc.take<double>(nkt);
     double* mw = wc.take<double>(nkt);  // M-step weights gamma sal / q / |y|^2 of every frame
     double* cov = wc.take<double>(nmat * D * D * 2);
@@ -518,6 +521,7 @@ PBBSS_API int pbbss_cacgmm_fit(pbbss_handle_t h, const void* y, int64_t B, int T
     int32_t* zero_bin = wc.take<int32_t>((size_t)B);
     double* csum = wc.take<double>(nmat);
     char* yt = transpose ? wc.take<char>(ny) : nullptr;
+    if (!wc.fits()) return PBBSS_ERR_INTERNAL;
     TimedRegion tr(h, s);
     const size_t ysz = o->y_is_c128 ? 16 : 8;
     const size_t ld2 = pbbss::gen_state_doubles(1, D);
@@ -1027,7 +1031,7 @@ PBBSS_API int pbbss_cwmm_fit(pbbss_handle_t h, const void* y, int64_t B, int T, 
                         3 * WorkCarver::pad(nmat * 8) + WorkCarver::pad(nmat * 4);
     void* wmem = handle_work(h, need);
     if (!wmem) return PBBSS_ERR_HIP;
-    WorkCarver wc(wmem);
+    WorkCarver wc(wmem, need);
     double* aff = wc.take<double>(nkt);
     double* lp = wc.take<double>(nkt);
     double* cov = wc.take<double>(nmat * D * D * 2);
@@ -1038,6 +1042,7 @@ PBBSS_API int pbbss_cwmm_fit(pbbss_handle_t h, const void* y, int64_t B, int T, 
     double* weight_w = wc.take<double>(nmat);
     double* lognorm = wc.take<double>(nmat);
     int32_t* status_w = wc.take<int32_t>(nmat);
+    if (!wc.fits()) return PBBSS_ERR_INTERNAL;
     double* mode = out_mode ? static_cast<double*>(out_mode) : mode_w;
     double* conc = out_concentration ? out_concentration : conc_w;
     double* weight = out_weight ? out_weight : weight_w;
@@ -1544,7 +1549,7 @@ PBBSS_API int pbbss_joint_fit(pbbss_handle_t h, const void* observation, const v
                       WorkCarver::pad(nconst * 8) + WorkCarver::pad(64);
   void* w = handle_work(h, need);
   if (!w) return PBBSS_ERR_HIP;
-  WorkCarver wc(w);
+  WorkCarver wc(w, need);
   char* yd = wc.take<char>((size_t)E * N * esz);
   double* aff = wc.take<double>(nfkt);
   double* slp = wc.take<double>(nfkt);
@@ -1570,6 +1575,7 @@ PBBSS_API int pbbss_joint_fit(pbbss_handle_t h, const void* observation, const v
   char* g_yt = gen ? wc.take<char>(nyt) : nullptr;
   double* g_lp = (gen && o->inline_pa) ? wc.take<double>(nfkt) : nullptr;  // spatial log-pdf
   double* g_q = (gen && o->inline_pa) ? wc.take<double>(nfkt) : nullptr;   // quadratic forms
+  if (!wc.fits()) return PBBSS_ERR_INTERNAL;
   if (hipMemsetAsync(gst, 0, 64, as_stream(stream)) != hipSuccess) return PBBSS_ERR_HIP;
   TimedRegion tr(h, s);
   int rc = pbbss::launch_embed_prepare(embedding, o->embedding_is_f64, 1, N, E, 0, yd, nullptr, s);
