@@ -46,6 +46,12 @@ def test_constants_match_header():
     assert define('PBBSS_ERR_UNSUPPORTED') == _lib.ERR_UNSUPPORTED
     assert define('PBBSS_ERR_HIP') == _lib.ERR_HIP
     assert define('PBBSS_ERR_LDS_CAPACITY') == _lib.ERR_LDS_CAPACITY
+    assert define('PBBSS_ERR_INTERNAL') == _lib.ERR_INTERNAL
+    # every error code of the header has its own text
+    codes = [int(c) for c in re.findall(r'#define\s+PBBSS_ERR_[A-Z_]+\s+\((-\d+)\)', txt)]
+    assert sorted(codes) == [-5, -4, -3, -2, -1]
+    texts = {_lib.load().pbbss_error_string(c) for c in codes}
+    assert len(texts) == len(codes) and b'unknown error' not in texts
     for n in ['NONFINITE', 'EIG_NOCONV', 'FLOORED', 'SLOWPATH', 'NOT_POSDEF', 'SINGULAR']:
         assert define('PBBSS_ST_' + n) == getattr(_lib, 'ST_' + n)
     assert define('PBBSS_COVNORM_EIGENVALUE') == _lib.COVNORM['eigenvalue']
