@@ -3,7 +3,7 @@
 (tools/prof_round3_kernels.sh): DHTV frame-slice path (T = 500 and 1000), Watson mixture with
 split groups (configs[3]) and at generic sizes (D = 12, K = 8), joint model at D = 12, generic
 GEV / BAN chain at D = 29, generic-size EM with the remainder-bin side chain."""
-import os, sys, time
+import gc, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from pb_bss_amd import _lib, engine
@@ -17,6 +17,7 @@ def timed(name, fn, reps=5):
     for _ in range(3):   # code-object load and the plan cache are first-call costs
         fn()
     ms = []
+    gc.collect()   # a generation-2 collection inside a timed call costs tens of ms with torch imported
     for _ in range(reps):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         fn()
