@@ -23,7 +23,8 @@ namespace pbbss {
 namespace {
 constexpr int kT = 256;
 
-// tmp (Bo*Bi, K, N1): per problem the (saliency-weighted) affiliation, summed over N if red_n
+// tmp (Bo*Bi, K): per problem the (saliency-weighted) affiliation summed over the frames
+// (red_n only: without that sum the finish kernel reads the affiliation itself)
 __global__ void __launch_bounds__(kT) mixw_rows_kernel(const double* __restrict__ aff,
                                                        const double* __restrict__ sal, int K,
                                                        int64_t N, int red_n,
@@ -33,11 +34,6 @@ __global__ void __launch_bounds__(kT) mixw_rows_kernel(const double* __restrict_
   const double* s = sal ? sal + b * N : nullptr;
   __shared__ double red[kT / kWave];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (!red_n) {
-    for (int64_t i = threadIdx.x; i < (int64_t)K * N; i += kT)
-      tmp[b * K * N + i] = a[i] * (s ? s[i % N] : 1.0);
-    return;
-  }
   for (int k = 0; k < K; ++k) {
     double acc = 0.0;
     for (int64_t n = threadIdx.x; n < N; n += kT) acc += a[(int64_t)k * N + n] * (s ? s[n] : 1.0);
@@ -58,6 +54,7 @@ __global__ void __launch_bounds__(kT) mixw_rows_kernel(const double* __restrict_
 // when the inner problems are summed, 64 x 4 (one part at work) when they are only normalised.
 template <int kFinFrames>
 __global__ void __launch_bounds__(kT) mixw_finish_kernel(const double* __restrict__ tmp,
+                                                         const double* __restrict__ sal_rows,
                                                          int64_t Bi, int K, int64_t N1,
                                                          int red_inner, int has_sal, double count,
                                                          double* __restrict__ out) {
@@ -114,16 +111,19 @@ __global__ void __launch_bounds__(kT) mixw_finish_kernel(const double* __restric
     for (int k = 0; k < 16; ++k) acc[k] = 0.0;
     if (n < N1) {
       if (red_inner) {
+        // N1 == N: tmp is the affiliation itself, weighted here (sal_rows (Bo*Bi, N) or null)
         for (int64_t bi = part; bi < Bi; bi += kFinParts) {
           const double* row = tmp + ((bo * Bi + bi) * K + k0) * N1 + n;
+          const double sv = sal_rows ? sal_rows[(bo * Bi + bi) * N1 + n] : 1.0;
 #pragma unroll
           for (int k = 0; k < 16; ++k)
-            if (k < kc) acc[k] += row[(int64_t)k * N1];
+            if (k < kc) acc[k] += row[(int64_t)k * N1] * sv;
         }
       } else if (part == 0) {
+        const double sv = sal_rows ? sal_rows[(bo * Bi + b2) * N1 + n] : 1.0;
 #pragma unroll
         for (int k = 0; k < 16; ++k)
-          if (k < kc) acc[k] = tmp[((bo * Bi + b2) * K + k0 + k) * N1 + n];
+          if (k < kc) acc[k] = tmp[((bo * Bi + b2) * K + k0 + k) * N1 + n] * sv;
       }
     }
 #pragma unroll
@@ -182,22 +182,26 @@ __global__ void __launch_bounds__(kT) lp_to_aff_kernel(const double* __restrict_
 }
 
 size_t mixture_weight_tmp_doubles(int64_t Bo, int64_t Bi, int K, int64_t N, int red_n) {
-  return (size_t)Bo * Bi * K * (red_n ? 1 : N);
+  (void)N;
+  return red_n ? (size_t)Bo * Bi * K : 1;
 }
 
 int launch_mixture_weight(const double* aff, const double* sal, int64_t Bo, int64_t Bi, int K,
                           int64_t N, int red_inner, int red_n, double* tmp, double* out,
                           hipStream_t s) {
   const int64_t N1 = red_n ? 1 : N;
-  hipLaunchKernelGGL(mixw_rows_kernel, dim3((unsigned)(Bo * Bi)), dim3(kT), 0, s, aff, sal, K, N,
-                     red_n, tmp);
+  // sums over the frames first; without them the finish kernel reads the affiliation itself
+  if (red_n)
+    hipLaunchKernelGGL(mixw_rows_kernel, dim3((unsigned)(Bo * Bi)), dim3(kT), 0, s, aff, sal, K, N,
+                       red_n, tmp);
   const double count = (red_n ? (double)N : 1.0) * (red_inner ? (double)Bi : 1.0);
   const int64_t Bi2 = red_inner ? 1 : Bi;
   const int frames = red_inner ? 8 : 64;
   const unsigned tiles = (unsigned)((N1 + frames - 1) / frames);  // N1 == 1: one tile
   auto kfn = red_inner ? mixw_finish_kernel<8> : mixw_finish_kernel<64>;
-  hipLaunchKernelGGL(kfn, dim3((unsigned)(Bo * Bi2), tiles), dim3(kT), K * sizeof(double), s, tmp,
-                     Bi, K, N1, red_inner, sal ? 1 : 0, count, out);
+  hipLaunchKernelGGL(kfn, dim3((unsigned)(Bo * Bi2), tiles), dim3(kT), K * sizeof(double), s,
+                     red_n ? tmp : aff, red_n ? nullptr : sal, Bi, K, N1, red_inner, sal ? 1 : 0,
+                     count, out);
   return hipGetLastError() == hipSuccess ? PBBSS_OK : PBBSS_ERR_HIP;
 }
 
