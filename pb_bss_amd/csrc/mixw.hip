@@ -23,20 +23,35 @@ namespace pbbss {
 namespace {
 constexpr int kT = 256;
 
-// tmp (Bo*Bi, K): per problem the (saliency-weighted) affiliation summed over the frames
-// (red_n only: without that sum the finish kernel reads the affiliation itself)
+// Frame chunks per problem of the sum over the frames: few problems with many frames (a mixture
+// over ONE batch of 256 500 samples is a single problem) would otherwise be summed by one
+// workgroup each -- 733 us of a 870 us diagonal-Gaussian EM iteration.  ~512 workgroups in total,
+// at least 1024 frames per chunk.
+int mixw_chunks(int64_t problems, int64_t N) {
+  int64_t c = 512 / (problems < 512 ? problems : 512);
+  const int64_t by_len = (N + 1023) / 1024;
+  if (c > by_len) c = by_len;
+  if (c > kT) c = kT;  // the finish kernel takes one chunk per thread
+  return (int)(c < 1 ? 1 : c);
+}
+
+// tmp (Bo*Bi, C, K): per problem and frame chunk the (saliency-weighted) affiliation summed over
+// the chunk's frames (red_n only: without that sum the finish kernel reads the affiliation itself)
 __global__ void __launch_bounds__(kT) mixw_rows_kernel(const double* __restrict__ aff,
                                                        const double* __restrict__ sal, int K,
-                                                       int64_t N, int red_n,
-                                                       double* __restrict__ tmp) {
+                                                       int64_t N, double* __restrict__ tmp) {
   const int64_t b = blockIdx.x;
+  const int C = gridDim.y, c = blockIdx.y;
+  const int64_t per = (N + C - 1) / C;
+  const int64_t n0 = per * c, n1 = (n0 + per < N) ? n0 + per : N;
   const double* a = aff + b * K * N;
   const double* s = sal ? sal + b * N : nullptr;
   __shared__ double red[kT / kWave];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int k = 0; k < K; ++k) {
     double acc = 0.0;
-    for (int64_t n = threadIdx.x; n < N; n += kT) acc += a[(int64_t)k * N + n] * (s ? s[n] : 1.0);
+    for (int64_t n = n0 + threadIdx.x; n < n1; n += kT)
+      acc += a[(int64_t)k * N + n] * (s ? s[n] : 1.0);
     acc = wave_sum(acc);
     __syncthreads();
     if (lane == 0) red[wave] = acc;
@@ -44,7 +59,7 @@ __global__ void __launch_bounds__(kT) mixw_rows_kernel(const double* __restrict_
     if (threadIdx.x == 0) {
       double t = 0.0;
       for (int w = 0; w < kT / kWave; ++w) t += red[w];
-      tmp[b * K + k] = t;
+      tmp[(b * C + c) * K + k] = t;
     }
   }
 }
@@ -55,7 +70,7 @@ __global__ void __launch_bounds__(kT) mixw_rows_kernel(const double* __restrict_
 template <int kFinFrames>
 __global__ void __launch_bounds__(kT) mixw_finish_kernel(const double* __restrict__ tmp,
                                                          const double* __restrict__ sal_rows,
-                                                         int64_t Bi, int K, int64_t N1,
+                                                         int64_t Bi, int C, int K, int64_t N1,
                                                          int red_inner, int has_sal, double count,
                                                          double* __restrict__ out) {
   const int64_t Bi2 = red_inner ? 1 : Bi;
@@ -67,10 +82,11 @@ __global__ void __launch_bounds__(kT) mixw_finish_kernel(const double* __restric
     __shared__ double red[kT / kWave];
     for (int k = 0; k < K; ++k) {
       double acc = 0.0;
+      // tmp (Bo*Bi, C, K): the (problem, chunk) pairs of one outer index are contiguous
       if (red_inner) {
-        for (int64_t bi = threadIdx.x; bi < Bi; bi += kT) acc += tmp[(bo * Bi + bi) * K + k];
-      } else if (threadIdx.x == 0) {
-        acc = tmp[(bo * Bi + b2) * K + k];
+        for (int64_t i = threadIdx.x; i < Bi * C; i += kT) acc += tmp[(bo * Bi * C + i) * K + k];
+      } else if (threadIdx.x < C) {
+        acc = tmp[((bo * Bi + b2) * C + threadIdx.x) * K + k];
       }
       acc = wave_sum(acc);
       __syncthreads();
@@ -182,8 +198,7 @@ __global__ void __launch_bounds__(kT) lp_to_aff_kernel(const double* __restrict_
 }
 
 size_t mixture_weight_tmp_doubles(int64_t Bo, int64_t Bi, int K, int64_t N, int red_n) {
-  (void)N;
-  return red_n ? (size_t)Bo * Bi * K : 1;
+  return red_n ? (size_t)Bo * Bi * mixw_chunks(Bo * Bi, N) * K : 1;
 }
 
 int launch_mixture_weight(const double* aff, const double* sal, int64_t Bo, int64_t Bi, int K,
@@ -191,16 +206,17 @@ int launch_mixture_weight(const double* aff, const double* sal, int64_t Bo, int6
                           hipStream_t s) {
   const int64_t N1 = red_n ? 1 : N;
   // sums over the frames first; without them the finish kernel reads the affiliation itself
+  const int C = red_n ? mixw_chunks(Bo * Bi, N) : 1;
   if (red_n)
-    hipLaunchKernelGGL(mixw_rows_kernel, dim3((unsigned)(Bo * Bi)), dim3(kT), 0, s, aff, sal, K, N,
-                       red_n, tmp);
+    hipLaunchKernelGGL(mixw_rows_kernel, dim3((unsigned)(Bo * Bi), (unsigned)C), dim3(kT), 0, s, aff,
+                       sal, K, N, tmp);
   const double count = (red_n ? (double)N : 1.0) * (red_inner ? (double)Bi : 1.0);
   const int64_t Bi2 = red_inner ? 1 : Bi;
   const int frames = red_inner ? 8 : 64;
   const unsigned tiles = (unsigned)((N1 + frames - 1) / frames);  // N1 == 1: one tile
   auto kfn = red_inner ? mixw_finish_kernel<8> : mixw_finish_kernel<64>;
   hipLaunchKernelGGL(kfn, dim3((unsigned)(Bo * Bi2), tiles), dim3(kT), K * sizeof(double), s,
-                     red_n ? tmp : aff, red_n ? nullptr : sal, Bi, K, N1, red_inner, sal ? 1 : 0,
+                     red_n ? tmp : aff, red_n ? nullptr : sal, Bi, C, K, N1, red_inner, sal ? 1 : 0,
                      count, out);
   return hipGetLastError() == hipSuccess ? PBBSS_OK : PBBSS_ERR_HIP;
 }

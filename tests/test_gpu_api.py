@@ -527,6 +527,25 @@ def test_estimate_mixture_weight_kernel_against_numpy():
             assert np.abs(_lib.to_host(got) - want).max() < 1e-13
 
 
+def test_mixture_weight_of_few_long_problems():
+    """One problem of 256 500 samples (a mixture over an utterance's embeddings): the sum over the
+    samples is cut into chunks over many workgroups; also three problems summed together."""
+    from pb_bss_amd import _lib, engine
+    from pb_bss_amd.distribution.mixture_model_utils import estimate_mixture_weight
+    rng = np.random.default_rng(3)
+    for Bi, N in ((1, 256500), (3, 70001), (2, 900)):
+        aff = rng.uniform(size=(1, Bi, 3, N))
+        aff /= aff.sum(-2, keepdims=True)
+        sal = rng.uniform(size=(1, Bi, N))
+        for red_inner, axes in ((False, (-1,)), (True, (-3, -1))):
+            for s in (None, sal):
+                want = estimate_mixture_weight(aff[0], None if s is None else s[0], axes)
+                got = engine.estimate_mixture_weight(
+                    _lib.to_device(aff), None if s is None else _lib.to_device(s), red_inner, True)
+                assert got.numel() == want.size
+                assert np.abs(_lib.to_host(got).reshape(want.shape) - want).max() < 1e-12
+
+
 def test_phase_correction_at_utterance_size():
     """2-D input scans along the frequency axis (one workgroup, chunked scan): 513 bins, a bin
     count that leaves the last threads without a chunk, and one bin short of a full chunk."""
