@@ -1064,17 +1064,21 @@ __global__ void __launch_bounds__(kThreads) diag_consts_kernel(const double* mea
   double* off = consts + (size_t)K * E;
   double* cm = off + K;
   for (int i = threadIdx.x; i < K * E; i += kThreads) pc[i] = 1.0 / sqrt(cov[i]);
-  __syncthreads();
-  for (int i = threadIdx.x; i < K; i += kThreads) {
+  // one wavefront per output value, lanes over the E dimensions (a thread per value walked E
+  // dependent loads of values other threads had just written: 15 us for 12 numbers)
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  for (int i = wave; i < K + K * K; i += kThreads / kWave) {
     double t = 0.0;
-    for (int e = 0; e < E; ++e) t += log(pc[i * E + e]);
-    off[i] = -0.5 * E * kLn2Pi + t;
-  }
-  for (int i = threadIdx.x; i < K * K; i += kThreads) {
-    const int j = i / K, k = i - j * K;
-    double t = 0.0;
-    for (int e = 0; e < E; ++e) t = fma(pc[j * E + e], mean[k * E + e], t);
-    cm[j * K + k] = t;
+    if (i < K) {
+      for (int e = lane; e < E; e += kWave) t += -0.5 * log(cov[i * E + e]);  // ln(1 / sqrt(cov))
+      t = wave_sum(t);
+      if (lane == 0) off[i] = -0.5 * E * kLn2Pi + t;
+    } else {
+      const int j = (i - K) / K, k = (i - K) - j * K;
+      for (int e = lane; e < E; e += kWave) t = fma(1.0 / sqrt(cov[j * E + e]), mean[k * E + e], t);
+      t = wave_sum(t);
+      if (lane == 0) cm[j * K + k] = t;
+    }
   }
 }
 
