@@ -128,7 +128,8 @@ def _chain_after_masks(Y, masks_fkt, mapping, ops, beamformer='gev+ban', shard_g
 
 def separate(Y, init, iterations=100, stft_size=None, *, shard=None, group=None,
              mask_gather_dtype=None, gather_output=False, ops=device_ops, beamformer='gev+ban'):
-    """Y (U, F, T, D) complex, init (U, F, K, T): run the chain above.
+    """Y (U, F, T, D) complex, init (U, F, K, T): run the chain above.  A single utterance may
+    come without the leading axis (Y (F, T, D), init (F, K, T)); the results then have none either.
 
     beamformer: 'gev+ban' (the reference's canonical recipe) or 'mvdr_souden' with the automatic
     reference channel (beamformer.py:627-698) -- the one extraction step that couples the bins:
@@ -140,6 +141,11 @@ def separate(Y, init, iterations=100, stft_size=None, *, shard=None, group=None,
     rank's own utterances for shard='utterances' without gather_output.
     """
     import torch
+    if Y.ndim == 3:
+        out = separate(Y[None], init[None], iterations, stft_size, shard=shard, group=group,
+                       mask_gather_dtype=mask_gather_dtype, gather_output=gather_output, ops=ops,
+                       beamformer=beamformer)
+        return {k: v[0] for k, v in out.items()}
     U, F, T, D = Y.shape
     if stft_size is None:
         stft_size = 2 * (F - 1)

@@ -119,3 +119,16 @@ def test_pipeline_with_mvdr_souden_matches_oracle_chain():
             assert np.abs(s - s_dev[u, k]).max() < 1e-7 * np.abs(s).max()
     with pytest.raises(ValueError):
         pipeline.separate(_lib.to_device(Y), _lib.to_device(init), 2, 512, beamformer='lcmv')
+
+
+def test_single_utterance_without_the_leading_axis():
+    from oracle import synth
+    from pb_bss_amd import _lib, pipeline
+    Y, init = synth.make_stft(257, 60, 4, 2, seed=7)
+    yd, gd = _lib.to_device(Y), _lib.to_device(init)
+    for bf in pipeline.BEAMFORMERS:
+        one = pipeline.separate(yd, gd, 5, 512, beamformer=bf)
+        ref = pipeline.separate(yd[None], gd[None], 5, 512, beamformer=bf)
+        assert tuple(one['masks'].shape) == (2, 257, 60) and tuple(one['mapping'].shape) == (2, 257)
+        for k in ref:
+            assert (one[k] == ref[k][0]).all(), k
