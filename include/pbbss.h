@@ -342,7 +342,11 @@ int pbbss_apply_beamforming_vector(pbbss_handle_t h, const void* w,
 /* end) = DHTVPermutationAlignment.alignment_plan (:204-293), a DEVICE array;    */
 /* scratch f64 (U,K,F,T) receives the aligned features (unit-norm for 'cos'); out_mapping    */
 /* int32 (U,K,F) is the reverse mapping; status int32 (U) gets                    */
-/* PBBSS_ST_NONFINITE where the reference raises 'score matrix is infeasible'.   */
+/* PBBSS_ST_NONFINITE where the reference raises 'score matrix is infeasible',   */
+/* and PBBSS_ST_EIG_NOCONV where a bounded wait between the workgroups that share */
+/* an utterance ran out (they were not co-resident: compute units held by other  */
+/* work) -- that utterance's mapping is then invalid; rerun with                  */
+/* pbbss_set_dhtv_team(h, 1), the one-workgroup kernel (the Python layer does).   */
 /* K <= 8.  One launch runs the whole plan.                                       */
 /* ------------------------------------------------------------------------- */
 int pbbss_dhtv_calculate_mapping(pbbss_handle_t h, const double* mask, int64_t U,

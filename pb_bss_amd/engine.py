@@ -6,6 +6,7 @@ torch stream, and raises the reference's exception types from status words.
 No arithmetic is done here beyond shape bookkeeping.
 """
 import ctypes
+import os
 
 import numpy as np
 
@@ -523,11 +524,34 @@ def set_split_tail(enable, device_index=None):
                'set_split_tail')
 
 
+_DHTV_TEAM = {}  # (device index, host thread) -- one C handle each -- -> last set_dhtv_team value
+
+
+def _handle_key(device_index):
+    import threading
+    if device_index is None:
+        device_index = _lib.require_gpu().cuda.current_device()
+    return (device_index, threading.get_ident())
+
+
 def set_dhtv_team(workgroups_per_utterance, device_index=None):
     """pbbss_set_dhtv_team: 0 automatic, 1 one workgroup per utterance, >= 2 frame-slice kernel,
     -2..-32 bin-chunk team kernel of that size."""
     _lib.check(_lib.load().pbbss_set_dhtv_team(_lib.handle(device_index),
                                                int(workgroups_per_utterance)), 'set_dhtv_team')
+    _DHTV_TEAM[_handle_key(device_index)] = int(workgroups_per_utterance)
+
+
+def dhtv_team(device_index=None):
+    """The team setting in force on this thread's handle: its last set_dhtv_team, else
+    PBBSS_DHTV_TEAM (read by the library when the handle is created), else 0 = automatic."""
+    key = _handle_key(device_index)
+    if key in _DHTV_TEAM:
+        return _DHTV_TEAM[key]
+    try:
+        return int(os.environ.get('PBBSS_DHTV_TEAM', '0'))
+    except ValueError:
+        return 0
 
 
 def split_error(device_index=None):

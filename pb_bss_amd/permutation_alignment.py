@@ -166,10 +166,30 @@ class DHTVPermutationAlignment(_PermutationAlignment):
             if len(_DEVICE_PLANS) > 64:
                 _DEVICE_PLANS.clear()
             plan_dev = _DEVICE_PLANS[key] = _lib.to_device(plan).to(m.device)
-        mapping, _, st = engine.dhtv_calculate_mapping(
-            m.reshape(-1, K, F, T).contiguous(), plan_dev,
-            optimal=(self.algorithm == 'optimal'), metric=self.similarity_metric)
-        if int(st.max().item()) != 0:
+        mu = m.reshape(-1, K, F, T).contiguous()
+
+        def run():
+            mapping, _, st = engine.dhtv_calculate_mapping(
+                mu, plan_dev, optimal=(self.algorithm == 'optimal'), metric=self.similarity_metric)
+            return mapping, int(np.bitwise_or.reduce(_lib.to_host(st).reshape(-1)))
+
+        mapping, bits = run()
+        if bits & _lib.ST_EIG_NOCONV and not bits & _lib.ST_NONFINITE:
+            # A wait between the workgroups that share an utterance ran out: they were not on the
+            # chip at the same time (other kernels of this or another process hold compute units).
+            # Nothing of that launch is used; the one-workgroup kernel needs no co-residency.
+            import warnings
+            warnings.warn('DHTV permutation alignment: the workgroups of an utterance were not '
+                          'co-resident (GPU shared with other work); running the one-workgroup '
+                          'kernel instead', RuntimeWarning)
+            dev = mu.device.index
+            before = engine.dhtv_team(dev)
+            engine.set_dhtv_team(1, dev)
+            try:
+                mapping, bits = run()
+            finally:
+                engine.set_dhtv_team(before, dev)
+        if bits != 0:
             raise ValueError('score matrix is infeasible')  # reference :512-514
         mapping = mapping.reshape(*lead, K, F).to(t.int64)
         return mapping if like_torch else _lib.to_host(mapping)

@@ -243,3 +243,50 @@ def test_pairwise_solvers_match_oracle_at_size(K, F, T):
     m1 = OraclePermutationAlignment('euclidean', 'greedy').calculate_mapping(mask[:, 0], ref[:, 0])
     assert m1.shape == (K,)
     assert (m1 == op.oracle_calculate_mapping(mask[:, :1], ref[:, :1], 'euclidean', 'greedy')[:, 0]).all()
+
+
+def test_team_timeout_falls_back_to_the_one_workgroup_kernel(monkeypatch):
+    """A timed-out wait between the workgroups of an utterance (status bit EIG_NOCONV: they were
+    not co-resident) is not an infeasible score matrix: the aligner warns, reruns with the
+    one-workgroup kernel and restores the team setting."""
+    import torch
+    from oracle import permutation_alignment as op
+    from pb_bss_amd import _lib, engine
+    from pb_bss_amd.permutation_alignment import DHTVPermutationAlignment
+    rng = np.random.default_rng(11)
+    K, F, T = 3, 257, 300
+    act = rng.uniform(size=(K, T)) ** 4
+    mask = act[:, None, :] * rng.uniform(0.5, 1.0, size=(K, F, T)) + 0.05 * rng.uniform(size=(K, F, T))
+    mask /= mask.sum(0, keepdims=True)
+    perm = np.stack([rng.permutation(K) for _ in range(F)], 1)
+    mask = mask[perm, np.arange(F)]
+    want = op.dhtv_calculate_mapping(mask, op.alignment_plan(512, **op.PRESETS[512]))
+
+    real = engine.dhtv_calculate_mapping
+    teams, calls = [], []
+    real_set = engine.set_dhtv_team
+
+    def fake_set(v, device_index=None):
+        teams.append(v)
+        return real_set(v, device_index)
+
+    def fake(*a, **kw):
+        mapping, feat, st = real(*a, **kw)
+        calls.append(engine.dhtv_team(a[0].device.index))
+        if len(calls) == 1:
+            st = st | _lib.ST_EIG_NOCONV   # as a timed-out team launch reports it
+            mapping = torch.zeros_like(mapping)
+        return mapping, feat, st
+
+    monkeypatch.setattr(engine, 'dhtv_calculate_mapping', fake)
+    monkeypatch.setattr(engine, 'set_dhtv_team', fake_set)
+    engine.set_dhtv_team(0)
+    with pytest.warns(RuntimeWarning, match='co-resident'):
+        got = DHTVPermutationAlignment.from_stft_size(512).calculate_mapping(_lib.to_device(mask))
+    assert (_lib.to_host(got) == want).all()
+    assert calls == [0, 1] and teams == [0, 1, 0]
+    # a non-finite mask stays the reference's error
+    bad = mask.copy()
+    bad[0, 3, 5] = np.nan
+    with pytest.raises(ValueError, match='infeasible'):
+        DHTVPermutationAlignment.from_stft_size(512).calculate_mapping(_lib.to_device(bad))
