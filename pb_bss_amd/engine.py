@@ -17,12 +17,15 @@ def _t():
     return _lib.torch()
 
 
-def _status_raise_em(status, what):
+def _status_bits(status):
+    """OR of all status words (one small D2H copy; 0 without it when every word is 0)."""
+    if not status.numel() or int(status.max().item()) == 0:
+        return 0
+    return int(np.bitwise_or.reduce(_lib.to_host(status).ravel()))
+
+
+def _raise_for_bits(bits, what):
     """Mirror the reference's failure modes of the M-step."""
-    st = int(status.max().item()) if status.numel() else 0
-    if st == 0:
-        return
-    bits = int(np.bitwise_or.reduce(_lib.to_host(status).ravel()))
     if bits & _lib.ST_NONFINITE:
         # distribution/complex_angular_central_gaussian.py:127, :326, :333
         raise AssertionError(
@@ -31,6 +34,35 @@ def _status_raise_em(status, what):
     if bits & _lib.ST_EIG_NOCONV:
         # complex_angular_central_gaussian.py:94-110 (LinAlgError from eigh/eig)
         raise np.linalg.LinAlgError(f'{what}: Hermitian eigensolver did not converge')
+
+
+def _status_raise_em(status, what):
+    _raise_for_bits(_status_bits(status), what)
+
+
+_SPLIT_POISON = _lib.ST_NONFINITE | _lib.ST_EIG_NOCONV
+
+
+def _checked_with_split_retry(launch, dev, what):
+    """Run launch() -> dict with 'status' and raise for its status bits.  The split groups of a
+    remainder bin (2^n + 1 bins) exchange their sums through bounded waits; when one runs out
+    -- the member workgroups were not on the chip together: compute units held by other work --
+    the launch marks the problems concerned with NONFINITE | EIG_NOCONV and raises the flag of
+    pbbss_split_error.  That is not a numerical failure: repeat once without split groups."""
+    r = launch()
+    bits = _status_bits(r['status'])
+    if (bits & _SPLIT_POISON) == _SPLIT_POISON and split_error(dev.index):
+        import warnings
+        warnings.warn(f'{what}: the split groups of the remainder bin were not co-resident (GPU '
+                      'shared with other work); repeating the fit without them', RuntimeWarning)
+        set_split_tail(False, dev.index)
+        try:
+            r = launch()
+            bits = _status_bits(r['status'])
+        finally:
+            set_split_tail(True, dev.index)
+    _raise_for_bits(bits, what)
+    return r
 
 
 def normalize_observation(y):
@@ -75,12 +107,6 @@ def em_fit(y, K, *, gamma0=None, model=None, iterations=100, saliency=None,
         affiliation_eps=float(affiliation_eps),
         eigenvalue_floor=float(eigenvalue_floor), precision=_lib.PRECISION[precision])
     f64 = t.float64
-    out_vec = t.empty((B, K, D, D), dtype=t.complex128, device=dev)
-    out_val = t.empty((B, K, D), dtype=f64, device=dev)
-    out_w = t.empty((B, K), dtype=f64, device=dev)
-    out_st = t.empty((B, K), dtype=t.int32, device=dev)  # every row is written by the library
-    out_aff = t.empty((B, K, T), dtype=f64, device=dev) if final_predict else None
-    out_q = t.empty((B, K, T), dtype=f64, device=dev) if (final_predict and return_q) else None
     if model is not None:
         in_vec, in_val, in_w = model
         assert in_vec.shape == (B, K, D, D) and in_val.shape == (B, K, D) and in_w.shape == (B, K)
@@ -91,17 +117,27 @@ def em_fit(y, K, *, gamma0=None, model=None, iterations=100, saliency=None,
         assert saliency.shape == (B, T) and saliency.dtype == f64
     if activity is not None:
         assert activity.shape == (B, K, T) and activity.dtype == t.uint8
-    rc = _lib.load().pbbss_cacgmm_fit(
-        _lib.handle(dev.index), _lib.ptr(y), B, T, D, K, _lib.ptr(gamma0),
-        _lib.ptr(in_vec), _lib.ptr(in_val), _lib.ptr(in_w), _lib.ptr(saliency),
-        _lib.ptr(activity), ctypes.byref(opts), _lib.ptr(out_vec),
-        _lib.ptr(out_val), _lib.ptr(out_w), _lib.ptr(out_st), _lib.ptr(out_aff),
-        _lib.ptr(out_q), _lib.stream_ptr(dev.index))
-    _lib.check(rc, f'cacgmm_fit(B={B},T={T},D={D},K={K})')
+
+    def launch():
+        out_vec = t.empty((B, K, D, D), dtype=t.complex128, device=dev)
+        out_val = t.empty((B, K, D), dtype=f64, device=dev)
+        out_w = t.empty((B, K), dtype=f64, device=dev)
+        out_st = t.empty((B, K), dtype=t.int32, device=dev)  # every row is written by the library
+        out_aff = t.empty((B, K, T), dtype=f64, device=dev) if final_predict else None
+        out_q = t.empty((B, K, T), dtype=f64, device=dev) if (final_predict and return_q) else None
+        rc = _lib.load().pbbss_cacgmm_fit(
+            _lib.handle(dev.index), _lib.ptr(y), B, T, D, K, _lib.ptr(gamma0),
+            _lib.ptr(in_vec), _lib.ptr(in_val), _lib.ptr(in_w), _lib.ptr(saliency),
+            _lib.ptr(activity), ctypes.byref(opts), _lib.ptr(out_vec),
+            _lib.ptr(out_val), _lib.ptr(out_w), _lib.ptr(out_st), _lib.ptr(out_aff),
+            _lib.ptr(out_q), _lib.stream_ptr(dev.index))
+        _lib.check(rc, f'cacgmm_fit(B={B},T={T},D={D},K={K})')
+        return dict(eigvec=out_vec, eigval=out_val, weight=out_w, status=out_st,
+                    affiliation=out_aff, quadratic_form=out_q)
+
     if check_status:
-        _status_raise_em(out_st, 'CACGMMTrainer.fit')
-    return dict(eigvec=out_vec, eigval=out_val, weight=out_w, status=out_st,
-                affiliation=out_aff, quadratic_form=out_q)
+        return _checked_with_split_retry(launch, dev, 'CACGMMTrainer.fit')
+    return launch()
 
 
 def em_fit_shared(y, K, group, *, weight_mode, gamma0=None, model=None, iterations=100,
@@ -476,30 +512,34 @@ def cwmm_fit(y, K, spline, *, gamma0=None, model=None, iterations=100, saliency=
         ev_max=0.0 if spline is None else float(spline['ev_max']),
         max_concentration=0.0 if spline is None else float(spline['max_concentration']))
     f64 = t.float64
-    out_mode = t.empty((B, K, D), dtype=t.complex128, device=dev)
-    out_conc = t.empty((B, K), dtype=f64, device=dev)
-    out_w = t.empty((B, K), dtype=f64, device=dev)
-    out_st = t.zeros((B, K), dtype=t.int32, device=dev)
-    out_aff = t.empty((B, K, T), dtype=f64, device=dev) if final_predict else None
-    out_lp = t.empty((B, K, T), dtype=f64, device=dev) if want_log_pdf else None
     in_mode = in_conc = in_w = None
     if model is not None:
         in_mode, in_conc, in_w = model
         assert in_mode.shape == (B, K, D) and in_conc.shape == (B, K) and in_w.shape == (B, K)
     else:
         assert gamma0.shape == (B, K, T) and gamma0.dtype == f64
-    rc = _lib.load().pbbss_cwmm_fit(
-        _lib.handle(dev.index), _lib.ptr(y), B, T, D, K, _lib.ptr(gamma0), _lib.ptr(in_mode),
-        _lib.ptr(in_conc), _lib.ptr(in_w), _lib.ptr(saliency), ctypes.byref(opts),
-        None if spline is None else _lib.ptr(spline['t']),
-        None if spline is None else _lib.ptr(spline['c']),
-        _lib.ptr(out_mode), _lib.ptr(out_conc), _lib.ptr(out_w), _lib.ptr(out_st),
-        _lib.ptr(out_aff), _lib.ptr(out_lp), _lib.stream_ptr(dev.index))
-    _lib.check(rc, f'cwmm_fit(B={B},T={T},D={D},K={K})')
+
+    def launch():
+        out_mode = t.empty((B, K, D), dtype=t.complex128, device=dev)
+        out_conc = t.empty((B, K), dtype=f64, device=dev)
+        out_w = t.empty((B, K), dtype=f64, device=dev)
+        out_st = t.zeros((B, K), dtype=t.int32, device=dev)
+        out_aff = t.empty((B, K, T), dtype=f64, device=dev) if final_predict else None
+        out_lp = t.empty((B, K, T), dtype=f64, device=dev) if want_log_pdf else None
+        rc = _lib.load().pbbss_cwmm_fit(
+            _lib.handle(dev.index), _lib.ptr(y), B, T, D, K, _lib.ptr(gamma0), _lib.ptr(in_mode),
+            _lib.ptr(in_conc), _lib.ptr(in_w), _lib.ptr(saliency), ctypes.byref(opts),
+            None if spline is None else _lib.ptr(spline['t']),
+            None if spline is None else _lib.ptr(spline['c']),
+            _lib.ptr(out_mode), _lib.ptr(out_conc), _lib.ptr(out_w), _lib.ptr(out_st),
+            _lib.ptr(out_aff), _lib.ptr(out_lp), _lib.stream_ptr(dev.index))
+        _lib.check(rc, f'cwmm_fit(B={B},T={T},D={D},K={K})')
+        return dict(mode=out_mode, concentration=out_conc, weight=out_w, status=out_st,
+                    affiliation=out_aff, log_pdf=out_lp)
+
     if check_status and iterations > 0:
-        _status_raise_em(out_st, 'CWMMTrainer.fit')
-    return dict(mode=out_mode, concentration=out_conc, weight=out_w, status=out_st,
-                affiliation=out_aff, log_pdf=out_lp)
+        return _checked_with_split_retry(launch, dev, 'CWMMTrainer.fit')
+    return launch()
 
 
 def wmwf(target, noise, distortion_weight=1.0, frequency_dependent=False):

@@ -304,3 +304,40 @@ def test_silent_bin_rank_one_bin_and_nan_input():
     bad[2, 5, 1] = np.nan
     with pytest.raises(AssertionError):
         CACGMMTrainer().fit(bad, initialization=init, iterations=3)
+
+
+def test_split_timeout_pattern_repeats_the_fit_without_split_groups(monkeypatch):
+    """NONFINITE | EIG_NOCONV together with the flag of pbbss_split_error is how a launch reports
+    that the member workgroups of a remainder bin were not co-resident: the wrapper warns and
+    repeats the fit once with the split groups switched off (and switches them on again)."""
+    from oracle import synth
+    from pb_bss_amd import _lib, engine
+    Y, init = synth.make_stft(257, 300, 4, 2, seed=21)
+    y, g0 = _lib.to_device(Y), _lib.to_device(init)
+    engine.set_split_tail(False)
+    want = engine.em_fit(y, 2, gamma0=g0, iterations=5, final_predict=True)
+    engine.set_split_tail(True)
+    calls, tails = [], []
+    real_bits, real_tail = engine._status_bits, engine.set_split_tail
+
+    def fake_bits(st):
+        calls.append(1)
+        return engine._SPLIT_POISON if len(calls) == 1 else real_bits(st)
+
+    def fake_tail(enable, device_index=None):
+        tails.append(bool(enable))
+        return real_tail(enable, device_index)
+
+    monkeypatch.setattr(engine, '_status_bits', fake_bits)
+    monkeypatch.setattr(engine, 'split_error', lambda device_index=None: 1)
+    monkeypatch.setattr(engine, 'set_split_tail', fake_tail)
+    with pytest.warns(RuntimeWarning, match='split groups'):
+        got = engine.em_fit(y, 2, gamma0=g0, iterations=5, final_predict=True)
+    assert tails == [False, True] and len(calls) == 2
+    assert (got['affiliation'] == want['affiliation']).all()
+    assert (got['eigval'] == want['eigval']).all()
+    # without the flag of pbbss_split_error the same bits are the reference's numerical failure
+    calls.clear()
+    monkeypatch.setattr(engine, 'split_error', lambda device_index=None: 0)
+    with pytest.raises(AssertionError, match='non-finite'):
+        engine.em_fit(y, 2, gamma0=g0, iterations=5, final_predict=True)
