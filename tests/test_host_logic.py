@@ -255,3 +255,46 @@ def test_reference_dtype_rounding_of_a_fitted_model():
     assert m.weight.dtype == np.float64 and a.dtype == np.float32
     assert m.cacg.covariance_eigenvectors.dtype == np.complex64
     assert model.weight.dtype == np.float64                 # the input model is left alone
+
+
+def test_split_timeout_retry_logic(monkeypatch):
+    """engine._checked_with_split_retry without a GPU: the poison pattern plus the flag of
+    pbbss_split_error repeats the launch once with the split groups off; the pattern without the
+    flag, or any other status, raises the reference's errors; a clean status passes through."""
+    import types
+    import torch
+    from pb_bss_amd import _lib, engine
+    dev = types.SimpleNamespace(index=0)
+    tails = []
+    monkeypatch.setattr(engine, 'set_split_tail', lambda e, d=None: tails.append((bool(e), d)))
+    poison = _lib.ST_NONFINITE | _lib.ST_EIG_NOCONV
+
+    def launcher(statuses):
+        seq = iter(statuses)
+        return lambda: dict(status=torch.tensor(next(seq), dtype=torch.int32), tag=object())
+
+    # clean
+    monkeypatch.setattr(engine, 'split_error', lambda d=None: 0)
+    r = engine._checked_with_split_retry(launcher([[[0, 0]]]), dev, 'x')
+    assert int(r['status'].max()) == 0 and tails == []
+    # informational bits alone never raise
+    r = engine._checked_with_split_retry(launcher([[[_lib.ST_FLOORED, _lib.ST_SLOWPATH]]]), dev, 'x')
+    assert tails == []
+    # poison + flag: one repeat without split groups, which are switched on again
+    monkeypatch.setattr(engine, 'split_error', lambda d=None: 1)
+    with pytest.warns(RuntimeWarning, match='split groups'):
+        r = engine._checked_with_split_retry(launcher([[[0, poison]], [[0, 0]]]), dev, 'x')
+    assert tails == [(False, 0), (True, 0)] and int(r['status'].max()) == 0
+    # the repeat fails for real: the error is raised, the split groups are on again
+    tails.clear()
+    with pytest.warns(RuntimeWarning), pytest.raises(AssertionError, match='non-finite'):
+        engine._checked_with_split_retry(launcher([[[poison, 0]], [[_lib.ST_NONFINITE, 0]]]), dev, 'x')
+    assert tails == [(False, 0), (True, 0)]
+    # poison without the flag: a numerical failure as the reference reports it
+    tails.clear()
+    monkeypatch.setattr(engine, 'split_error', lambda d=None: 0)
+    with pytest.raises(AssertionError, match='non-finite'):
+        engine._checked_with_split_retry(launcher([[[poison, 0]]]), dev, 'x')
+    with pytest.raises(np.linalg.LinAlgError):
+        engine._checked_with_split_retry(launcher([[[_lib.ST_EIG_NOCONV, 0]]]), dev, 'x')
+    assert tails == []
