@@ -90,9 +90,19 @@ def parse():
                         'line as `preheat` (0 = off)')
     p.add_argument('--sustained-s', type=float, default=2.0,
                    help='seconds of back-to-back steps after the timed region (0 = skip)')
-    p.add_argument('--workload', choices=['config2', 'config3'], default='config2',
-                   help='config2: BASELINE configs[1] (headline, with the config-3 legs inside the '
-                        'same line); config3: configs[2] as the primary line')
+    p.add_argument('--workload', choices=['config2', 'config3', 'config4', 'config5'],
+                   default='config2',
+                   help='config2: BASELINE configs[1] (headline, with the config-3/4/5 blocks inside '
+                        'the same line); config3 / config4 / config5: configs[2] / [3] / [4] as the '
+                        'primary line (what tools/profile_round.sh profiles)')
+    p.add_argument('--configs45', choices=['auto', 'off'], default='auto',
+                   help='auto: also run BASELINE configs[3] (Watson / vMF mixture + MVDR-Souden, '
+                        'F=257 T=800 D=6) and configs[4] (joint GCACGMM, F=513 T=500 D=8 E=40) and '
+                        'carry them in the line as `config4` / `config5` (N = 1 only)')
+    p.add_argument('--c4-extraction', choices=['on', 'off'], default='on',
+                   help='--workload config4: off = the step is the mixture fit alone (profiling runs)')
+    p.add_argument('--leg', choices=['watson', 'vmf'], default='watson',
+                   help='--workload config4: which mixture is the primary line')
     p.add_argument('--config3', choices=['auto', 'off'], default='auto',
                    help='auto: also run BASELINE configs[2] (64 utterances through the chain) and '
                         'carry it in the line -- at N > 1 with the bins and with the utterances '
@@ -241,21 +251,20 @@ def cpu_baseline_em(Y0, init0, iters):
             refshim.load()
             from pb_bss.distribution import CACGMMTrainer as RefTrainer
             runs = []
+            n = max(iters // 10, 2)
             for dtype, label in ((np.complex128, 'float64 path (complex128 input)'),
                                  (np.complex64, 'float32 path (complex64 input + ndarray init)')):
-                best = None
-                for _ in range(3):
-                    t1 = time.perf_counter()
-                    RefTrainer().fit(Y0.astype(dtype), initialization=init0, iterations=max(iters // 10, 2))
-                    dt = time.perf_counter() - t1
-                    best = dt if best is None else min(best, dt)
-                runs.append((label, max(iters // 10, 2) / best))
+                Yd = Y0.astype(dtype)
+                med, _ = median_rate(lambda: RefTrainer().fit(Yd, initialization=init0,
+                                                              iterations=n), n)
+                runs.append((label, med))
             return {
                 'value': runs[0][1], 'unit': 'EM iterations/s', 'cores': 1, 'kind': 'reference',
                 'sample': f'pb_bss CACGMMTrainer.fit imported from {ref_dir}, full F=513 T=500 D=8 '
-                          f'K=3, {max(iters // 10, 2)} EM iterations, best of 3: ' +
+                          f'K=3, {n} EM iterations, median of 3 runs: ' +
                           '; '.join(f'{l}: {v:.2f} it/s' for l, v in runs) +
                           f'; host has {os.cpu_count()} logical cores, einsum is single-threaded',
+                'reference_recorded': reference_recorded('config2'),
             }
         except Exception as e:  # fall through to the oracle, say why
             note = f' (reference import failed: {type(e).__name__}: {e})'
@@ -263,15 +272,18 @@ def cpu_baseline_em(Y0, init0, iters):
         note = ' (no /root/reference on this host)'
     from oracle import cacgmm as oc
     Y128 = Y0.astype(np.complex128)
+    n = max(iters // 3, 2)
     t1 = time.perf_counter()
-    oc.em_fit(Y128, init0, iterations=iters)
+    med, runs = median_rate(lambda: oc.em_fit(Y128, init0, iterations=n), n)
     dt = time.perf_counter() - t1
     return {
-        'value': iters / dt, 'unit': 'EM iterations/s', 'cores': 1, 'kind': 'port',
+        'value': med, 'unit': 'EM iterations/s', 'cores': 1, 'kind': 'port', 'runs': runs,
         'sample': f'NumPy oracle (oracle/cacgmm.py: restated einsum contractions, float64; it forms '
-                  f'B^-1 first and measures ~1.5x faster than the reference\'s own calls), full '
-                  f'F=513 T=500 D=8 K=3, {iters} EM iterations, {dt:.1f} s; host has '
-                  f'{os.cpu_count()} logical cores, einsum is single-threaded' + note,
+                  f'B^-1 first and measures ~1.3-1.5x faster than the reference\'s own calls), full '
+                  f'F=513 T=500 D=8 K=3, median of 3 runs of {n} EM iterations, {dt:.1f} s in all; '
+                  f'host has {os.cpu_count()} logical cores, 1 used (einsum is single-threaded; the '
+                  f'reference would use 1 core here too)' + note,
+        'reference_recorded': reference_recorded('config2'),
     }
 
 
@@ -888,6 +900,389 @@ def main_config3(args):
     emit(line, use_dist)
 
 
+# ------------------------------------------------------------------------------------------
+# BASELINE configs[3] and configs[4]: Watson / vMF mixtures + MVDR, joint spatial + spectral model
+# ------------------------------------------------------------------------------------------
+C4 = dict(F=257, T=800, D=6, K=3)             # configs[3]: 6-mic CHiME-style array
+C5 = dict(F=513, T=500, D=8, K=3, E=40)       # configs[4]: cACGMM x Gaussian on 40-dim embeddings
+
+
+def c4_flops(D, K):
+    """float64 flops per frame and EM iteration of the Watson kernel's algorithm (csrc/cwmm.hpp):
+    E phase |m_k^H y|^2 as D complex multiply-adds per class (8 D + 3), log-pdf / exp / softmax
+    (~35 per class); M phase Hermitian outer product P (3 D^2) and C_k += w_k P (2 D^2 K)."""
+    return K * (8 * D + 38) + 3 * D * D + 2 * D * D * K
+
+
+def c5_flops(D, K, E):
+    """float64 flops per time-frequency point and EM iteration of the joint model: the cACGMM
+    half as in the headline (2 * 3 D^2 + 4 D^2 K + ~100) plus the spherical Gaussian on the
+    embedding: E-step sum_e (e - mu_k)^2 (3 E K), M-step sum w_k e (2 E K) and the shifted second
+    moment (3 E + 2 K)."""
+    return 2 * 3 * D * D + 4 * D * D * K + 100 + 3 * E * K + 2 * E * K + 3 * E + 2 * K
+
+
+def reference_recorded(config):
+    """The UNMODIFIED reference timed in the build container (tools/record_reference_timings.py
+    -> profiles/reference_cpu_timings.json; /root/reference does not exist on the GPU box)."""
+    path = os.path.join(ROOT, 'profiles', 'reference_cpu_timings.json')
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+    except (OSError, ValueError):
+        return None
+    cfg = rec['configs'].get(config)
+    if not cfg:
+        return None
+    out = {k: round(v['it_per_s_median'], 3) for k, v in cfg.items() if isinstance(v, dict)
+           and 'it_per_s_median' in v}
+    out['unit'] = 'EM iterations/s, median of %d runs each' % next(
+        v['repeats'] for v in cfg.values() if isinstance(v, dict) and 'repeats' in v)
+    out['host'] = f"{rec['host']['cpu']}, {rec['host']['logical_cores']} logical cores, 1 used"
+    out['source'] = 'profiles/reference_cpu_timings.json (' + rec['script'] + ')'
+    return out
+
+
+def median_rate(fn, iterations, repeats=3):
+    """-> (median iterations/s, [runs]) of `repeats` timed calls of fn()."""
+    runs = []
+    for _ in range(repeats):
+        t1 = time.perf_counter()
+        fn()
+        runs.append(iterations / (time.perf_counter() - t1))
+    return float(np.median(runs)), runs
+
+
+SOURCES_BY_WORKLOAD = {
+    'config2': KERNEL_SOURCES,
+    'config4': ('cwmm.hpp', 'cw_inst.hip', 'cacgmm_em.hpp', 'wave_la.hpp', 'pbbss_dev.hpp',
+                'em_launch.hpp', 'beamform.hip', 'embed.hip'),
+    'config4_vmf': ('embed.hip',),
+    'config5': ('embed.hip', 'joint_inst.hip', 'cacgmm_em.hpp', 'wave_la.hpp', 'pbbss_dev.hpp',
+                'em_launch.hpp'),
+}
+
+
+def workload_source_sha(workload):
+    import hashlib
+    h = hashlib.sha1()
+    for name in SOURCES_BY_WORKLOAD[workload]:
+        with open(os.path.join(ROOT, 'pb_bss_amd', 'csrc', name), 'rb') as f:
+            h.update(f.read())
+    return h.hexdigest()[:12]
+
+
+def workload_pmc(workload, region_ms):
+    """PMC traffic of one step of `workload` from a committed tools/profile_round.sh summary taken
+    from exactly these kernel sources (profiles/r*_<workload>_profile.txt), or (None, reason).
+    The summary's `region_trace_us` row (sum of the kernels of one step in the kernel trace) must
+    not exceed this run's own region time by more than 5 %."""
+    import glob
+    sha = workload_source_sha(workload)
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', f'r*_{workload}*_profile.txt')),
+                       reverse=True):
+        with open(path) as f:
+            text = f.read()
+        if f'kernel_source_sha: {sha}' not in text[:3000]:
+            continue
+        rows = {}
+        for line in text.splitlines():
+            parts = [x.strip() for x in line.split('|')]
+            if len(parts) == 2:
+                try:
+                    rows[parts[0]] = float(parts[1])
+                except ValueError:
+                    pass
+        name = 'profiles/' + os.path.basename(path)
+        if 'step_fetch_bytes' not in rows:
+            return None, name + ' holds no step_fetch_bytes row'
+        trace_ms = rows.get('region_trace_us', 0.0) * 1e-3
+        if region_ms and trace_ms > 1.05 * region_ms:
+            return None, (f'{name}: kernels of one step sum to {trace_ms:.3f} ms in the trace, more '
+                          f'than 5 % above this run\'s {region_ms:.3f} ms: not used as evidence')
+        fetch2 = rows.get('step_fetch_bytes_x2', 2.0 * rows['step_fetch_bytes'])
+        return ({'fetch_bytes_per_step_raw': rows['step_fetch_bytes'],
+                 'fetch_bytes_per_step': fetch2,
+                 'write_bytes_per_step': rows.get('step_write_bytes'),
+                 'bytes_per_step': fetch2 + rows.get('step_write_bytes', 0.0),
+                 'l2_hit_rate': rows.get('l2_hit_rate')},
+                f'{name}: FETCH_SIZE (x2: the gfx950 correction of MI355X_MICROARCH.md for wide '
+                f'streaming reads) + WRITE_SIZE summed over the kernels of one step, separate --pmc '
+                f'passes; kernels of a step sum to {trace_ms:.3f} ms in the trace')
+    return None, (f'no committed profile carries kernel_source_sha {sha} for {workload} '
+                  f'(bash tools/profile_round.sh <tag> {workload})')
+
+
+def dual_roofline(region_ms, frames, iters, flops_per_frame_iter, bytes_per_iter, bytes_formula,
+                  kernel, workload, primary):
+    """roofline object with BOTH bounds: `primary` ('hbm' or 'fp64_valu') on top, the other one
+    under `other`.  region_ms = device time of one step's EM region (HIP events in the library)."""
+    sec = region_ms * 1e-3
+    alg_bytes = bytes_per_iter * iters
+    gbs = alg_bytes / sec / 1e9
+    tf = flops_per_frame_iter * frames * iters / sec / 1e12
+    traffic, src = workload_pmc(workload, region_ms)
+    hbm = {'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+           'frac': gbs / HBM_PEAK_GBS, 'algorithmic_bytes_per_step': alg_bytes,
+           'algorithmic_bytes_per_iteration': bytes_per_iter, 'formula': bytes_formula}
+    valu = {'bound': 'fp64_valu', 'achieved': tf, 'peak': FP64_VALU_PEAK_TF, 'unit': 'TFLOP/s',
+            'frac': tf / FP64_VALU_PEAK_TF, 'flops_per_frame_iter': flops_per_frame_iter}
+    top, other = (hbm, valu) if primary == 'hbm' else (valu, hbm)
+    out = dict(top)
+    out['other'] = other
+    out['kernel'] = kernel
+    out['region_ms'] = region_ms
+    out['traffic'] = None if traffic is None else traffic['bytes_per_step']
+    out['traffic_detail'] = traffic
+    out['traffic_source'] = src
+    if traffic is not None:
+        out['traffic_over_algorithmic'] = traffic['bytes_per_step'] / alg_bytes
+    return out
+
+
+def vmf_features(Y):
+    """(F, T, D) complex observation -> (F, T, 2 D) float32 unit vectors: phase-normalised to
+    channel 0, real and imaginary parts stacked (what a vMF mixture clusters on an array)."""
+    z = Y * np.exp(-1j * np.angle(Y[..., :1]))
+    f = np.concatenate([z.real, z.imag], axis=-1).astype(np.float64)
+    return (f / np.maximum(np.linalg.norm(f, axis=-1, keepdims=True), 1e-300)).astype(np.float32)
+
+
+def run_config4(args, local_rank, dev, leg='watson', steps=None, warmup=None, with_cpu=True):
+    """BASELINE configs[3]: mixture fit (100 EM iterations + final E-step) -> PSD -> MVDR-Souden
+    with the automatic reference channel -> apply, F=257 T=800 D=6 K=3, one GPU, everything
+    resident in HBM.  leg = 'watson' (CWMMTrainer's kernel on the complex observation) or 'vmf'
+    (VMFMMTrainer's kernel, one mixture per bin on the 2D-dim real features)."""
+    import torch
+    from pb_bss_amd import _lib, engine
+    from pb_bss_amd.distribution import ComplexWatsonTrainer
+    from pb_bss_amd.pipeline import device_ops as ops
+    from pb_bss_amd.testing import synth
+    F_, T_, D_, K_ = C4['F'], C4['T'], C4['D'], C4['K']
+    steps = steps or args.steps
+    warmup = args.warmup if warmup is None else warmup
+    Y0, init0 = synth.make_stft(F_, T_, D_, K_, seed=0)
+    y, g0 = _lib.to_device(Y0), _lib.to_device(init0)
+    engine.set_timing(True, local_rank)
+    if leg == 'watson':
+        spline = ComplexWatsonTrainer(D_).device_spline(y.device)
+
+        def fit():
+            return engine.cwmm_fit(y, K_, spline, gamma0=g0, iterations=args.iters,
+                                   final_predict=True, check_status=False)['affiliation']
+    else:
+        feat0 = vmf_features(Y0)
+        feat = _lib.to_device(feat0)
+
+        def fit():
+            return engine.vmfmm_fit(feat, K_, gamma0=g0, iterations=args.iters,
+                                    final_predict=True)['affiliation']
+
+    def extract(masks):
+        X = y.transpose(-2, -1).contiguous()                      # (F, D, T)
+        psd = ops.psd(X, masks)                                   # (F, K, D, D)
+        target = psd.movedim(-3, 0).contiguous()                  # (K, F, D, D)
+        noise = (psd.sum(dim=-3).unsqueeze(0) - target).contiguous()
+        w = ops.mvdr_souden(target, noise)                        # (K, F, D)
+        return w, torch.stack([ops.apply_bf(w[k], X) for k in range(K_)])
+
+    def step():
+        masks = fit()
+        if args.c4_extraction == 'off':
+            return masks, None, None
+        w, enh = extract(masks)
+        return masks, w, enh
+
+    read_ms = lambda lag: engine.last_kernel_ms(local_rank, lag)  # noqa: E731
+    ph = preheat(step, min(args.preheat_s, 0.5), False, dev)
+    elapsed, region_ms, last = timed(step, steps, warmup, False, dev, read_ms)
+    ms_per_step = elapsed / steps * 1e3
+    # the EM region alone, back to back (what the kernel trace of --workload config4 shows)
+    el_fit, fit_ms, _ = timed(fit, steps, 2, False, dev, read_ms)
+    name = 'CWMMTrainer (complex Watson mixture)' if leg == 'watson' else \
+        'VMFMMTrainer (von-Mises-Fisher mixture, one per bin, on 2D-dim real features)'
+    bytes_iter = 8.0 * F_ * T_ * D_ if leg == 'watson' else 4.0 * F_ * T_ * 2 * D_
+    flops = c4_flops(D_, K_) if leg == 'watson' else (2 * 2 * D_ * K_ + 35 * K_ + 2 * 2 * D_ * K_)
+    out = {
+        'workload': f'BASELINE configs[3]: {name} {args.iters} EM iterations + final E-step -> PSD '
+                    f'-> get_mvdr_vector_souden (automatic reference channel) per class -> apply, '
+                    f'F={F_} T={T_} D={D_} K={K_}, complex64 STFT resident in HBM',
+        'leg': leg,
+        'value': args.iters * steps / elapsed, 'unit': 'EM iterations/s (whole chain in the step)',
+        'ms_per_step': ms_per_step, 'steps': steps, 'warmup': warmup, 'dtype': 'f64',
+        'em_only': {'value': args.iters * steps / el_fit, 'ms_per_fit': el_fit / steps * 1e3,
+                    'region_ms': fit_ms,
+                    'what': 'the fit + final E-step alone, back to back (no extraction stage)'},
+        'preheat': ph,
+        'roofline': dual_roofline(
+            fit_ms, F_ * T_, args.iters, flops, bytes_iter,
+            '8*F*T*D (one read of the complex64 observation per EM iteration, SURVEY 8d)'
+            if leg == 'watson' else '4*F*T*2D (one read of the float32 features per EM iteration)',
+            ('cwmm_em_kernel<6,3,float,false> + cwmm_em_split_kernel (remainder bin 256 as split '
+             'groups)') if leg == 'watson' else 'vmf_em_kernel + embed_finalize_kernel per iteration',
+            'config4' if leg == 'watson' else 'config4_vmf', 'fp64_valu'),
+    }
+    if args.check_bins and args.c4_extraction == 'on':
+        from oracle import beamformer as ob
+        masks, w, enh = (_lib.to_host(x) for x in last)
+        fs = spread(0, F_, min(args.check_bins, 16))
+        Y128 = Y0[fs].astype(np.complex128)
+        if leg == 'watson':
+            from oracle import cwmm as ow
+            ref = ow.cwmm_predict(ow.cwmm_fit(Y128, init0[fs], iterations=args.iters), Y128)
+        else:
+            from oracle import embed as oe
+            f64 = feat0[fs].astype(np.float64)
+            ref = oe.vmfmm_predict(oe.vmfmm_fit(f64, init0[fs], args.iters), f64)
+        m_err = float(np.abs(masks[fs] - ref).max())
+        # extraction against the oracle fed with the DEVICE masks of ALL bins (the automatic
+        # reference channel sums over every bin; the mixture itself is checked above)
+        X = Y0.astype(np.complex128).transpose(0, 2, 1)
+        psd = ob.psd(X, masks)
+        w_err = e_err = 0.0
+        for k in range(K_):
+            w_ref = ob.mvdr_souden(psd[:, k], psd.sum(1) - psd[:, k])
+            w_err = max(w_err, float(np.abs(w[k] - w_ref).max() / np.abs(w_ref).max()))
+            s_ref = ob.apply_bf(w_ref, X)
+            e_err = max(e_err, float(np.abs(enh[k] - s_ref).max() / np.abs(s_ref).max()))
+        out['verify'] = {
+            'bins_checked': fs, 'mask_max_abs_err': m_err, 'bf_vector_max_rel_err': w_err,
+            'enhanced_max_rel_err': e_err, 'tolerance': 1e-5,
+            'ok': bool(m_err < 1e-5 and w_err < 1e-5 and e_err < 1e-5),
+            'includes_remainder_bin': True,
+            'what': f'posterior masks after {args.iters} EM iterations vs the float64 NumPy oracle '
+                    f'on evenly spaced bins (first and last included); MVDR-Souden vectors and '
+                    f'enhanced signals of all classes and bins vs the oracle PSD -> mvdr_souden -> '
+                    f'apply on the device masks',
+        }
+    if with_cpu and args.cpu_iters > 0:
+        from oracle import beamformer as ob
+        n = max(2, args.cpu_iters // 12)
+        Y128 = Y0.astype(np.complex128)
+        if leg == 'watson':
+            from oracle import cwmm as ow
+
+            def cpu():
+                m = ow.cwmm_fit(Y128, init0, iterations=n)
+                return ow.cwmm_predict(m, Y128)
+        else:
+            from oracle import embed as oe
+            f64 = feat0.astype(np.float64)
+
+            def cpu():
+                return oe.vmfmm_predict(oe.vmfmm_fit(f64, init0, n), f64)
+
+        def chain():
+            mk = cpu()
+            X = Y128.transpose(0, 2, 1)
+            psd = ob.psd(X, mk)
+            for k in range(K_):
+                ob.apply_bf(ob.mvdr_souden(psd[:, k], psd.sum(1) - psd[:, k]), X)
+        med, runs = median_rate(chain, n)
+        out['cpu_baseline'] = {
+            'value': med, 'unit': 'EM iterations/s', 'cores': 1, 'kind': 'port',
+            'runs': runs,
+            'sample': f'NumPy oracle chain (oracle/cwmm.py / oracle/embed.py fit of {n} EM iterations '
+                      f'+ predict + PSD + mvdr_souden + apply), full F={F_} T={T_} D={D_} K={K_}, '
+                      f'median of 3 runs; host has {os.cpu_count()} logical cores, einsum / LAPACK '
+                      f'on D x D matrices are single-threaded',
+            'reference_recorded': reference_recorded('config4'),
+        }
+    return out
+
+
+def run_config5(args, local_rank, dev, steps=None, warmup=None, with_cpu=True):
+    """BASELINE configs[4] on one GPU: GCACGMMTrainer's loop (cACGMM on the STFT x spherical
+    Gaussian on 40-dim embeddings, shared affiliations), 100 EM iterations + final E-step,
+    everything resident in HBM."""
+    from pb_bss_amd import _lib, engine
+    from pb_bss_amd.testing import synth
+    F_, T_, D_, K_, E_ = C5['F'], C5['T'], C5['D'], C5['K'], C5['E']
+    steps = steps or args.steps
+    warmup = args.warmup if warmup is None else warmup
+    Y0, e0, init0 = synth.make_joint(F_, T_, D_, K_, E_, seed=0)
+    y, e, g0 = _lib.to_device(Y0), _lib.to_device(e0), _lib.to_device(init0)
+    engine.set_timing(True, local_rank)
+    kind = _lib.EMBED_GAUSS_SPHERICAL
+
+    def step(iters=None):
+        return engine.joint_fit(y, e, K_, kind, gamma0=g0,
+                                iterations=args.iters if iters is None else iters,
+                                final_predict=True, check_status=False)
+
+    read_ms = lambda lag: engine.last_kernel_ms(local_rank, lag)  # noqa: E731
+    ph = preheat(step, min(args.preheat_s, 0.5), False, dev)
+    elapsed, region_ms, last = timed(step, steps, warmup, False, dev, read_ms)
+    ms_per_step = elapsed / steps * 1e3
+    bytes_iter = 8.0 * F_ * T_ * D_ + 4.0 * F_ * T_ * E_
+    out = {
+        'workload': f'BASELINE configs[4] on one GPU: joint spatial + spectral model (GCACGMMTrainer: '
+                    f'cACGMM on the STFT x spherical Gaussian on {E_}-dim float32 embeddings, shared '
+                    f'affiliations), {args.iters} EM iterations + final E-step, F={F_} T={T_} D={D_} '
+                    f'K={K_}, resident in HBM',
+        'value': args.iters * steps / elapsed, 'unit': 'EM iterations/s',
+        'ms_per_step': ms_per_step, 'us_per_iteration': ms_per_step * 1e3 / args.iters,
+        'steps': steps, 'warmup': warmup, 'dtype': 'f64', 'preheat': ph,
+        'status_bits_or': int(np.bitwise_or.reduce(_lib.to_host(last['status']).ravel())),
+        'roofline': dual_roofline(
+            region_ms, F_ * T_, args.iters, c5_flops(D_, K_, E_), bytes_iter,
+            '8*F*T*D + 4*F*T*E (one read of the complex64 observation and of the float32 '
+            'embedding per EM iteration)',
+            'per iteration: embedding E-step + cacgmm_joint_kernel<8,3> + embedding M-step sweep + '
+            'finalize (region_ms = HIP events around the whole enqueued loop, inside the library)',
+            'config5', 'hbm'),
+    }
+    if args.check_bins:
+        # the spectral mixture couples every bin: the oracle runs the full problem, a few
+        # iterations (0.3 s per iteration on a host core)
+        from oracle import embed as oe
+        n = 4
+        got = _lib.to_host(step(n)['affiliation'])
+        Y128, e64 = Y0.astype(np.complex128), e0.astype(np.float64)
+        ref = oe.joint_model_predict(oe.joint_fit('gaussian', Y128, e64, init0, n), Y128, e64)
+        err = float(np.abs(got - ref).max())
+        g100 = _lib.to_host(last['affiliation'])
+        out['verify'] = {
+            'mask_max_abs_err': err, 'iterations_checked': n, 'tolerance': 1e-6,
+            'bins_checked': F_, 'includes_remainder_bin': True,
+            'ok': bool(err < 1e-6 and np.isfinite(g100).all()
+                       and abs(float(g100.sum(1).mean()) - 1.0) < 1e-9),
+            'what': f'posterior masks of ALL {F_} bins after {n} EM iterations vs the float64 NumPy '
+                    f'oracle (oracle/embed.py joint_fit; the spectral mixture couples the bins, so '
+                    f'the oracle runs the full problem); the {args.iters}-iteration masks of the '
+                    f'timed steps are checked to be finite and to sum to one over the classes',
+        }
+        if with_cpu and args.cpu_iters > 0:
+            med, runs = median_rate(lambda: oe.joint_fit('gaussian', Y128, e64, init0, 3), 3)
+            out['cpu_baseline'] = {
+                'value': med, 'unit': 'EM iterations/s', 'cores': 1, 'kind': 'port', 'runs': runs,
+                'sample': f'NumPy oracle joint_fit (oracle/embed.py), full F={F_} T={T_} D={D_} '
+                          f'K={K_} E={E_}, 3 EM iterations, median of 3 runs; host has '
+                          f'{os.cpu_count()} logical cores, 1 used',
+                'reference_recorded': reference_recorded('config5'),
+            }
+    return out
+
+
+def main_config45(args):
+    """`--workload config4|config5`: that configuration as the primary line (profiling runs)."""
+    world, rank, local_rank, dev, use_dist = setup(args)
+    assert world == 1, 'configs[3] / [4] are measured on one GPU'
+    if args.workload == 'config4':
+        blk = run_config4(args, local_rank, dev, leg=args.leg)
+        metric = 'mixture-model EM iterations/sec on F=257,T=800,D=6,K=3 (+ MVDR-Souden)'
+    else:
+        blk = run_config5(args, local_rank, dev)
+        metric = 'joint GCACGMM EM iterations/sec on F=513,T=500,D=8,K=3,E=40'
+    res = {'metric': metric, 'value': blk['value'], 'unit': blk['unit'], 'n_gpus': 1,
+           'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': blk['ms_per_step'],
+           'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64',
+           'data': 'synthetic', 'config': {'workload': blk['workload']}}
+    res.update({k: v for k, v in blk.items() if k not in ('value', 'unit', 'ms_per_step', 'workload',
+                                                         'steps', 'warmup', 'dtype')})
+    emit(json.dumps(res), use_dist)
+
+
 def has_f32():
     from pb_bss_amd import _lib
     return _lib.load().pbbss_version() >= 300
@@ -896,10 +1291,16 @@ def has_f32():
 def main():
     args = parse()
     if args.print_source_sha:
-        print(kernel_source_sha())
+        if args.workload in ('config4', 'config5'):
+            print(workload_source_sha('config4_vmf' if (args.workload, args.leg) ==
+                                      ('config4', 'vmf') else args.workload))
+        else:
+            print(kernel_source_sha())
         return
     if args.workload == 'config3':
         return main_config3(args)
+    if args.workload in ('config4', 'config5'):
+        return main_config45(args)
     world, rank, local_rank, dev, use_dist = setup(args)
     res = run_headline(args, world, rank, local_rank, dev, use_dist)
     out = None
@@ -923,6 +1324,11 @@ def main():
         blk, _ = run_config3(args, world, rank, local_rank, dev, use_dist)
         if rank == 0:
             out['config3'] = blk
+    if args.configs45 == 'auto' and world == 1:
+        n45 = max(5, args.steps // 3)
+        out['config4'] = run_config4(args, local_rank, dev, 'watson', steps=n45, warmup=2)
+        out['config4']['vmf'] = run_config4(args, local_rank, dev, 'vmf', steps=n45, warmup=2)
+        out['config5'] = run_config5(args, local_rank, dev, steps=n45, warmup=2)
     if rank == 0 and os.environ.get('PBBSS_BENCH_ONE_DEVICE') == '1':
         out['rehearsal'] = ('PBBSS_BENCH_ONE_DEVICE=1: all ranks shared GPU 0 over gloo -- a '
                             'functional rehearsal of the multi-rank path, not a measurement')

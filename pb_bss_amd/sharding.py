@@ -343,13 +343,21 @@ def fit_predict_sharded(y, initialization, iterations=100, *, trainer=None, bin_
                            and y.is_cuda) else (
             t.device('cpu') if hasattr(trainer, '_to_device')
             else t.device('cuda', t.cuda.current_device()))
-        if hook is not None:  # keep the collective schedule of the other ranks
+        # keep the collective schedule of the ranks that own bins, IN THEIR ORDER (the step-wise
+        # loop of CACGMMTrainer, cacgmm.py:252-278): per EM iteration first -- from the second
+        # iteration on -- the aligner's mask gather after the E-step, then the weight hook's
+        # all-reduce before the M-step.  Issuing all all-reduces first and the gathers afterwards
+        # would pair this rank's n-th collective with a different one on its peers.
+        wshape = None
+        if hook is not None:
             nd_a = initialization.ndim
             red = sorted({a % nd_a for a in wca})
-            shape = [1 if ax in red else n for ax, n in enumerate(initialization.shape)]
-            hook.idle(shape, t.float64, dev, iterations)
-        if aligner is not None:  # one gather per E-step: every iteration but the first
-            aligner.idle(K, y.shape[-2], t.float64, dev, max(iterations - 1, 0))
+            wshape = [1 if ax in red else n for ax, n in enumerate(initialization.shape)]
+        for it in range(iterations):
+            if aligner is not None and it > 0:
+                aligner.idle(K, y.shape[-2], t.float64, dev, 1)
+            if hook is not None:
+                hook.idle(wshape, t.float64, dev, 1)
         # more ranks than bins: this rank owns nothing and contributes an empty block
         shape = list(y.shape[:-2]) + [K, y.shape[-2]]
         shape[f_axis_y] = 0

@@ -470,3 +470,80 @@ def test_joint_model_spectral_sums_allreduce_world2():
     ret = mgr.dict()
     mp.spawn(_joint_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
     assert dict(ret) == {0: True, 1: True}
+
+
+# ---------------------------------------------------------------------------------------------
+# A rank WITHOUT bins (world > F) next to an inline aligner and bin-constant weights: the idle
+# rank must issue its collectives in the order of the step-wise loop of the ranks that own bins
+# (cacgmm.py:252-278: weight all-reduce in iteration 0, then mask gather + weight all-reduce per
+# iteration) -- gloo pairs collectives by sequence, a different order mismatches or hangs.
+def _stepwise_cpu_trainer():
+    from pb_bss_amd.distribution import CACGMMTrainer
+
+    class _StepwiseCPUTrainer(CACGMMTrainer):
+        """CPU stand-in with the collective schedule of CACGMMTrainer's step-wise loop; the
+        arithmetic is a toy (the schedule is what is under test)."""
+        _to_device = staticmethod(lambda x: x if isinstance(x, torch.Tensor) else torch.from_numpy(x))
+
+        def fit_predict(self, y, initialization=None, iterations=100, *, weight_constant_axis=(-1,),
+                        inline_permutation_aligner=None, _weight_hook=None, **_):
+            aff = initialization.clone()                         # (F_local, K, T)
+            weights = []
+            for it in range(iterations):
+                if it > 0:
+                    aff = aff * (1.0 + 0.1 * it)
+                    aff = aff / aff.sum(-2, keepdim=True)
+                    kft = aff.transpose(0, 1).contiguous()
+                    mapping = inline_permutation_aligner.calculate_mapping(kft)
+                    aff = inline_permutation_aligner.apply_mapping(kft, mapping).transpose(0, 1)
+                weights.append(_weight_hook(aff, None))
+            self.weights = weights
+            return aff.contiguous()
+
+    return _StepwiseCPUTrainer()
+
+
+class _IdentityAligner:
+    def calculate_mapping(self, kft):
+        K, F, _ = kft.shape
+        return np.tile(np.arange(K)[:, None], (1, F))
+
+    def apply_mapping(self, kft, mapping):
+        return kft
+
+
+def _idle_order_worker(rank, world, port, ret):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from pb_bss_amd.sharding import fit_predict_sharded
+        rng = np.random.default_rng(5)
+        F, K, T, D = 1, 2, 12, 3                                 # world 2 > F: rank 1 owns nothing
+        y = torch.from_numpy(rng.normal(size=(F, T, D)) + 1j * rng.normal(size=(F, T, D)))
+        init = rng.uniform(size=(F, K, T))
+        init = torch.from_numpy(init / init.sum(1, keepdims=True))
+        tr = _stepwise_cpu_trainer()
+        got = fit_predict_sharded(y, init, iterations=4, trainer=tr, weight_constant_axis=(-3,),
+                                  inline_permutation_aligner=_IdentityAligner())
+        # single-process expectation of the toy loop
+        aff = init.clone()
+        for it in range(1, 4):
+            aff = aff * (1.0 + 0.1 * it)
+            aff = aff / aff.sum(-2, keepdim=True)
+        ok = got.shape == (F, K, T) and torch.allclose(got, aff, atol=1e-14)
+        if rank == 0:  # the owner's weights are means over ALL (= its own) bins
+            ok = ok and len(tr.weights) == 4 and torch.allclose(
+                tr.weights[-1], aff.mean(dim=0, keepdim=True), atol=1e-14)
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_idle_rank_keeps_collective_order_with_aligner_world2():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_idle_order_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}
