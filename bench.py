@@ -491,6 +491,23 @@ def identical_on_all_ranks(x, use_dist, world):
     return bool((allc == allc[0:1]).all().item())
 
 
+def per_rank_table(values, use_dist, world, dev):
+    """{name: float} of THIS rank -> {name: [value of rank 0, rank 1, ...]} on every rank (one
+    small all-gather; at N = 1 a one-element list each).  What a first scaling run needs in order
+    to explain itself: which rank, and which stage of it, sets the max-over-ranks time."""
+    import torch
+    import torch.distributed as dist
+    names = sorted(values)
+    mine = torch.tensor([float(values[n]) for n in names], dtype=torch.float64, device=dev)
+    if use_dist:
+        allv = torch.empty((world, len(names)), dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(allv, mine.unsqueeze(0).contiguous())
+    else:
+        allv = mine.unsqueeze(0)
+    allv = allv.cpu().tolist()
+    return {n: [round(allv[r][i], 4) for r in range(len(allv))] for i, n in enumerate(names)}
+
+
 def spread(lo, hi, n):
     """n bins of [lo, hi) including the first and the last."""
     if hi - lo <= n:
@@ -570,6 +587,17 @@ def run_headline(args, world, rank, local_rank, dev, use_dist, precision='f64'):
         torch.cuda.synchronize()
         gather_ms = max_over_ranks(e0.elapsed_time(e1) / 10, use_dist, dev)
     same = identical_on_all_ranks(masks, use_dist, world)
+    mine = {'em_kernel_ms': kernel_ms, 'bins_per_utterance': float(n_loc)}
+    if use_dist:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        fence(use_dist)
+        e0.record()
+        for _ in range(10):
+            all_gather_bins(loc, F, bin_axis=1)
+        e1.record()
+        torch.cuda.synchronize()
+        mine['gather_ms'] = e0.elapsed_time(e1) / 10
+    per_rank = per_rank_table(mine, use_dist, world, dev)
     got2 = None
     if precision != 'f64' and args.check_bins:
         # per-step check of the single-precision kernel (see the verification below): two
@@ -616,6 +644,10 @@ def run_headline(args, world, rank, local_rank, dev, use_dist, precision='f64'):
         'status_bits_or': status_or,
         'preheat': ph,
         'sustained': sus,
+        'per_rank': dict(per_rank, what='this rank\'s EM kernel time per step (HIP events in the '
+                                        'library, average over the timed steps), its block of '
+                                        'bins, and -- N > 1 -- its own time for one mask '
+                                        'all-gather (HIP events, 10 back to back)'),
     }
     if precision == 'f64':
         out['roofline'] = roofline_block(kernel_ms, world * n_loc, args.iters, ms_per_step)
@@ -720,6 +752,13 @@ def config3_leg(args, data, Y, init, shard, world, rank, dev, use_dist, steps, w
     # ---- untimed verification pass: outputs of ALL ranks gathered ----
     out = pipeline.separate(Y, init, args.iters, 2 * (F - 1), shard=shard, mask_gather_dtype=gdt,
                             beamformer=args.beamformer, gather_output=shard is not None)
+    # ---- untimed diagnostic pass: this rank's wall time per stage, synchronised after each ----
+    stage = {}
+    pipeline.separate(Y, init, args.iters, 2 * (F - 1), shard=shard, mask_gather_dtype=gdt,
+                      beamformer=args.beamformer, stage_ms=stage)
+    for name in ('em_ms', 'gather_ms', 'dhtv_ms', 'map_gather_ms', 'extract_ms'):
+        stage.setdefault(name, 0.0)
+    stage_tab = per_rank_table(stage, use_dist and shard is not None, world, dev)
     map_same = identical_on_all_ranks(out['mapping'], use_dist and shard is not None, world)
     enh_same = identical_on_all_ranks(torch.view_as_real(out['enhanced'].contiguous()),
                                       use_dist and shard is not None, world)
@@ -731,6 +770,12 @@ def config3_leg(args, data, Y, init, shard, world, rank, dev, use_dist, steps, w
                 'alignment, PSD, ' + args.beamformer + ' and apply for all utterances)',
         'ms_per_step': elapsed / steps * 1e3, 'steps': steps, 'warmup': warmup,
         'utterances_per_s': U * steps / elapsed, 'scaling': 'strong', 'n_gpus': world,
+        'per_rank_stage_ms': dict(stage_tab, what='untimed pass with a device synchronisation '
+                                                  'after every stage (the stages of the timed '
+                                                  'steps overlap, these do not): EM + predict, '
+                                                  'mask all-gather, DHTV mapping of the rank\'s '
+                                                  'utterances, mapping all-gather, alignment + '
+                                                  'PSD + beamformer + apply'),
         'sharding': ('none (1 GPU)' if shard is None else
                      f'{shard} over {world} ranks' +
                      (f'; one RCCL all-gather of the masks ({args.mask_gather}) + one of the '

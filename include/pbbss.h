@@ -723,6 +723,13 @@ int pbbss_set_split_tail(pbbss_handle_t h, int enable);
  * 128 frames each), -2..-32 = bin-chunk team kernel of that size (A/B). */
 int pbbss_set_dhtv_team(pbbss_handle_t h, int workgroups_per_utterance);
 int pbbss_split_error(pbbss_handle_t h, int* out_flag);
+/* Consume a reported time-out: waits for the device, then re-zeroes the arrival counters of the
+ * split / member protocols and the sticky flag of pbbss_split_error.  The Python layer calls it
+ * before it repeats a fit without split groups, so that (a) a LATER genuine NONFINITE |
+ * EIG_NOCONV status is not mistaken for another time-out and (b) counters left non-zero by an
+ * aborted launch cannot corrupt the next split launch of the handle.  (New in this library; the
+ * reference has no inter-process state to reset.) */
+int pbbss_split_reset(pbbss_handle_t h);
 /* Development aid: device buffer of 64 uint64 receiving per-phase shader-cycle sums
  * of the EM kernel ([wave 0..3][phase 0..7]); only written by library builds made
  * with -DPBBSS_PHASE_PROFILE (`make prof`), ignored otherwise.  NULL disables. */

@@ -439,6 +439,19 @@ PBBSS_API int pbbss_split_error(pbbss_handle_t h, int* out_flag) {
   return PBBSS_OK;
 }
 
+PBBSS_API int pbbss_split_reset(pbbss_handle_t h) {
+  DeviceGuard device_guard(h);
+  if (!h || !h->cfg.xbuf) return PBBSS_ERR_INVALID_ARG;
+  // every launch of this handle must have left the device: a member still running would see its
+  // arrival counter vanish.  Then the counters, the per-launch error word and the sticky flag of
+  // pbbss_split_error go back to their creation state (a launch that was aborted half-way -- a
+  // device fault, a debug-build trap, a timed-out hand-off -- leaves the counters non-zero, and
+  // every later split launch of the handle would pass its barriers early or time out).
+  if (hipDeviceSynchronize() != hipSuccess) return PBBSS_ERR_HIP;
+  if (hipMemset(h->cfg.xbuf, 0, 256) != hipSuccess) return PBBSS_ERR_HIP;
+  return PBBSS_OK;
+}
+
 PBBSS_API int pbbss_kernel_ms_lagged(pbbss_handle_t h, int lag, float* out_ms) {
   DeviceGuard device_guard(h);
   if (!h || !out_ms) return PBBSS_ERR_INVALID_ARG;
@@ -670,13 +683,19 @@ PBBSS_API int pbbss_cacgmm_fit(pbbss_handle_t h, const void* y, int64_t B, int T
     cfg.ev_t0 = h->ring0[slot];
     cfg.ev_t1 = h->ring1[slot];
   }
+  int rc;
   if (f32) {
-    const int rc = pbbss::em32_launch(D, K, a, cfg, as_stream(stream));
+    rc = pbbss::em32_launch(D, K, a, cfg, as_stream(stream));
     // a long utterance does not fit the LDS-resident packed kernel: say "unsupported", the
     // float64 kernel (which has an HBM-scratch variant) serves it
-    return rc == PBBSS_ERR_LDS_CAPACITY ? PBBSS_ERR_UNSUPPORTED : rc;
+    if (rc == PBBSS_ERR_LDS_CAPACITY) rc = PBBSS_ERR_UNSUPPORTED;
+  } else {
+    rc = pbbss::em_launch(D, K, o->y_is_c128, a, cfg, as_stream(stream));
   }
-  return pbbss::em_launch(D, K, o->y_is_c128, a, cfg, as_stream(stream));
+  // a launch that was refused (capacity, shape) recorded no events: give its ring slot back, or
+  // pbbss_kernel_ms_lagged would read an unrecorded / stale pair for it
+  if (rc != PBBSS_OK && h->timing) --h->ring_seq;
+  return rc;
 }
 
 PBBSS_API int pbbss_cacgmm_fit_shared(pbbss_handle_t h, const void* y, int64_t B, int T, int D,

@@ -280,6 +280,13 @@ class CACGMMTrainer:
                         precision='f32'), single, mode)
                 except NotImplementedError:
                     pass  # e.g. an utterance too long for the LDS-resident kernel: float64 serves it
+                except (AssertionError, np.linalg.LinAlgError) as e:
+                    # a status failure of the reduced-precision kernel (ill-conditioned bins are
+                    # likelier to go non-finite in float32): the float64 kernel is the accuracy
+                    # superset -- let it try before the reference's error is raised
+                    import warnings
+                    warnings.warn(f'packed-FP32 fit failed ({type(e).__name__}: {e}); repeating it '
+                                  'in float64', RuntimeWarning)
             return self._rounded(self._fit_fused(
                 y.reshape(-1, N, D), indep, K, gamma0, model, iterations, sal,
                 act, mode, covariance_norm, affiliation_eps, eigenvalue_floor,

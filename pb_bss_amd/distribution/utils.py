@@ -36,6 +36,32 @@ class _ProbabilisticModel:
             f'Close matches: {close}')
 
 
+def stack_parameters(parameters):
+    """A list of equally-typed model objects -> ONE model whose every parameter array carries a
+    new leading axis (pb_bss/distribution/utils.py:259-316: e.g. the per-utterance `CACGMM`s of a
+    batch stacked into one batched model, which `predict` then serves in a single launch).
+    Nested models are stacked recursively; NumPy parameters come back as NumPy arrays, device
+    tensors as device tensors (the reference only knows the former); the reference's assertions
+    -- one model type, one type per field -- are kept."""
+    parameters = list(parameters)
+    assert len(parameters) > 0, 'stack_parameters needs at least one model'
+    kinds = {type(p) for p in parameters}
+    assert len(kinds) == 1, kinds
+    cls = kinds.pop()
+    stacked = {}
+    for f in fields(cls):
+        values = [getattr(p, f.name) for p in parameters]
+        value_kinds = {type(v) for v in values}
+        assert len(value_kinds) == 1, (f.name, value_kinds)
+        if is_dataclass(values[0]):
+            stacked[f.name] = stack_parameters(values)
+        elif _lib.is_torch(values[0]):
+            stacked[f.name] = _lib.torch().stack(values)
+        else:
+            stacked[f.name] = np.stack(values)
+    return cls(**stacked)
+
+
 def as_result(x, like_torch):
     """Device tensor -> what the caller works with (torch in, torch out;
     NumPy in, NumPy out, as the reference returns)."""

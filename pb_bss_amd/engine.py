@@ -55,12 +55,16 @@ def _checked_with_split_retry(launch, dev, what):
         import warnings
         warnings.warn(f'{what}: the split groups of the remainder bin were not co-resident (GPU '
                       'shared with other work); repeating the fit without them', RuntimeWarning)
+        # consume the report: counters and the sticky flag go back to zero, so that a later
+        # genuine NONFINITE | EIG_NOCONV failure of this handle is raised, not refitted
+        split_reset(dev.index)
+        was = split_tail(dev.index)
         set_split_tail(False, dev.index)
         try:
             r = launch()
             bits = _status_bits(r['status'])
         finally:
-            set_split_tail(True, dev.index)
+            set_split_tail(was, dev.index)  # what the caller had chosen, not unconditionally on
     _raise_for_bits(bits, what)
     return r
 
@@ -204,6 +208,7 @@ def em_fit_shared(y, K, group, *, weight_mode, gamma0=None, model=None, iteratio
             import warnings
             warnings.warn('cooperative shared-weight launch timed out waiting for co-residency; '
                           'repeating the fit step by step', RuntimeWarning, stacklevel=2)
+            split_reset(dev.index)  # consume the report (see _checked_with_split_retry)
             return None
         _status_raise_em(out_st, 'CACGMMTrainer.fit')
     return dict(eigvec=out_vec, eigval=out_val, weight=out_w, status=out_st,
@@ -558,10 +563,25 @@ def wmwf(target, noise, distortion_weight=1.0, frequency_dependent=False):
     return mat, num, den, st
 
 
+_SPLIT_TAIL = {}  # (device index, host thread) -> last set_split_tail value (default: on)
+
+
 def set_split_tail(enable, device_index=None):
     """pbbss_set_split_tail: toggle the split-bin handling of remainder problems."""
     _lib.check(_lib.load().pbbss_set_split_tail(_lib.handle(device_index), int(bool(enable))),
                'set_split_tail')
+    _SPLIT_TAIL[_handle_key(device_index)] = bool(enable)
+
+
+def split_tail(device_index=None):
+    """The split-tail setting in force on this thread's handle (handles are created with it on)."""
+    return _SPLIT_TAIL.get(_handle_key(device_index), True)
+
+
+def split_reset(device_index=None):
+    """pbbss_split_reset: consume a reported time-out (re-zero the protocol counters and the
+    sticky flag of split_error) after the device has drained."""
+    _lib.check(_lib.load().pbbss_split_reset(_lib.handle(device_index)), 'split_reset')
 
 
 _DHTV_TEAM = {}  # (device index, host thread) -- one C handle each -- -> last set_dhtv_team value

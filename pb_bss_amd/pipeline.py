@@ -126,8 +126,36 @@ def _chain_after_masks(Y, masks_fkt, mapping, ops, beamformer='gev+ban', shard_g
     return aligned, w.movedim(0, 1).contiguous(), enhanced
 
 
+class _Laps:
+    """Stage clock of `separate(stage_ms=...)`: synchronises the device after every stage (so the
+    stages no longer overlap -- a diagnostic pass, not the timed one) and adds the wall time of
+    the stage to the caller's dict."""
+
+    def __init__(self, sink, device):
+        import time
+        self.sink, self.device, self.clock = sink, device, time.perf_counter
+        self.t0 = None
+        if sink is not None:
+            self._sync()
+            self.t0 = self.clock()
+
+    def _sync(self):
+        if getattr(self.device, 'type', 'cpu') == 'cuda':
+            import torch
+            torch.cuda.synchronize(self.device)
+
+    def lap(self, name):
+        if self.sink is None:
+            return
+        self._sync()
+        now = self.clock()
+        self.sink[name] = self.sink.get(name, 0.0) + (now - self.t0) * 1e3
+        self.t0 = now
+
+
 def separate(Y, init, iterations=100, stft_size=None, *, shard=None, group=None,
-             mask_gather_dtype=None, gather_output=False, ops=device_ops, beamformer='gev+ban'):
+             mask_gather_dtype=None, gather_output=False, ops=device_ops, beamformer='gev+ban',
+             stage_ms=None):
     """Y (U, F, T, D) complex, init (U, F, K, T): run the chain above.  A single utterance may
     come without the leading axis (Y (F, T, D), init (F, K, T)); the results then have none either.
 
@@ -136,6 +164,9 @@ def separate(Y, init, iterations=100, stft_size=None, *, shard=None, group=None,
     with shard='bins' its per-problem SNR sums are all-reduced over the group.
 
     shard: None (single process), 'bins' or 'utterances' (torch.distributed initialised).
+    stage_ms: a dict that receives this rank's wall time per stage in milliseconds (em_ms,
+    gather_ms, dhtv_ms, map_gather_ms, extract_ms, out_gather_ms) with a device synchronisation
+    after each -- a diagnostic pass that explains a scaling measurement, not the timed path.
     Returns dict(masks (U, K, F', T) aligned, enhanced (U, K, F', T), bf_vector (U, K, F', D),
     mapping (U, K, F)); F' = the rank's own bins for shard='bins' without gather_output, U the
     rank's own utterances for shard='utterances' without gather_output.
@@ -144,15 +175,19 @@ def separate(Y, init, iterations=100, stft_size=None, *, shard=None, group=None,
     if Y.ndim == 3:
         out = separate(Y[None], init[None], iterations, stft_size, shard=shard, group=group,
                        mask_gather_dtype=mask_gather_dtype, gather_output=gather_output, ops=ops,
-                       beamformer=beamformer)
+                       beamformer=beamformer, stage_ms=stage_ms)
         return {k: v[0] for k, v in out.items()}
     U, F, T, D = Y.shape
     if stft_size is None:
         stft_size = 2 * (F - 1)
+    laps = _Laps(stage_ms, getattr(Y, 'device', None))
     if shard is None:
         masks = ops.em_masks(Y, init, iterations)                     # (U, F, K, T)
+        laps.lap('em_ms')
         mapping = ops.dhtv_mapping(masks.transpose(-3, -2).contiguous(), stft_size)
+        laps.lap('dhtv_ms')
         aligned, w, enhanced = _chain_after_masks(Y, masks, mapping, ops, beamformer)
+        laps.lap('extract_ms')
         return dict(masks=aligned, enhanced=enhanced, bf_vector=w, mapping=mapping)
 
     import torch.distributed as dist
@@ -160,10 +195,13 @@ def separate(Y, init, iterations=100, stft_size=None, *, shard=None, group=None,
     if shard == 'utterances':
         assert U >= world, (U, world, 'fewer utterances than ranks: shard the bins instead')
         lo, hi = shard_bounds(U, world, rank)
-        out = separate(Y[lo:hi], init[lo:hi], iterations, stft_size, ops=ops, beamformer=beamformer)
+        out = separate(Y[lo:hi], init[lo:hi], iterations, stft_size, ops=ops, beamformer=beamformer,
+                       stage_ms=stage_ms)
+        laps = _Laps(stage_ms, getattr(Y, 'device', None))
         if gather_output:
             out = {k: all_gather_bins(v.contiguous(), U, bin_axis=0, group=group)
                    for k, v in out.items()}
+            laps.lap('out_gather_ms')
         return out
     assert shard == 'bins', shard
 
@@ -173,9 +211,11 @@ def separate(Y, init, iterations=100, stft_size=None, *, shard=None, group=None,
         masks_loc = ops.em_masks(Y_loc, init[:, lo:hi].contiguous(), iterations)  # (U, F_loc, K, T)
     else:  # more ranks than bins
         masks_loc = torch.empty((U, 0, init.shape[-2], T), dtype=torch.float64, device=Y.device)
+    laps.lap('em_ms')
     # ---- the one real exchange step of the path: masks of all bins on every rank ----------
     send = masks_loc if mask_gather_dtype is None else masks_loc.to(mask_gather_dtype)
     masks_all = all_gather_bins(send, F, bin_axis=1, group=group).to(masks_loc.dtype)
+    laps.lap('gather_ms')
     # ---- DHTV needs all bins of an utterance; utterances are independent: each rank solves
     #      its share and the (U, K, F) integer mappings are all-gathered (a few KB each) --------
     ulo, uhi = shard_bounds(U, world, rank)
@@ -185,7 +225,9 @@ def separate(Y, init, iterations=100, stft_size=None, *, shard=None, group=None,
         map_loc = map_loc.to(torch.int64).reshape(uhi - ulo, K, F)
     else:
         map_loc = torch.empty((0, K, F), dtype=torch.int64, device=Y.device)
+    laps.lap('dhtv_ms')
     mapping = all_gather_bins(map_loc, U, bin_axis=0, group=group)     # (U, K, F)
+    laps.lap('map_gather_ms')
     # ---- everything downstream is per bin: own bins only --------------------------------------
     sg = True if group is None else group
     if hi > lo:
@@ -202,8 +244,10 @@ def separate(Y, init, iterations=100, stft_size=None, *, shard=None, group=None,
         aligned = torch.empty((U, K, 0, T), dtype=masks_loc.dtype, device=Y.device)
         w = torch.empty((U, K, 0, D), dtype=torch.complex128, device=Y.device)
         enhanced = torch.empty((U, K, 0, T), dtype=torch.complex128, device=Y.device)
+    laps.lap('extract_ms')
     out = dict(masks=aligned, enhanced=enhanced, bf_vector=w, mapping=mapping)
     if gather_output:
         for key in ('masks', 'enhanced', 'bf_vector'):
             out[key] = all_gather_bins(out[key].contiguous(), F, bin_axis=2, group=group)
+        laps.lap('out_gather_ms')
     return out

@@ -629,3 +629,20 @@ def test_stepwise_weights_with_saliency_and_many_classes_fall_back_to_the_host_f
     assert engine.estimate_mixture_weight(_lib.to_device(aff), _lib.to_device(sal), True, True) is None
     assert CACGMMTrainer._device_weight(_lib.to_device(aff), _lib.to_device(sal), (-3, -1),
                                         (2, 3)) is None
+
+
+@pytest.mark.gpu
+def test_stack_parameters_batched_predict_equals_individual():
+    """`stack_parameters` (pb_bss/distribution/utils.py:259-316, named in SURVEY 8b among the
+    downstream calls that must keep working): per-utterance models stacked into one batched
+    model; its `predict` on the stacked observations equals the individual predictions."""
+    from pb_bss_amd.distribution import CACGMMTrainer
+    from pb_bss_amd.distribution.utils import stack_parameters
+    from pb_bss_amd.testing import synth
+    data = [synth.make_stft(11, 90, 4, 2, seed=40 + u) for u in range(3)]
+    models = [CACGMMTrainer().fit(Y, initialization=init, iterations=4) for Y, init in data]
+    stacked = stack_parameters(models)
+    assert stacked.weight.shape == (3,) + models[0].weight.shape
+    got = stacked.predict(np.stack([Y for Y, _ in data]))
+    for u, (Y, _) in enumerate(data):
+        np.testing.assert_allclose(got[u], models[u].predict(Y), atol=1e-12)

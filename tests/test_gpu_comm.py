@@ -211,3 +211,128 @@ def test_fit_predict_sharded_inline_aligner_world1(world1_nccl):
     assert np.abs(got.cpu().numpy() - want).max() < 1e-12
     with pytest.raises(AssertionError):  # needs frequency-constant weights, as the reference
         sharding.fit_predict_sharded(Y, init, iterations=2, inline_permutation_aligner=aligner)
+
+
+# ---------------------------------------------------------------------------------------------
+# All visible GPUs, one process each, over RCCL (skipped on a one-GPU box).  The same worker also
+# runs as a REHEARSAL on one GPU -- two ranks sharing device 0 over gloo -- so that its control
+# flow is exercised wherever the suite runs; only the multi-GPU variant puts more than one rank
+# on RCCL (torch's backend AND the library's own communicator, pbbss_comm_create).
+def _multi_gpu_worker(rank, world, port, one_device, ret):
+    import torch
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    dev_index = 0 if one_device else rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device('cuda', dev_index)
+    if one_device:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+    else:
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    from pb_bss_amd import _lib, pipeline, sharding
+    from pb_bss_amd.distribution import CACGMMTrainer, CWMMTrainer, GCACGMMTrainer
+    from pb_bss_amd.sharding import all_gather_bins, shard_bounds
+    from oracle import cacgmm as oc, cwmm as ow, embed as oe, synth
+    checks = {}
+    try:
+        # (a) uneven contiguous bin blocks through torch's backend
+        F = 8 * world + 1
+        rng = np.random.default_rng(0)
+        full = torch.from_numpy(rng.uniform(size=(2, F, 3, 5))).to(dev)
+        lo, hi = shard_bounds(F, world, rank)
+        got = all_gather_bins(full[:, lo:hi].contiguous(), F, bin_axis=1)
+        checks['gather_torch'] = bool((got == full).all())
+        # (b) ... and through the library's own RCCL communicator (C ABI)
+        if not one_device:
+            sharding.init_native_comm(device_index=dev_index)
+            got = all_gather_bins(full[:, lo:hi].contiguous(), F, bin_axis=1)
+            checks['gather_native'] = bool((got == full).all())
+            w, r = ctypes.c_int(-1), ctypes.c_int(-1)
+            rc = _lib.load().pbbss_comm_info(_lib.handle(dev_index), ctypes.byref(w), ctypes.byref(r))
+            checks['comm_info'] = (rc, w.value, r.value) == (0, world, rank)
+        # (c) sharded cACGMM fit_predict == oracle, every rank holds the full masks
+        Fb, T, D, K = 4 * world + 1, 120, 4, 2
+        Y, init = synth.make_stft(Fb, T, D, K, seed=3)
+        Y128 = Y.astype(np.complex128)
+        masks = sharding.fit_predict_sharded(_lib.to_device(Y), _lib.to_device(init), 6)
+        ref = oc.em_predict(oc.em_fit(Y128, init, iterations=6), Y128)
+        checks['cacgmm_sharded'] = float(np.abs(_lib.to_host(masks) - ref).max()) < 1e-9
+        # (d) weights shared over the (sharded) bins: one all-reduce per EM iteration
+        masks = sharding.fit_predict_sharded(_lib.to_device(Y), _lib.to_device(init), 4,
+                                             weight_constant_axis=(-3, -1))
+        ref = oc.em_predict(oc.em_fit(Y128, init, iterations=4, weight_constant_axis=(-3, -1)), Y128)
+        checks['shared_weights'] = float(np.abs(_lib.to_host(masks) - ref).max()) < 1e-9
+        # (e) Watson mixture (configs[3]) sharded
+        masks = sharding.fit_predict_sharded(_lib.to_device(Y), _lib.to_device(init), 5,
+                                             trainer=CWMMTrainer())
+        ref = ow.cwmm_predict(ow.cwmm_fit(Y128, init, iterations=5), Y128)
+        checks['watson_sharded'] = float(np.abs(_lib.to_host(masks) - ref).max()) < 1e-7
+        # (f) the config-3 chain, bins sharded, against the single-process run of the same code
+        U = 2
+        data = [synth.make_stft(257, 48, 3, 2, seed=50 + u) for u in range(U)]  # 257 bins: stft 512
+        Yb = _lib.to_device(np.stack([d[0] for d in data]))
+        ib = _lib.to_device(np.stack([d[1] for d in data]))
+        one = pipeline.separate(Yb, ib, 5, 512)
+        shd = pipeline.separate(Yb, ib, 5, 512, shard='bins', gather_output=True)
+        checks['chain_mapping'] = bool((one['mapping'] == shd['mapping']).all())
+        checks['chain_masks'] = float((one['masks'] - shd['masks']).abs().max()) < 1e-12
+        # (g) joint model: the spectral M-step sums all-reduced INSIDE the library (RCCL only)
+        if not one_device:
+            Fj, Tj, Dj, Kj, E = 4 * world, 100, 4, 3, 16
+            Yj, ej, ij = synth.make_joint(Fj, Tj, Dj, Kj, E, seed=11)
+            mj = sharding.fit_predict_sharded_joint(GCACGMMTrainer(), Yj, ej, ij, iterations=5)
+            rj = oe.joint_fit('gaussian', Yj.astype(np.complex128), ej.astype(np.float64), ij, 5)
+            wj = oe.joint_model_predict(rj, Yj.astype(np.complex128), ej.astype(np.float64))
+            checks['joint_sharded'] = float(np.abs(_lib.to_host(mj) - wj).max()) < 1e-6
+        ret[rank] = checks
+    except Exception as e:  # noqa: BLE001 -- reported to the parent, which fails the test
+        import traceback
+        ret[rank] = {'exception': f'{type(e).__name__}: {e}', 'trace': traceback.format_exc(),
+                     **checks}
+    finally:
+        try:
+            sharding.destroy_native_comm(dev_index)
+        finally:
+            dist.destroy_process_group()
+
+
+def _run_multi(world, one_device):
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_multi_gpu_worker, args=(world, port, one_device, ret), nprocs=world, join=True)
+    out = dict(ret)
+    assert sorted(out) == list(range(world)), out
+    for rank, checks in out.items():
+        assert 'exception' not in checks, (rank, checks)
+        assert all(checks.values()), (rank, checks)
+    return out
+
+
+@pytest.mark.timeout(600)
+def test_sharded_paths_two_ranks_one_gpu_rehearsal():
+    """Two ranks sharing GPU 0 over gloo: a functional rehearsal of the worker below (sharded
+    fits, bin-constant weights, the config-3 chain) -- it proves the control flow, not RCCL."""
+    out = _run_multi(2, one_device=True)
+    assert set(out[0]) >= {'gather_torch', 'cacgmm_sharded', 'shared_weights', 'watson_sharded',
+                           'chain_mapping', 'chain_masks'}
+
+
+@pytest.mark.timeout(900)
+def test_sharded_paths_all_visible_gpus_rccl():
+    """One process per visible GPU over RCCL (torch's nccl backend and the library's own
+    communicator): mask all-gather of uneven bin blocks, sharded cACGMM / Watson fits against the
+    oracle, bin-constant weights (all-reduce per iteration), the config-3 chain against the
+    single-process run, the joint model's in-library all-reduce.  Skipped on a one-GPU box."""
+    import torch
+    n = torch.cuda.device_count()
+    if n < 2:
+        pytest.skip(f'{n} GPU visible: RCCL with more than one rank needs at least two')
+    out = _run_multi(min(n, 8), one_device=False)
+    assert all('joint_sharded' in c and 'gather_native' in c for c in out.values())

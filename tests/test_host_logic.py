@@ -265,8 +265,10 @@ def test_split_timeout_retry_logic(monkeypatch):
     import torch
     from pb_bss_amd import _lib, engine
     dev = types.SimpleNamespace(index=0)
-    tails = []
+    tails, resets, setting = [], [], [True]
     monkeypatch.setattr(engine, 'set_split_tail', lambda e, d=None: tails.append((bool(e), d)))
+    monkeypatch.setattr(engine, 'split_tail', lambda d=None: setting[0])
+    monkeypatch.setattr(engine, 'split_reset', lambda d=None: resets.append(d))
     poison = _lib.ST_NONFINITE | _lib.ST_EIG_NOCONV
 
     def launcher(statuses):
@@ -285,6 +287,14 @@ def test_split_timeout_retry_logic(monkeypatch):
     with pytest.warns(RuntimeWarning, match='split groups'):
         r = engine._checked_with_split_retry(launcher([[[0, poison]], [[0, 0]]]), dev, 'x')
     assert tails == [(False, 0), (True, 0)] and int(r['status'].max()) == 0
+    assert resets == [0]                      # the report was consumed before the repeat
+    # a caller who had switched the split groups off gets them back OFF, not on
+    tails.clear()
+    setting[0] = False
+    with pytest.warns(RuntimeWarning, match='split groups'):
+        engine._checked_with_split_retry(launcher([[[0, poison]], [[0, 0]]]), dev, 'x')
+    assert tails == [(False, 0), (False, 0)]
+    setting[0] = True
     # the repeat fails for real: the error is raised, the split groups are on again
     tails.clear()
     with pytest.warns(RuntimeWarning), pytest.raises(AssertionError, match='non-finite'):
@@ -298,3 +308,35 @@ def test_split_timeout_retry_logic(monkeypatch):
     with pytest.raises(np.linalg.LinAlgError):
         engine._checked_with_split_retry(launcher([[[_lib.ST_EIG_NOCONV, 0]]]), dev, 'x')
     assert tails == []
+
+
+def test_stack_parameters_nested_models():
+    """pb_bss/distribution/utils.py:259-316: nested dataclasses stacked field by field along a new
+    leading axis; mixed model types are refused (the doctest's CACGMM(cacg=..., weight=...) shape)."""
+    from pb_bss_amd.distribution import CACGMM, ComplexAngularCentralGaussian
+    from pb_bss_amd.distribution.utils import stack_parameters
+    rng = np.random.default_rng(0)
+    models = []
+    for _ in range(3):
+        cacg = ComplexAngularCentralGaussian(
+            covariance_eigenvectors=rng.normal(size=(2, 4, 4)) + 1j * rng.normal(size=(2, 4, 4)),
+            covariance_eigenvalues=rng.uniform(size=(2, 4)))
+        models.append(CACGMM(weight=rng.uniform(size=(2, 1)), cacg=cacg))
+    st = stack_parameters(models)
+    assert isinstance(st, CACGMM) and isinstance(st.cacg, ComplexAngularCentralGaussian)
+    assert st.weight.shape == (3, 2, 1) and st.cacg.covariance_eigenvectors.shape == (3, 2, 4, 4)
+    for i, m in enumerate(models):
+        np.testing.assert_array_equal(st.weight[i], m.weight)
+        np.testing.assert_array_equal(st.cacg.covariance_eigenvalues[i], m.cacg.covariance_eigenvalues)
+    st2 = stack_parameters([m.cacg for m in models])
+    np.testing.assert_array_equal(st2.covariance_eigenvectors, st.cacg.covariance_eigenvectors)
+    with pytest.raises(AssertionError):
+        stack_parameters([models[0], models[0].cacg])
+    # torch parameters stay torch
+    import torch
+    tm = [ComplexAngularCentralGaussian(
+        covariance_eigenvectors=torch.from_numpy(m.cacg.covariance_eigenvectors),
+        covariance_eigenvalues=torch.from_numpy(m.cacg.covariance_eigenvalues)) for m in models]
+    st3 = stack_parameters(tm)
+    assert isinstance(st3.covariance_eigenvalues, torch.Tensor)
+    np.testing.assert_array_equal(st3.covariance_eigenvalues.numpy(), st2.covariance_eigenvalues)
