@@ -29,6 +29,7 @@
 #pragma once
 #include "pbbss.h"
 #include "wave_la.hpp"
+#include "embed_dev.hpp"
 
 namespace pbbss {
 
@@ -118,6 +119,34 @@ struct JointExtras {
   int main_grid;
   unsigned lds_given;  // dynamic LDS bytes of the launch (checked by the debug build only)
   unsigned xbuf_given; // bytes of the exchange buffer behind xcount (debug build)
+};
+
+// Spatial half of the ROTATED joint loop (round 4; pbbss_joint_fit).  The
+// joint models read the embedding once per EM iteration: one sweep kernel (embed.hip:
+// joint_sweep_kernel) evaluates the spectral log-pdf of a tile of embedding rows, combines it with
+// the spatial quadratic forms Q of the same points, forms the posteriors and accumulates the
+// spectral M-step sums from the SAME tile.  That moves the cACG E-step in front of the sweep:
+//   S(it)  [this kernel, one workgroup per bin]  M-step weights from the posteriors G and the
+//          quadratic forms Q of iteration it (phase_init_gamma: gamma0 = G, q0 = Q), covariance
+//          sums, factorisation  ->  model(it)  ->  quadratic forms of model(it) -> Q (in place),
+//          ln det B_k -> lndet
+//   P(it+1) [sweep]  posteriors of model(it)  ->  G, spectral sums
+// mode 0: E part only, model from a.in_eigvec / a.in_eigval (after the first M-step);
+// mode 1: M + F + E;  mode 2: M + F with the exact eigen path, (V, lambda) emitted, no E (last).
+struct JointMs {
+  int mode;
+  double* q_out;          // (B,K,T) quadratic forms max(|y^H B_k^-1 y|, tiny) of the new model
+  double* lndet_out;      // (B,K)   ln det B_k of the new model
+  double* weight_fk_out;  // (B,K) or null: class weights of weight_constant_axis=(-1,)
+  unsigned lds_given;     // dynamic LDS bytes of the launch (debug build)
+  // Grid: [0, main_grid) blocks over the bins (stride main_grid), then the HELPERS of the spectral
+  // finalize (embed_dev.hpp: SpectralFin), run beside the bins of the same launch; fin.kind < 0
+  // or fin.helpers == 0: none.  (Remainder bins as member blocks on frame windows -- the scheme of
+  // run_joint_member -- were built and measured for this kernel: the last arriver's serial tail
+  // (sum, factorisation, quadratic forms of every window) made the launch 8.5 us LONGER than
+  // the third workgroup on one CU it was meant to avoid: 38.1 vs 29.5 us, profiles/r04_*.)
+  int main_grid;
+  SpectralFin fin;
 };
 
 // SPILL=false: observation, norms and M-step weights live in LDS (the fast path).
@@ -342,7 +371,10 @@ struct EmKernel {
   // PAIR: frames are taken two per lane (512 per pass) while more than 256 remain -- every A_k
   //     operand fetched from LDS then feeds two frames -- and one per lane for the rest
   //     (T = 500: one paired pass; T <= 256: one single pass).
-  template <bool FINAL, bool TW, bool JOINT = false, bool PAIR = false>
+  // PERM: the joint E-step reads the spatial class of slot k through jx->perm (inline
+  // permutation alignment); a compile-time flag, so that the default joint kernel does not
+  // carry the selects' registers (the run-time test cost 224 bytes of scratch per lane)
+  template <bool FINAL, bool TW, bool JOINT = false, bool PAIR = false, bool PERM = false>
   static __device__ void phase_e(const EmArgs& a, const Lds& L, int64_t b, int tid, int wave,
                                  int lane, double eps, int tf = 0,
                                  const JointExtras* jx = nullptr,
@@ -451,7 +483,7 @@ struct EmKernel {
 #pragma unroll
           for (int k = 0; k < K; ++k) {
             double sv = val[k], st = tk[k];
-            if (jx->perm) {
+            if constexpr (PERM) {
               const int pk = jx->perm[k];
 #pragma unroll
               for (int j = 0; j < K; ++j) {
@@ -480,7 +512,7 @@ struct EmKernel {
 #pragma unroll
           for (int k = 0; k < K; ++k) {
             double sp = lps[k];
-            if (jx->perm) {
+            if constexpr (PERM) {
               const int pk = jx->perm[k];
 #pragma unroll
               for (int j = 0; j < K; ++j) sp = (pk == j) ? lps[j] : sp;
@@ -1104,15 +1136,17 @@ struct EmKernel {
   // model + spectral log-pdf -> affiliation (and q) to HBM, covariance update, eigen
   // decomposition.  a.iterations == 0: the E-step only (model.predict).
   // Mixture weights are always read through (wb, wk, wt) from a.in_weight.
-  static __device__ void run_joint(const EmArgs& a, const JointExtras& jx0, int inline_pa,
-                                   char* smem) {
+  template <bool PA>
+  static __device__ void run_joint(const EmArgs& a, const JointExtras& jx0, char* smem) {
     static_assert(!SPILL, "joint kernels keep the observation in LDS");
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
-    if (jx0.main_grid > 0 && (int)blockIdx.x >= jx0.main_grid) {
-      run_joint_member(a, jx0, smem);
-      return;
+    if constexpr (!PA) {  // members are never launched together with the inline aligner
+      if (jx0.main_grid > 0 && (int)blockIdx.x >= jx0.main_grid) {
+        run_joint_member(a, jx0, smem);
+        return;
+      }
     }
     const int bstride = jx0.main_grid > 0 ? jx0.main_grid : (int)gridDim.x;
     const Lds L = carve(smem, a.T);
@@ -1141,15 +1175,15 @@ struct EmKernel {
       __syncthreads();
       JointExtras jx = jx0;
       jx.perm = nullptr;
-      if (inline_pa) {
+      if constexpr (PA) {
         phase_joint_pa(a, L, b, tid, wave, lane, jx, perm);
         jx.perm = perm;
       }
       if (a.iterations == 0) {
-        phase_e<true, true, true>(a, L, b, tid, wave, lane, a.final_eps, 0, &jx);
+        phase_e<true, true, true, false, PA>(a, L, b, tid, wave, lane, a.final_eps, 0, &jx);
         continue;
       }
-      phase_e<false, true, true>(a, L, b, tid, wave, lane, a.aff_eps, 0, &jx);
+      phase_e<false, true, true, false, PA>(a, L, b, tid, wave, lane, a.aff_eps, 0, &jx);
       __syncthreads();
       if (jx0.weight_fk_out && tid == 0) {
         double v[K], tot = 0.0;
@@ -1183,6 +1217,188 @@ struct EmKernel {
       }
       __syncthreads();
       if (tid < K && a.out_status) a.out_status[(size_t)b * K + tid] = L.status[tid];
+    }
+  }
+
+  // ---- phase_load and phase_init_gamma in one pass (spatial kernel of the rotated joint loop):
+  // layout TD, gamma0 / q0 given.  Same arithmetic as the two phases, statement by statement.
+  static __device__ void phase_load_gamma(const EmArgs& a, const Lds& L, int64_t b, int tid,
+                                          int wave, int lane) {
+    const int T = a.T;
+    const YS2* yg = reinterpret_cast<const YS2*>(a.y);
+    bool zero_seen = false;
+    double s[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) s[k] = 0.0;
+    for (int t = tid; t < L.Tp; t += kEmThreads) {
+      const int tc = t < T ? t : T - 1;  // clamped: unconditional loads, masked below
+      YS2 v[D];
+      double g[K], q[K];
+#pragma unroll
+      for (int d = 0; d < D; ++d) v[d] = yg[((size_t)b * T + tc) * D + d];
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const size_t idx = ((size_t)b * K + k) * T + tc;
+        g[k] = a.gamma0[idx];
+        q[k] = a.q0[idx];
+      }
+      const double sal = a.saliency ? a.saliency[(size_t)b * T + tc] : 1.0;
+      double n2 = 0.0;
+      YS vr[2 * DP], vi[2 * DP];
+#pragma unroll
+      for (int d = 0; d < 2 * DP; ++d) {
+        vr[d] = (YS)0;
+        vi[d] = (YS)0;
+      }
+      if (t < T) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+          vr[d] = v[d].x;
+          vi[d] = v[d].y;
+          n2 += (double)v[d].x * (double)v[d].x + (double)v[d].y * (double)v[d].y;
+        }
+      }
+#pragma unroll
+      for (int dp = 0; dp < DP; ++dp) {
+        YS4 o;
+        o.x = vr[2 * dp];
+        o.y = vi[2 * dp];
+        o.z = vr[2 * dp + 1];
+        o.w = vi[2 * dp + 1];
+        *reinterpret_cast<YS4*>(L.ybuf + ((size_t)dp * L.Tp + t) * 4) = o;
+      }
+      const double inv = (t < T) ? ((n2 > 0.0) ? 1.0 / n2 : 0.0) : 0.0;
+      L.inv_n2[t] = inv;
+      if (t < T && !(n2 > 0.0)) zero_seen = true;
+      if (t < T) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          const double gs = g[k] * sal;
+          L.wbuf[(size_t)k * L.Tp + t] = mweight(gs, q[k], inv);
+          s[k] += gs;
+        }
+      }
+    }
+    if (zero_seen) atomicOr(L.flags, 1);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      double tot = wave_sum(s[k]);
+      if (lane == 0) L.red[wave * K + k] = tot;
+    }
+  }
+
+  // ---- quadratic forms of the model in LDS for every frame -> q_out (rotated joint loop) ----
+  // The dot product <A_k, P_t> of phase_e (DPP operands out of one register per 16 entries),
+  // one frame per lane; the clamp is the reference's (cacg.py:185-199).
+  static __device__ void phase_q(const EmArgs& a, const Lds& L, int64_t b, int tid, int lane,
+                                 double* q_out, int tf = 0) {
+    tid = opaque(tid);
+    lane = opaque(lane);
+    const int TS = t_stride(a);
+    constexpr int NG = (NA + 15) / 16;
+    double areg[K][NG];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        const int e = 16 * g + (lane & 15);
+        areg[k][g] = L.apack[k * NA + (e < NA ? e : NA - 1)];
+      }
+    }
+    for (int t0 = 0; t0 < a.T; t0 += kEmThreads) {
+      const int t = t0 + tid;
+      const bool ok = t < a.T;
+      const int tt = ok ? t : (a.T - 1);
+      double re[D], im[D], q[K];
+      load_frame(L, tt, re, im);
+#pragma unroll
+      for (int k = 0; k < K; ++k) q[k] = 0.0;
+      static_for<0, D>([&](auto ic) {
+        constexpr int i = ic;
+        const double dg = re[i] * re[i] + im[i] * im[i];
+#pragma unroll
+        for (int k = 0; k < K; ++k) fmac_row_bcast<i % 16>(q[k], areg[k][i / 16], dg);
+      });
+      static_for<0, NOFF>([&](auto pc) {
+        constexpr int p = pc;
+        constexpr int i = tri_i<D>(p), j = tri_j<D>(p);
+        constexpr int e0 = D + 2 * p, e1 = e0 + 1;
+        const double pr = re[i] * re[j] + im[i] * im[j];
+        const double pim = im[i] * re[j] - re[i] * im[j];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          fmac_row_bcast<e0 % 16>(q[k], areg[k][e0 / 16], pr);
+          fmac_row_bcast<e1 % 16>(q[k], areg[k][e1 / 16], pim);
+        }
+      });
+      const double inv = L.inv_n2[tt];
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const double qq = fmax(fabs(q[k] * inv), kTiny);
+        if (ok) q_out[((size_t)b * K + k) * TS + tf + t] = qq;
+      }
+    }
+  }
+
+  // Spatial half of one iteration of the rotated joint loop (see JointMs).
+  template <int MODE>
+  static __device__ void run_joint_ms(const EmArgs& a, const JointMs& jm, char* smem) {
+    static_assert(!SPILL, "joint kernels keep the observation in LDS");
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    if constexpr (MODE != 0) {
+      if ((int)blockIdx.x >= jm.main_grid) {  // spectral finalize beside the bins
+        spectral_finalize_block(jm.fin, (int)blockIdx.x - jm.main_grid, tid, kEmThreads,
+                                reinterpret_cast<double*>(smem));
+        return;
+      }
+    }
+    const Lds L = carve(smem, a.T);
+    for (int64_t b = blockIdx.x; b < a.B; b += jm.main_grid) {
+      __syncthreads();
+      if (tid < K) L.status[tid] = 0;
+      if (tid == 0) *L.flags = 0;
+      __syncthreads();
+      if constexpr (MODE == 0) {
+        phase_load(a, L, b, tid);
+        __syncthreads();
+        for (int k = wave; k < K; k += kEmWaves) prep_from_model(a, L, b, k, lane);
+      } else {
+        // observation, posteriors G and quadratic forms Q of a frame are requested together (one
+        // memory round trip instead of two, one barrier less): the thread that stages frame t
+        // also owns its M-step weights
+        phase_load_gamma(a, L, b, tid, wave, lane);
+        __syncthreads();
+        if (jm.weight_fk_out && tid == 0) {
+          double v[K], tot = 0.0;
+#pragma unroll
+          for (int k = 0; k < K; ++k) {
+            v[k] = 0.0;
+#pragma unroll
+            for (int w = 0; w < kEmWaves; ++w) v[k] += L.red[w * K + k];
+            tot += v[k];
+          }
+#pragma unroll
+          for (int k = 0; k < K; ++k) jm.weight_fk_out[(size_t)b * K + k] = v[k] / tot;
+        }
+        switch (wave) {
+          case 0: phase_m<0>(a, L, lane); break;
+          case 1: phase_m<1>(a, L, lane); break;
+          case 2: phase_m<2>(a, L, lane); break;
+          default: phase_m<3>(a, L, lane); break;
+        }
+        __syncthreads();
+        for (int k = wave; k < K; k += kEmWaves) factor_class(a, L, b, k, lane, MODE == 2);
+      }
+      __syncthreads();
+      if constexpr (MODE != 2) {
+        phase_q(a, L, b, tid, lane, jm.q_out);
+        if (tid < K)
+          jm.lndet_out[(size_t)b * K + tid] =
+              log(L.detm[tid]) + (double)L.dete[tid] * 0.6931471805599453;
+      }
+      if (MODE != 0 && tid < K && a.out_status) a.out_status[(size_t)b * K + tid] = L.status[tid];
     }
   }
 
@@ -1992,11 +2208,21 @@ __global__ void __launch_bounds__(kEmThreads, em_waves_per_simd(K)) cacgmm_em_ke
 }
 
 
-template <int D, int K, typename YS>
+// PA: with the per-bin permutation search of the inline aligner (its own instantiation: the
+// search and the class selects of the E-step would otherwise cost the default path 224 bytes of
+// scratch per lane -- profiles/r04_*_config5_profile.txt: 25 MB of spill writes per launch)
+template <int D, int K, typename YS, bool PA>
 __global__ void __launch_bounds__(kEmThreads, em_waves_per_simd(K))
-    cacgmm_joint_kernel(EmArgs a, JointExtras jx, int inline_pa) {
+    cacgmm_joint_kernel(EmArgs a, JointExtras jx) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  EmKernel<D, K, YS, false>::run_joint(a, jx, inline_pa, smem);
+  EmKernel<D, K, YS, false>::template run_joint<PA>(a, jx, smem);
+}
+
+template <int D, int K, typename YS, int MODE>
+__global__ void __launch_bounds__(kEmThreads, em_waves_per_simd(K))
+    cacgmm_joint_ms_kernel(EmArgs a, JointMs jm) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  EmKernel<D, K, YS, false>::template run_joint_ms<MODE>(a, jm, smem);
 }
 
 template <int D, int K, typename YS>

@@ -1489,6 +1489,17 @@ PBBSS_API int pbbss_gmm_fit(pbbss_handle_t h, const void* y, int64_t B, int64_t 
                            out_covariance, out_weight, out_affiliation, out_log_pdf, stream);
 }
 
+// helper blocks of the in-launch spectral finalize of the rotated joint loop (embed_dev.hpp)
+static constexpr int kJointFinHelpers = 32;
+static int joint_fin_helpers() {  // development knob: helper blocks actually launched (<= 32)
+  static const int n = [] {
+    const char* v = getenv("PBBSS_JOINT_FIN_HELPERS");
+    const int x = v ? atoi(v) : kJointFinHelpers;
+    return x < 1 ? 1 : (x > kJointFinHelpers ? kJointFinHelpers : x);
+  }();
+  return n;
+}
+
 PBBSS_API int pbbss_joint_fit(pbbss_handle_t h, const void* observation, const void* embedding,
                               int64_t F, int T, int D, int E, int K, const double* gamma0,
                               const void* in_eigvec, const double* in_eigval,
@@ -1545,7 +1556,23 @@ PBBSS_API int pbbss_joint_fit(pbbss_handle_t h, const void* observation, const v
     default: break;
   }
   const size_t esz = o->embedding_is_f64 ? 8 : 4;
-  const size_t np = pbbss::embed_partial_doubles(1, N, E, K, nullptr);
+  // Rotated loop (round 4): ONE pass over the embedding per EM iteration -- the sweep kernel forms
+  // the posteriors from the spatial quadratic forms Q and the spectral log-pdf of the SAME tile of
+  // embedding rows it then accumulates the spectral M-step sums from, the spatial kernel runs
+  // M-step, factorisation and the NEXT model's quadratic forms (embed.hip: joint_sweep_kernel,
+  // cacgmm_em.hpp: run_joint_ms).  Served: vMF / spherical Gaussian, D <= 8, K <= 6, no inline
+  // aligner, no fixed covariance; everything else keeps the three-kernel path below.
+  // PBBSS_JOINT_ROTATED=0 switches it off (A/B runs, tests of the other path).
+  static const bool rot_allowed = [] {
+    const char* v = getenv("PBBSS_JOINT_ROTATED");
+    return !(v && v[0] == '0');
+  }();
+  const bool rot = rot_allowed && !gen && !o->inline_pa && !(in_scale && gamma0) &&
+                   o->iterations >= 2 &&
+                   pbbss::joint_sweep_supported(o->kind, N, E, K, o->embedding_is_f64);
+  const size_t np0 = pbbss::embed_partial_doubles(1, N, E, K, nullptr);
+  const size_t npj = rot ? pbbss::joint_sweep_partial_doubles(o->kind, N, E, K, o->embedding_is_f64) : 0;
+  const size_t np = np0 > npj ? np0 : npj;
   const size_t nfkt = (size_t)F * K * T;
   const size_t nstate = (size_t)F * K * (D * D + 2);
   const size_t ngp = g_full ? pbbss::gauss_full_partial_doubles(1, N, E, K) : 0;
@@ -1565,7 +1592,9 @@ PBBSS_API int pbbss_joint_fit(pbbss_handle_t h, const void* observation, const v
                       (g_full ? 2 * WorkCarver::pad(nfkt * 8) + WorkCarver::pad(ngp * 8) +
                                     WorkCarver::pad((size_t)K * E * E * 8)
                               : 0) +
-                      WorkCarver::pad(nconst * 8) + WorkCarver::pad(64);
+                      WorkCarver::pad(nconst * 8) + WorkCarver::pad(64) +
+                      WorkCarver::pad((size_t)F * K * 8) +
+                      WorkCarver::pad((size_t)kJointFinHelpers * 2 * K * (E + 1) * 8);
   void* w = handle_work(h, need);
   if (!w) return PBBSS_ERR_HIP;
   WorkCarver wc(w, need);
@@ -1583,6 +1612,8 @@ PBBSS_API int pbbss_joint_fit(pbbss_handle_t h, const void* observation, const v
   double* mq = g_full ? wc.take<double>((size_t)K * E * E) : nullptr;
   double* dconst = g_diag ? wc.take<double>(nconst) : nullptr;
   int32_t* gst = reinterpret_cast<int32_t*>(wc.take<char>(64));  // status of the spectral half
+  double* lndet = wc.take<double>((size_t)F * K);  // rotated loop: ln det B_fk of the current model
+  double* fin_tmp = wc.take<double>((size_t)kJointFinHelpers * 2 * K * (E + 1));
   // generic-size spatial half: M-step weights, covariances, inverse state, class sums, zero-frame
   // flags, frame-contiguous copy of the observation
   double* g_mw = gen ? wc.take<double>(nfkt) : nullptr;
@@ -1703,6 +1734,53 @@ PBBSS_API int pbbss_joint_fit(pbbss_handle_t h, const void* observation, const v
                                                                                      : nullptr};
     return pbbss::joint_launch(D, K, o->obs_is_c128, a, jx, inline_pa, h->cfg, s);
   };
+  // spatial half of the rotated loop: mode 0 = quadratic forms of the eigen model in the output
+  // arrays, 1 = M-step from (G = aff, Q = slp) + factorisation + quadratic forms of the new
+  // model (Q in place), 2 = M-step + exact eigen path, (V, lambda) emitted (last iteration)
+  // in-launch finalize: not for sharded fits (the all-reduce of the partials has to sit between
+  // the sweep and the finalize, in stream order); PBBSS_JOINT_INLAUNCH_FINALIZE=0 for A/B runs
+  static const bool fin_allowed = [] {
+    const char* v = getenv("PBBSS_JOINT_INLAUNCH_FINALIZE");
+    return !(v && v[0] == '0');
+  }();
+  const bool fin_in_launch = rot && fin_allowed && !reduce && h->cfg.xbuf &&
+                             2 * K * (E + 1) <= pbbss::kSpectralFinMaxW2;
+  auto spatial_ms = [&](int mode) -> int {
+    pbbss::EmArgs a{};
+    a.y = observation;
+    a.B = F;
+    a.T = T;
+    a.gamma0 = mode == 0 ? nullptr : aff;
+    a.q0 = mode == 0 ? nullptr : slp;
+    a.saliency = saliency;
+    a.in_eigvec = static_cast<const double*>(out_eigvec);
+    a.in_eigval = out_eigval;
+    a.out_eigvec = static_cast<double*>(out_eigvec);
+    a.out_eigval = out_eigval;
+    a.out_status = out_status;
+    a.iterations = 1;
+    a.covariance_norm = o->covariance_norm;
+    a.weight_mode = PBBSS_WEIGHT_PER_CLASS_MEAN;
+    a.layout = PBBSS_LAYOUT_TD;
+    a.eig_floor = o->eigenvalue_floor;
+    pbbss::JointMs jm{};
+    jm.mode = mode;
+    jm.q_out = slp;
+    jm.lndet_out = lndet;
+    jm.weight_fk_out = (mode != 0 && o->weight_mode == PBBSS_JOINT_WEIGHT_FK) ? out_weight : nullptr;
+    jm.fin.kind = -1;
+    if (mode != 0 && fin_in_launch) {
+      int C = 0;
+      pbbss::joint_sweep_chunks(o->kind, N, E, K, o->embedding_is_f64, &C);
+      jm.fin = pbbss::SpectralFin{o->kind == PBBSS_EMBED_VMF ? 0 : 1, joint_fin_helpers(), C, E, K,
+                                  part, fin_tmp,
+                                  reinterpret_cast<unsigned*>(h->cfg.xbuf + 224),  // free word
+                                  o->min_concentration, o->max_concentration, out_mean, out_scale,
+                                  offset, prec};
+      if (jm.fin.helpers > C) jm.fin.helpers = C;
+    }
+    return pbbss::joint_ms_launch(D, K, o->obs_is_c128, a, jm, h->cfg, s);
+  };
   for (int it = 0; it < o->iterations; ++it) {
     const double* src = gamma0;
     if (it == 0 && gen) {
@@ -1728,6 +1806,45 @@ PBBSS_API int pbbss_joint_fit(pbbss_handle_t h, const void* observation, const v
       a.eig_floor = o->eigenvalue_floor;
       rc = pbbss::em_launch(D, K, o->obs_is_c128, a, h->cfg, s);
       if (rc != PBBSS_OK) return rc;
+    } else if (rot) {
+      // sweep: posteriors of the current model -> aff, spectral sums -> part; then the spectral
+      // finalize and the spatial M-step / factorisation / next quadratic forms
+      rc = pbbss::launch_joint_sweep(o->kind, embedding, o->embedding_is_f64, F, T, E, K, D, slp,
+                                     lndet, out_weight, wb, wk, wt, out_mean, prec, offset, o->spatial_weight,
+                                     o->spectral_weight, saliency, o->affiliation_eps, aff, part, s);
+      if (rc != PBBSS_OK) return rc;
+      // The spectral finalize (ONE workgroup walking the chunk partials: 14-18 us) and the spatial
+      // kernel are independent -- both only feed the NEXT sweep -- so the finalize runs beside
+      // the spatial kernel on the handle's side stream (fork after the sweep, join before the
+      // next sweep).  Sharded fits keep it in stream order (the all-reduce of the partials is
+      // enqueued on the caller's stream).  PBBSS_JOINT_SIDE_FINALIZE=0: in stream order (A/B).
+      static const bool side_allowed = [] {
+        const char* v = getenv("PBBSS_JOINT_SIDE_FINALIZE");
+        return !(v && v[0] == '0');
+      }();
+      const bool side = side_allowed && !reduce && h->cfg.side_stream && !fin_in_launch;
+      hipStream_t fs = s;
+      if (side) {
+        if (hipEventRecord(h->cfg.ev_fork, s) != hipSuccess ||
+            hipStreamWaitEvent(h->cfg.side_stream, h->cfg.ev_fork, 0) != hipSuccess)
+          return PBBSS_ERR_HIP;
+        fs = h->cfg.side_stream;
+      }
+      if (!fin_in_launch) {
+        rc = pbbss::launch_joint_sweep_finalize(o->kind, embedding, o->embedding_is_f64, N, E, K,
+                                                o->min_concentration, o->max_concentration, part,
+                                                out_mean, out_scale, offset, prec, fs, reduce);
+        if (rc != PBBSS_OK) return rc;
+      }
+      if (side && hipEventRecord(h->cfg.ev_join, fs) != hipSuccess) return PBBSS_ERR_HIP;
+      if ((rc = spatial_ms(it == o->iterations - 1 ? 2 : 1)) != PBBSS_OK) return rc;
+      if (o->weight_mode != PBBSS_JOINT_WEIGHT_FK) {
+        rc = pbbss::launch_joint_weight(o->weight_mode, aff, saliency, F, K, T, tmp, out_weight, s,
+                                        reduce);
+        if (rc != PBBSS_OK) return rc;
+      }
+      if (side && hipStreamWaitEvent(s, h->cfg.ev_join, 0) != hipSuccess) return PBBSS_ERR_HIP;
+      continue;
     } else {
       if ((rc = spectral()) != PBBSS_OK) return rc;
       // the model travels as packed inverse covariances between iterations; the first joint
@@ -1760,6 +1877,9 @@ PBBSS_API int pbbss_joint_fit(pbbss_handle_t h, const void* observation, const v
     if (rc != PBBSS_OK) return rc;
     if (fixed_scale) {  // fixed_covariance (gcacgmm.py:305-312)
       if ((rc = copy_d2d(out_scale, in_scale, nscale * 8, s)) != PBBSS_OK) return rc;
+    }
+    if (rot && it == 0) {  // quadratic forms of the first model for the first sweep
+      if ((rc = spatial_ms(0)) != PBBSS_OK) return rc;
     }
   }
   if (o->final_predict && out_affiliation) {

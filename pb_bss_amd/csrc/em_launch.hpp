@@ -199,3 +199,28 @@ inline int em_shared_launch(int D, int K, int y_is_c128, const EmArgs& a, const 
   }
 }
 }  // namespace pbbss
+
+namespace pbbss {
+// spatial half of the rotated joint loop (joint_inst.hip: run_joint_ms), one per compiled D
+int joint_ms_launch_d2(int K, int y_is_c128, const EmArgs&, const JointMs&, const EmLaunchCfg&, hipStream_t);
+int joint_ms_launch_d3(int K, int y_is_c128, const EmArgs&, const JointMs&, const EmLaunchCfg&, hipStream_t);
+int joint_ms_launch_d4(int K, int y_is_c128, const EmArgs&, const JointMs&, const EmLaunchCfg&, hipStream_t);
+int joint_ms_launch_d5(int K, int y_is_c128, const EmArgs&, const JointMs&, const EmLaunchCfg&, hipStream_t);
+int joint_ms_launch_d6(int K, int y_is_c128, const EmArgs&, const JointMs&, const EmLaunchCfg&, hipStream_t);
+int joint_ms_launch_d7(int K, int y_is_c128, const EmArgs&, const JointMs&, const EmLaunchCfg&, hipStream_t);
+int joint_ms_launch_d8(int K, int y_is_c128, const EmArgs&, const JointMs&, const EmLaunchCfg&, hipStream_t);
+
+inline int joint_ms_launch(int D, int K, int y_is_c128, const EmArgs& a, const JointMs& jm,
+                           const EmLaunchCfg& cfg, hipStream_t s) {
+  switch (D) {
+    case 2: return joint_ms_launch_d2(K, y_is_c128, a, jm, cfg, s);
+    case 3: return joint_ms_launch_d3(K, y_is_c128, a, jm, cfg, s);
+    case 4: return joint_ms_launch_d4(K, y_is_c128, a, jm, cfg, s);
+    case 5: return joint_ms_launch_d5(K, y_is_c128, a, jm, cfg, s);
+    case 6: return joint_ms_launch_d6(K, y_is_c128, a, jm, cfg, s);
+    case 7: return joint_ms_launch_d7(K, y_is_c128, a, jm, cfg, s);
+    case 8: return joint_ms_launch_d8(K, y_is_c128, a, jm, cfg, s);
+    default: return PBBSS_ERR_UNSUPPORTED;
+  }
+}
+}  // namespace pbbss

@@ -17,6 +17,7 @@
 #include "embed.hpp"
 #include <cmath>
 #include "pbbss_dev.hpp"
+#include "embed_dev.hpp"
 
 namespace pbbss {
 namespace {
@@ -83,57 +84,8 @@ __global__ void __launch_bounds__(kThreads) embed_prepare_kernel(const TS* y, in
 // ---------------------------------------------------------------- offsets
 // ln( I_nu(x) / x^nu ) by the ascending series (all terms positive), summed in the
 // log domain by one wavefront:  sum_m (x^2/4)^m / (m! Gamma(m+nu+1)) * 2^-nu.
-__device__ double wave_log_bessel_over_power(double nu, double x, int lane) {
-  const double q = 0.25 * x * x;
-  const double lx = 2.0 * log(x) - 1.3862943611198906;  // ln(x^2 / 4)
-  const int M = (int)ceil(fmin(x, 1.0e6)) + 48;        // terms fall by > 4x per step past m = x
-  // lane owns the terms [m0, m0 + R): ln t_m0 from lgamma, then the block's sum RELATIVE to its
-  // first term by the linear recurrence t_(m+1) / t_m = (x^2/4) / ((m+1)(m+1+nu)) -- no logarithm
-  // or exponential per term (they were a serial chain of ~150 instructions per term on the one
-  // wavefront the M-step finalize waits for).  Blocks longer than 16 terms (x > 1000) re-anchor
-  // in the log domain so that the running product cannot overflow.
-  const int R = (M + kWave - 1) / kWave;
-  const int m0 = lane * R;
-  double lt = (m0 ? (double)m0 * lx : 0.0) - lgamma((double)m0 + 1.0) - lgamma((double)m0 + nu + 1.0);
-  double mx = lt, sum = 0.0;   // block total = exp(mx) * sum
-  double p = 1.0, s = 1.0;     // running term and partial sum relative to the anchor term
-  for (int r = 1; r < R; ++r) {
-    const double m1 = (double)(m0 + r);
-    p *= q / (m1 * (m1 + nu));
-    s += p;
-    if ((r & 15) == 15) {      // re-anchor: fold the partial sum into (mx, sum), restart at term r
-      const double la = lt + log(s - p);  // the terms before r
-      const double lp = lt + log(p);      // term r itself becomes the new anchor
-      if (sum == 0.0) {
-        mx = la;
-        sum = 1.0;
-      } else if (la > mx) {
-        sum = sum * exp(mx - la) + 1.0;
-        mx = la;
-      } else {
-        sum += exp(la - mx);
-      }
-      lt = lp;
-      p = 1.0;
-      s = 1.0;
-    }
-  }
-  {
-    const double la = lt + log(s);
-    if (sum == 0.0) {
-      mx = la;
-      sum = 1.0;
-    } else if (la > mx) {
-      sum = sum * exp(mx - la) + 1.0;
-      mx = la;
-    } else {
-      sum += exp(la - mx);
-    }
-  }
-  const double gmx = wave_max(mx);
-  sum = wave_sum(sum * exp(mx - gmx));
-  return -nu * 0.6931471805599453 + gmx + log(sum);
-}
+// (wave_log_bessel_over_power lives in embed_dev.hpp: the spatial kernel of the rotated joint loop
+// runs the spectral finalize inside its own launch)
 
 // one wavefront per (mixture, class)
 __global__ void __launch_bounds__(kThreads) embed_offsets_kernel(int kind, int64_t BK, int E,
@@ -585,6 +537,242 @@ __global__ void __launch_bounds__(kFusedThreads)
     double t = 0.0;
     for (int ss = 0; ss < S; ++ss) t += red[((size_t)ss * K + k) * E + dd];
     dst[k * (E + 1) + dd] = t;
+  }
+  if (tid < K) {
+    double t = 0.0;
+    for (int w = 0; w < kFusedThreads / kWave; ++w) t += red0[w * K + tid];
+    dst[tid * (E + 1) + E] = t;
+  }
+}
+
+// ---------------------------------------------------------------- joint models: fused sweep
+// Round 4 (the "rotated" joint loop of pbbss_joint_fit): ONE pass over the
+// embedding per EM iteration for GCACGMM (spherical) / VMFCACGMM.  The tile machinery is the one
+// of vmf_em_kernel; the E part of a row n = (bin f, frame t) additionally takes the spatial half
+// of the posterior from the quadratic forms Q[f, k, t] and ln det B_fk that the spatial kernel
+// (cacgmm_em.hpp: run_joint_ms) left behind:
+//   log p_k = spatial_weight * (-D ln Q_fkt - ln det B_fk) + spectral_weight * spectral_k(e_n)
+//   gamma   = softmax_k(log p) * w      (gcacgmm.py:66-117, vmfcacgmm.py:57-97,
+//                                        mixture_model_utils.py:30-53: clip to [eps, 1 - eps])
+// gamma goes to G (F, K, T) for the spatial M-step; gamma * saliency are the weights of the
+// spectral M-step sums taken from the SAME tile: S1 = sum w e, S0 = sum w and, for the spherical
+// Gaussian, the second moment about the shift c = the mean the E part has just used (PASS 2 of
+// embed_fit_kernel; the finalize corrects it to the new mean).  The vMF half normalises the rows
+// in the E part only -- the reference's M-step takes the embedding as given (vmfcacgmm.py:286,
+// VonMisesFisherTrainer._fit).
+template <int KIND, int K, typename TS, bool VEC>
+__global__ void __launch_bounds__(kFusedThreads)
+    joint_sweep_kernel(const TS* __restrict__ y, int64_t N, int E, int R, int C, int64_t L, int T,
+                       int D, const double* __restrict__ Q, const double* __restrict__ lndet,
+                       const double* __restrict__ weight, int64_t wb, int64_t wk, int64_t wt,
+                       const double* __restrict__ mean, const double* __restrict__ prec,
+                       const double* __restrict__ offset, double spatial_weight,
+                       double spectral_weight, const double* __restrict__ sal, double eps,
+                       double* __restrict__ G, double* __restrict__ part,
+                       double* __restrict__ part2) {
+  extern __shared__ __attribute__((aligned(16))) char smraw[];
+  constexpr bool GAUSS = KIND != PBBSS_EMBED_VMF;
+  constexpr int KW = (K + 1) & ~1;
+  const int ES = E | 1;
+  const int S = kFusedThreads / E;
+  double* affw = reinterpret_cast<double*>(smraw);   // [R][KW]  gamma * saliency
+  double* red = affw + (size_t)R * KW;               // [S][K][E]
+  double* red2 = red + (size_t)S * K * E;            // [S][K][E]  (Gaussian)
+  double* red0 = red2 + (GAUSS ? (size_t)S * K * E : 0);  // [waves][K]
+  TS* tile = reinterpret_cast<TS*>(red0 + (kFusedThreads / kWave) * K);  // [R][ES]
+  const int c = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int s = tid / E, d = tid - s * E;
+  const bool active = s < S;
+  double acc[K], acc2[K], s0[K], mud[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    acc[k] = 0.0;
+    acc2[k] = 0.0;
+    s0[k] = 0.0;
+    mud[k] = (GAUSS && active) ? mean[k * E + d] : 0.0;  // shift of the second moment
+  }
+  const int64_t n0 = (int64_t)c * L;
+  const int64_t n1 = (n0 + L < N) ? (n0 + L) : N;
+  constexpr int VW = 16 / (int)sizeof(TS);
+  typedef TS VecT __attribute__((ext_vector_type(VW)));
+  constexpr int kVU = 12;
+  const bool vec = VEC && (R * E <= kVU * kFusedThreads * VW);
+  VecT pre[kVU];
+  auto request = [&](int64_t nb2) {
+    const int rows2 = (int)((n1 - nb2 < R) ? (n1 - nb2) : R);
+    const int nv = rows2 * E / VW;
+    const VecT* base = reinterpret_cast<const VecT*>(y + (size_t)nb2 * E);
+#pragma unroll
+    for (int u = 0; u < kVU; ++u) {
+      const int i = tid + u * kFusedThreads;
+      pre[u] = base[i < nv ? i : (nv > 0 ? nv - 1 : 0)];
+    }
+  };
+  if (vec && n0 < n1) request(n0);
+  for (int64_t nb = n0; nb < n1; nb += R) {
+    const int rows = (int)((n1 - nb < R) ? (n1 - nb) : R);
+    // the row's spatial inputs are requested before the tile lands in LDS (independent loads)
+    double qv[K], ld[K], wv[K], sv = 1.0;
+    int64_t gidx = 0;
+    const bool mine = tid < rows;
+    {
+      const int64_t n = nb + (mine ? tid : 0);
+      const int64_t f = n / T;
+      const int t = (int)(n - f * T);
+      gidx = (f * K) * (int64_t)T + t;
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        qv[k] = Q[gidx + (int64_t)k * T];
+        ld[k] = lndet[f * K + k];
+        wv[k] = weight ? weight[f * wb + k * wk + (int64_t)t * wt] : 1.0;
+      }
+      if (sal) sv = sal[n];
+    }
+    __syncthreads();  // previous tile fully consumed
+    if (vec) {
+      const int nv = rows * E / VW;
+#pragma unroll
+      for (int u = 0; u < kVU; ++u) {
+        const int i = tid + u * kFusedThreads;
+        if (i < nv) {
+          const int e0 = i * VW;
+          const int r = e0 / E;
+          TS* dst = tile + (size_t)r * ES + (e0 - r * E);
+#pragma unroll
+          for (int x = 0; x < VW; ++x) dst[x] = pre[u][x];
+        }
+      }
+      if (nb + R < n1) request(nb + R);
+    } else {
+      const TS* base = y + (size_t)nb * E;
+      const int total = rows * E;
+      constexpr int U = 8;
+      for (int i0 = tid; i0 < total; i0 += U * kFusedThreads) {
+        TS raw[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int i = i0 + u * kFusedThreads;
+          raw[u] = base[i < total ? i : total - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int i = i0 + u * kFusedThreads;
+          if (i < total) {
+            const int r = i / E;
+            tile[(size_t)r * ES + (i - r * E)] = raw[u];
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // ---- E part: thread = row
+    if (tid < R) {
+      double w[K];
+#pragma unroll
+      for (int k = 0; k < K; ++k) w[k] = 0.0;
+      if (mine) {
+        const TS* row = tile + (size_t)tid * ES;
+        double n2 = 0.0, a[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) a[k] = 0.0;
+        if (GAUSS) {
+          for (int e = 0; e < E; ++e) {
+            const double v = (double)row[e];
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+              const double u = v - mean[k * E + e];  // gaussian.py:127-131; the common
+              a[k] = fma(u, u, a[k]);                // precision factor is applied below
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < K; ++k) a[k] *= prec[k] * prec[k];
+        } else {
+          for (int e = 0; e < E; ++e) {
+            const double v = (double)row[e];
+            n2 = fma(v, v, n2);
+#pragma unroll
+            for (int k = 0; k < K; ++k) a[k] = fma(v, mean[k * E + e], a[k]);
+          }
+        }
+        const double inv = GAUSS ? 0.0 : 1.0 / fmax(sqrt(n2), kTiny);
+        double lp[K], mx = -1.79e308;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          const double spec = GAUSS ? offset[k] - 0.5 * a[k]                // gaussian.py:132-136
+                                    : fma(prec[k], a[k] * inv, offset[k]);  // von_mises_fisher.py:71-77
+          const double spat = -(double)D * log(qv[k]) - ld[k];              // cacg.py:200-201
+          lp[k] = spatial_weight * spat + spectral_weight * spec;
+          mx = fmax(mx, lp[k]);
+        }
+        double g[K], den = 0.0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          g[k] = exp(lp[k] - mx) * wv[k];
+          den += g[k];
+        }
+        den = fmax(den, kTiny);
+        const double rden = 1.0 / den;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          double gam = g[k] * rden;
+          if (eps != 0.0) gam = fmin(fmax(gam, eps), 1.0 - eps);
+          G[gidx + (int64_t)k * T] = gam;
+          const double wk2 = gam * sv;
+          s0[k] += wk2;
+          w[k] = wk2;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < KW; ++k) affw[tid * KW + k] = (k < K) ? w[k < K ? k : 0] : 0.0;
+    }
+    __syncthreads();
+    // ---- M part: thread = (slot, dimension)
+    if (active) {
+      for (int r = s; r < rows; r += S) {
+        const double v = (double)tile[(size_t)r * ES + d];
+        double wk3[KW];
+#pragma unroll
+        for (int k = 0; k < KW; k += 2) {
+          const double2 p2 = *reinterpret_cast<const double2*>(affw + r * KW + k);
+          wk3[k] = p2.x;
+          wk3[k + 1] = p2.y;
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          acc[k] = fma(wk3[k], v, acc[k]);
+          if (GAUSS) {
+            const double df = v - mud[k];
+            acc2[k] = fma(wk3[k] * df, df, acc2[k]);
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (active) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      red[((size_t)s * K + k) * E + d] = acc[k];
+      if (GAUSS) red2[((size_t)s * K + k) * E + d] = acc2[k];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const double t = wave_sum(s0[k]);
+    if ((tid & (kWave - 1)) == 0) red0[(tid / kWave) * K + k] = t;
+  }
+  __syncthreads();
+  double* dst = part + (size_t)c * K * (E + 1);
+  for (int i = tid; i < K * E; i += kFusedThreads) {
+    const int k = i / E, dd = i - k * E;
+    double t = 0.0, t2 = 0.0;
+    for (int ss = 0; ss < S; ++ss) {
+      t += red[((size_t)ss * K + k) * E + dd];
+      if (GAUSS) t2 += red2[((size_t)ss * K + k) * E + dd];
+    }
+    dst[k * (E + 1) + dd] = t;
+    if (GAUSS) part2[(size_t)c * K * (E + 1) + k * (E + 1) + dd] = t2;
   }
   if (tid < K) {
     double t = 0.0;
@@ -1349,6 +1537,129 @@ int launch_vmf_em(const void* y, int y_is_f64, int64_t B, int64_t N, int E, int 
   hipLaunchKernelGGL((embed_finalize_kernel<PBBSS_EMBED_VMF, 0>), dim3((unsigned)B),
                      dim3(kFinThreads), lds_fin, s, part, p.C, E, K, cmin, cmax, weight_mode,
                      den_buf, mean, conc, weight, offset, prec);
+  return ok_or_hip();
+}
+
+// ---- rotated joint loop: sweep (posteriors + spectral sums) and its finalize -------------------
+namespace {
+FusedPlan joint_sweep_plan(int64_t N, int E, int K, int y_is_f64, bool gauss) {
+  FusedPlan p{};
+  const size_t esz = y_is_f64 ? 8 : 4;
+  const int ES = E | 1;
+  if (E > kFusedThreads || E < 1) return p;
+  const int S = kFusedThreads / E;
+  const int KW = (K + 1) & ~1;
+  static const int rows_env = [] {  // development knob: rows per tile of the sweep
+    const char* v = getenv("PBBSS_JOINT_SWEEP_ROWS");
+    return v ? atoi(v) : 0;
+  }();
+  for (int R : {256, 128, 64}) {
+    if (rows_env > 0 && R > rows_env) continue;
+    const size_t lds = ((size_t)R * KW + (gauss ? 2 : 1) * (size_t)S * K * E +
+                        (size_t)(kFusedThreads / kWave) * K) * 8 + (size_t)R * ES * esz;
+    if (lds <= 64 * 1024) {
+      p.R = R;
+      p.lds = lds;
+      p.ok = true;
+      break;
+    }
+  }
+  if (!p.ok) return p;
+  static const int want_env = [] {  // development knob: chunks (= workgroups) of the sweep
+    const char* v = getenv("PBBSS_JOINT_SWEEP_CHUNKS");
+    return v ? atoi(v) : 0;
+  }();
+  int64_t want = want_env > 0 ? want_env : 512;
+  int64_t maxc = (N + p.R - 1) / p.R;
+  p.C = (int)(want < maxc ? want : maxc);
+  p.L = (N + p.C - 1) / p.C;
+  p.L = (p.L + p.R - 1) / p.R * p.R;
+  return p;
+}
+}  // namespace
+
+bool joint_sweep_supported(int kind, int64_t N, int E, int K, int y_is_f64) {
+  if (kind != PBBSS_EMBED_VMF && kind != PBBSS_EMBED_GAUSS_SPHERICAL) return false;
+  if (K < 1 || K > kEmbedMaxK) return false;
+  return joint_sweep_plan(N, E, K, y_is_f64, kind != PBBSS_EMBED_VMF).ok;
+}
+
+void joint_sweep_chunks(int kind, int64_t N, int E, int K, int y_is_f64, int* chunks) {
+  const FusedPlan p = joint_sweep_plan(N, E, K, y_is_f64, kind != PBBSS_EMBED_VMF);
+  *chunks = p.ok ? p.C : 0;
+}
+
+// chunk partials S1/S0 (+ S2' for the Gaussian) and the finalize's denominators
+size_t joint_sweep_partial_doubles(int kind, int64_t N, int E, int K, int y_is_f64) {
+  const FusedPlan p = joint_sweep_plan(N, E, K, y_is_f64, kind != PBBSS_EMBED_VMF);
+  if (!p.ok) return 0;
+  return 2 * (size_t)p.C * K * (E + 1) + (size_t)K;
+}
+
+int launch_joint_sweep(int kind, const void* y, int y_is_f64, int64_t F, int T, int E, int K, int D,
+                       const double* Q, const double* lndet, const double* weight, int64_t wb,
+                       int64_t wk, int64_t wt, const double* mean, const double* prec,
+                       const double* offset, double spatial_weight, double spectral_weight,
+                       const double* sal, double eps, double* G, double* part, hipStream_t s) {
+  const int64_t N = F * (int64_t)T;
+  const bool gauss = kind != PBBSS_EMBED_VMF;
+  const FusedPlan p = joint_sweep_plan(N, E, K, y_is_f64, gauss);
+  if (!p.ok || !joint_sweep_supported(kind, N, E, K, y_is_f64)) return PBBSS_ERR_UNSUPPORTED;
+  double* part2 = part + (size_t)p.C * K * (E + 1);
+  dim3 grid((unsigned)p.C);
+  const int vw = y_is_f64 ? 2 : 4;
+  const bool vec = (E % vw == 0) && (reinterpret_cast<uintptr_t>(y) % 16 == 0);
+#define PBBSS_JS_GO(KIND, KK, TT, VV)                                                              \
+  hipLaunchKernelGGL((joint_sweep_kernel<KIND, KK, TT, VV>), grid, dim3(kFusedThreads), p.lds, s,  \
+                     static_cast<const TT*>(y), N, E, p.R, p.C, p.L, T, D, Q, lndet, weight, wb,   \
+                     wk, wt, mean, prec, offset, spatial_weight, spectral_weight, sal, eps, G,     \
+                     part, part2)
+#define PBBSS_JS_T(KIND, KK)                                                                       \
+  if (y_is_f64) {                                                                                  \
+    if (vec) PBBSS_JS_GO(KIND, KK, double, true); else PBBSS_JS_GO(KIND, KK, double, false);       \
+  } else {                                                                                         \
+    if (vec) PBBSS_JS_GO(KIND, KK, float, true); else PBBSS_JS_GO(KIND, KK, float, false);         \
+  }
+#define PBBSS_JS_K(KK)                                                                             \
+  case KK:                                                                                         \
+    if (gauss) { PBBSS_JS_T(PBBSS_EMBED_GAUSS_SPHERICAL, KK) } else { PBBSS_JS_T(PBBSS_EMBED_VMF, KK) } \
+    break;
+  switch (K) {
+    PBBSS_JS_K(1) PBBSS_JS_K(2) PBBSS_JS_K(3) PBBSS_JS_K(4) PBBSS_JS_K(5) PBBSS_JS_K(6)
+    PBBSS_JS_K(7) PBBSS_JS_K(8)
+    default: return PBBSS_ERR_UNSUPPORTED;
+  }
+#undef PBBSS_JS_K
+#undef PBBSS_JS_T
+#undef PBBSS_JS_GO
+  return ok_or_hip();
+}
+
+// the model of the spectral half from the sweep's partials (+ the constants the next sweep
+// reads); `reduce`: sum the partials over the ranks first (bins sharded, pbbss_mix_opts.sharded)
+int launch_joint_sweep_finalize(int kind, const void* y, int y_is_f64, int64_t N, int E, int K,
+                                double cmin, double cmax, double* part, double* mean,
+                                double* scale, double* offset, double* prec, hipStream_t s,
+                                const PartialReduce* reduce) {
+  const bool gauss = kind != PBBSS_EMBED_VMF;
+  const FusedPlan p = joint_sweep_plan(N, E, K, y_is_f64, gauss);
+  if (!p.ok) return PBBSS_ERR_UNSUPPORTED;
+  const size_t nsum = (size_t)p.C * K * (E + 1);
+  if (reduce) {
+    if (int rc = reduce->fn(reduce->ctx, part, gauss ? 2 * nsum : nsum, s); rc != PBBSS_OK) return rc;
+  }
+  const size_t Wv = (size_t)K * (E + 1);
+  if (gauss) {
+    hipLaunchKernelGGL(embed_finalize_single_kernel, dim3(1), dim3(kFinThreads),
+                       (2 * Wv + (2 * Wv < (size_t)kFinThreads ? (size_t)kFinThreads : 0)) * sizeof(double),
+                       s, part, part + nsum, p.C, E, K, y, y_is_f64, N, 0, mean, scale, offset, prec);
+    return ok_or_hip();
+  }
+  const size_t lds_fin = (Wv + (Wv < (size_t)kFinThreads ? (kFinThreads / Wv) * Wv : 0)) * sizeof(double);
+  double* den_buf = part + 2 * nsum;
+  hipLaunchKernelGGL((embed_finalize_kernel<PBBSS_EMBED_VMF, 0>), dim3(1), dim3(kFinThreads),
+                     lds_fin, s, part, p.C, E, K, cmin, cmax, -1, den_buf, mean, scale,
+                     (double*)nullptr, offset, prec);
   return ok_or_hip();
 }
 

@@ -75,6 +75,27 @@ int launch_vmf_em(const void* y, int y_is_f64, int64_t B, int64_t N, int E, int 
                   int weight_mode, double* part, double* mean, double* conc, double* weight,
                   double* offset, double* prec, double* out_aff, int accumulate, hipStream_t s);
 
+// Rotated joint loop (round 4): ONE pass over the row-major embedding (F*T, E) per EM iteration of
+// GCACGMM (spherical) / VMFCACGMM.  launch_joint_sweep: posteriors of every point from the
+// spatial quadratic forms Q (F,K,T) + ln det B (F,K) (written by the spatial kernel,
+// cacgmm_em.hpp: run_joint_ms) and the spectral model (mean (K,E), prec / offset (K)) -> G (F,K,T)
+// (clipped to [eps, 1 - eps]); chunk partials of the spectral M-step sums with gamma * saliency
+// from the same tile -> part (joint_sweep_partial_doubles() doubles).  weight is read through
+// (wb, wk, wt) as w[f * wb + k * wk + t * wt] (null: 1).  launch_joint_sweep_finalize: the
+// spectral model of the next iteration from the partials (all-reduced first when `reduce`).
+bool joint_sweep_supported(int kind, int64_t N, int E, int K, int y_is_f64);
+size_t joint_sweep_partial_doubles(int kind, int64_t N, int E, int K, int y_is_f64);
+void joint_sweep_chunks(int kind, int64_t N, int E, int K, int y_is_f64, int* chunks);
+int launch_joint_sweep(int kind, const void* y, int y_is_f64, int64_t F, int T, int E, int K, int D,
+                       const double* Q, const double* lndet, const double* weight, int64_t wb,
+                       int64_t wk, int64_t wt, const double* mean, const double* prec,
+                       const double* offset, double spatial_weight, double spectral_weight,
+                       const double* sal, double eps, double* G, double* part, hipStream_t s);
+int launch_joint_sweep_finalize(int kind, const void* y, int y_is_f64, int64_t N, int E, int K,
+                                double cmin, double cmax, double* part, double* mean,
+                                double* scale, double* offset, double* prec, hipStream_t s,
+                                const PartialReduce* reduce = nullptr);
+
 // masked affiliation sums of the joint models (gcacgmm.py:286-295): aff (F,K,T), sal (F,T)
 //   mode 0 'fk' (-1,): w[f,k] = sum_t / sum_k sum_t          -> (F,K)
 //   mode 1 uniform    : 1/K                                   -> (1)

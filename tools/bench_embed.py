@@ -16,7 +16,7 @@ flat = ed.reshape(1, F * T, E)
 g0 = gd.permute(1, 0, 2).reshape(1, K, F * T).contiguous()
 engine.set_timing(True)
 iters = 100
-for rep in range(3):
+for rep in range(0 if '--joint-only' in sys.argv else 3):
     engine.vmfmm_fit(flat, K, gamma0=g0, iterations=iters, final_predict=True)
     ms = engine.last_kernel_ms()
     print(f'device vMFMM N={F*T} E={E} K={K}: {iters} iterations in {ms:.3f} ms -> '
@@ -27,7 +27,7 @@ for kind, name in ((_lib.EMBED_GAUSS_SPHERICAL, 'GCACGMM'), (_lib.EMBED_VMF, 'VM
         ms = engine.last_kernel_ms()
         print(f'device {name} config 5: {iters} iterations in {ms:.3f} ms -> '
               f'{iters/ms*1e3:.0f} EM it/s, {ms/iters*1e3:.1f} us/iter')
-if '--no-cpu' not in sys.argv:
+if '--no-cpu' not in sys.argv and '--joint-only' not in sys.argv:
     e64, Y128 = e.astype(np.float64), Y.astype(np.complex128)
     t0 = time.perf_counter(); oe.vmfmm_fit(e64.reshape(-1, E), init.transpose(1, 0, 2).reshape(K, -1), 5)
     dt = time.perf_counter() - t0

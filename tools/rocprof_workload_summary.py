@@ -80,9 +80,22 @@ def main(root, cmd, sha, workload):
         for r in csv.DictReader(open(f)):
             if 'pbbss' in r['Kernel_Name']:
                 acc[(short(r['Kernel_Name']), r['Counter_Name'])].append(float(r['Counter_Value']))
+        if not acc:
+            continue
+        # steps of THIS pass (the profiler slows the pre-heat loop down: every pass runs its own
+        # number of steps): launches of the once-per-fit marker kernel under one counter
+        c0 = sorted({c for (_, c) in acc})[0]
+        if marker:
+            psteps = sum(len(v) for (k, c), v in acc.items()
+                         if c == c0 and marker in k and 'split' not in k)
+        else:
+            psteps = sum(len(v) for (k, c), v in acc.items()
+                         if c == c0 and 'vmf_em_kernel' in k) // (iters + 1)
+        psteps = max(psteps, 1)
+        print(f'# pass {[d for d in f.split(os.sep) if d.startswith("pmc_")][0]}: {psteps} steps')
         for (k, c), v in sorted(acc.items()):
-            print(f'{k} | {c} | {len(v)} | {sum(v) / len(v):.1f} | {sum(v) / steps:.1f}')
-            step_tot[c] += sum(v) / steps
+            print(f'{k} | {c} | {len(v)} | {sum(v) / len(v):.1f} | {sum(v) / psteps:.1f}')
+            step_tot[c] += sum(v) / psteps
     if 'FETCH_SIZE' in step_tot:
         print('# FETCH_SIZE / WRITE_SIZE are KiB at the L2 <-> fabric interface (Infinity-Cache hits '
               'included); raw counters, no gfx950 correction applied (MI355X_MICROARCH.md: FETCH_SIZE '
