@@ -307,6 +307,34 @@ def pcie_inclusive(Y0, init0, iters, reps=10):
                     'never reported as `value`'}
 
 
+def canonical_call(Y0, reps=10):
+    """The reference's canonical call (examples/mixture_model_example.ipynb, cacgmm.py:205-210):
+    `CACGMMTrainer().fit(Y, num_classes=3)` with a RANDOM initialisation, 10 EM iterations, NumPy
+    observation in, model out.  'numpy' draws the initialisation from NumPy's global generator as
+    the reference does (host RNG + upload on the critical path); 'device' is the opt-in GPU draw
+    (pb_bss_amd.distribution.utils.set_random_init).  Secondary figures."""
+    import torch
+    from pb_bss_amd.distribution import CACGMMTrainer, utils
+    from pb_bss_amd import _lib
+    out = {}
+    Yd = _lib.to_device(Y0)
+    for mode in ('numpy', 'device'):
+        with utils.random_init(mode):
+            for resident, Yin in (('numpy_in', Y0), ('resident', Yd)):
+                CACGMMTrainer().fit(Yin, num_classes=K, iterations=10)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    CACGMMTrainer().fit(Yin, num_classes=K, iterations=10)
+                torch.cuda.synchronize()
+                out[f'{mode}_init_{resident}_ms'] = (time.perf_counter() - t0) / reps * 1e3
+    out['what'] = ('CACGMMTrainer().fit(Y, num_classes=3, iterations=10), ms per call: random '
+                   'initialisation drawn by NumPy\'s global generator (the reference\'s stream; '
+                   'default) or on the device (opt-in, a different stream), observation given as a '
+                   'NumPy array or already resident')
+    return out
+
+
 def single_utterance_chain(Y0, init0, iters, beamformer, reps=10):
     """Latency of the chain a caller runs on ONE utterance with everything resident in HBM: EM fit +
     predict, DHTV permutation alignment of the masks, PSD -> beamformer -> apply.  Wall clock per
@@ -1355,6 +1383,7 @@ def main():
             out['host_numpy_in_out'] = pcie_inclusive(Y0, init0, args.iters)
             out['single_utterance_chain'] = single_utterance_chain(Y0, init0, args.iters,
                                                                    args.beamformer)
+            out['canonical_call'] = canonical_call(Y0)
         # ---- CPU baseline on this host, bounded sample ------------------------
         if world == 1 and args.cpu_iters > 0:
             out['cpu_baseline'] = cpu_baseline_em(Y0, init0, args.cpu_iters)

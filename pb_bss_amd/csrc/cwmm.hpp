@@ -254,11 +254,15 @@ struct WatsonKernel {
     }
   }
 
-  // (pvre, pvim): eigenvector matrix of this class from the previous EM iteration, kept in
-  // the registers of the wave that owns the class.  The covariance is rotated into that basis
-  // first (B = V'^H C V'), which is nearly diagonal once EM settles, so the cyclic Jacobi
-  // converges in fewer sweeps; V = V' W.  Same eigenpairs to rounding; the eigenvector phase
-  // is free and cancels in m m^H.  `warm` is false on the first iteration.
+  // (pvre, pvim): MODE of this class from the previous EM iteration (component i on the lanes of
+  // row i), kept in the registers of the wave that owns the class.  The M-step keeps ONE
+  // eigenpair (complex_watson.py:300-315, utils.get_pca): from the previous mode the dominant
+  // eigenpair comes out of a few rounds of shifted inverse iteration on positive definite
+  // systems (wave_la.hpp: wave_dominant_eigenpair) instead of a full Jacobi decomposition
+  // (8.5-14.5 us of the 44 us iteration at D = 8; profiles/r03_l_api_sweep.txt).  The first
+  // iteration, a start vector that tracked a non-dominant eigenpair (certified by the sign of the
+  // pivots) and a residual that does not reach rounding level fall back to the cyclic Jacobi.
+  // The eigenvector phase is free and cancels in m m^H.  `warm` is false on the first iteration.
   static __device__ void factor_class(const WatsonArgs& wa, const Lds& L, const double* knot1,
                                       const uint32_t* jtab, int64_t b, int k, int lane,
                                       bool last, bool warm, double& pvre, double& pvim) {
@@ -295,47 +299,42 @@ struct WatsonKernel {
     }
     int st = 0;
     if (wave_or((isfinite(are) && isfinite(aim)) ? 0 : 1)) st |= PBBSS_ST_NONFINITE;
-    double vre, vim;
-    int sweeps;
-    if (warm && !(st & PBBSS_ST_NONFINITE)) {
-      double hre, him, tre, tim, bre, bim;
-      wave_adjoint(pvre, pvim, c, hre, him);               // V'^H
-      wave_matmul<D>(are, aim, pvre, pvim, c, tre, tim);   // C V'
-      wave_matmul<D>(hre, him, tre, tim, c, bre, bim);     // V'^H C V'
-      wave_adjoint(bre, bim, c, tre, tim);                 // re-symmetrise the rounding
-      bre = 0.5 * (bre + tre);
-      bim = 0.5 * (bim + tim);
-      if (!valid) {
-        bre = 0.0;
-        bim = 0.0;
+    double lmax = 0.0, mre_i = 0.0, mim_i = 0.0;
+    bool fast = false;
+    if (warm && !(st & PBBSS_ST_NONFINITE) && !a.force_eig) {
+      double xr = pvre, xi = pvim, lam = 0.0;
+      int rounds = 0;
+      fast = wave_dominant_eigenpair<D>(are, aim, c, xr, xi, lam, rounds);
+      fast = __builtin_amdgcn_readfirstlane((int)fast) != 0;
+      if (fast) {
+        lmax = lam;
+        mre_i = xr;
+        mim_i = xi;
       }
-      double wre, wim;
-      sweeps = wave_jacobi_heev_tab<D>(bre, bim, c, wre, wim, jtab, lane);
-      wave_matmul<D>(pvre, pvim, wre, wim, c, vre, vim);   // V = V' W
-      are = bre;
-      aim = bim;
-    } else {
-      sweeps = wave_jacobi_heev_tab<D>(are, aim, c, vre, vim, jtab, lane);
     }
-    if (sweeps < 0) st |= PBBSS_ST_EIG_NOCONV;
-    pvre = valid ? vre : 0.0;
-    pvim = valid ? vim : 0.0;
-    double lam = lane_get(are, ij_lane(c.j, c.j));
-    int rank = wave_sort_rank<D>(lam, c);
-    int col = 0;
-    double lmax = 0.0;
+    if (!fast) {
+      double vre, vim;
+      const int sweeps = wave_jacobi_heev_tab<D>(are, aim, c, vre, vim, jtab, lane);
+      if (sweeps < 0) st |= PBBSS_ST_EIG_NOCONV;
+      double lam = lane_get(are, ij_lane(c.j, c.j));
+      int rank = wave_sort_rank<D>(lam, c);
+      int col = 0;
 #pragma unroll
-    for (int m = 0; m < D; ++m) {
-      int rm = lane_get(rank, ij_lane(0, m));
-      double lm = lane_get(lam, ij_lane(0, m));
-      if (rm == D - 1) {
-        col = m;
-        lmax = lm;
+      for (int m = 0; m < D; ++m) {
+        int rm = lane_get(rank, ij_lane(0, m));
+        double lm = lane_get(lam, ij_lane(0, m));
+        if (rm == D - 1) {
+          col = m;
+          lmax = lm;
+        }
       }
+      // mode components for this lane's row index
+      mre_i = lane_get(vre, ij_lane(c.i, col));
+      mim_i = lane_get(vim, ij_lane(c.i, col));
     }
+    pvre = (c.i < D) ? mre_i : 0.0;
+    pvim = (c.i < D) ? mim_i : 0.0;
     const double kappa = watson_concentration(wa, knot1, lmax, lane);
-    // mode components for this lane's row and column index
-    double mre_i = lane_get(vre, ij_lane(c.i, col)), mim_i = lane_get(vim, ij_lane(c.i, col));
     set_class(L, k, lane, c, mre_i, mim_i, kappa);
     if (last) {
       if (c.j == 0 && c.i < D && wa.out_mode) {

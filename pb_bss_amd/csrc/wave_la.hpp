@@ -446,6 +446,107 @@ __device__ __forceinline__ int wave_jacobi_heev_tab(double& are, double& aim, La
   return sweeps;
 }
 
+// ---------------------------------------------------------------------------
+// Dominant eigenpair of a Hermitian positive semi-definite matrix from a good start vector
+// (the complex-Watson M-step keeps ONE eigenpair, complex_watson.py:300-315 / utils.get_pca; a
+// full Jacobi sweep set was 8.5-14.5 us of every EM iteration).
+//
+// Shifted inverse iteration that stays on positive definite systems: with the Rayleigh
+// quotient rho of the current vector and its residual norm r there is an eigenvalue within r of
+// rho; sigma = rho + 1.01 r + guard lies above it.  If that eigenvalue is the largest one,
+// sigma I - C is positive definite, the pivot-free Gauss-Jordan inverse (wave_hpd_inverse) is
+// stable, and two applications of the explicit inverse contract the error by
+// ((sigma - l1) / (sigma - l2))^2.  Rounds repeat (new rho, new shift: cubic-like convergence)
+// until the residual is at rounding level.  A non-positive pivot says that an eigenvalue LARGER
+// than sigma exists (the start vector tracked the wrong eigenpair) -> return false, and so does
+// a residual that does not reach the tolerance: the caller falls back to the full Jacobi
+// decomposition.  A successful last inversion certifies lambda_max < sigma, i.e. the returned
+// eigenvalue is the largest one up to the final residual.
+//
+// In:  A (lane (i,j) = entry), start vector x (xr, xi) with component i on the lanes of ROW i
+//      (any column), need not be normalised, must be non-zero.
+// Out: lambda, unit eigenvector on the lanes of row i (same layout), rounds used.
+// All 64 lanes call it.
+// ---------------------------------------------------------------------------
+template <int D>
+__device__ __forceinline__ void wave_row_sum8(double& a, double& b) {
+  a += dpp_f64<kDppQuadXor1, 0xF>(a, a);
+  b += dpp_f64<kDppQuadXor1, 0xF>(b, b);
+  a += dpp_f64<kDppQuadXor2, 0xF>(a, a);
+  b += dpp_f64<kDppQuadXor2, 0xF>(b, b);
+  a += dpp_f64<kDppRowHalfMirror, 0xF>(a, a);
+  b += dpp_f64<kDppRowHalfMirror, 0xF>(b, b);
+}
+
+// y = M x: x given per row (component i on row i); the product needs x_j on lane (i, j)
+template <int D>
+__device__ __forceinline__ void wave_matvec(double mre, double mim, double xr, double xi, LaneIJ c,
+                                            bool valid, double& yr, double& yi) {
+  const double xjr = lane_get(xr, ij_lane(c.j, 0)), xji = lane_get(xi, ij_lane(c.j, 0));
+  yr = valid ? mre * xjr - mim * xji : 0.0;
+  yi = valid ? mre * xji + mim * xjr : 0.0;
+  wave_row_sum8<D>(yr, yi);  // every lane of row i now holds y_i
+}
+
+constexpr int kDominantMaxRounds = 8;
+
+template <int D>
+__device__ __forceinline__ bool wave_dominant_eigenpair(double are, double aim, LaneIJ c,
+                                                        double& xr, double& xi, double& lambda,
+                                                        int& rounds) {
+  const bool valid = c.i < D && c.j < D;
+  const bool rowrep = c.j == 0 && c.i < D;  // one representative lane per vector component
+  if (!valid) {
+    are = 0.0;
+    aim = 0.0;
+  }
+  if (c.i >= D) {
+    xr = 0.0;
+    xi = 0.0;
+  }
+  // scale of the matrix (trace = sum of the eigenvalues >= lambda_max >= trace / D)
+  const double tr = wave_sum((valid && c.i == c.j) ? are : 0.0);
+  if (!(tr > 0.0) || !(tr < 1.79e308)) return false;
+  const double tol = 4e-15 * tr;
+  {
+    const double n2 = wave_sum(rowrep ? xr * xr + xi * xi : 0.0);
+    if (!(n2 > 0.0)) return false;
+    const double rn = fast_rsqrt(n2);
+    xr *= rn;
+    xi *= rn;
+  }
+  bool certified = false;
+  for (rounds = 0; rounds < kDominantMaxRounds; ++rounds) {
+    double yr, yi;
+    wave_matvec<D>(are, aim, xr, xi, c, valid, yr, yi);
+    const double rho = wave_sum(rowrep ? xr * yr + xi * yi : 0.0);  // Re x^H C x (x unit)
+    const double rr = yr - rho * xr, ri = yi - rho * xi;
+    const double res = sqrt(wave_sum(rowrep ? rr * rr + ri * ri : 0.0));
+    lambda = rho;
+    if (!(res < 1.79e308)) return false;
+    if (res <= tol && certified) return true;
+    // shift above the eigenvalue nearest to rho; the guard keeps the system safely definite
+    // once the residual is at rounding level
+    const double sigma = rho + 1.01 * res + 64.0 * tol;
+    double mre = valid ? ((c.i == c.j) ? sigma - are : -are) : ((c.i == c.j) ? 1.0 : 0.0);
+    double mim = valid ? -aim : 0.0;
+    ScaledReal det;
+    if (wave_hpd_inverse<8>(mre, mim, c, det) != 0) return false;  // an eigenvalue above sigma
+    certified = true;  // lambda_max < sigma = rho + 1.01 res + guard
+    if (res <= tol) return true;
+#pragma unroll
+    for (int rep = 0; rep < 2; ++rep) {
+      wave_matvec<D>(mre, mim, xr, xi, c, valid, yr, yi);
+      const double n2 = wave_sum(rowrep ? yr * yr + yi * yi : 0.0);
+      if (!(n2 > 0.0) || !(n2 < 1.79e308)) return false;
+      const double rn = fast_rsqrt(n2);
+      xr = yr * rn;
+      xi = yi * rn;
+    }
+  }
+  return false;
+}
+
 // rank of eigenvalue j among the D eigenvalues (ascending, ties by index):
 // column j of V belongs at sorted position rank.  lam = value on lane (j,j)
 // already broadcast down the column (every lane holds lambda of ITS column j).

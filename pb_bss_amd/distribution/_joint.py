@@ -7,7 +7,7 @@ import numpy as np
 
 from .. import _lib, engine
 from .complex_angular_central_gaussian import ComplexAngularCentralGaussian
-from .utils import as_result
+from .utils import as_result, random_affiliation
 
 
 import contextlib
@@ -57,9 +57,7 @@ def prepare(observation, embedding):
 def initial_affiliation(initialization, num_classes, F, T, device):
     t = _lib.torch()
     if initialization is None:
-        init = np.random.uniform(size=(F, num_classes, T))  # global RNG, gcacgmm.py:186-190
-        init /= np.einsum('...kt->...t', init)[..., None, :]
-        return _lib.to_device(init, t.float64).to(device)
+        return random_affiliation((F, num_classes, T), device)  # global NumPy RNG, gcacgmm.py:186-190
     g = _lib.to_device(initialization, t.float64).to(device)
     assert g.shape[0] == F and g.shape[2] == T, (g.shape, F, T)
     return g.contiguous()

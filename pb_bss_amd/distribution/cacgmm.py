@@ -34,8 +34,8 @@ from .mixture_model_utils import (
     apply_inline_permutation_alignment,
     estimate_mixture_weight,
 )
-from .utils import (_ProbabilisticModel, as_result, reference_arithmetic, reference_single,
-                    to_single)
+from .utils import (_ProbabilisticModel, as_result, random_affiliation, reference_arithmetic,
+                    reference_single, to_single)
 
 __all__ = ['CACGMM', 'CACGMMTrainer', 'normalize_observation', 'sample_cacgmm']
 
@@ -224,9 +224,8 @@ class CACGMMTrainer:
         if initialization is None:
             assert num_classes is not None, num_classes
             shape = (*indep, num_classes, N)
-            aff = np.random.uniform(size=shape)  # global RNG, as the reference
-            aff /= np.einsum('...kn->...n', aff)[..., None, :]
-            gamma0 = _lib.to_device(aff, t.float64).to(dev)
+            # global NumPy RNG, as the reference (utils.random_affiliation)
+            gamma0 = random_affiliation(shape, dev)
         elif isinstance(initialization, CACGMM):
             num_classes = initialization.cacg.covariance_eigenvectors.shape[-3]
             model = initialization

@@ -21,7 +21,7 @@ from .mixture_model_utils import (
     apply_inline_permutation_alignment,
     estimate_mixture_weight,
 )
-from .utils import _ProbabilisticModel, as_result
+from .utils import _ProbabilisticModel, as_result, random_affiliation
 
 __all__ = ['CWMM', 'CWMMTrainer']
 
@@ -110,9 +110,7 @@ class CWMMTrainer:
         indep = tuple(indep)
         if initialization is None:
             shape = (*indep, num_classes, N)
-            init = np.random.uniform(size=shape)  # global RNG, as the reference (:126-131)
-            init /= np.einsum('...kn->...n', init)[..., None, :]
-            gamma0 = _lib.to_device(init, t.float64).to(y.device)
+            gamma0 = random_affiliation(shape, y.device)  # global NumPy RNG (:126-131)
         else:
             gamma0 = _lib.to_device(initialization, t.float64).to(y.device)
             num_classes = gamma0.shape[-2]

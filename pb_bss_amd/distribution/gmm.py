@@ -16,7 +16,7 @@ import numpy as np
 
 from .. import _lib, engine
 from .gaussian import DiagonalGaussian, Gaussian, SphericalGaussian
-from .utils import _ProbabilisticModel, as_result
+from .utils import _ProbabilisticModel, as_result, random_affiliation
 
 __all__ = ['GMM', 'GMMTrainer']
 
@@ -134,9 +134,8 @@ class GMMTrainer:
         *indep, N, E = y.shape
         indep = tuple(indep)
         if initialization is None:
-            init = np.random.uniform(size=(*indep, num_classes, N))  # global RNG (:72-77)
-            init /= np.einsum('...kn->...n', init)[..., None, :]
-            gamma0 = _lib.to_device(init, t.float64).to(y.device)
+            # global NumPy RNG (:72-77)
+            gamma0 = random_affiliation((*indep, num_classes, N), y.device)
         else:
             gamma0 = _lib.to_device(initialization, t.float64).to(y.device)
             num_classes = gamma0.shape[-2]

@@ -62,6 +62,52 @@ def stack_parameters(parameters):
     return cls(**stacked)
 
 
+# ---- random affiliation initialisation (`num_classes=` instead of `initialization=`) ---------
+# The reference draws np.random.uniform(size=(..., K, N)) from NumPy's GLOBAL generator and
+# normalises over the classes (cacgmm.py:205-210, cwmm.py:126-131, ...).  'numpy' (default)
+# consumes exactly that stream -- a seeded script sees the numbers the reference would see --
+# and only moves the normalisation to the device (one host pass over the array less; the class
+# sum is taken k = 0, 1, ... like the reference's einsum, so the result is bit-identical).
+# 'device': the draw itself happens on the GPU (torch's Philox generator, seed with
+# torch.manual_seed): ~30 us instead of ~2 ms of host RNG + 6 MB of PCIe for F=513, K=3,
+# T=500 -- but NumPy's global stream is neither consumed nor reproduced.  Opt-in.
+_RANDOM_INITS = ('numpy', 'device')
+_random_init = os.environ.get('PBBSS_RANDOM_INIT', 'numpy')
+assert _random_init in _RANDOM_INITS, _random_init
+
+
+def set_random_init(mode):
+    """Where the random affiliation initialisation of `fit(..., num_classes=K)` is drawn:
+    'numpy' (the reference's global-RNG stream, default) or 'device' (on the GPU; a different
+    stream).  Returns the previous setting."""
+    global _random_init
+    assert mode in _RANDOM_INITS, (mode, _RANDOM_INITS)
+    old, _random_init = _random_init, mode
+    return old
+
+
+@contextlib.contextmanager
+def random_init(mode):
+    old = set_random_init(mode)
+    try:
+        yield
+    finally:
+        set_random_init(old)
+
+
+def random_affiliation(shape, device):
+    """(..., K, N) float64 device tensor, uniform draws normalised over the class axis."""
+    t = _lib.torch()
+    if _random_init == 'device':
+        aff = t.rand(tuple(shape), dtype=t.float64, device=device)
+    else:
+        aff = t.from_numpy(np.random.uniform(size=tuple(shape))).to(device)
+    den = aff[..., 0, :].clone()
+    for k in range(1, shape[-2]):  # ascending class order, like einsum('...kn->...n')
+        den += aff[..., k, :]
+    return aff / den[..., None, :]
+
+
 def as_result(x, like_torch):
     """Device tensor -> what the caller works with (torch in, torch out;
     NumPy in, NumPy out, as the reference returns)."""

@@ -12,7 +12,7 @@ from operator import xor
 import numpy as np
 
 from .. import _lib, engine
-from .utils import _ProbabilisticModel, as_result
+from .utils import _ProbabilisticModel, as_result, random_affiliation
 from .von_mises_fisher import VonMisesFisher
 
 __all__ = ['VMFMM', 'VMFMMTrainer']
@@ -85,9 +85,8 @@ class VMFMMTrainer:
         *indep, N, E = y.shape
         indep = tuple(indep)
         if initialization is None:
-            init = np.random.uniform(size=(*indep, num_classes, N))  # global RNG (:83-86)
-            init /= np.einsum('...kn->...n', init)[..., None, :]
-            gamma0 = _lib.to_device(init, t.float64).to(y.device)
+            # global NumPy RNG (:83-86)
+            gamma0 = random_affiliation((*indep, num_classes, N), y.device)
         else:
             gamma0 = _lib.to_device(initialization, t.float64).to(y.device)
             num_classes = gamma0.shape[-2]

@@ -340,3 +340,31 @@ def test_stack_parameters_nested_models():
     st3 = stack_parameters(tm)
     assert isinstance(st3.covariance_eigenvalues, torch.Tensor)
     np.testing.assert_array_equal(st3.covariance_eigenvalues.numpy(), st2.covariance_eigenvalues)
+
+
+def test_random_affiliation_consumes_the_reference_stream():
+    """`fit(..., num_classes=K)`: the draw comes from NumPy's global generator exactly as in the
+    reference (cacgmm.py:205-210) and the device-side normalisation is bit-identical to the
+    reference's host expression; the opt-in 'device' draw leaves NumPy's stream untouched."""
+    import torch
+    from pb_bss_amd.distribution import utils
+    np.random.seed(3)
+    got = utils.random_affiliation((4, 3, 7), torch.device('cpu')).numpy()
+    after = np.random.uniform()
+    np.random.seed(3)
+    want = np.random.uniform(size=(4, 3, 7))
+    want /= np.einsum('...kn->...n', want)[..., None, :]
+    assert np.array_equal(got, want) and after == np.random.uniform()
+    np.random.seed(5)
+    with utils.random_init('device'):
+        dev = utils.random_affiliation((2, 3, 5), torch.device('cpu'))
+    assert dev.shape == (2, 3, 5) and torch.allclose(dev.sum(-2), torch.ones(2, 5, dtype=torch.float64))
+    np.random.seed(5)
+    first = np.random.uniform()
+    np.random.seed(5)
+    utils.set_random_init('device')
+    try:
+        utils.random_affiliation((2, 3, 5), torch.device('cpu'))
+    finally:
+        utils.set_random_init('numpy')
+    assert np.random.uniform() == first   # the NumPy stream was not consumed
