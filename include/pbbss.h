@@ -730,6 +730,13 @@ int pbbss_split_error(pbbss_handle_t h, int* out_flag);
  * aborted launch cannot corrupt the next split launch of the handle.  (New in this library; the
  * reference has no inter-process state to reset.) */
 int pbbss_split_reset(pbbss_handle_t h);
+/* Test knob: the number of polls after which a bounded inter-workgroup wait (split groups,
+ * cooperative shared-weight kernel, DHTV teams) gives up; 0 restores the defaults (seconds).
+ * A tiny value makes the waits run out although the peers ARE co-resident, i.e. it provokes the
+ * real time-out path (status poison + pbbss_split_error, DHTV status) that the Python layer
+ * answers with a repeat on a path without inter-workgroup waits.  The DHTV part is a device
+ * global: it applies to every handle of the process on this device. */
+int pbbss_set_spin_limit(pbbss_handle_t h, unsigned polls);
 /* Development aid: device buffer of 64 uint64 receiving per-phase shader-cycle sums
  * of the EM kernel ([wave 0..3][phase 0..7]); only written by library builds made
  * with -DPBBSS_PHASE_PROFILE (`make prof`), ignored otherwise.  NULL disables. */

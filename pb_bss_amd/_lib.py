@@ -49,7 +49,7 @@ EXPORTS = (
     'pbbss_apply_beamforming_vector', 'pbbss_set_timing',
     'pbbss_last_kernel_ms', 'pbbss_kernel_ms_lagged', 'pbbss_set_phase_profile',
     'pbbss_dhtv_calculate_mapping', 'pbbss_apply_mapping', 'pbbss_cwmm_fit',
-    'pbbss_wmwf', 'pbbss_set_split_tail', 'pbbss_split_error', 'pbbss_split_reset',
+    'pbbss_wmwf', 'pbbss_set_split_tail', 'pbbss_split_error', 'pbbss_split_reset', 'pbbss_set_spin_limit',
     'pbbss_embed_log_pdf', 'pbbss_embed_fit', 'pbbss_vmfmm_fit', 'pbbss_joint_fit',
     'pbbss_lcmv', 'pbbss_phase_correction', 'pbbss_snr_postfilter',
     'pbbss_distortionless_normalization', 'pbbss_zero_degree_normalization',
@@ -165,6 +165,7 @@ def load():
         lib.pbbss_set_dhtv_team.argtypes = [vp, i32]
         lib.pbbss_split_error.argtypes = [vp, ctypes.POINTER(ctypes.c_int)]
         lib.pbbss_split_reset.argtypes = [vp]
+        lib.pbbss_set_spin_limit.argtypes = [vp, ctypes.c_uint]
         lib.pbbss_stft_num_frames.argtypes = [i64, i32, i32, i32, i32, i32]
         lib.pbbss_stft.argtypes = [vp, vp, i32, i64, i64, i32, i32, i32, vp, i32, i32, i32, i32, vp, vp]
         lib.pbbss_istft.argtypes = [vp, vp, i32, i64, i32, i32, i32, i32, vp, i32, vp, i64, vp]

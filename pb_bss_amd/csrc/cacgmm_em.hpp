@@ -77,6 +77,8 @@ struct EmArgs {
   int main_grid;
   unsigned lds_given;  // dynamic LDS bytes of the launch (checked by the debug build only)
   unsigned xbuf_given; // bytes of the exchange buffer behind xcount (debug build)
+  unsigned spin_limit; // polls of a bounded inter-workgroup wait before it gives up (0: default;
+                       // pbbss_set_spin_limit, a test knob that provokes REAL time-outs)
   // ---- weights shared across problems (run_shared: weight_mode PBBSS_WEIGHT_SHARED_*) ----
   int wgroup;          // problems (frequency bins) that share one set of mixture weights
   double* gsum;        // SHARED_K : [2][B][K]     masked class sums of every problem
@@ -1467,7 +1469,7 @@ struct EmKernel {
       unsigned spins = 0;
       while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
         __builtin_amdgcn_s_sleep(1);
-        if (++spins > kSpinLimit) {
+        if (++spins > (a.spin_limit ? a.spin_limit : kSpinLimit)) {
           split_timeout(a);
           break;
         }
@@ -1694,7 +1696,7 @@ struct EmKernel {
       unsigned spins = 0;
       while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
         __builtin_amdgcn_s_sleep(1);
-        if (++spins > kSpinLimit) {
+        if (++spins > (a.spin_limit ? a.spin_limit : kSpinLimit)) {
           split_timeout(a);
           break;
         }
@@ -1880,7 +1882,7 @@ struct EmKernel {
     while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
       __builtin_amdgcn_s_sleep(1);
       if ((spins & 4095u) == 0u && split_failed(a)) break;
-      if (++spins > kSharedSpinLimit) {
+      if (++spins > (a.spin_limit ? a.spin_limit : kSharedSpinLimit)) {
         split_timeout(a);
         break;
       }

@@ -216,6 +216,7 @@ PBBSS_API int pbbss_create(pbbss_handle_t* out, int device_id) {
   if (const char* p = getenv("PBBSS_SPLIT_PRIO")) h->cfg.split_prio = h->cfg.split_prio32 = atoi(p);
   h->split_epoch = 1;
   h->cfg.split_epoch = &h->split_epoch;
+  h->cfg.spin_limit = 0;
   h->cfg.ev_t0 = nullptr;
   h->cfg.ev_t1 = nullptr;
   if (const char* w = getenv("PBBSS_SPLIT_WINDOW")) {
@@ -427,6 +428,13 @@ PBBSS_API int pbbss_set_dhtv_team(pbbss_handle_t h, int workgroups_per_utterance
     return PBBSS_ERR_INVALID_ARG;
   h->dhtv_team = workgroups_per_utterance;
   return PBBSS_OK;
+}
+
+PBBSS_API int pbbss_set_spin_limit(pbbss_handle_t h, unsigned polls) {
+  DeviceGuard device_guard(h);
+  if (!h) return PBBSS_ERR_INVALID_ARG;
+  h->cfg.spin_limit = polls;
+  return pbbss::dhtv_set_spin_limit(polls);  // the DHTV team kernels read a device global
 }
 
 PBBSS_API int pbbss_split_error(pbbss_handle_t h, int* out_flag) {

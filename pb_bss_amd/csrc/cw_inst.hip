@@ -55,6 +55,7 @@ static int cw_launch_split(WatsonArgs wa, int64_t b_first, int r, const EmLaunch
   a.b_first = b_first;
   a.xcount = reinterpret_cast<unsigned*>(cfg.xbuf);
   a.xerror = reinterpret_cast<int*>(cfg.xbuf + 128);
+  a.spin_limit = cfg.spin_limit;
   a.xslab = reinterpret_cast<double*>(cfg.xbuf + head);
   if (hipStreamWaitEvent(cfg.side_stream, cfg.ev_fork, 0) != hipSuccess) return PBBSS_ERR_HIP;
   a.xepoch = next_split_epoch(cfg);

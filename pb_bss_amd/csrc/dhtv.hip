@@ -312,6 +312,8 @@ __device__ __forceinline__ void st_sc1(int32_t* p, int v) {
 }
 
 constexpr unsigned kTeamSpinLimit = 20000000u;
+// test knob (pbbss_set_spin_limit): polls before a team barrier gives up; 0 = kTeamSpinLimit
+__device__ unsigned g_team_spin_limit = 0u;
 
 // ctrl: [0] barrier counter, [1] error word, [2], [3] "changed" flags by iteration parity
 __device__ __forceinline__ void team_barrier(unsigned* ctrl, unsigned& target, int G, int tid) {
@@ -328,7 +330,7 @@ __device__ __forceinline__ void team_barrier(unsigned* ctrl, unsigned& target, i
       if ((spins & 1023u) == 1023u &&
           __hip_atomic_load(ctrl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)
         break;
-      if (++spins > kTeamSpinLimit) {
+      if (++spins > (g_team_spin_limit ? g_team_spin_limit : kTeamSpinLimit)) {
         __hip_atomic_store(ctrl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         break;
       }
@@ -1359,6 +1361,12 @@ int launch_apply_mapping(const double* mask, const int32_t* mapping, int64_t U, 
   hipLaunchKernelGGL(apply_mapping_kernel, dim3((unsigned)rows), dim3(256), 0, s, mask, mapping, K,
                      F, T, out);
   return hipGetLastError() == hipSuccess ? PBBSS_OK : PBBSS_ERR_HIP;
+}
+
+int dhtv_set_spin_limit(unsigned limit) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_team_spin_limit), &limit, sizeof(limit)) == hipSuccess
+             ? PBBSS_OK
+             : PBBSS_ERR_HIP;
 }
 
 }  // namespace pbbss

@@ -22,4 +22,6 @@ int launch_pa_pair(const double* mask, const double* ref, int64_t U, int K, int6
 int launch_pa_compose(int32_t* mapping, int64_t U, int K, int64_t F, hipStream_t s);
 int launch_pa_assign(const double* scores, int64_t N, int K, int optimal, int32_t* mapping,
                      int32_t* status, hipStream_t s);
+// test knob: polls of a team barrier before it gives up (0: default)
+int dhtv_set_spin_limit(unsigned limit);
 }  // namespace pbbss

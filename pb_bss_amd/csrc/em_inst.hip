@@ -80,6 +80,7 @@ static int launch_split(EmArgs a, int64_t b_first, int r, const EmLaunchCfg& cfg
   a.b_first = b_first;
   a.xcount = reinterpret_cast<unsigned*>(cfg.xbuf);
   a.xerror = reinterpret_cast<int*>(cfg.xbuf + 128);
+  a.spin_limit = cfg.spin_limit;
   a.xslab = reinterpret_cast<double*>(cfg.xbuf + head);
   // fork: everything enqueued on `stream` before the event (the inputs) precedes the side stream
   if (hipStreamWaitEvent(cfg.side_stream, cfg.ev_fork, 0) != hipSuccess) return PBBSS_ERR_HIP;

@@ -26,6 +26,7 @@ struct EmLaunchCfg {
   int split_prio;    // s_setprio level of the split waves (float64 kernels)
   int split_prio32;  // ... of the packed-FP32 kernel's member workgroups
   int* split_epoch;  // host counter stamping the launches of the split protocol
+  unsigned spin_limit;  // EmArgs::spin_limit of every launch (0: the kernels' defaults)
   // kernel timing (pbbss_set_timing): start / stop events attached to the DISPATCH of the EM kernel
   // itself (hipExtLaunchKernelGGL: timestamps of the kernel's own completion signal) instead of
   // two hipEventRecord packets around the call -- those cost ~30 us of queue time per step

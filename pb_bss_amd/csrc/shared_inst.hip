@@ -43,7 +43,8 @@ static int launch_shared_one(EmArgs a, const EmLaunchCfg& cfg, hipStream_t strea
   a.gsum = reinterpret_cast<double*>(ws + head);
   a.gaff = kt ? reinterpret_cast<double*>(ws + head + n_gsum) : nullptr;
   a.gw = kt ? reinterpret_cast<double*>(ws + head + n_gsum + n_gaff) : nullptr;
-  a.xerror = reinterpret_cast<int*>(cfg.xbuf + 128);  // [0] this call, [16] sticky (pbbss_split_error)
+  a.xerror = reinterpret_cast<int*>(cfg.xbuf + 128);
+  a.spin_limit = cfg.spin_limit;  // [0] this call, [16] sticky (pbbss_split_error)
   if (hipMemsetAsync(ws, 0, head, stream) != hipSuccess) return PBBSS_ERR_HIP;
   if (hipMemsetAsync(cfg.xbuf + 128, 0, 64, stream) != hipSuccess) return PBBSS_ERR_HIP;
   a.wb = a.wk = a.wt = 0;

@@ -578,6 +578,13 @@ def split_tail(device_index=None):
     return _SPLIT_TAIL.get(_handle_key(device_index), True)
 
 
+def set_spin_limit(polls, device_index=None):
+    """pbbss_set_spin_limit (test knob): polls before a bounded inter-workgroup wait gives up;
+    0 = defaults.  A tiny value provokes real time-outs of the split / team protocols."""
+    _lib.check(_lib.load().pbbss_set_spin_limit(_lib.handle(device_index), int(polls)),
+               'set_spin_limit')
+
+
 def split_reset(device_index=None):
     """pbbss_split_reset: consume a reported time-out (re-zero the protocol counters and the
     sticky flag of split_error) after the device has drained."""

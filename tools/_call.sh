@@ -1,11 +1,11 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_cwmm.py tests/test_gpu_golden.py tests/test_gpu_properties.py tests/test_gpu_pipeline.py -m gpu -x -q 2>&1 | tail -12 > gpurun_out/r04g_pytest.log
-L=gpurun_out/r04g_cwmm.log
+timeout 600 python -m pytest tests/test_gpu_timeouts.py -m gpu -q 2>&1 | tail -40 > gpurun_out/r04h_timeouts.log
+timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -8 > gpurun_out/r04h_pytest.log
+timeout 600 python bench.py > gpurun_out/r04h_bench.json 2> gpurun_out/r04h_bench.err
+L=gpurun_out/r04h_tail.log
 : > $L
-timeout 200 python tools/bench_cwmm.py 2>&1 | grep -v amdgpu >> $L
-timeout 300 python bench.py --workload config4 --steps 10 --warmup 2 --cpu-iters 0 2>/dev/null | python -c "
+for w in 64 128 256; do echo "== PBBSS_SPLIT_WINDOW=$w" >> $L; PBBSS_SPLIT_WINDOW=$w timeout 200 python bench.py --steps 30 --warmup 5 --cpu-iters 0 --check-bins 0 --config3 off --configs45 off --f32 off --extras off --sustained-s 0 2>/dev/null | python -c "
 import json,sys
-b=json.loads(sys.stdin.read().strip().splitlines()[-1])
-print('config4 chain', b['value'], 'em_only', b['em_only'], 'verify', b['verify']['mask_max_abs_err'], b['verify']['ok'])" >> $L
-cat gpurun_out/r04g_pytest.log; cat $L
+b=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(b['value'], b['ms_per_step'], b['roofline']['kernel_ms'])" >> $L; done
+cat gpurun_out/r04h_timeouts.log; cat gpurun_out/r04h_pytest.log; tail -c 300 gpurun_out/r04h_bench.err; cat $L
