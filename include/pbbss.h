@@ -611,6 +611,21 @@ int pbbss_phase_correction(pbbss_handle_t h, const void* vector, int64_t lead,
 int pbbss_snr_postfilter(pbbss_handle_t h, const void* w, const void* target,
                          const void* noise, int64_t F, int D, void* out,
                          void* stream);
+/* get_optimal_reference_channel (:601-624): w_mat, target, noise (F,D,D) c128 ->    */
+/* num[f,r] = w_r^H T w_r, den[f,r] = w_r^H N w_r (F,D) c128 for every column r; the  */
+/* caller sums over f (all-reduces under bin sharding) and takes the argmax.        */
+int pbbss_reference_channel_terms(pbbss_handle_t h, const void* w_mat, const void* target,
+                                  const void* noise, int64_t F, int D, void* out_num,
+                                  void* out_den, void* stream);
+/* rank-one approximation a a^H tr(C) / tr(a a^H) (beamformer_wrapper.py:18-25,     */
+/* :61-69): covariance (N,D,D), vector (N,D) c128 -> out (N,D,D).                   */
+int pbbss_rank_one_approximation(pbbss_handle_t h, const void* covariance,
+                                 const void* vector, int64_t N, int D, void* out,
+                                 void* stream);
+/* y = M x per problem (the ATF estimate Phi_nn w_gev, beamformer_wrapper.py:28-48): */
+/* matrix (N,D,D), vector (N,D) c128 -> out (N,D).                                  */
+int pbbss_matvec(pbbss_handle_t h, const void* matrix, const void* vector, int64_t N, int D,
+                 void* out, void* stream);
 /* distortionless_normalization (:491-499) -> out (F,D).                           */
 int pbbss_distortionless_normalization(pbbss_handle_t h, const void* w,
                                        const void* atf, const void* noise,

@@ -52,6 +52,7 @@ EXPORTS = (
     'pbbss_wmwf', 'pbbss_set_split_tail', 'pbbss_split_error', 'pbbss_split_reset', 'pbbss_set_spin_limit',
     'pbbss_embed_log_pdf', 'pbbss_embed_fit', 'pbbss_vmfmm_fit', 'pbbss_joint_fit',
     'pbbss_lcmv', 'pbbss_phase_correction', 'pbbss_snr_postfilter',
+    'pbbss_reference_channel_terms', 'pbbss_rank_one_approximation', 'pbbss_matvec',
     'pbbss_distortionless_normalization', 'pbbss_zero_degree_normalization',
     'pbbss_condition_covariance', 'pbbss_apply_online_beamforming_vector',
     'pbbss_set_dhtv_team', 'pbbss_stft_num_frames', 'pbbss_stft', 'pbbss_istft',
@@ -227,6 +228,9 @@ def load():
         lib.pbbss_lcmv.argtypes = [vp, vp, vp, vp, i64, i32, i32, vp, vp, vp]
         lib.pbbss_phase_correction.argtypes = [vp, vp, i64, i64, i32, i32, i32, vp, vp, vp]
         lib.pbbss_snr_postfilter.argtypes = [vp, vp, vp, vp, i64, i32, vp, vp]
+        lib.pbbss_reference_channel_terms.argtypes = [vp, vp, vp, vp, i64, i32, vp, vp, vp]
+        lib.pbbss_rank_one_approximation.argtypes = [vp, vp, vp, i64, i32, vp, vp]
+        lib.pbbss_matvec.argtypes = [vp, vp, vp, i64, i32, vp, vp]
         lib.pbbss_distortionless_normalization.argtypes = [vp, vp, vp, vp, i64, i32, vp, vp]
         lib.pbbss_zero_degree_normalization.argtypes = [vp, vp, i64, i32, i32, vp, vp]
         lib.pbbss_condition_covariance.argtypes = [vp, vp, i64, i32, dbl, vp, vp]

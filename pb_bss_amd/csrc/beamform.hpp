@@ -29,6 +29,10 @@ int launch_lcmv(const double* atf, const double* response, const double* noise, 
                 int K, double* w, int32_t* st, hipStream_t s);
 int launch_phase_correction(const double* v, int64_t lead, int64_t rest, int F, int D, int two_d,
                             double* scratch_u, double* out, hipStream_t s);
+int launch_refch_terms(const double* wm, const double* tp, const double* nn, int64_t F, int D,
+                       double* num, double* den, hipStream_t s);
+int launch_rank_one(const double* cov, const double* a, int64_t N, int D, double* out, hipStream_t s);
+int launch_matvec(const double* m, const double* x, int64_t N, int D, double* y, hipStream_t s);
 int launch_bf_quadratic(int mode, const double* w, const double* m1, const double* m2,
                         const double* atf, int64_t F, int D, double* out, hipStream_t s);
 int launch_zero_degree(const double* v, int64_t N, int D, int ref, double* out, hipStream_t s);

@@ -237,6 +237,77 @@ __global__ void bf_quadratic_kernel(int mode, const double* w, const double* m1,
 }
 
 // zero_degree_normalization: v * exp(-j angle(v[..., ref]))              (beamformer.py:512-514)
+// ------------------------------------------------------------------ reference channel, rank one
+// get_optimal_reference_channel (beamformer.py:601-624): per bin and candidate channel r the
+// two quadratic forms  w_r^H T w_r  and  w_r^H N w_r  of the r-th COLUMN of the filter matrix.
+// One thread per (bin, r); w_mat (F,D,D), T, N (F,D,D) c128 -> num, den (F,D) c128.
+__global__ void refch_terms_kernel(const double* wm, const double* tp, const double* nn, int64_t F,
+                                   int D, double* num, double* den) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= F * D) return;
+  const int64_t f = i / D;
+  const int r = (int)(i - f * D);
+  const double* W = wm + (size_t)f * D * D * 2;
+  const double* T = tp + (size_t)f * D * D * 2;
+  const double* N = nn + (size_t)f * D * D * 2;
+  Cx sn{0.0, 0.0}, sd{0.0, 0.0};
+  for (int a = 0; a < D; ++a) {
+    const Cx wa = ld(W, (size_t)a * D + r);
+    Cx rt{0.0, 0.0}, rn{0.0, 0.0};
+    for (int b = 0; b < D; ++b) {
+      const Cx wb = ld(W, (size_t)b * D + r);
+      const Cx pt = cmul(ld(T, (size_t)a * D + b), wb), pn = cmul(ld(N, (size_t)a * D + b), wb);
+      rt.re += pt.re;
+      rt.im += pt.im;
+      rn.re += pn.re;
+      rn.im += pn.im;
+    }
+    const Cx ct = cmulc(wa, rt), cn = cmulc(wa, rn);
+    sn.re += ct.re;
+    sn.im += ct.im;
+    sd.re += cn.re;
+    sd.im += cn.im;
+  }
+  st(num, (size_t)i, sn);
+  st(den, (size_t)i, sd);
+}
+
+// rank-one approximation scaled to the trace of the covariance (beamformer_wrapper.py:18-25,
+// :61-69):  out = a a^H * tr(C) / tr(a a^H).  One thread per (problem, i, j).
+__global__ void rank_one_kernel(const double* cov, const double* a, int64_t N, int D, double* out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * D * D) return;
+  const int64_t n = i / (D * D);
+  const int ij = (int)(i - n * D * D), r = ij / D, c = ij - r * D;
+  Cx trc{0.0, 0.0};
+  double tra = 0.0;
+  for (int d = 0; d < D; ++d) {
+    const Cx cd = ld(cov, ((size_t)n * D + d) * D + d), ad = ld(a, (size_t)n * D + d);
+    trc.re += cd.re;
+    trc.im += cd.im;
+    tra += ad.re * ad.re + ad.im * ad.im;
+  }
+  const Cx scale = cdiv(trc, Cx{tra, 0.0});
+  const Cx ar = ld(a, (size_t)n * D + r), ac = ld(a, (size_t)n * D + c);
+  const Cx outer{ar.re * ac.re + ar.im * ac.im, ar.im * ac.re - ar.re * ac.im};  // a_r conj(a_c)
+  st(out, (size_t)i, cmul(scale, outer));
+}
+
+// y = M x per problem (the ATF estimate Phi_nn w_gev, beamformer_wrapper.py:28-48).
+__global__ void matvec_kernel(const double* m, const double* x, int64_t N, int D, double* y) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * D) return;
+  const int64_t n = i / D;
+  const int r = (int)(i - n * D);
+  Cx acc{0.0, 0.0};
+  for (int c = 0; c < D; ++c) {
+    const Cx p = cmul(ld(m, ((size_t)n * D + r) * D + c), ld(x, (size_t)n * D + c));
+    acc.re += p.re;
+    acc.im += p.im;
+  }
+  st(y, (size_t)i, acc);
+}
+
 __global__ void zero_degree_kernel(const double* v, int64_t N, int D, int ref, double* out) {
   const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
@@ -335,6 +406,23 @@ int launch_bf_quadratic(int mode, const double* w, const double* m1, const doubl
                         const double* atf, int64_t F, int D, double* out, hipStream_t s) {
   hipLaunchKernelGGL(bf_quadratic_kernel, dim3(blocks(F, 64)), dim3(64), 0, s, mode, w, m1, m2,
                      atf, F, D, out);
+  return ok_or_hip();
+}
+
+int launch_refch_terms(const double* wm, const double* tp, const double* nn, int64_t F, int D,
+                       double* num, double* den, hipStream_t s) {
+  hipLaunchKernelGGL(refch_terms_kernel, dim3(blocks(F * D, 256)), dim3(256), 0, s, wm, tp, nn, F, D,
+                     num, den);
+  return ok_or_hip();
+}
+
+int launch_rank_one(const double* cov, const double* a, int64_t N, int D, double* out, hipStream_t s) {
+  hipLaunchKernelGGL(rank_one_kernel, dim3(blocks(N * D * D, 256)), dim3(256), 0, s, cov, a, N, D, out);
+  return ok_or_hip();
+}
+
+int launch_matvec(const double* m, const double* x, int64_t N, int D, double* y, hipStream_t s) {
+  hipLaunchKernelGGL(matvec_kernel, dim3(blocks(N * D, 256)), dim3(256), 0, s, m, x, N, D, y);
   return ok_or_hip();
 }
 

@@ -1469,7 +1469,7 @@ struct EmKernel {
       unsigned spins = 0;
       while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
         __builtin_amdgcn_s_sleep(1);
-        if (++spins > (a.spin_limit ? a.spin_limit : kSpinLimit)) {
+        if (++spins >= (a.spin_limit ? a.spin_limit : kSpinLimit)) {
           split_timeout(a);
           break;
         }
@@ -1696,7 +1696,7 @@ struct EmKernel {
       unsigned spins = 0;
       while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
         __builtin_amdgcn_s_sleep(1);
-        if (++spins > (a.spin_limit ? a.spin_limit : kSpinLimit)) {
+        if (++spins >= (a.spin_limit ? a.spin_limit : kSpinLimit)) {
           split_timeout(a);
           break;
         }
@@ -1882,7 +1882,7 @@ struct EmKernel {
     while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
       __builtin_amdgcn_s_sleep(1);
       if ((spins & 4095u) == 0u && split_failed(a)) break;
-      if (++spins > (a.spin_limit ? a.spin_limit : kSharedSpinLimit)) {
+      if (++spins >= (a.spin_limit ? a.spin_limit : kSharedSpinLimit)) {
         split_timeout(a);
         break;
       }

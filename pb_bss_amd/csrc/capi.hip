@@ -3,6 +3,7 @@
 #include "pbbss.h"
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
 #include "beamform.hpp"
 #include "dhtv.hpp"
 #include "embed.hpp"
@@ -38,6 +39,8 @@ struct pbbss_handle_s {
   static constexpr int kTimingRing = 4;
   hipEvent_t ring0[kTimingRing], ring1[kTimingRing];
   unsigned ring_seq;  // timed regions started so far
+  hipEvent_t gate_ev; // completion of this handle's last launch with inter-workgroup waits
+  int gate_dev;       // device index of the residency gate this handle takes part in (-1: none)
 };
 
 namespace {
@@ -151,6 +154,91 @@ struct TimedRegion {
   }
   ~TimedRegion() {
     if (h->timing) (void)hipEventRecord(h->ring1[slot], s);
+  }
+};
+// ---------------------------------------------------------------------------------------------
+// Residency gate (round 4).  Kernels whose workgroups WAIT for each other -- split groups of a
+// remainder bin, the cooperative shared-weight kernel, in-grid members, DHTV teams -- need their
+// peers on the chip at the same time.  Two such kernels launched concurrently from two handles
+// (host threads / streams) of one process can starve each other: each holds compute-unit slots
+// while it waits for peers that only fit once the other one lets go (round 3 measured the
+// cooperative kernel "not served" in 2-16 % of the fits that ran beside a packed-FP32 fit,
+// profiles/r03_i_coop_contention_probe.txt; the bounded waits turn the stall into a repeat, never
+// a hang).  The gate removes the situation instead of riding it out: per device, every launch of
+// that kind first waits (stream-ordered, hipStreamWaitEvent) for the completion event of the
+// previous one -- whichever handle issued it -- and leaves its own completion event behind.  With
+// a single handle on the device the gate does nothing at all (stream order already serialises its
+// launches); PBBSS_RESIDENCY_GATE=0 switches it off.
+struct ResidencyGate {
+  static constexpr int kMaxDev = 64;
+  struct State {
+    std::mutex mu;
+    hipEvent_t last = nullptr;        // completion of the most recent gated launch on this device
+    pbbss_handle_t owner = nullptr;   // handle whose gate_ev `last` is
+    hipStream_t owner_stream = nullptr;
+    int handles = 0;                  // live handles on this device
+  };
+  static State& state(int dev) {
+    static State st[kMaxDev];
+    return st[dev < 0 || dev >= kMaxDev ? 0 : dev];
+  }
+  static bool enabled() {
+    static const bool on = [] {
+      const char* v = getenv("PBBSS_RESIDENCY_GATE");
+      return !(v && v[0] == '0');
+    }();
+    return on;
+  }
+  pbbss_handle_t h;
+  hipStream_t s;
+  bool active;
+  ResidencyGate(pbbss_handle_t h_, hipStream_t s_) : h(h_), s(s_), active(false) {
+    if (!h || h->gate_dev < 0 || !enabled()) return;
+    State& st = state(h->gate_dev);
+    std::lock_guard<std::mutex> g(st.mu);
+    if (st.handles < 2) return;  // nobody to collide with
+    active = true;
+    if (st.last && !(st.owner == h && st.owner_stream == s))
+      (void)hipStreamWaitEvent(s, st.last, 0);
+  }
+  ~ResidencyGate() {
+    if (!active) return;
+    State& st = state(h->gate_dev);
+    std::lock_guard<std::mutex> g(st.mu);
+    if (hipEventRecord(h->gate_ev, s) == hipSuccess) {
+      st.last = h->gate_ev;
+      st.owner = h;
+      st.owner_stream = s;
+    }
+  }
+  static void on_create(pbbss_handle_t h, int dev) {
+    h->gate_dev = -1;
+    h->gate_ev = nullptr;
+    if (dev < 0 || dev >= kMaxDev) return;
+    if (hipEventCreateWithFlags(&h->gate_ev, hipEventDisableTiming) != hipSuccess) {
+      h->gate_ev = nullptr;
+      return;
+    }
+    h->gate_dev = dev;
+    State& st = state(dev);
+    std::lock_guard<std::mutex> g(st.mu);
+    // the gate becomes active with the second handle: whatever the first one has in flight was
+    // launched without leaving an event behind -- let it drain once
+    if (++st.handles == 2) (void)hipDeviceSynchronize();
+  }
+  static void on_destroy(pbbss_handle_t h) {
+    if (h->gate_dev < 0) return;
+    State& st = state(h->gate_dev);
+    {
+      std::lock_guard<std::mutex> g(st.mu);
+      --st.handles;
+      if (st.owner == h) {
+        st.last = nullptr;
+        st.owner = nullptr;
+        st.owner_stream = nullptr;
+      }
+    }
+    if (h->gate_ev) (void)hipEventDestroy(h->gate_ev);
   }
 };
 }  // namespace
@@ -274,6 +362,7 @@ PBBSS_API int pbbss_create(pbbss_handle_t* out, int device_id) {
       return PBBSS_ERR_HIP;
     }
   }
+  ResidencyGate::on_create(h, device_id);
   *out = h;
   return PBBSS_OK;
 }
@@ -293,6 +382,7 @@ PBBSS_API int pbbss_destroy(pbbss_handle_t h) {
   if (h->cfg.side_stream) (void)hipStreamDestroy(h->cfg.side_stream);
   (void)hipEventDestroy(h->cfg.ev_fork);
   (void)hipEventDestroy(h->cfg.ev_join);
+  ResidencyGate::on_destroy(h);
   delete h;
   return PBBSS_OK;
 }
@@ -504,6 +594,7 @@ PBBSS_API int pbbss_cacgmm_fit(pbbss_handle_t h, const void* y, int64_t B, int T
                                double* out_weight, int32_t* out_status, double* out_affiliation,
                                double* out_quadratic_form, void* stream) {
   DeviceGuard device_guard(h);
+  ResidencyGate residency_gate(h, as_stream(stream));  // see ResidencyGate
   if (!h || !y || !o || B <= 0 || T <= 0) return PBBSS_ERR_INVALID_ARG;
   if (o->iterations <= 0) return PBBSS_ERR_INVALID_ARG;  // cacgmm.py:200
   const bool has_gamma = gamma0 != nullptr;
@@ -715,6 +806,7 @@ PBBSS_API int pbbss_cacgmm_fit_shared(pbbss_handle_t h, const void* y, int64_t B
                                       int32_t* out_status, double* out_affiliation,
                                       double* out_quadratic_form, void* stream) {
   DeviceGuard device_guard(h);
+  ResidencyGate residency_gate(h, as_stream(stream));  // see ResidencyGate
   if (!h || !y || !o || B <= 0 || T <= 0 || group <= 0 || B % group != 0)
     return PBBSS_ERR_INVALID_ARG;
   if (o->iterations <= 0) return PBBSS_ERR_INVALID_ARG;  // cacgmm.py:200
@@ -980,6 +1072,7 @@ PBBSS_API int pbbss_dhtv_calculate_mapping(pbbss_handle_t h, const double* mask,
                                            int metric, double* scratch, int32_t* out_mapping,
                                            int32_t* out_status, void* stream) {
   DeviceGuard device_guard(h);
+  ResidencyGate residency_gate(h, as_stream(stream));  // see ResidencyGate
   if (!h || !mask || !plan || !scratch || !out_mapping || !out_status) return PBBSS_ERR_INVALID_ARG;
   if (U <= 0 || F <= 0 || T <= 0 || P <= 0) return PBBSS_ERR_INVALID_ARG;
   return pbbss::launch_dhtv(mask, U, K, F, T, plan, P, optimal, metric, scratch, out_mapping, out_status,
@@ -1036,6 +1129,7 @@ PBBSS_API int pbbss_cwmm_fit(pbbss_handle_t h, const void* y, int64_t B, int T, 
                              double* out_concentration, double* out_weight, int32_t* out_status,
                              double* out_affiliation, double* out_log_pdf, void* stream) {
   DeviceGuard device_guard(h);
+  ResidencyGate residency_gate(h, as_stream(stream));  // see ResidencyGate
   if (!h || !y || !o || B <= 0 || T <= 0) return PBBSS_ERR_INVALID_ARG;
   if (o->iterations < 0) return PBBSS_ERR_INVALID_ARG;
   const bool has_gamma = gamma0 != nullptr;
@@ -1497,6 +1591,16 @@ PBBSS_API int pbbss_gmm_fit(pbbss_handle_t h, const void* y, int64_t B, int64_t 
                            out_covariance, out_weight, out_affiliation, out_log_pdf, stream);
 }
 
+// dynamic LDS of the joint kernels for (D, K, T): EmKernel<D,K,YS,false>::lds_bytes(T) + the
+// 64 bytes of the inline aligner's class permutation, written out for a run-time D
+static size_t joint_kernel_lds_bytes(int D, int K, int T, int c128) {
+  const size_t DP = (size_t)(D + 1) / 2, Tp = (size_t)((T + 1) & ~1), NA = (size_t)D * D;
+  const size_t frames = DP * Tp * 4 * (c128 ? 8 : 4) + Tp * 8 + (size_t)K * Tp * 8;
+  const size_t small = 2 * (size_t)K * NA * 8 + (size_t)K * 8 * 4 + 4 * (size_t)K * 8 +
+                       (size_t)K * 4 * 2 + 16;
+  return ((frames + small + 15) & ~(size_t)15) + 64;
+}
+
 // helper blocks of the in-launch spectral finalize of the rotated joint loop (embed_dev.hpp)
 static constexpr int kJointFinHelpers = 32;
 static int joint_fin_helpers() {  // development knob: helper blocks actually launched (<= 32)
@@ -1517,11 +1621,17 @@ PBBSS_API int pbbss_joint_fit(pbbss_handle_t h, const void* observation, const v
                               double* out_weight, double* out_mean, double* out_scale,
                               int32_t* out_status, double* out_affiliation, void* stream) {
   DeviceGuard device_guard(h);
+  ResidencyGate residency_gate(h, as_stream(stream));  // see ResidencyGate
   if (!h || !observation || !embedding || !o || F <= 0 || T <= 0) return PBBSS_ERR_INVALID_ARG;
   // 9 <= D <= 32 or 7..8 classes: the spatial half runs on the generic-size kernels
   // (generic.hip), one E-step and one M-step launch group per iteration around the same spectral
   // kernels
-  const bool gen = D > 8 || K > 6;
+  // ... and so does an utterance too long for the LDS-resident joint kernels (no HBM-scratch
+  // variant of those): the generic kernels stream the frames (round 4; the reference has no
+  // length limit)
+  const size_t joint_lds =
+      D <= 8 ? joint_kernel_lds_bytes(D, K, T, o->obs_is_c128) : (size_t)0;
+  const bool gen = D > 8 || K > 6 || joint_lds > h->cfg.lds_limit;
   if (D < 2 || K < 1 || K > pbbss::kEmbedMaxK || (gen && !pbbss::gen_supported(D, K)))
     return PBBSS_ERR_UNSUPPORTED;
   if (gen && (F > 65535 || (o->inline_pa && K > 6))) return PBBSS_ERR_UNSUPPORTED;
@@ -1934,6 +2044,38 @@ PBBSS_API int pbbss_snr_postfilter(pbbss_handle_t h, const void* w, const void* 
                                     static_cast<const double*>(target),
                                     static_cast<const double*>(noise), nullptr, F, D,
                                     static_cast<double*>(out), as_stream(stream));
+}
+
+PBBSS_API int pbbss_reference_channel_terms(pbbss_handle_t h, const void* w_mat, const void* target,
+                                            const void* noise, int64_t F, int D, void* out_num,
+                                            void* out_den, void* stream) {
+  DeviceGuard device_guard(h);
+  if (!h || !w_mat || !target || !noise || !out_num || !out_den || F <= 0 || D <= 0)
+    return PBBSS_ERR_INVALID_ARG;
+  return pbbss::launch_refch_terms(static_cast<const double*>(w_mat),
+                                   static_cast<const double*>(target),
+                                   static_cast<const double*>(noise), F, D,
+                                   static_cast<double*>(out_num), static_cast<double*>(out_den),
+                                   as_stream(stream));
+}
+
+PBBSS_API int pbbss_rank_one_approximation(pbbss_handle_t h, const void* covariance,
+                                           const void* vector, int64_t N, int D, void* out,
+                                           void* stream) {
+  DeviceGuard device_guard(h);
+  if (!h || !covariance || !vector || !out || N <= 0 || D <= 0) return PBBSS_ERR_INVALID_ARG;
+  return pbbss::launch_rank_one(static_cast<const double*>(covariance),
+                                static_cast<const double*>(vector), N, D,
+                                static_cast<double*>(out), as_stream(stream));
+}
+
+PBBSS_API int pbbss_matvec(pbbss_handle_t h, const void* matrix, const void* vector, int64_t N,
+                           int D, void* out, void* stream) {
+  DeviceGuard device_guard(h);
+  if (!h || !matrix || !vector || !out || N <= 0 || D <= 0) return PBBSS_ERR_INVALID_ARG;
+  return pbbss::launch_matvec(static_cast<const double*>(matrix),
+                              static_cast<const double*>(vector), N, D, static_cast<double*>(out),
+                              as_stream(stream));
 }
 
 PBBSS_API int pbbss_distortionless_normalization(pbbss_handle_t h, const void* w, const void* atf,

@@ -330,7 +330,7 @@ __device__ __forceinline__ void team_barrier(unsigned* ctrl, unsigned& target, i
       if ((spins & 1023u) == 1023u &&
           __hip_atomic_load(ctrl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)
         break;
-      if (++spins > (g_team_spin_limit ? g_team_spin_limit : kTeamSpinLimit)) {
+      if (++spins >= (g_team_spin_limit ? g_team_spin_limit : kTeamSpinLimit)) {
         __hip_atomic_store(ctrl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         break;
       }

@@ -576,10 +576,12 @@ __global__ void __launch_bounds__(kFusedThreads)
   const int ES = E | 1;
   const int S = kFusedThreads / E;
   double* affw = reinterpret_cast<double*>(smraw);   // [R][KW]  gamma * saliency
-  double* red = affw + (size_t)R * KW;               // [S][K][E]
-  double* red2 = red + (size_t)S * K * E;            // [S][K][E]  (Gaussian)
-  double* red0 = red2 + (GAUSS ? (size_t)S * K * E : 0);  // [waves][K]
+  double* red0 = affw + (size_t)R * KW;              // [waves][K]
   TS* tile = reinterpret_cast<TS*>(red0 + (kFusedThreads / kWave) * K);  // [R][ES]
+  // the slot-reduction buffers alias the tile: they are written after the last tile has been
+  // consumed (barrier below).  11.5 KB less LDS per workgroup: three workgroups per CU.
+  double* red = reinterpret_cast<double*>(tile);     // [S][K][E]
+  double* red2 = red + (size_t)S * K * E;            // [S][K][E]  (Gaussian)
   const int c = blockIdx.x;
   const int tid = threadIdx.x;
   const int s = tid / E, d = tid - s * E;
@@ -1555,8 +1557,10 @@ FusedPlan joint_sweep_plan(int64_t N, int E, int K, int y_is_f64, bool gauss) {
   }();
   for (int R : {256, 128, 64}) {
     if (rows_env > 0 && R > rows_env) continue;
-    const size_t lds = ((size_t)R * KW + (gauss ? 2 : 1) * (size_t)S * K * E +
-                        (size_t)(kFusedThreads / kWave) * K) * 8 + (size_t)R * ES * esz;
+    size_t tile_bytes = (size_t)R * ES * esz;
+    const size_t red_bytes = (gauss ? 2 : 1) * (size_t)S * K * E * 8;  // aliases the tile
+    if (tile_bytes < red_bytes) tile_bytes = red_bytes;
+    const size_t lds = ((size_t)R * KW + (size_t)(kFusedThreads / kWave) * K) * 8 + tile_bytes;
     if (lds <= 64 * 1024) {
       p.R = R;
       p.lds = lds;

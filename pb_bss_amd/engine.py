@@ -257,20 +257,28 @@ def cacg_m_step(y, saliency, quadratic_form, *, layout=_lib.LAYOUT_DT,
         B, D, T = y.shape
     K = saliency.shape[1]
     is128 = y.dtype == t.complex128
-    out_vec = t.empty((B, K, D, D), dtype=t.complex128, device=dev)
-    out_val = t.empty((B, K, D), dtype=t.float64, device=dev)
-    out_st = t.zeros((B, K), dtype=t.int32, device=dev)
-    out_cov = t.empty((B, K, D, D), dtype=t.complex128, device=dev) if want_cov else None
-    rc = _lib.load().pbbss_cacg_m_step(
-        _lib.handle(dev.index), _lib.ptr(y), B, T, D, K, _lib.ptr(saliency),
-        _lib.ptr(quadratic_form), int(layout), int(is128),
-        _lib.COVNORM[covariance_norm], float(eigenvalue_floor),
-        _lib.ptr(out_vec), _lib.ptr(out_val), _lib.ptr(out_cov),
-        _lib.ptr(out_st), _lib.stream_ptr(dev.index))
-    _lib.check(rc, f'cacg_m_step(B={B},T={T},D={D},K={K})')
-    if check_status:
-        _status_raise_em(out_st, 'ComplexAngularCentralGaussianTrainer._fit')
-    return out_vec, out_val, out_cov, out_st
+
+    def launch():
+        out_vec = t.empty((B, K, D, D), dtype=t.complex128, device=dev)
+        out_val = t.empty((B, K, D), dtype=t.float64, device=dev)
+        out_st = t.zeros((B, K), dtype=t.int32, device=dev)
+        out_cov = t.empty((B, K, D, D), dtype=t.complex128, device=dev) if want_cov else None
+        rc = _lib.load().pbbss_cacg_m_step(
+            _lib.handle(dev.index), _lib.ptr(y), B, T, D, K, _lib.ptr(saliency),
+            _lib.ptr(quadratic_form), int(layout), int(is128),
+            _lib.COVNORM[covariance_norm], float(eigenvalue_floor),
+            _lib.ptr(out_vec), _lib.ptr(out_val), _lib.ptr(out_cov),
+            _lib.ptr(out_st), _lib.stream_ptr(dev.index))
+        _lib.check(rc, f'cacg_m_step(B={B},T={T},D={D},K={K})')
+        return dict(eigvec=out_vec, eigval=out_val, cov=out_cov, status=out_st)
+
+    # the M-step is ONE iteration of the EM kernel: a remainder bin (2^n + 1 bins) runs as split
+    # groups here too, so the step-wise loop -- the fallback of the cooperative kernel -- needs the
+    # same time-out handling as the fused fit (found by tests/test_gpu_timeouts.py: the fallback
+    # itself raised the reference's finiteness assert when its split groups timed out)
+    r = (_checked_with_split_retry(launch, dev, 'ComplexAngularCentralGaussianTrainer._fit')
+         if check_status else launch())
+    return r['eigvec'], r['eigval'], r['cov'], r['status']
 
 
 def heev(a):
@@ -955,6 +963,43 @@ def snr_postfilter(w, target, noise):
                                           _lib.ptr(target), _lib.ptr(noise), F, D, _lib.ptr(out),
                                           _lib.stream_ptr(w.device.index))
     _lib.check(rc, f'snr_postfilter(F={F},D={D})')
+    return out
+
+
+def reference_channel_terms(w_mat, target, noise):
+    """pbbss_reference_channel_terms.  (F,D,D) c128 x 3 -> num, den (F,D) c128."""
+    t = _t()
+    F, D, _ = w_mat.shape
+    num = t.empty((F, D), dtype=t.complex128, device=w_mat.device)
+    den = t.empty((F, D), dtype=t.complex128, device=w_mat.device)
+    rc = _lib.load().pbbss_reference_channel_terms(
+        _lib.handle(w_mat.device.index), _lib.ptr(w_mat), _lib.ptr(target), _lib.ptr(noise), F, D,
+        _lib.ptr(num), _lib.ptr(den), _lib.stream_ptr(w_mat.device.index))
+    _lib.check(rc, f'reference_channel_terms(F={F},D={D})')
+    return num, den
+
+
+def rank_one_approximation(covariance, vector):
+    """pbbss_rank_one_approximation.  (N,D,D), (N,D) c128 -> (N,D,D)."""
+    t = _t()
+    N, D = vector.shape
+    out = t.empty((N, D, D), dtype=t.complex128, device=vector.device)
+    rc = _lib.load().pbbss_rank_one_approximation(
+        _lib.handle(vector.device.index), _lib.ptr(covariance), _lib.ptr(vector), N, D,
+        _lib.ptr(out), _lib.stream_ptr(vector.device.index))
+    _lib.check(rc, f'rank_one_approximation(N={N},D={D})')
+    return out
+
+
+def matvec(matrix, vector):
+    """pbbss_matvec.  (N,D,D), (N,D) c128 -> (N,D)."""
+    t = _t()
+    N, D = vector.shape
+    out = t.empty((N, D), dtype=t.complex128, device=vector.device)
+    rc = _lib.load().pbbss_matvec(_lib.handle(vector.device.index), _lib.ptr(matrix),
+                                  _lib.ptr(vector), N, D, _lib.ptr(out),
+                                  _lib.stream_ptr(vector.device.index))
+    _lib.check(rc, f'matvec(N={N},D={D})')
     return out
 
 

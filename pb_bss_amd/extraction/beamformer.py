@@ -249,10 +249,9 @@ def get_optimal_reference_channel(w_mat, target_psd_matrix, noise_psd_matrix, ep
             'unique.')
     if eps is None:
         eps = np.finfo(np.float64).tiny
-    tp = _c128(target_psd_matrix)
-    nn = _c128(noise_psd_matrix)
-    num = t.einsum('fdr,fde,fer->fr', w.conj(), tp, w)
-    den = t.einsum('fdr,fde,fer->fr', w.conj(), nn, w)
+    tp = _c128(target_psd_matrix).expand(w.shape).contiguous()
+    nn = _c128(noise_psd_matrix).expand(w.shape).contiguous()
+    num, den = engine.reference_channel_terms(w.contiguous(), tp, nn)
     return _select_reference_channel(_lib.to_host(num), _lib.to_host(den), eps)
 
 

@@ -21,32 +21,38 @@ from .beamformer import (
 __all__ = ['get_bf_vector']
 
 
-def _xp(x):
-    return _lib.torch() if _lib.is_torch(x) else np
-
-
-def _outer(a):
-    xp = _xp(a)
-    return xp.einsum('...d,...e->...de', a, a.conj())
-
-
-def _trace(m):
-    xp = _xp(m)
-    return xp.einsum('...dd->...', m) if xp is not np else np.trace(m, axis1=-1, axis2=-2)
+def _on_device(fn, like, *arrays):
+    """Run the device function `fn` on (N, ...)-flattened complex128 device copies of `arrays`
+    and hand the result back in the array family of `like` (NumPy in -> NumPy out)."""
+    t = _lib.torch()
+    dev = [_lib.to_device(a, t.complex128) for a in arrays]
+    out = fn(*dev)
+    return out if _lib.is_torch(like) else _lib.to_host(out)
 
 
 def _rank_one(covariance_matrix, a):
-    """Scale a a^H to the trace of the covariance (wrapper.py:18-25, :61-69)."""
-    r1 = _outer(a)
-    scale = _trace(covariance_matrix) / _trace(r1)
-    return scale[..., None, None] * r1
+    """Scale a a^H to the trace of the covariance (wrapper.py:18-25, :61-69) --
+    pbbss_rank_one_approximation, one thread per matrix entry."""
+    from .. import engine
+    lead, D = tuple(a.shape[:-1]), a.shape[-1]
+
+    def run(cov, vec):
+        cov = cov.expand(*lead, D, D).reshape(-1, D, D).contiguous()
+        return engine.rank_one_approximation(cov, vec.reshape(-1, D).contiguous()).reshape(*lead, D, D)
+    return _on_device(run, a, covariance_matrix, a)
 
 
 def _gev_atf_vector(covariance_matrix, noise_covariance_matrix, **gev_kwargs):
-    """Phi_nn w_gev as an ATF estimate (wrapper.py:28-48)."""
+    """Phi_nn w_gev as an ATF estimate (wrapper.py:28-48) -- pbbss_matvec."""
+    from .. import engine
     assert noise_covariance_matrix is not None
     w = get_gev_vector(covariance_matrix, noise_covariance_matrix, **gev_kwargs)
-    return _xp(w).einsum('...de,...e->...d', _match(noise_covariance_matrix, w), w)
+    lead, D = tuple(w.shape[:-1]), w.shape[-1]
+
+    def run(noise, vec):
+        noise = noise.expand(*lead, D, D).reshape(-1, D, D).contiguous()
+        return engine.matvec(noise, vec.reshape(-1, D).contiguous()).reshape(*lead, D)
+    return _on_device(run, w, noise_covariance_matrix, w)
 
 
 def _match(x, like):

@@ -448,3 +448,21 @@ def test_joint_models_config5_full_size(kind):
     assert masks.shape == (F, K, T)
     assert np.abs(masks - want).max() < 1e-6
     assert np.abs(masks[512] - want[512]).max() < 1e-6
+
+
+@pytest.mark.parametrize('kind', ['gaussian', 'vmf'])
+def test_joint_models_long_utterance_runs_on_the_streaming_kernels(kind):
+    """An utterance too long for the LDS-resident joint kernels (T = 3 000 frames at D = 4, K = 2:
+    168 KB of frame arrays) is served by the size-generic kernels instead of being refused -- the
+    reference has no length limit (gcacgmm.py:121-225)."""
+    from pb_bss_amd.distribution import GCACGMMTrainer, VMFCACGMMTrainer
+    from oracle import embed as oe, synth
+    F, T, D, K, E = 3, 3000, 4, 2, 12
+    Y, e, init = synth.make_joint(F, T, D, K, E, seed=8)
+    trainer = GCACGMMTrainer() if kind == 'gaussian' else VMFCACGMMTrainer()
+    kw = {} if kind == 'gaussian' else dict(max_concentration=80.)
+    masks = trainer.fit_predict(Y, e, initialization=init, iterations=4, **kw)
+    ref = oe.joint_fit(kind, Y.astype(np.complex128), e.astype(np.float64), init, 4, **kw)
+    want = oe.joint_model_predict(ref, Y.astype(np.complex128), e.astype(np.float64))
+    assert masks.shape == (F, K, T)
+    assert np.abs(masks - want).max() < 1e-6

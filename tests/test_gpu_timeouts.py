@@ -71,8 +71,10 @@ def test_cooperative_shared_weight_launch_really_times_out(one_poll):
     from pb_bss_amd.distribution import CACGMMTrainer
     from pb_bss_amd.testing import synth
     from oracle import cacgmm as oc
-    # 257 bins on 256 compute units: one unit hosts two workgroups, the others wait for them
-    Y, init = synth.make_stft(257, 300, 4, 2, seed=33)
+    # 257 bins on 256 compute units, two workgroups of this size per unit at most: the unit that
+    # hosts two runs its phases ~1.4x slower, the other 255 workgroups wait for it at every grid
+    # barrier for several microseconds -- far longer than the two polls they are allowed
+    Y, init = synth.make_stft(257, 700, 8, 3, seed=33)
     with pytest.warns(RuntimeWarning, match='cooperative shared-weight launch timed out'):
         masks = CACGMMTrainer().fit_predict(Y, initialization=init, iterations=5,
                                             weight_constant_axis=(-3, -1))
