@@ -31,7 +31,9 @@
 extern "C" {
 #endif
 
-#define PBBSS_VERSION 300 /* 0.3.0: pbbss_em_opts.precision, pbbss_mix_opts.sharded, pbbss_comm_info */
+#define PBBSS_VERSION 400 /* 0.4.0: pbbss_split_reset, pbbss_set_spin_limit, pbbss_reference_channel_terms,
+                             pbbss_rank_one_approximation, pbbss_matvec (0.3.0: em_opts.precision,
+                             mix_opts.sharded, pbbss_comm_info) */
 
 /* ---- error codes --------------------------------------------------------- */
 #define PBBSS_OK 0

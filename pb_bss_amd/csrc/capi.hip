@@ -1485,6 +1485,27 @@ static int embed_mixture_fit(pbbss_handle_t h, int kind, const void* y, int64_t 
   if (!out_mean || !out_scale || !out_weight) return PBBSS_ERR_INVALID_ARG;
   const bool vmf = (kind == PBBSS_EMBED_VMF);
   hipStream_t s = as_stream(stream);
+  // many small vMF mixtures (e.g. one per frequency bin): the persistent one-workgroup-per-mixture
+  // kernel runs the whole loop in ONE launch (embed.hip: vmf_bin_em_kernel); a big mixture is
+  // better off spread over the chip by the sweep + finalize pair below
+  if (vmf && !out_log_pdf && B >= 16) {
+    const size_t lds = pbbss::vmf_bin_lds_bytes(N, E, K, o->embedding_is_f64);
+    if (lds > 0 && lds <= h->cfg.lds_limit) {
+      if (has_model) {
+        int rc0;
+        if ((rc0 = copy_d2d(out_mean, in_mean, (size_t)B * K * E * 8, s)) != PBBSS_OK) return rc0;
+        if ((rc0 = copy_d2d(out_scale, in_scale, (size_t)B * K * 8, s)) != PBBSS_OK) return rc0;
+        if ((rc0 = copy_d2d(out_weight, in_weight, (size_t)B * K * 8, s)) != PBBSS_OK) return rc0;
+      }
+      TimedRegion tr(h, s);
+      return pbbss::launch_vmf_bin_em(
+          y, o->embedding_is_f64, B, N, E, K, o->iterations, gamma0, saliency,
+          has_model ? out_mean : nullptr, has_model ? out_scale : nullptr,
+          has_model ? out_weight : nullptr, o->min_concentration, o->max_concentration,
+          o->weight_mode, out_mean, out_scale, out_weight,
+          (o->final_predict && out_affiliation) ? out_affiliation : nullptr, h->cfg.lds_limit, s);
+    }
+  }
   const size_t nyz = (size_t)B * N * E;
   const size_t np = pbbss::embed_partial_doubles(B, N, E, K, nullptr);
   // vMF mixture: ONE pass over the embedding per iteration (vmf_em_kernel, embed.hip) where the

@@ -545,6 +545,219 @@ __global__ void __launch_bounds__(kFusedThreads)
   }
 }
 
+// ---------------------------------------------------------------- persistent vMF mixture (many small mixtures)
+// Round 4 (BASELINE configs[3], vMF leg: one mixture per frequency bin, B = 257 mixtures of N = 800
+// points, E = 12).  A mixture that fits ONE workgroup's LDS needs no partials, no finalize kernel
+// and no relaunch: the workgroup stages its rows once and runs the WHOLE EM loop -- E part
+// (thread = row), M part (thread = (row slot, dimension)), slot reduction, model (mean, the
+// concentration of Banerjee 2005 eq. 4.4, the log-Bessel normaliser, the mixture weights) -- with
+// the model in LDS between the iterations (vmfmm.py:124-172, von_mises_fisher.py:28-144).  The
+// two-launches-per-iteration path took 26.8 us per iteration for that shape.
+template <int K, typename TS>
+__global__ void __launch_bounds__(kFusedThreads)
+    vmf_bin_em_kernel(const TS* __restrict__ y, int64_t N, int E, int iterations,
+                      const double* __restrict__ gamma, const double* __restrict__ sal,
+                      const double* __restrict__ in_mean, const double* __restrict__ in_conc,
+                      const double* __restrict__ in_weight, double cmin, double cmax,
+                      int weight_mode, double* __restrict__ out_mean, double* __restrict__ out_conc,
+                      double* __restrict__ out_weight, double* __restrict__ out_aff) {
+  extern __shared__ __attribute__((aligned(16))) char smraw[];
+  constexpr int KW = (K + 1) & ~1;
+  constexpr int kWaves = kFusedThreads / kWave;
+  const int ES = E | 1;
+  const int S = kFusedThreads / E;
+  double* affw = reinterpret_cast<double*>(smraw);          // [N][KW]  gamma * saliency / |y_n|
+  double* red = affw + (size_t)N * KW;                      // [S][K][E]
+  double* red0 = red + (size_t)S * K * E;                   // [waves][K]
+  double* mu = red0 + kWaves * K;                           // [K][E]
+  double* tot = mu + (size_t)K * E;                         // [K][E + 1]
+  double* prec = tot + (size_t)K * (E + 1);                 // [K]
+  double* off = prec + K;                                   // [K]
+  double* wgt = off + K;                                    // [K]
+  TS* tile = reinterpret_cast<TS*>(wgt + K);                // [N][ES]
+  const int64_t b = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int lane = tid & (kWave - 1), wave = tid / kWave;
+  const TS* base = y + (size_t)b * N * E;
+  const int total = (int)N * E;
+  {  // stage the rows: unconditional loads at clamped indices, 8 in flight per thread
+    constexpr int U = 8;
+    for (int i0 = tid; i0 < total; i0 += U * kFusedThreads) {
+      TS raw[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = i0 + u * kFusedThreads;
+        raw[u] = base[i < total ? i : total - 1];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = i0 + u * kFusedThreads;
+        if (i < total) {
+          const int r = i / E;
+          tile[(size_t)r * ES + (i - r * E)] = raw[u];
+        }
+      }
+    }
+  }
+  if (!gamma) {  // predict only (iterations == 0): the model comes from the caller
+    for (int i = tid; i < K * E; i += kFusedThreads) mu[i] = in_mean[(size_t)b * K * E + i];
+    for (int k = wave; k < K; k += kWaves) {
+      const double conc = in_conc[b * K + k];
+      const double o = -(0.5 * E * kLn2Pi + wave_log_bessel_over_power(0.5 * E - 1.0, conc, lane));
+      if (lane == 0) {
+        prec[k] = conc;
+        off[k] = o;
+        wgt[k] = in_weight[b * K + k];
+      }
+    }
+  }
+  __syncthreads();
+  const int s = tid / E, d = tid - s * E;
+  const bool active = s < S;
+  // E part of one sweep: posteriors of the model in LDS (or the caller's initialisation), the
+  // M-step weights into affw, the plain weight sums per class; FINAL: affiliations to out_aff
+  auto e_part = [&](bool from_gamma, bool final_pass) {
+    double s0[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) s0[k] = 0.0;
+    for (int n = tid; n < (int)N; n += kFusedThreads) {
+      const TS* row = tile + (size_t)n * ES;
+      double n2 = 0.0, dot[K];
+#pragma unroll
+      for (int k = 0; k < K; ++k) dot[k] = 0.0;
+      if (from_gamma) {
+        for (int e = 0; e < E; ++e) {
+          const double v = (double)row[e];
+          n2 = fma(v, v, n2);
+        }
+      } else {
+        for (int e = 0; e < E; ++e) {
+          const double v = (double)row[e];
+          n2 = fma(v, v, n2);
+#pragma unroll
+          for (int k = 0; k < K; ++k) dot[k] = fma(v, mu[k * E + e], dot[k]);
+        }
+      }
+      const double inv = 1.0 / fmax(sqrt(n2), kTiny);  // unit rows, vmfmm.py:76-78
+      double g[K];
+      if (from_gamma) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) g[k] = gamma[((size_t)b * K + k) * N + n];
+      } else {
+        double lp[K], mx = -1.79e308;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          lp[k] = fma(prec[k], dot[k] * inv, off[k]);  // von_mises_fisher.py:71-77
+          mx = fmax(mx, lp[k]);
+        }
+        double den = 0.0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          g[k] = exp(lp[k] - mx) * wgt[k];  // mixture_model_utils.py:30-47
+          den += g[k];
+        }
+        den = fmax(den, kTiny);
+#pragma unroll
+        for (int k = 0; k < K; ++k) g[k] /= den;
+      }
+      if (final_pass) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) out_aff[((size_t)b * K + k) * N + n] = g[k];
+      } else {
+        const double sv = sal ? sal[(size_t)b * N + n] : 1.0;  // vmfmm.py:167
+#pragma unroll
+        for (int k = 0; k < KW; ++k) {
+          const double wk = (k < K) ? g[k < K ? k : 0] * sv : 0.0;
+          if (k < K) s0[k] += wk;
+          affw[(size_t)n * KW + k] = wk * inv;
+        }
+      }
+    }
+    if (!final_pass) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const double t = wave_sum(s0[k]);
+        if (lane == 0) red0[wave * K + k] = t;
+      }
+    }
+  };
+  for (int it = 0; it < iterations; ++it) {
+    e_part(it == 0 && gamma != nullptr, false);
+    __syncthreads();
+    // ---- M part: thread = (slot, dimension) over all rows
+    if (active) {
+      double acc[K];
+#pragma unroll
+      for (int k = 0; k < K; ++k) acc[k] = 0.0;
+      for (int r = s; r < (int)N; r += S) {
+        const double v = (double)tile[(size_t)r * ES + d];
+        double wk[KW];
+#pragma unroll
+        for (int k = 0; k < KW; k += 2) {
+          const double2 p2 = *reinterpret_cast<const double2*>(affw + (size_t)r * KW + k);
+          wk[k] = p2.x;
+          wk[k + 1] = p2.y;
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[k] = fma(wk[k], v, acc[k]);
+      }
+#pragma unroll
+      for (int k = 0; k < K; ++k) red[((size_t)s * K + k) * E + d] = acc[k];
+    }
+    __syncthreads();
+    for (int i = tid; i < K * E; i += kFusedThreads) {
+      const int k = i / E, dd = i - k * E;
+      double t = 0.0;
+      for (int ss = 0; ss < S; ++ss) t += red[((size_t)ss * K + k) * E + dd];
+      tot[k * (E + 1) + dd] = t;
+    }
+    if (tid < K) {
+      double t = 0.0;
+      for (int w = 0; w < kWaves; ++w) t += red0[w * K + tid];
+      tot[tid * (E + 1) + E] = t;
+    }
+    __syncthreads();
+    // ---- model: one wavefront per class (von_mises_fisher.py:122-144)
+    for (int k = wave; k < K; k += kWaves) {
+      const double* row = tot + k * (E + 1);
+      const double s0k = row[E];
+      double n2 = 0.0;
+      for (int dd = lane; dd < E; dd += kWave) n2 = fma(row[dd], row[dd], n2);
+      n2 = wave_sum(n2);
+      const double norm = sqrt(n2);
+      const double rn = 1.0 / fmax(norm, kTiny);                            // eq. 2.4
+      for (int dd = lane; dd < E; dd += kWave) mu[k * E + dd] = row[dd] * rn;
+      const double rbar = norm / s0k;                                        // eq. 2.5
+      double conc = (rbar * E - rbar * rbar * rbar) / (1.0 - rbar * rbar);  // eq. 4.4
+      conc = conc < cmin ? cmin : (conc > cmax ? cmax : conc);              // NaN stays NaN
+      const double o = -(0.5 * E * kLn2Pi + wave_log_bessel_over_power(0.5 * E - 1.0, conc, lane));
+      if (lane == 0) {
+        prec[k] = conc;
+        off[k] = o;
+      }
+    }
+    if (tid == 0) {
+      if (weight_mode == 1) {
+        for (int k = 0; k < K; ++k) wgt[k] = 1.0 / K;
+      } else {  // estimate_mixture_weight with saliency: L1 unit norm, eps 'where' 1e-10
+        double t = 0.0;
+        for (int k = 0; k < K; ++k) t += fabs(tot[k * (E + 1) + E]);
+        if (t == 0.0) t = 1e-10;
+        for (int k = 0; k < K; ++k) wgt[k] = tot[k * (E + 1) + E] / t;
+      }
+    }
+    __syncthreads();
+  }
+  if (iterations > 0) {
+    for (int i = tid; i < K * E; i += kFusedThreads) out_mean[(size_t)b * K * E + i] = mu[i];
+    if (tid < K) {
+      out_conc[b * K + tid] = prec[tid];
+      out_weight[b * K + tid] = wgt[tid];
+    }
+  }
+  if (out_aff) e_part(false, true);
+}
+
 // ---------------------------------------------------------------- joint models: fused sweep
 // Round 4 (the "rotated" joint loop of pbbss_joint_fit): ONE pass over the
 // embedding per EM iteration for GCACGMM (spherical) / VMFCACGMM.  The tile machinery is the one
@@ -1539,6 +1752,48 @@ int launch_vmf_em(const void* y, int y_is_f64, int64_t B, int64_t N, int E, int 
   hipLaunchKernelGGL((embed_finalize_kernel<PBBSS_EMBED_VMF, 0>), dim3((unsigned)B),
                      dim3(kFinThreads), lds_fin, s, part, p.C, E, K, cmin, cmax, weight_mode,
                      den_buf, mean, conc, weight, offset, prec);
+  return ok_or_hip();
+}
+
+// ---- persistent vMF mixture for many small mixtures (vmf_bin_em_kernel) ------------------------
+size_t vmf_bin_lds_bytes(int64_t N, int E, int K, int y_is_f64) {
+  if (E < 1 || E > kFusedThreads || N < 1 || N > 65536) return 0;
+  const int KW = (K + 1) & ~1, ES = E | 1, S = kFusedThreads / E;
+  const size_t dbl = (size_t)N * KW + (size_t)S * K * E + (size_t)(kFusedThreads / kWave) * K +
+                     (size_t)K * E + (size_t)K * (E + 1) + 3 * (size_t)K;
+  return dbl * 8 + (size_t)N * ES * (y_is_f64 ? 8 : 4) + 16;
+}
+
+int launch_vmf_bin_em(const void* y, int y_is_f64, int64_t B, int64_t N, int E, int K,
+                      int iterations, const double* gamma, const double* sal,
+                      const double* in_mean, const double* in_conc, const double* in_weight,
+                      double cmin, double cmax, int weight_mode, double* mean, double* conc,
+                      double* weight, double* out_aff, size_t lds_limit, hipStream_t s) {
+  const size_t lds = vmf_bin_lds_bytes(N, E, K, y_is_f64);
+  if (lds == 0 || lds > lds_limit || K < 1 || K > kEmbedMaxK || B > 2147483647LL)
+    return PBBSS_ERR_UNSUPPORTED;
+#define PBBSS_VB_GO(KK, TT)                                                                        \
+  {                                                                                                \
+    auto kfn = vmf_bin_em_kernel<KK, TT>;                                                          \
+    if (lds > 64 * 1024 &&                                                                         \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                                    \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)   \
+      return PBBSS_ERR_HIP;                                                                        \
+    hipLaunchKernelGGL(kfn, dim3((unsigned)B), dim3(kFusedThreads), lds, s,                        \
+                       static_cast<const TT*>(y), N, E, iterations, gamma, sal, in_mean, in_conc,  \
+                       in_weight, cmin, cmax, weight_mode, mean, conc, weight, out_aff);           \
+  }
+#define PBBSS_VB_K(KK)                                                                             \
+  case KK:                                                                                         \
+    if (y_is_f64) PBBSS_VB_GO(KK, double) else PBBSS_VB_GO(KK, float)                              \
+    break;
+  switch (K) {
+    PBBSS_VB_K(1) PBBSS_VB_K(2) PBBSS_VB_K(3) PBBSS_VB_K(4) PBBSS_VB_K(5) PBBSS_VB_K(6)
+    PBBSS_VB_K(7) PBBSS_VB_K(8)
+    default: return PBBSS_ERR_UNSUPPORTED;
+  }
+#undef PBBSS_VB_K
+#undef PBBSS_VB_GO
   return ok_or_hip();
 }
 

@@ -75,6 +75,18 @@ int launch_vmf_em(const void* y, int y_is_f64, int64_t B, int64_t N, int E, int 
                   int weight_mode, double* part, double* mean, double* conc, double* weight,
                   double* offset, double* prec, double* out_aff, int accumulate, hipStream_t s);
 
+// Persistent vMF mixture EM for MANY SMALL mixtures (round 4): one workgroup per mixture keeps its
+// rows and the model in LDS for all iterations (vmf_bin_em_kernel).  gamma (B,K,N): affiliation
+// initialisation (iterations > 0), else the model (in_mean (B,K,E), in_conc, in_weight (B,K)) for a
+// pure predict (iterations == 0).  out_aff (B,K,N) or null.  vmf_bin_lds_bytes: dynamic LDS the
+// shape needs (0: not served).
+size_t vmf_bin_lds_bytes(int64_t N, int E, int K, int y_is_f64);
+int launch_vmf_bin_em(const void* y, int y_is_f64, int64_t B, int64_t N, int E, int K,
+                      int iterations, const double* gamma, const double* sal,
+                      const double* in_mean, const double* in_conc, const double* in_weight,
+                      double cmin, double cmax, int weight_mode, double* mean, double* conc,
+                      double* weight, double* out_aff, size_t lds_limit, hipStream_t s);
+
 // Rotated joint loop (round 4): ONE pass over the row-major embedding (F*T, E) per EM iteration of
 // GCACGMM (spherical) / VMFCACGMM.  launch_joint_sweep: posteriors of every point from the
 // spatial quadratic forms Q (F,K,T) + ln det B (F,K) (written by the spatial kernel,

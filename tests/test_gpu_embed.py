@@ -101,6 +101,38 @@ def test_vmfmm_shapes_against_oracle(N, E, K):
                                atol=1e-8)
 
 
+@pytest.mark.parametrize('B,N,E,K,dtype,uniform', [
+    (20, 300, 10, 3, np.float32, False), (257, 800, 12, 3, np.float32, False),
+    (33, 257, 7, 2, np.float64, True), (16, 1200, 40, 5, np.float32, False)])
+def test_vmfmm_many_small_mixtures_persistent_kernel(B, N, E, K, dtype, uniform):
+    """B >= 16 independent mixtures (one per frequency bin in BASELINE configs[3]) run in the
+    persistent one-workgroup-per-mixture kernel (embed.hip: vmf_bin_em_kernel): whole EM loop in
+    one launch, model in LDS -- against the oracle's reference loop, with saliency, uniform
+    weights, float64 input and the predict of the fitted model (iterations = 0 path)."""
+    from pb_bss_amd.distribution import VMFMMTrainer
+    from oracle import embed as oe
+    rng = np.random.default_rng(B + N)
+    mu = rng.standard_normal((B, K, E))
+    lab = rng.integers(K, size=(B, N))
+    y = (np.take_along_axis(mu, lab[..., None], 1) + 0.6 * rng.standard_normal((B, N, E))).astype(dtype)
+    init = rng.uniform(size=(B, K, N))
+    init /= init.sum(1, keepdims=True)
+    sal = rng.uniform(0.1, 1.0, size=(B, N))
+    kw = dict(weight_constant_axis=-2) if uniform else {}
+    y64 = y.astype(np.float64)
+    ref = oe.vmfmm_fit(y64, init, 7, saliency=sal, **kw)
+    model = VMFMMTrainer().fit(y, initialization=init, iterations=7, saliency=sal, **kw)
+    np.testing.assert_allclose(model.vmf.mean, ref['mean'], atol=1e-9)
+    np.testing.assert_allclose(model.vmf.concentration, ref['concentration'], rtol=1e-8)
+    if not uniform:
+        np.testing.assert_allclose(model.weight, ref['weight'], atol=1e-10)
+    want = oe.vmfmm_predict(ref, y64)
+    np.testing.assert_allclose(model.predict(y), want, atol=1e-8)
+    np.testing.assert_allclose(
+        VMFMMTrainer().fit_predict(y, initialization=init, iterations=7, saliency=sal, **kw),
+        want, atol=1e-8)
+
+
 def test_vmfmm_torch_in_torch_out_and_uniform_weight():
     import torch
     from pb_bss_amd.distribution import VMFMMTrainer
