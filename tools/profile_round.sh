@@ -11,7 +11,7 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out
 STEPS=25
 WARM=5
-CMD="python $ROOT/bench.py --steps $STEPS --warmup $WARM --cpu-iters 0 --check-bins 0 --config3 off --f32 off --extras off --sustained-s 0"
+CMD="python $ROOT/bench.py --steps $STEPS --warmup $WARM --cpu-iters 0 --check-bins 0 --config3 off --configs45 off --f32 off --extras off --sustained-s 0"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 rm -rf "$OUT/prof_$TAG"
