@@ -192,12 +192,19 @@ def pmc_evidence(ms_per_step):
     kib = sum(v for (k, c), v in prof['pmc'].items() if c in ('FETCH_SIZE', 'WRITE_SIZE'))
     if kib == 0.0:
         return None, prof['clock_ghz'], name + ' holds no FETCH_SIZE / WRITE_SIZE rows'
-    fetch = sum(v for (k, c), v in prof['pmc'].items() if c == 'FETCH_SIZE') * 1024.0
+    # gfx950: FETCH_SIZE reports half the bytes of coalesced streaming reads (MI355X_MICROARCH.md;
+    # calibrated here on embed_prepare_kernel's known 41.04 MB read: 20.06 MB counted,
+    # profiles/r04_e_config5_profile.txt) -- doubled; WRITE_SIZE is taken as counted (the same
+    # kernel's 41.04 MB written: 43.6 MB counted)
+    fetch_raw = sum(v for (k, c), v in prof['pmc'].items() if c == 'FETCH_SIZE') * 1024.0
+    write = sum(v for (k, c), v in prof['pmc'].items() if c == 'WRITE_SIZE') * 1024.0
     compulsory = 8.0 * F * T * D + 8.0 * F * K * T  # one read of Y (complex64) + the initialisation
-    return kib * 1024.0, prof['clock_ghz'], (
-        f'{name}: FETCH_SIZE + WRITE_SIZE, separate --pmc passes, per launch; kernel-trace median '
-        f'{med_ms:.4f} ms over {prof["trace"]["n"]} measured launches; reads counted '
-        f'{fetch / 1e6:.1f} MB vs {compulsory / 1e6:.1f} MB compulsory (Y + initialisation)')
+    return 2.0 * fetch_raw + write, prof['clock_ghz'], (
+        f'{name}: 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE of the EM and the split kernel, '
+        f'separate --pmc passes, per launch; kernel-trace median {med_ms:.4f} ms over '
+        f'{prof["trace"]["n"]} measured launches; reads {2.0 * fetch_raw / 1e6:.1f} MB (counted '
+        f'{fetch_raw / 1e6:.1f}) vs {compulsory / 1e6:.1f} MB compulsory (Y + initialisation), '
+        f'writes {write / 1e6:.1f} MB vs {8.0 * F * K * T / 1e6:.1f} MB of masks')
 
 
 def roofline_block(kernel_ms, bins, iters, ms_per_step=None, world_note='', peak_tf=FP64_VALU_PEAK_TF,

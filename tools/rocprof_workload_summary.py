@@ -13,7 +13,8 @@ import re
 import sys
 from collections import defaultdict
 
-MARKER = {'config5': 'embed_prepare_kernel', 'config4': 'cwmm_em_kernel', 'config4_vmf': None}
+MARKER = {'config5': 'embed_prepare_kernel', 'config4': 'cwmm_em_kernel',
+          'config4_vmf': 'vmf_bin_em_kernel'}
 
 
 def short(name):
