@@ -98,7 +98,7 @@ class CwmmOpts(ctypes.Structure):
         ('y_is_c128', ctypes.c_int32),
         ('final_predict', ctypes.c_int32),
         ('n_coef', ctypes.c_int32),
-        ('reserved', ctypes.c_int32),
+        ('group', ctypes.c_int32),
         ('ev_min', ctypes.c_double),
         ('ev_max', ctypes.c_double),
         ('max_concentration', ctypes.c_double),

@@ -1139,7 +1139,13 @@ PBBSS_API int pbbss_cwmm_fit(pbbss_handle_t h, const void* y, int64_t B, int T, 
   if (o->iterations > 0 && (!spline_t || !spline_c || o->n_coef < 3)) return PBBSS_ERR_INVALID_ARG;
   if (o->iterations > 0 && (!out_mode || !out_concentration || !out_weight))
     return PBBSS_ERR_INVALID_ARG;
-  if (o->weight_mode < 0 || o->weight_mode > 1) return PBBSS_ERR_INVALID_ARG;
+  // PBBSS_WEIGHT_SHARED_K (round 4): weights averaged over groups of `opts->group` consecutive
+  // problems (the bins of an utterance), fused kernels only, fit from affiliations only
+  const bool shared_k = o->weight_mode == PBBSS_WEIGHT_SHARED_K;
+  if (o->weight_mode < 0 || (o->weight_mode > 1 && !shared_k)) return PBBSS_ERR_INVALID_ARG;
+  if (shared_k && (o->group < 1 || B % o->group != 0 || !has_gamma || o->iterations < 1))
+    return PBBSS_ERR_INVALID_ARG;
+  if (shared_k && (D > 8 || K > 4)) return PBBSS_ERR_UNSUPPORTED;
   if (D > 8 || K > 4) {
     // generic-size path (generic_watson.hip): per iteration class log-pdfs -> softmax with the
     // weights -> masked covariance of the unit-norm frames + weights -> eigh -> principal pair,
@@ -1224,6 +1230,11 @@ PBBSS_API int pbbss_cwmm_fit(pbbss_handle_t h, const void* y, int64_t B, int T, 
   wa.em.out_logpdf = out_log_pdf;
   wa.em.iterations = o->iterations;
   wa.em.weight_mode = o->weight_mode;
+  if (shared_k) {  // out_weight is (B / group, K)
+    wa.em.wgroup = o->group;
+    wa.em.out_weight = nullptr;
+    wa.em.out_weight_shared = out_weight;
+  }
   wa.em.layout = PBBSS_LAYOUT_TD;
   wa.em.final_predict = o->final_predict && (out_affiliation || out_log_pdf);
   wa.in_mode = static_cast<const double*>(in_mode);

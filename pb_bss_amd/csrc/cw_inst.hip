@@ -66,8 +66,54 @@ static int cw_launch_split(WatsonArgs wa, int64_t b_first, int r, const EmLaunch
   return PBBSS_OK;
 }
 
+// weight_constant_axis (-3, -1): one cooperative launch per batch of groups whose workgroups fit
+// the device at once (shared_inst.hip: launch_shared_one is the cACGMM counterpart)
+template <int K, typename YS>
+static int cw_launch_shared(WatsonArgs wa, const EmLaunchCfg& cfg, hipStream_t stream) {
+  using Kern = WatsonKernel<PBBSS_EM_D, K, YS, false>;
+  EmArgs& a = wa.em;
+  const size_t lds = Kern::lds_bytes(a.T);
+  if (lds > cfg.lds_limit || !cfg.xbuf) return PBBSS_ERR_UNSUPPORTED;  // frames must be LDS-resident
+  auto kfn = cwmm_em_shared_kernel<PBBSS_EM_D, K, YS>;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return PBBSS_ERR_HIP;
+  int occ = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn, kEmThreads, lds) != hipSuccess)
+    return PBBSS_ERR_HIP;
+  const int64_t capacity = (int64_t)cfg.num_cu * occ;
+  if (a.wgroup < 1 || a.B % a.wgroup != 0 || a.wgroup > capacity) return PBBSS_ERR_UNSUPPORTED;
+  const int64_t ngroups = a.B / a.wgroup;
+  const int64_t per_launch = capacity / a.wgroup;
+  const size_t n_cnt = (size_t)ngroups * 16 * sizeof(unsigned);
+  const size_t head = (n_cnt + 255) & ~(size_t)255;
+  const size_t n_gsum = (size_t)2 * a.B * K * sizeof(double);
+  char* ws = static_cast<char*>(cfg.get_scratch(cfg.scratch_ctx, head + n_gsum));
+  if (!ws) return PBBSS_ERR_HIP;
+  a.gcount = reinterpret_cast<unsigned*>(ws);
+  a.gsum = reinterpret_cast<double*>(ws + head);
+  a.xerror = reinterpret_cast<int*>(cfg.xbuf + 128);
+  a.xepoch = 0;
+  a.spin_limit = cfg.spin_limit;
+  if (hipMemsetAsync(ws, 0, head, stream) != hipSuccess) return PBBSS_ERR_HIP;
+  if (hipMemsetAsync(cfg.xbuf + 128, 0, 64, stream) != hipSuccess) return PBBSS_ERR_HIP;
+  for (int64_t g0 = 0; g0 < ngroups; g0 += per_launch) {
+    const int64_t ng = (ngroups - g0 < per_launch) ? ngroups - g0 : per_launch;
+    a.b_first = g0 * a.wgroup;
+    void* params[] = {&wa};
+    if (hipLaunchCooperativeKernel(reinterpret_cast<const void*>(kfn),
+                                   dim3((unsigned)(ng * a.wgroup)), dim3(kEmThreads), params,
+                                   (unsigned)lds, stream) != hipSuccess) {
+      (void)hipGetLastError();
+      return PBBSS_ERR_UNSUPPORTED;  // the caller falls back to the step-wise loop
+    }
+  }
+  return PBBSS_OK;
+}
+
 template <int K, typename YS>
 static int cw_launch_one(const WatsonArgs& wa, const EmLaunchCfg& cfg, hipStream_t stream) {
+  if (wa.em.weight_mode == PBBSS_WEIGHT_SHARED_K) return cw_launch_shared<K, YS>(wa, cfg, stream);
   if (WatsonKernel<PBBSS_EM_D, K, YS, false>::lds_bytes(wa.em.T) > cfg.lds_limit)
     return cw_launch_variant<K, YS, true>(wa, cfg, stream);
   // 2^n + 1 bins: the r remainder problems would put one more full workgroup on r compute units

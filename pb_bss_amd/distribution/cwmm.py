@@ -144,6 +144,24 @@ class CWMMTrainer:
                 complex_watson=ComplexWatson(
                     mode=as_result(r['mode'].reshape(*indep, K, D), like_torch),
                     concentration=as_result(r['concentration'].reshape(*indep, K), like_torch)))
+        # weights averaged over the bins of an utterance ((-3, -1), cwmm.py:217-240): one
+        # cooperative launch (csrc/cwmm.hpp: WatsonShared); None: not served / timed out
+        axes = {a % (len(indep) + 2) - (len(indep) + 2) for a in (
+            (weight_constant_axis,) if isinstance(weight_constant_axis, int)
+            else weight_constant_axis)}
+        if axes == {-3, -1} and len(indep) >= 1 and inline_permutation_aligner is None:
+            group = indep[-1]
+            r = engine.cwmm_fit(yb, K, spline, gamma0=gamma0.reshape(-1, K, N).contiguous(),
+                                iterations=iterations, saliency=sal,
+                                weight_mode=_lib.WEIGHT_SHARED_K, group=group)
+            if r is not None:
+                weight = r['weight'].reshape(*indep[:-1], 1, K, 1)
+                return CWMM(
+                    weight=as_result(weight, like_torch),
+                    complex_watson=ComplexWatson(
+                        mode=as_result(r['mode'].reshape(*indep, K, D), like_torch),
+                        concentration=as_result(r['concentration'].reshape(*indep, K),
+                                                like_torch)))
         return self._fit_stepwise(yb, indep, K, gamma0, iterations, saliency, sal,
                                   weight_constant_axis, inline_permutation_aligner, spline,
                                   like_torch)

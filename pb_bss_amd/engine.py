@@ -508,19 +508,26 @@ def pa_mapping_from_scores(scores, optimal):
 
 
 def cwmm_fit(y, K, spline, *, gamma0=None, model=None, iterations=100, saliency=None,
-             weight_mode=0, final_predict=False, want_log_pdf=False, check_status=True):
+             weight_mode=0, final_predict=False, want_log_pdf=False, check_status=True,
+             group=None):
     """pbbss_cwmm_fit.  y (B,T,D) complex; gamma0 (B,K,T) f64 or
     model=(mode (B,K,D) c128, concentration (B,K), weight (B,K)).
     `spline` = dict(t, c device f64 arrays, ev_min, ev_max, max_concentration);
-    may be None for a pure predict (iterations=0)."""
+    may be None for a pure predict (iterations=0).
+    group (with weight_mode=_lib.WEIGHT_SHARED_K): consecutive problems that share one weight
+    set (weight_constant_axis (-3, -1)); the weight comes back as (B / group, K).  Returns None
+    when the cooperative kernel does not serve the configuration or its grid barrier timed out
+    (a RuntimeWarning): the caller then runs the loop step by step."""
     t = _t()
     dev = y.device
     B, T, D = y.shape
     is128 = y.dtype == t.complex128
+    shared = weight_mode == _lib.WEIGHT_SHARED_K
     opts = _lib.CwmmOpts(
         iterations=int(iterations), weight_mode=int(weight_mode), y_is_c128=int(is128),
         final_predict=int(bool(final_predict or want_log_pdf)),
-        n_coef=0 if spline is None else int(spline['c'].numel()), reserved=0,
+        n_coef=0 if spline is None else int(spline['c'].numel()),
+        group=int(group) if shared else 0,
         ev_min=0.0 if spline is None else float(spline['ev_min']),
         ev_max=0.0 if spline is None else float(spline['ev_max']),
         max_concentration=0.0 if spline is None else float(spline['max_concentration']))
@@ -535,7 +542,7 @@ def cwmm_fit(y, K, spline, *, gamma0=None, model=None, iterations=100, saliency=
     def launch():
         out_mode = t.empty((B, K, D), dtype=t.complex128, device=dev)
         out_conc = t.empty((B, K), dtype=f64, device=dev)
-        out_w = t.empty((B, K), dtype=f64, device=dev)
+        out_w = t.empty((B // group, K) if shared else (B, K), dtype=f64, device=dev)
         out_st = t.zeros((B, K), dtype=t.int32, device=dev)
         out_aff = t.empty((B, K, T), dtype=f64, device=dev) if final_predict else None
         out_lp = t.empty((B, K, T), dtype=f64, device=dev) if want_log_pdf else None
@@ -546,10 +553,27 @@ def cwmm_fit(y, K, spline, *, gamma0=None, model=None, iterations=100, saliency=
             None if spline is None else _lib.ptr(spline['c']),
             _lib.ptr(out_mode), _lib.ptr(out_conc), _lib.ptr(out_w), _lib.ptr(out_st),
             _lib.ptr(out_aff), _lib.ptr(out_lp), _lib.stream_ptr(dev.index))
+        if shared and rc == _lib.ERR_UNSUPPORTED:
+            return None
         _lib.check(rc, f'cwmm_fit(B={B},T={T},D={D},K={K})')
         return dict(mode=out_mode, concentration=out_conc, weight=out_w, status=out_st,
                     affiliation=out_aff, log_pdf=out_lp)
 
+    if shared:
+        r = launch()
+        if r is None:
+            return None
+        if check_status:
+            poison = _lib.ST_NONFINITE | _lib.ST_EIG_NOCONV
+            if bool(((r['status'] & poison) == poison).all().item()) and split_error(dev.index):
+                import warnings
+                warnings.warn('cooperative shared-weight launch timed out waiting for '
+                              'co-residency; repeating the fit step by step', RuntimeWarning,
+                              stacklevel=2)
+                split_reset(dev.index)
+                return None
+            _status_raise_em(r['status'], 'CWMMTrainer.fit')
+        return r
     if check_status and iterations > 0:
         return _checked_with_split_retry(launch, dev, 'CWMMTrainer.fit')
     return launch()
