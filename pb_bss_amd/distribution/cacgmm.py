@@ -538,6 +538,33 @@ class CACGMMTrainer:
                 covariance_eigenvectors=as_result(vec, like_torch),
                 covariance_eigenvalues=as_result(val, like_torch)))
 
+    def fit_with_log_likelihood(self, y, initialization=None, num_classes=None, iterations=100,
+                                **fit_kwargs):
+        """`fit` that also returns the log-likelihood after every EM iteration (SURVEY section 5
+        'metrics': the reference declares a `log_likelihood_history` (gmm.py:31) and never fills
+        it; `CACGMM.log_likelihood`, cacgmm.py:97-138, is what it would hold).  The loop runs one
+        iteration per launch -- resuming from the fitted model is exact (cacgmm.py:229-234) -- with
+        one log-pdf pass after each: a monitoring aid, ~3 launches per iteration instead of one
+        fused fit.  Returns (model, history) with history[i] = log-likelihood after iteration i+1."""
+        assert iterations > 0, iterations
+        like_torch = _lib.is_torch(y)
+        yd = _complex_device(y)
+        model = self.fit(yd, initialization=initialization, num_classes=num_classes, iterations=1,
+                         **fit_kwargs)
+        history = [model.log_likelihood(yd)]
+        for _ in range(iterations - 1):
+            model = self.fit(yd, initialization=model, iterations=1, **fit_kwargs)
+            history.append(model.log_likelihood(yd))
+        if not like_torch:  # NumPy in, NumPy out
+            model = CACGMM(
+                weight=as_result(_lib.to_device(model.weight), False),
+                cacg=ComplexAngularCentralGaussian(
+                    covariance_eigenvectors=as_result(
+                        _lib.to_device(model.cacg.covariance_eigenvectors), False),
+                    covariance_eigenvalues=as_result(
+                        _lib.to_device(model.cacg.covariance_eigenvalues), False)))
+        return model, np.asarray(history)
+
     def fit_predict(
             self,
             y,

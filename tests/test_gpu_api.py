@@ -646,3 +646,22 @@ def test_stack_parameters_batched_predict_equals_individual():
     got = stacked.predict(np.stack([Y for Y, _ in data]))
     for u, (Y, _) in enumerate(data):
         np.testing.assert_allclose(got[u], models[u].predict(Y), atol=1e-12)
+
+
+def test_fit_with_log_likelihood_history_matches_the_oracle_trajectory():
+    """Per-iteration log-likelihood (optional): one value per EM iteration,
+    equal to `log_likelihood` of the oracle's model after the same number of iterations, and the
+    final model equals the one of a single fused fit."""
+    from pb_bss_amd.distribution import CACGMMTrainer
+    from pb_bss_amd.testing import synth
+    from oracle import cacgmm as oc
+    Y, init = synth.make_stft(9, 150, 5, 3, seed=77)
+    Y128 = Y.astype(np.complex128)
+    model, hist = CACGMMTrainer().fit_with_log_likelihood(Y, initialization=init, iterations=5)
+    assert hist.shape == (5,)
+    for n in (1, 3, 5):
+        want = oc.log_likelihood(oc.em_fit(Y128, init, iterations=n), Y128)
+        assert abs(hist[n - 1] - want) < 1e-7 * abs(want), (n, hist[n - 1], want)
+    fused = CACGMMTrainer().fit(Y, initialization=init, iterations=5)
+    np.testing.assert_allclose(model.predict(Y), fused.predict(Y), atol=1e-9)
+    assert isinstance(model.weight, np.ndarray)
