@@ -869,12 +869,18 @@ def config3_leg(args, data, Y, init, shard, world, rank, dev, use_dist, steps, w
 def run_config3(args, world, rank, local_rank, dev, use_dist, primary=False):
     """All config-3 legs of this run -> dict (rank 0) or None."""
     from pb_bss_amd import _lib
+    import torch
     U = args.utterances
     data = make_batch(U)
+    # the legs before this one leave torch's caching allocator full of blocks of other sizes; the
+    # 0.4 GB temporaries of a 64-utterance step would then be carved by fresh hipMallocs inside the
+    # timed steps (measured: 87 instead of 82 ms per step) -- start from an empty cache, warm up twice
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
     Y = _lib.to_device(np.stack([d[0] for d in data]))          # (U, F, T, D) complex64
     init = _lib.to_device(np.stack([d[1] for d in data]))       # (U, F, K, T) float64
     steps = args.steps if primary else args.config3_steps
-    warmup = args.warmup if primary else 1
+    warmup = args.warmup if primary else 2
     legs = {}
     if use_dist and world > 1:
         shards = [args.shard] if primary else ['bins', 'utterances']
