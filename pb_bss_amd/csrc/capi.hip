@@ -1675,11 +1675,12 @@ PBBSS_API int pbbss_joint_fit(pbbss_handle_t h, const void* observation, const v
   if (g_full && E > pbbss::kGaussFullMaxE) return PBBSS_ERR_UNSUPPORTED;
   // opts->sharded: this call holds ONE RANK'S BLOCK of the frequency bins; the spectral M-step
   // sums and the bin-constant class weights are summed over the communicator of the handle, in
-  // stream order (no host round trip inside the loop).  The full-covariance scatter takes its
-  // shift from the first local point, which differs from rank to rank: not served.
+  // stream order (no host round trip inside the loop).  The full-covariance scatter centres its
+  // augmented vectors on a shift that must be THE SAME on every rank for the Gram tiles to add up:
+  // rank 0's first embedding row, broadcast once per fit by an all-reduce (the others contribute
+  // zeros); the reduced tiles are all-reduced between the reduction and the finalize kernel.
   const bool sharded = o->sharded != 0 && o->iterations > 0;
   if (sharded && !h->comm) return PBBSS_ERR_INVALID_ARG;  // pbbss_comm_create first
-  if (sharded && g_full) return PBBSS_ERR_UNSUPPORTED;
   pbbss::PartialReduce all_ranks{
       [](void* ctx, double* buf, size_t count, hipStream_t st) -> int {
         return pbbss::comm_all_reduce_f64(static_cast<pbbss_handle_t>(ctx)->comm, buf, count, st);
@@ -1744,7 +1745,8 @@ PBBSS_API int pbbss_joint_fit(pbbss_handle_t h, const void* observation, const v
                               : 0) +
                       WorkCarver::pad(nconst * 8) + WorkCarver::pad(64) +
                       WorkCarver::pad((size_t)F * K * 8) +
-                      WorkCarver::pad((size_t)kJointFinHelpers * 2 * K * (E + 1) * 8);
+                      WorkCarver::pad((size_t)kJointFinHelpers * 2 * K * (E + 1) * 8) +
+                      WorkCarver::pad((size_t)E * 8);
   void* w = handle_work(h, need);
   if (!w) return PBBSS_ERR_HIP;
   WorkCarver wc(w, need);
@@ -1764,6 +1766,7 @@ PBBSS_API int pbbss_joint_fit(pbbss_handle_t h, const void* observation, const v
   int32_t* gst = reinterpret_cast<int32_t*>(wc.take<char>(64));  // status of the spectral half
   double* lndet = wc.take<double>((size_t)F * K);  // rotated loop: ln det B_fk of the current model
   double* fin_tmp = wc.take<double>((size_t)kJointFinHelpers * 2 * K * (E + 1));
+  double* gshift = wc.take<double>((size_t)E);  // sharded full covariance: the common shift
   // generic-size spatial half: M-step weights, covariances, inverse state, class sums, zero-frame
   // flags, frame-contiguous copy of the observation
   double* g_mw = gen ? wc.take<double>(nfkt) : nullptr;
@@ -1780,6 +1783,16 @@ PBBSS_API int pbbss_joint_fit(pbbss_handle_t h, const void* observation, const v
   TimedRegion tr(h, s);
   int rc = pbbss::launch_embed_prepare(embedding, o->embedding_is_f64, 1, N, E, 0, yd, nullptr, s);
   if (rc != PBBSS_OK) return rc;
+  if (sharded && g_full) {
+    // rank 0's first embedding row (converted to float64) on every rank
+    if (h->comm_rank == 0) {
+      rc = pbbss::launch_first_row_f64(embedding, o->embedding_is_f64, E, gshift, s);
+      if (rc != PBBSS_OK) return rc;
+    } else if (hipMemsetAsync(gshift, 0, (size_t)E * 8, s) != hipSuccess) {
+      return PBBSS_ERR_HIP;
+    }
+    if ((rc = all_ranks.fn(all_ranks.ctx, gshift, (size_t)E, s)) != PBBSS_OK) return rc;
+  }
   if (has_model) {
     if ((rc = copy_d2d(out_eigvec, in_eigvec, (size_t)F * K * D * D * 16, s)) != PBBSS_OK) return rc;
     if ((rc = copy_d2d(out_eigval, in_eigval, (size_t)F * K * D * 8, s)) != PBBSS_OK) return rc;
@@ -2016,7 +2029,8 @@ PBBSS_API int pbbss_joint_fit(pbbss_handle_t h, const void* observation, const v
       // covariance and the factorisation the next E-step needs
       if ((rc = pbbss::launch_fkt_to_kn(src, saliency, F, K, T, wkn, s)) != PBBSS_OK) return rc;
       rc = pbbss::launch_gauss_full_fit(embedding, o->embedding_is_f64, 1, N, E, K, wkn, nullptr,
-                                        gpart, out_mean, out_scale, mq, offset, nullptr, gst, s);
+                                        gpart, out_mean, out_scale, mq, offset, nullptr, gst, s,
+                                        sharded ? gshift : nullptr, reduce);
       mq_fresh = true;
     } else {
       rc = pbbss::launch_embed_fit(o->kind, embedding, o->embedding_is_f64, 1, N, E, K, src, T,

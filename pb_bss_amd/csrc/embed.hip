@@ -1978,8 +1978,20 @@ int launch_joint_weight(int mode, const double* aff, const double* sal, int64_t 
 }
 
 namespace {
+__global__ void first_row_f64_kernel(const void* y, int y_is_f64, int E, double* out) {
+  const int d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d < E)
+    out[d] = y_is_f64 ? static_cast<const double*>(y)[d] : (double)static_cast<const float*>(y)[d];
+}
+
 __global__ void or_status_kernel(const int32_t* src, int32_t* dst) { dst[0] |= src[0]; }
 }  // namespace
+int launch_first_row_f64(const void* y, int y_is_f64, int E, double* out, hipStream_t s) {
+  hipLaunchKernelGGL(first_row_f64_kernel, dim3((unsigned)((E + 63) / 64)), dim3(64), 0, s, y,
+                     y_is_f64, E, out);
+  return ok_or_hip();
+}
+
 int launch_or_status(const int32_t* src, int32_t* dst, hipStream_t s) {
   hipLaunchKernelGGL(or_status_kernel, dim3(1), dim3(1), 0, s, src, dst);
   return ok_or_hip();

@@ -129,6 +129,8 @@ size_t diag_consts_doubles(int K, int E);
 int launch_diag_estep(const void* yd, int y_is_f64, int64_t N, int E, int K, const double* mean,
                       const double* cov, double out_scale, int64_t Tin, double* consts,
                       double* out_lp, hipStream_t s);
+// first row of a real (N, E) array as float64 (the common shift of a sharded full-covariance fit)
+int launch_first_row_f64(const void* y, int y_is_f64, int E, double* out, hipStream_t s);
 // (F, K, T) <-> (K, F*T) for the full-covariance kernels of gauss_full.hip
 int launch_fkt_to_kn(const double* aff, const double* sal, int64_t F, int K, int T, double* out,
                      hipStream_t s);

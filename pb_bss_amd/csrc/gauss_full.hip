@@ -44,7 +44,7 @@ template <int NT, typename TS>
 __global__ void __launch_bounds__(kGfThreads)
     gf_scatter_kernel(const TS* __restrict__ y, int64_t N, int E, int K,
                       const double* __restrict__ aff, const double* __restrict__ sal, int C,
-                      int64_t Lw, double* __restrict__ part) {
+                      int64_t Lw, double* __restrict__ part, const double* __restrict__ gshift) {
   constexpr int NTT = NT * (NT + 1) / 2;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -57,7 +57,9 @@ __global__ void __launch_bounds__(kGfThreads)
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int dim = 16 * t + i;
-    shift[t] = (dim < E) ? (double)yb[dim] : 0.0;  // c = row 0 of the mixture
+    // c = row 0 of the mixture, or the caller's shift (bins sharded over ranks: every rank must
+    // subtract the SAME c for the partial sums to add up)
+    shift[t] = (dim < E) ? (gshift ? gshift[dim] : (double)yb[dim]) : 0.0;
   }
   double4_t acc[NTT];
 #pragma unroll
@@ -328,7 +330,7 @@ __global__ void __launch_bounds__(kGfThreads)
     gf_finalize_kernel(const double* __restrict__ gsum, const TS* __restrict__ y, int64_t N,
                        int E, int K, double* __restrict__ out_mean, double* __restrict__ out_cov,
                        double* out_mq, double* out_offset, double* out_s0,
-                       int32_t* out_status) {
+                       int32_t* out_status, const double* __restrict__ gshift) {
   constexpr int NTT = NT * (NT + 1) / 2;
   constexpr int P = 16 * NT;
   extern __shared__ double sm[];
@@ -366,7 +368,8 @@ __global__ void __launch_bounds__(kGfThreads)
   if (out_s0 && tid == 0) out_s0[(size_t)b * K + k] = s0;
   double* mean = out_mean + ((size_t)b * K + k) * E;
   double* cov = out_cov + ((size_t)b * K + k) * (size_t)E * E;
-  for (int d = tid; d < E; d += kGfThreads) mean[d] = (double)yb[d] + G[E * (P + 1) + d] / den;
+  for (int d = tid; d < E; d += kGfThreads)
+    mean[d] = (gshift ? gshift[d] : (double)yb[d]) + G[E * (P + 1) + d] / den;
   for (int idx = tid; idx < E * E; idx += kGfThreads) {
     const int r = idx / E, cc = idx % E;
     // sum w (y - mean)(y - mean)^T with y - mean = (y - c) - m',  m' = S1' / den
@@ -604,7 +607,8 @@ int gf_chunks(int64_t B, int K, int64_t N) {
 template <int NT, typename TS>
 int gf_fit_go(const void* y, int64_t B, int64_t N, int E, int K, const double* w,
               const double* sal, double* part, double* out_mean, double* out_cov, double* out_mq,
-              double* out_offset, double* out_s0, int32_t* out_status, hipStream_t s) {
+              double* out_offset, double* out_s0, int32_t* out_status, hipStream_t s,
+              const double* gshift, const PartialReduce* reduce) {
   constexpr int P = 16 * NT;
   const int C = gf_chunks(B, K, N);
   int64_t Lw = (N + (int64_t)C * kGfWaves - 1) / ((int64_t)C * kGfWaves);
@@ -612,7 +616,7 @@ int gf_fit_go(const void* y, int64_t B, int64_t N, int E, int K, const double* w
   constexpr int NTT = NT * (NT + 1) / 2;
   hipLaunchKernelGGL((gf_scatter_kernel<NT, TS>), dim3((unsigned)C, (unsigned)K, (unsigned)B),
                      dim3(kGfThreads), (kGfWaves - 1) * NTT * 256 * sizeof(double), s,
-                     static_cast<const TS*>(y), N, E, K, w, sal, C, Lw, part);
+                     static_cast<const TS*>(y), N, E, K, w, sal, C, Lw, part, gshift);
   size_t ldsd = (size_t)P * (P + 1);
   if (out_mq && 2 * (size_t)E * (E + 1) > ldsd) ldsd = 2 * (size_t)E * (E + 1);
   const size_t lds = ldsd * sizeof(double);
@@ -623,9 +627,12 @@ int gf_fit_go(const void* y, int64_t B, int64_t N, int E, int K, const double* w
   double* gsum = part + (size_t)B * K * C * NTT * 256;  // behind the workgroup partials
   hipLaunchKernelGGL(gf_reduce_kernel, dim3((unsigned)NTT, (unsigned)K, (unsigned)B),
                      dim3(kGfThreads), 0, s, part, C, NTT, K, gsum);
+  if (reduce) {  // bins sharded over ranks: the reduced Gram tiles of all ranks (common shift)
+    if (int rc = reduce->fn(reduce->ctx, gsum, (size_t)B * K * NTT * 256, s); rc != PBBSS_OK) return rc;
+  }
   hipLaunchKernelGGL(kfn, dim3((unsigned)K, (unsigned)B), dim3(kGfThreads), lds, s, gsum,
                      static_cast<const TS*>(y), N, E, K, out_mean, out_cov, out_mq, out_offset,
-                     out_s0, out_status);
+                     out_s0, out_status, gshift);
   return gf_ok();
 }
 
@@ -677,11 +684,13 @@ size_t gauss_full_partial_doubles(int64_t B, int64_t N, int E, int K) {
 int launch_gauss_full_fit(const void* y, int y_is_f64, int64_t B, int64_t N, int E, int K,
                           const double* weights, const double* sal, double* part,
                           double* out_mean, double* out_cov, double* out_mq, double* out_offset,
-                          double* out_s0, int32_t* out_status, hipStream_t s) {
+                          double* out_s0, int32_t* out_status, hipStream_t s,
+                          const double* shift, const PartialReduce* reduce) {
   if (E < 1 || E > kGaussFullMaxE || K < 1 || B < 1 || B > 65535 || K > 65535)
     return PBBSS_ERR_UNSUPPORTED;
+  if ((shift || reduce) && B != 1) return PBBSS_ERR_INVALID_ARG;  // one mixture over the ranks
   PBBSS_GF_DISPATCH(gf_fit_go, y, B, N, E, K, weights, sal, part, out_mean, out_cov, out_mq,
-                    out_offset, out_s0, out_status, s)
+                    out_offset, out_s0, out_status, s, shift, reduce)
 }
 
 int launch_gauss_full_weights(const double* s0, int64_t B, int K, int mode, double* out_weight,

@@ -4,6 +4,7 @@
 #include <stddef.h>
 #include <stdint.h>
 #include "pbbss.h"
+#include "embed.hpp"  // PartialReduce
 
 namespace pbbss {
 constexpr int kGaussFullMaxE = 63;  // augmented vector [y - c; 1] in at most four 16-blocks
@@ -20,7 +21,11 @@ size_t gauss_full_partial_doubles(int64_t B, int64_t N, int E, int K);
 int launch_gauss_full_fit(const void* y, int y_is_f64, int64_t B, int64_t N, int E, int K,
                           const double* weights, const double* sal, double* part,
                           double* out_mean, double* out_cov, double* out_mq, double* out_offset,
-                          double* out_s0, int32_t* out_status, hipStream_t s);
+                          double* out_s0, int32_t* out_status, hipStream_t s,
+                          // bins sharded over ranks (B = 1): `shift` (E) is the common centre c of
+                          // the augmented vectors (null: row 0 of y), `reduce` sums the Gram tiles
+                          // over the ranks between the reduction and the finalize kernel
+                          const double* shift = nullptr, const PartialReduce* reduce = nullptr);
 // mixture weights from the weight sums: mode 0 L1-normalised over the classes, 1 uniform
 int launch_gauss_full_weights(const double* s0, int64_t B, int K, int mode, double* out_weight,
                               hipStream_t s);

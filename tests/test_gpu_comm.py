@@ -117,6 +117,7 @@ def test_comm_info_reports_what_rccl_sees(world1_nccl):
     ('gaussian', dict()),
     ('gaussian', dict(weight_constant_axis=(-3, -1))),
     ('gaussian', dict(weight_constant_axis=(-3,), covariance_type='diagonal')),
+    ('gaussian', dict(covariance_type='full')),   # common scatter shift + all-reduced Gram tiles
     ('vmf', dict(weight_constant_axis=(-3, -1), max_concentration=80.)),
 ])
 def test_sharded_joint_fit_world1_equals_oracle(world1_nccl, kind, kw):
@@ -286,6 +287,14 @@ def _multi_gpu_worker(rank, world, port, one_device, ret):
             rj = oe.joint_fit('gaussian', Yj.astype(np.complex128), ej.astype(np.float64), ij, 5)
             wj = oe.joint_model_predict(rj, Yj.astype(np.complex128), ej.astype(np.float64))
             checks['joint_sharded'] = float(np.abs(_lib.to_host(mj) - wj).max()) < 1e-6
+            # full covariance: every rank centres its scatter on rank 0's first row, the Gram
+            # tiles are all-reduced inside the library
+            mf = sharding.fit_predict_sharded_joint(GCACGMMTrainer(), Yj, ej, ij, iterations=4,
+                                                    covariance_type='full')
+            rf = oe.joint_fit('gaussian', Yj.astype(np.complex128), ej.astype(np.float64), ij, 4,
+                              covariance_type='full')
+            wf = oe.joint_model_predict(rf, Yj.astype(np.complex128), ej.astype(np.float64))
+            checks['joint_sharded_full'] = float(np.abs(_lib.to_host(mf) - wf).max()) < 1e-6
         ret[rank] = checks
     except Exception as e:  # noqa: BLE001 -- reported to the parent, which fails the test
         import traceback
