@@ -418,9 +418,10 @@ typedef struct pbbss_cwmm_opts {
   int32_t y_is_c128;
   int32_t final_predict;
   int32_t n_coef;        /* number of B-spline coefficients */
-  int32_t group;         /* weight_mode PBBSS_WEIGHT_SHARED_K (weight_constant_axis (-3, -1),
-                          * cwmm.py:217-240): consecutive problems (the bins of an utterance) that
-                          * share one weight set; out_weight is then (B / group, K).  One cooperative
+  int32_t group;         /* weight_mode PBBSS_WEIGHT_SHARED_K / _KT (weight_constant_axis (-3, -1) /
+                          * (-3,), cwmm.py:217-240): consecutive problems (the bins of an utterance)
+                          * that share one weight set; out_weight is then (B / group, K) /
+                          * (B / group, K, T).  One cooperative
                           * launch (D <= 8, K <= 4, frames LDS-resident, a group co-resident), else
                           * PBBSS_ERR_UNSUPPORTED and the caller runs the loop step by step.  A grid
                           * barrier that times out poisons every status word (pbbss_split_error).

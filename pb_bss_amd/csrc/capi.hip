@@ -1141,7 +1141,8 @@ PBBSS_API int pbbss_cwmm_fit(pbbss_handle_t h, const void* y, int64_t B, int T, 
     return PBBSS_ERR_INVALID_ARG;
   // PBBSS_WEIGHT_SHARED_K (round 4): weights averaged over groups of `opts->group` consecutive
   // problems (the bins of an utterance), fused kernels only, fit from affiliations only
-  const bool shared_k = o->weight_mode == PBBSS_WEIGHT_SHARED_K;
+  const bool shared_k = o->weight_mode == PBBSS_WEIGHT_SHARED_K ||
+                        o->weight_mode == PBBSS_WEIGHT_SHARED_KT;  // (group, K) / (group, K, T)
   if (o->weight_mode < 0 || (o->weight_mode > 1 && !shared_k)) return PBBSS_ERR_INVALID_ARG;
   if (shared_k && (o->group < 1 || B % o->group != 0 || !has_gamma || o->iterations < 1))
     return PBBSS_ERR_INVALID_ARG;

@@ -88,10 +88,15 @@ static int cw_launch_shared(WatsonArgs wa, const EmLaunchCfg& cfg, hipStream_t s
   const size_t n_cnt = (size_t)ngroups * 16 * sizeof(unsigned);
   const size_t head = (n_cnt + 255) & ~(size_t)255;
   const size_t n_gsum = (size_t)2 * a.B * K * sizeof(double);
-  char* ws = static_cast<char*>(cfg.get_scratch(cfg.scratch_ctx, head + n_gsum));
+  const bool kt = a.weight_mode == PBBSS_WEIGHT_SHARED_KT;
+  const size_t n_gaff = kt ? (size_t)2 * a.B * K * a.T * sizeof(double) : 0;
+  const size_t n_gw = kt ? (size_t)2 * ngroups * K * a.T * sizeof(double) : 0;
+  char* ws = static_cast<char*>(cfg.get_scratch(cfg.scratch_ctx, head + n_gsum + n_gaff + n_gw));
   if (!ws) return PBBSS_ERR_HIP;
   a.gcount = reinterpret_cast<unsigned*>(ws);
   a.gsum = reinterpret_cast<double*>(ws + head);
+  a.gaff = kt ? reinterpret_cast<double*>(ws + head + n_gsum) : nullptr;
+  a.gw = kt ? reinterpret_cast<double*>(ws + head + n_gsum + n_gaff) : nullptr;
   a.xerror = reinterpret_cast<int*>(cfg.xbuf + 128);
   a.xepoch = 0;
   a.spin_limit = cfg.spin_limit;
@@ -113,7 +118,8 @@ static int cw_launch_shared(WatsonArgs wa, const EmLaunchCfg& cfg, hipStream_t s
 
 template <int K, typename YS>
 static int cw_launch_one(const WatsonArgs& wa, const EmLaunchCfg& cfg, hipStream_t stream) {
-  if (wa.em.weight_mode == PBBSS_WEIGHT_SHARED_K) return cw_launch_shared<K, YS>(wa, cfg, stream);
+  if (wa.em.weight_mode == PBBSS_WEIGHT_SHARED_K || wa.em.weight_mode == PBBSS_WEIGHT_SHARED_KT)
+    return cw_launch_shared<K, YS>(wa, cfg, stream);
   if (WatsonKernel<PBBSS_EM_D, K, YS, false>::lds_bytes(wa.em.T) > cfg.lds_limit)
     return cw_launch_variant<K, YS, true>(wa, cfg, stream);
   // 2^n + 1 bins: the r remainder problems would put one more full workgroup on r compute units

@@ -132,9 +132,13 @@ struct WatsonKernel {
 
   // tf: first frame of this workgroup's window (split groups); the (B, K, T) / (B, T) arrays are
   // indexed with the whole problem's row stride
+  // w_kt: frame-varying weights (K, T) of the problem's group (weight_constant_axis (-3,)) or null
+  // (the per-class weights in LDS); pub_kt: !FINAL -- the masked affiliations (K, T) of this
+  // problem for the group's reduction (WatsonShared)
   template <bool FINAL>
   static __device__ void phase_e(const WatsonArgs& wa, const Lds& L, int64_t b, int tid, int wave,
-                                 int lane, int tf = 0) {
+                                 int lane, int tf = 0, const double* w_kt = nullptr,
+                                 double* pub_kt = nullptr) {
     tid = opaque(tid);
     lane = opaque(lane);
     const EmArgs& a = wa.em;
@@ -159,7 +163,9 @@ struct WatsonKernel {
       double g[K], den = 0.0;
 #pragma unroll
       for (int k = 0; k < K; ++k) {
-        double w = L.wgt[k];
+        const double w = w_kt ? __hip_atomic_load(w_kt + (size_t)k * TS + tf + t, __ATOMIC_RELAXED,
+                                                  __HIP_MEMORY_SCOPE_AGENT)
+                              : L.wgt[k];
         g[k] = exp(lp[k] - mx) * w;  // mixture_model_utils.py:32-37
         den += g[k];
       }
@@ -176,6 +182,9 @@ struct WatsonKernel {
           }
         } else {
           double gs = ok ? gam * sal : 0.0;
+          if (pub_kt && ok)
+            __hip_atomic_store(pub_kt + (size_t)k * TS + tf + t, gs, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
           if (ok) L.wbuf[(size_t)k * L.Tp + t] = gs * inv;  // complex_watson.py:306-309
           s[k] += gs;
         }
@@ -202,8 +211,11 @@ struct WatsonKernel {
       double inv = L.inv_n2[t];
 #pragma unroll
       for (int k = 0; k < K; ++k) {
-        double g = a.gamma0[((size_t)b * K + k) * TS + tf + t] * sal;
+        const size_t idx = ((size_t)b * K + k) * TS + tf + t;
+        double g = a.gamma0[idx] * sal;
         L.wbuf[(size_t)k * L.Tp + t] = g * inv;
+        if (a.gaff && a.weight_mode == PBBSS_WEIGHT_SHARED_KT)  // parity 0: iteration 0
+          __hip_atomic_store(a.gaff + idx, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s[k] += g;
       }
     }
@@ -460,13 +472,23 @@ struct WatsonShared {
     __syncthreads();
     Base::phase_load(a, L, b, tid);
     __syncthreads();
+    const bool kt = (a.weight_mode == PBBSS_WEIGHT_SHARED_KT);
+    const int TS = Base::t_stride(a);
     W::phase_init_gamma(a, L, b, tid, wave, lane);  // the fit starts from affiliations
+    if (kt) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     double pvre = 0.0, pvim = 0.0;
     for (int it = 0; it < a.iterations; ++it) {
       if (it > 0) {
-        Base::shared_acquire_k(a, L, b, it - 1, tid, wave, lane);  // group weights -> L.wgt
-        W::template phase_e<false>(wa, L, b, tid, wave, lane);
+        if (kt) {  // (-3,): weights (K, T) of the group, the E-step publishes its masked affiliations
+          double* pub = a.gaff + ((size_t)(it & 1) * a.B + b) * K * TS;
+          const double* w_kt = Base::shared_acquire_kt(a, b, it - 1, tid);
+          W::template phase_e<false>(wa, L, b, tid, wave, lane, 0, w_kt, pub);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {   // (-3, -1): weights (K) of the group -> L.wgt
+          Base::shared_acquire_k(a, L, b, it - 1, tid, wave, lane);
+          W::template phase_e<false>(wa, L, b, tid, wave, lane);
+        }
         __syncthreads();
       }
       Base::shared_post(a, L, b, it, tid);
@@ -480,18 +502,29 @@ struct WatsonShared {
       const bool last = (it == a.iterations - 1);
       if (wave < K) W::factor_class(wa, L, knot1, jtab, b, wave, lane, last, it > 0, pvre, pvim);
       __syncthreads();
+      if (kt) Base::shared_reduce_kt(a, L, b, it, tid, wave, lane);
     }
     const int64_t grp = b / a.wgroup;
-    Base::shared_acquire_k(a, L, b, a.iterations - 1, tid, wave, lane);
-    if (a.out_weight_shared && b == grp * a.wgroup && tid < K)
-      a.out_weight_shared[(size_t)grp * K + tid] = L.wgt[tid];
+    const double* w_fin = nullptr;
+    if (kt) {
+      w_fin = Base::shared_acquire_kt(a, b, a.iterations - 1, tid);
+      if (a.out_weight_shared && b == grp * a.wgroup) {
+        for (int i = tid; i < K * TS; i += kEmThreads)
+          a.out_weight_shared[(size_t)grp * K * TS + i] =
+              __hip_atomic_load(w_fin + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    } else {
+      Base::shared_acquire_k(a, L, b, a.iterations - 1, tid, wave, lane);
+      if (a.out_weight_shared && b == grp * a.wgroup && tid < K)
+        a.out_weight_shared[(size_t)grp * K + tid] = L.wgt[tid];
+    }
     if (tid < K && a.out_status) {
       int st = L.status[tid];
       if (Base::split_failed(a))
         st |= PBBSS_ST_EIG_NOCONV | PBBSS_ST_NONFINITE;  // a hand-off timed out: results are void
       a.out_status[(size_t)b * K + tid] = st;
     }
-    if (a.final_predict) W::template phase_e<true>(wa, L, b, tid, wave, lane);
+    if (a.final_predict) W::template phase_e<true>(wa, L, b, tid, wave, lane, 0, w_fin);
   }
 };
 

@@ -149,13 +149,14 @@ class CWMMTrainer:
         axes = {a % (len(indep) + 2) - (len(indep) + 2) for a in (
             (weight_constant_axis,) if isinstance(weight_constant_axis, int)
             else weight_constant_axis)}
-        if axes == {-3, -1} and len(indep) >= 1 and inline_permutation_aligner is None:
+        if axes in ({-3, -1}, {-3}) and len(indep) >= 1 and inline_permutation_aligner is None:
             group = indep[-1]
+            kt = axes == {-3}
             r = engine.cwmm_fit(yb, K, spline, gamma0=gamma0.reshape(-1, K, N).contiguous(),
-                                iterations=iterations, saliency=sal,
-                                weight_mode=_lib.WEIGHT_SHARED_K, group=group)
+                                iterations=iterations, saliency=sal, group=group,
+                                weight_mode=_lib.WEIGHT_SHARED_KT if kt else _lib.WEIGHT_SHARED_K)
             if r is not None:
-                weight = r['weight'].reshape(*indep[:-1], 1, K, 1)
+                weight = r['weight'].reshape(*indep[:-1], 1, K, N if kt else 1)
                 return CWMM(
                     weight=as_result(weight, like_torch),
                     complex_watson=ComplexWatson(

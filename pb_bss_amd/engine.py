@@ -522,7 +522,7 @@ def cwmm_fit(y, K, spline, *, gamma0=None, model=None, iterations=100, saliency=
     dev = y.device
     B, T, D = y.shape
     is128 = y.dtype == t.complex128
-    shared = weight_mode == _lib.WEIGHT_SHARED_K
+    shared = weight_mode in (_lib.WEIGHT_SHARED_K, _lib.WEIGHT_SHARED_KT)
     opts = _lib.CwmmOpts(
         iterations=int(iterations), weight_mode=int(weight_mode), y_is_c128=int(is128),
         final_predict=int(bool(final_predict or want_log_pdf)),
@@ -542,7 +542,8 @@ def cwmm_fit(y, K, spline, *, gamma0=None, model=None, iterations=100, saliency=
     def launch():
         out_mode = t.empty((B, K, D), dtype=t.complex128, device=dev)
         out_conc = t.empty((B, K), dtype=f64, device=dev)
-        out_w = t.empty((B // group, K) if shared else (B, K), dtype=f64, device=dev)
+        out_w = t.empty(((B // group, K, T) if weight_mode == _lib.WEIGHT_SHARED_KT else
+                         (B // group, K)) if shared else (B, K), dtype=f64, device=dev)
         out_st = t.zeros((B, K), dtype=t.int32, device=dev)
         out_aff = t.empty((B, K, T), dtype=f64, device=dev) if final_predict else None
         out_lp = t.empty((B, K, T), dtype=f64, device=dev) if want_log_pdf else None
