@@ -335,10 +335,35 @@ def canonical_call(Y0, reps=10):
                     CACGMMTrainer().fit(Yin, num_classes=K, iterations=10)
                 torch.cuda.synchronize()
                 out[f'{mode}_init_{resident}_ms'] = (time.perf_counter() - t0) / reps * 1e3
+    # cacgmm.py:260-267: the DHTV aligner between E- and M-step of every iteration (step-wise loop)
+    from pb_bss_amd.permutation_alignment import DHTVPermutationAlignment
+    try:
+        aligner = DHTVPermutationAlignment.from_stft_size(2 * (Y0.shape[0] - 1))
+    except ValueError:  # no preset for this STFT size
+        aligner = None
+    if aligner is not None:
+        rng = np.random.default_rng(11)
+        g0 = rng.uniform(size=(Y0.shape[0], K, Y0.shape[1]))
+        g0 = _lib.to_device(g0 / g0.sum(1, keepdims=True))
+        kw = dict(weight_constant_axis=(-3,), inline_permutation_aligner=aligner)
+        settled = CACGMMTrainer().fit(Yd, initialization=g0, iterations=40, **kw)
+        for tag, start, n in (('inline_aligner_first_20_ms_per_iteration', g0, 20),
+                              ('inline_aligner_settled_ms_per_iteration', settled, 20)):
+            best = None
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                CACGMMTrainer().fit(Yd, initialization=start, iterations=n, **kw)
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t0) / n * 1e3
+                best = dt if best is None else min(best, dt)
+            out[tag] = best
     out['what'] = ('CACGMMTrainer().fit(Y, num_classes=3, iterations=10), ms per call: random '
                    'initialisation drawn by NumPy\'s global generator (the reference\'s stream; '
                    'default) or on the device (opt-in, a different stream), observation given as a '
-                   'NumPy array or already resident')
+                   'NumPy array or already resident; inline_aligner_*: fit(..., weight_constant_axis='
+                   '(-3,), inline_permutation_aligner=DHTVPermutationAlignment.from_stft_size(...)), '
+                   'ms per EM iteration from a random start and resumed after 40 iterations')
     return out
 
 

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define PBBSS_VERSION 400 /* 0.4.0: pbbss_split_reset, pbbss_set_spin_limit, pbbss_reference_channel_terms,
+#define PBBSS_VERSION 401 /* 0.4.1: pbbss_set_dhtv_probe; 0.4.0: pbbss_split_reset, pbbss_set_spin_limit, pbbss_reference_channel_terms,
                              pbbss_rank_one_approximation, pbbss_matvec (0.3.0: em_opts.precision,
                              mix_opts.sharded, pbbss_comm_info) */
 
@@ -746,6 +746,18 @@ int pbbss_set_split_tail(pbbss_handle_t h, int enable);
  * utterance, >= 2 = frame-slice kernel with at most that many workgroups per utterance (64 or
  * 128 frames each), -2..-32 = bin-chunk team kernel of that size (A/B). */
 int pbbss_set_dhtv_team(pbbss_handle_t h, int workgroups_per_utterance);
+/* pbbss_dhtv_calculate_mapping, frame-slice kernel only: evaluate the first iteration of EVERY
+ * plan segment on the input as it stands (all segments at once, P teams per utterance) before
+ * the plan proper.  A segment in which no bin asks for a permutation -- and none of whose bins an
+ * earlier segment has permuted since -- would break out of the sequential walk of
+ * permutation_alignment.py:331-353 unchanged, so the plan kernel skips it; when that holds for
+ * every segment the mapping is the identity and the plan kernel returns at once.  Results are
+ * identical with and without the probe.  F = 513, T = 500, K = 3 (profiles/r04_i_inline_aligner.txt):
+ * probe 0.021 ms; plan 0.33 ms -> 0.22 ms with the ~10-40 flipped bins of the first EM iterations,
+ * ~0.1 ms with the 0-4 of a settled EM, ~0.003 ms for aligned masks.  Off by default (a one-shot
+ * alignment of freshly fitted masks touches every segment anyway); the inline aligner of
+ * CACGMMTrainer.fit (cacgmm.py:260-267) switches it on. */
+int pbbss_set_dhtv_probe(pbbss_handle_t h, int enable);
 int pbbss_split_error(pbbss_handle_t h, int* out_flag);
 /* Consume a reported time-out: waits for the device, then re-zeroes the arrival counters of the
  * split / member protocols and the sticky flag of pbbss_split_error.  The Python layer calls it

@@ -55,7 +55,7 @@ EXPORTS = (
     'pbbss_reference_channel_terms', 'pbbss_rank_one_approximation', 'pbbss_matvec',
     'pbbss_distortionless_normalization', 'pbbss_zero_degree_normalization',
     'pbbss_condition_covariance', 'pbbss_apply_online_beamforming_vector',
-    'pbbss_set_dhtv_team', 'pbbss_stft_num_frames', 'pbbss_stft', 'pbbss_istft',
+    'pbbss_set_dhtv_team', 'pbbss_set_dhtv_probe', 'pbbss_stft_num_frames', 'pbbss_stft', 'pbbss_istft',
     'pbbss_pa_pairwise_mapping', 'pbbss_pa_compose_mapping', 'pbbss_pa_mapping_from_scores',
     'pbbss_gmm_fit', 'pbbss_gauss_full_fit', 'pbbss_gauss_full_log_pdf',
     'pbbss_gmm_full_fit',
@@ -164,6 +164,7 @@ def load():
         lib.pbbss_set_phase_profile.argtypes = [vp, vp]
         lib.pbbss_set_split_tail.argtypes = [vp, i32]
         lib.pbbss_set_dhtv_team.argtypes = [vp, i32]
+        lib.pbbss_set_dhtv_probe.argtypes = [vp, i32]
         lib.pbbss_split_error.argtypes = [vp, ctypes.POINTER(ctypes.c_int)]
         lib.pbbss_split_reset.argtypes = [vp]
         lib.pbbss_set_spin_limit.argtypes = [vp, ctypes.c_uint]

@@ -31,6 +31,7 @@ struct pbbss_handle_s {
   void* team_buf;     // control words + centroid partials of the DHTV team kernel
   size_t team_bytes;
   int dhtv_team;      // workgroups per utterance (0 = default, 1 = one-workgroup kernel)
+  int dhtv_probe;     // all-segments-at-once identity probe in front of the plan (pbbss_set_dhtv_probe)
   unsigned long long* prof;
   int timing;
   float last_ms;
@@ -346,6 +347,7 @@ PBBSS_API int pbbss_create(pbbss_handle_t* out, int device_id) {
     h->team_bytes = 0;
   }
   h->dhtv_team = 0;
+  h->dhtv_probe = 0;
   h->comm = nullptr;
   h->comm_world = 1;
   h->comm_rank = 0;
@@ -517,6 +519,12 @@ PBBSS_API int pbbss_set_dhtv_team(pbbss_handle_t h, int workgroups_per_utterance
       workgroups_per_utterance == -1)
     return PBBSS_ERR_INVALID_ARG;
   h->dhtv_team = workgroups_per_utterance;
+  return PBBSS_OK;
+}
+
+PBBSS_API int pbbss_set_dhtv_probe(pbbss_handle_t h, int enable) {
+  if (!h) return PBBSS_ERR_INVALID_ARG;
+  h->dhtv_probe = enable ? 1 : 0;
   return PBBSS_OK;
 }
 
@@ -1077,7 +1085,7 @@ PBBSS_API int pbbss_dhtv_calculate_mapping(pbbss_handle_t h, const double* mask,
   if (U <= 0 || F <= 0 || T <= 0 || P <= 0) return PBBSS_ERR_INVALID_ARG;
   return pbbss::launch_dhtv(mask, U, K, F, T, plan, P, optimal, metric, scratch, out_mapping, out_status,
                             h->cfg.lds_limit, h->cfg.num_cu, h->dhtv_team, h->team_buf,
-                            h->team_bytes, as_stream(stream));
+                            h->team_bytes, h->dhtv_probe, as_stream(stream));
 }
 
 PBBSS_API int pbbss_pa_pairwise_mapping(pbbss_handle_t h, const double* mask,

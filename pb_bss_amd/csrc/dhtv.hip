@@ -719,12 +719,27 @@ __global__ void __launch_bounds__(256)
   for (int t = threadIdx.x; t < T; t += blockDim.x) dst[t] = src[t] * sc;
 }
 
-template <int K, int NFR>
+//
+// PROBE instantiation (pbbss_set_dhtv_probe): masks that are ALREADY aligned -- every call of an
+// inline aligner after the EM has settled (cacgmm.py:260-267) -- still walk the plan segment by
+// segment, one exchange hop each (20 hops = 0.33 ms at F = 513).  But as long as nothing changes
+// the features never move, so the first iteration of EVERY segment can be evaluated on the
+// input as it stands, all segments at once on P teams of G workgroups: if no bin of any segment
+// asks for a permutation, the sequential walk would have found the same ("nothing_changed" in
+// each segment, :352-353) and the mapping is the identity.  Per segment: the probe raises
+// flag[u][segment] when a bin asks for a permutation (or when it cannot tell: non-finite scores,
+// a timed-out wait, no room for its exchange area); the plan kernel proper skips every segment
+// whose flag is down as long as none of its bins has been permuted by an earlier segment (the
+// composite mapping of all its bins is still the identity: the segment then sees exactly the
+// probe's input), and leaves at once when no flag is up.  A handful of flipped bins -- the usual
+// state between two EM iterations -- costs the segments around them only.
+// Same arithmetic as the plan kernel (same code), so both take identical decisions.
+template <int K, int NFR, bool PROBE>
 __global__ void __launch_bounds__(kSliceThreads)
     dhtv_slice_kernel(const double* __restrict__ mask, const double* __restrict__ scale_all,
                       double* feat_all, int32_t* mapping_all, const int32_t* __restrict__ plan,
                       int P, int F, int T, int optimal, int metric, int32_t* status, int G,
-                      unsigned* ctrl_all) {
+                      unsigned* ctrl_all, unsigned* probe_flag) {
   using C = SliceCfg<K, NFR>;
   constexpr int KK = C::KK, NS = C::NS, QS = C::QS, NC = C::NC, QC = C::QC, MAXP = C::MAXP,
                 TS = C::TS;
@@ -732,14 +747,36 @@ __global__ void __launch_bounds__(kSliceThreads)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l = lane & 15, q = lane >> 4;  // frame lane inside the row, row (= bin) inside the wave
   const int rowid = wave * 4 + q;          // bin slot of this row inside a pass
-  const int64_t u = blockIdx.x / G;
+  const int64_t team = blockIdx.x / G;  // PROBE: (utterance, segment); else the utterance
+  const int64_t u = PROBE ? team / P : team;
+  const int only_seg = PROBE ? (int)(team % P) : -1;
   const int g = blockIdx.x % G;
   const int t0 = g * TS;
   const double* m = mask + u * (int64_t)K * F * T;
   double* feat = feat_all + u * (int64_t)K * F * T;
   int32_t* mapping = mapping_all + u * (int64_t)K * F;
-  unsigned* ctrl = ctrl_all + u * 4;
-  const size_t NE = slice_entries(K, F);
+  unsigned* ctrl = ctrl_all + team * 4;
+  // plan kernel: bit s = the probe saw a change in segment s (or could not tell); all ones
+  // without a probe.  A segment whose bit is down and whose bins still carry the identity
+  // mapping has exactly the probe's input: its first iteration would change nothing -> skipped.
+  unsigned long long seg_changed = ~0ull;
+  if constexpr (!PROBE) {
+    if (probe_flag) {
+      seg_changed = 0ull;
+      for (int sg = 0; sg < P; ++sg)  // P <= 64 (launch_slice)
+        if (__hip_atomic_load(probe_flag + u * P + sg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+          seg_changed |= 1ull << sg;
+      if (seg_changed == 0ull) {
+        // nothing to permute in any segment: identity (non-finite rows were already reported
+        // by dhtv_rowscale_kernel)
+        if (g == 0)
+          for (int i = tid; i < K * F; i += kSliceThreads) mapping[i] = i / F;
+        return;
+      }
+    }
+  }
+  unsigned* my_flag = PROBE ? probe_flag + team : nullptr;
+  size_t NE = slice_entries(K, F);
   const size_t uni_n = (size_t)kSliceWaves * K * TS > NE ? (size_t)kSliceWaves * K * TS : NE;
   double* cent = reinterpret_cast<double*>(smem);  // [K][TS]
   double* inv = cent + (size_t)K * TS;             // [K][F]
@@ -747,6 +784,22 @@ __global__ void __launch_bounds__(kSliceThreads)
   int* mapw = reinterpret_cast<int*>(uni + uni_n);  // [F] composite mapping, 4 bits per class
   int* lastp = mapw + F;                            // [F] permutation of the last assignment (0 = none)
   double* xch = feat;                               // [2][G][NE]
+  if constexpr (PROBE) {
+    // one exchange area [G][NE(segment)] per segment, packed in plan order inside the
+    // utterance's scratch
+    size_t off = 0, mine_ne = 8;
+    for (int sg = 0; sg <= only_seg; ++sg) {
+      const int nbs = min(plan[3 * sg + 2], F) - max(plan[3 * sg + 1], 0);
+      mine_ne = slice_entries(K, nbs > 0 ? nbs : 0);
+      if (sg < only_seg) off += (size_t)G * mine_ne;
+    }
+    if (off + (size_t)G * mine_ne > (size_t)K * F * T) {  // no room: cannot tell
+      if (tid == 0) __hip_atomic_store(my_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;  // the whole team takes this branch
+    }
+    xch = feat + off;
+    NE = mine_ne;
+  }
   unsigned target = 0;
   int hop = 0;
   int nonfinite = 0;
@@ -811,12 +864,20 @@ __global__ void __launch_bounds__(kSliceThreads)
     }
   };
 
-  for (int seg = 0; seg < P; ++seg) {
+  for (int seg = PROBE ? only_seg : 0; seg < (PROBE ? only_seg + 1 : P); ++seg) {
     // segments are clipped to the bins that exist (the Python layer asserts it; a raw C caller may not)
-    const int iterations = plan[3 * seg], start = max(plan[3 * seg + 1], 0),
-              end = min(plan[3 * seg + 2], F);
+    const int iterations = PROBE ? min(plan[3 * seg], 1) : plan[3 * seg],
+              start = max(plan[3 * seg + 1], 0), end = min(plan[3 * seg + 2], F);
     const int nb = end - start;
     if (nb <= 0) continue;
+    if constexpr (!PROBE) {
+      if (seg < 64 && !((seg_changed >> seg) & 1ull)) {
+        int clean = 1;
+        for (int f = start + tid; f < end; f += kSliceThreads)
+          clean &= mapw[f] == pack_identity<K>();
+        if (__syncthreads_and(clean)) continue;  // every workgroup of the team decides alike
+      }
+    }
     const double inv_n = 1.0 / (double)nb;
     const int npass = (nb + kSliceBins - 1) / kSliceBins;
     // register-resident part of the window
@@ -951,6 +1012,12 @@ __global__ void __launch_bounds__(kSliceThreads)
         }
       }
       const int any = __syncthreads_or(changed);
+      if constexpr (PROBE) {
+        const int bad = __syncthreads_or(nonfinite);
+        if ((any || bad) && tid == 0)
+          __hip_atomic_store(my_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
       if (!any) break;  // nothing_changed (:352-353)
       // features[:, f, :] = features[perm, f, :] for the register-resident bins
 #pragma unroll
@@ -977,6 +1044,11 @@ __global__ void __launch_bounds__(kSliceThreads)
         }
       }
     }
+  }
+  if constexpr (PROBE) {
+    if (tid == 0 && __hip_atomic_load(ctrl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)
+      __hip_atomic_store(my_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
   }
   // ---- output: the reverse mapping (dhtv_features_kernel then writes the aligned features over
   // the exchange area)
@@ -1231,19 +1303,31 @@ template <int K, int NF>
 static bool slice_launch_one(const double* mask, int64_t U, int F, int T, const int32_t* plan, int P,
                              int optimal, int metric, double* feat, int32_t* mapping,
                              int32_t* status, int G, size_t lds, unsigned* ctrl, double* scale,
-                             hipStream_t s, int* rc) {
-  auto kfn = dhtv_slice_kernel<K, NF>;
+                             bool probe, hipStream_t s, int* rc) {
+  auto kfn = dhtv_slice_kernel<K, NF, false>;
+  auto pfn = dhtv_slice_kernel<K, NF, true>;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+      (probe && hipFuncSetAttribute(reinterpret_cast<const void*>(pfn),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+                    hipSuccess)) {
     *rc = PBBSS_ERR_HIP;
     return true;
   }
-  // row scales on the whole chip -> the plan on G workgroups per utterance -> aligned features
+  // row scales on the whole chip -> [probe: every segment at once on P teams per utterance] ->
+  // the plan on G workgroups per utterance -> aligned features
+  // control words: [4 per utterance][probe: 4 + 1 flag per (utterance, segment)]
   const int64_t rows = U * K * F;
+  unsigned* pctrl = ctrl + 4 * U;
+  unsigned* pflag = probe ? pctrl + 4 * U * P : nullptr;
+  const int nctrl = (int)(probe ? 4 * U + 5 * U * P : 4 * U);
   hipLaunchKernelGGL(dhtv_rowscale_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, mask,
-                     rows, T, K * F, metric == PBBSS_PA_COS ? 1 : 0, scale, status, ctrl, (int)(4 * U));
+                     rows, T, K * F, metric == PBBSS_PA_COS ? 1 : 0, scale, status, ctrl, nctrl);
+  if (probe)
+    hipLaunchKernelGGL(pfn, dim3((unsigned)(U * P * G)), dim3(kSliceThreads), lds, s, mask, scale,
+                       feat, mapping, plan, P, F, T, optimal, metric, status, G, pctrl, pflag);
   hipLaunchKernelGGL(kfn, dim3((unsigned)(U * G)), dim3(kSliceThreads), lds, s, mask, scale, feat,
-                     mapping, plan, P, F, T, optimal, metric, status, G, ctrl);
+                     mapping, plan, P, F, T, optimal, metric, status, G, ctrl, pflag);
   hipLaunchKernelGGL(dhtv_features_kernel, dim3((unsigned)rows), dim3(256), 0, s, mask, mapping,
                      scale, K, F, T, feat);
   *rc = hipGetLastError() == hipSuccess ? PBBSS_OK : PBBSS_ERR_HIP;
@@ -1253,7 +1337,7 @@ static bool slice_launch_one(const double* mask, int64_t U, int F, int T, const 
 static bool launch_slice(const double* mask, int64_t U, int K, int F, int T, const int32_t* plan,
                          int P, int optimal, int metric, double* feat, int32_t* mapping,
                          int32_t* status, size_t lds_limit, int num_cu, int want_team,
-                         unsigned* ctrl, double* scale, hipStream_t s, int* rc) {
+                         unsigned* ctrl, double* scale, bool want_probe, hipStream_t s, int* rc) {
   if (K > 5) return false;  // K*K scores per bin live in registers through the butterfly
   if (U * K * F > 2147483647LL) return false;
   for (int NF = 4; NF <= 8; NF *= 2) {  // frames per lane; 16 * NF frames per workgroup
@@ -1269,10 +1353,12 @@ static bool launch_slice(const double* mask, int64_t U, int K, int F, int T, con
     if (lds > lds_limit) continue;
     // exchange area inside the utterance's feature scratch
     if (2 * (size_t)G * slice_entries(K, F) > (size_t)K * F * T) continue;
+    // the probe's P teams per utterance must be co-resident as well (one workgroup per CU)
+    const bool probe = want_probe && P <= 64 && (int64_t)G * U * P <= num_cu;
 #define PBBSS_SLICE_CASE(KK, NN)                                                               \
   if (K == KK && NF == NN)                                                                     \
     return slice_launch_one<KK, NN>(mask, U, F, T, plan, P, optimal, metric, feat, mapping,    \
-                                    status, G, lds, ctrl, scale, s, rc);
+                                    status, G, lds, ctrl, scale, probe, s, rc);
     PBBSS_SLICE_CASE(1, 4) PBBSS_SLICE_CASE(1, 8)
     PBBSS_SLICE_CASE(2, 4) PBBSS_SLICE_CASE(2, 8)
     PBBSS_SLICE_CASE(3, 4) PBBSS_SLICE_CASE(3, 8)
@@ -1289,12 +1375,14 @@ static bool launch_slice(const double* mask, int64_t U, int K, int F, int T, con
 // frame-slice kernel does not take: K > 5, fewer than 128 frames, no room for the exchange area).
 int launch_dhtv(const double* mask, int64_t U, int K, int F, int T, const int32_t* plan, int P,
                 int optimal, int metric, double* feat, int32_t* mapping, int32_t* status,
-                size_t lds_limit,
-                int num_cu, int team_size, void* team_buf, size_t team_bytes, hipStream_t s) {
+                size_t lds_limit, int num_cu, int team_size, void* team_buf, size_t team_bytes,
+                int probe, hipStream_t s) {
   if (K < 1 || K > kDhtvMaxK) return PBBSS_ERR_UNSUPPORTED;
   if (metric < PBBSS_PA_COS || metric > PBBSS_PA_EUCLIDEAN) return PBBSS_ERR_INVALID_ARG;
   const size_t ctrl_bytes = (size_t)U * 4 * sizeof(unsigned);
-  const size_t ctrl_pad = (ctrl_bytes + 255) & ~(size_t)255;
+  // the frame-slice path's probe keeps 4 words and a flag per (utterance, segment)
+  const size_t ctrl_pad =
+      (ctrl_bytes + (probe ? (size_t)U * P * 5 * sizeof(unsigned) : 0) + 255) & ~(size_t)255;
   unsigned* ctrl = static_cast<unsigned*>(team_buf);
   // team buffer: [control words][row scales of the frame-slice path]
   const size_t scale_bytes = (size_t)U * K * F * sizeof(double);
@@ -1302,7 +1390,8 @@ int launch_dhtv(const double* mask, int64_t U, int K, int F, int T, const int32_
     int rc = PBBSS_OK;
     if (launch_slice(mask, U, K, F, T, plan, P, optimal, metric, feat, mapping, status, lds_limit,
                      num_cu, team_size, ctrl,
-                     reinterpret_cast<double*>(static_cast<char*>(team_buf) + ctrl_pad), s, &rc))
+                     reinterpret_cast<double*>(static_cast<char*>(team_buf) + ctrl_pad), probe != 0,
+                     s, &rc))
       return rc;
   }
   size_t lds = ((size_t)K * T + kDhtvWaves) * sizeof(double) + 16;

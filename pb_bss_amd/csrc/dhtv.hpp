@@ -11,7 +11,8 @@ namespace pbbss {
 constexpr int kDhtvTeamMax = 32;
 int launch_dhtv(const double* mask, int64_t U, int K, int F, int T, const int32_t* plan, int P,
                 int optimal, int metric, double* feat, int32_t* mapping, int32_t* status,
-                size_t lds_limit, int num_cu, int team_size, void* team_buf, size_t team_bytes, hipStream_t s);
+                size_t lds_limit, int num_cu, int team_size, void* team_buf, size_t team_bytes,
+                int probe, hipStream_t s);  // probe: frame-slice path, see dhtv_slice_kernel
 int launch_apply_mapping(const double* mask, const int32_t* mapping, int64_t U, int K, int F,
                          int T, double* out, hipStream_t s);
 // pairwise solvers (Oracle / Greedy alignment) and the assignment on given score matrices

@@ -466,7 +466,7 @@ class CACGMMTrainer:
     def _fit_stepwise(self, yb, indep, K, gamma0, model, iterations, saliency,
                       sal, act, weight_constant_axis, covariance_norm,
                       affiliation_eps, eigenvalue_floor, hermitize, aligner,
-                      like_torch, weight_hook=None):
+                      like_torch, weight_hook=None, _retry_team=True):
         """The reference loop (cacgmm.py:252-278) for the options that couple frequency bins
         (weight_constant_axis with independent axes, inline_permutation_aligner), one E-step
         and one M-step launch per iteration with the cross-bin reduction
@@ -493,6 +493,7 @@ class CACGMMTrainer:
             val = _lib.to_device(model.cacg.covariance_eigenvalues, t.float64).to(dev)
             weight = _lib.to_device(model.weight, t.float64).to(dev)
         device_aligner = aligner is not None and type(aligner).__module__.startswith('pb_bss_amd')
+        aligner_status = []  # device status words of the aligner, read once after the loop
         for _ in range(iterations):
             if vec is not None:
                 w = _weight_for_predict(weight, indep, K, N, dev)
@@ -506,7 +507,8 @@ class CACGMMTrainer:
                     if device_aligner:
                         aff, q = apply_inline_permutation_alignment(
                             affiliation=aff, quadratic_form=q,
-                            weight_constant_axis=weight_constant_axis, aligner=aligner)
+                            weight_constant_axis=weight_constant_axis, aligner=aligner,
+                            status_out=aligner_status)
                     else:  # a foreign (NumPy) aligner object: the one host excursion left
                         a_h, q_h = apply_inline_permutation_alignment(
                             affiliation=_lib.to_host(aff), quadratic_form=_lib.to_host(q),
@@ -532,6 +534,28 @@ class CACGMMTrainer:
                 layout=_lib.LAYOUT_DT, covariance_norm=covariance_norm,
                 eigenvalue_floor=eigenvalue_floor)
             vec, val = vec.reshape(*indep, K, D, D), val.reshape(*indep, K, D)
+        if aligner_status:
+            bits = int(np.bitwise_or.reduce(_lib.to_host(t.cat(aligner_status)).reshape(-1)))
+            if bits & _lib.ST_EIG_NOCONV and not bits & _lib.ST_NONFINITE and _retry_team:
+                # a wait between the workgroups that share the utterance ran out in one of the
+                # iterations (GPU shared with other work): nothing downstream of that mapping
+                # is valid -- run the loop again on the one-workgroup kernel
+                import warnings
+                warnings.warn('inline DHTV permutation alignment: the workgroups of the '
+                              'utterance were not co-resident (GPU shared with other work); '
+                              'running the fit again on the one-workgroup kernel', RuntimeWarning)
+                before = engine.dhtv_team(dev.index)
+                engine.set_dhtv_team(1, dev.index)
+                try:
+                    return self._fit_stepwise(
+                        yb, indep, K, gamma0, model, iterations, saliency, sal, act,
+                        weight_constant_axis, covariance_norm, affiliation_eps, eigenvalue_floor,
+                        hermitize, aligner, like_torch, weight_hook=weight_hook,
+                        _retry_team=False)
+                finally:
+                    engine.set_dhtv_team(before, dev.index)
+            if bits != 0:
+                raise ValueError('score matrix is infeasible')  # permutation_alignment.py:512-514
         return CACGMM(
             weight=as_result(weight, like_torch),
             cacg=ComplexAngularCentralGaussian(

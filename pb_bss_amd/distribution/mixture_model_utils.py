@@ -62,13 +62,18 @@ def log_pdf_to_affiliation(weight, log_pdf, source_activity_mask=None,
 
 
 def apply_inline_permutation_alignment(affiliation, *, quadratic_form=None,
-                                       weight_constant_axis, aligner):
+                                       weight_constant_axis, aligner, status_out=None):
     """Run a permutation-alignment solver between E- and M-step.
 
     Reference: mixture_model_utils.py:264-306.  affiliation / quadratic_form
     are (F, K, T); `aligner` is any object with
     calculate_mapping((K, F, T)) -> (K, F) and apply_mapping(x, mapping)
     (e.g. pb_bss.permutation_alignment.DHTVPermutationAlignment).
+
+    `status_out` (a list; not in the reference) opts a device caller into the asynchronous
+    route: with device tensors and an aligner that offers `calculate_mapping_async` the
+    solver's status words are appended to the list instead of being read back here, and the
+    caller checks them when it next synchronises.
     """
     msg = ('Inline permutation alignment needs affiliation.ndim == 3 '
            f'({affiliation.shape}) and a frequency-constant mixture weight '
@@ -78,6 +83,22 @@ def apply_inline_permutation_alignment(affiliation, *, quadratic_form=None,
     def swap(x):  # (F, K, T) <-> (K, F, T) for NumPy arrays and torch tensors alike
         return x.permute(1, 0, 2).contiguous() if hasattr(x, 'permute') else x.transpose(1, 0, 2)
 
+    if status_out is not None and hasattr(affiliation, 'permute') and affiliation.is_cuda \
+            and hasattr(aligner, 'calculate_mapping_async'):
+        # device loop (CACGMMTrainer._fit_stepwise): no host synchronisation per EM iteration --
+        # the status words are queued for the caller -- and the reverse mapping is applied as a
+        # gather along the class axis of the (F, K, T) arrays themselves, without the two
+        # transposed copies per array of the generic route below
+        import torch as t
+        F, K, T = affiliation.shape
+        mapping, st = aligner.calculate_mapping_async(
+            affiliation.to(t.float64).permute(1, 0, 2).contiguous()[None])
+        status_out.append(st)
+        idx = mapping[0].t().to(t.int64)[:, :, None].expand(F, K, T)
+        aligned = affiliation.gather(1, idx)
+        if quadratic_form is None:
+            return aligned
+        return aligned, quadratic_form.gather(1, idx)
     kft = swap(affiliation)
     mapping = aligner.calculate_mapping(kft)
     aligned = swap(aligner.apply_mapping(kft, mapping))

@@ -642,6 +642,14 @@ def set_dhtv_team(workgroups_per_utterance, device_index=None):
     _DHTV_TEAM[_handle_key(device_index)] = int(workgroups_per_utterance)
 
 
+def set_dhtv_probe(enable, device_index=None):
+    """pbbss_set_dhtv_probe: evaluate all plan segments at once in front of the DHTV plan and
+    skip the plan when the masks are aligned already (same results; for callers that align
+    every EM iteration)."""
+    _lib.check(_lib.load().pbbss_set_dhtv_probe(_lib.handle(device_index), int(bool(enable))),
+               'set_dhtv_probe')
+
+
 def dhtv_team(device_index=None):
     """The team setting in force on this thread's handle: its last set_dhtv_team, else
     PBBSS_DHTV_TEAM (read by the library when the handle is created), else 0 = automatic."""

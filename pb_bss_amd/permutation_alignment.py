@@ -142,6 +142,46 @@ class DHTVPermutationAlignment(_PermutationAlignment):
             first[1] = 0
         return [first] + _interleave(up, down)
 
+    def _device_plan(self, F, device):
+        """The alignment plan as an int32 (P, 3) device tensor: a few hundred bytes, built and
+        uploaded once per (plan, device), not per call."""
+        ident = (self.stft_size, self.segment_start, self.segment_width, self.segment_shift,
+                 self.main_iterations, self.sub_iterations, F, str(device))
+        hit = _DEVICE_PLANS.get(ident)
+        if hit is not None:
+            return hit
+        plan = np.asarray(self.alignment_plan, dtype=np.int32)
+        assert plan[:, 2].max() <= F and plan[:, 1].min() >= 0, (plan, F)
+        if len(_DEVICE_PLANS) > 64:
+            _DEVICE_PLANS.clear()
+        _DEVICE_PLANS[ident] = _lib.to_device(plan).to(device)
+        return _DEVICE_PLANS[ident]
+
+    def calculate_mapping_async(self, mask):
+        """Device-only form for callers inside a loop (the inline aligner of
+        `CACGMMTrainer.fit`, reference cacgmm.py:260-267): mask float64 (U, K, F, T) contiguous
+        on the device -> (reverse mapping int32 (U, K, F), status int32 (U,)), both on the
+        device and NOT synchronised.  The caller reads the status words when it next has to
+        wait for the device anyway and applies the rules of `calculate_mapping` then (bit
+        `_lib.ST_EIG_NOCONV` alone: a team wait ran out, nothing of the launch is valid; any
+        other bit: 'score matrix is infeasible')."""
+        _check_metric(self.similarity_metric)
+        if self.algorithm not in ('greedy', 'optimal'):
+            raise ValueError(self.algorithm)
+        U, K, F, T = mask.shape
+        assert F % 2 == 1, (F, 'Sure? Usually F is odd.')
+        assert K < 10, (K, 'Sure?')
+        # masks of consecutive EM iterations mostly arrive aligned: let the library test that on
+        # all segments at once before it walks the plan (pbbss_set_dhtv_probe; same results)
+        engine.set_dhtv_probe(True, mask.device.index)
+        try:
+            mapping, _, st = engine.dhtv_calculate_mapping(
+                mask, self._device_plan(F, mask.device), optimal=(self.algorithm == 'optimal'),
+                metric=self.similarity_metric)
+        finally:
+            engine.set_dhtv_probe(False, mask.device.index)
+        return mapping, st
+
     def calculate_mapping(self, mask, plot=False):
         """mask (K, F, T) [or (..., K, F, T)] -> reverse mapping (K, F) int64."""
         if plot:
@@ -157,15 +197,7 @@ class DHTVPermutationAlignment(_PermutationAlignment):
         *lead, K, F, T = m.shape
         assert F % 2 == 1, (F, 'Sure? Usually F is odd.')
         assert K < 10, (K, 'Sure?')
-        plan = np.asarray(self.alignment_plan, dtype=np.int32)
-        assert plan[:, 2].max() <= F and plan[:, 1].min() >= 0, (plan, F)
-        # the plan is a few hundred bytes: upload it once per (plan, device), not per call
-        key = (plan.tobytes(), str(m.device))
-        plan_dev = _DEVICE_PLANS.get(key)
-        if plan_dev is None:
-            if len(_DEVICE_PLANS) > 64:
-                _DEVICE_PLANS.clear()
-            plan_dev = _DEVICE_PLANS[key] = _lib.to_device(plan).to(m.device)
+        plan_dev = self._device_plan(F, m.device)
         mu = m.reshape(-1, K, F, T).contiguous()
 
         def run():

@@ -290,3 +290,56 @@ def test_team_timeout_falls_back_to_the_one_workgroup_kernel(monkeypatch):
     bad[0, 3, 5] = np.nan
     with pytest.raises(ValueError, match='infeasible'):
         DHTVPermutationAlignment.from_stft_size(512).calculate_mapping(_lib.to_device(bad))
+
+
+def _structured_masks(K, F, T, seed, permuted_bins=()):
+    """masks with one activity pattern per class (aligned), the class rows of `permuted_bins`
+    rotated by one"""
+    rng = np.random.default_rng(seed)
+    act = rng.uniform(size=(K, 1, T)) ** 4
+    mask = act * rng.uniform(0.5, 1.0, size=(K, F, T)) + 0.05 * rng.uniform(size=(K, F, T))
+    mask /= mask.sum(0, keepdims=True)
+    for f in permuted_bins:
+        mask[:, f] = np.roll(mask[:, f], 1, axis=0)
+    return mask
+
+
+@pytest.mark.parametrize('K,F,T,stft', [(3, 513, 500, 1024), (2, 257, 300, 512), (4, 257, 200, 512)])
+@pytest.mark.parametrize('metric,algorithm', [('cos', 'greedy'), ('euclidean', 'optimal')])
+def test_identity_probe_changes_nothing_but_the_time(K, F, T, stft, metric, algorithm):
+    """pbbss_set_dhtv_probe: all segments evaluated at once in front of the plan.  Aligned masks
+    -> identity without walking the plan; one flipped bin anywhere (first segment, an outer
+    segment, the last bin) or fully shuffled masks -> the plan runs; always the mapping of the
+    plain kernel and of the oracle."""
+    import torch
+    from pb_bss_amd import _lib, engine
+    from pb_bss_amd.permutation_alignment import DHTVPermutationAlignment
+    from oracle import permutation_alignment as op
+    solver = DHTVPermutationAlignment.from_stft_size(stft, metric)
+    solver.algorithm = algorithm
+    plan = op.alignment_plan(stft, **op.PRESETS[stft])
+    rng = np.random.default_rng(5)
+    cases = {
+        'aligned': _structured_masks(K, F, T, 40),
+        'first_segment_bin': _structured_masks(K, F, T, 41, [plan[0][1] + 3]),
+        'outer_bins': _structured_masks(K, F, T, 42, [1, F - 1]),
+        'shuffled': _structured_masks(K, F, T, 43, rng.choice(F, F // 2, replace=False)),
+    }
+    for tag, mask in cases.items():
+        want = op.dhtv_calculate_mapping(mask, plan, algorithm=algorithm, similarity_metric=metric)
+        plain = solver.calculate_mapping(mask)
+        m = _lib.to_device(mask, torch.float64)[None].contiguous()
+        probed, st = solver.calculate_mapping_async(m)
+        probed = _lib.to_host(probed)[0]
+        assert int(_lib.to_host(st)[0]) == 0, tag
+        assert np.array_equal(plain, want), tag
+        assert np.array_equal(probed, want), tag
+        if tag == 'aligned':
+            assert np.array_equal(want, np.repeat(np.arange(K)[:, None], F, axis=1))
+        else:
+            assert not np.array_equal(want, np.repeat(np.arange(K)[:, None], F, axis=1)), tag
+    # non-finite input is reported with the probe in front as well
+    bad = cases['aligned'].copy()
+    bad[0, 5, 7] = np.nan
+    _, st = solver.calculate_mapping_async(_lib.to_device(bad, torch.float64)[None].contiguous())
+    assert int(_lib.to_host(st)[0]) & _lib.ST_NONFINITE

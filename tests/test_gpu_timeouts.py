@@ -98,3 +98,23 @@ def test_dhtv_team_really_times_out(one_poll):
         got = solver.calculate_mapping(mask)
     want = op.dhtv_calculate_mapping(mask, op.alignment_plan(512, **op.PRESETS[512]))
     assert np.array_equal(got, want)
+
+
+def test_inline_dhtv_team_time_out_repeats_the_fit_on_one_workgroup(one_poll):
+    """The inline aligner of CACGMMTrainer.fit reads its status words once after the loop: a team
+    time-out in any iteration makes the whole loop run again on the one-workgroup kernel."""
+    from pb_bss_amd import engine
+    from pb_bss_amd.distribution import CACGMMTrainer
+    from pb_bss_amd.permutation_alignment import DHTVPermutationAlignment
+    from pb_bss_amd.testing import synth
+    Y, init = synth.make_stft(257, 300, 4, 3, seed=35)
+    solver = DHTVPermutationAlignment.from_stft_size(512)
+    kw = dict(initialization=init, iterations=3, weight_constant_axis=(-3,),
+              inline_permutation_aligner=solver)
+    with pytest.warns(RuntimeWarning, match='co-resident'):
+        got = CACGMMTrainer().fit(Y, **kw)
+    engine.set_spin_limit(0)
+    want = CACGMMTrainer().fit(Y, **kw)
+    # (the remainder bin's sums are added in another order without split groups: not bit-equal)
+    assert np.abs(got.weight - want.weight).max() < 1e-10
+    assert np.abs(got.cacg.covariance_eigenvalues - want.cacg.covariance_eigenvalues).max() < 1e-8

@@ -26,6 +26,21 @@ def run(label, **kw):
     print(f'{label}: {best / iters * 1e6:.1f} us per EM iteration ({iters / best:.0f} it/s)')
 
 
+INLINE_ONLY = '--inline-only' in sys.argv
+if INLINE_ONLY:
+    from pb_bss_amd import engine
+    iters = 20
+    al = DHTVPermutationAlignment.from_stft_size(1024)
+    run('step-wise, (-3,) + inline device DHTV aligner, iterations 1-20 from a random start',
+        weight_constant_axis=(-3,), inline_permutation_aligner=al)
+    # the same loop once the EM has settled: resumed from the model after 40 iterations (a
+    # handful of bins still flip per iteration on this noisy synthetic mixture)
+    model = CACGMMTrainer().fit(y, initialization=g, iterations=40, weight_constant_axis=(-3,),
+                                inline_permutation_aligner=al)
+    g = model
+    run('step-wise, (-3,) + inline device DHTV aligner, iterations 41-60',
+        weight_constant_axis=(-3,), inline_permutation_aligner=al)
+    sys.exit(0)
 run('fused, weight_constant_axis=(-1,)')
 run('cooperative, weight_constant_axis=(-3,)', weight_constant_axis=(-3,))
 run('cooperative, weight_constant_axis=(-3, -1)', weight_constant_axis=(-3, -1))
