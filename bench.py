@@ -194,7 +194,7 @@ def pmc_evidence(ms_per_step):
         return None, prof['clock_ghz'], name + ' holds no FETCH_SIZE / WRITE_SIZE rows'
     # gfx950: FETCH_SIZE reports half the bytes of coalesced streaming reads (MI355X_MICROARCH.md;
     # calibrated here on embed_prepare_kernel's known 41.04 MB read: 20.06 MB counted,
-    # profiles/r04_g_config5_profile.txt) -- doubled; WRITE_SIZE is taken as counted (the same
+    # profiles/r04_l_config5_profile.txt) -- doubled; WRITE_SIZE is taken as counted (the same
     # kernel's 41.04 MB written: 43.6 MB counted)
     fetch_raw = sum(v for (k, c), v in prof['pmc'].items() if c == 'FETCH_SIZE') * 1024.0
     write = sum(v for (k, c), v in prof['pmc'].items() if c == 'WRITE_SIZE') * 1024.0

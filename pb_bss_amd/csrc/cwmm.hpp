@@ -78,44 +78,89 @@ __device__ __forceinline__ double watson_log_norm(double kappa) {
 
 constexpr int kWatsonKnotTable = 64;  // every S-th knot of the spline, staged in LDS
 
+// A 64-knot window of the spline around the interval the class's eigenvalue fell into last time,
+// one knot and one coefficient per lane, kept in the registers of the wave that owns the class.
+// Between two EM iterations the eigenvalue moves by a fraction of a knot spacing, so the next
+// evaluation finds its interval by a ballot over the window and fetches the seven operands of
+// the de Boor recursion with v_readlane -- no global load on the factorisation's serial path
+// (the two dependent loads of the search below were ~1.5 us of its 6.4 us; round 4).
+struct SplineWin {
+  int base = -1;  // knot index held by lane 0; < 0: empty
+  double t = 0.0, c = 0.0;
+};
+
 // scipy.interpolate.interp1d(kind='quadratic', bounds_error=False, fill_value=(0, max))
 // == BSpline(t, c, k=2) evaluated with de Boor inside [ev_min, ev_max].  Called by a whole
-// wavefront with a wave-uniform `ev`: the knot interval is found by a two-level 64-way search
-// (level 1 = `knot1`, every S-th knot, in LDS; level 2 = one global load per lane) instead of
-// a binary search (10 dependent global loads for the reference's 1000 markers).
+// wavefront with a wave-uniform `ev`: the knot interval comes from the window `win` when it
+// covers it, else from a two-level 64-way search (level 1 = `knot1`, every S-th knot, in LDS;
+// level 2 = one global load per lane) instead of a binary search (10 dependent global loads for
+// the reference's 1000 markers).  Same operands, same arithmetic on both routes.
 __device__ __forceinline__ double watson_concentration(const WatsonArgs& a, const double* knot1,
-                                                       double ev, int lane) {
+                                                       double ev, int lane, SplineWin& win) {
   if (!(ev >= a.ev_min)) return 0.0;  // also NaN -> 0 like fill_value below the range
   if (ev > a.ev_max) return a.max_concentration;
   constexpr int k = 2;
   const int n = a.n_coef;
-  const int S = (n - k + kWatsonKnotTable - 1) / kWatsonKnotTable;
   // largest i in [k, n-1] with t[i] <= ev (the knots ascend: the votes form a prefix)
-  int i;
-  if (S <= kWave) {
-    const unsigned long long v1 = __ballot(k + lane * S < n && knot1[lane] <= ev);
-    const int base = k + max(__popcll(v1) - 1, 0) * S;
-    const bool in2 = lane < S && base + lane < n;
-    const double t2 = a.spline_t[in2 ? base + lane : base];
-    const unsigned long long v2 = __ballot(in2 && t2 <= ev);
-    i = base + max(__popcll(v2) - 1, 0);
-  } else {
-    int lo = k, hi = n - 1;
-    while (lo < hi) {
-      int mid = (lo + hi + 1) >> 1;
-      if (a.spline_t[mid] <= ev) lo = mid; else hi = mid - 1;
+  int i = -1, m = -1;
+  if (win.base >= 0) {
+    const int idx = win.base + lane;
+    const unsigned long long v = __ballot(idx >= k && idx <= n - 1 && win.t <= ev);
+    if (v != 0ull) {
+      const int top = 63 - __builtin_clzll(v);
+      // lanes top-2 .. top+2 hold every operand; lane top+1 did not vote, so t[i+1] > ev (or
+      // i = n-1): i is the answer over the whole knot vector
+      if (top >= 2 && top <= 61) {
+        m = top;
+        i = win.base + top;
+      }
     }
-    i = lo;
   }
-  i = __builtin_amdgcn_readfirstlane(i);
-  double d[k + 1];
+  double tk[4], ck[3];  // t[i-1 .. i+2], c[i-2 .. i]
+  if (m >= 0) {
+    m = __builtin_amdgcn_readfirstlane(m);
 #pragma unroll
-  for (int j = 0; j <= k; ++j) d[j] = a.spline_c[j + i - k];
+    for (int x = 0; x < 4; ++x) tk[x] = lane_bcast_const(win.t, m - 1 + x);
+#pragma unroll
+    for (int x = 0; x < 3; ++x) ck[x] = lane_bcast_const(win.c, m - 2 + x);
+  } else {
+    const int S = (n - k + kWatsonKnotTable - 1) / kWatsonKnotTable;
+    if (S <= kWave) {
+      const unsigned long long v1 = __ballot(k + lane * S < n && knot1[lane] <= ev);
+      const int base = k + max(__popcll(v1) - 1, 0) * S;
+      const bool in2 = lane < S && base + lane < n;
+      const double t2 = a.spline_t[in2 ? base + lane : base];
+      const unsigned long long v2 = __ballot(in2 && t2 <= ev);
+      i = base + max(__popcll(v2) - 1, 0);
+    } else {
+      int lo = k, hi = n - 1;
+      while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if (a.spline_t[mid] <= ev) lo = mid; else hi = mid - 1;
+      }
+      i = lo;
+    }
+    i = __builtin_amdgcn_readfirstlane(i);
+#pragma unroll
+    for (int x = 0; x < 4; ++x) tk[x] = a.spline_t[i - 1 + x];
+#pragma unroll
+    for (int x = 0; x < 3; ++x) ck[x] = a.spline_c[i - 2 + x];
+  }
+  // (re-)centre the window when the interval is unknown to it or has drifted towards an edge;
+  // the loads complete behind the phases that follow
+  if (m < 12 || m > 51) {
+    const int nb = min(max(i - 32, 0), max(n + 3 - kWave, 0));
+    win.base = nb;
+    win.t = a.spline_t[min(nb + lane, n + 2)];
+    win.c = a.spline_c[min(nb + lane, n - 1)];
+  }
+  // de Boor, k = 2: d[j] = c[j + i - 2]; tl = t[j + i - 2], tr = t[j + 1 + i - r]
+  double d[k + 1] = {ck[0], ck[1], ck[2]};
 #pragma unroll
   for (int r = 1; r <= k; ++r) {
 #pragma unroll
     for (int j = k; j >= r; --j) {
-      double tl = a.spline_t[j + i - k], tr = a.spline_t[j + 1 + i - r];
+      const double tl = tk[j - 1], tr = tk[j + 2 - r];  // indices relative to i - 1
       double alpha = (ev - tl) / (tr - tl);
       d[j] = (1.0 - alpha) * d[j - 1] + alpha * d[j];
     }
@@ -277,7 +322,8 @@ struct WatsonKernel {
   // The eigenvector phase is free and cancels in m m^H.  `warm` is false on the first iteration.
   static __device__ void factor_class(const WatsonArgs& wa, const Lds& L, const double* knot1,
                                       const uint32_t* jtab, int64_t b, int k, int lane,
-                                      bool last, bool warm, double& pvre, double& pvim) {
+                                      bool last, bool warm, double& pvre, double& pvim,
+                                      SplineWin& win) {
     lane = opaque(lane);
     const EmArgs& a = wa.em;
     const LaneIJ c = lane_ij(lane);
@@ -346,7 +392,7 @@ struct WatsonKernel {
     }
     pvre = (c.i < D) ? mre_i : 0.0;
     pvim = (c.i < D) ? mim_i : 0.0;
-    const double kappa = watson_concentration(wa, knot1, lmax, lane);
+    const double kappa = watson_concentration(wa, knot1, lmax, lane, win);
     set_class(L, k, lane, c, mre_i, mim_i, kappa);
     if (last) {
       if (c.j == 0 && c.i < D && wa.out_mode) {
@@ -406,6 +452,7 @@ struct WatsonKernel {
       }
       __syncthreads();
       double pvre = 0.0, pvim = 0.0;  // previous eigenvectors of class `wave` (K <= 4 <= waves)
+      SplineWin win;                  // this class's window of the concentration spline
       for (int it = 0; it < a.iterations; ++it) {
         if (it > 0 || model_in) {
           phase_e<false>(wa, L, b, tid, wave, lane);
@@ -421,7 +468,7 @@ struct WatsonKernel {
         const bool last = (it == a.iterations - 1);
         static_assert(K <= kEmWaves, "one class per wave: the warm start lives in its registers");
         if (wave < K)
-          factor_class(wa, L, knot1, jtab, b, wave, lane, last, it > 0, pvre, pvim);
+          factor_class(wa, L, knot1, jtab, b, wave, lane, last, it > 0, pvre, pvim, win);
         __syncthreads();
       }
       if (tid < K) {
@@ -478,6 +525,7 @@ struct WatsonShared {
     if (kt) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     double pvre = 0.0, pvim = 0.0;
+    SplineWin win;
     for (int it = 0; it < a.iterations; ++it) {
       if (it > 0) {
         if (kt) {  // (-3,): weights (K, T) of the group, the E-step publishes its masked affiliations
@@ -500,7 +548,7 @@ struct WatsonShared {
       }
       __syncthreads();
       const bool last = (it == a.iterations - 1);
-      if (wave < K) W::factor_class(wa, L, knot1, jtab, b, wave, lane, last, it > 0, pvre, pvim);
+      if (wave < K) W::factor_class(wa, L, knot1, jtab, b, wave, lane, last, it > 0, pvre, pvim, win);
       __syncthreads();
       if (kt) Base::shared_reduce_kt(a, L, b, it, tid, wave, lane);
     }
@@ -598,6 +646,7 @@ struct WatsonSplit {
     }
     __syncthreads();
     double pvre = 0.0, pvim = 0.0;
+    SplineWin win;
     for (int it = 0; it < a.iterations; ++it) {
       if (it > 0 || model_in) {
         // windows are <= 256 frames: waves that own no frame skip the phase
@@ -617,7 +666,7 @@ struct WatsonSplit {
       __syncthreads();
       Base::split_exchange(a, L, prob, nprob, g, it, tid);
       const bool last = (it == a.iterations - 1);
-      if (wave < K) W::factor_class(wa, L, knot1, jtab, b, wave, lane, last, it > 0, pvre, pvim);
+      if (wave < K) W::factor_class(wa, L, knot1, jtab, b, wave, lane, last, it > 0, pvre, pvim, win);
       __syncthreads();
     }
     if (tid < K) {

@@ -488,6 +488,20 @@ __device__ __forceinline__ void wave_matvec(double mre, double mim, double xr, d
   wave_row_sum8<D>(yr, yi);  // every lane of row i now holds y_i
 }
 
+// sum over the eight rows of the 8 x 8 lane grid (lanes with the same column index), result on
+// every lane: three exchange steps instead of the six of wave_sum.  For values that are replicated
+// along their row (vector components): sum_i v_i.
+__device__ __forceinline__ double wave_colsum(double v) {
+  v += dpp_f64<kDppRowRor8, 0xF>(v, v);  // rows i, i ^ 1
+  double a = v, b = v;
+  swap16_f64(a, b);
+  v = a + b;                             // i ^ 2
+  a = v;
+  b = v;
+  swap32_f64(a, b);
+  return a + b;                          // i ^ 4
+}
+
 constexpr int kDominantMaxRounds = 8;
 
 template <int D>
@@ -495,7 +509,6 @@ __device__ __forceinline__ bool wave_dominant_eigenpair(double are, double aim, 
                                                         double& xr, double& xi, double& lambda,
                                                         int& rounds) {
   const bool valid = c.i < D && c.j < D;
-  const bool rowrep = c.j == 0 && c.i < D;  // one representative lane per vector component
   if (!valid) {
     are = 0.0;
     aim = 0.0;
@@ -509,7 +522,7 @@ __device__ __forceinline__ bool wave_dominant_eigenpair(double are, double aim, 
   if (!(tr > 0.0) || !(tr < 1.79e308)) return false;
   const double tol = 4e-15 * tr;
   {
-    const double n2 = wave_sum(rowrep ? xr * xr + xi * xi : 0.0);
+    const double n2 = wave_colsum(xr * xr + xi * xi);  // x is replicated along its rows, 0 beyond D
     if (!(n2 > 0.0)) return false;
     const double rn = fast_rsqrt(n2);
     xr *= rn;
@@ -519,9 +532,9 @@ __device__ __forceinline__ bool wave_dominant_eigenpair(double are, double aim, 
   for (rounds = 0; rounds < kDominantMaxRounds; ++rounds) {
     double yr, yi;
     wave_matvec<D>(are, aim, xr, xi, c, valid, yr, yi);
-    const double rho = wave_sum(rowrep ? xr * yr + xi * yi : 0.0);  // Re x^H C x (x unit)
+    const double rho = wave_colsum(xr * yr + xi * yi);  // Re x^H C x (x unit)
     const double rr = yr - rho * xr, ri = yi - rho * xi;
-    const double res = sqrt(wave_sum(rowrep ? rr * rr + ri * ri : 0.0));
+    const double res = sqrt(wave_colsum(rr * rr + ri * ri));
     lambda = rho;
     if (!(res < 1.79e308)) return false;
     if (res <= tol && certified) return true;
@@ -531,13 +544,13 @@ __device__ __forceinline__ bool wave_dominant_eigenpair(double are, double aim, 
     double mre = valid ? ((c.i == c.j) ? sigma - are : -are) : ((c.i == c.j) ? 1.0 : 0.0);
     double mim = valid ? -aim : 0.0;
     ScaledReal det;
-    if (wave_hpd_inverse<8>(mre, mim, c, det) != 0) return false;  // an eigenvalue above sigma
+    if (wave_hpd_inverse<D>(mre, mim, c, det) != 0) return false;  // an eigenvalue above sigma
     certified = true;  // lambda_max < sigma = rho + 1.01 res + guard
     if (res <= tol) return true;
 #pragma unroll
     for (int rep = 0; rep < 2; ++rep) {
       wave_matvec<D>(mre, mim, xr, xi, c, valid, yr, yi);
-      const double n2 = wave_sum(rowrep ? yr * yr + yi * yi : 0.0);
+      const double n2 = wave_colsum(yr * yr + yi * yi);
       if (!(n2 > 0.0) || !(n2 < 1.79e308)) return false;
       const double rn = fast_rsqrt(n2);
       xr = yr * rn;
