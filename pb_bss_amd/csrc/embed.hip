@@ -769,8 +769,11 @@ __global__ void __launch_bounds__(kFusedThreads)
 //                                        mixture_model_utils.py:30-53: clip to [eps, 1 - eps])
 // gamma goes to G (F, K, T) for the spatial M-step; gamma * saliency are the weights of the
 // spectral M-step sums taken from the SAME tile: S1 = sum w e, S0 = sum w and, for the spherical
-// Gaussian, the second moment about the shift c = the mean the E part has just used (PASS 2 of
-// embed_fit_kernel; the finalize corrects it to the new mean).  The vMF half normalises the rows
+// Gaussian, the second moment about the shift c = the mean the E part has just used (the finalize
+// corrects it to the new mean).  Only the TOTAL over the dimensions is needed ('spherical'), and
+// the E part has |e_n - c_k|^2 of every row in hand for the log-pdf: S2 = sum_n w_nk |e_n - c_k|^2
+// costs one fma per row and class (it was three VALU operations per row, class and DIMENSION in
+// the M part: 26.7 -> 22.4 us per sweep... see profiles/r04_m_gauss_sweep.txt).  The vMF half normalises the rows
 // in the E part only -- the reference's M-step takes the embedding as given (vmfcacgmm.py:286,
 // VonMisesFisherTrainer._fit).
 template <int KIND, int K, typename TS, bool VEC>
@@ -794,18 +797,17 @@ __global__ void __launch_bounds__(kFusedThreads)
   // the slot-reduction buffers alias the tile: they are written after the last tile has been
   // consumed (barrier below).  11.5 KB less LDS per workgroup: three workgroups per CU.
   double* red = reinterpret_cast<double*>(tile);     // [S][K][E]
-  double* red2 = red + (size_t)S * K * E;            // [S][K][E]  (Gaussian)
+  double* red2 = red + (size_t)S * K * E;            // [waves][K] second moments (Gaussian)
   const int c = blockIdx.x;
   const int tid = threadIdx.x;
   const int s = tid / E, d = tid - s * E;
   const bool active = s < S;
-  double acc[K], acc2[K], s0[K], mud[K];
+  double acc[K], s0[K], s2[K];
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     acc[k] = 0.0;
-    acc2[k] = 0.0;
     s0[k] = 0.0;
-    mud[k] = (GAUSS && active) ? mean[k * E + d] : 0.0;  // shift of the second moment
+    s2[k] = 0.0;  // Gaussian: sum w |e - c|^2 about the shift c = the mean of this sweep
   }
   const int64_t n0 = (int64_t)c * L;
   const int64_t n1 = (n0 + L < N) ? (n0 + L) : N;
@@ -888,9 +890,9 @@ __global__ void __launch_bounds__(kFusedThreads)
       for (int k = 0; k < K; ++k) w[k] = 0.0;
       if (mine) {
         const TS* row = tile + (size_t)tid * ES;
-        double n2 = 0.0, a[K];
+        double n2 = 0.0, a[K], d2[K];
 #pragma unroll
-        for (int k = 0; k < K; ++k) a[k] = 0.0;
+        for (int k = 0; k < K; ++k) a[k] = d2[k] = 0.0;
         if (GAUSS) {
           for (int e = 0; e < E; ++e) {
             const double v = (double)row[e];
@@ -901,7 +903,10 @@ __global__ void __launch_bounds__(kFusedThreads)
             }
           }
 #pragma unroll
-          for (int k = 0; k < K; ++k) a[k] *= prec[k] * prec[k];
+          for (int k = 0; k < K; ++k) {
+            d2[k] = a[k];  // |e - mean_k|^2: also this row's share of the second moment
+            a[k] *= prec[k] * prec[k];
+          }
         } else {
           for (int e = 0; e < E; ++e) {
             const double v = (double)row[e];
@@ -935,6 +940,7 @@ __global__ void __launch_bounds__(kFusedThreads)
           G[gidx + (int64_t)k * T] = gam;
           const double wk2 = gam * sv;
           s0[k] += wk2;
+          if (GAUSS) s2[k] = fma(wk2, d2[k], s2[k]);
           w[k] = wk2;
         }
       }
@@ -954,40 +960,39 @@ __global__ void __launch_bounds__(kFusedThreads)
           wk3[k + 1] = p2.y;
         }
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-          acc[k] = fma(wk3[k], v, acc[k]);
-          if (GAUSS) {
-            const double df = v - mud[k];
-            acc2[k] = fma(wk3[k] * df, df, acc2[k]);
-          }
-        }
+        for (int k = 0; k < K; ++k) acc[k] = fma(wk3[k], v, acc[k]);
       }
     }
   }
   __syncthreads();
   if (active) {
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-      red[((size_t)s * K + k) * E + d] = acc[k];
-      if (GAUSS) red2[((size_t)s * K + k) * E + d] = acc2[k];
-    }
+    for (int k = 0; k < K; ++k) red[((size_t)s * K + k) * E + d] = acc[k];
   }
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     const double t = wave_sum(s0[k]);
     if ((tid & (kWave - 1)) == 0) red0[(tid / kWave) * K + k] = t;
+    if (GAUSS) {
+      const double t2 = wave_sum(s2[k]);
+      if ((tid & (kWave - 1)) == 0) red2[(tid / kWave) * K + k] = t2;
+    }
   }
   __syncthreads();
   double* dst = part + (size_t)c * K * (E + 1);
   for (int i = tid; i < K * E; i += kFusedThreads) {
     const int k = i / E, dd = i - k * E;
-    double t = 0.0, t2 = 0.0;
-    for (int ss = 0; ss < S; ++ss) {
-      t += red[((size_t)ss * K + k) * E + dd];
-      if (GAUSS) t2 += red2[((size_t)ss * K + k) * E + dd];
-    }
+    double t = 0.0;
+    for (int ss = 0; ss < S; ++ss) t += red[((size_t)ss * K + k) * E + dd];
     dst[k * (E + 1) + dd] = t;
-    if (GAUSS) part2[(size_t)c * K * (E + 1) + k * (E + 1) + dd] = t2;
+    if (GAUSS) {
+      // the finalize adds the per-dimension second moments up anyway ('spherical'): the whole
+      // moment travels in dimension 0
+      double t2 = 0.0;
+      if (dd == 0)
+        for (int w = 0; w < kFusedThreads / kWave; ++w) t2 += red2[w * K + k];
+      part2[(size_t)c * K * (E + 1) + k * (E + 1) + dd] = t2;
+    }
   }
   if (tid < K) {
     double t = 0.0;
