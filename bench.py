@@ -1067,7 +1067,7 @@ def median_rate(fn, iterations, repeats=3):
 SOURCES_BY_WORKLOAD = {
     'config2': KERNEL_SOURCES,
     'config4': ('cwmm.hpp', 'cw_inst.hip', 'cacgmm_em.hpp', 'wave_la.hpp', 'pbbss_dev.hpp',
-                'em_launch.hpp', 'beamform.hip', 'embed.hip'),
+                'em_launch.hpp', 'beamform.hip'),  # Watson leg; the vMF leg: config4_vmf
     'config4_vmf': ('embed.hip',),
     'config5': ('embed.hip', 'joint_inst.hip', 'cacgmm_em.hpp', 'wave_la.hpp', 'pbbss_dev.hpp',
                 'em_launch.hpp'),

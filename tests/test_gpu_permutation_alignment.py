@@ -343,3 +343,41 @@ def test_identity_probe_changes_nothing_but_the_time(K, F, T, stft, metric, algo
     bad[0, 5, 7] = np.nan
     _, st = solver.calculate_mapping_async(_lib.to_device(bad, torch.float64)[None].contiguous())
     assert int(_lib.to_host(st)[0]) & _lib.ST_NONFINITE
+
+
+def test_identity_probe_with_two_utterances_and_sparse_plans():
+    """Probe flags are per (utterance, segment): one aligned and one shuffled utterance in the same
+    call; plus a hand-made plan with a zero-iteration segment and overlapping windows."""
+    import torch
+    from pb_bss_amd import _lib
+    from pb_bss_amd.permutation_alignment import DHTVPermutationAlignment
+    from oracle import permutation_alignment as op
+    K, F, T = 3, 257, 300
+    rng = np.random.default_rng(7)
+    masks = np.stack([_structured_masks(K, F, T, 50),
+                      _structured_masks(K, F, T, 51, rng.choice(F, 40, replace=False))])
+    for solver in (DHTVPermutationAlignment.from_stft_size(512),
+                   DHTVPermutationAlignment(stft_size=512, segment_start=40, segment_width=60,
+                                            segment_shift=30, main_iterations=3, sub_iterations=1)):
+        plan = solver.alignment_plan
+        got, st = solver.calculate_mapping_async(_lib.to_device(masks, torch.float64).contiguous())
+        got = _lib.to_host(got)
+        assert not _lib.to_host(st).any()
+        for u in range(2):
+            assert np.array_equal(got[u], op.dhtv_calculate_mapping(masks[u], plan)), u
+        assert np.array_equal(got[0], np.repeat(np.arange(K)[:, None], F, axis=1))
+        assert not np.array_equal(got[1], got[0])
+    # a raw plan with a segment of zero iterations (skipped by the reference's range(0) loop)
+    from pb_bss_amd import engine
+    plan = np.array([[4, 60, 160], [0, 0, 120], [2, 100, 257], [2, 0, 100]], dtype=np.int32)
+    m = _lib.to_device(masks, torch.float64).contiguous()
+    engine.set_dhtv_probe(True)
+    try:
+        got, _, st = engine.dhtv_calculate_mapping(m, _lib.to_device(plan))
+    finally:
+        engine.set_dhtv_probe(False)
+    want, _, _ = engine.dhtv_calculate_mapping(m, _lib.to_device(plan))
+    assert not _lib.to_host(st).any()
+    assert np.array_equal(_lib.to_host(got), _lib.to_host(want))
+    for u in range(2):
+        assert np.array_equal(_lib.to_host(got)[u], op.dhtv_calculate_mapping(masks[u], plan.tolist()))
