@@ -756,8 +756,11 @@ int pbbss_set_dhtv_team(pbbss_handle_t h, int workgroups_per_utterance);
  * probe 0.021 ms; plan 0.33 ms -> 0.22 ms with the ~10-40 flipped bins of the first EM iterations,
  * ~0.1 ms with the 0-4 of a settled EM, ~0.003 ms for aligned masks.  Off by default (a one-shot
  * alignment of freshly fitted masks touches every segment anyway); the inline aligner of
- * CACGMMTrainer.fit (cacgmm.py:260-267) switches it on. */
-int pbbss_set_dhtv_probe(pbbss_handle_t h, int enable);
+ * CACGMMTrainer.fit (cacgmm.py:260-267) switches it on.
+ * flags: bit 0 = the probe; bit 1 = the frame-slice path does NOT write the aligned features
+ * into `scratch` (a caller that only wants the mapping saves a K F T float64 store; scratch is
+ * still needed as the exchange area and holds unspecified data afterwards).  0..3. */
+int pbbss_set_dhtv_probe(pbbss_handle_t h, int flags);
 int pbbss_split_error(pbbss_handle_t h, int* out_flag);
 /* Consume a reported time-out: waits for the device, then re-zeroes the arrival counters of the
  * split / member protocols and the sticky flag of pbbss_split_error.  The Python layer calls it

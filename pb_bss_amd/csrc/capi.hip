@@ -524,7 +524,8 @@ PBBSS_API int pbbss_set_dhtv_team(pbbss_handle_t h, int workgroups_per_utterance
 
 PBBSS_API int pbbss_set_dhtv_probe(pbbss_handle_t h, int enable) {
   if (!h) return PBBSS_ERR_INVALID_ARG;
-  h->dhtv_probe = enable ? 1 : 0;
+  if (enable < 0 || enable > 3) return PBBSS_ERR_INVALID_ARG;
+  h->dhtv_probe = enable;
   return PBBSS_OK;
 }
 

@@ -1303,7 +1303,7 @@ template <int K, int NF>
 static bool slice_launch_one(const double* mask, int64_t U, int F, int T, const int32_t* plan, int P,
                              int optimal, int metric, double* feat, int32_t* mapping,
                              int32_t* status, int G, size_t lds, unsigned* ctrl, double* scale,
-                             bool probe, hipStream_t s, int* rc) {
+                             bool probe, bool features, hipStream_t s, int* rc) {
   auto kfn = dhtv_slice_kernel<K, NF, false>;
   auto pfn = dhtv_slice_kernel<K, NF, true>;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
@@ -1328,8 +1328,9 @@ static bool slice_launch_one(const double* mask, int64_t U, int F, int T, const 
                        feat, mapping, plan, P, F, T, optimal, metric, status, G, pctrl, pflag);
   hipLaunchKernelGGL(kfn, dim3((unsigned)(U * G)), dim3(kSliceThreads), lds, s, mask, scale, feat,
                      mapping, plan, P, F, T, optimal, metric, status, G, ctrl, pflag);
-  hipLaunchKernelGGL(dhtv_features_kernel, dim3((unsigned)rows), dim3(256), 0, s, mask, mapping,
-                     scale, K, F, T, feat);
+  if (features)
+    hipLaunchKernelGGL(dhtv_features_kernel, dim3((unsigned)rows), dim3(256), 0, s, mask, mapping,
+                       scale, K, F, T, feat);
   *rc = hipGetLastError() == hipSuccess ? PBBSS_OK : PBBSS_ERR_HIP;
   return true;
 }
@@ -1337,7 +1338,8 @@ static bool slice_launch_one(const double* mask, int64_t U, int F, int T, const 
 static bool launch_slice(const double* mask, int64_t U, int K, int F, int T, const int32_t* plan,
                          int P, int optimal, int metric, double* feat, int32_t* mapping,
                          int32_t* status, size_t lds_limit, int num_cu, int want_team,
-                         unsigned* ctrl, double* scale, bool want_probe, hipStream_t s, int* rc) {
+                         unsigned* ctrl, double* scale, bool want_probe, bool features,
+                         hipStream_t s, int* rc) {
   if (K > 5) return false;  // K*K scores per bin live in registers through the butterfly
   if (U * K * F > 2147483647LL) return false;
   for (int NF = 4; NF <= 8; NF *= 2) {  // frames per lane; 16 * NF frames per workgroup
@@ -1358,7 +1360,7 @@ static bool launch_slice(const double* mask, int64_t U, int K, int F, int T, con
 #define PBBSS_SLICE_CASE(KK, NN)                                                               \
   if (K == KK && NF == NN)                                                                     \
     return slice_launch_one<KK, NN>(mask, U, F, T, plan, P, optimal, metric, feat, mapping,    \
-                                    status, G, lds, ctrl, scale, probe, s, rc);
+                                    status, G, lds, ctrl, scale, probe, features, s, rc);
     PBBSS_SLICE_CASE(1, 4) PBBSS_SLICE_CASE(1, 8)
     PBBSS_SLICE_CASE(2, 4) PBBSS_SLICE_CASE(2, 8)
     PBBSS_SLICE_CASE(3, 4) PBBSS_SLICE_CASE(3, 8)
@@ -1390,8 +1392,8 @@ int launch_dhtv(const double* mask, int64_t U, int K, int F, int T, const int32_
     int rc = PBBSS_OK;
     if (launch_slice(mask, U, K, F, T, plan, P, optimal, metric, feat, mapping, status, lds_limit,
                      num_cu, team_size, ctrl,
-                     reinterpret_cast<double*>(static_cast<char*>(team_buf) + ctrl_pad), probe != 0,
-                     s, &rc))
+                     reinterpret_cast<double*>(static_cast<char*>(team_buf) + ctrl_pad),
+                     (probe & 1) != 0, (probe & 2) == 0, s, &rc))
       return rc;
   }
   size_t lds = ((size_t)K * T + kDhtvWaves) * sizeof(double) + 16;

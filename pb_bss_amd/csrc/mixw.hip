@@ -128,7 +128,29 @@ __global__ void __launch_bounds__(kT) mixw_finish_kernel(const double* __restric
     if (n < N1) {
       if (red_inner) {
         // N1 == N: tmp is the affiliation itself, weighted here (sal_rows (Bo*Bi, N) or null)
-        for (int64_t bi = part; bi < Bi; bi += kFinParts) {
+        // four problems per trip (their loads in flight together: the loop is a chain of L2
+        // round trips), added in ascending order like the one-at-a-time loop
+        constexpr int kU = 4;
+        int64_t bi = part;
+        if (kc <= 4) {
+          for (; bi + (kU - 1) * kFinParts < Bi; bi += kU * kFinParts) {
+            double v[kU][4], sv[kU];
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+              const int64_t bb = bi + u * kFinParts;
+              const double* row = tmp + ((bo * Bi + bb) * K + k0) * N1 + n;
+              sv[u] = sal_rows ? sal_rows[(bo * Bi + bb) * N1 + n] : 1.0;
+#pragma unroll
+              for (int k = 0; k < 4; ++k) v[u][k] = (k < kc) ? row[(int64_t)k * N1] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < kU; ++u)
+#pragma unroll
+              for (int k = 0; k < 4; ++k)
+                if (k < kc) acc[k] += v[u][k] * sv[u];
+          }
+        }
+        for (; bi < Bi; bi += kFinParts) {
           const double* row = tmp + ((bo * Bi + bi) * K + k0) * N1 + n;
           const double sv = sal_rows ? sal_rows[(bo * Bi + bi) * N1 + n] : 1.0;
 #pragma unroll

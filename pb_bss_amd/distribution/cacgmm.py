@@ -466,7 +466,7 @@ class CACGMMTrainer:
     def _fit_stepwise(self, yb, indep, K, gamma0, model, iterations, saliency,
                       sal, act, weight_constant_axis, covariance_norm,
                       affiliation_eps, eigenvalue_floor, hermitize, aligner,
-                      like_torch, weight_hook=None, _retry_team=True):
+                      like_torch, weight_hook=None, _retry_team=True, _retry_split=True):
         """The reference loop (cacgmm.py:252-278) for the options that couple frequency bins
         (weight_constant_axis with independent axes, inline_permutation_aligner), one E-step
         and one M-step launch per iteration with the cross-bin reduction
@@ -477,9 +477,13 @@ class CACGMMTrainer:
         t = _lib.torch()
         B, N, D = yb.shape
         dev = yb.device
-        # normalise in float64 (the reference keeps the input precision; with
-        # complex64 input that alone costs 6e-8 per step)
-        yn = engine.normalize_observation(yb.to(t.complex128))  # (B, D, N)
+        if yb.dtype == t.complex64:
+            # as in the fused fit: the kernels keep the raw complex64 frames (exact) and apply
+            # 1 / |y|^2 in float64 -- half the bytes of a widened, normalised copy per launch
+            yn, y_layout = yb.contiguous(), _lib.LAYOUT_TD  # (B, N, D)
+        else:
+            # normalise in float64 (the reference keeps the input precision)
+            yn, y_layout = engine.normalize_observation(yb), _lib.LAYOUT_DT  # (B, D, N)
         shape = (*indep, K, N)
         sal_dev = None
         if saliency is not None:
@@ -494,13 +498,14 @@ class CACGMMTrainer:
             weight = _lib.to_device(model.weight, t.float64).to(dev)
         device_aligner = aligner is not None and type(aligner).__module__.startswith('pb_bss_amd')
         aligner_status = []  # device status words of the aligner, read once after the loop
+        m_status = []
         for _ in range(iterations):
             if vec is not None:
                 w = _weight_for_predict(weight, indep, K, N, dev)
                 aff, q, _ = engine.em_predict(
                     yn, vec.expand(*indep, K, D, D).reshape(B, K, D, D).contiguous(),
                     val.expand(*indep, K, D).reshape(B, K, D).contiguous(), w,
-                    activity=act, layout=_lib.LAYOUT_DT,
+                    activity=act, layout=y_layout,
                     affiliation_eps=affiliation_eps, want_q=True)
                 aff, q = aff.reshape(shape), q.reshape(shape)
                 if aligner is not None:
@@ -529,11 +534,35 @@ class CACGMMTrainer:
                     saliency=None if sal_dev is None else _lib.to_host(sal_dev),
                     weight_constant_axis=weight_constant_axis), t.float64, device=dev)
             masked = aff if sal_dev is None else aff * sal_dev[..., None, :]
-            vec, val, _, _ = engine.cacg_m_step(
+            # status words of the M-step: queued like the aligner's, one read-back after the loop
+            vec, val, _, st = engine.cacg_m_step(
                 yn, masked.reshape(B, K, N).contiguous(), q.reshape(B, K, N).contiguous(),
-                layout=_lib.LAYOUT_DT, covariance_norm=covariance_norm,
-                eigenvalue_floor=eigenvalue_floor)
+                layout=y_layout, covariance_norm=covariance_norm,
+                eigenvalue_floor=eigenvalue_floor, check_status=False)
+            m_status.append(st.reshape(-1))
             vec, val = vec.reshape(*indep, K, D, D), val.reshape(*indep, K, D)
+        what = 'ComplexAngularCentralGaussianTrainer._fit'
+        bits = int(np.bitwise_or.reduce(_lib.to_host(t.cat(m_status)))) if m_status else 0
+        poison = _lib.ST_NONFINITE | _lib.ST_EIG_NOCONV
+        if (bits & poison) == poison and _retry_split and engine.split_error(dev.index):
+            # the split groups of a remainder bin timed out in one of the M-steps (engine.
+            # _checked_with_split_retry has the story): the whole loop again without them
+            import warnings
+            warnings.warn(f'{what}: the split groups of the remainder bin were not co-resident '
+                          '(GPU shared with other work); repeating the fit without them',
+                          RuntimeWarning)
+            engine.split_reset(dev.index)
+            was = engine.split_tail(dev.index)
+            engine.set_split_tail(False, dev.index)
+            try:
+                return self._fit_stepwise(
+                    yb, indep, K, gamma0, model, iterations, saliency, sal, act,
+                    weight_constant_axis, covariance_norm, affiliation_eps, eigenvalue_floor,
+                    hermitize, aligner, like_torch, weight_hook=weight_hook,
+                    _retry_team=_retry_team, _retry_split=False)
+            finally:
+                engine.set_split_tail(was, dev.index)
+        engine._raise_for_bits(bits, what)
         if aligner_status:
             bits = int(np.bitwise_or.reduce(_lib.to_host(t.cat(aligner_status)).reshape(-1)))
             if bits & _lib.ST_EIG_NOCONV and not bits & _lib.ST_NONFINITE and _retry_team:
@@ -551,7 +580,7 @@ class CACGMMTrainer:
                         yb, indep, K, gamma0, model, iterations, saliency, sal, act,
                         weight_constant_axis, covariance_norm, affiliation_eps, eigenvalue_floor,
                         hermitize, aligner, like_torch, weight_hook=weight_hook,
-                        _retry_team=False)
+                        _retry_team=False, _retry_split=_retry_split)
                 finally:
                     engine.set_dhtv_team(before, dev.index)
             if bits != 0:

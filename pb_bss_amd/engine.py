@@ -645,8 +645,10 @@ def set_dhtv_team(workgroups_per_utterance, device_index=None):
 def set_dhtv_probe(enable, device_index=None):
     """pbbss_set_dhtv_probe: evaluate all plan segments at once in front of the DHTV plan and
     skip the plan when the masks are aligned already (same results; for callers that align
-    every EM iteration)."""
-    _lib.check(_lib.load().pbbss_set_dhtv_probe(_lib.handle(device_index), int(bool(enable))),
+    every EM iteration).  `enable` True / False, or the flag word of the C call (2: the aligned
+    features are not written, 3: probe + no features)."""
+    flags = int(enable) if isinstance(enable, int) and not isinstance(enable, bool) else int(bool(enable))
+    _lib.check(_lib.load().pbbss_set_dhtv_probe(_lib.handle(device_index), flags),
                'set_dhtv_probe')
 
 

@@ -173,7 +173,7 @@ class DHTVPermutationAlignment(_PermutationAlignment):
         assert K < 10, (K, 'Sure?')
         # masks of consecutive EM iterations mostly arrive aligned: let the library test that on
         # all segments at once before it walks the plan (pbbss_set_dhtv_probe; same results)
-        engine.set_dhtv_probe(True, mask.device.index)
+        engine.set_dhtv_probe(3, mask.device.index)  # + the aligned features are not needed
         try:
             mapping, _, st = engine.dhtv_calculate_mapping(
                 mask, self._device_plan(F, mask.device), optimal=(self.algorithm == 'optimal'),
