@@ -130,7 +130,7 @@ static int cw_launch_one(const WatsonArgs& wa, const EmLaunchCfg& cfg, hipStream
   const size_t slab_need =
       256 + EmKernel<PBBSS_EM_D, K, YS, false>::split_slab_doubles((int)r, (a.T + window - 1) / window) *
                 sizeof(double);
-  const bool split = cfg.allow_split && cfg.side_stream && cfg.xbuf && a.iterations > 0 &&
+  const bool split = cfg.allow_split && cfg.side_stream && cfg.xbuf && a.iterations >= kSplitMinIterations &&
                      a.B > cfg.num_cu && a.B <= 3 * (int64_t)cfg.num_cu && r >= 1 &&
                      r <= kSplitMaxProblems && a.T >= 2 * cfg.split_window && a.wt == 0 &&
                      slab_need <= cfg.xbuf_bytes;

@@ -36,7 +36,7 @@ static int launch32(EmArgs a, const EmLaunchCfg& cfg, hipStream_t stream) {
   const int window = cfg.split_window > 256 ? 256 : cfg.split_window;
   const int G = (a.T + window - 1) / window;
   const size_t slab_need = 256 + Kern::Base::split_slab_doubles((int)r, G) * sizeof(double);
-  const bool split = cfg.allow_split && a.iterations > 0 && a.B > cfg.num_cu && r >= 1 &&
+  const bool split = cfg.allow_split && a.iterations >= kSplitMinIterations && a.B > cfg.num_cu && r >= 1 &&
                      r <= kSplitMaxProblems && a.T >= 2 * cfg.split_window &&
                      slab_need <= cfg.xbuf_bytes &&
                      (a.B - r) <= (int64_t)cfg.num_cu * (occ - 1);

@@ -106,7 +106,7 @@ static int launch_one(const EmArgs& a, const EmLaunchCfg& cfg, hipStream_t strea
       256 + EmKernel<PBBSS_EM_D, K, YS, false>::split_slab_doubles((int)r, (a.T + window - 1) /
                                                                                window) *
                 sizeof(double);
-  const bool split = cfg.allow_split && a.iterations > 0 && a.B > cfg.num_cu &&
+  const bool split = cfg.allow_split && a.iterations >= kSplitMinIterations && a.B > cfg.num_cu &&
                      a.B <= 3 * (int64_t)cfg.num_cu && r >= 1 && r <= kSplitMaxProblems &&
                      a.T >= 2 * cfg.split_window && a.wt == 0 && slab_need <= cfg.xbuf_bytes;
   if (!split) return launch_variant<K, YS, false>(a, cfg, stream);

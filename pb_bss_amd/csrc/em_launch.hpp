@@ -10,6 +10,12 @@
 
 namespace pbbss {
 
+// Split groups for the remainder bins pay a fixed price per LAUNCH (fork / join across streams
+// and the members' first hand-offs, ~10 us) against ~5 us per ITERATION that an extra full
+// workgroup on one compute unit costs: launches of one or two iterations -- the E- and M-steps of
+// the step-wise loop -- run without them (inline aligner loop 387 -> 376 us per iteration).
+constexpr int kSplitMinIterations = 3;
+
 struct EmLaunchCfg {
   int num_cu;        // compute units of the bound device
   size_t lds_limit;  // usable LDS bytes per workgroup
