@@ -513,8 +513,35 @@ def cacgmm_single_precision_cases():
     _save('cacgmm_single_precision_path', **out)
 
 
+def cacgmm_single_precision_mask_case():
+    """source_activity_mask on the reference's single-precision path (cacgmm.py:269-271 ->
+    mixture_model_utils.py:39-41): pins the mask handling of the packed-FP32 kernel, per step."""
+    from pb_bss.distribution import CACGMMTrainer
+    out = {}
+    F, T, D, K = 6, 200, 5, 3
+    Y, init = synth.make_stft(F, T, D, K, seed=77)
+    rng = np.random.default_rng(78)
+    mask = rng.uniform(size=(F, K, T)) > 0.3
+    mask[:, 0, :] |= ~mask.any(axis=1)          # every frame keeps at least one active class
+    mask[2, :, 50:60] = False                   # ... except a stretch of bin 2: all classes off
+    assert Y.dtype == np.complex64
+    for iters in (1, 2):
+        model = CACGMMTrainer().fit(Y, initialization=init, iterations=iters,
+                                    source_activity_mask=mask)
+        aff = model.predict(Y)
+        assert aff.dtype == np.float32
+        m64 = CACGMMTrainer().fit(Y.astype(np.complex128), initialization=init, iterations=iters,
+                                  source_activity_mask=mask)
+        out[f'aff32_it{iters}'] = aff
+        out[f'weight32_it{iters}'] = model.weight
+        out[f'aff64_it{iters}'] = m64.predict(Y.astype(np.complex128))
+    out['Y'], out['init'], out['mask'] = Y, init, mask
+    _save('cacgmm_single_precision_mask', **out)
+
+
 def main():
     """python -m oracle.make_golden            -> every fixture of the pure-Python reference
+    python -m oracle.make_golden f32mask    -> tests/golden/cacgmm_single_precision_mask.npz
     python -m oracle.make_golden f32        -> tests/golden/cacgmm_single_precision_path.npz
     python -m oracle.make_golden joint_cov  -> tests/golden/embed_gcacgmm_{full,diagonal}*.npz
     python -m oracle.make_golden gev_eig    -> tests/golden/gev_use_eig.npz only (own process:
@@ -530,6 +557,10 @@ def main():
     if sys.argv[1:] == ['f32']:
         refshim.load()
         cacgmm_single_precision_cases()
+        return
+    if sys.argv[1:] == ['f32mask']:
+        refshim.load()
+        cacgmm_single_precision_mask_case()
         return
     if sys.argv[1:] == ['gev_eig']:
         refshim.load_cython()

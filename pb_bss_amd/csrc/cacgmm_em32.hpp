@@ -363,6 +363,8 @@ struct EmKernel32 {
         }
         __builtin_amdgcn_sched_barrier(0);
       });
+      // source_activity_mask of the EM loop / of the final predict (wave-uniform pointer)
+      const uint8_t* act = FINAL ? a.final_activity : a.activity;
       // per-class constants of the softmax (float64 in LDS, written by the factorisation)
       float rdet[K], wgt[K];
       int dete[K];
@@ -410,7 +412,8 @@ struct EmKernel32 {
         float g[K], den = 0.f;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-          const float v = ldexpf(val[k], ex[k] - emax) * wgt[k];  // mixture_model_utils.py:32-37
+          float v = ldexpf(val[k], ex[k] - emax) * wgt[k];  // mixture_model_utils.py:32-37
+          if (act) v *= (float)act[((size_t)b * K + k) * TS + tf + t];  // :39-41
           g[k] = v;
           den += v;
         }

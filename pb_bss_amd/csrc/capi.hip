@@ -752,7 +752,7 @@ PBBSS_API int pbbss_cacgmm_fit(pbbss_handle_t h, const void* y, int64_t B, int T
   }
   if (D < 2 || D > 8 || K < 1 || K > 6) return PBBSS_ERR_UNSUPPORTED;
   const bool f32 = o->precision == PBBSS_PRECISION_F32;
-  if (f32 && (o->y_is_c128 || K > 4 || activity || out_quadratic_form)) return PBBSS_ERR_UNSUPPORTED;
+  if (f32 && (o->y_is_c128 || K > 4 || out_quadratic_form)) return PBBSS_ERR_UNSUPPORTED;
   pbbss::EmArgs a{};
   a.y = y;
   a.B = B;

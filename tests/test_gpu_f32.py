@@ -55,6 +55,35 @@ def test_per_step_against_the_references_float32_path(tag, iters):
     assert int(r['status'].max()) & 3 == 0
 
 
+@pytest.mark.parametrize('iters', [1, 2])
+def test_source_activity_mask_against_the_references_float32_path(iters):
+    """source_activity_mask in the packed-FP32 kernel (refused until round 4): per step against
+    the reference's own complex64 / float32 run with the same mask -- some frames with every class
+    switched off -- and against its float64 run; the float64 kernel on the same input as well."""
+    from pb_bss_amd import _lib
+    g = np.load(os.path.join(os.path.dirname(GOLD), 'cacgmm_single_precision_mask.npz'))
+    Y, init, mask = g['Y'], g['init'], g['mask']
+    act = _lib.to_device(mask.astype(np.uint8))
+    r = _fit32(Y, init, iters, activity=act)
+    aff32 = g[f'aff32_it{iters}'].astype(np.float64)
+    aff64 = g[f'aff64_it{iters}']
+    ref_gap = np.abs(aff32 - aff64).max()
+    assert np.abs(r['affiliation'] - aff64).max() < max(2.0 * ref_gap, 2e-5)
+    assert np.abs(r['affiliation'] - aff32).max() < 1e-4
+    assert np.abs(r['weight'] - g[f'weight32_it{iters}'][..., 0]).max() < 1e-5
+    assert int(r['status'].max()) & 3 == 0
+    from pb_bss_amd import engine
+    r64 = engine.em_fit(_lib.to_device(Y), init.shape[1], gamma0=_lib.to_device(init),
+                        iterations=iters, final_predict=True, activity=act)
+    assert np.abs(_lib.to_host(r64['affiliation']) - aff64).max() < 1e-9
+    # the trainer takes the packed kernel for this call now (reference arithmetic)
+    import pb_bss_amd
+    from pb_bss_amd.distribution import CACGMMTrainer
+    with pb_bss_amd.arithmetic('reference'):
+        m = CACGMMTrainer().fit(Y, initialization=init, iterations=iters, source_activity_mask=mask)
+    assert np.abs(m.predict(Y) - aff32).max() < 1e-4
+
+
 @pytest.mark.parametrize('D,K,T', [(2, 2, 90), (3, 1, 130), (4, 3, 257), (5, 4, 300), (6, 2, 64),
                                    (7, 3, 511), (8, 4, 500), (8, 3, 256)])
 def test_every_compiled_size_against_the_float64_oracle(D, K, T):
