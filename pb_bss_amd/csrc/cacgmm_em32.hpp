@@ -278,8 +278,11 @@ struct EmKernel32 {
   }
 
   // ---- phase E ---------------------------------------------------------------------------------
-  template <bool FINAL>
-  static __device__ void phase_e(const EmArgs& a, const Lds& L, int64_t b, int tid, int wave,
+  // MASK: source_activity_mask given (its own instantiation: a wave-uniform test inside the
+  // softmax block cost the mask-less fit 2 % -- it splits the block the scheduler overlaps the
+  // next operand chunk with)
+  template <bool FINAL, bool MASK>
+  static __device__ void phase_e_impl(const EmArgs& a, const Lds& L, int64_t b, int tid, int wave,
                                  int lane, float eps, int tf = 0) {
     tid = opaque(tid);
     lane = opaque(lane);
@@ -409,11 +412,18 @@ struct EmKernel32 {
           ex[k] = -(e * D + dete[k]);
           emax = max(emax, ex[k]);
         }
+        // weight x source_activity_mask (:39-41)
+        float wam[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) wam[k] = wgt[k];
+        if constexpr (MASK) {
+#pragma unroll
+          for (int k = 0; k < K; ++k) wam[k] *= (float)act[((size_t)b * K + k) * TS + tf + t];
+        }
         float g[K], den = 0.f;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-          float v = ldexpf(val[k], ex[k] - emax) * wgt[k];  // mixture_model_utils.py:32-37
-          if (act) v *= (float)act[((size_t)b * K + k) * TS + tf + t];  // :39-41
+          const float v = ldexpf(val[k], ex[k] - emax) * wam[k];  // mixture_model_utils.py:32-41
           g[k] = v;
           den += v;
         }
@@ -452,6 +462,16 @@ struct EmKernel32 {
         const double tot = wave_sum((double)s[k]);
         if (lane == 0) L.b.red[wave * K + k] = tot;
       }
+    }
+  }
+
+  template <bool FINAL>
+  static __device__ __forceinline__ void phase_e(const EmArgs& a, const Lds& L, int64_t b, int tid,
+                                                 int wave, int lane, float eps, int tf = 0) {
+    if ((FINAL ? a.final_activity : a.activity) != nullptr) {
+      phase_e_impl<FINAL, true>(a, L, b, tid, wave, lane, eps, tf);
+    } else {
+      phase_e_impl<FINAL, false>(a, L, b, tid, wave, lane, eps, tf);
     }
   }
 
