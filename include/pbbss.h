@@ -132,9 +132,9 @@ typedef struct pbbss_em_opts {
 /* cast to y.real.dtype, every einsum then runs in complex64 / float32): quadratic       */
 /* forms, posteriors and covariance sums in packed float32 (csrc/cacgmm_em32.hpp), class */
 /* sums, factorisation, eigenvalue floor and the returned model in float64.  complex64   */
-/* input, 2 <= D <= 8, K <= 4, frames resident in LDS, no quadratic-form output:         */
+/* input, 2 <= D <= 8, K <= 6, frames resident in LDS, no quadratic-form output:         */
 /* otherwise PBBSS_ERR_UNSUPPORTED (the caller uses F64, which is a superset in          */
-/* accuracy).  source_activity_mask is served since 0.4.1.                               */
+/* accuracy).  K = 5, 6 and source_activity_mask are served since 0.4.1.                 */
 #define PBBSS_PRECISION_F64 0
 #define PBBSS_PRECISION_F32 1
 

@@ -539,8 +539,31 @@ def cacgmm_single_precision_mask_case():
     _save('cacgmm_single_precision_mask', **out)
 
 
+def cacgmm_single_precision_many_classes():
+    """Five and six classes on the reference's single-precision path (cacgmm.py:226-227): pins the
+    K > 4 instantiations of the packed-FP32 kernel, per step."""
+    from pb_bss.distribution import CACGMMTrainer
+    out = {}
+    for tag, F, T, D, K in (('k5', 5, 220, 6, 5), ('k6', 4, 300, 8, 6)):
+        Y, init = synth.make_stft(F, T, D, K, seed=90 + K)
+        assert Y.dtype == np.complex64
+        for iters in (1, 2):
+            model = CACGMMTrainer().fit(Y, initialization=init, iterations=iters)
+            aff = model.predict(Y)
+            assert aff.dtype == np.float32
+            m64 = CACGMMTrainer().fit(Y.astype(np.complex128), initialization=init,
+                                      iterations=iters)
+            out[f'{tag}_aff32_it{iters}'] = aff
+            out[f'{tag}_weight32_it{iters}'] = model.weight
+            out[f'{tag}_aff64_it{iters}'] = m64.predict(Y.astype(np.complex128))
+        out[f'{tag}_Y'] = Y
+        out[f'{tag}_init'] = init
+    _save('cacgmm_single_precision_k56', **out)
+
+
 def main():
     """python -m oracle.make_golden            -> every fixture of the pure-Python reference
+    python -m oracle.make_golden f32k56     -> tests/golden/cacgmm_single_precision_k56.npz
     python -m oracle.make_golden f32mask    -> tests/golden/cacgmm_single_precision_mask.npz
     python -m oracle.make_golden f32        -> tests/golden/cacgmm_single_precision_path.npz
     python -m oracle.make_golden joint_cov  -> tests/golden/embed_gcacgmm_{full,diagonal}*.npz
@@ -557,6 +580,10 @@ def main():
     if sys.argv[1:] == ['f32']:
         refshim.load()
         cacgmm_single_precision_cases()
+        return
+    if sys.argv[1:] == ['f32k56']:
+        refshim.load()
+        cacgmm_single_precision_many_classes()
         return
     if sys.argv[1:] == ['f32mask']:
         refshim.load()

@@ -32,7 +32,7 @@
 //    the L2 round trip of every chunk was exposed: the E phase took 3x the M phase,
 //    profiles/r03_b_f32_experiments.txt.)
 //  * y is kept PRE-NORMALISED in LDS (float32, 32 KB at T = 500, D = 8): no widening, no
-//    1 / |y|^2 factor anywhere; M-step weights as float32 (K padded to 4 per frame, one
+//    1 / |y|^2 factor anywhere; M-step weights as float32 (K padded to 2, 4 or 8 per frame, one
 //    ds_write_b128 / ds_read_b128 per frame).
 //  * Softmax in mantissa / exponent form as in the float64 kernel, on v_frexp / v_rcp_f32.
 //  * The M-phase butterfly runs on 32-bit registers (half the swaps), the totals are widened
@@ -154,7 +154,7 @@ __device__ __forceinline__ void wave_reduce_scatter32(float (&v)[N]) {
 
 template <int D, int K>
 struct EmKernel32 {
-  static_assert(K >= 1 && K <= 4, "packed-FP32 instantiation: up to four classes");
+  static_assert(K >= 1 && K <= 6, "packed-FP32 instantiation: up to six classes");
   using Base = EmKernel<D, K, float, false>;
   using BLds = typename Base::Lds;
   static constexpr int DP = Base::DP, NOFF = Base::NOFF, NA = Base::NA;
@@ -163,7 +163,7 @@ struct EmKernel32 {
   static constexpr int NA32 = DPAD + 2 * NOFF;              // operands of one class
   static constexpr int NAP = (NA32 + 7) & ~7;               // row stride: whole chunks of eight operands
   static constexpr int NCH = NAP / 8;
-  static constexpr int KP = K <= 2 ? 2 : 4;                 // M-step weights of a frame: one vector
+  static constexpr int KP = K <= 2 ? 2 : (K <= 4 ? 4 : 8);  // M-step weights of a frame: one or two vectors
 
   struct Lds {
     BLds b;     // the float64 small arrays of the float64 kernel (frame arrays unused)
@@ -244,9 +244,14 @@ struct EmKernel32 {
     if constexpr (KP == 2) {
       f32x2 o = {w[0], K > 1 ? w[K > 1 ? 1 : 0] : 0.f};
       *reinterpret_cast<f32x2*>(L.w + (size_t)t * KP) = o;
-    } else {
+    } else if constexpr (KP == 4) {
       f32x4 o = {w[0], w[1], w[2], K > 3 ? w[K > 3 ? 3 : 0] : 0.f};
       *reinterpret_cast<f32x4*>(L.w + (size_t)t * KP) = o;
+    } else {
+      f32x4 o0 = {w[0], w[1], w[2], w[3]};
+      f32x4 o1 = {w[K > 4 ? 4 : 0], K > 5 ? w[K > 5 ? 5 : 0] : 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(L.w + (size_t)t * KP) = o0;
+      *reinterpret_cast<f32x4*>(L.w + (size_t)t * KP + 4) = o1;
     }
   }
 
@@ -503,6 +508,11 @@ struct EmKernel32 {
         const f32x4 wv = *reinterpret_cast<const f32x4*>(L.w + (size_t)tc * KP);
         tr.wp[0] = pair_of<0>(wv);
         tr.wp[1] = pair_of<1>(wv);
+        if constexpr (KP == 8) {
+          const f32x4 wv1 = *reinterpret_cast<const f32x4*>(L.w + (size_t)tc * KP + 4);
+          tr.wp[2] = pair_of<0>(wv1);
+          tr.wp[3] = pair_of<1>(wv1);
+        }
       }
 #pragma unroll
       for (int x = 0; x < KP / 2; ++x) tr.wp[x] = ok ? tr.wp[x] : f32x2{0.f, 0.f};
@@ -767,7 +777,7 @@ struct EmKernel32 {
 };
 
 template <int D, int K>
-__global__ void __launch_bounds__(kEmThreads, 3) cacgmm_em32_kernel(EmArgs a) {
+__global__ void __launch_bounds__(kEmThreads, em_waves_per_simd(K)) cacgmm_em32_kernel(EmArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   EmKernel32<D, K>::run(a, smem);
 }

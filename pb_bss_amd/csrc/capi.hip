@@ -614,7 +614,7 @@ PBBSS_API int pbbss_cacgmm_fit(pbbss_handle_t h, const void* y, int64_t B, int T
   if (o->weight_mode < 0 || o->weight_mode > 1) return PBBSS_ERR_INVALID_ARG;
   if (o->precision != PBBSS_PRECISION_F64 && o->precision != PBBSS_PRECISION_F32)
     return PBBSS_ERR_INVALID_ARG;
-  if (o->precision == PBBSS_PRECISION_F32 && (D > 8 || K > 4)) return PBBSS_ERR_UNSUPPORTED;
+  if (o->precision == PBBSS_PRECISION_F32 && (D > 8 || K > 6)) return PBBSS_ERR_UNSUPPORTED;
   if (D > 8 || K > 6) {
     // generic-size path (generic.hip; also more than 6 classes at any D): E-step, covariance + weights, eigendecomposition per
     // iteration, enqueued back to back; the model lives in the caller's output buffers
@@ -752,7 +752,7 @@ PBBSS_API int pbbss_cacgmm_fit(pbbss_handle_t h, const void* y, int64_t B, int T
   }
   if (D < 2 || D > 8 || K < 1 || K > 6) return PBBSS_ERR_UNSUPPORTED;
   const bool f32 = o->precision == PBBSS_PRECISION_F32;
-  if (f32 && (o->y_is_c128 || K > 4 || out_quadratic_form)) return PBBSS_ERR_UNSUPPORTED;
+  if (f32 && (o->y_is_c128 || out_quadratic_form)) return PBBSS_ERR_UNSUPPORTED;
   pbbss::EmArgs a{};
   a.y = y;
   a.B = B;

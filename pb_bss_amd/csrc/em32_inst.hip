@@ -79,6 +79,8 @@ int PBBSS_CAT(em32_launch_d, PBBSS_EM_D)(int K, const EmArgs& a, const EmLaunchC
     case 2: return launch32<2>(a, cfg, stream);
     case 3: return launch32<3>(a, cfg, stream);
     case 4: return launch32<4>(a, cfg, stream);
+    case 5: return launch32<5>(a, cfg, stream);
+    case 6: return launch32<6>(a, cfg, stream);
     default: return PBBSS_ERR_UNSUPPORTED;
   }
 }

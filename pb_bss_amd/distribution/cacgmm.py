@@ -270,7 +270,7 @@ class CACGMMTrainer:
             sal = sal.reshape(-1, N).contiguous()
 
         if fused:
-            if packed32 and D <= 8 and K <= 4:
+            if packed32 and D <= 8 and K <= 6:
                 try:
                     return self._rounded(self._fit_fused(
                         y.reshape(-1, N, D), indep, K, gamma0, model, iterations, sal,

@@ -151,7 +151,7 @@ def result_dtype(mode):
 # itself computes in single precision -- a complex64 observation with an array initialisation
 # (cacgmm.py:226-227) -- use the packed-FP32 kernel (csrc/cacgmm_em32.hpp: E / M phases in
 # float32, class sums and factorisation in float64); anything that kernel does not serve
-# (complex128, K > 4, long utterances, bin-coupled weights) runs in float64.
+# (complex128, long utterances, bin-coupled weights) runs in float64.
 _ARITHMETICS = ('float64', 'reference')
 _arithmetic = os.environ.get('PBBSS_ARITHMETIC', 'float64')
 assert _arithmetic in _ARITHMETICS, _arithmetic

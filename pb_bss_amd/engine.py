@@ -88,7 +88,7 @@ def em_fit(y, K, *, gamma0=None, model=None, iterations=100, saliency=None,
            layout=_lib.LAYOUT_TD, final_predict=False, return_q=False,
            force_eig=False, check_status=True, precision='f64'):
     """pbbss_cacgmm_fit.  y (B,T,D) [layout TD] or (B,D,T) [layout DT] complex.
-    precision 'f32': the packed-FP32 "reference precision" kernel (complex64 y, D <= 8, K <= 4,
+    precision 'f32': the packed-FP32 "reference precision" kernel (complex64 y, D <= 8, K <= 6,
     LDS-resident frames) -- NotImplementedError where it does not apply.
 
     gamma0 (B,K,T) f64, or model=(eigvec (B,K,D,D) c128, eigval (B,K,D), weight (B,K)).

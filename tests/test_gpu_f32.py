@@ -55,6 +55,45 @@ def test_per_step_against_the_references_float32_path(tag, iters):
     assert int(r['status'].max()) & 3 == 0
 
 
+@pytest.mark.parametrize('tag', ['k5', 'k6'])
+@pytest.mark.parametrize('iters', [1, 2])
+def test_five_and_six_classes_against_the_references_float32_path(tag, iters):
+    """K = 5, 6 in the packed-FP32 kernel (refused until round 4; two weight vectors per frame,
+    two waves per SIMD): per step against the reference's own float32 and float64 runs."""
+    g = np.load(os.path.join(os.path.dirname(GOLD), 'cacgmm_single_precision_k56.npz'))
+    Y, init = g[f'{tag}_Y'], g[f'{tag}_init']
+    r = _fit32(Y, init, iters)
+    aff32 = g[f'{tag}_aff32_it{iters}'].astype(np.float64)
+    aff64 = g[f'{tag}_aff64_it{iters}']
+    ref_gap = np.abs(aff32 - aff64).max()
+    assert np.abs(r['affiliation'] - aff64).max() < max(2.0 * ref_gap, 2e-5)
+    assert np.abs(r['affiliation'] - aff32).max() < 1e-4
+    assert np.abs(r['weight'] - g[f'{tag}_weight32_it{iters}'][..., 0]).max() < 1e-5
+    assert int(r['status'].max()) & 3 == 0
+
+
+@pytest.mark.parametrize('T', [300, 500])   # 5 members < K: every member factors; 8 >= K: distributed
+def test_remainder_bin_members_with_six_classes(T):
+    from oracle import cacgmm as oc, synth
+    from pb_bss_amd import engine
+    F, D, K = 257, 4, 6
+    Y, init = synth.make_stft(F, T, D, K, seed=T)
+    r_split = _fit32(Y, init, 3)
+    engine.set_split_tail(False)
+    try:
+        r_plain = _fit32(Y, init, 3)
+    finally:
+        engine.set_split_tail(True)
+    assert engine.split_error() == 0
+    assert np.abs(r_split['affiliation'][:256] - r_plain['affiliation'][:256]).max() == 0.0
+    assert np.abs(r_split['affiliation'][256] - r_plain['affiliation'][256]).max() < 2e-4
+    sel = [0, 255, 256]
+    Y128 = Y[sel].astype(np.complex128)
+    ref = oc.em_predict(oc.em_fit(Y128, init[sel], iterations=3), Y128)
+    assert np.abs(r_split['affiliation'][sel] - ref).max() < 1e-3
+    assert int(r_split['status'].max()) & 3 == 0
+
+
 @pytest.mark.parametrize('iters', [1, 2])
 def test_source_activity_mask_against_the_references_float32_path(iters):
     """source_activity_mask in the packed-FP32 kernel (refused until round 4): per step against
@@ -85,7 +124,8 @@ def test_source_activity_mask_against_the_references_float32_path(iters):
 
 
 @pytest.mark.parametrize('D,K,T', [(2, 2, 90), (3, 1, 130), (4, 3, 257), (5, 4, 300), (6, 2, 64),
-                                   (7, 3, 511), (8, 4, 500), (8, 3, 256)])
+                                   (7, 3, 511), (8, 4, 500), (8, 3, 256), (2, 5, 130), (3, 6, 257),
+                                   (5, 5, 300), (7, 6, 200), (8, 5, 500), (8, 6, 500)])
 def test_every_compiled_size_against_the_float64_oracle(D, K, T):
     from oracle import cacgmm as oc, synth
     F = 7
@@ -162,9 +202,9 @@ def test_trainer_switch_model_resume_and_fallbacks():
         # complex128 input: the reference computes in float64 -> float64 kernel (exact parity)
         m64 = CACGMMTrainer().fit(Y128, initialization=init, iterations=3)
         assert np.abs(m64.predict(Y128) - ref).max() < 1e-9
-        # K = 5 is not served by the packed kernel -> float64 kernel, silently
-        Y5, init5 = synth.make_stft(3, 120, 4, 5, seed=9)
-        CACGMMTrainer().fit(Y5, initialization=init5, iterations=2)
+        # K = 7 is not served by the packed kernel -> generic-size float64 path, silently
+        Y7, init7 = synth.make_stft(3, 120, 4, 7, seed=9)
+        CACGMMTrainer().fit(Y7, initialization=init7, iterations=2)
     assert np.abs(got - ref).max() < 5e-4
     assert 1e-9 < np.abs(got - ref).max()  # it really was the single-precision kernel
     # resume from a model through the C ABI (precision F32, model initialisation)
@@ -179,5 +219,5 @@ def test_trainer_switch_model_resume_and_fallbacks():
         engine.em_fit(_lib.to_device(Y128), 3, gamma0=_lib.to_device(init), iterations=1,
                       precision='f32')
     with pytest.raises(NotImplementedError):
-        engine.em_fit(_lib.to_device(Y5), 5, gamma0=_lib.to_device(init5), iterations=1,
+        engine.em_fit(_lib.to_device(Y7), 7, gamma0=_lib.to_device(init7), iterations=1,
                       precision='f32')
