@@ -169,7 +169,13 @@ struct TimedRegion {
 // that kind first waits (stream-ordered, hipStreamWaitEvent) for the completion event of the
 // previous one -- whichever handle issued it -- and leaves its own completion event behind.  With
 // a single handle on the device the gate does nothing at all (stream order already serialises its
-// launches); PBBSS_RESIDENCY_GATE=0 switches it off.
+// launches); PBBSS_RESIDENCY_GATE=0 switches it off.  The entry points arm it only for calls that
+// CAN launch such a kernel (`needed`: may_split() for the fused fits, always for the cooperative
+// shared-weight fit and the DHTV solver): plain fits -- no remainder bin, fewer than three
+// iterations, generic-size path, the joint models (their members never wait) -- keep their
+// multi-stream concurrency beside other handles.  Best effort by design: two host threads whose
+// constructor-to-destructor windows overlap do not see each other's event; the bounded waits and
+// the host-side repeats remain the safety net.
 struct ResidencyGate {
   static constexpr int kMaxDev = 64;
   struct State {
@@ -193,8 +199,8 @@ struct ResidencyGate {
   pbbss_handle_t h;
   hipStream_t s;
   bool active;
-  ResidencyGate(pbbss_handle_t h_, hipStream_t s_) : h(h_), s(s_), active(false) {
-    if (!h || h->gate_dev < 0 || !enabled()) return;
+  ResidencyGate(pbbss_handle_t h_, hipStream_t s_, bool needed = true) : h(h_), s(s_), active(false) {
+    if (!needed || !h || h->gate_dev < 0 || !enabled()) return;
     State& st = state(h->gate_dev);
     std::lock_guard<std::mutex> g(st.mu);
     if (st.handles < 2) return;  // nobody to collide with
@@ -222,10 +228,23 @@ struct ResidencyGate {
     }
     h->gate_dev = dev;
     State& st = state(dev);
-    std::lock_guard<std::mutex> g(st.mu);
     // the gate becomes active with the second handle: whatever the first one has in flight was
-    // launched without leaving an event behind -- let it drain once
-    if (++st.handles == 2) (void)hipDeviceSynchronize();
+    // launched without leaving an event behind -- let it drain once (outside the lock: a gated
+    // launch of another thread must not wait behind a device-wide synchronisation)
+    bool drain;
+    {
+      std::lock_guard<std::mutex> g(st.mu);
+      drain = ++st.handles == 2;
+    }
+    if (drain) (void)hipDeviceSynchronize();
+  }
+  // Can a fused fit of B problems launch workgroups that wait for each other (split groups /
+  // in-grid members of the remainder problems: em_inst.hip, em32_inst.hip, cw_inst.hip)?  A
+  // superset of the launchers' own conditions, from the arguments alone.
+  static bool may_split(pbbss_handle_t h, int64_t B, int D, int iterations) {
+    if (!h) return false;
+    const int64_t cu = h->cfg.num_cu > 0 ? h->cfg.num_cu : 256;
+    return D <= 8 && iterations >= pbbss::kSplitMinIterations && B > cu && B % cu != 0;
   }
   static void on_destroy(pbbss_handle_t h) {
     if (h->gate_dev < 0) return;
@@ -603,7 +622,8 @@ PBBSS_API int pbbss_cacgmm_fit(pbbss_handle_t h, const void* y, int64_t B, int T
                                double* out_weight, int32_t* out_status, double* out_affiliation,
                                double* out_quadratic_form, void* stream) {
   DeviceGuard device_guard(h);
-  ResidencyGate residency_gate(h, as_stream(stream));  // see ResidencyGate
+  ResidencyGate residency_gate(h, as_stream(stream),
+                               o && ResidencyGate::may_split(h, B, D, o->iterations));
   if (!h || !y || !o || B <= 0 || T <= 0) return PBBSS_ERR_INVALID_ARG;
   if (o->iterations <= 0) return PBBSS_ERR_INVALID_ARG;  // cacgmm.py:200
   const bool has_gamma = gamma0 != nullptr;
@@ -1138,7 +1158,11 @@ PBBSS_API int pbbss_cwmm_fit(pbbss_handle_t h, const void* y, int64_t B, int T, 
                              double* out_concentration, double* out_weight, int32_t* out_status,
                              double* out_affiliation, double* out_log_pdf, void* stream) {
   DeviceGuard device_guard(h);
-  ResidencyGate residency_gate(h, as_stream(stream));  // see ResidencyGate
+  // shared class weights run as ONE cooperative launch per batch of groups (cw_launch_shared)
+  ResidencyGate residency_gate(
+      h, as_stream(stream),
+      o && (o->weight_mode == PBBSS_WEIGHT_SHARED_K || o->weight_mode == PBBSS_WEIGHT_SHARED_KT ||
+            ResidencyGate::may_split(h, B, D, o->iterations)));
   if (!h || !y || !o || B <= 0 || T <= 0) return PBBSS_ERR_INVALID_ARG;
   if (o->iterations < 0) return PBBSS_ERR_INVALID_ARG;
   const bool has_gamma = gamma0 != nullptr;
@@ -1663,7 +1687,8 @@ PBBSS_API int pbbss_joint_fit(pbbss_handle_t h, const void* observation, const v
                               double* out_weight, double* out_mean, double* out_scale,
                               int32_t* out_status, double* out_affiliation, void* stream) {
   DeviceGuard device_guard(h);
-  ResidencyGate residency_gate(h, as_stream(stream));  // see ResidencyGate
+  // (no residency gate: the member workgroups of the joint kernels never wait for each other --
+  // the last arriver finishes the problem, run_joint_member in cacgmm_em.hpp)
   if (!h || !observation || !embedding || !o || F <= 0 || T <= 0) return PBBSS_ERR_INVALID_ARG;
   // 9 <= D <= 32 or 7..8 classes: the spatial half runs on the generic-size kernels
   // (generic.hip), one E-step and one M-step launch group per iteration around the same spectral

@@ -202,8 +202,7 @@ class CACGMMTrainer:
         # reference computes in single precision (cacgmm.py:226-227) -> packed-FP32 kernel
         packed32 = (reference_arithmetic() and initialization is not None
                     and not isinstance(initialization, CACGMM)
-                    and str(y.dtype).rsplit('.', 1)[-1] == 'complex64'
-                    and source_activity_mask is None)
+                    and str(y.dtype).rsplit('.', 1)[-1] == 'complex64')
         # result dtype 'reference': an array initialisation is cast to y.real.dtype
         # (cacgmm.py:226-227), a model keeps its own, random affiliations are float64
         # (:208); a saliency enters the M step as it is (:336-339)
@@ -279,7 +278,9 @@ class CACGMMTrainer:
                         precision='f32'), single, mode)
                 except NotImplementedError:
                     pass  # e.g. an utterance too long for the LDS-resident kernel: float64 serves it
-                except (AssertionError, np.linalg.LinAlgError) as e:
+                except (engine.StatusAssertionError, engine.StatusLinAlgError) as e:
+                    # (only the status-derived errors: an argument check that fails in
+                    # _fit_fused must surface, not run the fit twice)
                     # a status failure of the reduced-precision kernel (ill-conditioned bins are
                     # likelier to go non-finite in float32): the float64 kernel is the accuracy
                     # superset -- let it try before the reference's error is raised
@@ -466,7 +467,7 @@ class CACGMMTrainer:
     def _fit_stepwise(self, yb, indep, K, gamma0, model, iterations, saliency,
                       sal, act, weight_constant_axis, covariance_norm,
                       affiliation_eps, eigenvalue_floor, hermitize, aligner,
-                      like_torch, weight_hook=None, _retry_team=True, _retry_split=True):
+                      like_torch, weight_hook=None, _retry_team=True):
         """The reference loop (cacgmm.py:252-278) for the options that couple frequency bins
         (weight_constant_axis with independent axes, inline_permutation_aligner), one E-step
         and one M-step launch per iteration with the cross-bin reduction
@@ -543,25 +544,8 @@ class CACGMMTrainer:
             vec, val = vec.reshape(*indep, K, D, D), val.reshape(*indep, K, D)
         what = 'ComplexAngularCentralGaussianTrainer._fit'
         bits = int(np.bitwise_or.reduce(_lib.to_host(t.cat(m_status)))) if m_status else 0
-        poison = _lib.ST_NONFINITE | _lib.ST_EIG_NOCONV
-        if (bits & poison) == poison and _retry_split and engine.split_error(dev.index):
-            # the split groups of a remainder bin timed out in one of the M-steps (engine.
-            # _checked_with_split_retry has the story): the whole loop again without them
-            import warnings
-            warnings.warn(f'{what}: the split groups of the remainder bin were not co-resident '
-                          '(GPU shared with other work); repeating the fit without them',
-                          RuntimeWarning)
-            engine.split_reset(dev.index)
-            was = engine.split_tail(dev.index)
-            engine.set_split_tail(False, dev.index)
-            try:
-                return self._fit_stepwise(
-                    yb, indep, K, gamma0, model, iterations, saliency, sal, act,
-                    weight_constant_axis, covariance_norm, affiliation_eps, eigenvalue_floor,
-                    hermitize, aligner, like_torch, weight_hook=weight_hook,
-                    _retry_team=_retry_team, _retry_split=False)
-            finally:
-                engine.set_split_tail(was, dev.index)
+        # (one-iteration M-step launches never use split groups -- kSplitMinIterations = 3,
+        # csrc/em_launch.hpp -- so there is no inter-workgroup time-out to recover from here)
         engine._raise_for_bits(bits, what)
         if aligner_status:
             bits = int(np.bitwise_or.reduce(_lib.to_host(t.cat(aligner_status)).reshape(-1)))
@@ -569,6 +553,12 @@ class CACGMMTrainer:
                 # a wait between the workgroups that share the utterance ran out in one of the
                 # iterations (GPU shared with other work): nothing downstream of that mapping
                 # is valid -- run the loop again on the one-workgroup kernel
+                if weight_hook is not None:
+                    # a rank-local repeat of the loop would issue `iterations` collectives its
+                    # peers never join (not reachable today: under sharding the aligner is the
+                    # synchronous sharded_inline_aligner, which recovers inside the solver)
+                    raise RuntimeError('inline DHTV permutation alignment timed out inside a '
+                                       'sharded fit; set_dhtv_team(1) avoids the team kernel')
                 import warnings
                 warnings.warn('inline DHTV permutation alignment: the workgroups of the '
                               'utterance were not co-resident (GPU shared with other work); '
@@ -580,7 +570,7 @@ class CACGMMTrainer:
                         yb, indep, K, gamma0, model, iterations, saliency, sal, act,
                         weight_constant_axis, covariance_norm, affiliation_eps, eigenvalue_floor,
                         hermitize, aligner, like_torch, weight_hook=weight_hook,
-                        _retry_team=False, _retry_split=_retry_split)
+                        _retry_team=False)
                 finally:
                     engine.set_dhtv_team(before, dev.index)
             if bits != 0:

@@ -16,6 +16,7 @@ from .. import _lib
 from . import _joint
 from .complex_angular_central_gaussian import ComplexAngularCentralGaussian
 from .gaussian import DiagonalGaussian, Gaussian, SphericalGaussian
+from .utils import _ProbabilisticModel, as_result
 
 _KIND = {'spherical': _lib.EMBED_GAUSS_SPHERICAL, 'diagonal': _lib.EMBED_GAUSS_DIAG,
          'full': _lib.EMBED_GAUSS_FULL}
@@ -27,7 +28,7 @@ def _kind_of(gaussian):
         if isinstance(gaussian, cls):
             return _KIND[name]
     raise TypeError(type(gaussian))
-from .utils import _ProbabilisticModel, as_result
+
 
 __all__ = ['GCACGMM', 'GCACGMMTrainer']
 

@@ -24,16 +24,26 @@ def _status_bits(status):
     return int(np.bitwise_or.reduce(_lib.to_host(status).ravel()))
 
 
+class StatusAssertionError(AssertionError):
+    """The reference's `assert np.isfinite(...)` failure, derived from a kernel's status words
+    (an AssertionError for callers that catch the reference's; a type of its own for callers that
+    must tell a status failure from an argument check)."""
+
+
+class StatusLinAlgError(np.linalg.LinAlgError):
+    """The reference's eigensolver failure, derived from a kernel's status words."""
+
+
 def _raise_for_bits(bits, what):
     """Mirror the reference's failure modes of the M-step."""
     if bits & _lib.ST_NONFINITE:
         # distribution/complex_angular_central_gaussian.py:127, :326, :333
-        raise AssertionError(
+        raise StatusAssertionError(
             f'{what}: non-finite covariance / eigenvalues '
             '(reference: assert np.isfinite(...))')
     if bits & _lib.ST_EIG_NOCONV:
         # complex_angular_central_gaussian.py:94-110 (LinAlgError from eigh/eig)
-        raise np.linalg.LinAlgError(f'{what}: Hermitian eigensolver did not converge')
+        raise StatusLinAlgError(f'{what}: Hermitian eigensolver did not converge')
 
 
 def _status_raise_em(status, what):
@@ -199,11 +209,12 @@ def em_fit_shared(y, K, group, *, weight_mode, gamma0=None, model=None, iteratio
     _lib.check(rc, f'cacgmm_fit_shared(B={B},group={group},T={T},D={D},K={K})')
     if check_status:
         poison = _lib.ST_NONFINITE | _lib.ST_EIG_NOCONV
-        if iterations > 0 and bool(((out_st & poison) == poison).all().item()) \
-                and split_error(dev.index):
-            # every status word carries the time-out pattern and the handle's wait flag is up:
-            # the cooperative launch did not get its workgroups co-resident (other kernels of
-            # this process held the compute units).  Not a numerical failure: say "not served"
+        if iterations > 0 and split_error(dev.index) \
+                and bool(((out_st & poison) == poison).any().item()):
+            # some status words carry the time-out pattern and the handle's wait flag is up (the
+            # groups of a big batch go out as several cooperative launches: one of them can time
+            # out alone): a cooperative launch did not get its workgroups co-resident (other
+            # kernels of this process held the compute units).  Not a numerical failure: say "not served"
             # and let the caller run the step-wise loop, which needs no co-residency.
             import warnings
             warnings.warn('cooperative shared-weight launch timed out waiting for co-residency; '
@@ -272,12 +283,11 @@ def cacg_m_step(y, saliency, quadratic_form, *, layout=_lib.LAYOUT_DT,
         _lib.check(rc, f'cacg_m_step(B={B},T={T},D={D},K={K})')
         return dict(eigvec=out_vec, eigval=out_val, cov=out_cov, status=out_st)
 
-    # the M-step is ONE iteration of the EM kernel: a remainder bin (2^n + 1 bins) runs as split
-    # groups here too, so the step-wise loop -- the fallback of the cooperative kernel -- needs the
-    # same time-out handling as the fused fit (found by tests/test_gpu_timeouts.py: the fallback
-    # itself raised the reference's finiteness assert when its split groups timed out)
-    r = (_checked_with_split_retry(launch, dev, 'ComplexAngularCentralGaussianTrainer._fit')
-         if check_status else launch())
+    # ONE iteration of the EM kernel: split groups need kSplitMinIterations = 3 (em_launch.hpp), so
+    # this launch has no inter-workgroup wait and no time-out to recover from
+    r = launch()
+    if check_status:
+        _status_raise_em(r['status'], 'ComplexAngularCentralGaussianTrainer._fit')
     return r['eigvec'], r['eigval'], r['cov'], r['status']
 
 
@@ -566,7 +576,9 @@ def cwmm_fit(y, K, spline, *, gamma0=None, model=None, iterations=100, saliency=
             return None
         if check_status:
             poison = _lib.ST_NONFINITE | _lib.ST_EIG_NOCONV
-            if bool(((r['status'] & poison) == poison).all().item()) and split_error(dev.index):
+            # .any(): the groups of a big batch go out as several cooperative launches, one of
+            # which can time out alone
+            if split_error(dev.index) and bool(((r['status'] & poison) == poison).any().item()):
                 import warnings
                 warnings.warn('cooperative shared-weight launch timed out waiting for '
                               'co-residency; repeating the fit step by step', RuntimeWarning,
@@ -596,6 +608,7 @@ def wmwf(target, noise, distortion_weight=1.0, frequency_dependent=False):
     return mat, num, den, st
 
 
+_DHTV_PROBE = {}  # (device index, host thread) -> last set_dhtv_probe flag word (default 0)
 _SPLIT_TAIL = {}  # (device index, host thread) -> last set_split_tail value (default: on)
 
 
@@ -650,6 +663,12 @@ def set_dhtv_probe(enable, device_index=None):
     flags = int(enable) if isinstance(enable, int) and not isinstance(enable, bool) else int(bool(enable))
     _lib.check(_lib.load().pbbss_set_dhtv_probe(_lib.handle(device_index), flags),
                'set_dhtv_probe')
+    _DHTV_PROBE[_handle_key(device_index)] = flags
+
+
+def dhtv_probe(device_index=None):
+    """The probe flag word in force on this thread's handle (its last set_dhtv_probe, else 0)."""
+    return _DHTV_PROBE.get(_handle_key(device_index), 0)
 
 
 def dhtv_team(device_index=None):

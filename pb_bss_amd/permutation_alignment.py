@@ -173,13 +173,14 @@ class DHTVPermutationAlignment(_PermutationAlignment):
         assert K < 10, (K, 'Sure?')
         # masks of consecutive EM iterations mostly arrive aligned: let the library test that on
         # all segments at once before it walks the plan (pbbss_set_dhtv_probe; same results)
+        before = engine.dhtv_probe(mask.device.index)  # a caller's own setting is put back
         engine.set_dhtv_probe(3, mask.device.index)  # + the aligned features are not needed
         try:
             mapping, _, st = engine.dhtv_calculate_mapping(
                 mask, self._device_plan(F, mask.device), optimal=(self.algorithm == 'optimal'),
                 metric=self.similarity_metric)
         finally:
-            engine.set_dhtv_probe(False, mask.device.index)
+            engine.set_dhtv_probe(before, mask.device.index)
         return mapping, st
 
     def calculate_mapping(self, mask, plot=False):

@@ -501,3 +501,69 @@ def test_joint_models_long_utterance_runs_on_the_streaming_kernels(kind):
     want = oe.joint_model_predict(ref, Y.astype(np.complex128), e.astype(np.float64))
     assert masks.shape == (F, K, T)
     assert np.abs(masks - want).max() < 1e-6
+
+
+def _joint_trajectory(kind, F, T, iterations, seed, **kw):
+    """Device fit + predict and the oracle's, same inputs -> (model, masks, oracle model, oracle
+    masks) of a config-5-shaped problem (8 mics, K = 3, 40-dim embeddings) with F bins."""
+    from pb_bss_amd.distribution import GCACGMMTrainer, VMFCACGMMTrainer
+    from oracle import embed as oe, synth
+    D, K, E = 8, 3, 40
+    Y, e, init = synth.make_joint(F, T, D, K, E, seed=seed)
+    Y128, e64 = Y.astype(np.complex128), e.astype(np.float64)
+    trainer = GCACGMMTrainer() if kind == 'gaussian' else VMFCACGMMTrainer()
+    model = trainer.fit(Y, e, initialization=init, iterations=iterations, **kw)
+    masks = model.predict(Y, e)
+    ref = oe.joint_fit(kind, Y128, e64, init, iterations, **kw)
+    want = oe.joint_model_predict(ref, Y128, e64)
+    return model, masks, ref, want
+
+
+def _assert_joint_model_close(model, ref, kind, tol):
+    """Spectral model (mean + covariance / concentration), cACG covariance V diag(lambda) V^H
+    (eigenvector phases are arbitrary, the product is not) and class weights."""
+    np.testing.assert_allclose(np.squeeze(model.weight), np.squeeze(ref['weight']), atol=tol)
+    got = cov(model.cacg.covariance_eigenvectors, model.cacg.covariance_eigenvalues)
+    np.testing.assert_allclose(got, cov(ref['eigvec'], ref['eigval']), atol=tol)
+    if kind == 'gaussian':
+        np.testing.assert_allclose(model.gaussian.mean, ref['mean'], atol=tol)
+        np.testing.assert_allclose(model.gaussian.covariance, ref['covariance'], rtol=tol, atol=tol)
+    else:
+        np.testing.assert_allclose(model.vmf.mean, ref['mean'], atol=tol)
+        np.testing.assert_allclose(model.vmf.concentration, ref['concentration'], rtol=tol)
+
+
+@pytest.mark.parametrize('kind', ['gaussian', 'vmf'])
+def test_joint_models_100_iterations_against_oracle(kind):
+    """The trajectory bench.py times (configs[4]: 100 EM iterations), pinned end to end: every
+    iteration but the last goes through the Gauss-Jordan fast path with the conditioning veto
+    (gcacgmm.py:121-225; complex_angular_central_gaussian.py:112-126 is evaluated exactly only
+    where the floor could bind), so a drift of that path would show here and nowhere in the
+    4 / 5 / 8-iteration cases above.  F = 65 keeps the oracle at a few seconds; the spectral
+    mixture couples the bins, so this is a self-contained problem, not a slice of the big one."""
+    kw = {} if kind == 'gaussian' else dict(max_concentration=80.)
+    model, masks, ref, want = _joint_trajectory(kind, 65, 500, 100, seed=3, **kw)
+    assert np.abs(masks - want).max() < 1e-6
+    _assert_joint_model_close(model, ref, kind, 1e-7)
+
+
+def test_gcacgmm_full_covariance_50_iterations_against_oracle():
+    """covariance_type='full' (gaussian.py:152-193 behind gcacgmm.py:267-333): 50 iterations of the
+    FP64-MFMA scatter / Cholesky path inside the joint loop."""
+    model, masks, ref, want = _joint_trajectory('gaussian', 17, 500, 50, seed=4,
+                                                covariance_type='full')
+    assert np.abs(masks - want).max() < 1e-6
+    _assert_joint_model_close(model, ref, 'gaussian', 1e-7)
+
+
+@pytest.mark.parametrize('kind', ['gaussian', 'vmf'])
+def test_joint_inline_permutation_alignment_50_iterations_against_oracle(kind):
+    """inline_permutation_alignment=True (mixture_model_utils.py:58-130) over 50 iterations: the
+    per-bin permutation search must take the same decision as the reference in every bin of every
+    iteration, otherwise the trajectories part for good."""
+    kw = dict(weight_constant_axis=(-3,), inline_permutation_alignment=True)
+    if kind == 'vmf':
+        kw['max_concentration'] = 80.
+    model, masks, ref, want = _joint_trajectory(kind, 33, 500, 50, seed=5, **kw)
+    assert np.abs(masks - want).max() < 1e-6
+    _assert_joint_model_close(model, ref, kind, 1e-7)

@@ -121,6 +121,15 @@ def test_source_activity_mask_against_the_references_float32_path(iters):
     with pb_bss_amd.arithmetic('reference'):
         m = CACGMMTrainer().fit(Y, initialization=init, iterations=iters, source_activity_mask=mask)
     assert np.abs(m.predict(Y) - aff32).max() < 1e-4
+    # ... which kernel served it is visible in the model: bit-identical to the packed kernel's
+    # (rounded to the reference's float32 result dtype), not to the float64 kernel's
+    cov = lambda vec, val: np.einsum('...ij,...j,...kj->...ik', vec, val, vec.conj())  # noqa: E731
+    got = cov(m.cacg.covariance_eigenvectors, m.cacg.covariance_eigenvalues)
+    c32 = cov(r['eigvec'].astype(got.dtype), r['eigval'].astype(m.cacg.covariance_eigenvalues.dtype))
+    c64 = cov(_lib.to_host(r64['eigvec']).astype(got.dtype),
+              _lib.to_host(r64['eigval']).astype(m.cacg.covariance_eigenvalues.dtype))
+    assert np.array_equal(got, c32)
+    assert not np.array_equal(got, c64)
 
 
 @pytest.mark.parametrize('D,K,T', [(2, 2, 90), (3, 1, 130), (4, 3, 257), (5, 4, 300), (6, 2, 64),
