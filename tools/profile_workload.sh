@@ -1,11 +1,12 @@
 #!/bin/bash
-# rocprofv3 evidence for BASELINE configs[3] / configs[4] (bench.py --workload config4|config5):
+# rocprofv3 evidence for BASELINE configs[2] / [3] / [4] (bench.py --workload config3|config4|config5):
 # an un-profiled run, one --kernel-trace --stats pass and SEPARATE --pmc passes of the same
 # command (never combined with other trace domains).  The step of the profiled command is the EM
 # region only (config4: --c4-extraction off), so that the kernels of one step in the trace are the
 # ones bench.py's HIP events bracket.
 #   gpurun -- 'bash tools/profile_workload.sh r04_a config5'
 #   gpurun -- 'bash tools/profile_workload.sh r04_a config4 watson'
+#   gpurun -- 'bash tools/profile_workload.sh r05_a config3'        (the whole 64-utterance chain)
 #   -> gpurun_out/<tag>_<workload>[_vmf]_profile.txt   (copy to profiles/)
 set -u
 TAG=${1:-rXX}
@@ -15,6 +16,7 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out
 STEPS=20
 WARM=3
+[ "$WL" = config3 ] && STEPS=6 && WARM=2
 NAME=$WL
 [ "$WL" = config4 ] && [ "$LEG" = vmf ] && NAME=config4_vmf
 CMD="python $ROOT/bench.py --workload $WL --leg $LEG --steps $STEPS --warmup $WARM --cpu-iters 0 --check-bins 0 --c4-extraction off --preheat-s 0.3"

@@ -14,14 +14,22 @@ import sys
 from collections import defaultdict
 
 MARKER = {'config5': 'embed_prepare_kernel', 'config4': 'cwmm_em_kernel',
-          'config4_vmf': 'vmf_bin_em_kernel'}
+          'config4_vmf': 'vmf_bin_em_kernel', 'config3': 'cacgmm_em_kernel'}
+# config3's step is the whole chain of pipeline.separate: the torch copy / reduction kernels
+# between the library's launches (transposes, the sum over the classes, the stack of the outputs)
+# are part of the step and of its traffic, so they are listed and counted too
+ALL_KERNELS = {'config3'}
 
 
 def short(name):
     name = re.sub(r'\(anonymous namespace\)::', '', name)
     name = re.sub(r'^void ', '', name)
     m = re.match(r'(pbbss::[A-Za-z0-9_]+(<[^(]*>)?)', name)
-    return m.group(1) if m else name[:70]
+    if m:
+        return m.group(1)
+    # torch kernels: the function name without its template arguments
+    m = re.match(r'([A-Za-z0-9_:]+)', name)
+    return 'torch: ' + (m.group(1) if m else name)[:60]
 
 
 def rows_of(pattern):
@@ -47,7 +55,7 @@ def main(root, cmd, sha, workload):
     # ---- kernel trace: per-kernel totals, steps from the marker kernel ----
     dur, calls = defaultdict(float), defaultdict(int)
     for r in rows_of(os.path.join(root, 'trace', '**', '*kernel_trace.csv')):
-        if 'pbbss' not in r['Kernel_Name']:
+        if 'pbbss' not in r['Kernel_Name'] and workload not in ALL_KERNELS:
             continue
         k = short(r['Kernel_Name'])
         dur[k] += (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
@@ -79,7 +87,7 @@ def main(root, cmd, sha, workload):
                               recursive=True)):
         acc = defaultdict(list)
         for r in csv.DictReader(open(f)):
-            if 'pbbss' in r['Kernel_Name']:
+            if 'pbbss' in r['Kernel_Name'] or workload in ALL_KERNELS:
                 acc[(short(r['Kernel_Name']), r['Counter_Name'])].append(float(r['Counter_Value']))
         if not acc:
             continue
