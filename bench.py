@@ -1170,7 +1170,7 @@ def workload_pmc(workload, region_ms):
                 f'streaming reads) + WRITE_SIZE summed over the kernels of one step, separate --pmc '
                 f'passes; kernels of a step sum to {trace_ms:.3f} ms in the trace')
     return None, (f'no committed profile carries kernel_source_sha {sha} for {workload} '
-                  f'(bash tools/profile_round.sh <tag> {workload})')
+                  f'(bash tools/profile_workload.sh <tag> {workload})')
 
 
 def dual_roofline(region_ms, frames, iters, flops_per_frame_iter, bytes_per_iter, bytes_formula,

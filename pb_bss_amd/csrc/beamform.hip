@@ -460,12 +460,12 @@ __global__ void __launch_bounds__(kEmThreads, 3)
 #pragma unroll
         for (int k = 0; k < K; ++k) {
           double m = mask[b * mask_bstride + (int64_t)k * T + t];
-          L.wbuf[(size_t)k * L.Tp + t] = m;
+          L.wbuf[Kern::woff(k, t)] = m;
           s[k] += m;
         }
       }
     } else {
-      for (int t = tid; t < T; t += kEmThreads) L.wbuf[t] = 1.0 / (double)T;  // :114-117
+      for (int t = tid; t < T; t += kEmThreads) L.wbuf[Kern::woff(0, t)] = 1.0 / (double)T;  // :114-117
     }
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -484,7 +484,7 @@ __global__ void __launch_bounds__(kEmThreads, 3)
       }
       for (int t = tid; t < T; t += kEmThreads) {
 #pragma unroll
-        for (int k = 0; k < K; ++k) L.wbuf[(size_t)k * L.Tp + t] *= inv[k];
+        for (int k = 0; k < K; ++k) L.wbuf[Kern::woff(k, t)] *= inv[k];
       }
     }
     __syncthreads();

@@ -172,9 +172,15 @@ struct EmKernel {
   using YS2 = typename std::conditional<std::is_same<YS, float>::value, float2, double2>::type;
 
   struct Lds {
-    YS* ybuf;        // [DP][Tp][4]   channel pairs, frame contiguous
+    // Frame-sized arrays are kept in CHUNKS of 64 frames (one wavefront's worth), the planes of a
+    // chunk back to back: inside a chunk every plane sits at a compile-time offset from the lane's
+    // address, so a sweep over the frames advances ONE address register per array and the plane
+    // offsets ride in the instructions' immediate fields (round 5: the [plane][Tp] layout cost
+    // the M phase 13 VALU address instructions per 64 frames).  Tp is a multiple of 64; frames
+    // [T, Tp) hold y = 0, 1/|y|^2 = 0, w = 0, so every sweep runs over whole chunks unmasked.
+    YS* ybuf;        // [Tp/64][DP][64][4]  channel pairs (yoff)
     double* inv_n2;  // [Tp]
-    double* wbuf;    // [K][Tp]       M-step weights
+    double* wbuf;    // [Tp/64][K][64]      M-step weights (woff)
     double* cpack;   // [K][NA]       covariance sums, packed like apack: diag, then (Re, Im) per pair i<j
     double* apack;   // [K][NA]       A_k packed for the dot with P: diag, then (2Re, 2Im) per pair
     double* wgt;     // [K]           mixture weights
@@ -188,8 +194,17 @@ struct EmKernel {
     int Tp;
   };
 
+  static constexpr int kFC = 64;  // frames per chunk of the frame-sized arrays
+  static __host__ __device__ __forceinline__ int padded_frames(int T) { return (T + kFC - 1) & ~(kFC - 1); }
+  // element offsets into ybuf (in YS units) / wbuf of frame t
+  static __host__ __device__ __forceinline__ int yoff(int dp, int t) {
+    return ((((t >> 6) * DP + dp) << 6) + (t & 63)) * 4;
+  }
+  static __host__ __device__ __forceinline__ int woff(int k, int t) {
+    return (((t >> 6) * K + k) << 6) + (t & 63);
+  }
   static __host__ __device__ size_t frame_bytes(int T) {
-    size_t Tp = (size_t)((T + 1) & ~1);
+    size_t Tp = (size_t)padded_frames(T);
     return (size_t)DP * Tp * 4 * sizeof(YS) + Tp * 8 + (size_t)K * Tp * 8;
   }
   static __host__ __device__ size_t small_bytes() {
@@ -223,7 +238,7 @@ struct EmKernel {
 
   static __device__ Lds carve(char* base, int T, char* scratch = nullptr) {
     Lds L;
-    L.Tp = (T + 1) & ~1;
+    L.Tp = padded_frames(T);
     char* p = base;
     char* f = SPILL ? scratch : base;  // frame-sized arrays
     L.ybuf = reinterpret_cast<YS*>(f);
@@ -270,7 +285,7 @@ struct EmKernel {
     PBBSS_DEV_ASSERT(t >= 0 && t < L.Tp);
     static_for<0, DP>([&](auto dpc) {
       constexpr int dp = dpc;
-      YS4 v = *reinterpret_cast<const YS4*>(L.ybuf + ((size_t)dp * L.Tp + t) * 4);
+      YS4 v = *reinterpret_cast<const YS4*>(L.ybuf + yoff(dp, t));
       re[2 * dp] = (double)v.x;
       im[2 * dp] = (double)v.y;
       if constexpr (2 * dp + 1 < D) {
@@ -313,7 +328,7 @@ struct EmKernel {
         o.y = vi[2 * dp];
         o.z = vr[2 * dp + 1];
         o.w = vi[2 * dp + 1];
-        *reinterpret_cast<YS4*>(L.ybuf + ((size_t)dp * L.Tp + t) * 4) = o;
+        *reinterpret_cast<YS4*>(L.ybuf + yoff(dp, t)) = o;
       }
       double inv;
       if (a.layout == PBBSS_LAYOUT_TD) {
@@ -323,6 +338,10 @@ struct EmKernel {
       }
       L.inv_n2[t] = (t < T) ? inv : 0.0;
       if (t < T && !(n2 > 0.0)) zero_seen = true;
+      if (t >= T) {  // padding frames of the last chunk: weight 0 until an E phase rewrites them
+#pragma unroll
+        for (int k = 0; k < K; ++k) L.wbuf[woff(k, t)] = 0.0;
+      }
     }
     // An all-zero frame has q floored at `tiny` whatever the scale of B_k
     // (cacg.py:185-199), so its posterior depends on the eigenvalue
@@ -350,7 +369,7 @@ struct EmKernel {
         size_t idx = ((size_t)b * K + k) * TS + tf + t;
         double g = a.gamma0[idx] * sal;
         double q = a.q0 ? a.q0[idx] : 1.0;
-        L.wbuf[(size_t)k * L.Tp + t] = mweight(g, q, inv);
+        L.wbuf[woff(k, t)] = mweight(g, q, inv);
         if (a.gaff && a.weight_mode == PBBSS_WEIGHT_SHARED_KT)  // parity 0: iteration 0
           __hip_atomic_store(a.gaff + idx, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s[k] += g;
@@ -395,15 +414,22 @@ struct EmKernel {
       jlogdet[k] = JOINT ? log(L.detm[k]) + (double)L.dete[k] * 0.6931471805599453 : 0.0;
     auto pass = [&](int t0, auto nfc) {
       constexpr int NF = decltype(nfc)::value;  // frames per lane in this pass
-      int tt[NF];
+      // the wave's 64 frames of this pass are one chunk of the frame arrays: a chunk beyond the
+      // padded frame count has nothing in it (wave-uniform: the whole wave leaves)
+      if (t0 + wave * kWave >= padded_frames(a.T)) return;
+      int tl[NF];  // frame in LDS (padding frames [T, Tp) read y = 0, 1/|y|^2 = 0)
+      int tt[NF];  // frame clamped to [0, T) for the HBM side arrays
       bool ok[NF];
+      bool inl[NF];  // the frame exists in LDS (always for f = 0: the chunk test above)
       double re[NF][D], im[NF][D], q[NF][K];
 #pragma unroll
       for (int f = 0; f < NF; ++f) {
         int t = t0 + f * kEmThreads + tid;
         ok[f] = t < a.T;
+        inl[f] = (f == 0) || t < padded_frames(a.T);
         tt[f] = ok[f] ? t : (a.T - 1);
-        load_frame(L, tt[f], re[f], im[f]);
+        tl[f] = (f == 0) ? t : min(t, padded_frames(a.T) - 1);
+        load_frame(L, tl[f], re[f], im[f]);
 #pragma unroll
         for (int k = 0; k < K; ++k) q[f][k] = 0.0;
       }
@@ -463,7 +489,7 @@ struct EmKernel {
         // softmax of the weighted sum of spatial and spectral log-pdfs
         // (gcacgmm.py:108-115 -> mixture_model_utils.py:30-53)
         const int t = tt[0];
-        const double inv = L.inv_n2[t];
+        const double inv = L.inv_n2[tl[0]];
         double g[K], den = 0.0;
         if (jx->spatial_weight == 1.0) {
           // spatial_weight = 1 (the default): exp(spatial log-pdf) = 1 / (det_k q_k^D) in the
@@ -543,7 +569,9 @@ struct EmKernel {
           }
           if constexpr (!FINAL) {
             double gs = ok[0] ? gam * sal : 0.0;
-            if (ok[0]) L.wbuf[(size_t)k * L.Tp + t] = mweight(gs, q[0][k], inv);
+            // unconditional: a padding frame stores weight 0 (gs = 0, inv = 0), which is what the
+            // unmasked M sweep needs -- and whatever parked data in wbuf since the last M phase
+            L.wbuf[woff(k, tl[0])] = mweight(gs, q[0][k], inv);
             s[k] += gs;
           }
         }
@@ -551,7 +579,7 @@ struct EmKernel {
 #pragma unroll
       for (int f = 0; f < NF; ++f) {
         const int t = tt[f];
-        const double inv = L.inv_n2[t];
+        const double inv = L.inv_n2[tl[f]];
         // softmax over classes in mantissa/exponent form:
         //   exp(log_pdf_k) = 1 / (det_k q_k^D)   (cacg.py:200-201)
         // with q = m 2^e: one reciprocal of the mantissa serves both 1/q (M-step
@@ -614,7 +642,9 @@ struct EmKernel {
             // M-step weight gamma/max(q, 10 tiny)/|y|^2 (cacg.py:310, :322); q >= 10 tiny
             // except for all-zero frames, where inv = 0 makes the weight 0 anyway
             double rqk = (q[f][k] >= 10.0 * kTiny) ? rq[k] : (1.0 / (10.0 * kTiny));
-            if (ok[f]) L.wbuf[(size_t)k * L.Tp + t] = gs * rqk * inv;
+            // unmasked for the first frame of a lane: a padding frame writes 0 (gs = 0, inv = 0,
+            // rqk finite), which the unmasked M sweep relies on
+            if (f == 0 || inl[f]) L.wbuf[woff(k, tl[f])] = gs * rqk * inv;
             s[k] += gs;
           }
         }
@@ -649,24 +679,38 @@ struct EmKernel {
   static __device__ void phase_m(const EmArgs& a, const Lds& L, int lane) {
     lane = opaque(lane);
     double acc[NACC];
-#pragma unroll
-    for (int x = 0; x < NACC; ++x) acc[x] = 0.0;
-    auto trip = [&](int t0, auto fullc) {
-      constexpr bool FULL = fullc;
+    // One trip = one chunk of 64 frames, lane = frame, whole chunks only: the padding frames of
+    // the last chunk carry w = 0 and y = 0.  The lane's addresses advance by one chunk per trip;
+    // the planes of a chunk (channel pairs, classes) sit at compile-time offsets.  The first
+    // trip initialises the accumulators with products instead of adding to zeros.
+    const YS* yp = L.ybuf + (size_t)lane * 4;
+    const double* wp = L.wbuf + lane;
+    auto trip = [&](auto firstc) {
+      constexpr bool FIRST = firstc;
       double re[D], im[D], w[K];
-      const int t = t0 + lane;
-      const bool ok = FULL || t < a.T;
-      const int tc = ok ? t : a.T - 1;
-      load_frame(L, tc, re, im);
+      static_for<0, DP>([&](auto dpc) {
+        constexpr int dp = dpc;
+        YS4 v = *reinterpret_cast<const YS4*>(yp + dp * (kFC * 4));
+        re[2 * dp] = (double)v.x;
+        im[2 * dp] = (double)v.y;
+        if constexpr (2 * dp + 1 < D) {
+          re[2 * dp + 1] = (double)v.z;
+          im[2 * dp + 1] = (double)v.w;
+        }
+      });
 #pragma unroll
-      for (int k = 0; k < K; ++k) w[k] = ok ? L.wbuf[(size_t)k * L.Tp + tc] : 0.0;
+      for (int k = 0; k < K; ++k) w[k] = wp[k * kFC];
+      yp += DP * kFC * 4;
+      wp += K * kFC;
       static_for<0, D>([&](auto ic) {
         constexpr int i = ic;
         if constexpr (i % kEmWaves == W) {
           double dg = re[i] * re[i] + im[i] * im[i];
 #pragma unroll
-          for (int k = 0; k < K; ++k)
-            acc[k * NSLOT + i / kEmWaves] = fma(w[k], dg, acc[k * NSLOT + i / kEmWaves]);
+          for (int k = 0; k < K; ++k) {
+            double& x = acc[k * NSLOT + i / kEmWaves];
+            x = FIRST ? w[k] * dg : fma(w[k], dg, x);
+          }
         }
       });
       static_for<0, NOFF>([&](auto pc) {
@@ -678,13 +722,26 @@ struct EmKernel {
           double pim = im[i] * re[j] - re[i] * im[j];
 #pragma unroll
           for (int k = 0; k < K; ++k) {
-            acc[k * NSLOT + s] = fma(w[k], pr, acc[k * NSLOT + s]);
-            acc[k * NSLOT + s + 1] = fma(w[k], pim, acc[k * NSLOT + s + 1]);
+            double& xr = acc[k * NSLOT + s];
+            double& xi = acc[k * NSLOT + s + 1];
+            xr = FIRST ? w[k] * pr : fma(w[k], pr, xr);
+            xi = FIRST ? w[k] * pim : fma(w[k], pim, xi);
           }
         }
       });
     };
-    for (int t0 = 0; t0 < a.T; t0 += kWave) trip(t0, std::false_type{});
+    // slots no entry maps to (wave W owns fewer diagonal entries / pairs than NDW / NOW; padding
+    // of the butterfly) are never touched by a trip
+    static_for<0, NACC>([&](auto xc) {
+      constexpr int x = xc;
+      constexpr int sl = x % NSLOT;
+      constexpr bool used = x < K * NSLOT &&
+                            (sl < NDW ? (sl * kEmWaves + W < D)
+                                      : (((sl - NDW) >> 1) * kEmWaves + W < NOFF));
+      if constexpr (!used) acc[x] = 0.0;
+    });
+    trip(std::true_type{});  // at least one chunk
+    for (int c = padded_frames(a.T) >> 6; c > 1; --c) trip(std::false_type{});
 #ifdef PBBSS_PHASE_PROFILE
     unsigned long long tm0 = __builtin_readcyclecounter(), tm1 = tm0;
 #endif
@@ -1082,7 +1139,7 @@ struct EmKernel {
 #pragma unroll
       for (int k = 0; k < K; ++k) {
         double ld = log(L.detm[k]) + (double)L.dete[k] * 0.6931471805599453;
-        L.wbuf[(size_t)k * L.Tp + t] = jx.spatial_weight * (-(double)D * log(q[k]) - ld);
+        L.wbuf[woff(k, t)] = jx.spatial_weight * (-(double)D * log(q[k]) - ld);
       }
     }
     __syncthreads();
@@ -1099,7 +1156,7 @@ struct EmKernel {
         double lp[K], mx = -1.79e308;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-          lp[k] = L.wbuf[(size_t)perm[k] * L.Tp + t] +
+          lp[k] = L.wbuf[woff(perm[k], t)] +
                   jx.extra_logpdf[((size_t)b * K + k) * a.T + t];
           mx = fmax(mx, lp[k]);
         }
@@ -1267,18 +1324,16 @@ struct EmKernel {
         o.y = vi[2 * dp];
         o.z = vr[2 * dp + 1];
         o.w = vi[2 * dp + 1];
-        *reinterpret_cast<YS4*>(L.ybuf + ((size_t)dp * L.Tp + t) * 4) = o;
+        *reinterpret_cast<YS4*>(L.ybuf + yoff(dp, t)) = o;
       }
       const double inv = (t < T) ? ((n2 > 0.0) ? 1.0 / n2 : 0.0) : 0.0;
       L.inv_n2[t] = inv;
       if (t < T && !(n2 > 0.0)) zero_seen = true;
-      if (t < T) {
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-          const double gs = g[k] * sal;
-          L.wbuf[(size_t)k * L.Tp + t] = mweight(gs, q[k], inv);
-          s[k] += gs;
-        }
+      for (int k = 0; k < K; ++k) {
+        const double gs = (t < T) ? g[k] * sal : 0.0;
+        L.wbuf[woff(k, t)] = (t < T) ? mweight(gs, q[k], inv) : 0.0;  // padding frames: weight 0
+        s[k] += gs;
       }
     }
     if (zero_seen) atomicOr(L.flags, 1);

@@ -1660,7 +1660,8 @@ PBBSS_API int pbbss_gmm_fit(pbbss_handle_t h, const void* y, int64_t B, int64_t 
 // dynamic LDS of the joint kernels for (D, K, T): EmKernel<D,K,YS,false>::lds_bytes(T) + the
 // 64 bytes of the inline aligner's class permutation, written out for a run-time D
 static size_t joint_kernel_lds_bytes(int D, int K, int T, int c128) {
-  const size_t DP = (size_t)(D + 1) / 2, Tp = (size_t)((T + 1) & ~1), NA = (size_t)D * D;
+  // frame arrays in chunks of 64 frames (cacgmm_em.hpp: EmKernel::padded_frames)
+  const size_t DP = (size_t)(D + 1) / 2, Tp = (size_t)((T + 63) & ~63), NA = (size_t)D * D;
   const size_t frames = DP * Tp * 4 * (c128 ? 8 : 4) + Tp * 8 + (size_t)K * Tp * 8;
   const size_t small = 2 * (size_t)K * NA * 8 + (size_t)K * 8 * 4 + 4 * (size_t)K * 8 +
                        (size_t)K * 4 * 2 + 16;

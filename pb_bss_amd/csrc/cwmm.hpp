@@ -192,13 +192,16 @@ struct WatsonKernel {
 #pragma unroll
     for (int k = 0; k < K; ++k) s[k] = 0.0;
     for (int t0 = 0; t0 < a.T; t0 += kEmThreads) {
-      const int tt = t0 + tid;
+      // the wave's 64 frames are one chunk of the frame arrays (cacgmm_em.hpp: Lds); beyond the
+      // padded frame count there is nothing (wave-uniform exit: later passes lie further out)
+      if (t0 + wave * kWave >= Base::padded_frames(a.T)) break;
+      const int tt = t0 + tid;         // frame in LDS: padding frames read y = 0, 1/|y|^2 = 0
       const bool ok = tt < a.T;
-      const int t = ok ? tt : a.T - 1;
+      const int t = ok ? tt : a.T - 1;  // clamped for the HBM side arrays
       double re[D], im[D], q[K];
-      Base::load_frame(L, t, re, im);
+      Base::load_frame(L, tt, re, im);
       mode_forms(L, lane, re, im, q);  // |m_k^H y|^2
-      const double inv = L.inv_n2[t];
+      const double inv = L.inv_n2[tt];
       double lp[K], mx = -1.79e308;
 #pragma unroll
       for (int k = 0; k < K; ++k) {
@@ -230,7 +233,9 @@ struct WatsonKernel {
           if (pub_kt && ok)
             __hip_atomic_store(pub_kt + (size_t)k * TS + tf + t, gs, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
-          if (ok) L.wbuf[(size_t)k * L.Tp + t] = gs * inv;  // complex_watson.py:306-309
+          // complex_watson.py:306-309; unmasked: a padding frame stores 0 (gs = 0, inv = 0), as
+          // the unmasked M sweep needs
+          L.wbuf[Base::woff(k, tt)] = gs * inv;
           s[k] += gs;
         }
       }
@@ -258,7 +263,7 @@ struct WatsonKernel {
       for (int k = 0; k < K; ++k) {
         const size_t idx = ((size_t)b * K + k) * TS + tf + t;
         double g = a.gamma0[idx] * sal;
-        L.wbuf[(size_t)k * L.Tp + t] = g * inv;
+        L.wbuf[Base::woff(k, t)] = g * inv;
         if (a.gaff && a.weight_mode == PBBSS_WEIGHT_SHARED_KT)  // parity 0: iteration 0
           __hip_atomic_store(a.gaff + idx, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s[k] += g;

@@ -163,7 +163,8 @@ def separate(Y, init, iterations=100, stft_size=None, *, shard=None, group=None,
     reference channel (beamformer.py:627-698) -- the one extraction step that couples the bins:
     with shard='bins' its per-problem SNR sums are all-reduced over the group.
 
-    shard: None (single process), 'bins' or 'utterances' (torch.distributed initialised).
+    shard: None (single process), 'bins', 'utterances' or 'auto' (torch.distributed initialised;
+    'auto' = 'utterances' when there are at least as many utterances as ranks, else 'bins').
     stage_ms: a dict that receives this rank's wall time per stage in milliseconds (em_ms,
     gather_ms, dhtv_ms, map_gather_ms, extract_ms, out_gather_ms) with a device synchronisation
     after each -- a diagnostic pass that explains a scaling measurement, not the timed path.
@@ -192,6 +193,11 @@ def separate(Y, init, iterations=100, stft_size=None, *, shard=None, group=None,
 
     import torch.distributed as dist
     world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if shard == 'auto':
+        # utterances when there is at least one per rank (no collective, and the scaling model of
+        # DESIGN section 5 / profiles/r05_scaling_model.json has it ahead of the bins at every N);
+        # a single utterance or a small batch can only be split along its bins
+        shard = 'utterances' if U >= world else 'bins'
     if shard == 'utterances':
         assert U >= world, (U, world, 'fewer utterances than ranks: shard the bins instead')
         lo, hi = shard_bounds(U, world, rank)

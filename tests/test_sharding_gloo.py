@@ -306,12 +306,20 @@ def _souden_worker(rank, world, port, ret):
         Y, init = _pipeline_inputs(U=2, F=257, T=30, D=3, K=2)
         ref = pipeline.separate(Y, init, 3, 512, ops=_oracle_ops_souden, beamformer='mvdr_souden')
         ok = True
-        for shard in ('bins', 'utterances'):
+        for shard in ('bins', 'utterances', 'auto'):  # auto: two utterances, two ranks -> utterances
             got = pipeline.separate(Y, init, 3, 512, shard=shard, gather_output=True,
                                     ops=_oracle_ops_souden, beamformer='mvdr_souden')
             ok = ok and bool((got['mapping'] == ref['mapping']).all())
             for k in ('masks', 'enhanced', 'bf_vector'):
                 ok = ok and float((got[k] - ref[k]).abs().max()) < 1e-12
+        # shard='auto' with ONE utterance on two ranks: only the bins can be split
+        ref1 = pipeline.separate(Y[0], init[0], 3, 512, ops=_oracle_ops_souden,
+                                 beamformer='mvdr_souden')
+        got1 = pipeline.separate(Y[0], init[0], 3, 512, shard='auto', gather_output=True,
+                                 ops=_oracle_ops_souden, beamformer='mvdr_souden')
+        ok = ok and bool((got1['mapping'] == ref1['mapping']).all())
+        for k in ('masks', 'enhanced', 'bf_vector'):
+            ok = ok and float((got1[k] - ref1[k]).abs().max()) < 1e-12
         # ... and the unsharded stand-in is the reference function itself, problem by problem
         X = Y.numpy().astype(np.complex128).transpose(0, 1, 3, 2)
         aligned = ref['masks'].numpy()                                   # (U, K, F, T)
