@@ -658,13 +658,7 @@ struct EmKernel {
       }
       for (; t0 < a.T; t0 += kEmThreads) pass(t0, std::integral_constant<int, 1>{});
     }
-    if constexpr (!FINAL) {
-#pragma unroll
-      for (int k = 0; k < K; ++k) {
-        double tot = wave_sum(s[k]);
-        if (lane == 0) L.red[wave * K + k] = tot;
-      }
-    }
+    if constexpr (!FINAL) wave_class_sums<K>(s, lane, L.red + wave * K);
   }
 
   // ---- phase M: wave W accumulates its share of the Hermitian entries ------

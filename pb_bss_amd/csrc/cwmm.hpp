@@ -240,13 +240,7 @@ struct WatsonKernel {
         }
       }
     }
-    if constexpr (!FINAL) {
-#pragma unroll
-      for (int k = 0; k < K; ++k) {
-        double tot = wave_sum(s[k]);
-        if (lane == 0) L.red[wave * K + k] = tot;
-      }
-    }
+    if constexpr (!FINAL) wave_class_sums<K>(s, lane, L.red + wave * K);
   }
 
   // affiliation initialisation -> M-step weights (cwmm.py:162-163 with saliency)

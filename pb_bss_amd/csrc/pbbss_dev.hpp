@@ -296,6 +296,40 @@ __device__ __forceinline__ int reduce_scatter_base(int lane) {
   return (N / 16) * ((lane >> 2) & 15);
 }
 
+// Totals of up to four per-lane values over the 64 lanes in ONE butterfly (the class sums of an
+// E phase): the two swap steps leave the partial sums of value r on row r of 16 lanes, four DPP
+// steps inside the rows finish.  Returns the total of v_r on every lane of row r -- 7 cross-lane
+// exchanges of doubles and 7 adds instead of the 6 + 6 per value of wave_sum.
+__device__ __forceinline__ double wave_sum_rows4(double v0, double v1, double v2, double v3) {
+  swap32_f64(v0, v2);
+  double a = v0 + v2;  // lanes 0..31: v0, lanes 32..63: v2
+  swap32_f64(v1, v3);
+  double b = v1 + v3;  // lanes 0..31: v1, lanes 32..63: v3
+  swap16_f64(a, b);
+  double v = a + b;    // row 0: v0, row 1: v1, row 2: v2, row 3: v3
+  v += dpp_f64<kDppQuadXor1, 0xF>(v, v);
+  v += dpp_f64<kDppQuadXor2, 0xF>(v, v);
+  v += dpp_f64<kDppRowHalfMirror, 0xF>(v, v);
+  v += dpp_f64<kDppRowMirror, 0xF>(v, v);
+  return v;
+}
+// red[k] = sum over the 64 lanes of s[k], k < K (K <= 8), written by one lane per class
+template <int K>
+__device__ __forceinline__ void wave_class_sums(const double (&s)[K], int lane, double* red) {
+  static_assert(K <= 8, "two groups of four rows");
+  const int row = lane >> 4;
+  {
+    const double t = wave_sum_rows4(s[0], K > 1 ? s[K > 1 ? 1 : 0] : 0.0, K > 2 ? s[K > 2 ? 2 : 0] : 0.0,
+                                    K > 3 ? s[K > 3 ? 3 : 0] : 0.0);
+    if ((lane & 15) == 0 && row < K) red[row] = t;
+  }
+  if constexpr (K > 4) {
+    const double t = wave_sum_rows4(s[4], K > 5 ? s[K > 5 ? 5 : 0] : 0.0, K > 6 ? s[K > 6 ? 6 : 0] : 0.0,
+                                    K > 7 ? s[K > 7 ? 7 : 0] : 0.0);
+    if ((lane & 15) == 0 && row + 4 < K) red[row + 4] = t;
+  }
+}
+
 // two all-reduce sums (independent instruction streams interleave)
 __device__ __forceinline__ void wave_sum2(double& a, double& b) {
   a = wave_sum(a);
