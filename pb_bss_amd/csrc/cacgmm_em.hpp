@@ -167,6 +167,9 @@ struct EmKernel {
 #ifndef PBBSS_E_PAIR
 #define PBBSS_E_PAIR 0
 #endif
+#ifndef PBBSS_M_PREFETCH
+#define PBBSS_M_PREFETCH 0
+#endif
   static constexpr int kOperandChunk = PBBSS_E_CHUNK;  // pairs of A_k operands per prefetch stage of the E phase
   using YS4 = typename std::conditional<std::is_same<YS, float>::value, float4, double4>::type;
   using YS2 = typename std::conditional<std::is_same<YS, float>::value, float2, double2>::type;
@@ -679,23 +682,35 @@ struct EmKernel {
     // trip initialises the accumulators with products instead of adding to zeros.
     const YS* yp = L.ybuf + (size_t)lane * 4;
     const double* wp = L.wbuf + lane;
-    auto trip = [&](auto firstc) {
-      constexpr bool FIRST = firstc;
-      double re[D], im[D], w[K];
+    // raw frame + weights of one chunk: loaded one trip ahead of their use (PBBSS_M_PREFETCH), so
+    // that the LDS round trip of chunk c + 1 hides behind the 96 FMAs of chunk c
+    struct Raw {
+      YS4 v[DP];
+      double w[K];
+    };
+    auto fetch = [&](Raw& r) {
       static_for<0, DP>([&](auto dpc) {
         constexpr int dp = dpc;
-        YS4 v = *reinterpret_cast<const YS4*>(yp + dp * (kFC * 4));
-        re[2 * dp] = (double)v.x;
-        im[2 * dp] = (double)v.y;
-        if constexpr (2 * dp + 1 < D) {
-          re[2 * dp + 1] = (double)v.z;
-          im[2 * dp + 1] = (double)v.w;
-        }
+        r.v[dp] = *reinterpret_cast<const YS4*>(yp + dp * (kFC * 4));
       });
 #pragma unroll
-      for (int k = 0; k < K; ++k) w[k] = wp[k * kFC];
+      for (int k = 0; k < K; ++k) r.w[k] = wp[k * kFC];
       yp += DP * kFC * 4;
       wp += K * kFC;
+    };
+    auto compute = [&](const Raw& r, auto firstc) {
+      constexpr bool FIRST = firstc;
+      double re[D], im[D];
+      static_for<0, DP>([&](auto dpc) {
+        constexpr int dp = dpc;
+        re[2 * dp] = (double)r.v[dp].x;
+        im[2 * dp] = (double)r.v[dp].y;
+        if constexpr (2 * dp + 1 < D) {
+          re[2 * dp + 1] = (double)r.v[dp].z;
+          im[2 * dp + 1] = (double)r.v[dp].w;
+        }
+      });
+      const double (&w)[K] = r.w;
       static_for<0, D>([&](auto ic) {
         constexpr int i = ic;
         if constexpr (i % kEmWaves == W) {
@@ -734,8 +749,51 @@ struct EmKernel {
                                       : (((sl - NDW) >> 1) * kEmWaves + W < NOFF));
       if constexpr (!used) acc[x] = 0.0;
     });
-    trip(std::true_type{});  // at least one chunk
-    for (int c = padded_frames(a.T) >> 6; c > 1; --c) trip(std::false_type{});
+    const int nchunk = padded_frames(a.T) >> 6;  // >= 1
+#if PBBSS_M_PREFETCH
+    {
+      // two buffers, ping-pong (no copies): the loads of chunk c + 1 are in flight while chunk c
+      // is accumulated; LDS returns in order, so the wait in front of a compute only covers its
+      // own buffer
+      Raw A, B;
+      fetch(A);
+      if (nchunk > 1) {
+        fetch(B);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(A, std::true_type{});
+        int c = nchunk - 1;  // chunks left to accumulate, B (loaded) included
+        while (c > 2) {
+          fetch(A);
+          __builtin_amdgcn_sched_barrier(0);
+          compute(B, std::false_type{});
+          fetch(B);
+          __builtin_amdgcn_sched_barrier(0);
+          compute(A, std::false_type{});
+          c -= 2;
+        }
+        if (c == 2) {
+          fetch(A);
+          __builtin_amdgcn_sched_barrier(0);
+          compute(B, std::false_type{});
+          compute(A, std::false_type{});
+        } else {
+          compute(B, std::false_type{});
+        }
+      } else {
+        compute(A, std::true_type{});
+      }
+    }
+#else
+    {
+      Raw r;
+      fetch(r);
+      compute(r, std::true_type{});
+      for (int c = nchunk; c > 1; --c) {
+        fetch(r);
+        compute(r, std::false_type{});
+      }
+    }
+#endif
 #ifdef PBBSS_PHASE_PROFILE
     unsigned long long tm0 = __builtin_readcyclecounter(), tm1 = tm0;
 #endif
@@ -2250,7 +2308,10 @@ struct EmKernel {
 
 // Register budget: K <= 4 fits 168 VGPRs (3 workgroups per CU, the LDS limit at T=500);
 // more classes need more M-phase accumulators (16 float64 per class) -> 2 per CU.
-constexpr int em_waves_per_simd(int K) { return K <= 4 ? 3 : 2; }
+#ifndef PBBSS_EM_WAVES
+#define PBBSS_EM_WAVES 3
+#endif
+constexpr int em_waves_per_simd(int K) { return K <= 4 ? PBBSS_EM_WAVES : 2; }
 
 template <int D, int K, typename YS, bool SPILL>
 __global__ void __launch_bounds__(kEmThreads, em_waves_per_simd(K)) cacgmm_em_kernel(EmArgs a) {

@@ -12,6 +12,6 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -I. -I../.
 hipcc $FLAGS -DPBBSS_EM_D=8 -DPBBSS_EM_DEV_ONLY_K=3 "$@" -Rpass-analysis=kernel-resource-usage \
   -save-temps=obj -c em_inst.hip -o /tmp/dev_$TAG/em_d8.o 2>&1 | grep -E "Function Name|VGPRs:|Scratch|Spill" | \
   sed 's/.*remark: *//;s/\[-Rpass.*//' | paste - - - - - | sed 's/ \+/ /g'
-OBJS=$(ls build/*.o | grep -v 'em_d8' | tr '\n' ' ')
+OBJS=$(ls build/*.o | grep -v 'em_d8\|_prof\.o' | tr '\n' ' ')
 hipcc --offload-arch=gfx950 -shared -fPIC -o ../libpbbss_hip_$TAG.so $OBJS /tmp/dev_$TAG/em_d8.o
 ls -la ../libpbbss_hip_$TAG.so
