@@ -285,8 +285,8 @@ def cpu_baseline_em(Y0, init0, iters):
     dt = time.perf_counter() - t1
     return {
         'value': med, 'unit': 'EM iterations/s', 'cores': 1, 'kind': 'port', 'runs': runs,
-        'sample': f'NumPy oracle (oracle/cacgmm.py: restated einsum contractions, float64; it forms '
-                  f'B^-1 first and measures ~1.3-1.5x faster than the reference\'s own calls), full '
+        'timing_mode': PORT_NOTE,
+        'sample': f'NumPy oracle (oracle/cacgmm.py, float64, reference-shaped timing mode), full '
                   f'F=513 T=500 D=8 K=3, median of 3 runs of {n} EM iterations, {dt:.1f} s in all; '
                   f'host has {os.cpu_count()} logical cores, 1 used (einsum is single-threaded; the '
                   f'reference would use 1 core here too)' + note,
@@ -985,7 +985,7 @@ def config3_cpu_baseline(args, data, U):
     return {
         'value': med, 'unit': 'EM iterations/s (utterance-iterations; every run also pays DHTV '
                               'alignment, PSD, gev+ban and apply once)',
-        'cores': 1, 'kind': 'port', 'runs': runs,
+        'cores': 1, 'kind': 'port', 'runs': runs, 'timing_mode': PORT_NOTE,
         'sample': f'NumPy oracle chain (oracle/: EM {n} iterations + final E-step + DHTV alignment + '
                   f'PSD + gev+ban + apply) on ONE of the {U} utterances, median of 3 runs, {dt:.1f} s '
                   f'in all; host has {os.cpu_count()} logical cores, 1 used',
@@ -1102,13 +1102,23 @@ def reference_recorded(config):
     return out
 
 
+PORT_KIND = 'port'  # cpu_baseline.kind of the oracle-timed baselines (the contract's two values)
+PORT_NOTE = ('timed in the oracle\'s reference-shaped mode (oracle/cacgmm.py REFERENCE_SHAPED: the '
+             'reference\'s own einsum calls, e.g. the five-operand einsum(optimize=\'optimal\') of '
+             'complex_angular_central_gaussian.py:187-196, where the restatement would be cheaper); '
+             'profiles/reference_cpu_timings.json holds reference vs oracle in this mode on one host')
+
+
 def median_rate(fn, iterations, repeats=3):
-    """-> (median iterations/s, [runs]) of `repeats` timed calls of fn()."""
+    """-> (median iterations/s, [runs]) of `repeats` timed calls of fn(), the oracle in its
+    reference-shaped timing mode (it then costs what the reference's own calls cost)."""
+    from oracle import cacgmm as oc
     runs = []
-    for _ in range(repeats):
-        t1 = time.perf_counter()
-        fn()
-        runs.append(iterations / (time.perf_counter() - t1))
+    with oc.reference_shaped():
+        for _ in range(repeats):
+            t1 = time.perf_counter()
+            fn()
+            runs.append(iterations / (time.perf_counter() - t1))
     return float(np.median(runs)), runs
 
 
@@ -1342,6 +1352,7 @@ def run_config4(args, local_rank, dev, leg='watson', steps=None, warmup=None, wi
         out['cpu_baseline'] = {
             'value': med, 'unit': 'EM iterations/s', 'cores': 1, 'kind': 'port',
             'runs': runs,
+            'timing_mode': PORT_NOTE,
             'sample': f'NumPy oracle chain (oracle/cwmm.py / oracle/embed.py fit of {n} EM iterations '
                       f'+ predict + PSD + mvdr_souden + apply), full F={F_} T={T_} D={D_} K={K_}, '
                       f'median of 3 runs; host has {os.cpu_count()} logical cores, einsum / LAPACK '
@@ -1407,8 +1418,10 @@ def run_config5(args, local_rank, dev, steps=None, warmup=None, with_cpu=True):
         g100 = _lib.to_host(last['affiliation'])
         err, cpu_s = err_short, None
         if n != n_short:
+            from oracle import cacgmm as oc
             t1 = time.perf_counter()
-            ref_model = oe.joint_fit('gaussian', Y128, e64, init0, n)
+            with oc.reference_shaped():  # same results up to rounding; costs what the reference costs
+                ref_model = oe.joint_fit('gaussian', Y128, e64, init0, n)
             cpu_s = time.perf_counter() - t1
             err = float(np.abs(g100 - oe.joint_model_predict(ref_model, Y128, e64)).max())
         out['verify'] = {
@@ -1426,6 +1439,7 @@ def run_config5(args, local_rank, dev, steps=None, warmup=None, with_cpu=True):
             out['cpu_baseline'] = {
                 'value': n / cpu_s, 'unit': 'EM iterations/s', 'cores': 1, 'kind': 'port',
                 'runs': [n / cpu_s],
+                'timing_mode': PORT_NOTE,
                 'sample': f'NumPy oracle joint_fit (oracle/embed.py), full F={F_} T={T_} D={D_} '
                           f'K={K_} E={E_}, ONE run of {n} EM iterations ({cpu_s:.1f} s; the run the '
                           f'verify block compares against); host has {os.cpu_count()} logical cores, '

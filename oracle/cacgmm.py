@@ -10,8 +10,32 @@ layout is (..., D, N) ("time last"), affiliations are (..., K, N).
 """
 import numpy as np
 
+import contextlib
+
+# Timing mode (bench.py's cpu_baseline, tools/record_reference_timings.py): issue the SAME NumPy
+# calls as the reference where this restatement would otherwise be cheaper -- the E-step's
+# five-operand einsum(optimize='optimal') (complex_angular_central_gaussian.py:187-196: a path
+# search per call and its own temporaries) instead of the three small contractions below, the vMF
+# mixture's re-normalisation of the observation on every predict (vmfmm.py:28-31,
+# von_mises_fisher.py:71-73).  Same results up to rounding; a CPU baseline timed in this mode costs
+# what the reference costs (checked against the reference itself in the build container:
+# profiles/reference_cpu_timings.json, column oracle_reference_shaped).
+REFERENCE_SHAPED = False
+
+
+@contextlib.contextmanager
+def reference_shaped(on=True):
+    global REFERENCE_SHAPED
+    before = REFERENCE_SHAPED
+    REFERENCE_SHAPED = bool(on)
+    try:
+        yield
+    finally:
+        REFERENCE_SHAPED = before
+
+
 __all__ = [
-    'unit_norm_where', 'normalize_observation', 'force_hermitian',
+    'reference_shaped', 'unit_norm_where', 'normalize_observation', 'force_hermitian',
     'cacg_log_pdf', 'log_pdf_to_affiliation', 'estimate_mixture_weight',
     'cacg_from_covariance', 'cacg_m_step', 'cacg_covariance',
     'em_fit', 'em_predict', 'e_step',
@@ -47,9 +71,13 @@ def cacg_log_pdf(y, eigvec, eigval):
     B^-1 = V diag(1/lambda) V^H, then y^H (B^-1 y); we follow that order.
     """
     D = y.shape[-2]
-    binv = np.einsum('...de,...e,...ge->...dg', eigvec, 1 / eigval, eigvec.conj())
-    by = np.einsum('...dg,...gt->...dt', binv, y)
-    q = np.abs(np.einsum('...dt,...dt->...t', y.conj(), by))
+    if REFERENCE_SHAPED:  # the reference's own call, operand for operand (:187-196)
+        q = np.abs(np.einsum('...dt,...de,...e,...ge,...gt->...t', y.conj(), eigvec, 1 / eigval,
+                             eigvec.conj(), y, optimize='optimal'))
+    else:
+        binv = np.einsum('...de,...e,...ge->...dg', eigvec, 1 / eigval, eigvec.conj())
+        by = np.einsum('...dg,...gt->...dt', binv, y)
+        q = np.abs(np.einsum('...dt,...dt->...t', y.conj(), by))
     q = np.maximum(q, np.finfo(y.dtype).tiny)
     log_pdf = -D * np.log(q) - np.sum(np.log(eigval), axis=-1)[..., None]
     return log_pdf, q

@@ -34,7 +34,10 @@ def vmf_log_pdf(y, mean, concentration, normalized=False):
     """von_mises_fisher.py:62-78.  y (..., N, D), mean (..., D) -> (..., N)."""
     if not normalized:
         y = unit_rows(y)
-    proj = np.einsum('...nd,...d->...n', y, mean)
+    if oc.REFERENCE_SHAPED:  # the reference's contraction (von_mises_fisher.py:74)
+        proj = np.einsum('...d,...d', y, mean[..., None, :])
+    else:
+        proj = np.einsum('...nd,...d->...n', y, mean)
     return proj * concentration[..., None] - vmf_log_norm(concentration, mean.shape[-1])[..., None]
 
 
@@ -55,7 +58,8 @@ def vmfmm_predict(model, y, normalized=False):
     """vmfmm.py:19-37."""
     if not normalized:
         y = unit_rows(y)
-    lp = vmf_log_pdf(y[..., None, :, :], model['mean'], model['concentration'], normalized=True)
+    lp = vmf_log_pdf(y[..., None, :, :], model['mean'], model['concentration'],
+                     normalized=not oc.REFERENCE_SHAPED)
     return oc.log_pdf_to_affiliation(model['weight'], lp)
 
 
@@ -78,7 +82,9 @@ def vmfmm_fit(y, initialization, iterations=100, saliency=None, weight_constant_
     model = None
     for _ in range(iterations):
         if model is not None:
-            aff = vmfmm_predict(model, y, normalized=True)
+            # timing mode: VMFMM.predict normalises the (already normalised) rows again, and so
+            # does VonMisesFisher.log_pdf inside it (vmfmm.py:28-31, von_mises_fisher.py:71-73)
+            aff = vmfmm_predict(model, y, normalized=not oc.REFERENCE_SHAPED)
         model = vmfmm_m_step(y, aff, saliency, weight_constant_axis,
                              min_concentration, max_concentration)
     return model

@@ -665,12 +665,69 @@ struct EmKernel {
   }
 
   // ---- phase M: wave W accumulates its share of the Hermitian entries ------
-  // Entry slots of wave W within one class: diagonal i = 4s + W (s < NDW), then
-  // (re, im) of the strict-upper pairs p = 4s + W (s < NOW).  All classes are
+  // Entry slots of wave W within one class: its diagonal entries (rank s < NDW), then (re, im)
+  // of its strict-upper pairs (rank s < NOW) -- kMap below says which.  All classes are
   // accumulated in one flat array acc[k * NSLOT + slot], padded to a multiple
   // of 16 for the halving butterfly.
   static constexpr int NSLOT = NDW + 2 * NOW;
   static constexpr int NACC = ((K * NSLOT + 15) / 16) * 16;
+
+  // Which wave accumulates which entry.  Default: round robin (diagonal i -> wave i % 4, pair p ->
+  // wave p % 4).  D = 8 (round 5): the 28 pairs are grouped by CHANNELS -- waves 0 / 1 take the
+  // pairs inside {0,1,2,3} / {4,5,6,7} plus one cross pair, waves 2 / 3 the remaining cross pairs
+  // of {0,1} / {2,3} with {4,..,7} -- so that a wave needs 5 or 6 of the 8 channels: three of the
+  // four float4 planes of a frame to load and 10 or 12 instead of 16 values to widen per trip
+  // (round robin touches every channel in every wave).  7 pairs + 2 diagonals per wave as before.
+  struct EntryMap {
+    int dwave[D], drank[D];                        // diagonal i -> wave, rank among the wave's
+    int pwave[NOFF > 0 ? NOFF : 1], prank[NOFF > 0 ? NOFF : 1];  // pair p -> wave, rank
+    unsigned long long dcode[kEmWaves], pcode[kEmWaves];  // inverse: 4 / 5 bits per rank, all ones = none
+  };
+  static constexpr EntryMap make_entry_map() {
+    EntryMap m{};
+    int nd[kEmWaves] = {}, np[kEmWaves] = {};
+    for (int w = 0; w < kEmWaves; ++w) {
+      m.dcode[w] = ~0ull;
+      m.pcode[w] = ~0ull;
+    }
+    for (int i = 0; i < D; ++i) {
+      int w = i % kEmWaves;
+      if (D == 8) w = (i < 2) ? 0 : (i < 4) ? 3 : (i < 6) ? 1 : 2;
+      m.dwave[i] = w;
+      m.drank[i] = nd[w]++;
+    }
+    for (int p = 0; p < NOFF; ++p) {
+      const int i = tri_i<D>(p), j = tri_j<D>(p);
+      int w = p % kEmWaves;
+      if (D == 8) {
+        if (j < 4) w = 0;                                  // inside {0,1,2,3}
+        else if (i >= 4) w = 1;                            // inside {4,5,6,7}
+        else if (i == 0 && j == 4) w = 0;                  // the two cross pairs that fill waves 0 / 1
+        else if (i == 3 && j == 7) w = 1;
+        else w = (i < 2) ? 2 : 3;                          // {0,1} x {4..7} / {2,3} x {4..7}
+      }
+      m.pwave[p] = w;
+      m.prank[p] = np[w]++;
+    }
+    for (int i = 0; i < D; ++i) {
+      const int w = m.dwave[i], r = m.drank[i];
+      m.dcode[w] = (m.dcode[w] & ~(15ull << (4 * r))) | ((unsigned long long)i << (4 * r));
+    }
+    for (int p = 0; p < NOFF; ++p) {
+      const int w = m.pwave[p], r = m.prank[p];
+      m.pcode[w] = (m.pcode[w] & ~(31ull << (5 * r))) | ((unsigned long long)p << (5 * r));
+    }
+    return m;
+  }
+  static constexpr EntryMap kMap = make_entry_map();
+  static constexpr bool entry_map_fits() {
+    for (int i = 0; i < D; ++i)
+      if (kMap.drank[i] >= NDW) return false;
+    for (int p = 0; p < NOFF; ++p)
+      if (kMap.prank[p] >= NOW) return false;
+    return true;
+  }
+  static_assert(entry_map_fits(), "a wave owns more entries than it has accumulator slots");
 
   template <int W>
   static __device__ void phase_m(const EmArgs& a, const Lds& L, int lane) {
@@ -713,20 +770,20 @@ struct EmKernel {
       const double (&w)[K] = r.w;
       static_for<0, D>([&](auto ic) {
         constexpr int i = ic;
-        if constexpr (i % kEmWaves == W) {
+        if constexpr (kMap.dwave[i] == W) {
           double dg = re[i] * re[i] + im[i] * im[i];
 #pragma unroll
           for (int k = 0; k < K; ++k) {
-            double& x = acc[k * NSLOT + i / kEmWaves];
+            double& x = acc[k * NSLOT + kMap.drank[i]];
             x = FIRST ? w[k] * dg : fma(w[k], dg, x);
           }
         }
       });
       static_for<0, NOFF>([&](auto pc) {
         constexpr int p = pc;
-        if constexpr (p % kEmWaves == W) {
+        if constexpr (kMap.pwave[p] == W) {
           constexpr int i = tri_i<D>(p), j = tri_j<D>(p);
-          constexpr int s = NDW + 2 * (p / kEmWaves);
+          constexpr int s = NDW + 2 * kMap.prank[p];
           double pr = re[i] * re[j] + im[i] * im[j];
           double pim = im[i] * re[j] - re[i] * im[j];
 #pragma unroll
@@ -744,9 +801,10 @@ struct EmKernel {
     static_for<0, NACC>([&](auto xc) {
       constexpr int x = xc;
       constexpr int sl = x % NSLOT;
-      constexpr bool used = x < K * NSLOT &&
-                            (sl < NDW ? (sl * kEmWaves + W < D)
-                                      : (((sl - NDW) >> 1) * kEmWaves + W < NOFF));
+      constexpr bool used =
+          x < K * NSLOT &&
+          (sl < NDW ? (int)((kMap.dcode[W] >> (4 * sl)) & 15) < D
+                    : (int)((kMap.pcode[W] >> (5 * ((sl - NDW) >> 1))) & 31) < NOFF);
       if constexpr (!used) acc[x] = 0.0;
     });
     const int nchunk = padded_frames(a.T) >> 6;  // >= 1
@@ -813,7 +871,9 @@ struct EmKernel {
         if (idx < K * NSLOT) {
           const int k = idx / NSLOT, s = idx % NSLOT;
           const bool dg = s < NDW;
-          const int u = dg ? s * kEmWaves + W : ((s - NDW) >> 1) * kEmWaves + W;  // diag i / pair p
+          // diag i / pair p of this slot (inverse of the entry map, packed into two constants)
+          const int u = dg ? (int)((kMap.dcode[W] >> (4 * s)) & 15)
+                           : (int)((kMap.pcode[W] >> (5 * ((s - NDW) >> 1))) & 31);
           const int e = dg ? u : D + 2 * u + ((s - NDW) & 1);
           if (u < (dg ? D : NOFF)) L.cpack[k * NA + e] = acc[m];
         }

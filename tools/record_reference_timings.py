@@ -52,6 +52,10 @@ def main():
     import pb_bss.distribution as dist
     import pb_bss.extraction.beamformer as bf
 
+    def shaped(fn):
+        with oc.reference_shaped():
+            return fn()
+
     cpu = ''
     try:
         with open('/proc/cpuinfo') as f:
@@ -81,7 +85,10 @@ def main():
         'reference_f32': timed(lambda: dist.CACGMMTrainer().fit(Y, initialization=init,
                                                                iterations=n), n),
         'oracle_f64': timed(lambda: oc.em_fit(Y128, init, iterations=n), n),
-        'note': 'reference_f64: complex128 observation (the arithmetic the device kernel is held '
+        'oracle_reference_shaped': timed(lambda: shaped(lambda: oc.em_fit(Y128, init, iterations=n)), n),
+        'note': 'oracle_reference_shaped: the oracle in its timing mode (oracle/cacgmm.py '
+                'REFERENCE_SHAPED: the reference\'s own five-operand einsum(optimize=\'optimal\') in '
+                'the E-step) -- what bench.py times as cpu_baseline on the GPU box; reference_f64: complex128 observation (the arithmetic the device kernel is held '
                 'to); reference_f32: complex64 observation + ndarray initialisation, the '
                 'reference\'s own single-precision path (cacgmm.py:226-227)',
     }
@@ -118,6 +125,8 @@ def main():
         'reference_watson_fit': timed(lambda: dist.CWMMTrainer().fit(Y128, initialization=init,
                                                                     iterations=n), n),
         'oracle_watson_fit': timed(lambda: ow.cwmm_fit(Y128, init, iterations=n), n),
+        'oracle_watson_chain_reference_shaped': timed(lambda: shaped(oracle_chain), n),
+        'oracle_vmf_fit_reference_shaped': timed(lambda: shaped(lambda: oe.vmfmm_fit(feat, init, n)), n),
         'reference_vmf_fit': timed(lambda: dist.VMFMMTrainer().fit(feat, initialization=init,
                                                                   iterations=n), n),
         'oracle_vmf_fit': timed(lambda: oe.vmfmm_fit(feat, init, n), n),
@@ -138,6 +147,8 @@ def main():
         'reference_gcacgmm_fit': timed(lambda: dist.GCACGMMTrainer().fit(
             Y128, e64, initialization=init, iterations=n), n),
         'oracle_gcacgmm_fit': timed(lambda: oe.joint_fit('gaussian', Y128, e64, init, n), n),
+        'oracle_gcacgmm_fit_reference_shaped': timed(
+            lambda: shaped(lambda: oe.joint_fit('gaussian', Y128, e64, init, n)), n),
         'note': 'GCACGMMTrainer.fit, spherical Gaussian on the embedding (its default), float64',
     }
     print(json.dumps(out['configs']['config5']), flush=True)
