@@ -1128,6 +1128,7 @@ SOURCES_BY_WORKLOAD = {
     'config4': ('cwmm.hpp', 'cw_inst.hip', 'cacgmm_em.hpp', 'wave_la.hpp', 'pbbss_dev.hpp',
                 'em_launch.hpp', 'beamform.hip'),  # Watson leg; the vMF leg: config4_vmf
     'config4_vmf': ('embed.hip',),
+    'config4_batched': (),  # no PMC pass of its own: the roofline block carries no traffic
     'config5': ('embed.hip', 'joint_inst.hip', 'cacgmm_em.hpp', 'wave_la.hpp', 'pbbss_dev.hpp',
                 'em_launch.hpp'),
 }
@@ -1292,6 +1293,45 @@ def run_config4(args, local_rank, dev, leg='watson', steps=None, warmup=None, wi
              'groups)') if leg == 'watson' else 'vmf_em_kernel + embed_finalize_kernel per iteration',
             'config4' if leg == 'watson' else 'config4_vmf', 'fp64_valu'),
     }
+    # ---- the chip-filling figure: 8 utterances (2 056 bins) in ONE fit -- what a rank of an
+    #      8-GPU run of a 64-utterance batch executes (the single utterance above leaves one wave
+    #      per SIMD: 257 bins on 256 compute units) ----
+    if args.c4_extraction == 'on':
+        UB = 8
+        datab = [synth.make_stft(F_, T_, D_, K_, seed=u) for u in range(UB)]
+        gb = _lib.to_device(np.concatenate([d[1] for d in datab]))             # (UB F, K, T)
+        if leg == 'watson':
+            yb = _lib.to_device(np.concatenate([d[0] for d in datab]))         # (UB F, T, D)
+
+            def fit_b():
+                return engine.cwmm_fit(yb, K_, spline, gamma0=gb, iterations=args.iters,
+                                       final_predict=True, check_status=False)['affiliation']
+        else:
+            fb = _lib.to_device(np.concatenate([vmf_features(d[0]) for d in datab]))
+
+            def fit_b():
+                return engine.vmfmm_fit(fb, K_, gamma0=gb, iterations=args.iters,
+                                        final_predict=True)['affiliation']
+        nb = max(3, steps // 2)
+        el_b, fit_b_ms, last_b = timed(fit_b, nb, 2, False, dev, read_ms)
+        gb_host = _lib.to_host(last_b)
+        rb = dual_roofline(
+            fit_b_ms, UB * F_ * T_, args.iters, flops, UB * bytes_iter,
+            f'{UB} x the single-utterance figure', f'the same kernels over {UB * F_} bins in one fit',
+            'config4_batched', 'fp64_valu')
+        out['batched'] = {
+            'utterances': UB, 'bins': UB * F_,
+            'value': UB * args.iters * nb / el_b,
+            'unit': 'EM iterations/s (utterance-iterations; the fit + final E-step alone)',
+            'ms_per_fit': el_b / nb * 1e3, 'region_ms': fit_b_ms, 'steps': nb,
+            'speedup_over_single_utterance_fit': (UB * args.iters * nb / el_b) /
+                                                 (args.iters * steps / el_fit),
+            'masks_finite': bool(np.isfinite(gb_host).all()),
+            'first_utterance_equals_single_fit': float(np.abs(
+                gb_host[:F_] - _lib.to_host(fit())).max()),
+            'roofline': {k: rb[k] for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'other',
+                                            'region_ms')},
+        }
     if args.check_bins and args.c4_extraction == 'on':
         from oracle import beamformer as ob
         masks, w, enh = (_lib.to_host(x) for x in last)

@@ -72,7 +72,7 @@ int pbbss_create(pbbss_handle_t* out, int device_id);
  * (pbbss_cacgmm_fit / _predict, pbbss_cacg_m_step, pbbss_heev_batched, pbbss_psd, pbbss_gev,
  * pbbss_solve, pbbss_mvdr_souden, pbbss_wmwf, pbbss_mvdr, pbbss_ban) run a generic-size path
  * (one workgroup per matrix, matrices in LDS; the EM loop enqueues three kernels per iteration;
- * layout TD only for the fit).  1 <= K <= 6 classes on the fused kernels, 7 <= K <= 16 on the
+ * layout TD only for the fit).  1 <= K <= 6 classes on the fused kernels, 7 <= K <= 19 on the
  * generic-size path at any D.  Watson mixture (pbbss_cwmm_fit): fused kernel for D <= 8, K <= 4,
  * generic-size path up to D = 32, K = 16.  Joint models (pbbss_joint_fit): D <= 32 (the spatial
  * half of 9 <= D <= 32, or of 7..8 classes, on the generic-size kernels; inline permutation
@@ -409,7 +409,7 @@ int pbbss_apply_mapping(pbbss_handle_t h, const double* mask,
 /* Outputs: mode c128 (B,K,D), concentration f64 (B,K), weight f64 (B,K),        */
 /* status int32 (B,K); optional affiliation / log_pdf f64 (B,K,T) from the final  */
 /* E-step (final_predict).  2 <= D <= 8 and K <= 4: one fused persistent kernel;   */
-/* up to D = 32 sensors / K = 16 classes: generic-size kernels, one launch group   */
+/* up to D = 32 sensors / K = 19 classes: generic-size kernels, one launch group   */
 /* per iteration (csrc/generic_watson.hip).                                       */
 /* ------------------------------------------------------------------------- */
 typedef struct pbbss_cwmm_opts {

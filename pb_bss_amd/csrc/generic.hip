@@ -28,7 +28,7 @@
 namespace pbbss {
 namespace {
 
-constexpr int kGenMaxK = 16;   // classes of the generic path
+constexpr int kGenMaxK = 20;   // classes of the generic path (the reference asserts K < 20, cacgmm.py:249)
 constexpr int kCovMaxK = 6;    // classes accumulated by one gen_cov launch (register tiles)
 constexpr int kTile = 64;  // frames per LDS tile of gen_cov
 
@@ -197,7 +197,7 @@ __global__ void __launch_bounds__(kGenThreads) gen_estep_kernel(GenEstep a) {
     qs[k * kGenThreads + tid] = q;
   }
   if (!valid) return;
-  // softmax over the classes in three rolled passes through the thread's LDS slots (K <= 16
+  // softmax over the classes in three rolled passes through the thread's LDS slots (K <= 19
   // without per-class register arrays)
   double mx = -1.79e308;
 #pragma unroll 1

@@ -147,8 +147,10 @@ def test_unsupported_shapes_fail_loudly():
     with pytest.raises(NotImplementedError):
         CACGMMTrainer().fit(x, num_classes=2, iterations=1)  # D = 33 > 32 (generic path limit)
     x = rng.standard_normal((2, 50, 4)) + 1j * rng.standard_normal((2, 50, 4))
-    with pytest.raises(NotImplementedError):
-        CACGMMTrainer().fit(x, num_classes=17, iterations=1)  # K = 17 > 16
+    m = CACGMMTrainer().fit(x, num_classes=19, iterations=1)  # K = 17 .. 19: served since round 5
+    assert m.weight.shape == (2, 19, 1)
+    with pytest.raises(AssertionError, match='num_classes'):
+        CACGMMTrainer().fit(x, num_classes=20, iterations=1)  # the reference's assert (cacgmm.py:249)
 
 
 # ------------------------------------------------------------------ extraction

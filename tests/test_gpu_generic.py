@@ -74,9 +74,10 @@ def test_remainder_bins_run_as_a_side_chain():
     np.testing.assert_allclose(got[1][2], oc.em_predict(ref, Y128), atol=1e-8)
 
 
-@pytest.mark.parametrize('F,T,D,K', [(4, 200, 6, 7), (3, 260, 12, 9), (2, 300, 9, 16), (3, 150, 24, 8)])
+@pytest.mark.parametrize('F,T,D,K', [(4, 200, 6, 7), (3, 260, 12, 9), (2, 300, 9, 16), (3, 150, 24, 8),
+                                     (2, 260, 9, 19), (2, 200, 8, 17)])
 def test_many_classes(F, T, D, K):
-    """7 <= K <= 16 classes run on the generic path at any D (class chunks of <= 6 in gen_cov,
+    """7 <= K <= 19 classes (the reference asserts K < 20, cacgmm.py:249) run on the generic path at any D (class chunks of <= 6 in gen_cov,
     LDS softmax in gen_estep)."""
     from oracle import beamformer as ob, cacgmm as oc, synth
     from pb_bss_amd import extraction as ex
@@ -95,6 +96,19 @@ def test_many_classes(F, T, D, K):
     X = np.ascontiguousarray(Y.transpose(0, 2, 1))
     np.testing.assert_allclose(ex.get_power_spectral_density_matrix(X, masks),
                                ob.psd(X.astype(np.complex128), masks), atol=1e-11)
+
+
+def test_sensor_counts_beyond_the_compiled_kernels_say_so():
+    """The reference's sanity assert admits D = 33, 34 (cacgmm.py:250); the engine serves D <= 32 and
+    refuses the two sizes in between with its own limit in the message (D >= 35: the reference's
+    AssertionError)."""
+    from pb_bss_amd.distribution import CACGMMTrainer
+    rng = np.random.default_rng(0)
+    for D, exc in ((33, NotImplementedError), (34, NotImplementedError), (35, AssertionError)):
+        Y = (rng.standard_normal((2, 40, D)) + 1j * rng.standard_normal((2, 40, D))).astype(np.complex64)
+        init = rng.uniform(size=(2, 2, 40))
+        with pytest.raises(exc, match='32 sensors' if exc is NotImplementedError else 'Channels'):
+            CACGMMTrainer().fit(Y, initialization=init / init.sum(1, keepdims=True), iterations=2)
 
 
 def test_guided_source_separation_shape():
