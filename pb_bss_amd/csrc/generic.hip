@@ -28,7 +28,7 @@
 namespace pbbss {
 namespace {
 
-constexpr int kGenMaxK = 20;   // classes of the generic path (the reference asserts K < 20, cacgmm.py:249)
+constexpr int kGenMaxK = 19;   // classes of the generic path (the reference asserts K < 20, cacgmm.py:249)
 constexpr int kCovMaxK = 6;    // classes accumulated by one gen_cov launch (register tiles)
 constexpr int kTile = 64;  // frames per LDS tile of gen_cov
 

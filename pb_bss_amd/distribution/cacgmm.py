@@ -88,6 +88,14 @@ def _activity(mask, indep, K, N, device):
     return m.expand(*indep, K, N).reshape(-1, K, N).contiguous()
 
 
+def _stepwise_graph_enabled():
+    # opt-in: measured on an MI355X (profiles/r05_i_stepwise_graph.txt) one graph launch per
+    # iteration is NOT faster than the dozen eager launches it replaces -- the loop is bound by the
+    # device time of its kernels, not by launch overhead, and capture + instantiation cost ~0.7 ms
+    import os
+    return os.environ.get('PBBSS_STEPWISE_GRAPH', '0') == '1'
+
+
 @dataclass
 class CACGMM(_ProbabilisticModel):
     """weight (..., K, 1) [or (K, 1) / (..., 1, K, N)], cacg parameters with a
@@ -470,6 +478,47 @@ class CACGMMTrainer:
         shape = list(indep[:len(indep) - r]) + [1] * r + [K, 1 if red_n else N]
         return w.reshape(shape)
 
+    @staticmethod
+    def _replay_iterations(t, e_step, m_step, vec, val, weight, m_status, aligner_status, count):
+        """Capture one E + M iteration that reads the model from static tensors and writes the new
+        model back into them, replay it `count` times.  -> (vec, val, weight) or None when the
+        capture is refused (the caller continues eagerly).  The status words of the captured
+        launches are OR-ed into static accumulators inside the graph and appended to the lists."""
+        sv, sl, sw = vec.clone(), val.clone(), weight.clone()
+        n_m, n_a = len(m_status), len(aligner_status)
+        # status accumulators of the replays, shaped like the words of the last eager iteration
+        acc_m = t.zeros_like(m_status[-1])
+        acc_a = t.zeros_like(aligner_status[-1]) if aligner_status else None
+        graph = t.cuda.CUDAGraph()
+        try:
+            with t.cuda.graph(graph):
+                aff, q = e_step(sv, sl, sw)
+                nv, nl, nw = m_step(aff, q)
+                assert len(m_status) == n_m + 1 and len(aligner_status) <= n_a + 1
+                acc_m.bitwise_or_(m_status[-1])
+                if len(aligner_status) > n_a:
+                    acc_a.bitwise_or_(aligner_status[-1])
+                sv.copy_(nv)
+                sl.copy_(nl)
+                sw.copy_(nw)
+        except Exception as e:  # noqa: BLE001 -- a runtime that cannot capture: eager loop
+            import warnings
+            warnings.warn(f'step-wise EM loop: graph capture refused ({type(e).__name__}: {e}); '
+                          'continuing launch by launch', RuntimeWarning)
+            del m_status[n_m:], aligner_status[n_a:]
+            return None
+        # the entries appended while capturing belong to the graph's memory pool: drop them
+        del m_status[n_m:], aligner_status[n_a:]
+        for _ in range(count):
+            graph.replay()
+        m_status.append(acc_m)
+        if acc_a is not None:
+            aligner_status.append(acc_a)
+        # keep the graph (and its private memory pool, which owns the tensors above) alive until
+        # the caller has read the results
+        sv._pbbss_graph = graph
+        return sv, sl, sw
+
     def _fit_stepwise(self, yb, indep, K, gamma0, model, iterations, saliency,
                       sal, act, weight_constant_axis, covariance_norm,
                       affiliation_eps, eigenvalue_floor, hermitize, aligner,
@@ -506,27 +555,31 @@ class CACGMMTrainer:
         device_aligner = aligner is not None and type(aligner).__module__.startswith('pb_bss_amd')
         aligner_status = []  # device status words of the aligner, read once after the loop
         m_status = []
-        for _ in range(iterations):
-            if vec is not None:
-                w = _weight_for_predict(weight, indep, K, N, dev)
-                aff, q, _ = engine.em_predict(
-                    yn, vec.expand(*indep, K, D, D).reshape(B, K, D, D).contiguous(),
-                    val.expand(*indep, K, D).reshape(B, K, D).contiguous(), w,
-                    activity=act, layout=y_layout,
-                    affiliation_eps=affiliation_eps, want_q=True)
-                aff, q = aff.reshape(shape), q.reshape(shape)
-                if aligner is not None:
-                    if device_aligner:
-                        aff, q = apply_inline_permutation_alignment(
-                            affiliation=aff, quadratic_form=q,
-                            weight_constant_axis=weight_constant_axis, aligner=aligner,
-                            status_out=aligner_status)
-                    else:  # a foreign (NumPy) aligner object: the one host excursion left
-                        a_h, q_h = apply_inline_permutation_alignment(
-                            affiliation=_lib.to_host(aff), quadratic_form=_lib.to_host(q),
-                            weight_constant_axis=weight_constant_axis, aligner=aligner)
-                        aff = _lib.to_device(a_h, t.float64, device=dev)
-                        q = _lib.to_device(q_h, t.float64, device=dev)
+        host_excursion = [not device_aligner and aligner is not None]  # any step that leaves the device
+
+        def e_step(vec, val, weight):
+            w = _weight_for_predict(weight, indep, K, N, dev)
+            aff, q, _ = engine.em_predict(
+                yn, vec.expand(*indep, K, D, D).reshape(B, K, D, D).contiguous(),
+                val.expand(*indep, K, D).reshape(B, K, D).contiguous(), w,
+                activity=act, layout=y_layout,
+                affiliation_eps=affiliation_eps, want_q=True)
+            aff, q = aff.reshape(shape), q.reshape(shape)
+            if aligner is not None:
+                if device_aligner:
+                    aff, q = apply_inline_permutation_alignment(
+                        affiliation=aff, quadratic_form=q,
+                        weight_constant_axis=weight_constant_axis, aligner=aligner,
+                        status_out=aligner_status)
+                else:  # a foreign (NumPy) aligner object: the one host excursion left
+                    a_h, q_h = apply_inline_permutation_alignment(
+                        affiliation=_lib.to_host(aff), quadratic_form=_lib.to_host(q),
+                        weight_constant_axis=weight_constant_axis, aligner=aligner)
+                    aff = _lib.to_device(a_h, t.float64, device=dev)
+                    q = _lib.to_device(q_h, t.float64, device=dev)
+            return aff, q
+
+        def m_step(aff, q):
             weight = None
             if weight_hook is not None:
                 weight = weight_hook(aff, sal_dev)  # e.g. an all-reduce over the ranks' bins
@@ -536,6 +589,7 @@ class CACGMMTrainer:
             else:
                 weight = self._device_weight(aff, sal_dev, weight_constant_axis, indep)
             if weight is None:  # exotic axis sets: the NumPy formula
+                host_excursion[0] = True
                 weight = _lib.to_device(estimate_mixture_weight(
                     affiliation=_lib.to_host(aff),
                     saliency=None if sal_dev is None else _lib.to_host(sal_dev),
@@ -547,7 +601,29 @@ class CACGMMTrainer:
                 layout=y_layout, covariance_norm=covariance_norm,
                 eigenvalue_floor=eigenvalue_floor, check_status=False)
             m_status.append(st.reshape(-1))
-            vec, val = vec.reshape(*indep, K, D, D), val.reshape(*indep, K, D)
+            return vec.reshape(*indep, K, D, D), val.reshape(*indep, K, D), weight
+
+        # The loop body is a fixed sequence of ~12 launches on device-resident state: after two
+        # eager iterations (code objects loaded, allocator warm, every host-side decision taken)
+        # ONE iteration is captured into a graph that feeds itself -- its last nodes copy the new
+        # model over the inputs of its first -- and replayed for the rest of the fit: one graph
+        # launch per EM iteration instead of a dozen kernel launches with their host-side argument
+        # marshalling.  Only when nothing in the iteration leaves the device (device aligner or
+        # none, mixture weights from the device reduction, no collective hook) and only on request
+        # (PBBSS_STEPWISE_GRAPH=1): see _stepwise_graph_enabled for the measurement that keeps it off.
+        done = 0
+        while done < iterations:
+            if vec is not None:
+                aff, q = e_step(vec, val, weight)
+            vec, val, weight = m_step(aff, q)
+            done += 1
+            if (done == 2 and iterations - done >= 3 and weight_hook is None
+                    and not host_excursion[0] and _stepwise_graph_enabled()):
+                left = self._replay_iterations(t, e_step, m_step, vec, val, weight, m_status,
+                                               aligner_status, iterations - done)
+                if left is not None:
+                    vec, val, weight = left
+                    done = iterations
         what = 'ComplexAngularCentralGaussianTrainer._fit'
         bits = int(np.bitwise_or.reduce(_lib.to_host(t.cat(m_status)))) if m_status else 0
         # (one-iteration M-step launches never use split groups -- kSplitMinIterations = 3,

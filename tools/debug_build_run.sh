@@ -13,6 +13,6 @@ LIB=pb_bss_amd/libpbbss_hip_debug.so
   echo "# library: $LIB  sha256 $(sha256sum $LIB | cut -c1-16)  bytes $(stat -c %s $LIB)"
   echo "# kernel_source_sha (bench.py --print-source-sha): $(python bench.py --print-source-sha)"
   echo "# git HEAD at the time of the run is recorded by the commit that adds this file"
-  PBBSS_LIB=libpbbss_hip_debug.so timeout 1500 python -m pytest tests -m gpu -q --deselect tests/test_gpu_timeouts.py 2>&1 | tail -6
+  PBBSS_LIB=libpbbss_hip_debug.so timeout 1500 python -m pytest tests -m gpu -q -rf --deselect tests/test_gpu_timeouts.py 2>&1 | grep -E "^FAILED|^ERROR|passed|failed" | head -20
 } > $OUT 2>&1
 cat $OUT
