@@ -173,13 +173,13 @@ struct TimedRegion {
 // CAN launch such a kernel (`needed`: may_split() for the fused fits, always for the cooperative
 // shared-weight fit and the DHTV solver): plain fits -- no remainder bin, fewer than three
 // iterations, generic-size path, the joint models (their members never wait) -- keep their
-// multi-stream concurrency beside other handles.  Best effort by design: two host threads whose
-// constructor-to-destructor windows overlap do not see each other's event; the bounded waits and
-// the host-side repeats remain the safety net.
+// multi-stream concurrency beside other handles.  Within one process the gate is exact since
+// round 5 (the enqueue of gated launches is serialised, see the constructor); the bounded waits
+// and the host-side repeats remain the safety net for work of OTHER processes on the device.
 struct ResidencyGate {
   static constexpr int kMaxDev = 64;
   struct State {
-    std::mutex mu;
+    std::recursive_mutex mu;  // recursive: a gated entry point may create / destroy a handle
     hipEvent_t last = nullptr;        // completion of the most recent gated launch on this device
     pbbss_handle_t owner = nullptr;   // handle whose gate_ev `last` is
     hipStream_t owner_stream = nullptr;
@@ -202,8 +202,17 @@ struct ResidencyGate {
   ResidencyGate(pbbss_handle_t h_, hipStream_t s_, bool needed = true) : h(h_), s(s_), active(false) {
     if (!needed || !h || h->gate_dev < 0 || !enabled()) return;
     State& st = state(h->gate_dev);
-    std::lock_guard<std::mutex> g(st.mu);
-    if (st.handles < 2) return;  // nobody to collide with
+    st.mu.lock();
+    if (st.handles < 2) {  // nobody to collide with
+      st.mu.unlock();
+      return;
+    }
+    // The device mutex stays held until the destructor has recorded this launch's completion
+    // event: the host-side ENQUEUE of gated launches is serialised (microseconds; the device work
+    // is not waited for), so a second thread always finds the event of the launch in front of it.
+    // (Until round 5 the lock was dropped in between: two threads entering together both waited
+    // for the same older event and then ran side by side -- the residual "not co-resident" case
+    // of tests/test_gpu_contention.py, about one full-suite run in ten.)
     active = true;
     if (st.last && !(st.owner == h && st.owner_stream == s))
       (void)hipStreamWaitEvent(s, st.last, 0);
@@ -211,12 +220,12 @@ struct ResidencyGate {
   ~ResidencyGate() {
     if (!active) return;
     State& st = state(h->gate_dev);
-    std::lock_guard<std::mutex> g(st.mu);
     if (hipEventRecord(h->gate_ev, s) == hipSuccess) {
       st.last = h->gate_ev;
       st.owner = h;
       st.owner_stream = s;
     }
+    st.mu.unlock();
   }
   static void on_create(pbbss_handle_t h, int dev) {
     h->gate_dev = -1;
@@ -233,7 +242,7 @@ struct ResidencyGate {
     // launch of another thread must not wait behind a device-wide synchronisation)
     bool drain;
     {
-      std::lock_guard<std::mutex> g(st.mu);
+      std::lock_guard<std::recursive_mutex> g(st.mu);
       drain = ++st.handles == 2;
     }
     if (drain) (void)hipDeviceSynchronize();
@@ -250,7 +259,7 @@ struct ResidencyGate {
     if (h->gate_dev < 0) return;
     State& st = state(h->gate_dev);
     {
-      std::lock_guard<std::mutex> g(st.mu);
+      std::lock_guard<std::recursive_mutex> g(st.mu);
       --st.handles;
       if (st.owner == h) {
         st.last = nullptr;
