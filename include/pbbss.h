@@ -74,7 +74,7 @@ int pbbss_create(pbbss_handle_t* out, int device_id);
  * (one workgroup per matrix, matrices in LDS; the EM loop enqueues three kernels per iteration;
  * layout TD only for the fit).  1 <= K <= 6 classes on the fused kernels, 7 <= K <= 19 on the
  * generic-size path at any D.  Watson mixture (pbbss_cwmm_fit): fused kernel for D <= 8, K <= 4,
- * generic-size path up to D = 32, K = 16.  Joint models (pbbss_joint_fit): D <= 32 (the spatial
+ * generic-size path up to D = 32, K = 19.  Joint models (pbbss_joint_fit): D <= 32 (the spatial
  * half of 9 <= D <= 32, or of 7..8 classes, on the generic-size kernels; inline permutation
  * alignment for K <= 6), K <= 8 (bound of the spectral kernels).  LCMV: D <= 8. */
 int pbbss_destroy(pbbss_handle_t h);
