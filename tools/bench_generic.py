@@ -23,8 +23,16 @@ for D in (12, 16, 24, 29):  # apply_beamforming_vector asserts D < 30 like the r
         w = ex.get_bf_vector('gev+ban', psd[:, 0], psd[:, 1] + psd[:, 2])
         s = ex.apply_beamforming_vector(w, X)
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    # useful float64 flops per frame and EM iteration of the generic-size path: Hermitian quadratic
+    # form y^H A_k y (4 D^2 per class), outer product of the M-step (3 D^2), C_k += w_k P (2 D^2 per
+    # class) -> D^2 (6 K + 3); bytes: one read of the complex64 observation per E-step and per M-step
+    flops = D * D * (6 * K + 3) * F * T * iters
+    tf = flops / (ms * 1e-3) / 1e12
+    gbs = 2 * 8.0 * F * T * D * iters / (ms * 1e-3) / 1e9
     line = (f'D={D}: {iters} EM iterations in {ms:.2f} ms -> {iters / ms * 1e3:.0f} EM it/s '
-            f'({ms / iters * 1e3:.0f} us/iter); psd + gev+ban + apply {dt * 1e3:.2f} ms')
+            f'({ms / iters * 1e3:.0f} us/iter; {tf:.1f} TFLOP/s = {tf / 78.6 * 100:.1f} % of the FP64 vector '
+            f'peak, {gbs:.0f} GB/s of observation reads = {gbs / 8000 * 100:.1f} % of 8 TB/s); '
+            f'psd + gev+ban + apply {dt * 1e3:.2f} ms')
     if '--no-cpu' not in sys.argv and D in (16,):
         Y128 = Y.astype(np.complex128)
         t0 = time.perf_counter(); oc.em_fit(Y128[:64], init[:64], iterations=2); dt = time.perf_counter() - t0
