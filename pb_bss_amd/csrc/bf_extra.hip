@@ -186,54 +186,49 @@ __global__ void __launch_bounds__(kScanThreads)
 // ------------------------------------------------------------------ per-frequency scalars
 // mode 0: mvdr_snr_postfilter  (w^H T w) / (w^H N w)                    (beamformer.py:502-509)
 // mode 1: distortionless_normalization  (N w)(w^H a) / (w^H N w)        (:491-499)
+// One lane per (bin, row a): DP = next power of two >= D lanes form a bin's group (64 / DP bins per
+// wavefront); a lane reads ROW a of the matrices (contiguous, neighbouring lanes neighbouring rows)
+// and the group sums over the rows with xor shuffles.  (Until round 5: one thread per bin walking
+// D x D strided entries -- 513 threads for the whole call.)
+__device__ __forceinline__ Cx group_sum(Cx v, int DP) {
+  for (int off = DP >> 1; off > 0; off >>= 1) {
+    v.re += __shfl_xor(v.re, off);
+    v.im += __shfl_xor(v.im, off);
+  }
+  return v;
+}
 __global__ void bf_quadratic_kernel(int mode, const double* w, const double* m1, const double* m2,
-                                    const double* atf, int64_t F, int D, double* out) {
-  const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (f >= F) return;
-  const double* M2 = m2 + (size_t)f * D * D * 2;
-  Cx den{0.0, 0.0}, num{0.0, 0.0};
-  for (int a = 0; a < D; ++a) {
-    Cx wa = ld(w, (size_t)f * D + a);
-    Cx r2{0.0, 0.0}, r1{0.0, 0.0};
+                                    const double* atf, int64_t F, int D, int DP, double* out) {
+  const int lane = threadIdx.x & 63;
+  const int a = lane & (DP - 1);
+  const int64_t f = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / DP;
+  const bool on = f < F && a < D;
+  const int64_t fc = f < F ? f : F - 1;  // idle lanes take part in the shuffles with zeros
+  Cx r2{0.0, 0.0}, r1{0.0, 0.0}, wa{0.0, 0.0};
+  if (on) {
+    wa = ld(w, (size_t)fc * D + a);
+    const double* M2 = m2 + ((size_t)fc * D + a) * D * 2;
+    const double* M1 = m1 ? m1 + ((size_t)fc * D + a) * D * 2 : nullptr;
     for (int b = 0; b < D; ++b) {
-      Cx wb = ld(w, (size_t)f * D + b);
-      Cx p = cmul(ld(M2, (size_t)a * D + b), wb);
+      const Cx wb = ld(w, (size_t)fc * D + b);
+      const Cx p = cmul(ld(M2, (size_t)b), wb);
       r2.re += p.re;
       r2.im += p.im;
       if (mode == 0) {
-        Cx q = cmul(ld(m1 + (size_t)f * D * D * 2, (size_t)a * D + b), wb);
+        const Cx q = cmul(ld(M1, (size_t)b), wb);
         r1.re += q.re;
         r1.im += q.im;
       }
     }
-    Cx t = cmulc(wa, r2);
-    den.re += t.re;
-    den.im += t.im;
-    if (mode == 0) {
-      Cx s = cmulc(wa, r1);
-      num.re += s.re;
-      num.im += s.im;
-    }
   }
+  const Cx den = group_sum(cmulc(wa, r2), DP);  // w^H N w
   if (mode == 0) {
-    st(out, (size_t)f, cdiv(num, den));
+    const Cx num = group_sum(cmulc(wa, r1), DP);  // w^H T w
+    if (on && a == 0) st(out, (size_t)f, cdiv(num, den));
     return;
   }
-  Cx proj{0.0, 0.0};  // w^H a
-  for (int c = 0; c < D; ++c) {
-    Cx p = cmulc(ld(w, (size_t)f * D + c), ld(atf, (size_t)f * D + c));
-    proj.re += p.re;
-    proj.im += p.im;
-  }
-  for (int a = 0; a < D; ++a) {
-    Cx r{0.0, 0.0};
-    for (int b = 0; b < D; ++b) {
-      Cx p = cmul(ld(M2, (size_t)a * D + b), ld(w, (size_t)f * D + b));
-      r.re += p.re;
-      r.im += p.im;
-    }
-    st(out, (size_t)f * D + a, cmul(cdiv(r, den), proj));
-  }
+  const Cx proj = group_sum(on ? cmulc(wa, ld(atf, (size_t)fc * D + a)) : Cx{0.0, 0.0}, DP);  // w^H a
+  if (on) st(out, (size_t)f * D + a, cmul(cdiv(r2, den), proj));
 }
 
 // zero_degree_normalization: v * exp(-j angle(v[..., ref]))              (beamformer.py:512-514)
@@ -318,35 +313,41 @@ __global__ void zero_degree_kernel(const double* v, int64_t N, int D, int ref, d
 }
 
 // condition_covariance: (x + gamma tr(x)/D I) / (1 + gamma)              (beamformer.py:563-569)
+// one thread per matrix ENTRY (the D diagonal reads of the trace hit the cache lines the
+// neighbouring threads stream)
 __global__ void condition_kernel(const double* x, int64_t N, int D, double gamma, double* out) {
-  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= N) return;
-  Cx tr{0.0, 0.0};
-  for (int d = 0; d < D; ++d) {
-    Cx e = ld(x, ((size_t)n * D + d) * D + d);
-    tr.re += e.re;
-    tr.im += e.im;
-  }
-  const Cx sc{gamma * tr.re / D, gamma * tr.im / D};
-  const double inv = 1.0 + gamma;
-  for (int a = 0; a < D; ++a)
-    for (int b = 0; b < D; ++b) {
-      Cx e = ld(x, ((size_t)n * D + a) * D + b);
-      if (a == b) {
-        e.re += sc.re;
-        e.im += sc.im;
-      }
-      st(out, ((size_t)n * D + a) * D + b, Cx{e.re / inv, e.im / inv});
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= N * D * D) return;
+  const int64_t n = e / (D * D);
+  const int ab = (int)(e - n * D * D);
+  const int a = ab / D, b = ab - a * D;
+  Cx v = ld(x, (size_t)e);
+  if (a == b) {
+    Cx tr{0.0, 0.0};
+    for (int d = 0; d < D; ++d) {
+      const Cx t = ld(x, ((size_t)n * D + d) * D + d);
+      tr.re += t.re;
+      tr.im += t.im;
     }
+    v.re += gamma * tr.re / D;
+    v.im += gamma * tr.im / D;
+  }
+  const double inv = 1.0 + gamma;
+  st(out, (size_t)e, Cx{v.re / inv, v.im / inv});
 }
 
 // apply_online_beamforming_vector: out[f,t] = sum_d conj(v[t,f,d]) mix[f,d,t]   (:586-598)
+// Tile of 16 bins x 16 frames per workgroup, the bin index fastest: the frame-varying vectors
+// v (T, F, D) are then read in runs of 16 D contiguous complex numbers, the observation (F, D, T)
+// in runs of 16 frames.  (Until round 5: one bin per block row -- every lane of a wavefront read v
+// with a stride of F D complex numbers.)
 template <typename YS>
 __global__ void apply_online_kernel(const double* v, const void* mixv, int64_t F, int T, int D,
                                     double* out) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t f = blockIdx.y;
-  if (t >= T) return;
+  const int fl = threadIdx.x & 15, tl = threadIdx.x >> 4;
+  const int64_t f = (int64_t)blockIdx.y * 16 + fl;
+  const int t = blockIdx.x * 16 + tl;
+  if (t >= T || f >= F) return;
   const YS* mix = static_cast<const YS*>(mixv);
   Cx s{0.0, 0.0};
   for (int d = 0; d < D; ++d) {
@@ -404,8 +405,11 @@ int launch_phase_correction(const double* v, int64_t lead, int64_t rest, int F, 
 
 int launch_bf_quadratic(int mode, const double* w, const double* m1, const double* m2,
                         const double* atf, int64_t F, int D, double* out, hipStream_t s) {
-  hipLaunchKernelGGL(bf_quadratic_kernel, dim3(blocks(F, 64)), dim3(64), 0, s, mode, w, m1, m2,
-                     atf, F, D, out);
+  if (D < 1 || D > 64) return PBBSS_ERR_UNSUPPORTED;
+  int DP = 1;
+  while (DP < D) DP <<= 1;  // lanes per bin
+  hipLaunchKernelGGL(bf_quadratic_kernel, dim3(blocks(F * DP, 256)), dim3(256), 0, s, mode, w, m1,
+                     m2, atf, F, D, DP, out);
   return ok_or_hip();
 }
 
@@ -433,14 +437,15 @@ int launch_zero_degree(const double* v, int64_t N, int D, int ref, double* out, 
 
 int launch_condition_covariance(const double* x, int64_t N, int D, double gamma, double* out,
                                 hipStream_t s) {
-  hipLaunchKernelGGL(condition_kernel, dim3(blocks(N, 64)), dim3(64), 0, s, x, N, D, gamma, out);
+  hipLaunchKernelGGL(condition_kernel, dim3(blocks(N * D * D, 256)), dim3(256), 0, s, x, N, D, gamma,
+                     out);
   return ok_or_hip();
 }
 
 int launch_apply_online(const double* v, const void* mix, int mix_is_c128, int64_t F, int T, int D,
                         double* out, hipStream_t s) {
-  if (F > 65535) return PBBSS_ERR_UNSUPPORTED;
-  dim3 grid(blocks(T, 256), (unsigned)F);
+  if (F > 65535 * 16) return PBBSS_ERR_UNSUPPORTED;
+  dim3 grid(blocks(T, 16), blocks(F, 16));
   if (mix_is_c128)
     hipLaunchKernelGGL(apply_online_kernel<double>, grid, dim3(256), 0, s, v, mix, F, T, D, out);
   else
