@@ -916,7 +916,9 @@ def run_config3(args, world, rank, local_rank, dev, use_dist, primary=False):
     if use_dist and world > 1:
         shards = [args.shard] if primary else ['bins', 'utterances']
         for sh in shards:
-            legs[sh] = config3_leg(args, data, Y, init, sh, world, rank, dev, use_dist, steps, warmup)
+            # (keys 'bins_sharded' / 'utterances_sharded': 'utterances' is the batch size of the block)
+            legs[sh + '_sharded'] = config3_leg(args, data, Y, init, sh, world, rank, dev, use_dist,
+                                                steps, warmup)
     else:
         legs['single'] = config3_leg(args, data, Y, init, None, world, rank, dev, use_dist, steps,
                                      warmup)
