@@ -56,7 +56,10 @@ def test_saliency_zero_frame_rank_deficient_batch():
     g = load('cacgmm_rank_deficient')
     m = CACGMMTrainer().fit(g['Y'], initialization=g['init'], iterations=int(g['iterations']))
     assert (m.cacg.covariance_eigenvalues.min(axis=-1) == 1e-10).all()
-    assert np.abs(m.cacg.covariance_eigenvalues - g['eigval']).max() < 1e-4  # cond*eps, see test_gpu_em
+    # condition number 1e10: two float64 evaluation orders of the reference's own formulas differ by
+    # 5e-8 .. 2e-7 on this fixture (tests/test_oracle_golden.py::test_rank_deficient_fixture_spread),
+    # the device by 4.8e-7 (round 5); 5e-6 leaves a decade (was 1e-4 until round 5)
+    assert np.abs(m.cacg.covariance_eigenvalues - g['eigval']).max() < 5e-6
     g = load('cacgmm_batch_axis')
     m = CACGMMTrainer().fit(g['Y'], initialization=g['init'], iterations=int(g['iterations']))
     assert m.cacg.covariance_eigenvectors.shape == (2, 3, 2, 4, 4)
