@@ -341,3 +341,49 @@ def test_split_timeout_pattern_repeats_the_fit_without_split_groups(monkeypatch)
     monkeypatch.setattr(engine, 'split_error', lambda device_index=None: 0)
     with pytest.raises(AssertionError, match='non-finite'):
         engine.em_fit(y, 2, gamma0=g0, iterations=5, final_predict=True)
+
+
+@pytest.mark.parametrize('T', [40, 63, 64, 65, 127, 128, 129, 255, 256, 257, 320, 511, 513])
+def test_frame_counts_around_the_chunk_size(T):
+    """The LDS frame arrays live in chunks of 64 frames with zero padding frames behind T (round 5):
+    the M sweep runs over whole chunks unmasked, E passes skip chunks beyond the padded count, the
+    E phase rewrites the padding frames' weights with zeros.  Frame counts on both sides of every
+    chunk and pass boundary, odd sensor counts (a half-used float4 plane), saliency with zeros, an
+    activity mask, an all-zero frame at the very end -- against the oracle after 4 iterations."""
+    from oracle import synth
+    rng = np.random.default_rng(T)
+    for D, K in ((2, 2), (5, 3), (8, 3)):
+        F = 3
+        Y, init = synth.make_stft(F, T, D, K, seed=T + D)
+        Y[1, -1] = 0                                    # zero frame in the last (partial) chunk
+        sal = rng.uniform(0.0, 1.0, size=(F, T))
+        sal[:, ::7] = 0.0
+        act = (rng.uniform(size=(F, K, T)) > 0.1)
+        act[:, 0] = True                                # at least one class active everywhere
+        for kw_o, kw_d in (({}, {}),
+                           (dict(saliency=sal), dict(saliency=_dev(sal))),
+                           (dict(source_activity_mask=act), dict(activity=_dev(act.astype(np.uint8))))):
+            ref, want = _oracle_fit(Y, init, 4, **kw_o)
+            r = _device_fit(Y, init, 4, **kw_d)
+            got = _host(r['affiliation'])
+            tol = 1e-8
+            # the final predict of the oracle applies no mask (CACGMM.predict); the device's too
+            assert np.abs(got - want).max() < tol, (T, D, K, list(kw_o))
+            np.testing.assert_allclose(_cov(_host(r['eigvec']), _host(r['eigval'])),
+                                       _cov(ref['eigvec'], ref['eigval']), atol=tol)
+
+
+@pytest.mark.parametrize('T', [130, 192, 200])
+def test_remainder_bins_with_partial_last_window(T):
+    """Split groups (2^n + 1 bins) whose last 64-frame window is partial or whose frame count is a
+    whole number of windows: the members carve their LDS for a full window and sweep only the
+    chunks their frames fill."""
+    from oracle import synth
+    from pb_bss_amd import engine
+    F, D, K = 258, 4, 2
+    Y, init = synth.make_stft(F, T, D, K, seed=T)
+    r = _device_fit(Y, init, 5)
+    sel = [0, 100, 255, 256, 257]
+    ref, want = _oracle_fit(Y[sel], init[sel], 5)
+    assert engine.split_error() == 0
+    assert np.abs(_host(r['affiliation'])[sel] - want).max() < 1e-8
