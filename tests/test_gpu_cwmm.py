@@ -165,3 +165,32 @@ def test_cwmm_config4_full_size():
     w = ex.get_mvdr_vector_souden(psd[:, 0], psd[:, 1] + psd[:, 2])
     w_ref = ob.mvdr_souden(psd_ref[:, 0], psd_ref[:, 1] + psd_ref[:, 2])
     assert np.abs(w - w_ref).max() < 1e-5 * np.abs(w_ref).max()
+
+
+@pytest.mark.parametrize('T', [40, 64, 65, 129, 256, 257, 330])
+def test_cwmm_frame_counts_around_the_chunk_size(T):
+    """The Watson kernel shares the 64-frame chunk layout of the LDS frame arrays (round 5: unmasked
+    M sweep, E passes that skip empty chunks, padding weights rewritten with zeros): frame counts on
+    both sides of the chunk and pass boundaries, with and without saliency (zeros included), and the
+    PSD kernel on the same layout (masked, mask-less, un-normalised)."""
+    from pb_bss_amd.distribution import CWMMTrainer
+    from pb_bss_amd import extraction as ex
+    from oracle import beamformer as ob, cwmm as ow, synth
+    rng = np.random.default_rng(T)
+    for D, K in ((3, 2), (6, 3), (8, 4)):
+        F = 3
+        Y, init = synth.make_stft(F, T, D, K, seed=T + D)
+        Y128 = Y.astype(np.complex128)
+        sal = rng.uniform(0.0, 1.0, size=(F, T))
+        sal[:, ::5] = 0.0
+        for s in (None, sal):
+            ref = ow.cwmm_fit(Y128, init, iterations=4, saliency=s)
+            got = CWMMTrainer().fit_predict(Y, initialization=init, iterations=4, saliency=s)
+            assert np.abs(got - ow.cwmm_predict(ref, Y128)).max() < 1e-7, (T, D, K, s is not None)
+        X, X128 = Y.transpose(0, 2, 1), Y128.transpose(0, 2, 1)
+        np.testing.assert_allclose(ex.get_power_spectral_density_matrix(X, got),
+                                   ob.psd(X128, got), atol=1e-11)
+        np.testing.assert_allclose(ex.get_power_spectral_density_matrix(X, got, normalize=False),
+                                   ob.psd(X128, got, normalize=False), atol=1e-9)
+        np.testing.assert_allclose(ex.get_power_spectral_density_matrix(X),
+                                   ob.psd(X128), atol=1e-11)

@@ -567,3 +567,22 @@ def test_joint_inline_permutation_alignment_50_iterations_against_oracle(kind):
     model, masks, ref, want = _joint_trajectory(kind, 33, 500, 50, seed=5, **kw)
     assert np.abs(masks - want).max() < 1e-6
     _assert_joint_model_close(model, ref, kind, 1e-7)
+
+
+@pytest.mark.parametrize('T', [64, 65, 130, 257])
+def test_joint_models_frame_counts_around_the_chunk_size(T):
+    """The spatial kernels of the joint models share the 64-frame chunk layout of the LDS frame
+    arrays (round 5): frame counts on both sides of the chunk / pass boundaries, the rotated
+    two-kernel loop (spherical Gaussian, vMF) and the three-kernel path (diagonal Gaussian)."""
+    from pb_bss_amd.distribution import GCACGMMTrainer, VMFCACGMMTrainer
+    from oracle import embed as oe, synth
+    F, D, K, E = 5, 6, 3, 12
+    Y, e, init = synth.make_joint(F, T, D, K, E, seed=T)
+    Y128, e64 = Y.astype(np.complex128), e.astype(np.float64)
+    sal = np.random.default_rng(T).uniform(0.1, 1.0, size=(F, T))
+    for kind, trainer, kw in (('gaussian', GCACGMMTrainer(), {}),
+                              ('gaussian', GCACGMMTrainer(), dict(covariance_type='diagonal')),
+                              ('vmf', VMFCACGMMTrainer(), dict(max_concentration=80.))):
+        got = trainer.fit_predict(Y, e, initialization=init, iterations=5, saliency=sal, **kw)
+        ref = oe.joint_fit(kind, Y128, e64, init, 5, saliency=sal, **kw)
+        assert np.abs(got - oe.joint_model_predict(ref, Y128, e64)).max() < 1e-6, (T, kind, kw)
