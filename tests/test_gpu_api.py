@@ -667,3 +667,25 @@ def test_fit_with_log_likelihood_history_matches_the_oracle_trajectory():
     fused = CACGMMTrainer().fit(Y, initialization=init, iterations=5)
     np.testing.assert_allclose(model.predict(Y), fused.predict(Y), atol=1e-9)
     assert isinstance(model.weight, np.ndarray)
+
+
+def test_stepwise_loop_as_a_captured_graph_is_bit_identical(monkeypatch):
+    """PBBSS_STEPWISE_GRAPH=1 (opt-in, round 5): after two eager iterations the step-wise EM loop
+    replays ONE captured graph per iteration -- E-step, device DHTV aligner, weight reduction,
+    M-step, status accumulation, the new model copied over the graph's inputs.  Same launches, same
+    arguments: the model must equal the eager loop's bit for bit."""
+    from pb_bss_amd.distribution import CACGMMTrainer
+    from pb_bss_amd.permutation_alignment import DHTVPermutationAlignment
+    from pb_bss_amd.testing import synth
+    F, T, D, K = 257, 130, 4, 2   # stft_size 512: one of the reference's two presets
+    Y, init = synth.make_stft(F, T, D, K, seed=11)
+    out = {}
+    for flag in ('0', '1'):
+        monkeypatch.setenv('PBBSS_STEPWISE_GRAPH', flag)
+        out[flag] = CACGMMTrainer().fit(
+            Y, initialization=init, iterations=9, weight_constant_axis=(-3,),
+            inline_permutation_aligner=DHTVPermutationAlignment.from_stft_size(2 * (F - 1)))
+    a, b = out['0'], out['1']
+    assert np.array_equal(a.weight, b.weight)
+    assert np.array_equal(a.cacg.covariance_eigenvalues, b.cacg.covariance_eigenvalues)
+    assert np.array_equal(a.cacg.covariance_eigenvectors, b.cacg.covariance_eigenvectors)
