@@ -194,6 +194,8 @@ struct EmKernel {
     int* dete;       // [K]           det B_k exponent
     int* status;     // [K]
     int* flags;      // [1]  bit0: the problem contains an all-zero frame
+    unsigned short* wbtab;  // [kEmWaves][16][NACC/16] M-phase write-back: index into cpack per value
+    double* sink;    // [1]  where the butterfly's padding values go
     int Tp;
   };
 
@@ -217,6 +219,7 @@ struct EmKernel {
     n += (size_t)K * 8 * 4;         // wgt, detm, rdet, ssum
     n += (size_t)kEmWaves * K * 8;  // red
     n += (size_t)K * 4 * 2 + 16;    // dete, status, flags
+    n += wbtab_bytes() + 8;         // wbtab, sink
     return n;
   }
   static __host__ __device__ size_t lds_bytes(int T) {
@@ -252,6 +255,7 @@ struct EmKernel {
     f += (size_t)K * L.Tp * 8;
     if (!SPILL) p = f;
     carve_small_into(L, p);
+    fill_wbtab(L);
     return L;
   }
 
@@ -275,6 +279,10 @@ struct EmKernel {
     L.status = reinterpret_cast<int*>(p);
     p += K * 4;
     L.flags = reinterpret_cast<int*>(p);
+    p += 16;
+    L.wbtab = reinterpret_cast<unsigned short*>(p);
+    p += wbtab_bytes();
+    L.sink = reinterpret_cast<double*>(p);
   }
 
   // row stride of the (B,K,T)/(B,T) arrays and first global frame of this workgroup
@@ -729,6 +737,42 @@ struct EmKernel {
   }
   static_assert(entry_map_fits(), "a wave owns more entries than it has accumulator slots");
 
+  // ---- write-back table of the M phase ----------------------------------------------------
+  // After the halving butterfly lane group g = (lane >> 2) & 15 of wave W holds the totals of the
+  // accumulator indices R g .. R g + R - 1 (R = NACC / 16).  Where each of them goes in cpack
+  // (class, packed entry) depends on the lane only: computed ONCE per kernel into LDS by carve()
+  // (until round 5 every wave decoded it after every butterfly: ~70 branchy instructions per
+  // wave-iteration).  Values that belong to no entry go to `sink`.
+  static constexpr int kWbR = NACC / 16;
+  static __host__ __device__ constexpr size_t wbtab_bytes() {
+    return ((size_t)kEmWaves * 16 * kWbR * sizeof(unsigned short) + 7) & ~(size_t)7;
+  }
+  // ROUND_ROBIN: the entry map of the packed-FP32 kernel (diagonal i -> wave i % 4, pair p -> p % 4)
+  template <bool ROUND_ROBIN = false>
+  static __device__ __forceinline__ void fill_wbtab(const Lds& L) {
+    const int tid = threadIdx.x;
+    if (tid >= kEmWaves * 16) return;
+    const int w = tid >> 4, g = tid & 15;
+    const unsigned long long dcode = kMap.dcode[w], pcode = kMap.pcode[w];
+    const int sink = (int)(L.sink - L.cpack);
+#pragma unroll
+    for (int m = 0; m < kWbR; ++m) {
+      const int idx = kWbR * g + m;
+      int off = sink;
+      if (idx < K * NSLOT) {
+        const int k = idx / NSLOT, sl = idx % NSLOT;
+        const bool dg = sl < NDW;
+        const int u = ROUND_ROBIN
+                          ? (dg ? sl * kEmWaves + w : ((sl - NDW) >> 1) * kEmWaves + w)
+                          : (dg ? (int)((dcode >> (4 * sl)) & 15)
+                                : (int)((pcode >> (5 * ((sl - NDW) >> 1))) & 31));
+        const int e = dg ? u : D + 2 * u + ((sl - NDW) & 1);
+        if (u < (dg ? D : NOFF)) off = k * NA + e;
+      }
+      L.wbtab[(w * 16 + g) * kWbR + m] = (unsigned short)off;
+    }
+  }
+
   template <int W>
   static __device__ void phase_m(const EmArgs& a, const Lds& L, int lane) {
     lane = opaque(lane);
@@ -860,24 +904,13 @@ struct EmKernel {
 #ifdef PBBSS_PHASE_PROFILE
     tm1 = __builtin_readcyclecounter();
 #endif
-    // write-back in the packed order of apack (diag i -> i, pair p -> D + 2p + {Re, Im}): a few
-    // integer operations per value; the consumers (factor_class, split_exchange, psd read-out)
-    // unpack with pair_index()
+    // write-back in the packed order of apack (diag i -> i, pair p -> D + 2p + {Re, Im}) through
+    // the per-lane table carve() left in LDS; the consumers (factor_class, split_exchange, psd
+    // read-out) unpack with pair_index()
     if ((lane & 3) == 0) {
-      const int base = reduce_scatter_base<NACC>(lane);
+      const unsigned short* tab = L.wbtab + (W * 16 + ((lane >> 2) & 15)) * kWbR;
 #pragma unroll
-      for (int m = 0; m < NACC / 16; ++m) {
-        const int idx = base + m;
-        if (idx < K * NSLOT) {
-          const int k = idx / NSLOT, s = idx % NSLOT;
-          const bool dg = s < NDW;
-          // diag i / pair p of this slot (inverse of the entry map, packed into two constants)
-          const int u = dg ? (int)((kMap.dcode[W] >> (4 * s)) & 15)
-                           : (int)((kMap.pcode[W] >> (5 * ((s - NDW) >> 1))) & 31);
-          const int e = dg ? u : D + 2 * u + ((s - NDW) & 1);
-          if (u < (dg ? D : NOFF)) L.cpack[k * NA + e] = acc[m];
-        }
-      }
+      for (int m = 0; m < kWbR; ++m) L.cpack[tab[m]] = acc[m];
     }
 #ifdef PBBSS_PHASE_PROFILE
     if (a.prof && lane == 0 && W == 0) {

@@ -188,6 +188,7 @@ struct EmKernel32 {
     L.w = L.y + (size_t)DP * L.Tp * 4;
     L.a32 = L.w + (size_t)L.Tp * KP;  // Tp even, KP even: 16-byte aligned when Tp * KP % 4 == 0
     L.b = Base::carve_small(reinterpret_cast<char*>(L.a32 + (size_t)K * NAP), L.Tp);
+    Base::template fill_wbtab<true>(L.b);  // write-back table of phase_m (this kernel's entry map)
     return L;
   }
 
@@ -574,19 +575,10 @@ struct EmKernel32 {
       }
     }
     wave_reduce_scatter32<NACC>(flat);
-    if ((lane & 3) == 0) {
-      const int base = reduce_scatter_base<NACC>(lane);
+    if ((lane & 3) == 0) {  // destinations from the table carve() left in LDS (cacgmm_em.hpp: fill_wbtab)
+      const unsigned short* tab = L.b.wbtab + (W * 16 + ((lane >> 2) & 15)) * Base::kWbR;
 #pragma unroll
-      for (int m = 0; m < NACC / 16; ++m) {
-        const int idx = base + m;
-        if (idx < K * NSLOT) {
-          const int k = idx / NSLOT, s = idx % NSLOT;
-          const bool dg = s < NDW;
-          const int u = dg ? s * kEmWaves + W : ((s - NDW) >> 1) * kEmWaves + W;  // diag i / pair p
-          const int e = dg ? u : D + 2 * u + ((s - NDW) & 1);
-          if (u < (dg ? D : NOFF)) L.b.cpack[k * NA + e] = (double)flat[m];
-        }
-      }
+      for (int m = 0; m < Base::kWbR; ++m) L.b.cpack[tab[m]] = (double)flat[m];
     }
   }
   static __device__ __forceinline__ void phase_m_dispatch(const EmArgs& a, const Lds& L, int wave,

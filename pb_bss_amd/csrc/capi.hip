@@ -1672,8 +1672,11 @@ static size_t joint_kernel_lds_bytes(int D, int K, int T, int c128) {
   // frame arrays in chunks of 64 frames (cacgmm_em.hpp: EmKernel::padded_frames)
   const size_t DP = (size_t)(D + 1) / 2, Tp = (size_t)((T + 63) & ~63), NA = (size_t)D * D;
   const size_t frames = DP * Tp * 4 * (c128 ? 8 : 4) + Tp * 8 + (size_t)K * Tp * 8;
+  // (+ the write-back table of the M phase and its sink: EmKernel::wbtab_bytes() + 8)
+  const size_t noff = (size_t)D * (D - 1) / 2, nslot = (D + 3) / 4 + 2 * ((noff + 3) / 4);
+  const size_t wbtab = (4 * 16 * ((K * nslot + 15) / 16) * 2 + 7) & ~(size_t)7;
   const size_t small = 2 * (size_t)K * NA * 8 + (size_t)K * 8 * 4 + 4 * (size_t)K * 8 +
-                       (size_t)K * 4 * 2 + 16;
+                       (size_t)K * 4 * 2 + 16 + wbtab + 8;
   return ((frames + small + 15) & ~(size_t)15) + 64;
 }
 
