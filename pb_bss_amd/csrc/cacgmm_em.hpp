@@ -572,7 +572,7 @@ struct EmKernel {
 #pragma unroll
         for (int k = 0; k < K; ++k) {
           double gam = g[k] * rden;
-          if (eps != 0.0) gam = fmin(fmax(gam, eps), 1.0 - eps);
+          if (!FINAL || eps != 0.0) gam = fmin(fmax(gam, eps), 1.0 - eps);  // (see the non-joint branch)
           size_t idx = ((size_t)b * K + k) * TS + tf + t;
           if (ok[0]) {
             if (a.out_aff) a.out_aff[idx] = gam;  // unmasked affiliation of this E-step
@@ -633,7 +633,10 @@ struct EmKernel {
 #pragma unroll
         for (int k = 0; k < K; ++k) {
           double gam = g[k] * rden;
-          if (eps != 0.0) gam = fmin(fmax(gam, eps), 1.0 - eps);  // :50-53, no renormalisation
+          // :50-53, no renormalisation.  In the loop the clip is applied unconditionally: with
+          // eps = 0 it is [0, 1], which only catches a posterior that the reciprocal's rounding put
+          // an ulp above 1 (the uniform `eps != 0` test cost two 64-bit selects per class)
+          if (!FINAL || eps != 0.0) gam = fmin(fmax(gam, eps), 1.0 - eps);
           if constexpr (FINAL) {
             if (ok[f]) {
               size_t idx = ((size_t)b * K + k) * TS + tf + t;
@@ -652,7 +655,9 @@ struct EmKernel {
                                  __HIP_MEMORY_SCOPE_AGENT);
             // M-step weight gamma/max(q, 10 tiny)/|y|^2 (cacg.py:310, :322); q >= 10 tiny
             // except for all-zero frames, where inv = 0 makes the weight 0 anyway
-            double rqk = (q[f][k] >= 10.0 * kTiny) ? rq[k] : (1.0 / (10.0 * kTiny));
+            // (one v_min: 1/q <= 1/(10 tiny) exactly when q >= 10 tiny -- a compare and a 64-bit
+            // select per class until round 5)
+            double rqk = fmin(rq[k], 1.0 / (10.0 * kTiny));
             // unmasked for the first frame of a lane: a padding frame writes 0 (gs = 0, inv = 0,
             // rqk finite), which the unmasked M sweep relies on
             if (f == 0 || inl[f]) L.wbuf[woff(k, tl[f])] = gs * rqk * inv;
