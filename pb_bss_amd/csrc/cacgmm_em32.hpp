@@ -440,14 +440,16 @@ struct EmKernel32 {
 #pragma unroll
         for (int k = 0; k < K; ++k) {
           float gam = g[k] * rden;
-          if (eps != 0.f) gam = fminf(fmaxf(gam, eps), 1.f - eps);  // :50-53, no renormalisation
+          // :50-53, no renormalisation; unconditional inside the loop (as in cacgmm_em.hpp: with
+          // eps = 0 the clip is [0, 1])
+          if (!FINAL || eps != 0.f) gam = fminf(fmaxf(gam, eps), 1.f - eps);
           if constexpr (FINAL) {
             if (ok[f] && a.out_aff) a.out_aff[((size_t)b * K + k) * TS + tf + t] = (double)gam;
             wout[k] = 0.f;
           } else {
             const float gs = ok[f] ? gam * sal : 0.f;
             // gamma / max(q, 10 tiny) (cacg.py:310, :322); y is unit-norm in LDS
-            const float rqk = (q[k] >= 10.f * kTiny32) ? rq[k] : (1.f / (10.f * kTiny32));
+            const float rqk = fminf(rq[k], 1.f / (10.f * kTiny32));  // one v_min instead of compare + select
             wout[k] = gs * rqk;
             s[k] += gs;
           }
