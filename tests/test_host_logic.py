@@ -368,3 +368,23 @@ def test_random_affiliation_consumes_the_reference_stream():
     finally:
         utils.set_random_init('numpy')
     assert np.random.uniform() == first   # the NumPy stream was not consumed
+
+
+def test_committed_profiles_match_the_kernel_sources_of_this_tree():
+    """bench.py attaches PMC traffic to its roofline blocks only from a committed rocprofv3 summary
+    whose header carries the hash of the kernel sources in the tree: a kernel edit without a new
+    profile would silently turn `traffic` into null on the driver's line.  Every workload of the
+    default line must find its profile."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('bench_for_test', os.path.join(root, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    path = bench.matching_profile()
+    assert path is not None, 'no profiles/r*_profile.txt carries kernel_source_sha ' + bench.kernel_source_sha()
+    prof = bench.read_profile(path)
+    assert prof['trace'] is not None and prof['pmc'], path
+    for workload in ('config3', 'config4', 'config4_vmf', 'config5'):
+        traffic, src = bench.workload_pmc(workload, None)
+        assert traffic is not None and traffic['bytes_per_step'] > 0, (workload, src)
