@@ -66,7 +66,7 @@ def back_to_back_ms(fn, reps, warm=3):
 
 def main():
     import torch
-    import bench
+    import bench_blocks as bench  # kernel_source_sha, make_batch
     from pb_bss_amd import _lib, engine, pipeline
     from pb_bss_amd.pipeline import device_ops as ops, _chain_after_masks
     from pb_bss_amd.sharding import shard_bounds
