@@ -209,8 +209,10 @@ def em_fit_shared(y, K, group, *, weight_mode, gamma0=None, model=None, iteratio
     _lib.check(rc, f'cacgmm_fit_shared(B={B},group={group},T={T},D={D},K={K})')
     if check_status:
         poison = _lib.ST_NONFINITE | _lib.ST_EIG_NOCONV
-        if iterations > 0 and split_error(dev.index) \
-                and bool(((out_st & poison) == poison).any().item()):
+        # the status test first: split_error() is a blocking read of the handle's flag word and
+        # is only worth its round trip when some status word carries the time-out pattern
+        if iterations > 0 and bool(((out_st & poison) == poison).any().item()) \
+                and split_error(dev.index):
             # some status words carry the time-out pattern and the handle's wait flag is up (the
             # groups of a big batch go out as several cooperative launches: one of them can time
             # out alone): a cooperative launch did not get its workgroups co-resident (other
@@ -578,7 +580,7 @@ def cwmm_fit(y, K, spline, *, gamma0=None, model=None, iterations=100, saliency=
             poison = _lib.ST_NONFINITE | _lib.ST_EIG_NOCONV
             # .any(): the groups of a big batch go out as several cooperative launches, one of
             # which can time out alone
-            if split_error(dev.index) and bool(((r['status'] & poison) == poison).any().item()):
+            if bool(((r['status'] & poison) == poison).any().item()) and split_error(dev.index):
                 import warnings
                 warnings.warn('cooperative shared-weight launch timed out waiting for '
                               'co-residency; repeating the fit step by step', RuntimeWarning,

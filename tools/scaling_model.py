@@ -28,6 +28,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 XGMI_LINK_GBS = 153.0        # MI355X_MICROARCH.md: per xGMI link, per direction
 GATHER_LATENCY_US = 20.0     # assumption: one RCCL all-gather call, launch + sync, small-message floor
