@@ -643,7 +643,8 @@ int pbbss_distortionless_normalization(pbbss_handle_t h, const void* w,
 int pbbss_zero_degree_normalization(pbbss_handle_t h, const void* vector, int64_t N,
                                     int D, int reference_channel, void* out,
                                     void* stream);
-/* condition_covariance (:563-569): x (N,D,D) -> out (N,D,D).                      */
+/* condition_covariance (:563-569): x (N,D,D) -> out (N,D,D).  out must not alias  */
+/* x (PBBSS_ERR_INVALID_ARG when out == x): entries are processed independently.   */
 int pbbss_condition_covariance(pbbss_handle_t h, const void* x, int64_t N, int D,
                                double gamma, void* out, void* stream);
 /* apply_online_beamforming_vector (:586-598): vector (T,F,D) c128, mix (F,D,T)    */

@@ -566,13 +566,16 @@ struct EmKernel {
             den += g[k];
           }
         }
+        const double poison = den - den;  // 0, or NaN for a non-finite sum (see the non-joint branch)
         den = fmax(den, kTiny);
         const double rden = fast_rcp(den);  // one reciprocal instead of K divisions
         const double sal = (!FINAL && a.saliency) ? a.saliency[(size_t)b * TS + tf + t] : 1.0;
+        const double invp = inv + poison;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
           double gam = g[k] * rden;
           if (!FINAL || eps != 0.0) gam = fmin(fmax(gam, eps), 1.0 - eps);  // (see the non-joint branch)
+          if constexpr (FINAL) gam += poison;
           size_t idx = ((size_t)b * K + k) * TS + tf + t;
           if (ok[0]) {
             if (a.out_aff) a.out_aff[idx] = gam;  // unmasked affiliation of this E-step
@@ -582,7 +585,7 @@ struct EmKernel {
             double gs = ok[0] ? gam * sal : 0.0;
             // unconditional: a padding frame stores weight 0 (gs = 0, inv = 0), which is what the
             // unmasked M sweep needs -- and whatever parked data in wbuf since the last M phase
-            L.wbuf[woff(k, tl[0])] = mweight(gs, q[0][k], inv);
+            L.wbuf[woff(k, tl[0])] = mweight(gs, q[0][k], invp);
             s[k] += gs;
           }
         }
@@ -627,9 +630,16 @@ struct EmKernel {
           g[k] = v;
           den += v;
         }
+        // np.maximum and np.clip keep a NaN (mixture_model_utils.py:43-53), v_max / v_min drop it:
+        // a non-finite class sum (NaN weights, a NaN model) would come out of the clip below as a
+        // clean eps and the fit would report success where the reference's isfinite assert fires
+        // (cacg.py:326-333).  `poison` is 0 for a finite sum and NaN otherwise; it rides on 1/|y|^2
+        // into the M-step weights -> covariance -> PBBSS_ST_NONFINITE (two VALU per frame).
+        const double poison = den - den;
         den = fmax(den, kTiny);  // mixture_model_utils.py:43-47
         const double rden = fast_rcp(den);
         const double sal = (!FINAL && a.saliency) ? a.saliency[(size_t)b * TS + tf + t] : 1.0;
+        const double invp = inv + poison;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
           double gam = g[k] * rden;
@@ -638,6 +648,7 @@ struct EmKernel {
           // an ulp above 1 (the uniform `eps != 0` test cost two 64-bit selects per class)
           if (!FINAL || eps != 0.0) gam = fmin(fmax(gam, eps), 1.0 - eps);
           if constexpr (FINAL) {
+            gam += poison;
             if (ok[f]) {
               size_t idx = ((size_t)b * K + k) * TS + tf + t;
               if (a.out_aff) a.out_aff[idx] = gam;
@@ -660,7 +671,7 @@ struct EmKernel {
             double rqk = fmin(rq[k], 1.0 / (10.0 * kTiny));
             // unmasked for the first frame of a lane: a padding frame writes 0 (gs = 0, inv = 0,
             // rqk finite), which the unmasked M sweep relies on
-            if (f == 0 || inl[f]) L.wbuf[woff(k, tl[f])] = gs * rqk * inv;
+            if (f == 0 || inl[f]) L.wbuf[woff(k, tl[f])] = gs * rqk * invp;
             s[k] += gs;
           }
         }

@@ -433,9 +433,14 @@ struct EmKernel32 {
           g[k] = v;
           den += v;
         }
+        // 0, or NaN for a non-finite class sum: v_max / v_min drop the NaN that np.maximum / np.clip
+        // keep -- it rides on the saliency factor into the weights and the class sums, so that the
+        // covariance turns non-finite and the status says so (cacgmm_em.hpp, same place)
+        const float poison = den - den;
         den = fmaxf(den, kTiny32);  // :43-47
         const float rden = __builtin_amdgcn_rcpf(den);
-        const float sal = (!FINAL && a.saliency) ? (float)a.saliency[(size_t)b * TS + tf + t] : 1.f;
+        const float sal =
+            ((!FINAL && a.saliency) ? (float)a.saliency[(size_t)b * TS + tf + t] : 1.f) + poison;
         float wout[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) {
@@ -444,7 +449,8 @@ struct EmKernel32 {
           // eps = 0 the clip is [0, 1])
           if (!FINAL || eps != 0.f) gam = fminf(fmaxf(gam, eps), 1.f - eps);
           if constexpr (FINAL) {
-            if (ok[f] && a.out_aff) a.out_aff[((size_t)b * K + k) * TS + tf + t] = (double)gam;
+            if (ok[f] && a.out_aff)
+              a.out_aff[((size_t)b * K + k) * TS + tf + t] = (double)(gam + poison);
             wout[k] = 0.f;
           } else {
             const float gs = ok[f] ? gam * sal : 0.f;

@@ -173,9 +173,12 @@ struct TimedRegion {
 // CAN launch such a kernel (`needed`: may_split() for the fused fits, always for the cooperative
 // shared-weight fit and the DHTV solver): plain fits -- no remainder bin, fewer than three
 // iterations, generic-size path, the joint models (their members never wait) -- keep their
-// multi-stream concurrency beside other handles.  Within one process the gate is exact since
-// round 5 (the enqueue of gated launches is serialised, see the constructor); the bounded waits
-// and the host-side repeats remain the safety net for work of OTHER processes on the device.
+// multi-stream concurrency beside other handles.  Within one process the gate orders the GATED
+// launches exactly since round 5 (their enqueue is serialised, see the constructor).  It does
+// not order ungated work: a plain fit, a joint fit or a generic-size fit of another handle can
+// still hold compute units while a gated kernel's members are being placed -- for that case,
+// and for work of OTHER processes on the device, the bounded waits and the host-side repeats
+// remain the safety net.
 struct ResidencyGate {
   static constexpr int kMaxDev = 64;
   struct State {
@@ -208,8 +211,12 @@ struct ResidencyGate {
       return;
     }
     // The device mutex stays held until the destructor has recorded this launch's completion
-    // event: the host-side ENQUEUE of gated launches is serialised (microseconds; the device work
-    // is not waited for), so a second thread always finds the event of the launch in front of it.
+    // event: the host-side ENQUEUE of gated launches is serialised (the device work is not waited
+    // for), so a second thread always finds the event of the launch in front of it.  The lock
+    // spans the entry point's body: normally microseconds, but a body that has to GROW the
+    // handle's workspace (handle_scratch / handle_work: hipDeviceSynchronize + hipFree +
+    // hipMalloc, first call at a larger shape only) does so under the lock, and other threads'
+    // gated calls wait behind it once.
     // (Until round 5 the lock was dropped in between: two threads entering together both waited
     // for the same older event and then ran side by side -- the residual "not co-resident" case
     // of tests/test_gpu_contention.py, about one full-suite run in ten.)
@@ -2197,6 +2204,9 @@ PBBSS_API int pbbss_condition_covariance(pbbss_handle_t h, const void* x, int64_
                                          double gamma, void* out, void* stream) {
   DeviceGuard device_guard(h);
   if (!h || !x || !out || N <= 0 || D <= 0) return PBBSS_ERR_INVALID_ARG;
+  // one thread per entry: the diagonal threads read the whole diagonal of x while their
+  // neighbours store to out -- in place the trace would pick up conditioned entries
+  if (x == out) return PBBSS_ERR_INVALID_ARG;
   return pbbss::launch_condition_covariance(static_cast<const double*>(x), N, D, gamma,
                                             static_cast<double*>(out), as_stream(stream));
 }

@@ -57,6 +57,13 @@ def test_invalid_arguments_return_codes_not_crashes():
     a = torch.zeros((3, 5, 2), dtype=torch.complex128, device='cuda')
     assert lib.pbbss_lcmv(h, _lib.ptr(a), _lib.ptr(a), _lib.ptr(a), 5, 2, 3, _lib.ptr(a), None,
                           stream) == _lib.ERR_INVALID_ARG
+    # condition_covariance works entry by entry: in place is refused, not raced
+    cx = torch.zeros((3, 4, 4), dtype=torch.complex128, device='cuda')
+    co = torch.zeros_like(cx)
+    assert lib.pbbss_condition_covariance(h, _lib.ptr(cx), 3, 4, ctypes.c_double(0.1), _lib.ptr(cx),
+                                          stream) == _lib.ERR_INVALID_ARG
+    assert lib.pbbss_condition_covariance(h, _lib.ptr(cx), 3, 4, ctypes.c_double(0.1), _lib.ptr(co),
+                                          stream) == _lib.OK
     # permutation solvers: K <= 8, metric in range, mapping window inside the output row
     mk = torch.rand((1, 9, 5, 16), dtype=torch.float64, device='cuda')
     mp = torch.zeros((1, 9, 5), dtype=torch.int32, device='cuda')

@@ -387,3 +387,31 @@ def test_remainder_bins_with_partial_last_window(T):
     ref, want = _oracle_fit(Y[sel], init[sel], 5)
     assert engine.split_error() == 0
     assert np.abs(_host(r['affiliation'])[sel] - want).max() < 1e-8
+
+
+def test_nonfinite_posterior_is_reported_for_any_affiliation_eps():
+    """np.maximum / np.clip keep a NaN (mixture_model_utils.py:43-53) and the reference's M-step
+    asserts on the covariance it produces (complex_angular_central_gaussian.py:326-333); the
+    device's v_max / v_min would hand back a clean `eps` -- also for affiliation_eps = 0 since the
+    in-loop clip became unconditional.  A model whose mixture weight is NaN in one bin (finite
+    observation) must fail the same way for both settings, in the float64 and in the packed-FP32
+    kernel."""
+    import dataclasses
+    from oracle import synth
+    from pb_bss_amd.distribution import CACGMMTrainer, utils
+    Y, init = synth.make_stft(5, 80, 4, 2, seed=3)
+    model = CACGMMTrainer().fit(Y, initialization=init, iterations=2)
+    good = CACGMMTrainer().fit(Y, initialization=model, iterations=3, affiliation_eps=0.)
+    assert np.isfinite(good.predict(Y)).all()
+    w = np.array(model.weight, copy=True)
+    w[2] = np.nan
+    bad = dataclasses.replace(model, weight=w)
+    for eps in (0.0, 1e-10):
+        with pytest.raises(AssertionError):
+            CACGMMTrainer().fit(Y, initialization=bad, iterations=3, affiliation_eps=eps)
+    with utils.arithmetic('reference'):
+        for eps in (0.0, 1e-10):
+            with pytest.raises(AssertionError):
+                CACGMMTrainer().fit(Y, initialization=bad, iterations=3, affiliation_eps=eps)
+    # predict hands the NaN posterior out, like the reference
+    assert np.isnan(bad.predict(Y)[2]).all() and np.isfinite(bad.predict(Y)[[0, 1, 3, 4]]).all()
