@@ -484,6 +484,20 @@ int pbbss_log_pdf_to_affiliation(pbbss_handle_t h, const double* log_pdf, int64_
                                  int64_t wn, const uint8_t* activity, double affiliation_eps,
                                  double* out_affiliation, void* stream);
 
+/* log_pdf_to_affiliation_for_integration_models_with_inline_pa                                */
+/* (mixture_model_utils.py:58-130) as a stand-alone step: per bin f the class permutation of   */
+/* the spatial log-pdf (F,K,T) that maximises sum_{k,t} softmax_k(lp)(t) lp_k(t),              */
+/* lp = spatial[perm] + spectral (itertools.permutations order, first strict maximum wins,     */
+/* no weights in the search), then log_pdf_to_affiliation of that sum with the weights         */
+/* (strides as above), the activity mask and the clip.  out_permutation (F,K) int32 or NULL.   */
+/* K <= 6 (PBBSS_ERR_UNSUPPORTED beyond).  The fused joint fits run the same search in-kernel. */
+int pbbss_log_pdf_to_affiliation_inline_pa(pbbss_handle_t h, const double* spatial_log_pdf,
+                                           const double* spectral_log_pdf, int64_t F, int K,
+                                           int64_t T, const double* weight, int64_t wb,
+                                           int64_t wk, int64_t wn, const uint8_t* activity,
+                                           double affiliation_eps, double* out_affiliation,
+                                           int32_t* out_permutation, void* stream);
+
 int pbbss_embed_fit(pbbss_handle_t h, const void* y, int y_is_f64, int64_t B,
                     int64_t N, int E, int K, int kind, int normalize,
                     const double* weights, double min_concentration,

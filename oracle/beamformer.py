@@ -163,6 +163,21 @@ def pca_vector(target_psd):
     return vecs[..., -1].reshape(shape[:-1])
 
 
+def rank_one_estimate(kind, cov, noise_psd=None):
+    """extraction/beamformer_wrapper.py:11-25 ('rank1_pca': get_pca_rank_one_estimate) and :49-69
+    ('rank1_gev': get_gev_rank_one_estimate): a a^H scaled to the trace of `cov`, with a the
+    dominant eigenvector or the GEV ATF estimate Phi_nn w_gev (:28-47)."""
+    if kind == 'rank1_pca':
+        a = pca_vector(cov)
+    elif kind == 'rank1_gev':
+        a = np.einsum('...dD,...D->...d', noise_psd, gev_vector(cov, noise_psd))
+    else:
+        raise ValueError(kind)
+    r1 = np.einsum('...d,...D->...dD', a, a.conj())
+    scale = np.trace(cov, axis1=-1, axis2=-2) / np.trace(r1, axis1=-1, axis2=-2)
+    return scale[..., None, None] * r1
+
+
 def bf_vector(beamformer, target_psd, noise_psd=None, **kw):
     """extraction/beamformer_wrapper.py:117-236 for the cores on the hot path:
     'gev', 'mvdr_souden', 'pca', 'pca+mvdr', 'scaled_gev_atf+mvdr',
@@ -171,15 +186,7 @@ def bf_vector(beamformer, target_psd, noise_psd=None, **kw):
     core = beamformer[:-4] if do_ban else beamformer
 
     def rank1(kind, cov):
-        if kind == 'rank1_pca':
-            a = pca_vector(cov)
-        elif kind == 'rank1_gev':
-            a = np.einsum('...dD,...D->...d', noise_psd, gev_vector(cov, noise_psd))
-        else:
-            raise ValueError(kind)
-        r1 = np.einsum('...d,...D->...dD', a, a.conj())
-        scale = np.trace(cov, axis1=-1, axis2=-2) / np.trace(r1, axis1=-1, axis2=-2)
-        return scale[..., None, None] * r1
+        return rank_one_estimate(kind, cov, noise_psd)
 
     if core == 'pca':
         w = pca_vector(target_psd)

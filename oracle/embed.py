@@ -180,9 +180,11 @@ def _unsqueeze(array, axis):
     return array.reshape(shape)
 
 
-def inline_pa_affiliation(weight, spatial_log_pdf, spectral_log_pdf, affiliation_eps=0.):
+def inline_pa_affiliation(weight, spatial_log_pdf, spectral_log_pdf, affiliation_eps=0.,
+                          source_activity_mask=None):
     """mixture_model_utils.py:58-130 (per-frequency best class permutation of the
-    spatial model against the spectral model)."""
+    spatial model against the spectral model; the activity mask only enters the final
+    posterior, :121-126)."""
     F, K, T = spatial_log_pdf.shape
     out = np.zeros((F, K, T))
     wfull = np.broadcast_to(weight, spatial_log_pdf.shape)
@@ -195,8 +197,10 @@ def inline_pa_affiliation(weight, spatial_log_pdf, spectral_log_pdf, affiliation
             val = np.sum(cand * lp)
             if val > best_val:
                 best, best_val = list(perm), val
-        out[f] = oc.log_pdf_to_affiliation(wfull[f], spatial_log_pdf[f, best, :] + spectral_log_pdf[f],
-                                           affiliation_eps=affiliation_eps)
+        out[f] = oc.log_pdf_to_affiliation(
+            wfull[f], spatial_log_pdf[f, best, :] + spectral_log_pdf[f],
+            source_activity_mask=None if source_activity_mask is None else source_activity_mask[f],
+            affiliation_eps=affiliation_eps)
     return out
 
 

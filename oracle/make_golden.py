@@ -561,12 +561,72 @@ def cacgmm_single_precision_many_classes():
     _save('cacgmm_single_precision_k56', **out)
 
 
+def public_names_cases():
+    """Round 6: the remaining public names of the hot-path modules -- rank-one estimates
+    (beamformer_wrapper.py:11-69), get_single_source_bf_vector (extraction/__init__.py:4), the
+    stand-alone inline-PA posterior (mixture_model_utils.py:58-130), log_pdf_to_affiliation and
+    estimate_mixture_weight called directly (mixture_model_utils.py:7-55, :133-203)."""
+    import pb_bss.extraction as ex
+    from pb_bss.extraction import beamformer_wrapper as bw
+    from pb_bss.distribution import mixture_model_utils as mmu
+    rng = np.random.default_rng(61)
+    F, D, K, T = 11, 4, 3, 50
+
+    def cn(*shape):
+        return rng.standard_normal(shape) + 1j * rng.standard_normal(shape)
+
+    def psd(n):
+        a = cn(n, D, 2 * D)
+        return a @ a.conj().swapaxes(-1, -2) / (2 * D)
+
+    target, noise = psd(F), psd(F) + 0.1 * np.eye(D)
+    spatial = 3.0 * rng.standard_normal((F, K, T))
+    spectral = 3.0 * rng.standard_normal((F, K, T))
+    # make the search matter: per bin a hidden permutation of a common pattern plus noise
+    base = 4.0 * rng.standard_normal((K, T))
+    for f in range(F):
+        spatial[f] += base[rng.permutation(K)]
+        spectral[f] += base
+    weight_k = rng.uniform(0.2, 1.0, size=(K, 1))
+    weight_k /= weight_k.sum()
+    weight_fk = rng.uniform(0.2, 1.0, size=(F, K, 1))
+    weight_fk /= weight_fk.sum(1, keepdims=True)
+    activity = rng.uniform(size=(F, K, T)) > 0.2
+    activity[:, 0] = True
+    aff = rng.uniform(size=(2, F, K, T))
+    aff /= aff.sum(-2, keepdims=True)
+    sal = rng.uniform(0.1, 1.0, size=(2, F, T))
+    _save('public_names_r06',
+          target=target, noise=noise, spatial=spatial, spectral=spectral, weight_k=weight_k,
+          weight_fk=weight_fk, activity=activity, aff=aff, sal=sal,
+          pca_rank1=bw.get_pca_rank_one_estimate(target),
+          gev_rank1=bw.get_gev_rank_one_estimate(target, noise),
+          single_source_gev_ban=ex.get_single_source_bf_vector('gev+ban', target, noise),
+          single_source_rank1=ex.get_single_source_bf_vector('rank1_gev+mvdr_souden', target, noise),
+          inline_pa_k=mmu.log_pdf_to_affiliation_for_integration_models_with_inline_pa(
+              weight_k, spatial, spectral),
+          inline_pa_fk_eps=mmu.log_pdf_to_affiliation_for_integration_models_with_inline_pa(
+              weight_fk, spatial, spectral, affiliation_eps=1e-3),
+          inline_pa_act=mmu.log_pdf_to_affiliation_for_integration_models_with_inline_pa(
+              weight_k, spatial, spectral, source_activity_mask=activity),
+          l2a_k=mmu.log_pdf_to_affiliation(weight_k, spatial),
+          l2a_fk_act_eps=mmu.log_pdf_to_affiliation(weight_fk, spatial, source_activity_mask=activity,
+                                                    affiliation_eps=1e-4),
+          l2a_batched=mmu.log_pdf_to_affiliation(weight_k, np.stack([spatial, spectral])),
+          mixw_n=mmu.estimate_mixture_weight(aff, weight_constant_axis=-1),
+          mixw_fn_sal=mmu.estimate_mixture_weight(aff, saliency=sal, weight_constant_axis=(-3, -1)),
+          mixw_f=mmu.estimate_mixture_weight(aff, weight_constant_axis=(-3,)),
+          mixw_class=mmu.estimate_mixture_weight(aff, weight_constant_axis=-2),
+          mixw_outer=mmu.estimate_mixture_weight(aff, weight_constant_axis=(0, -1)))
+
+
 def main():
     """python -m oracle.make_golden            -> every fixture of the pure-Python reference
     python -m oracle.make_golden f32k56     -> tests/golden/cacgmm_single_precision_k56.npz
     python -m oracle.make_golden f32mask    -> tests/golden/cacgmm_single_precision_mask.npz
     python -m oracle.make_golden f32        -> tests/golden/cacgmm_single_precision_path.npz
     python -m oracle.make_golden joint_cov  -> tests/golden/embed_gcacgmm_{full,diagonal}*.npz
+    python -m oracle.make_golden public_names -> tests/golden/public_names_r06.npz
     python -m oracle.make_golden gev_eig    -> tests/golden/gev_use_eig.npz only (own process:
     the reference's Cython modules must be injected BEFORE pb_bss.extraction.beamformer is
     imported, and the other fixtures are defined as the Cython-less reference's output)."""
@@ -589,6 +649,10 @@ def main():
         refshim.load()
         cacgmm_single_precision_mask_case()
         return
+    if sys.argv[1:] == ['public_names']:
+        refshim.load()
+        public_names_cases()
+        return
     if sys.argv[1:] == ['gev_eig']:
         refshim.load_cython()
         gev_eig_cases()
@@ -605,6 +669,7 @@ def main():
     embed_cases()
     beamformer_extra_cases()
     sampler_cases()
+    public_names_cases()
 
 
 if __name__ == '__main__':

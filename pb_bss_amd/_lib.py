@@ -44,7 +44,7 @@ EXPORTS = (
     'pbbss_comm_unique_id', 'pbbss_comm_create', 'pbbss_comm_destroy', 'pbbss_comm_info',
     'pbbss_shard_bounds',
     'pbbss_allgather_masks', 'pbbss_allgather_unpack', 'pbbss_estimate_mixture_weight',
-    'pbbss_log_pdf_to_affiliation',
+    'pbbss_log_pdf_to_affiliation', 'pbbss_log_pdf_to_affiliation_inline_pa',
     'pbbss_solve', 'pbbss_mvdr_souden', 'pbbss_mvdr', 'pbbss_ban',
     'pbbss_apply_beamforming_vector', 'pbbss_set_timing',
     'pbbss_last_kernel_ms', 'pbbss_kernel_ms_lagged', 'pbbss_set_phase_profile',
@@ -199,6 +199,8 @@ def load():
         lib.pbbss_gev_general.argtypes = [vp, vp, vp, i64, i32, vp, vp, vp, vp]
         lib.pbbss_estimate_mixture_weight.argtypes = [vp, vp, vp, i64, i64, i32, i64, i32, i32, vp, vp]
         lib.pbbss_log_pdf_to_affiliation.argtypes = [vp, vp, i64, i32, i64, vp, i64, i64, i64, vp, dbl, vp, vp]
+        lib.pbbss_log_pdf_to_affiliation_inline_pa.argtypes = [vp, vp, vp, i64, i32, i64, vp, i64, i64, i64, vp,
+                                                               dbl, vp, vp, vp]
         lib.pbbss_comm_unique_id.argtypes = [vp]
         lib.pbbss_comm_create.argtypes = [vp, vp, i32, i32]
         lib.pbbss_comm_destroy.argtypes = [vp]

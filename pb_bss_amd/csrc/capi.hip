@@ -1390,6 +1390,24 @@ PBBSS_API int pbbss_log_pdf_to_affiliation(pbbss_handle_t h, const double* log_p
                                               affiliation_eps, out_affiliation, as_stream(stream));
 }
 
+PBBSS_API int pbbss_log_pdf_to_affiliation_inline_pa(
+    pbbss_handle_t h, const double* spatial_log_pdf, const double* spectral_log_pdf, int64_t F, int K,
+    int64_t T, const double* weight, int64_t wb, int64_t wk, int64_t wn, const uint8_t* activity,
+    double affiliation_eps, double* out_affiliation, int32_t* out_permutation, void* stream) {
+  DeviceGuard device_guard(h);
+  if (!h || !spatial_log_pdf || !spectral_log_pdf || !weight || !out_affiliation || F <= 0 ||
+      T <= 0 || K < 1)
+    return PBBSS_ERR_INVALID_ARG;
+  if (wb < 0 || wk < 0 || wn < 0) return PBBSS_ERR_INVALID_ARG;
+  if (T > 2147483647LL) return PBBSS_ERR_UNSUPPORTED;
+  // the permutation search of the generic-size joint E-step without its M-step half: no
+  // observation, no quadratic forms (K > 6: 5 040+ permutations per bin -- refused)
+  return pbbss::launch_gen_joint_pa(nullptr, 0, F, (int)T, 0, K, spatial_log_pdf, nullptr,
+                                    spectral_log_pdf, 1.0, weight, wb, wk, wn, nullptr,
+                                    affiliation_eps, out_affiliation, nullptr, nullptr,
+                                    as_stream(stream), activity, out_permutation);
+}
+
 PBBSS_API int pbbss_embed_fit(pbbss_handle_t h, const void* y, int y_is_f64, int64_t B, int64_t N,
                               int E, int K, int kind, int normalize, const double* weights,
                               double min_concentration, double max_concentration,

@@ -1228,6 +1228,8 @@ struct GenJointPa {
   double* out_aff;           // (B,K,T)
   double* out_mweight;       // (B,K,T) or null
   int32_t* out_zero;         // (B) or null
+  const uint8_t* activity;   // (B,K,T) source_activity_mask or null (stand-alone entry point)
+  int32_t* out_perm;         // (B,K) chosen permutation or null
 };
 
 __device__ __forceinline__ void pa_nth_permutation(int p, int K, int* perm) {
@@ -1307,15 +1309,20 @@ __global__ void __launch_bounds__(kGenThreads) gen_joint_pa_kernel(GenJointPa a)
   }
   if (tid == 0) pa_nth_permutation(best_p, K, best_perm);
   __syncthreads();
-  const YS* y = static_cast<const YS*>(a.yt) + (size_t)b * D * T * 2;
+  if (a.out_perm && tid < K) a.out_perm[b * K + tid] = best_perm[tid];
+  // yt == null: the stand-alone posterior (pbbss_log_pdf_to_affiliation_inline_pa), no M-step weights
+  const YS* y = a.yt ? static_cast<const YS*>(a.yt) + (size_t)b * D * T * 2 : nullptr;
   for (int t = tid; t < T; t += kGenThreads) {
-    double n2 = 0.0;
-    for (int d = 0; d < D; ++d) {
-      const double re = (double)y[((size_t)d * T + t) * 2], im = (double)y[((size_t)d * T + t) * 2 + 1];
-      n2 += re * re + im * im;
+    double inv = 0.0;
+    if (y) {
+      double n2 = 0.0;
+      for (int d = 0; d < D; ++d) {
+        const double re = (double)y[((size_t)d * T + t) * 2], im = (double)y[((size_t)d * T + t) * 2 + 1];
+        n2 += re * re + im * im;
+      }
+      inv = (n2 > 0.0) ? 1.0 / n2 : 0.0;
+      if (!(n2 > 0.0)) zero_seen = 1;  // benign race: every writer stores 1
     }
-    const double inv = (n2 > 0.0) ? 1.0 / n2 : 0.0;
-    if (!(n2 > 0.0)) zero_seen = 1;  // benign race: every writer stores 1
     double lp[kPaMaxK], mx = -1.79e308;
     for (int k = 0; k < K; ++k) {
       lp[k] = fma(a.spatial_scale, sp[(size_t)best_perm[k] * T + t], ex[(size_t)k * T + t]);
@@ -1324,6 +1331,7 @@ __global__ void __launch_bounds__(kGenThreads) gen_joint_pa_kernel(GenJointPa a)
     double v[kPaMaxK], den = 0.0;
     for (int k = 0; k < K; ++k) {
       v[k] = exp(lp[k] - mx) * a.weight[b * a.wb + k * a.wk + (int64_t)t * a.wt];
+      if (a.activity) v[k] *= (double)a.activity[((size_t)b * K + k) * T + t];  // mmu.py:39-41
       den += v[k];
     }
     den = fmax(den, kTiny);
@@ -1346,10 +1354,11 @@ int launch_gen_joint_pa(const void* yt, int y_is_c128, int64_t B, int T, int D, 
                         const double* lp_spatial, const double* q, const double* extra,
                         double spatial_scale, const double* weight, int64_t wb, int64_t wk,
                         int64_t wt, const double* saliency, double eps, double* out_aff,
-                        double* out_mweight, int32_t* out_zero, hipStream_t s) {
+                        double* out_mweight, int32_t* out_zero, hipStream_t s,
+                        const uint8_t* activity, int32_t* out_perm) {
   if (K < 1 || K > kPaMaxK || B > 2147483647LL) return PBBSS_ERR_UNSUPPORTED;
   GenJointPa a{yt, T, D, K, lp_spatial, q, extra, spatial_scale, weight, wb, wk, wt, saliency, eps,
-               out_aff, out_mweight, out_zero};
+               out_aff, out_mweight, out_zero, activity, out_perm};
   if (y_is_c128)
     hipLaunchKernelGGL(gen_joint_pa_kernel<double>, dim3((unsigned)B), dim3(kGenThreads), 0, s, a);
   else

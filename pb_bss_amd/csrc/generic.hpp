@@ -44,7 +44,8 @@ int launch_gen_joint_pa(const void* yt, int y_is_c128, int64_t B, int T, int D, 
                         const double* lp_spatial, const double* q, const double* extra,
                         double spatial_scale, const double* weight, int64_t wb, int64_t wk,
                         int64_t wt, const double* saliency, double eps, double* out_aff,
-                        double* out_mweight, int32_t* out_zero, hipStream_t s);
+                        double* out_mweight, int32_t* out_zero, hipStream_t s,
+                        const uint8_t* activity = nullptr, int32_t* out_perm = nullptr);
 
 // (B, T, D) -> (B, D, T) copy of the raw observation for the E-steps of the EM loop
 int launch_gen_transpose(const void* y, int y_is_c128, int64_t B, int T, int D, void* out,

@@ -25,7 +25,7 @@ def device_weight(aff, sal, weight_constant_axis, indep):
     """estimate_mixture_weight (mixture_model_utils.py:133-203), reference-shaped (keepdims),
     as a device tensor."""
     from .cacgmm import CACGMMTrainer
-    from .mixture_model_utils import estimate_mixture_weight
+    from .mixture_model_utils import _host_estimate_mixture_weight
     t = _lib.torch()
     nd = len(indep) + 2
     K = aff.shape[-2]
@@ -33,7 +33,7 @@ def device_weight(aff, sal, weight_constant_axis, indep):
         return t.full((K, 1), 1.0 / K, dtype=t.float64, device=aff.device)  # :180-183
     w = CACGMMTrainer._device_weight(aff, sal, weight_constant_axis, indep)
     if w is None:  # axis sets the reduction kernel does not cover (e.g. the class axis in a tuple)
-        w = _lib.to_device(estimate_mixture_weight(
+        w = _lib.to_device(_host_estimate_mixture_weight(
             _lib.to_host(aff), None if sal is None else _lib.to_host(sal), weight_constant_axis),
             t.float64).to(aff.device)
     return w

@@ -30,9 +30,11 @@ from .complex_angular_central_gaussian import (
     _complex_device,
     normalize_observation,
 )
-from .mixture_model_utils import (
+from .mixture_model_utils import (  # noqa: F401  (log_pdf_to_affiliation: the reference re-exports it)
+    _host_estimate_mixture_weight,
     apply_inline_permutation_alignment,
     estimate_mixture_weight,
+    log_pdf_to_affiliation,
 )
 from .utils import (_ProbabilisticModel, as_result, random_affiliation, reference_arithmetic,
                     reference_single, to_single)
@@ -590,10 +592,9 @@ class CACGMMTrainer:
                 weight = self._device_weight(aff, sal_dev, weight_constant_axis, indep)
             if weight is None:  # exotic axis sets: the NumPy formula
                 host_excursion[0] = True
-                weight = _lib.to_device(estimate_mixture_weight(
-                    affiliation=_lib.to_host(aff),
-                    saliency=None if sal_dev is None else _lib.to_host(sal_dev),
-                    weight_constant_axis=weight_constant_axis), t.float64, device=dev)
+                weight = _lib.to_device(_host_estimate_mixture_weight(
+                    _lib.to_host(aff), None if sal_dev is None else _lib.to_host(sal_dev),
+                    weight_constant_axis), t.float64, device=dev)
             masked = aff if sal_dev is None else aff * sal_dev[..., None, :]
             # status words of the M-step: queued like the aligner's, one read-back after the loop
             vec, val, _, st = engine.cacg_m_step(

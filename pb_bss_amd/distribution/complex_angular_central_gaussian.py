@@ -10,6 +10,8 @@ import numpy as np
 
 from .. import _lib, engine
 from .utils import _ProbabilisticModel, as_result
+from .utils import force_hermitian  # noqa: F401  (names the reference module exposes)
+from ..utils import is_broadcast_compatible  # noqa: F401  (names the reference module exposes)
 
 __all__ = [
     'ComplexAngularCentralGaussian',

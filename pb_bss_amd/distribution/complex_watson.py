@@ -14,6 +14,7 @@ import numpy as np
 
 from .. import _lib, engine
 from .utils import _ProbabilisticModel, as_result
+from ..utils import get_pca, is_broadcast_compatible  # noqa: F401  (names the reference module exposes)
 
 __all__ = ['ComplexWatson', 'ComplexWatsonTrainer', 'normalize_observation']
 

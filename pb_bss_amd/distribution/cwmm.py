@@ -17,10 +17,12 @@ import numpy as np
 from .. import _lib, engine
 from .cacgmm import CACGMMTrainer
 from .complex_watson import ComplexWatson, ComplexWatsonTrainer
-from .mixture_model_utils import (
+from .mixture_model_utils import (  # noqa: F401  (re-exported like the reference's cwmm.py)
     apply_inline_permutation_alignment,
     estimate_mixture_weight,
+    log_pdf_to_affiliation,
 )
+from .complex_angular_central_gaussian import normalize_observation  # noqa: F401
 from .utils import _ProbabilisticModel, as_result, random_affiliation
 
 __all__ = ['CWMM', 'CWMMTrainer']

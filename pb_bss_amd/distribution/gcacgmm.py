@@ -17,6 +17,13 @@ from . import _joint
 from .complex_angular_central_gaussian import ComplexAngularCentralGaussian
 from .gaussian import DiagonalGaussian, Gaussian, SphericalGaussian
 from .utils import _ProbabilisticModel, as_result
+from ..utils import unsqueeze  # noqa: F401  (names the reference module exposes)
+from .complex_angular_central_gaussian import ComplexAngularCentralGaussianTrainer  # noqa: F401  (names the reference module exposes)
+from .gaussian import GaussianTrainer  # noqa: F401  (names the reference module exposes)
+from .mixture_model_utils import (  # noqa: F401
+    log_pdf_to_affiliation,
+    log_pdf_to_affiliation_for_integration_models_with_inline_pa,
+)
 
 _KIND = {'spherical': _lib.EMBED_GAUSS_SPHERICAL, 'diagonal': _lib.EMBED_GAUSS_DIAG,
          'full': _lib.EMBED_GAUSS_FULL}

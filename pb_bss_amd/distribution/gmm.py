@@ -17,6 +17,9 @@ import numpy as np
 from .. import _lib, engine
 from .gaussian import DiagonalGaussian, Gaussian, SphericalGaussian
 from .utils import _ProbabilisticModel, as_result, random_affiliation
+from ..utils import labels_to_one_hot  # noqa: F401  (names the reference module exposes)
+from .gaussian import GaussianTrainer  # noqa: F401  (names the reference module exposes)
+from .mixture_model_utils import estimate_mixture_weight, log_pdf_to_affiliation  # noqa: F401  (names the reference module exposes)
 
 __all__ = ['GMM', 'GMMTrainer']
 

@@ -36,6 +36,33 @@ class _ProbabilisticModel:
             f'Close matches: {close}')
 
 
+def get_trainer_class_from_model(parameter):
+    """Model class (or instance) -> its trainer class, by name: `X` -> `XTrainer` looked up in
+    pb_bss_amd.distribution (reference: distribution/utils.py:6-28)."""
+    from .. import distribution
+    cls = parameter if isinstance(parameter, type) else type(parameter)
+    assert 'Trainer' not in cls.__name__, cls.__name__
+    return getattr(distribution, cls.__name__ + 'Trainer')
+
+
+def parameter_from_dict(parameter_class_or_str, d: dict):
+    """Rebuild a model from `model.to_dict()`; the class may be given by name
+    (reference: distribution/utils.py:83-113)."""
+    if isinstance(parameter_class_or_str, str):
+        from .. import distribution
+        parameter_class_or_str = getattr(distribution, parameter_class_or_str)
+    return parameter_class_or_str.from_dict(d)
+
+
+def force_hermitian(matrix):
+    """(A + A^H) / 2 over the last two axes (reference: distribution/utils.py:318-329); NumPy
+    arrays and torch tensors alike."""
+    if _lib.is_torch(matrix):
+        return (matrix + matrix.conj().transpose(-1, -2)) / 2
+    matrix = np.asarray(matrix)
+    return (matrix + np.swapaxes(matrix.conj(), -1, -2)) / 2
+
+
 def stack_parameters(parameters):
     """A list of equally-typed model objects -> ONE model whose every parameter array carries a
     new leading axis (pb_bss/distribution/utils.py:259-316: e.g. the per-utterance `CACGMM`s of a

@@ -14,6 +14,13 @@ from . import _joint
 from .complex_angular_central_gaussian import ComplexAngularCentralGaussian
 from .utils import _ProbabilisticModel, as_result
 from .von_mises_fisher import VonMisesFisher
+from ..utils import unsqueeze  # noqa: F401  (names the reference module exposes)
+from .complex_angular_central_gaussian import ComplexAngularCentralGaussianTrainer  # noqa: F401  (names the reference module exposes)
+from .von_mises_fisher import VonMisesFisherTrainer  # noqa: F401  (names the reference module exposes)
+from .mixture_model_utils import (  # noqa: F401
+    log_pdf_to_affiliation,
+    log_pdf_to_affiliation_for_integration_models_with_inline_pa,
+)
 
 __all__ = ['VMFCACGMM', 'VMFCACGMMTrainer']
 

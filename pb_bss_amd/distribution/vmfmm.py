@@ -14,6 +14,8 @@ import numpy as np
 from .. import _lib, engine
 from .utils import _ProbabilisticModel, as_result, random_affiliation
 from .von_mises_fisher import VonMisesFisher
+from .von_mises_fisher import VonMisesFisherTrainer  # noqa: F401  (names the reference module exposes)
+from .mixture_model_utils import estimate_mixture_weight, log_pdf_to_affiliation  # noqa: F401  (names the reference module exposes)
 
 __all__ = ['VMFMM', 'VMFMMTrainer']
 

@@ -7,6 +7,7 @@ import numpy as np
 
 from .. import _lib, engine
 from .utils import _ProbabilisticModel, as_result
+from ..utils import is_broadcast_compatible  # noqa: F401  (names the reference module exposes)
 
 __all__ = ['VonMisesFisher', 'VonMisesFisherTrainer']
 

@@ -914,6 +914,42 @@ def log_pdf_to_affiliation(log_pdf, weight, activity=None, affiliation_eps=0.):
     return out
 
 
+def _broadcast_weight(weight, shape):
+    """weight -> (contiguous float64 tensor, strides with 0 on singleton axes) against `shape`."""
+    t = _t()
+    w = weight.to(t.float64)
+    while w.ndim < len(shape):
+        w = w.unsqueeze(0)
+    assert w.ndim == len(shape) and all(a in (1, b) for a, b in zip(w.shape, shape)), \
+        (tuple(w.shape), tuple(shape))
+    w = w.contiguous()
+    return w, [0 if w.shape[i] == 1 else w.stride(i) for i in range(w.ndim)]
+
+
+def log_pdf_to_affiliation_inline_pa(spatial_log_pdf, spectral_log_pdf, weight, activity=None,
+                                     affiliation_eps=0., want_permutation=False):
+    """pbbss_log_pdf_to_affiliation_inline_pa: both log-pdfs (F,K,T) f64, weight broadcastable."""
+    t = _t()
+    F, K, T = spatial_log_pdf.shape
+    assert spectral_log_pdf.shape == (F, K, T), (spectral_log_pdf.shape, (F, K, T))
+    if K > 6:
+        raise NotImplementedError(f'inline permutation alignment searches K! permutations per bin: '
+                                  f'K <= 6 is served, got K={K}')
+    w, st = _broadcast_weight(weight, (F, K, T))
+    dev = spatial_log_pdf.device
+    out = t.empty((F, K, T), dtype=t.float64, device=dev)
+    perm = t.empty((F, K), dtype=t.int32, device=dev) if want_permutation else None
+    if activity is not None:
+        assert activity.shape == (F, K, T) and activity.dtype == t.uint8
+    rc = _lib.load().pbbss_log_pdf_to_affiliation_inline_pa(
+        _lib.handle(dev.index), _lib.ptr(spatial_log_pdf.to(t.float64).contiguous()),
+        _lib.ptr(spectral_log_pdf.to(t.float64).contiguous()), F, K, T, _lib.ptr(w), st[0], st[1],
+        st[2], _lib.ptr(activity), float(affiliation_eps), _lib.ptr(out), _lib.ptr(perm),
+        _lib.stream_ptr(dev.index))
+    _lib.check(rc, f'log_pdf_to_affiliation_inline_pa(F={F},K={K},T={T})')
+    return (out, perm) if want_permutation else out
+
+
 def joint_weight_shape(weight_mode, F, K, T):
     return {_lib.JOINT_WEIGHT_FK: (F, K), _lib.JOINT_WEIGHT_UNIFORM: (), _lib.JOINT_WEIGHT_K: (K,),
             _lib.JOINT_WEIGHT_KT: (K, T), _lib.JOINT_WEIGHT_CONST: ()}[weight_mode]

@@ -23,6 +23,7 @@ from .beamformer import (
     stable_solve,
 )
 from .beamformer_wrapper import get_bf_vector
+from .beamformer_wrapper import get_bf_vector as get_single_source_bf_vector  # extraction/__init__.py:4
 
 __all__ = [
     'get_power_spectral_density_matrix', 'get_mvdr_vector_souden',
@@ -32,5 +33,5 @@ __all__ = [
     'get_wmwf_vector', 'get_pca', 'get_mvdr_vector_merl', 'get_lcmv_vector',
     'get_lcmv_vector_souden', 'distortionless_normalization', 'mvdr_snr_postfilter',
     'zero_degree_normalization', 'phase_correction', 'condition_covariance',
-    'apply_online_beamforming_vector',
+    'apply_online_beamforming_vector', 'get_single_source_bf_vector',
 ]

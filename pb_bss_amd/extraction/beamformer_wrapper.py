@@ -9,6 +9,8 @@ variants and 'ch<N>', each optionally followed by '+ban'.
 import numpy as np
 
 from .. import _lib
+from ..utils import labels_to_one_hot  # noqa: F401  (the reference module re-exports it)
+from .beamformer import *  # noqa: F401,F403  (as the reference: beamformer_wrapper.py:4)
 from .beamformer import (
     blind_analytic_normalization,
     get_gev_vector,
@@ -55,6 +57,20 @@ def _gev_atf_vector(covariance_matrix, noise_covariance_matrix, **gev_kwargs):
     return _on_device(run, w, noise_covariance_matrix, w)
 
 
+def get_pca_rank_one_estimate(covariance_matrix, **atf_kwargs):
+    """The covariance as the outer product of its dominant eigenvector, scaled to the
+    covariance's trace (wrapper.py:11-25; Wang et al., "Rank-1 constrained ...", eq. 25-26)."""
+    a = get_pca_vector(covariance_matrix, **atf_kwargs)
+    return _rank_one(_match(covariance_matrix, a), a)
+
+
+def get_gev_rank_one_estimate(covariance_matrix, noise_covariance_matrix, **gev_kwargs):
+    """The covariance as the outer product of the GEV ATF estimate Phi_nn w_gev, scaled to the
+    covariance's trace (wrapper.py:49-69)."""
+    a = _gev_atf_vector(covariance_matrix, noise_covariance_matrix, **gev_kwargs)
+    return _rank_one(_match(covariance_matrix, a), a)
+
+
 def _match(x, like):
     """Bring x to the array family / dtype of `like`."""
     if _lib.is_torch(like):
@@ -72,12 +88,22 @@ def _atf_vector(atf_type, target_psd_matrix, noise_psd_matrix, **atf_kwargs):
 
 def _rank_1_approximation(atf_type, target_psd_matrix, noise_psd_matrix, **atf_kwargs):
     if atf_type == 'rank1_pca':
-        a = get_pca_vector(target_psd_matrix, **atf_kwargs)
-    elif atf_type == 'rank1_gev':
-        a = _gev_atf_vector(target_psd_matrix, noise_psd_matrix, **atf_kwargs)
-    else:
-        raise ValueError(atf_type, 'use either rank1_pca or rank1_gev')
-    return _rank_one(_match(target_psd_matrix, a), a)
+        return get_pca_rank_one_estimate(target_psd_matrix, **atf_kwargs)
+    if atf_type == 'rank1_gev':
+        return get_gev_rank_one_estimate(target_psd_matrix, noise_psd_matrix, **atf_kwargs)
+    raise ValueError(atf_type, 'use either rank1_pca or rank1_gev')
+
+
+def _get_response_vector(source_index, num_sources, epsilon=0.):
+    """One-hot LCMV response vector, floored at `epsilon` (wrapper.py:106-114)."""
+    response = labels_to_one_hot(np.array(source_index), num_sources, dtype=np.float64)
+    return np.clip(response, epsilon, 1.)
+
+
+# the reference's private spellings (wrapper.py:28, :72, :93, :106), for callers that import them
+_get_gev_atf_vector = _gev_atf_vector
+_get_atf_vector = _atf_vector
+_get_rank_1_approximation = _rank_1_approximation
 
 
 # filter stage -> (device function, needs the noise PSD, may be preceded by a rank-1 stage)

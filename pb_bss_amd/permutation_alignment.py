@@ -18,6 +18,24 @@ import numpy as np
 
 from . import _lib, engine
 
+
+def interleave(*lists):
+    """Round-robin over several iterables of unequal length until all are exhausted
+    (reference: permutation_alignment.py:11-38): interleave([1, 2, 3], 'ab') -> 1 a 2 b 3."""
+    import itertools
+    gone = object()
+    for group in itertools.zip_longest(*lists, fillvalue=gone):
+        for item in group:
+            if item is not gone:
+                yield item
+
+
+def sample_random_mapping(K, F, random_state=np.random):
+    """A random class permutation per frequency bin -> (K, F) (reference:
+    permutation_alignment.py:41-51; same draws from `random_state`: one permutation(K) per bin)."""
+    return np.stack([random_state.permutation(K) for _ in range(F)], axis=1)
+
+
 __all__ = ['DHTVPermutationAlignment', 'GreedyPermutationAlignment',
            'OraclePermutationAlignment', 'apply_mapping']
 

@@ -196,3 +196,81 @@ def test_gev_use_eig_singular_noise_raises():
     n[1] = 0
     with pytest.raises(np.linalg.LinAlgError):
         get_gev_vector(t, n, use_eig=True)
+
+
+def test_public_names_match_reference():
+    """The public names added in round 6, on the device, against the unmodified reference's
+    outputs (tests/golden/public_names_r06.npz): get_pca_rank_one_estimate /
+    get_gev_rank_one_estimate (beamformer_wrapper.py:11-69), get_single_source_bf_vector
+    (extraction/__init__.py:4), log_pdf_to_affiliation_for_integration_models_with_inline_pa
+    (mixture_model_utils.py:58-130: pbbss_log_pdf_to_affiliation_inline_pa), and
+    log_pdf_to_affiliation / estimate_mixture_weight called directly with NumPy and with
+    device arrays."""
+    import torch
+    import pb_bss_amd.extraction as ex
+    from pb_bss_amd import _lib, engine
+    from pb_bss_amd.extraction import beamformer_wrapper as bw
+    from pb_bss_amd.distribution import mixture_model_utils as mmu
+    g = load('public_names_r06')
+    at = dict(rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(bw.get_pca_rank_one_estimate(g['target']), g['pca_rank1'], **at)
+    np.testing.assert_allclose(bw.get_gev_rank_one_estimate(g['target'], g['noise']),
+                               g['gev_rank1'], **at)
+    dev = bw.get_gev_rank_one_estimate(_lib.to_device(g['target']), _lib.to_device(g['noise']))
+    assert dev.is_cuda
+    np.testing.assert_allclose(_lib.to_host(dev), g['gev_rank1'], **at)
+    assert ex.get_single_source_bf_vector is ex.get_bf_vector
+    w = ex.get_single_source_bf_vector('gev+ban', g['target'], g['noise'])
+    assert np.abs(cos_sim(w, g['single_source_gev_ban']) - 1).max() < 1e-9
+    np.testing.assert_allclose(np.linalg.norm(w, axis=-1),
+                               np.linalg.norm(g['single_source_gev_ban'], axis=-1), rtol=1e-8)
+    np.testing.assert_allclose(
+        ex.get_single_source_bf_vector('rank1_gev+mvdr_souden', g['target'], g['noise']),
+        g['single_source_rank1'], rtol=1e-7, atol=1e-9)
+    f = mmu.log_pdf_to_affiliation_for_integration_models_with_inline_pa
+    np.testing.assert_allclose(f(g['weight_k'], g['spatial'], g['spectral']), g['inline_pa_k'], **at)
+    np.testing.assert_allclose(f(g['weight_fk'], g['spatial'], g['spectral'], affiliation_eps=1e-3),
+                               g['inline_pa_fk_eps'], **at)
+    np.testing.assert_allclose(f(g['weight_k'], g['spatial'], g['spectral'],
+                                 source_activity_mask=g['activity']), g['inline_pa_act'], **at)
+    out = f(_lib.to_device(g['weight_k']), _lib.to_device(g['spatial']), _lib.to_device(g['spectral']))
+    assert out.is_cuda and out.dtype == torch.float64
+    np.testing.assert_allclose(_lib.to_host(out), g['inline_pa_k'], **at)
+    # the chosen permutations: exact against an exhaustive host search on the same log-pdfs
+    import itertools
+    _, perm = engine.log_pdf_to_affiliation_inline_pa(
+        _lib.to_device(g['spatial']), _lib.to_device(g['spectral']), _lib.to_device(g['weight_k']),
+        want_permutation=True)
+    perm = _lib.to_host(perm)
+    K = g['spatial'].shape[1]
+    for b in range(g['spatial'].shape[0]):
+        best, best_val = None, -np.inf
+        for p in itertools.permutations(range(K)):
+            lp = g['spatial'][b, list(p)] + g['spectral'][b]
+            c = np.exp(lp - lp.max(0))
+            val = np.sum(c / c.sum(0) * lp)
+            if val > best_val:
+                best, best_val = p, val
+        assert tuple(perm[b]) == best, (b, perm[b], best)
+    with pytest.raises(NotImplementedError):
+        f(np.full((7, 1), 1 / 7), np.zeros((2, 7, 5)), np.zeros((2, 7, 5)))
+    # log_pdf_to_affiliation / estimate_mixture_weight as public device steps
+    np.testing.assert_allclose(mmu.log_pdf_to_affiliation(g['weight_k'], g['spatial']), g['l2a_k'], **at)
+    np.testing.assert_allclose(
+        mmu.log_pdf_to_affiliation(g['weight_fk'], g['spatial'], source_activity_mask=g['activity'],
+                                   affiliation_eps=1e-4), g['l2a_fk_act_eps'], **at)
+    np.testing.assert_allclose(
+        mmu.log_pdf_to_affiliation(g['weight_k'], np.stack([g['spatial'], g['spectral']])),
+        g['l2a_batched'], **at)
+    for key, kw in (('mixw_n', dict(weight_constant_axis=-1)),
+                    ('mixw_fn_sal', dict(saliency=g['sal'], weight_constant_axis=(-3, -1))),
+                    ('mixw_f', dict(weight_constant_axis=(-3,))),
+                    ('mixw_class', dict(weight_constant_axis=-2)),
+                    ('mixw_outer', dict(weight_constant_axis=(0, -1)))):
+        got = mmu.estimate_mixture_weight(g['aff'], **kw)
+        assert got.shape == g[key].shape, (key, got.shape, g[key].shape)
+        np.testing.assert_allclose(got, g[key], **at)
+    wdev = mmu.estimate_mixture_weight(_lib.to_device(g['aff']), weight_constant_axis=(-3,))
+    assert wdev.is_cuda
+    np.testing.assert_allclose(_lib.to_host(wdev), g['mixw_f'], **at)
+

