@@ -1577,6 +1577,14 @@ static int embed_mixture_fit(pbbss_handle_t h, int kind, const void* y, int64_t 
         if ((rc0 = copy_d2d(out_weight, in_weight, (size_t)B * K * 8, s)) != PBBSS_OK) return rc0;
       }
       TimedRegion tr(h, s);
+      const int rc2 = pbbss::launch_vmf_bin_em2(
+          y, o->embedding_is_f64, B, N, E, K, o->iterations, gamma0, saliency,
+          has_model ? out_mean : nullptr, has_model ? out_scale : nullptr,
+          has_model ? out_weight : nullptr, o->min_concentration, o->max_concentration,
+          o->weight_mode, out_mean, out_scale, out_weight,
+          (o->final_predict && out_affiliation) ? out_affiliation : nullptr, h->cfg.lds_limit,
+          h->cfg.num_cu > 0 ? h->cfg.num_cu : 256, s);
+      if (rc2 != PBBSS_ERR_UNSUPPORTED) return rc2;
       return pbbss::launch_vmf_bin_em(
           y, o->embedding_is_f64, B, N, E, K, o->iterations, gamma0, saliency,
           has_model ? out_mean : nullptr, has_model ? out_scale : nullptr,

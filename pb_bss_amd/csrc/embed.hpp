@@ -87,6 +87,17 @@ int launch_vmf_bin_em(const void* y, int y_is_f64, int64_t B, int64_t N, int E, 
                       double cmin, double cmax, int weight_mode, double* mean, double* conc,
                       double* weight, double* out_aff, size_t lds_limit, hipStream_t s);
 
+// Round-6 kernel for the same job at E <= 16 features, 2 <= K <= 4 classes (vmf_bin.hip: feature
+// count as a template parameter, E and M in one sweep with lane = row, class means as DPP
+// operands, eight wavefronts per mixture).  PBBSS_ERR_UNSUPPORTED: shape not served, take
+// launch_vmf_bin_em.
+int launch_vmf_bin_em2(const void* y, int y_is_f64, int64_t B, int64_t N, int E, int K,
+                       int iterations, const double* gamma, const double* sal,
+                       const double* in_mean, const double* in_conc, const double* in_weight,
+                       double cmin, double cmax, int weight_mode, double* mean, double* conc,
+                       double* weight, double* out_aff, size_t lds_limit, int num_cu,
+                       hipStream_t s);
+
 // Rotated joint loop (round 4): ONE pass over the row-major embedding (F*T, E) per EM iteration of
 // GCACGMM (spherical) / VMFCACGMM.  launch_joint_sweep: posteriors of every point from the
 // spatial quadratic forms Q (F,K,T) + ln det B (F,K) (written by the spatial kernel,

@@ -103,10 +103,15 @@ def test_vmfmm_shapes_against_oracle(N, E, K):
 
 @pytest.mark.parametrize('B,N,E,K,dtype,uniform', [
     (20, 300, 10, 3, np.float32, False), (257, 800, 12, 3, np.float32, False),
-    (33, 257, 7, 2, np.float64, True), (16, 1200, 40, 5, np.float32, False)])
+    (33, 257, 7, 2, np.float64, True), (16, 1200, 40, 5, np.float32, False),
+    # round-6 kernel (vmf_bin.hip): four waves (<= 4 chunks), 64 accumulators with more
+    # mixtures than compute units (four waves), float64 rows at six waves, one chunk only
+    (40, 200, 4, 4, np.float32, False), (300, 500, 14, 3, np.float32, True),
+    (260, 330, 12, 2, np.float64, False), (17, 50, 16, 2, np.float32, False)])
 def test_vmfmm_many_small_mixtures_persistent_kernel(B, N, E, K, dtype, uniform):
     """B >= 16 independent mixtures (one per frequency bin in BASELINE configs[3]) run in the
-    persistent one-workgroup-per-mixture kernel (embed.hip: vmf_bin_em_kernel): whole EM loop in
+    persistent one-workgroup-per-mixture kernels (vmf_bin.hip: vmf_bin_em2_kernel for E <= 16
+    features and 2 <= K <= 4 classes, embed.hip: vmf_bin_em_kernel otherwise): whole EM loop in
     one launch, model in LDS -- against the oracle's reference loop, with saliency, uniform
     weights, float64 input and the predict of the fitted model (iterations = 0 path)."""
     from pb_bss_amd.distribution import VMFMMTrainer
