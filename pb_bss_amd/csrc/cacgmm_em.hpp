@@ -789,16 +789,20 @@ struct EmKernel {
     }
   }
 
+  // c_begin / c_end: the chunks [c_begin, c_end) of the frame arrays only (c_end < 0: all of
+  // them) and cpack_out: where the packed sums go (null: L.cpack) -- the eight-wave Watson kernel
+  // splits the frames of a bin over two groups of four waves and adds the two partial arrays
   template <int W>
-  static __device__ void phase_m(const EmArgs& a, const Lds& L, int lane) {
+  static __device__ void phase_m(const EmArgs& a, const Lds& L, int lane, int c_begin = 0,
+                                 int c_end = -1, double* cpack_out = nullptr) {
     lane = opaque(lane);
     double acc[NACC];
     // One trip = one chunk of 64 frames, lane = frame, whole chunks only: the padding frames of
     // the last chunk carry w = 0 and y = 0.  The lane's addresses advance by one chunk per trip;
     // the planes of a chunk (channel pairs, classes) sit at compile-time offsets.  The first
     // trip initialises the accumulators with products instead of adding to zeros.
-    const YS* yp = L.ybuf + (size_t)lane * 4;
-    const double* wp = L.wbuf + lane;
+    const YS* yp = L.ybuf + (size_t)lane * 4 + (size_t)c_begin * (DP * kFC * 4);
+    const double* wp = L.wbuf + lane + (size_t)c_begin * (K * kFC);
     // raw frame + weights of one chunk: loaded one trip ahead of their use (PBBSS_M_PREFETCH), so
     // that the LDS round trip of chunk c + 1 hides behind the 96 FMAs of chunk c
     struct Raw {
@@ -867,7 +871,7 @@ struct EmKernel {
                     : (int)((kMap.pcode[W] >> (5 * ((sl - NDW) >> 1))) & 31) < NOFF);
       if constexpr (!used) acc[x] = 0.0;
     });
-    const int nchunk = padded_frames(a.T) >> 6;  // >= 1
+    const int nchunk = (c_end < 0 ? (padded_frames(a.T) >> 6) : c_end) - c_begin;  // >= 1
 #if PBBSS_M_PREFETCH
     {
       // two buffers, ping-pong (no copies): the loads of chunk c + 1 are in flight while chunk c
@@ -925,8 +929,9 @@ struct EmKernel {
     // read-out) unpack with pair_index()
     if ((lane & 3) == 0) {
       const unsigned short* tab = L.wbtab + (W * 16 + ((lane >> 2) & 15)) * kWbR;
+      double* dst = cpack_out ? cpack_out : L.cpack;
 #pragma unroll
-      for (int m = 0; m < kWbR; ++m) L.cpack[tab[m]] = acc[m];
+      for (int m = 0; m < kWbR; ++m) dst[tab[m]] = acc[m];
     }
 #ifdef PBBSS_PHASE_PROFILE
     if (a.prof && lane == 0 && W == 0) {

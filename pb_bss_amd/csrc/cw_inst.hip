@@ -1,5 +1,6 @@
 // Complex-Watson mixture EM kernels, one translation unit per sensor count D
 // (compiled with -DPBBSS_EM_D=<D>), like em_inst.hip.
+#include <cstdlib>
 #include "cwmm.hpp"
 #include "em_launch.hpp"
 
@@ -31,6 +32,27 @@ static int cw_launch_variant(WatsonArgs wa, const EmLaunchCfg& cfg, hipStream_t 
     if (!wa.em.scratch) return PBBSS_ERR_HIP;
   }
   hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(kEmThreads), lds, stream, wa);
+  return hipGetLastError() == hipSuccess ? PBBSS_OK : PBBSS_ERR_HIP;
+}
+
+// Eight wavefronts per bin (cwmm.hpp: WatsonWide) for a launch in which every bin has a compute
+// unit of its own: two wavefronts per SIMD instead of one.  PBBSS_ERR_UNSUPPORTED: not served.
+template <int K, typename YS>
+static int cw_launch_wide(const WatsonArgs& wa, const EmLaunchCfg& cfg, hipStream_t stream) {
+  using Kern = WatsonWide<PBBSS_EM_D, K, YS>;
+  static const bool off = [] {  // development knob: PBBSS_CW_WIDE=0 keeps the four-wave kernel
+    const char* v = getenv("PBBSS_CW_WIDE");
+    return v && v[0] == '0';
+  }();
+  const EmArgs& a = wa.em;
+  if (off || a.B > cfg.num_cu || a.T <= 4 * kWave || a.wt != 0) return PBBSS_ERR_UNSUPPORTED;
+  const size_t lds = Kern::lds_bytes(a.T);
+  if (lds > cfg.lds_limit) return PBBSS_ERR_UNSUPPORTED;
+  auto kfn = cwmm_em_wide_kernel<PBBSS_EM_D, K, YS>;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return PBBSS_ERR_HIP;
+  hipLaunchKernelGGL(kfn, dim3((unsigned)a.B), dim3(2 * kEmThreads), lds, stream, wa);
   return hipGetLastError() == hipSuccess ? PBBSS_OK : PBBSS_ERR_HIP;
 }
 
@@ -134,11 +156,16 @@ static int cw_launch_one(const WatsonArgs& wa, const EmLaunchCfg& cfg, hipStream
                      a.B > cfg.num_cu && a.B <= 3 * (int64_t)cfg.num_cu && r >= 1 &&
                      r <= kSplitMaxProblems && a.T >= 2 * cfg.split_window && a.wt == 0 &&
                      slab_need <= cfg.xbuf_bytes;
-  if (!split) return cw_launch_variant<K, YS, false>(wa, cfg, stream);
+  if (!split) {
+    const int rcw = cw_launch_wide<K, YS>(wa, cfg, stream);
+    if (rcw != PBBSS_ERR_UNSUPPORTED) return rcw;
+    return cw_launch_variant<K, YS, false>(wa, cfg, stream);
+  }
   WatsonArgs main_wa = wa;
   main_wa.em.B = a.B - r;
   if (hipEventRecord(cfg.ev_fork, stream) != hipSuccess) return PBBSS_ERR_HIP;
-  int rc = cw_launch_variant<K, YS, false>(main_wa, cfg, stream);
+  int rc = cw_launch_wide<K, YS>(main_wa, cfg, stream);
+  if (rc == PBBSS_ERR_UNSUPPORTED) rc = cw_launch_variant<K, YS, false>(main_wa, cfg, stream);
   if (rc != PBBSS_OK) return rc;
   rc = cw_launch_split<K, YS>(wa, a.B - r, (int)r, cfg);
   if (rc != PBBSS_OK) return rc;

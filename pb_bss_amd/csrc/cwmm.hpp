@@ -66,7 +66,7 @@ __device__ __forceinline__ double log_hyp1f1_1_D(double kappa) {
     term *= kappa * (1.0 / (double)r);
     ssum += term;
   });
-  return ln_factorial(D - 1) - (double)(D - 1) * log(kappa) + kappa + log1p(-exp(-kappa) * ssum);
+  return ln_factorial(D - 1) - (double)(D - 1) * log(kappa) + kappa + log1p(-exp_nonpos(-kappa) * ssum);
 }
 
 // ln c(kappa) as complex_watson.py:157-168
@@ -161,7 +161,7 @@ __device__ __forceinline__ double watson_concentration(const WatsonArgs& a, cons
 #pragma unroll
     for (int j = k; j >= r; --j) {
       const double tl = tk[j - 1], tr = tk[j + 2 - r];  // indices relative to i - 1
-      double alpha = (ev - tl) / (tr - tl);
+      double alpha = (ev - tl) * fast_rcp(tr - tl);  // distinct knots: a finite normal difference
       d[j] = (1.0 - alpha) * d[j - 1] + alpha * d[j];
     }
   }
@@ -180,10 +180,13 @@ struct WatsonKernel {
   // w_kt: frame-varying weights (K, T) of the problem's group (weight_constant_axis (-3,)) or null
   // (the per-class weights in LDS); pub_kt: !FINAL -- the masked affiliations (K, T) of this
   // problem for the group's reduction (WatsonShared)
-  template <bool FINAL>
+  // NT: threads that share the frames of the bin (kEmThreads; 2 kEmThreads in WatsonWide, where
+  // `tid` / `wave` run over both halves of the workgroup); red_out: [NT / 64][K] class sums of the
+  // waves (null: L.red)
+  template <bool FINAL, int NT = kEmThreads>
   static __device__ void phase_e(const WatsonArgs& wa, const Lds& L, int64_t b, int tid, int wave,
                                  int lane, int tf = 0, const double* w_kt = nullptr,
-                                 double* pub_kt = nullptr) {
+                                 double* pub_kt = nullptr, double* red_out = nullptr) {
     tid = opaque(tid);
     lane = opaque(lane);
     const EmArgs& a = wa.em;
@@ -191,7 +194,7 @@ struct WatsonKernel {
     double s[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) s[k] = 0.0;
-    for (int t0 = 0; t0 < a.T; t0 += kEmThreads) {
+    for (int t0 = 0; t0 < a.T; t0 += NT) {
       // the wave's 64 frames are one chunk of the frame arrays (cacgmm_em.hpp: Lds); beyond the
       // padded frame count there is nothing (wave-uniform exit: later passes lie further out)
       if (t0 + wave * kWave >= Base::padded_frames(a.T)) break;
@@ -214,10 +217,12 @@ struct WatsonKernel {
         const double w = w_kt ? __hip_atomic_load(w_kt + (size_t)k * TS + tf + t, __ATOMIC_RELAXED,
                                                   __HIP_MEMORY_SCOPE_AGENT)
                               : L.wgt[k];
-        g[k] = exp(lp[k] - mx) * w;  // mixture_model_utils.py:32-37
+        g[k] = exp_nonpos(lp[k] - mx) * w;  // mixture_model_utils.py:32-37
         den += g[k];
       }
-      const double rden = 1.0 / fmax(den, kTiny);
+      // one Newton-refined reciprocal (~1 ulp) instead of an IEEE division; a non-finite class
+      // sum stays visible (np.maximum keeps the NaN that v_max drops: den - den is 0 or NaN)
+      const double rden = fast_rcp(fmax(den, kTiny)) + (den - den);
       const double sal = (!FINAL && a.saliency) ? a.saliency[(size_t)b * TS + tf + t] : 1.0;
 #pragma unroll
       for (int k = 0; k < K; ++k) {
@@ -240,7 +245,7 @@ struct WatsonKernel {
         }
       }
     }
-    if constexpr (!FINAL) wave_class_sums<K>(s, lane, L.red + wave * K);
+    if constexpr (!FINAL) wave_class_sums<K>(s, lane, (red_out ? red_out : L.red) + wave * K);
   }
 
   // affiliation initialisation -> M-step weights (cwmm.py:162-163 with saliency)
@@ -327,6 +332,9 @@ struct WatsonKernel {
     const EmArgs& a = wa.em;
     const LaneIJ c = lane_ij(lane);
     const bool valid = c.i < D && c.j < D;
+    // covariance entry of this lane first: its LDS round trip overlaps the class sums below
+    double are = 0.0, aim = 0.0;
+    if (valid) Base::cov_entry(L, k, c.i, c.j, are, aim);
     double S = 0.0, tot = 0.0;
 #pragma unroll
     for (int kk = 0; kk < K; ++kk) {
@@ -336,26 +344,16 @@ struct WatsonKernel {
       tot += fabs(sk);
       S = (kk == k) ? sk : S;
     }
-    if (lane == 0 && a.weight_mode < PBBSS_WEIGHT_SHARED_K) {  // shared weights: WatsonShared
-      double wnew;
-      if (a.weight_mode == PBBSS_WEIGHT_UNIFORM) {
-        wnew = 1.0 / K;
-      } else {
-        // the reference always passes a saliency (ones by default, cwmm.py:134-135):
-        // L1-normalised weighted sums (mixture_model_utils.py:192-201)
-        wnew = S / ((tot == 0.0) ? 1e-10 : tot);
-      }
-      L.wgt[k] = wnew;
-    }
-    double are = 0.0, aim = 0.0;
     if (valid) {
-      const double scale = 1.0 / S;  // complex_watson.py:311 (no floor in the reference)
-      Base::cov_entry(L, k, c.i, c.j, are, aim);
+      // complex_watson.py:311 (no floor in the reference).  A normal S takes the Newton-refined
+      // reciprocal (~1 ulp; the IEEE division was ~30 dependent instructions at the head of the
+      // class's serial chain), anything else -- zero, denormal, non-finite -- the division
+      const double scale = (fabs(S) > 1e-300 && fabs(S) < 1e300) ? fast_rcp(S) : 1.0 / S;
       are *= scale;
       aim *= scale;
     }
     int st = 0;
-    if (wave_or((isfinite(are) && isfinite(aim)) ? 0 : 1)) st |= PBBSS_ST_NONFINITE;
+    if (__ballot(!(isfinite(are) && isfinite(aim))) != 0ull) st |= PBBSS_ST_NONFINITE;
     double lmax = 0.0, mre_i = 0.0, mim_i = 0.0;
     bool fast = false;
     if (warm && !(st & PBBSS_ST_NONFINITE) && !a.force_eig) {
@@ -401,7 +399,17 @@ struct WatsonKernel {
       }
       if (lane == 0 && wa.out_conc) wa.out_conc[(size_t)b * K + k] = kappa;
     }
-    if (lane == 0) L.status[k] |= st;
+    if (lane == 0) {
+      L.status[k] |= st;
+      // the new mixture weight: off the head of the serial chain (one lane's division used to sit
+      // in front of the eigenpair), nothing in this phase reads it
+      if (a.weight_mode < PBBSS_WEIGHT_SHARED_K) {  // shared weights: WatsonShared
+        // the reference always passes a saliency (ones by default, cwmm.py:134-135):
+        // L1-normalised weighted sums (mixture_model_utils.py:192-201)
+        L.wgt[k] = (a.weight_mode == PBBSS_WEIGHT_UNIFORM) ? 1.0 / K
+                                                           : S / ((tot == 0.0) ? 1e-10 : tot);
+      }
+    }
   }
 
   static __device__ void prep_from_model(const WatsonArgs& wa, const Lds& L, int64_t b, int k,
@@ -453,20 +461,28 @@ struct WatsonKernel {
       double pvre = 0.0, pvim = 0.0;  // previous eigenvectors of class `wave` (K <= 4 <= waves)
       SplineWin win;                  // this class's window of the concentration spline
       for (int it = 0; it < a.iterations; ++it) {
-        if (it > 0 || model_in) {
+#ifdef PBBSS_CW_DBG
+        const bool dbg_on = it > 2 && it < a.iterations - 1;
+#define PBBSS_CW_SKIP(bit) (dbg_on && (PBBSS_CW_DBG & (bit)))
+#else
+#define PBBSS_CW_SKIP(bit) false
+#endif
+        if ((it > 0 || model_in) && !PBBSS_CW_SKIP(4)) {
           phase_e<false>(wa, L, b, tid, wave, lane);
           __syncthreads();
         }
+        if (!PBBSS_CW_SKIP(2)) {
         switch (wave) {
           case 0: Base::template phase_m<0>(a, L, lane); break;
           case 1: Base::template phase_m<1>(a, L, lane); break;
           case 2: Base::template phase_m<2>(a, L, lane); break;
           default: Base::template phase_m<3>(a, L, lane); break;
         }
+        }
         __syncthreads();
         const bool last = (it == a.iterations - 1);
         static_assert(K <= kEmWaves, "one class per wave: the warm start lives in its registers");
-        if (wave < K)
+        if (wave < K && !PBBSS_CW_SKIP(1))
           factor_class(wa, L, knot1, jtab, b, wave, lane, last, it > 0, pvre, pvim, win);
         __syncthreads();
       }
@@ -478,6 +494,104 @@ struct WatsonKernel {
     }
   }
 };
+
+// EIGHT wavefronts per bin (round 6).  BASELINE configs[3] has 257 bins for 256 compute units: one
+// workgroup per CU, one wavefront per SIMD, and every phase of the four-wave kernel runs at the
+// latency of its dependent instruction chains (s_memtime per phase, profiles/r06_d_watson_phases.txt:
+// 5.8 cycles per issued instruction in E and M).  Here the frames of a bin are shared by two
+// groups of four waves -- two wavefronts per SIMD that interleave:
+//   E   chunk c of 64 frames belongs to wave c mod 8 (phase_e<.., 2 kEmThreads>)
+//   M   group g accumulates its half of the chunks for the same four entry sets (phase_m with a
+//       chunk range); group 1 writes its packed sums to a second array, a 108-element add merges
+//   F   unchanged: wave k < K factors class k from the merged sums.
+// One more workgroup barrier per iteration (the merge).  Used for the main launch when every
+// bin has a compute unit of its own (cw_inst.hip); remainder bins stay with the split groups,
+// spilled frames and shared weights with the four-wave kernels.
+template <int D, int K, typename YS>
+struct WatsonWide {
+  using W = WatsonKernel<D, K, YS, false>;
+  using Base = typename W::Base;
+  using Lds = typename W::Lds;
+  static constexpr int NT = 2 * kEmThreads;
+  static constexpr int NA = Base::NA;
+
+  // Base arrays | knot table | Jacobi table | second packed-sum array (a whole small block: the
+  // write-back table addresses its padding sink relative to the array) | class sums of 8 waves
+  static __host__ __device__ size_t lds_bytes(int T) {
+    return W::lds_bytes(T) + ((Base::small_bytes() + 15) & ~(size_t)15) + 2 * kEmWaves * K * sizeof(double);
+  }
+
+  static __device__ void run(const WatsonArgs& wa, char* smem) {
+    const EmArgs& a = wa.em;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int grp = wave >> 2, wv = wave & 3;
+    const Lds L = Base::carve(smem, a.T, nullptr);
+    double* knot1 = reinterpret_cast<double*>(smem + Base::lds_bytes(a.T));
+    uint32_t* jtab = reinterpret_cast<uint32_t*>(knot1 + kWatsonKnotTable);
+    char* extra = smem + W::lds_bytes(a.T);
+    double* cpack2 = reinterpret_cast<double*>(extra);
+    double* red8 = reinterpret_cast<double*>(extra + ((Base::small_bytes() + 15) & ~(size_t)15));
+    if (wave == 0) jacobi_table_build<D>(jtab, lane);  // visible after the loop's first barrier
+    if (tid < kWatsonKnotTable && wa.spline_t && wa.n_coef > 2) {  // predict carries no spline
+      const int S = (wa.n_coef - 2 + kWatsonKnotTable - 1) / kWatsonKnotTable;
+      knot1[tid] = wa.spline_t[min(2 + tid * S, wa.n_coef - 1)];
+    }
+    const int nchunk = Base::padded_frames(a.T) >> 6;
+    const int csplit = (nchunk + 1) >> 1;  // group 0: chunks [0, csplit), group 1: the rest (>= 1)
+    const int64_t b = blockIdx.x;          // one workgroup per problem
+    if (tid < K) L.status[tid] = 0;
+    if (tid == 0) *L.flags = 0;
+    __syncthreads();
+    if (grp == 0) Base::phase_load(a, L, b, tid);
+    __syncthreads();
+    const bool model_in = (a.gamma0 == nullptr);
+    if (grp == 0) {
+      if (model_in) {
+        for (int k = wave; k < K; k += kEmWaves) W::prep_from_model(wa, L, b, k, lane);
+      } else {
+        W::phase_init_gamma(a, L, b, tid, wave, lane);  // class sums -> L.red
+      }
+    }
+    __syncthreads();
+    double pvre = 0.0, pvim = 0.0;  // previous eigenvectors of class `wave` (waves 0 .. K-1)
+    SplineWin win;
+    for (int it = 0; it < a.iterations; ++it) {
+      const bool e_ran = (it > 0 || model_in);
+      if (e_ran) {
+        W::template phase_e<false, NT>(wa, L, b, tid, wave, lane, 0, nullptr, nullptr, red8);
+        __syncthreads();
+      }
+      switch (wv) {
+        case 0: Base::template phase_m<0>(a, L, lane, grp ? csplit : 0, grp ? nchunk : csplit, grp ? cpack2 : nullptr); break;
+        case 1: Base::template phase_m<1>(a, L, lane, grp ? csplit : 0, grp ? nchunk : csplit, grp ? cpack2 : nullptr); break;
+        case 2: Base::template phase_m<2>(a, L, lane, grp ? csplit : 0, grp ? nchunk : csplit, grp ? cpack2 : nullptr); break;
+        default: Base::template phase_m<3>(a, L, lane, grp ? csplit : 0, grp ? nchunk : csplit, grp ? cpack2 : nullptr); break;
+      }
+      __syncthreads();
+      // merge: packed sums of the two groups, class sums of the eight waves (a wave beyond the
+      // last chunk wrote zeros)
+      for (int i = tid; i < K * NA; i += NT) L.cpack[i] += cpack2[i];
+      if (e_ran && tid < kEmWaves * K) L.red[tid] = red8[tid] + red8[tid + kEmWaves * K];
+      __syncthreads();
+      const bool last = (it == a.iterations - 1);
+      if (wave < K) W::factor_class(wa, L, knot1, jtab, b, wave, lane, last, it > 0, pvre, pvim, win);
+      __syncthreads();
+    }
+    if (tid < K) {
+      if (a.out_weight && a.iterations > 0) a.out_weight[(size_t)b * K + tid] = L.wgt[tid];
+      if (a.out_status) a.out_status[(size_t)b * K + tid] = L.status[tid];
+    }
+    if (a.final_predict) W::template phase_e<true, NT>(wa, L, b, tid, wave, lane);
+  }
+};
+
+template <int D, int K, typename YS>
+__global__ void __launch_bounds__(2 * kEmThreads, 2) cwmm_em_wide_kernel(WatsonArgs wa) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  WatsonWide<D, K, YS>::run(wa, smem);
+}
 
 template <int D, int K, typename YS, bool SPILL>
 __global__ void __launch_bounds__(kEmThreads, em_waves_per_simd(K)) cwmm_em_kernel(WatsonArgs wa) {

@@ -373,6 +373,32 @@ __device__ __forceinline__ double fast_rsqrt(double x) {
   return y;
 }
 
+// exp(x) for x <= 0 (a max-shifted log-pdf): n = rint(x / ln 2), r = x - n ln 2 in two pieces,
+// degree-12 Taylor polynomial on |r| <= 0.347 (truncation 1.7e-16), scaled by 2^n with v_ldexp
+// (gradual underflow like libm's).  ~19 VALU instructions against the ~40 of the library call
+// with its special-case handling; NaN propagates, and the lower clamp (written as a select so
+// that a NaN survives it) keeps -inf away from the inf - inf of the range reduction.
+__device__ __forceinline__ double exp_nonpos(double x) {
+  x = (x < -800.0) ? -800.0 : x;
+  const double n = __builtin_rint(x * 1.4426950408889634);
+  double r = fma(-n, 0.6931471805599453094, x);
+  r = fma(-n, 2.3190468138462996e-17, r);
+  double p = 1.0 / 479001600.0;
+  p = fma(p, r, 1.0 / 39916800.0);
+  p = fma(p, r, 1.0 / 3628800.0);
+  p = fma(p, r, 1.0 / 362880.0);
+  p = fma(p, r, 1.0 / 40320.0);
+  p = fma(p, r, 1.0 / 5040.0);
+  p = fma(p, r, 1.0 / 720.0);
+  p = fma(p, r, 1.0 / 120.0);
+  p = fma(p, r, 1.0 / 24.0);
+  p = fma(p, r, 1.0 / 6.0);
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  return ldexp(p, (int)n);
+}
+
 constexpr double kTiny = 2.2250738585072014e-308;  // np.finfo(np.float64).tiny
 
 }  // namespace pbbss

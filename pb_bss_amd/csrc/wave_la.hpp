@@ -520,7 +520,11 @@ __device__ __forceinline__ bool wave_dominant_eigenpair(double are, double aim, 
   // scale of the matrix (trace = sum of the eigenvalues >= lambda_max >= trace / D)
   const double tr = wave_sum((valid && c.i == c.j) ? are : 0.0);
   if (!(tr > 0.0) || !(tr < 1.79e308)) return false;
-  const double tol = 4e-15 * tr;
+  // residual at which the pair is accepted.  4e-15 tr (round 4) sat within a factor six of the
+  // rounding floor of the residual itself (D eps tr): one call in four paid a second inversion
+  // (~2 500 cycles) to move a residual of 5e-15 tr below it (profiles/r06_d_watson_phases.txt).
+  // 1e-12 tr bounds the eigenvector error by 1e-12 tr / gap; the eigenvalue is second order.
+  const double tol = 1e-12 * tr;
   {
     const double n2 = wave_colsum(xr * xr + xi * xi);  // x is replicated along its rows, 0 beyond D
     if (!(n2 > 0.0)) return false;
@@ -547,8 +551,12 @@ __device__ __forceinline__ bool wave_dominant_eigenpair(double are, double aim, 
     if (wave_hpd_inverse<D>(mre, mim, c, det) != 0) return false;  // an eigenvalue above sigma
     certified = true;  // lambda_max < sigma = rho + 1.01 res + guard
     if (res <= tol) return true;
-#pragma unroll
-    for (int rep = 0; rep < 2; ++rep) {
+    // applications of the explicit inverse: each contracts the error by (sigma - l1)/(sigma - l2)
+    // ~ the error itself.  Two bring a late EM iteration (mode moved by < 1e-7) to rounding
+    // level; an early one (1e-3) needs four -- two more matrix-vector products (~150 cycles
+    // each) where a second round would pay a second inversion (~2 500 cycles at D = 6).
+    const int reps = (res > 1e-7 * tr) ? 4 : 2;
+    for (int rep = 0; rep < reps; ++rep) {
       wave_matvec<D>(mre, mim, xr, xi, c, valid, yr, yi);
       const double n2 = wave_colsum(yr * yr + yi * yi);
       if (!(n2 > 0.0) || !(n2 < 1.79e308)) return false;
