@@ -654,7 +654,7 @@ PBBSS_API int pbbss_cacgmm_fit(pbbss_handle_t h, const void* y, int64_t B, int T
   if (D > 8 || K > 6) {
     // generic-size path (generic.hip; also more than 6 classes at any D): E-step, covariance + weights, eigendecomposition per
     // iteration, enqueued back to back; the model lives in the caller's output buffers
-    if (!pbbss::gen_supported(D, K)) return PBBSS_ERR_UNSUPPORTED;
+    if (!pbbss::gen_em_supported(D, K)) return PBBSS_ERR_UNSUPPORTED;
     if (o->layout != PBBSS_LAYOUT_TD) return PBBSS_ERR_UNSUPPORTED;
     hipStream_t s = as_stream(stream);
     const size_t nkt = (size_t)B * K * T;
@@ -904,7 +904,7 @@ PBBSS_API int pbbss_cacgmm_predict(pbbss_handle_t h, const void* y, int64_t B, i
   if (!h || !y || !eigvec || !eigval || !weight || B <= 0 || T <= 0) return PBBSS_ERR_INVALID_ARG;
   if (!out_affiliation && !out_quadratic_form && !out_log_pdf) return PBBSS_ERR_INVALID_ARG;
   if (D > 8 || K > 6) {
-    if (!pbbss::gen_supported(D, K)) return PBBSS_ERR_UNSUPPORTED;
+    if (!pbbss::gen_em_supported(D, K)) return PBBSS_ERR_UNSUPPORTED;
     const size_t ninv = pbbss::gen_state_doubles(B * K, D);
     void* wmem = handle_work(h, WorkCarver::pad(ninv * 8) + WorkCarver::pad((size_t)B * K * 8));
     if (!wmem) return PBBSS_ERR_HIP;

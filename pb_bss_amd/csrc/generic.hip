@@ -946,12 +946,13 @@ struct GenInv {
 };
 
 // The matrix lives in REGISTERS for the whole sweep: thread (bi, bj) owns the BS x BS block of
-// entries (bi BS + r, bj BS + c) (BS = 2 for DP > 16: 256 threads x 4 entries at DP = 32); per
+// entries (bi BS + r, bj BS + c) (BS = 2 for DP > 16: 256 threads x 4 entries at DP = 32; BS = 3
+// at DP = 36, D = 33 / 34: 144 threads x 9 entries); per
 // pivot only the pivot row and column travel through LDS (double-buffered by pivot parity:
 // one barrier per pivot), instead of the whole matrix being read and written there.
 template <int DP>
 __global__ void __launch_bounds__(kGenThreads) gen_inv_kernel(GenInv g) {
-  constexpr int BS = (DP > 16) ? 2 : 1;
+  constexpr int BS = (DP > 32) ? 3 : ((DP > 16) ? 2 : 1);  // DP = 36: 12 x 12 blocks of 3 x 3
   constexpr int NBK = DP / BS;  // blocks per dimension
   static_assert(NBK * NBK <= kGenThreads && DP % BS == 0, "one block per thread");
   __shared__ __attribute__((aligned(16))) double A[DP * DP * 2];  // only for the final symmetrisation
@@ -1131,6 +1132,7 @@ int set_lds(KFN kfn, size_t lds, size_t lds_limit) {
 }  // namespace
 
 bool gen_supported(int D, int K) { return D >= 2 && D <= kGenMaxD && K >= 1 && K <= kGenMaxK; }
+bool gen_em_supported(int D, int K) { return D >= 2 && D <= kGenMaxDEm && K >= 1 && K <= kGenMaxK; }
 
 int launch_gen_estep(const void* y, int y_is_c128, int layout, int64_t B, int T, int D, int K,
                      const double* eigvec, const double* eigval, const double* weight, int64_t wb,
@@ -1138,7 +1140,7 @@ int launch_gen_estep(const void* y, int y_is_c128, int layout, int64_t B, int T,
                      double* out_q, double* out_logpdf, hipStream_t s,
                      const GenInverseState& state, const double* saliency, double* out_mweight,
                      int32_t* out_zero, int raw_dt, const double* extra, double spatial_scale) {
-  if (!gen_supported(D, K)) return PBBSS_ERR_UNSUPPORTED;
+  if (!gen_em_supported(D, K)) return PBBSS_ERR_UNSUPPORTED;
   if (!state.inv || !state.logdet) return PBBSS_ERR_INVALID_ARG;
   const int DP = gen_state_ld(D);
   GenEigToInv c{eigvec, eigval, D, DP, state.ok, state.inv, state.logdet};
@@ -1159,7 +1161,7 @@ int launch_gen_estep(const void* y, int y_is_c128, int layout, int64_t B, int T,
   case DPV: if (y_is_c128) { PBBSS_GEN_E(DPV, double) } else { PBBSS_GEN_E(DPV, float) } break;
   switch (DP) {
     PBBSS_GEN_ED(12) PBBSS_GEN_ED(16) PBBSS_GEN_ED(20) PBBSS_GEN_ED(24) PBBSS_GEN_ED(28)
-    PBBSS_GEN_ED(32)
+    PBBSS_GEN_ED(32) PBBSS_GEN_ED(36)
     default: return PBBSS_ERR_UNSUPPORTED;
   }
 #undef PBBSS_GEN_ED
@@ -1172,8 +1174,8 @@ int launch_gen_cov(const void* y, int y_is_c128, int layout, int64_t B, int T, i
                    const double* saliency, int mode, int weight_mode, double* out_cov,
                    double* out_weight, double* out_sum, size_t lds_limit, hipStream_t s,
                    int32_t* out_zero) {
-  if (!gen_supported(D, K)) return PBBSS_ERR_UNSUPPORTED;
-  const int DP = D <= 16 ? 16 : 32;
+  if (!gen_em_supported(D, K)) return PBBSS_ERR_UNSUPPORTED;
+  const int DP = D <= 16 ? 16 : (D <= 32 ? 32 : 36);
   const size_t lds = (gen_cov_stage_doubles(DP) + (size_t)kCovMaxK * kTile +
                       (size_t)kGenMaxK * kTile + kGenMaxK) * sizeof(double);
   int rc;
@@ -1193,8 +1195,10 @@ int launch_gen_cov(const void* y, int y_is_c128, int layout, int64_t B, int T, i
              out_cov, out_weight, out_sum, out_zero, k0, kc};
     if (DP == 16) {
       if (y_is_c128) { PBBSS_GEN_CK(16, double) } else { PBBSS_GEN_CK(16, float) }
-    } else {
+    } else if (DP == 32) {
       if (y_is_c128) { PBBSS_GEN_CK(32, double) } else { PBBSS_GEN_CK(32, float) }
+    } else {
+      if (y_is_c128) { PBBSS_GEN_CK(36, double) } else { PBBSS_GEN_CK(36, float) }
     }
     k0 += kc;
   }
@@ -1412,7 +1416,7 @@ int launch_gen_transpose(const void* y, int y_is_c128, int64_t B, int T, int D, 
 int launch_gen_init_weights(const void* y, int y_is_c128, int layout, int64_t B, int T, int D, int K,
                             const double* gamma0, const double* saliency, double* out_mweight,
                             int32_t* out_zero, hipStream_t s) {
-  if (!gen_supported(D, K)) return PBBSS_ERR_UNSUPPORTED;
+  if (!gen_em_supported(D, K)) return PBBSS_ERR_UNSUPPORTED;
   const dim3 grid((unsigned)B, (unsigned)((T + kGenThreads - 1) / kGenThreads));
   if (grid.y > 65535u) return PBBSS_ERR_UNSUPPORTED;
   if (y_is_c128)
@@ -1428,7 +1432,7 @@ int launch_gen_mstep_cov(const void* y, int y_is_c128, int64_t B, int T, int D, 
                          const double* mweight, const double* gamma, const double* saliency,
                          int weight_mode, double* csum, double* out_cov, double* out_weight,
                          hipStream_t s) {
-  if (!gen_supported(D, K)) return PBBSS_ERR_UNSUPPORTED;
+  if (!gen_em_supported(D, K)) return PBBSS_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(gen_csum_kernel, dim3((unsigned)B), dim3(kGenThreads), 0, s, gamma, saliency,
                      K, T, weight_mode, csum, out_weight);
   const int NI = (D + 7) / 8, NJ = (D + 15) / 16;
@@ -1450,15 +1454,15 @@ int launch_gen_mstep_cov(const void* y, int y_is_c128, int64_t B, int T, int D, 
 int launch_gen_heev(const double* a, int64_t N, int D, int covariance_norm, double eig_floor,
                     double* out_val, double* out_vec, int32_t* out_status, size_t lds_limit,
                     hipStream_t s, const int32_t* skip) {
-  if (D < 2 || D > kGenMaxD) return PBBSS_ERR_UNSUPPORTED;
+  if (D < 2 || D > kGenMaxDEm) return PBBSS_ERR_UNSUPPORTED;
   GenHeev g{a, N, D, covariance_norm, eig_floor, out_val, out_vec, out_status, skip};
-  const int DP = D <= 16 ? 16 : (D <= 24 ? 24 : 32);
+  const int DP = D <= 16 ? 16 : (D <= 24 ? 24 : (D <= 32 ? 32 : 36));
   int rc;
   static const bool use_jacobi = [] {
     const char* v = getenv("PBBSS_GEN_HEEV");
     return v && v[0] == 'j';
   }();
-  if (!use_jacobi) {  // tridiagonal QL, one wavefront per matrix
+  if (!use_jacobi || D > kGenMaxD) {  // tridiagonal QL, one wavefront per matrix (the only solver beyond 32)
     const size_t lds = ((size_t)D * (D + 1) * 3 + 2 * (DP + 1) + 6 * DP) * sizeof(double);
 #define PBBSS_GEN_Q(DPV)                                                          \
   {                                                                               \
@@ -1468,7 +1472,8 @@ int launch_gen_heev(const double* a, int64_t N, int D, int covariance_norm, doub
   }
     if (DP == 16) PBBSS_GEN_Q(16)
     else if (DP == 24) PBBSS_GEN_Q(24)
-    else PBBSS_GEN_Q(32)
+    else if (DP == 32) PBBSS_GEN_Q(32)
+    else PBBSS_GEN_Q(36)
 #undef PBBSS_GEN_Q
     return ok_or_hip();
   }
@@ -1490,14 +1495,16 @@ int launch_gen_heev(const double* a, int64_t N, int D, int covariance_norm, doub
 int launch_gen_inverse(const double* a, int64_t N, int D, double eig_floor, double* out_inv,
                        double* out_logdet, int32_t* out_ok, hipStream_t s, const int32_t* veto,
                        int K) {
-  if (D < 2 || D > kGenMaxD || K < 1) return PBBSS_ERR_UNSUPPORTED;
+  if (D < 2 || D > kGenMaxDEm || K < 1) return PBBSS_ERR_UNSUPPORTED;
   GenInv g{a, N, D, eig_floor, out_inv, out_logdet, out_ok, veto, K, gen_state_ld(D)};
   if (D <= 16) {
     hipLaunchKernelGGL(gen_inv_kernel<16>, dim3((unsigned)N), dim3(kGenThreads), 0, s, g);
   } else if (D <= 24) {
     hipLaunchKernelGGL(gen_inv_kernel<24>, dim3((unsigned)N), dim3(kGenThreads), 0, s, g);
-  } else {
+  } else if (D <= 32) {
     hipLaunchKernelGGL(gen_inv_kernel<32>, dim3((unsigned)N), dim3(kGenThreads), 0, s, g);
+  } else {
+    hipLaunchKernelGGL(gen_inv_kernel<36>, dim3((unsigned)N), dim3(kGenThreads), 0, s, g);
   }
   return ok_or_hip();
 }

@@ -7,8 +7,12 @@
 namespace pbbss {
 
 constexpr int kGenMaxD = 32;
+// the cACGMM trainer's own kernels (E-step, covariance, eigendecomposition, inverse) also serve
+// D = 33, 34: the reference's sanity assert admits D < 35 (cacgmm.py:250); 36-wide padded tiles
+constexpr int kGenMaxDEm = 34;
 
 bool gen_supported(int D, int K);
+bool gen_em_supported(int D, int K);  // the cACGMM fit / predict path: D <= kGenMaxDEm
 
 // The E-step consumes the model as the "inverse state": B^-1 (complex128 (N, LD, LD) with
 // LD = gen_state_ld(D), zero beyond D) and log det B of matrix n = b * K + k.  ok (nullable)

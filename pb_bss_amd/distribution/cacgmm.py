@@ -261,12 +261,8 @@ class CACGMMTrainer:
                     source_activity_mask.shape, initialization.shape)
         assert K < 20, f'num_classes: {K}, sure?'
         assert D < 35, f'Channels: {D}, sure?'
-        if D > 32:
-            # the reference's sanity asserts (cacgmm.py:249-250) admit D = 33, 34; the compiled
-            # kernels pad the D x D matrices to 16 or 32 rows and stop there
-            raise NotImplementedError(
-                f'pb_bss_amd serves 2 <= D <= 32 sensors (got D = {D}; the reference asserts D < 35): '
-                'the generic-size kernels keep their matrices in 32 x 32 tiles')
+        # (D = 33, 34 -- admitted by the sanity assert above -- run on 36-wide padded tiles of the
+        # generic-size kernels since round 6: csrc/generic.hip)
 
         ndim = len(indep) + 2
         mode = self._weight_mode(weight_constant_axis, ndim)

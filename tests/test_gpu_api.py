@@ -143,9 +143,9 @@ def test_inline_permutation_aligner_hook():
 def test_unsupported_shapes_fail_loudly():
     from pb_bss_amd.distribution import CACGMMTrainer
     rng = np.random.default_rng(0)
-    x = rng.standard_normal((2, 50, 33)) + 1j * rng.standard_normal((2, 50, 33))
-    with pytest.raises(NotImplementedError):
-        CACGMMTrainer().fit(x, num_classes=2, iterations=1)  # D = 33 > 32 (generic path limit)
+    x = rng.standard_normal((2, 50, 35)) + 1j * rng.standard_normal((2, 50, 35))
+    with pytest.raises(AssertionError):
+        CACGMMTrainer().fit(x, num_classes=2, iterations=1)  # the reference's `assert D < 35`
     x = rng.standard_normal((2, 50, 4)) + 1j * rng.standard_normal((2, 50, 4))
     m = CACGMMTrainer().fit(x, num_classes=19, iterations=1)  # K = 17 .. 19: served since round 5
     assert m.weight.shape == (2, 19, 1)

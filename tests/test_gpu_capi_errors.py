@@ -38,7 +38,7 @@ def test_invalid_arguments_return_codes_not_crashes():
     assert fit(o=None) == _lib.ERR_INVALID_ARG
     assert fit(vv=None) == _lib.ERR_INVALID_ARG
     assert fit(gg=None) == _lib.ERR_INVALID_ARG              # neither affiliations nor a model
-    assert fit(DD=33) == _lib.ERR_UNSUPPORTED              # 2..8 fused kernel, 9..32 generic path
+    assert fit(DD=35) == _lib.ERR_UNSUPPORTED              # 2..8 fused kernel, 9..34 generic path
     assert fit(KK=20) == _lib.ERR_UNSUPPORTED             # 1..6 fused kernel, 7..19 generic path
     bad = _lib.EmOpts(iterations=0, covariance_norm=1)
     assert fit(o=bad) == _lib.ERR_INVALID_ARG                # cacgmm.py:200 asserts iterations > 0

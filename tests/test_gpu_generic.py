@@ -11,7 +11,7 @@ def _cov(vec, val):
     return np.einsum('...wx,...x,...zx->...wz', vec, val, vec.conj())
 
 
-@pytest.mark.parametrize('D', [9, 12, 16, 17, 24, 32])
+@pytest.mark.parametrize('D', [9, 12, 16, 17, 24, 32, 33, 34])
 def test_heev_matches_eigh(D):
     from pb_bss_amd import _lib, engine
     rng = np.random.default_rng(D)
@@ -29,7 +29,10 @@ def test_heev_matches_eigh(D):
     assert int(_lib.to_host(st).max()) == 0
 
 
-@pytest.mark.parametrize('F,T,D,K', [(5, 70, 9, 2), (4, 300, 16, 3), (3, 130, 24, 5), (2, 90, 32, 6)])
+@pytest.mark.parametrize('F,T,D,K', [(5, 70, 9, 2), (4, 300, 16, 3), (3, 130, 24, 5), (2, 90, 32, 6),
+                                     # the sensor counts between the engine's 32 x 32 tiles and the
+                                     # reference's `assert D < 35` (cacgmm.py:250): 36-wide tiles
+                                     (3, 140, 33, 2), (2, 260, 34, 3)])
 def test_single_step_and_trajectory(F, T, D, K):
     from oracle import cacgmm as oc, synth
     from pb_bss_amd.distribution import CACGMMTrainer
@@ -98,17 +101,32 @@ def test_many_classes(F, T, D, K):
                                ob.psd(X.astype(np.complex128), masks), atol=1e-11)
 
 
-def test_sensor_counts_beyond_the_compiled_kernels_say_so():
-    """The reference's sanity assert admits D = 33, 34 (cacgmm.py:250); the engine serves D <= 32 and
-    refuses the two sizes in between with its own limit in the message (D >= 35: the reference's
-    AssertionError)."""
+def test_sensor_counts_33_and_34_are_served_35_is_the_references_assert():
+    """The reference's sanity assert admits D < 35 (cacgmm.py:250).  Rounds 1-5 stopped at the
+    32 x 32 tiles of the generic-size kernels; D = 33, 34 now run on 36-wide tiles (E-step,
+    covariance, QL eigensolver, Gauss-Jordan fast path): a full fit with saliency, the predict of
+    the fitted model and fit_predict against the oracle; D >= 35 is the reference's AssertionError."""
+    from oracle import cacgmm as oc, synth
     from pb_bss_amd.distribution import CACGMMTrainer
     rng = np.random.default_rng(0)
-    for D, exc in ((33, NotImplementedError), (34, NotImplementedError), (35, AssertionError)):
-        Y = (rng.standard_normal((2, 40, D)) + 1j * rng.standard_normal((2, 40, D))).astype(np.complex64)
-        init = rng.uniform(size=(2, 2, 40))
-        with pytest.raises(exc, match='32 sensors' if exc is NotImplementedError else 'Channels'):
-            CACGMMTrainer().fit(Y, initialization=init / init.sum(1, keepdims=True), iterations=2)
+    for D, K in ((33, 3), (34, 2)):
+        F, T = 3, 420   # >= 4 D frames per class: the covariances stay well conditioned
+        Y, init = synth.make_stft(F, T, D, K, seed=D)
+        sal = rng.uniform(0.2, 1.0, size=(F, T))
+        Y128 = Y.astype(np.complex128)
+        ref = oc.em_fit(Y128, init, iterations=8, saliency=sal)
+        model = CACGMMTrainer().fit(Y, initialization=init, iterations=8, saliency=sal)
+        np.testing.assert_allclose(model.weight, ref['weight'], atol=1e-8)
+        np.testing.assert_allclose(model.cacg.covariance, _cov(ref['eigvec'], ref['eigval']), atol=1e-7)
+        want = oc.em_predict(ref, Y128)
+        np.testing.assert_allclose(model.predict(Y), want, atol=1e-7)
+        np.testing.assert_allclose(
+            CACGMMTrainer().fit_predict(Y, initialization=init, iterations=8, saliency=sal), want,
+            atol=1e-7)
+    Y = (rng.standard_normal((2, 40, 35)) + 1j * rng.standard_normal((2, 40, 35))).astype(np.complex64)
+    init = rng.uniform(size=(2, 2, 40))
+    with pytest.raises(AssertionError, match='Channels'):
+        CACGMMTrainer().fit(Y, initialization=init / init.sum(1, keepdims=True), iterations=2)
 
 
 def test_guided_source_separation_shape():
