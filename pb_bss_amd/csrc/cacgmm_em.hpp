@@ -920,6 +920,14 @@ struct EmKernel {
     unsigned long long tm0 = __builtin_readcyclecounter(), tm1 = tm0;
 #endif
     // halving butterfly over the 64 frame-lanes; 16 lanes each store NACC/16 totals
+    // Issue priority (round 6).  The butterfly and the factorisation are chains of dependent
+    // instructions; the trips above and the E phase are issue-bound streams.  When a chain shares
+    // its SIMD with another workgroup's stream at equal priority it waits for issue slots it
+    // could use at once and then leaves the SIMD to the stream while its result is in flight:
+    // s_setprio 1 for the butterfly + write-back, 3 for the factorisation, 0 again afterwards --
+    // 1.304 -> 1.257 ms per fit on one box (profiles/r06_e_issue_priority.txt).  Member
+    // workgroups of a split group keep the level of their launch (split_prio) throughout.
+    if (a.split_groups == 0) __builtin_amdgcn_s_setprio(1);
     wave_reduce_scatter<NACC>(acc, lane);
 #ifdef PBBSS_PHASE_PROFILE
     tm1 = __builtin_readcyclecounter();
@@ -933,6 +941,7 @@ struct EmKernel {
 #pragma unroll
       for (int m = 0; m < kWbR; ++m) dst[tab[m]] = acc[m];
     }
+    if (a.split_groups == 0) __builtin_amdgcn_s_setprio(0);
 #ifdef PBBSS_PHASE_PROFILE
     if (a.prof && lane == 0 && W == 0) {
       unsigned long long tm2 = __builtin_readcyclecounter();
@@ -995,6 +1004,9 @@ struct EmKernel {
   // ---- phase F for one class (one wave) ------------------------------------
   static __device__ void factor_class(const EmArgs& a, const Lds& L, int64_t b, int k, int lane,
                                       bool last) {
+    // a dependent chain beside another workgroup's issue-bound stream: top issue priority for its
+    // duration (see phase_m; members of a split group keep the level of their launch)
+    if (a.split_groups == 0) __builtin_amdgcn_s_setprio(3);
     lane = opaque(lane);
     const LaneIJ c = lane_ij(lane);
     const bool valid = c.i < D && c.j < D;
@@ -1149,6 +1161,7 @@ struct EmKernel {
       }
       L.wgt[k] = wnew;
     }
+    if (a.split_groups == 0) __builtin_amdgcn_s_setprio(0);
   }
 
   // model (V, lambda) given by the caller -> A_k, det  (cacgmm.py:229-234)

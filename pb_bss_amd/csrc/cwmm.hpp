@@ -330,6 +330,8 @@ struct WatsonKernel {
                                       SplineWin& win) {
     lane = opaque(lane);
     const EmArgs& a = wa.em;
+    // top issue priority for the serial chain (cacgmm_em.hpp: phase_m / factor_class)
+    if (a.split_groups == 0) __builtin_amdgcn_s_setprio(3);
     const LaneIJ c = lane_ij(lane);
     const bool valid = c.i < D && c.j < D;
     // covariance entry of this lane first: its LDS round trip overlaps the class sums below
@@ -410,6 +412,7 @@ struct WatsonKernel {
                                                            : S / ((tot == 0.0) ? 1e-10 : tot);
       }
     }
+    if (a.split_groups == 0) __builtin_amdgcn_s_setprio(0);
   }
 
   static __device__ void prep_from_model(const WatsonArgs& wa, const Lds& L, int64_t b, int k,
