@@ -582,12 +582,17 @@ struct EmKernel32 {
         flat[k * NSLOT + NDW + 2 * s + 1] = acc[k * NPK + NDW + s].y;
       }
     }
+    // issue priority of the dependent chains beside the co-resident workgroup's stream
+    // (cacgmm_em.hpp: phase_m); member workgroups keep the level of their launch
+    const bool host = a.main_grid <= 0 || (int)blockIdx.x < a.main_grid;
+    if (host) __builtin_amdgcn_s_setprio(1);
     wave_reduce_scatter32<NACC>(flat);
     if ((lane & 3) == 0) {  // destinations from the table carve() left in LDS (cacgmm_em.hpp: fill_wbtab)
       const unsigned short* tab = L.b.wbtab + (W * 16 + ((lane >> 2) & 15)) * Base::kWbR;
 #pragma unroll
       for (int m = 0; m < Base::kWbR; ++m) L.b.cpack[tab[m]] = (double)flat[m];
     }
+    if (host) __builtin_amdgcn_s_setprio(0);
   }
   static __device__ __forceinline__ void phase_m_dispatch(const EmArgs& a, const Lds& L, int wave,
                                                           int lane) {
@@ -752,10 +757,14 @@ struct EmKernel32 {
         __syncthreads();
         PBBSS_TICK32(4)
         const bool last = (it == a.iterations - 1);
+        // (factor_class raises the priority itself only where split_groups == 0; this launch
+        // carries the group count for its in-grid members, so the hosts do it here)
+        __builtin_amdgcn_s_setprio(3);
         for (int k = wave; k < K; k += kEmWaves) {
           Base::factor_class(a, L.b, b, k, lane, last);
           publish_class(L, k, lane);  // same wave wrote apack of class k: wave-ordered LDS
         }
+        __builtin_amdgcn_s_setprio(0);
         PBBSS_TICK32(5)
         __syncthreads();
         PBBSS_TICK32(6)
