@@ -31,7 +31,8 @@
 extern "C" {
 #endif
 
-#define PBBSS_VERSION 401 /* 0.4.1: pbbss_set_dhtv_probe; 0.4.0: pbbss_split_reset, pbbss_set_spin_limit, pbbss_reference_channel_terms,
+#define PBBSS_VERSION 600 /* 0.6.0: pbbss_log_pdf_to_affiliation_inline_pa, D = 33 / 34 in pbbss_cacgmm_fit / _predict;
+                             0.4.1: pbbss_set_dhtv_probe; 0.4.0: pbbss_split_reset, pbbss_set_spin_limit, pbbss_reference_channel_terms,
                              pbbss_rank_one_approximation, pbbss_matvec (0.3.0: em_opts.precision,
                              mix_opts.sharded, pbbss_comm_info) */
 

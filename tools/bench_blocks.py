@@ -664,7 +664,7 @@ SOURCES_BY_WORKLOAD = {
     'config3': KERNEL_SOURCES + ('dhtv.hip', 'beamform.hip'),
     'config4': ('cwmm.hpp', 'cw_inst.hip', 'cacgmm_em.hpp', 'wave_la.hpp', 'pbbss_dev.hpp',
                 'em_launch.hpp', 'beamform.hip'),  # Watson leg; the vMF leg: config4_vmf
-    'config4_vmf': ('embed.hip',),
+    'config4_vmf': ('vmf_bin.hip', 'embed.hip', 'embed_dev.hpp', 'pbbss_dev.hpp'),
     'config4_batched': (),  # no PMC pass of its own: the roofline block carries no traffic
     'config5': ('embed.hip', 'joint_inst.hip', 'cacgmm_em.hpp', 'wave_la.hpp', 'pbbss_dev.hpp',
                 'em_launch.hpp'),
@@ -826,8 +826,9 @@ def run_config4(args, local_rank, dev, leg='watson', steps=None, warmup=None, wi
             fit_ms, F_ * T_, args.iters, flops, bytes_iter,
             '8*F*T*D (one read of the complex64 observation per EM iteration, SURVEY 8d)'
             if leg == 'watson' else '4*F*T*2D (one read of the float32 features per EM iteration)',
-            ('cwmm_em_kernel<6,3,float,false> + cwmm_em_split_kernel (remainder bin 256 as split '
-             'groups)') if leg == 'watson' else 'vmf_em_kernel + embed_finalize_kernel per iteration',
+            ('cwmm_em_wide_kernel<6,3,float> (256 bins, eight wavefronts each) + cwmm_em_split_kernel '
+             '(remainder bin 256 as split groups, side stream)') if leg == 'watson' else
+            'vmf_bin_em2_kernel<3,12,float,4> (one launch per fit: the whole EM loop)',
             'config4' if leg == 'watson' else 'config4_vmf', 'fp64_valu'),
     }
     # ---- the chip-filling figure: 8 utterances (2 056 bins) in ONE fit -- what a rank of an

@@ -13,8 +13,8 @@ import re
 import sys
 from collections import defaultdict
 
-MARKER = {'config5': 'embed_prepare_kernel', 'config4': 'cwmm_em_kernel',
-          'config4_vmf': 'vmf_bin_em_kernel', 'config3': 'cacgmm_em_kernel'}
+MARKER = {'config5': 'embed_prepare_kernel', 'config4': 'cwmm_em_',  # cwmm_em_kernel / cwmm_em_wide_kernel
+          'config4_vmf': 'vmf_bin_em', 'config3': 'cacgmm_em_kernel'}        # vmf_bin_em_kernel / vmf_bin_em2_kernel
 # config3's step is the whole chain of pipeline.separate: the torch copy / reduction kernels
 # between the library's launches (transposes, the sum over the classes, the stack of the outputs)
 # are part of the step and of its traffic, so they are listed and counted too
