@@ -568,7 +568,7 @@ PBBSS_API int pbbss_set_spin_limit(pbbss_handle_t h, unsigned polls) {
   DeviceGuard device_guard(h);
   if (!h) return PBBSS_ERR_INVALID_ARG;
   h->cfg.spin_limit = polls;
-  return pbbss::dhtv_set_spin_limit(polls);  // the DHTV team kernels read a device global
+  return PBBSS_OK;  // (the DHTV team kernels take it as a kernel argument since round 6)
 }
 
 PBBSS_API int pbbss_split_error(pbbss_handle_t h, int* out_flag) {
@@ -1122,7 +1122,7 @@ PBBSS_API int pbbss_dhtv_calculate_mapping(pbbss_handle_t h, const double* mask,
   if (U <= 0 || F <= 0 || T <= 0 || P <= 0) return PBBSS_ERR_INVALID_ARG;
   return pbbss::launch_dhtv(mask, U, K, F, T, plan, P, optimal, metric, scratch, out_mapping, out_status,
                             h->cfg.lds_limit, h->cfg.num_cu, h->dhtv_team, h->team_buf,
-                            h->team_bytes, h->dhtv_probe, as_stream(stream));
+                            h->team_bytes, h->dhtv_probe, h->cfg.spin_limit, as_stream(stream));
 }
 
 PBBSS_API int pbbss_pa_pairwise_mapping(pbbss_handle_t h, const double* mask,

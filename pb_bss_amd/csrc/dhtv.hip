@@ -312,11 +312,13 @@ __device__ __forceinline__ void st_sc1(int32_t* p, int v) {
 }
 
 constexpr unsigned kTeamSpinLimit = 20000000u;
-// test knob (pbbss_set_spin_limit): polls before a team barrier gives up; 0 = kTeamSpinLimit
-__device__ unsigned g_team_spin_limit = 0u;
 
 // ctrl: [0] barrier counter, [1] error word, [2], [3] "changed" flags by iteration parity
-__device__ __forceinline__ void team_barrier(unsigned* ctrl, unsigned& target, int G, int tid) {
+// spin_limit: polls before the barrier gives up (a kernel argument: the handle's
+// pbbss_set_spin_limit value -- it was a device global shared by every handle until round 6);
+// 0 = kTeamSpinLimit
+__device__ __forceinline__ void team_barrier(unsigned* ctrl, unsigned& target, int G, int tid,
+                                             unsigned spin_limit) {
   target += (unsigned)G;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's sc1 stores have reached L2
   __syncthreads();
@@ -330,7 +332,7 @@ __device__ __forceinline__ void team_barrier(unsigned* ctrl, unsigned& target, i
       if ((spins & 1023u) == 1023u &&
           __hip_atomic_load(ctrl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)
         break;
-      if (++spins >= (g_team_spin_limit ? g_team_spin_limit : kTeamSpinLimit)) {
+      if (++spins >= (spin_limit ? spin_limit : kTeamSpinLimit)) {
         __hip_atomic_store(ctrl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         break;
       }
@@ -343,7 +345,8 @@ template <int K>
 __global__ void __launch_bounds__(kDhtvThreads)
     dhtv_team_kernel(const double* __restrict__ mask, double* feat_all, int32_t* mapping_all,
                      const int32_t* __restrict__ plan, int P, int F, int T, int optimal,
-                     int metric, int32_t* status, int G, double* part_all, unsigned* ctrl_all) {
+                     int metric, int32_t* status, int G, double* part_all, unsigned* ctrl_all,
+                     unsigned spin_limit) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* cent = reinterpret_cast<double*>(smem);  // [K][T]
   double* red = cent + (size_t)K * T;              // [kDhtvWaves]
@@ -377,7 +380,7 @@ __global__ void __launch_bounds__(kDhtvThreads)
   }
   if (g == 0)
     for (int i = tid; i < K * F; i += kDhtvThreads) st_sc1(mapping + i, i / F);
-  team_barrier(ctrl, target, G, tid);
+  team_barrier(ctrl, target, G, tid, spin_limit);
 
   int itn = 0;  // global iteration counter (parity of the changed flag)
   for (int seg = 0; seg < P; ++seg) {
@@ -409,7 +412,7 @@ __global__ void __launch_bounds__(kDhtvThreads)
                  ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7])));
         }
       }
-      team_barrier(ctrl, target, G, tid);
+      team_barrier(ctrl, target, G, tid, spin_limit);
       if (g == 0 && tid == 0) st_sc1(reinterpret_cast<int32_t*>(ctrl + 2 + ((itn + 1) & 1)), 0);
       // ---- centroid = ordered sum of the chunk partials, mean, unit norm per class
       for (int col = tid; col < KT; col += kDhtvThreads) {
@@ -529,7 +532,7 @@ __global__ void __launch_bounds__(kDhtvThreads)
       }
       if (changed && lane == 0)
         __hip_atomic_fetch_or(ctrl + 2 + (itn & 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      team_barrier(ctrl, target, G, tid);
+      team_barrier(ctrl, target, G, tid, spin_limit);
       const unsigned any =
           __hip_atomic_load(ctrl + 2 + (itn & 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (!any) {
@@ -739,7 +742,7 @@ __global__ void __launch_bounds__(kSliceThreads)
     dhtv_slice_kernel(const double* __restrict__ mask, const double* __restrict__ scale_all,
                       double* feat_all, int32_t* mapping_all, const int32_t* __restrict__ plan,
                       int P, int F, int T, int optimal, int metric, int32_t* status, int G,
-                      unsigned* ctrl_all, unsigned* probe_flag) {
+                      unsigned* ctrl_all, unsigned* probe_flag, unsigned spin_limit) {
   using C = SliceCfg<K, NFR>;
   constexpr int KK = C::KK, NS = C::NS, QS = C::QS, NC = C::NC, QC = C::QC, MAXP = C::MAXP,
                 TS = C::TS;
@@ -972,7 +975,7 @@ __global__ void __launch_bounds__(kSliceThreads)
         score_bin(f, x);
       }
       // ---- the one exchange hop of the iteration
-      team_barrier(ctrl, target, G, tid);
+      team_barrier(ctrl, target, G, tid, spin_limit);
       gather(hop & 1, K + nb * KK);
       ++hop;
       __syncthreads();
@@ -1303,7 +1306,7 @@ template <int K, int NF>
 static bool slice_launch_one(const double* mask, int64_t U, int F, int T, const int32_t* plan, int P,
                              int optimal, int metric, double* feat, int32_t* mapping,
                              int32_t* status, int G, size_t lds, unsigned* ctrl, double* scale,
-                             bool probe, bool features, hipStream_t s, int* rc) {
+                             bool probe, bool features, unsigned spin_limit, hipStream_t s, int* rc) {
   auto kfn = dhtv_slice_kernel<K, NF, false>;
   auto pfn = dhtv_slice_kernel<K, NF, true>;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
@@ -1325,9 +1328,10 @@ static bool slice_launch_one(const double* mask, int64_t U, int F, int T, const 
                      rows, T, K * F, metric == PBBSS_PA_COS ? 1 : 0, scale, status, ctrl, nctrl);
   if (probe)
     hipLaunchKernelGGL(pfn, dim3((unsigned)(U * P * G)), dim3(kSliceThreads), lds, s, mask, scale,
-                       feat, mapping, plan, P, F, T, optimal, metric, status, G, pctrl, pflag);
+                       feat, mapping, plan, P, F, T, optimal, metric, status, G, pctrl, pflag,
+                       spin_limit);
   hipLaunchKernelGGL(kfn, dim3((unsigned)(U * G)), dim3(kSliceThreads), lds, s, mask, scale, feat,
-                     mapping, plan, P, F, T, optimal, metric, status, G, ctrl, pflag);
+                     mapping, plan, P, F, T, optimal, metric, status, G, ctrl, pflag, spin_limit);
   if (features)
     hipLaunchKernelGGL(dhtv_features_kernel, dim3((unsigned)rows), dim3(256), 0, s, mask, mapping,
                        scale, K, F, T, feat);
@@ -1339,7 +1343,7 @@ static bool launch_slice(const double* mask, int64_t U, int K, int F, int T, con
                          int P, int optimal, int metric, double* feat, int32_t* mapping,
                          int32_t* status, size_t lds_limit, int num_cu, int want_team,
                          unsigned* ctrl, double* scale, bool want_probe, bool features,
-                         hipStream_t s, int* rc) {
+                         unsigned spin_limit, hipStream_t s, int* rc) {
   if (K > 5) return false;  // K*K scores per bin live in registers through the butterfly
   if (U * K * F > 2147483647LL) return false;
   for (int NF = 4; NF <= 8; NF *= 2) {  // frames per lane; 16 * NF frames per workgroup
@@ -1360,7 +1364,8 @@ static bool launch_slice(const double* mask, int64_t U, int K, int F, int T, con
 #define PBBSS_SLICE_CASE(KK, NN)                                                               \
   if (K == KK && NF == NN)                                                                     \
     return slice_launch_one<KK, NN>(mask, U, F, T, plan, P, optimal, metric, feat, mapping,    \
-                                    status, G, lds, ctrl, scale, probe, features, s, rc);
+                                    status, G, lds, ctrl, scale, probe, features, spin_limit, s, \
+                                    rc);
     PBBSS_SLICE_CASE(1, 4) PBBSS_SLICE_CASE(1, 8)
     PBBSS_SLICE_CASE(2, 4) PBBSS_SLICE_CASE(2, 8)
     PBBSS_SLICE_CASE(3, 4) PBBSS_SLICE_CASE(3, 8)
@@ -1378,7 +1383,7 @@ static bool launch_slice(const double* mask, int64_t U, int K, int F, int T, con
 int launch_dhtv(const double* mask, int64_t U, int K, int F, int T, const int32_t* plan, int P,
                 int optimal, int metric, double* feat, int32_t* mapping, int32_t* status,
                 size_t lds_limit, int num_cu, int team_size, void* team_buf, size_t team_bytes,
-                int probe, hipStream_t s) {
+                int probe, unsigned spin_limit, hipStream_t s) {
   if (K < 1 || K > kDhtvMaxK) return PBBSS_ERR_UNSUPPORTED;
   if (metric < PBBSS_PA_COS || metric > PBBSS_PA_EUCLIDEAN) return PBBSS_ERR_INVALID_ARG;
   const size_t ctrl_bytes = (size_t)U * 4 * sizeof(unsigned);
@@ -1393,7 +1398,7 @@ int launch_dhtv(const double* mask, int64_t U, int K, int F, int T, const int32_
     if (launch_slice(mask, U, K, F, T, plan, P, optimal, metric, feat, mapping, status, lds_limit,
                      num_cu, team_size, ctrl,
                      reinterpret_cast<double*>(static_cast<char*>(team_buf) + ctrl_pad),
-                     (probe & 1) != 0, (probe & 2) == 0, s, &rc))
+                     (probe & 1) != 0, (probe & 2) == 0, spin_limit, s, &rc))
       return rc;
   }
   size_t lds = ((size_t)K * T + kDhtvWaves) * sizeof(double) + 16;
@@ -1420,7 +1425,7 @@ int launch_dhtv(const double* mask, int64_t U, int K, int F, int T, const int32_
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
         return PBBSS_ERR_HIP;                                                                   \
       hipLaunchKernelGGL(kfn, dim3((unsigned)(U * G)), dim3(kDhtvThreads), lds, s, mask, feat,  \
-                         mapping, plan, P, F, T, optimal, metric, status, G, part, ctrl);               \
+                         mapping, plan, P, F, T, optimal, metric, status, G, part, ctrl, spin_limit);   \
     } else {                                                                                    \
       auto kfn = dhtv_kernel<KK>;                                                               \
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                               \
@@ -1452,12 +1457,6 @@ int launch_apply_mapping(const double* mask, const int32_t* mapping, int64_t U, 
   hipLaunchKernelGGL(apply_mapping_kernel, dim3((unsigned)rows), dim3(256), 0, s, mask, mapping, K,
                      F, T, out);
   return hipGetLastError() == hipSuccess ? PBBSS_OK : PBBSS_ERR_HIP;
-}
-
-int dhtv_set_spin_limit(unsigned limit) {
-  return hipMemcpyToSymbol(HIP_SYMBOL(g_team_spin_limit), &limit, sizeof(limit)) == hipSuccess
-             ? PBBSS_OK
-             : PBBSS_ERR_HIP;
 }
 
 }  // namespace pbbss

@@ -12,7 +12,8 @@ constexpr int kDhtvTeamMax = 32;
 int launch_dhtv(const double* mask, int64_t U, int K, int F, int T, const int32_t* plan, int P,
                 int optimal, int metric, double* feat, int32_t* mapping, int32_t* status,
                 size_t lds_limit, int num_cu, int team_size, void* team_buf, size_t team_bytes,
-                int probe, hipStream_t s);  // probe: frame-slice path, see dhtv_slice_kernel
+                int probe, unsigned spin_limit, hipStream_t s);  // probe: frame-slice path, see
+                // dhtv_slice_kernel; spin_limit: polls before a team barrier gives up (0: default)
 int launch_apply_mapping(const double* mask, const int32_t* mapping, int64_t U, int K, int F,
                          int T, double* out, hipStream_t s);
 // pairwise solvers (Oracle / Greedy alignment) and the assignment on given score matrices
@@ -23,6 +24,4 @@ int launch_pa_pair(const double* mask, const double* ref, int64_t U, int K, int6
 int launch_pa_compose(int32_t* mapping, int64_t U, int K, int64_t F, hipStream_t s);
 int launch_pa_assign(const double* scores, int64_t N, int K, int optimal, int32_t* mapping,
                      int32_t* status, hipStream_t s);
-// test knob: polls of a team barrier before it gives up (0: default)
-int dhtv_set_spin_limit(unsigned limit);
 }  // namespace pbbss
