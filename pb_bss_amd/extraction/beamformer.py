@@ -221,6 +221,25 @@ def _select_reference_channel(num, den, eps):
     return int(np.argmax(snr.real))
 
 
+def _select_reference_channel_device(num, den, eps):
+    """The selection of `_select_reference_channel` without leaving the device (round 6: the
+    chain of `pipeline.separate` / bench configs[3] used to stop for a device-to-host copy of
+    2 x D numbers per problem in the middle of every step -- the host could not enqueue the rest
+    of the step, nor the next fit, while it waited).  num / den: (..., F, D) device tensors.
+    -> (int64 tensor (...) of argmax_r Re(sum_f num / max(sum_f den, eps)) -- first maximum, as
+    np.argmax --, bool tensor (): every SNR finite -- what the reference asserts, :619; the
+    caller checks it when it next synchronises (`pipeline.device_ops.assert_finite`))."""
+    t = _lib.torch()
+    n, d = num.sum(dim=-2), den.sum(dim=-2)
+    # np.maximum on complex numbers orders by the real part first, then the imaginary part; the
+    # denominators w^H N w are real up to rounding: compare the real parts, keep the complex value
+    floor = t.full_like(d.real, eps)
+    dd = t.where((d.real > floor) | ((d.real == floor) & (d.imag >= 0)), d, floor.to(d.dtype))
+    snr = n / dd
+    ok = t.isfinite(snr.real).all() & t.isfinite(snr.imag).all()
+    return t.argmax(snr.real, dim=-1), ok
+
+
 def _select_reference_channel_sharded(num, den, eps, shard_group):
     """The same selection when the frequency bins are sharded over the ranks of a
     torch.distributed group: the SNR of :616-620 sums over ALL bins, so

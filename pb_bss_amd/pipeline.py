@@ -61,13 +61,20 @@ class device_ops:
         from .extraction import get_bf_vector
         return get_bf_vector('gev+ban', target, noise)
 
+    # SNR-finiteness flags of reference-channel selections that stayed on the device (one bool
+    # tensor per call); `assert_finite` reads them back together -- the reference's assert
+    # (beamformer.py:619), raised where the caller synchronises instead of in the middle of a step
+    _pending_finite = []
+
     @staticmethod
     def mvdr_souden(target, noise, shard_group=None):
         """target / noise (..., F_local, D, D) -> w (..., F_local, D); the reference channel of
         every leading problem maximises the SNR summed over ALL bins (beamformer.py:601-624,
-        :627-698): under bin sharding the 2 x D sums per problem are all-reduced once."""
+        :627-698): under bin sharding the 2 x D sums per problem are all-reduced once.  Without
+        sharding nothing leaves the device: arg-max and column gather are device ops, the
+        finiteness check is deferred to `assert_finite`."""
         from . import _lib, engine
-        from .extraction.beamformer import (_select_reference_channel,
+        from .extraction.beamformer import (_select_reference_channel_device,
                                             _select_reference_channel_sharded)
         t = _lib.torch()
         *lead, Fl, D, _ = target.shape
@@ -79,11 +86,21 @@ class device_ops:
         if shard_group is not None:
             ref = _select_reference_channel_sharded(num, den, eps, shard_group)
         else:
-            nh, dh = _lib.to_host(num), _lib.to_host(den)
-            ref = np.empty(tuple(lead), dtype=np.int64)
-            for idx in np.ndindex(*lead):
-                ref[idx] = _select_reference_channel(nh[idx], dh[idx], eps)
+            ref, ok = _select_reference_channel_device(num, den, eps)
+            device_ops._pending_finite.append(ok)
+            if len(device_ops._pending_finite) > 4096:  # a caller that never asks: keep it bounded
+                device_ops.assert_finite()
         return select_column(mat.reshape(*lead, Fl, D, D), ref)
+
+    @staticmethod
+    def assert_finite():
+        """Raise the reference's AssertionError (non-finite SNR in the reference-channel choice)
+        for the `mvdr_souden` calls since the last check; one device-to-host read."""
+        pend, device_ops._pending_finite = device_ops._pending_finite, []
+        if pend:
+            import torch
+            ok = bool(torch.stack([p.reshape(()) for p in pend]).all().item())
+            assert ok, 'non-finite SNR in the automatic reference-channel selection'
 
     @staticmethod
     def apply_bf(w, X):
@@ -95,7 +112,8 @@ def select_column(mat, ref):
     """mat (..., F, D, D), ref int array (...): column ref[...] of every matrix -> (..., F, D)."""
     import torch
     *lead, Fl, D, _ = mat.shape
-    idx = torch.as_tensor(np.asarray(ref), device=mat.device).reshape(*lead, 1, 1, 1)
+    idx = ref if torch.is_tensor(ref) else torch.as_tensor(np.asarray(ref))
+    idx = idx.to(device=mat.device, dtype=torch.int64).reshape(*lead, 1, 1, 1)
     return torch.gather(mat, -1, idx.expand(*lead, Fl, D, 1)).squeeze(-1)
 
 
@@ -188,6 +206,8 @@ def separate(Y, init, iterations=100, stft_size=None, *, shard=None, group=None,
         mapping = ops.dhtv_mapping(masks.transpose(-3, -2).contiguous(), stft_size)
         laps.lap('dhtv_ms')
         aligned, w, enhanced = _chain_after_masks(Y, masks, mapping, ops, beamformer)
+        if beamformer == 'mvdr_souden' and hasattr(ops, 'assert_finite'):
+            ops.assert_finite()  # the reference's SNR assert, deferred to the end of the chain
         laps.lap('extract_ms')
         return dict(masks=aligned, enhanced=enhanced, bf_vector=w, mapping=mapping)
 

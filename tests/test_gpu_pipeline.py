@@ -132,3 +132,45 @@ def test_single_utterance_without_the_leading_axis():
         assert tuple(one['masks'].shape) == (2, 257, 60) and tuple(one['mapping'].shape) == (2, 257)
         for k in ref:
             assert (one[k] == ref[k][0]).all(), k
+
+
+def test_reference_channel_selection_stays_on_the_device_and_defers_its_assert():
+    """pipeline.device_ops.mvdr_souden (round 6): the SNR-optimal reference channel
+    (beamformer.py:601-624) is chosen by device ops -- same channel as the host selection of
+    get_mvdr_vector_souden, first maximum on ties --, the reference's finiteness assert is
+    raised by device_ops.assert_finite() instead of in the middle of the step."""
+    import torch
+    from pb_bss_amd import _lib
+    from pb_bss_amd import extraction as ex
+    from pb_bss_amd.extraction.beamformer import (_select_reference_channel,
+                                                  _select_reference_channel_device)
+    from pb_bss_amd.pipeline import device_ops as ops
+    rng = np.random.default_rng(5)
+    K, F, D = 3, 40, 5
+
+    def psd(*lead):
+        a = rng.standard_normal((*lead, D, 2 * D)) + 1j * rng.standard_normal((*lead, D, 2 * D))
+        return a @ a.conj().swapaxes(-1, -2) / (2 * D)
+    target, noise = psd(K, F), psd(K, F) + 0.1 * np.eye(D)
+    ops.assert_finite()                                   # start from an empty queue
+    w = _lib.to_host(ops.mvdr_souden(_lib.to_device(target), _lib.to_device(noise)))
+    ops.assert_finite()
+    for k in range(K):
+        want, ref = ex.get_mvdr_vector_souden(target[k], noise[k], return_ref_channel=True)
+        np.testing.assert_allclose(w[k], want, rtol=1e-12, atol=1e-14)
+    # ties: the first maximum, like np.argmax
+    num = torch.ones((2, 7, 4), dtype=torch.complex128, device='cuda')
+    den = torch.ones((2, 7, 4), dtype=torch.complex128, device='cuda')
+    num[1, :, 2] = 3.0
+    num[1, :, 3] = 3.0
+    idx, ok = _select_reference_channel_device(num, den, 1e-300)
+    assert idx.tolist() == [0, 2] and bool(ok)
+    assert [_select_reference_channel(_lib.to_host(num[i]), _lib.to_host(den[i]), 1e-300)
+            for i in range(2)] == [0, 2]
+    bad = target.copy()
+    bad[1, 3] = np.nan
+    ops.mvdr_souden(_lib.to_device(bad), _lib.to_device(noise))   # returns: nothing is read back
+    with pytest.raises(AssertionError):
+        ops.assert_finite()
+    ops.assert_finite()                                   # the queue is empty again
+

@@ -805,6 +805,8 @@ def run_config4(args, local_rank, dev, leg='watson', steps=None, warmup=None, wi
     ph = preheat(step, min(args.preheat_s, 0.5), False, dev)
     elapsed, region_ms, last = timed(step, steps, warmup, False, dev, read_ms)
     ms_per_step = elapsed / steps * 1e3
+    ops.assert_finite()  # the reference-channel SNR checks of the timed steps (deferred: no host
+    #                      round trip inside a step since round 6)
     # the EM region alone, back to back (what the kernel trace of --workload config4 shows)
     el_fit, fit_ms, _ = timed(fit, steps, 2, False, dev, read_ms)
     name = 'CWMMTrainer (complex Watson mixture)' if leg == 'watson' else \
