@@ -18,10 +18,10 @@ __global__ void __launch_bounds__(256, 3) emprobe(EmArgs a, int mode, unsigned l
   for (int t = tid; t < L.Tp; t += 256) {
     for (int dp = 0; dp < 4; ++dp) {
       float4 v = {0.1f * (t % 7) + dp, 0.2f - 0.01f * (t % 5), 0.3f + dp, -0.1f * (t % 3)};
-      *reinterpret_cast<float4*>(L.ybuf + ((size_t)dp * L.Tp + t) * 4) = v;
+      *reinterpret_cast<float4*>(L.ybuf + Kern::yoff(dp, t)) = v;  // 64-frame chunk layout (round 5)
     }
     L.inv_n2[t] = 0.05;
-    for (int k = 0; k < 3; ++k) L.wbuf[(size_t)k * L.Tp + t] = 0.3 + 0.1 * k;
+    for (int k = 0; k < 3; ++k) L.wbuf[Kern::woff(k, t)] = 0.3 + 0.1 * k;
   }
   for (int i = tid; i < 3 * 64; i += 256) L.apack[i] = (i % 64 < 8) ? 2.0 : 0.01 * (i % 5);
   if (tid < 3) {
