@@ -58,8 +58,14 @@ __global__ void __launch_bounds__(256, 3) fprobe(EmArgs a, int active_waves, uns
     const int i = lane >> 3, j = lane & 7;
     double re = (i == j) ? 3.0 + 0.1 * i + wave : 0.05 * (i + j + 1) / (1.0 + (i > j ? i - j : j - i));
     double im = (i == j) ? 0.0 : (i < j ? 0.02 * (j - i) : -0.02 * (i - j));
-    L.cmat[(((size_t)wave * 8 + i) * 8 + j) * 2] = re;
-    L.cmat[(((size_t)wave * 8 + i) * 8 + j) * 2 + 1] = im;
+    // packed covariance sums as the M phase leaves them: diag i -> i, pair (i < j) -> D + 2 p + {Re, Im}
+    if (i == j) {
+      L.cpack[wave * Kern::NA + i] = re;
+    } else if (i < j) {
+      const int p = Kern::pair_index(i, j);
+      L.cpack[wave * Kern::NA + 8 + 2 * p] = re;
+      L.cpack[wave * Kern::NA + 8 + 2 * p + 1] = im;
+    }
   }
   if (threadIdx.x < 12) L.red[threadIdx.x] = 40.0 + threadIdx.x;
   if (threadIdx.x < 3) L.status[threadIdx.x] = 0;
