@@ -538,3 +538,30 @@ def test_small_host_helpers_behave_like_the_reference():
         assert isinstance(back, ComplexAngularCentralGaussian)
         assert np.array_equal(back.covariance_eigenvalues, model.covariance_eigenvalues)
 
+
+def test_bench_line_of_a_multi_rank_run_carries_the_strong_curve():
+    """The N > 1 line (canned: the full blocks of the N = 2 one-device rehearsal of round 6): the
+    top-level `strong` block names the faster sharding of BASELINE configs[2], both shardings' step
+    times and the speed-up against the newest committed N = 1 line; `comm` says what the
+    collective layer saw; the line stays under the limit."""
+    import json
+    import os
+    bench, _ = _bench_modules()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, 'tests', 'golden', 'bench_full_line_n2_rehearsal.json')) as f:
+        full = json.load(f)
+    line = bench.compact_line(full, None)
+    assert len(line.encode()) <= 8192
+    d = json.loads(line)
+    assert d['n_gpus'] == 2 and d['scaling'] == 'weak'
+    st = d['strong']
+    assert st['n_gpus'] == 2 and st['sharding'] in ('utterances_sharded', 'bins_sharded')
+    legs = st['per_sharding_ms_per_step']
+    assert set(legs) == {'bins_sharded', 'utterances_sharded'}
+    assert st['ms_per_step'] == pytest.approx(min(legs.values()), rel=1e-4)
+    assert st['speedup_vs_recorded_n1'] == pytest.approx(
+        st['n1_ms_per_step_recorded'] / st['ms_per_step'], rel=1e-4)
+    assert d['comm']['world_size'] == 2 and d['comm']['bytes_per_rank'] > 0
+    assert d['config3']['mapping_identical_across_shardings'] is True
+    assert d['verify']['gathered_masks_identical_on_all_ranks'] is True
+
