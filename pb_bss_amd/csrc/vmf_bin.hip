@@ -97,7 +97,9 @@ __device__ __forceinline__ double wave_log_bessel_fixed(const double* tab, doubl
 #pragma unroll
   for (int r = 0; r < kBesselRows; ++r) c[r] = tab[r * kWave + lane];  // in flight during the log
   const double q = 0.25 * x * x;
-  const double lx = 2.0 * log(x) - 1.3862943611198906;  // ln(x^2 / 4)
+  // (log_pos / exp_nonpos, pbbss_dev.hpp: x is the clamped concentration -- finite, positive and
+  // normal, or NaN, which both propagate)
+  const double lx = 2.0 * log_pos(x) - 1.3862943611198906;  // ln(x^2 / 4)
   const int m0 = lane * R;
   const double lt = (m0 ? (double)m0 * lx : 0.0) - c[0];
   double s = 0.0;  // rows >= R hold zeros: the Horner chain may always start at the last row
@@ -108,10 +110,10 @@ __device__ __forceinline__ double wave_log_bessel_fixed(const double* tab, doubl
 #pragma unroll
   for (int r = 8; r >= 1; --r) s = fma(s, q, c[r]);
   s = fma(s, q, 1.0);
-  const double la = lt + log(s);
+  const double la = lt + log_pos(s);  // s >= 1
   const double gmx = wave_max(la);
-  const double sum = wave_sum(exp(la - gmx));
-  return -nu * 0.6931471805599453 + gmx + log(sum);
+  const double sum = wave_sum(exp_nonpos(la - gmx));  // >= 1: the maximal lane contributes 1
+  return -nu * 0.6931471805599453 + gmx + log_pos(sum);
 }
 
 template <int K, int EP, typename TS, int NW>
