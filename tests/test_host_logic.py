@@ -539,6 +539,28 @@ def test_small_host_helpers_behave_like_the_reference():
         assert np.array_equal(back.covariance_eigenvalues, model.covariance_eigenvalues)
 
 
+def test_bench_line_survives_a_failed_additional_block():
+    """A block beyond the contract that raised (bench.py: guarded) is recorded as {"error": ...}: the
+    line keeps the headline, roofline and cpu_baseline and names the failure."""
+    import json
+    import os
+    bench, _ = _bench_modules()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, 'tests', 'golden', 'bench_full_line_r05.json')) as f:
+        full = json.load(f)
+    for k in ('f32', 'config3', 'config5', 'single_utterance_chain'):
+        full[k] = {'error': 'RuntimeError: out of memory ' * 20}
+    full['config4'] = {'error': 'boom', 'vmf': {'error': 'boom too'}}
+    line = bench.compact_line(full, None)
+    assert len(line.encode()) <= 8192
+    d = json.loads(line)
+    assert d['value'] == full['value'] and 'roofline' in d and 'cpu_baseline' in d
+    assert d['f32']['error'].startswith('RuntimeError') and len(d['f32']['error']) <= 160
+    assert d['config3']['error'] and d['config5']['error'] and d['single_utterance_chain']['error']
+    assert d['config4'] == {'watson': {'error': 'boom'}, 'vmf': {'error': 'boom too'}}
+    assert 'strong' not in d
+
+
 def test_bench_line_of_a_multi_rank_run_carries_the_strong_curve():
     """The N > 1 line (canned: the full blocks of the N = 2 one-device rehearsal of round 6): the
     top-level `strong` block names the faster sharding of BASELINE configs[2], both shardings' step

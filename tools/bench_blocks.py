@@ -1134,6 +1134,8 @@ def _summary(blk, frac_of=None):
     ratio, parity.  The full block is in the side file."""
     if not isinstance(blk, dict):
         return None
+    if 'error' in blk and 'value' not in blk:   # a block bench.py's guard recorded as failed
+        return {'error': str(blk['error'])[:160]}
     rf = blk.get('roofline') or {}
     other = rf.get('other') or rf.get('hbm_contract') or {}
     v = blk.get('verify') or {}
