@@ -915,24 +915,32 @@ __global__ void __launch_bounds__(kFusedThreads)
             for (int k = 0; k < K; ++k) a[k] = fma(v, mean[k * E + e], a[k]);
           }
         }
-        const double inv = GAUSS ? 0.0 : 1.0 / fmax(sqrt(n2), kTiny);
+        // The transcendental part of a row (three logarithms, three exponentials, a division, a
+        // square root) was ~300 of the ~1 450 VALU instructions a lane spends per tile with the
+        // library calls; the mantissa / exponent forms of pbbss_dev.hpp (~2 ulp) are a third of that.
+        // Q >= tiny (normal) by construction; NaN passes through, +Inf takes the branch.
+        const double inv = GAUSS ? 0.0
+                                 : ((n2 > 1e-280 && n2 < 1e280) ? fast_rsqrt(n2)
+                                                                 : 1.0 / fmax(sqrt(n2), kTiny));
         double lp[K], mx = -1.79e308;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
           const double spec = GAUSS ? offset[k] - 0.5 * a[k]                // gaussian.py:132-136
                                     : fma(prec[k], a[k] * inv, offset[k]);  // von_mises_fisher.py:71-77
-          const double spat = -(double)D * log(qv[k]) - ld[k];              // cacg.py:200-201
+          const double lq = (qv[k] >= kTiny && qv[k] < 1.79e308) ? log_pos(qv[k]) : log(qv[k]);
+          const double spat = -(double)D * lq - ld[k];                      // cacg.py:200-201
           lp[k] = spatial_weight * spat + spectral_weight * spec;
           mx = fmax(mx, lp[k]);
         }
         double g[K], den = 0.0;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-          g[k] = exp(lp[k] - mx) * wv[k];
+          g[k] = exp_nonpos(lp[k] - mx) * wv[k];
           den += g[k];
         }
-        den = fmax(den, kTiny);
-        const double rden = 1.0 / den;
+        // 1 / max(den, tiny) (mixture_model_utils.py:43-47) by a Newton-refined reciprocal; den - den
+        // carries a NaN / Inf denominator into the posterior exactly as the division did
+        const double rden = fast_rcp(fmax(den, kTiny)) + (den - den);
 #pragma unroll
         for (int k = 0; k < K; ++k) {
           double gam = g[k] * rden;
@@ -997,6 +1005,232 @@ __global__ void __launch_bounds__(kFusedThreads)
   if (tid < K) {
     double t = 0.0;
     for (int w = 0; w < kFusedThreads / kWave; ++w) t += red0[w * K + tid];
+    dst[tid * (E + 1) + E] = t;
+  }
+}
+
+// ---------------------------------------------------------------- joint models: wave-private sweep
+// Round 6.  joint_sweep_kernel above walks its chunk in tiles of 256 rows with three workgroup
+// barriers per tile, and a chunk is two tiles: every workgroup of the launch loads, computes the E
+// part and computes the M part in lockstep with all the others -- the memory system and the vector
+// units take turns (54 MB in 22.4 us with ~9 us of issue, profiles/r04_m_joint_pmc.txt).  Here a
+// WAVEFRONT owns a sub-tile of 64 rows (lane = row in the E part, lane = dimension in the M part)
+// in its own LDS region: no workgroup barrier inside the sweep, the four wavefronts of a
+// workgroup drift apart and the loads of one overlap the arithmetic of another; the next sub-tile
+// of the wavefront is requested into registers before the current one is consumed.  Chunk
+// geometry (C chunks of L rows, one partial per chunk) and the partials' layout are those of
+// joint_sweep_kernel, so the finalize (helper blocks of the spatial kernel, embed_dev.hpp) does
+// not change.  float32 embeddings, E % 4 == 0, E <= 4 NU <= 64; anything else takes the kernel
+// above.
+__device__ __forceinline__ void sweep_lds_order() { __asm__ volatile("" ::: "memory"); }
+
+template <int KIND, int K, int NU>
+__global__ void __launch_bounds__(kFusedThreads)
+    joint_sweep_wave_kernel(const float* __restrict__ y, int64_t N, int E, int64_t L, int T, int D,
+                            const double* __restrict__ Q, const double* __restrict__ lndet,
+                            const double* __restrict__ weight, int64_t wb, int64_t wk, int64_t wt,
+                            const double* __restrict__ mean, const double* __restrict__ prec,
+                            const double* __restrict__ offset, double spatial_weight,
+                            double spectral_weight, const double* __restrict__ sal, double eps,
+                            double* __restrict__ G, double* __restrict__ part,
+                            double* __restrict__ part2) {
+  extern __shared__ __attribute__((aligned(16))) char smraw[];
+  constexpr bool GAUSS = KIND != PBBSS_EMBED_VMF;
+  constexpr int KW = (K + 1) & ~1;
+  constexpr int NWAVE = kFusedThreads / kWave;
+  const int ES = E | 1;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & (kWave - 1);
+  const size_t wbytes = (size_t)kWave * ES * 4 + (size_t)kWave * KW * 8;  // multiple of 16
+  float* tile = reinterpret_cast<float*>(smraw + wave * wbytes);         // [64][ES]
+  double* gam = reinterpret_cast<double*>(tile + (size_t)kWave * ES);    // [64][KW] gamma * saliency
+  double* red = reinterpret_cast<double*>(smraw + NWAVE * wbytes);       // [NWAVE][K][E]
+  double* red0 = red + (size_t)NWAVE * K * E;                            // [NWAVE][K]
+  double* red2 = red0 + NWAVE * K;                                       // [NWAVE][K]
+  const int c = blockIdx.x;
+  const int64_t n0 = (int64_t)c * L;
+  const int64_t n1 = (n0 + L < N) ? (n0 + L) : N;
+  const int nsub = n1 > n0 ? (int)((n1 - n0 + kWave - 1) / kWave) : 0;
+  typedef float Vec4 __attribute__((ext_vector_type(4)));
+  // where the lane's u-th 16-byte piece of a sub-tile lands in the padded tile
+  int dst_off[NU];
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const int e0 = (lane + u * kWave) * 4;
+    const int r = e0 / E;
+    dst_off[u] = r * ES + (e0 - r * E);
+  }
+  Vec4 pre[NU];
+  auto request = [&](int ti) {
+    const int64_t nb = n0 + (int64_t)ti * kWave;
+    const int rows = (int)((n1 - nb < kWave) ? (n1 - nb) : kWave);
+    const int nv = rows * E / 4;
+    const Vec4* base = reinterpret_cast<const Vec4*>(y + (size_t)nb * E);
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const int i = lane + u * kWave;
+      pre[u] = base[i < nv ? i : nv - 1];
+    }
+  };
+  double acc[K], s0[K], s2[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) acc[k] = s0[k] = s2[k] = 0.0;
+  if (wave < nsub) request(wave);
+  for (int ti = wave; ti < nsub; ti += NWAVE) {
+    const int64_t nb = n0 + (int64_t)ti * kWave;
+    const int rows = (int)((n1 - nb < kWave) ? (n1 - nb) : kWave);
+    const bool mine = lane < rows;
+    // the row's spatial inputs: independent loads, in flight while the tile is staged
+    double qv[K], ld[K], wv[K], sv = 1.0;
+    int64_t gidx;
+    {
+      const int64_t n = nb + (mine ? lane : 0);
+      const int64_t f = n / T;
+      const int t = (int)(n - f * T);
+      gidx = (f * K) * (int64_t)T + t;
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        qv[k] = Q[gidx + (int64_t)k * T];
+        ld[k] = lndet[f * K + k];
+        wv[k] = weight ? weight[f * wb + k * wk + (int64_t)t * wt] : 1.0;
+      }
+      if (sal) sv = sal[n];
+    }
+    {
+      const int nv = rows * E / 4;
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        if (lane + u * kWave < nv) {
+          float* dst = tile + dst_off[u];
+#pragma unroll
+          for (int x = 0; x < 4; ++x) dst[x] = pre[u][x];
+        }
+      }
+    }
+    if (ti + NWAVE < nsub) request(ti + NWAVE);
+    sweep_lds_order();
+    // ---- E part: lane = row (the arithmetic of joint_sweep_kernel, same references)
+    {
+      double w[K];
+#pragma unroll
+      for (int k = 0; k < K; ++k) w[k] = 0.0;
+      if (mine) {
+        const float* row = tile + (size_t)lane * ES;
+        double n2 = 0.0, a[K], d2[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) a[k] = d2[k] = 0.0;
+        if (GAUSS) {
+          for (int e = 0; e < E; ++e) {
+            const double v = (double)row[e];
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+              const double u = v - mean[k * E + e];  // gaussian.py:127-131
+              a[k] = fma(u, u, a[k]);
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < K; ++k) {
+            d2[k] = a[k];
+            a[k] *= prec[k] * prec[k];
+          }
+        } else {
+          for (int e = 0; e < E; ++e) {
+            const double v = (double)row[e];
+            n2 = fma(v, v, n2);
+#pragma unroll
+            for (int k = 0; k < K; ++k) a[k] = fma(v, mean[k * E + e], a[k]);
+          }
+        }
+        const double inv = GAUSS ? 0.0
+                                 : ((n2 > 1e-280 && n2 < 1e280) ? fast_rsqrt(n2)
+                                                                 : 1.0 / fmax(sqrt(n2), kTiny));
+        double lp[K], mx = -1.79e308;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          const double spec = GAUSS ? offset[k] - 0.5 * a[k]                // gaussian.py:132-136
+                                    : fma(prec[k], a[k] * inv, offset[k]);  // von_mises_fisher.py:71-77
+          const double lq = (qv[k] >= kTiny && qv[k] < 1.79e308) ? log_pos(qv[k]) : log(qv[k]);
+          const double spat = -(double)D * lq - ld[k];                      // cacg.py:200-201
+          lp[k] = spatial_weight * spat + spectral_weight * spec;
+          mx = fmax(mx, lp[k]);
+        }
+        double g[K], den = 0.0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          g[k] = exp_nonpos(lp[k] - mx) * wv[k];  // mixture_model_utils.py:30-37
+          den += g[k];
+        }
+        const double rden = fast_rcp(fmax(den, kTiny)) + (den - den);  // :43-47
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          double gm = g[k] * rden;
+          if (eps != 0.0) gm = fmin(fmax(gm, eps), 1.0 - eps);  // :50-53
+          G[gidx + (int64_t)k * T] = gm;
+          const double wk2 = gm * sv;
+          s0[k] += wk2;
+          if (GAUSS) s2[k] = fma(wk2, d2[k], s2[k]);
+          w[k] = wk2;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < KW; k += 2) {
+        double2 p2;
+        p2.x = w[k];
+        p2.y = (k + 1 < K) ? w[k + 1 < K ? k + 1 : 0] : 0.0;
+        *reinterpret_cast<double2*>(gam + lane * KW + k) = p2;
+      }
+    }
+    sweep_lds_order();
+    // ---- M part: lane = dimension; the row's weights are one broadcast read
+    if (lane < E) {
+#pragma unroll 4
+      for (int r = 0; r < rows; ++r) {
+        const double v = (double)tile[(size_t)r * ES + lane];
+        double wk3[KW];
+#pragma unroll
+        for (int k = 0; k < KW; k += 2) {
+          const double2 p2 = *reinterpret_cast<const double2*>(gam + r * KW + k);
+          wk3[k] = p2.x;
+          wk3[k + 1] = p2.y;
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[k] = fma(wk3[k], v, acc[k]);
+      }
+    }
+    sweep_lds_order();  // the next sub-tile overwrites what the M part has read
+  }
+  // ---- chunk partial: the four wavefronts in ascending order (bit-reproducible)
+  if (lane < E) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) red[((size_t)wave * K + k) * E + lane] = acc[k];
+  }
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const double t = wave_sum(s0[k]);
+    if (lane == 0) red0[wave * K + k] = t;
+    if (GAUSS) {
+      const double t2 = wave_sum(s2[k]);
+      if (lane == 0) red2[wave * K + k] = t2;
+    }
+  }
+  __syncthreads();
+  double* dst = part + (size_t)c * K * (E + 1);
+  for (int i = tid; i < K * E; i += kFusedThreads) {
+    const int k = i / E, dd = i - k * E;
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < NWAVE; ++w) t += red[((size_t)w * K + k) * E + dd];
+    dst[k * (E + 1) + dd] = t;
+    if (GAUSS) {
+      double t2 = 0.0;  // 'spherical': the whole second moment travels in dimension 0
+      if (dd == 0)
+        for (int w = 0; w < NWAVE; ++w) t2 += red2[w * K + k];
+      part2[(size_t)c * K * (E + 1) + k * (E + 1) + dd] = t2;
+    }
+  }
+  if (tid < K) {
+    double t = 0.0;
+    for (int w = 0; w < NWAVE; ++w) t += red0[w * K + tid];
     dst[tid * (E + 1) + E] = t;
   }
 }
@@ -1871,6 +2105,34 @@ int launch_joint_sweep(int kind, const void* y, int y_is_f64, int64_t F, int T, 
   if (!p.ok || !joint_sweep_supported(kind, N, E, K, y_is_f64)) return PBBSS_ERR_UNSUPPORTED;
   double* part2 = part + (size_t)p.C * K * (E + 1);
   dim3 grid((unsigned)p.C);
+  {
+    // wave-private sweep (joint_sweep_wave_kernel): float32 rows of whole 16-byte pieces
+    static const bool wave_off = [] {
+      const char* v = getenv("PBBSS_JOINT_SWEEP_WAVE");
+      return v && atoi(v) == 0;
+    }();
+    const int KW = (K + 1) & ~1;
+    const size_t wlds = (size_t)(kFusedThreads / kWave) * ((size_t)kWave * (E | 1) * 4 + (size_t)kWave * KW * 8) +
+                        ((size_t)(kFusedThreads / kWave) * K * E + 2 * (size_t)(kFusedThreads / kWave) * K) * 8;
+    if (!wave_off && !y_is_f64 && E % 4 == 0 && E >= 4 && E <= 64 && K >= 2 && K <= 4 &&
+        reinterpret_cast<uintptr_t>(y) % 16 == 0 && p.L % kWave == 0 && wlds <= 64 * 1024) {
+#define PBBSS_JW_GO(KIND, KK, NU)                                                                  \
+  hipLaunchKernelGGL((joint_sweep_wave_kernel<KIND, KK, NU>), grid, dim3(kFusedThreads), wlds, s,  \
+                     static_cast<const float*>(y), N, E, p.L, T, D, Q, lndet, weight, wb, wk, wt,  \
+                     mean, prec, offset, spatial_weight, spectral_weight, sal, eps, G, part, part2)
+#define PBBSS_JW_N(KIND, KK)                                                                       \
+  if (E <= 40) PBBSS_JW_GO(KIND, KK, 10); else PBBSS_JW_GO(KIND, KK, 16)
+#define PBBSS_JW_K(KK)                                                                             \
+  case KK:                                                                                         \
+    if (gauss) { PBBSS_JW_N(PBBSS_EMBED_GAUSS_SPHERICAL, KK); } else { PBBSS_JW_N(PBBSS_EMBED_VMF, KK); } \
+    break;
+      switch (K) { PBBSS_JW_K(2) PBBSS_JW_K(3) PBBSS_JW_K(4) }
+#undef PBBSS_JW_K
+#undef PBBSS_JW_N
+#undef PBBSS_JW_GO
+      return ok_or_hip();
+    }
+  }
   const int vw = y_is_f64 ? 2 : 4;
   const bool vec = (E % vw == 0) && (reinterpret_cast<uintptr_t>(y) % 16 == 0);
 #define PBBSS_JS_GO(KIND, KK, TT, VV)                                                              \
