@@ -574,6 +574,26 @@ def test_joint_inline_permutation_alignment_50_iterations_against_oracle(kind):
     _assert_joint_model_close(model, ref, kind, 1e-7)
 
 
+@pytest.mark.parametrize('E,K', [(52, 2), (44, 4), (8, 4), (64, 3), (30, 3)])
+def test_joint_sweep_wavefront_kernel_dimension_range(E, K):
+    """The sweep of the rotated joint loop has a wavefront-per-64-rows kernel since round 6
+    (embed.hip: joint_sweep_wave_kernel; float32 embeddings, E % 4 == 0, K = 2 ... 4, LDS <= 64 KB)
+    with 10 or 16 sixteen-byte pieces per lane: dimensions on both sides of the 40 / 64 limits and
+    the ones it refuses (E = 64 at K = 3: LDS; E = 30: not whole pieces) must all agree with the
+    oracle -- whichever kernel served them.  Ragged last chunk (F T = 3 x 341 rows), saliency."""
+    from pb_bss_amd.distribution import GCACGMMTrainer, VMFCACGMMTrainer
+    from oracle import embed as oe, synth
+    F, T, D = 3, 341, 4
+    Y, e, init = synth.make_joint(F, T, D, K, E, seed=E + K)
+    Y128, e64 = Y.astype(np.complex128), e.astype(np.float64)
+    sal = np.random.default_rng(E).uniform(0.1, 1.0, size=(F, T))
+    for kind, trainer, kw in (('gaussian', GCACGMMTrainer(), {}),
+                              ('vmf', VMFCACGMMTrainer(), dict(max_concentration=80.))):
+        got = trainer.fit_predict(Y, e, initialization=init, iterations=4, saliency=sal, **kw)
+        ref = oe.joint_fit(kind, Y128, e64, init, 4, saliency=sal, **kw)
+        assert np.abs(got - oe.joint_model_predict(ref, Y128, e64)).max() < 1e-6, (E, K, kind)
+
+
 @pytest.mark.parametrize('T', [64, 65, 130, 257])
 def test_joint_models_frame_counts_around_the_chunk_size(T):
     """The spatial kernels of the joint models share the 64-frame chunk layout of the LDS frame
