@@ -31,7 +31,8 @@
 extern "C" {
 #endif
 
-#define PBBSS_VERSION 600 /* 0.6.0: pbbss_log_pdf_to_affiliation_inline_pa, D = 33 / 34 in pbbss_cacgmm_fit / _predict;
+#define PBBSS_VERSION 610 /* 0.6.1: pbbss_select_reference_channel, pbbss_apply_beamforming_vector_shared;
+                             0.6.0: pbbss_log_pdf_to_affiliation_inline_pa, D = 33 / 34 in pbbss_cacgmm_fit / _predict;
                              0.4.1: pbbss_set_dhtv_probe; 0.4.0: pbbss_split_reset, pbbss_set_spin_limit, pbbss_reference_channel_terms,
                              pbbss_rank_one_approximation, pbbss_matvec (0.3.0: em_opts.precision,
                              mix_opts.sharded, pbbss_comm_info) */
@@ -329,6 +330,30 @@ int pbbss_ban(pbbss_handle_t h, const void* w, const void* noise, int64_t N,
 int pbbss_apply_beamforming_vector(pbbss_handle_t h, const void* w,
                                    const void* x, int x_is_c128, int64_t B,
                                    int T, int D, void* out, void* stream);
+/* The same with ONE observation shared by several vectors per bin (K beamformers on one   */
+/* STFT, the broadcast of the reference's einsum '...a,...at->...t' over a leading axis of    */
+/* `vector`): x (x_batch,D,T), w (B,D) and out (B,T) with B a multiple of x_batch; problem b  */
+/* reads x[b % x_batch].  No copies of x are made.                                            */
+int pbbss_apply_beamforming_vector_shared(pbbss_handle_t h, const void* w, const void* x,
+                                          int x_is_c128, int64_t B, int64_t x_batch, int T,
+                                          int D, void* out, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* a12, phase 2 on the device: get_optimal_reference_channel                   */
+/* extraction/beamformer.py:601-624 and the column select :690-698, for L      */
+/* problems (classes / utterances) of F bins each, from the outputs of         */
+/* pbbss_mvdr_souden: problem l, bin f is matrix n = l*lead_stride +            */
+/* f*bin_stride of that call.  snr_r = sum_f num[f,r] / max(sum_f den[f,r],     */
+/* eps) (NumPy's complex ordering in the maximum), ref = first argmax of Re     */
+/* snr; out_w c128 (L,F,D) = column ref of every bin's matrix, out_ref (L),     */
+/* out_ok (L): 1 if every SNR of the problem is finite (the reference asserts   */
+/* it, :619 -- the caller raises when it next synchronises).  Not for sharded   */
+/* bins (the sums then need an all-reduce between the phases).                  */
+/* ------------------------------------------------------------------------- */
+int pbbss_select_reference_channel(pbbss_handle_t h, const void* mat, const void* snr_num,
+                                   const void* snr_den, int64_t L, int64_t F, int D,
+                                   int64_t lead_stride, int64_t bin_stride, double eps,
+                                   void* out_w, int32_t* out_ref, int32_t* out_ok, void* stream);
 
 /* similarity metrics of the permutation solvers (_ScoreMatrix, permutation_alignment.py:380-417) */
 #define PBBSS_PA_COS 0

@@ -46,7 +46,8 @@ EXPORTS = (
     'pbbss_allgather_masks', 'pbbss_allgather_unpack', 'pbbss_estimate_mixture_weight',
     'pbbss_log_pdf_to_affiliation', 'pbbss_log_pdf_to_affiliation_inline_pa',
     'pbbss_solve', 'pbbss_mvdr_souden', 'pbbss_mvdr', 'pbbss_ban',
-    'pbbss_apply_beamforming_vector', 'pbbss_set_timing',
+    'pbbss_apply_beamforming_vector', 'pbbss_apply_beamforming_vector_shared',
+    'pbbss_select_reference_channel', 'pbbss_set_timing',
     'pbbss_last_kernel_ms', 'pbbss_kernel_ms_lagged', 'pbbss_set_phase_profile',
     'pbbss_dhtv_calculate_mapping', 'pbbss_apply_mapping', 'pbbss_cwmm_fit',
     'pbbss_wmwf', 'pbbss_set_split_tail', 'pbbss_split_error', 'pbbss_split_reset', 'pbbss_set_spin_limit',
@@ -214,6 +215,10 @@ def load():
         lib.pbbss_wmwf.argtypes = [vp, vp, vp, i64, i32, dbl, i32, vp, vp, vp, vp, vp]
         lib.pbbss_ban.argtypes = [vp, vp, vp, i64, i32, vp, vp]
         lib.pbbss_apply_beamforming_vector.argtypes = [vp, vp, vp, i32, i64, i32, i32, vp, vp]
+        lib.pbbss_apply_beamforming_vector_shared.argtypes = [vp, vp, vp, i32, i64, i64, i32, i32,
+                                                              vp, vp]
+        lib.pbbss_select_reference_channel.argtypes = [vp, vp, vp, vp, i64, i64, i32, i64, i64, dbl,
+                                                       vp, vp, vp, vp]
         lib.pbbss_embed_log_pdf.argtypes = [vp, vp, i32, i64, i64, i32, i32, i32, vp, vp, vp, vp]
         lib.pbbss_embed_fit.argtypes = [vp, vp, i32, i64, i64, i32, i32, i32, i32, vp, dbl, dbl,
                                         vp, vp, vp]

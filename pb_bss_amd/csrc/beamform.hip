@@ -362,17 +362,21 @@ __global__ void __launch_bounds__(kLaThreads) ban_kernel(const double* w, const 
 
 // ------------------------------------------------------------------ apply
 // out[b,t] = sum_d conj(w[b,d]) x[b,d,t]; lane = frame, coalesced along t.
+// xmod > 0: the observation has xmod problems, shared by B = m * xmod vectors (problem b reads
+// x[b % xmod] -- K beamformers per bin on one STFT without K copies of it)
 template <typename YS>
 __global__ void __launch_bounds__(256) apply_kernel(const double* w, const void* xv, int64_t B,
-                                                    int T, int D, double* out) {
+                                                    int T, int D, double* out, int64_t xmod,
+                                                    int64_t b_first) {
   using YS2 = typename std::conditional<std::is_same<YS, float>::value, float2, double2>::type;
   const YS2* x = reinterpret_cast<const YS2*>(xv);
   const int64_t b = blockIdx.y;
+  const int64_t bx = xmod > 0 ? (b_first + b) % xmod : b;
   for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < T; t += gridDim.x * blockDim.x) {
     double ar = 0.0, ai = 0.0;
     for (int d = 0; d < D; ++d) {
       double wr = w[(b * D + d) * 2], wi = w[(b * D + d) * 2 + 1];
-      YS2 v = x[((size_t)b * D + d) * T + t];
+      YS2 v = x[((size_t)bx * D + d) * T + t];
       double xr = (double)v.x, xi = (double)v.y;
       ar += wr * xr + wi * xi;
       ai += wr * xi - wi * xr;
@@ -561,14 +565,104 @@ int launch_ban(const double* w, const double* nn, int64_t N, int D, double* out,
   return check_launch();
 }
 int launch_apply(const double* w, const void* x, int x128, int64_t B, int T, int D, double* out,
-                 hipStream_t s) {
+                 hipStream_t s, int64_t xmod, int64_t b_first) {
   unsigned gx = (unsigned)((T + 255) / 256);
   if (gx > 64) gx = 64;
   dim3 grid(gx, (unsigned)B);
   if (x128)
-    hipLaunchKernelGGL(apply_kernel<double>, grid, dim3(256), 0, s, w, x, B, T, D, out);
+    hipLaunchKernelGGL(apply_kernel<double>, grid, dim3(256), 0, s, w, x, B, T, D, out, xmod, b_first);
   else
-    hipLaunchKernelGGL(apply_kernel<float>, grid, dim3(256), 0, s, w, x, B, T, D, out);
+    hipLaunchKernelGGL(apply_kernel<float>, grid, dim3(256), 0, s, w, x, B, T, D, out, xmod, b_first);
+  return check_launch();
+}
+
+// ------------------------------------------------------------------ reference channel
+// get_optimal_reference_channel (beamformer.py:601-624) + the column select of
+// get_mvdr_vector_souden (:690-698) for L problems at once, after pbbss_mvdr_souden left
+// mat (N,D,D) and the per-bin SNR terms num / den (N,D) behind: one workgroup per problem sums the
+// terms over its F bins (thread = (slot, channel), slots in ascending order: bit-reproducible),
+//   snr_r = sum_f num[f,r] / max(sum_f den[f,r], eps)        (np.maximum on complex numbers orders
+//   by the real part first, then the imaginary part: the complex value is kept when it wins),
+// takes the first arg-max of Re snr (np.argmax), copies column r of every bin's matrix to out_w and
+// reports whether every SNR was finite (the reference's assert, :619).  Problem l, bin f is matrix
+// n = l * lead_stride + f * bin_stride of the pbbss_mvdr_souden call.  It replaced ~25 elementwise
+// launches of the host framework per call in the separation chain (profiles/r06_h_extraction_chain.txt).
+constexpr int kRefThreads = 256;
+__global__ void __launch_bounds__(kRefThreads)
+    refchan_select_kernel(const double* __restrict__ mat, const double* __restrict__ num,
+                          const double* __restrict__ den, int64_t F, int D, int64_t lead_stride,
+                          int64_t bin_stride, double eps, double* __restrict__ out_w,
+                          int32_t* __restrict__ out_ref, int32_t* __restrict__ out_ok) {
+  __shared__ double red[4][kRefThreads];
+  __shared__ double snr_re[32], snr_im[32];
+  __shared__ int ref_s;
+  const int64_t l = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int S = kRefThreads / D;  // slots (D <= 32: S >= 8)
+  const int slot = tid / D, r = tid - slot * D;
+  double a[4] = {0.0, 0.0, 0.0, 0.0};
+  if (slot < S) {
+    for (int64_t f = slot; f < F; f += S) {
+      const size_t n = (size_t)(l * lead_stride + f * bin_stride);
+      a[0] += num[(n * D + r) * 2];
+      a[1] += num[(n * D + r) * 2 + 1];
+      a[2] += den[(n * D + r) * 2];
+      a[3] += den[(n * D + r) * 2 + 1];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) red[i][tid] = a[i];
+  __syncthreads();
+  if (tid < D) {
+    double t[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int sl = 0; sl < S; ++sl) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) t[i] += red[i][sl * D + tid];
+    }
+    // max(den, eps) in NumPy's complex order, then the complex quotient
+    double dr = t[2], di = t[3];
+    const bool keep = (dr > eps) || (dr == eps && di >= 0.0);
+    if (!keep) {
+      dr = eps;
+      di = 0.0;
+    }
+    const double m = dr * dr + di * di;
+    snr_re[tid] = (t[0] * dr + t[1] * di) / m;
+    snr_im[tid] = (t[1] * dr - t[0] * di) / m;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int best = 0;
+    bool ok = true;
+    for (int i = 0; i < D; ++i) {
+      const double v = snr_re[i];
+      ok = ok && (fabs(v) <= 1.79e308) && (fabs(snr_im[i]) <= 1.79e308);  // false for NaN / Inf
+      // np.argmax: the first maximum; a NaN counts as the maximum
+      if (i > 0 && !(snr_re[best] != snr_re[best]) && (v > snr_re[best] || v != v)) best = i;
+    }
+    ref_s = best;
+    out_ref[l] = best;
+    out_ok[l] = ok ? 1 : 0;
+  }
+  __syncthreads();
+  const int ref = ref_s;
+  for (int64_t e = tid; e < F * D; e += kRefThreads) {
+    const int64_t f = e / D;
+    const int i = (int)(e - f * D);
+    const size_t n = (size_t)(l * lead_stride + f * bin_stride);
+    const size_t src = ((n * D + i) * D + ref) * 2;
+    out_w[((size_t)(l * F + f) * D + i) * 2] = mat[src];
+    out_w[((size_t)(l * F + f) * D + i) * 2 + 1] = mat[src + 1];
+  }
+}
+
+int launch_select_reference_channel(const double* mat, const double* num, const double* den,
+                                    int64_t L, int64_t F, int D, int64_t lead_stride,
+                                    int64_t bin_stride, double eps, double* out_w, int32_t* out_ref,
+                                    int32_t* out_ok, hipStream_t s) {
+  if (D < 1 || D > 32 || L < 1 || F < 1) return PBBSS_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(refchan_select_kernel, dim3((unsigned)L), dim3(kRefThreads), 0, s, mat, num,
+                     den, F, D, lead_stride, bin_stride, eps, out_w, out_ref, out_ok);
   return check_launch();
 }
 int launch_normalize(const void* y, int is128, int64_t B, int T, int D, void* out,

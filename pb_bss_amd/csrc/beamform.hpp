@@ -20,7 +20,12 @@ int launch_mvdr(const double* atf, const double* nn, int64_t N, int D, double* w
                 hipStream_t s);
 int launch_ban(const double* w, const double* nn, int64_t N, int D, double* out, hipStream_t s);
 int launch_apply(const double* w, const void* x, int x128, int64_t B, int T, int D, double* out,
-                 hipStream_t s);
+                 hipStream_t s, int64_t xmod = 0, int64_t b_first = 0);
+// reference channel of get_mvdr_vector_souden for L problems (beamformer.py:601-624, :690-698)
+int launch_select_reference_channel(const double* mat, const double* num, const double* den,
+                                    int64_t L, int64_t F, int D, int64_t lead_stride,
+                                    int64_t bin_stride, double eps, double* out_w, int32_t* out_ref,
+                                    int32_t* out_ok, hipStream_t s);
 int launch_normalize(const void* y, int is128, int64_t B, int T, int D, void* out, hipStream_t s);
 int launch_psd(const void* x, int x128, int64_t B, int T, int D, int K, const double* mask,
                int normalize, double* out, const EmLaunchCfg& cfg, hipStream_t s);

@@ -1112,6 +1112,39 @@ PBBSS_API int pbbss_apply_beamforming_vector(pbbss_handle_t h, const void* w, co
   return PBBSS_OK;
 }
 
+PBBSS_API int pbbss_apply_beamforming_vector_shared(pbbss_handle_t h, const void* w, const void* x,
+                                                    int x_is_c128, int64_t B, int64_t x_batch, int T,
+                                                    int D, void* out, void* stream) {
+  DeviceGuard device_guard(h);
+  if (!h || !w || !x || !out || B <= 0 || T <= 0 || D <= 0 || x_batch <= 0 || B % x_batch != 0)
+    return PBBSS_ERR_INVALID_ARG;
+  if (D >= 30) return PBBSS_ERR_INVALID_ARG;  // beamformer.py:582
+  for (int64_t b0 = 0; b0 < B; b0 += 65535) {
+    int64_t nb = (B - b0 < 65535) ? (B - b0) : 65535;
+    int rc = pbbss::launch_apply(static_cast<const double*>(w) + b0 * D * 2, x, x_is_c128, nb, T, D,
+                                 static_cast<double*>(out) + b0 * T * 2, as_stream(stream), x_batch,
+                                 b0);
+    if (rc != PBBSS_OK) return rc;
+  }
+  return PBBSS_OK;
+}
+
+PBBSS_API int pbbss_select_reference_channel(pbbss_handle_t h, const void* mat, const void* snr_num,
+                                             const void* snr_den, int64_t L, int64_t F, int D,
+                                             int64_t lead_stride, int64_t bin_stride, double eps,
+                                             void* out_w, int32_t* out_ref, int32_t* out_ok,
+                                             void* stream) {
+  DeviceGuard device_guard(h);
+  if (!h || !mat || !snr_num || !snr_den || !out_w || !out_ref || !out_ok || L <= 0 || F <= 0 ||
+      D < 1 || lead_stride < 0 || bin_stride < 0 || out_w == mat)
+    return PBBSS_ERR_INVALID_ARG;
+  if (D > 32) return PBBSS_ERR_UNSUPPORTED;
+  return pbbss::launch_select_reference_channel(
+      static_cast<const double*>(mat), static_cast<const double*>(snr_num),
+      static_cast<const double*>(snr_den), L, F, D, lead_stride, bin_stride, eps,
+      static_cast<double*>(out_w), out_ref, out_ok, as_stream(stream));
+}
+
 PBBSS_API int pbbss_dhtv_calculate_mapping(pbbss_handle_t h, const double* mask, int64_t U, int K,
                                            int F, int T, const int32_t* plan, int P, int optimal,
                                            int metric, double* scratch, int32_t* out_mapping,

@@ -371,13 +371,33 @@ def mvdr_souden(target, noise, eps):
     mat = t.empty((N, D, D), dtype=t.complex128, device=target.device)
     num = t.empty((N, D), dtype=t.complex128, device=target.device)
     den = t.empty((N, D), dtype=t.complex128, device=target.device)
-    st = t.zeros((N,), dtype=t.int32, device=target.device)
+    # the fused kernels (D <= 8) write every status word; no fill launch in front of them
+    st = (t.empty if D <= 8 else t.zeros)((N,), dtype=t.int32, device=target.device)
     rc = _lib.load().pbbss_mvdr_souden(
         _lib.handle(target.device.index), _lib.ptr(target), _lib.ptr(noise), N,
         D, float(eps), _lib.ptr(mat), _lib.ptr(num), _lib.ptr(den), _lib.ptr(st),
         _lib.stream_ptr(target.device.index))
     _lib.check(rc, f'mvdr_souden(N={N},D={D})')
     return mat, num, den, st
+
+
+def select_reference_channel(mat, num, den, L, F, eps, lead_stride=None, bin_stride=1):
+    """pbbss_select_reference_channel (round 6): the automatic reference channel of
+    get_mvdr_vector_souden (beamformer.py:601-624) and the column select (:690-698) for L problems
+    of F bins in ONE launch, from the outputs of `mvdr_souden` (mat (N,D,D), num / den (N,D) c128;
+    problem l, bin f = matrix l * lead_stride + f * bin_stride).
+    -> (w (L,F,D) c128, ref (L) int32, ok (L) int32: every SNR of the problem finite)."""
+    t = _t()
+    D = mat.shape[-1]
+    w = t.empty((L, F, D), dtype=t.complex128, device=mat.device)
+    ref = t.empty((L,), dtype=t.int32, device=mat.device)
+    ok = t.empty((L,), dtype=t.int32, device=mat.device)
+    rc = _lib.load().pbbss_select_reference_channel(
+        _lib.handle(mat.device.index), _lib.ptr(mat), _lib.ptr(num), _lib.ptr(den), int(L), int(F),
+        int(D), int(F if lead_stride is None else lead_stride), int(bin_stride), float(eps),
+        _lib.ptr(w), _lib.ptr(ref), _lib.ptr(ok), _lib.stream_ptr(mat.device.index))
+    _lib.check(rc, f'select_reference_channel(L={L},F={F},D={D})')
+    return w, ref, ok
 
 
 def mvdr(atf, noise):
@@ -406,15 +426,24 @@ def ban(w, noise):
 
 
 def apply_bf(w, x):
-    """pbbss_apply_beamforming_vector: w (B,D) c128, x (B,D,T) -> (B,T) c128."""
+    """pbbss_apply_beamforming_vector: w (B,D) c128, x (B,D,T) -> (B,T) c128.  With fewer
+    observations than vectors (x (Bx,D,T), B a multiple of Bx) problem b reads x[b % Bx] --
+    pbbss_apply_beamforming_vector_shared, no copies of x."""
     t = _t()
-    B, D, T = x.shape
+    Bx, D, T = x.shape
+    B = w.shape[0]
     out = t.empty((B, T), dtype=t.complex128, device=x.device)
-    rc = _lib.load().pbbss_apply_beamforming_vector(
-        _lib.handle(x.device.index), _lib.ptr(w), _lib.ptr(x),
-        int(x.dtype == t.complex128), B, T, D, _lib.ptr(out),
-        _lib.stream_ptr(x.device.index))
-    _lib.check(rc, f'apply_beamforming_vector(B={B},T={T},D={D})')
+    if B == Bx:
+        rc = _lib.load().pbbss_apply_beamforming_vector(
+            _lib.handle(x.device.index), _lib.ptr(w), _lib.ptr(x),
+            int(x.dtype == t.complex128), B, T, D, _lib.ptr(out),
+            _lib.stream_ptr(x.device.index))
+    else:
+        rc = _lib.load().pbbss_apply_beamforming_vector_shared(
+            _lib.handle(x.device.index), _lib.ptr(w), _lib.ptr(x),
+            int(x.dtype == t.complex128), B, Bx, T, D, _lib.ptr(out),
+            _lib.stream_ptr(x.device.index))
+    _lib.check(rc, f'apply_beamforming_vector(B={B},Bx={Bx},T={T},D={D})')
     return out
 
 

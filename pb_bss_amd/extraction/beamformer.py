@@ -208,7 +208,13 @@ def apply_beamforming_vector(vector, mix):
     D, T = x.shape[-2:]
     lead = np.broadcast_shapes(tuple(w.shape[:-1]), tuple(x.shape[:-2]))
     wb = w.expand(*lead, D).reshape(-1, D).contiguous()
-    xb = x.expand(*lead, D, T).reshape(-1, D, T).contiguous()
+    xl = tuple(x.shape[:-2])
+    if len(xl) < len(lead) and lead[len(lead) - len(xl):] == xl:
+        # the observation is shared along leading axes of `vector` (K beamformers per bin on one
+        # STFT): the kernel reads x[b % Bx] instead of K expanded copies
+        xb = x.reshape(-1, D, T).contiguous()
+    else:
+        xb = x.expand(*lead, D, T).reshape(-1, D, T).contiguous()
     out = engine.apply_bf(wb, xb)
     return _res(out.reshape(*lead, T), like_torch)
 

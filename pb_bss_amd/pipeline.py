@@ -74,23 +74,25 @@ class device_ops:
         sharding nothing leaves the device: arg-max and column gather are device ops, the
         finiteness check is deferred to `assert_finite`."""
         from . import _lib, engine
-        from .extraction.beamformer import (_select_reference_channel_device,
-                                            _select_reference_channel_sharded)
+        from .extraction.beamformer import _select_reference_channel_sharded
         t = _lib.torch()
         *lead, Fl, D, _ = target.shape
         eps = np.finfo(np.float64).tiny
         mat, num, den, _ = engine.mvdr_souden(
             target.to(t.complex128).reshape(-1, D, D).contiguous(),
             noise.to(t.complex128).expand(target.shape).reshape(-1, D, D).contiguous(), eps)
-        num, den = num.reshape(*lead, Fl, D), den.reshape(*lead, Fl, D)
         if shard_group is not None:
+            num, den = num.reshape(*lead, Fl, D), den.reshape(*lead, Fl, D)
             ref = _select_reference_channel_sharded(num, den, eps, shard_group)
-        else:
-            ref, ok = _select_reference_channel_device(num, den, eps)
-            device_ops._pending_finite.append(ok)
-            if len(device_ops._pending_finite) > 4096:  # a caller that never asks: keep it bounded
-                device_ops.assert_finite()
-        return select_column(mat.reshape(*lead, Fl, D, D), ref)
+            return select_column(mat.reshape(*lead, Fl, D, D), ref)
+        # one launch: sums over the bins, arg-max, column gather (pbbss_select_reference_channel;
+        # it replaced ~25 elementwise launches of the framework per call)
+        L = int(np.prod(lead)) if lead else 1
+        w, _, ok = engine.select_reference_channel(mat, num, den, L, Fl, eps)
+        device_ops._pending_finite.append(ok)
+        if len(device_ops._pending_finite) > 4096:  # a caller that never asks: keep it bounded
+            device_ops.assert_finite()
+        return w.reshape(*lead, Fl, D)
 
     @staticmethod
     def assert_finite():
@@ -99,7 +101,7 @@ class device_ops:
         pend, device_ops._pending_finite = device_ops._pending_finite, []
         if pend:
             import torch
-            ok = bool(torch.stack([p.reshape(()) for p in pend]).all().item())
+            ok = bool(torch.cat([p.reshape(-1).to(torch.bool) for p in pend]).all().item())
             assert ok, 'non-finite SNR in the automatic reference-channel selection'
 
     @staticmethod
@@ -130,7 +132,6 @@ def _chain_after_masks(Y, masks_fkt, mapping, ops, beamformer='gev+ban', shard_g
     aligned = ops.apply_mapping(kft, mapping)                         # (U, K, F, T)
     X = Y.transpose(-2, -1).contiguous()                              # (U, F, D, T)
     psd = ops.psd(X, aligned.transpose(-3, -2).contiguous())          # (U, F, K, D, D)
-    K = psd.shape[-3]
     total = psd.sum(dim=-3)
     target = psd.movedim(-3, 0).contiguous()                          # (K, U, F, D, D)
     noise = (total.unsqueeze(0) - target).contiguous()
@@ -140,7 +141,9 @@ def _chain_after_masks(Y, masks_fkt, mapping, ops, beamformer='gev+ban', shard_g
         w = ops.mvdr_souden(target, noise, shard_group)
     else:
         raise ValueError(f'beamformer={beamformer!r}: one of {BEAMFORMERS}')
-    enhanced = torch.stack([ops.apply_bf(w[k], X) for k in range(K)], dim=1)  # (U, K, F, T)
+    # one launch for all classes: the observation is shared along the class axis of `w`
+    # (pbbss_apply_beamforming_vector_shared); (K, U, F, T) -> a (U, K, F, T) view, no stack copy
+    enhanced = ops.apply_bf(w, X).movedim(0, 1)
     return aligned, w.movedim(0, 1).contiguous(), enhanced
 
 

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     assert sorted(_lib.EXPORTS) == names
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.pbbss_version() == 600
+    assert lib.pbbss_version() == 610
     assert lib.pbbss_error_string(0) == b'ok'
     assert b'shape' in lib.pbbss_error_string(-2)
 

@@ -174,3 +174,74 @@ def test_reference_channel_selection_stays_on_the_device_and_defers_its_assert()
         ops.assert_finite()
     ops.assert_finite()                                   # the queue is empty again
 
+
+
+@pytest.mark.gpu
+def test_select_reference_channel_kernel_against_the_host_selection():
+    """pbbss_select_reference_channel (round 6): sums over the bins, NumPy's complex maximum with
+    eps, first arg-max of the real part, column gather and the finiteness flag in one launch --
+    against `_select_reference_channel` (the host statement of beamformer.py:616-624) on both
+    problem layouts ((L, F) and (F, L) order of the matrices), with ties, denominators below eps,
+    a complex denominator whose real part equals eps, D up to 32 and a NaN."""
+    import torch
+    from pb_bss_amd import _lib, engine
+    from pb_bss_amd.extraction.beamformer import _select_reference_channel
+    rng = np.random.default_rng(11)
+    for L, F, D in ((3, 257, 6), (1, 5, 2), (4, 70, 32), (2, 1, 8)):
+        mat = rng.standard_normal((L, F, D, D)) + 1j * rng.standard_normal((L, F, D, D))
+        num = rng.uniform(0.5, 2.0, (L, F, D)) + 1e-3j * rng.standard_normal((L, F, D))
+        den = rng.uniform(0.5, 2.0, (L, F, D)) + 1e-3j * rng.standard_normal((L, F, D))
+        eps = 1e-300
+        if L > 1:
+            den[1, :, 0] = 0.0                       # below eps: the floor wins
+            eps = 1e-3
+            num[L - 1, :, D - 1] = num[L - 1, :, D - 2]   # a tie: the first maximum
+            den[L - 1, :, D - 1] = den[L - 1, :, D - 2]
+        for order in ('lf', 'fl'):
+            if order == 'lf':
+                m, n, d = (_lib.to_device(a.reshape(L * F, *a.shape[2:])) for a in (mat, num, den))
+                w, ref, ok = engine.select_reference_channel(m, n, d, L, F, eps)
+            else:
+                m, n, d = (_lib.to_device(np.ascontiguousarray(a.swapaxes(0, 1)).reshape(
+                    L * F, *a.shape[2:])) for a in (mat, num, den))
+                w, ref, ok = engine.select_reference_channel(m, n, d, L, F, eps, lead_stride=1,
+                                                             bin_stride=L)
+            want = [_select_reference_channel(num[i], den[i], eps) for i in range(L)]
+            assert ref.tolist() == want, (L, F, D, order)
+            assert ok.tolist() == [1] * L
+            got = _lib.to_host(w)
+            for i in range(L):
+                np.testing.assert_array_equal(got[i], mat[i, :, :, want[i]])
+    # the complex maximum keeps a denominator whose real part EQUALS eps and whose imaginary part
+    # is non-negative (np.maximum orders complex numbers by real part, then imaginary part)
+    num = torch.ones((1, 1, 2), dtype=torch.complex128, device='cuda')
+    den = torch.tensor([[[0.5 + 0.5j, 0.5 - 0.5j]]], dtype=torch.complex128, device='cuda')
+    mat = torch.zeros((1, 2, 2), dtype=torch.complex128, device='cuda')
+    _, ref, ok = engine.select_reference_channel(mat, num.reshape(1, 2), den.reshape(1, 2), 1, 1, 0.5)
+    hn, hd = _lib.to_host(num[0]), _lib.to_host(den[0])
+    assert ref.tolist() == [int(np.argmax((hn.sum(0) / np.maximum(hd.sum(0), 0.5)).real))]
+    # a NaN: reported, and it is the arg-max (np.argmax returns the first NaN)
+    bad = torch.ones((1, 3, 4), dtype=torch.complex128, device='cuda')
+    bad[0, 1, 2] = float('nan')
+    _, ref, ok = engine.select_reference_channel(
+        torch.zeros((3, 4, 4), dtype=torch.complex128, device='cuda'), bad.reshape(3, 4),
+        torch.ones((3, 4), dtype=torch.complex128, device='cuda'), 1, 3, 1e-300)
+    assert ok.tolist() == [0] and ref.tolist() == [2]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [np.complex64, np.complex128])
+def test_apply_beamforming_vector_shares_the_observation_over_leading_axes(dtype):
+    """apply_beamforming_vector(vector (K, F, D), mix (F, D, T)) -- the broadcast of the reference's
+    einsum '...a,...at->...t' (beamformer.py:572-583) -- reads the one observation K times
+    (pbbss_apply_beamforming_vector_shared) instead of expanding it; also (2, K, F, D) on (F, D, T)
+    and the plain same-shape call."""
+    from pb_bss_amd import extraction as ex
+    rng = np.random.default_rng(3)
+    K, F, D, T = 3, 17, 5, 130
+    x = (rng.standard_normal((F, D, T)) + 1j * rng.standard_normal((F, D, T))).astype(dtype)
+    for lead in ((K,), (2, K), ()):
+        w = rng.standard_normal((*lead, F, D)) + 1j * rng.standard_normal((*lead, F, D))
+        got = ex.apply_beamforming_vector(w, x)
+        want = np.einsum('...a,...at->...t', w.conj(), x.astype(np.complex128))
+        np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-12)

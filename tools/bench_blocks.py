@@ -792,7 +792,7 @@ def run_config4(args, local_rank, dev, leg='watson', steps=None, warmup=None, wi
         target = psd.movedim(-3, 0).contiguous()                  # (K, F, D, D)
         noise = (psd.sum(dim=-3).unsqueeze(0) - target).contiguous()
         w = ops.mvdr_souden(target, noise)                        # (K, F, D)
-        return w, torch.stack([ops.apply_bf(w[k], X) for k in range(K_)])
+        return w, ops.apply_bf(w, X)                              # (K, F, T): X shared by the classes
 
     def step():
         masks = fit()

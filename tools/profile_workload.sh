@@ -29,7 +29,7 @@ $CMD > "$D/unprofiled.json" 2> "$D/unprofiled.err"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$D/trace" -o p -- $CMD > "$D.log" 2>&1
 # PBBSS_PMC_GROUPS="A B;C D": other counter groups (one pass each) instead of the traffic set, e.g. the
 # instruction mix  PBBSS_PMC_GROUPS="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM;SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS"
-if [ -n "$PBBSS_PMC_GROUPS" ]; then IFS=';' read -ra GROUPS_ <<< "$PBBSS_PMC_GROUPS"; else
+if [ -n "${PBBSS_PMC_GROUPS:-}" ]; then IFS=';' read -ra GROUPS_ <<< "$PBBSS_PMC_GROUPS"; else
 GROUPS_=("FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU" "TCC_HIT_sum TCC_MISS_sum"); fi
 for grp in "${GROUPS_[@]}"; do
   name=$(echo "$grp" | tr ' ' '_' | cut -c1-40)
