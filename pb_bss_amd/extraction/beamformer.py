@@ -154,8 +154,10 @@ def get_gev_vector(target_psd_matrix, noise_psd_matrix, force_cython=False,
     if use_eig:
         w, _, st = engine.gev_general(a.reshape(-1, D, D).contiguous(),
                                       b.reshape(-1, D, D).contiguous())
-        bad = (st != 0).nonzero()
-        if bad.numel():
+        # one reduce + one read-back in the common case; the index search only on a failure
+        # (`nonzero` is five launches and a second synchronisation of its own)
+        if bool(st.any()):
+            bad = (st != 0).nonzero()
             f = int(bad[0].item())
             code = int(st[f].item())
             if code & _lib.ST_EIG_NOCONV:
@@ -170,8 +172,8 @@ def get_gev_vector(target_psd_matrix, noise_psd_matrix, force_cython=False,
             raise np.linalg.LinAlgError(f'Error for frequency {f}\n{msg}')  # :403-407
         return _res(w.reshape(a.shape[:-1]), like_torch)
     w, st = engine.gev(a.reshape(-1, D, D).contiguous(), b.reshape(-1, D, D).contiguous())
-    bad = (st != 0).nonzero()
-    if bad.numel():
+    if bool(st.any()):
+        bad = (st != 0).nonzero()
         f = int(bad[0].item())
         code = int(st[f].item())
         if code & _lib.ST_NOT_POSDEF:
