@@ -626,9 +626,17 @@ __global__ void __launch_bounds__(kRefThreads)
       dr = eps;
       di = 0.0;
     }
-    const double m = dr * dr + di * di;
-    snr_re[tid] = (t[0] * dr + t[1] * di) / m;
-    snr_im[tid] = (t[1] * dr - t[0] * di) / m;
+    // complex quotient by Smith's method (what NumPy's division does): no dr^2 + di^2, which
+    // underflows to 0 for the floor eps = tiny and would turn 0 / tiny into NaN
+    if (fabs(dr) >= fabs(di)) {
+      const double rat = di / dr, dd = dr + di * rat;
+      snr_re[tid] = (t[0] + t[1] * rat) / dd;
+      snr_im[tid] = (t[1] - t[0] * rat) / dd;
+    } else {
+      const double rat = dr / di, dd = dr * rat + di;
+      snr_re[tid] = (t[0] * rat + t[1]) / dd;
+      snr_im[tid] = (t[1] * rat - t[0]) / dd;
+    }
   }
   __syncthreads();
   if (tid == 0) {

@@ -220,6 +220,16 @@ def test_select_reference_channel_kernel_against_the_host_selection():
     _, ref, ok = engine.select_reference_channel(mat, num.reshape(1, 2), den.reshape(1, 2), 1, 1, 0.5)
     hn, hd = _lib.to_host(num[0]), _lib.to_host(den[0])
     assert ref.tolist() == [int(np.argmax((hn.sum(0) / np.maximum(hd.sum(0), 0.5)).real))]
+    # an all-zero class (silent source) with the floor eps = tiny: 0 / tiny = 0, finite -- the
+    # quotient must not go through |den|^2 (tiny^2 underflows to 0)
+    tiny = float(np.finfo(np.float64).tiny)
+    zn = torch.zeros((2, 3), dtype=torch.complex128, device='cuda')
+    zn[:, 1] = 1.0
+    zd = torch.zeros((2, 3), dtype=torch.complex128, device='cuda')
+    _, ref, ok = engine.select_reference_channel(
+        torch.zeros((2, 3, 3), dtype=torch.complex128, device='cuda'), zn, zd, 1, 2, tiny)
+    hs = _lib.to_host(zn).sum(0) / np.maximum(_lib.to_host(zd).sum(0), tiny)
+    assert ok.tolist() == [int(np.all(np.isfinite(hs)))] and ref.tolist() == [int(np.argmax(hs.real))]
     # a NaN: reported, and it is the arg-max (np.argmax returns the first NaN)
     bad = torch.ones((1, 3, 4), dtype=torch.complex128, device='cuda')
     bad[0, 1, 2] = float('nan')
