@@ -131,3 +131,52 @@ def test_handles_create_destroy_and_threads():
     assert not errs, errs
     for i in range(4):
         assert np.array_equal(got[i], want)
+
+
+def test_souden_binding_of_integration_section_j_through_the_raw_abi():
+    """The reference-side binding INTEGRATION.md section J shows for pbbss_mvdr_souden ->
+    pbbss_select_reference_channel -> pbbss_apply_beamforming_vector_shared, written out with
+    plain ctypes on device pointers: same beam-forming vectors and outputs as the oracle's
+    get_mvdr_vector_souden (automatic reference channel) + apply per class; bad arguments of the
+    two round-6 exports come back as codes."""
+    torch, _lib, lib, h, stream = _env()
+    from oracle import beamformer as ob
+    rng = np.random.default_rng(21)
+    K, F, D, T = 3, 33, 5, 70
+
+    def psd():
+        a = rng.standard_normal((K, F, D, 2 * D)) + 1j * rng.standard_normal((K, F, D, 2 * D))
+        return a @ a.conj().swapaxes(-1, -2) / (2 * D)
+    target, noise = psd(), psd() + 0.1 * np.eye(D)
+    X = (rng.standard_normal((F, D, T)) + 1j * rng.standard_normal((F, D, T))).astype(np.complex64)
+    eps = float(np.finfo(np.float64).tiny)
+    td, nd, xd = (_lib.to_device(a) for a in (target, noise, X))
+    c128 = dict(dtype=torch.complex128, device='cuda')
+    mat, num, den = (torch.empty(s, **c128) for s in ((K * F, D, D), (K * F, D), (K * F, D)))
+    st = torch.empty(K * F, dtype=torch.int32, device='cuda')
+    p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+    assert lib.pbbss_mvdr_souden(h, p(td), p(nd), K * F, D, ctypes.c_double(eps), p(mat), p(num),
+                                 p(den), p(st), stream) == 0
+    w = torch.empty((K, F, D), **c128)
+    ref, ok = (torch.empty(K, dtype=torch.int32, device='cuda') for _ in range(2))
+    sel = lambda **kw: lib.pbbss_select_reference_channel(  # noqa: E731
+        kw.get('h', h), kw.get('mat', p(mat)), p(num), p(den), kw.get('L', K), F, kw.get('D', D), F, 1,
+        ctypes.c_double(eps), kw.get('w', p(w)), p(ref), p(ok), stream)
+    assert sel() == 0
+    s = torch.empty((K, F, T), **c128)
+    app = lambda B=K * F, xb=F: lib.pbbss_apply_beamforming_vector_shared(  # noqa: E731
+        h, p(w), p(xd), 0, B, xb, T, D, p(s), stream)
+    assert app() == 0
+    assert bool(ok.all())
+    got_w, got_s = _lib.to_host(w), _lib.to_host(s)
+    for k in range(K):
+        want = ob.mvdr_souden(target[k], noise[k])
+        np.testing.assert_allclose(got_w[k], want, rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(got_s[k], ob.apply_bf(want, X.astype(np.complex128)),
+                                   rtol=1e-9, atol=1e-10)
+    assert sel(h=None) == _lib.ERR_INVALID_ARG
+    assert sel(L=0) == _lib.ERR_INVALID_ARG
+    assert sel(w=p(mat)) == _lib.ERR_INVALID_ARG            # out_w must not alias the matrices
+    assert sel(D=33) == _lib.ERR_UNSUPPORTED
+    assert app(B=K * F + 1) == _lib.ERR_INVALID_ARG         # B is not a multiple of x_batch
+    assert app(xb=0) == _lib.ERR_INVALID_ARG
