@@ -255,3 +255,54 @@ def test_apply_beamforming_vector_shares_the_observation_over_leading_axes(dtype
         got = ex.apply_beamforming_vector(w, x)
         want = np.einsum('...a,...at->...t', w.conj(), x.astype(np.complex128))
         np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-12)
+
+
+def test_graphed_extraction_stage_replays_bit_identically():
+    """pipeline.graphed: PSD -> MVDR-Souden (device-side reference channel) -> apply captured once
+    into a HIP graph; replays on NEW masks give exactly what the eager stage gives on them, the
+    deferred finiteness check still fires for a replay with a NaN, and a stage that synchronises
+    with the host (gev: status read-back) falls back to eager calls with a RuntimeWarning."""
+    import torch
+    from pb_bss_amd import _lib
+    from pb_bss_amd.pipeline import device_ops as ops, graphed
+    rng = np.random.default_rng(8)
+    F, T, D, K = 33, 120, 4, 3
+    X = _lib.to_device((rng.standard_normal((F, D, T)) + 1j * rng.standard_normal((F, D, T)))
+                       .astype(np.complex64))
+
+    def masks():
+        m = rng.uniform(0.05, 1.0, size=(F, K, T))
+        return _lib.to_device(m / m.sum(1, keepdims=True))
+
+    def extract(mk):
+        psd = ops.psd(X, mk)
+        target = psd.movedim(-3, 0).contiguous()
+        noise = (psd.sum(dim=-3).unsqueeze(0) - target).contiguous()
+        w = ops.mvdr_souden(target, noise)
+        return w, ops.apply_bf(w, X)
+
+    ops.assert_finite()
+    g = graphed(extract, masks())
+    assert g.captured
+    for _ in range(3):
+        mk = masks()
+        w, s = g(mk)
+        w, s = w.clone(), s.clone()                    # the results are the graph's own buffers
+        we, se = extract(mk)
+        assert torch.equal(w, we) and torch.equal(s, se)
+    ops.assert_finite()
+    bad = masks()
+    bad[3, 1, :] = float('nan')
+    g(bad)
+    with pytest.raises(AssertionError):
+        ops.assert_finite()
+    ops.assert_finite()
+
+    def with_host_sync(mk):
+        psd = ops.psd(X, mk)
+        return ops.gev_ban(psd[:, 0].contiguous(), (psd.sum(1) - psd[:, 0]).contiguous())
+    with pytest.warns(RuntimeWarning, match='capture failed'):
+        h = graphed(with_host_sync, masks())
+    assert not h.captured
+    mk = masks()
+    assert torch.equal(h(mk), with_host_sync(mk))
